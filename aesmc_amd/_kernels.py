@@ -1,0 +1,235 @@
+"""Host-side launcher for the HIP kernels: validates operands, allocates outputs, enqueues on the
+caller's current HIP stream through the C ABI (include/aesmc_hip.h).
+
+Every operand is checked here against what the kernel and its grid assume (device, dtype, shape,
+density, alignment) before anything is launched.  Kernels report data-dependent conditions (NaN
+log-weights, degenerate rows, out-of-range indices) by OR-ing bits into a per-device int32 word
+that the host reads once per ELBO evaluation (`read_flags`) instead of synchronising per timestep.
+"""
+import threading
+
+import torch
+
+from . import _lib
+
+_DTYPE_TAG = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _require_hip(t, what):
+    if not isinstance(t, torch.Tensor):
+        raise AttributeError("{} must be a torch.Tensor. Got: {}".format(what, type(t)))
+    if not t.is_cuda:
+        raise RuntimeError(
+            "aesmc_amd: {} lives on '{}'; this package computes only on a HIP device (MI355X) "
+            "and has no CPU fallback.".format(what, t.device))
+
+
+def _tag(t, what):
+    try:
+        return _DTYPE_TAG[t.dtype]
+    except KeyError:
+        raise TypeError("aesmc_amd: {} must be float32 or float64, got {}".format(what, t.dtype))
+
+
+def _inner_dense(t):
+    """True when dims 2.. of `t` are laid out densely (row payload is one contiguous run)."""
+    expect = 1
+    for size, stride in zip(reversed(t.shape[2:]), reversed(t.stride()[2:])):
+        if size != 1 and stride != expect:
+            return False
+        expect *= size
+    return True
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class HipKernels:
+    """The product backend.  One instance per process; per-device state is created lazily."""
+
+    name = "hip"
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self._flags = {}
+        self._lock = threading.Lock()
+
+    # ---- deferred status word ---------------------------------------------------------------
+    def flags(self, device):
+        key = torch.device(device).index
+        if key is None:
+            key = torch.cuda.current_device()
+        word = self._flags.get(key)
+        if word is None:
+            with self._lock:
+                word = self._flags.get(key)
+                if word is None:
+                    word = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
+                    self._flags[key] = word
+        return word
+
+    def read_flags(self, device):
+        """Synchronising read-and-clear of the device status word."""
+        word = self.flags(device)
+        value = int(word.item())
+        if value:
+            word.zero_()
+        return value
+
+    @staticmethod
+    def _stream(t):
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    # ---- K1 ------------------------------------------------------------------------------------
+    def logweight_lse(self, a, b=None, c=None, want_lw=True, want_lse=True):
+        """lw = a + b - c over [B,K]; lse[b] = logsumexp_k lw.  Returns (lw or None, lse or None)."""
+        _require_hip(a, "log-prob term")
+        tag = _tag(a, "log-prob term")
+        if a.dim() != 2:
+            raise ValueError("aesmc_amd: log-prob terms must be [batch_size, num_particles], got {}"
+                             .format(tuple(a.shape)))
+        terms = [a]
+        for t in (b, c):
+            if t is not None:
+                _require_hip(t, "log-prob term")
+                if t.shape != a.shape or t.dtype != a.dtype or t.device != a.device:
+                    raise ValueError("aesmc_amd: log-prob terms disagree: {} {} {} vs {} {} {}".format(
+                        tuple(t.shape), t.dtype, t.device, tuple(a.shape), a.dtype, a.device))
+            terms.append(t)
+        a, b, c = [None if t is None else t.contiguous() for t in terms]
+        B, K = a.shape
+        if b is None and c is None and not want_lse:
+            return (a if want_lw else None), None
+        need_lw = want_lw and not (b is None and c is None)
+        lw = torch.empty_like(a) if need_lw else None
+        lse = torch.empty(B, dtype=a.dtype, device=a.device) if want_lse else None
+        with torch.cuda.device(a.device):
+            _lib.check(self._lib.aesmc_logweight_lse(tag, _ptr(a), _ptr(b), _ptr(c), _ptr(lw),
+                                                     _ptr(lse), B, K, self._stream(a)),
+                       "aesmc_logweight_lse")
+        if want_lw and not need_lw:
+            lw = a
+        return lw, lse
+
+    def logweight_lse_backward(self, lw, lse, grad_lw, grad_lse, want_neg=True):
+        _require_hip(lw, "lw")
+        tag = _tag(lw, "lw")
+        B, K = lw.shape
+        lw = lw.contiguous()
+        lse = lse.contiguous()
+        if lse.shape != (B,) or lse.dtype != lw.dtype or lse.device != lw.device:
+            raise ValueError("aesmc_amd: lse must be [{}] {} on {}".format(B, lw.dtype, lw.device))
+        if grad_lw is not None:
+            if grad_lw.shape != lw.shape or grad_lw.dtype != lw.dtype or grad_lw.device != lw.device:
+                raise ValueError("aesmc_amd: grad_lw does not match lw")
+            grad_lw = grad_lw.contiguous()
+        if grad_lse is not None:
+            if grad_lse.shape != (B,) or grad_lse.dtype != lw.dtype or grad_lse.device != lw.device:
+                raise ValueError("aesmc_amd: grad_lse does not match lse")
+            grad_lse = grad_lse.contiguous()
+        g = torch.empty_like(lw)
+        ng = torch.empty_like(lw) if want_neg else None
+        with torch.cuda.device(lw.device):
+            _lib.check(self._lib.aesmc_logweight_lse_backward(
+                tag, _ptr(lw), _ptr(lse), _ptr(grad_lw), _ptr(grad_lse), _ptr(g), _ptr(ng), B, K,
+                self._stream(lw)), "aesmc_logweight_lse_backward")
+        return g, ng
+
+    # ---- K2 ------------------------------------------------------------------------------------
+    def ancestor_index(self, log_w, u):
+        """log_w [B,K] float32/64, u [B] float64 (both on the HIP device) -> int64 [B,K]."""
+        _require_hip(log_w, "log_weight")
+        _require_hip(u, "uniforms")
+        tag = _tag(log_w, "log_weight")
+        if log_w.dim() != 2:
+            raise ValueError("aesmc_amd: log_weight must be [batch_size, num_particles], got {}"
+                             .format(tuple(log_w.shape)))
+        B, K = log_w.shape
+        if u.dtype != torch.float64 or u.numel() != B or u.device != log_w.device:
+            raise ValueError("aesmc_amd: uniforms must be {} float64 values on {}".format(B, log_w.device))
+        log_w = log_w.contiguous()
+        u = u.contiguous()
+        idx = torch.empty((B, K), dtype=torch.int64, device=log_w.device)
+        ws_bytes = int(self._lib.aesmc_workspace_bytes(B, K))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=log_w.device) if ws_bytes else None
+        with torch.cuda.device(log_w.device):
+            _lib.check(self._lib.aesmc_ancestor_index(
+                tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(self.flags(log_w.device)), B, K, _ptr(ws),
+                ws_bytes, self._stream(log_w)), "aesmc_ancestor_index")
+        return idx
+
+    # ---- K3 ------------------------------------------------------------------------------------
+    @staticmethod
+    def _check_index(value, idx):
+        _require_hip(idx, "ancestral_index")
+        if idx.dtype != torch.int64:
+            raise TypeError("aesmc_amd: ancestral_index must be int64 (torch.LongTensor), got {}"
+                            .format(idx.dtype))
+        if idx.device != value.device:
+            raise RuntimeError("aesmc_amd: ancestral_index on {} but value on {}".format(
+                idx.device, value.device))
+
+    def gather(self, src, idx):
+        """dst[b,k,...] = src[b, idx[b,k], ...]; src [B,K,...] any dtype, idx int64 [B,K]."""
+        _require_hip(src, "value")
+        self._check_index(src, idx)
+        assert idx.size() == src.size()[:2]
+        B, K = idx.shape
+        if not _inner_dense(src):
+            src = src.contiguous()  # trailing dims must be dense; the leading two may be strided
+        row_elems = 1
+        for s in src.shape[2:]:
+            row_elems *= s
+        esz = src.element_size()
+        dst = torch.empty(src.shape, dtype=src.dtype, device=src.device)
+        if dst.numel() == 0:
+            return dst
+        idx = idx.contiguous()
+        with torch.cuda.device(src.device):
+            _lib.check(self._lib.aesmc_resample_gather(
+                _ptr(src), _ptr(idx), _ptr(dst), _ptr(self.flags(src.device)), B, K, row_elems * esz,
+                src.stride(0) * esz, src.stride(1) * esz, self._stream(src)), "aesmc_resample_gather")
+        return dst
+
+    def gather_backward(self, grad_out, idx):
+        """grad_src[b,j,...] = sum over {k: idx[b,k]==j} of grad_out[b,k,...]."""
+        _require_hip(grad_out, "grad")
+        self._check_index(grad_out, idx)
+        tag = _tag(grad_out, "gradient of a resampled value")
+        B, K = idx.shape
+        grad_out = grad_out.contiguous()
+        idx = idx.contiguous()
+        row_elems = 1
+        for s in grad_out.shape[2:]:
+            row_elems *= s
+        grad_src = torch.empty_like(grad_out)
+        if grad_src.numel() == 0:
+            return grad_src
+        with torch.cuda.device(grad_out.device):
+            _lib.check(self._lib.aesmc_resample_gather_backward(
+                tag, _ptr(grad_out), _ptr(idx), _ptr(grad_src), _ptr(self.flags(grad_out.device)), B,
+                K, row_elems, self._stream(grad_out)), "aesmc_resample_gather_backward")
+        return grad_src
+
+
+_provider = None
+_provider_lock = threading.Lock()
+
+
+def get():
+    """The active kernel provider (created on first use; raises if the library is missing)."""
+    global _provider
+    if _provider is None:
+        with _provider_lock:
+            if _provider is None:
+                _provider = HipKernels()
+    return _provider
+
+
+def _swap_provider_for_tests(provider):
+    """Test hook (used by tests/conftest.py only): substitute the kernel provider so the host
+    logic can be exercised on CPU tensors against the oracle.  Returns the previous provider."""
+    global _provider
+    previous, _provider = _provider, provider
+    return previous

@@ -1,0 +1,65 @@
+"""ctypes binding of libaesmc_hip.so (C ABI declared in include/aesmc_hip.h).
+
+The library is the only compute backend of this package: if it is missing or a tensor is not on
+a HIP device the callers raise — there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime that the library's DT_NEEDED resolves against)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaesmc_hip.so")
+
+OK = 0
+ERR_NAMES = {1: "invalid argument", 2: "unsupported shape", 3: "kernel launch failed",
+             4: "workspace missing or too small"}
+FLAG_NAN_LOG_WEIGHT = 1
+FLAG_DEGENERATE_ROW = 2
+FLAG_INDEX_OUT_OF_RANGE = 4
+F32, F64 = 0, 1
+
+_vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/aesmc_hip.h one to one.
+SIGNATURES = {
+    "aesmc_version": (_i32, []),
+    "aesmc_target_arch": (ctypes.c_char_p, []),
+    "aesmc_logweight_lse": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "aesmc_logweight_lse_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "aesmc_ancestor_index": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
+    "aesmc_ancestor_index_lds_max_particles": (_i64, []),
+    "aesmc_workspace_bytes": (_sz, [_i64, _i64]),
+    "aesmc_resample_gather": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "aesmc_resample_gather_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+}
+
+_lib = None
+
+
+class AesmcLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library once and declares every entry point's signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AesmcLibraryError(
+            "aesmc_amd: HIP library not built ({} missing). Run `python -m aesmc_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == the library does not export the symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != OK:
+        raise AesmcLibraryError("aesmc_amd: {} failed: {} (status {})".format(
+            what, ERR_NAMES.get(status, "unknown error"), status))

@@ -1,0 +1,241 @@
+"""Importance sampling / sequential Monte Carlo over a state-space model given by four callables,
+with the interface of the reference's aesmc/inference.py and the per-timestep work on MI355X:
+
+    propagate (user callables, PyTorch)  ->  K1 fused log-weight + log-sum-exp
+        ->  K2 systematic ancestor indices (CDF prefix scan)  ->  K3 resample row gather
+
+Differences from the reference that a caller can observe (all documented in DESIGN.md):
+  * `previous_latents` handed to proposal / transition is a lazy read-only sequence that gathers
+    an entry on first access (the reference re-gathers the whole history every step, O(T^2));
+    `set_history_mode("eager")` restores plain lists;
+  * data-dependent failures (NaN log-weights, an all -inf row) are detected on the device and
+    raised once at the end of `infer` instead of synchronising the device every timestep.
+"""
+import collections.abc
+
+import numpy as np
+import torch
+
+from . import _kernels
+from . import _ops
+from . import state
+
+_HISTORY_MODE = "lazy"
+
+
+def set_history_mode(mode):
+    """'lazy' (default): resample history entries on access; 'eager': build the full list of
+    re-indexed latents every step exactly as aesmc/inference.py:102-104 does."""
+    global _HISTORY_MODE
+    if mode not in ("lazy", "eager"):
+        raise ValueError("history mode must be 'lazy' or 'eager', got {}".format(mode))
+    _HISTORY_MODE = mode
+
+
+class ResampledHistory(collections.abc.Sequence):
+    """Read-only view of [resample(x, index) for x in latents] whose entries are gathered (K3)
+    when first read.  Markov models read only [-1], so a step costs one gather, not `time`."""
+
+    def __init__(self, latents, index):
+        self._latents = list(latents)
+        self._index = index
+        self._cache = {}
+
+    def __len__(self):
+        return len(self._latents)
+
+    def __getitem__(self, item):
+        if isinstance(item, slice):
+            return [self[i] for i in range(*item.indices(len(self._latents)))]
+        position = item + len(self._latents) if item < 0 else item
+        if not 0 <= position < len(self._latents):
+            raise IndexError("list index out of range")
+        if position not in self._cache:
+            self._cache[position] = state.resample(self._latents[position], self._index)
+        return self._cache[position]
+
+
+class _UniformFeed:
+    """Per-resample uniforms: drawn from numpy's global RandomState one [batch_size, 1] block per
+    timestep (the reference's RNG consumption, aesmc/inference.py:250) and shipped to the device
+    through a pinned ring so the copy never blocks the host."""
+
+    def __init__(self, batch_size, num_draws, device):
+        self.device = device
+        self.batch_size = batch_size
+        self.cursor = 0
+        if device.type == "cuda":
+            self.host = torch.empty((max(num_draws, 1), batch_size), dtype=torch.float64,
+                                    pin_memory=True)
+            self.dev = torch.empty((max(num_draws, 1), batch_size), dtype=torch.float64,
+                                   device=device)
+        else:
+            self.host = self.dev = None
+
+    def next(self):
+        draw = np.random.uniform(size=[self.batch_size, 1])
+        if self.host is None:
+            return torch.from_numpy(draw.reshape(-1))
+        slot = self.cursor % self.host.size(0)
+        self.cursor += 1
+        self.host[slot].copy_(torch.from_numpy(draw.reshape(-1)))
+        self.dev[slot].copy_(self.host[slot], non_blocking=True)
+        return self.dev[slot]
+
+
+def _raise_for_flags(flags):
+    from . import _lib
+    if flags & _lib.FLAG_NAN_LOG_WEIGHT:
+        raise FloatingPointError("log_weight contains nan element(s)")
+    if flags & (_lib.FLAG_DEGENERATE_ROW | _lib.FLAG_INDEX_OUT_OF_RANGE):
+        raise RuntimeError(
+            "ancestral index out of range: a row of log-weights had no finite maximum (all -inf, "
+            "or +inf present), or an index outside [0, num_particles) was passed to resample")
+
+
+def _first_tensor(value):
+    return next(iter(value.values())) if isinstance(value, dict) else value
+
+
+def sample_ancestral_index(log_weight):
+    """Systematic resampling (aesmc/inference.py:234-269): log_weight [batch_size, num_particles]
+    unnormalised -> zero-indexed ancestor LongTensor of the same shape on the same device.
+    Draws one np.random.uniform(size=[batch_size, 1]) block; raises FloatingPointError on NaN."""
+    batch_size = log_weight.size(0)
+    uniforms = torch.from_numpy(np.random.uniform(size=[batch_size, 1]).reshape(-1))
+    if log_weight.is_cuda:
+        uniforms = uniforms.to(log_weight.device)
+    index = _ops.ancestor_index(log_weight, uniforms)
+    from . import _lib
+    flags = _kernels.get().read_flags(log_weight.device)
+    if flags & _lib.FLAG_NAN_LOG_WEIGHT:
+        raise FloatingPointError("log_weight contains nan element(s)")
+    return index
+
+
+def get_resampled_latents(latents, ancestral_indices):
+    """Traces every final particle's genealogy back through `ancestral_indices` (length
+    len(latents) - 1, may be empty) and returns the latents re-indexed along it
+    (aesmc/inference.py:196-231)."""
+    assert len(ancestral_indices) == len(latents) - 1
+    probe = _first_tensor(latents[0])
+    batch_size, num_particles = probe.size()[:2]
+    lineage = torch.arange(num_particles, dtype=torch.int64, device=probe.device) \
+        .unsqueeze(0).expand(batch_size, num_particles)
+    resampled = [None] * len(latents)
+    for time in range(len(latents) - 1, -1, -1):
+        resampled[time] = state.resample(latents[time], lineage)
+        if time > 0:
+            lineage = _ops.resample_gather(ancestral_indices[time - 1], lineage)
+    return resampled
+
+
+def infer(inference_algorithm, observations, initial, transition, emission,
+          proposal, num_particles, return_log_marginal_likelihood=False,
+          return_latents=True, return_original_latents=False,
+          return_log_weight=True, return_log_weights=False,
+          return_ancestral_indices=False):
+    """Runs 'is' or 'smc' inference (aesmc/inference.py:8-193).
+
+    observations: length-T sequence of [batch_size, ...] tensors (or dicts of them).
+    initial():                                   -> Distribution (or dict of them)
+    transition(previous_latents, time, previous_observations) -> Distribution
+    emission(latents, time, previous_observations)            -> Distribution
+    proposal(previous_latents, time, observations)            -> Distribution with rsample
+    All four are called with keyword arguments; at time 0 the proposal gets no previous_latents
+    and the emission no previous_observations.
+
+    Returns a dict with keys log_marginal_likelihood [batch_size], latents, original_latents,
+    log_weight [batch_size, num_particles], log_weights, ancestral_indices (None unless requested
+    through the return_* flags) and last_latent (always).
+    """
+    if inference_algorithm not in ("is", "smc"):
+        raise ValueError("inference_algorithm must be either is or smc. currently = {}".format(
+            inference_algorithm))
+    use_smc = inference_algorithm == "smc"
+    num_timesteps = len(observations)
+    batch_size = _first_tensor(observations[0]).size(0)
+    keep_originals = return_original_latents or return_latents
+
+    history = []          # un-resampled draws x_0..x_t, what `emission(latents=...)` receives
+    originals = []
+    indices = []
+    log_weights = []
+    step_lse = []
+    feed = None
+    device = None
+
+    for time in range(num_timesteps):
+        if time == 0:
+            ancestors = None
+            proposal_dist = proposal(time=0, observations=observations)
+        else:
+            if use_smc:
+                previous = log_weights[-1]
+                if feed is None:
+                    feed = _UniformFeed(batch_size, num_timesteps - 1, previous.device)
+                index = _ops.ancestor_index(previous, feed.next())
+                indices.append(index)
+                if _HISTORY_MODE == "lazy":
+                    ancestors = ResampledHistory(history, index)
+                else:
+                    ancestors = [state.resample(x, index) for x in history]
+            else:
+                ancestors = history
+            proposal_dist = proposal(previous_latents=ancestors, time=time,
+                                     observations=observations)
+        latent = state.sample(proposal_dist, batch_size, num_particles)
+        history.append(latent)
+        log_q = state.log_prob(proposal_dist, latent)
+        if time == 0:
+            log_p = state.log_prob(initial(), latent)
+            emission_dist = emission(latents=history, time=0)
+        else:
+            log_p = state.log_prob(
+                transition(previous_latents=ancestors, time=time,
+                           previous_observations=observations[:time]), latent)
+            emission_dist = emission(latents=history, time=time,
+                                     previous_observations=observations[:time])
+        log_g = state.log_prob(emission_dist,
+                               state.expand_observation(observations[time], num_particles))
+        if keep_originals:
+            originals.append(latent)
+        log_weight_t, lse_t = _ops.logweight_lse(log_p, log_g, log_q)
+        log_weights.append(log_weight_t)
+        step_lse.append(lse_t)
+        device = log_weight_t.device
+
+    log_num_particles = np.log(num_particles)
+    log_marginal_likelihood = latents = log_weight = None
+    if use_smc:
+        if return_log_marginal_likelihood:
+            log_marginal_likelihood = torch.sum(
+                torch.stack(step_lse, dim=0) - log_num_particles, dim=0)
+        if return_latents:
+            latents = get_resampled_latents(originals, indices)
+        if return_log_weight:
+            log_weight = log_weights[-1]
+    else:
+        if return_log_marginal_likelihood or return_log_weight:
+            log_weight = torch.sum(torch.stack(log_weights, dim=0), dim=0)
+        if return_log_marginal_likelihood:
+            log_marginal_likelihood = _ops.row_logsumexp(log_weight) - log_num_particles
+        if return_latents:
+            latents = originals
+        if return_original_latents:
+            raise RuntimeWarning("return_original_latents shouldn't be True for is")
+        if return_ancestral_indices:
+            raise RuntimeWarning("return_ancestral_indices shouldn't be True for is")
+        if not return_log_weight:
+            log_weight = None
+
+    if device is not None:
+        _raise_for_flags(_kernels.get().read_flags(device))
+
+    return {"log_marginal_likelihood": log_marginal_likelihood,
+            "latents": latents,
+            "original_latents": originals if (use_smc and return_original_latents) else None,
+            "log_weight": log_weight,
+            "log_weights": log_weights if return_log_weights else None,
+            "ancestral_indices": indices if (use_smc and return_ancestral_indices) else None,
+            "last_latent": latent}

@@ -1,0 +1,130 @@
+"""Particle-state helpers with the semantics of the reference's aesmc/state.py.
+
+Every particle quantity is laid out [batch_size, num_particles, ...].  `resample` is the HIP row
+gather (kernel K3); the rest is shape plumbing around `torch.distributions` objects that the
+user's initial / transition / emission / proposal callables return.
+"""
+import enum
+import warnings
+
+import torch
+
+from . import _ops
+
+
+class BatchShapeMode(enum.Enum):
+    """How much of [batch_size, num_particles] a distribution's batch_shape already spans
+    (reference: aesmc/state.py:6-9)."""
+    NOT_EXPANDED = 0    # batch_shape == [...]
+    BATCH_EXPANDED = 1  # batch_shape == [batch_size, ...]
+    FULLY_EXPANDED = 2  # batch_shape == [batch_size, num_particles, ...]
+
+
+def set_batch_shape_mode(distribution, batch_shape_mode):
+    """Tags `distribution` with an explicit BatchShapeMode and returns it (state.py:12-17)."""
+    distribution.batch_shape_mode = batch_shape_mode
+    return distribution
+
+
+def _guess_batch_shape_mode(batch_shape, batch_size, num_particles):
+    """Returns (mode, ambiguous) from the leading batch dims alone (state.py:24-58)."""
+    rank = len(batch_shape)
+    if rank == 0 or batch_shape[0] != batch_size:
+        return BatchShapeMode.NOT_EXPANDED, False
+    if rank >= 2 and batch_shape[1] == num_particles:
+        return BatchShapeMode.FULLY_EXPANDED, True
+    return BatchShapeMode.BATCH_EXPANDED, True
+
+
+def get_batch_shape_mode(distribution, batch_size=None, num_particles=None):
+    """The explicit tag if one was set, else a guess from batch_shape; a guess that rests on a
+    coincidence of sizes emits a RuntimeWarning, as the reference does."""
+    if hasattr(distribution, "batch_shape_mode"):
+        return distribution.batch_shape_mode
+    mode, ambiguous = _guess_batch_shape_mode(distribution.batch_shape, batch_size, num_particles)
+    if ambiguous:
+        warnings.warn(
+            "Inferred batch_shape_mode ({}) of distribution ({}) might be wrong given its "
+            "batch_shape ({}), batch_size ({}) and num_particles ({}). Consider specifying the "
+            "batch_shape_mode explicitly.".format(mode, distribution, distribution.batch_shape,
+                                                  batch_size, num_particles), RuntimeWarning)
+    return mode
+
+
+_SAMPLE_SHAPE = {
+    BatchShapeMode.NOT_EXPANDED: lambda b, k: (b, k),
+    BatchShapeMode.BATCH_EXPANDED: lambda b, k: (k,),
+    BatchShapeMode.FULLY_EXPANDED: lambda b, k: (),
+}
+
+
+def sample(distribution, batch_size, num_particles):
+    """Reparameterised draw shaped [batch_size, num_particles, ...] (state.py:61-111).
+
+    Accepts a Distribution, a dict of them (sampled per key) or a Tensor (returned as is).
+    """
+    if isinstance(distribution, dict):
+        return {key: sample(dist, batch_size, num_particles) for key, dist in distribution.items()}
+    if isinstance(distribution, torch.Tensor):
+        return distribution
+    if not isinstance(distribution, torch.distributions.Distribution):
+        raise AttributeError("distribution must be a dict or a torch.distributions.Distribution. "
+                             "Got: {}".format(distribution))
+    mode = get_batch_shape_mode(distribution, batch_size, num_particles)
+    if mode not in _SAMPLE_SHAPE:
+        raise ValueError("batch_shape_mode {} not supported".format(mode))
+    if not distribution.has_rsample:
+        raise ValueError("distribution not reparameterizable")
+    draw = distribution.rsample(sample_shape=_SAMPLE_SHAPE[mode](batch_size, num_particles))
+    if mode == BatchShapeMode.BATCH_EXPANDED:
+        draw = draw.transpose(0, 1)  # [K, B, ...] -> [B, K, ...] view, as in the reference
+    return draw
+
+
+def log_prob(distribution, value):
+    """Log-density of `value` [batch_size, num_particles, ...] summed over everything past the
+    first two dims -> [batch_size, num_particles] (state.py:114-155).
+
+    The distribution may be missing zero, one (num_particles) or two leading batch dims.  A dict
+    of distributions sums its members' log-densities (the reference's dict branch is unreachable:
+    it names an undefined variable, state.py:130; this is the evident intent).
+    """
+    if isinstance(distribution, dict):
+        total = None
+        for key, dist in distribution.items():
+            term = log_prob(dist, value[key])
+            total = term if total is None else total + term
+        return total
+    if not isinstance(distribution, torch.distributions.Distribution):
+        raise AttributeError("distribution must be a dict or a torch.distributions.Distribution. "
+                             "Got: {}".format(distribution))
+    missing = (value.dim() - len(distribution.event_shape)) - len(distribution.batch_shape)
+    if missing == 0 or missing == 2:
+        distribution._validate_sample(value)
+        logp = distribution.log_prob(value)
+    elif missing == 1:
+        logp = distribution.log_prob(value.transpose(0, 1)).transpose(0, 1)
+    else:
+        raise RuntimeError("Incompatible distribution.batch_shape ({}) and value.shape ({}).".format(
+            distribution.batch_shape, value.shape))
+    return logp.reshape(value.size(0), value.size(1), -1).sum(dim=2)
+
+
+def resample(value, ancestral_index):
+    """out[b, k, ...] = value[b, ancestral_index[b, k], ...] without side effects
+    (state.py:158-183); recurses through dicts; differentiable w.r.t. `value`."""
+    if isinstance(value, dict):
+        return {key: resample(item, ancestral_index) for key, item in value.items()}
+    if not torch.is_tensor(value):
+        raise AttributeError("value must be a dict or a torch.Tensor. Got: {}".format(value))
+    assert ancestral_index.size() == value.size()[:2]
+    return _ops.resample_gather(value, ancestral_index)
+
+
+def expand_observation(observation, num_particles):
+    """[batch_size, ...] -> stride-0 view [batch_size, num_particles, ...]; dict-aware
+    (state.py:186-203)."""
+    if isinstance(observation, dict):
+        return {key: expand_observation(item, num_particles) for key, item in observation.items()}
+    shape = list(observation.size())
+    return observation.unsqueeze(1).expand(shape[0], num_particles, *shape[1:])

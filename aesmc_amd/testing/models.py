@@ -1,0 +1,273 @@
+"""State-space models written against the initial / transition / emission / proposal contract.
+
+Used by the parity tests, `__graft_entry__.smoke()` and `bench.py`.  Each model takes the `state`
+module it should tag distributions with, so the same definition runs under this package and —
+inside oracle/capture_golden.py only — under the imported reference when fixtures are generated.
+
+  * Lgssm1d*  : counterpart of the reference's test/models/lgssm.py (the config-1 plumbing model),
+                including its quirk that the proposal uses scale_0 at every time step
+                (test/models/lgssm.py:71).
+  * Gaussian* : counterpart of the reference's test/models/gaussian.py (one-step IWAE model).
+  * LgssmNd   : d-dimensional linear-Gaussian SSM of SURVEY.md section 8(d) (bench workloads).
+  * NonlinearSsm : tanh transition + 2-layer MLP proposal (config 4 of BASELINE.json).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import state as _default_state
+
+
+# ------------------------------------------------------------------------------------------------
+# 1-D linear-Gaussian SSM (reference test/models/lgssm.py)
+# ------------------------------------------------------------------------------------------------
+class Lgssm1dInitial:
+    def __init__(self, loc, scale):
+        self.loc, self.scale = loc, scale
+
+    def __call__(self):
+        return torch.distributions.Normal(self.loc, self.scale)
+
+
+class Lgssm1dTransition(nn.Module):
+    def __init__(self, init_mult, scale, state=_default_state):
+        super().__init__()
+        self.mult = nn.Parameter(torch.tensor(float(init_mult)))
+        self.scale = scale
+        self._state = state
+
+    def forward(self, previous_latents=None, time=None, previous_observations=None):
+        dist = torch.distributions.Normal(self.mult * previous_latents[-1], self.scale)
+        return self._state.set_batch_shape_mode(dist, self._state.BatchShapeMode.FULLY_EXPANDED)
+
+
+class Lgssm1dEmission(nn.Module):
+    def __init__(self, init_mult, scale, state=_default_state):
+        super().__init__()
+        self.mult = nn.Parameter(torch.tensor(float(init_mult)))
+        self.scale = scale
+        self._state = state
+
+    def forward(self, latents=None, time=None, previous_observations=None):
+        dist = torch.distributions.Normal(self.mult * latents[-1], self.scale)
+        return self._state.set_batch_shape_mode(dist, self._state.BatchShapeMode.FULLY_EXPANDED)
+
+
+class Lgssm1dProposal(nn.Module):
+    def __init__(self, scale_0, scale_t, state=_default_state):
+        super().__init__()
+        self.scale_0, self.scale_t = scale_0, scale_t
+        self.lin_0 = nn.Linear(1, 1)
+        self.lin_t = nn.Linear(2, 1)
+        self._state = state
+
+    def forward(self, previous_latents=None, time=None, observations=None):
+        modes = self._state.BatchShapeMode
+        if time == 0:
+            loc = self.lin_0(observations[0].unsqueeze(-1)).squeeze(-1)
+            return self._state.set_batch_shape_mode(
+                torch.distributions.Normal(loc=loc, scale=self.scale_0), modes.BATCH_EXPANDED)
+        x_prev = previous_latents[-1]
+        num_particles = x_prev.shape[1]
+        y_now = observations[time].view(-1, 1, 1).expand(-1, num_particles, 1)
+        features = torch.cat([x_prev.unsqueeze(-1), y_now], dim=2).view(-1, 2)
+        loc = self.lin_t(features).squeeze(-1).view(-1, num_particles)
+        # scale_0 at t > 0 too: the reference never reads scale_t (test/models/lgssm.py:71)
+        return self._state.set_batch_shape_mode(
+            torch.distributions.Normal(loc=loc, scale=self.scale_0), modes.FULLY_EXPANDED)
+
+
+# ------------------------------------------------------------------------------------------------
+# One-step Gaussian model (reference test/models/gaussian.py)
+# ------------------------------------------------------------------------------------------------
+class GaussianPrior(nn.Module):
+    def __init__(self, init_mean, std):
+        super().__init__()
+        self.mean = nn.Parameter(torch.tensor(init_mean, dtype=torch.float))
+        self.register_buffer("std", torch.tensor(std, dtype=torch.float))
+
+    def forward(self):
+        return torch.distributions.Normal(loc=self.mean, scale=self.std)
+
+
+class GaussianLikelihood(nn.Module):
+    def __init__(self, init_std):
+        super().__init__()
+        self.log_std = nn.Parameter(torch.log(torch.tensor(init_std, dtype=torch.float)))
+
+    def forward(self, latents=None, time=None, previous_observations=None):
+        return torch.distributions.Normal(loc=latents[-1], scale=torch.exp(self.log_std))
+
+
+class GaussianInferenceNetwork(nn.Module):
+    def __init__(self, init_mult, init_bias, init_std):
+        super().__init__()
+        self.mult = nn.Parameter(torch.tensor(init_mult, dtype=torch.float))
+        self.bias = nn.Parameter(torch.tensor(init_bias, dtype=torch.float))
+        self.log_std = nn.Parameter(torch.log(torch.tensor(init_std, dtype=torch.float)))
+
+    def forward(self, previous_latents=None, time=None, observations=None):
+        return torch.distributions.Normal(loc=self.mult * observations[0] + self.bias,
+                                          scale=torch.exp(self.log_std))
+
+
+# ------------------------------------------------------------------------------------------------
+# d-dimensional linear-Gaussian SSM; latents are [B, K, d]
+# ------------------------------------------------------------------------------------------------
+class LgssmNd(nn.Module):
+    """x_0 ~ N(0, I), x_t ~ N(A x_{t-1}, sx^2 I), y_t ~ N(C x_t, sy^2 I); proposal is a linear
+    map of [x_{t-1}, y_t] with a fixed scale.  The four contract callables are the bound methods
+    `initial`, `transition`, `emission`, `proposal`."""
+
+    def __init__(self, dim, transition_scale=1.0, emission_scale=0.5, proposal_scale=0.7, seed=0,
+                 dtype=torch.float32, state=_default_state):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        eye = torch.eye(dim, dtype=torch.float64)
+        self.dim = dim
+        self._state = state
+        self.transition_scale = transition_scale
+        self.emission_scale = emission_scale
+        self.proposal_scale = proposal_scale
+        g1 = torch.randn(dim, dim, generator=gen, dtype=torch.float64)
+        g2 = torch.randn(dim, dim, generator=gen, dtype=torch.float64)
+        self.A = nn.Parameter((0.9 * eye + 0.01 * g1).to(dtype))
+        self.C = nn.Parameter((eye + 0.01 * g2).to(dtype))
+        self.register_buffer("loc0", torch.zeros(dim, dtype=dtype))
+        self.register_buffer("scale0", torch.ones(dim, dtype=dtype))
+        # learned-proposal stand-in: mean = Wx x_{t-1} + Wy y_t + b (t = 0: W0 y_0 + b0)
+        self.W0 = nn.Parameter((0.5 * eye + 0.01 * torch.randn(dim, dim, generator=gen,
+                                                               dtype=torch.float64)).to(dtype))
+        self.b0 = nn.Parameter(torch.zeros(dim, dtype=dtype))
+        self.Wx = nn.Parameter((0.45 * eye + 0.01 * torch.randn(dim, dim, generator=gen,
+                                                                dtype=torch.float64)).to(dtype))
+        self.Wy = nn.Parameter((0.5 * eye + 0.01 * torch.randn(dim, dim, generator=gen,
+                                                               dtype=torch.float64)).to(dtype))
+        self.b = nn.Parameter(torch.zeros(dim, dtype=dtype))
+
+    def _tag(self, dist, mode_name):
+        return self._state.set_batch_shape_mode(dist, getattr(self._state.BatchShapeMode, mode_name))
+
+    def initial(self):
+        return self._tag(torch.distributions.Normal(self.loc0, self.scale0), "NOT_EXPANDED")
+
+    def transition(self, previous_latents=None, time=None, previous_observations=None):
+        loc = previous_latents[-1] @ self.A.t()
+        return self._tag(torch.distributions.Normal(loc, self.transition_scale), "FULLY_EXPANDED")
+
+    def emission(self, latents=None, time=None, previous_observations=None):
+        loc = latents[-1] @ self.C.t()
+        return self._tag(torch.distributions.Normal(loc, self.emission_scale), "FULLY_EXPANDED")
+
+    def proposal(self, previous_latents=None, time=None, observations=None):
+        if time == 0:
+            loc = observations[0] @ self.W0.t() + self.b0
+            return self._tag(torch.distributions.Normal(loc, self.proposal_scale), "BATCH_EXPANDED")
+        loc = previous_latents[-1] @ self.Wx.t() + (observations[time] @ self.Wy.t() + self.b).unsqueeze(1)
+        return self._tag(torch.distributions.Normal(loc, self.proposal_scale), "FULLY_EXPANDED")
+
+    @torch.no_grad()
+    def simulate(self, num_timesteps, batch_size, seed=0):
+        """Observations [T] x [B, d] drawn from the model itself on its own device."""
+        device, dtype = self.A.device, self.A.dtype
+        gen = torch.Generator().manual_seed(seed)
+
+        def noise():
+            return torch.randn(batch_size, self.dim, generator=gen, dtype=torch.float64).to(device, dtype)
+
+        x = self.loc0 + self.scale0 * noise()
+        observations = []
+        for time in range(num_timesteps):
+            if time > 0:
+                x = x @ self.A.t() + self.transition_scale * noise()
+            observations.append(x @ self.C.t() + self.emission_scale * noise())
+        return observations
+
+
+class NonlinearSsm(nn.Module):
+    """x_t ~ N(tanh(A x_{t-1}), sx^2 I), y_t ~ N(C x_t, sy^2 I), proposal = 2-layer MLP of
+    [x_{t-1}, y_t] (config 4 of BASELINE.json: 'nonlinear SSM with learned proposal net')."""
+
+    def __init__(self, dim, hidden=64, transition_scale=1.0, emission_scale=0.5, proposal_scale=0.7,
+                 seed=0, dtype=torch.float32, state=_default_state):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        eye = torch.eye(dim, dtype=torch.float64)
+        self.dim = dim
+        self._state = state
+        self.transition_scale = transition_scale
+        self.emission_scale = emission_scale
+        self.proposal_scale = proposal_scale
+        self.A = nn.Parameter((0.9 * eye + 0.05 * torch.randn(dim, dim, generator=gen,
+                                                              dtype=torch.float64)).to(dtype))
+        self.C = nn.Parameter((eye + 0.01 * torch.randn(dim, dim, generator=gen,
+                                                        dtype=torch.float64)).to(dtype))
+        self.register_buffer("loc0", torch.zeros(dim, dtype=dtype))
+        self.register_buffer("scale0", torch.ones(dim, dtype=dtype))
+        torch.manual_seed(seed)
+        self.net0 = nn.Sequential(nn.Linear(dim, hidden), nn.Tanh(), nn.Linear(hidden, dim)).to(dtype)
+        self.net = nn.Sequential(nn.Linear(2 * dim, hidden), nn.Tanh(), nn.Linear(hidden, dim)).to(dtype)
+
+    def _tag(self, dist, mode_name):
+        return self._state.set_batch_shape_mode(dist, getattr(self._state.BatchShapeMode, mode_name))
+
+    def initial(self):
+        return self._tag(torch.distributions.Normal(self.loc0, self.scale0), "NOT_EXPANDED")
+
+    def transition(self, previous_latents=None, time=None, previous_observations=None):
+        loc = torch.tanh(previous_latents[-1] @ self.A.t())
+        return self._tag(torch.distributions.Normal(loc, self.transition_scale), "FULLY_EXPANDED")
+
+    def emission(self, latents=None, time=None, previous_observations=None):
+        return self._tag(torch.distributions.Normal(latents[-1] @ self.C.t(), self.emission_scale),
+                         "FULLY_EXPANDED")
+
+    def proposal(self, previous_latents=None, time=None, observations=None):
+        if time == 0:
+            return self._tag(torch.distributions.Normal(self.net0(observations[0]), self.proposal_scale),
+                             "BATCH_EXPANDED")
+        x_prev = previous_latents[-1]
+        y_now = observations[time].unsqueeze(1).expand(-1, x_prev.size(1), -1)
+        loc = self.net(torch.cat([x_prev, y_now], dim=2))
+        return self._tag(torch.distributions.Normal(loc, self.proposal_scale), "FULLY_EXPANDED")
+
+    @torch.no_grad()
+    def simulate(self, num_timesteps, batch_size, seed=0):
+        device, dtype = self.A.device, self.A.dtype
+        gen = torch.Generator().manual_seed(seed)
+
+        def noise():
+            return torch.randn(batch_size, self.dim, generator=gen, dtype=torch.float64).to(device, dtype)
+
+        x = self.loc0 + self.scale0 * noise()
+        observations = []
+        for time in range(num_timesteps):
+            if time > 0:
+                x = torch.tanh(x @ self.A.t()) + self.transition_scale * noise()
+            observations.append(x @ self.C.t() + self.emission_scale * noise())
+        return observations
+
+
+def kalman_log_likelihood(model, observations):
+    """Exact log p(y_{1:T}) per batch row of an LgssmNd by the Kalman filter (float64, host):
+    an independent statistical oracle — E[exp(log Z_hat)] of IS/SMC equals exp of this."""
+    A = model.A.detach().double().cpu().numpy()
+    C = model.C.detach().double().cpu().numpy()
+    d = A.shape[0]
+    Q = np.eye(d) * model.transition_scale ** 2
+    R = np.eye(d) * model.emission_scale ** 2
+    ys = [y.detach().double().cpu().numpy() for y in observations]
+    batch = ys[0].shape[0]
+    out = np.zeros(batch)
+    for b in range(batch):
+        mean, cov = np.zeros(d), np.eye(d)
+        for t, y in enumerate(ys):
+            if t > 0:
+                mean, cov = A @ mean, A @ cov @ A.T + Q
+            s = C @ cov @ C.T + R
+            resid = y[b] - C @ mean
+            sol = np.linalg.solve(s, resid)
+            out[b] += -0.5 * (resid @ sol + np.linalg.slogdet(s)[1] + d * np.log(2 * np.pi))
+            gain = cov @ C.T @ np.linalg.inv(s)
+            mean, cov = mean + gain @ resid, cov - gain @ C @ cov
+    return out

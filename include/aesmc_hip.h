@@ -1,0 +1,110 @@
+/*
+ * aesmc_hip.h — C ABI of libaesmc_hip.so, the MI355X (gfx950) kernels behind the batched SMC
+ * inner loop of aesmc (reference: tuananhle7/aesmc, paths are into /root/reference).
+ *
+ * The reference has no FFI: its "operators" for this path are third-party CPU library calls made
+ * from Python.  Each entry point below replaces one such call site; the Python host binds them
+ * with ctypes (aesmc_amd/_lib.py) and INTEGRATION.md shows the stub a reference maintainer adds.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", return int status (AESMC_OK == 0), never throw, never allocate, never sync.
+ *   - every pointer is a DEVICE pointer borrowed for the duration of the enqueued work;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - tensors are dense row-major [B, K, ...] unless a stride argument says otherwise;
+ *   - `flags` is an optional device int32 word that kernels OR status bits into (AESMC_FLAG_*);
+ *     the host reads it once per ELBO evaluation instead of synchronising per timestep.
+ */
+#ifndef AESMC_HIP_H_
+#define AESMC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------------------------- */
+#define AESMC_OK 0
+#define AESMC_ERR_INVALID_ARGUMENT 1 /* null pointer, negative size, misaligned base pointer    */
+#define AESMC_ERR_UNSUPPORTED 2      /* shape outside what the kernels handle (see each entry)  */
+#define AESMC_ERR_LAUNCH 3           /* hipGetLastError() != hipSuccess after the launch        */
+#define AESMC_ERR_WORKSPACE 4        /* workspace too small / missing                           */
+
+/* ---- bits OR-ed into the device `flags` word ------------------------------------------------ */
+#define AESMC_FLAG_NAN_LOG_WEIGHT 1  /* a log-weight was NaN  -> FloatingPointError, inference.py:244-245 */
+#define AESMC_FLAG_DEGENERATE_ROW 2  /* a row had max = +-inf -> every index == K (reference: NaN CDF)     */
+#define AESMC_FLAG_INDEX_OUT_OF_RANGE 4 /* gather saw idx < 0 or idx >= K (torch.gather would raise)     */
+
+/* ---- dtype tags ----------------------------------------------------------------------------- */
+#define AESMC_F32 0
+#define AESMC_F64 1
+
+/* Library / build identification. */
+int aesmc_version(void);             /* 10000*major + 100*minor + patch */
+const char *aesmc_target_arch(void); /* "gfx950" */
+
+/*
+ * K1 — fused log-weight combine + per-row log-sum-exp.
+ *   lw[b,k]  = lp_a[b,k] + lp_b[b,k] - lp_c[b,k]           (lp_b / lp_c may be NULL: term dropped)
+ *   lse[b]   = log sum_k exp(lw[b,k])                      (out_lse may be NULL)
+ * Replaces: the two elementwise torch ops at aesmc/inference.py:97-98 and :125-126, and the
+ * torch.logsumexp of aesmc/inference.py:130 / :158 and aesmc/math.py:28 (per timestep, no stack).
+ * out_lw may be NULL (pure row-LSE of lp_a).  out_lw may alias lp_a.  Inputs dense [B,K].
+ * Special values follow torch.logsumexp: row of -inf -> -inf; any +inf -> +inf; any NaN -> NaN.
+ */
+int aesmc_logweight_lse(int dtype, const void *lp_a, const void *lp_b, const void *lp_c,
+                        void *out_lw, void *out_lse, int64_t B, int64_t K, void *stream);
+
+/*
+ * K1 backward.  g[b,k] = grad_lw[b,k] + grad_lse[b] * exp(lw[b,k] - lse[b])   (either grad may be
+ * NULL = zero).  Writes out_g (gradient w.r.t. lp_a and lp_b) and, if non-NULL, out_neg_g = -g
+ * (gradient w.r.t. lp_c).  Replaces autograd of the ops listed under K1.
+ */
+int aesmc_logweight_lse_backward(int dtype, const void *lw, const void *lse, const void *grad_lw,
+                                 const void *grad_lse, void *out_g, void *out_neg_g, int64_t B,
+                                 int64_t K, void *stream);
+
+/*
+ * K2 — systematic ancestral resampling, one independent problem per batch row.
+ *   w        = exp(log_w[b,:] - max_k log_w[b,:])                 (evaluated in float64)
+ *   c[j]     = (w[0] + ... + w[j]) / (w[0] + ... + w[K-1])        (float64 segmented prefix scan)
+ *   pos[k]   = (u[b] + k) / K                                     (float64, true division)
+ *   idx[b,k] = #{ j : c[j] <= pos[k] }                            (== np.digitize(pos, c))
+ * Replaces aesmc/inference.py:234-269 (numpy uniform draw excluded: `u` [B] float64 comes from the
+ * host's numpy global RandomState so RNG consumption is unchanged) and aesmc/math.py:33-51 on the
+ * numpy branch.  NaN anywhere -> AESMC_FLAG_NAN_LOG_WEIGHT (reference raises FloatingPointError);
+ * rows whose max is +-inf -> every idx == K and AESMC_FLAG_DEGENERATE_ROW (reference: NaN CDF makes
+ * np.digitize return K).  `ws` is needed only when K > aesmc_ancestor_index_lds_max_particles():
+ * then it must hold aesmc_workspace_bytes(B, K) bytes.
+ */
+int aesmc_ancestor_index(int dtype, const void *log_w, const double *u, int64_t *out_idx,
+                         int32_t *flags, int64_t B, int64_t K, void *ws, size_t ws_bytes,
+                         void *stream);
+int64_t aesmc_ancestor_index_lds_max_particles(void);
+size_t aesmc_workspace_bytes(int64_t B, int64_t K);
+
+/*
+ * K3 — resample gather:  dst[b,k,:] = src[b, idx[b,k], :]  with `row_bytes` contiguous bytes per
+ * particle.  src may be strided in its first two dims (byte strides src_stride_b / src_stride_k;
+ * this covers the transposed time-0 latent of aesmc/state.py:102-103); dst is dense.
+ * Replaces torch.gather at aesmc/state.py:179 (and aesmc/inference.py:226 with row_bytes = 8).
+ * idx outside [0,K) never faults: it is clamped and AESMC_FLAG_INDEX_OUT_OF_RANGE is raised.
+ */
+int aesmc_resample_gather(const void *src, const int64_t *idx, void *dst, int32_t *flags,
+                          int64_t B, int64_t K, int64_t row_bytes, int64_t src_stride_b,
+                          int64_t src_stride_k, void *stream);
+
+/*
+ * K3 backward:  grad_src[b,j,:] = sum_{k : idx[b,k]==j} grad_out[b,k,:]   (`row_elems` elements of
+ * `dtype` per particle, both tensors dense).  grad_src is fully overwritten (zero where a particle
+ * has no offspring).  Replaces the scatter_add autograd of torch.gather (aesmc/state.py:179).
+ */
+int aesmc_resample_gather_backward(int dtype, const void *grad_out, const int64_t *idx,
+                                   void *grad_src, int32_t *flags, int64_t B, int64_t K,
+                                   int64_t row_elems, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AESMC_HIP_H_ */

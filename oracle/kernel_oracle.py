@@ -1,0 +1,122 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  NumPy restatement of the CONTRACT of each HIP kernel
+(include/aesmc_hip.h): what K1 / K2 / K3 must return for given inputs, written independently of
+the kernels' parallel structure.  The HIP results are compared against these; these in turn are
+pinned to the reference by tests/golden/*.npz and to oracle/reference_port.py (the op-for-op port)
+in tests/test_oracle.py.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Where the contract deliberately departs from the reference's arithmetic (and why):
+  * K2 evaluates the weight CDF in float64 whatever the input dtype.  The reference works in the
+    input dtype (float32 CDF by sequential np.cumsum, aesmc/inference.py:253-261).  For float64
+    inputs both agree exactly; for float32 inputs ~1e-4 of the indices differ by +-1 because the
+    reference's float32 CDF carries ~1e-5 rounding noise (hard part 1).
+    `ancestor_index_reference_dtype` below keeps the reference's dtype for comparison.
+"""
+import numpy as np
+
+FLAG_NAN_LOG_WEIGHT = 1
+FLAG_DEGENERATE_ROW = 2
+FLAG_INDEX_OUT_OF_RANGE = 4
+
+
+def logweight_lse(a, b=None, c=None):
+    """K1.  lw = a + b - c in the input dtype (aesmc/inference.py:97-98, :125-126);
+    lse = logsumexp over axis 1 with torch.logsumexp's special-value rules (inference.py:130)."""
+    lw = np.array(a, copy=True)
+    if b is not None:
+        lw = lw + b
+    if c is not None:
+        lw = lw - c
+    lw = lw.astype(a.dtype, copy=False)
+    with np.errstate(all="ignore"):
+        m = np.max(lw, axis=1, keepdims=True) if lw.shape[1] else np.full((lw.shape[0], 1), -np.inf, lw.dtype)
+        shift = np.where(np.isfinite(m), m, 0).astype(lw.dtype)
+        lse = (np.log(np.sum(np.exp(lw - shift), axis=1, keepdims=True, dtype=lw.dtype)) + shift)[:, 0]
+    return lw, lse.astype(a.dtype)
+
+
+def logweight_lse_backward(lw, lse, grad_lw, grad_lse):
+    """K1 backward: g = grad_lw + grad_lse * softmax(lw); returns (g, -g)."""
+    g = np.zeros_like(lw)
+    if grad_lse is not None:
+        with np.errstate(all="ignore"):
+            g = g + grad_lse[:, None] * np.exp(lw - lse[:, None])
+    if grad_lw is not None:
+        g = g + grad_lw
+    g = g.astype(lw.dtype, copy=False)
+    return g, -g
+
+
+def ancestor_index(log_w, u):
+    """K2 contract: float64 CDF, idx[b,k] = #{j : c[b,j] <= (u[b] + k) / K}  (the reference's
+    np.digitize(pos, c), aesmc/inference.py:250-264).  Returns (idx int64 [B,K], flags)."""
+    log_w = np.asarray(log_w)
+    B, K = log_w.shape
+    u = np.asarray(u, dtype=np.float64).reshape(B)
+    idx = np.empty((B, K), dtype=np.int64)
+    flags = 0
+    pos_k = np.arange(0, K)
+    for b in range(B):
+        row = log_w[b]
+        if np.isnan(row).any():
+            flags |= FLAG_NAN_LOG_WEIGHT
+            idx[b] = K
+            continue
+        m = row.max() if K else 0.0
+        if not np.isfinite(m):
+            flags |= FLAG_DEGENERATE_ROW
+            idx[b] = K
+            continue
+        w = np.exp(row.astype(np.float64) - np.float64(m))
+        c = np.cumsum(w)
+        c = c / c[-1]
+        pos = (u[b] + pos_k) / K
+        idx[b] = np.searchsorted(c, pos, side="right")
+    return idx, flags
+
+
+def ancestor_index_reference_dtype(log_w, u):
+    """The reference's own arithmetic (CDF in the input dtype through scipy logsumexp, np.exp,
+    sequential np.cumsum, division by the row max; aesmc/inference.py:253-264, math.py:21-26,48-49)
+    with the uniforms passed in instead of drawn.  Used to measure the float32 mismatch rate."""
+    import scipy.special
+    log_w = np.asarray(log_w)
+    B, K = log_w.shape
+    u = np.asarray(u, dtype=np.float64).reshape(B, 1)
+    pos = (u + np.arange(0, K)) / K
+    with np.errstate(all="ignore"):
+        w = np.exp(log_w - scipy.special.logsumexp(log_w, axis=1, keepdims=True))
+        c = np.cumsum(w, axis=1)
+        c = c / np.max(c, axis=1, keepdims=True)
+    idx = np.empty((B, K), dtype=np.int64)
+    for b in range(B):
+        idx[b] = np.digitize(pos[b], c[b])
+    return idx
+
+
+def gather(src, idx):
+    """K3: dst[b,k,...] = src[b, idx[b,k], ...] (torch.gather of aesmc/state.py:179).  Indices
+    outside [0,K) are clamped and reported.  Returns (dst, flags)."""
+    B, K = idx.shape
+    flags = 0
+    if ((idx < 0) | (idx >= K)).any():
+        flags |= FLAG_INDEX_OUT_OF_RANGE
+    safe = np.clip(idx, 0, max(K - 1, 0))
+    rows = np.arange(B)[:, None]
+    return np.array(src[rows, safe], copy=True), flags
+
+
+def gather_backward(grad_out, idx):
+    """K3 backward: grad_src[b,j,...] = sum_{k: idx[b,k]==j} grad_out[b,k,...].  Out-of-range
+    indices contribute nothing and are reported."""
+    B, K = idx.shape
+    flags = 0
+    bad = (idx < 0) | (idx >= K)
+    if bad.any():
+        flags |= FLAG_INDEX_OUT_OF_RANGE
+    grad_src = np.zeros_like(grad_out)
+    rows = np.broadcast_to(np.arange(B)[:, None], idx.shape)
+    good = ~bad
+    np.add.at(grad_src, (rows[good], idx[good]), grad_out[good])
+    return grad_src, flags

@@ -1,0 +1,49 @@
+"""Kernel provider backed by oracle/kernel_oracle.py (NumPy) with the interface of
+aesmc_amd._kernels.HipKernels, for exercising the package's host logic on CPU tensors in tests."""
+import torch
+
+from oracle import kernel_oracle
+
+
+def _t(array, like):
+    return torch.from_numpy(array).to(like.dtype if array.dtype.kind == "f" else None)
+
+
+class OracleKernels:
+    name = "oracle"
+
+    def __init__(self):
+        self._flags = 0
+
+    def read_flags(self, device):
+        flags, self._flags = self._flags, 0
+        return flags
+
+    def logweight_lse(self, a, b=None, c=None, want_lw=True, want_lse=True):
+        arrays = [None if t is None else t.detach().numpy() for t in (a, b, c)]
+        lw, lse = kernel_oracle.logweight_lse(*arrays)
+        return (torch.from_numpy(lw) if want_lw else None,
+                torch.from_numpy(lse) if want_lse else None)
+
+    def logweight_lse_backward(self, lw, lse, grad_lw, grad_lse, want_neg=True):
+        g, ng = kernel_oracle.logweight_lse_backward(
+            lw.detach().numpy(), lse.detach().numpy(),
+            None if grad_lw is None else grad_lw.detach().numpy(),
+            None if grad_lse is None else grad_lse.detach().numpy())
+        return torch.from_numpy(g), (torch.from_numpy(ng) if want_neg else None)
+
+    def ancestor_index(self, log_w, u):
+        idx, flags = kernel_oracle.ancestor_index(log_w.detach().numpy(), u.numpy())
+        self._flags |= flags
+        return torch.from_numpy(idx)
+
+    def gather(self, src, idx):
+        assert idx.size() == src.size()[:2]
+        out, flags = kernel_oracle.gather(src.detach().numpy(), idx.numpy())
+        self._flags |= flags
+        return torch.from_numpy(out)
+
+    def gather_backward(self, grad_out, idx):
+        out, flags = kernel_oracle.gather_backward(grad_out.detach().contiguous().numpy(), idx.numpy())
+        self._flags |= flags
+        return torch.from_numpy(out)

@@ -1,0 +1,291 @@
+"""GPU parity tests, kernel level: every C-ABI entry point (through aesmc_amd._kernels, which is a
+ctypes veneer over include/aesmc_hip.h) against oracle/kernel_oracle.py on seeded inputs, against
+the reference-captured fixtures in tests/golden/, and — at BASELINE.json's full sizes — through
+size-independent properties.
+
+Bars: integer / index / byte work bit-exact; float32 log-sum-exp within rtol 2e-6, float64 1e-13.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_oracle
+from tests.golden_io import Golden, RESAMPLER_CASES
+
+pytestmark = pytest.mark.gpu
+
+F32_RTOL, F32_ATOL = 2e-6, 2e-6
+F64_RTOL, F64_ATOL = 1e-13, 1e-13
+
+
+def tol(dtype):
+    return (F32_RTOL, F32_ATOL) if dtype in (torch.float32, np.float32) else (F64_RTOL, F64_ATOL)
+
+
+@pytest.fixture(scope="module")
+def kernels(hip_device):
+    from aesmc_amd import _kernels
+    provider = _kernels.get()
+    assert provider.name == "hip"
+    provider.read_flags(hip_device)
+    return provider
+
+
+def dev(array, device):
+    return torch.from_numpy(np.ascontiguousarray(array)).to(device)
+
+
+# ---- K1 ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 16), (3, 7), (5, 64), (4, 1000), (7, 1024), (3, 1025),
+                                   (2, 4096), (5, 8192), (300, 33), (2, 16385)])
+def test_logweight_lse_matches_oracle(kernels, hip_device, dtype, shape):
+    rng = np.random.RandomState(hash(shape) % 1000)
+    a, b, c = [(3 * rng.randn(*shape)).astype(dtype) for _ in range(3)]
+    lw, lse = kernels.logweight_lse(dev(a, hip_device), dev(b, hip_device), dev(c, hip_device))
+    want_lw, want_lse = kernel_oracle.logweight_lse(a, b, c)
+    np.testing.assert_array_equal(lw.cpu().numpy(), want_lw)  # two IEEE adds: exact
+    rtol, atol = tol(dtype)
+    np.testing.assert_allclose(lse.cpu().numpy(), want_lse, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_logweight_lse_optional_terms_and_special_values(kernels, hip_device, dtype):
+    rng = np.random.RandomState(3)
+    a = rng.randn(6, 40).astype(dtype)
+    a[0, :] = -np.inf                 # empty row -> -inf
+    a[1, 5] = np.inf                  # -> +inf
+    a[2, 7] = np.nan                  # -> nan
+    a[3, 3:30] = -np.inf              # partial -inf is fine
+    a[4, :] = 1e4 if dtype == np.float64 else 80.0
+    lw, lse = kernels.logweight_lse(dev(a, hip_device))
+    want_lw, want_lse = kernel_oracle.logweight_lse(a)
+    np.testing.assert_array_equal(lw.cpu().numpy(), want_lw)
+    got = lse.cpu().numpy()
+    assert got[0] == -np.inf and got[1] == np.inf and np.isnan(got[2])
+    rtol, atol = tol(dtype)
+    np.testing.assert_allclose(got[3:], want_lse[3:], rtol=rtol, atol=atol)
+    # b only / c only
+    b = rng.randn(6, 40).astype(dtype)
+    lw_b, _ = kernels.logweight_lse(dev(a, hip_device), dev(b, hip_device), None)
+    np.testing.assert_array_equal(lw_b.cpu().numpy()[3:], (a + b)[3:])
+    lw_c, _ = kernels.logweight_lse(dev(a, hip_device), None, dev(b, hip_device))
+    np.testing.assert_array_equal(lw_c.cpu().numpy()[3:], (a - b)[3:])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(2, 16), (3, 7), (4, 1000), (3, 2048), (2, 4100)])
+def test_logweight_lse_backward_matches_oracle(kernels, hip_device, dtype, shape):
+    rng = np.random.RandomState(5)
+    lw = (2 * rng.randn(*shape)).astype(dtype)
+    _, lse = kernel_oracle.logweight_lse(lw)
+    glw = rng.randn(*shape).astype(dtype)
+    glse = rng.randn(shape[0]).astype(dtype)
+    rtol, atol = tol(dtype)
+    for use_glw, use_glse in [(True, True), (False, True), (True, False)]:
+        g, ng = kernels.logweight_lse_backward(
+            dev(lw, hip_device), dev(lse, hip_device), dev(glw, hip_device) if use_glw else None,
+            dev(glse, hip_device) if use_glse else None)
+        want_g, want_ng = kernel_oracle.logweight_lse_backward(
+            lw, lse, glw if use_glw else None, glse if use_glse else None)
+        np.testing.assert_allclose(g.cpu().numpy(), want_g, rtol=10 * rtol, atol=10 * atol)
+        np.testing.assert_array_equal(ng.cpu().numpy(), -g.cpu().numpy())
+
+
+# ---- K2 ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", RESAMPLER_CASES)
+def test_ancestor_index_golden(kernels, hip_device, name):
+    """Fixtures captured from aesmc.inference.sample_ancestral_index (reference)."""
+    case = Golden(name)
+    log_w, u = case["log_weight"], case["uniform"].reshape(-1)
+    kernels.read_flags(hip_device)
+    idx = kernels.ancestor_index(dev(log_w, hip_device), dev(u, hip_device)).cpu().numpy()
+    flags = kernels.read_flags(hip_device)
+    want, want_flags = kernel_oracle.ancestor_index(log_w, u)
+    np.testing.assert_array_equal(idx, want)            # HIP == contract oracle, always
+    assert flags == want_flags
+    mismatches = int((idx != case["out_idx"]).sum())     # HIP vs the reference itself
+    assert mismatches == case.meta["mismatches_vs_float64_cdf"]
+    if log_w.dtype == np.float64:
+        assert mismatches == 0
+    else:
+        assert np.abs(idx - case["out_idx"]).max() <= 1
+        assert mismatches <= 2e-3 * idx.size
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,scale", [((1, 1), 1.0), ((2, 16), 1.0), ((3, 7), 1.0), ((5, 64), 3.0),
+                                         ((4, 129), 1.0), ((6, 1000), 1.0), ((3, 1024), 5.0),
+                                         ((2, 4096), 1.0), ((2, 8191), 2.0), ((2, 16384), 1.0),
+                                         ((300, 50), 1.0)])
+def test_ancestor_index_matches_oracle(kernels, hip_device, dtype, shape, scale):
+    rng = np.random.RandomState(shape[1])
+    log_w = (scale * rng.randn(*shape)).astype(dtype)
+    u = rng.uniform(size=shape[0])
+    idx = kernels.ancestor_index(dev(log_w, hip_device), dev(u, hip_device)).cpu().numpy()
+    want, _ = kernel_oracle.ancestor_index(log_w, u)
+    np.testing.assert_array_equal(idx, want)
+    assert (np.diff(idx, axis=1) >= 0).all()            # systematic resampling is monotone
+    assert idx.min() >= 0 and idx.max() < shape[1]
+
+
+def test_ancestor_index_large_k_uses_workspace(kernels, hip_device):
+    """K above the LDS-resident limit goes through the global-workspace CDF."""
+    limit = int(kernels._lib.aesmc_ancestor_index_lds_max_particles())
+    K = limit + 1500
+    rng = np.random.RandomState(9)
+    log_w = rng.randn(3, K)
+    u = rng.uniform(size=3)
+    assert kernels._lib.aesmc_workspace_bytes(3, K) == 3 * K * 8
+    idx = kernels.ancestor_index(dev(log_w, hip_device), dev(u, hip_device)).cpu().numpy()
+    want, _ = kernel_oracle.ancestor_index(log_w, u)
+    np.testing.assert_array_equal(idx, want)
+
+
+def test_ancestor_index_flags(kernels, hip_device):
+    rng = np.random.RandomState(2)
+    log_w = rng.randn(4, 50).astype(np.float32)
+    u = rng.uniform(size=4)
+    kernels.read_flags(hip_device)
+    kernels.ancestor_index(dev(log_w, hip_device), dev(u, hip_device))
+    assert kernels.read_flags(hip_device) == 0
+    bad = log_w.copy()
+    bad[2, 7] = np.nan
+    idx = kernels.ancestor_index(dev(bad, hip_device), dev(u, hip_device)).cpu().numpy()
+    assert kernels.read_flags(hip_device) == kernel_oracle.FLAG_NAN_LOG_WEIGHT
+    assert (idx[2] == 50).all()
+    empty = log_w.copy()
+    empty[1, :] = -np.inf
+    idx = kernels.ancestor_index(dev(empty, hip_device), dev(u, hip_device)).cpu().numpy()
+    assert kernels.read_flags(hip_device) == kernel_oracle.FLAG_DEGENERATE_ROW
+    assert (idx[1] == 50).all() and idx[0].max() < 50
+
+
+def test_ancestor_index_frequencies(kernels, hip_device):
+    """The reference's statistical test (test/test_inference.py:64-84): weights [0.2, 0.3, 0.5],
+    10 000 rows, empirical ancestor frequencies within 1e-2."""
+    weight = np.array([0.2, 0.3, 0.5])
+    trials = 10000
+    rng = np.random.RandomState(0)
+    log_w = np.log(np.broadcast_to(weight, (trials, 3))).astype(np.float32)
+    idx = kernels.ancestor_index(dev(log_w, hip_device), dev(rng.uniform(size=trials), hip_device))
+    idx = idx.cpu().numpy()
+    freq = np.array([(idx == i).sum() for i in range(3)]) / (trials * 3)
+    np.testing.assert_allclose(freq, weight, atol=1e-2)
+
+
+# ---- K3 ------------------------------------------------------------------------------------------
+def sorted_indices(rng, B, K, scale=1.0):
+    log_w = scale * rng.randn(B, K)
+    idx, _ = kernel_oracle.ancestor_index(log_w, rng.uniform(size=B))
+    return idx
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64, np.uint8, np.float16, np.int16])
+@pytest.mark.parametrize("shape", [(2, 16), (2, 16, 1), (3, 7, 3), (4, 100, 10), (2, 256, 128),
+                                   (3, 33, 2, 5), (1, 1, 4), (5, 64, 7), (2, 1000, 6)])
+def test_gather_matches_oracle(kernels, hip_device, dtype, shape):
+    rng = np.random.RandomState(len(shape) * 100 + shape[1])
+    src = (100 * rng.randn(*shape)).astype(dtype)
+    for idx in (sorted_indices(rng, shape[0], shape[1]),
+                rng.randint(0, shape[1], size=shape[:2]).astype(np.int64)):   # arbitrary order too
+        out = kernels.gather(dev(src, hip_device), dev(idx, hip_device)).cpu().numpy()
+        want, _ = kernel_oracle.gather(src, idx)
+        np.testing.assert_array_equal(out, want)
+
+
+def test_gather_reference_known_answers(kernels, hip_device):
+    """test/test_state.py:286-303 (exact small gather)."""
+    idx = torch.tensor([[1, 2, 0], [0, 0, 1]], device=hip_device)
+    value = torch.tensor([[1., 2., 3.], [4., 5., 6.]], device=hip_device)
+    want = torch.tensor([[2., 3., 1.], [4., 4., 5.]], device=hip_device)
+    assert torch.equal(kernels.gather(value, idx), want)
+
+
+def test_gather_strided_sources(kernels, hip_device):
+    """Transposed time-0 latent (aesmc/state.py:102-103), stride-0 expands, sliced parents."""
+    rng = np.random.RandomState(4)
+    B, K, d = 5, 48, 3
+    idx = sorted_indices(rng, B, K)
+    idx_d = dev(idx, hip_device)
+    for src in (torch.randn(K, B, device=hip_device).transpose(0, 1),
+                torch.randn(K, B, d, device=hip_device).transpose(0, 1),
+                torch.randn(B, 1, d, device=hip_device).expand(B, K, d),
+                torch.randn(B, 2 * K, d, device=hip_device)[:, ::2],
+                torch.randn(B, K, 2 * d, device=hip_device)[:, :, ::2],
+                torch.randn(B, K, d + 1, device=hip_device)[:, :, 1:]):
+        out = kernels.gather(src, idx_d)
+        want, _ = kernel_oracle.gather(src.cpu().numpy(), idx)
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+        assert out.is_contiguous()
+
+
+def test_gather_out_of_range_is_flagged_not_fatal(kernels, hip_device):
+    src = torch.arange(24, dtype=torch.float32, device=hip_device).reshape(2, 4, 3)
+    idx = torch.tensor([[0, 1, 4, 3], [-1, 0, 0, 2]], device=hip_device)
+    kernels.read_flags(hip_device)
+    out = kernels.gather(src, idx).cpu().numpy()
+    assert kernels.read_flags(hip_device) == kernel_oracle.FLAG_INDEX_OUT_OF_RANGE
+    want, flags = kernel_oracle.gather(src.cpu().numpy(), idx.cpu().numpy())
+    assert flags == kernel_oracle.FLAG_INDEX_OUT_OF_RANGE
+    np.testing.assert_array_equal(out, want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,scale", [((2, 16), 1.0), ((3, 7, 3), 1.0), ((4, 100, 10), 1.0),
+                                         ((2, 300, 10), 8.0), ((2, 1000, 6), 30.0), ((3, 64, 2, 5), 1.0)])
+def test_gather_backward_matches_oracle(kernels, hip_device, dtype, shape, scale):
+    rng = np.random.RandomState(shape[1])
+    go = rng.randn(*shape).astype(dtype)
+    for idx in (sorted_indices(rng, shape[0], shape[1], scale),
+                rng.randint(0, shape[1], size=shape[:2]).astype(np.int64)):
+        got = kernels.gather_backward(dev(go, hip_device), dev(idx, hip_device)).cpu().numpy()
+        want, _ = kernel_oracle.gather_backward(go, idx)
+        rtol, atol = tol(dtype)
+        np.testing.assert_allclose(got, want, rtol=50 * rtol, atol=50 * atol)
+
+
+# ---- full-size properties (BASELINE.json configs) -----------------------------------------------
+@pytest.mark.parametrize("B,K,d", [(256, 1024, 10), (1024, 4096, 10), (16, 16384, 128)])
+def test_full_size_resample_properties(kernels, hip_device, B, K, d):
+    gen = torch.Generator(device=hip_device).manual_seed(B + K)
+    log_w = torch.randn(B, K, device=hip_device, generator=gen)
+    u = torch.rand(B, device=hip_device, generator=gen, dtype=torch.float64)
+    kernels.read_flags(hip_device)
+    idx = kernels.ancestor_index(log_w, u)
+    assert kernels.read_flags(hip_device) == 0
+    assert bool((idx[:, 1:] >= idx[:, :-1]).all()) and int(idx.min()) >= 0 and int(idx.max()) < K
+    # offspring counts are within 1 of K * normalised weight (systematic resampling's guarantee)
+    counts = torch.zeros(B, K, device=hip_device, dtype=torch.float64)
+    counts.scatter_add_(1, idx, torch.ones(B, K, device=hip_device, dtype=torch.float64))
+    expected = torch.softmax(log_w.double(), dim=1) * K
+    assert float((counts - expected).abs().max()) < 1.0 + 1e-6
+    # a host-side check of a few rows against the oracle
+    rows = [0, B // 2, B - 1]
+    want, _ = kernel_oracle.ancestor_index(log_w[rows].cpu().numpy(), u[rows].cpu().numpy())
+    np.testing.assert_array_equal(idx[rows].cpu().numpy(), want)
+    # gather: equals torch.gather; identity index is a copy; checksum of gathered rows
+    value = torch.randn(B, K, d, device=hip_device, generator=gen)
+    out = kernels.gather(value, idx)
+    assert torch.equal(out, torch.gather(value, 1, idx.unsqueeze(-1).expand_as(value)))
+    identity = torch.arange(K, device=hip_device).unsqueeze(0).expand(B, K).contiguous()
+    assert torch.equal(kernels.gather(value, identity), value)
+    # backward of gather is the adjoint: <gather(v), g> == <v, gather_backward(g)>
+    g = torch.randn(B, K, d, device=hip_device, generator=gen)
+    lhs = (out.double() * g.double()).sum()
+    rhs = (value.double() * kernels.gather_backward(g, idx).double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-5 * float(lhs.abs() + 1)
+
+
+def test_full_size_logweight_lse(kernels, hip_device):
+    """Config 3 of BASELINE.json: B=4096, K=8192 row log-sum-exp."""
+    B, K = 4096, 8192
+    gen = torch.Generator(device=hip_device).manual_seed(1)
+    a, b, c = [torch.randn(B, K, device=hip_device, generator=gen) for _ in range(3)]
+    lw, lse = kernels.logweight_lse(a, b, c)
+    assert torch.equal(lw, a + b - c)
+    want = torch.logsumexp(lw.double(), dim=1)
+    assert float((lse.double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+    # shift invariance: lse(x + s) == lse(x) + s
+    _, shifted = kernels.logweight_lse(lw + 3.0)
+    assert float((shifted - (lse + 3.0)).abs().max()) < 1e-5
