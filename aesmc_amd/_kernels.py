@@ -45,6 +45,52 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+class KernelTimer:
+    """Optional per-kernel timing for bench.py's `roofline` leg.  While installed on the provider
+    it keeps a bounded random sample of the launches made (the ctypes call with its operands);
+    `summary()` then replays each kernel's sample back to back on the current stream between two
+    HIP events, so the figure is kernel time on the real operands without the host gaps that
+    surround a launch inside the (host-bound) timestep loop.  `bytes` is the ALGORITHMIC traffic
+    of a launch: what the operation must move, not what the hardware
+    happened to move."""
+
+    def __init__(self, keep=24, seed=0):
+        import random
+        self.keep = keep
+        self.random = random.Random(seed)
+        self.launches = {}   # name -> [count, [(fn, nbytes, keepalive), ...]]
+
+    def note(self, name, fn, nbytes, keepalive):
+        entry = self.launches.setdefault(name, [0, []])
+        entry[0] += 1
+        if len(entry[1]) < self.keep:
+            entry[1].append((fn, nbytes, keepalive))
+        else:  # reservoir sampling keeps a uniform sample of all launches seen
+            slot = self.random.randrange(entry[0])
+            if slot < self.keep:
+                entry[1][slot] = (fn, nbytes, keepalive)
+
+    def summary(self, repeats=3):
+        out = {}
+        for name, (count, sample) in self.launches.items():
+            torch.cuda.synchronize()
+            for fn, _, _ in sample:  # warm
+                fn()
+            begin = torch.cuda.Event(enable_timing=True)
+            end = torch.cuda.Event(enable_timing=True)
+            begin.record()
+            for _ in range(repeats):
+                for fn, _, _ in sample:
+                    fn()
+            end.record()
+            torch.cuda.synchronize()
+            seconds = begin.elapsed_time(end) * 1e-3 / (repeats * len(sample))
+            nbytes = sum(n for _, n, _ in sample) / len(sample)
+            out[name] = {"launches": count, "sampled": len(sample), "avg_us": 1e6 * seconds,
+                         "bytes_per_launch": nbytes, "GBps": nbytes / seconds / 1e9}
+        return out
+
+
 class HipKernels:
     """The product backend.  One instance per process; per-device state is created lazily."""
 
@@ -54,6 +100,7 @@ class HipKernels:
         self._lib = _lib.load()
         self._flags = {}
         self._lock = threading.Lock()
+        self.timer = None  # set to a KernelTimer to time every launch (bench only)
 
     # ---- deferred status word ---------------------------------------------------------------
     def flags(self, device):
@@ -76,6 +123,12 @@ class HipKernels:
         if value:
             word.zero_()
         return value
+
+    def defer_support_check(self, valid):
+        """ORs FLAG_VALUE_OUTSIDE_SUPPORT into the status word if any element of the boolean
+        tensor `valid` is False — device-side, no synchronisation."""
+        bad = torch.logical_not(valid).any().to(torch.int32) * _lib.FLAG_VALUE_OUTSIDE_SUPPORT
+        self.flags(valid.device).bitwise_or_(bad)
 
     @staticmethod
     def _stream(t):
@@ -105,9 +158,13 @@ class HipKernels:
         lw = torch.empty_like(a) if need_lw else None
         lse = torch.empty(B, dtype=a.dtype, device=a.device) if want_lse else None
         with torch.cuda.device(a.device):
-            _lib.check(self._lib.aesmc_logweight_lse(tag, _ptr(a), _ptr(b), _ptr(c), _ptr(lw),
-                                                     _ptr(lse), B, K, self._stream(a)),
-                       "aesmc_logweight_lse")
+            args = (tag, _ptr(a), _ptr(b), _ptr(c), _ptr(lw), _ptr(lse), B, K, self._stream(a))
+            _lib.check(self._lib.aesmc_logweight_lse(*args), "aesmc_logweight_lse")
+            if self.timer is not None:
+                esz = a.element_size()
+                terms = 1 + (b is not None) + (c is not None) + (lw is not None)
+                self.timer.note("logweight_lse", lambda: self._lib.aesmc_logweight_lse(*args),
+                                B * K * esz * terms + B * esz, (a, b, c, lw, lse))
         if want_lw and not need_lw:
             lw = a
         return lw, lse
@@ -131,9 +188,14 @@ class HipKernels:
         g = torch.empty_like(lw)
         ng = torch.empty_like(lw) if want_neg else None
         with torch.cuda.device(lw.device):
-            _lib.check(self._lib.aesmc_logweight_lse_backward(
-                tag, _ptr(lw), _ptr(lse), _ptr(grad_lw), _ptr(grad_lse), _ptr(g), _ptr(ng), B, K,
-                self._stream(lw)), "aesmc_logweight_lse_backward")
+            args = (tag, _ptr(lw), _ptr(lse), _ptr(grad_lw), _ptr(grad_lse), _ptr(g), _ptr(ng), B, K,
+                    self._stream(lw))
+            _lib.check(self._lib.aesmc_logweight_lse_backward(*args), "aesmc_logweight_lse_backward")
+            if self.timer is not None:
+                terms = 2 + (grad_lw is not None) + (ng is not None)
+                self.timer.note("logweight_lse_backward",
+                                lambda: self._lib.aesmc_logweight_lse_backward(*args),
+                                B * K * lw.element_size() * terms, (lw, lse, grad_lw, grad_lse, g, ng))
         return g, ng
 
     # ---- K2 ------------------------------------------------------------------------------------
@@ -154,9 +216,13 @@ class HipKernels:
         ws_bytes = int(self._lib.aesmc_workspace_bytes(B, K))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=log_w.device) if ws_bytes else None
         with torch.cuda.device(log_w.device):
-            _lib.check(self._lib.aesmc_ancestor_index(
-                tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(self.flags(log_w.device)), B, K, _ptr(ws),
-                ws_bytes, self._stream(log_w)), "aesmc_ancestor_index")
+            flags = self.flags(log_w.device)
+            args = (tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(flags), B, K, _ptr(ws), ws_bytes,
+                    self._stream(log_w))
+            _lib.check(self._lib.aesmc_ancestor_index(*args), "aesmc_ancestor_index")
+            if self.timer is not None:
+                self.timer.note("ancestor_index", lambda: self._lib.aesmc_ancestor_index(*args),
+                                B * K * (log_w.element_size() + 8) + 8 * B, (log_w, u, idx, ws))
         return idx
 
     # ---- K3 ------------------------------------------------------------------------------------
@@ -187,9 +253,13 @@ class HipKernels:
             return dst
         idx = idx.contiguous()
         with torch.cuda.device(src.device):
-            _lib.check(self._lib.aesmc_resample_gather(
-                _ptr(src), _ptr(idx), _ptr(dst), _ptr(self.flags(src.device)), B, K, row_elems * esz,
-                src.stride(0) * esz, src.stride(1) * esz, self._stream(src)), "aesmc_resample_gather")
+            flags = self.flags(src.device)
+            args = (_ptr(src), _ptr(idx), _ptr(dst), _ptr(flags), B, K, row_elems * esz,
+                    src.stride(0) * esz, src.stride(1) * esz, self._stream(src))
+            _lib.check(self._lib.aesmc_resample_gather(*args), "aesmc_resample_gather")
+            if self.timer is not None:
+                self.timer.note("resample_gather", lambda: self._lib.aesmc_resample_gather(*args),
+                                B * K * (8 + 2 * row_elems * esz), (src, idx, dst))
         return dst
 
     def gather_backward(self, grad_out, idx):
@@ -207,9 +277,16 @@ class HipKernels:
         if grad_src.numel() == 0:
             return grad_src
         with torch.cuda.device(grad_out.device):
-            _lib.check(self._lib.aesmc_resample_gather_backward(
-                tag, _ptr(grad_out), _ptr(idx), _ptr(grad_src), _ptr(self.flags(grad_out.device)), B,
-                K, row_elems, self._stream(grad_out)), "aesmc_resample_gather_backward")
+            flags = self.flags(grad_out.device)
+            args = (tag, _ptr(grad_out), _ptr(idx), _ptr(grad_src), _ptr(flags), B, K, row_elems,
+                    self._stream(grad_out))
+            _lib.check(self._lib.aesmc_resample_gather_backward(*args),
+                       "aesmc_resample_gather_backward")
+            if self.timer is not None:
+                self.timer.note("resample_gather_backward",
+                                lambda: self._lib.aesmc_resample_gather_backward(*args),
+                                B * K * (8 + 2 * row_elems * grad_out.element_size()),
+                                (grad_out, idx, grad_src))
         return grad_src
 
 

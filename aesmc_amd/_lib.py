@@ -17,6 +17,7 @@ ERR_NAMES = {1: "invalid argument", 2: "unsupported shape", 3: "kernel launch fa
 FLAG_NAN_LOG_WEIGHT = 1
 FLAG_DEGENERATE_ROW = 2
 FLAG_INDEX_OUT_OF_RANGE = 4
+FLAG_VALUE_OUTSIDE_SUPPORT = 8  # host-side deferred validation (state.log_prob), not a kernel
 F32, F64 = 0, 1
 
 _vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t

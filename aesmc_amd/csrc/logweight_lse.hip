@@ -160,6 +160,12 @@ __global__ __launch_bounds__(kBlock) void logweight_lse_bwd_kernel(
   }
 }
 
+// One 256-thread workgroup per row for long rows, or whenever one wavefront per row would leave
+// most of the 256 CUs without a workgroup; otherwise one wavefront per row (4 rows per workgroup).
+static inline bool use_whole_workgroup_per_row(int64_t B, int64_t K) {
+  return K > 1024 || (K >= 256 && B < 2048);
+}
+
 static inline bool aligned16(const void *p) { return p == nullptr || ((uintptr_t)p & 15u) == 0; }
 
 template <typename T>
@@ -167,7 +173,7 @@ static int launch_fwd(const void *a, const void *b, const void *c, void *lw, voi
                       int64_t K, hipStream_t s) {
   constexpr int N = Vec16<T>::N;
   const bool vec = (K % N == 0) && aligned16(a) && aligned16(b) && aligned16(c) && aligned16(lw);
-  const bool wide = K > 1024;
+  const bool wide = use_whole_workgroup_per_row(B, K);
   const int rows = wide ? 1 : kBlock / kWave;
   const int64_t grid64 = (B + rows - 1) / rows;
   if (grid64 > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
@@ -196,7 +202,7 @@ static int launch_bwd(const void *lw, const void *lse, const void *glw, const vo
                       void *ng, int64_t B, int64_t K, hipStream_t s) {
   constexpr int N = Vec16<T>::N;
   const bool vec = (K % N == 0) && aligned16(lw) && aligned16(glw) && aligned16(g) && aligned16(ng);
-  const bool wide = K > 1024;
+  const bool wide = use_whole_workgroup_per_row(B, K);
   const int rows = wide ? 1 : kBlock / kWave;
   const int64_t grid64 = (B + rows - 1) / rows;
   if (grid64 > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;

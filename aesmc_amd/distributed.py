@@ -1,0 +1,105 @@
+"""Batch sharding of the SMC ELBO across the GPUs of one node.
+
+Every operation on the hot path is independent per batch row (log-sum-exp, CDF scan and search,
+gather all run along the particle dim), so rank r simply owns rows [lo, hi) of the batch with
+model parameters replicated: no data-path collective.  The one exchange step is the reduction of
+sum_b log Z_b (one scalar per ELBO evaluation) — RCCL all-reduce over xGMI with backend "nccl";
+"gloo" on CPU in tests.  For training the parameter gradients are all-reduced once per step as one
+flat bucket.
+
+For index parity with an unsharded run every rank draws the FULL [global_batch, 1] uniform block
+from numpy's global RandomState (same seed on every rank) and keeps its own rows, see
+`shard_scope`.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+from . import inference
+
+_ACTIVE_SHARD = None  # (global_batch_size, lo, hi) while inside shard_scope
+
+
+def shard_bounds(global_batch_size, rank, world_size):
+    """Rows [lo, hi) of the batch owned by `rank` (contiguous, sizes differ by at most one)."""
+    base, extra = divmod(global_batch_size, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_observations(observations, rank, world_size):
+    """Slices every observation [global_batch, ...] (or dict of them) down to this rank's rows."""
+    first = observations[0]
+    first = next(iter(first.values())) if isinstance(first, dict) else first
+    lo, hi = shard_bounds(first.size(0), rank, world_size)
+
+    def cut(obs):
+        if isinstance(obs, dict):
+            return {key: cut(item) for key, item in obs.items()}
+        return obs[lo:hi]
+
+    return [cut(obs) for obs in observations]
+
+
+@contextlib.contextmanager
+def shard_scope(global_batch_size, rank, world_size):
+    """While active, the resampler's per-step uniforms are drawn for the whole global batch and
+    sliced to this rank's rows, so a sharded run consumes numpy's RNG exactly like an unsharded
+    one and produces the same ancestor indices row for row."""
+    global _ACTIVE_SHARD
+    lo, hi = shard_bounds(global_batch_size, rank, world_size)
+    previous, _ACTIVE_SHARD = _ACTIVE_SHARD, (global_batch_size, lo, hi)
+    try:
+        yield
+    finally:
+        _ACTIVE_SHARD = previous
+
+
+def active_shard():
+    return _ACTIVE_SHARD
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x; dy/dx = 1 on every rank (each rank differentiates the global
+    objective with respect to its local contribution)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        y = x.detach().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None
+
+
+def sharded_get_loss(local_observations, num_particles, algorithm, initial, transition, emission,
+                     proposal, global_batch_size, rank=None, world_size=None, group=None):
+    """`losses.get_loss` for a batch sharded over the process group: each rank runs `infer` on its
+    rows, then ONE all-reduce of the local sum of log Z_b yields -mean over the global batch."""
+    rank = dist.get_rank(group) if rank is None else rank
+    world_size = dist.get_world_size(group) if world_size is None else world_size
+    with shard_scope(global_batch_size, rank, world_size):
+        result = inference.infer(
+            {"iwae": "is", "aesmc": "smc"}[algorithm], local_observations, initial, transition,
+            emission, proposal, num_particles, return_log_marginal_likelihood=True,
+            return_latents=False, return_log_weight=False)
+    local_sum = result["log_marginal_likelihood"].sum()
+    total = _AllReduceSum.apply(local_sum, group) if world_size > 1 else local_sum
+    return -total / global_batch_size
+
+
+def all_reduce_gradients(parameters, group=None):
+    """Sums parameter gradients over ranks with one flat-bucket all-reduce (the model is tiny
+    next to the particle state: one latency-bound collective per optimiser step)."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    offset = 0
+    for g in grads:
+        g.copy_(flat[offset:offset + g.numel()].view_as(g))
+        offset += g.numel()

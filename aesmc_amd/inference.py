@@ -73,7 +73,14 @@ class _UniformFeed:
             self.host = self.dev = None
 
     def next(self):
-        draw = np.random.uniform(size=[self.batch_size, 1])
+        from . import distributed
+        shard = distributed.active_shard()
+        if shard is None:
+            draw = np.random.uniform(size=[self.batch_size, 1])
+        else:  # batch-sharded run: consume the global block, keep this rank's rows
+            global_batch, lo, hi = shard
+            draw = np.random.uniform(size=[global_batch, 1])[lo:hi]
+            assert draw.shape[0] == self.batch_size, "shard_scope does not match the local batch"
         if self.host is None:
             return torch.from_numpy(draw.reshape(-1))
         slot = self.cursor % self.host.size(0)
@@ -87,6 +94,9 @@ def _raise_for_flags(flags):
     from . import _lib
     if flags & _lib.FLAG_NAN_LOG_WEIGHT:
         raise FloatingPointError("log_weight contains nan element(s)")
+    if flags & _lib.FLAG_VALUE_OUTSIDE_SUPPORT:
+        raise ValueError("The value argument must be within the support of the distribution "
+                         "(detected on the device during log_prob)")
     if flags & (_lib.FLAG_DEGENERATE_ROW | _lib.FLAG_INDEX_OUT_OF_RANGE):
         raise RuntimeError(
             "ancestral index out of range: a row of log-weights had no finite maximum (all -inf, "

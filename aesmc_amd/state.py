@@ -9,7 +9,59 @@ import warnings
 
 import torch
 
+from . import _kernels
 from . import _ops
+
+_VALIDATION_MODE = "deferred"
+
+
+def set_validation_mode(mode):
+    """How `log_prob` performs the reference's explicit `distribution._validate_sample(value)`
+    (aesmc/state.py:142) for values on the HIP device:
+      'deferred' (default) — shapes are checked on the host at once; the support check runs on
+          the device without synchronising and a violation raises ValueError at the end of
+          `inference.infer` (values outside a real-valued support are NaN and surface through the
+          resampler's NaN flag as FloatingPointError);
+      'eager' — call `_validate_sample` as the reference does (one host sync per call)."""
+    global _VALIDATION_MODE
+    if mode not in ("deferred", "eager"):
+        raise ValueError("validation mode must be 'deferred' or 'eager', got {}".format(mode))
+    _VALIDATION_MODE = mode
+
+
+def _is_real_support(support):
+    constraints = torch.distributions.constraints
+    while isinstance(support, constraints.independent):
+        support = support.base_constraint
+    return support is constraints.real or isinstance(support, type(constraints.real))
+
+
+def _validate_sample(distribution, value):
+    if _VALIDATION_MODE == "eager" or not value.is_cuda:
+        distribution._validate_sample(value)
+        return
+    # Host half of torch.distributions.Distribution._validate_sample: shapes only, no sync.
+    if not isinstance(value, torch.Tensor):
+        raise ValueError("The value argument to log_prob must be a Tensor")
+    event_start = value.dim() - len(distribution.event_shape)
+    if value.size()[event_start:] != distribution.event_shape:
+        raise ValueError("The right-most size of value must match event_shape: {} vs {}.".format(
+            value.size(), distribution.event_shape))
+    expected = distribution.batch_shape + distribution.event_shape
+    for got, want in zip(reversed(value.size()), reversed(expected)):
+        if got != 1 and want != 1 and got != want:
+            raise ValueError("Value is not broadcastable with batch_shape+event_shape: {} vs {}."
+                             .format(value.size(), expected))
+    try:
+        support = distribution.support
+    except NotImplementedError:
+        warnings.warn("{} does not define `support` to enable sample validation. Please "
+                      "initialize the distribution with `validate_args=False` to turn off "
+                      "validation.".format(distribution.__class__))
+        return
+    if _is_real_support(support):
+        return  # only NaN violates it; NaN reaches the log-weights and raises there
+    _kernels.get().defer_support_check(support.check(value))
 
 
 class BatchShapeMode(enum.Enum):
@@ -100,7 +152,7 @@ def log_prob(distribution, value):
                              "Got: {}".format(distribution))
     missing = (value.dim() - len(distribution.event_shape)) - len(distribution.batch_shape)
     if missing == 0 or missing == 2:
-        distribution._validate_sample(value)
+        _validate_sample(distribution, value)
         logp = distribution.log_prob(value)
     elif missing == 1:
         logp = distribution.log_prob(value.transpose(0, 1)).transpose(0, 1)

@@ -120,8 +120,9 @@ class LgssmNd(nn.Module):
     `initial`, `transition`, `emission`, `proposal`."""
 
     def __init__(self, dim, transition_scale=1.0, emission_scale=0.5, proposal_scale=0.7, seed=0,
-                 dtype=torch.float32, state=_default_state):
+                 dtype=torch.float32, state=_default_state, validate_args=None):
         super().__init__()
+        self.validate_args = validate_args  # None = PyTorch default; False skips per-call host syncs
         gen = torch.Generator().manual_seed(seed)
         eye = torch.eye(dim, dtype=torch.float64)
         self.dim = dim
@@ -148,23 +149,26 @@ class LgssmNd(nn.Module):
     def _tag(self, dist, mode_name):
         return self._state.set_batch_shape_mode(dist, getattr(self._state.BatchShapeMode, mode_name))
 
+    def _normal(self, loc, scale):
+        return torch.distributions.Normal(loc, scale, validate_args=self.validate_args)
+
     def initial(self):
-        return self._tag(torch.distributions.Normal(self.loc0, self.scale0), "NOT_EXPANDED")
+        return self._tag(self._normal(self.loc0, self.scale0), "NOT_EXPANDED")
 
     def transition(self, previous_latents=None, time=None, previous_observations=None):
         loc = previous_latents[-1] @ self.A.t()
-        return self._tag(torch.distributions.Normal(loc, self.transition_scale), "FULLY_EXPANDED")
+        return self._tag(self._normal(loc, self.transition_scale), "FULLY_EXPANDED")
 
     def emission(self, latents=None, time=None, previous_observations=None):
         loc = latents[-1] @ self.C.t()
-        return self._tag(torch.distributions.Normal(loc, self.emission_scale), "FULLY_EXPANDED")
+        return self._tag(self._normal(loc, self.emission_scale), "FULLY_EXPANDED")
 
     def proposal(self, previous_latents=None, time=None, observations=None):
         if time == 0:
             loc = observations[0] @ self.W0.t() + self.b0
-            return self._tag(torch.distributions.Normal(loc, self.proposal_scale), "BATCH_EXPANDED")
+            return self._tag(self._normal(loc, self.proposal_scale), "BATCH_EXPANDED")
         loc = previous_latents[-1] @ self.Wx.t() + (observations[time] @ self.Wy.t() + self.b).unsqueeze(1)
-        return self._tag(torch.distributions.Normal(loc, self.proposal_scale), "FULLY_EXPANDED")
+        return self._tag(self._normal(loc, self.proposal_scale), "FULLY_EXPANDED")
 
     @torch.no_grad()
     def simulate(self, num_timesteps, batch_size, seed=0):
@@ -189,8 +193,9 @@ class NonlinearSsm(nn.Module):
     [x_{t-1}, y_t] (config 4 of BASELINE.json: 'nonlinear SSM with learned proposal net')."""
 
     def __init__(self, dim, hidden=64, transition_scale=1.0, emission_scale=0.5, proposal_scale=0.7,
-                 seed=0, dtype=torch.float32, state=_default_state):
+                 seed=0, dtype=torch.float32, state=_default_state, validate_args=None):
         super().__init__()
+        self.validate_args = validate_args
         gen = torch.Generator().manual_seed(seed)
         eye = torch.eye(dim, dtype=torch.float64)
         self.dim = dim
@@ -211,25 +216,28 @@ class NonlinearSsm(nn.Module):
     def _tag(self, dist, mode_name):
         return self._state.set_batch_shape_mode(dist, getattr(self._state.BatchShapeMode, mode_name))
 
+    def _normal(self, loc, scale):
+        return torch.distributions.Normal(loc, scale, validate_args=self.validate_args)
+
     def initial(self):
-        return self._tag(torch.distributions.Normal(self.loc0, self.scale0), "NOT_EXPANDED")
+        return self._tag(self._normal(self.loc0, self.scale0), "NOT_EXPANDED")
 
     def transition(self, previous_latents=None, time=None, previous_observations=None):
         loc = torch.tanh(previous_latents[-1] @ self.A.t())
-        return self._tag(torch.distributions.Normal(loc, self.transition_scale), "FULLY_EXPANDED")
+        return self._tag(self._normal(loc, self.transition_scale), "FULLY_EXPANDED")
 
     def emission(self, latents=None, time=None, previous_observations=None):
-        return self._tag(torch.distributions.Normal(latents[-1] @ self.C.t(), self.emission_scale),
+        return self._tag(self._normal(latents[-1] @ self.C.t(), self.emission_scale),
                          "FULLY_EXPANDED")
 
     def proposal(self, previous_latents=None, time=None, observations=None):
         if time == 0:
-            return self._tag(torch.distributions.Normal(self.net0(observations[0]), self.proposal_scale),
+            return self._tag(self._normal(self.net0(observations[0]), self.proposal_scale),
                              "BATCH_EXPANDED")
         x_prev = previous_latents[-1]
         y_now = observations[time].unsqueeze(1).expand(-1, x_prev.size(1), -1)
         loc = self.net(torch.cat([x_prev, y_now], dim=2))
-        return self._tag(torch.distributions.Normal(loc, self.proposal_scale), "FULLY_EXPANDED")
+        return self._tag(self._normal(loc, self.proposal_scale), "FULLY_EXPANDED")
 
     @torch.no_grad()
     def simulate(self, num_timesteps, batch_size, seed=0):

@@ -1,0 +1,229 @@
+"""Throughput of the SMC ELBO hot path on MI355X (BASELINE.json metric: particle-steps/sec).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5|c3|c4nl]
+
+One "step" = one SMC ELBO evaluation (aesmc_amd.losses.get_loss(..., 'aesmc') forward, autograd
+graph recorded as in training) over one synthetic batch already resident in HBM.  N > 1: the driver
+launches one process per GPU via torch.distributed.run; each rank owns `B` batch rows (weak
+scaling), the only collective is the all-reduce of sum_b log Z_b (RCCL over xGMI).
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the resample-gather kernel (K3), timed per launch with HIP events on its stream
+                 while the same steps run again; achieved = algorithmic bytes / launch time;
+  cpu_baseline : oracle/reference_port.py (the op-for-op CPU port of the reference, kind "port")
+                 timed on this box's host cores on a bounded sample of the same workload;
+  kernels      : the same per-launch figures for every kernel of the path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+FORWARD_ONLY = {"c5"}  # autograd retention of T x 512 MiB latents would exceed HBM
+
+# name: (description, model kind, d, per-GPU B, K, T)
+WORKLOADS = {
+    "c2": ("LGSSM d=10 B=256 K=1024 T=50, SMC ELBO (configs[1])", "lgssm", 10, 256, 1024, 50),
+    "c4": ("LGSSM d=10 B=1024 K=4096 T=100, SMC ELBO (north-star target shape)", "lgssm", 10, 1024, 4096, 100),
+    "c4s": ("LGSSM d=10 B=128 K=4096 T=100, SMC ELBO (one GPU's shard of c4 at 8 GPUs)", "lgssm", 10, 128, 4096, 100),
+    "c4nl": ("nonlinear SSM + MLP proposal d=10 B=128 K=4096 T=100 (configs[3] per-GPU shard)", "nonlinear", 10, 128, 4096, 100),
+    "c5": ("LGSSM d=128 B=64 K=16384 T=200, SMC ELBO forward, degeneracy stress (configs[4])", "lgssm", 128, 64, 16384, 200),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-backward", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(kind, dim, device, state):
+    from aesmc_amd.testing import models
+    cls = models.LgssmNd if kind == "lgssm" else models.NonlinearSsm
+    # validate_args=False: no per-call host sync inside torch.distributions (standard practice)
+    return cls(dim, seed=0, state=state, validate_args=False).to(device)
+
+
+def cpu_baseline(kind, dim, B, K, T, budget_s=20.0):
+    """The CPU port of the reference (oracle/reference_port.py) on a BOUNDED sample of the same
+    workload: same model, K and d; batch rows (and, if still too slow, timesteps) are cut until a
+    calibrated estimate fits `budget_s` seconds.  Threads: min(cores, 16) — PyTorch's default of
+    one thread per core is far slower on big hosts for these small ops."""
+    from oracle import reference_port
+    cores = os.cpu_count() or 1
+    threads = min(cores, 16)
+    torch.set_num_threads(threads)
+    model = build_model(kind, dim, torch.device("cpu"), reference_port)
+    parts = (model.initial, model.transition, model.emission, model.proposal)
+
+    def run(b, t):
+        observations = model.simulate(t, b, seed=1)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        t0 = time.perf_counter()
+        loss = reference_port.get_loss(observations, K, "aesmc", *parts)
+        return time.perf_counter() - t0, float(loss.detach())
+
+    def cost(b, t):  # per-step work + O(T^2) history re-gather
+        return b * K * dim * (t + 0.35 * t * t)
+
+    cal_b, cal_t = max(1, min(B, 32)), min(T, 6)
+    run(cal_b, cal_t)                       # warm-up (thread pool, allocator)
+    cal_s, _ = run(cal_b, cal_t)
+    rate = cost(cal_b, cal_t) / max(cal_s, 1e-6)
+    b, t = B, T
+    while cost(b, t) / rate > budget_s and b > 8:
+        b //= 2
+    while cost(b, t) / rate > budget_s and t > 10:
+        t -= 5
+    dt, loss = run(b, t)
+    return {"value": b * K * t / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": "1 forward ELBO, B={} K={} T={} d={} in {:.1f} s on {} of {} host cores; "
+                      "oracle/reference_port.py (PyTorch-CPU + NumPy, keeps the reference's O(T^2) "
+                      "history re-gather and per-row np.digitize loop)".format(b, K, t, dim, dt, threads, cores),
+            "loss": loss}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus {} must be launched with torch.distributed.run "
+                             "--nproc-per-node {}".format(args.gpus, args.gpus))
+    import torch.distributed as dist
+    import aesmc_amd
+    from aesmc_amd import _kernels, distributed
+
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    description, kind, dim, B, K, T = WORKLOADS[args.workload]
+    provider = _kernels.get()
+    assert provider.name == "hip"
+    model = build_model(kind, dim, device, aesmc_amd.state)
+    global_B = B * world
+    observations = model.simulate(T, global_B, seed=1)          # same data on every rank ...
+    observations = distributed.shard_observations(observations, rank, world)  # ... own rows only
+    parts = (model.initial, model.transition, model.emission, model.proposal)
+    np.random.seed(0)
+    torch.manual_seed(0)
+
+    grad_mode = torch.no_grad if args.workload in FORWARD_ONLY else torch.enable_grad
+    if args.workload in FORWARD_ONLY:
+        args.no_backward = True
+
+    def step(backward=False):
+        with grad_mode():
+            return _step(backward)
+
+    def _step(backward=False):
+        if world > 1:
+            loss = distributed.sharded_get_loss(observations, K, "aesmc", *parts, global_batch_size=global_B,
+                                                rank=rank, world_size=world)
+        else:
+            loss = aesmc_amd.losses.get_loss(observations, K, "aesmc", *parts)
+        if backward:
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+            if world > 1:
+                distributed.all_reduce_gradients(list(model.parameters()))
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(n, backward=False):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step(backward)
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item()), float(loss.detach())
+
+    for _ in range(args.warmup):
+        step()
+    seconds, loss = timed(args.steps)
+    ms_per_step = 1e3 * seconds / args.steps
+    value = global_B * K * T * args.steps / seconds
+
+    fwd_bwd = None
+    if not args.no_backward:
+        step(backward=True)
+        sb, _ = timed(max(1, args.steps // 2), backward=True)
+        fwd_bwd = global_B * K * T * max(1, args.steps // 2) / sb
+
+    # ---- per-kernel timing: the same steps again with HIP events around every launch ------------
+    provider.timer = _kernels.KernelTimer()
+    for _ in range(args.steps):
+        step()
+    kernels = provider.timer.summary()
+    provider.timer = None
+    gather = kernels.get("resample_gather")
+    roofline = None
+    if gather:
+        achieved = gather["GBps"]
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                traffic = json.load(fh).get(args.workload, {}).get("resample_gather_bytes_per_launch")
+        roofline = {"kernel": "resample_gather_kernel (K3)", "bound": "hbm", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": traffic, "avg_launch_us": round(gather["avg_us"], 2),
+                    "algorithmic_bytes_per_launch": gather["bytes_per_launch"],
+                    "launches": gather["launches"]}
+
+    out = {
+        "metric": "particle_steps_per_sec", "value": value, "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "{}: {}".format(args.workload, description), "batch_per_gpu": B,
+                   "global_batch": global_B, "num_particles": K, "num_timesteps": T, "state_dim": dim,
+                   "parallelism": "batch-shard x{} (one RCCL all-reduce of sum log Z per ELBO)".format(world),
+                   "step": "one forward SMC ELBO, get_loss(..., 'aesmc'), autograd graph recorded"},
+        "loss": loss,
+        "fwd_bwd_particle_steps_per_sec": fwd_bwd,
+        "roofline": roofline,
+        "kernels": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                    for k, v in kernels.items()},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(kind, dim, B, K, T)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,7 @@ extern "C" {
 #define AESMC_FLAG_NAN_LOG_WEIGHT 1  /* a log-weight was NaN  -> FloatingPointError, inference.py:244-245 */
 #define AESMC_FLAG_DEGENERATE_ROW 2  /* a row had max = +-inf -> every index == K (reference: NaN CDF)     */
 #define AESMC_FLAG_INDEX_OUT_OF_RANGE 4 /* gather saw idx < 0 or idx >= K (torch.gather would raise)     */
+#define AESMC_FLAG_VALUE_OUTSIDE_SUPPORT 8 /* reserved for the host's deferred sample validation         */
 
 /* ---- dtype tags ----------------------------------------------------------------------------- */
 #define AESMC_F32 0

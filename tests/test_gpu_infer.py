@@ -1,0 +1,275 @@
+"""GPU parity tests, path level: aesmc_amd.inference.infer / losses.get_loss / train.train on the
+MI355X against the fixtures captured from the reference (tests/golden/), with the reference's
+random draws replayed on the device.
+
+Stated tolerances (north star: indices bit-exact under a fixed seed, ELBO within fp32 tolerance):
+  ancestor indices : exact.  For the one float32 fixture whose closest CDF comparison sits 8e-7
+                     from flipping (meta["margin"]) end-to-end float32 rounding on a different
+                     device may legitimately move it, so that case demands >= 99.9 % agreement end
+                     to end AND exact equality when the kernel is fed the reference's own
+                     log-weights (teacher forcing);
+  log-weights      : float32 rtol 1e-5 / atol 1e-5, float64 1e-11;
+  log Z, loss      : float32 |d| <= 1e-4 (1 + |x|), float64 1e-10;
+  gradients        : float32 1e-3 of the largest entry, float64 1e-8.
+"""
+import numpy as np
+import pytest
+import torch
+
+from aesmc_amd import inference, losses, state, statistics, train
+from aesmc_amd import math as amath
+from aesmc_amd.testing import models, replay
+from tests.golden_io import Golden, INFER_CASES
+
+pytestmark = pytest.mark.gpu
+
+Normal = torch.distributions.Normal
+Modes = state.BatchShapeMode
+
+
+def test_native_library_is_loaded_and_is_the_backend(hip_device):
+    from aesmc_amd import _kernels
+    provider = _kernels.get()
+    assert provider.name == "hip"
+    state.resample(torch.zeros(1, 2, device=hip_device), torch.zeros(1, 2, dtype=torch.int64, device=hip_device))
+    with open("/proc/self/maps") as fh:
+        assert "libaesmc_hip.so" in fh.read()
+
+
+def tolerances(dtype):
+    if dtype == torch.float32:
+        return dict(lw=dict(rtol=1e-5, atol=1e-5), lml=1e-4, grad=1e-3)
+    return dict(lw=dict(rtol=1e-11, atol=1e-11), lml=1e-10, grad=1e-8)
+
+
+def run(case, device, **flags):
+    parts, named = case.build_parts(state, device)
+    observations = case.observations(device)
+    smc = case.meta["algorithm"] == "aesmc"
+    with replay.replay(case.tape()):
+        result = inference.infer("smc" if smc else "is", observations, parts["initial"],
+                                 parts["transition"], parts["emission"], parts["proposal"],
+                                 case.meta["num_particles"], **flags)
+    return result, parts, named, observations
+
+
+@pytest.mark.parametrize("name", INFER_CASES)
+def test_infer_matches_reference_fixture(hip_device, name):
+    case = Golden(name)
+    tol = tolerances(case.dtype)
+    smc = case.meta["algorithm"] == "aesmc"
+    result, parts, named, observations = run(
+        case, hip_device, return_log_marginal_likelihood=True, return_latents=True,
+        return_original_latents=smc, return_log_weights=True, return_ancestral_indices=smc)
+    fragile = smc and case.dtype == torch.float32 and case.meta.get("margin", 1.0) < 5e-6
+    if smc:
+        got_idx = [a.cpu().numpy() for a in result["ancestral_indices"]]
+        assert all(a.dtype == torch.int64 and a.is_cuda for a in result["ancestral_indices"])
+        want_idx = case.series("out_idx")
+        agreement = np.mean([(g == w).mean() for g, w in zip(got_idx, want_idx)])
+        if fragile:
+            assert agreement >= 0.999, agreement
+        else:
+            for g, w in zip(got_idx, want_idx):
+                np.testing.assert_array_equal(g, w)
+        # teacher forcing: reference log-weights + reference uniforms -> reference indices, exactly
+        from aesmc_amd import _ops
+        for t, want in enumerate(want_idx):
+            lw = torch.from_numpy(case["out_log_weights_{}".format(t)]).to(hip_device)
+            u = torch.from_numpy(case["uniform_{}".format(t)].reshape(-1)).to(hip_device)
+            np.testing.assert_array_equal(_ops.ancestor_index(lw, u).cpu().numpy(), want)
+        exact = all((g == w).all() for g, w in zip(got_idx, want_idx))
+    else:
+        exact = True
+    if exact:  # past the first flipped ancestor the two runs are different (valid) particle systems
+        for got, want in zip(result["log_weights"], case.series("out_log_weights")):
+            np.testing.assert_allclose(got.detach().cpu().numpy(), want, **tol["lw"])
+        for got, want in zip(result["latents"], case.series("out_latents")):
+            np.testing.assert_allclose(got.detach().cpu().numpy(), want, **tol["lw"])
+        np.testing.assert_allclose(result["last_latent"].detach().cpu().numpy(), case["out_last_latent"], **tol["lw"])
+        if smc:
+            for got, want in zip(result["original_latents"], case.series("out_original_latents")):
+                np.testing.assert_allclose(got.detach().cpu().numpy(), want, **tol["lw"])
+    lml = result["log_marginal_likelihood"].detach().cpu().numpy()
+    want = case["out_lml"]
+    bound = (tol["lml"] if exact else 0.05) * (1 + np.abs(want))
+    assert (np.abs(lml - want) <= bound).all(), (lml, want)
+
+    with replay.replay(case.tape()):
+        loss = losses.get_loss(observations, case.meta["num_particles"], case.meta["algorithm"],
+                               parts["initial"], parts["transition"], parts["emission"], parts["proposal"])
+    loss.backward()
+    want_loss = float(case["out_loss"])
+    assert abs(loss.item() - want_loss) <= (tol["lml"] if exact else 0.05) * (1 + abs(want_loss))
+    if exact:
+        for pname, p in named.items():
+            want = case["grad_" + pname]
+            scale = np.abs(want).max() + 1e-30
+            np.testing.assert_allclose(p.grad.cpu().numpy() / scale, want / scale, rtol=0, atol=tol["grad"])
+
+
+def test_smc_estimate_is_unbiased_against_kalman_filter(hip_device):
+    """Statistical pin independent of any fixture: E[Z_hat] == exact LGSSM likelihood."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = models.LgssmNd(2, seed=0, dtype=torch.float64, validate_args=False).to(hip_device)
+    observations = model.simulate(5, 1, seed=2)
+    exact = models.kalman_log_likelihood(model, observations)[0]
+    repeated = [o.expand(64, -1).contiguous() for o in observations]   # 64 independent runs as a batch
+    with torch.no_grad():
+        out = inference.infer("smc", repeated, model.initial, model.transition, model.emission,
+                              model.proposal, 2000, return_log_marginal_likelihood=True,
+                              return_latents=False)
+    estimates = out["log_marginal_likelihood"].cpu().numpy()
+    log_mean = np.log(np.mean(np.exp(estimates - exact))) + exact
+    assert abs(log_mean - exact) < 0.05, (log_mean, exact)
+
+
+def test_full_size_config2_runs_and_matches_cpu_port_statistically(hip_device):
+    """configs[1] of BASELINE.json at full size: finite ELBO, sorted in-range ancestors, the
+    batch-mean ELBO within Monte-Carlo error of the Kalman likelihood bound."""
+    B, K, T, d = 256, 1024, 50, 10
+    model = models.LgssmNd(d, seed=0, validate_args=False).to(hip_device)
+    observations = model.simulate(T, B, seed=1)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        out = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                              model.proposal, K, return_log_marginal_likelihood=True,
+                              return_latents=False, return_ancestral_indices=True)
+    lml = out["log_marginal_likelihood"]
+    assert lml.shape == (B,) and bool(torch.isfinite(lml).all())
+    for idx in out["ancestral_indices"]:
+        assert idx.shape == (B, K)
+        assert bool((idx[:, 1:] >= idx[:, :-1]).all()) and int(idx.min()) >= 0 and int(idx.max()) < K
+    exact = models.kalman_log_likelihood(model, [o[:8] for o in observations])
+    assert np.abs(lml[:8].cpu().numpy() - exact).max() < 1.0   # SMC log Z_hat std << 1 at K = 1024
+
+
+def test_deferred_errors_surface_at_the_end_of_infer(hip_device):
+    model = models.LgssmNd(2, seed=0, validate_args=False).to(hip_device)
+    observations = model.simulate(3, 2, seed=0)
+
+    def nan_emission(latents=None, time=None, previous_observations=None):
+        dist = model.emission(latents=latents, time=time)
+        return state.set_batch_shape_mode(Normal(dist.loc * float("nan"), 1.0, validate_args=False),
+                                          Modes.FULLY_EXPANDED)
+
+    with pytest.raises(FloatingPointError):      # aesmc/inference.py:244-245
+        inference.infer("smc", observations, model.initial, model.transition, nan_emission, model.proposal, 8)
+    with pytest.raises(FloatingPointError):
+        inference.sample_ancestral_index(torch.tensor([[0.0, float("nan")]], device=hip_device))
+
+    def dead_emission(latents=None, time=None, previous_observations=None):
+        dist = model.emission(latents=latents, time=time)
+        return state.set_batch_shape_mode(Normal(dist.loc, 1e-30, validate_args=False), Modes.FULLY_EXPANDED)
+
+    with pytest.raises(RuntimeError):            # index K out of range, as torch.gather would raise
+        inference.infer("smc", [1e6 * o for o in observations], model.initial, model.transition,
+                        dead_emission, model.proposal, 8)
+    # the status word is clean again: a healthy call right after succeeds
+    out = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                          model.proposal, 8, return_log_marginal_likelihood=True)
+    assert bool(torch.isfinite(out["log_marginal_likelihood"]).all())
+
+
+def test_validation_modes(hip_device):
+    gamma = torch.distributions.Gamma(torch.ones(2, 3, device=hip_device), 1.0, validate_args=False)
+    bad = -torch.ones(2, 3, device=hip_device)
+    from aesmc_amd import _kernels, _lib
+    _kernels.get().read_flags(hip_device)
+    state.log_prob(gamma, bad)                   # deferred: no raise here ...
+    assert _kernels.get().read_flags(hip_device) == _lib.FLAG_VALUE_OUTSIDE_SUPPORT   # ... flagged
+    with pytest.raises(ValueError):              # shapes are still checked at once
+        state.log_prob(Normal(torch.zeros(2, 3, device=hip_device), 1.0), torch.zeros(2, 4, device=hip_device))
+    state.set_validation_mode("eager")
+    try:
+        with pytest.raises(ValueError):
+            state.log_prob(gamma, bad)
+    finally:
+        state.set_validation_mode("deferred")
+
+
+def test_sample_ancestral_index_on_device(hip_device):
+    out = inference.sample_ancestral_index(torch.rand(4, 9, device=hip_device))
+    assert out.is_cuda and out.dtype == torch.int64 and out.shape == (4, 9)
+    np.random.seed(1)
+    lw = torch.randn(16, 300, device=hip_device, dtype=torch.float64)
+    with replay.record() as tape:
+        got = inference.sample_ancestral_index(lw)
+    from oracle import kernel_oracle
+    want, _ = kernel_oracle.ancestor_index(lw.cpu().numpy(), tape.uniforms[0].reshape(-1))
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_math_and_statistics_on_device(hip_device):
+    x = torch.randn(3, 5, 7, device=hip_device, dtype=torch.float64)
+    for dim in (0, 1, 2):
+        torch.testing.assert_close(amath.lognormexp(x, dim=dim), x - torch.logsumexp(x, dim, keepdim=True))
+        torch.testing.assert_close(amath.exponentiate_and_normalize(x, dim=dim), torch.softmax(x, dim))
+    arr = np.array([1.0, 2.0, 3.0])              # test/test_math.py:51-64, numpy branch
+    want = np.log(np.exp(arr) / np.exp(arr).sum())
+    got = amath.lognormexp(arr)
+    assert isinstance(got, np.ndarray)
+    np.testing.assert_allclose(got, want, atol=1e-6)
+    np.testing.assert_allclose(amath.lognormexp(np.array([1, 2, 3])), want, atol=1e-6)
+    np.testing.assert_allclose(amath.exponentiate_and_normalize(arr), np.exp(want), rtol=1e-7)
+    lw = torch.randn(4, 50, device=hip_device, dtype=torch.float64)
+    w = torch.softmax(lw, 1)
+    torch.testing.assert_close(statistics.ess(lw), 1.0 / (w ** 2).sum(1))
+    value = torch.randn(4, 50, 3, device=hip_device, dtype=torch.float64)
+    torch.testing.assert_close(statistics.empirical_mean(value, lw), (w[..., None] * value).sum(1))
+    xg = x.clone().requires_grad_()
+    amath.lognormexp(xg, dim=1).exp().sum().backward()      # autograd through K1's backward
+    assert float(xg.grad.abs().max()) < 1e-9                # d/dx sum softmax == 0
+
+
+def test_autograd_through_the_hot_path_matches_torch(hip_device):
+    """K3 and K1 backward against autograd of the torch primitives they replace."""
+    from aesmc_amd import _ops
+    B, K, d = 5, 200, 4
+    gen = torch.Generator(device=hip_device).manual_seed(0)
+    value = torch.randn(B, K, d, device=hip_device, dtype=torch.float64, generator=gen)
+    terms = [torch.randn(B, K, device=hip_device, dtype=torch.float64, generator=gen) for _ in range(3)]
+    idx = _ops.ancestor_index(terms[0], torch.rand(B, device=hip_device, dtype=torch.float64, generator=gen))
+
+    def objective(gather, combine):
+        v = value.clone().requires_grad_()
+        ts = [t.clone().requires_grad_() for t in terms]
+        lw, lse = combine(*ts)
+        loss = (gather(v, idx).sum(-1) * lw).sum() + (lse ** 2).sum()
+        loss.backward()
+        return loss.detach(), [v.grad] + [t.grad for t in ts]
+
+    mine = objective(_ops.resample_gather, _ops.logweight_lse)
+    ref = objective(lambda v, i: torch.gather(v, 1, i[..., None].expand_as(v)),
+                    lambda a, b, c: (a + b - c, torch.logsumexp(a + b - c, 1)))
+    torch.testing.assert_close(mine[0], ref[0], rtol=1e-12, atol=1e-12)
+    for g, w in zip(mine[1], ref[1]):
+        torch.testing.assert_close(g, w, rtol=1e-10, atol=1e-10)
+
+
+def test_train_on_device(hip_device):
+    """test/test_losses.py:11-79 shape of test: the whole train -> loss -> infer -> backward chain."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    prior = models.GaussianPrior(0.0, 1.0).to(hip_device)
+    likelihood = models.GaussianLikelihood(1.0).to(hip_device)
+    network = models.GaussianInferenceNetwork(0.1, 0.0, 1.5).to(hip_device)
+    true_prior = models.GaussianPrior(1.0, 1.0).to(hip_device)
+    true_likelihood = models.GaussianLikelihood(0.5).to(hip_device)
+    loader = train.get_synthetic_dataloader(true_prior, None, true_likelihood, 1, 64)
+    history = []
+    train.train(loader, 16, "iwae", prior, None, likelihood, network, num_epochs=1,
+                num_iterations_per_epoch=80, optimizer_algorithm=torch.optim.SGD,
+                optimizer_kwargs={"lr": 0.05},
+                callback=lambda e, i, loss, *parts: history.append(loss.item()))
+    assert len(history) == 80 and np.isfinite(history).all()
+    assert np.mean(history[-10:]) < np.mean(history[:10])
+    # SMC training step on the d-dim LGSSM: gradients reach every parameter
+    model = models.LgssmNd(3, seed=0, validate_args=False).to(hip_device)
+    loss = losses.get_loss(model.simulate(6, 8, seed=1), 64, "aesmc", model.initial, model.transition,
+                           model.emission, model.proposal)
+    loss.backward()
+    for name, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name

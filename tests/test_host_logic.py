@@ -1,0 +1,391 @@
+"""CPU tests of aesmc_amd's HOST logic (shape modes, the infer loop, error behaviour, lazy
+history, training glue).  Kernels are substituted by the NumPy oracle through the `oracle_backend`
+fixture — a test hook; the product itself refuses CPU tensors (see test_library.py).
+
+Structure follows the reference's own suites (test/test_state.py, test/test_inference.py,
+test/test_losses.py, test/test_statistics.py), cited per test.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import aesmc_amd
+from aesmc_amd import inference, losses, state, statistics, train
+from aesmc_amd import math as amath
+from aesmc_amd.testing import models, replay
+from tests.golden_io import Golden, INFER_CASES
+
+Normal = torch.distributions.Normal
+Modes = state.BatchShapeMode
+
+
+# ---- state: batch shape modes (test/test_state.py:7-52) ------------------------------------------
+def test_batch_shape_mode_explicit_and_inferred():
+    B, K = 2, 3
+    dist = state.set_batch_shape_mode(Normal(torch.zeros(B, K), 1.0), Modes.FULLY_EXPANDED)
+    assert state.get_batch_shape_mode(dist) == Modes.FULLY_EXPANDED
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # unambiguous cases must not warn
+        assert state.get_batch_shape_mode(Normal(0.0, 1.0), B, K) == Modes.NOT_EXPANDED
+        assert state.get_batch_shape_mode(Normal(torch.zeros(5), 1.0), B, K) == Modes.NOT_EXPANDED
+        assert state.get_batch_shape_mode(Normal(torch.zeros(5, 6), 1.0), B, K) == Modes.NOT_EXPANDED
+    with pytest.warns(RuntimeWarning):
+        assert state.get_batch_shape_mode(Normal(torch.zeros(B), 1.0), B, K) == Modes.BATCH_EXPANDED
+    with pytest.warns(RuntimeWarning):
+        assert state.get_batch_shape_mode(Normal(torch.zeros(B, 7), 1.0), B, K) == Modes.BATCH_EXPANDED
+    with pytest.warns(RuntimeWarning):
+        assert state.get_batch_shape_mode(Normal(torch.zeros(B, K, 4), 1.0), B, K) == Modes.FULLY_EXPANDED
+
+
+# ---- state.sample (test/test_state.py:86-193) ----------------------------------------------------
+@pytest.mark.parametrize("dims", [(), (4,), (4, 5)])
+def test_sample_shapes_all_modes(dims):
+    B, K = 2, 3
+    cases = [(Normal(torch.zeros(*dims), 1.0) if dims else Normal(0.0, 1.0), Modes.NOT_EXPANDED),
+             (Normal(torch.zeros(B, *dims), 1.0), Modes.BATCH_EXPANDED),
+             (Normal(torch.zeros(B, K, *dims), 1.0), Modes.FULLY_EXPANDED)]
+    for dist, mode in cases:
+        state.set_batch_shape_mode(dist, mode)
+        assert state.sample(dist, B, K).shape == (B, K) + dims
+    nested = {"a": state.set_batch_shape_mode(Normal(torch.zeros(B), 1.0), Modes.BATCH_EXPANDED),
+              "b": state.set_batch_shape_mode(Normal(0.0, 1.0), Modes.NOT_EXPANDED)}
+    out = state.sample(nested, B, K)
+    assert out["a"].shape == (B, K) and out["b"].shape == (B, K)
+    tensor = torch.zeros(B, K)
+    assert state.sample(tensor, B, K) is tensor
+
+
+def test_sample_errors():
+    with pytest.raises(ValueError):   # not reparameterisable (state.py:97-100)
+        state.sample(torch.distributions.Categorical(torch.ones(3)), 2, 3)
+    with pytest.raises(AttributeError):
+        state.sample("not a distribution", 2, 3)
+    with pytest.raises(ValueError):   # unsupported mode tag (state.py:93-95)
+        state.sample(state.set_batch_shape_mode(Normal(0.0, 1.0), "bogus"), 2, 3)
+
+
+def test_sample_batch_expanded_is_transposed_view_and_uses_k_first_noise():
+    """state.py:102-103: BATCH_EXPANDED draws [K, B] noise and returns its transpose."""
+    B, K = 3, 5
+    dist = state.set_batch_shape_mode(Normal(torch.zeros(B), 1.0), Modes.BATCH_EXPANDED)
+    with replay.record() as tape:
+        x = state.sample(dist, B, K)
+    assert tape.normals[0].shape == (K, B)
+    assert x.shape == (B, K) and x.stride() == (1, B)
+    np.testing.assert_array_equal(x.numpy(), tape.normals[0].T)
+
+
+# ---- state.log_prob (test/test_state.py:196-268) -------------------------------------------------
+@pytest.mark.parametrize("dims", [(), (4,), (4, 5)])
+def test_log_prob_shapes_and_values(dims):
+    B, K = 2, 3
+    value = torch.randn(B, K, *dims)
+    full_loc = torch.randn(B, K, *dims)
+    batch_loc = torch.randn(B, *dims)
+    want_full = Normal(full_loc, 1.5).log_prob(value).reshape(B, K, -1).sum(2)
+    want_batch = Normal(batch_loc.unsqueeze(1).expand(B, K, *dims), 1.5).log_prob(value).reshape(B, K, -1).sum(2)
+    want_none = Normal(torch.zeros(B, K, *dims), 1.5).log_prob(value).reshape(B, K, -1).sum(2)
+    torch.testing.assert_close(state.log_prob(Normal(full_loc, 1.5), value), want_full)
+    torch.testing.assert_close(state.log_prob(Normal(batch_loc, 1.5), value), want_batch)
+    none = Normal(torch.zeros(*dims), 1.5) if dims else Normal(0.0, 1.5)
+    torch.testing.assert_close(state.log_prob(none, value), want_none)
+
+
+def test_log_prob_event_shapes_and_errors():
+    B, K, C = 2, 3, 4
+    one_hot = torch.distributions.OneHotCategorical(probs=torch.ones(C) / C)
+    value = one_hot.sample((B, K))
+    assert state.log_prob(one_hot, value).shape == (B, K)
+    with pytest.raises(RuntimeError):   # state.py:146-150
+        state.log_prob(Normal(torch.zeros(2, 3, 4, 5), 1.0), torch.zeros(2, 3))
+    with pytest.raises(AttributeError):
+        state.log_prob(3.0, torch.zeros(2, 3))
+    with pytest.raises(ValueError):     # _validate_sample, state.py:142
+        state.log_prob(torch.distributions.Gamma(torch.ones(2, 3), 1.0), -torch.ones(2, 3))
+    both = {"a": Normal(0.0, 1.0), "b": Normal(1.0, 2.0)}
+    value = {"a": torch.randn(B, K), "b": torch.randn(B, K)}
+    torch.testing.assert_close(state.log_prob(both, value),
+                               Normal(0.0, 1.0).log_prob(value["a"]) + Normal(1.0, 2.0).log_prob(value["b"]))
+
+
+# ---- state.resample / expand_observation (test/test_state.py:272-334) ----------------------------
+def test_resample_and_expand(oracle_backend):
+    idx = torch.zeros(3, 2, dtype=torch.int64)
+    for shape in [(3, 2), (3, 2, 4, 5)]:
+        assert state.resample(torch.rand(*shape), idx).shape == shape
+    got = state.resample(torch.tensor([[1.0, 2, 3], [4, 5, 6]]), torch.tensor([[1, 2, 0], [0, 0, 1]]))
+    assert torch.equal(got, torch.tensor([[2.0, 3, 1], [4, 4, 5]]))
+    nested = state.resample({"x": torch.rand(3, 2), "y": torch.rand(3, 2, 4)}, idx)
+    assert nested["x"].shape == (3, 2) and nested["y"].shape == (3, 2, 4)
+    with pytest.raises(AssertionError):
+        state.resample(torch.rand(3, 2), torch.zeros(3, 5, dtype=torch.int64))
+    with pytest.raises(AttributeError):
+        state.resample([1, 2, 3], idx)
+    for dims in [(), (4,), (4, 5)]:
+        obs = torch.rand(2, *dims)
+        expanded = state.expand_observation(obs, 3)
+        assert expanded.shape == (2, 3) + dims and expanded.stride(1) == 0
+    assert state.expand_observation({"a": torch.rand(2, 4)}, 3)["a"].shape == (2, 3, 4)
+
+
+def test_resample_gradient_is_scatter_add(oracle_backend):
+    value = torch.randn(2, 6, 3, dtype=torch.float64, requires_grad=True)
+    idx = torch.tensor([[0, 0, 2, 2, 2, 5], [1, 1, 1, 1, 4, 4]])
+    out = state.resample(value, idx)
+    weights = torch.randn_like(out)
+    (out * weights).sum().backward()
+    reference = value.detach().clone().requires_grad_()
+    (torch.gather(reference, 1, idx[..., None].expand(2, 6, 3)) * weights).sum().backward()
+    torch.testing.assert_close(value.grad, reference.grad)
+
+
+# ---- math (test/test_math.py) --------------------------------------------------------------------
+def test_math_torch_branch(oracle_backend):
+    for shape, dim in [((2, 3, 4), 0), ((2, 3, 4), 1), ((2, 3, 4), 2), ((5,), 0)]:
+        x = torch.randn(*shape, dtype=torch.float64)
+        torch.testing.assert_close(amath.lognormexp(x, dim=dim), x - torch.logsumexp(x, dim, keepdim=True))
+        torch.testing.assert_close(amath.exponentiate_and_normalize(x, dim=dim), torch.softmax(x, dim))
+    x = torch.tensor([1.0, 2.0, 3.0])
+    want = torch.log(torch.exp(x) / torch.exp(x).sum())
+    torch.testing.assert_close(amath.lognormexp(x), want, atol=1e-6, rtol=0)
+    assert isinstance(amath.lognormexp(x), torch.Tensor)
+
+
+# ---- inference: golden fixtures through the host loop --------------------------------------------
+def run_infer(case, device, **flags):
+    parts, named = case.build_parts(state, device)
+    observations = case.observations(device)
+    smc = case.meta["algorithm"] == "aesmc"
+    with replay.replay(case.tape()):
+        result = inference.infer("smc" if smc else "is", observations, parts["initial"],
+                                 parts["transition"], parts["emission"], parts["proposal"],
+                                 case.meta["num_particles"], **flags)
+    return result, parts, named, observations
+
+
+@pytest.mark.parametrize("name", INFER_CASES)
+def test_infer_reproduces_golden_on_host(oracle_backend, name):
+    case = Golden(name)
+    smc = case.meta["algorithm"] == "aesmc"
+    result, parts, named, observations = run_infer(
+        case, torch.device("cpu"), return_log_marginal_likelihood=True, return_latents=True,
+        return_original_latents=smc, return_log_weights=True, return_ancestral_indices=smc)
+    tol = dict(rtol=2e-6, atol=2e-6) if case.dtype == torch.float32 else dict(rtol=1e-12, atol=1e-12)
+    for got, want in zip(result["log_weights"], case.series("out_log_weights")):
+        np.testing.assert_allclose(got.detach().numpy(), want, **tol)
+    if smc:
+        for got, want in zip(result["ancestral_indices"], case.series("out_idx")):
+            np.testing.assert_array_equal(got.numpy(), want)
+        assert all(a.dtype == torch.int64 for a in result["ancestral_indices"])
+    for got, want in zip(result["latents"], case.series("out_latents")):
+        np.testing.assert_allclose(got.detach().numpy(), want, **tol)
+    lml_tol = dict(rtol=1e-5, atol=1e-5) if case.dtype == torch.float32 else tol
+    np.testing.assert_allclose(result["log_marginal_likelihood"].detach().numpy(), case["out_lml"], **lml_tol)
+    np.testing.assert_allclose(result["last_latent"].detach().numpy(), case["out_last_latent"], **tol)
+
+    with replay.replay(case.tape()):
+        loss = losses.get_loss(observations, case.meta["num_particles"], case.meta["algorithm"],
+                               parts["initial"], parts["transition"], parts["emission"], parts["proposal"])
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(case["out_loss"]), rtol=lml_tol["rtol"])
+    for pname, p in named.items():
+        want = case["grad_" + pname]
+        scale = np.abs(want).max() + 1e-30
+        np.testing.assert_allclose(p.grad.numpy() / scale, want / scale, rtol=0,
+                                   atol=5e-5 if case.dtype == torch.float32 else 1e-10)
+
+
+def test_infer_return_flags_and_keys(oracle_backend):
+    """inference.py:187-193: seven keys always; unrequested entries are None; last_latent always."""
+    case = Golden("c1_lgssm1d_smc_f32")
+    result, *_ = run_infer(case, torch.device("cpu"))
+    assert set(result) == {"log_marginal_likelihood", "latents", "original_latents", "log_weight",
+                           "log_weights", "ancestral_indices", "last_latent"}
+    assert result["log_marginal_likelihood"] is None and result["original_latents"] is None
+    assert result["log_weights"] is None and result["ancestral_indices"] is None
+    assert len(result["latents"]) == 8 and result["log_weight"].shape == (2, 16)
+    assert result["last_latent"].shape == (2, 16)
+    result, *_ = run_infer(case, torch.device("cpu"), return_latents=False, return_log_weight=False,
+                           return_log_marginal_likelihood=True)
+    assert result["latents"] is None and result["log_weight"] is None
+    assert result["log_marginal_likelihood"].shape == (2,)
+
+
+def test_infer_error_behaviour(oracle_backend):
+    case = Golden("c1_lgssm1d_is_f32")
+    with pytest.raises(ValueError):       # inference.py:71-74
+        inference.infer("pf", [torch.zeros(2)], None, None, None, None, 4)
+    with pytest.raises(RuntimeWarning):   # inference.py:169-171
+        run_infer(case, torch.device("cpu"), return_original_latents=True)
+    with pytest.raises(RuntimeWarning):   # inference.py:184-186
+        run_infer(case, torch.device("cpu"), return_ancestral_indices=True)
+    with pytest.raises(UnboundLocalError):  # losses.py:45-50
+        losses.get_loss([torch.zeros(2)], 4, "vae", None, None, None, None)
+
+
+def test_nan_log_weight_raises_floating_point_error(oracle_backend):
+    """inference.py:244-245.  Inside infer the check is deferred to the end of the call."""
+    with pytest.raises(FloatingPointError):
+        inference.sample_ancestral_index(torch.tensor([[0.0, float("nan"), 1.0]]))
+    model = models.LgssmNd(2, seed=0)
+
+    def bad_emission(latents=None, time=None, previous_observations=None):
+        dist = model.emission(latents=latents, time=time)
+        return state.set_batch_shape_mode(Normal(dist.loc * float("nan"), 1.0, validate_args=False),
+                                          Modes.FULLY_EXPANDED)
+
+    observations = model.simulate(3, 2, seed=0)
+    with pytest.raises(FloatingPointError):
+        inference.infer("smc", observations, model.initial, model.transition, bad_emission,
+                        model.proposal, 8)
+
+
+def test_degenerate_row_raises_like_out_of_range_gather(oracle_backend):
+    """A row of all -inf log-weights: reference's digitize returns K and torch.gather raises."""
+    model = models.LgssmNd(2, seed=0)
+
+    def dead_emission(latents=None, time=None, previous_observations=None):
+        dist = model.emission(latents=latents, time=time)
+        return state.set_batch_shape_mode(Normal(dist.loc, 1e-30), Modes.FULLY_EXPANDED)
+
+    observations = [1e6 * o for o in model.simulate(3, 2, seed=0)]
+    with pytest.raises(RuntimeError):
+        inference.infer("smc", observations, model.initial, model.transition, dead_emission,
+                        model.proposal, 8)
+
+
+def test_sample_ancestral_index_contract(oracle_backend):
+    """test/test_inference.py:44-84: shapes, LongTensor, frequencies; plus RNG consumption."""
+    for shape in [(2, 3), (1, 2), (2, 1), (1, 1)]:
+        out = inference.sample_ancestral_index(torch.rand(*shape))
+        assert out.shape == shape and isinstance(out, torch.LongTensor)
+    weight = [0.2, 0.3, 0.5]
+    trials = 10000
+    idx = inference.sample_ancestral_index(torch.log(torch.tensor(weight)).unsqueeze(0).expand(trials, 3))
+    freq = [(idx == i).float().sum().item() / (trials * 3) for i in range(3)]
+    np.testing.assert_allclose(freq, weight, atol=1e-2)
+    np.random.seed(3)
+    with replay.record() as tape:
+        inference.sample_ancestral_index(torch.rand(5, 4))
+    assert len(tape.uniforms) == 1 and tape.uniforms[0].shape == (5, 1)  # inference.py:250
+
+
+def test_get_resampled_latents_known_answer(oracle_backend):
+    """test/test_inference.py:13-40 (indices there are NOT sorted: arbitrary index order works)."""
+    latents = [torch.tensor([[1.0, 2, 3]]), torch.tensor([[4.0, 5, 6]]), torch.tensor([[7.0, 8, 9]]),
+               torch.tensor([[10.0, 11, 12]])]
+    indices = [torch.tensor([[0, 2, 1]]), torch.tensor([[2, 0, 0]]), torch.tensor([[1, 2, 0]])]
+    want = [[1, 1, 2], [4, 4, 6], [8, 9, 7], [10, 11, 12]]
+    for got, expected in zip(inference.get_resampled_latents(latents, indices), want):
+        np.testing.assert_array_equal(got[0].numpy(), expected)
+    assert len(inference.get_resampled_latents(latents[:1], [])) == 1
+    with pytest.raises(AssertionError):
+        inference.get_resampled_latents(latents, indices[:1])
+
+
+def test_lazy_history_equals_eager_history(oracle_backend):
+    """The lazy `previous_latents` must be indistinguishable from the reference's eager list for a
+    model that reads the WHOLE history (non-Markov), and must gather only what is read."""
+    d, B, K, T = 2, 3, 12, 5
+    model = models.LgssmNd(d, seed=1, dtype=torch.float64)
+    seen = []
+
+    def transition(previous_latents=None, time=None, previous_observations=None):
+        seen.append(previous_latents)
+        assert len(previous_latents) == time
+        mean = sum(x for x in previous_latents) / len(previous_latents)      # iteration
+        mean = mean + 0.1 * previous_latents[0] + 0.0 * sum(previous_latents[-2:])  # indexing, slicing
+        return state.set_batch_shape_mode(Normal(mean @ model.A.t(), 1.0), Modes.FULLY_EXPANDED)
+
+    observations = model.simulate(T, B, seed=3)
+    outs = {}
+    for mode in ("lazy", "eager"):
+        inference.set_history_mode(mode)
+        try:
+            np.random.seed(0)
+            torch.manual_seed(0)
+            outs[mode] = inference.infer("smc", observations, model.initial, transition, model.emission,
+                                         model.proposal, K, return_log_marginal_likelihood=True,
+                                         return_log_weights=True, return_ancestral_indices=True)
+        finally:
+            inference.set_history_mode("lazy")
+    for a, b in zip(outs["lazy"]["log_weights"], outs["eager"]["log_weights"]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs["lazy"]["ancestral_indices"], outs["eager"]["ancestral_indices"]):
+        assert torch.equal(a, b)
+    assert isinstance(seen[0], inference.ResampledHistory) and isinstance(seen[-1], list)
+    lazy = inference.ResampledHistory([torch.zeros(1, 2), torch.ones(1, 2)], torch.tensor([[1, 1]]))
+    assert len(lazy) == 2 and lazy._cache == {}
+    lazy[-1]
+    assert list(lazy._cache) == [1]
+    with pytest.raises(IndexError):
+        lazy[2]
+    with pytest.raises(ValueError):
+        inference.set_history_mode("sometimes")
+
+
+def test_observations_as_stacked_tensor(oracle_backend):
+    """test/test_inference.py:176-177 passes a [T, B] tensor instead of a list."""
+    case = Golden("c1_lgssm1d_smc_f64")
+    parts, _ = case.build_parts(state, torch.device("cpu"))
+    stacked = torch.stack(case.observations(torch.device("cpu")))
+    with replay.replay(case.tape()):
+        result = inference.infer("smc", stacked, parts["initial"], parts["transition"],
+                                 parts["emission"], parts["proposal"], case.meta["num_particles"],
+                                 return_log_marginal_likelihood=True)
+    np.testing.assert_allclose(result["log_marginal_likelihood"].detach().numpy(), case["out_lml"], rtol=1e-12)
+
+
+# ---- statistics (test/test_statistics.py) --------------------------------------------------------
+def test_statistics(oracle_backend):
+    B, K = 3, 7
+    value = torch.randn(B, K, 4, dtype=torch.float64)
+    log_weight = torch.randn(B, K, dtype=torch.float64)
+    w = torch.softmax(log_weight, 1)
+    mean = (w[..., None] * value).sum(1)
+    torch.testing.assert_close(statistics.empirical_mean(value, log_weight), mean)
+    torch.testing.assert_close(statistics.empirical_expectation(value, log_weight, lambda x: x), mean)
+    torch.testing.assert_close(statistics.empirical_variance(value, log_weight),
+                               (w[..., None] * value ** 2).sum(1) - mean ** 2)
+    for offset in (0.0, 1e6, -1e6):      # test_statistics.py:71-115: stable under huge offsets
+        torch.testing.assert_close(statistics.ess(torch.zeros(B, K, dtype=torch.float64) + offset),
+                                   torch.full((B,), float(K), dtype=torch.float64))
+    assert statistics.log_ess(torch.zeros(K, dtype=torch.float64)).shape == ()
+    one_hot = torch.full((B, K), -1e30, dtype=torch.float64)
+    one_hot[:, 0] = 0.0
+    torch.testing.assert_close(statistics.ess(one_hot), torch.ones(B, dtype=torch.float64))
+
+
+# ---- train (test/test_losses.py:11-79) -----------------------------------------------------------
+def test_train_loop_runs_and_learns(oracle_backend):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    prior = models.GaussianPrior(0.0, 1.0)
+    likelihood = models.GaussianLikelihood(1.0)
+    network = models.GaussianInferenceNetwork(0.1, 0.0, 1.5)
+    true_prior, true_likelihood = models.GaussianPrior(1.0, 1.0), models.GaussianLikelihood(0.5)
+    loader = train.get_synthetic_dataloader(true_prior, None, true_likelihood, 1, 10)
+    seen = []
+
+    def callback(epoch_idx, it_idx, loss, initial, transition, emission, proposal):
+        seen.append((epoch_idx, it_idx, loss.item()))
+        assert initial is prior and transition is None and emission is likelihood and proposal is network
+
+    train.train(loader, 4, "iwae", prior, None, likelihood, network, num_epochs=1,
+                num_iterations_per_epoch=60, optimizer_algorithm=torch.optim.SGD,
+                optimizer_kwargs={"lr": 0.05}, callback=callback)
+    assert len(seen) == 60 and seen[-1][:2] == (0, 59)
+    assert np.mean([s[2] for s in seen[-10:]]) < np.mean([s[2] for s in seen[:10]])
+    assert train.get_chained_params(lambda: 0, None) is None
+    assert len(list(train.get_chained_params(prior, None, likelihood, network))) == 5
+    latents, observations = statistics.sample_from_prior(true_prior, None, true_likelihood, 1, 6)
+    assert latents[0].shape == (6,) and observations[0].shape == (6,)
+
+
+def test_package_surface():
+    """aesmc/__init__.py:1-7."""
+    for name in ("inference", "losses", "math", "state", "statistics", "train"):
+        assert hasattr(aesmc_amd, name)
+    assert aesmc_amd.__version__ == "0.1.0"

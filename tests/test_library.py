@@ -1,0 +1,97 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol
+that include/aesmc_hip.h declares (no compute without a GPU), and the product path refuses to run
+anywhere but on a HIP device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, "include", "aesmc_hip.h")) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(aesmc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from aesmc_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 9
+    for name in names:
+        assert hasattr(lib, name), "libaesmc_hip.so does not export " + name
+    assert sorted(_lib.SIGNATURES) == names       # ctypes binding covers the header one to one
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in names:
+        getattr(raw, name)
+    assert lib.aesmc_version() == 100
+    assert lib.aesmc_target_arch() == b"gfx950"
+    assert lib.aesmc_ancestor_index_lds_max_particles() >= 16384
+    assert lib.aesmc_workspace_bytes(4, 1024) == 0
+    assert lib.aesmc_workspace_bytes(4, 40000) == 4 * 40000 * 8
+
+
+def test_library_is_gfx950_code_object():
+    from aesmc_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as fh:
+        blob = fh.read()
+    assert b"gfx950" in blob
+    for kernel in (b"logweight_lse_kernel", b"ancestor_index_kernel", b"resample_gather_kernel",
+                   b"resample_gather_bwd_kernel"):
+        assert kernel in blob
+
+
+def test_argument_validation_happens_before_any_launch():
+    """NULL pointers / negative sizes are rejected by the ABI itself (status 1), no GPU needed."""
+    from aesmc_amd import _lib
+    lib = _lib.load()
+    assert lib.aesmc_logweight_lse(0, None, None, None, None, None, 1, 1, None) == 1
+    assert lib.aesmc_logweight_lse(7, 8, None, None, 8, None, 0, 4, None) == 0      # B == 0: no-op
+    assert lib.aesmc_ancestor_index(0, None, None, None, None, 1, 1, None, 0, None) == 1
+    assert lib.aesmc_ancestor_index(0, 8, 8, 8, None, -1, 4, None, 0, None) == 1
+    assert lib.aesmc_resample_gather(None, None, None, None, 1, 1, 4, 4, 4, None) == 1
+    assert lib.aesmc_resample_gather(8, 8, 8, None, 1, 1 << 31, 4, 4, 4, None) == 2   # unsupported size
+    assert lib.aesmc_resample_gather_backward(5, 8, 8, 8, None, 1, 1, 1, None) == 1   # bad dtype tag
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_refuses_cpu_tensors_loudly():
+    """No CPU fallback: every operator of the hot path raises on host tensors."""
+    from aesmc_amd import inference, math, state
+    from aesmc_amd.testing import models
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        state.resample(torch.zeros(2, 3), torch.zeros(2, 3, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        inference.sample_ancestral_index(torch.zeros(2, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        math.lognormexp(torch.zeros(2, 3), dim=1)
+    model = models.LgssmNd(2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        inference.infer("smc", model.simulate(3, 2), model.initial, model.transition, model.emission,
+                        model.proposal, 4)
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch):
+    from aesmc_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(_lib.AesmcLibraryError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under aesmc_amd/ may reference it."""
+    package = os.path.join(ROOT, "aesmc_amd")
+    for folder, _, files in os.walk(package):
+        for name in files:
+            if name.endswith((".py", ".hip", ".hpp")):
+                with open(os.path.join(folder, name)) as fh:
+                    text = fh.read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), name
+                assert "kernel_oracle" not in text and "reference_port" not in text, name
