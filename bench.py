@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
-FORWARD_ONLY = {"c5"}  # autograd retention of T x 512 MiB latents would exceed HBM
+FORWARD_ONLY = {"c4", "c5"}  # autograd retention of T x (dozens of [B,K,d] temporaries) would exceed HBM
 
 # name: (description, model kind, d, per-GPU B, K, T)
 WORKLOADS = {
@@ -208,7 +208,8 @@ def main():
         "config": {"workload": "{}: {}".format(args.workload, description), "batch_per_gpu": B,
                    "global_batch": global_B, "num_particles": K, "num_timesteps": T, "state_dim": dim,
                    "parallelism": "batch-shard x{} (one RCCL all-reduce of sum log Z per ELBO)".format(world),
-                   "step": "one forward SMC ELBO, get_loss(..., 'aesmc'), autograd graph recorded"},
+                   "step": "one forward SMC ELBO, get_loss(..., 'aesmc'), " +
+                           ("torch.no_grad()" if args.workload in FORWARD_ONLY else "autograd graph recorded")},
         "loss": loss,
         "fwd_bwd_particle_steps_per_sec": fwd_bwd,
         "roofline": roofline,
