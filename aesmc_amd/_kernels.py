@@ -290,6 +290,89 @@ class HipKernels:
         return grad_src
 
 
+    # ---- K4 ------------------------------------------------------------------------------------
+    @staticmethod
+    def _view3(t):
+        """Describes a [B,K,*] tensor as (tensor, (sb, sk, sd), D) with the trailing dims collapsed
+        into one of extent D and element stride sd (0 = broadcast).  Copies only when the trailing
+        dims cannot be described by a single stride."""
+        D = 1
+        for size in t.shape[2:]:
+            D *= size
+        dims = [(size, stride) for size, stride in zip(t.shape[2:], t.stride()[2:]) if size != 1]
+        for (_, outer), (size, inner) in zip(dims, dims[1:]):
+            if outer != inner * size:
+                t = t.contiguous()
+                return t, (t.stride(0), t.stride(1), 1), D
+        sd = dims[-1][1] if dims else 0
+        return t, (t.stride(0), t.stride(1), sd), D
+
+    @staticmethod
+    def _unique_bytes(t):
+        n = t.element_size()
+        for size, stride in zip(t.shape, t.stride()):
+            if stride != 0:
+                n *= size
+        return n
+
+    def _normal_operands(self, value, loc, scale):
+        _require_hip(value, "value")
+        tag = _tag(value, "value")
+        if value.dim() < 2:
+            raise ValueError("aesmc_amd: value must be [batch_size, num_particles, ...]")
+        for name, t in (("loc", loc), ("scale", scale)):
+            _require_hip(t, name)
+            if t.shape != value.shape or t.dtype != value.dtype or t.device != value.device:
+                raise ValueError("aesmc_amd: {} must be a {} view of shape {} on {}, got {} {} on {}"
+                                 .format(name, value.dtype, tuple(value.shape), value.device, t.dtype,
+                                         tuple(t.shape), t.device))
+        (value, sv, D), (loc, sm, _), (scale, ss, _) = [self._view3(t) for t in (value, loc, scale)]
+        return tag, value, loc, scale, sv, sm, ss, D
+
+    def normal_logprob_sum(self, value, loc, scale):
+        """sum over trailing dims of Normal(loc, scale).log_prob(value) -> [B,K]; loc and scale are
+        views already expanded to value's shape (stride 0 where broadcast)."""
+        tag, value, loc, scale, sv, sm, ss, D = self._normal_operands(value, loc, scale)
+        B, K = value.shape[:2]
+        out = torch.empty((B, K), dtype=value.dtype, device=value.device)
+        if out.numel() == 0:
+            return out
+        with torch.cuda.device(value.device):
+            args = (tag, _ptr(value), _ptr(loc), _ptr(scale), _ptr(out), B, K, D) + sv + sm + ss + \
+                (self._stream(value),)
+            _lib.check(self._lib.aesmc_normal_logprob_sum(*args), "aesmc_normal_logprob_sum")
+            if self.timer is not None:
+                nbytes = sum(self._unique_bytes(t) for t in (value, loc, scale)) + out.numel() * out.element_size()
+                self.timer.note("normal_logprob_sum", lambda: self._lib.aesmc_normal_logprob_sum(*args),
+                                nbytes, (value, loc, scale, out))
+        return out
+
+    def normal_logprob_sum_backward(self, value, loc, scale, grad_out, need_value, need_loc, need_scale):
+        """Dense [B,K,*] gradients w.r.t. value / loc / scale (None where not needed)."""
+        shape = value.shape
+        tag, value, loc, scale, sv, sm, ss, D = self._normal_operands(value, loc, scale)
+        B, K = shape[:2]
+        if grad_out.shape != (B, K) or grad_out.dtype != value.dtype or grad_out.device != value.device:
+            raise ValueError("aesmc_amd: grad_out must be [{}, {}] {}".format(B, K, value.dtype))
+        grad_out = grad_out.contiguous()
+        outs = [torch.empty(shape, dtype=value.dtype, device=value.device) if need else None
+                for need in (need_value, need_loc, need_scale)]
+        if value.numel() == 0 or not any(o is not None for o in outs):
+            return tuple(None if o is None else o.zero_() for o in outs)
+        with torch.cuda.device(value.device):
+            args = (tag, _ptr(value), _ptr(loc), _ptr(scale), _ptr(grad_out), _ptr(outs[0]),
+                    _ptr(outs[1]), _ptr(outs[2]), B, K, D) + sv + sm + ss + (self._stream(value),)
+            _lib.check(self._lib.aesmc_normal_logprob_sum_backward(*args),
+                       "aesmc_normal_logprob_sum_backward")
+            if self.timer is not None:
+                nbytes = sum(self._unique_bytes(t) for t in (value, loc, scale, grad_out)) + \
+                    sum(o.numel() * o.element_size() for o in outs if o is not None)
+                self.timer.note("normal_logprob_sum_backward",
+                                lambda: self._lib.aesmc_normal_logprob_sum_backward(*args), nbytes,
+                                (value, loc, scale, grad_out) + tuple(outs))
+        return tuple(outs)
+
+
 _provider = None
 _provider_lock = threading.Lock()
 

@@ -33,6 +33,8 @@ SIGNATURES = {
     "aesmc_workspace_bytes": (_sz, [_i64, _i64]),
     "aesmc_resample_gather": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "aesmc_resample_gather_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "aesmc_normal_logprob_sum": (_i32, [_i32, _vp, _vp, _vp, _vp] + [_i64] * 12 + [_vp]),
+    "aesmc_normal_logprob_sum_backward": (_i32, [_i32] + [_vp] * 7 + [_i64] * 12 + [_vp]),
 }
 
 _lib = None

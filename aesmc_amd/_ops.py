@@ -50,6 +50,29 @@ class _ResampleGather(torch.autograd.Function):
         return _kernels.get().gather_backward(grad_out, idx), None
 
 
+class _NormalLogProbSum(torch.autograd.Function):
+    """sum over trailing dims of Normal(loc, scale).log_prob(value); all three are views of
+    value's shape, so autograd's own expand-backward reduces gradients of broadcast operands."""
+
+    @staticmethod
+    def forward(ctx, value, loc, scale):
+        ctx.save_for_backward(value, loc, scale)
+        return _kernels.get().normal_logprob_sum(value, loc, scale)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        value, loc, scale = ctx.saved_tensors
+        return _kernels.get().normal_logprob_sum_backward(value, loc, scale, grad_out,
+                                                          *ctx.needs_input_grad)
+
+
+def normal_log_prob_sum(value, loc, scale):
+    """[B,K] summed Normal log-density (kernel K4); differentiable in value, loc and scale."""
+    if torch.is_grad_enabled() and (value.requires_grad or loc.requires_grad or scale.requires_grad):
+        return _NormalLogProbSum.apply(value, loc, scale)
+    return _kernels.get().normal_logprob_sum(value.detach(), loc.detach(), scale.detach())
+
+
 def logweight_lse(a, b=None, c=None):
     """Returns (log_weight [B,K], logsumexp over particles [B]) for log_weight = a + b - c."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (a, b, c)):

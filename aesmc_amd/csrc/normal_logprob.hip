@@ -1,0 +1,215 @@
+// K4: summed Normal log-density  out[b,k] = sum_j log N(value[b,k,j]; loc[b,k,j], scale[b,k,j])
+// and its backward.
+//
+// Replaces, inside aesmc/state.py:114-155 (`state.log_prob`), the chain of ~11 elementwise /
+// reduction launches that torch.distributions.Normal.log_prob + `.view(B,K,-1).sum(2)` expands to
+// (sub, pow, neg, mul, div, log, sub, sub, sum ...), each a full pass over [B,K,d].  One pass here:
+// value + loc (+ scale when it is a tensor) in, 4 B per particle out.
+//
+// Per element the arithmetic is PyTorch's, operation for operation (torch/distributions/normal.py
+// log_prob):  -((v - mu)^2) / (2 * sigma^2) - log(sigma) - log(sqrt(2 pi)), so element values agree
+// with the eager path to the last place; only the order of the d-sum differs.
+//
+// Operands are [B,K,D] views given by element strides (0 = broadcast), which covers every
+// BatchShapeMode of the reference without materialising an expand: loc [D] (NOT_EXPANDED),
+// loc [B,D] (BATCH_EXPANDED), loc [B,K,D] (FULLY_EXPANDED), value = observation expanded over K,
+// the transposed time-0 latent, scalar scales.
+#include "common.hpp"
+
+namespace aesmc {
+
+struct Strides3 {
+  int64_t b, k, d;
+};
+
+constexpr int kLpBlock = 256;
+constexpr int kTileBytes = 32 * 1024;  // LDS tile budget per workgroup
+
+template <typename T> struct NormConst;
+template <> struct NormConst<float> {
+  // (float)math.log(math.sqrt(2 * math.pi)) as PyTorch's scalar operand is narrowed
+  static __device__ __forceinline__ float half_log_2pi() { return 0.9189385332046727f; }
+};
+template <> struct NormConst<double> {
+  static __device__ __forceinline__ double half_log_2pi() { return 0.9189385332046727; }
+};
+
+template <typename T> __device__ __forceinline__ T normal_logpdf(T v, T mu, T sigma) {
+  const T diff = v - mu;
+  const T var = sigma * sigma;
+  return (-(diff * diff)) / (T(2) * var) - Num<T>::log(sigma) - NormConst<T>::half_log_2pi();
+}
+
+__device__ __forceinline__ uint32_t pad_index(uint32_t e) { return e + (e >> 5); }
+
+// Small D: a workgroup owns P consecutive particles of one batch row.  Lanes walk the tile's P*D
+// elements in memory order (coalesced for dense operands), park the per-element log-densities in
+// LDS, then one lane per particle adds its D values.
+template <typename T>
+__global__ __launch_bounds__(kLpBlock) void normal_lps_tile_kernel(
+    const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ scale,
+    T *__restrict__ out, uint32_t K, uint32_t D, uint32_t P, uint32_t tiles_per_row, Strides3 sv,
+    Strides3 sm, Strides3 ss) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lps_smem[];
+  T *tile = reinterpret_cast<T *>(lps_smem);
+  const uint32_t b = blockIdx.x / tiles_per_row;
+  const uint32_t k0 = (blockIdx.x - b * tiles_per_row) * P;
+  const uint32_t np = min(P, K - k0);
+  const uint32_t ne = np * D;
+  const T *vb = value + (int64_t)b * sv.b;
+  const T *mb = loc + (int64_t)b * sm.b;
+  const T *sb = scale + (int64_t)b * ss.b;
+
+  uint32_t e = threadIdx.x;
+  uint32_t kk = e / D, j = e - kk * D;
+  const uint32_t dk = kLpBlock / D, dj = kLpBlock - dk * D;
+  for (; e < ne; e += kLpBlock) {
+    const int64_t k = k0 + kk;
+    const T f = normal_logpdf<T>(vb[k * sv.k + (int64_t)j * sv.d], mb[k * sm.k + (int64_t)j * sm.d],
+                                 sb[k * ss.k + (int64_t)j * ss.d]);
+    tile[pad_index(e)] = f;
+    kk += dk;
+    j += dj;
+    if (j >= D) {
+      j -= D;
+      ++kk;
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < np; p += kLpBlock) {
+    T sum = T(0);
+    const uint32_t base = p * D;
+    for (uint32_t jj = 0; jj < D; ++jj) sum += tile[pad_index(base + jj)];
+    out[(int64_t)b * K + k0 + p] = sum;
+  }
+}
+
+// Large D: one wavefront per particle, lanes stride over D, shuffle reduction.
+template <typename T>
+__global__ __launch_bounds__(kLpBlock) void normal_lps_wave_kernel(
+    const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ scale,
+    T *__restrict__ out, int64_t particles, uint32_t K, uint32_t D, Strides3 sv, Strides3 sm,
+    Strides3 ss) {
+  const int64_t p = (int64_t)blockIdx.x * (kLpBlock / kWave) + threadIdx.x / kWave;
+  if (p >= particles) return;
+  const int lane = threadIdx.x % kWave;
+  const int64_t b = p / K, k = p - b * K;
+  const T *vp = value + b * sv.b + k * sv.k;
+  const T *mp = loc + b * sm.b + k * sm.k;
+  const T *sp = scale + b * ss.b + k * ss.k;
+  T sum = T(0);
+  for (uint32_t j = lane; j < D; j += kWave)
+    sum += normal_logpdf<T>(vp[(int64_t)j * sv.d], mp[(int64_t)j * sm.d], sp[(int64_t)j * ss.d]);
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+  if (lane == 0) out[p] = sum;
+}
+
+// Backward: with g = grad_out[b,k], z = (v - mu) / sigma^2 :
+//   d/dv = -g z,   d/dmu = g z,   d/dsigma = g ((v - mu)^2 / sigma^3 - 1 / sigma).
+// Each requested gradient is written densely [B,K,D]; autograd's expand-backward reduces the
+// broadcast operands.
+template <typename T>
+__global__ __launch_bounds__(kLpBlock) void normal_lps_bwd_kernel(
+    const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ scale,
+    const T *__restrict__ grad_out, T *__restrict__ grad_value, T *__restrict__ grad_loc,
+    T *__restrict__ grad_scale, int64_t total, uint32_t K, uint32_t D, Strides3 sv, Strides3 sm,
+    Strides3 ss) {
+  const int64_t stride = (int64_t)gridDim.x * kLpBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kLpBlock + threadIdx.x; e < total; e += stride) {
+    const int64_t p = e / D;
+    const uint32_t j = (uint32_t)(e - p * D);
+    const int64_t b = p / K, k = p - b * K;
+    const T v = value[b * sv.b + k * sv.k + (int64_t)j * sv.d];
+    const T mu = loc[b * sm.b + k * sm.k + (int64_t)j * sm.d];
+    const T sigma = scale[b * ss.b + k * ss.k + (int64_t)j * ss.d];
+    const T g = grad_out[p];
+    const T diff = v - mu;
+    const T var = sigma * sigma;
+    const T gz = g * (diff / var);
+    if (grad_value) grad_value[e] = -gz;
+    if (grad_loc) grad_loc[e] = gz;
+    if (grad_scale) grad_scale[e] = g * ((diff * diff) / (var * sigma) - T(1) / sigma);
+  }
+}
+
+template <typename T>
+static int launch_lps(const void *value, const void *loc, const void *scale, void *out, int64_t B,
+                      int64_t K, int64_t D, Strides3 sv, Strides3 sm, Strides3 ss, hipStream_t s) {
+  if (D <= 64) {
+    uint32_t P = (uint32_t)((kTileBytes / (int)sizeof(T)) / D);
+    if (P > 256) P = 256;
+    if (P > K) P = (uint32_t)K;
+    const uint32_t tiles = (uint32_t)((K + P - 1) / P);
+    if ((uint64_t)B * tiles > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
+    const uint32_t ne = P * (uint32_t)D;
+    const size_t lds = (size_t)(ne + (ne >> 5) + 1) * sizeof(T);
+    hipLaunchKernelGGL((normal_lps_tile_kernel<T>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds,
+                       s, (const T *)value, (const T *)loc, (const T *)scale, (T *)out, (uint32_t)K,
+                       (uint32_t)D, P, tiles, sv, sm, ss);
+  } else {
+    const int64_t particles = B * K;
+    const int64_t blocks = (particles + (kLpBlock / kWave) - 1) / (kLpBlock / kWave);
+    if (blocks > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((normal_lps_wave_kernel<T>), dim3((unsigned)blocks), dim3(kLpBlock), 0, s,
+                       (const T *)value, (const T *)loc, (const T *)scale, (T *)out, particles,
+                       (uint32_t)K, (uint32_t)D, sv, sm, ss);
+  }
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+template <typename T>
+static int launch_lps_bwd(const void *value, const void *loc, const void *scale, const void *go,
+                          void *gv, void *gm, void *gs, int64_t B, int64_t K, int64_t D, Strides3 sv,
+                          Strides3 sm, Strides3 ss, hipStream_t s) {
+  const int64_t total = B * K * D;
+  int64_t blocks = (total + kLpBlock - 1) / kLpBlock;
+  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
+  hipLaunchKernelGGL((normal_lps_bwd_kernel<T>), dim3((unsigned)blocks), dim3(kLpBlock), 0, s,
+                     (const T *)value, (const T *)loc, (const T *)scale, (const T *)go, (T *)gv,
+                     (T *)gm, (T *)gs, total, (uint32_t)K, (uint32_t)D, sv, sm, ss);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+}  // namespace aesmc
+
+extern "C" int aesmc_normal_logprob_sum(int dtype, const void *value, const void *loc,
+                                        const void *scale, void *out, int64_t B, int64_t K,
+                                        int64_t D, int64_t v_sb, int64_t v_sk, int64_t v_sd,
+                                        int64_t m_sb, int64_t m_sk, int64_t m_sd, int64_t s_sb,
+                                        int64_t s_sk, int64_t s_sd, void *stream) {
+  using namespace aesmc;
+  if (!value || !loc || !scale || !out || B < 0 || K < 0 || D < 0) return AESMC_ERR_INVALID_ARGUMENT;
+  if (B == 0 || K == 0) return AESMC_OK;
+  if (K >= (1ll << 31) || D >= (1ll << 31) || B >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
+  if (D == 0) {  // empty event: the sum is 0
+    return hipMemsetAsync(out, 0, (size_t)B * K * (dtype == AESMC_F32 ? 4 : 8), (hipStream_t)stream) ==
+                   hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
+  Strides3 sv{v_sb, v_sk, v_sd}, sm{m_sb, m_sk, m_sd}, ss{s_sb, s_sk, s_sd};
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AESMC_F32) return launch_lps<float>(value, loc, scale, out, B, K, D, sv, sm, ss, s);
+  if (dtype == AESMC_F64) return launch_lps<double>(value, loc, scale, out, B, K, D, sv, sm, ss, s);
+  return AESMC_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int aesmc_normal_logprob_sum_backward(
+    int dtype, const void *value, const void *loc, const void *scale, const void *grad_out,
+    void *grad_value, void *grad_loc, void *grad_scale, int64_t B, int64_t K, int64_t D, int64_t v_sb,
+    int64_t v_sk, int64_t v_sd, int64_t m_sb, int64_t m_sk, int64_t m_sd, int64_t s_sb, int64_t s_sk,
+    int64_t s_sd, void *stream) {
+  using namespace aesmc;
+  if (!value || !loc || !scale || !grad_out || B < 0 || K < 0 || D < 0) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!grad_value && !grad_loc && !grad_scale) return AESMC_OK;
+  if (B == 0 || K == 0 || D == 0) return AESMC_OK;
+  if (K >= (1ll << 31) || D >= (1ll << 31) || B >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
+  Strides3 sv{v_sb, v_sk, v_sd}, sm{m_sb, m_sk, m_sd}, ss{s_sb, s_sk, s_sd};
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AESMC_F32)
+    return launch_lps_bwd<float>(value, loc, scale, grad_out, grad_value, grad_loc, grad_scale, B, K, D,
+                                 sv, sm, ss, s);
+  if (dtype == AESMC_F64)
+    return launch_lps_bwd<double>(value, loc, scale, grad_out, grad_value, grad_loc, grad_scale, B, K, D,
+                                  sv, sm, ss, s);
+  return AESMC_ERR_INVALID_ARGUMENT;
+}

@@ -1,0 +1,181 @@
+"""hipGraph capture of a whole ELBO evaluation.
+
+At small per-step sizes (BASELINE.json configs[1]: 23 MB per gather) every kernel of the timestep
+loop runs for 5-10 us while the Python host needs ~10 us to issue each one, so the eager loop is
+host-bound.  `GraphedLoss` records one complete `losses.get_loss` — all T timesteps: the user's
+callables, the K1-K4 kernels, the uniform upload, optionally `loss.backward()` — into a single
+hipGraph (torch.cuda.CUDAGraph on ROCm) and replays it with one launch.
+
+What stays faithful to the eager path
+  * numpy's global RandomState is consumed exactly as before: T-1 blocks of
+    `np.random.uniform(size=[batch_size, 1])` per evaluation, drawn on the host just before the
+    replay and uploaded by one async copy ahead of it;
+  * torch's generator advances per replay (PyTorch registers the philox offset with the graph);
+  * the device status word (NaN log-weights, degenerate rows, ...) is read after the replay and
+    raises the same exceptions as `inference.infer`.
+
+Requirements on the model (they hold for any capture): callables must not synchronise with the
+host (construct distributions with validate_args=False and tensor — not Python-number —
+parameters, no .item()/.cpu() inside), shapes are fixed, parameters and observations stay at the
+same addresses (update them in place).  With backward=True no autograd graph built EAGERLY from the
+same parameters may still be alive when the capture starts (drop earlier `loss` tensors): PyTorch
+would reuse that graph's gradient accumulators, which are bound to the eager stream, and the
+capture could not be closed.
+"""
+import contextlib
+import gc
+
+import torch
+import torch.distributed as dist
+
+from . import _kernels
+from . import distributed
+from . import inference
+
+
+class _StaticUniformFeed:
+    """Uniform feed whose pinned host block [T-1, B] and device block live as long as the graph;
+    the graph's resampling kernels read rows of the device block."""
+
+    def __init__(self, batch_size, num_draws, device):
+        self.batch_size = batch_size
+        self.num_draws = max(num_draws, 1)
+        self.host = torch.empty((self.num_draws, batch_size), dtype=torch.float64, pin_memory=True)
+        self.dev = torch.empty((self.num_draws, batch_size), dtype=torch.float64, device=device)
+        self.cursor = 0
+
+    def refill(self):
+        """Draws this evaluation's blocks in timestep order (the eager loop's RNG consumption)."""
+        for step in range(self.num_draws):
+            self.host[step].copy_(torch.from_numpy(inference.draw_uniform_block(self.batch_size)))
+
+    def begin(self):
+        self.cursor = 0
+
+    def upload(self):
+        """Host -> device copy of the whole block, issued OUTSIDE the graph before each replay (a
+        pinned-memory copy node inside a capture trips the host allocator's event tracking)."""
+        self.dev.copy_(self.host, non_blocking=True)
+
+    def next(self):
+        row = self.dev[self.cursor]
+        self.cursor += 1
+        return row
+
+
+class GraphedLoss:
+    """One hipGraph holding `losses.get_loss(observations, num_particles, algorithm, ...)` and,
+    with backward=True, `loss.backward()` for the parameters of the four model parts.
+
+        graphed = GraphedLoss(observations, K, 'aesmc', initial, transition, emission, proposal,
+                              backward=True)
+        for batch in data:
+            loss = graphed(batch)        # copies `batch` into the static inputs, replays
+            optimizer.step()             # .grad tensors are static and refreshed by every replay
+    """
+
+    def __init__(self, observations, num_particles, algorithm, initial, transition, emission,
+                 proposal, backward=False, warmup=2, check_flags=True, shard=None, group=None):
+        """`shard=(global_batch_size, rank, world_size)`: `observations` are this rank's rows of a
+        batch sharded over the process group; the graph then holds the LOCAL share
+        -sum_local(log Z_b) / global_batch_size (and its backward) and every call finishes with
+        the one all-reduce of the loss (gradients: `distributed.all_reduce_gradients`)."""
+        first = observations[0]
+        self.shard = shard
+        self.group = group
+        self.global_batch = shard[0] if shard else first.size(0)
+        if isinstance(first, dict):
+            raise TypeError("GraphedLoss needs tensor observations (fixed addresses)")
+        self.device = first.device
+        if self.device.type != "cuda":
+            raise RuntimeError("aesmc_amd: GraphedLoss captures a hipGraph and needs a HIP device, "
+                               "got {}".format(self.device))
+        self.static_observations = [obs.clone() for obs in observations]
+        self.check_flags = check_flags
+        self.backward = backward
+        self._args = (num_particles, algorithm, initial, transition, emission, proposal)
+        self.parameters = []
+        if backward:
+            for part in (initial, transition, emission, proposal):
+                owner = getattr(part, "__self__", part)   # bound method of an nn.Module, or a Module
+                if isinstance(owner, torch.nn.Module):
+                    for p in owner.parameters():
+                        if p.requires_grad and all(p is not q for q in self.parameters):
+                            self.parameters.append(p)
+        num_timesteps = len(observations)
+        self.feed = _StaticUniformFeed(first.size(0), num_timesteps - 1, self.device) \
+            if algorithm == "aesmc" and num_timesteps > 1 else None
+
+        kernels = _kernels.get()
+        kernels.flags(self.device)                       # allocate the status word before capture
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                    # warm-up on a side stream, as PyTorch asks
+            for _ in range(warmup):
+                self._evaluate(refill=True)
+                if backward:
+                    for p in self.parameters:
+                        p.grad = None
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        inference._raise_for_flags(kernels.read_flags(self.device))
+        if backward:
+            for p in self.parameters:                    # capture allocates fresh static .grad
+                p.grad = None
+        gc.collect()                                     # drop dead eager autograd graphs first
+        self.graph = torch.cuda.CUDAGraph()
+        self._refill()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._evaluate(refill=False)
+        self.replays = 0
+        self._done = None
+
+    def _shard_scope(self):
+        return distributed.shard_scope(*self.shard) if self.shard else contextlib.nullcontext()
+
+    def _refill(self):
+        if self.feed is not None:
+            with self._shard_scope():
+                self.feed.refill()
+            self.feed.upload()
+
+    def _evaluate(self, refill):
+        num_particles, algorithm, initial, transition, emission, proposal = self._args
+        if refill:
+            self._refill()
+        if self.feed is not None:
+            self.feed.begin()
+        previous, inference._FEED_OVERRIDE = inference._FEED_OVERRIDE, self.feed
+        try:
+            result = inference.infer(
+                {"iwae": "is", "aesmc": "smc"}[algorithm], self.static_observations, initial,
+                transition, emission, proposal, num_particles, return_log_marginal_likelihood=True,
+                return_latents=False, return_log_weight=False)
+            # == losses.get_loss when unsharded: -mean_b(log Z_b)
+            loss = -torch.sum(result["log_marginal_likelihood"]) / self.global_batch
+            if self.backward:
+                loss.backward()
+        finally:
+            inference._FEED_OVERRIDE = previous
+        return loss.detach()
+
+    def __call__(self, observations=None):
+        """Replays the graph (after copying `observations`, if given, into the static inputs) and
+        returns the static loss tensor; parameter gradients, when captured, are in `.grad`."""
+        if observations is not None:
+            for static, fresh in zip(self.static_observations, observations):
+                static.copy_(fresh, non_blocking=True)
+        if self._done is not None:
+            self._done.synchronize()   # the previous replay must have consumed the pinned uniforms
+        self._refill()
+        self.graph.replay()
+        self._done = torch.cuda.Event()
+        self._done.record(torch.cuda.current_stream(self.device))
+        self.replays += 1
+        if self.check_flags:
+            inference._raise_for_flags(_kernels.get().read_flags(self.device))
+        if self.shard and self.shard[2] > 1:
+            total = self.static_loss.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+            return total
+        return self.static_loss

@@ -73,21 +73,30 @@ class _UniformFeed:
             self.host = self.dev = None
 
     def next(self):
-        from . import distributed
-        shard = distributed.active_shard()
-        if shard is None:
-            draw = np.random.uniform(size=[self.batch_size, 1])
-        else:  # batch-sharded run: consume the global block, keep this rank's rows
-            global_batch, lo, hi = shard
-            draw = np.random.uniform(size=[global_batch, 1])[lo:hi]
-            assert draw.shape[0] == self.batch_size, "shard_scope does not match the local batch"
+        draw = draw_uniform_block(self.batch_size)
         if self.host is None:
-            return torch.from_numpy(draw.reshape(-1))
+            return torch.from_numpy(draw)
         slot = self.cursor % self.host.size(0)
         self.cursor += 1
-        self.host[slot].copy_(torch.from_numpy(draw.reshape(-1)))
+        self.host[slot].copy_(torch.from_numpy(draw))
         self.dev[slot].copy_(self.host[slot], non_blocking=True)
         return self.dev[slot]
+
+
+def draw_uniform_block(batch_size):
+    """One resampling step's uniforms, float64 [batch_size], consuming numpy's global RandomState
+    exactly as aesmc/inference.py:250 does (`np.random.uniform(size=[batch_size, 1])`); inside
+    `distributed.shard_scope` the block is drawn for the global batch and cut to this rank's rows."""
+    from . import distributed
+    shard = distributed.active_shard()
+    if shard is None:
+        return np.random.uniform(size=[batch_size, 1]).reshape(-1)
+    global_batch, lo, hi = shard
+    assert hi - lo == batch_size, "shard_scope does not match the local batch"
+    return np.random.uniform(size=[global_batch, 1])[lo:hi].reshape(-1)
+
+
+_FEED_OVERRIDE = None  # set by graphs.GraphedLoss while it captures: a feed with static buffers
 
 
 def _raise_for_flags(flags):
@@ -183,7 +192,8 @@ def infer(inference_algorithm, observations, initial, transition, emission,
             if use_smc:
                 previous = log_weights[-1]
                 if feed is None:
-                    feed = _UniformFeed(batch_size, num_timesteps - 1, previous.device)
+                    feed = _FEED_OVERRIDE if _FEED_OVERRIDE is not None else \
+                        _UniformFeed(batch_size, num_timesteps - 1, previous.device)
                 index = _ops.ancestor_index(previous, feed.next())
                 indices.append(index)
                 if _HISTORY_MODE == "lazy":
@@ -239,7 +249,8 @@ def infer(inference_algorithm, observations, initial, transition, emission,
         if not return_log_weight:
             log_weight = None
 
-    if device is not None:
+    capturing = device is not None and device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if device is not None and not capturing:  # under hipGraph capture the replayer checks instead
         _raise_for_flags(_kernels.get().read_flags(device))
 
     return {"log_marginal_likelihood": log_marginal_likelihood,

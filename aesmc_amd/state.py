@@ -151,15 +151,64 @@ def log_prob(distribution, value):
         raise AttributeError("distribution must be a dict or a torch.distributions.Distribution. "
                              "Got: {}".format(distribution))
     missing = (value.dim() - len(distribution.event_shape)) - len(distribution.batch_shape)
-    if missing == 0 or missing == 2:
-        _validate_sample(distribution, value)
-        logp = distribution.log_prob(value)
-    elif missing == 1:
-        logp = distribution.log_prob(value.transpose(0, 1)).transpose(0, 1)
-    else:
+    if missing not in (0, 1, 2):
         raise RuntimeError("Incompatible distribution.batch_shape ({}) and value.shape ({}).".format(
             distribution.batch_shape, value.shape))
+    if missing != 1:
+        _validate_sample(distribution, value)
+    fused = _fused_normal_views(distribution, value, missing) if _FUSED_NORMAL else None
+    if fused is not None:
+        if missing == 1 and distribution._validate_args:  # what Normal.log_prob itself would check
+            _validate_sample(distribution, value.transpose(0, 1))
+        return _ops.normal_log_prob_sum(value, *fused)
+    if missing == 1:
+        logp = distribution.log_prob(value.transpose(0, 1)).transpose(0, 1)
+    else:
+        logp = distribution.log_prob(value)
     return logp.reshape(value.size(0), value.size(1), -1).sum(dim=2)
+
+
+_FUSED_NORMAL = True
+
+
+def set_fused_normal(enabled):
+    """Switches the fused Normal log-density (kernel K4) inside `log_prob` on (default) or off;
+    off evaluates `distribution.log_prob` in eager PyTorch exactly as the reference does."""
+    global _FUSED_NORMAL
+    _FUSED_NORMAL = bool(enabled)
+
+
+def _fused_normal_views(distribution, value, missing):
+    """(loc, scale) as views of value's shape if `distribution` is a plain Normal (optionally
+    wrapped in Independent) that kernel K4 can evaluate on `value`; None sends the caller down
+    the generic path.  `missing` leading batch dims are filled in as broadcast (stride-0) dims:
+    two in front (NOT_EXPANDED) or the particle dim (BATCH_EXPANDED, where the reference
+    transposes instead, state.py:144-145)."""
+    base = distribution
+    if type(base) is torch.distributions.Independent:
+        base = base.base_dist
+    if type(base) is not torch.distributions.Normal:
+        return None
+    if not (torch.is_tensor(value) and value.is_cuda and value.dim() >= 2 and
+            value.dtype in (torch.float32, torch.float64)):
+        return None
+    views = []
+    for param in (base.loc, base.scale):
+        if param.dtype != value.dtype:
+            return None
+        if param.device != value.device:
+            if param.numel() != 1:
+                return None
+            param = param.to(value.device)  # Normal(0.0, 1.0): Python-number parameters live on the host
+        if missing == 1:
+            if param.dim() == 0:
+                return None
+            param = param.unsqueeze(1)
+        try:
+            views.append(param.expand(value.shape))
+        except RuntimeError:
+            return None
+    return views
 
 
 def resample(value, ancestral_index):

@@ -127,9 +127,11 @@ class LgssmNd(nn.Module):
         eye = torch.eye(dim, dtype=torch.float64)
         self.dim = dim
         self._state = state
-        self.transition_scale = transition_scale
-        self.emission_scale = emission_scale
-        self.proposal_scale = proposal_scale
+        # scales are device buffers, not Python numbers: Normal(loc, 0.7) would upload the scalar on
+        # every call (a host-to-device copy, which also cannot be captured into a hipGraph)
+        self.register_buffer("transition_scale", torch.tensor(transition_scale, dtype=dtype))
+        self.register_buffer("emission_scale", torch.tensor(emission_scale, dtype=dtype))
+        self.register_buffer("proposal_scale", torch.tensor(proposal_scale, dtype=dtype))
         g1 = torch.randn(dim, dim, generator=gen, dtype=torch.float64)
         g2 = torch.randn(dim, dim, generator=gen, dtype=torch.float64)
         self.A = nn.Parameter((0.9 * eye + 0.01 * g1).to(dtype))
@@ -200,9 +202,11 @@ class NonlinearSsm(nn.Module):
         eye = torch.eye(dim, dtype=torch.float64)
         self.dim = dim
         self._state = state
-        self.transition_scale = transition_scale
-        self.emission_scale = emission_scale
-        self.proposal_scale = proposal_scale
+        # scales are device buffers, not Python numbers: Normal(loc, 0.7) would upload the scalar on
+        # every call (a host-to-device copy, which also cannot be captured into a hipGraph)
+        self.register_buffer("transition_scale", torch.tensor(transition_scale, dtype=dtype))
+        self.register_buffer("emission_scale", torch.tensor(emission_scale, dtype=dtype))
+        self.register_buffer("proposal_scale", torch.tensor(proposal_scale, dtype=dtype))
         self.A = nn.Parameter((0.9 * eye + 0.05 * torch.randn(dim, dim, generator=gen,
                                                               dtype=torch.float64)).to(dtype))
         self.C = nn.Parameter((eye + 0.01 * torch.randn(dim, dim, generator=gen,
@@ -262,8 +266,8 @@ def kalman_log_likelihood(model, observations):
     A = model.A.detach().double().cpu().numpy()
     C = model.C.detach().double().cpu().numpy()
     d = A.shape[0]
-    Q = np.eye(d) * model.transition_scale ** 2
-    R = np.eye(d) * model.emission_scale ** 2
+    Q = np.eye(d) * float(model.transition_scale) ** 2
+    R = np.eye(d) * float(model.emission_scale) ** 2
     ys = [y.detach().double().cpu().numpy() for y in observations]
     batch = ys[0].shape[0]
     out = np.zeros(batch)

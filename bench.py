@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-backward", action="store_true")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+                    help="graph: replay the whole ELBO as one hipGraph (aesmc_amd.graphs); eager: Python loop")
     return ap.parse_args()
 
 
@@ -156,28 +158,70 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n, backward=False):
+    def timed(fn, n):
+        """n calls of fn between barrier + synchronize on both sides; max over ranks."""
         barrier()
         t0 = time.perf_counter()
         for _ in range(n):
-            loss = step(backward)
+            loss = fn()
         barrier()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return float(dt.item()), float(loss.detach())
 
+    # ---- the step: one hipGraph replay of the whole ELBO (default) or the eager Python loop ------
+    shard = (global_B, rank, world) if world > 1 else None
+    mode, graph_error, graphed = "eager", None, None
+    if args.mode == "graph":
+        try:
+            from aesmc_amd import graphs
+            with grad_mode():
+                graphed = graphs.GraphedLoss(observations, K, "aesmc", *parts, shard=shard)
+            mode = "hipgraph"
+        except Exception as error:  # capture is an optimisation: report and fall back to eager
+            graph_error = "{}: {}".format(type(error).__name__, error)
+            torch.cuda.synchronize()
+    forward = graphed if graphed is not None else step
+
     for _ in range(args.warmup):
-        step()
-    seconds, loss = timed(args.steps)
+        forward()
+    seconds, loss = timed(forward, args.steps)
     ms_per_step = 1e3 * seconds / args.steps
     value = global_B * K * T * args.steps / seconds
 
+    eager_value = None
+    if graphed is not None:  # the eager loop beside it, for the record
+        step()
+        n = max(1, args.steps // 2)
+        se, _ = timed(step, n)
+        eager_value = global_B * K * T * n / se
+
     fwd_bwd = None
     if not args.no_backward:
-        step(backward=True)
-        sb, _ = timed(max(1, args.steps // 2), backward=True)
-        fwd_bwd = global_B * K * T * max(1, args.steps // 2) / sb
+        n = max(1, args.steps // 2)
+        train_step = None
+        if graphed is not None:
+            try:
+                from aesmc_amd import graphs
+                graphed_train = graphs.GraphedLoss(observations, K, "aesmc", *parts, backward=True, shard=shard)
+                params = list(model.parameters())
+
+                def train_step():
+                    out = graphed_train()
+                    if world > 1:
+                        distributed.all_reduce_gradients(params)
+                    return out
+            except Exception as error:
+                graph_error = "backward capture: {}: {}".format(type(error).__name__, error)
+                torch.cuda.synchronize()
+                train_step = None
+        if train_step is None:
+            def train_step():
+                return step(backward=True)
+        train_step()
+        sb, _ = timed(train_step, n)
+        fwd_bwd = global_B * K * T * n / sb
 
     # ---- per-kernel timing: the same steps again with HIP events around every launch ------------
     provider.timer = _kernels.KernelTimer()
@@ -209,8 +253,11 @@ def main():
                    "global_batch": global_B, "num_particles": K, "num_timesteps": T, "state_dim": dim,
                    "parallelism": "batch-shard x{} (one RCCL all-reduce of sum log Z per ELBO)".format(world),
                    "step": "one forward SMC ELBO, get_loss(..., 'aesmc'), " +
-                           ("torch.no_grad()" if args.workload in FORWARD_ONLY else "autograd graph recorded")},
+                           ("torch.no_grad()" if args.workload in FORWARD_ONLY else "autograd graph recorded") +
+                           (", all T timesteps replayed as one hipGraph" if mode == "hipgraph" else ", eager Python loop")},
         "loss": loss,
+        "mode": mode, "graph_error": graph_error,
+        "eager_particle_steps_per_sec": eager_value,
         "fwd_bwd_particle_steps_per_sec": fwd_bwd,
         "roofline": roofline,
         "kernels": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()}

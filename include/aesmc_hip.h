@@ -105,6 +105,34 @@ int aesmc_resample_gather_backward(int dtype, const void *grad_out, const int64_
                                    void *grad_src, int32_t *flags, int64_t B, int64_t K,
                                    int64_t row_elems, void *stream);
 
+/*
+ * K4 — summed Normal log-density:
+ *   out[b,k] = sum_{j<D} ( -((v-mu)^2) / (2 sigma^2) - log(sigma) - log(sqrt(2 pi)) )
+ * with v = value[b,k,j], mu = loc[b,k,j], sigma = scale[b,k,j]; each operand is a [B,K,D] VIEW given
+ * by its element strides (sb, sk, sd), 0 meaning broadcast along that dim.  out is dense [B,K].
+ * Replaces, inside aesmc/state.py:114-155 (`state.log_prob`), torch.distributions.Normal.log_prob
+ * followed by `.view(B, K, -1).sum(2)` (state.py:143-151) — about eleven launches per call —
+ * element arithmetic in PyTorch's own order.
+ */
+int aesmc_normal_logprob_sum(int dtype, const void *value, const void *loc, const void *scale,
+                             void *out, int64_t B, int64_t K, int64_t D, int64_t value_sb,
+                             int64_t value_sk, int64_t value_sd, int64_t loc_sb, int64_t loc_sk,
+                             int64_t loc_sd, int64_t scale_sb, int64_t scale_sk, int64_t scale_sd,
+                             void *stream);
+
+/*
+ * K4 backward.  grad_out dense [B,K]; each non-NULL grad_* is written densely [B,K,D]:
+ *   grad_value = -g z,  grad_loc = g z,  grad_scale = g ((v-mu)^2 / sigma^3 - 1/sigma),
+ *   z = (v-mu)/sigma^2.  Reduction over broadcast dims is left to the caller (autograd's expand).
+ */
+int aesmc_normal_logprob_sum_backward(int dtype, const void *value, const void *loc,
+                                      const void *scale, const void *grad_out, void *grad_value,
+                                      void *grad_loc, void *grad_scale, int64_t B, int64_t K,
+                                      int64_t D, int64_t value_sb, int64_t value_sk, int64_t value_sd,
+                                      int64_t loc_sb, int64_t loc_sk, int64_t loc_sd,
+                                      int64_t scale_sb, int64_t scale_sk, int64_t scale_sd,
+                                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

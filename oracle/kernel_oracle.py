@@ -95,6 +95,34 @@ def ancestor_index_reference_dtype(log_w, u):
     return idx
 
 
+def normal_logprob_sum(value, loc, scale):
+    """K4: torch.distributions.Normal(loc, scale).log_prob(value) in PyTorch's operation order
+    (normal.py log_prob: -((v - mu)**2) / (2 * var) - log(scale) - log(sqrt(2 pi))), summed over
+    all dims past the first two as aesmc/state.py:151 does.  loc / scale broadcast to value."""
+    value = np.asarray(value)
+    dtype = value.dtype
+    loc = np.broadcast_to(np.asarray(loc, dtype=dtype), value.shape)
+    scale = np.broadcast_to(np.asarray(scale, dtype=dtype), value.shape)
+    diff = value - loc
+    var = scale * scale
+    with np.errstate(all="ignore"):
+        logp = (-(diff * diff)) / (dtype.type(2) * var) - np.log(scale) - dtype.type(0.9189385332046727)
+    return logp.reshape(value.shape[0], value.shape[1], -1).sum(axis=2, dtype=dtype)
+
+
+def normal_logprob_sum_backward(value, loc, scale, grad_out):
+    """K4 backward: dense gradients (d/dvalue, d/dloc, d/dscale), each of value's shape."""
+    value = np.asarray(value)
+    dtype = value.dtype
+    loc = np.broadcast_to(np.asarray(loc, dtype=dtype), value.shape)
+    scale = np.broadcast_to(np.asarray(scale, dtype=dtype), value.shape)
+    g = np.asarray(grad_out, dtype=dtype).reshape(value.shape[:2] + (1,) * (value.ndim - 2))
+    diff = value - loc
+    var = scale * scale
+    gz = g * (diff / var)
+    return -gz, gz, g * ((diff * diff) / (var * scale) - dtype.type(1) / scale)
+
+
 def gather(src, idx):
     """K3: dst[b,k,...] = src[b, idx[b,k], ...] (torch.gather of aesmc/state.py:179).  Indices
     outside [0,K) are clamped and reported.  Returns (dst, flags)."""

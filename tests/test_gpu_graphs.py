@@ -1,0 +1,99 @@
+"""GPU tests of aesmc_amd.graphs.GraphedLoss: a whole SMC ELBO (forward, optionally backward)
+replayed as one hipGraph must reproduce the eager path draw for draw."""
+import numpy as np
+import pytest
+import torch
+
+from aesmc_amd import graphs, losses
+from aesmc_amd.testing import models
+
+pytestmark = pytest.mark.gpu
+
+
+def make(hip_device, dtype=torch.float32, d=3, B=8, T=6):
+    model = models.LgssmNd(d, seed=0, dtype=dtype, validate_args=False).to(hip_device)
+    observations = model.simulate(T, B, seed=1)
+    parts = (model.initial, model.transition, model.emission, model.proposal)
+    return model, observations, parts
+
+
+def seed(value):
+    torch.manual_seed(value)
+    np.random.seed(value)
+
+
+@pytest.mark.parametrize("algorithm", ["aesmc", "iwae"])
+def test_graphed_forward_backward_equals_eager(hip_device, algorithm):
+    model, observations, parts = make(hip_device, dtype=torch.float64)
+    K = 64
+    seed(11)
+    eager_loss = losses.get_loss(observations, K, algorithm, *parts)
+    eager_loss.backward()
+    eager = eager_loss.detach().clone()
+    del eager_loss   # a live eager autograd graph of these parameters would poison a backward capture
+    eager_grads = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+
+    graphed = graphs.GraphedLoss(observations, K, algorithm, *parts, backward=True)
+    seed(11)
+    loss = graphed()
+    torch.testing.assert_close(loss, eager, rtol=1e-12, atol=1e-12)
+    for p, want in zip(model.parameters(), eager_grads):
+        torch.testing.assert_close(p.grad, want, rtol=1e-9, atol=1e-11)
+
+    # a replay is a fresh evaluation: new draws, gradients refreshed (not accumulated)
+    first = loss.clone()
+    again = graphed().clone()
+    assert float((again - first).abs()) > 0
+    seed(11)
+    third = graphed()
+    torch.testing.assert_close(third, first, rtol=1e-12, atol=1e-12)
+    for p, want in zip(model.parameters(), eager_grads):
+        torch.testing.assert_close(p.grad, want, rtol=1e-9, atol=1e-11)
+
+    # new observations are copied into the static inputs
+    other = model.simulate(len(observations), observations[0].size(0), seed=5)
+    seed(3)
+    with torch.no_grad():
+        want = losses.get_loss(other, K, algorithm, *parts)
+    seed(3)
+    torch.testing.assert_close(graphed(other), want, rtol=1e-12, atol=1e-12)
+
+
+def test_graphed_forward_only_float32(hip_device):
+    model, observations, parts = make(hip_device, d=10, B=16, T=8)
+    seed(2)
+    with torch.no_grad():
+        eager = losses.get_loss(observations, 128, "aesmc", *parts)
+    graphed = graphs.GraphedLoss(observations, 128, "aesmc", *parts)
+    seed(2)
+    torch.testing.assert_close(graphed(), eager, rtol=1e-6, atol=1e-6)
+    assert graphed.replays == 1
+
+
+def test_graphed_loss_raises_deferred_errors(hip_device):
+    from aesmc_amd import state
+    model, observations, parts = make(hip_device)
+    scale = torch.ones((), device=hip_device)
+
+    def emission(latents=None, time=None, previous_observations=None):
+        dist = model.emission(latents=latents, time=time)
+        return state.set_batch_shape_mode(
+            torch.distributions.Normal(dist.loc * scale, dist.scale, validate_args=False),
+            state.BatchShapeMode.FULLY_EXPANDED)
+
+    graphed = graphs.GraphedLoss(observations, 16, "aesmc", model.initial, model.transition, emission,
+                                 model.proposal)
+    graphed()
+    scale.fill_(float("nan"))          # poison an input the graph reads
+    with pytest.raises(FloatingPointError):
+        graphed()
+    scale.fill_(1.0)
+    assert bool(torch.isfinite(graphed()))
+
+
+def test_graphed_loss_needs_hip_device():
+    model = models.LgssmNd(2)
+    with pytest.raises(RuntimeError):
+        graphs.GraphedLoss(model.simulate(3, 2), 4, "aesmc", model.initial, model.transition,
+                           model.emission, model.proposal)

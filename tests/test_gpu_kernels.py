@@ -289,3 +289,87 @@ def test_full_size_logweight_lse(kernels, hip_device):
     # shift invariance: lse(x + s) == lse(x) + s
     _, shifted = kernels.logweight_lse(lw + 3.0)
     assert float((shifted - (lse + 3.0)).abs().max()) < 1e-5
+
+
+# ---- K4 ------------------------------------------------------------------------------------------
+def _normal_case(rng, shape, dtype, loc_kind, scale_kind, device):
+    """value plus loc / scale given as tensors of the shapes the three BatchShapeModes produce."""
+    B, K = shape[:2]
+    trail = shape[2:]
+    value = torch.from_numpy(rng.randn(*shape).astype(dtype)).to(device)
+    loc_shape = {"full": shape, "batch": (B, 1) + trail, "none": trail, "scalar": ()}[loc_kind]
+    scale_shape = {"full": shape, "batch": (B, 1) + trail, "none": trail, "scalar": ()}[scale_kind]
+    loc = torch.from_numpy(np.asarray(rng.randn(*loc_shape)).astype(dtype)).to(device)
+    scale = torch.from_numpy(np.asarray(0.3 + rng.rand(*scale_shape)).astype(dtype)).to(device)
+    return value, loc, scale
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(2, 16), (3, 7, 1), (4, 100, 10), (2, 33, 3, 5), (2, 50, 64), (2, 9, 65),
+                                   (3, 20, 128), (1, 1, 4), (2, 300, 16), (2, 64, 32)])
+@pytest.mark.parametrize("loc_kind,scale_kind", [("full", "scalar"), ("full", "full"), ("batch", "none"),
+                                                 ("none", "scalar"), ("scalar", "batch")])
+def test_normal_logprob_sum_matches_oracle_and_torch(kernels, hip_device, dtype, shape, loc_kind, scale_kind):
+    rng = np.random.RandomState(len(shape) * 7 + shape[1])
+    value, loc, scale = _normal_case(rng, shape, dtype, loc_kind, scale_kind, hip_device)
+    got = kernels.normal_logprob_sum(value, loc.expand(shape), scale.expand(shape)).cpu().numpy()
+    want = kernel_oracle.normal_logprob_sum(value.cpu().numpy(), loc.cpu().numpy(), scale.cpu().numpy())
+    eager = torch.distributions.Normal(loc, scale).log_prob(value).reshape(shape[0], shape[1], -1).sum(2)
+    D = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+    rtol = (4e-6 if dtype == np.float32 else 1e-13) * max(1, D) ** 0.5
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * D)
+    np.testing.assert_allclose(got, eager.cpu().numpy(), rtol=rtol, atol=rtol * D)
+    if D == 1:  # no reduction: element arithmetic is PyTorch's own order, bit for bit
+        np.testing.assert_array_equal(got, eager.cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(2, 16), (4, 100, 10), (2, 33, 3, 5), (2, 9, 65), (3, 20, 128)])
+@pytest.mark.parametrize("loc_kind,scale_kind", [("full", "scalar"), ("full", "full"), ("batch", "none")])
+def test_normal_logprob_sum_backward_matches_oracle(kernels, hip_device, dtype, shape, loc_kind, scale_kind):
+    rng = np.random.RandomState(shape[1])
+    value, loc, scale = _normal_case(rng, shape, dtype, loc_kind, scale_kind, hip_device)
+    go = torch.from_numpy(rng.randn(*shape[:2]).astype(dtype)).to(hip_device)
+    got = kernels.normal_logprob_sum_backward(value, loc.expand(shape), scale.expand(shape), go, True, True, True)
+    want = kernel_oracle.normal_logprob_sum_backward(value.cpu().numpy(), loc.cpu().numpy(),
+                                                     scale.cpu().numpy(), go.cpu().numpy())
+    rtol = 1e-5 if dtype == np.float32 else 1e-12
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g.cpu().numpy(), w, rtol=rtol, atol=rtol)
+    only_loc = kernels.normal_logprob_sum_backward(value, loc.expand(shape), scale.expand(shape), go,
+                                                   False, True, False)
+    assert only_loc[0] is None and only_loc[2] is None
+    np.testing.assert_array_equal(only_loc[1].cpu().numpy(), got[1].cpu().numpy())
+
+
+def test_normal_logprob_sum_strided_views(kernels, hip_device):
+    """Operands as the SMC loop really produces them: transposed time-0 latent, observation
+    expanded over particles, per-dimension scale vector."""
+    B, K, d = 4, 37, 10
+    gen = torch.Generator(device=hip_device).manual_seed(0)
+    latent = torch.randn(K, B, d, device=hip_device, generator=gen).transpose(0, 1)     # state.py:102-103
+    loc_b = torch.randn(B, d, device=hip_device, generator=gen)
+    obs = torch.randn(B, d, device=hip_device, generator=gen).unsqueeze(1).expand(B, K, d)  # state.py:202
+    loc_full = torch.randn(B, K, d, device=hip_device, generator=gen)
+    scale_vec = 0.5 + torch.rand(d, device=hip_device, generator=gen)
+    for value, loc, scale in [(latent, loc_b.unsqueeze(1), torch.tensor(0.7, device=hip_device)),
+                              (obs, loc_full, scale_vec), (loc_full[:, ::2], loc_full[:, 1::2], scale_vec)]:
+        shape = value.shape
+        got = kernels.normal_logprob_sum(value, loc.expand(shape), scale.expand(shape))
+        want = torch.distributions.Normal(loc, scale).log_prob(value).sum(-1)
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
+def test_full_size_normal_logprob_sum(kernels, hip_device):
+    """North-star shape: B=1024, K=4096, d=10."""
+    B, K, d = 1024, 4096, 10
+    gen = torch.Generator(device=hip_device).manual_seed(3)
+    value = torch.randn(B, K, d, device=hip_device, generator=gen)
+    loc = torch.randn(B, K, d, device=hip_device, generator=gen)
+    scale = torch.tensor(0.7, device=hip_device)
+    got = kernels.normal_logprob_sum(value, loc, scale.expand(value.shape))
+    want = torch.distributions.Normal(loc, scale).log_prob(value).sum(-1)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-4)
+    # linearity in the scale: log N(v; mu, s) summed == -d log s + log N((v - mu)/s; 0, 1) summed
+    unit = kernels.normal_logprob_sum((value - loc) / 0.7, torch.zeros_like(loc), torch.ones_like(loc))
+    torch.testing.assert_close(got, unit - d * float(np.log(0.7)), rtol=1e-5, atol=1e-4)

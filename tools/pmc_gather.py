@@ -1,0 +1,31 @@
+"""Workload for the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one counter per
+run): launches K3 on known operands so HBM traffic per launch can be read off the counters.
+
+Order of resample_gather launches (3 each): for shape in (c2, c4):
+  calibration: identity index (every source row read exactly once: bytes known exactly)
+  workload   : systematic-resampling indices from log-weights ~ N(0,1)   (ESS/K ~ 0.37)
+  degenerate : indices from log-weights ~ 5 N(0,1)                        (few survivors)
+"""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aesmc_amd import _kernels
+
+k = _kernels.get()
+dev = torch.device("cuda", 0)
+gen = torch.Generator(device=dev).manual_seed(0)
+for (B, K, d) in [(256, 1024, 10), (1024, 4096, 10)]:
+    value = torch.randn(B, K, d, device=dev, generator=gen)
+    u = torch.rand(B, device=dev, dtype=torch.float64, generator=gen)
+    identity = torch.arange(K, device=dev).unsqueeze(0).expand(B, K).contiguous()
+    idx1 = k.ancestor_index(torch.randn(B, K, device=dev, generator=gen), u)
+    idx5 = k.ancestor_index(5 * torch.randn(B, K, device=dev, generator=gen), u)
+    torch.cuda.synchronize()
+    for idx in (identity, idx1, idx5):
+        for _ in range(3):
+            k.gather(value, idx)
+        torch.cuda.synchronize()
+    uniq1 = float((idx1[:, 1:] != idx1[:, :-1]).sum() + B) / (B * K)
+    uniq5 = float((idx5[:, 1:] != idx5[:, :-1]).sum() + B) / (B * K)
+    print("shape", (B, K, d), "unique-ancestor fraction: s=1 %.3f, s=5 %.3f" % (uniq1, uniq5))
