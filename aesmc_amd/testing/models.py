@@ -260,6 +260,48 @@ class NonlinearSsm(nn.Module):
         return observations
 
 
+class GaussianIwae(nn.Module):
+    """The one-step Gaussian model above bundled as one module (config 3 of BASELINE.json: IWAE,
+    T = 1, no resampling): x ~ N(mean, 1), y ~ N(x, obs_std), q(x | y) = N(mult y + bias, q_std).
+    `transition` is None, as in the reference's test/test_losses.py:45."""
+
+    transition = None
+
+    def __init__(self, prior_mean=0.3, obs_std=0.8, q_mult=0.6, q_bias=0.1, q_std=0.9,
+                 dtype=torch.float32, state=_default_state, validate_args=None, **_):
+        super().__init__()
+        self._state = state
+        self.validate_args = validate_args
+        self.mean = nn.Parameter(torch.tensor(prior_mean, dtype=dtype))
+        self.register_buffer("prior_std", torch.tensor(1.0, dtype=dtype))
+        self.obs_log_std = nn.Parameter(torch.log(torch.tensor(obs_std, dtype=dtype)))
+        self.q_mult = nn.Parameter(torch.tensor(q_mult, dtype=dtype))
+        self.q_bias = nn.Parameter(torch.tensor(q_bias, dtype=dtype))
+        self.q_log_std = nn.Parameter(torch.log(torch.tensor(q_std, dtype=dtype)))
+
+    def _normal(self, loc, scale, mode_name):
+        dist = torch.distributions.Normal(loc, scale, validate_args=self.validate_args)
+        return self._state.set_batch_shape_mode(dist, getattr(self._state.BatchShapeMode, mode_name))
+
+    def initial(self):
+        return self._normal(self.mean, self.prior_std, "NOT_EXPANDED")
+
+    def emission(self, latents=None, time=None, previous_observations=None):
+        return self._normal(latents[-1], torch.exp(self.obs_log_std), "FULLY_EXPANDED")
+
+    def proposal(self, previous_latents=None, time=None, observations=None):
+        return self._normal(self.q_mult * observations[0] + self.q_bias, torch.exp(self.q_log_std),
+                            "BATCH_EXPANDED")
+
+    @torch.no_grad()
+    def simulate(self, num_timesteps, batch_size, seed=0):
+        gen = torch.Generator().manual_seed(seed)
+        device, dtype = self.mean.device, self.mean.dtype
+        x = self.mean + torch.randn(batch_size, generator=gen, dtype=torch.float64).to(device, dtype)
+        noise = torch.randn(batch_size, generator=gen, dtype=torch.float64).to(device, dtype)
+        return [x + torch.exp(self.obs_log_std) * noise]
+
+
 def kalman_log_likelihood(model, observations):
     """Exact log p(y_{1:T}) per batch row of an LgssmNd by the Kalman filter (float64, host):
     an independent statistical oracle — E[exp(log Z_hat)] of IS/SMC equals exp of this."""

@@ -31,9 +31,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-leve
 
 FORWARD_ONLY = {"c4", "c5"}  # autograd retention of T x (dozens of [B,K,d] temporaries) would exceed HBM
 
+ALGORITHM = {"c3": "iwae"}  # every other workload is the SMC ELBO ('aesmc')
+
 # name: (description, model kind, d, per-GPU B, K, T)
 WORKLOADS = {
     "c2": ("LGSSM d=10 B=256 K=1024 T=50, SMC ELBO (configs[1])", "lgssm", 10, 256, 1024, 50),
+    "c3": ("one-step Gaussian IWAE d=1 B=4096 K=8192 T=1, no resampling (configs[2])", "gaussian", 1, 4096, 8192, 1),
     "c4": ("LGSSM d=10 B=1024 K=4096 T=100, SMC ELBO (north-star target shape)", "lgssm", 10, 1024, 4096, 100),
     "c4s": ("LGSSM d=10 B=128 K=4096 T=100, SMC ELBO (one GPU's shard of c4 at 8 GPUs)", "lgssm", 10, 128, 4096, 100),
     "c4nl": ("nonlinear SSM + MLP proposal d=10 B=128 K=4096 T=100 (configs[3] per-GPU shard)", "nonlinear", 10, 128, 4096, 100),
@@ -49,19 +52,21 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-backward", action="store_true")
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+    ap.add_argument("--mode", default=None, choices=["graph", "eager"],
                     help="graph: replay the whole ELBO as one hipGraph (aesmc_amd.graphs); eager: Python loop")
     return ap.parse_args()
 
 
 def build_model(kind, dim, device, state):
     from aesmc_amd.testing import models
-    cls = models.LgssmNd if kind == "lgssm" else models.NonlinearSsm
+    cls = {"lgssm": models.LgssmNd, "nonlinear": models.NonlinearSsm, "gaussian": models.GaussianIwae}[kind]
+    if kind == "gaussian":
+        return cls(state=state, validate_args=False).to(device)
     # validate_args=False: no per-call host sync inside torch.distributions (standard practice)
     return cls(dim, seed=0, state=state, validate_args=False).to(device)
 
 
-def cpu_baseline(kind, dim, B, K, T, budget_s=20.0):
+def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", budget_s=20.0):
     """The CPU port of the reference (oracle/reference_port.py) on a BOUNDED sample of the same
     workload: same model, K and d; batch rows (and, if still too slow, timesteps) are cut until a
     calibrated estimate fits `budget_s` seconds.  Threads: min(cores, 16) — PyTorch's default of
@@ -78,7 +83,7 @@ def cpu_baseline(kind, dim, B, K, T, budget_s=20.0):
         np.random.seed(0)
         torch.manual_seed(0)
         t0 = time.perf_counter()
-        loss = reference_port.get_loss(observations, K, "aesmc", *parts)
+        loss = reference_port.get_loss(observations, K, algorithm, *parts)
         return time.perf_counter() - t0, float(loss.detach())
 
     def cost(b, t):  # per-step work + O(T^2) history re-gather
@@ -122,6 +127,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     description, kind, dim, B, K, T = WORKLOADS[args.workload]
+    algorithm = ALGORITHM.get(args.workload, "aesmc")
     provider = _kernels.get()
     assert provider.name == "hip"
     model = build_model(kind, dim, device, aesmc_amd.state)
@@ -132,6 +138,8 @@ def main():
     np.random.seed(0)
     torch.manual_seed(0)
 
+    if args.mode is None:  # the big forward-only shapes are device-bound and need the HBM for data
+        args.mode = "eager" if args.workload in FORWARD_ONLY else "graph"
     grad_mode = torch.no_grad if args.workload in FORWARD_ONLY else torch.enable_grad
     if args.workload in FORWARD_ONLY:
         args.no_backward = True
@@ -142,10 +150,10 @@ def main():
 
     def _step(backward=False):
         if world > 1:
-            loss = distributed.sharded_get_loss(observations, K, "aesmc", *parts, global_batch_size=global_B,
+            loss = distributed.sharded_get_loss(observations, K, algorithm, *parts, global_batch_size=global_B,
                                                 rank=rank, world_size=world)
         else:
-            loss = aesmc_amd.losses.get_loss(observations, K, "aesmc", *parts)
+            loss = aesmc_amd.losses.get_loss(observations, K, algorithm, *parts)
         if backward:
             model.zero_grad(set_to_none=True)
             loss.backward()
@@ -177,7 +185,7 @@ def main():
         try:
             from aesmc_amd import graphs
             with grad_mode():
-                graphed = graphs.GraphedLoss(observations, K, "aesmc", *parts, shard=shard)
+                graphed = graphs.GraphedLoss(observations, K, algorithm, *parts, shard=shard)
             mode = "hipgraph"
         except Exception as error:  # capture is an optimisation: report and fall back to eager
             graph_error = "{}: {}".format(type(error).__name__, error)
@@ -204,7 +212,7 @@ def main():
         if graphed is not None:
             try:
                 from aesmc_amd import graphs
-                graphed_train = graphs.GraphedLoss(observations, K, "aesmc", *parts, backward=True, shard=shard)
+                graphed_train = graphs.GraphedLoss(observations, K, algorithm, *parts, backward=True, shard=shard)
                 params = list(model.parameters())
 
                 def train_step():
@@ -229,20 +237,24 @@ def main():
         step()
     kernels = provider.timer.summary()
     provider.timer = None
-    gather = kernels.get("resample_gather")
+    # the roofline kernel: the resample gather (K3); a workload that never resamples (c3, IWAE) is
+    # what BASELINE.json uses to isolate the fused log-weight + log-sum-exp kernel (K1)
+    name, label = ("resample_gather", "resample_gather_kernel (K3)") if "resample_gather" in kernels \
+        else ("logweight_lse", "logweight_lse_kernel (K1)")
+    dominant = kernels.get(name)
     roofline = None
-    if gather:
-        achieved = gather["GBps"]
+    if dominant:
+        achieved = dominant["GBps"]
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path):  # PMC passes are separate rocprofv3 runs (tools/pmc_gather.py)
             with open(pmc_path) as fh:
-                traffic = json.load(fh).get(args.workload, {}).get("resample_gather_bytes_per_launch")
-        roofline = {"kernel": "resample_gather_kernel (K3)", "bound": "hbm", "achieved": round(achieved, 1),
+                traffic = json.load(fh).get(args.workload, {}).get(name + "_bytes_per_launch")
+        roofline = {"kernel": label, "bound": "hbm", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic, "avg_launch_us": round(gather["avg_us"], 2),
-                    "algorithmic_bytes_per_launch": gather["bytes_per_launch"],
-                    "launches": gather["launches"]}
+                    "traffic": traffic, "avg_launch_us": round(dominant["avg_us"], 2),
+                    "algorithmic_bytes_per_launch": dominant["bytes_per_launch"],
+                    "launches": dominant["launches"]}
 
     out = {
         "metric": "particle_steps_per_sec", "value": value, "unit": "particle-steps/s",
@@ -252,7 +264,7 @@ def main():
         "config": {"workload": "{}: {}".format(args.workload, description), "batch_per_gpu": B,
                    "global_batch": global_B, "num_particles": K, "num_timesteps": T, "state_dim": dim,
                    "parallelism": "batch-shard x{} (one RCCL all-reduce of sum log Z per ELBO)".format(world),
-                   "step": "one forward SMC ELBO, get_loss(..., 'aesmc'), " +
+                   "step": "one forward ELBO, get_loss(..., '{}'), ".format(algorithm) +
                            ("torch.no_grad()" if args.workload in FORWARD_ONLY else "autograd graph recorded") +
                            (", all T timesteps replayed as one hipGraph" if mode == "hipgraph" else ", eager Python loop")},
         "loss": loss,
@@ -264,7 +276,7 @@ def main():
                     for k, v in kernels.items()},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(kind, dim, B, K, T)
+        out["cpu_baseline"] = cpu_baseline(kind, dim, B, K, T, algorithm)
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -23,7 +23,7 @@
 // in the first, strided version), hence: a short exp() specialised to arguments <= 0, and both
 // per-particle divisions done as reciprocal + two FMAs, which still yields the correctly rounded
 // quotient (Markstein's theorem; verified against true division in tests/test_oracle.py).
-#include "common.hpp"
+#include "../../aesmc_amd/csrc/common.hpp"
 
 namespace aesmc {
 
@@ -68,8 +68,8 @@ __device__ __forceinline__ double divide_with_reciprocal(double a, double b, dou
   return __builtin_fma(r, y, q0);
 }
 
-template <typename T, int kChunk, bool CDF_IN_LDS>
-__global__ __launch_bounds__(kMaxThreads) void ancestor_index_kernel(
+template <typename T, int kChunk, bool CDF_IN_LDS, int STOP>
+__global__ __launch_bounds__(kMaxThreads) void exp_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
     int32_t *flags, int K, double *__restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_kernel(
     return;
   }
 
+  if (STOP == 1) { if (tid == 0) idx[0] = (int64_t)dm; return; }
   // ---- pass 2: float64 weights, blocked scan ---------------------------------------------------
   // Round r covers particles [r * nt * kChunk, (r + 1) * nt * kChunk); lane `tid` owns kChunk
   // consecutive ones.  `carry` is the sum of all earlier rounds.
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_kernel(
     __syncthreads();  // scratch is rewritten by the next round
   }
 
+  if (STOP == 2) { __syncthreads(); if (tid == 0) idx[0] = (int64_t)cdf[cdf_slot(K - 1)]; return; }
   // ---- pass 3: normalise by the row total (every lane rereads only what it wrote) -------------
   // The last particle's CDF entry was formed by exactly the additions that formed `carry`'s
   // summands in a different association; dividing by that entry itself keeps c[K-1] == 1.0.
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_kernel(
   }
   __syncthreads();
 
+  if (STOP == 3) { if (tid == 0) idx[0] = (int64_t)(cdf[cdf_slot(K / 2)] * 1000.0); return; }
   // ---- pass 4: idx[k] = #{ j : c[j] <= (u + k) / K } -------------------------------------------
   const double ub = u[row];
   const double dK = (double)K;
@@ -232,65 +235,37 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_kernel(
   }
 }
 
-static int pick_threads(int64_t K, int chunk) {
-  int64_t nt = (K + chunk - 1) / chunk;  // one round when it fits
-  nt = (nt + kWave - 1) / kWave * kWave;
-  if (nt < kWave) nt = kWave;
-  if (nt > kMaxThreads) nt = kMaxThreads;
-  return (int)nt;
-}
-
-template <typename T, int CHUNK>
-static int launch_chunk(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
-                        int64_t K, void *ws, size_t ws_bytes, hipStream_t s) {
-  const int nt = pick_threads(K, CHUNK);
-  if (K <= kLdsMaxParticles) {
-    const size_t lds = (size_t)(cdf_row_slots(K) + kScratchDoubles) * sizeof(double);
-    static bool attr_set = false;  // raise the dynamic-LDS cap once per process and instantiation
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void *)ancestor_index_kernel<T, CHUNK, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return AESMC_ERR_LAUNCH;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((ancestor_index_kernel<T, CHUNK, true>), dim3((unsigned)B), dim3(nt), lds, s,
-                       (const T *)log_w, u, idx, flags, (int)K, (double *)nullptr);
-  } else {
-    if (ws == nullptr || ws_bytes < aesmc_workspace_bytes(B, K)) return AESMC_ERR_WORKSPACE;
-    const size_t lds = (size_t)kScratchDoubles * sizeof(double);
-    hipLaunchKernelGGL((ancestor_index_kernel<T, CHUNK, false>), dim3((unsigned)B), dim3(nt), lds, s,
-                       (const T *)log_w, u, idx, flags, (int)K, (double *)ws);
-  }
-  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
-}
-
-// Fewer particles per lane for short rows: more lanes per row hide latency when K is small.
-template <typename T>
-static int launch(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
-                  int64_t K, void *ws, size_t ws_bytes, hipStream_t s) {
-  if (K >= 2048) return launch_chunk<T, 8>(log_w, u, idx, flags, B, K, ws, ws_bytes, s);
-  if (K >= 512) return launch_chunk<T, 4>(log_w, u, idx, flags, B, K, ws, ws_bytes, s);
-  return launch_chunk<T, 2>(log_w, u, idx, flags, B, K, ws, ws_bytes, s);
-}
 
 }  // namespace aesmc
-
-extern "C" int64_t aesmc_ancestor_index_lds_max_particles(void) { return aesmc::kLdsMaxParticles; }
-
-extern "C" size_t aesmc_workspace_bytes(int64_t B, int64_t K) {
-  if (B <= 0 || K <= aesmc::kLdsMaxParticles) return 0;
-  return (size_t)B * (size_t)aesmc::cdf_row_slots(K) * sizeof(double);
+#include <cstdio>
+#include <vector>
+#include <cmath>
+using namespace aesmc;
+template <int CH, int STOP> float run(const float* lw, const double* u, int64_t* idx, int B, int K, int nt) {
+  size_t lds = (size_t)(cdf_row_slots(K) + kScratchDoubles) * sizeof(double);
+  hipFuncSetAttribute((const void*)exp_kernel<float, CH, true, STOP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((exp_kernel<float, CH, true, STOP>), dim3(B), dim3(nt), lds, 0, lw, u, idx, (int32_t*)nullptr, K, (double*)nullptr);
+  hipEventRecord(a);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((exp_kernel<float, CH, true, STOP>), dim3(B), dim3(nt), lds, 0, lw, u, idx, (int32_t*)nullptr, K, (double*)nullptr);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms * 1000.f / 20;
 }
-
-extern "C" int aesmc_ancestor_index(int dtype, const void *log_w, const double *u, int64_t *out_idx,
-                                    int32_t *flags, int64_t B, int64_t K, void *ws, size_t ws_bytes,
-                                    void *stream) {
-  if (log_w == nullptr || u == nullptr || out_idx == nullptr || B < 0 || K < 0)
-    return AESMC_ERR_INVALID_ARGUMENT;
-  if (B == 0 || K == 0) return AESMC_OK;
-  if (K > 0x3fffffffLL || B > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == AESMC_F32) return aesmc::launch<float>(log_w, u, out_idx, flags, B, K, ws, ws_bytes, s);
-  if (dtype == AESMC_F64) return aesmc::launch<double>(log_w, u, out_idx, flags, B, K, ws, ws_bytes, s);
-  return AESMC_ERR_INVALID_ARGUMENT;
+int main() {
+  for (auto shape : std::vector<std::pair<int,int>>{{1024, 4096}, {256, 1024}, {4096, 8192}}) {
+    int B = shape.first, K = shape.second;
+    std::vector<float> h((size_t)B * K); std::vector<double> hu(B);
+    unsigned s = 12345; for (auto& v : h) { s = s * 1664525u + 1013904223u; float a = (s >> 8) / 16777216.f; s = s * 1664525u + 1013904223u; float b = (s >> 8) / 16777216.f; v = sqrtf(-2.f * logf(a + 1e-7f)) * cosf(6.2831853f * b); }
+    for (auto& v : hu) { s = s * 1664525u + 1013904223u; v = (s >> 8) / 16777216.0; }
+    float* lw; double* u; int64_t* idx;
+    hipMalloc(&lw, h.size() * 4); hipMalloc(&u, B * 8); hipMalloc(&idx, (size_t)B * K * 8);
+    hipMemcpy(lw, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(u, hu.data(), B * 8, hipMemcpyHostToDevice);
+    int nt8 = std::min(1024, ((K + 7) / 8 + 63) / 64 * 64), nt4 = std::min(1024, ((K + 3) / 4 + 63) / 64 * 64);
+    printf("B=%d K=%d chunk8 nt=%d: pass1 %.1f  +pass2 %.1f  +pass3 %.1f  full %.1f us\n", B, K, nt8,
+           run<8, 1>(lw, u, idx, B, K, nt8), run<8, 2>(lw, u, idx, B, K, nt8), run<8, 3>(lw, u, idx, B, K, nt8), run<8, 0>(lw, u, idx, B, K, nt8));
+    printf("B=%d K=%d chunk4 nt=%d: pass1 %.1f  +pass2 %.1f  +pass3 %.1f  full %.1f us\n", B, K, nt4,
+           run<4, 1>(lw, u, idx, B, K, nt4), run<4, 2>(lw, u, idx, B, K, nt4), run<4, 3>(lw, u, idx, B, K, nt4), run<4, 0>(lw, u, idx, B, K, nt4));
+    hipFree(lw); hipFree(u); hipFree(idx);
+  }
+  return 0;
 }
