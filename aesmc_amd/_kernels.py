@@ -223,6 +223,7 @@ class HipKernels:
             if self.timer is not None:
                 self.timer.note("ancestor_index", lambda: self._lib.aesmc_ancestor_index(*args),
                                 B * K * (log_w.element_size() + 8) + 8 * B, (log_w, u, idx, ws))
+        idx._aesmc_sorted = True  # systematic resampling is monotone in k: lets K3's backward skip atomics
         return idx
 
     # ---- K3 ------------------------------------------------------------------------------------
@@ -262,8 +263,9 @@ class HipKernels:
                                 B * K * (8 + 2 * row_elems * esz), (src, idx, dst))
         return dst
 
-    def gather_backward(self, grad_out, idx):
-        """grad_src[b,j,...] = sum over {k: idx[b,k]==j} of grad_out[b,k,...]."""
+    def gather_backward(self, grad_out, idx, sorted_index=False):
+        """grad_src[b,j,...] = sum over {k: idx[b,k]==j} of grad_out[b,k,...].  `sorted_index`
+        promises idx non-decreasing along k (outputs of `ancestor_index`): segmented sum, no atomics."""
         _require_hip(grad_out, "grad")
         self._check_index(grad_out, idx)
         tag = _tag(grad_out, "gradient of a resampled value")
@@ -279,7 +281,7 @@ class HipKernels:
         with torch.cuda.device(grad_out.device):
             flags = self.flags(grad_out.device)
             args = (tag, _ptr(grad_out), _ptr(idx), _ptr(grad_src), _ptr(flags), B, K, row_elems,
-                    self._stream(grad_out))
+                    1 if sorted_index else 0, self._stream(grad_out))
             _lib.check(self._lib.aesmc_resample_gather_backward(*args),
                        "aesmc_resample_gather_backward")
             if self.timer is not None:

@@ -18,6 +18,7 @@ FLAG_NAN_LOG_WEIGHT = 1
 FLAG_DEGENERATE_ROW = 2
 FLAG_INDEX_OUT_OF_RANGE = 4
 FLAG_VALUE_OUTSIDE_SUPPORT = 8  # host-side deferred validation (state.log_prob), not a kernel
+FLAG_UNSORTED_INDEX = 16
 F32, F64 = 0, 1
 
 _vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
@@ -32,7 +33,7 @@ SIGNATURES = {
     "aesmc_ancestor_index_lds_max_particles": (_i64, []),
     "aesmc_workspace_bytes": (_sz, [_i64, _i64]),
     "aesmc_resample_gather": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
-    "aesmc_resample_gather_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "aesmc_resample_gather_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "aesmc_normal_logprob_sum": (_i32, [_i32, _vp, _vp, _vp, _vp] + [_i64] * 12 + [_vp]),
     "aesmc_normal_logprob_sum_backward": (_i32, [_i32] + [_vp] * 7 + [_i64] * 12 + [_vp]),
 }

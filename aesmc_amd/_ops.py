@@ -41,13 +41,15 @@ class _ResampleGather(torch.autograd.Function):
     def forward(ctx, value, idx):
         out = _kernels.get().gather(value, idx)
         ctx.save_for_backward(idx)
+        # set only by kernel K2 on its own outputs; any other index tensor takes the general path
+        ctx.sorted_index = bool(getattr(idx, "_aesmc_sorted", False))
         ctx.mark_non_differentiable(idx)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
-        return _kernels.get().gather_backward(grad_out, idx), None
+        return _kernels.get().gather_backward(grad_out, idx, sorted_index=ctx.sorted_index), None
 
 
 class _NormalLogProbSum(torch.autograd.Function):

@@ -114,6 +114,166 @@ __global__ __launch_bounds__(kGatherBlock) void resample_gather_bwd_kernel(
   unsafeAtomicAdd(grad_src + ((uint64_t)b * K + (uint64_t)a) * D + c, sum);
 }
 
+// Backward for SORTED indices (what systematic resampling produces): no atomics, and results that
+// are bitwise reproducible from launch to launch.
+//
+// With idx non-decreasing along k the offspring of source row j form one contiguous run of k, so
+// grad_src[b,j,:] is a segmented sum over consecutive rows.  grad_src is zero-filled first (rows
+// without offspring stay zero); then one workgroup takes ONE tile of TK consecutive particles of
+// one batch row and writes the sums of exactly those runs that END inside its tile:
+//   1. stage the tile's indices (+ the particle before and after) in LDS, find run heads and
+//      tails with wavefront ballots, compact the tails; no tail -> the tile lies inside one run
+//      that flows on, and the workgroup exits before touching any gradient row;
+//   2. stage the tile's gradient rows in LDS (coalesced, 16-byte loads);
+//   3. if the first run started in an earlier tile, add its earlier rows straight from global
+//      memory (`lead`; its start is found by one coalesced look-back, else a binary search);
+//   4. every (tail, column) pair sums its run's rows from LDS and stores one element.
+// No workgroup waits for another; every gradient row is staged once.
+constexpr int kSortedBlock = 256;
+
+template <typename T, bool VEC_LOAD>
+__global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_sorted_kernel(
+    const T *__restrict__ grad_out, const int64_t *__restrict__ idx, T *__restrict__ grad_src,
+    int32_t *flags, uint32_t K, uint32_t D, uint32_t TK, uint32_t tiles_per_row) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bwd_smem[];
+  T *G = reinterpret_cast<T *>(bwd_smem);                      // [TK * D] staged gradient rows
+  T *lead = G + (size_t)TK * D;                                // [D] rows of the first run before the tile
+  T *partials = lead + D;                                      // [256] per-lane partial sums of `lead`
+  int *ids = reinterpret_cast<int *>(partials + kSortedBlock); // [TK + 2]: before, tile, after
+  int *tails = ids + TK + 2;                                   // [TK] positions of run tails, compacted
+  int *head_of = tails + TK;                                   // [TK] position of the run head at or before i (-1: earlier tile)
+  int *wave_tails = head_of + TK;                              // [4] tails per wavefront
+  int *wave_head = wave_tails + 4;                             // [4] last head position per wavefront
+  int *shared_lo = wave_head + 4;                              // [1]
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid % kWave, wave = tid / kWave;
+  const uint32_t b = blockIdx.x / tiles_per_row;
+  const uint32_t k0 = (blockIdx.x - b * tiles_per_row) * TK;
+  const uint32_t n = min(TK, K - k0);
+  const uint64_t row_base = (uint64_t)b * K;
+  const int64_t *irow = idx + row_base;
+  const T *grow = grad_out + row_base * D;
+  T *drow = grad_src + row_base * D;
+
+  // ---- 1. indices: the tile, the particle before it and the one after ---------------------------
+  int bad = 0;
+  for (uint32_t i = tid; i < n + 2; i += kSortedBlock) {
+    const int64_t k = (int64_t)k0 + i - 1;                     // ids[0] = particle k0 - 1, ids[n + 1] = k0 + n
+    int64_t a = (k < 0) ? -1 : (k >= (int64_t)K ? (int64_t)K : irow[k]);
+    if (k >= 0 && k < (int64_t)K && (uint64_t)a >= (uint64_t)K) {
+      bad |= AESMC_FLAG_INDEX_OUT_OF_RANGE;
+      a = a < 0 ? -1 : (int64_t)K;                             // contributes nothing, stays memory-safe
+    }
+    ids[i] = (int)a;
+  }
+  __syncthreads();
+  const bool live = tid < n;                                   // TK <= 256: one particle per lane
+  const int mine = live ? ids[1 + tid] : -2;
+  const bool is_head = live && ids[tid] != mine;
+  const bool is_tail = live && ids[2 + tid] != mine;
+  if (live && mine < ids[tid]) bad |= AESMC_FLAG_UNSORTED_INDEX;
+  if (live && tid == n - 1 && k0 + n < K && ids[n + 1] < mine) bad |= AESMC_FLAG_UNSORTED_INDEX;
+  if (bad) raise_flag(flags, bad);
+  const unsigned long long tail_mask = __ballot(is_tail);
+  const unsigned long long head_mask = __ballot(is_head);
+  const unsigned long long below = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);  // lanes <= mine
+  if (lane == 0) {
+    wave_tails[wave] = __popcll(tail_mask);
+    wave_head[wave] = head_mask ? (int)(wave * kWave + 63 - __clzll(head_mask)) : -1;
+  }
+  __syncthreads();
+  int tail_base = 0, head_before = -1;
+  for (uint32_t w = 0; w < wave; ++w) {
+    tail_base += wave_tails[w];
+    if (wave_head[w] >= 0) head_before = wave_head[w];
+  }
+  const int num_tails = wave_tails[0] + wave_tails[1] + wave_tails[2] + wave_tails[3];
+  if (num_tails == 0) return;                                  // wholly inside one run that flows on
+  if (live) {
+    const unsigned long long heads_here = head_mask & below;
+    head_of[tid] = heads_here ? (int)(wave * kWave + 63 - __clzll(heads_here)) : head_before;
+    if (is_tail) tails[tail_base + __popcll(tail_mask & below) - 1] = (int)tid;
+  }
+
+  // ---- 2. stage the gradient rows ------------------------------------------------------------------
+  const uint32_t ne = n * D;
+  if constexpr (VEC_LOAD) {
+    using V = typename Vec16<T>::type;
+    const V *src = reinterpret_cast<const V *>(grow + (uint64_t)k0 * D);
+    V *dst = reinterpret_cast<V *>(G);
+    for (uint32_t v = tid; v < ne / Vec16<T>::N; v += kSortedBlock) dst[v] = src[v];
+  } else {
+    for (uint32_t e = tid; e < ne; e += kSortedBlock) G[e] = grow[(uint64_t)k0 * D + e];
+  }
+
+  // ---- 3. rows of the first run that lie before the tile -----------------------------------------
+  const int before = ids[0], first_id = ids[1];
+  const bool has_lead = (k0 > 0) && (first_id == before) && first_id >= 0 && first_id < (int)K;
+  if (has_lead) {
+    if (tid == 0) *shared_lo = -1;
+    __syncthreads();
+    const int64_t back = (int64_t)k0 - 1 - tid;                // lane's candidate for "last particle before the run"
+    if (tid > 0 && back >= -1) {
+      const bool differs = back < 0 || irow[back] != (int64_t)first_id;
+      if (differs && irow[back + 1] == (int64_t)first_id)
+        *shared_lo = (int)(back + 1);                          // unique lane (ids are sorted): the run's first particle
+    }
+    __syncthreads();
+    uint32_t lo;
+    if (*shared_lo >= 0) {
+      lo = (uint32_t)*shared_lo;
+    } else {                                                   // longer than the look-back: binary search the rest
+      uint32_t l = 0, h = k0 - kSortedBlock;
+      while (l < h) {
+        const uint32_t mid = (l + h) >> 1;
+        if (irow[mid] < (int64_t)first_id) l = mid + 1; else h = mid;
+      }
+      lo = l;
+    }
+    // `slots` lanes share a column and take every slots-th row; their partial sums are combined
+    // through LDS in slot order (fixed order: reproducible).  Control flow is workgroup-uniform.
+    const uint32_t cols = min(D, (uint32_t)kSortedBlock), slots = kSortedBlock / cols;
+    const uint32_t slot = tid / cols, col = tid - slot * cols;
+    for (uint32_t cbase = 0; cbase < D; cbase += cols) {
+      const uint32_t c = cbase + col;
+      T acc = T(0);
+      if (slot < slots && c < D) {
+        // eight independent accumulators keep eight global loads in flight on long runs
+        T a[8] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+        uint32_t i = lo + slot;
+        for (; (uint64_t)i + 7ull * slots < k0; i += 8 * slots) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a[q] += grow[(uint64_t)(i + q * slots) * D + c];
+        }
+        for (; i < k0; i += slots) a[0] += grow[(uint64_t)i * D + c];
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      }
+      if (slot < slots) partials[slot * cols + col] = acc;
+      __syncthreads();
+      if (tid < cols && cbase + tid < D) {
+        T sum = T(0);
+        for (uint32_t s2 = 0; s2 < slots; ++s2) sum += partials[s2 * cols + tid];
+        lead[cbase + tid] = sum;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  // ---- 4. one element per (tail, column) ---------------------------------------------------------
+  const uint32_t total = (uint32_t)num_tails * D;
+  for (uint32_t e = tid; e < total; e += kSortedBlock) {
+    const uint32_t t = e / D, c = e - t * D;
+    const int i = tails[t];
+    const int id = ids[1 + i];
+    if ((uint32_t)id >= K) continue;                           // out-of-range index: reported above
+    const int h = head_of[i];
+    T sum = (h < 0 && has_lead) ? lead[c] : T(0);
+    for (int r = h < 0 ? 0 : h; r <= i; ++r) sum += G[(uint32_t)r * D + c];
+    drow[(uint64_t)id * D + c] = sum;
+  }
+}
+
 static inline int low_pow2(uint64_t x, int cap) {  // largest power of two <= cap dividing x
   int g = cap;
   while (g > 1 && (x % (uint64_t)g) != 0) g >>= 1;
@@ -133,6 +293,8 @@ static void launch_gather(const void *src, const int64_t *idx, void *dst, int32_
 }
 
 }  // namespace aesmc
+
+using namespace aesmc;
 
 extern "C" int aesmc_resample_gather(const void *src, const int64_t *idx, void *dst, int32_t *flags,
                                      int64_t B, int64_t K, int64_t row_bytes, int64_t src_stride_b,
@@ -178,9 +340,35 @@ extern "C" int aesmc_resample_gather(const void *src, const int64_t *idx, void *
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
+template <typename T>
+static bool launch_sorted_backward(const void *grad_out, const int64_t *idx, void *grad_src,
+                                   int32_t *flags, int64_t B, int64_t K, int64_t D, hipStream_t s) {
+  // tile: as many particles as fit 32 KiB of staged gradient rows, at most 256
+  const int64_t row_bytes = D * (int64_t)sizeof(T);
+  int64_t TK = (32 * 1024) / row_bytes;
+  if (TK > 256) TK = 256;
+  if (TK < 8) return false;                                    // very wide rows: use the general kernel
+  if (TK > K) TK = K;
+  const int64_t tiles = (K + TK - 1) / TK;
+  if (B * tiles > 0x7fffffffLL) return false;
+  const size_t lds = (size_t)(TK * D + D + kSortedBlock) * sizeof(T) + (size_t)(3 * TK + 2 + 12) * sizeof(int);
+  constexpr int N = Vec16<T>::N;
+  const bool vec = (((uintptr_t)grad_out & 15u) == 0) && ((K * D) % N == 0) && ((TK * D) % N == 0);
+  dim3 grid((unsigned)(B * tiles)), block(kSortedBlock);
+  if (vec)
+    hipLaunchKernelGGL((resample_gather_bwd_sorted_kernel<T, true>), grid, block, lds, s,
+                       (const T *)grad_out, idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D,
+                       (uint32_t)TK, (uint32_t)tiles);
+  else
+    hipLaunchKernelGGL((resample_gather_bwd_sorted_kernel<T, false>), grid, block, lds, s,
+                       (const T *)grad_out, idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D,
+                       (uint32_t)TK, (uint32_t)tiles);
+  return true;
+}
+
 extern "C" int aesmc_resample_gather_backward(int dtype, const void *grad_out, const int64_t *idx,
                                               void *grad_src, int32_t *flags, int64_t B, int64_t K,
-                                              int64_t row_elems, void *stream) {
+                                              int64_t row_elems, int index_is_sorted, void *stream) {
   using namespace aesmc;
   if (grad_out == nullptr || idx == nullptr || grad_src == nullptr || B < 0 || K < 0 || row_elems < 0)
     return AESMC_ERR_INVALID_ARGUMENT;
@@ -190,9 +378,16 @@ extern "C" int aesmc_resample_gather_backward(int dtype, const void *grad_out, c
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == AESMC_F32 ? 4 : 8;
   const uint64_t re = (uint64_t)K * (uint64_t)row_elems;
+  // both kernels write only rows that have offspring: everything else must read as zero
+  if (hipMemsetAsync(grad_src, 0, (size_t)B * re * esz, s) != hipSuccess) return AESMC_ERR_LAUNCH;
+  if (index_is_sorted) {
+    const bool launched = dtype == AESMC_F32
+        ? launch_sorted_backward<float>(grad_out, idx, grad_src, flags, B, K, row_elems, s)
+        : launch_sorted_backward<double>(grad_out, idx, grad_src, flags, B, K, row_elems, s);
+    if (launched) return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
   const uint64_t bpr = (re + kGatherBlock - 1) / kGatherBlock;
   if ((uint64_t)B * bpr > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
-  if (hipMemsetAsync(grad_src, 0, (size_t)B * re * esz, s) != hipSuccess) return AESMC_ERR_LAUNCH;
   dim3 grid((unsigned)((uint64_t)B * bpr)), block(kGatherBlock);
   if (dtype == AESMC_F32)
     hipLaunchKernelGGL((resample_gather_bwd_kernel<float>), grid, block, 0, s, (const float *)grad_out,

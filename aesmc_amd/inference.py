@@ -106,6 +106,8 @@ def _raise_for_flags(flags):
     if flags & _lib.FLAG_VALUE_OUTSIDE_SUPPORT:
         raise ValueError("The value argument must be within the support of the distribution "
                          "(detected on the device during log_prob)")
+    if flags & _lib.FLAG_UNSORTED_INDEX:
+        raise RuntimeError("aesmc_amd internal error: an index tensor tagged as sorted was not")
     if flags & (_lib.FLAG_DEGENERATE_ROW | _lib.FLAG_INDEX_OUT_OF_RANGE):
         raise RuntimeError(
             "ancestral index out of range: a row of log-weights had no finite maximum (all -inf, "

@@ -36,6 +36,7 @@ extern "C" {
 #define AESMC_FLAG_DEGENERATE_ROW 2  /* a row had max = +-inf -> every index == K (reference: NaN CDF)     */
 #define AESMC_FLAG_INDEX_OUT_OF_RANGE 4 /* gather saw idx < 0 or idx >= K (torch.gather would raise)     */
 #define AESMC_FLAG_VALUE_OUTSIDE_SUPPORT 8 /* reserved for the host's deferred sample validation         */
+#define AESMC_FLAG_UNSORTED_INDEX 16 /* gather backward was promised sorted indices and met a descent   */
 
 /* ---- dtype tags ----------------------------------------------------------------------------- */
 #define AESMC_F32 0
@@ -100,10 +101,13 @@ int aesmc_resample_gather(const void *src, const int64_t *idx, void *dst, int32_
  * K3 backward:  grad_src[b,j,:] = sum_{k : idx[b,k]==j} grad_out[b,k,:]   (`row_elems` elements of
  * `dtype` per particle, both tensors dense).  grad_src is fully overwritten (zero where a particle
  * has no offspring).  Replaces the scatter_add autograd of torch.gather (aesmc/state.py:179).
+ * index_is_sorted != 0 promises idx non-decreasing along k (true for every output of
+ * aesmc_ancestor_index): the segmented-sum kernel without atomics is used and a violation raises
+ * AESMC_FLAG_UNSORTED_INDEX; 0 selects the order-agnostic kernel (one float atomic per run).
  */
 int aesmc_resample_gather_backward(int dtype, const void *grad_out, const int64_t *idx,
                                    void *grad_src, int32_t *flags, int64_t B, int64_t K,
-                                   int64_t row_elems, void *stream);
+                                   int64_t row_elems, int index_is_sorted, void *stream);
 
 /*
  * K4 — summed Normal log-density:

@@ -35,7 +35,9 @@ class OracleKernels:
     def ancestor_index(self, log_w, u):
         idx, flags = kernel_oracle.ancestor_index(log_w.detach().numpy(), u.numpy())
         self._flags |= flags
-        return torch.from_numpy(idx)
+        out = torch.from_numpy(idx)
+        out._aesmc_sorted = True
+        return out
 
     def gather(self, src, idx):
         assert idx.size() == src.size()[:2]
@@ -43,7 +45,7 @@ class OracleKernels:
         self._flags |= flags
         return torch.from_numpy(out)
 
-    def gather_backward(self, grad_out, idx):
+    def gather_backward(self, grad_out, idx, sorted_index=False):
         out, flags = kernel_oracle.gather_backward(grad_out.detach().contiguous().numpy(), idx.numpy())
         self._flags |= flags
         return torch.from_numpy(out)

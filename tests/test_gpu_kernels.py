@@ -245,6 +245,64 @@ def test_gather_backward_matches_oracle(kernels, hip_device, dtype, shape, scale
         np.testing.assert_allclose(got, want, rtol=50 * rtol, atol=50 * atol)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,scale", [((2, 16), 1.0), ((3, 7, 3), 1.0), ((4, 100, 10), 1.0),
+                                         ((2, 300, 10), 8.0), ((2, 1000, 6), 30.0), ((3, 64, 2, 5), 1.0),
+                                         ((1, 5000, 10), 1.0), ((1, 5000, 10), 40.0), ((3, 700, 128), 3.0),
+                                         ((2, 2049, 1), 2.0), ((300, 33, 4), 1.0), ((2, 600, 129), 0.0),
+                                         ((1, 1, 7), 1.0), ((5, 1024, 16), 200.0)])
+def test_gather_backward_sorted_path_matches_oracle(kernels, hip_device, dtype, shape, scale):
+    """The segmented-sum backward (no atomics) on what K2 produces: uniform weights (scale 0:
+    every particle survives), ordinary, and collapsed (scale >> 1: a few long runs crossing tiles
+    and sections)."""
+    rng = np.random.RandomState(shape[1] + int(scale))
+    go = rng.randn(*shape).astype(dtype)
+    idx = sorted_indices(rng, shape[0], shape[1], scale)
+    kernels.read_flags(hip_device)
+    got = kernels.gather_backward(dev(go, hip_device), dev(idx, hip_device), sorted_index=True).cpu().numpy()
+    assert kernels.read_flags(hip_device) == 0
+    want, _ = kernel_oracle.gather_backward(go, idx)
+    rtol, atol = tol(dtype)
+    longest = np.max(np.bincount(idx.reshape(-1) + np.repeat(np.arange(shape[0]), shape[1]) * shape[1]))
+    # sums of `longest` standard-normal terms in a different association than the oracle's
+    np.testing.assert_allclose(got, want, rtol=50 * rtol, atol=20 * atol * max(longest, 1) ** 0.5)
+    # deterministic: same bits on a second launch (the atomic path cannot promise this)
+    again = kernels.gather_backward(dev(go, hip_device), dev(idx, hip_device), sorted_index=True).cpu().numpy()
+    np.testing.assert_array_equal(got, again)
+
+
+def test_gather_backward_sorted_path_edge_indices(kernels, hip_device):
+    K, d = 700, 3
+    rng = np.random.RandomState(0)
+    go = rng.randn(4, K, d)
+    idx = np.stack([np.zeros(K, np.int64),                          # everyone descends from particle 0
+                    np.full(K, K - 1, np.int64),                    # ... from the last particle
+                    np.arange(K, dtype=np.int64),                   # identity
+                    np.sort(rng.randint(0, K, size=K)).astype(np.int64)])
+    got = kernels.gather_backward(dev(go, hip_device), dev(idx, hip_device), sorted_index=True).cpu().numpy()
+    want, _ = kernel_oracle.gather_backward(go, idx)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-11)
+    # a descent in an index promised sorted is reported, not silently mis-summed
+    bad = idx.copy()
+    bad[3, 300] = 0
+    kernels.read_flags(hip_device)
+    kernels.gather_backward(dev(go, hip_device), dev(bad, hip_device), sorted_index=True)
+    assert kernels.read_flags(hip_device) & 16
+    # the autograd wrapper only trusts indices tagged by K2 itself
+    from aesmc_amd import _ops
+    value = torch.randn(2, 50, 3, device=hip_device, dtype=torch.float64, requires_grad=True)
+    tagged = _ops.ancestor_index(torch.randn(2, 50, device=hip_device), torch.rand(2, device=hip_device, dtype=torch.float64))
+    assert getattr(tagged, "_aesmc_sorted", False)
+    untagged = torch.randint(0, 50, (2, 50), device=hip_device)
+    for index in (tagged, untagged):
+        value.grad = None
+        weights = torch.randn(2, 50, 3, device=hip_device, dtype=torch.float64)
+        (_ops.resample_gather(value, index) * weights).sum().backward()
+        want = torch.zeros_like(value).scatter_add_(1, index[..., None].expand(2, 50, 3), weights)
+        torch.testing.assert_close(value.grad, want, rtol=1e-12, atol=1e-12)
+    assert kernels.read_flags(hip_device) == 0
+
+
 # ---- full-size properties (BASELINE.json configs) -----------------------------------------------
 @pytest.mark.parametrize("B,K,d", [(256, 1024, 10), (1024, 4096, 10), (16, 16384, 128)])
 def test_full_size_resample_properties(kernels, hip_device, B, K, d):
@@ -353,7 +411,8 @@ def test_normal_logprob_sum_strided_views(kernels, hip_device):
     loc_full = torch.randn(B, K, d, device=hip_device, generator=gen)
     scale_vec = 0.5 + torch.rand(d, device=hip_device, generator=gen)
     for value, loc, scale in [(latent, loc_b.unsqueeze(1), torch.tensor(0.7, device=hip_device)),
-                              (obs, loc_full, scale_vec), (loc_full[:, ::2], loc_full[:, 1::2], scale_vec)]:
+                              (obs, loc_full, scale_vec),
+                              (loc_full[:, 0:36:2], loc_full[:, 1:36:2], scale_vec)]:
         shape = value.shape
         got = kernels.normal_logprob_sum(value, loc.expand(shape), scale.expand(shape))
         want = torch.distributions.Normal(loc, scale).log_prob(value).sum(-1)

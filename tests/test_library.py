@@ -57,7 +57,7 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.aesmc_ancestor_index(0, 8, 8, 8, None, -1, 4, None, 0, None) == 1
     assert lib.aesmc_resample_gather(None, None, None, None, 1, 1, 4, 4, 4, None) == 1
     assert lib.aesmc_resample_gather(8, 8, 8, None, 1, 1 << 31, 4, 4, 4, None) == 2   # unsupported size
-    assert lib.aesmc_resample_gather_backward(5, 8, 8, 8, None, 1, 1, 1, None) == 1   # bad dtype tag
+    assert lib.aesmc_resample_gather_backward(5, 8, 8, 8, None, 1, 1, 1, 0, None) == 1   # bad dtype tag
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

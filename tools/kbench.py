@@ -56,10 +56,12 @@ def main(names):
             rows.append(("K3 gather s=1", us, B * K * (8 + 8 * d)))
             us = timeit(lambda: k.gather(x, idx5))
             rows.append(("K3 gather s=5", us, B * K * (8 + 8 * d)))
+            us = timeit(lambda: k.gather_backward(x, idx, sorted_index=True))
+            rows.append(("K3 backward s=1 (sorted path)", us, B * K * (8 + 8 * d)))
+            us = timeit(lambda: k.gather_backward(x, idx5, sorted_index=True))
+            rows.append(("K3 backward s=5 (sorted path)", us, B * K * (8 + 8 * d)))
             us = timeit(lambda: k.gather_backward(x, idx))
-            rows.append(("K3 backward s=1", us, B * K * (8 + 8 * d)))
-            us = timeit(lambda: k.gather_backward(x, idx5))
-            rows.append(("K3 backward s=5", us, B * K * (8 + 8 * d)))
+            rows.append(("K3 backward s=1 (atomic path)", us, B * K * (8 + 8 * d)))
             scale = torch.tensor(0.7, device=dev).expand(B, K, d)
             us = timeit(lambda: k.normal_logprob_sum(x, loc, scale))
             rows.append(("K4 normal_logprob_sum", us, B * K * (8 * d + 4)))
