@@ -60,6 +60,11 @@ def active_shard():
     return _ACTIVE_SHARD
 
 
+def _group_is_live():
+    """True inside an initialised process group (also a one-rank group: same code path)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 class _AllReduceSum(torch.autograd.Function):
     """y = sum over ranks of x; dy/dx = 1 on every rank (each rank differentiates the global
     objective with respect to its local contribution)."""
@@ -87,7 +92,7 @@ def sharded_get_loss(local_observations, num_particles, algorithm, initial, tran
             emission, proposal, num_particles, return_log_marginal_likelihood=True,
             return_latents=False, return_log_weight=False)
     local_sum = result["log_marginal_likelihood"].sum()
-    total = _AllReduceSum.apply(local_sum, group) if world_size > 1 else local_sum
+    total = _AllReduceSum.apply(local_sum, group) if _group_is_live() else local_sum
     return -total / global_batch_size
 
 
@@ -95,7 +100,7 @@ def all_reduce_gradients(parameters, group=None):
     """Sums parameter gradients over ranks with one flat-bucket all-reduce (the model is tiny
     next to the particle state: one latency-bound collective per optimiser step)."""
     grads = [p.grad for p in parameters if p.grad is not None]
-    if not grads or dist.get_world_size(group) == 1:
+    if not grads or not _group_is_live():
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

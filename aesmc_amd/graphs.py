@@ -125,7 +125,10 @@ class GraphedLoss:
         gc.collect()                                     # drop dead eager autograd graphs first
         self.graph = torch.cuda.CUDAGraph()
         self._refill()
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, RCCL's watchdog thread may call the HIP runtime at any time;
+        # "thread_local" keeps such calls from other threads from invalidating this capture.
+        error_mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=error_mode):
             self.static_loss = self._evaluate(refill=False)
         self.replays = 0
         self._done = None
@@ -174,7 +177,7 @@ class GraphedLoss:
         self.replays += 1
         if self.check_flags:
             inference._raise_for_flags(_kernels.get().read_flags(self.device))
-        if self.shard and self.shard[2] > 1:
+        if self.shard and dist.is_available() and dist.is_initialized():
             total = self.static_loss.clone()
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
             return total

@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-backward", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and take the sharded code path even with one rank (test hook)")
     ap.add_argument("--mode", default=None, choices=["graph", "eager"],
                     help="graph: replay the whole ELBO as one hipGraph (aesmc_amd.graphs); eager: Python loop")
     return ap.parse_args()
@@ -122,8 +124,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     description, kind, dim, B, K, T = WORKLOADS[args.workload]
@@ -149,7 +153,7 @@ def main():
             return _step(backward)
 
     def _step(backward=False):
-        if world > 1:
+        if use_dist:
             loss = distributed.sharded_get_loss(observations, K, algorithm, *parts, global_batch_size=global_B,
                                                 rank=rank, world_size=world)
         else:
@@ -157,12 +161,12 @@ def main():
         if backward:
             model.zero_grad(set_to_none=True)
             loss.backward()
-            if world > 1:
+            if use_dist:
                 distributed.all_reduce_gradients(list(model.parameters()))
         return loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -174,12 +178,12 @@ def main():
             loss = fn()
         barrier()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return float(dt.item()), float(loss.detach())
 
     # ---- the step: one hipGraph replay of the whole ELBO (default) or the eager Python loop ------
-    shard = (global_B, rank, world) if world > 1 else None
+    shard = (global_B, rank, world) if use_dist else None
     mode, graph_error, graphed = "eager", None, None
     if args.mode == "graph":
         try:
@@ -217,7 +221,7 @@ def main():
 
                 def train_step():
                     out = graphed_train()
-                    if world > 1:
+                    if use_dist:
                         distributed.all_reduce_gradients(params)
                     return out
             except Exception as error:
@@ -277,11 +281,11 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kind, dim, B, K, T, algorithm)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
