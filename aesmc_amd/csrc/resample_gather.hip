@@ -23,8 +23,13 @@ template <> struct Piece<4> { using type = uint32_t; };
 template <> struct Piece<8> { using type = uint2; };
 template <> struct Piece<16> { using type = uint4; };
 
-// V pieces of G bytes per lane; V*G == 16 on the vector path, V == 1 on the unaligned fallback.
-template <int G, int V>
+// V pieces of G bytes per 16-byte chunk (V == 1 on the unaligned fallback) and U chunks per lane,
+// 256 lanes apart so each store instruction of a wavefront still covers 1 KiB contiguously.  The
+// U*V index loads are issued together, then the U*V row loads: the kernel is a chain of two
+// dependent global loads per piece, and at the small per-step sizes of BASELINE.json configs[1]
+// (23 MB per launch) it is that latency, not bandwidth, that bounds it — more loads in flight per
+// lane shorten the chain count per CU.
+template <int G, int V, int U>
 __global__ __launch_bounds__(kGatherBlock) void resample_gather_kernel(
     const char *__restrict__ src, const int64_t *__restrict__ idx, char *__restrict__ dst,
     int32_t *flags, uint32_t K, uint32_t ppp /* pieces per particle */,
@@ -33,52 +38,66 @@ __global__ __launch_bounds__(kGatherBlock) void resample_gather_kernel(
   using P = typename Piece<G>::type;
   const uint32_t b = blockIdx.x / blocks_per_row;
   const uint32_t cb = blockIdx.x - b * blocks_per_row;
-  const uint32_t chunk = cb * kGatherBlock + threadIdx.x;
-  if (chunk >= chunks_per_row) return;
-
-  const uint64_t p0 = (uint64_t)chunk * V;
-  uint32_t k = (uint32_t)(p0 / ppp);
-  uint32_t r = (uint32_t)(p0 - (uint64_t)k * ppp);
   const int64_t *irow = idx + (uint64_t)b * K;
   const char *srow = src + (int64_t)b * stride_b;
-  char *drow = dst + ((uint64_t)b * row_pieces + p0) * G;
+  char *drow = dst + (uint64_t)b * row_pieces * G;
 
-  P piece[V];
-  int bad = 0;
-  uint32_t cur_k = 0xffffffffu;
-  const char *prow = nullptr;
+  uint32_t kk[U][V], rr[U][V];
+  bool live[U][V];
 #pragma unroll
-  for (int i = 0; i < V; ++i) {
-    if (p0 + i < row_pieces) {
-      if (k != cur_k) {
-        int64_t a = irow[k];
-        if ((uint64_t)a >= (uint64_t)K) {  // torch.gather would raise; never fault, report instead
-          bad = 1;
-          a = a < 0 ? 0 : (int64_t)K - 1;
-        }
-        prow = srow + a * stride_k;
-        cur_k = k;
-      }
-      piece[i] = *reinterpret_cast<const P *>(prow + (uint64_t)r * G);
+  for (int j = 0; j < U; ++j) {
+    const uint32_t chunk = (cb * U + j) * kGatherBlock + threadIdx.x;
+    const uint64_t p0 = (uint64_t)chunk * V;
+    const uint64_t q0 = p0 < row_pieces ? p0 : 0;
+    uint32_t k = (uint32_t)(q0 / ppp);
+    uint32_t r = (uint32_t)(q0 - (uint64_t)k * ppp);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      live[j][i] = chunk < chunks_per_row && p0 + i < row_pieces;
+      kk[j][i] = live[j][i] ? k : 0;
+      rr[j][i] = r;
       if (++r == ppp) {
         r = 0;
         ++k;
       }
     }
   }
-  if (p0 + V <= row_pieces) {
-    if constexpr (V * G == 16 && V > 1) {
-      uint4 out;
-      __builtin_memcpy(&out, piece, 16);
-      *reinterpret_cast<uint4 *>(drow) = out;
+  int64_t anc[U][V];
+#pragma unroll
+  for (int j = 0; j < U; ++j)
+#pragma unroll
+    for (int i = 0; i < V; ++i) anc[j][i] = irow[kk[j][i]];
+  int bad = 0;
+  P piece[U][V];
+#pragma unroll
+  for (int j = 0; j < U; ++j)
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int64_t a = anc[j][i];
+      if ((uint64_t)a >= (uint64_t)K) {  // torch.gather would raise; never fault, report instead
+        bad |= live[j][i] ? 1 : 0;
+        a = a < 0 ? 0 : (int64_t)K - 1;
+      }
+      piece[j][i] = *reinterpret_cast<const P *>(srow + a * stride_k + (uint64_t)rr[j][i] * G);
+    }
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    const uint32_t chunk = (cb * U + j) * kGatherBlock + threadIdx.x;
+    char *out = drow + (uint64_t)chunk * V * G;
+    if (live[j][V - 1]) {
+      if constexpr (V * G == 16 && V > 1) {
+        uint4 packed;
+        __builtin_memcpy(&packed, piece[j], 16);
+        *reinterpret_cast<uint4 *>(out) = packed;
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) reinterpret_cast<P *>(out)[i] = piece[j][i];
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < V; ++i) reinterpret_cast<P *>(drow)[i] = piece[i];
+      for (int i = 0; i < V; ++i)
+        if (live[j][i]) reinterpret_cast<P *>(out)[i] = piece[j][i];
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < V; ++i)
-      if (p0 + i < row_pieces) reinterpret_cast<P *>(drow)[i] = piece[i];
   }
   if (bad) raise_flag(flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
 }
@@ -286,10 +305,18 @@ static void launch_gather(const void *src, const int64_t *idx, void *dst, int32_
   const uint32_t ppp = (uint32_t)(row_bytes / G);
   const uint64_t row_pieces = (uint64_t)K * ppp;
   const uint32_t chunks = (uint32_t)((row_pieces + V - 1) / V);
-  const uint32_t bpr = (chunks + kGatherBlock - 1) / kGatherBlock;
-  hipLaunchKernelGGL((resample_gather_kernel<G, V>), dim3((unsigned)(B * bpr)), dim3(kGatherBlock),
-                     0, s, (const char *)src, idx, (char *)dst, flags, (uint32_t)K, ppp, row_pieces,
-                     chunks, bpr, sb, sk);
+  // four chunks per lane once a row holds at least that much work for a full workgroup
+  if (chunks >= 4u * kGatherBlock) {
+    const uint32_t bpr = (chunks + 4 * kGatherBlock - 1) / (4 * kGatherBlock);
+    hipLaunchKernelGGL((resample_gather_kernel<G, V, 4>), dim3((unsigned)(B * bpr)), dim3(kGatherBlock),
+                       0, s, (const char *)src, idx, (char *)dst, flags, (uint32_t)K, ppp, row_pieces,
+                       chunks, bpr, sb, sk);
+  } else {
+    const uint32_t bpr = (chunks + kGatherBlock - 1) / kGatherBlock;
+    hipLaunchKernelGGL((resample_gather_kernel<G, V, 1>), dim3((unsigned)(B * bpr)), dim3(kGatherBlock),
+                       0, s, (const char *)src, idx, (char *)dst, flags, (uint32_t)K, ppp, row_pieces,
+                       chunks, bpr, sb, sk);
+  }
 }
 
 }  // namespace aesmc
