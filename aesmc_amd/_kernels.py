@@ -88,6 +88,20 @@ class KernelTimer:
             nbytes = sum(n for _, n, _ in sample) / len(sample)
             out[name] = {"launches": count, "sampled": len(sample), "avg_us": 1e6 * seconds,
                          "bytes_per_launch": nbytes, "GBps": nbytes / seconds / 1e9}
+            if name == "resample_gather":
+                # The algorithmic figure counts a full read of the source; only rows that still
+                # have offspring are actually fetched.  Report how many that was on these operands
+                # and the bytes that had to move (index + surviving rows + every output row).
+                fractions, moved = [], []
+                for _, _, (src, idx, dst) in sample:
+                    rows = idx.numel()
+                    unique = int((idx[:, 1:] != idx[:, :-1]).sum().item()) + idx.size(0)
+                    payload = dst.numel() * dst.element_size() / rows
+                    fractions.append(unique / rows)
+                    moved.append(rows * 8 + (rows + unique) * payload)
+                out[name]["unique_ancestor_fraction"] = sum(fractions) / len(fractions)
+                out[name]["moved_bytes_per_launch"] = sum(moved) / len(moved)
+                out[name]["moved_GBps"] = out[name]["moved_bytes_per_launch"] / seconds / 1e9
         return out
 
 

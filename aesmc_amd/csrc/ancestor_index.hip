@@ -232,6 +232,201 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_kernel(
   }
 }
 
+// ---- primary kernel: everything in registers, no per-particle search ------------------------------
+//
+// Each lane owns C consecutive particles j and keeps their CDF entries in registers.  Instead of
+// searching the CDF for every position k, it inverts the question: first[j] = the first k whose
+// position (u + k) / K reaches c[j], i.e. ceil(c[j] K - u) corrected against the exactly rounded
+// positions.  Since idx[k] = #{j : first[j] <= k}, lane j drops the marker j + 1 at k = first[j]
+// (when any particle starts there) into an LDS array, and an inclusive max-scan over k — the same
+// blocked scan as for the CDF, on int32 — turns the markers into the ancestor indices.  O(1) work
+// per particle, no data-dependent loops, 4 B of LDS per particle (K <= 32768 in one workgroup).
+constexpr int kInvMaxChunk = 32;
+constexpr int64_t kInvMaxParticles = (int64_t)kMaxThreads * kInvMaxChunk;
+
+template <typename T, int C>
+__global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
+    const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
+    int32_t *flags, int K) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *scratch = smem;                                        // [64]
+  int *scratch_i = reinterpret_cast<int *>(scratch + 32);
+  int *marker = reinterpret_cast<int *>(smem + kScratchDoubles);  // [K rounded up to C]
+  const int tid = threadIdx.x;
+  const int nt = blockDim.x;
+  const int lane = tid % kWave;
+  const int wave = tid / kWave;
+  const int nwaves = nt / kWave;
+  int *first_of_lane = marker + nt * C;                           // [nwaves]: first[] of each wavefront's lane 0
+  const int64_t row = blockIdx.x;
+  const T *lw = log_w + row * (int64_t)K;
+  int64_t *idx = out_idx + row * (int64_t)K;
+  const int j0 = tid * C;                                         // nt * C >= K: one round
+
+  // ---- load once, row max + NaN scan ---------------------------------------------------------
+  T v[C];
+  constexpr int NV = Vec16<T>::N;
+  if (C % NV == 0 && j0 + C <= K && (((uintptr_t)(lw + j0)) & 15u) == 0) {
+    using V = typename Vec16<T>::type;                       // the lane's C values as 16-byte loads
+#pragma unroll
+    for (int q = 0; q < C / NV; ++q) {
+      const V packed = reinterpret_cast<const V *>(lw + j0)[q];
+#pragma unroll
+      for (int r = 0; r < NV; ++r) v[q * NV + r] = Vec16<T>::get(packed, r);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) v[i] = (j0 + i < K) ? lw[j0 + i] : Num<T>::neg_inf();
+  }
+  T m = Num<T>::neg_inf();
+  int has_nan = 0;
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    has_nan |= (v[i] != v[i]);
+    m = Num<T>::max(m, v[i]);
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    m = Num<T>::max(m, __shfl_xor(m, off, kWave));
+    has_nan |= __shfl_xor(has_nan, off, kWave);
+  }
+  if (lane == 0) {
+    scratch[wave] = (double)m;
+    scratch_i[wave] = has_nan;
+  }
+  __syncthreads();
+  double dm = scratch[0];
+  has_nan = scratch_i[0];
+  for (int w = 1; w < nwaves; ++w) {
+    dm = fmax(dm, scratch[w]);
+    has_nan |= scratch_i[w];
+  }
+  __syncthreads();
+  const bool degenerate = has_nan || !(dm > -__builtin_huge_val() && dm < __builtin_huge_val());
+  if (degenerate) {  // same conventions as the reference: see include/aesmc_hip.h, K2
+    if (tid == 0) raise_flag(flags, has_nan ? AESMC_FLAG_NAN_LOG_WEIGHT : AESMC_FLAG_DEGENERATE_ROW);
+    for (int k = tid; k < K; k += nt) idx[k] = (int64_t)K;
+    return;
+  }
+
+  // ---- float64 weights, blocked inclusive scan ---------------------------------------------------
+  double s[C];
+  double run = 0.0;
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    run += (j0 + i < K) ? exp_nonpositive((double)v[i] - dm) : 0.0;
+    s[i] = run;
+  }
+  double incl = run;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const double y = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += y;
+  }
+  double base = __shfl_up(incl, 1, kWave);
+  if (lane == 0) base = 0.0;
+  if (lane == kWave - 1) scratch[wave] = incl;
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) base += scratch[w];
+  // the CDF's last entry is the normaliser, so that c[K-1] == 1.0 exactly (reference: c / max(c))
+  if (j0 <= K - 1 && K - 1 < j0 + C) scratch[31] = base + s[K - 1 - j0];
+  __syncthreads();
+  const double total = scratch[31];
+  const double inv_total = 1.0 / total;
+
+  // ---- first[j] = min{ k : (u + k) / K >= c[j] } ---------------------------------------------------
+  const double ub = u[row];
+  const double dK = (double)K;
+  const double inv_K = 1.0 / dK;
+  int first[C];
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    if (j0 + i < K) {
+      const double c = divide_with_reciprocal(base + s[i], total, inv_total);
+      // c <= (u + k) / K  <=>  k >= c K - u, up to the rounding of the position and of this
+      // product: both are below K * 2^-52, so unless c K - u sits within K * 1e-15 of an integer
+      // its ceiling IS the answer; only that rare case is settled against the exact positions.
+      const double x = __builtin_fma(c, dK, -ub);
+      const double t = __builtin_ceil(x);
+      int k0 = t < 0.0 ? 0 : (t > dK ? K : (int)t);
+      if (__builtin_fabs(x - __builtin_rint(x)) <= dK * 1e-15) {
+        while (k0 > 0 && divide_with_reciprocal(ub + (double)(k0 - 1), dK, inv_K) >= c) --k0;
+        while (k0 < K && divide_with_reciprocal(ub + (double)k0, dK, inv_K) < c) ++k0;
+      }
+      first[i] = k0;
+    } else {
+      first[i] = K;
+    }
+  }
+  if (lane == 0) first_of_lane[wave] = first[0];            // the next wavefront's first entry, via LDS
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) reinterpret_cast<int4 *>(marker + j0)[q] = make_int4(0, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) marker[j0 + i] = 0;
+  }
+  __syncthreads();
+  int next_lane_first = __shfl_down(first[0], 1, kWave);     // the next lane's first entry, in-register
+  if (lane == kWave - 1) next_lane_first = (wave + 1 < nwaves) ? first_of_lane[wave + 1] : K;
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    const int j = j0 + i;
+    if (j < K) {
+      int next = (i + 1 < C) ? first[i + 1 < C ? i + 1 : i] : next_lane_first;
+      if (j == K - 1) next = K;
+      if (first[i] < next) marker[first[i]] = j + 1;       // distinct j write distinct slots
+    }
+  }
+  __syncthreads();
+
+  // ---- idx[k] = running maximum of the markers ------------------------------------------------
+  int best[C];
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      const int4 packed = reinterpret_cast<const int4 *>(marker + j0)[q];
+      best[4 * q] = packed.x;
+      best[4 * q + 1] = packed.y;
+      best[4 * q + 2] = packed.z;
+      best[4 * q + 3] = packed.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) best[i] = marker[j0 + i];
+  }
+  int acc = 0;
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    acc = max(acc, best[i]);
+    best[i] = acc;
+  }
+  int incl_max = acc;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int y = __shfl_up(incl_max, off, kWave);
+    if (lane >= off) incl_max = max(incl_max, y);
+  }
+  int before = __shfl_up(incl_max, 1, kWave);
+  if (lane == 0) before = 0;
+  if (lane == kWave - 1) scratch_i[wave] = incl_max;
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) before = max(before, scratch_i[w]);
+  if (j0 + C <= K && (((uintptr_t)(idx + j0)) & 15u) == 0) {
+#pragma unroll
+    for (int i = 0; i < C; i += 2) {
+      longlong2 pair;
+      pair.x = (int64_t)max(before, best[i]);
+      pair.y = (int64_t)max(before, best[i + 1]);
+      *reinterpret_cast<longlong2 *>(idx + j0 + i) = pair;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+      if (j0 + i < K) idx[j0 + i] = (int64_t)max(before, best[i]);
+  }
+}
+
 static int pick_threads(int64_t K, int chunk) {
   int64_t nt = (K + chunk - 1) / chunk;  // one round when it fits
   nt = (nt + kWave - 1) / kWave * kWave;
@@ -240,45 +435,46 @@ static int pick_threads(int64_t K, int chunk) {
   return (int)nt;
 }
 
-template <typename T, int CHUNK>
-static int launch_chunk(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
-                        int64_t K, void *ws, size_t ws_bytes, hipStream_t s) {
-  const int nt = pick_threads(K, CHUNK);
-  if (K <= kLdsMaxParticles) {
-    const size_t lds = (size_t)(cdf_row_slots(K) + kScratchDoubles) * sizeof(double);
-    static bool attr_set = false;  // raise the dynamic-LDS cap once per process and instantiation
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void *)ancestor_index_kernel<T, CHUNK, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return AESMC_ERR_LAUNCH;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((ancestor_index_kernel<T, CHUNK, true>), dim3((unsigned)B), dim3(nt), lds, s,
-                       (const T *)log_w, u, idx, flags, (int)K, (double *)nullptr);
-  } else {
-    if (ws == nullptr || ws_bytes < aesmc_workspace_bytes(B, K)) return AESMC_ERR_WORKSPACE;
-    const size_t lds = (size_t)kScratchDoubles * sizeof(double);
-    hipLaunchKernelGGL((ancestor_index_kernel<T, CHUNK, false>), dim3((unsigned)B), dim3(nt), lds, s,
-                       (const T *)log_w, u, idx, flags, (int)K, (double *)ws);
+template <typename T, int C>
+static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
+                      int64_t K, hipStream_t s) {
+  const int nt = pick_threads(K, C);
+  const size_t lds = (size_t)kScratchDoubles * sizeof(double) + (size_t)(nt * C + nt + 8) * sizeof(int);
+  static bool attr_set = false;  // raise the dynamic-LDS cap once per process and instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return AESMC_ERR_LAUNCH;
+    attr_set = true;
   }
+  hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C>), dim3((unsigned)B), dim3(nt), lds, s,
+                     (const T *)log_w, u, idx, flags, (int)K);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
-// Fewer particles per lane for short rows: more lanes per row hide latency when K is small.
+// Particles per lane grow with the row so that one workgroup (<= 1024 lanes) covers it; beyond
+// 32768 particles the CDF no longer fits registers + LDS and goes through the caller's workspace.
 template <typename T>
 static int launch(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
                   int64_t K, void *ws, size_t ws_bytes, hipStream_t s) {
-  if (K >= 2048) return launch_chunk<T, 8>(log_w, u, idx, flags, B, K, ws, ws_bytes, s);
-  if (K >= 512) return launch_chunk<T, 4>(log_w, u, idx, flags, B, K, ws, ws_bytes, s);
-  return launch_chunk<T, 2>(log_w, u, idx, flags, B, K, ws, ws_bytes, s);
+  if (K <= 512) return launch_inv<T, 2>(log_w, u, idx, flags, B, K, s);
+  if (K <= 2048) return launch_inv<T, 4>(log_w, u, idx, flags, B, K, s);
+  if (K <= 8192) return launch_inv<T, 8>(log_w, u, idx, flags, B, K, s);
+  if (K <= 16384) return launch_inv<T, 16>(log_w, u, idx, flags, B, K, s);
+  if (K <= kInvMaxParticles) return launch_inv<T, 32>(log_w, u, idx, flags, B, K, s);
+  if (ws == nullptr || ws_bytes < aesmc_workspace_bytes(B, K)) return AESMC_ERR_WORKSPACE;
+  const size_t lds = (size_t)kScratchDoubles * sizeof(double);
+  hipLaunchKernelGGL((ancestor_index_kernel<T, 8, false>), dim3((unsigned)B), dim3(kMaxThreads), lds, s,
+                     (const T *)log_w, u, idx, flags, (int)K, (double *)ws);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
 }  // namespace aesmc
 
-extern "C" int64_t aesmc_ancestor_index_lds_max_particles(void) { return aesmc::kLdsMaxParticles; }
+extern "C" int64_t aesmc_ancestor_index_lds_max_particles(void) { return aesmc::kInvMaxParticles; }
 
 extern "C" size_t aesmc_workspace_bytes(int64_t B, int64_t K) {
-  if (B <= 0 || K <= aesmc::kLdsMaxParticles) return 0;
+  if (B <= 0 || K <= aesmc::kInvMaxParticles) return 0;
   return (size_t)B * (size_t)aesmc::cdf_row_slots(K) * sizeof(double);
 }
 

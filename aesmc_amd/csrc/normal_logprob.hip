@@ -133,9 +133,175 @@ __global__ __launch_bounds__(kLpBlock) void normal_lps_bwd_kernel(
   }
 }
 
+// Small D, SCALAR scale (one value for the whole tensor — Normal(loc, 0.7)), and `value` and / or
+// `loc` dense ([K, D] contiguous inside a batch row): the dense operands are streamed with 16-byte
+// loads; log(scale) and 2*scale^2 are formed once per lane.  Same arithmetic, same LDS reduction.
+template <typename T, bool VALUE_DENSE, bool LOC_DENSE>
+__global__ __launch_bounds__(kLpBlock) void normal_lps_tile_vec_kernel(
+    const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ scale,
+    T *__restrict__ out, uint32_t K, uint32_t D, uint32_t P, uint32_t tiles_per_row, Strides3 sv,
+    Strides3 sm) {
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lps_smem[];
+  T *tile = reinterpret_cast<T *>(lps_smem);
+  const uint32_t b = blockIdx.x / tiles_per_row;
+  const uint32_t k0 = (blockIdx.x - b * tiles_per_row) * P;
+  const uint32_t np = min(P, K - k0);
+  const uint32_t ne = np * D;
+  const T *vb = value + (int64_t)b * sv.b;
+  const T *mb = loc + (int64_t)b * sm.b;
+  const T sigma = scale[0];
+  const T two_var = T(2) * (sigma * sigma);
+  const T log_sigma = Num<T>::log(sigma);
+  const T half_log_2pi = NormConst<T>::half_log_2pi();
+
+  const uint32_t nvec = ne / N;
+  uint32_t e = threadIdx.x * N;
+  uint32_t kk = e / D, j = e - kk * D;
+  const uint32_t step = kLpBlock * N, dk = step / D, dj = step - dk * D;
+  for (uint32_t v = threadIdx.x; v < nvec; v += kLpBlock) {
+    T x[N], m[N];
+    if constexpr (VALUE_DENSE) {
+      const V packed = *reinterpret_cast<const V *>(vb + (int64_t)k0 * sv.k + e);
+#pragma unroll
+      for (int q = 0; q < N; ++q) x[q] = Vec16<T>::get(packed, q);
+    }
+    if constexpr (LOC_DENSE) {
+      const V packed = *reinterpret_cast<const V *>(mb + (int64_t)k0 * sm.k + e);
+#pragma unroll
+      for (int q = 0; q < N; ++q) m[q] = Vec16<T>::get(packed, q);
+    }
+    if constexpr (!VALUE_DENSE || !LOC_DENSE) {
+      uint32_t k2 = kk, j2 = j;
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const int64_t k = (int64_t)k0 + k2;
+        if constexpr (!VALUE_DENSE) x[q] = vb[k * sv.k + (int64_t)j2 * sv.d];
+        if constexpr (!LOC_DENSE) m[q] = mb[k * sm.k + (int64_t)j2 * sm.d];
+        if (++j2 == D) {
+          j2 = 0;
+          ++k2;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const T diff = x[q] - m[q];
+      tile[pad_index(e + q)] = (-(diff * diff)) / two_var - log_sigma - half_log_2pi;
+    }
+    e += step;
+    kk += dk;
+    j += dj;
+    if (j >= D) {
+      j -= D;
+      ++kk;
+    }
+  }
+  for (uint32_t t = nvec * N + threadIdx.x; t < ne; t += kLpBlock) {  // at most N - 1 leftovers
+    const uint32_t k2 = t / D, j2 = t - k2 * D;
+    const int64_t k = (int64_t)k0 + k2;
+    const T diff = vb[k * sv.k + (int64_t)j2 * sv.d] - mb[k * sm.k + (int64_t)j2 * sm.d];
+    tile[pad_index(t)] = (-(diff * diff)) / two_var - log_sigma - half_log_2pi;
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < np; p += kLpBlock) {
+    T sum = T(0);
+    const uint32_t base = p * D;
+    for (uint32_t jj = 0; jj < D; ++jj) sum += tile[pad_index(base + jj)];
+    out[(int64_t)b * K + k0 + p] = sum;
+  }
+}
+
+// Large D, dense value and loc rows, scalar scale: TPR lanes per particle, each streaming 16-byte
+// vectors of the row; partial sums meet by shuffles inside the TPR-lane team.
+template <typename T, int TPR>
+__global__ __launch_bounds__(kLpBlock) void normal_lps_row_vec_kernel(
+    const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ scale,
+    T *__restrict__ out, int64_t particles, uint32_t K, uint32_t D, Strides3 sv, Strides3 sm) {
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const int64_t p = (int64_t)blockIdx.x * (kLpBlock / TPR) + threadIdx.x / TPR;
+  const int t = threadIdx.x % TPR;
+  T sum = T(0);
+  if (p < particles) {
+    const int64_t b = p / K, k = p - b * K;
+    const V *vp = reinterpret_cast<const V *>(value + b * sv.b + k * sv.k);
+    const V *mp = reinterpret_cast<const V *>(loc + b * sm.b + k * sm.k);
+    const T sigma = scale[0];
+    const T two_var = T(2) * (sigma * sigma);
+    const T log_sigma = Num<T>::log(sigma);
+    for (uint32_t v = t; v < D / N; v += TPR) {
+      const V x = vp[v], m = mp[v];
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const T diff = Vec16<T>::get(x, q) - Vec16<T>::get(m, q);
+        sum += (-(diff * diff)) / two_var - log_sigma - NormConst<T>::half_log_2pi();
+      }
+    }
+  }
+#pragma unroll
+  for (int off = TPR / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+  if (t == 0 && p < particles) out[p] = sum;
+}
+
+static inline bool is_scalar(const Strides3 &s) { return s.b == 0 && s.k == 0 && s.d == 0; }
+
+template <typename T>
+static inline bool is_dense(const void *ptr, const Strides3 &s, int64_t D) {
+  constexpr int N = Vec16<T>::N;
+  return s.d == 1 && s.k == D && (s.b % N) == 0 && (((uintptr_t)ptr) & 15u) == 0;
+}
+
 template <typename T>
 static int launch_lps(const void *value, const void *loc, const void *scale, void *out, int64_t B,
                       int64_t K, int64_t D, Strides3 sv, Strides3 sm, Strides3 ss, hipStream_t s) {
+  constexpr int N = Vec16<T>::N;
+  const bool vdense = is_dense<T>(value, sv, D), ldense = is_dense<T>(loc, sm, D);
+  // the row kernel only needs each particle's D values contiguous and 16-byte aligned; the row
+  // itself may be anywhere (e.g. an observation broadcast over particles: particle stride 0)
+  auto rows_ok = [&](const void *ptr, const Strides3 &st) {
+    return st.d == 1 && st.k % N == 0 && st.b % N == 0 && (((uintptr_t)ptr) & 15u) == 0;
+  };
+  if (D > 64 && D % N == 0 && is_scalar(ss) && rows_ok(value, sv) && rows_ok(loc, sm)) {
+    const int64_t particles = B * K;
+    const int tpr = D / N <= 16 ? 16 : (D / N <= 32 ? 32 : 64);
+    const int64_t blocks = (particles + (kLpBlock / tpr) - 1) / (kLpBlock / tpr);
+    if (blocks > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)blocks), block(kLpBlock);
+    auto X = (const T *)value;
+    auto M = (const T *)loc;
+    auto S = (const T *)scale;
+    if (tpr == 16)
+      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 16>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm);
+    else if (tpr == 32)
+      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 32>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm);
+    else
+      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 64>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm);
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
+  if (D <= 64 && is_scalar(ss) && (vdense || ldense)) {
+    uint32_t P = (uint32_t)((kTileBytes / (int)sizeof(T)) / D);
+    if (P > 256) P = 256;
+    if (P > K) P = (uint32_t)K;
+    const uint32_t tiles = (uint32_t)((K + P - 1) / P);
+    // a dense operand's tile must start on a 16-byte boundary: P*D (tile pitch) and K*D (row pitch)
+    if ((uint64_t)B * tiles <= 0x7fffffffull && (tiles == 1 || ((uint64_t)P * D) % N == 0)) {
+      const uint32_t ne = P * (uint32_t)D;
+      const size_t lds = (size_t)(ne + (ne >> 5) + 1) * sizeof(T);
+      dim3 grid((unsigned)(B * tiles)), block(kLpBlock);
+      auto X = (const T *)value;
+      auto M = (const T *)loc;
+      auto S = (const T *)scale;
+      if (vdense && ldense)
+        hipLaunchKernelGGL((normal_lps_tile_vec_kernel<T, true, true>), grid, block, lds, s, X, M, S, (T *)out, (uint32_t)K, (uint32_t)D, P, tiles, sv, sm);
+      else if (vdense)
+        hipLaunchKernelGGL((normal_lps_tile_vec_kernel<T, true, false>), grid, block, lds, s, X, M, S, (T *)out, (uint32_t)K, (uint32_t)D, P, tiles, sv, sm);
+      else
+        hipLaunchKernelGGL((normal_lps_tile_vec_kernel<T, false, true>), grid, block, lds, s, X, M, S, (T *)out, (uint32_t)K, (uint32_t)D, P, tiles, sv, sm);
+      return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+    }
+  }
   if (D <= 64) {
     uint32_t P = (uint32_t)((kTileBytes / (int)sizeof(T)) / D);
     if (P > 256) P = 256;

@@ -259,6 +259,13 @@ def main():
                     "traffic": traffic, "avg_launch_us": round(dominant["avg_us"], 2),
                     "algorithmic_bytes_per_launch": dominant["bytes_per_launch"],
                     "launches": dominant["launches"]}
+        if "unique_ancestor_fraction" in dominant:
+            # `achieved` prices a full read of the source; with a collapsed particle
+            # system only the surviving rows are fetched, so it can exceed what HBM moved: the
+            # surviving fraction and the bytes that did move on these operands are stated beside it.
+            roofline["unique_ancestor_fraction"] = round(dominant["unique_ancestor_fraction"], 4)
+            roofline["achieved_moved_bytes"] = round(dominant["moved_GBps"], 1)
+            roofline["frac_moved_bytes"] = round(dominant["moved_GBps"] / HBM_PEAK_GBPS, 4)
 
     out = {
         "metric": "particle_steps_per_sec", "value": value, "unit": "particle-steps/s",
