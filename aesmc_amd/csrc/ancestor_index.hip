@@ -3,26 +3,23 @@
 // Replaces aesmc/inference.py:234-269 (+ aesmc/math.py:33-51, numpy branch): the reference copies
 // the log-weights to the host, runs scipy logsumexp / np.exp / np.cumsum and a Python loop of
 // np.digitize per batch row, then copies int64 indices back.  Here one workgroup owns one batch row
-// and every lane owns kChunk (8, 4 or 2) CONSECUTIVE particles (blocked layout: a wavefront reads /
-// writes one contiguous span, and the scan needs one cross-lane step per kChunk particles):
+// and every lane owns C CONSECUTIVE particles (blocked layout: a wavefront reads / writes one
+// contiguous span, and a scan needs one cross-lane step per C particles, not per particle).
 //
-//   pass 1  row maximum + NaN scan                        (coalesced reads, shuffle + LDS reduce)
-//   pass 2  w = exp(lw - max) in float64; per-lane running sums in registers; one wavefront scan
-//           of the lane totals (shuffles); wavefront totals through LDS; unnormalised CDF -> LDS
-//   pass 3  c = CDF / total, correctly rounded (c[K-1] == 1.0 as in the reference's c / max(c))
-//   pass 4  idx[k] = #{ j : c[j] <= (u + k) / K }: binary search for a lane's first particle,
-//           exponential (galloping) search from the previous answer for the next ones — ancestors
-//           are monotone in k, so consecutive particles land a few slots apart
+// Two kernels share the arithmetic helpers below:
+//   * ancestor_index_inv_kernel (K <= 32768, the one that runs in practice): CDF entries stay in
+//     registers; ancestor indices come from inverting the CDF per SOURCE particle and an int32
+//     max-scan over the positions — no search (see the comment above the kernel);
+//   * ancestor_index_kernel (larger K): the float64 CDF is stored (caller workspace) and every
+//     position searches it, galloping from the previous particle's answer.
 //
-// The CDF lives in LDS (8 B x K, padded; up to 160 KiB -> K <= kLdsMaxParticles); larger K uses a
-// caller-supplied global workspace with the same code path.  Float64 inside regardless of the I/O
-// dtype: the result then does not depend on the scan's association order (SURVEY.md section 7,
-// hard part 1) and matches the reference bit-for-bit on float64 inputs.
-//
-// The kernel is VALU-bound on float64 arithmetic (rocprofv3: ~230 VALU instructions per particle
-// in the first, strided version), hence: a short exp() specialised to arguments <= 0, and both
-// per-particle divisions done as reciprocal + two FMAs, which still yields the correctly rounded
-// quotient (Markstein's theorem; verified against true division in tests/test_oracle.py).
+// Float64 inside regardless of the I/O dtype: the result then does not depend on the scan's
+// association order (hard part 1) and matches the reference bit-for-bit on
+// float64 inputs.  The kernels are VALU-bound on float64 arithmetic (rocprofv3: ~230 VALU
+// instructions per particle in the first, strided + binary-search version), hence: a short exp()
+// specialised to arguments <= 0, and the per-particle divisions done as reciprocal + two FMAs,
+// which still yields the correctly rounded quotient (Markstein's theorem; verified against true
+// division in exact rational arithmetic in tests/test_oracle.py).
 #include "common.hpp"
 
 namespace aesmc {
@@ -33,8 +30,6 @@ constexpr int kScratchDoubles = 64;  // per-workgroup LDS scratch (wavefront tot
 // pad turns the 64-byte lane stride into 72 bytes, which spreads the lanes over the LDS banks.
 __host__ __device__ __forceinline__ int64_t cdf_slot(int64_t e) { return e + (e >> 3); }
 __host__ __device__ __forceinline__ int64_t cdf_row_slots(int64_t K) { return cdf_slot(K) + 1; }
-// 160 KiB LDS per workgroup on gfx950, 1 KiB kept free: K + K/8 + 1 + scratch doubles must fit.
-constexpr int64_t kLdsMaxParticles = (((160 * 1024 - 1024) / 8 - kScratchDoubles - 2) * 8) / 9;
 
 // exp(x) for x <= 0 in float64: Cody-Waite reduction x = n ln2 + r, |r| <= ln2 / 2, degree-13
 // Taylor polynomial (truncation < 5e-18 relative), scaling by v_ldexp_f64.  exp(0) == 1 exactly.
