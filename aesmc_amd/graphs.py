@@ -25,6 +25,7 @@ capture could not be closed.
 import contextlib
 import gc
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -34,28 +35,45 @@ from . import inference
 
 
 class _StaticUniformFeed:
-    """Uniform feed whose pinned host block [T-1, B] and device block live as long as the graph;
-    the graph's resampling kernels read rows of the device block."""
+    """Uniform feed whose device block [T-1, B] lives as long as the graph (its resampling kernels
+    read rows of it) and is refreshed from one of two pinned host blocks before each replay, so the
+    host can draw the next evaluation's numbers while the previous upload is still in flight."""
 
     def __init__(self, batch_size, num_draws, device):
         self.batch_size = batch_size
         self.num_draws = max(num_draws, 1)
-        self.host = torch.empty((self.num_draws, batch_size), dtype=torch.float64, pin_memory=True)
+        self.host = [torch.empty((self.num_draws, batch_size), dtype=torch.float64, pin_memory=True)
+                     for _ in range(2)]
+        self.uploaded = [None, None]    # event after the last upload out of each pinned block
+        self.turn = 0
         self.dev = torch.empty((self.num_draws, batch_size), dtype=torch.float64, device=device)
         self.cursor = 0
 
-    def refill(self):
-        """Draws this evaluation's blocks in timestep order (the eager loop's RNG consumption)."""
-        for step in range(self.num_draws):
-            self.host[step].copy_(torch.from_numpy(inference.draw_uniform_block(self.batch_size)))
+    def refill_and_upload(self):
+        """Draws this evaluation's T-1 blocks — ONE numpy call, which consumes the global
+        RandomState exactly like T-1 successive np.random.uniform(size=[B, 1]) calls of the eager
+        loop (inside `distributed.shard_scope`: global batch, own rows kept) — and enqueues the
+        host -> device copy ahead of the replay, outside the graph (a pinned-memory copy node inside a
+        capture trips the host allocator's event tracking)."""
+        slot = self.turn
+        self.turn ^= 1
+        if self.uploaded[slot] is not None:
+            self.uploaded[slot].synchronize()   # two evaluations ago: long done
+        shard = distributed.active_shard()
+        if shard is None:
+            block = np.random.uniform(size=[self.num_draws, self.batch_size, 1])[:, :, 0]
+        else:
+            global_batch, lo, hi = shard
+            assert hi - lo == self.batch_size, "shard_scope does not match the local batch"
+            block = np.random.uniform(size=[self.num_draws, global_batch, 1])[:, lo:hi, 0]
+        self.host[slot].copy_(torch.from_numpy(np.ascontiguousarray(block)))
+        self.dev.copy_(self.host[slot], non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(self.dev.device))
+        self.uploaded[slot] = event
 
     def begin(self):
         self.cursor = 0
-
-    def upload(self):
-        """Host -> device copy of the whole block, issued OUTSIDE the graph before each replay (a
-        pinned-memory copy node inside a capture trips the host allocator's event tracking)."""
-        self.dev.copy_(self.host, non_blocking=True)
 
     def next(self):
         row = self.dev[self.cursor]
@@ -131,7 +149,6 @@ class GraphedLoss:
         with torch.cuda.graph(self.graph, capture_error_mode=error_mode):
             self.static_loss = self._evaluate(refill=False)
         self.replays = 0
-        self._done = None
 
     def _shard_scope(self):
         return distributed.shard_scope(*self.shard) if self.shard else contextlib.nullcontext()
@@ -139,8 +156,7 @@ class GraphedLoss:
     def _refill(self):
         if self.feed is not None:
             with self._shard_scope():
-                self.feed.refill()
-            self.feed.upload()
+                self.feed.refill_and_upload()
 
     def _evaluate(self, refill):
         num_particles, algorithm, initial, transition, emission, proposal = self._args
@@ -162,21 +178,23 @@ class GraphedLoss:
             inference._FEED_OVERRIDE = previous
         return loss.detach()
 
+    def check(self):
+        """Synchronising read of the device status word; raises what `inference.infer` would have
+        raised for any replay since the last check (with check_flags=False call it yourself, e.g.
+        once per logging interval, and the replays run back to back without a host sync)."""
+        inference._raise_for_flags(_kernels.get().read_flags(self.device))
+
     def __call__(self, observations=None):
         """Replays the graph (after copying `observations`, if given, into the static inputs) and
         returns the static loss tensor; parameter gradients, when captured, are in `.grad`."""
         if observations is not None:
             for static, fresh in zip(self.static_observations, observations):
                 static.copy_(fresh, non_blocking=True)
-        if self._done is not None:
-            self._done.synchronize()   # the previous replay must have consumed the pinned uniforms
-        self._refill()
+        self._refill()      # stream order keeps the upload behind the previous replay's reads
         self.graph.replay()
-        self._done = torch.cuda.Event()
-        self._done.record(torch.cuda.current_stream(self.device))
         self.replays += 1
         if self.check_flags:
-            inference._raise_for_flags(_kernels.get().read_flags(self.device))
+            self.check()
         if self.shard and dist.is_available() and dist.is_initialized():
             total = self.static_loss.clone()
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)

@@ -108,6 +108,24 @@ def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", budget_s=20.0):
             "loss": loss}
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on stdout when the first communicator is created; the contract
+    is ONE JSON line on stdout, so the banner is steered to stderr (file-descriptor level)."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,7 +146,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)          # creates the communicator now (and prints its banner)
+            torch.cuda.synchronize()
 
     description, kind, dim, B, K, T = WORKLOADS[args.workload]
     algorithm = ALGORITHM.get(args.workload, "aesmc")
@@ -189,7 +211,9 @@ def main():
         try:
             from aesmc_amd import graphs
             with grad_mode():
-                graphed = graphs.GraphedLoss(observations, K, algorithm, *parts, shard=shard)
+                # check_flags=False: replays run back to back; the device status word (NaN weights,
+                # degenerate rows, ...) is read once after each timed region instead of every step
+                graphed = graphs.GraphedLoss(observations, K, algorithm, *parts, shard=shard, check_flags=False)
             mode = "hipgraph"
         except Exception as error:  # capture is an optimisation: report and fall back to eager
             graph_error = "{}: {}".format(type(error).__name__, error)
@@ -199,6 +223,8 @@ def main():
     for _ in range(args.warmup):
         forward()
     seconds, loss = timed(forward, args.steps)
+    if graphed is not None:
+        graphed.check()
     ms_per_step = 1e3 * seconds / args.steps
     value = global_B * K * T * args.steps / seconds
 
@@ -212,11 +238,12 @@ def main():
     fwd_bwd = None
     if not args.no_backward:
         n = max(1, args.steps // 2)
-        train_step = None
+        train_step = graphed_train = None
         if graphed is not None:
             try:
                 from aesmc_amd import graphs
-                graphed_train = graphs.GraphedLoss(observations, K, algorithm, *parts, backward=True, shard=shard)
+                graphed_train = graphs.GraphedLoss(observations, K, algorithm, *parts, backward=True, shard=shard,
+                                                   check_flags=False)
                 params = list(model.parameters())
 
                 def train_step():
@@ -227,12 +254,14 @@ def main():
             except Exception as error:
                 graph_error = "backward capture: {}: {}".format(type(error).__name__, error)
                 torch.cuda.synchronize()
-                train_step = None
+                train_step = graphed_train = None
         if train_step is None:
             def train_step():
                 return step(backward=True)
         train_step()
         sb, _ = timed(train_step, n)
+        if graphed_train is not None and train_step is not None:
+            graphed_train.check()
         fwd_bwd = global_B * K * T * n / sb
 
     # ---- per-kernel timing: the same steps again with HIP events around every launch ------------
