@@ -23,6 +23,13 @@ F32, F64 = 0, 1
 
 _vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 
+
+class View3(ctypes.Structure):
+    """`aesmc_view3` of include/aesmc_hip.h: a [B,K,D] view by element strides (0 = broadcast)."""
+    _fields_ = [("ptr", ctypes.c_void_p), ("stride_b", ctypes.c_int64), ("stride_k", ctypes.c_int64),
+                ("stride_d", ctypes.c_int64)]
+
+
 # name -> (restype, argtypes); mirrors include/aesmc_hip.h one to one.
 SIGNATURES = {
     "aesmc_version": (_i32, []),
@@ -36,6 +43,7 @@ SIGNATURES = {
     "aesmc_resample_gather_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "aesmc_normal_logprob_sum": (_i32, [_i32, _vp, _vp, _vp, _vp] + [_i64] * 12 + [_vp]),
     "aesmc_normal_logprob_sum_backward": (_i32, [_i32] + [_vp] * 7 + [_i64] * 12 + [_vp]),
+    "aesmc_normal_logweight": (_i32, [_i32, ctypes.POINTER(View3), _vp, _i64, _i64, _i64, _i64, _vp]),
 }
 
 _lib = None

@@ -75,6 +75,41 @@ def normal_log_prob_sum(value, loc, scale):
     return _kernels.get().normal_logprob_sum(value.detach(), loc.detach(), scale.detach())
 
 
+class _NormalLogWeight(torch.autograd.Function):
+    """lw = logN(x; p) + logN(y; g) - logN(x; q) through kernel K5; backward through K4's."""
+
+    @staticmethod
+    def forward(ctx, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
+        out = _kernels.get().normal_logweight(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q)
+        if out is None:
+            raise RuntimeError("aesmc_amd: fused log-weight kernel rejected operands it was offered")
+        ctx.save_for_backward(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        k = _kernels.get()
+        grad = grad.contiguous()
+        gx_p, g_loc_p, g_scale_p = k.normal_logprob_sum_backward(x, loc_p, scale_p, grad, need[0], need[1], need[2])
+        g_y, g_loc_g, g_scale_g = k.normal_logprob_sum_backward(y, loc_g, scale_g, grad, need[3], need[4], need[5])
+        gx_q, g_loc_q, g_scale_q = k.normal_logprob_sum_backward(x, loc_q, scale_q, -grad, need[0], need[6], need[7])
+        gx = gx_p + gx_q if need[0] else None
+        return gx, g_loc_p, g_scale_p, g_y, g_loc_g, g_scale_g, g_loc_q, g_scale_q
+
+
+def normal_log_weight(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
+    """[B,K] log-weight of one step for three Normal terms (kernel K5), or None if K5 does not
+    cover the operands (the caller then sums three K4 terms through K1: same numbers)."""
+    tensors = (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q)
+    if not _kernels.get().normal_logweight_covers(x, scale_p, y, scale_g, scale_q):
+        return None
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return _NormalLogWeight.apply(*tensors)
+    return _kernels.get().normal_logweight(*[t.detach() for t in tensors])
+
+
 def logweight_lse(a, b=None, c=None):
     """Returns (log_weight [B,K], logsumexp over particles [B]) for log_weight = a + b - c."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (a, b, c)):

@@ -337,6 +337,184 @@ static int launch_lps_bwd(const void *value, const void *loc, const void *scale,
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
+// K5: the whole log-weight of one SMC step when prior / transition, emission and proposal are all
+// Normal with scalar scales:
+//   lw[b,k] = sum_j log N(x; mu_p, s_p) + sum_j log N(y; mu_g, s_g) - sum_j log N(x; mu_q, s_q)
+// One pass instead of three K4 launches and K1's combine: x is read once for both of its terms.
+// The three d-sums are formed separately, each in K4's order, and combined as (p + g) - q exactly
+// like aesmc/inference.py:125-126, so the result is bit-identical to the unfused route.
+struct View3 {
+  const void *ptr;
+  Strides3 st;
+};
+
+template <typename T>
+__device__ __forceinline__ T load_view(const View3 &v, int64_t b, int64_t k, uint32_t j) {
+  return reinterpret_cast<const T *>(v.ptr)[b * v.st.b + k * v.st.k + (int64_t)j * v.st.d];
+}
+
+// `dense` bit i set: operand i ([K,D] contiguous inside a batch row, 16-byte aligned tiles) is read
+// with 16-byte loads.  Bits: 0 x, 1 mu_p, 2 mu_q (extent Dx); 3 y, 4 mu_g (extent Dy).
+// STATIC_MASK >= 0 fixes the mask at compile time (the t > 0 layout of a Markov model: x, mu_p,
+// mu_q, mu_g dense, y broadcast = 0b10111), so the loads are straight-line code the compiler can
+// keep in flight together; -1 takes the mask from the argument.
+template <typename T, int STATIC_MASK>
+__global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
+    View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
+    T *__restrict__ out, uint32_t K, uint32_t Dx, uint32_t Dy, uint32_t P, uint32_t tiles_per_row,
+    uint32_t dense_arg) {
+  const uint32_t dense = STATIC_MASK >= 0 ? (uint32_t)STATIC_MASK : dense_arg;
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lps_smem[];
+  T *term_p = reinterpret_cast<T *>(lps_smem);                 // [P * Dx] (padded)
+  const uint32_t span_x = P * Dx + ((P * Dx) >> 5) + 1;
+  T *term_q = term_p + span_x;                                 // [P * Dx]
+  T *term_g = term_q + span_x;                                 // [P * Dy]
+  const uint32_t b = blockIdx.x / tiles_per_row;
+  const uint32_t k0 = (blockIdx.x - b * tiles_per_row) * P;
+  const uint32_t np = min(P, K - k0);
+  const T half_log_2pi = NormConst<T>::half_log_2pi();
+
+  {  // ---- the two terms in x ---------------------------------------------------------------------
+    const T s_p = reinterpret_cast<const T *>(sc_p.ptr)[0], s_q = reinterpret_cast<const T *>(sc_q.ptr)[0];
+    const T two_var_p = T(2) * (s_p * s_p), log_p = Num<T>::log(s_p);
+    const T two_var_q = T(2) * (s_q * s_q), log_q = Num<T>::log(s_q);
+    const uint32_t ne = np * Dx, nvec = ne / N;
+    const T *xt = reinterpret_cast<const T *>(x.ptr) + (int64_t)b * x.st.b + (int64_t)k0 * x.st.k;
+    const T *pt = reinterpret_cast<const T *>(mu_p.ptr) + (int64_t)b * mu_p.st.b + (int64_t)k0 * mu_p.st.k;
+    const T *qt = reinterpret_cast<const T *>(mu_q.ptr) + (int64_t)b * mu_q.st.b + (int64_t)k0 * mu_q.st.k;
+    uint32_t e = threadIdx.x * N;
+    uint32_t kk = e / Dx, j = e - kk * Dx;
+    const uint32_t step = kLpBlock * N, dk = step / Dx, dj = step - dk * Dx;
+    for (uint32_t v = threadIdx.x; v < nvec; v += kLpBlock) {
+      T xv[N], pv[N], qv[N];
+      if (dense & 1u) { const V t = *reinterpret_cast<const V *>(xt + e);
+#pragma unroll
+        for (int r = 0; r < N; ++r) xv[r] = Vec16<T>::get(t, r); }
+      if (dense & 2u) { const V t = *reinterpret_cast<const V *>(pt + e);
+#pragma unroll
+        for (int r = 0; r < N; ++r) pv[r] = Vec16<T>::get(t, r); }
+      if (dense & 4u) { const V t = *reinterpret_cast<const V *>(qt + e);
+#pragma unroll
+        for (int r = 0; r < N; ++r) qv[r] = Vec16<T>::get(t, r); }
+      if ((dense & 7u) != 7u) {
+        uint32_t k2 = kk, j2 = j;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+          const int64_t k = (int64_t)k0 + k2;
+          if (!(dense & 1u)) xv[r] = load_view<T>(x, b, k, j2);
+          if (!(dense & 2u)) pv[r] = load_view<T>(mu_p, b, k, j2);
+          if (!(dense & 4u)) qv[r] = load_view<T>(mu_q, b, k, j2);
+          if (++j2 == Dx) { j2 = 0; ++k2; }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const T dp = xv[r] - pv[r], dq = xv[r] - qv[r];
+        term_p[pad_index(e + r)] = (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
+        term_q[pad_index(e + r)] = (-(dq * dq)) / two_var_q - log_q - half_log_2pi;
+      }
+      e += step; kk += dk; j += dj;
+      if (j >= Dx) { j -= Dx; ++kk; }
+    }
+    for (uint32_t t = nvec * N + threadIdx.x; t < ne; t += kLpBlock) {
+      const uint32_t k2 = t / Dx, j2 = t - k2 * Dx;
+      const int64_t k = (int64_t)k0 + k2;
+      const T xv = load_view<T>(x, b, k, j2);
+      const T dp = xv - load_view<T>(mu_p, b, k, j2), dq = xv - load_view<T>(mu_q, b, k, j2);
+      term_p[pad_index(t)] = (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
+      term_q[pad_index(t)] = (-(dq * dq)) / two_var_q - log_q - half_log_2pi;
+    }
+  }
+  {  // ---- the emission term in y ----------------------------------------------------------------
+    const T s_g = reinterpret_cast<const T *>(sc_g.ptr)[0];
+    const T two_var_g = T(2) * (s_g * s_g), log_g = Num<T>::log(s_g);
+    const uint32_t ne = np * Dy, nvec = ne / N;
+    const T *yt = reinterpret_cast<const T *>(y.ptr) + (int64_t)b * y.st.b + (int64_t)k0 * y.st.k;
+    const T *gt = reinterpret_cast<const T *>(mu_g.ptr) + (int64_t)b * mu_g.st.b + (int64_t)k0 * mu_g.st.k;
+    uint32_t e = threadIdx.x * N;
+    uint32_t kk = e / Dy, j = e - kk * Dy;
+    const uint32_t step = kLpBlock * N, dk = step / Dy, dj = step - dk * Dy;
+    for (uint32_t v = threadIdx.x; v < nvec; v += kLpBlock) {
+      T yv[N], gv[N];
+      if (dense & 8u) { const V t = *reinterpret_cast<const V *>(yt + e);
+#pragma unroll
+        for (int r = 0; r < N; ++r) yv[r] = Vec16<T>::get(t, r); }
+      if (dense & 16u) { const V t = *reinterpret_cast<const V *>(gt + e);
+#pragma unroll
+        for (int r = 0; r < N; ++r) gv[r] = Vec16<T>::get(t, r); }
+      if ((dense & 24u) != 24u) {
+        uint32_t k2 = kk, j2 = j;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+          const int64_t k = (int64_t)k0 + k2;
+          if (!(dense & 8u)) yv[r] = load_view<T>(y, b, k, j2);
+          if (!(dense & 16u)) gv[r] = load_view<T>(mu_g, b, k, j2);
+          if (++j2 == Dy) { j2 = 0; ++k2; }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const T dg = yv[r] - gv[r];
+        term_g[pad_index(e + r)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
+      }
+      e += step; kk += dk; j += dj;
+      if (j >= Dy) { j -= Dy; ++kk; }
+    }
+    for (uint32_t t = nvec * N + threadIdx.x; t < ne; t += kLpBlock) {
+      const uint32_t k2 = t / Dy, j2 = t - k2 * Dy;
+      const int64_t k = (int64_t)k0 + k2;
+      const T dg = load_view<T>(y, b, k, j2) - load_view<T>(mu_g, b, k, j2);
+      term_g[pad_index(t)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < np; p += kLpBlock) {
+    T sum_p = T(0), sum_q = T(0), sum_g = T(0);
+    for (uint32_t jj = 0; jj < Dx; ++jj) {
+      sum_p += term_p[pad_index(p * Dx + jj)];
+      sum_q += term_q[pad_index(p * Dx + jj)];
+    }
+    for (uint32_t jj = 0; jj < Dy; ++jj) sum_g += term_g[pad_index(p * Dy + jj)];
+    out[(int64_t)b * K + k0 + p] = (sum_p + sum_g) - sum_q;
+  }
+}
+
+template <typename T>
+static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int64_t Dx, int64_t Dy,
+                            hipStream_t s) {
+  constexpr int N = Vec16<T>::N;
+  if (Dx > 64 || Dy > 64 || Dx < 1 || Dy < 1) return AESMC_ERR_UNSUPPORTED;
+  if (!is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st)) return AESMC_ERR_UNSUPPORTED;
+  uint32_t P = (uint32_t)((kTileBytes / (int)sizeof(T)) / (2 * Dx + Dy));
+  if (P > 256) P = 256;
+  if (P > K) P = (uint32_t)K;
+  if (P == 0) return AESMC_ERR_UNSUPPORTED;
+  const uint32_t tiles = (uint32_t)((K + P - 1) / P);
+  if ((uint64_t)B * tiles > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
+  auto dense = [&](const View3 &view, int64_t D) {
+    return is_dense<T>(view.ptr, view.st, D) && (tiles == 1 || ((uint64_t)P * D) % N == 0);
+  };
+  uint32_t mask = 0;
+  if (dense(v[0], Dx)) mask |= 1u;
+  if (dense(v[1], Dx)) mask |= 2u;
+  if (dense(v[6], Dx)) mask |= 4u;
+  if (dense(v[3], Dy)) mask |= 8u;
+  if (dense(v[4], Dy)) mask |= 16u;
+  const uint32_t ex = P * (uint32_t)Dx, ey = P * (uint32_t)Dy;
+  const size_t lds = (size_t)(2 * (ex + (ex >> 5) + 1) + ey + (ey >> 5) + 1) * sizeof(T);
+  if (mask == 23u)
+    hipLaunchKernelGGL((normal_logweight_kernel<T, 23>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
+                       v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
+                       (uint32_t)Dy, P, tiles, mask);
+  else
+    hipLaunchKernelGGL((normal_logweight_kernel<T, -1>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
+                       v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
+                       (uint32_t)Dy, P, tiles, mask);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
 }  // namespace aesmc
 
 extern "C" int aesmc_normal_logprob_sum(int dtype, const void *value, const void *loc,
@@ -377,5 +555,23 @@ extern "C" int aesmc_normal_logprob_sum_backward(
   if (dtype == AESMC_F64)
     return launch_lps_bwd<double>(value, loc, scale, grad_out, grad_value, grad_loc, grad_scale, B, K, D,
                                   sv, sm, ss, s);
+  return AESMC_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int aesmc_normal_logweight(int dtype, const aesmc_view3 *views, void *out_lw, int64_t B,
+                                      int64_t K, int64_t Dx, int64_t Dy, void *stream) {
+  using namespace aesmc;
+  if (views == nullptr || out_lw == nullptr || B < 0 || K < 0) return AESMC_ERR_INVALID_ARGUMENT;
+  View3 v[8];
+  for (int i = 0; i < 8; ++i) {
+    if (views[i].ptr == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+    v[i].ptr = views[i].ptr;
+    v[i].st = Strides3{views[i].stride_b, views[i].stride_k, views[i].stride_d};
+  }
+  if (B == 0 || K == 0) return AESMC_OK;
+  if (K >= (1ll << 31) || B >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AESMC_F32) return launch_logweight<float>(v, out_lw, B, K, Dx, Dy, s);
+  if (dtype == AESMC_F64) return launch_logweight<double>(v, out_lw, B, K, Dx, Dy, s);
   return AESMC_ERR_INVALID_ARGUMENT;
 }

@@ -208,21 +208,31 @@ def infer(inference_algorithm, observations, initial, transition, emission,
                                      observations=observations)
         latent = state.sample(proposal_dist, batch_size, num_particles)
         history.append(latent)
-        log_q = state.log_prob(proposal_dist, latent)
         if time == 0:
-            log_p = state.log_prob(initial(), latent)
+            prior_dist = initial()
             emission_dist = emission(latents=history, time=0)
         else:
-            log_p = state.log_prob(
-                transition(previous_latents=ancestors, time=time,
-                           previous_observations=observations[:time]), latent)
+            prior_dist = transition(previous_latents=ancestors, time=time,
+                                    previous_observations=observations[:time])
             emission_dist = emission(latents=history, time=time,
                                      previous_observations=observations[:time])
-        log_g = state.log_prob(emission_dist,
-                               state.expand_observation(observations[time], num_particles))
+        observation = state.expand_observation(observations[time], num_particles)
         if keep_originals:
             originals.append(latent)
-        log_weight_t, lse_t = _ops.logweight_lse(log_p, log_g, log_q)
+        # log-weight = log prior/transition + log emission - log proposal (inference.py:97-98,
+        # :125-126): one kernel when all three are Normal with scalar scales (K5), else three
+        # summed log-densities (K4 or the distribution's own log_prob) combined by K1
+        log_weight_t = None
+        if not isinstance(latent, dict) and not isinstance(observation, dict):
+            log_weight_t = state.normal_log_weight(prior_dist, proposal_dist, latent, emission_dist,
+                                                   observation)
+        if log_weight_t is not None:
+            lse_t = _ops.row_logsumexp(log_weight_t)
+        else:
+            log_q = state.log_prob(proposal_dist, latent)
+            log_p = state.log_prob(prior_dist, latent)
+            log_g = state.log_prob(emission_dist, observation)
+            log_weight_t, lse_t = _ops.logweight_lse(log_p, log_g, log_q)
         log_weights.append(log_weight_t)
         step_lse.append(lse_t)
         device = log_weight_t.device

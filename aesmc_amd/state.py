@@ -168,6 +168,35 @@ def log_prob(distribution, value):
     return logp.reshape(value.size(0), value.size(1), -1).sum(dim=2)
 
 
+def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observation):
+    """One step's log-weight  log_prob(prior, latent) + log_prob(emission, observation)
+    - log_prob(proposal, latent)  (aesmc/inference.py:112-126) in ONE kernel (K5) when all three
+    distributions are plain Normals with scalar scales on the HIP device; None otherwise — the
+    caller then takes three `log_prob` calls, which give bit-identical numbers.  `observation` is
+    already expanded over particles.  Validation is what the three `log_prob` calls would do."""
+    if not _FUSED_NORMAL:
+        return None
+    operands = []
+    for distribution, value in ((prior_dist, latent), (emission_dist, observation),
+                                (proposal_dist, latent)):
+        if not isinstance(distribution, torch.distributions.Distribution) or not torch.is_tensor(value):
+            return None
+        missing = (value.dim() - len(distribution.event_shape)) - len(distribution.batch_shape)
+        if missing not in (0, 1, 2):
+            return None  # let log_prob raise its RuntimeError
+        views = _fused_normal_views(distribution, value, missing)
+        if views is None:
+            return None
+        operands.append((distribution, value, missing, views))
+    for distribution, value, missing, _ in operands:
+        if missing != 1:
+            _validate_sample(distribution, value)
+        elif distribution._validate_args:
+            _validate_sample(distribution, value.transpose(0, 1))
+    (_, _, _, (loc_p, scale_p)), (_, _, _, (loc_g, scale_g)), (_, _, _, (loc_q, scale_q)) = operands
+    return _ops.normal_log_weight(latent, loc_p, scale_p, observation, loc_g, scale_g, loc_q, scale_q)
+
+
 _FUSED_NORMAL = True
 
 

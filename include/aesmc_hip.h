@@ -137,6 +137,26 @@ int aesmc_normal_logprob_sum_backward(int dtype, const void *value, const void *
                                       int64_t scale_sb, int64_t scale_sk, int64_t scale_sd,
                                       void *stream);
 
+/*
+ * K5 — the whole log-weight of one SMC step when the prior / transition, the emission and the
+ * proposal are all Normal with SCALAR scales (one value for the tensor, e.g. Normal(loc, 0.7)):
+ *   lw[b,k] = sum_j log N(x; mu_p, s_p) + sum_j log N(y; mu_g, s_g) - sum_j log N(x; mu_q, s_q)
+ * `views` points to eight [B,K,D] views in this order:
+ *   0 x (latent, extent Dx)   1 mu_p   2 s_p      (prior or transition)
+ *   3 y (observation, Dy)     4 mu_g   5 s_g      (emission)
+ *   6 mu_q (extent Dx)        7 s_q               (proposal, evaluated at x)
+ * Replaces three calls of K4 and the combine of K1 (aesmc/inference.py:112-126 via
+ * aesmc/state.py:114-155); bit-identical to that route.  Returns AESMC_ERR_UNSUPPORTED for
+ * extents above 64 or non-scalar scales: the caller then takes the K4 + K1 route.
+ */
+typedef struct aesmc_view3 {
+  const void *ptr;
+  int64_t stride_b, stride_k, stride_d; /* element strides, 0 = broadcast */
+} aesmc_view3;
+
+int aesmc_normal_logweight(int dtype, const aesmc_view3 *views, void *out_lw, int64_t B, int64_t K,
+                           int64_t Dx, int64_t Dy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -419,6 +419,85 @@ def test_normal_logprob_sum_strided_views(kernels, hip_device):
         torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("B,K,dx,dy", [(2, 16, 1, 1), (3, 37, 10, 10), (4, 300, 10, 4), (2, 1000, 3, 7),
+                                       (1, 257, 64, 64), (5, 64, 33, 2), (2, 4096, 10, 10)])
+def test_normal_logweight_is_bitwise_the_unfused_route(kernels, hip_device, dtype, B, K, dx, dy):
+    """K5 == K4 x 3 combined by K1, bit for bit, for the operand layouts the SMC loop produces."""
+    gen = torch.Generator(device=hip_device).manual_seed(B * K + dx)
+
+    def rand(*shape):
+        return torch.randn(*shape, device=hip_device, dtype=dtype, generator=gen)
+
+    scales = [torch.tensor(v, device=hip_device, dtype=dtype) for v in (1.0, 0.5, 0.7)]
+    layouts = [
+        # t > 0: dense latent, FULLY_EXPANDED transition / emission / proposal, observation expanded
+        dict(x=rand(B, K, dx), loc_p=rand(B, K, dx), y=rand(B, dy).unsqueeze(1).expand(B, K, dy),
+             loc_g=rand(B, K, dy), loc_q=rand(B, K, dx)),
+        # t = 0: transposed latent, NOT_EXPANDED prior, BATCH_EXPANDED proposal
+        dict(x=rand(K, B, dx).transpose(0, 1), loc_p=rand(dx).expand(B, K, dx),
+             y=rand(B, dy).unsqueeze(1).expand(B, K, dy), loc_g=rand(B, K, dy),
+             loc_q=rand(B, dx).unsqueeze(1).expand(B, K, dx)),
+        # sliced (non-dense) operands
+        dict(x=rand(B, 2 * K, dx)[:, ::2], loc_p=rand(B, K, dx + 1)[:, :, 1:], y=rand(B, K, dy),
+             loc_g=rand(B, K, dy), loc_q=rand(B, K, dx)),
+    ]
+    for lay in layouts:
+        sp, sg, sq = [s.expand(lay[k].shape) for s, k in zip(scales, ("x", "y", "x"))]
+        fused = kernels.normal_logweight(lay["x"], lay["loc_p"], sp, lay["y"], lay["loc_g"], sg, lay["loc_q"], sq)
+        assert fused is not None
+        log_p = kernels.normal_logprob_sum(lay["x"], lay["loc_p"], sp)
+        log_g = kernels.normal_logprob_sum(lay["y"], lay["loc_g"], sg)
+        log_q = kernels.normal_logprob_sum(lay["x"], lay["loc_q"], sq)
+        unfused, _ = kernels.logweight_lse(log_p, log_g, log_q)
+        assert torch.equal(fused, unfused)
+        eager = (torch.distributions.Normal(lay["loc_p"], scales[0]).log_prob(lay["x"]).sum(-1)
+                 + torch.distributions.Normal(lay["loc_g"], scales[1]).log_prob(lay["y"]).sum(-1)
+                 - torch.distributions.Normal(lay["loc_q"], scales[2]).log_prob(lay["x"]).sum(-1))
+        tol_ = 2e-5 if dtype == torch.float32 else 1e-12
+        torch.testing.assert_close(fused, eager, rtol=tol_, atol=tol_ * (dx + dy))
+
+
+def test_normal_logweight_declines_what_it_does_not_cover(kernels, hip_device):
+    B, K = 2, 8
+    x = torch.randn(B, K, 3, device=hip_device)
+    y = torch.randn(B, K, 3, device=hip_device)
+    one = torch.ones((), device=hip_device).expand(B, K, 3)
+    vector_scale = torch.ones(3, device=hip_device).expand(B, K, 3)
+    assert kernels.normal_logweight(x, x, vector_scale, y, y, one, x, one) is None       # non-scalar scale
+    wide = torch.randn(B, K, 65, device=hip_device)
+    one_w = torch.ones((), device=hip_device).expand(B, K, 65)
+    assert kernels.normal_logweight(wide, wide, one_w, y, y, one, wide, one_w) is None    # > 64 per particle
+    assert not kernels.normal_logweight_covers(x, vector_scale, y, one, one)
+    assert kernels.normal_logweight_covers(x, one, y, one, one)
+
+
+def test_normal_logweight_gradients_match_the_unfused_route(hip_device):
+    from aesmc_amd import _ops
+    B, K, d = 3, 50, 4
+    gen = torch.Generator(device=hip_device).manual_seed(0)
+    base = [torch.randn(B, K, d, device=hip_device, dtype=torch.float64, generator=gen) for _ in range(5)]
+    log_scales = torch.randn(3, device=hip_device, dtype=torch.float64, generator=gen) * 0.1
+    weights = torch.randn(B, K, device=hip_device, dtype=torch.float64, generator=gen)
+
+    def run(fused):
+        x, loc_p, y, loc_g, loc_q = [t.clone().requires_grad_() for t in base]
+        ls = log_scales.clone().requires_grad_()
+        sp, sg, sq = [ls[i].exp().expand(B, K, d) for i in range(3)]
+        if fused:
+            lw = _ops.normal_log_weight(x, loc_p, sp, y, loc_g, sg, loc_q, sq)
+        else:
+            lw = _ops.logweight_lse(_ops.normal_log_prob_sum(x, loc_p, sp), _ops.normal_log_prob_sum(y, loc_g, sg),
+                                    _ops.normal_log_prob_sum(x, loc_q, sq))[0]
+        (lw * weights).sum().backward()
+        return lw.detach(), [t.grad for t in (x, loc_p, y, loc_g, loc_q, ls)]
+
+    fused, unfused = run(True), run(False)
+    assert torch.equal(fused[0], unfused[0])
+    for a, b in zip(fused[1], unfused[1]):
+        torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+
+
 def test_full_size_normal_logprob_sum(kernels, hip_device):
     """North-star shape: B=1024, K=4096, d=10."""
     B, K, d = 1024, 4096, 10
