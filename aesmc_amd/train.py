@@ -1,72 +1,79 @@
 """Optimisation loop and synthetic data source with the interface of the reference's
-aesmc/train.py; `losses.get_loss` underneath runs the HIP hot path."""
+aesmc/train.py (train.py:10-71); `losses.get_loss` underneath runs the HIP hot path."""
 import itertools
 import sys
 
 import torch
 import torch.nn as nn
-import torch.utils.data
+from torch.utils.data import DataLoader, Dataset
 
 from . import losses
 from . import statistics
 
 
 def get_chained_params(*objects):
-    """Parameters of every nn.Module among `objects`, chained; None if there is none
-    (aesmc/train.py:10-19)."""
-    modules = [obj for obj in objects if isinstance(obj, nn.Module)]
-    if not modules:
+    """One iterator over the parameters of every `nn.Module` among `objects` (anything else —
+    plain callables, None — contributes nothing); None when there is no module at all."""
+    modules = [candidate for candidate in objects if isinstance(candidate, nn.Module)]
+    if len(modules) == 0:
         return None
-    return itertools.chain.from_iterable(module.parameters() for module in modules)
+    return itertools.chain.from_iterable(m.parameters() for m in modules)
+
+
+def _minibatches(dataloader, num_epochs, limit):
+    """(epoch, iteration, observations) triples: every epoch walks the dataloader afresh and stops
+    after `limit` minibatches when a limit is given.  As in the reference (train.py:29-32) the
+    batch that trips the limit has already been fetched when the epoch ends, so a generative
+    dataloader consumes its random stream identically."""
+    for epoch in range(num_epochs):
+        for iteration, observations in enumerate(dataloader):
+            if limit is not None and iteration == limit:
+                break
+            yield epoch, iteration, observations
 
 
 def train(dataloader, num_particles, algorithm, initial, transition, emission,
           proposal, num_epochs, num_iterations_per_epoch=None,
           optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
           callback=None):
-    """One optimiser over the parameters of the four model parts; per minibatch: zero_grad,
-    get_loss, backward, step, then callback(epoch_idx, epoch_iteration_idx, loss, initial,
-    transition, emission, proposal) (aesmc/train.py:22-41)."""
-    optimizer = optimizer_algorithm(
-        get_chained_params(initial, transition, emission, proposal), **optimizer_kwargs)
-    for epoch_idx in range(num_epochs):
-        for epoch_iteration_idx, observations in enumerate(dataloader):
-            if num_iterations_per_epoch is not None and \
-                    epoch_iteration_idx == num_iterations_per_epoch:
-                break
-            optimizer.zero_grad()
-            loss = losses.get_loss(observations, num_particles, algorithm, initial, transition,
-                                   emission, proposal)
-            loss.backward()
-            optimizer.step()
-            if callback is not None:
-                callback(epoch_idx, epoch_iteration_idx, loss, initial, transition, emission,
-                         proposal)
+    """Fits the model parts by stochastic gradient descent on `losses.get_loss`.
+
+    A single optimiser (`optimizer_algorithm(params, **optimizer_kwargs)`) owns the parameters of
+    all four parts.  Per minibatch: clear gradients, evaluate the loss ('iwae' or 'aesmc' with
+    `num_particles` particles), back-propagate, step; then, if given,
+    `callback(epoch_idx, epoch_iteration_idx, loss, initial, transition, emission, proposal)`.
+    Returns nothing, like the reference."""
+    model_parts = (initial, transition, emission, proposal)
+    optimizer = optimizer_algorithm(get_chained_params(*model_parts), **optimizer_kwargs)
+    for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
+        optimizer.zero_grad()
+        loss = losses.get_loss(observations, num_particles, algorithm, *model_parts)
+        loss.backward()
+        optimizer.step()
+        if callback is not None:
+            callback(epoch, iteration, loss, *model_parts)
 
 
-class SyntheticDataset(torch.utils.data.Dataset):
-    """Endless dataset: every item is a fresh length-num_timesteps list of [batch_size, ...]
-    observations drawn from the generative model (aesmc/train.py:44-62)."""
+class SyntheticDataset(Dataset):
+    """A dataset without end: whatever index is asked for, the item is a freshly simulated
+    sequence — a list of `num_timesteps` observation tensors [batch_size, ...] drawn from the
+    generative model (initial, transition, emission) through `statistics.sample_from_prior`."""
 
     def __init__(self, initial, transition, emission, num_timesteps, batch_size):
-        self.initial = initial
-        self.transition = transition
-        self.emission = emission
-        self.num_timesteps = num_timesteps
-        self.batch_size = batch_size
-
-    def __getitem__(self, index):
-        _, observations = statistics.sample_from_prior(
-            self.initial, self.transition, self.emission, self.num_timesteps, self.batch_size)
-        return [observation.detach().squeeze(0) for observation in observations]
+        self.initial, self.transition, self.emission = initial, transition, emission
+        self.num_timesteps, self.batch_size = num_timesteps, batch_size
 
     def __len__(self):
         return sys.maxsize
 
+    def __getitem__(self, index):
+        simulated = statistics.sample_from_prior(self.initial, self.transition, self.emission,
+                                                 self.num_timesteps, self.batch_size)
+        return [y.detach().squeeze(0) for y in simulated[1]]
+
 
 def get_synthetic_dataloader(initial, transition, emission, num_timesteps, batch_size):
-    """DataLoader over SyntheticDataset that yields one whole batch per iteration
-    (aesmc/train.py:65-71)."""
-    return torch.utils.data.DataLoader(
-        SyntheticDataset(initial, transition, emission, num_timesteps, batch_size),
-        batch_size=1, collate_fn=lambda items: items[0])
+    """DataLoader whose every iteration yields one whole simulated batch (the loader's own batch
+    size is 1 and its collate function unwraps that single item)."""
+    dataset = SyntheticDataset(initial, transition, emission, num_timesteps, batch_size)
+    return DataLoader(dataset, batch_size=1, collate_fn=lambda items: items[0])

@@ -218,6 +218,48 @@ def case_resampler(name, log_weight, seed):
         name, mismatches, idx.numel(), os.path.getsize(path)))
 
 
+def case_train(name, algorithm, seed=9):
+    """aesmc.train.train driven end to end by the reference (its SyntheticDataset, its optimiser
+    loop): pins RNG consumption order of data generation + inference across steps and epochs."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    if algorithm == "iwae":
+        true_parts = (ref_gaussian.Prior(1.0, 1.0), None, ref_gaussian.Likelihood(0.5))
+        parts = {"initial": ref_gaussian.Prior(0.0, 1.0), "transition": None,
+                 "emission": ref_gaussian.Likelihood(1.0),
+                 "proposal": ref_gaussian.InferenceNetwork(0.1, 0.0, 1.5)}
+        num_timesteps, batch_size, num_particles = 1, 6, 8
+        meta = {"model": "gaussian", "prior_std": 1.0, "true": [1.0, 1.0, 0.5]}
+    else:
+        true_parts = (ref_lgssm.Initial(0.0, 1.0), ref_lgssm.Transition(0.9, 1.0), ref_lgssm.Emission(1.0, 1.0))
+        parts = {"initial": ref_lgssm.Initial(0.0, 1.0), "transition": ref_lgssm.Transition(0.5, 1.0),
+                 "emission": ref_lgssm.Emission(0.7, 1.0), "proposal": ref_lgssm.Proposal(1.0, 0.1)}
+        num_timesteps, batch_size, num_particles = 4, 3, 8
+        meta = {"model": "lgssm1d", "initial": [0.0, 1.0], "transition_scale": 1.0, "emission_scale": 1.0,
+                "proposal_scales": [1.0, 0.1], "true": [0.9, 1.0]}
+    params = _named_params(parts)
+    arrays = {"init_" + k: _np(v) for k, v in params.items()}
+    torch.manual_seed(seed + 1)   # model construction drew from the stream: restart it here
+    np.random.seed(seed + 1)
+    dataloader = ref.train.get_synthetic_dataloader(*true_parts, num_timesteps, batch_size)
+    losses = []
+    ref.train.train(dataloader, num_particles, algorithm, parts["initial"], parts["transition"],
+                    parts["emission"], parts["proposal"], num_epochs=2, num_iterations_per_epoch=2,
+                    optimizer_algorithm=torch.optim.SGD, optimizer_kwargs={"lr": 0.05},
+                    callback=lambda e, i, loss, *rest: losses.append(float(loss)))
+    for k, v in params.items():
+        arrays["final_" + k] = _np(v)
+    arrays["losses"] = np.array(losses)
+    arrays["torch_state_probe"] = _np(torch.rand(3))          # where the torch stream ended up
+    arrays["numpy_state_probe"] = np.random.uniform(size=3)   # and numpy's
+    meta = dict(meta, name=name, algorithm=algorithm, seed=seed, num_timesteps=num_timesteps,
+                batch_size=batch_size, num_particles=num_particles, dtype="float32",
+                param_names=sorted(params))
+    arrays["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **arrays)
+    print("{:32s} losses={}".format(name, np.round(losses, 5)))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     f32, f64 = torch.float32, torch.float64
@@ -252,6 +294,9 @@ def main():
     lw[1, :] = -np.inf
     lw[2, 2] = np.inf
     case_resampler("resampler_degenerate_f64", lw, 28)
+    # the whole training loop
+    case_train("train_iwae_gaussian", "iwae")
+    case_train("train_aesmc_lgssm1d", "aesmc")
 
 
 if __name__ == "__main__":

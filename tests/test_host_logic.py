@@ -384,6 +384,52 @@ def test_train_loop_runs_and_learns(oracle_backend):
     assert latents[0].shape == (6,) and observations[0].shape == (6,)
 
 
+@pytest.mark.parametrize("name", ["train_iwae_gaussian", "train_aesmc_lgssm1d"])
+def test_train_reproduces_reference_training_run(oracle_backend, name):
+    """tests/golden/train_*.npz: aesmc.train.train run by the reference for 2 epochs x 2
+    iterations on its own SyntheticDataset.  Same seeds here must give the same losses, the same
+    final parameters and leave both random streams at the same position (i.e. data generation,
+    proposal sampling and resampling consume torch's and numpy's generators in the same order,
+    including the batch the reference fetches and drops at each epoch end, train.py:29-32)."""
+    case = Golden(name)
+    meta = case.meta
+    if meta["model"] == "gaussian":
+        true = (models.GaussianPrior(meta["true"][0], meta["true"][1]), None,
+                models.GaussianLikelihood(meta["true"][2]))
+        parts = {"initial": models.GaussianPrior(0.0, meta["prior_std"]), "transition": None,
+                 "emission": models.GaussianLikelihood(1.0),
+                 "proposal": models.GaussianInferenceNetwork(0.0, 0.0, 1.0)}
+    else:
+        true = (models.Lgssm1dInitial(*meta["initial"]),
+                models.Lgssm1dTransition(meta["true"][0], meta["transition_scale"]),
+                models.Lgssm1dEmission(meta["true"][1], meta["emission_scale"]))
+        parts = {"initial": models.Lgssm1dInitial(*meta["initial"]),
+                 "transition": models.Lgssm1dTransition(0.0, meta["transition_scale"]),
+                 "emission": models.Lgssm1dEmission(0.0, meta["emission_scale"]),
+                 "proposal": models.Lgssm1dProposal(*meta["proposal_scales"])}
+    named = {"{}.{}".format(part, pname): p for part, module in parts.items()
+             if isinstance(module, torch.nn.Module) for pname, p in module.named_parameters()}
+    assert sorted(named) == meta["param_names"]
+    with torch.no_grad():
+        for pname, p in named.items():
+            p.copy_(torch.from_numpy(case["init_" + pname]))
+    torch.manual_seed(meta["seed"] + 1)
+    np.random.seed(meta["seed"] + 1)
+    loader = train.get_synthetic_dataloader(*true, meta["num_timesteps"], meta["batch_size"])
+    seen = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        train.train(loader, meta["num_particles"], meta["algorithm"], parts["initial"], parts["transition"],
+                    parts["emission"], parts["proposal"], num_epochs=2, num_iterations_per_epoch=2,
+                    optimizer_algorithm=torch.optim.SGD, optimizer_kwargs={"lr": 0.05},
+                    callback=lambda e, i, loss, *rest: seen.append(float(loss)))
+    np.testing.assert_allclose(seen, case["losses"], rtol=2e-6)
+    for pname, p in named.items():
+        np.testing.assert_allclose(p.detach().numpy(), case["final_" + pname], rtol=2e-5, atol=1e-6)
+    np.testing.assert_array_equal(torch.rand(3).numpy(), case["torch_state_probe"])
+    np.testing.assert_array_equal(np.random.uniform(size=3), case["numpy_state_probe"])
+
+
 def test_package_surface():
     """aesmc/__init__.py:1-7."""
     for name in ("inference", "losses", "math", "state", "statistics", "train"):
