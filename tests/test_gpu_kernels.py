@@ -129,6 +129,36 @@ def test_ancestor_index_matches_oracle(kernels, hip_device, dtype, shape, scale)
     assert idx.min() >= 0 and idx.max() < shape[1]
 
 
+def test_ancestor_index_randomised_stress(kernels, hip_device):
+    """Random shapes and weight profiles aimed at the inverted search: ties (quantised weights),
+    zero-weight stretches (-inf), one dominant particle, near-uniform weights whose CDF steps
+    land exactly on positions (u = 0 with K a power of two), K around every chunk-size switch."""
+    rng = np.random.RandomState(1234)
+    sizes = [1, 2, 3, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 5000, 8192, 8193, 16384, 16385, 20000]
+    for case in range(60):
+        K = int(sizes[case % len(sizes)]) if case < 2 * len(sizes) else int(rng.randint(1, 3000))
+        B = int(rng.randint(1, 5))
+        dtype = [np.float32, np.float64][case % 2]
+        kind = case % 6
+        log_w = rng.randn(B, K) * [0.0, 0.1, 1.0, 10.0, 100.0, 1.0][kind]
+        if kind == 5:
+            log_w = np.round(log_w * 2) / 2                       # many exact ties
+        if case % 4 == 1 and K > 4:
+            lo = rng.randint(0, K - 2)
+            log_w[:, lo:lo + max(1, K // 3)] = -np.inf             # a stretch without weight
+            log_w[:, (lo + K // 2) % K] = 0.0                        # ... but never a dead row
+        if case % 7 == 3:
+            log_w[:, rng.randint(0, K)] += 50.0                      # one dominant particle
+        log_w = log_w.astype(dtype)
+        u = rng.uniform(size=B)
+        if kind == 0:
+            u[0] = 0.0                                               # positions k / K hit CDF steps exactly
+        got = kernels.ancestor_index(dev(log_w, hip_device), dev(u, hip_device)).cpu().numpy()
+        want, _ = kernel_oracle.ancestor_index(log_w, u)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (case, K, B, dtype, kind, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+
+
 def test_ancestor_index_large_k_uses_workspace(kernels, hip_device):
     """K above the LDS-resident limit goes through the global-workspace CDF."""
     limit = int(kernels._lib.aesmc_ancestor_index_lds_max_particles())
