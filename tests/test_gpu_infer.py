@@ -278,6 +278,85 @@ def test_train_on_device(hip_device):
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
 
 
+def test_dict_latents_and_observations_end_to_end(hip_device):
+    """The reference's helpers recurse through dicts (state.py:93, 168-170, 199-200) but its
+    log_prob dict branch is dead code (state.py:130); here a model whose latent and observation are
+    dicts {'a', 'b'} must give exactly the numbers of the same model written with one tensor."""
+    B, K, T = 3, 32, 4
+    torch.manual_seed(0)
+    y = [torch.randn(B, 2, device=hip_device, dtype=torch.float64) for _ in range(T)]
+    scale = torch.tensor(0.9, device=hip_device, dtype=torch.float64)
+    full = Modes.FULLY_EXPANDED
+
+    def tag(dist, mode):
+        return state.set_batch_shape_mode(dist, mode)
+
+    def tensor_model():
+        def initial():
+            return tag(Normal(torch.zeros(2, device=hip_device, dtype=torch.float64), scale), Modes.NOT_EXPANDED)
+
+        def transition(previous_latents=None, time=None, previous_observations=None):
+            return tag(Normal(0.8 * previous_latents[-1], scale), full)
+
+        def emission(latents=None, time=None, previous_observations=None):
+            return tag(Normal(latents[-1], scale), full)
+
+        def proposal(previous_latents=None, time=None, observations=None):
+            if time == 0:
+                return tag(Normal(0.5 * observations[0], scale), Modes.BATCH_EXPANDED)
+            return tag(Normal(0.4 * previous_latents[-1] + 0.5 * observations[time].unsqueeze(1), scale), full)
+
+        return initial, transition, emission, proposal, y
+
+    def dict_model():
+        def split(t):
+            return {"a": t[..., 0], "b": t[..., 1]}
+
+        def initial():
+            zero = torch.zeros((), device=hip_device, dtype=torch.float64)
+            return {k: tag(Normal(zero, scale), Modes.NOT_EXPANDED) for k in ("a", "b")}
+
+        def transition(previous_latents=None, time=None, previous_observations=None):
+            return {k: tag(Normal(0.8 * previous_latents[-1][k], scale), full) for k in ("a", "b")}
+
+        def emission(latents=None, time=None, previous_observations=None):
+            return {k: tag(Normal(latents[-1][k], scale), full) for k in ("a", "b")}
+
+        def proposal(previous_latents=None, time=None, observations=None):
+            if time == 0:
+                return {k: tag(Normal(0.5 * observations[0][k], scale), Modes.BATCH_EXPANDED) for k in ("a", "b")}
+            return {k: tag(Normal(0.4 * previous_latents[-1][k] + 0.5 * observations[time][k].unsqueeze(1), scale), full)
+                    for k in ("a", "b")}
+
+        return initial, transition, emission, proposal, [split(o) for o in y]
+
+    def run(make, noise):
+        initial, transition, emission, proposal, observations = make()
+        with replay.replay(noise):
+            return inference.infer("smc", observations, initial, transition, emission, proposal, K,
+                                   return_log_marginal_likelihood=True, return_log_weights=True,
+                                   return_ancestral_indices=True, return_latents=True)
+
+    gen = torch.Generator().manual_seed(1)
+    eps = [torch.randn(K, B, 2, generator=gen, dtype=torch.float64).numpy()] + \
+        [torch.randn(B, K, 2, generator=gen, dtype=torch.float64).numpy() for _ in range(T - 1)]
+    uniforms = [np.random.RandomState(t).uniform(size=(B, 1)) for t in range(T - 1)]
+    per_key = []
+    for block in eps:                       # dict proposals draw key 'a' then key 'b'
+        per_key += [np.ascontiguousarray(block[..., 0]), np.ascontiguousarray(block[..., 1])]
+    as_tensor = run(tensor_model, replay.Tape(eps, uniforms))
+    as_dict = run(dict_model, replay.Tape(per_key, uniforms))
+    for a, b in zip(as_tensor["ancestral_indices"], as_dict["ancestral_indices"]):
+        assert torch.equal(a, b)
+    for a, b in zip(as_tensor["log_weights"], as_dict["log_weights"]):
+        torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(as_tensor["log_marginal_likelihood"], as_dict["log_marginal_likelihood"],
+                               rtol=1e-12, atol=1e-12)
+    for a, b in zip(as_tensor["latents"], as_dict["latents"]):
+        torch.testing.assert_close(a[..., 0], b["a"])
+        torch.testing.assert_close(a[..., 1], b["b"])
+
+
 def test_fused_normal_log_prob_equals_eager_path(hip_device):
     """state.log_prob through kernel K4 vs the reference's eager Normal.log_prob route, forward
     and backward, for every BatchShapeMode."""
