@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-backward", action="store_true")
+    ap.add_argument("--tunableop", default="on", choices=["on", "off"],
+                    help="PyTorch TunableOp for the user callables' matmuls (tunes each GEMM shape once, in warm-up)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and take the sharded code path even with one rank (test hook)")
     ap.add_argument("--mode", default=None, choices=["graph", "eager"],
@@ -163,6 +165,14 @@ def main():
     parts = (model.initial, model.transition, model.emission, model.proposal)
     np.random.seed(0)
     torch.manual_seed(0)
+    if args.tunableop == "on":
+        # hipBLASLt's default pick for the callables' [B*K, d] x [d, d] maps runs at ~1.3 TB/s;
+        # TunableOp (a stock PyTorch feature) times the candidates on first use and keeps the best.
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "aesmc_tunableop_%d.csv" % os.getpid()))
+        torch.cuda.tunable.set_max_tuning_duration(30)
+        torch.cuda.tunable.set_max_tuning_iterations(20)
 
     if args.mode is None:  # the big forward-only shapes are device-bound and need the HBM for data
         args.mode = "eager" if args.workload in FORWARD_ONLY else "graph"
@@ -304,11 +314,13 @@ def main():
         "config": {"workload": "{}: {}".format(args.workload, description), "batch_per_gpu": B,
                    "global_batch": global_B, "num_particles": K, "num_timesteps": T, "state_dim": dim,
                    "parallelism": "batch-shard x{} (one RCCL all-reduce of sum log Z per ELBO)".format(world),
+                   "pytorch": "TunableOp {} for the user callables' matmuls; distributions built with "
+                              "validate_args=False".format(args.tunableop),
                    "step": "one forward ELBO, get_loss(..., '{}'), ".format(algorithm) +
                            ("torch.no_grad()" if args.workload in FORWARD_ONLY else "autograd graph recorded") +
                            (", all T timesteps replayed as one hipGraph" if mode == "hipgraph" else ", eager Python loop")},
         "loss": loss,
-        "mode": mode, "graph_error": graph_error,
+        "mode": mode, "graph_error": graph_error, "tunableop": args.tunableop,
         "eager_particle_steps_per_sec": eager_value,
         "fwd_bwd_particle_steps_per_sec": fwd_bwd,
         "roofline": roofline,
