@@ -6,6 +6,7 @@ density, alignment) before anything is launched.  Kernels report data-dependent 
 log-weights, degenerate rows, out-of-range indices) by OR-ing bits into a per-device int32 word
 that the host reads once per ELBO evaluation (`read_flags`) instead of synchronising per timestep.
 """
+import ctypes
 import threading
 
 import torch
@@ -438,6 +439,27 @@ class HipKernels:
                     out.numel() * out.element_size()
                 self.timer.note("normal_logweight", lambda: self._lib.aesmc_normal_logweight(*args), nbytes,
                                 (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, out, views))
+        return out
+
+    def normal_rsample(self, eps, loc, scale):
+        """loc + eps * scale (product rounded first, as eager PyTorch) -> dense tensor of eps's
+        shape [B,K,*]; loc and scale are views already expanded to that shape."""
+        tag = _DTYPE_TAG[eps.dtype]
+        eps = eps.contiguous()
+        (_, _, D), (loc, sm, _), (scale, ss, _) = [self._view3(t) for t in (eps, loc, scale)]
+        B, K = eps.shape[:2]
+        out = torch.empty_like(eps)
+        if out.numel() == 0:
+            return out
+        loc_view, scale_view = _lib.View3(_ptr(loc), *sm), _lib.View3(_ptr(scale), *ss)
+        with torch.cuda.device(eps.device):
+            args = (tag, _ptr(eps), ctypes.byref(loc_view), ctypes.byref(scale_view), _ptr(out), B, K, D,
+                    self._stream(eps))
+            _lib.check(self._lib.aesmc_normal_rsample(*args), "aesmc_normal_rsample")
+            if self.timer is not None:
+                nbytes = sum(self._unique_bytes(t) for t in (eps, loc, scale)) + out.numel() * out.element_size()
+                self.timer.note("normal_rsample", lambda: self._lib.aesmc_normal_rsample(*args), nbytes,
+                                (eps, loc, scale, out, loc_view, scale_view))
         return out
 
 

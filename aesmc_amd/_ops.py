@@ -110,6 +110,30 @@ def normal_log_weight(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
     return _kernels.get().normal_logweight(*[t.detach() for t in tensors])
 
 
+class _NormalRsample(torch.autograd.Function):
+    """draw = loc + eps * scale (kernel K6); loc and scale arrive expanded to eps's shape, so the
+    gradients returned here are dense and autograd's expand-backward folds the broadcast dims."""
+
+    @staticmethod
+    def forward(ctx, eps, loc, scale):
+        ctx.save_for_backward(eps if scale.requires_grad else None)
+        return _kernels.get().normal_rsample(eps, loc, scale)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (eps,) = ctx.saved_tensors
+        grad_loc = grad if ctx.needs_input_grad[1] else None
+        grad_scale = grad * eps if ctx.needs_input_grad[2] else None
+        return None, grad_loc, grad_scale
+
+
+def normal_rsample(eps, loc, scale):
+    """Reparameterised Normal draw from standard-normal noise `eps` [B,K,*] (kernel K6)."""
+    if torch.is_grad_enabled() and (loc.requires_grad or scale.requires_grad):
+        return _NormalRsample.apply(eps, loc, scale)
+    return _kernels.get().normal_rsample(eps, loc.detach(), scale.detach())
+
+
 def logweight_lse(a, b=None, c=None):
     """Returns (log_weight [B,K], logsumexp over particles [B]) for log_weight = a + b - c."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (a, b, c)):

@@ -127,7 +127,10 @@ def sample(distribution, batch_size, num_particles):
         raise ValueError("batch_shape_mode {} not supported".format(mode))
     if not distribution.has_rsample:
         raise ValueError("distribution not reparameterizable")
-    draw = distribution.rsample(sample_shape=_SAMPLE_SHAPE[mode](batch_size, num_particles))
+    sample_shape = _SAMPLE_SHAPE[mode](batch_size, num_particles)
+    draw = _fused_normal_rsample(distribution, sample_shape) if _FUSED_NORMAL else None
+    if draw is None:
+        draw = distribution.rsample(sample_shape=sample_shape)
     if mode == BatchShapeMode.BATCH_EXPANDED:
         draw = draw.transpose(0, 1)  # [K, B, ...] -> [B, K, ...] view, as in the reference
     return draw
@@ -201,10 +204,33 @@ _FUSED_NORMAL = True
 
 
 def set_fused_normal(enabled):
-    """Switches the fused Normal log-density (kernel K4) inside `log_prob` on (default) or off;
-    off evaluates `distribution.log_prob` in eager PyTorch exactly as the reference does."""
+    """Switches the fused Normal kernels (log-density K4 / K5 inside `log_prob`, draw K6 inside
+    `sample`) on (default) or off; off evaluates `distribution.log_prob` / `rsample` in eager
+    PyTorch exactly as the reference does."""
     global _FUSED_NORMAL
     _FUSED_NORMAL = bool(enabled)
+
+
+def _fused_normal_rsample(distribution, sample_shape):
+    """`distribution.rsample(sample_shape)` for a plain Normal (optionally inside Independent) with
+    tensor parameters on the HIP device: the noise comes from the very call torch makes
+    (torch/distributions/normal.py rsample -> `_standard_normal`, so the generator advances
+    identically) and `loc + eps * scale` is one pass of kernel K6 instead of two eager ones.
+    None for anything else."""
+    base = distribution
+    if type(base) is torch.distributions.Independent:
+        base = base.base_dist
+    if type(base) is not torch.distributions.Normal:
+        return None
+    loc, scale = base.loc, base.scale
+    if not (loc.is_cuda and scale.device == loc.device and loc.dtype == scale.dtype and
+            loc.dtype in (torch.float32, torch.float64)):
+        return None
+    shape = base._extended_shape(torch.Size(sample_shape))
+    if len(shape) < 2:
+        return None
+    eps = torch.distributions.normal._standard_normal(shape, dtype=loc.dtype, device=loc.device)
+    return _ops.normal_rsample(eps, loc.expand(shape), scale.expand(shape))
 
 
 def _fused_normal_views(distribution, value, missing):

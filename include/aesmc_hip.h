@@ -157,6 +157,17 @@ typedef struct aesmc_view3 {
 int aesmc_normal_logweight(int dtype, const aesmc_view3 *views, void *out_lw, int64_t B, int64_t K,
                            int64_t Dx, int64_t Dy, void *stream);
 
+/* K6 — reparameterised Normal draw  out[b,k,j] = loc[b,k,j] + eps[b,k,j] * scale[b,k,j].
+ *
+ * Replaces the broadcast multiply and the add that follow the noise draw in
+ * torch.distributions.Normal.rsample as aesmc/state.py:61-111 (`state.sample`) calls it; the
+ * product is rounded before the sum, so the result equals eager PyTorch bit for bit.  `eps` (the
+ * caller's standard-normal noise) and `out` are dense [B,K,D]; `loc` and `scale` are [B,K,D]
+ * views by element strides (0 = broadcast); `out` must not alias the inputs.
+ */
+int aesmc_normal_rsample(int dtype, const void *eps, const aesmc_view3 *loc, const aesmc_view3 *scale,
+                         void *out, int64_t B, int64_t K, int64_t D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

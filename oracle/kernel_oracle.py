@@ -148,3 +148,11 @@ def gather_backward(grad_out, idx):
     good = ~bad
     np.add.at(grad_src, (rows[good], idx[good]), grad_out[good])
     return grad_src, flags
+
+
+def normal_rsample(eps, loc, scale):
+    """K6: loc + eps * scale with the product rounded before the sum, in eps's dtype — the two
+    eager ops of torch/distributions/normal.py rsample (reached from aesmc/state.py:98-104)."""
+    eps = np.asarray(eps)
+    product = (eps * np.broadcast_to(np.asarray(scale, dtype=eps.dtype), eps.shape)).astype(eps.dtype)
+    return (np.broadcast_to(np.asarray(loc, dtype=eps.dtype), eps.shape) + product).astype(eps.dtype)

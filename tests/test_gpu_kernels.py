@@ -541,3 +541,59 @@ def test_full_size_normal_logprob_sum(kernels, hip_device):
     # linearity in the scale: log N(v; mu, s) summed == -d log s + log N((v - mu)/s; 0, 1) summed
     unit = kernels.normal_logprob_sum((value - loc) / 0.7, torch.zeros_like(loc), torch.ones_like(loc))
     torch.testing.assert_close(got, unit - d * float(np.log(0.7)), rtol=1e-5, atol=1e-4)
+
+
+# ---- K6 ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 16, 1), (3, 7, 10), (5, 64, 3), (4, 1000, 10), (2, 33, 128),
+                                   (3, 5, 2, 3)])
+@pytest.mark.parametrize("loc_kind", ["full", "per_batch", "vector", "scalar"])
+@pytest.mark.parametrize("scale_kind", ["scalar", "vector", "full"])
+def test_normal_rsample_is_bitwise_eager_torch(kernels, hip_device, dtype, shape, loc_kind, scale_kind):
+    gen = torch.Generator().manual_seed(sum(shape) * 131 + len(loc_kind) * 17 + len(scale_kind))
+    make = lambda *s: torch.randn(tuple(s), generator=gen, dtype=dtype).to(hip_device)
+    kinds = {"full": shape, "per_batch": (shape[0], 1) + shape[2:], "vector": shape[2:], "scalar": ()}
+    eps = make(*shape)
+    loc = make(*kinds[loc_kind])
+    scale = make(*kinds[scale_kind]).abs() + 0.1
+    got = kernels.normal_rsample(eps, loc.expand(shape), scale.expand(shape))
+    want = loc + eps * scale
+    assert got.shape == want.shape and got.is_contiguous()
+    assert torch.equal(got, want)
+    np.testing.assert_array_equal(got.cpu().numpy(),
+                                  kernel_oracle.normal_rsample(eps.cpu().numpy(), loc.cpu().numpy(),
+                                                               scale.cpu().numpy()))
+
+
+def test_sample_draws_what_torch_draws_and_differentiates(hip_device):
+    """state.sample through K6 == Distribution.rsample from the same generator state, for each
+    BatchShapeMode; gradients w.r.t. loc and scale equal eager autograd's."""
+    from aesmc_amd import state
+    B, K, D = 4, 9, 5
+    for dtype in (torch.float32, torch.float64):
+        cases = [
+            (lambda l, s: torch.distributions.Normal(l, s), (B, K, D), state.BatchShapeMode.FULLY_EXPANDED),
+            (lambda l, s: torch.distributions.Independent(torch.distributions.Normal(l, s), 1), (B, K, D),
+             state.BatchShapeMode.FULLY_EXPANDED),
+            (lambda l, s: torch.distributions.Normal(l, s), (B, D), state.BatchShapeMode.BATCH_EXPANDED),
+            (lambda l, s: torch.distributions.Normal(l, s), (D,), state.BatchShapeMode.NOT_EXPANDED),
+        ]
+        for make, loc_shape, mode in cases:
+            loc = torch.randn(*loc_shape, dtype=dtype, device=hip_device, requires_grad=True)
+            scale = (torch.rand(D, dtype=dtype, device=hip_device) + 0.5).requires_grad_()
+            results = []
+            for fused in (True, False):
+                state.set_fused_normal(fused)
+                try:
+                    torch.manual_seed(11)
+                    dist = state.set_batch_shape_mode(make(loc, scale.expand(loc_shape)), mode)
+                    draw = state.sample(dist, B, K)
+                    weights = torch.arange(draw.numel(), dtype=dtype, device=hip_device).reshape(draw.shape)
+                    g_loc, g_scale = torch.autograd.grad((draw * weights.sin()).sum(), (loc, scale))
+                finally:
+                    state.set_fused_normal(True)
+                results.append((draw.detach(), g_loc, g_scale))
+            (d1, gl1, gs1), (d0, gl0, gs0) = results
+            assert d1.shape == (B, K, D) and torch.equal(d1, d0)
+            torch.testing.assert_close(gl1, gl0, rtol=1e-6, atol=1e-6)
+            torch.testing.assert_close(gs1, gs0, rtol=1e-5, atol=1e-5)
