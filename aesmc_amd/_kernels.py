@@ -89,20 +89,26 @@ class KernelTimer:
             nbytes = sum(n for _, n, _ in sample) / len(sample)
             out[name] = {"launches": count, "sampled": len(sample), "avg_us": 1e6 * seconds,
                          "bytes_per_launch": nbytes, "GBps": nbytes / seconds / 1e9}
-            if name == "resample_gather":
-                # The algorithmic figure counts a full read of the source; only rows that still
-                # have offspring are actually fetched.  Report how many that was on these operands
-                # and the bytes that had to move (index + surviving rows + every output row).
+            if name in ("resample_gather", "resample_step"):
+                # The algorithmic figure counts a full read of the source (and, for the fused step,
+                # K3's re-read of the indices, which it skips); only rows that still have offspring
+                # are actually fetched.  Report how many that was on these operands and the bytes
+                # that had to move.
                 fractions, moved = [], []
-                for _, _, (src, idx, dst) in sample:
+                for _, _, keep in sample:
+                    idx, dst = (keep[1], keep[2]) if name == "resample_gather" else (keep[2], keep[5])
+                    if dst is None:
+                        continue
                     rows = idx.numel()
                     unique = int((idx[:, 1:] != idx[:, :-1]).sum().item()) + idx.size(0)
                     payload = dst.numel() * dst.element_size() / rows
                     fractions.append(unique / rows)
-                    moved.append(rows * 8 + (rows + unique) * payload)
-                out[name]["unique_ancestor_fraction"] = sum(fractions) / len(fractions)
-                out[name]["moved_bytes_per_launch"] = sum(moved) / len(moved)
-                out[name]["moved_GBps"] = out[name]["moved_bytes_per_launch"] / seconds / 1e9
+                    fixed = rows * 8 if name == "resample_gather" else rows * (keep[0].element_size() + 8)
+                    moved.append(fixed + (rows + unique) * payload)
+                if fractions:
+                    out[name]["unique_ancestor_fraction"] = sum(fractions) / len(fractions)
+                    out[name]["moved_bytes_per_launch"] = sum(moved) / len(moved)
+                    out[name]["moved_GBps"] = out[name]["moved_bytes_per_launch"] / seconds / 1e9
         return out
 
 
@@ -116,6 +122,7 @@ class HipKernels:
         self._flags = {}
         self._lock = threading.Lock()
         self.timer = None  # set to a KernelTimer to time every launch (bench only)
+        self.lds_max_particles = int(self._lib.aesmc_ancestor_index_lds_max_particles())
 
     # ---- deferred status word ---------------------------------------------------------------
     def flags(self, device):
@@ -240,6 +247,87 @@ class HipKernels:
                                 B * K * (log_w.element_size() + 8) + 8 * B, (log_w, u, idx, ws))
         idx._aesmc_sorted = True  # systematic resampling is monotone in k: lets K3's backward skip atomics
         return idx
+
+    # A workgroup owns a whole batch row: copying the payload inside the step pays while one row's
+    # payload is small next to the chip (measured: 160 KB rows at B >= 128 gain, 8 MB rows lose 2x).
+    STEP_PAYLOAD_MAX_ROW_BYTES = 1 << 20
+
+    def step_covers(self, log_w, payload=None):
+        """Host-only: can `resample_step` take this log-weight tensor (and payload)?"""
+        if not (log_w.is_cuda and log_w.dim() == 2 and log_w.dtype in _DTYPE_TAG):
+            return False
+        K = log_w.size(1)
+        if K > self.lds_max_particles or log_w.numel() == 0:
+            return False
+        if payload is None:
+            return True
+        if not (torch.is_tensor(payload) and payload.is_cuda and payload.device == log_w.device and
+                payload.size()[:2] == log_w.size() and payload.numel() > 0 and _inner_dense(payload)):
+            return False
+        esz = payload.element_size()
+        row_bytes = esz * (payload[0, 0].numel())
+        if row_bytes % 4 or (K * row_bytes) % 16 or K * row_bytes > self.STEP_PAYLOAD_MAX_ROW_BYTES:
+            return False
+        return all((x * esz) % 4 == 0 for x in (payload.stride(0), payload.stride(1))) and \
+            payload.data_ptr() % 4 == 0
+
+    def resample_step(self, log_w, u, payload=None, want_lse=False):
+        """The fused step: (idx, lse, resampled payload) from one launch — idx as `ancestor_index`,
+        lse = logsumexp over particles [B] when `want_lse`, payload[b, idx[b,k]] as `gather` when a
+        payload tensor [B,K,...] is given (else None).  Returns None when the launch does not cover
+        the operands (more particles than one workgroup holds, payload rows not 4-byte multiples):
+        the caller then runs `ancestor_index` / `gather` / `logweight_lse` separately."""
+        _require_hip(log_w, "log_weight")
+        _require_hip(u, "uniforms")
+        tag = _tag(log_w, "log_weight")
+        if log_w.dim() != 2:
+            raise ValueError("aesmc_amd: log_weight must be [batch_size, num_particles], got {}"
+                             .format(tuple(log_w.shape)))
+        B, K = log_w.shape
+        if u.dtype != torch.float64 or u.numel() != B or u.device != log_w.device:
+            raise ValueError("aesmc_amd: uniforms must be {} float64 values on {}".format(B, log_w.device))
+        if K > self.lds_max_particles:
+            return None
+        log_w = log_w.contiguous()
+        u = u.contiguous()
+        row_bytes = sb = sk = 0
+        dst = None
+        if payload is not None:
+            _require_hip(payload, "value")
+            assert payload.size()[:2] == log_w.size()
+            if payload.device != log_w.device:
+                raise RuntimeError("aesmc_amd: value on {} but log_weight on {}".format(payload.device,
+                                                                                   log_w.device))
+            if not _inner_dense(payload):
+                payload = payload.contiguous()
+            esz = payload.element_size()
+            row_bytes = esz
+            for size in payload.shape[2:]:
+                row_bytes *= size
+            sb, sk = payload.stride(0) * esz, payload.stride(1) * esz
+            dst = torch.empty(payload.shape, dtype=payload.dtype, device=payload.device)
+            if dst.numel() == 0:
+                payload = dst = None
+        idx = torch.empty((B, K), dtype=torch.int64, device=log_w.device)
+        lse = torch.empty((B,), dtype=log_w.dtype, device=log_w.device) if want_lse else None
+        if idx.numel() == 0:
+            return None
+        with torch.cuda.device(log_w.device):
+            flags = self.flags(log_w.device)
+            args = (tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(lse), _ptr(payload if dst is not None else None),
+                    _ptr(dst), _ptr(flags), B, K, row_bytes, sb, sk, self._stream(log_w))
+            status = self._lib.aesmc_resample_step(*args)
+            if status == 2:
+                return None
+            _lib.check(status, "aesmc_resample_step")
+            if self.timer is not None:
+                nbytes = B * K * (log_w.element_size() + 8) + 8 * B
+                if dst is not None:  # SURVEY 8(d): K2's 12 B + K3's (8 + 2 row_bytes) per particle
+                    nbytes += B * K * (8 + 2 * row_bytes)
+                self.timer.note("resample_step", lambda: self._lib.aesmc_resample_step(*args), nbytes,
+                                (log_w, u, idx, lse, payload, dst))
+        idx._aesmc_sorted = True
+        return idx, lse, dst
 
     # ---- K3 ------------------------------------------------------------------------------------
     @staticmethod

@@ -146,6 +146,55 @@ def row_logsumexp(x):
     return logweight_lse(x)[1]
 
 
+class _ResampleStep(torch.autograd.Function):
+    """(idx, lse, moved) of the fused resampling step.  idx carries no gradient
+    (aesmc/inference.py:254); lse differentiates into the log-weights as K1's does; moved =
+    payload[b, idx[b,k]] differentiates into the payload by the sorted segmented sum."""
+
+    @staticmethod
+    def forward(ctx, log_w, uniforms, payload, want_lse):
+        out = _kernels.get().resample_step(log_w, uniforms, payload, want_lse)
+        if out is None:
+            raise RuntimeError("aesmc_amd: fused resampling step rejected operands it was offered")
+        idx, lse, moved = out
+        ctx.mark_non_differentiable(idx)
+        ctx.save_for_backward(log_w, lse, idx)
+        return idx, lse, moved
+
+    @staticmethod
+    def backward(ctx, _grad_idx, grad_lse, grad_moved):
+        log_w, lse, idx = ctx.saved_tensors
+        k = _kernels.get()
+        grad_w = grad_payload = None
+        if ctx.needs_input_grad[0] and lse is not None and grad_lse is not None:
+            grad_w, _ = k.logweight_lse_backward(log_w, lse, None, grad_lse, want_neg=False)
+        if ctx.needs_input_grad[2] and grad_moved is not None:
+            grad_payload = k.gather_backward(grad_moved, idx, sorted_index=True)
+        return grad_w, None, grad_payload, None
+
+
+def resample_step(log_weight, uniforms, payload=None, want_lse=False):
+    """One resampling step: (ancestor indices [B,K], logsumexp over particles [B] or None,
+    payload[b, idx[b,k], ...] or None).  One launch when the fused kernel covers the operands;
+    `moved` is None when it does not cover the payload (the caller gathers with the indices)."""
+    k = _kernels.get()
+    if not k.step_covers(log_weight):
+        idx = ancestor_index(log_weight, uniforms)
+        return idx, (row_logsumexp(log_weight) if want_lse else None), None
+    if payload is not None and not k.step_covers(log_weight, payload):
+        payload = None
+    wants_grad = torch.is_grad_enabled() and (
+        (want_lse and log_weight.requires_grad) or
+        (payload is not None and payload.requires_grad and payload.is_floating_point()))
+    if wants_grad:
+        idx, lse, moved = _ResampleStep.apply(log_weight, uniforms, payload, want_lse)
+    else:
+        idx, lse, moved = k.resample_step(log_weight.detach(), uniforms,
+                                          None if payload is None else payload.detach(), want_lse)
+    idx._aesmc_sorted = True
+    return idx, lse, moved
+
+
 def resample_gather(value, idx):
     if torch.is_grad_enabled() and value.requires_grad and value.is_floating_point():
         return _ResampleGather.apply(value, idx)

@@ -239,10 +239,60 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_kernel(
 constexpr int kInvMaxChunk = 32;
 constexpr int64_t kInvMaxParticles = (int64_t)kMaxThreads * kInvMaxChunk;
 
+// Optional tail of the kernel (the fused resampling step): with the row's ancestor indices still
+// in LDS, copy the payload rows  dst[b,k,:] = src[b, idx[b,k], :]  — K3's chunking (16-byte
+// stores, G-byte source pieces), minus the round trip of the int64 indices through HBM and one
+// launch.  `src == nullptr` switches it off.
+struct StepPayload {
+  const char *src;
+  char *dst;
+  int64_t stride_b, stride_k;  // bytes
+  uint32_t ppp;                // G-byte pieces per particle row
+  int G;                       // 4, 8 or 16
+};
+
+template <int G>
+__device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *srow, char *drow,
+                                                    uint32_t K, uint32_t ppp, int64_t stride_k,
+                                                    uint32_t tid, uint32_t nt) {
+  constexpr int V = 16 / G;
+  constexpr int U = 4;
+  using P = typename Piece<G>::type;
+  const uint64_t row_pieces = (uint64_t)K * ppp;             // a multiple of V (checked on the host)
+  const uint32_t chunks = (uint32_t)(row_pieces / V);
+  for (uint32_t c0 = 0; c0 < chunks; c0 += nt * U) {
+    P piece[U][V];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t chunk = c0 + j * nt + tid;
+      const uint32_t p0 = (chunk < chunks ? chunk : 0u) * V;
+      uint32_t k = p0 / ppp;
+      uint32_t r = p0 - k * ppp;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        piece[j][i] = *reinterpret_cast<const P *>(srow + (int64_t)anc[k] * stride_k + (uint64_t)r * G);
+        if (++r == ppp) {
+          r = 0;
+          ++k;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t chunk = c0 + j * nt + tid;
+      if (chunk < chunks) {
+        uint4 packed;
+        __builtin_memcpy(&packed, piece[j], 16);
+        *reinterpret_cast<uint4 *>(drow + (uint64_t)chunk * 16) = packed;
+      }
+    }
+  }
+}
+
 template <typename T, int C>
 __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
-    int32_t *flags, int K) {
+    int32_t *flags, int K, T *__restrict__ out_lse, StepPayload payload) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *scratch = smem;                                        // [64]
   int *scratch_i = reinterpret_cast<int *>(scratch + 32);
@@ -299,8 +349,24 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   __syncthreads();
   const bool degenerate = has_nan || !(dm > -__builtin_huge_val() && dm < __builtin_huge_val());
   if (degenerate) {  // same conventions as the reference: see include/aesmc_hip.h, K2
-    if (tid == 0) raise_flag(flags, has_nan ? AESMC_FLAG_NAN_LOG_WEIGHT : AESMC_FLAG_DEGENERATE_ROW);
+    if (tid == 0) {
+      raise_flag(flags, has_nan ? AESMC_FLAG_NAN_LOG_WEIGHT : AESMC_FLAG_DEGENERATE_ROW);
+      // torch.logsumexp's values for such rows (K1 returns the same)
+      if (out_lse != nullptr) out_lse[row] = has_nan ? Num<T>::nan() : (T)dm;
+    }
     for (int k = tid; k < K; k += nt) idx[k] = (int64_t)K;
+    if (payload.src == nullptr) return;
+    // the unfused route would clamp the out-of-range index K to K - 1 in K3: same bytes here
+    for (int k = tid; k < nt * C; k += nt) marker[k] = K - 1;
+    __syncthreads();
+    const char *srow = payload.src + row * payload.stride_b;
+    char *drow = payload.dst + (uint64_t)row * K * payload.ppp * payload.G;
+    if (payload.G == 16)
+      gather_row_from_lds<16>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+    else if (payload.G == 8)
+      gather_row_from_lds<8>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+    else
+      gather_row_from_lds<4>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
     return;
   }
 
@@ -328,6 +394,8 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   __syncthreads();
   const double total = scratch[31];
   const double inv_total = 1.0 / total;
+  // by-product: logsumexp of the row (the step's contribution to log Z), float64 inside
+  if (out_lse != nullptr && tid == 0) out_lse[row] = (T)(dm + ::log(total));
 
   // ---- first[j] = min{ k : (u + k) / K >= c[j] } ---------------------------------------------------
   const double ub = u[row];
@@ -407,19 +475,43 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   if (lane == kWave - 1) scratch_i[wave] = incl_max;
   __syncthreads();
   for (int w = 0; w < wave; ++w) before = max(before, scratch_i[w]);
+#pragma unroll
+  for (int i = 0; i < C; ++i) best[i] = max(before, best[i]);
   if (j0 + C <= K && (((uintptr_t)(idx + j0)) & 15u) == 0) {
 #pragma unroll
     for (int i = 0; i < C; i += 2) {
       longlong2 pair;
-      pair.x = (int64_t)max(before, best[i]);
-      pair.y = (int64_t)max(before, best[i + 1]);
+      pair.x = (int64_t)best[i];
+      pair.y = (int64_t)best[i + 1];
       *reinterpret_cast<longlong2 *>(idx + j0 + i) = pair;
     }
   } else {
 #pragma unroll
     for (int i = 0; i < C; ++i)
-      if (j0 + i < K) idx[j0 + i] = (int64_t)max(before, best[i]);
+      if (j0 + i < K) idx[j0 + i] = (int64_t)best[i];
   }
+  if (payload.src == nullptr) return;
+
+  // ---- fused step: the payload rows follow their ancestors ------------------------------------
+  // Every lane read its marker slots before the last barrier, so they can now hold the indices.
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q)
+      reinterpret_cast<int4 *>(marker + j0)[q] =
+          make_int4(best[4 * q], best[4 * q + 1], best[4 * q + 2], best[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) marker[j0 + i] = best[i];
+  }
+  __syncthreads();
+  const char *srow = payload.src + row * payload.stride_b;
+  char *drow = payload.dst + (uint64_t)row * K * payload.ppp * payload.G;
+  if (payload.G == 16)
+    gather_row_from_lds<16>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+  else if (payload.G == 8)
+    gather_row_from_lds<8>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+  else
+    gather_row_from_lds<4>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
 }
 
 static int pick_threads(int64_t K, int chunk) {
@@ -432,7 +524,8 @@ static int pick_threads(int64_t K, int chunk) {
 
 template <typename T, int C>
 static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
-                      int64_t K, hipStream_t s) {
+                      int64_t K, hipStream_t s, void *out_lse = nullptr,
+                      const StepPayload &payload = StepPayload{nullptr, nullptr, 0, 0, 0, 0}) {
   const int nt = pick_threads(K, C);
   const size_t lds = (size_t)kScratchDoubles * sizeof(double) + (size_t)(nt * C + nt + 8) * sizeof(int);
   static bool attr_set = false;  // raise the dynamic-LDS cap once per process and instantiation
@@ -443,8 +536,19 @@ static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t 
     attr_set = true;
   }
   hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C>), dim3((unsigned)B), dim3(nt), lds, s,
-                     (const T *)log_w, u, idx, flags, (int)K);
+                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+template <typename T>
+static int launch_step(const void *log_w, const double *u, int64_t *idx, void *out_lse, int32_t *flags,
+                       int64_t B, int64_t K, const StepPayload &payload, hipStream_t s) {
+  if (K <= 512) return launch_inv<T, 2>(log_w, u, idx, flags, B, K, s, out_lse, payload);
+  if (K <= 2048) return launch_inv<T, 4>(log_w, u, idx, flags, B, K, s, out_lse, payload);
+  if (K <= 8192) return launch_inv<T, 8>(log_w, u, idx, flags, B, K, s, out_lse, payload);
+  if (K <= 16384) return launch_inv<T, 16>(log_w, u, idx, flags, B, K, s, out_lse, payload);
+  if (K <= kInvMaxParticles) return launch_inv<T, 32>(log_w, u, idx, flags, B, K, s, out_lse, payload);
+  return AESMC_ERR_UNSUPPORTED;
 }
 
 // Particles per lane grow with the row so that one workgroup (<= 1024 lanes) covers it; beyond
@@ -483,5 +587,39 @@ extern "C" int aesmc_ancestor_index(int dtype, const void *log_w, const double *
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AESMC_F32) return aesmc::launch<float>(log_w, u, out_idx, flags, B, K, ws, ws_bytes, s);
   if (dtype == AESMC_F64) return aesmc::launch<double>(log_w, u, out_idx, flags, B, K, ws, ws_bytes, s);
+  return AESMC_ERR_INVALID_ARGUMENT;
+}
+
+static inline int64_t step_pow2_divisor(uint64_t x, int64_t cap) {
+  while (cap > 1 && (x % (uint64_t)cap) != 0) cap >>= 1;
+  return cap;
+}
+
+extern "C" int aesmc_resample_step(int dtype, const void *log_w, const double *u, int64_t *out_idx,
+                                   void *out_lse, const void *src, void *dst, int32_t *flags, int64_t B,
+                                   int64_t K, int64_t row_bytes, int64_t src_stride_b,
+                                   int64_t src_stride_k, void *stream) {
+  using namespace aesmc;
+  if (log_w == nullptr || u == nullptr || out_idx == nullptr || B < 0 || K < 0 || row_bytes < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if ((src == nullptr) != (dst == nullptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (B == 0 || K == 0) return AESMC_OK;
+  if (K > kInvMaxParticles || B > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
+  StepPayload payload{nullptr, nullptr, 0, 0, 0, 0};
+  if (src != nullptr && row_bytes > 0) {
+    if ((uint64_t)K * (uint64_t)row_bytes >= (1ull << 32)) return AESMC_ERR_UNSUPPORTED;
+    int64_t G = step_pow2_divisor((uint64_t)row_bytes, 16);
+    G = step_pow2_divisor((uint64_t)(uintptr_t)src, G);
+    G = step_pow2_divisor((uint64_t)(src_stride_b < 0 ? -src_stride_b : src_stride_b), G);
+    G = step_pow2_divisor((uint64_t)(src_stride_k < 0 ? -src_stride_k : src_stride_k), G);
+    // 16-byte stores: aligned destination and batch-row pitch; pieces of at least 4 bytes
+    if (G < 4 || ((uintptr_t)dst & 15u) != 0 || ((uint64_t)K * (uint64_t)row_bytes) % 16 != 0)
+      return AESMC_ERR_UNSUPPORTED;
+    payload = StepPayload{(const char *)src, (char *)dst, src_stride_b, src_stride_k,
+                          (uint32_t)(row_bytes / G), (int)G};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AESMC_F32) return launch_step<float>(log_w, u, out_idx, out_lse, flags, B, K, payload, s);
+  if (dtype == AESMC_F64) return launch_step<double>(log_w, u, out_idx, out_lse, flags, B, K, payload, s);
   return AESMC_ERR_INVALID_ARGUMENT;
 }

@@ -95,6 +95,15 @@ template <typename T> __device__ __forceinline__ void wave_merge(LseState<T> &st
   }
 }
 
+// G-byte unit of a row copy (K3 and the fused step): the widest power of two <= 16 that divides
+// the row length and every address involved.
+template <int G> struct Piece;
+template <> struct Piece<1> { using type = uint8_t; };
+template <> struct Piece<2> { using type = uint16_t; };
+template <> struct Piece<4> { using type = uint32_t; };
+template <> struct Piece<8> { using type = uint2; };
+template <> struct Piece<16> { using type = uint4; };
+
 __device__ __forceinline__ void raise_flag(int32_t *flags, int32_t bit) {
   if (flags != nullptr) atomicOr(flags, bit);
 }

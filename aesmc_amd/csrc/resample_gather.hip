@@ -16,13 +16,6 @@ namespace aesmc {
 
 constexpr int kGatherBlock = 256;
 
-template <int G> struct Piece;
-template <> struct Piece<1> { using type = uint8_t; };
-template <> struct Piece<2> { using type = uint16_t; };
-template <> struct Piece<4> { using type = uint32_t; };
-template <> struct Piece<8> { using type = uint2; };
-template <> struct Piece<16> { using type = uint4; };
-
 // V pieces of G bytes per 16-byte chunk (V == 1 on the unaligned fallback) and U chunks per lane,
 // 256 lanes apart so each store instruction of a wavefront still covers 1 KiB contiguously.  The
 // U*V index loads are issued together, then the U*V row loads: the kernel is a chain of two

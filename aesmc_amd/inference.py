@@ -36,10 +36,11 @@ class ResampledHistory(collections.abc.Sequence):
     """Read-only view of [resample(x, index) for x in latents] whose entries are gathered (K3)
     when first read.  Markov models read only [-1], so a step costs one gather, not `time`."""
 
-    def __init__(self, latents, index):
+    def __init__(self, latents, index, newest=None):
         self._latents = list(latents)
         self._index = index
-        self._cache = {}
+        # `newest`: the last entry already re-indexed (the fused step copies it along the way)
+        self._cache = {} if newest is None else {len(self._latents) - 1: newest}
 
     def __len__(self):
         return len(self._latents)
@@ -196,12 +197,19 @@ def infer(inference_algorithm, observations, initial, transition, emission,
                 if feed is None:
                     feed = _FEED_OVERRIDE if _FEED_OVERRIDE is not None else \
                         _UniformFeed(batch_size, num_timesteps - 1, previous.device)
-                index = _ops.ancestor_index(previous, feed.next())
+                # K2; the same launch re-indexes the newest latent (what a Markov model reads) and
+                # returns the row log-sum-exp when the step before left it pending (K5 route)
+                newest = history[-1] if torch.is_tensor(history[-1]) else None
+                index, lse_previous, moved = _ops.resample_step(previous, feed.next(), newest,
+                                                                want_lse=step_lse[-1] is None)
+                if step_lse[-1] is None:
+                    step_lse[-1] = lse_previous
                 indices.append(index)
                 if _HISTORY_MODE == "lazy":
-                    ancestors = ResampledHistory(history, index)
+                    ancestors = ResampledHistory(history, index, newest=moved)
                 else:
-                    ancestors = [state.resample(x, index) for x in history]
+                    ancestors = [state.resample(x, index) for x in history[:-1]]
+                    ancestors.append(moved if moved is not None else state.resample(history[-1], index))
             else:
                 ancestors = history
             proposal_dist = proposal(previous_latents=ancestors, time=time,
@@ -227,7 +235,10 @@ def infer(inference_algorithm, observations, initial, transition, emission,
             log_weight_t = state.normal_log_weight(prior_dist, proposal_dist, latent, emission_dist,
                                                    observation)
         if log_weight_t is not None:
-            lse_t = _ops.row_logsumexp(log_weight_t)
+            # K5 gave the log-weights only; their row log-sum-exp comes out of the next resampling
+            # launch for free — or from K1 when no resampling follows
+            pending = use_smc and time + 1 < num_timesteps
+            lse_t = None if pending else _ops.row_logsumexp(log_weight_t)
         else:
             log_q = state.log_prob(proposal_dist, latent)
             log_p = state.log_prob(prior_dist, latent)

@@ -8,7 +8,7 @@ launches one process per GPU via torch.distributed.run; each rank owns `B` batch
 scaling), the only collective is the all-reduce of sum_b log Z_b (RCCL over xGMI).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the resample-gather kernel (K3), timed per launch with HIP events on its stream
+  roofline     : the resampling kernel (fused step K2+K3, or K3 alone), timed per launch with HIP events on its stream
                  while the same steps run again; achieved = algorithmic bytes / launch time;
   cpu_baseline : oracle/reference_port.py (the op-for-op CPU port of the reference, kind "port")
                  timed on this box's host cores on a bounded sample of the same workload;
@@ -282,8 +282,12 @@ def main():
     provider.timer = None
     # the roofline kernel: the resample gather (K3); a workload that never resamples (c3, IWAE) is
     # what BASELINE.json uses to isolate the fused log-weight + log-sum-exp kernel (K1)
-    name, label = ("resample_gather", "resample_gather_kernel (K3)") if "resample_gather" in kernels \
-        else ("logweight_lse", "logweight_lse_kernel (K1)")
+    if "moved_GBps" in kernels.get("resample_step", {}):
+        name, label = "resample_step", "ancestor_index_inv_kernel with payload (fused step: K2 + K3)"
+    elif "resample_gather" in kernels:
+        name, label = "resample_gather", "resample_gather_kernel (K3)"
+    else:
+        name, label = "logweight_lse", "logweight_lse_kernel (K1)"
     dominant = kernels.get(name)
     roofline = None
     if dominant:

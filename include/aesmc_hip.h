@@ -157,6 +157,23 @@ typedef struct aesmc_view3 {
 int aesmc_normal_logweight(int dtype, const aesmc_view3 *views, void *out_lw, int64_t B, int64_t K,
                            int64_t Dx, int64_t Dy, void *stream);
 
+/* Fused resampling step — K2, plus two optional by-products of having the whole batch row in one
+ * workgroup:
+ *   out_lse[b] = logsumexp_k log_w[b,k]  (dtype of log_w; the row's term of log Z,
+ *                aesmc/inference.py:130-132), computed in float64 from K2's own max and sum — the
+ *                special rows give what K1 gives (NaN, +inf, -inf);
+ *   dst[b,k,:] = src[b, out_idx[b,k], :]  (K3's contract for ONE payload tensor,
+ *                aesmc/state.py:158-183), with the indices taken from LDS instead of HBM.
+ * `out_lse` may be NULL; `src` and `dst` are NULL together.  out_idx is always written and equals
+ * aesmc_ancestor_index's bit for bit; dst equals aesmc_resample_gather's (rows of a degenerate
+ * batch row: source row K-1, as K3's clamp gives).  Returns AESMC_ERR_UNSUPPORTED — caller takes
+ * K2 then K3 — when K exceeds aesmc_ancestor_index_lds_max_particles(), or the payload rows are
+ * not multiples of 4 bytes / dst is not 16-byte aligned with a 16-byte batch-row pitch.
+ */
+int aesmc_resample_step(int dtype, const void *log_w, const double *u, int64_t *out_idx, void *out_lse,
+                        const void *src, void *dst, int32_t *flags, int64_t B, int64_t K,
+                        int64_t row_bytes, int64_t src_stride_b, int64_t src_stride_k, void *stream);
+
 /* K6 — reparameterised Normal draw  out[b,k,j] = loc[b,k,j] + eps[b,k,j] * scale[b,k,j].
  *
  * Replaces the broadcast multiply and the add that follow the noise draw in

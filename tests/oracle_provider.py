@@ -49,3 +49,13 @@ class OracleKernels:
         out, flags = kernel_oracle.gather_backward(grad_out.detach().contiguous().numpy(), idx.numpy())
         self._flags |= flags
         return torch.from_numpy(out)
+
+    def step_covers(self, log_w, payload=None):
+        return log_w.dim() == 2 and log_w.numel() > 0 and (payload is None or torch.is_tensor(payload))
+
+    def resample_step(self, log_w, u, payload=None, want_lse=False):
+        """The fused step as the composition it must equal: K2, then K1's row log-sum-exp and K3."""
+        idx = self.ancestor_index(log_w, u)
+        lse = self.logweight_lse(log_w, None, None, want_lw=False, want_lse=True)[1] if want_lse else None
+        moved = self.gather(payload, idx) if payload is not None else None
+        return idx, lse, moved

@@ -597,3 +597,61 @@ def test_sample_draws_what_torch_draws_and_differentiates(hip_device):
             assert d1.shape == (B, K, D) and torch.equal(d1, d0)
             torch.testing.assert_close(gl1, gl0, rtol=1e-6, atol=1e-6)
             torch.testing.assert_close(gs1, gs0, rtol=1e-5, atol=1e-5)
+
+
+# ---- fused resampling step -----------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 16), (3, 7), (5, 64), (4, 1000), (7, 1024), (3, 1025), (2, 4096),
+                                   (2, 5000), (1, 20000), (1, 32768)])
+@pytest.mark.parametrize("row", [None, (1,), (4,), (10,), (3, 4), (5,)])
+def test_resample_step_equals_its_parts(kernels, hip_device, dtype, shape, row):
+    """idx bit-exact == K2 (and the oracle), payload bit-exact == K3 on that idx, lse within the K1 bar."""
+    B, K = shape
+    rng = np.random.RandomState(B * 7919 + K + (0 if row is None else 13 * sum(row)))
+    lw = dev((rng.randn(B, K) * 2.5).astype(dtype), hip_device)
+    u = dev(rng.uniform(size=B), hip_device)
+    payload = None if row is None else dev(rng.randn(B, K, *row).astype(np.float32), hip_device)
+    out = kernels.resample_step(lw, u, payload, want_lse=True)
+    want_idx = kernels.ancestor_index(lw, u)
+    if out is None:  # declined: payload rows the fused launch does not cover
+        assert payload is not None and (K * payload[0, 0].numel() * 4) % 16 != 0
+        return
+    idx, lse, moved = out
+    assert torch.equal(idx, want_idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(),
+                                  kernel_oracle.ancestor_index(lw.cpu().numpy(), u.cpu().numpy())[0])
+    _, want_lse = kernel_oracle.logweight_lse(lw.cpu().numpy(), None, None)
+    rtol, atol = tol(dtype)
+    np.testing.assert_allclose(lse.cpu().numpy(), want_lse, rtol=rtol, atol=atol)
+    if payload is None:
+        assert moved is None
+    else:
+        assert torch.equal(moved, kernels.gather(payload, want_idx))
+    assert kernels.read_flags(hip_device) == 0
+
+
+def test_resample_step_strided_payload_and_special_rows(kernels, hip_device):
+    from aesmc_amd import _lib
+    rng = np.random.RandomState(5)
+    B, K = 6, 128
+    lw = rng.randn(B, K).astype(np.float32)
+    lw[1, :] = -np.inf          # degenerate: index K, lse -inf
+    lw[2, 5] = np.inf           # degenerate: lse +inf
+    lw[3, 7] = np.nan           # NaN: lse NaN
+    lw[4, ::2] = -np.inf        # fine: zero-weight particles
+    lw_d, u = dev(lw, hip_device), dev(rng.uniform(size=B), hip_device)
+    base = dev(rng.randn(B, 2 * K, 12).astype(np.float32), hip_device)
+    payload = base[:, ::2, 2:10]                                    # strided in k, offset rows of 8 floats
+    idx, lse, moved = kernels.resample_step(lw_d, u, payload, want_lse=True)
+    flags = kernels.read_flags(hip_device)
+    assert flags & _lib.FLAG_NAN_LOG_WEIGHT and flags & _lib.FLAG_DEGENERATE_ROW
+    want_idx = kernels.ancestor_index(lw_d, u)
+    assert torch.equal(idx, want_idx)
+    want_moved = kernels.gather(payload, want_idx)                  # K3 clamps index K to K - 1
+    kernels.read_flags(hip_device)
+    assert torch.equal(moved, want_moved)
+    lse = lse.cpu().numpy()
+    assert lse[1] == -np.inf and lse[2] == np.inf and np.isnan(lse[3])
+    good = [0, 4, 5]
+    _, want_lse = kernel_oracle.logweight_lse(lw[good], None, None)
+    np.testing.assert_allclose(lse[good], want_lse, rtol=F32_RTOL, atol=F32_ATOL)

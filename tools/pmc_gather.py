@@ -5,6 +5,8 @@ Order of resample_gather launches (3 each): for shape in (c2, c4):
   calibration: identity index (every source row read exactly once: bytes known exactly)
   workload   : systematic-resampling indices from log-weights ~ N(0,1)   (ESS/K ~ 0.37)
   degenerate : indices from log-weights ~ 5 N(0,1)                        (few survivors)
+Order of ancestor_index_inv_kernel launches per shape: K2 alone on the two weight sets (1 each),
+then the fused step (K2 + row log-sum-exp + payload gather) 3x on each weight set.
 """
 import sys
 import os
@@ -19,12 +21,18 @@ for (B, K, d) in [(256, 1024, 10), (1024, 4096, 10)]:
     value = torch.randn(B, K, d, device=dev, generator=gen)
     u = torch.rand(B, device=dev, dtype=torch.float64, generator=gen)
     identity = torch.arange(K, device=dev).unsqueeze(0).expand(B, K).contiguous()
-    idx1 = k.ancestor_index(torch.randn(B, K, device=dev, generator=gen), u)
-    idx5 = k.ancestor_index(5 * torch.randn(B, K, device=dev, generator=gen), u)
+    lw1 = torch.randn(B, K, device=dev, generator=gen)
+    lw5 = 5 * torch.randn(B, K, device=dev, generator=gen)
+    idx1 = k.ancestor_index(lw1, u)
+    idx5 = k.ancestor_index(lw5, u)
     torch.cuda.synchronize()
     for idx in (identity, idx1, idx5):
         for _ in range(3):
             k.gather(value, idx)
+        torch.cuda.synchronize()
+    for lw in (lw1, lw5):
+        for _ in range(3):
+            k.resample_step(lw, u, value, want_lse=True)
         torch.cuda.synchronize()
     uniq1 = float((idx1[:, 1:] != idx1[:, :-1]).sum() + B) / (B * K)
     uniq5 = float((idx5[:, 1:] != idx5[:, :-1]).sum() + B) / (B * K)
