@@ -530,26 +530,31 @@ class HipKernels:
         return out
 
     def normal_rsample(self, eps, loc, scale):
-        """loc + eps * scale (product rounded first, as eager PyTorch) -> dense tensor of eps's
-        shape [B,K,*]; loc and scale are views already expanded to that shape."""
+        """loc + eps * scale (product rounded first, as eager PyTorch) -> DENSE tensor of eps's
+        shape [B,K,*]; loc and scale are views already expanded to that shape.  eps may be the
+        transposed view of a [K,B,*] draw: the result is written in [B,K,*] order directly."""
         tag = _DTYPE_TAG[eps.dtype]
-        eps = eps.contiguous()
-        (_, _, D), (loc, sm, _), (scale, ss, _) = [self._view3(t) for t in (eps, loc, scale)]
+        (eps, se, D), (loc, sm, _), (scale, ss, _) = [self._view3(t) for t in (eps, loc, scale)]
         B, K = eps.shape[:2]
-        out = torch.empty_like(eps)
+        out = torch.empty(eps.shape, dtype=eps.dtype, device=eps.device)
         if out.numel() == 0:
             return out
-        loc_view, scale_view = _lib.View3(_ptr(loc), *sm), _lib.View3(_ptr(scale), *ss)
         with torch.cuda.device(eps.device):
-            args = (tag, _ptr(eps), ctypes.byref(loc_view), ctypes.byref(scale_view), _ptr(out), B, K, D,
-                    self._stream(eps))
-            _lib.check(self._lib.aesmc_normal_rsample(*args), "aesmc_normal_rsample")
+            for attempt in (0, 1):
+                views = [_lib.View3(_ptr(t), *st) for t, st in ((eps, se), (loc, sm), (scale, ss))]
+                args = (tag, ctypes.byref(views[0]), ctypes.byref(views[1]), ctypes.byref(views[2]), _ptr(out),
+                        B, K, D, self._stream(eps))
+                status = self._lib.aesmc_normal_rsample(*args)
+                if status != 2 or attempt == 1:
+                    break
+                eps = eps.contiguous()   # a noise layout the kernel does not know: materialise it
+                se = (eps.stride(0), eps.stride(1), 1)
+            _lib.check(status, "aesmc_normal_rsample")
             if self.timer is not None:
                 nbytes = sum(self._unique_bytes(t) for t in (eps, loc, scale)) + out.numel() * out.element_size()
                 self.timer.note("normal_rsample", lambda: self._lib.aesmc_normal_rsample(*args), nbytes,
-                                (eps, loc, scale, out, loc_view, scale_view))
+                                (eps, loc, scale, out, views))
         return out
-
 
 _provider = None
 _provider_lock = threading.Lock()

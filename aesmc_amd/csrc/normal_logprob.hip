@@ -25,6 +25,18 @@ struct Strides3 {
 constexpr int kLpBlock = 256;
 constexpr int kTileBytes = 32 * 1024;  // LDS tile budget per workgroup
 
+// Particles per tile: as many as the LDS budget holds, as a power of two (a dense operand's tile
+// then starts on a 16-byte boundary whenever its batch row does) between 256 — one per lane — and
+// 2048: with a handful of values per particle a 256-particle tile is a few hundred bytes of work
+// per workgroup and the launch is all scheduling (d=1, 33 M particles: 346 us -> see DESIGN.md).
+static inline uint32_t particles_per_tile(int64_t budget_elems, int64_t elems_per_particle, int64_t K) {
+  int64_t fit = budget_elems / elems_per_particle;
+  uint32_t P = 1;
+  while ((int64_t)P * 2 <= fit && P < 2048u) P *= 2;
+  if (P > K) P = (uint32_t)K;
+  return P;
+}
+
 template <typename T> struct NormConst;
 template <> struct NormConst<float> {
   // (float)math.log(math.sqrt(2 * math.pi)) as PyTorch's scalar operand is narrowed
@@ -281,9 +293,7 @@ static int launch_lps(const void *value, const void *loc, const void *scale, voi
     return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
   }
   if (D <= 64 && is_scalar(ss) && (vdense || ldense)) {
-    uint32_t P = (uint32_t)((kTileBytes / (int)sizeof(T)) / D);
-    if (P > 256) P = 256;
-    if (P > K) P = (uint32_t)K;
+    const uint32_t P = particles_per_tile(kTileBytes / (int)sizeof(T), D, K);
     const uint32_t tiles = (uint32_t)((K + P - 1) / P);
     // a dense operand's tile must start on a 16-byte boundary: P*D (tile pitch) and K*D (row pitch)
     if ((uint64_t)B * tiles <= 0x7fffffffull && (tiles == 1 || ((uint64_t)P * D) % N == 0)) {
@@ -303,9 +313,7 @@ static int launch_lps(const void *value, const void *loc, const void *scale, voi
     }
   }
   if (D <= 64) {
-    uint32_t P = (uint32_t)((kTileBytes / (int)sizeof(T)) / D);
-    if (P > 256) P = 256;
-    if (P > K) P = (uint32_t)K;
+    const uint32_t P = particles_per_tile(kTileBytes / (int)sizeof(T), D, K);
     const uint32_t tiles = (uint32_t)((K + P - 1) / P);
     if ((uint64_t)B * tiles > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
     const uint32_t ne = P * (uint32_t)D;
@@ -481,15 +489,83 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
   }
 }
 
+// K5 with one value per particle in both x and y (Dx == Dy == 1, e.g. the scalar IWAE model of
+// BASELINE.json configs[2]): no d-sum, so no LDS tile — a lane takes four consecutive particles of
+// a batch row; each operand is read as one 16-byte load (dense along k), one scalar load
+// (broadcast along k) or four strided ones.  Same element arithmetic and the same (p + g) - q
+// combine as the tiled kernel; the sums of one term are `0 + term`, as there.
+template <typename T>
+__device__ __forceinline__ void load_four(const View3 &v, int64_t b, uint32_t k0, uint32_t live, T (&dst)[4]) {
+  const T *row = reinterpret_cast<const T *>(v.ptr) + b * v.st.b;
+  if (v.st.k == 0) {
+    const T value = row[0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = value;
+  } else if (v.st.k == 1 && live == 4 && ((reinterpret_cast<uintptr_t>(row + k0) & (4 * sizeof(T) - 1)) == 0)) {
+    struct alignas(4 * sizeof(T)) Four { T v[4]; };
+    const Four packed = *reinterpret_cast<const Four *>(row + k0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = packed.v[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = row[(int64_t)(k0 + (r < (int)live ? r : 0)) * v.st.k];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kLpBlock) void normal_logweight_d1_kernel(
+    View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
+    T *__restrict__ out, uint32_t K, uint32_t blocks_per_row) {
+  const uint32_t b = blockIdx.x / blocks_per_row;
+  const uint32_t k0 = ((blockIdx.x - b * blocks_per_row) * kLpBlock + threadIdx.x) * 4;
+  if (k0 >= K) return;
+  const uint32_t live = min(4u, K - k0);
+  const T s_p = reinterpret_cast<const T *>(sc_p.ptr)[0], s_g = reinterpret_cast<const T *>(sc_g.ptr)[0],
+          s_q = reinterpret_cast<const T *>(sc_q.ptr)[0];
+  const T two_var_p = T(2) * (s_p * s_p), log_p = Num<T>::log(s_p);
+  const T two_var_g = T(2) * (s_g * s_g), log_g = Num<T>::log(s_g);
+  const T two_var_q = T(2) * (s_q * s_q), log_q = Num<T>::log(s_q);
+  const T half_log_2pi = NormConst<T>::half_log_2pi();
+  T xv[4], pv[4], qv[4], yv[4], gv[4], lw[4];
+  load_four<T>(x, b, k0, live, xv);
+  load_four<T>(mu_p, b, k0, live, pv);
+  load_four<T>(mu_q, b, k0, live, qv);
+  load_four<T>(y, b, k0, live, yv);
+  load_four<T>(mu_g, b, k0, live, gv);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const T dp = xv[r] - pv[r], dq = xv[r] - qv[r], dg = yv[r] - gv[r];
+    const T sum_p = T(0) + ((-(dp * dp)) / two_var_p - log_p - half_log_2pi);
+    const T sum_q = T(0) + ((-(dq * dq)) / two_var_q - log_q - half_log_2pi);
+    const T sum_g = T(0) + ((-(dg * dg)) / two_var_g - log_g - half_log_2pi);
+    lw[r] = (sum_p + sum_g) - sum_q;
+  }
+  T *orow = out + (int64_t)b * K + k0;
+  if (live == 4 && ((reinterpret_cast<uintptr_t>(orow) & (4 * sizeof(T) - 1)) == 0)) {
+    struct alignas(4 * sizeof(T)) Four { T v[4]; };
+    Four packed;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) packed.v[r] = lw[r];
+    *reinterpret_cast<Four *>(orow) = packed;
+  } else {
+    for (uint32_t r = 0; r < live; ++r) orow[r] = lw[r];
+  }
+}
+
 template <typename T>
 static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int64_t Dx, int64_t Dy,
                             hipStream_t s) {
   constexpr int N = Vec16<T>::N;
   if (Dx > 64 || Dy > 64 || Dx < 1 || Dy < 1) return AESMC_ERR_UNSUPPORTED;
   if (!is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st)) return AESMC_ERR_UNSUPPORTED;
-  uint32_t P = (uint32_t)((kTileBytes / (int)sizeof(T)) / (2 * Dx + Dy));
-  if (P > 256) P = 256;
-  if (P > K) P = (uint32_t)K;
+  if (Dx == 1 && Dy == 1) {
+    const uint32_t bpr = (uint32_t)((K + 4 * kLpBlock - 1) / (4 * kLpBlock));
+    if ((uint64_t)B * bpr > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((normal_logweight_d1_kernel<T>), dim3((unsigned)(B * bpr)), dim3(kLpBlock), 0, s, v[0],
+                       v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, bpr);
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
+  const uint32_t P = particles_per_tile(kTileBytes / (int)sizeof(T), 2 * Dx + Dy, K);
   if (P == 0) return AESMC_ERR_UNSUPPORTED;
   const uint32_t tiles = (uint32_t)((K + P - 1) / P);
   if ((uint64_t)B * tiles > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;

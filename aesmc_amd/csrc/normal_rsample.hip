@@ -8,8 +8,11 @@
 // same particles as the reference.  The product is rounded before the sum (the build disables
 // contraction), so every element equals the eager result bit for bit.
 //
-// eps and out are dense [B,K,D]; loc and scale are [B,K,D] views by element strides (0 =
-// broadcast), as in K4.
+// out is dense [B,K,D]; eps, loc and scale are [B,K,D] views by element strides (0 = broadcast),
+// as in K4.  Besides dense noise the kernel knows the TRANSPOSED layout: a BATCH_EXPANDED
+// distribution is sampled as [K,B,...] and handed on as a transposed view (aesmc/state.py:102-103),
+// which every later consumer would read with a stride of B rows; the draw is instead written
+// straight into [B,K,...] order through an LDS tile, so the time-0 latent is dense from the start.
 #include "common.hpp"
 
 namespace aesmc {
@@ -67,14 +70,68 @@ __global__ __launch_bounds__(kRsBlock) void normal_rsample_strided_kernel(
   out[i] = mu + eps[i] * sigma;
 }
 
+// eps laid out [K,B,D] dense (read as the view eps[b,k,j] = base[(k B + b) D + j]): a workgroup
+// owns a TILE x TILE block of (k, b) rows, reads it in runs along (b, j), parks the finished draws
+// in LDS and writes them in runs along (k, j).
 template <typename T>
-static int launch_rsample(const void *eps, const aesmc_view3 &loc, const aesmc_view3 &scale, void *out,
-                          int64_t B, int64_t K, int64_t D, hipStream_t stream) {
+__global__ __launch_bounds__(kRsBlock) void normal_rsample_transposed_kernel(
+    const T *__restrict__ eps, const T *__restrict__ loc, const T *__restrict__ scale,
+    T *__restrict__ out, uint32_t B, uint32_t K, uint32_t D, uint32_t tile, RsStrides sm, RsStrides ss) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+  T *park = reinterpret_cast<T *>(rs_smem);             // [tile][tile * D + 1]
+  const uint32_t b0 = blockIdx.x * tile, k0 = blockIdx.y * tile;
+  const uint32_t nb = min(tile, B - b0), nk = min(tile, K - k0);
+  const uint32_t pitch = tile * D + 1;
+  const uint32_t run_in = nb * D;
+  for (uint32_t t = threadIdx.x; t < nk * run_in; t += kRsBlock) {
+    const uint32_t kk = t / run_in, rest = t - kk * run_in;
+    const uint32_t bb = rest / D, j = rest - bb * D;
+    const int64_t b = b0 + bb, k = k0 + kk;
+    const T noise = eps[((uint64_t)k * B + (uint64_t)b) * D + j];
+    const T mu = loc[b * sm.b + k * sm.k + (int64_t)j * sm.d];
+    const T sigma = scale[b * ss.b + k * ss.k + (int64_t)j * ss.d];
+    park[bb * pitch + kk * D + j] = mu + noise * sigma;
+  }
+  __syncthreads();
+  const uint32_t run_out = nk * D;
+  for (uint32_t t = threadIdx.x; t < nb * run_out; t += kRsBlock) {
+    const uint32_t bb = t / run_out, rest = t - bb * run_out;          // rest = kk * D + j
+    out[((uint64_t)(b0 + bb) * K + k0) * D + rest] = park[bb * pitch + rest];
+  }
+}
+
+template <typename T>
+static int launch_rsample(const aesmc_view3 &eps_view, const aesmc_view3 &loc, const aesmc_view3 &scale,
+                          void *out, int64_t B, int64_t K, int64_t D, hipStream_t stream) {
   const uint64_t n = (uint64_t)B * K * D;
-  const T *e = static_cast<const T *>(eps);
+  const T *e = static_cast<const T *>(eps_view.ptr);
   const T *m = static_cast<const T *>(loc.ptr);
   const T *s = static_cast<const T *>(scale.ptr);
   T *o = static_cast<T *>(out);
+  const bool eps_dense = (D == 1 || eps_view.stride_d == 1) && (K == 1 || eps_view.stride_k == D) &&
+                         (B == 1 || eps_view.stride_b == K * D);
+  if (!eps_dense) {
+    const bool eps_transposed = (D == 1 || eps_view.stride_d == 1) && eps_view.stride_b == D &&
+                                eps_view.stride_k == B * D;
+    uint32_t tile = 0;
+    if (eps_transposed) {
+      const uint32_t budget = 48 * 1024 / sizeof(T);
+      for (uint32_t cand : {64u, 32u, 16u, 8u})
+        if ((uint64_t)cand * (cand * D + 1) <= budget) {
+          tile = cand;
+          break;
+        }
+    }
+    if (tile == 0) return AESMC_ERR_UNSUPPORTED;    // the caller materialises eps and comes back
+    const dim3 grid((unsigned)((B + tile - 1) / tile), (unsigned)((K + tile - 1) / tile));
+    if (grid.y > 65535u) return AESMC_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)tile * (tile * D + 1) * sizeof(T);
+    hipLaunchKernelGGL(normal_rsample_transposed_kernel<T>, grid, dim3(kRsBlock), lds, stream, e, m, s, o,
+                       (uint32_t)B, (uint32_t)K, (uint32_t)D, tile,
+                       RsStrides{loc.stride_b, loc.stride_k, loc.stride_d},
+                       RsStrides{scale.stride_b, scale.stride_k, scale.stride_d});
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
   const bool loc_dense = (D == 1 || loc.stride_d == 1) && (K == 1 || loc.stride_k == D) &&
                          (B == 1 || loc.stride_b == K * D);
   const bool scale_by_column = (B == 1 || scale.stride_b == 0) && (K == 1 || scale.stride_k == 0) &&
@@ -102,16 +159,16 @@ static int launch_rsample(const void *eps, const aesmc_view3 &loc, const aesmc_v
 
 }  // namespace aesmc
 
-extern "C" int aesmc_normal_rsample(int dtype, const void *eps, const aesmc_view3 *loc,
+extern "C" int aesmc_normal_rsample(int dtype, const aesmc_view3 *eps, const aesmc_view3 *loc,
                                     const aesmc_view3 *scale, void *out, int64_t B, int64_t K, int64_t D,
                                     void *stream) {
   using namespace aesmc;
-  if (!eps || !loc || !scale || !out || !loc->ptr || !scale->ptr || B < 0 || K < 0 || D < 0)
+  if (!eps || !loc || !scale || !out || !eps->ptr || !loc->ptr || !scale->ptr || B < 0 || K < 0 || D < 0)
     return AESMC_ERR_INVALID_ARGUMENT;
   if (B == 0 || K == 0 || D == 0) return AESMC_OK;
   if (K >= (1ll << 31) || D >= (1ll << 31) || B >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AESMC_F32) return launch_rsample<float>(eps, *loc, *scale, out, B, K, D, s);
-  if (dtype == AESMC_F64) return launch_rsample<double>(eps, *loc, *scale, out, B, K, D, s);
+  if (dtype == AESMC_F32) return launch_rsample<float>(*eps, *loc, *scale, out, B, K, D, s);
+  if (dtype == AESMC_F64) return launch_rsample<double>(*eps, *loc, *scale, out, B, K, D, s);
   return AESMC_ERR_INVALID_ARGUMENT;
 }

@@ -128,11 +128,12 @@ def sample(distribution, batch_size, num_particles):
     if not distribution.has_rsample:
         raise ValueError("distribution not reparameterizable")
     sample_shape = _SAMPLE_SHAPE[mode](batch_size, num_particles)
-    draw = _fused_normal_rsample(distribution, sample_shape) if _FUSED_NORMAL else None
+    batch_expanded = mode == BatchShapeMode.BATCH_EXPANDED
+    draw = _fused_normal_rsample(distribution, sample_shape, batch_expanded) if _FUSED_NORMAL else None
     if draw is None:
         draw = distribution.rsample(sample_shape=sample_shape)
-    if mode == BatchShapeMode.BATCH_EXPANDED:
-        draw = draw.transpose(0, 1)  # [K, B, ...] -> [B, K, ...] view, as in the reference
+        if batch_expanded:
+            draw = draw.transpose(0, 1)  # [K, B, ...] -> [B, K, ...] view, as in the reference
     return draw
 
 
@@ -211,12 +212,14 @@ def set_fused_normal(enabled):
     _FUSED_NORMAL = bool(enabled)
 
 
-def _fused_normal_rsample(distribution, sample_shape):
+def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
     """`distribution.rsample(sample_shape)` for a plain Normal (optionally inside Independent) with
     tensor parameters on the HIP device: the noise comes from the very call torch makes
     (torch/distributions/normal.py rsample -> `_standard_normal`, so the generator advances
     identically) and `loc + eps * scale` is one pass of kernel K6 instead of two eager ones.
-    None for anything else."""
+    With `swap_leading_dims` (a BATCH_EXPANDED distribution drawn as [K, B, ...]) the result is
+    the transposed draw, [B, K, ...] — the same values the reference's `.transpose(0, 1)` view
+    holds (state.py:102-103), stored densely.  None for anything else."""
     base = distribution
     if type(base) is torch.distributions.Independent:
         base = base.base_dist
@@ -230,7 +233,10 @@ def _fused_normal_rsample(distribution, sample_shape):
     if len(shape) < 2:
         return None
     eps = torch.distributions.normal._standard_normal(shape, dtype=loc.dtype, device=loc.device)
-    return _ops.normal_rsample(eps, loc.expand(shape), scale.expand(shape))
+    loc, scale = loc.expand(shape), scale.expand(shape)
+    if swap_leading_dims:
+        eps, loc, scale = eps.transpose(0, 1), loc.transpose(0, 1), scale.transpose(0, 1)
+    return _ops.normal_rsample(eps, loc, scale)
 
 
 def _fused_normal_views(distribution, value, missing):

@@ -178,12 +178,16 @@ int aesmc_resample_step(int dtype, const void *log_w, const double *u, int64_t *
  *
  * Replaces the broadcast multiply and the add that follow the noise draw in
  * torch.distributions.Normal.rsample as aesmc/state.py:61-111 (`state.sample`) calls it; the
- * product is rounded before the sum, so the result equals eager PyTorch bit for bit.  `eps` (the
- * caller's standard-normal noise) and `out` are dense [B,K,D]; `loc` and `scale` are [B,K,D]
- * views by element strides (0 = broadcast); `out` must not alias the inputs.
+ * product is rounded before the sum, so the result equals eager PyTorch bit for bit.  `out` is
+ * dense [B,K,D]; `eps` (the caller's standard-normal noise), `loc` and `scale` are [B,K,D] views
+ * by element strides (0 = broadcast).  eps must be dense in [B,K,D] order or in [K,B,D] order
+ * (stride_b = D, stride_k = B*D: the BATCH_EXPANDED draw of aesmc/state.py:102-103, written here
+ * directly into [B,K,D] order); other eps layouts return AESMC_ERR_UNSUPPORTED.  `out` must not
+ * alias the inputs.
  */
-int aesmc_normal_rsample(int dtype, const void *eps, const aesmc_view3 *loc, const aesmc_view3 *scale,
-                         void *out, int64_t B, int64_t K, int64_t D, void *stream);
+int aesmc_normal_rsample(int dtype, const aesmc_view3 *eps, const aesmc_view3 *loc,
+                         const aesmc_view3 *scale, void *out, int64_t B, int64_t K, int64_t D,
+                         void *stream);
 
 #ifdef __cplusplus
 }

@@ -450,7 +450,7 @@ def test_normal_logprob_sum_strided_views(kernels, hip_device):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-@pytest.mark.parametrize("B,K,dx,dy", [(2, 16, 1, 1), (3, 37, 10, 10), (4, 300, 10, 4), (2, 1000, 3, 7),
+@pytest.mark.parametrize("B,K,dx,dy", [(2, 16, 1, 1), (3, 37, 1, 1), (2, 1030, 1, 1), (3, 4096, 1, 1), (3, 37, 10, 10), (4, 300, 10, 4), (2, 1000, 3, 7),
                                        (1, 257, 64, 64), (5, 64, 33, 2), (2, 4096, 10, 10)])
 def test_normal_logweight_is_bitwise_the_unfused_route(kernels, hip_device, dtype, B, K, dx, dy):
     """K5 == K4 x 3 combined by K1, bit for bit, for the operand layouts the SMC loop produces."""
@@ -655,3 +655,23 @@ def test_resample_step_strided_payload_and_special_rows(kernels, hip_device):
     good = [0, 4, 5]
     _, want_lse = kernel_oracle.logweight_lse(lw[good], None, None)
     np.testing.assert_allclose(lse[good], want_lse, rtol=F32_RTOL, atol=F32_ATOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("K,B,rest", [(1, 1, ()), (16, 4, ()), (33, 70, ()), (257, 129, ()), (8192, 16, ()),
+                                      (33, 70, (3,)), (100, 65, (10,)), (40, 9, (4, 5)), (17, 5, (100,)),
+                                      (9, 3, (200,))])
+@pytest.mark.parametrize("loc_kind", ["per_batch", "vector", "scalar"])
+def test_normal_rsample_transposed_noise(kernels, hip_device, dtype, K, B, rest, loc_kind):
+    """BATCH_EXPANDED layout: noise drawn as [K,B,...], result wanted as [B,K,...] (state.py:102-103)."""
+    gen = torch.Generator().manual_seed(K * 31 + B)
+    make = lambda *s: torch.randn(tuple(s), generator=gen, dtype=dtype).to(hip_device)
+    shape = (K, B) + rest
+    eps = make(*shape)
+    loc = make(*{"per_batch": (B,) + rest, "vector": rest, "scalar": ()}[loc_kind])
+    scale = make(*rest).abs() + 0.1
+    got = kernels.normal_rsample(eps.transpose(0, 1), loc.expand(shape).transpose(0, 1),
+                                 scale.expand(shape).transpose(0, 1))
+    want = (loc + eps * scale).transpose(0, 1)
+    assert got.shape == want.shape and got.is_contiguous()
+    assert torch.equal(got, want)
