@@ -555,6 +555,53 @@ class HipKernels:
                 self.timer.note("normal_rsample", lambda: self._lib.aesmc_normal_rsample(*args), nbytes,
                                 (eps, loc, scale, out, views))
         return out
+    # ---- K7 ------------------------------------------------------------------------------------
+    def particle_summary(self, log_w, value=None, want_log_ess=False, want_mean=False, want_second=False):
+        """(log_ess [B], mean [B,...], second moment [B,...]) under w = softmax(log_w, dim=1); entries
+        not asked for are None.  value [B,K,...] of log_w's dtype, may be strided."""
+        _require_hip(log_w, "log_weight")
+        tag = _tag(log_w, "log_weight")
+        if log_w.dim() != 2:
+            raise ValueError("aesmc_amd: log_weight must be [batch_size, num_particles], got {}"
+                             .format(tuple(log_w.shape)))
+        B, K = log_w.shape
+        if K == 0:
+            raise ValueError("aesmc_amd: particle summaries need at least one particle")
+        log_w = log_w.contiguous()
+        view, D, tail = None, 0, ()
+        if want_mean or want_second:
+            _require_hip(value, "value")
+            if value.dtype != log_w.dtype or value.device != log_w.device:
+                raise ValueError("aesmc_amd: value must be {} on {}".format(log_w.dtype, log_w.device))
+            assert value.size()[:2] == log_w.size()
+            tail = tuple(value.shape[2:])
+            value, sv, D = self._view3(value)
+            view = _lib.View3(_ptr(value), *sv)
+        make = lambda shape: torch.empty(shape, dtype=log_w.dtype, device=log_w.device)
+        log_ess = make((B,)) if want_log_ess else None
+        mean = make((B,) + tail) if want_mean else None
+        second = make((B,) + tail) if want_second else None
+        if B == 0:
+            return log_ess, mean, second
+        if view is None or D == 0:
+            view, D = None, 0
+            if mean is not None:
+                mean.zero_()        # rows without values: empty sums
+            if second is not None:
+                second.zero_()
+        ws_bytes = int(self._lib.aesmc_particle_summary_workspace_bytes(tag, B, K, D))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=log_w.device) if ws_bytes else None
+        with torch.cuda.device(log_w.device):
+            args = (tag, _ptr(log_w), ctypes.byref(view) if view is not None else None,
+                    _ptr(log_ess), _ptr(mean) if D > 0 else 0, _ptr(second) if D > 0 else 0, B, K, D,
+                    _ptr(ws), ws_bytes, self._stream(log_w))
+            _lib.check(self._lib.aesmc_particle_summary(*args), "aesmc_particle_summary")
+            if self.timer is not None:
+                nbytes = log_w.numel() * log_w.element_size() + (self._unique_bytes(value) if view is not None else 0)
+                self.timer.note("particle_summary", lambda: self._lib.aesmc_particle_summary(*args), nbytes,
+                                (log_w, value, view, log_ess, mean, second, ws))
+        return log_ess, mean, second
+
 
 _provider = None
 _provider_lock = threading.Lock()

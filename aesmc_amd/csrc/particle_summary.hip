@@ -1,0 +1,305 @@
+// K7: weighted particle summaries in one pass over the particles.
+//
+//   w[b,k]        = softmax_k log_w[b,k]
+//   mean[b,j]     = sum_k w[b,k] value[b,k,j]                  aesmc/statistics.py:47-60
+//   second[b,j]   = sum_k w[b,k] value[b,k,j]^2                aesmc/statistics.py:63-76 (variance =
+//                                                              second - mean^2, formed by the caller)
+//   log_ess[b]    = 2 lse_k(log_w) - lse_k(2 log_w)            aesmc/statistics.py:79-91
+//
+// The reference loops over the K particles in Python (statistics.py:32-42: two elementwise
+// launches per particle) after a softmax, and takes two log-sum-exps for the ESS.  Here a batch
+// row is cut into S slices of particles (S = 1 when there are rows enough to fill the chip); one
+// workgroup owns a slice: slice max, then ONE sweep in which TX = min(D, 256) lanes walk a
+// particle's values (consecutive lanes read consecutive elements, also across particle
+// boundaries) while TY = 256 / TX lane groups stride over k, four particles in flight per lane.
+// Every lane keeps its columns' sums of e = exp(log_w - max) times v and v^2 in registers; lane 0
+// of a group also sum e and sum e^2.  Partials meet in LDS and are added in a fixed order.  With
+// S > 1 the slice records (max, sum e, sum e^2, column sums) go to a workspace and a second small
+// kernel merges them by rescaling to the row max — again in a fixed order, so results are
+// reproducible.  Sums are divided by sum e at the end (the reference multiplies by the normalised
+// weight first: same value up to rounding; tolerance in tests/test_gpu_kernels.py).
+// HBM-bound: value is read once (4 D B per particle), log_w twice (L2 hit).
+#include "common.hpp"
+
+namespace aesmc {
+
+constexpr int kSumBlock = 256;
+constexpr int kSumRegs = 4;    // columns per lane per sweep: one sweep covers TX * kSumRegs columns
+constexpr int kSumUnroll = 4;  // particles in flight per lane
+
+struct SumStrides {
+  int64_t b, k, d;
+};
+
+// Record of one slice in the workspace: [max, sum e, sum e^2, A_0..A_{D-1}, Q_0..Q_{D-1}]
+__host__ __device__ __forceinline__ int64_t record_elems(int64_t D) { return 3 + 2 * D; }
+
+static inline uint32_t pick_slices(int64_t B, int64_t K) {
+  // at least ~4 workgroups per CU in total, at least 512 particles per slice
+  int64_t want = (1024 + B - 1) / B;
+  int64_t most = K / 512;
+  if (most < 1) most = 1;
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  return (uint32_t)want;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSumBlock) void particle_summary_kernel(
+    const T *__restrict__ log_w, const T *__restrict__ value, SumStrides sv, T *__restrict__ out_log_ess,
+    T *__restrict__ out_mean, T *__restrict__ out_second, T *__restrict__ records, uint32_t K, uint32_t D,
+    uint32_t TX, uint32_t S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sum_smem[];
+  T *partial = reinterpret_cast<T *>(sum_smem);  // [TY][TX * kSumRegs][2] column sums / [kSumBlock][2]
+  __shared__ T red_m[kSumBlock / kWave];
+  __shared__ int red_nan[kSumBlock / kWave];
+  __shared__ T slice_stats[2];                   // sum e, sum e^2
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid % kWave, wave = tid / kWave;
+  const int64_t b = blockIdx.x / S;
+  const uint32_t slice = blockIdx.x - (uint32_t)b * S;
+  const uint32_t per_slice = (K + S - 1) / S;
+  const uint32_t k_lo = min(K, slice * per_slice), k_hi = min(K, k_lo + per_slice);
+  const T *lw = log_w + b * (int64_t)K;
+
+  // ---- slice max and NaN scan --------------------------------------------------------------------
+  T m = Num<T>::neg_inf();
+  int has_nan = 0;
+  for (uint32_t k = k_lo + tid; k < k_hi; k += kSumBlock) {
+    const T v = lw[k];
+    has_nan |= (v != v);
+    m = Num<T>::max(m, v);
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    m = Num<T>::max(m, __shfl_xor(m, off, kWave));
+    has_nan |= __shfl_xor(has_nan, off, kWave);
+  }
+  if (lane == 0) {
+    red_m[wave] = m;
+    red_nan[wave] = has_nan;
+  }
+  __syncthreads();
+  m = red_m[0];
+  has_nan = red_nan[0];
+  for (int w = 1; w < kSumBlock / kWave; ++w) {
+    m = Num<T>::max(m, red_m[w]);
+    has_nan |= red_nan[w];
+  }
+  if (has_nan) m = Num<T>::nan();
+  // exp(x - max) needs a finite max; an empty or all -inf slice contributes nothing, +inf / NaN
+  // poison the row (handled where the row is finalised)
+  const bool usable = m > Num<T>::neg_inf() && m < Num<T>::pos_inf();
+
+  const uint32_t TY = kSumBlock / TX;
+  const uint32_t tx = tid % TX, ty = tid / TX;   // lanes with ty >= TY (TX not a power of two) idle
+  const uint32_t cols_per_sweep = TX * kSumRegs;
+  const uint32_t num_cols = value != nullptr ? D : 0;
+  const T *vrow = value != nullptr ? value + b * sv.b : nullptr;
+  T *record = records != nullptr ? records + ((int64_t)b * S + slice) * record_elems(D) : nullptr;
+
+  for (uint32_t c0 = 0; c0 == 0 || c0 < num_cols; c0 += cols_per_sweep) {
+    T acc1[kSumRegs], acc2[kSumRegs];
+#pragma unroll
+    for (int r = 0; r < kSumRegs; ++r) acc1[r] = acc2[r] = T(0);
+    T s1 = T(0), s2 = T(0);
+    if (usable && ty < TY) {
+      for (uint32_t k0 = k_lo + ty; k0 < k_hi; k0 += TY * kSumUnroll) {
+        T e[kSumUnroll];
+        T v[kSumUnroll][kSumRegs];
+#pragma unroll
+        for (int q = 0; q < kSumUnroll; ++q) {
+          const uint32_t k = k0 + q * TY;
+          const bool live = k < k_hi;
+          e[q] = live ? Num<T>::exp(lw[k] - m) : T(0);
+#pragma unroll
+          for (int r = 0; r < kSumRegs; ++r) {
+            const uint32_t j = c0 + r * TX + tx;
+            v[q][r] = (live && j < num_cols) ? vrow[(int64_t)k * sv.k + (int64_t)j * sv.d] : T(0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kSumUnroll; ++q) {
+          if (tx == 0 && c0 == 0) {
+            s1 += e[q];
+            s2 += e[q] * e[q];
+          }
+#pragma unroll
+          for (int r = 0; r < kSumRegs; ++r) {
+            const T ev = e[q] * v[q][r];
+            acc1[r] += ev;
+            acc2[r] += ev * v[q][r];
+          }
+        }
+      }
+    }
+    // ---- weight sums (first sweep only): one pair per lane group, added in group order ------------
+    if (c0 == 0) {
+      __syncthreads();
+      partial[2 * tid] = s1;
+      partial[2 * tid + 1] = s2;
+      __syncthreads();
+      if (tid == 0) {
+        T t1 = T(0), t2 = T(0);
+        for (uint32_t i = 0; i < TY; ++i) {   // only tx == 0 lanes hold non-zero sums
+          t1 += partial[2 * (i * TX)];
+          t2 += partial[2 * (i * TX) + 1];
+        }
+        slice_stats[0] = t1;
+        slice_stats[1] = t2;
+        if (record != nullptr) {
+          record[0] = m;
+          record[1] = t1;
+          record[2] = t2;
+        }
+      }
+      __syncthreads();
+    }
+    if (num_cols == 0) break;
+    // ---- column sums of this sweep ----------------------------------------------------------------
+    __syncthreads();
+    if (ty < TY) {
+#pragma unroll
+      for (int r = 0; r < kSumRegs; ++r) {
+        partial[(ty * cols_per_sweep + r * TX + tx) * 2] = acc1[r];
+        partial[(ty * cols_per_sweep + r * TX + tx) * 2 + 1] = acc2[r];
+      }
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < cols_per_sweep && c0 + c < num_cols; c += kSumBlock) {
+      T t1 = T(0), t2 = T(0);
+      for (uint32_t i = 0; i < TY; ++i) {
+        t1 += partial[(i * cols_per_sweep + c) * 2];
+        t2 += partial[(i * cols_per_sweep + c) * 2 + 1];
+      }
+      if (record != nullptr) {
+        record[3 + c0 + c] = t1;
+        record[3 + D + c0 + c] = t2;
+      } else {
+        const T total = slice_stats[0];
+        const int64_t o = b * (int64_t)D + c0 + c;
+        if (out_mean != nullptr) out_mean[o] = usable ? t1 / total : Num<T>::nan();
+        if (out_second != nullptr) out_second[o] = usable ? t2 / total : Num<T>::nan();
+      }
+    }
+  }
+  if (record == nullptr && out_log_ess != nullptr && tid == 0) {
+    // 2 (m + log S1) - (2 m + log S2): the max cancels, so huge offsets do not lose digits
+    out_log_ess[b] = usable ? T(2) * Num<T>::log(slice_stats[0]) - Num<T>::log(slice_stats[1]) : Num<T>::nan();
+  }
+}
+
+// Merges the S slice records of a batch row: everything rescaled to the row max, slices in order.
+template <typename T>
+__global__ __launch_bounds__(kSumBlock) void particle_summary_merge_kernel(
+    const T *__restrict__ records, T *__restrict__ out_log_ess, T *__restrict__ out_mean,
+    T *__restrict__ out_second, uint32_t D, uint32_t S) {
+  const int64_t b = blockIdx.x;
+  const int64_t stride = record_elems(D);
+  const T *row = records + b * (int64_t)S * stride;
+  T m = Num<T>::neg_inf();
+  bool poisoned = false;
+  for (uint32_t s = 0; s < S; ++s) {
+    const T ms = row[s * stride];
+    poisoned |= (ms != ms) || ms == Num<T>::pos_inf();
+    m = Num<T>::max(m, ms);
+  }
+  const bool usable = !poisoned && m > Num<T>::neg_inf();
+  T s1 = T(0), s2 = T(0);
+  if (usable) {
+    for (uint32_t s = 0; s < S; ++s) {
+      const T ms = row[s * stride];
+      if (ms == Num<T>::neg_inf()) continue;   // slice of zero-weight particles
+      const T f = Num<T>::exp(ms - m);
+      s1 += row[s * stride + 1] * f;
+      s2 += row[s * stride + 2] * (f * f);
+    }
+  }
+  for (uint32_t c = threadIdx.x; c < D; c += kSumBlock) {
+    T t1 = T(0), t2 = T(0);
+    if (usable) {
+      for (uint32_t s = 0; s < S; ++s) {
+        const T ms = row[s * stride];
+        if (ms == Num<T>::neg_inf()) continue;
+        const T f = Num<T>::exp(ms - m);
+        t1 += row[s * stride + 3 + c] * f;
+        t2 += row[s * stride + 3 + D + c] * f;
+      }
+    }
+    if (out_mean != nullptr) out_mean[b * (int64_t)D + c] = usable ? t1 / s1 : Num<T>::nan();
+    if (out_second != nullptr) out_second[b * (int64_t)D + c] = usable ? t2 / s1 : Num<T>::nan();
+  }
+  if (out_log_ess != nullptr && threadIdx.x == 0)
+    out_log_ess[b] = usable ? T(2) * Num<T>::log(s1) - Num<T>::log(s2) : Num<T>::nan();
+}
+
+template <typename T>
+static int launch_summary(const void *log_w, const aesmc_view3 *value, void *out_log_ess, void *out_mean,
+                          void *out_second, int64_t B, int64_t K, int64_t D, void *ws, size_t ws_bytes,
+                          hipStream_t s) {
+  uint32_t TX = 1;
+  if (value != nullptr) TX = (uint32_t)(D < kSumBlock ? D : kSumBlock);
+  const uint32_t TY = kSumBlock / TX;
+  size_t lds = (size_t)TY * TX * kSumRegs * 2 * sizeof(T);
+  const size_t lds_weights = (size_t)kSumBlock * 2 * sizeof(T);
+  if (lds < lds_weights) lds = lds_weights;
+  SumStrides sv{0, 0, 0};
+  const T *v = nullptr;
+  if (value != nullptr) {
+    v = static_cast<const T *>(value->ptr);
+    sv = SumStrides{value->stride_b, value->stride_k, value->stride_d};
+  }
+  const uint32_t S = pick_slices(B, K);
+  T *records = nullptr;
+  if (S > 1) {
+    if (ws == nullptr || ws_bytes < (size_t)B * S * record_elems(value != nullptr ? D : 0) * sizeof(T))
+      return AESMC_ERR_WORKSPACE;
+    records = static_cast<T *>(ws);
+  }
+  if ((uint64_t)B * S > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
+  const uint32_t cols = value != nullptr ? (uint32_t)D : 0u;
+  hipLaunchKernelGGL(particle_summary_kernel<T>, dim3((unsigned)(B * S)), dim3(kSumBlock), lds, s,
+                     static_cast<const T *>(log_w), v, sv, static_cast<T *>(out_log_ess),
+                     static_cast<T *>(out_mean), static_cast<T *>(out_second), records, (uint32_t)K, cols, TX,
+                     S);
+  if (S > 1)
+    hipLaunchKernelGGL(particle_summary_merge_kernel<T>, dim3((unsigned)B), dim3(kSumBlock), 0, s, records,
+                       static_cast<T *>(out_log_ess), static_cast<T *>(out_mean),
+                       static_cast<T *>(out_second), cols, S);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+}  // namespace aesmc
+
+extern "C" size_t aesmc_particle_summary_workspace_bytes(int dtype, int64_t B, int64_t K, int64_t D) {
+  if (B <= 0 || K <= 0 || D < 0) return 0;
+  const uint32_t S = aesmc::pick_slices(B, K);
+  if (S <= 1) return 0;
+  return (size_t)B * S * (size_t)aesmc::record_elems(D) * (dtype == AESMC_F64 ? 8 : 4);
+}
+
+extern "C" int aesmc_particle_summary(int dtype, const void *log_w, const aesmc_view3 *value,
+                                      void *out_log_ess, void *out_mean, void *out_second, int64_t B,
+                                      int64_t K, int64_t D, void *ws, size_t ws_bytes, void *stream) {
+  using namespace aesmc;
+  if (log_w == nullptr || B < 0 || K < 0 || D < 0) return AESMC_ERR_INVALID_ARGUMENT;
+  if (value != nullptr && value->ptr == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  if (value == nullptr && (out_mean != nullptr || out_second != nullptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (out_log_ess == nullptr && out_mean == nullptr && out_second == nullptr) return AESMC_OK;
+  if (B == 0) return AESMC_OK;
+  if (K == 0) return AESMC_ERR_INVALID_ARGUMENT;  // no particles: the weights are undefined
+  if (K >= (1ll << 31) || D >= (1ll << 31) || B >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
+  if (value != nullptr && D == 0) value = nullptr;  // empty rows: nothing to average
+  if (value == nullptr) {
+    out_mean = out_second = nullptr;
+    D = 0;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AESMC_F32)
+    return launch_summary<float>(log_w, value, out_log_ess, out_mean, out_second, B, K, D, ws, ws_bytes, s);
+  if (dtype == AESMC_F64)
+    return launch_summary<double>(log_w, value, out_log_ess, out_mean, out_second, B, K, D, ws, ws_bytes, s);
+  return AESMC_ERR_INVALID_ARGUMENT;
+}

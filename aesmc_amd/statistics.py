@@ -1,7 +1,10 @@
 """Particle diagnostics and prior sampling with the interface of the reference's
-aesmc/statistics.py.  Off the ELBO hot path; reductions over particles reuse kernel K1."""
+aesmc/statistics.py.  Off the ELBO hot path.  Values on the HIP device come from kernel K7 (one
+pass over the particles: ESS, weighted mean and second moment); when gradients are wanted the same
+quantities are PyTorch expressions over K1's softmax, as differentiable as the reference's."""
 import torch
 
+from . import _kernels
 from . import _ops
 from . import math
 from . import state
@@ -25,9 +28,24 @@ def empirical_expectation(value, log_weight, f):
     return total
 
 
+def _summary_kernel_applies(log_weight, value=None):
+    """Kernel K7 computes values only; whoever needs gradients keeps the PyTorch expression."""
+    tensors = [log_weight] if value is None else [log_weight, value]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return False
+    if not (log_weight.is_cuda and log_weight.dtype in (torch.float32, torch.float64) and
+            log_weight.dim() == 2 and log_weight.size(1) > 0):
+        return False
+    return value is None or (torch.is_tensor(value) and value.is_cuda and value.dtype == log_weight.dtype
+                             and value.device == log_weight.device)
+
+
 def empirical_mean(value, log_weight):
-    """Weighted particle mean over dim 1 (aesmc/statistics.py:47-60), as one reduction."""
+    """Weighted particle mean over dim 1 (aesmc/statistics.py:47-60): one pass of kernel K7 for
+    values on the HIP device, the differentiable PyTorch reduction when gradients are wanted."""
     assert value.size()[:2] == log_weight.size()
+    if _summary_kernel_applies(log_weight, value):
+        return _kernels.get().particle_summary(log_weight.detach(), value.detach(), want_mean=True)[1]
     weights = math.exponentiate_and_normalize(log_weight, dim=1)
     return torch.sum(_broadcast_weights(weights, value) * value, dim=1)
 
@@ -35,6 +53,10 @@ def empirical_mean(value, log_weight):
 def empirical_variance(value, log_weight):
     """Weighted particle variance E[x^2] - E[x]^2 (aesmc/statistics.py:63-76)."""
     assert value.size()[:2] == log_weight.size()
+    if _summary_kernel_applies(log_weight, value):
+        _, mean, second = _kernels.get().particle_summary(log_weight.detach(), value.detach(),
+                                                          want_mean=True, want_second=True)
+        return second - mean ** 2
     weights = _broadcast_weights(math.exponentiate_and_normalize(log_weight, dim=1), value)
     mean = torch.sum(weights * value, dim=1)
     return torch.sum(weights * value ** 2, dim=1) - mean ** 2
@@ -44,6 +66,9 @@ def log_ess(log_weight):
     """log effective sample size, 2 lse(lw) - lse(2 lw), over particles
     (aesmc/statistics.py:79-91); accepts [batch_size, num_particles] or [num_particles]."""
     rows = log_weight if log_weight.dim() == 2 else log_weight.unsqueeze(0)
+    if _summary_kernel_applies(rows):
+        value = _kernels.get().particle_summary(rows.detach(), want_log_ess=True)[0]
+        return value if log_weight.dim() == 2 else value.squeeze(0)
     value = 2 * _ops.row_logsumexp(rows) - _ops.row_logsumexp(2 * rows)
     return value if log_weight.dim() == 2 else value.squeeze(0)
 

@@ -189,6 +189,24 @@ int aesmc_normal_rsample(int dtype, const aesmc_view3 *eps, const aesmc_view3 *l
                          const aesmc_view3 *scale, void *out, int64_t B, int64_t K, int64_t D,
                          void *stream);
 
+/* K7 — weighted particle summaries of a batch row in one pass:
+ *   w = softmax_k(log_w[b,:]);  out_mean[b,j] = sum_k w[k] value[b,k,j];
+ *   out_second[b,j] = sum_k w[k] value[b,k,j]^2;  out_log_ess[b] = 2 lse(log_w) - lse(2 log_w).
+ * Replaces the per-particle Python loop of aesmc/statistics.py:7-76 (empirical_mean; the variance
+ * is out_second - out_mean^2 as at statistics.py:75-76) and the two log-sum-exps of
+ * aesmc/statistics.py:79-91.  `value` is a [B,K,D] view by element strides (NULL: only the ESS);
+ * any of the three outputs may be NULL.  Rows whose weights cannot be normalised (NaN, no finite
+ * maximum) give NaN, as the reference's softmax does.  With few batch rows a row is cut into
+ * slices of particles, one workgroup each, whose records are merged by a second launch: `ws` must
+ * then hold aesmc_particle_summary_workspace_bytes(dtype, B, K, D) bytes (0 = not needed), else
+ * AESMC_ERR_WORKSPACE.  Not differentiable: callers that need gradients keep the PyTorch
+ * expression.
+ */
+size_t aesmc_particle_summary_workspace_bytes(int dtype, int64_t B, int64_t K, int64_t D);
+int aesmc_particle_summary(int dtype, const void *log_w, const aesmc_view3 *value, void *out_log_ess,
+                           void *out_mean, void *out_second, int64_t B, int64_t K, int64_t D, void *ws,
+                           size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,26 @@ def normal_rsample(eps, loc, scale):
     eps = np.asarray(eps)
     product = (eps * np.broadcast_to(np.asarray(scale, dtype=eps.dtype), eps.shape)).astype(eps.dtype)
     return (np.broadcast_to(np.asarray(loc, dtype=eps.dtype), eps.shape) + product).astype(eps.dtype)
+
+
+def particle_summary(log_w, value=None):
+    """K7 contract in float64: (log_ess [B], mean [B,...], second moment [B,...]) under
+    w = softmax(log_w, axis=1) — aesmc/statistics.py:47-60 (mean), :63-76 (second moment; the
+    variance is second - mean**2), :79-91 (log ESS = 2 lse(lw) - lse(2 lw)).  Rows without
+    normalisable weights (NaN, max = +-inf) give NaN."""
+    lw = np.asarray(log_w, dtype=np.float64)
+    B, K = lw.shape
+    with np.errstate(invalid="ignore", over="ignore"):
+        m = lw.max(axis=1, keepdims=True)
+        e = np.exp(lw - m)
+        s1, s2 = e.sum(axis=1), (e * e).sum(axis=1)
+        broken = ~np.isfinite(m[:, 0])
+        log_ess = np.where(broken, np.nan, 2 * np.log(s1) - np.log(s2))
+        mean = second = None
+        if value is not None:
+            v = np.asarray(value, dtype=np.float64)
+            w = (e / s1[:, None]).reshape((B, K) + (1,) * (v.ndim - 2))
+            mean, second = (w * v).sum(axis=1), (w * v * v).sum(axis=1)
+            mean[broken] = np.nan
+            second[broken] = np.nan
+    return log_ess, mean, second

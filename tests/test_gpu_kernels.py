@@ -675,3 +675,67 @@ def test_normal_rsample_transposed_noise(kernels, hip_device, dtype, K, B, rest,
     want = (loc + eps * scale).transpose(0, 1)
     assert got.shape == want.shape and got.is_contiguous()
     assert torch.equal(got, want)
+
+
+# ---- K7 ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(1, 1, ()), (2, 16, ()), (3, 7, (1,)), (5, 64, (3,)), (4, 1000, (10,)),
+                                   (2, 33, (128,)), (3, 5, (2, 3)), (2, 300, (300,)), (1, 5000, (17,))])
+@pytest.mark.parametrize("scale", [1.0, 8.0])
+def test_particle_summary_matches_oracle(kernels, hip_device, dtype, shape, scale):
+    B, K, tail = shape
+    rng = np.random.RandomState(B * 131 + K)
+    lw = (rng.randn(B, K) * scale).astype(dtype)
+    value = rng.randn(B, K, *tail).astype(dtype)
+    log_ess, mean, second = kernels.particle_summary(dev(lw, hip_device), dev(value, hip_device),
+                                                     want_log_ess=True, want_mean=True, want_second=True)
+    want_ess, want_mean, want_second = kernel_oracle.particle_summary(lw, value)
+    rtol, atol = (2e-5, 2e-5) if dtype == np.float32 else (1e-12, 1e-12)
+    assert mean.shape == (B,) + tail and second.shape == (B,) + tail and log_ess.shape == (B,)
+    np.testing.assert_allclose(log_ess.cpu().numpy(), want_ess, rtol=rtol, atol=atol)
+    np.testing.assert_allclose(mean.cpu().numpy(), want_mean, rtol=rtol, atol=atol)
+    np.testing.assert_allclose(second.cpu().numpy(), want_second, rtol=rtol, atol=atol * 4)
+
+
+def test_particle_summary_strided_value_offsets_and_broken_rows(kernels, hip_device):
+    rng = np.random.RandomState(9)
+    B, K = 5, 200
+    base = rng.randn(B, 2 * K, 9)
+    lw = rng.randn(B, K)
+    lw[0] += 1e6                 # the reference's own offset cases (test/test_statistics.py:71-93)
+    lw[1] -= 1e6
+    lw[2, 3] = np.nan
+    lw[3, :] = -np.inf
+    lw[4, ::2] = -np.inf         # zero-weight particles are fine
+    value = dev(base, hip_device)[:, ::2, 1:8]
+    log_ess, mean, second = kernels.particle_summary(dev(lw, hip_device), value, want_log_ess=True,
+                                                     want_mean=True, want_second=True)
+    want = kernel_oracle.particle_summary(lw, base[:, ::2, 1:8])
+    for got, expected in zip((log_ess, mean, second), want):
+        np.testing.assert_allclose(got.cpu().numpy(), expected, rtol=1e-12, atol=1e-12, equal_nan=True)
+    assert np.isnan(log_ess.cpu().numpy()[[2, 3]]).all() and np.isnan(mean.cpu().numpy()[[2, 3]]).all()
+
+
+def test_statistics_known_answers_of_the_reference(hip_device):
+    """test/test_statistics.py:71-115 (log_ess / ess of [0.2, 0.3, 0.5] under offsets 0.47x, +1e6,
+    -1e6) and the weighted mean / variance against their definitions, through aesmc_amd.statistics."""
+    from aesmc_amd import statistics
+    normalized = np.array([0.2, 0.3, 0.5])
+    for log_weight in (np.log(normalized * 0.47), np.log(normalized) + 1e6, np.log(normalized) - 1e6):
+        lw = torch.from_numpy(log_weight).to(hip_device)
+        assert statistics.log_ess(lw).shape == ()
+        np.testing.assert_allclose(statistics.log_ess(lw).item(), np.log(1 / np.sum(normalized ** 2)), atol=1e-7)
+        np.testing.assert_allclose(statistics.ess(lw).item(), 1 / np.sum(normalized ** 2), atol=1e-7)
+    assert statistics.log_ess(-torch.rand(3, 4, device=hip_device)).shape == (3,)
+    gen = torch.Generator().manual_seed(3)
+    value = torch.randn(6, 50, 4, generator=gen, dtype=torch.float64).to(hip_device)
+    lw = torch.randn(6, 50, generator=gen, dtype=torch.float64).to(hip_device)
+    w = torch.softmax(lw, dim=1).unsqueeze(-1)
+    mean = (w * value).sum(1)
+    torch.testing.assert_close(statistics.empirical_mean(value, lw), mean)
+    torch.testing.assert_close(statistics.empirical_variance(value, lw), (w * value ** 2).sum(1) - mean ** 2)
+    torch.testing.assert_close(statistics.empirical_expectation(value, lw, lambda x: x ** 2), (w * value ** 2).sum(1))
+    # with gradients wanted the PyTorch expression runs and differentiates
+    lw_g = lw.clone().requires_grad_()
+    statistics.empirical_mean(value, lw_g).sum().backward()
+    assert lw_g.grad is not None and torch.isfinite(lw_g.grad).all()
