@@ -64,6 +64,25 @@ template <typename T> struct LseState {
     }
     if (m != Num<T>::neg_inf()) s += Num<T>::exp(v - m);
   }
+  // Fold N values in with at most one rescale: the same (max, sum) pair as N single pushes up to
+  // rounding, without a data-dependent branch per value.
+  template <int N> __device__ __forceinline__ void push_many(const T (&v)[N]) {
+    T top = v[0];
+    nan |= (v[0] != v[0]);
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+      nan |= (v[i] != v[i]);
+      top = Num<T>::max(top, v[i]);
+    }
+    if (top > m) {
+      s = (m == Num<T>::neg_inf()) ? T(0) : s * Num<T>::exp(m - top);
+      m = top;
+    }
+    if (m != Num<T>::neg_inf()) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) s += Num<T>::exp(v[i] - m);
+    }
+  }
   // Fold another partial state in.
   __device__ __forceinline__ void merge(T m2, T s2, int nan2) {
     nan |= nan2;

@@ -37,29 +37,57 @@ __global__ __launch_bounds__(kBlock) void logweight_lse_kernel(
       const V *bv = b ? reinterpret_cast<const V *>(b + base) : nullptr;
       const V *cv = c ? reinterpret_cast<const V *>(c + base) : nullptr;
       V *ov = out_lw ? reinterpret_cast<V *>(out_lw + base) : nullptr;
-      for (int64_t i = t; i < nvec; i += TPR) {
-        V x = av[i];
+      // U vectors per input in flight per lane before any arithmetic: the running (max, sum) pair
+      // is a serial chain, so without this the loads of the next trip wait behind it.
+      constexpr int U = 4;
+      for (int64_t i0 = t; i0 < nvec; i0 += (int64_t)TPR * U) {
+        V x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t i = i0 + (int64_t)u * TPR;
+          if (i < nvec) x[u] = av[i];
+        }
         if (bv) {
-          V y = bv[i];
-          x.x += y.x;
-          x.y += y.y;
-          if constexpr (N == 4) {
-            x.z += y.z;
-            x.w += y.w;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * TPR;
+            if (i < nvec) {
+              const V y = bv[i];
+              x[u].x += y.x;
+              x[u].y += y.y;
+              if constexpr (N == 4) {
+                x[u].z += y.z;
+                x[u].w += y.w;
+              }
+            }
           }
         }
         if (cv) {
-          V y = cv[i];
-          x.x -= y.x;
-          x.y -= y.y;
-          if constexpr (N == 4) {
-            x.z -= y.z;
-            x.w -= y.w;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * TPR;
+            if (i < nvec) {
+              const V y = cv[i];
+              x[u].x -= y.x;
+              x[u].y -= y.y;
+              if constexpr (N == 4) {
+                x[u].z -= y.z;
+                x[u].w -= y.w;
+              }
+            }
           }
         }
-        if (ov) ov[i] = x;
 #pragma unroll
-        for (int j = 0; j < N; ++j) st.push(Vec16<T>::get(x, j));
+        for (int u = 0; u < U; ++u) {
+          const int64_t i = i0 + (int64_t)u * TPR;
+          if (i < nvec) {
+            if (ov) ov[i] = x[u];
+            T vals[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) vals[j] = Vec16<T>::get(x[u], j);
+            st.template push_many<N>(vals);
+          }
+        }
       }
     } else {
       for (int64_t k = t; k < K; k += TPR) {
