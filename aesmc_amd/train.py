@@ -12,9 +12,17 @@ from . import statistics
 
 
 def get_chained_params(*objects):
-    """One iterator over the parameters of every `nn.Module` among `objects` (anything else —
-    plain callables, None — contributes nothing); None when there is no module at all."""
-    modules = [candidate for candidate in objects if isinstance(candidate, nn.Module)]
+    """One iterator over the parameters of every `nn.Module` among `objects`; None when there is no
+    module at all (aesmc/train.py:10-19).  Beyond the reference, a bound method of a module (a
+    model written as ONE module with `initial` / `transition` / ... methods) contributes its
+    module's parameters too — once, however many of its methods are passed.  Anything else (plain
+    callables, None) contributes nothing."""
+    modules = []
+    for candidate in objects:
+        if not isinstance(candidate, nn.Module):
+            candidate = getattr(candidate, "__self__", None)   # bound method -> its module
+        if isinstance(candidate, nn.Module) and all(candidate is not m for m in modules):
+            modules.append(candidate)
     if len(modules) == 0:
         return None
     return itertools.chain.from_iterable(m.parameters() for m in modules)
@@ -35,16 +43,36 @@ def _minibatches(dataloader, num_epochs, limit):
 def train(dataloader, num_particles, algorithm, initial, transition, emission,
           proposal, num_epochs, num_iterations_per_epoch=None,
           optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
-          callback=None):
+          callback=None, hip_graph=False):
     """Fits the model parts by stochastic gradient descent on `losses.get_loss`.
 
     A single optimiser (`optimizer_algorithm(params, **optimizer_kwargs)`) owns the parameters of
     all four parts.  Per minibatch: clear gradients, evaluate the loss ('iwae' or 'aesmc' with
     `num_particles` particles), back-propagate, step; then, if given,
     `callback(epoch_idx, epoch_iteration_idx, loss, initial, transition, emission, proposal)`.
-    Returns nothing, like the reference."""
+    Returns nothing, like the reference.
+
+    `hip_graph=True` (not in the reference; off by default) captures loss + backward of the first
+    minibatch into one hipGraph (`graphs.GraphedLoss`) and replays it for every later one — the
+    loop is then no longer bound by the host issuing each small kernel.  It needs what any capture
+    needs (fixed minibatch shapes, tensor observations, callables that never synchronise with the
+    host; see `aesmc_amd/graphs.py`) and its warm-up evaluations consume random numbers, so a
+    seeded run follows a different — equally distributed — trajectory than the eager loop."""
     model_parts = (initial, transition, emission, proposal)
     optimizer = optimizer_algorithm(get_chained_params(*model_parts), **optimizer_kwargs)
+    if hip_graph:
+        from . import graphs
+        graphed = None
+        for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
+            if graphed is None:
+                optimizer.zero_grad(set_to_none=True)   # the capture allocates the static .grad tensors
+                graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
+                                             backward=True)
+            loss = graphed(observations)     # refreshes every captured parameter's .grad in place
+            optimizer.step()
+            if callback is not None:
+                callback(epoch, iteration, loss, *model_parts)
+        return
     for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
         optimizer.zero_grad()
         loss = losses.get_loss(observations, num_particles, algorithm, *model_parts)
