@@ -108,3 +108,35 @@ def all_reduce_gradients(parameters, group=None):
     for g in grads:
         g.copy_(flat[offset:offset + g.numel()].view_as(g))
         offset += g.numel()
+
+
+def train(dataloader, num_particles, algorithm, initial, transition, emission, proposal, num_epochs,
+          num_iterations_per_epoch=None, optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
+          callback=None, group=None):
+    """`train.train` (aesmc/train.py:22-41) with one process per GPU: every rank's `dataloader`
+    yields ITS OWN rows of each minibatch (equal counts on all ranks), the loss is the mean over
+    the global batch (one all-reduce of sum log Z, `sharded_get_loss`) and the parameter gradients
+    are summed over ranks by one flat-bucket all-reduce before each optimiser step, so replicas
+    stay identical.  Seed numpy identically on all ranks (the resampler draws the global uniform
+    block and keeps its rows) and torch differently per rank (independent proposal noise).
+    `callback` sees the global loss."""
+    from . import train as _train
+    rank = dist.get_rank(group) if _group_is_live() else 0
+    world_size = dist.get_world_size(group) if _group_is_live() else 1
+    model_parts = (initial, transition, emission, proposal)
+    parameters = list(_train.get_chained_params(*model_parts))
+    optimizer = optimizer_algorithm(parameters, **optimizer_kwargs)
+    for epoch, iteration, observations in _train._minibatches(dataloader, num_epochs,
+                                                              num_iterations_per_epoch):
+        first = observations[0]
+        first = next(iter(first.values())) if isinstance(first, dict) else first
+        global_batch_size = first.size(0) * world_size
+        optimizer.zero_grad()
+        loss = sharded_get_loss(observations, num_particles, algorithm, *model_parts,
+                                global_batch_size=global_batch_size, rank=rank, world_size=world_size,
+                                group=group)
+        loss.backward()
+        all_reduce_gradients(parameters, group=group)
+        optimizer.step()
+        if callback is not None:
+            callback(epoch, iteration, loss, *model_parts)

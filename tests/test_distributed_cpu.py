@@ -100,6 +100,52 @@ def test_two_rank_batch_shard_matches_single_process(tmp_path, oracle_backend):
             torch.testing.assert_close(got, want, rtol=1e-10, atol=1e-12)
 
 
+def _train_rank(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from aesmc_amd import _kernels, distributed, train
+        from aesmc_amd.testing import models
+        from tests.oracle_provider import OracleKernels
+        _kernels._swap_provider_for_tests(OracleKernels())
+        torch.set_num_threads(1)
+        np.random.seed(5)                  # same on every rank: global uniform blocks
+        torch.manual_seed(100 + rank)      # different per rank: own data rows, own proposal noise
+        truth = models.LgssmNd(2, seed=1, dtype=torch.float64)
+        model = models.LgssmNd(2, seed=0, dtype=torch.float64)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(0.5)
+        loader = train.get_synthetic_dataloader(truth.initial, truth.transition, truth.emission, 3, 4)
+        losses_seen = []
+        distributed.train(loader, 16, "aesmc", model.initial, model.transition, model.emission,
+                          model.proposal, num_epochs=1, num_iterations_per_epoch=6,
+                          optimizer_algorithm=torch.optim.SGD, optimizer_kwargs={"lr": 0.01},
+                          callback=lambda e, i, loss, *parts: losses_seen.append(loss.item()))
+        torch.save({"params": [p.detach().clone() for p in model.parameters()], "losses": losses_seen},
+                   os.path.join(out_dir, "train_rank{}.pt".format(rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_training_keeps_replicas_identical(tmp_path, oracle_backend):
+    """distributed.train: own data rows and proposal noise per rank, one all-reduce for the loss and
+    one for the gradients per step -> both ranks report the same global loss and hold the same
+    parameters after every step, and those parameters moved."""
+    world = 2
+    mp.spawn(_train_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = [torch.load(os.path.join(str(tmp_path), "train_rank{}.pt".format(r))) for r in range(world)]
+    assert len(a["losses"]) == 6 and np.isfinite(a["losses"]).all()
+    np.testing.assert_allclose(a["losses"], b["losses"], rtol=1e-12)
+    from aesmc_amd.testing import models
+    start = models.LgssmNd(2, seed=0, dtype=torch.float64)
+    for pa, pb, p0 in zip(a["params"], b["params"], start.parameters()):
+        torch.testing.assert_close(pa, pb, rtol=1e-12, atol=1e-14)
+        assert not torch.allclose(pa, 0.5 * p0.detach())
+
+
 def test_shard_bounds_cover_the_batch():
     from aesmc_amd import distributed
     for batch in (1, 7, 8, 1024):
