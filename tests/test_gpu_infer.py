@@ -391,3 +391,43 @@ def test_fused_normal_log_prob_equals_eager_path(hip_device):
     torch.testing.assert_close(state.log_prob(Normal(0.0, 1.0), flat), Normal(0.0, 1.0).log_prob(flat))
     with pytest.raises(RuntimeError):   # three missing batch dims: rejected like state.py:146-150
         state.log_prob(Normal(0.0, 1.0), value.float())
+
+
+@pytest.mark.parametrize("B,K,T,d", [(3, 1, 4, 2), (1, 7, 3, 1), (2, 7, 3, 3), (2, 1023, 3, 5), (5, 64, 1, 3),
+                                     (4, 256, 6, 4), (2, 33000, 3, 2), (1, 4096, 2, 16)])
+@pytest.mark.parametrize("history", ["lazy", "eager"])
+def test_odd_shapes_match_the_cpu_port_draw_for_draw(hip_device, B, K, T, d, history):
+    """The op-for-op CPU port of the reference (oracle/reference_port.py) run on CPU with its random
+    draws recorded; the product on the GPU replays them.  float64: indices exact, log-weights and
+    log Z to 1e-10.  Shapes chosen to cross every dispatch boundary of the resampling launch: one
+    particle, payload rows the fused step declines (K * row_bytes not a multiple of 16), T = 1,
+    more particles than one workgroup holds (K2 over the workspace + K1 + K3), wide rows."""
+    from oracle import reference_port
+    dtype = torch.float64
+    cpu_model = models.LgssmNd(d, seed=0, dtype=dtype, state=reference_port)
+    observations = cpu_model.simulate(T, B, seed=1)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    flags = dict(return_log_marginal_likelihood=True, return_log_weights=True, return_ancestral_indices=True,
+                 return_original_latents=True)
+    with replay.record() as tape:
+        want = reference_port.infer("smc", observations, cpu_model.initial, cpu_model.transition,
+                                    cpu_model.emission, cpu_model.proposal, K, **flags)
+    model = models.LgssmNd(d, seed=0, dtype=dtype).to(hip_device)
+    inference.set_history_mode(history)
+    try:
+        with replay.replay(tape):
+            got = inference.infer("smc", [o.to(hip_device) for o in observations], model.initial,
+                                  model.transition, model.emission, model.proposal, K, **flags)
+    finally:
+        inference.set_history_mode("lazy")
+    assert len(got["ancestral_indices"]) == T - 1
+    for a, b in zip(got["ancestral_indices"], want["ancestral_indices"]):
+        assert torch.equal(a.cpu(), b)
+    for a, b in zip(got["log_weights"], want["log_weights"]):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-10, atol=1e-10)
+    for a, b in zip(got["latents"], want["latents"]):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(got["log_marginal_likelihood"].cpu(), want["log_marginal_likelihood"],
+                               rtol=1e-10, atol=1e-10)
+    torch.testing.assert_close(got["last_latent"].cpu(), want["last_latent"], rtol=1e-12, atol=1e-12)
