@@ -123,6 +123,42 @@ template <> struct Piece<4> { using type = uint32_t; };
 template <> struct Piece<8> { using type = uint2; };
 template <> struct Piece<16> { using type = uint4; };
 
+// Zero fill as an ordinary kernel.  hipMemsetAsync is avoided on purpose: captured into a large
+// hipGraph (a whole backward pass) its memset node was observed NOT to be ordered after the
+// nodes captured before it on the same stream, so a block recycled inside the graph's memory pool
+// was zeroed too early and read back stale (rows without offspring in K3's backward came out as
+// garbage from the second graph of a process on).  A kernel node keeps the stream order.
+__global__ __launch_bounds__(256) static void zero_fill_kernel(uint4 *__restrict__ dst16, uint64_t n16,
+                                                               unsigned char *__restrict__ tail,
+                                                               uint32_t ntail) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+    dst16[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+static inline bool zero_fill_async(void *dst, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return true;
+  // bytes up to the first 16-byte boundary go with the tail bytes' mechanism (at most 15 lanes)
+  const uint32_t head = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u);
+  if (head != 0) {
+    const uint32_t nhead = head < bytes ? head : (uint32_t)bytes;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(256), 0, stream, static_cast<uint4 *>(nullptr),
+                       (uint64_t)0, static_cast<unsigned char *>(dst), nhead);
+    dst = static_cast<unsigned char *>(dst) + nhead;
+    bytes -= nhead;
+    if (bytes == 0) return hipGetLastError() == hipSuccess;
+  }
+  const uint64_t n16 = bytes / 16;
+  const uint32_t ntail = (uint32_t)(bytes - n16 * 16);
+  uint64_t blocks = (n16 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<uint4 *>(dst),
+                     n16, static_cast<unsigned char *>(dst) + n16 * 16, ntail);
+  return hipGetLastError() == hipSuccess;
+}
+
 __device__ __forceinline__ void raise_flag(int32_t *flags, int32_t bit) {
   if (flags != nullptr) atomicOr(flags, bit);
 }

@@ -603,8 +603,8 @@ extern "C" int aesmc_normal_logprob_sum(int dtype, const void *value, const void
   if (B == 0 || K == 0) return AESMC_OK;
   if (K >= (1ll << 31) || D >= (1ll << 31) || B >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
   if (D == 0) {  // empty event: the sum is 0
-    return hipMemsetAsync(out, 0, (size_t)B * K * (dtype == AESMC_F32 ? 4 : 8), (hipStream_t)stream) ==
-                   hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+    return zero_fill_async(out, (size_t)B * K * (dtype == AESMC_F32 ? 4 : 8), (hipStream_t)stream)
+               ? AESMC_OK : AESMC_ERR_LAUNCH;
   }
   Strides3 sv{v_sb, v_sk, v_sd}, sm{m_sb, m_sk, m_sd}, ss{s_sb, s_sk, s_sd};
   hipStream_t s = (hipStream_t)stream;

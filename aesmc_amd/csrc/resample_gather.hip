@@ -399,7 +399,7 @@ extern "C" int aesmc_resample_gather_backward(int dtype, const void *grad_out, c
   const size_t esz = dtype == AESMC_F32 ? 4 : 8;
   const uint64_t re = (uint64_t)K * (uint64_t)row_elems;
   // both kernels write only rows that have offspring: everything else must read as zero
-  if (hipMemsetAsync(grad_src, 0, (size_t)B * re * esz, s) != hipSuccess) return AESMC_ERR_LAUNCH;
+  if (!zero_fill_async(grad_src, (size_t)B * re * esz, s)) return AESMC_ERR_LAUNCH;
   if (index_is_sorted) {
     const bool launched = dtype == AESMC_F32
         ? launch_sorted_backward<float>(grad_out, idx, grad_src, flags, B, K, row_elems, s)

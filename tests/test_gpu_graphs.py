@@ -110,15 +110,47 @@ def test_train_with_hip_graph_learns(hip_device):
     model = models.LgssmNd(2, seed=0, validate_args=False).to(hip_device)
     truth = models.LgssmNd(2, seed=1, validate_args=False).to(hip_device)
     loader = train.get_synthetic_dataloader(truth.initial, truth.transition, truth.emission, 5, 32)
-    with torch.no_grad():       # start well away from the data-generating parameters
-        for p in model.parameters():
-            p.add_(0.6 * torch.randn_like(p))
+    with torch.no_grad():       # start with a poor proposal (the generative parts stay stable)
+        for p in (model.W0, model.b0, model.Wx, model.Wy, model.b):
+            p.add_(0.5 * torch.randn_like(p))
     before = [p.detach().clone() for p in model.parameters()]
     history = []
     train.train(loader, 64, "aesmc", model.initial, model.transition, model.emission, model.proposal,
                 num_epochs=2, num_iterations_per_epoch=60, optimizer_algorithm=torch.optim.Adam,
-                optimizer_kwargs={"lr": 3e-2}, hip_graph=True,
+                optimizer_kwargs={"lr": 1e-2}, hip_graph=True,
                 callback=lambda e, i, loss, *parts: history.append(loss.item()))
     assert len(history) == 120 and np.isfinite(history).all()
-    assert np.mean(history[-10:]) < np.mean(history[:10]) - 1.0, (history[:10], history[-10:])
+    assert np.mean(history[-10:]) < np.mean(history[:10]) - 0.5, (history[:10], history[-10:])
     assert all(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+
+
+def test_graphs_captured_into_recycled_memory_give_eager_gradients(hip_device):
+    """Regression: a graph captured after an earlier one was destroyed gets the earlier graph's
+    memory back, dirty.  Every gradient of a replay must still equal the eager one bit for bit —
+    i.e. nothing in the captured backward may depend on what a recycled block held (K3's backward
+    zero-fills rows without offspring; a captured hipMemsetAsync node was seen to run too early)."""
+    import gc
+    dtype = torch.float32
+    for round_ in range(3):
+        seed(0)
+        model = models.LgssmNd(3, seed=0, dtype=dtype, validate_args=False).to(hip_device)
+        parts = (model.initial, model.transition, model.emission, model.proposal)
+        observations = model.simulate(6, 8, seed=3)
+        graphed = graphs.GraphedLoss(observations, 64, "aesmc", *parts, backward=True)
+        params = list(model.parameters())
+        seed(100 + round_)
+        graph_loss = graphed(observations).clone()
+        graph_grads = [p.grad.clone() for p in params]
+        static = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        seed(100 + round_)
+        eager_loss = losses.get_loss(observations, 64, "aesmc", *parts)
+        eager_loss.backward()
+        assert torch.equal(graph_loss, eager_loss.detach())
+        for name, got, p in zip([n for n, _ in model.named_parameters()], graph_grads, params):
+            assert torch.equal(got, p.grad), (round_, name)
+        for p, grad in zip(params, static):
+            p.grad = grad
+        del eager_loss, graphed, model, parts, params, static
+        gc.collect()

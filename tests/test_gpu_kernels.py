@@ -358,6 +358,10 @@ def test_full_size_resample_properties(kernels, hip_device, B, K, d):
     assert torch.equal(out, torch.gather(value, 1, idx.unsqueeze(-1).expand_as(value)))
     identity = torch.arange(K, device=hip_device).unsqueeze(0).expand(B, K).contiguous()
     assert torch.equal(kernels.gather(value, identity), value)
+    # the fused step gives the same indices and rows in one launch, and K1's row log-sum-exp
+    step = kernels.resample_step(log_w, u, value, want_lse=True)
+    assert torch.equal(step[0], idx) and torch.equal(step[2], out)
+    torch.testing.assert_close(step[1], torch.logsumexp(log_w, dim=1), rtol=F32_RTOL, atol=F32_ATOL)
     # backward of gather is the adjoint: <gather(v), g> == <v, gather_backward(g)>
     g = torch.randn(B, K, d, device=hip_device, generator=gen)
     lhs = (out.double() * g.double()).sum()
