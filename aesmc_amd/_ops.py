@@ -15,6 +15,7 @@ class _LogWeightLSE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, c):
+        ctx.set_materialize_grads(False)   # an unused output costs nothing (no zero tensors made)
         k = _kernels.get()
         lw, lse = k.logweight_lse(a, b, c, want_lw=True, want_lse=True)
         ctx.save_for_backward(lw, lse)
@@ -25,6 +26,8 @@ class _LogWeightLSE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_lw, grad_lse):
+        if grad_lw is None and grad_lse is None:
+            return None, None, None
         lw, lse = ctx.saved_tensors
         has_b, has_c = ctx.has
         need_c = has_c and ctx.needs_input_grad[2]
@@ -153,6 +156,7 @@ class _ResampleStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, log_w, uniforms, payload, want_lse):
+        ctx.set_materialize_grads(False)
         out = _kernels.get().resample_step(log_w, uniforms, payload, want_lse)
         if out is None:
             raise RuntimeError("aesmc_amd: fused resampling step rejected operands it was offered")

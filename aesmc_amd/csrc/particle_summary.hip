@@ -191,6 +191,140 @@ __global__ __launch_bounds__(kSumBlock) void particle_summary_kernel(
   }
 }
 
+// Few values per particle (D <= kSmallD): the sweep above would leave most of a wavefront's lanes
+// computing the same exp and issue 4-byte loads.  Instead a tile of 256 particles is copied to LDS
+// in memory order (16-byte loads when the slice is dense), then lane p owns particle p: one exp,
+// D products, all sums in registers; the 2 D + 2 lane sums meet by wavefront shuffles and four
+// LDS slots.  Same slicing, records and merge as the general kernel.
+constexpr int kSmallD = 16;
+
+template <typename T>
+__global__ __launch_bounds__(kSumBlock) void particle_summary_small_kernel(
+    const T *__restrict__ log_w, const T *__restrict__ value, SumStrides sv, T *__restrict__ out_log_ess,
+    T *__restrict__ out_mean, T *__restrict__ out_second, T *__restrict__ records, uint32_t K, uint32_t D,
+    uint32_t S, int dense, uint32_t R /* particles per lane per tile: R * D <= kSmallD */) {
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  __shared__ T tile[kSumBlock * kSmallD + (kSumBlock * kSmallD) / 32 + 1];
+  __shared__ T red_m[kSumBlock / kWave];
+  __shared__ int red_nan[kSumBlock / kWave];
+  __shared__ T red_sum[kSumBlock / kWave][2 * kSmallD + 2];
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid % kWave, wave = tid / kWave;
+  const int64_t b = blockIdx.x / S;
+  const uint32_t slice = blockIdx.x - (uint32_t)b * S;
+  const uint32_t per_slice = (K + S - 1) / S;
+  const uint32_t k_lo = min(K, slice * per_slice), k_hi = min(K, k_lo + per_slice);
+  const T *lw = log_w + b * (int64_t)K;
+
+  T m = Num<T>::neg_inf();
+  int has_nan = 0;
+  for (uint32_t k = k_lo + tid; k < k_hi; k += kSumBlock) {
+    const T v = lw[k];
+    has_nan |= (v != v);
+    m = Num<T>::max(m, v);
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    m = Num<T>::max(m, __shfl_xor(m, off, kWave));
+    has_nan |= __shfl_xor(has_nan, off, kWave);
+  }
+  if (lane == 0) {
+    red_m[wave] = m;
+    red_nan[wave] = has_nan;
+  }
+  __syncthreads();
+  m = red_m[0];
+  has_nan = red_nan[0];
+  for (int w = 1; w < kSumBlock / kWave; ++w) {
+    m = Num<T>::max(m, red_m[w]);
+    has_nan |= red_nan[w];
+  }
+  if (has_nan) m = Num<T>::nan();
+  const bool usable = m > Num<T>::neg_inf() && m < Num<T>::pos_inf();
+
+  T acc[2 * kSmallD + 2];   // [0..D) sum e v, [kSmallD..kSmallD+D) sum e v^2, then sum e, sum e^2
+#pragma unroll
+  for (int i = 0; i < 2 * kSmallD + 2; ++i) acc[i] = T(0);
+  const T *vrow = value + b * sv.b;
+  if (usable) {
+    const uint32_t per_tile = kSumBlock * R;
+    for (uint32_t t0 = k_lo; t0 < k_hi; t0 += per_tile) {
+      const uint32_t np = min(per_tile, k_hi - t0);
+      const uint32_t ne = np * D;
+      __syncthreads();   // the previous tile has been consumed
+      if (dense) {       // the slice's rows are one contiguous, 16-byte aligned run
+        const T *src = vrow + (int64_t)t0 * D;
+        const uint32_t nvec = ne / N;
+        for (uint32_t i = tid; i < nvec; i += kSumBlock) {
+          const V packed = reinterpret_cast<const V *>(src)[i];
+#pragma unroll
+          for (int r = 0; r < N; ++r) tile[i * N + r + ((i * N + r) >> 5)] = Vec16<T>::get(packed, r);
+        }
+        for (uint32_t e = nvec * N + tid; e < ne; e += kSumBlock) tile[e + (e >> 5)] = src[e];
+      } else {
+        for (uint32_t e = tid; e < ne; e += kSumBlock) {
+          const uint32_t p = e / D, j = e - p * D;
+          tile[e + (e >> 5)] = vrow[(int64_t)(t0 + p) * sv.k + (int64_t)j * sv.d];
+        }
+      }
+      __syncthreads();
+      for (uint32_t p = tid; p < np; p += kSumBlock) {
+        const T e = Num<T>::exp(lw[t0 + p] - m);
+        acc[2 * kSmallD] += e;
+        acc[2 * kSmallD + 1] += e * e;
+        const uint32_t base = p * D;
+#pragma unroll
+        for (int j = 0; j < kSmallD; ++j) {
+          if ((uint32_t)j < D) {
+            const T v = tile[base + j + ((base + j) >> 5)];
+            const T ev = e * v;
+            acc[j] += ev;
+            acc[kSmallD + j] += ev * v;
+          }
+        }
+      }
+    }
+  }
+  // ---- 256 lane sums -> one, per quantity: shuffles inside a wavefront, then the 4 wavefronts ----
+#pragma unroll
+  for (int i = 0; i < 2 * kSmallD + 2; ++i) {
+    T x = acc[i];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    if (lane == 0) red_sum[wave][i] = x;
+  }
+  __syncthreads();
+  if (tid < 2 * kSmallD + 2) {
+    T total = red_sum[0][tid];
+    for (int w = 1; w < kSumBlock / kWave; ++w) total += red_sum[w][tid];
+    red_sum[0][tid] = total;
+  }
+  __syncthreads();
+  const T s1 = red_sum[0][2 * kSmallD], s2 = red_sum[0][2 * kSmallD + 1];
+  T *record = records != nullptr ? records + ((int64_t)b * S + slice) * record_elems(D) : nullptr;
+  if (record != nullptr) {
+    if (tid == 0) {
+      record[0] = m;
+      record[1] = s1;
+      record[2] = s2;
+    }
+    if (tid < D) {
+      record[3 + tid] = red_sum[0][tid];
+      record[3 + D + tid] = red_sum[0][kSmallD + tid];
+    }
+  } else {
+    if (tid < D) {
+      const int64_t o = b * (int64_t)D + tid;
+      if (out_mean != nullptr) out_mean[o] = usable ? red_sum[0][tid] / s1 : Num<T>::nan();
+      if (out_second != nullptr) out_second[o] = usable ? red_sum[0][kSmallD + tid] / s1 : Num<T>::nan();
+    }
+    if (out_log_ess != nullptr && tid == 0)
+      out_log_ess[b] = usable ? T(2) * Num<T>::log(s1) - Num<T>::log(s2) : Num<T>::nan();
+  }
+}
+
 // Merges the S slice records of a batch row: everything rescaled to the row max, slices in order.
 template <typename T>
 __global__ __launch_bounds__(kSumBlock) void particle_summary_merge_kernel(
@@ -260,6 +394,19 @@ static int launch_summary(const void *log_w, const aesmc_view3 *value, void *out
   }
   if ((uint64_t)B * S > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
   const uint32_t cols = value != nullptr ? (uint32_t)D : 0u;
+  if (value != nullptr && D >= 3 && D <= kSmallD) {   // D <= 2: the lane-per-element sweep is already dense
+    constexpr int N = Vec16<T>::N;
+    // dense: particle rows back to back inside a batch row, and every slice / tile start 16-byte aligned
+    const uint32_t per_slice = (uint32_t)((K + S - 1) / S);
+    const bool dense = (D == 1 || sv.d == 1) && (K == 1 || sv.k == D) &&
+                       ((reinterpret_cast<uintptr_t>(v) & 15u) == 0) && ((sv.b * (int64_t)sizeof(T)) % 16 == 0) &&
+                       (((uint64_t)per_slice * D) % N == 0) && (((uint64_t)kSumBlock * D) % N == 0);
+    const uint32_t R = (uint32_t)(kSmallD / D);
+    hipLaunchKernelGGL(particle_summary_small_kernel<T>, dim3((unsigned)(B * S)), dim3(kSumBlock), 0, s,
+                       static_cast<const T *>(log_w), v, sv, static_cast<T *>(out_log_ess),
+                       static_cast<T *>(out_mean), static_cast<T *>(out_second), records, (uint32_t)K, cols, S,
+                       dense ? 1 : 0, R);
+  } else
   hipLaunchKernelGGL(particle_summary_kernel<T>, dim3((unsigned)(B * S)), dim3(kSumBlock), lds, s,
                      static_cast<const T *>(log_w), v, sv, static_cast<T *>(out_log_ess),
                      static_cast<T *>(out_mean), static_cast<T *>(out_second), records, (uint32_t)K, cols, TX,
