@@ -743,3 +743,32 @@ def test_statistics_known_answers_of_the_reference(hip_device):
     lw_g = lw.clone().requires_grad_()
     statistics.empirical_mean(value, lw_g).sum().backward()
     assert lw_g.grad is not None and torch.isfinite(lw_g.grad).all()
+
+
+# ---- second, independent oracle: plain C (oracle/smc_core.c) at full sizes -------------------------
+@pytest.mark.parametrize("B,K,d", [(256, 1024, 10), (1024, 4096, 10), (4, 40000, 3), (7, 333, 1)])
+def test_hip_equals_c_oracle_at_full_size(kernels, hip_device, B, K, d):
+    from oracle import c_oracle
+    from aesmc_amd import inference
+    rng = np.random.RandomState(B + K + d)
+    lw = (rng.randn(B, K) * 2).astype(np.float32)
+    lw[rng.randint(B), rng.randint(K)] = -np.inf
+    u = rng.uniform(size=B)
+    want_idx, flags = c_oracle.ancestor_index(lw, u)
+    assert flags == 0
+    idx = kernels.ancestor_index(dev(lw, hip_device), dev(u, hip_device))
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+    value = rng.randn(B, K, d).astype(np.float32)
+    moved = kernels.gather(dev(value, hip_device), idx)
+    np.testing.assert_array_equal(moved.cpu().numpy(), c_oracle.gather(value, want_idx)[0])
+    grad = rng.randn(B, K, d).astype(np.float32)
+    back = kernels.gather_backward(dev(grad, hip_device), idx, sorted_index=True)
+    # float32 segmented sums against float64 ones: runs of a few hundred N(0,1) terms
+    np.testing.assert_allclose(back.cpu().numpy(), c_oracle.gather_backward(grad, want_idx)[0], rtol=1e-4, atol=2e-4)
+    # genealogy over three resampling steps (inference.get_resampled_latents vs the C lineage)
+    steps = [c_oracle.ancestor_index((rng.randn(B, K) * 2).astype(np.float32), rng.uniform(size=B))[0] for _ in range(3)]
+    latents = [rng.randn(B, K, d).astype(np.float32) for _ in range(4)]
+    got = inference.get_resampled_latents([dev(x, hip_device) for x in latents], [dev(i, hip_device) for i in steps])
+    for x, line, have in zip(latents, c_oracle.lineage(steps), got):
+        np.testing.assert_array_equal(have.cpu().numpy(), c_oracle.gather(x, line)[0])
+    assert kernels.read_flags(hip_device) == 0
