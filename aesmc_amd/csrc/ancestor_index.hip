@@ -26,8 +26,9 @@ namespace aesmc {
 
 constexpr int kMaxThreads = 1024;
 constexpr int kScratchDoubles = 64;  // per-workgroup LDS scratch (wavefront totals, reduce slots)
-// The CDF is stored with one padding slot per 8 entries: lane t writes entries 8t..8t+7, and the
-// pad turns the 64-byte lane stride into 72 bytes, which spreads the lanes over the LDS banks.
+// Stored-CDF kernel (K > 32768): the row's float64 CDF lives in the caller's workspace with one
+// padding slot per 8 entries (lane t writes entries 8t..8t+7: a 72-byte lane stride keeps the
+// lanes of a wavefront in different memory channels); aesmc_workspace_bytes accounts for the pad.
 __host__ __device__ __forceinline__ int64_t cdf_slot(int64_t e) { return e + (e >> 3); }
 __host__ __device__ __forceinline__ int64_t cdf_row_slots(int64_t K) { return cdf_slot(K) + 1; }
 
@@ -63,13 +64,13 @@ __device__ __forceinline__ double divide_with_reciprocal(double a, double b, dou
   return __builtin_fma(r, y, q0);
 }
 
-template <typename T, int kChunk, bool CDF_IN_LDS>
+template <typename T, int kChunk>
 __global__ __launch_bounds__(kMaxThreads) void ancestor_index_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
     int32_t *flags, int K, double *__restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *scratch = smem;
-  double *cdf = CDF_IN_LDS ? (smem + kScratchDoubles) : (ws + (size_t)blockIdx.x * (size_t)cdf_row_slots(K));
+  double *cdf = ws + (size_t)blockIdx.x * (size_t)cdf_row_slots(K);   // this row's slice of the workspace
 
   const int tid = threadIdx.x;
   const int nt = blockDim.x;
@@ -563,7 +564,7 @@ static int launch(const void *log_w, const double *u, int64_t *idx, int32_t *fla
   if (K <= kInvMaxParticles) return launch_inv<T, 32>(log_w, u, idx, flags, B, K, s);
   if (ws == nullptr || ws_bytes < aesmc_workspace_bytes(B, K)) return AESMC_ERR_WORKSPACE;
   const size_t lds = (size_t)kScratchDoubles * sizeof(double);
-  hipLaunchKernelGGL((ancestor_index_kernel<T, 8, false>), dim3((unsigned)B), dim3(kMaxThreads), lds, s,
+  hipLaunchKernelGGL((ancestor_index_kernel<T, 8>), dim3((unsigned)B), dim3(kMaxThreads), lds, s,
                      (const T *)log_w, u, idx, flags, (int)K, (double *)ws);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
