@@ -78,6 +78,11 @@ def normal_log_prob_sum(value, loc, scale):
     return _kernels.get().normal_logprob_sum(value.detach(), loc.detach(), scale.detach())
 
 
+class _Declined(Exception):
+    """A fused kernel does not cover the operands it was offered (raised inside an autograd
+    Function's forward, caught by the operator that offered them)."""
+
+
 class _NormalLogWeight(torch.autograd.Function):
     """lw = logN(x; p) + logN(y; g) - logN(x; q) through kernel K5; backward through K4's."""
 
@@ -85,7 +90,7 @@ class _NormalLogWeight(torch.autograd.Function):
     def forward(ctx, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
         out = _kernels.get().normal_logweight(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q)
         if out is None:
-            raise RuntimeError("aesmc_amd: fused log-weight kernel rejected operands it was offered")
+            raise _Declined()   # caught by normal_log_weight: the caller takes the K4 + K1 route
         ctx.save_for_backward(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q)
         return out
 
@@ -109,7 +114,10 @@ def normal_log_weight(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
     if not _kernels.get().normal_logweight_covers(x, scale_p, y, scale_g, scale_q):
         return None
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        return _NormalLogWeight.apply(*tensors)
+        try:
+            return _NormalLogWeight.apply(*tensors)
+        except _Declined:
+            return None
     return _kernels.get().normal_logweight(*[t.detach() for t in tensors])
 
 

@@ -552,12 +552,91 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_d1_kernel(
   }
 }
 
+// K5 for wide rows (more than 64 values per particle, e.g. d = 128): K4's row mapping — TPR lanes
+// per particle stream 16-byte vectors of the row, partial sums meet by shuffles — with the three
+// terms accumulated side by side, x read once for two of them.  Same per-lane order and the same
+// shuffle tree as normal_lps_row_vec_kernel, so each sum is bit-identical to K4's.
+template <typename T, int TPR>
+__global__ __launch_bounds__(kLpBlock) void normal_logweight_row_kernel(
+    View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
+    T *__restrict__ out, int64_t particles, uint32_t K, uint32_t Dx, uint32_t Dy) {
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const int64_t p = (int64_t)blockIdx.x * (kLpBlock / TPR) + threadIdx.x / TPR;
+  const int t = threadIdx.x % TPR;
+  T sum_p = T(0), sum_q = T(0), sum_g = T(0);
+  if (p < particles) {
+    const int64_t b = p / K, k = p - b * K;
+    auto row = [&](const View3 &v) {
+      return reinterpret_cast<const V *>(reinterpret_cast<const T *>(v.ptr) + b * v.st.b + k * v.st.k);
+    };
+    const V *xp = row(x), *pp = row(mu_p), *qp = row(mu_q), *yp = row(y), *gp = row(mu_g);
+    const T s_p = reinterpret_cast<const T *>(sc_p.ptr)[0], s_g = reinterpret_cast<const T *>(sc_g.ptr)[0],
+            s_q = reinterpret_cast<const T *>(sc_q.ptr)[0];
+    const T two_var_p = T(2) * (s_p * s_p), log_p = Num<T>::log(s_p);
+    const T two_var_g = T(2) * (s_g * s_g), log_g = Num<T>::log(s_g);
+    const T two_var_q = T(2) * (s_q * s_q), log_q = Num<T>::log(s_q);
+    const T half_log_2pi = NormConst<T>::half_log_2pi();
+    for (uint32_t v = t; v < Dx / N; v += TPR) {
+      const V xv = xp[v], pv = pp[v], qv = qp[v];
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const T dp = Vec16<T>::get(xv, r) - Vec16<T>::get(pv, r);
+        const T dq = Vec16<T>::get(xv, r) - Vec16<T>::get(qv, r);
+        sum_p += (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
+        sum_q += (-(dq * dq)) / two_var_q - log_q - half_log_2pi;
+      }
+    }
+    for (uint32_t v = t; v < Dy / N; v += TPR) {
+      const V yv = yp[v], gv = gp[v];
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const T dg = Vec16<T>::get(yv, r) - Vec16<T>::get(gv, r);
+        sum_g += (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = TPR / 2; off > 0; off >>= 1) {
+    sum_p += __shfl_xor(sum_p, off, kWave);
+    sum_q += __shfl_xor(sum_q, off, kWave);
+    sum_g += __shfl_xor(sum_g, off, kWave);
+  }
+  if (t == 0 && p < particles) out[p] = (sum_p + sum_g) - sum_q;
+}
+
+static inline int row_team(int64_t D, int N) { return D / N <= 16 ? 16 : (D / N <= 32 ? 32 : 64); }
+
 template <typename T>
 static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int64_t Dx, int64_t Dy,
                             hipStream_t s) {
   constexpr int N = Vec16<T>::N;
-  if (Dx > 64 || Dy > 64 || Dx < 1 || Dy < 1) return AESMC_ERR_UNSUPPORTED;
+  if (Dx < 1 || Dy < 1) return AESMC_ERR_UNSUPPORTED;
   if (!is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st)) return AESMC_ERR_UNSUPPORTED;
+  if (Dx > 64 || Dy > 64) {
+    // wide rows: both extents wide, whole 16-byte vectors, the same lane team as K4 picks for
+    // each (so that every sum keeps K4's order), rows contiguous and 16-byte aligned
+    auto rows_ok = [&](const View3 &view) {
+      return view.st.d == 1 && view.st.k % N == 0 && view.st.b % N == 0 && (((uintptr_t)view.ptr) & 15u) == 0;
+    };
+    if (Dx <= 64 || Dy <= 64 || Dx % N != 0 || Dy % N != 0 || row_team(Dx, N) != row_team(Dy, N))
+      return AESMC_ERR_UNSUPPORTED;
+    if (!rows_ok(v[0]) || !rows_ok(v[1]) || !rows_ok(v[6]) || !rows_ok(v[3]) || !rows_ok(v[4]))
+      return AESMC_ERR_UNSUPPORTED;
+    const int64_t particles = B * K;
+    const int tpr = row_team(Dx, N);
+    const int64_t blocks = (particles + (kLpBlock / tpr) - 1) / (kLpBlock / tpr);
+    if (blocks > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)blocks), block(kLpBlock);
+#define AESMC_ROW_CASE(team)                                                                            \
+    hipLaunchKernelGGL((normal_logweight_row_kernel<T, team>), grid, block, 0, s, v[0], v[1], v[2], v[3],  \
+                       v[4], v[5], v[6], v[7], (T *)out, particles, (uint32_t)K, (uint32_t)Dx, (uint32_t)Dy)
+    if (tpr == 16) AESMC_ROW_CASE(16);
+    else if (tpr == 32) AESMC_ROW_CASE(32);
+    else AESMC_ROW_CASE(64);
+#undef AESMC_ROW_CASE
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
   if (Dx == 1 && Dy == 1) {
     const uint32_t bpr = (uint32_t)((K + 4 * kLpBlock - 1) / (4 * kLpBlock));
     if ((uint64_t)B * bpr > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;

@@ -492,6 +492,33 @@ def test_normal_logweight_is_bitwise_the_unfused_route(kernels, hip_device, dtyp
         torch.testing.assert_close(fused, eager, rtol=tol_, atol=tol_ * (dx + dy))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("B,K,dx,dy", [(2, 50, 128, 128), (1, 33, 68, 72), (3, 7, 256, 512), (2, 16, 1024, 1024)])
+def test_normal_logweight_wide_rows_are_bitwise_the_unfused_route(kernels, hip_device, dtype, B, K, dx, dy):
+    """More than 64 values per particle (d = 128 of BASELINE.json configs[4]): the row kernel."""
+    gen = torch.Generator(device=hip_device).manual_seed(B * K + dx)
+    rand = lambda *shape: torch.randn(*shape, device=hip_device, dtype=dtype, generator=gen)
+    scales = [torch.tensor(v, device=hip_device, dtype=dtype) for v in (1.0, 0.5, 0.7)]
+    layouts = [
+        dict(x=rand(B, K, dx), loc_p=rand(B, K, dx), y=rand(B, dy).unsqueeze(1).expand(B, K, dy),
+             loc_g=rand(B, K, dy), loc_q=rand(B, K, dx)),
+        dict(x=rand(K, B, dx).transpose(0, 1), loc_p=rand(dx).expand(B, K, dx),
+             y=rand(B, dy).unsqueeze(1).expand(B, K, dy), loc_g=rand(B, K, dy),
+             loc_q=rand(B, dx).unsqueeze(1).expand(B, K, dx)),
+        dict(x=rand(B, 2 * K, dx)[:, ::2], loc_p=rand(B, K, 2 * dx)[:, :, dx:], y=rand(B, K, dy),
+             loc_g=rand(B, K, dy), loc_q=rand(B, K, dx)),
+    ]
+    for lay in layouts:
+        sp, sg, sq = [s.expand(lay[k].shape) for s, k in zip(scales, ("x", "y", "x"))]
+        fused = kernels.normal_logweight(lay["x"], lay["loc_p"], sp, lay["y"], lay["loc_g"], sg, lay["loc_q"], sq)
+        assert fused is not None
+        log_p = kernels.normal_logprob_sum(lay["x"], lay["loc_p"], sp)
+        log_g = kernels.normal_logprob_sum(lay["y"], lay["loc_g"], sg)
+        log_q = kernels.normal_logprob_sum(lay["x"], lay["loc_q"], sq)
+        unfused, _ = kernels.logweight_lse(log_p, log_g, log_q)
+        assert torch.equal(fused, unfused)
+
+
 def test_normal_logweight_declines_what_it_does_not_cover(kernels, hip_device):
     B, K = 2, 8
     x = torch.randn(B, K, 3, device=hip_device)
@@ -501,7 +528,12 @@ def test_normal_logweight_declines_what_it_does_not_cover(kernels, hip_device):
     assert kernels.normal_logweight(x, x, vector_scale, y, y, one, x, one) is None       # non-scalar scale
     wide = torch.randn(B, K, 65, device=hip_device)
     one_w = torch.ones((), device=hip_device).expand(B, K, 65)
-    assert kernels.normal_logweight(wide, wide, one_w, y, y, one, wide, one_w) is None    # > 64 per particle
+    assert kernels.normal_logweight(wide, wide, one_w, y, y, one, wide, one_w) is None    # 65 values: not whole vectors
+    w128 = torch.randn(B, K, 128, device=hip_device)
+    one128 = torch.ones((), device=hip_device).expand(B, K, 128)
+    assert kernels.normal_logweight(w128, w128, one128, y, y, one, w128, one128) is None  # wide x, narrow y
+    off = torch.randn(B, K, 129, device=hip_device)[:, :, 1:]                             # misaligned rows
+    assert kernels.normal_logweight(w128, off, one128, w128, w128, one128, w128, one128) is None
     assert not kernels.normal_logweight_covers(x, vector_scale, y, one, one)
     assert kernels.normal_logweight_covers(x, one, y, one, one)
 
