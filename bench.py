@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-backward", action="store_true")
     ap.add_argument("--tunableop", default="on", choices=["on", "off"],
                     help="PyTorch TunableOp for the user callables' matmuls (tunes each GEMM shape once, in warm-up)")
+    ap.add_argument("--tunableop-file", default=None,
+                    help="keep TunableOp's picks in this CSV: a later run that finds it skips the tuning trials "
+                         "(used to profile without them)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and take the sharded code path even with one rank (test hook)")
     ap.add_argument("--mode", default=None, choices=["graph", "eager"],
@@ -171,8 +174,8 @@ def main():
         try:
             torch.cuda.tunable.enable(True)
             torch.cuda.tunable.tuning_enable(True)
-            torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"),
-                                                         "aesmc_tunableop_%d.csv" % os.getpid()))
+            torch.cuda.tunable.set_filename(args.tunableop_file or os.path.join(
+                os.environ.get("TMPDIR", "/tmp"), "aesmc_tunableop_%d.csv" % os.getpid()))
             torch.cuda.tunable.set_max_tuning_duration(30)
             torch.cuda.tunable.set_max_tuning_iterations(20)
         except Exception as error:     # an optional PyTorch knob: the bench must not depend on it
