@@ -157,6 +157,24 @@ def test_ancestor_index_randomised_stress(kernels, hip_device):
         want, _ = kernel_oracle.ancestor_index(log_w, u)
         bad = np.argwhere(got != want)
         assert bad.size == 0, (case, K, B, dtype, kind, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+        # the same rows through the fused step, with a payload whose row length varies with the case
+        # (incl. lengths the launch declines: then it must say so, not write something else)
+        from oracle import c_oracle
+        np.testing.assert_array_equal(c_oracle.ancestor_index(log_w, u)[0], want)
+        d = [1, 2, 3, 4, 5, 8, 10, 12][case % 8]
+        payload_dtype = [np.float32, np.float64, np.int32][case % 3]
+        payload = (rng.randn(B, K, d) * 100).astype(payload_dtype)
+        step = kernels.resample_step(dev(log_w, hip_device), dev(u, hip_device), dev(payload, hip_device),
+                                     want_lse=True)
+        if step is None:
+            assert K > kernels.lds_max_particles or (K * d * payload.dtype.itemsize) % 16 != 0
+            continue
+        idx, lse, moved = step
+        np.testing.assert_array_equal(idx.cpu().numpy(), want)
+        np.testing.assert_array_equal(moved.cpu().numpy(), c_oracle.gather(payload, want)[0])
+        _, want_lse = c_oracle.logweight_lse(log_w)
+        rtol, atol = tol(dtype)
+        np.testing.assert_allclose(lse.cpu().numpy().astype(np.float64), want_lse, rtol=rtol, atol=atol)
 
 
 def test_ancestor_index_large_k_uses_workspace(kernels, hip_device):
