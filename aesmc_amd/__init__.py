@@ -5,6 +5,26 @@ Public surface mirrors the reference package: `inference`, `losses`, `state`, `m
 `statistics`, `train`.  Importing the package does not touch the GPU; the first kernel call loads
 libaesmc_hip.so and raises if it has not been built (`python -m aesmc_amd.build`).
 """
+import os as _os
+
+import torch as _torch
+
+# hipGraph workaround, needed before the HIP runtime starts.  ROCm 7.0's graph fast path ("AQL
+# packet capture") was found to run captured MEMSET nodes out of stream order: in a captured
+# backward pass PyTorch's multi-block reductions zero their semaphores with cudaMemsetAsync, and
+# from the third or fourth replay on the gradients of small broadcast parameters came out wrong
+# (losses stayed right).  With the fast path off every replay equals the eager gradients bit for
+# bit (tests/test_gpu_graphs.py) at no measurable cost (4.65 vs 4.58 ms per ELBO at configs[1]).
+# The variable is read once, at the first HIP call; a value the user has set is left alone.
+HIPGRAPH_ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+if _os.environ.get(HIPGRAPH_ENV) is not None:
+    HIPGRAPH_MEMSET_WORKAROUND = "preset:" + _os.environ[HIPGRAPH_ENV]
+elif _torch.cuda.is_initialized():
+    HIPGRAPH_MEMSET_WORKAROUND = "too-late"   # graphs.GraphedLoss(backward=True) warns about it
+else:
+    _os.environ[HIPGRAPH_ENV] = "0"
+    HIPGRAPH_MEMSET_WORKAROUND = "set"
+
 from . import inference  # noqa: F401
 from . import losses  # noqa: F401
 from . import math  # noqa: F401

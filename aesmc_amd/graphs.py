@@ -21,9 +21,14 @@ same addresses (update them in place).  With backward=True no autograd graph bui
 same parameters may still be alive when the capture starts (drop earlier `loss` tensors): PyTorch
 would reuse that graph's gradient accumulators, which are bound to the eager stream, and the
 capture could not be closed.
+
+ROCm 7.0 caveat: captured memset nodes (PyTorch's reductions issue them) run out of stream order
+under the runtime's graph fast path; `import aesmc_amd` switches that path off through
+DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 if the HIP runtime has not started yet (aesmc_amd/__init__.py).
 """
 import contextlib
 import gc
+import warnings
 
 import numpy as np
 import torch
@@ -98,6 +103,14 @@ class GraphedLoss:
         batch sharded over the process group; the graph then holds the LOCAL share
         -sum_local(log Z_b) / global_batch_size (and its backward) and every call finishes with
         the one all-reduce of the loss (gradients: `distributed.all_reduce_gradients`)."""
+        import aesmc_amd
+        if backward and aesmc_amd.HIPGRAPH_MEMSET_WORKAROUND in ("too-late", "preset:1"):
+            warnings.warn(
+                "aesmc_amd: capturing a backward pass into a hipGraph with {}=0 not in effect (the HIP "
+                "runtime was initialised before `import aesmc_amd`, or the variable is set to 1). On ROCm "
+                "7.0 captured memset nodes then run out of order and replayed gradients can be wrong; "
+                "import aesmc_amd (or set the variable) before the first GPU call.".format(
+                    aesmc_amd.HIPGRAPH_ENV), RuntimeWarning)
         first = observations[0]
         self.shard = shard
         self.group = group

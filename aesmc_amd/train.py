@@ -70,8 +70,8 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
                                              backward=True)
             loss = graphed(observations)     # refreshes every captured parameter's .grad in place
             optimizer.step()
-            if callback is not None:
-                callback(epoch, iteration, loss, *model_parts)
+            if callback is not None:         # the graph's loss tensor is reused by the next replay
+                callback(epoch, iteration, loss.clone(), *model_parts)
         return
     for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
         optimizer.zero_grad()

@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# before the HIP runtime starts: ROCm 7.0's graph fast path misorders captured memset nodes
+# (aesmc_amd/__init__.py sets the same default on import; stated here because it shapes the numbers)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import numpy as np
 import torch
 
@@ -329,6 +333,8 @@ def main():
                    "parallelism": "batch-shard x{} (one RCCL all-reduce of sum log Z per ELBO)".format(world),
                    "pytorch": "TunableOp {} for the user callables' matmuls; distributions built with "
                               "validate_args=False".format(args.tunableop),
+                   "hip_runtime": "DEBUG_CLR_GRAPH_PACKET_CAPTURE={} (0: captured memset nodes keep stream "
+                                  "order on ROCm 7.0)".format(os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")),
                    "step": "one forward ELBO, get_loss(..., '{}'), ".format(algorithm) +
                            ("torch.no_grad()" if args.workload in FORWARD_ONLY else "autograd graph recorded") +
                            (", all T timesteps replayed as one hipGraph" if mode == "hipgraph" else ", eager Python loop")},

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# before anything can start the HIP runtime (torch.cuda.is_available() does): see aesmc_amd/__init__.py
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -154,3 +154,48 @@ def test_graphs_captured_into_recycled_memory_give_eager_gradients(hip_device):
             p.grad = grad
         del eager_loss, graphed, model, parts, params, static
         gc.collect()
+
+
+def test_replayed_gradients_stay_equal_to_eager_over_a_training_run(hip_device):
+    """Regression for ROCm 7.0's hipGraph fast path running captured MEMSET nodes out of stream
+    order (PyTorch's multi-block reductions zero their semaphores that way): at configs[1]-like
+    sizes the replayed gradients of the small broadcast parameters went wrong from the fourth
+    iteration on while the loss stayed right.  aesmc_amd switches the fast path off on import
+    (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0); every replay — at whatever state the random streams are in,
+    with eager work and optimiser steps in between — must equal the eager gradients bit for bit."""
+    import gc
+    import os
+    import aesmc_amd
+    assert os.environ.get(aesmc_amd.HIPGRAPH_ENV) == "0"
+    dim, K, B, T = 10, 1024, 256, 20
+    seed(0)
+    truth = models.LgssmNd(dim, seed=1, validate_args=False).to(hip_device)
+    model = models.LgssmNd(dim, seed=0, validate_args=False).to(hip_device)
+    parts = (model.initial, model.transition, model.emission, model.proposal)
+    params = list(model.parameters())
+    names = [n for n, _ in model.named_parameters()]
+    optimizer = torch.optim.Adam(params, lr=3e-3)
+    graphed = None
+    for iteration in range(8):
+        observations = truth.simulate(T, B, seed=50 + iteration)
+        torch.randn(1000, device=hip_device)                 # eager use of the generator in between
+        if graphed is None:
+            graphed = graphs.GraphedLoss(observations, K, "aesmc", *parts, backward=True)
+        cuda_state, numpy_state = torch.cuda.get_rng_state(hip_device), np.random.get_state()
+        graph_loss = graphed(observations).clone()
+        graph_grads = [p.grad.clone() for p in params]
+        static = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        torch.cuda.set_rng_state(cuda_state, hip_device)
+        np.random.set_state(numpy_state)
+        eager_loss = losses.get_loss(observations, K, "aesmc", *parts)
+        eager_loss.backward()
+        assert torch.equal(graph_loss, eager_loss.detach()), iteration
+        for name, got, p in zip(names, graph_grads, params):
+            assert torch.equal(got, p.grad), (iteration, name, float((got - p.grad).abs().max()))
+        for p, grad in zip(params, static):
+            p.grad = grad
+        del eager_loss
+        gc.collect()
+        optimizer.step()
