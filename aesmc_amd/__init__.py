@@ -14,7 +14,8 @@ import torch as _torch
 # backward pass PyTorch's multi-block reductions zero their semaphores with cudaMemsetAsync, and
 # from the third or fourth replay on the gradients of small broadcast parameters came out wrong
 # (losses stayed right).  With the fast path off every replay equals the eager gradients bit for
-# bit (tests/test_gpu_graphs.py) at no measurable cost (4.65 vs 4.58 ms per ELBO at configs[1]).
+# bit (tests/test_gpu_graphs.py) at no cost (4.36-4.40 ms per ELBO at configs[1] with the fast
+# path off, 4.41-4.42 with it on).
 # The variable is read once, at the first HIP call; a value the user has set is left alone.
 HIPGRAPH_ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 if _os.environ.get(HIPGRAPH_ENV) is not None:
