@@ -431,3 +431,42 @@ def test_odd_shapes_match_the_cpu_port_draw_for_draw(hip_device, B, K, T, d, his
     torch.testing.assert_close(got["log_marginal_likelihood"].cpu(), want["log_marginal_likelihood"],
                                rtol=1e-10, atol=1e-10)
     torch.testing.assert_close(got["last_latent"].cpu(), want["last_latent"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind,algorithm,B,K,T,d", [("nonlinear", "aesmc", 4, 256, 5, 6), ("nonlinear", "iwae", 3, 64, 3, 4),
+                                                    ("iwae", "iwae", 64, 512, 1, 1), ("lgssm", "aesmc", 3, 300, 4, 5)])
+def test_other_model_families_match_the_cpu_port_with_gradients(hip_device, kind, algorithm, B, K, T, d):
+    """BASELINE.json's other configs (nonlinear SSM + MLP proposal; one-step Gaussian IWAE) and the
+    LGSSM once more, through get_loss + backward: the CPU port records its draws, the GPU replays
+    them; float64: loss to 1e-10, every parameter gradient to 1e-8 of its largest entry."""
+    from oracle import reference_port
+    dtype = torch.float64
+
+    def build(state_module, device):
+        if kind == "nonlinear":
+            model = models.NonlinearSsm(d, hidden=16, seed=0, dtype=dtype, state=state_module)
+        elif kind == "iwae":
+            model = models.GaussianIwae(dtype=dtype, state=state_module)
+        else:
+            model = models.LgssmNd(d, seed=0, dtype=dtype, state=state_module)
+        return model.to(device)
+
+    cpu_model = build(reference_port, torch.device("cpu"))
+    observations = cpu_model.simulate(T, B, seed=1)
+    parts = lambda m: (m.initial, m.transition, m.emission, m.proposal)
+    np.random.seed(4)
+    torch.manual_seed(4)
+    with replay.record() as tape:
+        want = reference_port.get_loss(observations, K, algorithm, *parts(cpu_model))
+    want.backward()
+    model = build(state, hip_device)
+    with replay.replay(tape):
+        got = losses.get_loss([o.to(hip_device) for o in observations], K, algorithm, *parts(model))
+    got.backward()
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-10, atol=1e-10)
+    for (name, p), q in zip(model.named_parameters(), cpu_model.parameters()):
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        scale = float(q.grad.abs().max()) + 1e-300
+        torch.testing.assert_close(p.grad.cpu() / scale, q.grad / scale, rtol=0, atol=1e-8, msg=name)
