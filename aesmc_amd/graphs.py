@@ -159,8 +159,20 @@ class GraphedLoss:
         # With a process group alive, RCCL's watchdog thread may call the HIP runtime at any time;
         # "thread_local" keeps such calls from other threads from invalidating this capture.
         error_mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=error_mode):
-            self.static_loss = self._evaluate(refill=False)
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode=error_mode):
+                self.static_loss = self._evaluate(refill=False)
+        except RuntimeError as error:
+            if "captur" not in str(error).lower():
+                raise
+            raise RuntimeError(
+                "aesmc_amd: the ELBO could not be captured into a hipGraph — something in the four "
+                "callables talks to the host while the stream is capturing. Usual causes: a "
+                "distribution built with validate_args=True (its checks call .all() on the device: "
+                "pass validate_args=False), a Python-number distribution parameter such as "
+                "Normal(loc, 0.7) (uploaded on every call: keep it in a buffer on the device), "
+                ".item() / .cpu() / print of a device tensor, or host-side control flow on tensor "
+                "values. Original error: {}".format(error)) from error
         self.replays = 0
 
     def _shard_scope(self):

@@ -199,3 +199,21 @@ def test_replayed_gradients_stay_equal_to_eager_over_a_training_run(hip_device):
         del eager_loss
         gc.collect()
         optimizer.step()
+
+
+def test_capture_failure_explains_itself(hip_device):
+    """A callable that synchronises with the host (Python-number scale: uploaded on every call)
+    cannot be captured; the error must say what to change."""
+    from aesmc_amd import state
+    model, observations, parts = make(hip_device)
+
+    def emission(latents=None, time=None, previous_observations=None):
+        dist = model.emission(latents=latents, time=time)
+        return state.set_batch_shape_mode(torch.distributions.Normal(dist.loc, 0.5, validate_args=False),
+                                          state.BatchShapeMode.FULLY_EXPANDED)
+
+    with pytest.raises(RuntimeError, match="could not be captured"):
+        graphs.GraphedLoss(observations, 16, "aesmc", model.initial, model.transition, emission, model.proposal)
+    torch.cuda.synchronize()
+    # the device and the package are still usable afterwards
+    assert bool(torch.isfinite(losses.get_loss(observations, 16, "aesmc", *parts)))
