@@ -112,20 +112,37 @@ def all_reduce_gradients(parameters, group=None):
 
 def train(dataloader, num_particles, algorithm, initial, transition, emission, proposal, num_epochs,
           num_iterations_per_epoch=None, optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
-          callback=None, group=None):
+          callback=None, group=None, hip_graph=False):
     """`train.train` (aesmc/train.py:22-41) with one process per GPU: every rank's `dataloader`
     yields ITS OWN rows of each minibatch (equal counts on all ranks), the loss is the mean over
     the global batch (one all-reduce of sum log Z, `sharded_get_loss`) and the parameter gradients
     are summed over ranks by one flat-bucket all-reduce before each optimiser step, so replicas
     stay identical.  Seed numpy identically on all ranks (the resampler draws the global uniform
     block and keeps its rows) and torch differently per rank (independent proposal noise).
-    `callback` sees the global loss."""
+    `callback` sees the global loss.  `hip_graph=True` replays each rank's share of loss + backward
+    as one captured hipGraph (`graphs.GraphedLoss(shard=...)`); the two collectives stay outside it."""
     from . import train as _train
     rank = dist.get_rank(group) if _group_is_live() else 0
     world_size = dist.get_world_size(group) if _group_is_live() else 1
     model_parts = (initial, transition, emission, proposal)
     parameters = list(_train.get_chained_params(*model_parts))
     optimizer = optimizer_algorithm(parameters, **optimizer_kwargs)
+    if hip_graph:
+        from . import graphs
+        graphed = None
+        for epoch, iteration, observations in _train._minibatches(dataloader, num_epochs,
+                                                                  num_iterations_per_epoch):
+            if graphed is None:
+                optimizer.zero_grad(set_to_none=True)
+                shard = (observations[0].size(0) * world_size, rank, world_size)
+                graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
+                                             backward=True, shard=shard, group=group)
+            loss = graphed(observations)            # local replay + the all-reduce of the loss
+            all_reduce_gradients(parameters, group=group)
+            optimizer.step()
+            if callback is not None:
+                callback(epoch, iteration, loss.clone(), *model_parts)
+        return
     for epoch, iteration, observations in _train._minibatches(dataloader, num_epochs,
                                                               num_iterations_per_epoch):
         first = observations[0]

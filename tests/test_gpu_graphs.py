@@ -217,3 +217,42 @@ def test_capture_failure_explains_itself(hip_device):
     torch.cuda.synchronize()
     # the device and the package are still usable afterwards
     assert bool(torch.isfinite(losses.get_loss(observations, 16, "aesmc", *parts)))
+
+
+def test_distributed_train_on_a_one_rank_rccl_group_equals_single_process_training(hip_device):
+    """distributed.train (eager and hip_graph) with a one-rank RCCL group takes the sharded code
+    path — shard scope, all-reduce of the loss and of the flat gradient bucket — and must land on
+    exactly the parameters train.train reaches from the same seeds."""
+    import torch.distributed as dist
+    from aesmc_amd import distributed, train
+    created = False
+    if not dist.is_initialized():
+        import socket
+        with socket.socket() as probe:
+            probe.bind(("127.0.0.1", 0))
+            port = probe.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{}".format(port), rank=0, world_size=1,
+                                device_id=hip_device)
+        created = True
+    try:
+        results = {}
+        for label, fn, kwargs in (("single", train.train, {}), ("sharded", distributed.train, {}),
+                                  ("single_graph", train.train, {"hip_graph": True}),
+                                  ("sharded_graph", distributed.train, {"hip_graph": True})):
+            seed(0)
+            truth = models.LgssmNd(2, seed=1, validate_args=False).to(hip_device)
+            model = models.LgssmNd(2, seed=0, validate_args=False).to(hip_device)
+            loader = [truth.simulate(4, 16, seed=20 + i) for i in range(6)]
+            seen = []
+            fn(loader, 32, "aesmc", model.initial, model.transition, model.emission, model.proposal,
+               num_epochs=1, num_iterations_per_epoch=5, optimizer_algorithm=torch.optim.SGD,
+               optimizer_kwargs={"lr": 1e-2}, callback=lambda e, i, loss, *parts: seen.append(loss.item()),
+               **kwargs)
+            results[label] = (seen, [p.detach().clone() for p in model.parameters()])
+        for a, b in (("single", "sharded"), ("single_graph", "sharded_graph")):
+            np.testing.assert_allclose(results[a][0], results[b][0], rtol=1e-6)
+            for pa, pb in zip(results[a][1], results[b][1]):
+                torch.testing.assert_close(pa, pb, rtol=1e-6, atol=1e-7)
+    finally:
+        if created:
+            dist.destroy_process_group()
