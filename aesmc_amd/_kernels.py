@@ -6,6 +6,7 @@ density, alignment) before anything is launched.  Kernels report data-dependent 
 log-weights, degenerate rows, out-of-range indices) by OR-ing bits into a per-device int32 word
 that the host reads once per ELBO evaluation (`read_flags`) instead of synchronising per timestep.
 """
+import contextlib
 import ctypes
 import threading
 
@@ -44,6 +45,17 @@ def _inner_dense(t):
 
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
+
+
+_NO_SWITCH = contextlib.nullcontext()
+
+
+def _on_device(device):
+    """Context that makes `device` current for the launch; free when it already is (the usual
+    case: entering torch.cuda.device costs ~4 us of host time per kernel in the eager loop)."""
+    if torch.cuda.current_device() == device.index:
+        return _NO_SWITCH
+    return torch.cuda.device(device)
 
 
 class KernelTimer:
@@ -179,7 +191,7 @@ class HipKernels:
         need_lw = want_lw and not (b is None and c is None)
         lw = torch.empty_like(a) if need_lw else None
         lse = torch.empty(B, dtype=a.dtype, device=a.device) if want_lse else None
-        with torch.cuda.device(a.device):
+        with _on_device(a.device):
             args = (tag, _ptr(a), _ptr(b), _ptr(c), _ptr(lw), _ptr(lse), B, K, self._stream(a))
             _lib.check(self._lib.aesmc_logweight_lse(*args), "aesmc_logweight_lse")
             if self.timer is not None:
@@ -209,7 +221,7 @@ class HipKernels:
             grad_lse = grad_lse.contiguous()
         g = torch.empty_like(lw)
         ng = torch.empty_like(lw) if want_neg else None
-        with torch.cuda.device(lw.device):
+        with _on_device(lw.device):
             args = (tag, _ptr(lw), _ptr(lse), _ptr(grad_lw), _ptr(grad_lse), _ptr(g), _ptr(ng), B, K,
                     self._stream(lw))
             _lib.check(self._lib.aesmc_logweight_lse_backward(*args), "aesmc_logweight_lse_backward")
@@ -237,7 +249,7 @@ class HipKernels:
         idx = torch.empty((B, K), dtype=torch.int64, device=log_w.device)
         ws_bytes = int(self._lib.aesmc_workspace_bytes(B, K))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=log_w.device) if ws_bytes else None
-        with torch.cuda.device(log_w.device):
+        with _on_device(log_w.device):
             flags = self.flags(log_w.device)
             args = (tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(flags), B, K, _ptr(ws), ws_bytes,
                     self._stream(log_w))
@@ -312,7 +324,7 @@ class HipKernels:
         lse = torch.empty((B,), dtype=log_w.dtype, device=log_w.device) if want_lse else None
         if idx.numel() == 0:
             return None
-        with torch.cuda.device(log_w.device):
+        with _on_device(log_w.device):
             flags = self.flags(log_w.device)
             args = (tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(lse), _ptr(payload if dst is not None else None),
                     _ptr(dst), _ptr(flags), B, K, row_bytes, sb, sk, self._stream(log_w))
@@ -356,7 +368,7 @@ class HipKernels:
         if dst.numel() == 0:
             return dst
         idx = idx.contiguous()
-        with torch.cuda.device(src.device):
+        with _on_device(src.device):
             flags = self.flags(src.device)
             args = (_ptr(src), _ptr(idx), _ptr(dst), _ptr(flags), B, K, row_elems * esz,
                     src.stride(0) * esz, src.stride(1) * esz, self._stream(src))
@@ -381,7 +393,7 @@ class HipKernels:
         grad_src = torch.empty_like(grad_out)
         if grad_src.numel() == 0:
             return grad_src
-        with torch.cuda.device(grad_out.device):
+        with _on_device(grad_out.device):
             flags = self.flags(grad_out.device)
             args = (tag, _ptr(grad_out), _ptr(idx), _ptr(grad_src), _ptr(flags), B, K, row_elems,
                     1 if sorted_index else 0, self._stream(grad_out))
@@ -401,6 +413,11 @@ class HipKernels:
         """Describes a [B,K,*] tensor as (tensor, (sb, sk, sd), D) with the trailing dims collapsed
         into one of extent D and element stride sd (0 = broadcast).  Copies only when the trailing
         dims cannot be described by a single stride."""
+        rank = t.dim()
+        if rank == 3:                     # the usual case: nothing to collapse
+            return t, t.stride(), t.size(2)
+        if rank == 2:
+            return t, t.stride() + (0,), 1
         D = 1
         for size in t.shape[2:]:
             D *= size
@@ -442,7 +459,7 @@ class HipKernels:
         out = torch.empty((B, K), dtype=value.dtype, device=value.device)
         if out.numel() == 0:
             return out
-        with torch.cuda.device(value.device):
+        with _on_device(value.device):
             args = (tag, _ptr(value), _ptr(loc), _ptr(scale), _ptr(out), B, K, D) + sv + sm + ss + \
                 (self._stream(value),)
             _lib.check(self._lib.aesmc_normal_logprob_sum(*args), "aesmc_normal_logprob_sum")
@@ -464,7 +481,7 @@ class HipKernels:
                 for need in (need_value, need_loc, need_scale)]
         if value.numel() == 0 or not any(o is not None for o in outs):
             return tuple(None if o is None else o.zero_() for o in outs)
-        with torch.cuda.device(value.device):
+        with _on_device(value.device):
             args = (tag, _ptr(value), _ptr(loc), _ptr(scale), _ptr(grad_out), _ptr(outs[0]),
                     _ptr(outs[1]), _ptr(outs[2]), B, K, D) + sv + sm + ss + (self._stream(value),)
             _lib.check(self._lib.aesmc_normal_logprob_sum_backward(*args),
@@ -515,7 +532,7 @@ class HipKernels:
         views = (_lib.View3 * 8)(*[_lib.View3(_ptr(t), *st) for t, st in (
             (x, sx), (loc_p, sp), (scale_p, ssp), (y, sy), (loc_g, sg), (scale_g, ssg), (loc_q, sq),
             (scale_q, ssq))])
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             args = (tag, views, _ptr(out), B, K, Dx, Dy, self._stream(x))
             status = self._lib.aesmc_normal_logweight(*args)
             if status == 2:
@@ -538,7 +555,7 @@ class HipKernels:
         out = torch.empty(eps.shape, dtype=eps.dtype, device=eps.device)
         if out.numel() == 0:
             return out
-        with torch.cuda.device(eps.device):
+        with _on_device(eps.device):
             for attempt in (0, 1):
                 views = [_lib.View3(_ptr(t), *st) for t, st in ((eps, se), (loc, sm), (scale, ss))]
                 args = (tag, ctypes.byref(views[0]), ctypes.byref(views[1]), ctypes.byref(views[2]), _ptr(out),
@@ -590,7 +607,7 @@ class HipKernels:
                 second.zero_()
         ws_bytes = int(self._lib.aesmc_particle_summary_workspace_bytes(tag, B, K, D))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=log_w.device) if ws_bytes else None
-        with torch.cuda.device(log_w.device):
+        with _on_device(log_w.device):
             args = (tag, _ptr(log_w), ctypes.byref(view) if view is not None else None,
                     _ptr(log_ess), _ptr(mean) if D > 0 else 0, _ptr(second) if D > 0 else 0, B, K, D,
                     _ptr(ws), ws_bytes, self._stream(log_w))

@@ -233,7 +233,10 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
     if len(shape) < 2:
         return None
     eps = torch.distributions.normal._standard_normal(shape, dtype=loc.dtype, device=loc.device)
-    loc, scale = loc.expand(shape), scale.expand(shape)
+    if loc.shape != shape:
+        loc = loc.expand(shape)
+    if scale.shape != shape:
+        scale = scale.expand(shape)
     if swap_leading_dims:
         eps, loc, scale = eps.transpose(0, 1), loc.transpose(0, 1), scale.transpose(0, 1)
     return _ops.normal_rsample(eps, loc, scale)
@@ -265,10 +268,12 @@ def _fused_normal_views(distribution, value, missing):
             if param.dim() == 0:
                 return None
             param = param.unsqueeze(1)
-        try:
-            views.append(param.expand(value.shape))
-        except RuntimeError:
-            return None
+        if param.shape != value.shape:      # an expand of the full shape would be a no-op view
+            try:
+                param = param.expand(value.shape)
+            except RuntimeError:
+                return None
+        views.append(param)
     return views
 
 
