@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line with the contract fields plus
   kernels      : the same per-launch figures for every kernel of the path.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -115,9 +116,6 @@ def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", budget_s=20.0):
                       "oracle/reference_port.py (PyTorch-CPU + NumPy, keeps the reference's O(T^2) "
                       "history re-gather and per-row np.digitize loop)".format(b, K, t, dim, dt, threads, cores),
             "loss": loss}
-
-
-import contextlib
 
 
 @contextlib.contextmanager
