@@ -1,0 +1,269 @@
+"""The reference's own unit tests (test/test_math.py, test_state.py, test_inference.py,
+test_statistics.py, test_losses.py), restated for this package and run on the MI355X: same
+inputs, same expectations, every tensor on the HIP device.  Each test names the reference test it
+follows; together they are the "switch packages and your tests still pass" check."""
+import itertools
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import aesmc_amd as aesmc
+from aesmc_amd import inference, losses, state, statistics, train
+from aesmc_amd import math as amath
+from aesmc_amd.testing import models
+
+pytestmark = pytest.mark.gpu
+Modes = state.BatchShapeMode
+
+
+# ---- test/test_math.py ---------------------------------------------------------------------------
+@pytest.mark.parametrize("fn", [amath.lognormexp, amath.exponentiate_and_normalize])
+def test_math_dimensions_and_types(hip_device, fn):
+    """TestLognormexp / TestExponentiateAndNormalize :: test_dimensions, test_type."""
+    assert fn(torch.rand(2, 3, 4, 5, device=hip_device), dim=2).size() == torch.Size([2, 3, 4, 5])
+    assert fn(torch.rand(3, device=hip_device)).size() == torch.Size([3])
+    assert fn(torch.rand(1, device=hip_device)).size() == torch.Size([1])
+    assert list(np.shape(fn(np.random.rand(2, 3, 4, 5), dim=2))) == [2, 3, 4, 5]
+    assert list(np.shape(fn(np.random.rand(3)))) == [3]
+    assert list(np.shape(fn(np.random.rand(1)))) == [1]
+    assert isinstance(fn(torch.rand(1, device=hip_device)), torch.Tensor)
+    assert isinstance(fn(np.array([2])), np.ndarray)
+
+
+def test_math_values(hip_device):
+    """TestLognormexp / TestExponentiateAndNormalize :: test_value (the [1, 2, 3] case)."""
+    x = [1, 2, 3]
+    total = np.exp(1) + np.exp(2) + np.exp(3)
+    log_result, result = np.log(np.exp(x) / total), np.exp(x) / total
+    np.testing.assert_allclose(amath.lognormexp(torch.Tensor(x).to(hip_device)).cpu().numpy(), log_result, atol=1e-6)
+    np.testing.assert_allclose(amath.lognormexp(np.array(x)), log_result, atol=1e-6)
+    np.testing.assert_allclose(amath.exponentiate_and_normalize(torch.Tensor(x).to(hip_device)).cpu().numpy(),
+                               result, atol=1e-6)
+    np.testing.assert_allclose(amath.exponentiate_and_normalize(np.array(x)), result, atol=1e-6)
+
+
+# ---- test/test_inference.py ----------------------------------------------------------------------
+def test_get_resampled_latents_value(hip_device):
+    """TestGetResampledLatentStates :: test_value (the exact genealogy)."""
+    latents = [torch.Tensor([[1, 2, 3]]), torch.Tensor([[4, 5, 6]]), torch.Tensor([[7, 8, 9]]),
+               torch.Tensor([[10, 11, 12]])]
+    indices = [torch.LongTensor([[0, 2, 1]]), torch.LongTensor([[2, 0, 0]]), torch.LongTensor([[1, 2, 0]])]
+    want = [[1, 1, 2], [4, 4, 6], [8, 9, 7], [10, 11, 12]]
+    got = inference.get_resampled_latents([x.to(hip_device) for x in latents], [i.to(hip_device) for i in indices])
+    for have, expected in zip(got, want):
+        assert torch.equal(have.cpu(), torch.Tensor([expected]))
+
+
+def test_sample_ancestral_index_dimensions_type_and_frequencies(hip_device):
+    """TestSampleAncestralIndex :: test_dimensions, test_type, test_sampler."""
+    for shape in [(2, 3), (1, 2), (2, 1)]:
+        assert inference.sample_ancestral_index(torch.rand(*shape, device=hip_device)).size() == torch.Size(shape)
+    index = inference.sample_ancestral_index(torch.rand(1, 1, device=hip_device))
+    assert index.dtype == torch.int64 and index.device == hip_device
+    weight, trials = [0.2, 0.3, 0.5], 10000
+    np.random.seed(0)
+    index = inference.sample_ancestral_index(
+        torch.log(torch.Tensor(weight)).unsqueeze(0).expand(trials, len(weight)).to(hip_device))
+    frequencies = [(index == i).float().sum().item() / (trials * len(weight)) for i in range(len(weight))]
+    np.testing.assert_allclose(frequencies, weight, atol=1e-2)
+
+
+def test_infer_shapes_and_flags_for_is_and_smc(hip_device):
+    """TestInfer :: test_importance_sampling, test_smc — what can run without pykalman: every
+    return_* flag gives the documented shapes / Nones for both algorithms, with the reference's
+    1-D LGSSM callables (test/models/lgssm.py restated in aesmc_amd.testing.models)."""
+    B, K, T = 3, 50, 6
+    parts = (models.Lgssm1dInitial(0.0, 1.0), models.Lgssm1dTransition(0.9, 1.0).to(hip_device),
+             models.Lgssm1dEmission(1.0, 0.5).to(hip_device), models.Lgssm1dProposal(0.7, 0.7).to(hip_device))
+    torch.manual_seed(0)
+    observations = [torch.randn(B, device=hip_device) for _ in range(T)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        smc = inference.infer("smc", observations, *parts, K, return_log_marginal_likelihood=True,
+                              return_latents=True, return_original_latents=True, return_log_weight=True,
+                              return_log_weights=True, return_ancestral_indices=True)
+        assert smc["log_marginal_likelihood"].shape == (B,) and smc["log_weight"].shape == (B, K)
+        assert len(smc["latents"]) == T and len(smc["original_latents"]) == T and len(smc["log_weights"]) == T
+        assert len(smc["ancestral_indices"]) == T - 1 and smc["last_latent"].shape == (B, K)
+        assert all(x.shape == (B, K) for x in smc["latents"] + smc["log_weights"])
+        imp = inference.infer("is", observations, *parts, K, return_log_marginal_likelihood=True)
+        assert imp["log_marginal_likelihood"].shape == (B,) and imp["ancestral_indices"] is None
+        assert imp["original_latents"] is None and len(imp["latents"]) == T
+        none = inference.infer("smc", observations, *parts, K, return_latents=False, return_log_weight=False)
+        assert all(none[key] is None for key in ("log_marginal_likelihood", "latents", "original_latents",
+                                                 "log_weight", "log_weights", "ancestral_indices"))
+        with pytest.raises(ValueError):
+            inference.infer("mcmc", observations, *parts, K)
+        for bad in (dict(return_original_latents=True), dict(return_ancestral_indices=True)):
+            with pytest.raises(RuntimeWarning):
+                inference.infer("is", observations, *parts, K, **bad)
+
+
+# ---- test/test_state.py --------------------------------------------------------------------------
+def test_batch_shape_mode_implicit_and_explicit(hip_device):
+    """TestBatchShapeMode :: test_dimensions."""
+    B, K, d = 2, 3, 4
+    cases = [((), Modes.NOT_EXPANDED, False), ((B,), Modes.BATCH_EXPANDED, True), ((d,), Modes.NOT_EXPANDED, False),
+             ((B, K), Modes.FULLY_EXPANDED, True), ((B, d), Modes.BATCH_EXPANDED, True),
+             ((B, K, d), Modes.FULLY_EXPANDED, True)]
+    for batch_shape, mode, ambiguous in cases:
+        dist = torch.distributions.Normal(torch.zeros(batch_shape, device=hip_device),
+                                          torch.ones(batch_shape, device=hip_device))
+        if ambiguous:
+            with pytest.warns(RuntimeWarning):
+                assert state.get_batch_shape_mode(dist, B, K) == mode
+        else:
+            assert state.get_batch_shape_mode(dist, B, K) == mode
+    for mode in Modes:
+        dist = state.set_batch_shape_mode(torch.distributions.Normal(torch.zeros(B, K, device=hip_device),
+                                                                     torch.ones(B, K, device=hip_device)), mode)
+        assert state.get_batch_shape_mode(dist, B, K) == mode
+
+
+def test_sample_dimensions_and_values(hip_device):
+    """TestSample :: test_dimensions (implicit and explicit modes, dicts), test_sample_values."""
+    normal = lambda shape: torch.distributions.Normal(torch.zeros(shape, device=hip_device),
+                                                      torch.ones(shape, device=hip_device))
+    for (B, K), dims in itertools.product([(2, 2), (2, 3)], [(), (4,), (4, 5)]):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            for batch_shape, want in [(dims, (B, K) + dims), ((B,), (B, K)), ((B, K), (B, K)),
+                                      ((B,) + dims, (B, K) + dims), ((B, K) + dims, (B, K) + dims)]:
+                if batch_shape == dims and dims[:1] == (B,):
+                    continue
+                assert state.sample(normal(batch_shape), B, K).size() == torch.Size(want)
+        for mode, batch_shape in [(Modes.NOT_EXPANDED, dims), (Modes.BATCH_EXPANDED, (B,) + dims),
+                                  (Modes.FULLY_EXPANDED, (B, K) + dims)]:
+            dist = state.set_batch_shape_mode(normal(batch_shape), mode)
+            assert state.sample(dist, B, K).size() == torch.Size((B, K) + dims)
+            both = state.sample({"a": dist, "b": dist}, B, K)
+            assert both["a"].size() == both["b"].size() == torch.Size((B, K) + dims)
+    for B, K in [(2, 2), (2, 3)]:
+        loc = 100 * torch.arange(B * K, dtype=torch.float, device=hip_device).view(B, K)
+        dist = torch.distributions.Normal(loc, torch.ones(B, K, device=hip_device))
+        for mode, extra in [(Modes.NOT_EXPANDED, (0, 1)), (Modes.BATCH_EXPANDED, (1,)), (Modes.FULLY_EXPANDED, ())]:
+            state.set_batch_shape_mode(dist, mode)
+            samples = state.sample(dist, B, K)
+            mean = samples.mean(dim=extra) if extra else samples
+            np.testing.assert_allclose(mean.cpu().numpy(), loc.cpu().numpy(), atol=10)   # within 10 sigma
+
+
+def test_log_prob_dimensions_and_values(hip_device):
+    """TestLogProb :: test_dimensions (Normal and OneHotCategorical with an event shape), test_value."""
+    categories = 5
+    for (B, K), dims in itertools.product([(2, 2), (2, 3)], [(), (4,), (4, 5), (2,), (2, 3)]):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            for idx, batch_shape in enumerate([(B, K) + dims, (B,) + dims, dims]):
+                value = torch.rand((B, K) + dims, device=hip_device)
+                dist = torch.distributions.Normal(torch.zeros(batch_shape, device=hip_device),
+                                                  torch.ones(batch_shape, device=hip_device))
+                assert state.log_prob(dist, value).size() == torch.Size([B, K])
+                one_hot = torch.zeros((B, K) + dims + (categories,), device=hip_device)
+                one_hot[..., 0] = 1
+                categorical = torch.distributions.OneHotCategorical(
+                    probs=torch.ones(dims + (categories,), device=hip_device))
+                assert state.log_prob(categorical, one_hot).size() == torch.Size([B, K])
+                # values: loc = 10 * arange, scale 1, value 0 — against the explicitly expanded distribution
+                zeros = torch.zeros((B, K) + dims, device=hip_device)
+                loc = 10 * torch.arange(int(np.prod(batch_shape)), dtype=torch.float, device=hip_device).view(batch_shape)
+                expanded = loc if idx == 0 else (loc.unsqueeze(1) if idx == 1 else loc.unsqueeze(0).unsqueeze(0))
+                expanded = expanded.expand((B, K) + dims)
+                want = torch.distributions.Normal(expanded, 1).log_prob(zeros).reshape(B, K, -1).sum(dim=2)
+                got = state.log_prob(torch.distributions.Normal(loc, torch.ones((), device=hip_device)), zeros)
+                np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
+
+
+def test_resample_and_expand_observation(hip_device):
+    """TestResample :: test_dimensions, test_small;  TestExpandObservation :: test_dimensions."""
+    index = torch.zeros(3, 2, dtype=torch.int64, device=hip_device)
+    for shape in [(3, 2), (3, 2, 4, 5)]:
+        value = torch.rand(*shape, device=hip_device)
+        assert state.resample(value, index).size() == value.size()
+    got = state.resample(torch.Tensor([[1, 2, 3], [4, 5, 6]]).to(hip_device),
+                         torch.LongTensor([[1, 2, 0], [0, 0, 1]]).to(hip_device))
+    assert torch.equal(got.cpu(), torch.Tensor([[2, 3, 1], [4, 4, 5]]))
+    B, K, dims_list = 2, 3, [(), (4,), (4, 5)]
+    for dims in dims_list:
+        assert state.expand_observation(torch.rand((B,) + dims, device=hip_device), K).size() == \
+            torch.Size((B, K) + dims)
+    for a, b in itertools.product(dims_list, dims_list):
+        out = state.expand_observation({"a": torch.rand((B,) + a, device=hip_device),
+                                        "b": torch.rand((B,) + b, device=hip_device)}, K)
+        assert out["a"].size() == torch.Size((B, K) + a) and out["b"].size() == torch.Size((B, K) + b)
+
+
+# ---- test/test_statistics.py ---------------------------------------------------------------------
+def test_statistics_dimensions_and_values(hip_device):
+    """TestEmpiricalExpectation :: test_dimensions, test_value;  TestLogEss :: test_dimensions,
+    test_value;  TestEss :: test_value."""
+    value = torch.rand(2, 3, 4, 5, 6, device=hip_device)
+    log_weight = -torch.rand(2, 3, device=hip_device)
+    assert statistics.empirical_expectation(value, log_weight, lambda v: torch.rand(2, 7, 8, device=hip_device)).size() \
+        == torch.Size([2, 7, 8])
+    assert statistics.empirical_expectation(torch.rand(2, 3, device=hip_device), log_weight,
+                                            lambda v: torch.rand(2, device=hip_device)).size() == torch.Size([2])
+    value = torch.Tensor([1, 2, 3]).unsqueeze(0).to(hip_device)
+    log_weight = torch.log(torch.Tensor([0.2, 0.3, 0.5])).unsqueeze(0).to(hip_device)
+    np.testing.assert_allclose(statistics.empirical_expectation(value, log_weight, lambda v: v * 2).cpu().numpy(),
+                               [1 * 2 * 0.2 + 2 * 2 * 0.3 + 3 * 2 * 0.5], rtol=1e-6)
+    np.testing.assert_allclose(statistics.empirical_mean(value, log_weight).cpu().numpy(), [2.3], rtol=1e-6)
+    assert statistics.log_ess(-torch.rand(3, 4, device=hip_device)).size() == torch.Size([3])
+    assert statistics.log_ess(-torch.rand(3, device=hip_device)).size() == torch.Size([])
+    normalized = np.array([0.2, 0.3, 0.5])
+    for log_w in (np.log(normalized * 0.47), np.log(normalized) + 1e6, np.log(normalized) - 1e6):
+        on_device = torch.from_numpy(log_w).to(hip_device)
+        np.testing.assert_allclose(statistics.log_ess(on_device).item(), np.log(1 / np.sum(normalized ** 2)), atol=1e-7)
+        np.testing.assert_allclose(statistics.ess(on_device).item(), 1 / np.sum(normalized ** 2), atol=1e-7)
+
+
+# ---- test/test_losses.py -------------------------------------------------------------------------
+def test_losses_gaussian_autoencoder_learns(hip_device):
+    """TestModels :: test_gaussian — IWAE training of the Gaussian model from the reference's
+    initial values (shortened: the reference only plots; here the parameters must move towards the
+    closed-form optimum)."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    true_prior, true_likelihood = models.GaussianPrior(0.0, 1.0).to(hip_device), models.GaussianLikelihood(1.0).to(hip_device)
+    prior = models.GaussianPrior(2.0, 1.0).to(hip_device)
+    likelihood = models.GaussianLikelihood(0.5).to(hip_device)
+    network = models.GaussianInferenceNetwork(2.0, 2.0, 2.0).to(hip_device)
+    start = [p.detach().clone() for p in itertools.chain(prior.parameters(), likelihood.parameters(), network.parameters())]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        train.train(train.get_synthetic_dataloader(true_prior, None, true_likelihood, 1, 10), 2, "iwae", prior, None,
+                    likelihood, network, num_epochs=1, num_iterations_per_epoch=400,
+                    optimizer_algorithm=torch.optim.SGD, optimizer_kwargs={"lr": 0.01})
+    end = list(itertools.chain(prior.parameters(), likelihood.parameters(), network.parameters()))
+    assert all(torch.isfinite(p).all() for p in end)
+    assert abs(float(prior.mean.detach())) < 2.0 - 0.3                      # prior mean: 2 -> towards 0
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(start, end))
+
+
+@pytest.mark.parametrize("algorithm", ["iwae", "aesmc"])
+def test_losses_lgssm_autoencoder_learns(hip_device, algorithm):
+    """TestModels :: test_lgssm — both objectives on the reference's 1-D LGSSM with its optimal
+    proposal scales (shortened to 60 iterations of T = 20): transition and emission multipliers
+    leave 0."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    emission_scale = 0.1
+    optimal = float(np.sqrt(1 - 1 / (emission_scale ** 2 + 1)))
+    on_device = lambda v: torch.tensor(v, device=hip_device)     # the generative model lives on the GPU
+    loader = train.get_synthetic_dataloader(models.Lgssm1dInitial(on_device(0.0), on_device(1.0)),
+                                            models.Lgssm1dTransition(0.9, 1.0).to(hip_device),
+                                            models.Lgssm1dEmission(1.0, emission_scale).to(hip_device), 20, 10)
+    transition = models.Lgssm1dTransition(0.0, 1.0).to(hip_device)
+    emission = models.Lgssm1dEmission(0.0, emission_scale).to(hip_device)
+    seen = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        train.train(loader, 100, algorithm, models.Lgssm1dInitial(on_device(0.0), on_device(1.0)), transition, emission,
+                    models.Lgssm1dProposal(optimal, optimal).to(hip_device), num_epochs=1,
+                    num_iterations_per_epoch=60, callback=lambda e, i, loss, *parts: seen.append(loss.item()))
+    assert len(seen) == 60 and np.isfinite(seen).all()
+    assert np.mean(seen[-10:]) < np.mean(seen[:10])
+    # (the sign of the emission multiplier is not identified: the latent's sign can flip with it)
+    assert abs(float(next(emission.parameters()).detach())) > 0.02
