@@ -267,3 +267,58 @@ def test_losses_lgssm_autoencoder_learns(hip_device, algorithm):
     assert np.mean(seen[-10:]) < np.mean(seen[:10])
     # (the sign of the emission multiplier is not identified: the latent's sign can flip with it)
     assert abs(float(next(emission.parameters()).detach())) > 0.02
+
+
+def test_infer_against_a_kalman_filter(hip_device):
+    """TestInfer (setUpClass + test_smc / test_importance_sampling): the reference fits a random-walk
+    model to 40 (sin x + 0.2 noise) with pykalman and only PLOTS particle estimates against the
+    Kalman smoother.  Here (no pykalman): fixed random-walk parameters, a closed-form scalar Kalman
+    filter written out below, the same observation container (ONE tensor [T, 1], batch size 1) and
+    a bootstrap proposal as in the reference's Proposal class; the SMC filtering mean / variance at
+    the last step and log Z must agree with the filter, and importance sampling must run."""
+    T, K = 100, 1000
+    rng = np.random.RandomState(0)
+    grid = np.linspace(0, 3 * np.pi, T)
+    y = 40 * (np.sin(grid) + 0.2 * rng.randn(T))
+    m0, p0, q, r = 0.0, 100.0, 25.0, 64.0          # x_0 ~ N(m0, p0), x_t = x_{t-1} + N(0, q), y_t = x_t + N(0, r)
+    mean, var, loglik = m0, p0, 0.0
+    for t in range(T):                               # scalar Kalman filter
+        if t > 0:
+            var = var + q
+        s = var + r
+        loglik += -0.5 * (np.log(2 * np.pi * s) + (y[t] - mean) ** 2 / s)
+        gain = var / s
+        mean, var = mean + gain * (y[t] - mean), (1 - gain) * var
+    dev_t = lambda v: torch.tensor(v, device=hip_device, dtype=torch.float32)
+    full = Modes.FULLY_EXPANDED
+
+    def initial():
+        return torch.distributions.Normal(dev_t(m0), dev_t(np.sqrt(p0)))
+
+    def transition(previous_latents=None, time=None, previous_observations=None):
+        return state.set_batch_shape_mode(torch.distributions.Normal(previous_latents[-1], dev_t(np.sqrt(q))), full)
+
+    def emission(latents=None, time=None, previous_observations=None):
+        return state.set_batch_shape_mode(torch.distributions.Normal(latents[-1], dev_t(np.sqrt(r))), full)
+
+    def proposal(previous_latents=None, time=None, observations=None):
+        if time == 0:
+            return state.set_batch_shape_mode(torch.distributions.Normal(dev_t(m0), dev_t(np.sqrt(p0))), Modes.NOT_EXPANDED)
+        return transition(previous_latents=previous_latents)
+
+    observations = torch.from_numpy(y).unsqueeze(-1).float().to(hip_device)      # [T, 1]: time first, batch of one
+    torch.manual_seed(1)
+    np.random.seed(1)
+    smc = inference.infer("smc", observations, initial, transition, emission, proposal, K,
+                          return_log_marginal_likelihood=True)
+    assert len(smc["latents"]) == T and smc["latents"][0].shape == (1, K)
+    got_mean = statistics.empirical_mean(smc["latents"][-1], smc["log_weight"])[0].item()
+    got_var = statistics.empirical_variance(smc["latents"][-1], smc["log_weight"])[0].item()
+    ess = statistics.ess(smc["log_weight"])[0].item()
+    assert abs(got_mean - mean) < 5 * np.sqrt(var / ess) + 0.5, (got_mean, mean, ess)
+    assert 0.5 * var < got_var < 1.6 * var, (got_var, var)
+    assert abs(smc["log_marginal_likelihood"][0].item() - loglik) < 3.0, (smc["log_marginal_likelihood"], loglik)
+    imp = inference.infer("is", observations, initial, transition, emission, proposal, K,
+                          return_log_marginal_likelihood=True)
+    assert len(imp["latents"]) == T and bool(torch.isfinite(imp["log_marginal_likelihood"]).all())
+    assert imp["log_marginal_likelihood"][0].item() < loglik + 3.0      # IS over 100 steps: a (very) loose lower estimate
