@@ -822,3 +822,39 @@ def test_hip_equals_c_oracle_at_full_size(kernels, hip_device, B, K, d):
     for x, line, have in zip(latents, c_oracle.lineage(steps), got):
         np.testing.assert_array_equal(have.cpu().numpy(), c_oracle.gather(x, line)[0])
     assert kernels.read_flags(hip_device) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("B,K,dx,dy", [(3, 50, 4, 4), (2, 16, 1, 1), (2, 257, 10, 3), (1, 33, 128, 128)])
+def test_normal_logweight_backward_is_bitwise_the_three_launch_route(hip_device, dtype, B, K, dx, dy):
+    """Scales without gradients (buffers): K5's backward is ONE launch and must give, bit for bit, what
+    three K4 backward launches and the eager add of the two x-gradients give — also for broadcast
+    (BATCH_EXPANDED / NOT_EXPANDED) locations, whose gradients autograd's expand-backward reduces."""
+    from aesmc_amd import _ops
+    gen = torch.Generator(device=hip_device).manual_seed(B * K + dx)
+    rand = lambda *shape: torch.randn(*shape, device=hip_device, dtype=dtype, generator=gen)
+    scales = [torch.tensor(v, device=hip_device, dtype=dtype) for v in (1.0, 0.5, 0.7)]
+    weights = rand(B, K)
+    layouts = [
+        dict(x=rand(B, K, dx), loc_p=rand(B, K, dx), y=rand(B, dy), loc_g=rand(B, K, dy), loc_q=rand(B, K, dx)),
+        dict(x=rand(B, K, dx), loc_p=rand(dx), y=rand(B, dy), loc_g=rand(B, K, dy), loc_q=rand(B, dx)),
+    ]
+    for lay in layouts:
+        def run(fused):
+            leaves = {name: t.clone().requires_grad_() for name, t in lay.items()}
+            x, y = leaves["x"], leaves["y"].unsqueeze(1).expand(B, K, dy)
+            loc_p = leaves["loc_p"].expand(B, K, dx)
+            loc_q = leaves["loc_q"].unsqueeze(1).expand(B, K, dx) if leaves["loc_q"].dim() == 2 else leaves["loc_q"]
+            sp, sg, sq = scales[0].expand(B, K, dx), scales[1].expand(B, K, dy), scales[2].expand(B, K, dx)
+            if fused:
+                lw = _ops.normal_log_weight(x, loc_p, sp, y, leaves["loc_g"], sg, loc_q, sq)
+            else:
+                lw = _ops.logweight_lse(_ops.normal_log_prob_sum(x, loc_p, sp),
+                                        _ops.normal_log_prob_sum(y, leaves["loc_g"], sg),
+                                        _ops.normal_log_prob_sum(x, loc_q, sq))[0]
+            (lw * weights).sum().backward()
+            return lw.detach(), {name: t.grad for name, t in leaves.items()}
+        fused, unfused = run(True), run(False)
+        assert torch.equal(fused[0], unfused[0])
+        for name in lay:
+            assert torch.equal(fused[1][name], unfused[1][name]), name
