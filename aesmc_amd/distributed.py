@@ -80,10 +80,35 @@ class _AllReduceSum(torch.autograd.Function):
         return grad, None
 
 
+class _AllGatherRows(torch.autograd.Function):
+    """The [global_batch] vector of per-row values from every rank's rows (ranks in order); the
+    gradient of a rank's rows is its slice of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, local, global_batch_size, rank, world_size, group):
+        spans = [shard_bounds(global_batch_size, r, world_size) for r in range(world_size)]
+        longest = max(hi - lo for lo, hi in spans)
+        padded = local.detach().new_zeros(longest)
+        padded[:local.numel()] = local.detach()
+        pieces = [torch.empty_like(padded) for _ in range(world_size)]
+        dist.all_gather(pieces, padded, group=group)
+        ctx.span = spans[rank]
+        return torch.cat([piece[:hi - lo] for piece, (lo, hi) in zip(pieces, spans)])
+
+    @staticmethod
+    def backward(ctx, grad):
+        lo, hi = ctx.span
+        return grad[lo:hi], None, None, None, None
+
+
 def sharded_get_loss(local_observations, num_particles, algorithm, initial, transition, emission,
-                     proposal, global_batch_size, rank=None, world_size=None, group=None):
+                     proposal, global_batch_size, rank=None, world_size=None, group=None,
+                     exact_mean=False):
     """`losses.get_loss` for a batch sharded over the process group: each rank runs `infer` on its
-    rows, then ONE all-reduce of the local sum of log Z_b yields -mean over the global batch."""
+    rows, then ONE all-reduce of the local sum of log Z_b yields -mean over the global batch.
+    `exact_mean=True` all-gathers the [global_batch] vector of log Z_b instead and takes
+    `-torch.mean` of it, which reproduces the unsharded loss to the last bit (the all-reduced sum
+    can differ from it in the final place)."""
     rank = dist.get_rank(group) if rank is None else rank
     world_size = dist.get_world_size(group) if world_size is None else world_size
     with shard_scope(global_batch_size, rank, world_size):
@@ -91,6 +116,10 @@ def sharded_get_loss(local_observations, num_particles, algorithm, initial, tran
             {"iwae": "is", "aesmc": "smc"}[algorithm], local_observations, initial, transition,
             emission, proposal, num_particles, return_log_marginal_likelihood=True,
             return_latents=False, return_log_weight=False)
+    if exact_mean and _group_is_live():
+        everyone = _AllGatherRows.apply(result["log_marginal_likelihood"], global_batch_size, rank,
+                                        world_size, group)
+        return -torch.mean(everyone)
     local_sum = result["log_marginal_likelihood"].sum()
     total = _AllReduceSum.apply(local_sum, group) if _group_is_live() else local_sum
     return -total / global_batch_size

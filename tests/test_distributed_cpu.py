@@ -60,10 +60,18 @@ def _run_rank(rank, world, port, out_dir):
             loss = distributed.sharded_get_loss(local_obs, K, "aesmc", *parts, global_batch_size=B)
         loss.backward()
         distributed.all_reduce_gradients(list(model.parameters()))
+        with replay.replay(_slice_tape(tape, lo, hi)):
+            exact = distributed.sharded_get_loss(local_obs, K, "aesmc", *parts, global_batch_size=B,
+                                                 exact_mean=True)
+        exact_grads = torch.autograd.grad(exact, list(model.parameters()))
+        exact_grads = [g.clone() for g in exact_grads]
+        for g in exact_grads:
+            dist.all_reduce(g)
         with replay.replay(_slice_tape(tape, lo, hi)), distributed.shard_scope(B, rank, world):
             result = inference.infer("smc", local_obs, *parts, K, return_ancestral_indices=True,
                                      return_latents=False)
         torch.save({"loss": loss.detach(), "grads": [p.grad.clone() for p in model.parameters()],
+                    "exact_loss": exact.detach(), "exact_grads": exact_grads,
                     "indices": result["ancestral_indices"], "rows": (lo, hi)},
                    os.path.join(out_dir, "rank{}.pt".format(rank)))
     finally:
@@ -93,6 +101,9 @@ def test_two_rank_batch_shard_matches_single_process(tmp_path, oracle_backend):
     assert shards[0]["rows"] == (0, 3) and shards[1]["rows"] == (3, 6)
     for shard in shards:
         torch.testing.assert_close(shard["loss"], loss.detach(), rtol=1e-12, atol=1e-12)
+        assert torch.equal(shard["exact_loss"], loss.detach())       # all-gather + torch.mean: to the last bit
+        for got, want in zip(shard["exact_grads"], [p.grad for p in model.parameters()]):
+            torch.testing.assert_close(got, want, rtol=1e-10, atol=1e-12)
         lo, hi = shard["rows"]
         for got, want in zip(shard["indices"], full["ancestral_indices"]):
             assert torch.equal(got, want[lo:hi])
