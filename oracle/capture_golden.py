@@ -260,8 +260,43 @@ def case_train(name, algorithm, seed=9):
     print("{:32s} losses={}".format(name, np.round(losses, 5)))
 
 
+def case_api_signatures():
+    """The reference's public surface as data: for every public function / class of its six
+    modules, the parameter names, which of them have defaults, and the defaults that are plain
+    constants.  tests/test_host_logic.py holds this package's modules against it."""
+    import inspect
+    import aesmc
+    table = {}
+    for module_name in ("inference", "losses", "math", "state", "statistics", "train"):
+        module = getattr(aesmc, module_name)
+        for name, member in sorted(vars(module).items()):
+            if name.startswith("_") or getattr(member, "__module__", None) != module.__name__:
+                continue
+            if inspect.isclass(member) and not issubclass(member, __import__("enum").Enum):
+                target = member.__init__
+            elif inspect.isfunction(member):
+                target = member
+            elif inspect.isclass(member):
+                table["{}.{}".format(module_name, name)] = {"enum": sorted(m.name for m in member)}
+                continue
+            else:
+                continue
+            params = []
+            for p in inspect.signature(target).parameters.values():
+                default = None
+                if p.default is not inspect.Parameter.empty:
+                    default = repr(p.default) if isinstance(p.default, (bool, int, float, str, type(None), dict)) \
+                        else "<object>"
+                params.append([p.name, default])
+            table["{}.{}".format(module_name, name)] = {"params": params}
+    with open(os.path.join(GOLDEN, "api_signatures.json"), "w") as fh:
+        json.dump(table, fh, indent=1, sort_keys=True)
+    print("api_signatures.json: {} entries".format(len(table)))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
+    case_api_signatures()
     f32, f64 = torch.float32, torch.float64
     # config 1 of BASELINE.json: reference's 1-D LGSSM, B=2, K=16, T=8
     case_lgssm1d("c1_lgssm1d_smc_f32", "aesmc", 1.0, f32)

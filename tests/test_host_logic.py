@@ -435,3 +435,37 @@ def test_package_surface():
     for name in ("inference", "losses", "math", "state", "statistics", "train"):
         assert hasattr(aesmc_amd, name)
     assert aesmc_amd.__version__ == "0.1.0"
+
+
+def test_public_surface_matches_the_reference_signature_table():
+    """tests/golden/api_signatures.json (oracle/capture_golden.py: inspect.signature over the
+    reference's six modules): every public function / class exists here under the same name with
+    the same parameters in the same order, the same set of defaulted parameters and the same
+    constant defaults; this package may only ADD trailing parameters that have defaults."""
+    import enum
+    import inspect
+    import json
+    import os
+    import aesmc_amd
+    from tests.golden_io import GOLDEN_DIR
+    with open(os.path.join(GOLDEN_DIR, "api_signatures.json")) as fh:
+        table = json.load(fh)
+    assert len(table) >= 20
+    for qualified, entry in table.items():
+        module_name, name = qualified.split(".")
+        member = getattr(getattr(aesmc_amd, module_name), name)
+        if "enum" in entry:
+            assert issubclass(member, enum.Enum) and sorted(m.name for m in member) == entry["enum"], qualified
+            continue
+        target = member.__init__ if inspect.isclass(member) else member
+        mine = list(inspect.signature(target).parameters.values())
+        want = entry["params"]
+        assert [p.name for p in mine[:len(want)]] == [n for n, _ in want], qualified
+        for p, (_, default) in zip(mine, want):
+            if default is None:
+                assert p.default is inspect.Parameter.empty, (qualified, p.name)
+            elif default != "<object>":
+                assert repr(p.default) == default, (qualified, p.name, p.default, default)
+            else:
+                assert p.default is not inspect.Parameter.empty, (qualified, p.name)
+        assert all(p.default is not inspect.Parameter.empty for p in mine[len(want):]), qualified
