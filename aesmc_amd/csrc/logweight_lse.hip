@@ -17,7 +17,7 @@ constexpr int kBlock = 256;
 template <typename T, int TPR, bool VEC>
 __global__ __launch_bounds__(kBlock) void logweight_lse_kernel(
     const T *__restrict__ a, const T *__restrict__ b, const T *__restrict__ c, T *out_lw,
-    T *__restrict__ out_lse, int64_t B, int64_t K) {
+    T *__restrict__ out_lse, int64_t B, int64_t K, int stream) {
   constexpr int ROWS = kBlock / TPR;
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void logweight_lse_kernel(
           for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + (int64_t)u * TPR;
             if (i < nvec) {
-              const V y = bv[i];
+              const V y = load16(bv + i, stream);
               x[u].x += y.x;
               x[u].y += y.y;
               if constexpr (N == 4) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void logweight_lse_kernel(
           for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + (int64_t)u * TPR;
             if (i < nvec) {
-              const V y = cv[i];
+              const V y = load16(cv + i, stream);
               x[u].x -= y.x;
               x[u].y -= y.y;
               if constexpr (N == 4) {
@@ -211,16 +211,18 @@ static int launch_fwd(const void *a, const void *b, const void *c, void *lw, voi
   auto C = (const T *)c;
   auto L = (T *)lw;
   auto S = (T *)lse;
+  const int stream = stream_hint((uint64_t)B * (uint64_t)K * sizeof(T) *
+                                 (1 + (b != nullptr) + (c != nullptr) + (lw != nullptr)));
   if (wide) {
     if (vec)
-      hipLaunchKernelGGL((logweight_lse_kernel<T, 256, true>), grid, block, 0, s, A, Bp, C, L, S, B, K);
+      hipLaunchKernelGGL((logweight_lse_kernel<T, 256, true>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream);
     else
-      hipLaunchKernelGGL((logweight_lse_kernel<T, 256, false>), grid, block, 0, s, A, Bp, C, L, S, B, K);
+      hipLaunchKernelGGL((logweight_lse_kernel<T, 256, false>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream);
   } else {
     if (vec)
-      hipLaunchKernelGGL((logweight_lse_kernel<T, 64, true>), grid, block, 0, s, A, Bp, C, L, S, B, K);
+      hipLaunchKernelGGL((logweight_lse_kernel<T, 64, true>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream);
     else
-      hipLaunchKernelGGL((logweight_lse_kernel<T, 64, false>), grid, block, 0, s, A, Bp, C, L, S, B, K);
+      hipLaunchKernelGGL((logweight_lse_kernel<T, 64, false>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream);
   }
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }

@@ -15,7 +15,6 @@
 // loc [B,D] (BATCH_EXPANDED), loc [B,K,D] (FULLY_EXPANDED), value = observation expanded over K,
 // the transposed time-0 latent, scalar scales.
 #include "common.hpp"
-
 namespace aesmc {
 
 struct Strides3 {
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_lps_tile_vec_kernel(
 template <typename T, int TPR>
 __global__ __launch_bounds__(kLpBlock) void normal_lps_row_vec_kernel(
     const T *__restrict__ value, const T *__restrict__ loc, const T *__restrict__ scale,
-    T *__restrict__ out, int64_t particles, uint32_t K, uint32_t D, Strides3 sv, Strides3 sm) {
+    T *__restrict__ out, int64_t particles, uint32_t K, uint32_t D, Strides3 sv, Strides3 sm, int stream) {
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const int64_t p = (int64_t)blockIdx.x * (kLpBlock / TPR) + threadIdx.x / TPR;
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_lps_row_vec_kernel(
     const T two_var = T(2) * (sigma * sigma);
     const T log_sigma = Num<T>::log(sigma);
     for (uint32_t v = t; v < D / N; v += TPR) {
-      const V x = vp[v], m = mp[v];
+      const V x = vp[v], m = load16(mp + v, stream);
 #pragma unroll
       for (int q = 0; q < N; ++q) {
         const T diff = Vec16<T>::get(x, q) - Vec16<T>::get(m, q);
@@ -281,15 +280,16 @@ static int launch_lps(const void *value, const void *loc, const void *scale, voi
     const int64_t blocks = (particles + (kLpBlock / tpr) - 1) / (kLpBlock / tpr);
     if (blocks > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
     dim3 grid((unsigned)blocks), block(kLpBlock);
+    const int stream = stream_hint((uint64_t)particles * D * sizeof(T) * 2);
     auto X = (const T *)value;
     auto M = (const T *)loc;
     auto S = (const T *)scale;
     if (tpr == 16)
-      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 16>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm);
+      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 16>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm, stream);
     else if (tpr == 32)
-      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 32>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm);
+      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 32>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm, stream);
     else
-      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 64>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm);
+      hipLaunchKernelGGL((normal_lps_row_vec_kernel<T, 64>), grid, block, 0, s, X, M, S, (T *)out, particles, (uint32_t)K, (uint32_t)D, sv, sm, stream);
     return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
   }
   if (D <= 64 && is_scalar(ss) && (vdense || ldense)) {
@@ -370,7 +370,7 @@ template <typename T, int STATIC_MASK>
 __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
     View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
     T *__restrict__ out, uint32_t K, uint32_t Dx, uint32_t Dy, uint32_t P, uint32_t tiles_per_row,
-    uint32_t dense_arg) {
+    uint32_t dense_arg, int stream) {
   const uint32_t dense = STATIC_MASK >= 0 ? (uint32_t)STATIC_MASK : dense_arg;
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
@@ -400,10 +400,10 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
       if (dense & 1u) { const V t = *reinterpret_cast<const V *>(xt + e);
 #pragma unroll
         for (int r = 0; r < N; ++r) xv[r] = Vec16<T>::get(t, r); }
-      if (dense & 2u) { const V t = *reinterpret_cast<const V *>(pt + e);
+      if (dense & 2u) { const V t = load16(reinterpret_cast<const V *>(pt + e), stream);
 #pragma unroll
         for (int r = 0; r < N; ++r) pv[r] = Vec16<T>::get(t, r); }
-      if (dense & 4u) { const V t = *reinterpret_cast<const V *>(qt + e);
+      if (dense & 4u) { const V t = load16(reinterpret_cast<const V *>(qt + e), stream);
 #pragma unroll
         for (int r = 0; r < N; ++r) qv[r] = Vec16<T>::get(t, r); }
       if ((dense & 7u) != 7u) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
       if (dense & 8u) { const V t = *reinterpret_cast<const V *>(yt + e);
 #pragma unroll
         for (int r = 0; r < N; ++r) yv[r] = Vec16<T>::get(t, r); }
-      if (dense & 16u) { const V t = *reinterpret_cast<const V *>(gt + e);
+      if (dense & 16u) { const V t = load16(reinterpret_cast<const V *>(gt + e), stream);
 #pragma unroll
         for (int r = 0; r < N; ++r) gv[r] = Vec16<T>::get(t, r); }
       if ((dense & 24u) != 24u) {
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_d1_kernel(
 template <typename T, int TPR>
 __global__ __launch_bounds__(kLpBlock) void normal_logweight_row_kernel(
     View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
-    T *__restrict__ out, int64_t particles, uint32_t K, uint32_t Dx, uint32_t Dy) {
+    T *__restrict__ out, int64_t particles, uint32_t K, uint32_t Dx, uint32_t Dy, int stream) {
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const int64_t p = (int64_t)blockIdx.x * (kLpBlock / TPR) + threadIdx.x / TPR;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_row_kernel(
     const T two_var_q = T(2) * (s_q * s_q), log_q = Num<T>::log(s_q);
     const T half_log_2pi = NormConst<T>::half_log_2pi();
     for (uint32_t v = t; v < Dx / N; v += TPR) {
-      const V xv = xp[v], pv = pp[v], qv = qp[v];
+      const V xv = xp[v], pv = load16(pp + v, stream), qv = load16(qp + v, stream);
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const T dp = Vec16<T>::get(xv, r) - Vec16<T>::get(pv, r);
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_row_kernel(
       }
     }
     for (uint32_t v = t; v < Dy / N; v += TPR) {
-      const V yv = yp[v], gv = gp[v];
+      const V yv = yp[v], gv = load16(gp + v, stream);
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const T dg = Vec16<T>::get(yv, r) - Vec16<T>::get(gv, r);
@@ -628,9 +628,10 @@ static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int
     const int64_t blocks = (particles + (kLpBlock / tpr) - 1) / (kLpBlock / tpr);
     if (blocks > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
     dim3 grid((unsigned)blocks), block(kLpBlock);
+    const int stream = stream_hint((uint64_t)particles * (3 * Dx + Dy) * sizeof(T));
 #define AESMC_ROW_CASE(team)                                                                            \
     hipLaunchKernelGGL((normal_logweight_row_kernel<T, team>), grid, block, 0, s, v[0], v[1], v[2], v[3],  \
-                       v[4], v[5], v[6], v[7], (T *)out, particles, (uint32_t)K, (uint32_t)Dx, (uint32_t)Dy)
+                       v[4], v[5], v[6], v[7], (T *)out, particles, (uint32_t)K, (uint32_t)Dx, (uint32_t)Dy, stream)
     if (tpr == 16) AESMC_ROW_CASE(16);
     else if (tpr == 32) AESMC_ROW_CASE(32);
     else AESMC_ROW_CASE(64);
@@ -659,14 +660,15 @@ static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int
   if (dense(v[4], Dy)) mask |= 16u;
   const uint32_t ex = P * (uint32_t)Dx, ey = P * (uint32_t)Dy;
   const size_t lds = (size_t)(2 * (ex + (ex >> 5) + 1) + ey + (ey >> 5) + 1) * sizeof(T);
+  const int stream = stream_hint((uint64_t)B * K * (3 * Dx + Dy) * sizeof(T));
   if (mask == 23u)
     hipLaunchKernelGGL((normal_logweight_kernel<T, 23>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
                        v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
-                       (uint32_t)Dy, P, tiles, mask);
+                       (uint32_t)Dy, P, tiles, mask, stream);
   else
     hipLaunchKernelGGL((normal_logweight_kernel<T, -1>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
                        v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
-                       (uint32_t)Dy, P, tiles, mask);
+                       (uint32_t)Dy, P, tiles, mask, stream);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 

@@ -32,13 +32,13 @@ template <typename T> struct alignas(16) Pack16 {
 template <typename T>
 __global__ __launch_bounds__(kRsBlock) void normal_rsample_dense_kernel(
     const T *__restrict__ eps, const T *__restrict__ loc, const T *__restrict__ scale,
-    T *__restrict__ out, uint64_t n, uint32_t D, uint32_t scale_stride_d) {
+    T *__restrict__ out, uint64_t n, uint32_t D, uint32_t scale_stride_d, int stream) {
   constexpr uint32_t V = Vec16<T>::N;
   const uint64_t first = ((uint64_t)blockIdx.x * kRsBlock + threadIdx.x) * V;
   if (first >= n) return;
   if (first + V <= n) {
-    const Pack16<T> e = *reinterpret_cast<const Pack16<T> *>(eps + first);
-    const Pack16<T> m = *reinterpret_cast<const Pack16<T> *>(loc + first);
+    const Pack16<T> e = load16(reinterpret_cast<const Pack16<T> *>(eps + first), stream);   // read once
+    const Pack16<T> m = *reinterpret_cast<const Pack16<T> *>(loc + first);                // K5 reads it again
     Pack16<T> r;
     uint32_t j = (uint32_t)(first % D);
 #pragma unroll
@@ -145,7 +145,7 @@ static int launch_rsample(const aesmc_view3 &eps_view, const aesmc_view3 &loc, c
     if (blocks >= (1ull << 31)) return AESMC_ERR_UNSUPPORTED;
     const uint32_t sd = (D == 1) ? 0u : (uint32_t)scale.stride_d;
     hipLaunchKernelGGL(normal_rsample_dense_kernel<T>, dim3((uint32_t)blocks), dim3(kRsBlock), 0, stream,
-                       e, m, s, o, n, (uint32_t)D, sd);
+                       e, m, s, o, n, (uint32_t)D, sd, stream_hint(3 * n * sizeof(T)));
   } else {
     const uint64_t blocks = (n + kRsBlock - 1) / kRsBlock;
     if (blocks >= (1ull << 31)) return AESMC_ERR_UNSUPPORTED;
