@@ -858,3 +858,75 @@ def test_normal_logweight_backward_is_bitwise_the_three_launch_route(hip_device,
         assert torch.equal(fused[0], unfused[0])
         for name in lay:
             assert torch.equal(fused[1][name], unfused[1][name]), name
+
+
+def test_fused_normal_ops_on_random_views_match_eager_torch(hip_device):
+    """Fuzz: state.log_prob (K4), state.normal_log_weight (K5) and state.sample (K6) on randomly
+    shaped, sliced, transposed and broadcast operands against the eager PyTorch expressions
+    (set_fused_normal(False)), values and gradients."""
+    from aesmc_amd import state
+    rng = np.random.RandomState(2024)
+    gen = torch.Generator(device=hip_device).manual_seed(7)
+    Normal = torch.distributions.Normal
+
+    def random_view(shape, dtype):
+        """A tensor of `shape` that may be a slice / transpose of a larger buffer (never a copy)."""
+        kind = rng.randint(4)
+        full = list(shape)
+        if kind == 1 and len(shape) >= 2:          # every other particle
+            full[1] *= 2
+            return torch.randn(*full, device=hip_device, dtype=dtype, generator=gen)[:, ::2]
+        if kind == 2 and len(shape) >= 3:          # a window of a wider last dim
+            full[-1] += 3
+            return torch.randn(*full, device=hip_device, dtype=dtype, generator=gen)[..., 1:1 + shape[-1]]
+        if kind == 3 and len(shape) >= 2:          # transposed leading dims
+            full[0], full[1] = full[1], full[0]
+            return torch.randn(*full, device=hip_device, dtype=dtype, generator=gen).transpose(0, 1)
+        return torch.randn(*shape, device=hip_device, dtype=dtype, generator=gen)
+
+    for case in range(40):
+        dtype = [torch.float32, torch.float64][case % 2]
+        B, K = int(rng.randint(1, 6)), int(rng.randint(1, 70))
+        tail = [(), (1,), (3,), (10,), (2, 3), (70,)][rng.randint(6)]
+        shape = (B, K) + tail
+        loc_shapes = [shape, (B,) + tail, tail]                       # FULLY / BATCH / NOT expanded
+        modes = [state.BatchShapeMode.FULLY_EXPANDED, state.BatchShapeMode.BATCH_EXPANDED,
+                 state.BatchShapeMode.NOT_EXPANDED]
+        which = rng.randint(3, size=3)
+        scale = [torch.tensor(float(rng.uniform(0.3, 2.0)), device=hip_device, dtype=dtype) for _ in range(3)]
+        base = dict(x=random_view(shape, dtype), y=random_view((B,) + tail, dtype),
+                    **{"loc%d" % i: random_view(loc_shapes[which[i]], dtype) if loc_shapes[which[i]] else
+                       torch.randn((), device=hip_device, dtype=dtype, generator=gen) for i in range(3)})
+        weights = torch.randn(B, K, device=hip_device, dtype=dtype, generator=gen)
+
+        def run(fused):
+            state.set_fused_normal(fused)
+            try:
+                leaves = {name: t.detach().clone().requires_grad_() if False else t.detach().requires_grad_()
+                          for name, t in base.items()}
+                dists = [state.set_batch_shape_mode(Normal(leaves["loc%d" % i], scale[i], validate_args=False),
+                                                    modes[which[i]]) for i in range(3)]
+                obs = state.expand_observation(leaves["y"], K)
+                lw = None
+                if fused:
+                    lw = state.normal_log_weight(dists[0], dists[2], leaves["x"], dists[1], obs)
+                if lw is None:
+                    lw = state.log_prob(dists[0], leaves["x"]) + state.log_prob(dists[1], obs) \
+                        - state.log_prob(dists[2], leaves["x"])
+                torch.manual_seed(case)
+                draw = state.sample(dists[2], B, K)
+                total = (lw * weights).sum() + (draw * draw.detach().cos()).sum()
+                grads = torch.autograd.grad(total, list(leaves.values()), allow_unused=True)
+                return lw.detach(), draw.detach(), grads
+            finally:
+                state.set_fused_normal(True)
+
+        fused, eager = run(True), run(False)
+        rtol, atol = (2e-5, 2e-4) if dtype == torch.float32 else (1e-11, 1e-10)
+        torch.testing.assert_close(fused[0], eager[0], rtol=rtol, atol=atol, msg=str((case, shape, which)))
+        assert torch.equal(fused[1], eager[1]), (case, shape, which)           # the draw: bit for bit
+        for name, a, b in zip(base, fused[2], eager[2]):
+            if a is None or b is None:
+                assert a is None and b is None, (case, name)
+                continue
+            torch.testing.assert_close(a, b, rtol=rtol * 10, atol=atol * 10, msg=str((case, name, shape, which)))
