@@ -384,6 +384,49 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
   const uint32_t np = min(P, K - k0);
   const T half_log_2pi = NormConst<T>::half_log_2pi();
 
+  // The t > 0 layout of a Markov model with equal extents (x, mu_p, mu_q, mu_g dense, y broadcast):
+  // ONE sweep issues all four 16-byte loads of a vector slot before any arithmetic, instead of the
+  // x-terms' sweep followed by the emission term's (whose loads could only start after the first
+  // sweep's had landed).  Same element arithmetic, same LDS layout, same sums.
+  if (STATIC_MASK == 23 && Dx == Dy && (np * Dx) % N == 0) {
+    const T s_p = reinterpret_cast<const T *>(sc_p.ptr)[0], s_q = reinterpret_cast<const T *>(sc_q.ptr)[0],
+            s_g = reinterpret_cast<const T *>(sc_g.ptr)[0];
+    const T two_var_p = T(2) * (s_p * s_p), log_p = Num<T>::log(s_p);
+    const T two_var_q = T(2) * (s_q * s_q), log_q = Num<T>::log(s_q);
+    const T two_var_g = T(2) * (s_g * s_g), log_g = Num<T>::log(s_g);
+    const uint32_t ne = np * Dx, nvec = ne / N;
+    const T *xt = reinterpret_cast<const T *>(x.ptr) + (int64_t)b * x.st.b + (int64_t)k0 * x.st.k;
+    const T *pt = reinterpret_cast<const T *>(mu_p.ptr) + (int64_t)b * mu_p.st.b + (int64_t)k0 * mu_p.st.k;
+    const T *qt = reinterpret_cast<const T *>(mu_q.ptr) + (int64_t)b * mu_q.st.b + (int64_t)k0 * mu_q.st.k;
+    const T *gt = reinterpret_cast<const T *>(mu_g.ptr) + (int64_t)b * mu_g.st.b + (int64_t)k0 * mu_g.st.k;
+    uint32_t e = threadIdx.x * N;
+    uint32_t kk = e / Dx, j = e - kk * Dx;
+    const uint32_t step = kLpBlock * N, dk = step / Dx, dj = step - dk * Dx;
+    for (uint32_t v = threadIdx.x; v < nvec; v += kLpBlock) {
+      const V tx = *reinterpret_cast<const V *>(xt + e);
+      const V tp = load16(reinterpret_cast<const V *>(pt + e), stream);
+      const V tq = load16(reinterpret_cast<const V *>(qt + e), stream);
+      const V tg = load16(reinterpret_cast<const V *>(gt + e), stream);
+      T yv[N];
+      uint32_t k2 = kk, j2 = j;
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        yv[r] = load_view<T>(y, b, (int64_t)k0 + k2, j2);
+        if (++j2 == Dx) { j2 = 0; ++k2; }
+      }
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const T xr = Vec16<T>::get(tx, r);
+        const T dp = xr - Vec16<T>::get(tp, r), dq = xr - Vec16<T>::get(tq, r);
+        const T dg = yv[r] - Vec16<T>::get(tg, r);
+        term_p[pad_index(e + r)] = (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
+        term_q[pad_index(e + r)] = (-(dq * dq)) / two_var_q - log_q - half_log_2pi;
+        term_g[pad_index(e + r)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
+      }
+      e += step; kk += dk; j += dj;
+      if (j >= Dx) { j -= Dx; ++kk; }
+    }
+  } else {
   {  // ---- the two terms in x ---------------------------------------------------------------------
     const T s_p = reinterpret_cast<const T *>(sc_p.ptr)[0], s_q = reinterpret_cast<const T *>(sc_q.ptr)[0];
     const T two_var_p = T(2) * (s_p * s_p), log_p = Num<T>::log(s_p);
@@ -476,6 +519,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
       const T dg = load_view<T>(y, b, k, j2) - load_view<T>(mu_g, b, k, j2);
       term_g[pad_index(t)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
     }
+  }
   }
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < np; p += kLpBlock) {
