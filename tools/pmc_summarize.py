@@ -45,6 +45,17 @@ def main(fetch_csv, write_csv, out_json):
             w = mean(step_write[sbase + off:sbase + off + 3]) * w_corr
             entry[label] = {"fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w}
         entry["resample_step_bytes_per_launch"] = entry["step_workload_s1"]["hbm_bytes"]
+        # K5 / K6: 3 launches each per shape, streaming kernels (same correction factors)
+        for key, kernel, algorithmic in (
+                ("normal_logweight", "normal_logweight_kernel", B * K * (4 * d + 1) * 4 + B * d * 4),
+                ("normal_rsample", "normal_rsample_dense_kernel", B * K * d * 4 * 3)):
+            f_all = per_launch(fetch_csv, "FETCH_SIZE", kernel)
+            w_all = per_launch(write_csv, "WRITE_SIZE", kernel)
+            if len(f_all) >= 3 * (s + 1) and len(w_all) >= 3 * (s + 1):
+                f = mean(f_all[3 * s:3 * s + 3]) * f_corr
+                w = mean(w_all[3 * s:3 * s + 3]) * w_corr
+                entry[key] = {"algorithmic_bytes": algorithmic, "fetch_bytes": f, "write_bytes": w,
+                              "hbm_bytes": f + w}
         result[name] = entry
     json.dump(result, open(out_json, "w"), indent=1)
     print(json.dumps(result, indent=1))
