@@ -100,6 +100,29 @@ __global__ __launch_bounds__(kRsBlock) void normal_rsample_transposed_kernel(
   }
 }
 
+// One value per particle (the scalar IWAE model: 134 MB of noise at B=4096 K=8192): the classic
+// 64 x 64 transpose — lane x walks b on the way in and k on the way out, four rows per trip, no
+// index divisions.  For B and K multiples of 64; other shapes take the general kernel above.
+template <typename T>
+__global__ __launch_bounds__(kRsBlock) void normal_rsample_transposed_d1_kernel(
+    const T *__restrict__ eps, const T *__restrict__ loc, const T *__restrict__ scale,
+    T *__restrict__ out, uint32_t B, uint32_t K, RsStrides sm, RsStrides ss) {
+  constexpr uint32_t TILE = 64;
+  __shared__ T park[TILE][TILE + 1];
+  const uint32_t b0 = blockIdx.x * TILE, k0 = blockIdx.y * TILE;
+  const uint32_t tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;     // 256 lanes: 4 rows per trip
+#pragma unroll 4
+  for (uint32_t r = ty; r < TILE; r += kRsBlock / TILE) {
+    const int64_t b = b0 + tx, k = k0 + r;
+    const T noise = eps[(uint64_t)k * B + (uint64_t)b];
+    park[tx][r] = loc[b * sm.b + k * sm.k] + noise * scale[b * ss.b + k * ss.k];
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (uint32_t r = ty; r < TILE; r += kRsBlock / TILE)
+    out[(uint64_t)(b0 + r) * K + k0 + tx] = park[r][tx];
+}
+
 template <typename T>
 static int launch_rsample(const aesmc_view3 &eps_view, const aesmc_view3 &loc, const aesmc_view3 &scale,
                           void *out, int64_t B, int64_t K, int64_t D, hipStream_t stream) {
@@ -121,6 +144,13 @@ static int launch_rsample(const aesmc_view3 &eps_view, const aesmc_view3 &loc, c
           tile = cand;
           break;
         }
+    }
+    if (eps_transposed && D == 1 && B % 64 == 0 && K % 64 == 0 && K / 64 <= 65535) {
+      hipLaunchKernelGGL(normal_rsample_transposed_d1_kernel<T>, dim3((unsigned)(B / 64), (unsigned)(K / 64)),
+                         dim3(kRsBlock), 0, stream, e, m, s, o, (uint32_t)B, (uint32_t)K,
+                         RsStrides{loc.stride_b, loc.stride_k, loc.stride_d},
+                         RsStrides{scale.stride_b, scale.stride_k, scale.stride_d});
+      return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
     }
     if (tile == 0) return AESMC_ERR_UNSUPPORTED;    // the caller materialises eps and comes back
     const dim3 grid((unsigned)((B + tile - 1) / tile), (unsigned)((K + tile - 1) / tile));

@@ -237,8 +237,9 @@ def infer(inference_algorithm, observations, initial, transition, emission,
         if log_weight_t is not None:
             # K5 gave the log-weights only; their row log-sum-exp comes out of the next resampling
             # launch for free — or from K1 when no resampling follows
+            # (importance sampling never needs the per-step value: it normalises the summed weights)
             pending = use_smc and time + 1 < num_timesteps
-            lse_t = None if pending else _ops.row_logsumexp(log_weight_t)
+            lse_t = None if (pending or not use_smc) else _ops.row_logsumexp(log_weight_t)
         else:
             log_q = state.log_prob(proposal_dist, latent)
             log_p = state.log_prob(prior_dist, latent)

@@ -713,6 +713,7 @@ def test_resample_step_strided_payload_and_special_rows(kernels, hip_device):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("K,B,rest", [(1, 1, ()), (16, 4, ()), (33, 70, ()), (257, 129, ()), (8192, 16, ()),
+                                      (64, 64, ()), (128, 192, ()), (512, 64, (1,)),
                                       (33, 70, (3,)), (100, 65, (10,)), (40, 9, (4, 5)), (17, 5, (100,)),
                                       (9, 3, (200,))])
 @pytest.mark.parametrize("loc_kind", ["per_batch", "vector", "scalar"])
