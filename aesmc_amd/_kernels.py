@@ -499,16 +499,13 @@ class HipKernels:
     @staticmethod
     def normal_logweight_covers(x, scale_p, y, scale_g, scale_q):
         """Host-only pre-test of K5's preconditions: HIP float tensors of equal leading shape, at
-        least one value per particle, and scales that are one scalar each (expanded with stride 0).
-        The launch itself may still decline (wide rows that are not whole 16-byte vectors, ...):
-        `normal_logweight` then returns None."""
+        least one value per particle.  The launch itself may still decline (wide rows that are not
+        whole 16-byte vectors, wide rows with tensor scales): `normal_logweight` then returns None."""
         if not (x.is_cuda and y.is_cuda and x.dtype in _DTYPE_TAG and y.dtype == x.dtype):
             return False
         if x.dim() < 2 or y.dim() < 2 or x.shape[:2] != y.shape[:2] or x.device != y.device:
             return False
-        if x.numel() == 0 or y.numel() == 0:
-            return False
-        return all(all(st == 0 for st in scale.stride()) for scale in (scale_p, scale_g, scale_q))
+        return x.numel() != 0 and y.numel() != 0
 
     def normal_logweight(self, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
         """lw = logN(x; loc_p, scale_p) + logN(y; loc_g, scale_g) - logN(x; loc_q, scale_q), each
@@ -521,7 +518,7 @@ class HipKernels:
         _, x2, loc_q, scale_q, sx2, sq, ssq, _ = self._normal_operands(x, loc_q, scale_q)
         if y.dtype != x.dtype or y.device != x.device or y.shape[:2] != x.shape[:2]:
             return None
-        if any(st != (0, 0, 0) for st in (ssp, ssg, ssq)) or Dx < 1 or Dy < 1:
+        if Dx < 1 or Dy < 1:
             return None
         if x2 is not x and x2.data_ptr() != x.data_ptr():    # _view3 had to copy x: keep one copy
             x2, sx2 = x, sx

@@ -649,6 +649,57 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_row_kernel(
   if (t == 0 && p < particles) out[p] = (sum_p + sum_g) - sum_q;
 }
 
+// K5 for any scales (a vector, or the [B,K,D] output of a proposal network): the tile scheme with
+// every operand read through its strides, one element per lane per trip (consecutive lanes read
+// consecutive elements of dense operands), log(sigma) and 2 sigma^2 formed per element exactly as
+// K4 forms them, so each term — and the log-weight — equals the K4 x 3 + K1 route bit for bit.
+template <typename T>
+__global__ __launch_bounds__(kLpBlock) void normal_logweight_general_kernel(
+    View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
+    T *__restrict__ out, uint32_t K, uint32_t Dx, uint32_t Dy, uint32_t P, uint32_t tiles_per_row) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lps_smem[];
+  T *term_p = reinterpret_cast<T *>(lps_smem);
+  const uint32_t span_x = P * Dx + ((P * Dx) >> 5) + 1;
+  T *term_q = term_p + span_x;
+  T *term_g = term_q + span_x;
+  const uint32_t b = blockIdx.x / tiles_per_row;
+  const uint32_t k0 = (blockIdx.x - b * tiles_per_row) * P;
+  const uint32_t np = min(P, K - k0);
+  {
+    const uint32_t ne = np * Dx, dk = kLpBlock / Dx, dj = kLpBlock - dk * Dx;
+    uint32_t kk = threadIdx.x / Dx, j = threadIdx.x - kk * Dx;
+    for (uint32_t e = threadIdx.x; e < ne; e += kLpBlock) {
+      const int64_t k = (int64_t)k0 + kk;
+      const T xv = load_view<T>(x, b, k, j);
+      term_p[pad_index(e)] = normal_logpdf(xv, load_view<T>(mu_p, b, k, j), load_view<T>(sc_p, b, k, j));
+      term_q[pad_index(e)] = normal_logpdf(xv, load_view<T>(mu_q, b, k, j), load_view<T>(sc_q, b, k, j));
+      kk += dk; j += dj;
+      if (j >= Dx) { j -= Dx; ++kk; }
+    }
+  }
+  {
+    const uint32_t ne = np * Dy, dk = kLpBlock / Dy, dj = kLpBlock - dk * Dy;
+    uint32_t kk = threadIdx.x / Dy, j = threadIdx.x - kk * Dy;
+    for (uint32_t e = threadIdx.x; e < ne; e += kLpBlock) {
+      const int64_t k = (int64_t)k0 + kk;
+      term_g[pad_index(e)] = normal_logpdf(load_view<T>(y, b, k, j), load_view<T>(mu_g, b, k, j),
+                                           load_view<T>(sc_g, b, k, j));
+      kk += dk; j += dj;
+      if (j >= Dy) { j -= Dy; ++kk; }
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < np; p += kLpBlock) {
+    T sum_p = T(0), sum_q = T(0), sum_g = T(0);
+    for (uint32_t jj = 0; jj < Dx; ++jj) {
+      sum_p += term_p[pad_index(p * Dx + jj)];
+      sum_q += term_q[pad_index(p * Dx + jj)];
+    }
+    for (uint32_t jj = 0; jj < Dy; ++jj) sum_g += term_g[pad_index(p * Dy + jj)];
+    out[(int64_t)b * K + k0 + p] = (sum_p + sum_g) - sum_q;
+  }
+}
+
 static inline int row_team(int64_t D, int N) { return D / N <= 16 ? 16 : (D / N <= 32 ? 32 : 64); }
 
 template <typename T>
@@ -656,7 +707,19 @@ static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int
                             hipStream_t s) {
   constexpr int N = Vec16<T>::N;
   if (Dx < 1 || Dy < 1) return AESMC_ERR_UNSUPPORTED;
-  if (!is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st)) return AESMC_ERR_UNSUPPORTED;
+  if (!is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st)) {   // vector / tensor scales
+    if (Dx > 64 || Dy > 64) return AESMC_ERR_UNSUPPORTED;
+    const uint32_t P = particles_per_tile(kTileBytes / (int)sizeof(T), 2 * Dx + Dy, K);
+    if (P == 0) return AESMC_ERR_UNSUPPORTED;
+    const uint32_t tiles = (uint32_t)((K + P - 1) / P);
+    if ((uint64_t)B * tiles > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
+    const uint32_t ex = P * (uint32_t)Dx, ey = P * (uint32_t)Dy;
+    const size_t lds = (size_t)(2 * (ex + (ex >> 5) + 1) + ey + (ey >> 5) + 1) * sizeof(T);
+    hipLaunchKernelGGL((normal_logweight_general_kernel<T>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
+                       v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
+                       (uint32_t)Dy, P, tiles);
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
   if (Dx > 64 || Dy > 64) {
     // wide rows: both extents wide, whole 16-byte vectors, the same lane team as K4 picks for
     // each (so that every sum keeps K4's order), rows contiguous and 16-byte aligned

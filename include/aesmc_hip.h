@@ -146,8 +146,9 @@ int aesmc_normal_logprob_sum_backward(int dtype, const void *value, const void *
  *   3 y (observation, Dy)     4 mu_g   5 s_g      (emission)
  *   6 mu_q (extent Dx)        7 s_q               (proposal, evaluated at x)
  * Replaces three calls of K4 and the combine of K1 (aesmc/inference.py:112-126 via
- * aesmc/state.py:114-155); bit-identical to that route.  Returns AESMC_ERR_UNSUPPORTED for
- * non-scalar scales, and for extents above 64 unless both are, are multiples of 16 bytes, take the
+ * aesmc/state.py:114-155); bit-identical to that route.  Scales may be scalars (the fast kernels)
+ * or any [B,K,D] views (one general kernel, extents up to 64).  Returns AESMC_ERR_UNSUPPORTED for
+ * extents above 64 with non-scalar scales, and for extents above 64 unless both are, are multiples of 16 bytes, take the
  * same lane team in K4 and all five rows are contiguous and 16-byte aligned: the caller then
  * takes the K4 + K1 route.
  */

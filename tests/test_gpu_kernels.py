@@ -537,13 +537,53 @@ def test_normal_logweight_wide_rows_are_bitwise_the_unfused_route(kernels, hip_d
         assert torch.equal(fused, unfused)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("B,K,dx,dy", [(2, 16, 1, 1), (3, 37, 10, 10), (4, 300, 10, 4), (2, 1000, 3, 7), (1, 257, 64, 64)])
+def test_normal_logweight_with_tensor_scales_is_bitwise_the_unfused_route(hip_device, dtype, B, K, dx, dy):
+    """Learned scales — a per-dimension vector, a per-sequence [B,D] tensor, a full [B,K,D] network
+    output — take K5's general kernel: log-weights bit-identical to K4 x 3 + K1, gradients (incl.
+    those of the scales, through K4's backward) equal to the unfused route's."""
+    from aesmc_amd import _ops
+    gen = torch.Generator(device=hip_device).manual_seed(B * K + dx + dy)
+    rand = lambda *shape: torch.randn(*shape, device=hip_device, dtype=dtype, generator=gen)
+    pos = lambda *shape: torch.rand(*shape, device=hip_device, dtype=dtype, generator=gen) + 0.3
+    weights = rand(B, K)
+    base = dict(x=rand(B, K, dx), loc_p=rand(B, K, dx), y=rand(B, dy), loc_g=rand(B, K, dy), loc_q=rand(B, K, dx),
+                s_p=pos(dx), s_g=pos(B, dy), s_q=pos(B, K, dx))
+
+    def run(fused):
+        t = {name: v.clone().requires_grad_() for name, v in base.items()}
+        y = t["y"].unsqueeze(1).expand(B, K, dy)
+        sp, sg, sq = t["s_p"].expand(B, K, dx), t["s_g"].unsqueeze(1).expand(B, K, dy), t["s_q"]
+        if fused:
+            lw = _ops.normal_log_weight(t["x"], t["loc_p"], sp, y, t["loc_g"], sg, t["loc_q"], sq)
+            assert lw is not None
+        else:
+            lw = _ops.logweight_lse(_ops.normal_log_prob_sum(t["x"], t["loc_p"], sp),
+                                    _ops.normal_log_prob_sum(y, t["loc_g"], sg),
+                                    _ops.normal_log_prob_sum(t["x"], t["loc_q"], sq))[0]
+        (lw * weights).sum().backward()
+        return lw.detach(), {name: v.grad for name, v in t.items()}
+
+    fused, unfused = run(True), run(False)
+    assert torch.equal(fused[0], unfused[0])
+    rtol = 1e-5 if dtype == torch.float32 else 1e-12
+    for name in base:
+        torch.testing.assert_close(fused[1][name], unfused[1][name], rtol=rtol, atol=rtol, msg=name)
+    eager = (torch.distributions.Normal(base["loc_p"], base["s_p"]).log_prob(base["x"]).sum(-1)
+             + torch.distributions.Normal(base["loc_g"], base["s_g"].unsqueeze(1)).log_prob(base["y"].unsqueeze(1)).sum(-1)
+             - torch.distributions.Normal(base["loc_q"], base["s_q"]).log_prob(base["x"]).sum(-1))
+    tol_ = 2e-5 if dtype == torch.float32 else 1e-12
+    torch.testing.assert_close(fused[0], eager, rtol=tol_, atol=tol_ * (dx + dy))
+
+
 def test_normal_logweight_declines_what_it_does_not_cover(kernels, hip_device):
     B, K = 2, 8
     x = torch.randn(B, K, 3, device=hip_device)
     y = torch.randn(B, K, 3, device=hip_device)
     one = torch.ones((), device=hip_device).expand(B, K, 3)
     vector_scale = torch.ones(3, device=hip_device).expand(B, K, 3)
-    assert kernels.normal_logweight(x, x, vector_scale, y, y, one, x, one) is None       # non-scalar scale
+    assert kernels.normal_logweight(x, x, vector_scale, y, y, one, x, one) is not None   # general kernel
     wide = torch.randn(B, K, 65, device=hip_device)
     one_w = torch.ones((), device=hip_device).expand(B, K, 65)
     assert kernels.normal_logweight(wide, wide, one_w, y, y, one, wide, one_w) is None    # 65 values: not whole vectors
@@ -552,8 +592,10 @@ def test_normal_logweight_declines_what_it_does_not_cover(kernels, hip_device):
     assert kernels.normal_logweight(w128, w128, one128, y, y, one, w128, one128) is None  # wide x, narrow y
     off = torch.randn(B, K, 129, device=hip_device)[:, :, 1:]                             # misaligned rows
     assert kernels.normal_logweight(w128, off, one128, w128, w128, one128, w128, one128) is None
-    assert not kernels.normal_logweight_covers(x, vector_scale, y, one, one)
+    assert kernels.normal_logweight_covers(x, vector_scale, y, one, one)
     assert kernels.normal_logweight_covers(x, one, y, one, one)
+    wide_vector = torch.ones(128, device=hip_device).expand(B, K, 128)
+    assert kernels.normal_logweight(w128, w128, wide_vector, w128, w128, one128, w128, one128) is None  # wide + tensor scale
 
 
 def test_normal_logweight_gradients_match_the_unfused_route(hip_device):
