@@ -543,39 +543,39 @@ class HipKernels:
         return out
 
     def normal_logweight_backward(self, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, need):
-        """Gradients of `normal_logweight` w.r.t. (x, loc_p, y, loc_g, loc_q) in one launch, dense
-        [B,K,*] tensors (None where `need[name]` is false).  None when the launch does not cover the
-        operands (non-scalar scales): the caller then differentiates term by term."""
+        """Gradients of `normal_logweight` in one launch: dense [B,K,*] tensors in the order
+        (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q), None where `need[i]` is false."""
         tag, x, loc_p, scale_p, sx, sp, ssp, Dx = self._normal_operands(x, loc_p, scale_p)
         _, y, loc_g, scale_g, sy, sg, ssg, Dy = self._normal_operands(y, loc_g, scale_g)
         _, _, loc_q, scale_q, _, sq, ssq, _ = self._normal_operands(x, loc_q, scale_q)
-        if any(st != (0, 0, 0) for st in (ssp, ssg, ssq)) or Dx < 1 or Dy < 1:
+        if Dx < 1 or Dy < 1:
             return None
         B, K = x.shape[:2]
         grad_lw = grad_lw.contiguous()
         make = lambda like, wanted: torch.empty(like.shape, dtype=like.dtype, device=like.device) if wanted else None
-        gx, gp, gq = make(x, need["x"]), make(x, need["loc_p"]), make(x, need["loc_q"])
-        gy, gg = make(y, need["y"]), make(y, need["loc_g"])
+        outs = [make(x, need[0]), make(x, need[1]), make(x, need[2]), make(y, need[3]), make(y, need[4]),
+                make(y, need[5]), make(x, need[6]), make(x, need[7])]
         if x.numel() == 0:
-            return gx, gp, gy, gg, gq
+            return outs
+        gx, gp, gsp, gy, gg, gsg, gq, gsq = outs
         views = (_lib.View3 * 8)(*[_lib.View3(_ptr(t), *st) for t, st in (
             (x, sx), (loc_p, sp), (scale_p, ssp), (y, sy), (loc_g, sg), (scale_g, ssg), (loc_q, sq),
             (scale_q, ssq))])
         with _on_device(x.device):
-            args = (tag, views, _ptr(grad_lw), _ptr(gx), _ptr(gp), _ptr(gy), _ptr(gg), _ptr(gq), B, K, Dx, Dy,
-                    self._stream(x))
+            args = (tag, views, _ptr(grad_lw), _ptr(gx), _ptr(gp), _ptr(gy), _ptr(gg), _ptr(gq), _ptr(gsp),
+                    _ptr(gsg), _ptr(gsq), B, K, Dx, Dy, self._stream(x))
             status = self._lib.aesmc_normal_logweight_backward(*args)
             if status == 2:
                 return None
             _lib.check(status, "aesmc_normal_logweight_backward")
             if self.timer is not None:
-                outs = [t for t in (gx, gp, gy, gg, gq) if t is not None]
-                nbytes = sum(self._unique_bytes(t) for t in (x, loc_p, y, loc_g, loc_q, grad_lw)) + \
-                    sum(t.numel() * t.element_size() for t in outs)
+                live = [t for t in outs if t is not None]
+                nbytes = sum(self._unique_bytes(t) for t in (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q,
+                                                             grad_lw)) + sum(t.numel() * t.element_size() for t in live)
                 self.timer.note("normal_logweight_backward",
                                 lambda: self._lib.aesmc_normal_logweight_backward(*args), nbytes,
-                                (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, views) + tuple(outs))
-        return gx, gp, gy, gg, gq
+                                (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, views) + tuple(live))
+        return outs
 
     def normal_rsample(self, eps, loc, scale):
         """loc + eps * scale (product rounded first, as eager PyTorch) -> DENSE tensor of eps's

@@ -100,13 +100,10 @@ class _NormalLogWeight(torch.autograd.Function):
         need = ctx.needs_input_grad
         k = _kernels.get()
         grad = grad.contiguous()
-        if not (need[2] or need[5] or need[7]):     # no scale wants a gradient: one launch for the rest
-            fused = k.normal_logweight_backward(
-                x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad,
-                {"x": need[0], "loc_p": need[1], "y": need[3], "loc_g": need[4], "loc_q": need[6]})
-            if fused is not None:
-                gx, g_loc_p, g_y, g_loc_g, g_loc_q = fused
-                return gx, g_loc_p, None, g_y, g_loc_g, None, g_loc_q, None
+        fused = k.normal_logweight_backward(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad,
+                                            list(need))
+        if fused is not None:
+            return tuple(fused)
         gx_p, g_loc_p, g_scale_p = k.normal_logprob_sum_backward(x, loc_p, scale_p, grad, need[0], need[1], need[2])
         g_y, g_loc_g, g_scale_g = k.normal_logprob_sum_backward(y, loc_g, scale_g, grad, need[3], need[4], need[5])
         gx_q, g_loc_q, g_scale_q = k.normal_logprob_sum_backward(x, loc_q, scale_q, -grad, need[0], need[6], need[7])

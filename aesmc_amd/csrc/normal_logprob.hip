@@ -779,52 +779,58 @@ static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
-// K5 backward for the locations and the values (scales that need gradients take K4's backward,
-// term by term): one pass writes, densely, the gradient of every operand that wants one.  Element
-// arithmetic and the final gx = gx_p + gx_q are K4's backward plus the eager add, operation for
-// operation, so the numbers equal the three-launch route bit for bit.
+// K5 backward: one pass writes, densely, the gradient of every operand that wants one — values,
+// locations and scales.  Element arithmetic and the final gx = gx_p + gx_q are K4's backward plus
+// the eager add, operation for operation, so the numbers equal the three-launch route bit for bit.
 template <typename T>
 __global__ __launch_bounds__(kLpBlock) void normal_logweight_bwd_kernel(
     View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
     const T *__restrict__ grad_lw, T *__restrict__ gx, T *__restrict__ gmu_p, T *__restrict__ gy,
-    T *__restrict__ gmu_g, T *__restrict__ gmu_q, int64_t total_x, int64_t total_y, uint32_t K, uint32_t Dx,
-    uint32_t Dy) {
+    T *__restrict__ gmu_g, T *__restrict__ gmu_q, T *__restrict__ gs_p, T *__restrict__ gs_g,
+    T *__restrict__ gs_q, int64_t total_x, int64_t total_y, uint32_t K, uint32_t Dx, uint32_t Dy) {
   const int64_t stride = (int64_t)gridDim.x * kLpBlock;
   const int64_t first = (int64_t)blockIdx.x * kLpBlock + threadIdx.x;
-  const T s_p = reinterpret_cast<const T *>(sc_p.ptr)[0], s_g = reinterpret_cast<const T *>(sc_g.ptr)[0],
-          s_q = reinterpret_cast<const T *>(sc_q.ptr)[0];
-  const T var_p = s_p * s_p, var_g = s_g * s_g, var_q = s_q * s_q;
-  if (gx != nullptr || gmu_p != nullptr || gmu_q != nullptr) {
+  if (gx != nullptr || gmu_p != nullptr || gmu_q != nullptr || gs_p != nullptr || gs_q != nullptr) {
     for (int64_t e = first; e < total_x; e += stride) {
       const int64_t p = e / Dx;
       const uint32_t j = (uint32_t)(e - p * Dx);
       const int64_t b = p / K, k = p - b * K;
       const T v = load_view<T>(x, b, k, j);
       const T g = grad_lw[p];
-      const T gz_p = g * ((v - load_view<T>(mu_p, b, k, j)) / var_p);
-      const T gz_q = (-g) * ((v - load_view<T>(mu_q, b, k, j)) / var_q);   // log q enters with a minus sign
+      const T s_p = load_view<T>(sc_p, b, k, j), s_q = load_view<T>(sc_q, b, k, j);
+      const T var_p = s_p * s_p, var_q = s_q * s_q;
+      const T dp = v - load_view<T>(mu_p, b, k, j), dq = v - load_view<T>(mu_q, b, k, j);
+      const T gq = -g;                                  // log q enters the weight with a minus sign
+      const T gz_p = g * (dp / var_p);
+      const T gz_q = gq * (dq / var_q);
       if (gmu_p) gmu_p[e] = gz_p;
       if (gmu_q) gmu_q[e] = gz_q;
       if (gx) gx[e] = (-gz_p) + (-gz_q);
+      if (gs_p) gs_p[e] = g * ((dp * dp) / (var_p * s_p) - T(1) / s_p);
+      if (gs_q) gs_q[e] = gq * ((dq * dq) / (var_q * s_q) - T(1) / s_q);
     }
   }
-  if (gy != nullptr || gmu_g != nullptr) {
+  if (gy != nullptr || gmu_g != nullptr || gs_g != nullptr) {
     for (int64_t e = first; e < total_y; e += stride) {
       const int64_t p = e / Dy;
       const uint32_t j = (uint32_t)(e - p * Dy);
       const int64_t b = p / K, k = p - b * K;
-      const T gz_g = grad_lw[p] * ((load_view<T>(y, b, k, j) - load_view<T>(mu_g, b, k, j)) / var_g);
+      const T g = grad_lw[p];
+      const T s_g = load_view<T>(sc_g, b, k, j);
+      const T var_g = s_g * s_g;
+      const T dg = load_view<T>(y, b, k, j) - load_view<T>(mu_g, b, k, j);
+      const T gz_g = g * (dg / var_g);
       if (gmu_g) gmu_g[e] = gz_g;
       if (gy) gy[e] = -gz_g;
+      if (gs_g) gs_g[e] = g * ((dg * dg) / (var_g * s_g) - T(1) / s_g);
     }
   }
 }
 
 template <typename T>
 static int launch_logweight_bwd(const View3 *v, const void *grad_lw, void *gx, void *gmu_p, void *gy,
-                                void *gmu_g, void *gmu_q, int64_t B, int64_t K, int64_t Dx, int64_t Dy,
-                                hipStream_t s) {
-  if (!is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st)) return AESMC_ERR_UNSUPPORTED;
+                                void *gmu_g, void *gmu_q, void *gs_p, void *gs_g, void *gs_q, int64_t B,
+                                int64_t K, int64_t Dx, int64_t Dy, hipStream_t s) {
   const int64_t total_x = B * K * Dx, total_y = B * K * Dy;
   const int64_t most = total_x > total_y ? total_x : total_y;
   int64_t blocks = (most + kLpBlock - 1) / kLpBlock;
@@ -832,7 +838,8 @@ static int launch_logweight_bwd(const View3 *v, const void *grad_lw, void *gx, v
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((normal_logweight_bwd_kernel<T>), dim3((unsigned)blocks), dim3(kLpBlock), 0, s, v[0], v[1],
                      v[2], v[3], v[4], v[5], v[6], v[7], (const T *)grad_lw, (T *)gx, (T *)gmu_p, (T *)gy,
-                     (T *)gmu_g, (T *)gmu_q, total_x, total_y, (uint32_t)K, (uint32_t)Dx, (uint32_t)Dy);
+                     (T *)gmu_g, (T *)gmu_q, (T *)gs_p, (T *)gs_g, (T *)gs_q, total_x, total_y, (uint32_t)K,
+                     (uint32_t)Dx, (uint32_t)Dy);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
@@ -899,8 +906,8 @@ extern "C" int aesmc_normal_logweight(int dtype, const aesmc_view3 *views, void 
 
 extern "C" int aesmc_normal_logweight_backward(int dtype, const aesmc_view3 *views, const void *grad_lw,
                                                void *grad_x, void *grad_mu_p, void *grad_y, void *grad_mu_g,
-                                               void *grad_mu_q, int64_t B, int64_t K, int64_t Dx, int64_t Dy,
-                                               void *stream) {
+                                               void *grad_mu_q, void *grad_s_p, void *grad_s_g, void *grad_s_q,
+                                               int64_t B, int64_t K, int64_t Dx, int64_t Dy, void *stream) {
   using namespace aesmc;
   if (views == nullptr || grad_lw == nullptr || B < 0 || K < 0 || Dx < 1 || Dy < 1) return AESMC_ERR_INVALID_ARGUMENT;
   View3 v[8];
@@ -909,13 +916,16 @@ extern "C" int aesmc_normal_logweight_backward(int dtype, const aesmc_view3 *vie
     v[i].ptr = views[i].ptr;
     v[i].st = Strides3{views[i].stride_b, views[i].stride_k, views[i].stride_d};
   }
-  if (!grad_x && !grad_mu_p && !grad_y && !grad_mu_g && !grad_mu_q) return AESMC_OK;
+  if (!grad_x && !grad_mu_p && !grad_y && !grad_mu_g && !grad_mu_q && !grad_s_p && !grad_s_g && !grad_s_q)
+    return AESMC_OK;
   if (B == 0 || K == 0) return AESMC_OK;
   if (K >= (1ll << 31) || B >= (1ll << 31) || Dx >= (1ll << 31) || Dy >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AESMC_F32)
-    return launch_logweight_bwd<float>(v, grad_lw, grad_x, grad_mu_p, grad_y, grad_mu_g, grad_mu_q, B, K, Dx, Dy, s);
+    return launch_logweight_bwd<float>(v, grad_lw, grad_x, grad_mu_p, grad_y, grad_mu_g, grad_mu_q, grad_s_p,
+                                       grad_s_g, grad_s_q, B, K, Dx, Dy, s);
   if (dtype == AESMC_F64)
-    return launch_logweight_bwd<double>(v, grad_lw, grad_x, grad_mu_p, grad_y, grad_mu_g, grad_mu_q, B, K, Dx, Dy, s);
+    return launch_logweight_bwd<double>(v, grad_lw, grad_x, grad_mu_p, grad_y, grad_mu_g, grad_mu_q, grad_s_p,
+                                        grad_s_g, grad_s_q, B, K, Dx, Dy, s);
   return AESMC_ERR_INVALID_ARGUMENT;
 }

@@ -160,16 +160,17 @@ typedef struct aesmc_view3 {
 int aesmc_normal_logweight(int dtype, const aesmc_view3 *views, void *out_lw, int64_t B, int64_t K,
                            int64_t Dx, int64_t Dy, void *stream);
 
-/* K5 backward: gradients of aesmc_normal_logweight with respect to the values and the locations,
- * each written densely over [B,K,Dx] (grad_x, grad_mu_p, grad_mu_q) or [B,K,Dy] (grad_y,
- * grad_mu_g); NULL outputs are skipped.  `views` as for the forward, grad_lw [B,K].  Bit-identical
- * to three aesmc_normal_logprob_sum_backward launches (with -grad_lw for the proposal term) and
- * the add grad_x = grad_x_p + grad_x_q.  Scales must be scalars; gradients of scales are not
- * produced here (callers that need them use aesmc_normal_logprob_sum_backward per term).
+/* K5 backward: gradients of aesmc_normal_logweight with respect to the values, the locations and
+ * the scales, each written densely over [B,K,Dx] (grad_x, grad_mu_p, grad_mu_q, grad_s_p, grad_s_q)
+ * or [B,K,Dy] (grad_y, grad_mu_g, grad_s_g); NULL outputs are skipped; a broadcast operand's
+ * gradient is reduced by the caller (autograd's expand-backward).  `views` as for the forward (any
+ * scales), grad_lw [B,K].  Bit-identical to three aesmc_normal_logprob_sum_backward launches (with
+ * -grad_lw for the proposal term) and the add grad_x = grad_x_p + grad_x_q.
  */
 int aesmc_normal_logweight_backward(int dtype, const aesmc_view3 *views, const void *grad_lw, void *grad_x,
                                     void *grad_mu_p, void *grad_y, void *grad_mu_g, void *grad_mu_q,
-                                    int64_t B, int64_t K, int64_t Dx, int64_t Dy, void *stream);
+                                    void *grad_s_p, void *grad_s_g, void *grad_s_q, int64_t B, int64_t K,
+                                    int64_t Dx, int64_t Dy, void *stream);
 
 /* Fused resampling step — K2, plus two optional by-products of having the whole batch row in one
  * workgroup:
