@@ -346,7 +346,8 @@ static int launch_lps_bwd(const void *value, const void *loc, const void *scale,
 }
 
 // K5: the whole log-weight of one SMC step when prior / transition, emission and proposal are all
-// Normal with scalar scales:
+// Normal (scalar scales are constants of the launch; vector / tensor scales — learned proposals —
+// are read like the locations, TENSOR_SCALES):
 //   lw[b,k] = sum_j log N(x; mu_p, s_p) + sum_j log N(y; mu_g, s_g) - sum_j log N(x; mu_q, s_q)
 // One pass instead of three K4 launches and K1's combine: x is read once for both of its terms.
 // The three d-sums are formed separately, each in K4's order, and combined as (p + g) - q exactly
@@ -366,7 +367,7 @@ __device__ __forceinline__ T load_view(const View3 &v, int64_t b, int64_t k, uin
 // STATIC_MASK >= 0 fixes the mask at compile time (the t > 0 layout of a Markov model: x, mu_p,
 // mu_q, mu_g dense, y broadcast = 0b10111), so the loads are straight-line code the compiler can
 // keep in flight together; -1 takes the mask from the argument.
-template <typename T, int STATIC_MASK>
+template <typename T, int STATIC_MASK, bool TENSOR_SCALES = false>
 __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
     View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
     T *__restrict__ out, uint32_t K, uint32_t Dx, uint32_t Dy, uint32_t P, uint32_t tiles_per_row,
@@ -428,9 +429,13 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
     }
   } else {
   {  // ---- the two terms in x ---------------------------------------------------------------------
+    // scalar scales: constants of the launch; tensor scales (TENSOR_SCALES: dense bits 32 s_p,
+    // 64 s_q, 128 s_g) are read like the locations and enter element by element, as K4 forms them
     const T s_p = reinterpret_cast<const T *>(sc_p.ptr)[0], s_q = reinterpret_cast<const T *>(sc_q.ptr)[0];
     const T two_var_p = T(2) * (s_p * s_p), log_p = Num<T>::log(s_p);
     const T two_var_q = T(2) * (s_q * s_q), log_q = Num<T>::log(s_q);
+    const T *spt = reinterpret_cast<const T *>(sc_p.ptr) + (int64_t)b * sc_p.st.b + (int64_t)k0 * sc_p.st.k;
+    const T *sqt = reinterpret_cast<const T *>(sc_q.ptr) + (int64_t)b * sc_q.st.b + (int64_t)k0 * sc_q.st.k;
     const uint32_t ne = np * Dx, nvec = ne / N;
     const T *xt = reinterpret_cast<const T *>(x.ptr) + (int64_t)b * x.st.b + (int64_t)k0 * x.st.k;
     const T *pt = reinterpret_cast<const T *>(mu_p.ptr) + (int64_t)b * mu_p.st.b + (int64_t)k0 * mu_p.st.k;
@@ -449,7 +454,16 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
       if (dense & 4u) { const V t = load16(reinterpret_cast<const V *>(qt + e), stream);
 #pragma unroll
         for (int r = 0; r < N; ++r) qv[r] = Vec16<T>::get(t, r); }
-      if ((dense & 7u) != 7u) {
+      T spv[N], sqv[N];
+      if constexpr (TENSOR_SCALES) {
+        if (dense & 32u) { const V t = load16(reinterpret_cast<const V *>(spt + e), stream);
+#pragma unroll
+          for (int r = 0; r < N; ++r) spv[r] = Vec16<T>::get(t, r); }
+        if (dense & 64u) { const V t = load16(reinterpret_cast<const V *>(sqt + e), stream);
+#pragma unroll
+          for (int r = 0; r < N; ++r) sqv[r] = Vec16<T>::get(t, r); }
+      }
+      if ((dense & 7u) != 7u || (TENSOR_SCALES && (dense & 96u) != 96u)) {
         uint32_t k2 = kk, j2 = j;
 #pragma unroll
         for (int r = 0; r < N; ++r) {
@@ -457,14 +471,23 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
           if (!(dense & 1u)) xv[r] = load_view<T>(x, b, k, j2);
           if (!(dense & 2u)) pv[r] = load_view<T>(mu_p, b, k, j2);
           if (!(dense & 4u)) qv[r] = load_view<T>(mu_q, b, k, j2);
+          if constexpr (TENSOR_SCALES) {
+            if (!(dense & 32u)) spv[r] = load_view<T>(sc_p, b, k, j2);
+            if (!(dense & 64u)) sqv[r] = load_view<T>(sc_q, b, k, j2);
+          }
           if (++j2 == Dx) { j2 = 0; ++k2; }
         }
       }
 #pragma unroll
       for (int r = 0; r < N; ++r) {
-        const T dp = xv[r] - pv[r], dq = xv[r] - qv[r];
-        term_p[pad_index(e + r)] = (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
-        term_q[pad_index(e + r)] = (-(dq * dq)) / two_var_q - log_q - half_log_2pi;
+        if constexpr (TENSOR_SCALES) {
+          term_p[pad_index(e + r)] = normal_logpdf(xv[r], pv[r], spv[r]);
+          term_q[pad_index(e + r)] = normal_logpdf(xv[r], qv[r], sqv[r]);
+        } else {
+          const T dp = xv[r] - pv[r], dq = xv[r] - qv[r];
+          term_p[pad_index(e + r)] = (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
+          term_q[pad_index(e + r)] = (-(dq * dq)) / two_var_q - log_q - half_log_2pi;
+        }
       }
       e += step; kk += dk; j += dj;
       if (j >= Dx) { j -= Dx; ++kk; }
@@ -473,9 +496,14 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
       const uint32_t k2 = t / Dx, j2 = t - k2 * Dx;
       const int64_t k = (int64_t)k0 + k2;
       const T xv = load_view<T>(x, b, k, j2);
-      const T dp = xv - load_view<T>(mu_p, b, k, j2), dq = xv - load_view<T>(mu_q, b, k, j2);
-      term_p[pad_index(t)] = (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
-      term_q[pad_index(t)] = (-(dq * dq)) / two_var_q - log_q - half_log_2pi;
+      if constexpr (TENSOR_SCALES) {
+        term_p[pad_index(t)] = normal_logpdf(xv, load_view<T>(mu_p, b, k, j2), load_view<T>(sc_p, b, k, j2));
+        term_q[pad_index(t)] = normal_logpdf(xv, load_view<T>(mu_q, b, k, j2), load_view<T>(sc_q, b, k, j2));
+      } else {
+        const T dp = xv - load_view<T>(mu_p, b, k, j2), dq = xv - load_view<T>(mu_q, b, k, j2);
+        term_p[pad_index(t)] = (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
+        term_q[pad_index(t)] = (-(dq * dq)) / two_var_q - log_q - half_log_2pi;
+      }
     }
   }
   {  // ---- the emission term in y ----------------------------------------------------------------
@@ -483,6 +511,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
     const T two_var_g = T(2) * (s_g * s_g), log_g = Num<T>::log(s_g);
     const uint32_t ne = np * Dy, nvec = ne / N;
     const T *yt = reinterpret_cast<const T *>(y.ptr) + (int64_t)b * y.st.b + (int64_t)k0 * y.st.k;
+    const T *sgt = reinterpret_cast<const T *>(sc_g.ptr) + (int64_t)b * sc_g.st.b + (int64_t)k0 * sc_g.st.k;
     const T *gt = reinterpret_cast<const T *>(mu_g.ptr) + (int64_t)b * mu_g.st.b + (int64_t)k0 * mu_g.st.k;
     uint32_t e = threadIdx.x * N;
     uint32_t kk = e / Dy, j = e - kk * Dy;
@@ -495,20 +524,33 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
       if (dense & 16u) { const V t = load16(reinterpret_cast<const V *>(gt + e), stream);
 #pragma unroll
         for (int r = 0; r < N; ++r) gv[r] = Vec16<T>::get(t, r); }
-      if ((dense & 24u) != 24u) {
+      T sgv[N];
+      if constexpr (TENSOR_SCALES) {
+        if (dense & 128u) { const V t = load16(reinterpret_cast<const V *>(sgt + e), stream);
+#pragma unroll
+          for (int r = 0; r < N; ++r) sgv[r] = Vec16<T>::get(t, r); }
+      }
+      if ((dense & 24u) != 24u || (TENSOR_SCALES && !(dense & 128u))) {
         uint32_t k2 = kk, j2 = j;
 #pragma unroll
         for (int r = 0; r < N; ++r) {
           const int64_t k = (int64_t)k0 + k2;
           if (!(dense & 8u)) yv[r] = load_view<T>(y, b, k, j2);
           if (!(dense & 16u)) gv[r] = load_view<T>(mu_g, b, k, j2);
+          if constexpr (TENSOR_SCALES) {
+            if (!(dense & 128u)) sgv[r] = load_view<T>(sc_g, b, k, j2);
+          }
           if (++j2 == Dy) { j2 = 0; ++k2; }
         }
       }
 #pragma unroll
       for (int r = 0; r < N; ++r) {
-        const T dg = yv[r] - gv[r];
-        term_g[pad_index(e + r)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
+        if constexpr (TENSOR_SCALES) {
+          term_g[pad_index(e + r)] = normal_logpdf(yv[r], gv[r], sgv[r]);
+        } else {
+          const T dg = yv[r] - gv[r];
+          term_g[pad_index(e + r)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
+        }
       }
       e += step; kk += dk; j += dj;
       if (j >= Dy) { j -= Dy; ++kk; }
@@ -516,8 +558,13 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
     for (uint32_t t = nvec * N + threadIdx.x; t < ne; t += kLpBlock) {
       const uint32_t k2 = t / Dy, j2 = t - k2 * Dy;
       const int64_t k = (int64_t)k0 + k2;
-      const T dg = load_view<T>(y, b, k, j2) - load_view<T>(mu_g, b, k, j2);
-      term_g[pad_index(t)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
+      if constexpr (TENSOR_SCALES) {
+        term_g[pad_index(t)] = normal_logpdf(load_view<T>(y, b, k, j2), load_view<T>(mu_g, b, k, j2),
+                                             load_view<T>(sc_g, b, k, j2));
+      } else {
+        const T dg = load_view<T>(y, b, k, j2) - load_view<T>(mu_g, b, k, j2);
+        term_g[pad_index(t)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
+      }
     }
   }
   }
@@ -649,57 +696,6 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_row_kernel(
   if (t == 0 && p < particles) out[p] = (sum_p + sum_g) - sum_q;
 }
 
-// K5 for any scales (a vector, or the [B,K,D] output of a proposal network): the tile scheme with
-// every operand read through its strides, one element per lane per trip (consecutive lanes read
-// consecutive elements of dense operands), log(sigma) and 2 sigma^2 formed per element exactly as
-// K4 forms them, so each term — and the log-weight — equals the K4 x 3 + K1 route bit for bit.
-template <typename T>
-__global__ __launch_bounds__(kLpBlock) void normal_logweight_general_kernel(
-    View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
-    T *__restrict__ out, uint32_t K, uint32_t Dx, uint32_t Dy, uint32_t P, uint32_t tiles_per_row) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lps_smem[];
-  T *term_p = reinterpret_cast<T *>(lps_smem);
-  const uint32_t span_x = P * Dx + ((P * Dx) >> 5) + 1;
-  T *term_q = term_p + span_x;
-  T *term_g = term_q + span_x;
-  const uint32_t b = blockIdx.x / tiles_per_row;
-  const uint32_t k0 = (blockIdx.x - b * tiles_per_row) * P;
-  const uint32_t np = min(P, K - k0);
-  {
-    const uint32_t ne = np * Dx, dk = kLpBlock / Dx, dj = kLpBlock - dk * Dx;
-    uint32_t kk = threadIdx.x / Dx, j = threadIdx.x - kk * Dx;
-    for (uint32_t e = threadIdx.x; e < ne; e += kLpBlock) {
-      const int64_t k = (int64_t)k0 + kk;
-      const T xv = load_view<T>(x, b, k, j);
-      term_p[pad_index(e)] = normal_logpdf(xv, load_view<T>(mu_p, b, k, j), load_view<T>(sc_p, b, k, j));
-      term_q[pad_index(e)] = normal_logpdf(xv, load_view<T>(mu_q, b, k, j), load_view<T>(sc_q, b, k, j));
-      kk += dk; j += dj;
-      if (j >= Dx) { j -= Dx; ++kk; }
-    }
-  }
-  {
-    const uint32_t ne = np * Dy, dk = kLpBlock / Dy, dj = kLpBlock - dk * Dy;
-    uint32_t kk = threadIdx.x / Dy, j = threadIdx.x - kk * Dy;
-    for (uint32_t e = threadIdx.x; e < ne; e += kLpBlock) {
-      const int64_t k = (int64_t)k0 + kk;
-      term_g[pad_index(e)] = normal_logpdf(load_view<T>(y, b, k, j), load_view<T>(mu_g, b, k, j),
-                                           load_view<T>(sc_g, b, k, j));
-      kk += dk; j += dj;
-      if (j >= Dy) { j -= Dy; ++kk; }
-    }
-  }
-  __syncthreads();
-  for (uint32_t p = threadIdx.x; p < np; p += kLpBlock) {
-    T sum_p = T(0), sum_q = T(0), sum_g = T(0);
-    for (uint32_t jj = 0; jj < Dx; ++jj) {
-      sum_p += term_p[pad_index(p * Dx + jj)];
-      sum_q += term_q[pad_index(p * Dx + jj)];
-    }
-    for (uint32_t jj = 0; jj < Dy; ++jj) sum_g += term_g[pad_index(p * Dy + jj)];
-    out[(int64_t)b * K + k0 + p] = (sum_p + sum_g) - sum_q;
-  }
-}
-
 static inline int row_team(int64_t D, int N) { return D / N <= 16 ? 16 : (D / N <= 32 ? 32 : 64); }
 
 template <typename T>
@@ -707,19 +703,8 @@ static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int
                             hipStream_t s) {
   constexpr int N = Vec16<T>::N;
   if (Dx < 1 || Dy < 1) return AESMC_ERR_UNSUPPORTED;
-  if (!is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st)) {   // vector / tensor scales
-    if (Dx > 64 || Dy > 64) return AESMC_ERR_UNSUPPORTED;
-    const uint32_t P = particles_per_tile(kTileBytes / (int)sizeof(T), 2 * Dx + Dy, K);
-    if (P == 0) return AESMC_ERR_UNSUPPORTED;
-    const uint32_t tiles = (uint32_t)((K + P - 1) / P);
-    if ((uint64_t)B * tiles > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
-    const uint32_t ex = P * (uint32_t)Dx, ey = P * (uint32_t)Dy;
-    const size_t lds = (size_t)(2 * (ex + (ex >> 5) + 1) + ey + (ey >> 5) + 1) * sizeof(T);
-    hipLaunchKernelGGL((normal_logweight_general_kernel<T>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
-                       v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
-                       (uint32_t)Dy, P, tiles);
-    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
-  }
+  const bool tensor_scales = !is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st);
+  if (tensor_scales && (Dx > 64 || Dy > 64)) return AESMC_ERR_UNSUPPORTED;
   if (Dx > 64 || Dy > 64) {
     // wide rows: both extents wide, whole 16-byte vectors, the same lane team as K4 picks for
     // each (so that every sum keeps K4's order), rows contiguous and 16-byte aligned
@@ -745,7 +730,7 @@ static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int
 #undef AESMC_ROW_CASE
     return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
   }
-  if (Dx == 1 && Dy == 1) {
+  if (Dx == 1 && Dy == 1 && !tensor_scales) {
     const uint32_t bpr = (uint32_t)((K + 4 * kLpBlock - 1) / (4 * kLpBlock));
     if ((uint64_t)B * bpr > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((normal_logweight_d1_kernel<T>), dim3((unsigned)(B * bpr)), dim3(kLpBlock), 0, s, v[0],
@@ -768,6 +753,15 @@ static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int
   const uint32_t ex = P * (uint32_t)Dx, ey = P * (uint32_t)Dy;
   const size_t lds = (size_t)(2 * (ex + (ex >> 5) + 1) + ey + (ey >> 5) + 1) * sizeof(T);
   const int stream = stream_hint((uint64_t)B * K * (3 * Dx + Dy) * sizeof(T));
+  if (tensor_scales) {   // scales read like locations: dense ones by 16-byte loads (bits 32 s_p, 64 s_q, 128 s_g)
+    if (dense(v[2], Dx)) mask |= 32u;
+    if (dense(v[7], Dx)) mask |= 64u;
+    if (dense(v[5], Dy)) mask |= 128u;
+    hipLaunchKernelGGL((normal_logweight_kernel<T, -1, true>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
+                       v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
+                       (uint32_t)Dy, P, tiles, mask, stream);
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
   if (mask == 23u)
     hipLaunchKernelGGL((normal_logweight_kernel<T, 23>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
                        v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
