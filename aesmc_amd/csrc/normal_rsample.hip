@@ -28,8 +28,9 @@ template <typename T> struct alignas(16) Pack16 {
   T v[Vec16<T>::N];
 };
 
-// loc dense like eps; scale varies along j only (stride_d 0 or 1, the other strides 0).
-template <typename T>
+// loc dense like eps; scale varies along j only (stride_d 0 or 1, the other strides 0), or is
+// dense like loc (SCALE_DENSE: the [B,K,D] output of a proposal network, also read again by K5).
+template <typename T, bool SCALE_DENSE>
 __global__ __launch_bounds__(kRsBlock) void normal_rsample_dense_kernel(
     const T *__restrict__ eps, const T *__restrict__ loc, const T *__restrict__ scale,
     T *__restrict__ out, uint64_t n, uint32_t D, uint32_t scale_stride_d, int stream) {
@@ -40,17 +41,23 @@ __global__ __launch_bounds__(kRsBlock) void normal_rsample_dense_kernel(
     const Pack16<T> e = load16(reinterpret_cast<const Pack16<T> *>(eps + first), stream);   // read once
     const Pack16<T> m = *reinterpret_cast<const Pack16<T> *>(loc + first);                // K5 reads it again
     Pack16<T> r;
-    uint32_t j = (uint32_t)(first % D);
+    if constexpr (SCALE_DENSE) {
+      const Pack16<T> sg = *reinterpret_cast<const Pack16<T> *>(scale + first);
 #pragma unroll
-    for (uint32_t i = 0; i < V; ++i) {
-      const T sigma = scale[(uint64_t)j * scale_stride_d];
-      r.v[i] = m.v[i] + e.v[i] * sigma;
-      j = (j + 1 == D) ? 0u : j + 1;
+      for (uint32_t i = 0; i < V; ++i) r.v[i] = m.v[i] + e.v[i] * sg.v[i];
+    } else {
+      uint32_t j = (uint32_t)(first % D);
+#pragma unroll
+      for (uint32_t i = 0; i < V; ++i) {
+        const T sigma = scale[(uint64_t)j * scale_stride_d];
+        r.v[i] = m.v[i] + e.v[i] * sigma;
+        j = (j + 1 == D) ? 0u : j + 1;
+      }
     }
     *reinterpret_cast<Pack16<T> *>(out + first) = r;
   } else {
     for (uint64_t i = first; i < n; ++i)
-      out[i] = loc[i] + eps[i] * scale[(uint64_t)(i % D) * scale_stride_d];
+      out[i] = loc[i] + eps[i] * (SCALE_DENSE ? scale[i] : scale[(uint64_t)(i % D) * scale_stride_d]);
   }
 }
 
@@ -168,13 +175,24 @@ static int launch_rsample(const aesmc_view3 &eps_view, const aesmc_view3 &loc, c
                                (D == 1 || scale.stride_d == 0 || scale.stride_d == 1);
   const bool aligned = ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(m) |
                          reinterpret_cast<uintptr_t>(o)) & 15u) == 0;
+  const bool scale_dense = !scale_by_column && (D == 1 || scale.stride_d == 1) &&
+                           (K == 1 || scale.stride_k == D) && (B == 1 || scale.stride_b == K * D) &&
+                           (reinterpret_cast<uintptr_t>(s) & 15u) == 0;
+  if (loc_dense && scale_dense && aligned) {
+    constexpr uint64_t V = Vec16<T>::N;
+    const uint64_t blocks = ((n + V - 1) / V + kRsBlock - 1) / kRsBlock;
+    if (blocks >= (1ull << 31)) return AESMC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((normal_rsample_dense_kernel<T, true>), dim3((uint32_t)blocks), dim3(kRsBlock), 0, stream,
+                       e, m, s, o, n, (uint32_t)D, 0u, stream_hint(4 * n * sizeof(T)));
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
   if (loc_dense && scale_by_column && aligned) {
     constexpr uint64_t V = Vec16<T>::N;
     const uint64_t threads = (n + V - 1) / V;
     const uint64_t blocks = (threads + kRsBlock - 1) / kRsBlock;
     if (blocks >= (1ull << 31)) return AESMC_ERR_UNSUPPORTED;
     const uint32_t sd = (D == 1) ? 0u : (uint32_t)scale.stride_d;
-    hipLaunchKernelGGL(normal_rsample_dense_kernel<T>, dim3((uint32_t)blocks), dim3(kRsBlock), 0, stream,
+    hipLaunchKernelGGL((normal_rsample_dense_kernel<T, false>), dim3((uint32_t)blocks), dim3(kRsBlock), 0, stream,
                        e, m, s, o, n, (uint32_t)D, sd, stream_hint(3 * n * sizeof(T)));
   } else {
     const uint64_t blocks = (n + kRsBlock - 1) / kRsBlock;
