@@ -260,6 +260,35 @@ class NonlinearSsm(nn.Module):
         return observations
 
 
+class LearnedScaleSsm(NonlinearSsm):
+    """The nonlinear SSM with the scales a learned-proposal model has: the proposal network outputs
+    location AND scale per particle ([B,K,d] tensors), the transition noise is a learned
+    per-dimension vector, the emission noise stays a scalar buffer."""
+
+    def __init__(self, dim, hidden=64, seed=0, dtype=torch.float32, state=_default_state, validate_args=None, **kw):
+        super().__init__(dim, hidden=hidden, seed=seed, dtype=dtype, state=state, validate_args=validate_args, **kw)
+        torch.manual_seed(seed + 1)
+        self.net0 = nn.Sequential(nn.Linear(dim, hidden), nn.Tanh(), nn.Linear(hidden, 2 * dim)).to(dtype)
+        self.net = nn.Sequential(nn.Linear(2 * dim, hidden), nn.Tanh(), nn.Linear(hidden, 2 * dim)).to(dtype)
+        self.transition_log_scale = nn.Parameter(torch.zeros(dim, dtype=dtype))
+
+    def transition(self, previous_latents=None, time=None, previous_observations=None):
+        loc = torch.tanh(previous_latents[-1] @ self.A.t())
+        return self._tag(self._normal(loc, torch.exp(self.transition_log_scale)), "FULLY_EXPANDED")
+
+    def _split(self, raw):
+        loc, raw_scale = raw[..., :self.dim], raw[..., self.dim:]
+        return loc.contiguous(), (torch.nn.functional.softplus(raw_scale) + 0.1).contiguous()
+
+    def proposal(self, previous_latents=None, time=None, observations=None):
+        if time == 0:
+            return self._tag(self._normal(*self._split(self.net0(observations[0]))), "BATCH_EXPANDED")
+        x_prev = previous_latents[-1]
+        y_now = observations[time].unsqueeze(1).expand(-1, x_prev.size(1), -1)
+        return self._tag(self._normal(*self._split(self.net(torch.cat([x_prev, y_now], dim=2)))),
+                         "FULLY_EXPANDED")
+
+
 class GaussianIwae(nn.Module):
     """The one-step Gaussian model above bundled as one module (config 3 of BASELINE.json: IWAE,
     T = 1, no resampling): x ~ N(mean, 1), y ~ N(x, obs_std), q(x | y) = N(mult y + bias, q_std).

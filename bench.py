@@ -45,6 +45,8 @@ WORKLOADS = {
     "c4": ("LGSSM d=10 B=1024 K=4096 T=100, SMC ELBO (north-star target shape)", "lgssm", 10, 1024, 4096, 100),
     "c4s": ("LGSSM d=10 B=128 K=4096 T=100, SMC ELBO (one GPU's shard of c4 at 8 GPUs)", "lgssm", 10, 128, 4096, 100),
     "c4nl": ("nonlinear SSM + MLP proposal d=10 B=128 K=4096 T=100 (configs[3] per-GPU shard)", "nonlinear", 10, 128, 4096, 100),
+    "c4ls": ("nonlinear SSM, proposal net outputs loc and scale, learned vector transition scale, d=10 B=128 K=4096 T=100",
+             "learned_scale", 10, 128, 4096, 100),
     "c5": ("LGSSM d=128 B=64 K=16384 T=200, SMC ELBO forward, degeneracy stress (configs[4])", "lgssm", 128, 64, 16384, 200),
 }
 
@@ -71,7 +73,8 @@ def parse():
 
 def build_model(kind, dim, device, state):
     from aesmc_amd.testing import models
-    cls = {"lgssm": models.LgssmNd, "nonlinear": models.NonlinearSsm, "gaussian": models.GaussianIwae}[kind]
+    cls = {"lgssm": models.LgssmNd, "nonlinear": models.NonlinearSsm, "gaussian": models.GaussianIwae,
+           "learned_scale": models.LearnedScaleSsm}[kind]
     if kind == "gaussian":
         return cls(state=state, validate_args=False).to(device)
     # validate_args=False: no per-call host sync inside torch.distributions (standard practice)

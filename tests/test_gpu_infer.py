@@ -434,6 +434,7 @@ def test_odd_shapes_match_the_cpu_port_draw_for_draw(hip_device, B, K, T, d, his
 
 
 @pytest.mark.parametrize("kind,algorithm,B,K,T,d", [("nonlinear", "aesmc", 4, 256, 5, 6), ("nonlinear", "iwae", 3, 64, 3, 4),
+                                                    ("learned_scale", "aesmc", 4, 256, 5, 6), ("learned_scale", "iwae", 3, 64, 3, 4),
                                                     ("iwae", "iwae", 64, 512, 1, 1), ("lgssm", "aesmc", 3, 300, 4, 5)])
 def test_other_model_families_match_the_cpu_port_with_gradients(hip_device, kind, algorithm, B, K, T, d):
     """BASELINE.json's other configs (nonlinear SSM + MLP proposal; one-step Gaussian IWAE) and the
@@ -445,6 +446,8 @@ def test_other_model_families_match_the_cpu_port_with_gradients(hip_device, kind
     def build(state_module, device):
         if kind == "nonlinear":
             model = models.NonlinearSsm(d, hidden=16, seed=0, dtype=dtype, state=state_module)
+        elif kind == "learned_scale":     # tensor scales from the proposal net, a learned vector scale
+            model = models.LearnedScaleSsm(d, hidden=16, seed=0, dtype=dtype, state=state_module)
         elif kind == "iwae":
             model = models.GaussianIwae(dtype=dtype, state=state_module)
         else:
