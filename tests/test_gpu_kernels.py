@@ -973,3 +973,36 @@ def test_fused_normal_ops_on_random_views_match_eager_torch(hip_device):
                 assert a is None and b is None, (case, name)
                 continue
             torch.testing.assert_close(a, b, rtol=rtol * 10, atol=atol * 10, msg=str((case, name, shape, which)))
+
+
+def test_many_short_rows(kernels, hip_device):
+    """A very large batch of very short particle systems (B = 200 000, K = 3): every kernel's grid
+    is sized by B here; indices and rows against the C oracle, sums against float64."""
+    from oracle import c_oracle
+    B, K, d = 200000, 3, 2
+    rng = np.random.RandomState(12)
+    lw = rng.randn(B, K).astype(np.float32)
+    u = rng.uniform(size=B)
+    x = rng.randn(B, K, d).astype(np.float32)
+    idx, lse, moved = kernels.resample_step(dev(lw, hip_device), dev(u, hip_device), dev(x, hip_device), want_lse=True) \
+        or (None, None, None)
+    want_idx, _ = c_oracle.ancestor_index(lw, u)
+    if idx is None:      # K * row_bytes = 24 is not a multiple of 16: the fused payload is declined
+        idx = kernels.ancestor_index(dev(lw, hip_device), dev(u, hip_device))
+        moved = kernels.gather(dev(x, hip_device), idx)
+        _, lse = kernels.logweight_lse(dev(lw, hip_device), None, None, want_lw=False, want_lse=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+    np.testing.assert_array_equal(moved.cpu().numpy(), c_oracle.gather(x, want_idx)[0])
+    np.testing.assert_allclose(lse.cpu().numpy(), c_oracle.logweight_lse(lw)[1], rtol=2e-6, atol=2e-6)
+    back = kernels.gather_backward(dev(x, hip_device), idx, sorted_index=True)
+    np.testing.assert_allclose(back.cpu().numpy(), c_oracle.gather_backward(x, want_idx)[0], rtol=1e-5, atol=1e-5)
+    scale = torch.tensor(0.7, device=hip_device).expand(B, K, d)
+    lp = kernels.normal_logprob_sum(dev(x, hip_device), dev(x[:, ::-1].copy(), hip_device), scale)
+    want = torch.distributions.Normal(torch.from_numpy(x[:, ::-1].copy()).double(), 0.7).log_prob(
+        torch.from_numpy(x).double()).sum(-1)
+    np.testing.assert_allclose(lp.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    ess, mean, _ = kernels.particle_summary(dev(lw, hip_device), dev(x, hip_device), True, True, False)
+    want_ess, want_mean, _ = kernel_oracle.particle_summary(lw, x)
+    np.testing.assert_allclose(ess.cpu().numpy(), want_ess, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(mean.cpu().numpy(), want_mean, rtol=2e-5, atol=2e-5)
+    assert kernels.read_flags(hip_device) == 0
