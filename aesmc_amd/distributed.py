@@ -165,12 +165,16 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
                 optimizer.zero_grad(set_to_none=True)
                 shard = (observations[0].size(0) * world_size, rank, world_size)
                 graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
-                                             backward=True, shard=shard, group=group)
+                                             backward=True, shard=shard, group=group, check_flags=False)
             loss = graphed(observations)            # local replay + the all-reduce of the loss
             all_reduce_gradients(parameters, group=group)
             optimizer.step()
+            if graphed.replays % _train._FLAG_CHECK_INTERVAL == 0:
+                graphed.check()
             if callback is not None:
                 callback(epoch, iteration, loss.clone(), *model_parts)
+        if graphed is not None:
+            graphed.check()
         return
     for epoch, iteration, observations in _train._minibatches(dataloader, num_epochs,
                                                               num_iterations_per_epoch):

@@ -28,6 +28,9 @@ def get_chained_params(*objects):
     return itertools.chain.from_iterable(m.parameters() for m in modules)
 
 
+_FLAG_CHECK_INTERVAL = 32   # replays between reads of the device status word in hip_graph training
+
+
 def _minibatches(dataloader, num_epochs, limit):
     """(epoch, iteration, observations) triples: every epoch walks the dataloader afresh and stops
     after `limit` minibatches when a limit is given.  As in the reference (train.py:29-32) the
@@ -66,12 +69,19 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
         for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
             if graphed is None:
                 optimizer.zero_grad(set_to_none=True)   # the capture allocates the static .grad tensors
+                # check_flags=False: the device status word (NaN weights, ...) is read every
+                # _FLAG_CHECK_INTERVAL replays and once at the end instead of after each replay, so
+                # the host can prepare the next minibatch while the GPU still works on this one
                 graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
-                                             backward=True)
+                                             backward=True, check_flags=False)
             loss = graphed(observations)     # refreshes every captured parameter's .grad in place
             optimizer.step()
+            if graphed.replays % _FLAG_CHECK_INTERVAL == 0:
+                graphed.check()
             if callback is not None:         # the graph's loss tensor is reused by the next replay
                 callback(epoch, iteration, loss.clone(), *model_parts)
+        if graphed is not None:
+            graphed.check()
         return
     for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
         optimizer.zero_grad()
