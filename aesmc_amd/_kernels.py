@@ -510,8 +510,8 @@ class HipKernels:
     def normal_logweight(self, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
         """lw = logN(x; loc_p, scale_p) + logN(y; loc_g, scale_g) - logN(x; loc_q, scale_q), each
         summed over trailing dims -> [B,K]; loc / scale are views expanded to x's (resp. y's) shape.
-        Returns None when the kernel does not cover the operands (non-scalar scales, wide rows
-        that are not whole aligned 16-byte vectors):
+        Returns None when the kernel does not cover the operands (wide rows that are not whole
+        aligned 16-byte vectors, or wide rows with tensor scales):
         the caller then takes the K4 + K1 route, which gives bit-identical numbers."""
         tag, x, loc_p, scale_p, sx, sp, ssp, Dx = self._normal_operands(x, loc_p, scale_p)
         _, y, loc_g, scale_g, sy, sg, ssg, Dy = self._normal_operands(y, loc_g, scale_g)

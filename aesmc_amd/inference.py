@@ -228,8 +228,8 @@ def infer(inference_algorithm, observations, initial, transition, emission,
         if keep_originals:
             originals.append(latent)
         # log-weight = log prior/transition + log emission - log proposal (inference.py:97-98,
-        # :125-126): one kernel when all three are Normal with scalar scales (K5), else three
-        # summed log-densities (K4 or the distribution's own log_prob) combined by K1
+        # :125-126): one kernel when all three are Normal (K5), else three summed log-densities
+        # (K4 or the distribution's own log_prob) combined by K1
         log_weight_t = None
         if not isinstance(latent, dict) and not isinstance(observation, dict):
             log_weight_t = state.normal_log_weight(prior_dist, proposal_dist, latent, emission_dist,

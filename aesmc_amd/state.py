@@ -175,7 +175,7 @@ def log_prob(distribution, value):
 def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observation):
     """One step's log-weight  log_prob(prior, latent) + log_prob(emission, observation)
     - log_prob(proposal, latent)  (aesmc/inference.py:112-126) in ONE kernel (K5) when all three
-    distributions are plain Normals with scalar scales on the HIP device; None otherwise — the
+    distributions are plain Normals (any scales) on the HIP device; None otherwise — the
     caller then takes three `log_prob` calls, which give bit-identical numbers.  `observation` is
     already expanded over particles.  Validation is what the three `log_prob` calls would do."""
     if not _FUSED_NORMAL:
