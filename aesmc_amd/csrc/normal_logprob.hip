@@ -367,12 +367,16 @@ __device__ __forceinline__ T load_view(const View3 &v, int64_t b, int64_t k, uin
 // STATIC_MASK >= 0 fixes the mask at compile time (the t > 0 layout of a Markov model: x, mu_p,
 // mu_q, mu_g dense, y broadcast = 0b10111), so the loads are straight-line code the compiler can
 // keep in flight together; -1 takes the mask from the argument.
-template <typename T, int STATIC_MASK, bool TENSOR_SCALES = false>
+template <typename T, int STATIC_MASK, bool TENSOR_SCALES = false, bool SCALE_TABLE = false>
 __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
     View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
     T *__restrict__ out, uint32_t K, uint32_t Dx, uint32_t Dy, uint32_t P, uint32_t tiles_per_row,
-    uint32_t dense_arg, int stream) {
+    uint32_t dense_arg, int stream, uint32_t perd = 0) {
   const uint32_t dense = STATIC_MASK >= 0 ? (uint32_t)STATIC_MASK : dense_arg;
+  // TENSOR_SCALES: a scale that varies along j only (`perd` bit 0 s_p, 1 s_q, 2 s_g — a learned
+  // per-dimension vector) is tabulated once per workgroup as (2 sigma_j^2, log sigma_j); `covered`
+  // marks the scales that need no per-element load (dense: vector loads, per-d: the table)
+  const uint32_t covered = dense | ((perd & 7u) << 5);
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char lps_smem[];
@@ -380,6 +384,30 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
   const uint32_t span_x = P * Dx + ((P * Dx) >> 5) + 1;
   T *term_q = term_p + span_x;                                 // [P * Dx]
   T *term_g = term_q + span_x;                                 // [P * Dy]
+  T *table = term_g + (P * Dy + ((P * Dy) >> 5) + 1);           // [6][64], TENSOR_SCALES with per-d scales
+  if constexpr (TENSOR_SCALES && SCALE_TABLE) {
+    {
+      const uint32_t j = threadIdx.x;
+      if (j < 64) {
+        if ((perd & 1u) && j < Dx) {
+          const T sg = reinterpret_cast<const T *>(sc_p.ptr)[(int64_t)j * sc_p.st.d];
+          table[j] = T(2) * (sg * sg);
+          table[64 + j] = Num<T>::log(sg);
+        }
+        if ((perd & 2u) && j < Dx) {
+          const T sg = reinterpret_cast<const T *>(sc_q.ptr)[(int64_t)j * sc_q.st.d];
+          table[128 + j] = T(2) * (sg * sg);
+          table[192 + j] = Num<T>::log(sg);
+        }
+        if ((perd & 4u) && j < Dy) {
+          const T sg = reinterpret_cast<const T *>(sc_g.ptr)[(int64_t)j * sc_g.st.d];
+          table[256 + j] = T(2) * (sg * sg);
+          table[320 + j] = Num<T>::log(sg);
+        }
+      }
+      __syncthreads();
+    }
+  }
   const uint32_t b = blockIdx.x / tiles_per_row;
   const uint32_t k0 = (blockIdx.x - b * tiles_per_row) * P;
   const uint32_t np = min(P, K - k0);
@@ -463,7 +491,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
 #pragma unroll
           for (int r = 0; r < N; ++r) sqv[r] = Vec16<T>::get(t, r); }
       }
-      if ((dense & 7u) != 7u || (TENSOR_SCALES && (dense & 96u) != 96u)) {
+      if ((dense & 7u) != 7u || (TENSOR_SCALES && (covered & 96u) != 96u)) {
         uint32_t k2 = kk, j2 = j;
 #pragma unroll
         for (int r = 0; r < N; ++r) {
@@ -472,8 +500,8 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
           if (!(dense & 2u)) pv[r] = load_view<T>(mu_p, b, k, j2);
           if (!(dense & 4u)) qv[r] = load_view<T>(mu_q, b, k, j2);
           if constexpr (TENSOR_SCALES) {
-            if (!(dense & 32u)) spv[r] = load_view<T>(sc_p, b, k, j2);
-            if (!(dense & 64u)) sqv[r] = load_view<T>(sc_q, b, k, j2);
+            if (!(covered & 32u)) spv[r] = load_view<T>(sc_p, b, k, j2);
+            if (!(covered & 64u)) sqv[r] = load_view<T>(sc_q, b, k, j2);
           }
           if (++j2 == Dx) { j2 = 0; ++k2; }
         }
@@ -481,8 +509,21 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         if constexpr (TENSOR_SCALES) {
-          term_p[pad_index(e + r)] = normal_logpdf(xv[r], pv[r], spv[r]);
-          term_q[pad_index(e + r)] = normal_logpdf(xv[r], qv[r], sqv[r]);
+          if constexpr (!SCALE_TABLE) {             // no per-dimension scale in this launch
+            term_p[pad_index(e + r)] = normal_logpdf(xv[r], pv[r], spv[r]);
+            term_q[pad_index(e + r)] = normal_logpdf(xv[r], qv[r], sqv[r]);
+            continue;
+          }
+          uint32_t jr = j + r;                      // this element's dimension index (r < N <= Dx wraps once)
+          if (jr >= Dx) jr -= Dx;
+          if (Dx < (uint32_t)N) jr = (j + r) % Dx;
+          const T dp = xv[r] - pv[r], dq = xv[r] - qv[r];
+          const T tvp = (perd & 1u) ? table[jr] : T(2) * (spv[r] * spv[r]);
+          const T lgp = (perd & 1u) ? table[64 + jr] : Num<T>::log(spv[r]);
+          const T tvq = (perd & 2u) ? table[128 + jr] : T(2) * (sqv[r] * sqv[r]);
+          const T lgq = (perd & 2u) ? table[192 + jr] : Num<T>::log(sqv[r]);
+          term_p[pad_index(e + r)] = (-(dp * dp)) / tvp - lgp - half_log_2pi;
+          term_q[pad_index(e + r)] = (-(dq * dq)) / tvq - lgq - half_log_2pi;
         } else {
           const T dp = xv[r] - pv[r], dq = xv[r] - qv[r];
           term_p[pad_index(e + r)] = (-(dp * dp)) / two_var_p - log_p - half_log_2pi;
@@ -530,7 +571,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
 #pragma unroll
           for (int r = 0; r < N; ++r) sgv[r] = Vec16<T>::get(t, r); }
       }
-      if ((dense & 24u) != 24u || (TENSOR_SCALES && !(dense & 128u))) {
+      if ((dense & 24u) != 24u || (TENSOR_SCALES && !(covered & 128u))) {
         uint32_t k2 = kk, j2 = j;
 #pragma unroll
         for (int r = 0; r < N; ++r) {
@@ -538,7 +579,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
           if (!(dense & 8u)) yv[r] = load_view<T>(y, b, k, j2);
           if (!(dense & 16u)) gv[r] = load_view<T>(mu_g, b, k, j2);
           if constexpr (TENSOR_SCALES) {
-            if (!(dense & 128u)) sgv[r] = load_view<T>(sc_g, b, k, j2);
+            if (!(covered & 128u)) sgv[r] = load_view<T>(sc_g, b, k, j2);
           }
           if (++j2 == Dy) { j2 = 0; ++k2; }
         }
@@ -546,7 +587,17 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_kernel(
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         if constexpr (TENSOR_SCALES) {
-          term_g[pad_index(e + r)] = normal_logpdf(yv[r], gv[r], sgv[r]);
+          if constexpr (!SCALE_TABLE) {
+            term_g[pad_index(e + r)] = normal_logpdf(yv[r], gv[r], sgv[r]);
+            continue;
+          }
+          uint32_t jr = j + r;
+          if (jr >= Dy) jr -= Dy;
+          if (Dy < (uint32_t)N) jr = (j + r) % Dy;
+          const T dg = yv[r] - gv[r];
+          const T tvg = (perd & 4u) ? table[256 + jr] : T(2) * (sgv[r] * sgv[r]);
+          const T lgg = (perd & 4u) ? table[320 + jr] : Num<T>::log(sgv[r]);
+          term_g[pad_index(e + r)] = (-(dg * dg)) / tvg - lgg - half_log_2pi;
         } else {
           const T dg = yv[r] - gv[r];
           term_g[pad_index(e + r)] = (-(dg * dg)) / two_var_g - log_g - half_log_2pi;
@@ -757,9 +808,17 @@ static int launch_logweight(const View3 *v, void *out, int64_t B, int64_t K, int
     if (dense(v[2], Dx)) mask |= 32u;
     if (dense(v[7], Dx)) mask |= 64u;
     if (dense(v[5], Dy)) mask |= 128u;
-    hipLaunchKernelGGL((normal_logweight_kernel<T, -1, true>), dim3((unsigned)(B * tiles)), dim3(kLpBlock), lds, s,
-                       v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K, (uint32_t)Dx,
-                       (uint32_t)Dy, P, tiles, mask, stream);
+    auto per_dimension = [](const View3 &view) { return view.st.b == 0 && view.st.k == 0; };  // scalars included
+    const uint32_t perd = (per_dimension(v[2]) ? 1u : 0u) | (per_dimension(v[7]) ? 2u : 0u) |
+                          (per_dimension(v[5]) ? 4u : 0u);
+    if (perd != 0)
+      hipLaunchKernelGGL((normal_logweight_kernel<T, -1, true, true>), dim3((unsigned)(B * tiles)), dim3(kLpBlock),
+                         lds + 6 * 64 * sizeof(T), s, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out,
+                         (uint32_t)K, (uint32_t)Dx, (uint32_t)Dy, P, tiles, mask, stream, perd);
+    else
+      hipLaunchKernelGGL((normal_logweight_kernel<T, -1, true, false>), dim3((unsigned)(B * tiles)), dim3(kLpBlock),
+                         lds, s, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], (T *)out, (uint32_t)K,
+                         (uint32_t)Dx, (uint32_t)Dy, P, tiles, mask, stream, 0u);
     return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
   }
   if (mask == 23u)
