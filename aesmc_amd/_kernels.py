@@ -106,11 +106,14 @@ class KernelTimer:
                 # K3's re-read of the indices, which it skips); only rows that still have offspring
                 # are actually fetched.  Report how many that was on these operands and the bytes
                 # that had to move.
-                fractions, moved = [], []
+                fractions, moved, ess = [], [], []
                 for _, _, keep in sample:
                     idx, dst = (keep[1], keep[2]) if name == "resample_gather" else (keep[2], keep[5])
                     if dst is None:
                         continue
+                    if name == "resample_step":   # effective sample size of the weights resampled from (K7)
+                        log_ess = get().particle_summary(keep[0], want_log_ess=True)[0]
+                        ess.append(float(torch.exp(log_ess.double()).mean().item()) / idx.size(1))
                     rows = idx.numel()
                     unique = int((idx[:, 1:] != idx[:, :-1]).sum().item()) + idx.size(0)
                     payload = dst.numel() * dst.element_size() / rows
@@ -121,6 +124,8 @@ class KernelTimer:
                     out[name]["unique_ancestor_fraction"] = sum(fractions) / len(fractions)
                     out[name]["moved_bytes_per_launch"] = sum(moved) / len(moved)
                     out[name]["moved_GBps"] = out[name]["moved_bytes_per_launch"] / seconds / 1e9
+                if ess:
+                    out[name]["ess_over_k"] = sum(ess) / len(ess)
         return out
 
 

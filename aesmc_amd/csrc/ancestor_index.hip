@@ -255,13 +255,18 @@ struct StepPayload {
 template <int G>
 __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *srow, char *drow,
                                                     uint32_t K, uint32_t ppp, int64_t stride_k,
-                                                    uint32_t tid, uint32_t nt) {
+                                                    uint32_t tid, uint32_t nt, uint32_t part,
+                                                    uint32_t parts) {
   constexpr int V = 16 / G;
   constexpr int U = 4;
   using P = typename Piece<G>::type;
   const uint64_t row_pieces = (uint64_t)K * ppp;             // a multiple of V (checked on the host)
-  const uint32_t chunks = (uint32_t)(row_pieces / V);
-  for (uint32_t c0 = 0; c0 < chunks; c0 += nt * U) {
+  const uint32_t row_chunks = (uint32_t)(row_pieces / V);
+  // a batch row shared by `parts` workgroups: this one copies chunks [begin, chunks)
+  const uint32_t per_part = (row_chunks + parts - 1) / parts;
+  const uint32_t begin = min(row_chunks, part * per_part);
+  const uint32_t chunks = min(row_chunks, begin + per_part);
+  for (uint32_t c0 = begin; c0 < chunks; c0 += nt * U) {
     P piece[U][V];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -293,7 +298,7 @@ __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *
 template <typename T, int C>
 __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
-    int32_t *flags, int K, T *__restrict__ out_lse, StepPayload payload) {
+    int32_t *flags, int K, T *__restrict__ out_lse, StepPayload payload, int B, int parts) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *scratch = smem;                                        // [64]
   int *scratch_i = reinterpret_cast<int *>(scratch + 32);
@@ -304,7 +309,13 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   const int wave = tid / kWave;
   const int nwaves = nt / kWave;
   int *first_of_lane = marker + nt * C;                           // [nwaves]: first[] of each wavefront's lane 0
-  const int64_t row = blockIdx.x;
+  // `parts` workgroups share a batch row (grid = parts * B, see launch_inv): each repeats the
+  // row's scan — 4 B per particle, L2-resident after the first reader — and owns 1/parts of the
+  // OUTPUT: the lanes [part, part + 1) * nt / parts store their indices, and the payload copy is
+  // cut by 16-byte chunks.  No workgroup waits for another.
+  const int64_t row = blockIdx.x % (unsigned)B;
+  const uint32_t part = blockIdx.x / (unsigned)B;
+  const bool owns_idx = (uint32_t)tid * parts / nt == part;       // nt is a multiple of parts
   const T *lw = log_w + row * (int64_t)K;
   int64_t *idx = out_idx + row * (int64_t)K;
   const int j0 = tid * C;                                         // nt * C >= K: one round
@@ -350,12 +361,14 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   __syncthreads();
   const bool degenerate = has_nan || !(dm > -__builtin_huge_val() && dm < __builtin_huge_val());
   if (degenerate) {  // same conventions as the reference: see include/aesmc_hip.h, K2
-    if (tid == 0) {
+    if (tid == 0 && part == 0) {
       raise_flag(flags, has_nan ? AESMC_FLAG_NAN_LOG_WEIGHT : AESMC_FLAG_DEGENERATE_ROW);
       // torch.logsumexp's values for such rows (K1 returns the same)
       if (out_lse != nullptr) out_lse[row] = has_nan ? Num<T>::nan() : (T)dm;
     }
-    for (int k = tid; k < K; k += nt) idx[k] = (int64_t)K;
+    if (owns_idx)
+      for (int i = 0; i < C; ++i)
+        if (j0 + i < K) idx[j0 + i] = (int64_t)K;
     if (payload.src == nullptr) return;
     // the unfused route would clamp the out-of-range index K to K - 1 in K3: same bytes here
     for (int k = tid; k < nt * C; k += nt) marker[k] = K - 1;
@@ -363,11 +376,11 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     const char *srow = payload.src + row * payload.stride_b;
     char *drow = payload.dst + (uint64_t)row * K * payload.ppp * payload.G;
     if (payload.G == 16)
-      gather_row_from_lds<16>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+      gather_row_from_lds<16>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
     else if (payload.G == 8)
-      gather_row_from_lds<8>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+      gather_row_from_lds<8>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
     else
-      gather_row_from_lds<4>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+      gather_row_from_lds<4>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
     return;
   }
 
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   const double total = scratch[31];
   const double inv_total = 1.0 / total;
   // by-product: logsumexp of the row (the step's contribution to log Z), float64 inside
-  if (out_lse != nullptr && tid == 0) out_lse[row] = (T)(dm + ::log(total));
+  if (out_lse != nullptr && tid == 0 && part == 0) out_lse[row] = (T)(dm + ::log(total));
 
   // ---- first[j] = min{ k : (u + k) / K >= c[j] } ---------------------------------------------------
   const double ub = u[row];
@@ -478,7 +491,9 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   for (int w = 0; w < wave; ++w) before = max(before, scratch_i[w]);
 #pragma unroll
   for (int i = 0; i < C; ++i) best[i] = max(before, best[i]);
-  if (j0 + C <= K && (((uintptr_t)(idx + j0)) & 15u) == 0) {
+  if (!owns_idx) {
+    // another workgroup of this row stores these indices
+  } else if (j0 + C <= K && (((uintptr_t)(idx + j0)) & 15u) == 0) {
 #pragma unroll
     for (int i = 0; i < C; i += 2) {
       longlong2 pair;
@@ -508,11 +523,11 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   const char *srow = payload.src + row * payload.stride_b;
   char *drow = payload.dst + (uint64_t)row * K * payload.ppp * payload.G;
   if (payload.G == 16)
-    gather_row_from_lds<16>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+    gather_row_from_lds<16>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
   else if (payload.G == 8)
-    gather_row_from_lds<8>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+    gather_row_from_lds<8>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
   else
-    gather_row_from_lds<4>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt);
+    gather_row_from_lds<4>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
 }
 
 static int pick_threads(int64_t K, int chunk) {
@@ -523,21 +538,42 @@ static int pick_threads(int64_t K, int chunk) {
   return (int)nt;
 }
 
+// Workgroups per batch row of the fused step.  One workgroup per row leaves CUs idle below ~1000
+// rows and is then capped by what ONE CU pulls from HBM (~24 GB/s: 160 KB of payload per row at
+// K=4096 d=10 take 7 us); sharing a row's output among `parts` workgroups (each repeating the cheap
+// scan) fills the chip.  0 = automatic; aesmc_set_step_parts() pins a value (tuning / tests).
+static int g_step_parts = 0;
+
+static int pick_parts(int64_t B, int nt, bool has_payload) {
+  int limit = nt / kWave;                        // at least one wavefront of index stores per part
+  if (limit > 8) limit = 8;
+  if (g_step_parts > 0) return g_step_parts < limit ? g_step_parts : limit;
+  if (!has_payload) return 1;
+  int parts = 1;
+  while (parts < limit && B * parts < 768) parts *= 2;
+  return parts;
+}
+
 template <typename T, int C>
 static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
                       int64_t K, hipStream_t s, void *out_lse = nullptr,
                       const StepPayload &payload = StepPayload{nullptr, nullptr, 0, 0, 0, 0}) {
   const int nt = pick_threads(K, C);
   const size_t lds = (size_t)kScratchDoubles * sizeof(double) + (size_t)(nt * C + nt + 8) * sizeof(int);
-  static bool attr_set = false;  // raise the dynamic-LDS cap once per process and instantiation
-  if (!attr_set) {
+  // raise the dynamic-LDS cap once per device and instantiation (a process may drive several GPUs)
+  static bool attr_set[64] = {};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return AESMC_ERR_LAUNCH;
+  if (!attr_set[device]) {
     if (hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return AESMC_ERR_LAUNCH;
-    attr_set = true;
+    attr_set[device] = true;
   }
-  hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C>), dim3((unsigned)B), dim3(nt), lds, s,
-                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload);
+  int parts = pick_parts(B, nt, payload.src != nullptr);
+  while (parts > 1 && (nt % parts != 0 || B * parts > 0x7fffffffLL)) parts /= 2;
+  hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
+                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
@@ -572,6 +608,12 @@ static int launch(const void *log_w, const double *u, int64_t *idx, int32_t *fla
 }  // namespace aesmc
 
 extern "C" int64_t aesmc_ancestor_index_lds_max_particles(void) { return aesmc::kInvMaxParticles; }
+
+extern "C" int aesmc_set_step_parts(int parts) {
+  if (parts < 0 || (parts & (parts - 1)) != 0) return AESMC_ERR_INVALID_ARGUMENT;
+  aesmc::g_step_parts = parts;
+  return AESMC_OK;
+}
 
 extern "C" size_t aesmc_workspace_bytes(int64_t B, int64_t K) {
   if (B <= 0 || K <= aesmc::kInvMaxParticles) return 0;

@@ -144,11 +144,20 @@ def get_resampled_latents(latents, ancestral_indices):
     batch_size, num_particles = probe.size()[:2]
     lineage = torch.arange(num_particles, dtype=torch.int64, device=probe.device) \
         .unsqueeze(0).expand(batch_size, num_particles)
+    # Systematic resampling returns non-decreasing indices; `arange` is sorted and a composition of
+    # non-decreasing maps is non-decreasing, so every lineage built from K2's own outputs is sorted
+    # too: the tag sends the backward of these gathers to the atomic-free segmented-sum kernel
+    # (which re-checks the promise).  Indices of any other origin stay untagged.
+    monotone = all(getattr(index, "_aesmc_sorted", False) for index in ancestral_indices)
+    if monotone:
+        lineage._aesmc_sorted = True
     resampled = [None] * len(latents)
     for time in range(len(latents) - 1, -1, -1):
         resampled[time] = state.resample(latents[time], lineage)
         if time > 0:
             lineage = _ops.resample_gather(ancestral_indices[time - 1], lineage)
+            if monotone:
+                lineage._aesmc_sorted = True
     return resampled
 
 

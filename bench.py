@@ -1,32 +1,45 @@
 """Throughput of the SMC ELBO hot path on MI355X (BASELINE.json metric: particle-steps/sec).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5|c3|c4nl]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3|c4s|c4nl|c4ls|c5]
+                    [--proposal tuned|stock] [--scaling weak|strong] [--extras on|off]
 
 One "step" = one SMC ELBO evaluation (aesmc_amd.losses.get_loss(..., 'aesmc') forward, autograd
-graph recorded as in training) over one synthetic batch already resident in HBM.  N > 1: the driver
-launches one process per GPU via torch.distributed.run; each rank owns `B` batch rows (weak
-scaling), the only collective is the all-reduce of sum_b log Z_b (RCCL over xGMI).
+graph recorded as in training) over one synthetic batch already resident in HBM.  The default
+workload is the north-star shape of BASELINE.json: LGSSM d=10, B=1024, K=4096, T=100 ("c4").
+
+N > 1: `python bench.py --gpus N` starts N fresh children itself (python -m
+torch.distributed.run, one rank per GPU, RCCL) before anything touches the GPU; it also runs as a
+child of an external torchrun (RANK / WORLD_SIZE in the environment).  Batch rows shard over the
+ranks; the only collective on the data path is the all-reduce of sum_b log Z_b.  `--scaling weak`
+(default): every rank owns the workload's B rows; `--scaling strong`: the workload's B rows are
+split over the ranks (the north-star curve: global B=1024 on 1, 2, 4, 8 GPUs).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the resampling kernel (fused step K2+K3, or K3 alone), timed per launch with HIP events on its stream
-                 while the same steps run again; achieved = algorithmic bytes / launch time;
+  roofline     : the resampling kernel (fused step K2+K3; K3 alone where the step does not cover the
+                 payload; K1 for the IWAE workload), timed per launch with HIP events on its stream
+                 on operands sampled from the timed steps; achieved = algorithmic bytes / time,
+                 next to the bytes that had to move given how many ancestors survived;
   cpu_baseline : oracle/reference_port.py (the op-for-op CPU port of the reference, kind "port")
                  timed on this box's host cores on a bounded sample of the same workload;
-  kernels      : the same per-launch figures for every kernel of the path.
+  kernels      : the same per-launch figures for every kernel of the path;
+  extras       : (N = 1) the same workload with SURVEY.md 8(d)'s untrained proposal stand-in,
+                 configs[1] replayed as one hipGraph (round 1's headline), kernel legs at the
+                 shapes BASELINE.json uses to isolate K1 and K3, and the float32 index flip rate
+                 against the reference's fixtures.
 """
 import argparse
 import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 # before the HIP runtime starts: ROCm 7.0's graph fast path misorders captured memset nodes
 # (aesmc_amd/__init__.py sets the same default on import; stated here because it shapes the numbers)
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -34,29 +47,40 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
-FORWARD_ONLY = {"c4", "c5"}  # autograd retention of T x (dozens of [B,K,d] temporaries) would exceed HBM
-
-ALGORITHM = {"c3": "iwae"}  # every other workload is the SMC ELBO ('aesmc')
-
-# name: (description, model kind, d, per-GPU B, K, T)
+# name: description, model kind, d, B (per GPU under weak scaling), K, T, model keyword arguments
 WORKLOADS = {
-    "c2": ("LGSSM d=10 B=256 K=1024 T=50, SMC ELBO (configs[1])", "lgssm", 10, 256, 1024, 50),
-    "c3": ("one-step Gaussian IWAE d=1 B=4096 K=8192 T=1, no resampling (configs[2])", "gaussian", 1, 4096, 8192, 1),
-    "c4": ("LGSSM d=10 B=1024 K=4096 T=100, SMC ELBO (north-star target shape)", "lgssm", 10, 1024, 4096, 100),
-    "c4s": ("LGSSM d=10 B=128 K=4096 T=100, SMC ELBO (one GPU's shard of c4 at 8 GPUs)", "lgssm", 10, 128, 4096, 100),
-    "c4nl": ("nonlinear SSM + MLP proposal d=10 B=128 K=4096 T=100 (configs[3] per-GPU shard)", "nonlinear", 10, 128, 4096, 100),
+    "c4": ("LGSSM d=10 B=1024 K=4096 T=100, SMC ELBO (north-star target shape)", "lgssm", 10, 1024, 4096, 100, {}),
+    "c2": ("LGSSM d=10 B=256 K=1024 T=50, SMC ELBO (configs[1])", "lgssm", 10, 256, 1024, 50, {}),
+    "c3": ("one-step Gaussian IWAE d=1 B=4096 K=8192 T=1, no resampling (configs[2])", "gaussian", 1, 4096, 8192, 1, {}),
+    "c4s": ("LGSSM d=10 B=128 K=4096 T=100, SMC ELBO (one GPU's shard of c4 at 8 GPUs)", "lgssm", 10, 128, 4096, 100, {}),
+    "c4nl": ("nonlinear SSM + MLP proposal d=10 B=128 K=4096 T=100 (configs[3] per-GPU shard)", "nonlinear", 10, 128, 4096, 100, {}),
     "c4ls": ("nonlinear SSM, proposal net outputs loc and scale, learned vector transition scale, d=10 B=128 K=4096 T=100",
-             "learned_scale", 10, 128, 4096, 100),
-    "c5": ("LGSSM d=128 B=64 K=16384 T=200, SMC ELBO forward, degeneracy stress (configs[4])", "lgssm", 128, 64, 16384, 200),
+             "learned_scale", 10, 128, 4096, 100, {}),
+    "c5": ("LGSSM d=128 B=64 K=16384 T=200, SMC ELBO forward, degeneracy stress (configs[4])", "lgssm", 128, 64, 16384, 200, {}),
+    # configs[4]'s shape on a particle system that is NOT collapsed: at d=128 even the locally optimal
+    # proposal keeps only ~20 % of the ancestors per step with SURVEY's emission noise 0.5; with 0.05
+    # (an informative sensor) half of them survive, so the gather reads what it is priced for
+    "c5h": ("LGSSM d=128 B=64 K=16384 T=200, emission scale 0.05, SMC ELBO forward (configs[4] shape, healthy particle system)",
+            "lgssm", 128, 64, 16384, 200, {"emission_scale": 0.05}),
 }
+ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
+NO_GRAD = {"c5", "c5h"}             # autograd retention of T x [B,K,128] temporaries exceeds HBM: forward under no_grad
+GRAPH_PARTICLES = 1 << 20           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--proposal", default="tuned", choices=["tuned", "stock"],
+                    help="LGSSM workloads: 'tuned' = the model's locally optimal proposal in closed form (what "
+                         "training converges towards: a healthy particle system); 'stock' = SURVEY.md 8(d)'s "
+                         "untrained linear stand-in (collapses to ~14 %% surviving ancestors per step)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--extras", default=None, choices=["on", "off"],
+                    help="the extra blocks (stock proposal, configs[1] hipGraph, kernel legs, parity); default: on for N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-backward", action="store_true")
     ap.add_argument("--tunableop", default="on", choices=["on", "off"],
@@ -68,29 +92,74 @@ def parse():
                     help="initialise the process group and take the sharded code path even with one rank (test hook)")
     ap.add_argument("--mode", default=None, choices=["graph", "eager"],
                     help="graph: replay the whole ELBO as one hipGraph (aesmc_amd.graphs); eager: Python loop")
-    return ap.parse_args()
+    ap.add_argument("--grad", default=None, choices=["on", "off"],
+                    help="record the autograd graph during the forward step (default: on where it fits in HBM)")
+    return ap.parse_args(argv)
 
 
-def build_model(kind, dim, device, state):
+# ---- launcher --------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def child_command(argv, gpus, port=None, python=None):
+    """The command `python bench.py --gpus N ...` runs for N > 1: one rank per GPU under
+    torch.distributed.run on this node, rendezvous on 127.0.0.1 (the hostname may not resolve)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def child_environment(base=None):
+    env = dict(os.environ if base is None else base)
+    env.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")          # torchrun's default of 1 starves the CPU-side numpy draws
+    env["AESMC_BENCH_CHILD"] = "1"
+    return env
+
+
+def needs_launcher(args, environ=None):
+    environ = os.environ if environ is None else environ
+    return args.gpus > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
+def self_launch(args, argv):
+    """Nothing in this process has touched the GPU (importing torch does not): the N ranks are fresh
+    children; their rank 0 prints the one JSON line on the stdout they inherit."""
+    command = child_command(argv, args.gpus)
+    print("bench.py: launching {} ranks: {}".format(args.gpus, " ".join(command)), file=sys.stderr, flush=True)
+    return subprocess.run(command, env=child_environment()).returncode
+
+
+# ---- models / CPU baseline -------------------------------------------------------------------------
+def build_model(kind, dim, device, state, proposal="stock", **model_kwargs):
     from aesmc_amd.testing import models
     cls = {"lgssm": models.LgssmNd, "nonlinear": models.NonlinearSsm, "gaussian": models.GaussianIwae,
            "learned_scale": models.LearnedScaleSsm}[kind]
     if kind == "gaussian":
         return cls(state=state, validate_args=False).to(device)
     # validate_args=False: no per-call host sync inside torch.distributions (standard practice)
-    return cls(dim, seed=0, state=state, validate_args=False).to(device)
+    model = cls(dim, seed=0, state=state, validate_args=False, **model_kwargs).to(device)
+    if proposal == "tuned" and hasattr(model, "tune_proposal"):
+        model.tune_proposal()
+    return model
 
 
-def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", budget_s=20.0):
+def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_kwargs=None, budget_s=20.0):
     """The CPU port of the reference (oracle/reference_port.py) on a BOUNDED sample of the same
     workload: same model, K and d; batch rows (and, if still too slow, timesteps) are cut until a
     calibrated estimate fits `budget_s` seconds.  Threads: min(cores, 16) — PyTorch's default of
     one thread per core is far slower on big hosts for these small ops."""
+    import numpy as np
+    import torch
     from oracle import reference_port
     cores = os.cpu_count() or 1
     threads = min(cores, 16)
     torch.set_num_threads(threads)
-    model = build_model(kind, dim, torch.device("cpu"), reference_port)
+    model = build_model(kind, dim, torch.device("cpu"), reference_port, proposal, **(model_kwargs or {}))
     parts = (model.initial, model.transition, model.emission, model.proposal)
 
     def run(b, t):
@@ -115,9 +184,9 @@ def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", budget_s=20.0):
         t -= 5
     dt, loss = run(b, t)
     return {"value": b * K * t / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
-            "sample": "1 forward ELBO, B={} K={} T={} d={} in {:.1f} s on {} of {} host cores; "
+            "sample": "1 forward ELBO, B={} K={} T={} d={} ({} proposal) in {:.1f} s on {} of {} host cores; "
                       "oracle/reference_port.py (PyTorch-CPU + NumPy, keeps the reference's O(T^2) "
-                      "history re-gather and per-row np.digitize loop)".format(b, K, t, dim, dt, threads, cores),
+                      "history re-gather and per-row np.digitize loop)".format(b, K, t, dim, proposal, dt, threads, cores),
             "loss": loss}
 
 
@@ -136,23 +205,367 @@ def stdout_to_stderr():
         os.close(saved)
 
 
-def main():
-    args = parse()
+def _round(stats):
+    return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in stats.items()}
+
+
+# ---- one workload ------------------------------------------------------------------------------------
+class Context:
+    """What every leg of the bench shares: the device, the process group and the kernel provider."""
+
+    def __init__(self, args, device, rank, world, use_dist):
+        self.args, self.device, self.rank, self.world, self.use_dist = args, device, rank, world, use_dist
+
+    def barrier(self):
+        import torch
+        if self.use_dist:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, fn, n):
+        """n calls of fn between barrier + synchronize on both sides; max over ranks."""
+        import torch
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = fn()
+        self.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.device)
+        if self.use_dist:
+            import torch.distributed as dist
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item()), float(loss.detach())
+
+
+def traffic_record(workload, proposal, kernel):
+    """HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/
+    (tools/pmc_workload.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per run, over the
+    first timesteps of this same seeded workload; FETCH_SIZE doubled as calibrated on an
+    identity-index launch).  Counters cannot be read from inside an unprofiled run, so the line
+    carries the committed figure and says where it came from."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        table = json.load(fh)
+    entry = table.get("{}:{}".format(workload, proposal), {}).get(kernel)
+    if not entry:
+        return None, None
+    return entry.get("hbm_bytes_per_launch"), entry.get("source", "profiles/pmc_traffic.json")
+
+
+def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backward=True, want_kernels=True,
+                 mode=None, grad=None):
+    """Times `steps` forward ELBOs of one workload (after `warmup`), then forward+backward, then the
+    per-kernel pass.  Returns a dict with the contract's numbers for this workload."""
+    import numpy as np
+    import torch
+    import aesmc_amd
+    from aesmc_amd import _kernels, distributed
+
+    args, device, rank, world = ctx.args, ctx.device, ctx.rank, ctx.world
+    description, kind, dim, B, K, T, model_kwargs = WORKLOADS[name]
+    algorithm = ALGORITHM.get(name, "aesmc")
+    if kind != "lgssm":
+        proposal = "stock"
+    if scaling == "strong":
+        global_B = B
+        lo, hi = distributed.shard_bounds(global_B, rank, world)
+        local_B = hi - lo
+    else:
+        global_B, local_B = B * world, B
+    provider = _kernels.get()
+    torch.cuda.reset_peak_memory_stats(device)
+    model = build_model(kind, dim, device, aesmc_amd.state, proposal, **model_kwargs)
+    observations = model.simulate(T, global_B, seed=1)          # same data on every rank ...
+    observations = distributed.shard_observations(observations, rank, world)  # ... own rows only
+    parts = (model.initial, model.transition, model.emission, model.proposal)
+    np.random.seed(0)
+    torch.manual_seed(0)
+
+    if mode is None:      # small per-step sizes are host-bound in the eager loop
+        mode = "graph" if (local_B * K <= GRAPH_PARTICLES and name not in NO_GRAD) else "eager"
+    if grad is None:
+        grad = "off" if name in NO_GRAD else "on"
+    grad_mode = torch.enable_grad if grad == "on" else torch.no_grad
+    if grad == "off":
+        want_backward = False
+
+    def step(backward=False):
+        with grad_mode():
+            if ctx.use_dist:
+                loss = distributed.sharded_get_loss(observations, K, algorithm, *parts, global_batch_size=global_B,
+                                                    rank=rank, world_size=world)
+            else:
+                loss = aesmc_amd.losses.get_loss(observations, K, algorithm, *parts)
+            if backward:
+                model.zero_grad(set_to_none=True)
+                loss.backward()
+                if ctx.use_dist:
+                    distributed.all_reduce_gradients(list(model.parameters()))
+            return loss.detach()
+
+    # ---- the step: one hipGraph replay of the whole ELBO or the eager Python loop -----------------
+    shard = (global_B, rank, world) if ctx.use_dist else None
+    ran_as, graph_error, graphed = "eager", None, None
+    if mode == "graph":
+        try:
+            from aesmc_amd import graphs
+            with grad_mode():
+                # check_flags=False: replays run back to back; the device status word (NaN weights,
+                # degenerate rows, ...) is read once after each timed region instead of every step
+                graphed = graphs.GraphedLoss(observations, K, algorithm, *parts, shard=shard, check_flags=False)
+            ran_as = "hipgraph"
+        except Exception as error:  # capture is an optimisation: report and fall back to eager
+            graph_error = "{}: {}".format(type(error).__name__, error)
+            torch.cuda.synchronize()
+    forward = graphed if graphed is not None else step
+
+    for _ in range(warmup):
+        forward()
+    seconds, loss = ctx.timed(forward, steps)
+    if graphed is not None:
+        graphed.check()
+    out = {
+        "workload": "{}: {}".format(name, description), "proposal": proposal if kind == "lgssm" else None,
+        "value": global_B * K * T * steps / seconds, "ms_per_step": 1e3 * seconds / steps, "loss": loss,
+        "mode": ran_as, "graph_error": graph_error, "grad": grad, "scaling": scaling,
+        "batch_per_gpu": local_B, "global_batch": global_B, "num_particles": K, "num_timesteps": T,
+        "state_dim": dim, "algorithm": algorithm,
+        "peak_memory_GB": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+    }
+
+    if graphed is not None:  # the eager loop beside it, for the record
+        step()
+        n = max(1, steps // 2)
+        se, _ = ctx.timed(step, n)
+        out["eager_particle_steps_per_sec"] = global_B * K * T * n / se
+
+    if want_backward:
+        n = max(1, steps // 2)
+        train_step = graphed_train = None
+        if graphed is not None:
+            try:
+                from aesmc_amd import graphs
+                graphed_train = graphs.GraphedLoss(observations, K, algorithm, *parts, backward=True, shard=shard,
+                                                   check_flags=False)
+                params = list(model.parameters())
+
+                def train_step():
+                    result = graphed_train()
+                    if ctx.use_dist:
+                        distributed.all_reduce_gradients(params)
+                    return result
+            except Exception as error:
+                out["graph_error"] = "backward capture: {}: {}".format(type(error).__name__, error)
+                torch.cuda.synchronize()
+                train_step = graphed_train = None
+        if train_step is None:
+            def train_step():
+                return step(backward=True)
+        try:
+            train_step()
+            sb, _ = ctx.timed(train_step, n)
+            if graphed_train is not None:
+                graphed_train.check()
+            out["fwd_bwd_particle_steps_per_sec"] = global_B * K * T * n / sb
+            out["fwd_bwd_ms_per_step"] = 1e3 * sb / n
+        except torch.OutOfMemoryError as error:
+            out["fwd_bwd_error"] = "OutOfMemoryError: {}".format(str(error)[:200])
+            model.zero_grad(set_to_none=True)
+        del graphed_train, train_step
+    out["peak_memory_GB"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
+
+    # ---- per-kernel timing: the same steps again with every launch noted, a sample of them replayed
+    # back to back between two HIP events on the stream they are launched on ------------------------
+    if want_kernels:
+        provider.timer = _kernels.KernelTimer()
+        try:
+            for _ in range(max(1, min(steps, 3))):
+                step()
+            kernels = provider.timer.summary()
+        finally:
+            provider.timer = None
+        out["kernels"] = {k: _round(v) for k, v in kernels.items()}
+        # the roofline kernel: the resample gather (K3, or the fused step that contains it); a workload
+        # that never resamples (c3, IWAE) is what BASELINE.json uses to isolate the fused log-weight
+        # + log-sum-exp kernel (K1)
+        if "moved_GBps" in kernels.get("resample_step", {}):
+            key, label = "resample_step", "ancestor_index_inv_kernel with payload (fused step: K2 + K3)"
+        elif "resample_gather" in kernels:
+            key, label = "resample_gather", "resample_gather_kernel (K3)"
+        else:
+            key, label = "logweight_lse", "logweight_lse_kernel (K1)"
+        out["roofline"] = roofline_of(kernels.get(key), label, name, proposal, key)
+    del graphed, forward, step, model, observations
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def roofline_of(stats, label, workload, proposal, key):
+    """The contract's `roofline` object for one kernel's timing record.  `achieved` prices SURVEY.md
+    8(d)'s ALGORITHMIC bytes (a full read of the gather's source).  A collapsed particle system
+    fetches only the surviving rows, so the bytes that had to move are priced beside it, and when
+    fewer than 30 % of the ancestors survive `achieved` / `frac` are the moved-bytes figures
+    (`pricing` says which): a gather that mostly re-reads one cached row is not HBM traffic."""
+    if not stats:
+        return None
+    algorithmic = stats["GBps"]
+    out = {"kernel": label, "bound": "hbm", "achieved": round(algorithmic, 1), "peak": HBM_PEAK_GBPS,
+           "unit": "GB/s", "frac": round(algorithmic / HBM_PEAK_GBPS, 4), "pricing": "algorithmic",
+           "avg_launch_us": round(stats["avg_us"], 2),
+           "algorithmic_bytes_per_launch": stats["bytes_per_launch"], "launches": stats["launches"],
+           "frac_algorithmic": round(algorithmic / HBM_PEAK_GBPS, 4)}
+    traffic, source = traffic_record(workload, proposal, key)
+    out["traffic"] = traffic
+    out["traffic_source"] = source
+    if "unique_ancestor_fraction" in stats:
+        out["unique_ancestor_fraction"] = round(stats["unique_ancestor_fraction"], 4)
+        out["moved_bytes_per_launch"] = stats["moved_bytes_per_launch"]
+        out["achieved_moved_bytes"] = round(stats["moved_GBps"], 1)
+        out["frac_moved_bytes"] = round(stats["moved_GBps"] / HBM_PEAK_GBPS, 4)
+        if "ess_over_k" in stats:
+            out["ess_over_k"] = round(stats["ess_over_k"], 4)
+        if stats["unique_ancestor_fraction"] < 0.3:
+            out["achieved"], out["frac"], out["pricing"] = out["achieved_moved_bytes"], out["frac_moved_bytes"], \
+                "moved bytes (collapsed particle system: fewer than 30 % of the ancestors survive)"
+    out["frac"] = min(out["frac"], 1.0)
+    return out
+
+
+# ---- kernel legs: the shapes BASELINE.json uses to isolate single kernels ---------------------------
+def kernel_legs(ctx):
+    """K1 at configs[2]'s shape (combine + log-sum-exp over [4096, 8192]); K3 at configs[4]'s shape
+    (d=128, K=16384) on indices of a healthy and of a collapsed particle system; the fused step at
+    configs[1]'s and at the 8-GPU shard's shape.  Synthetic operands as SURVEY.md 8(d) prescribes for
+    kernel isolation: log_weight = s * randn (s = 1: ESS/K ~ 0.37), value = randn."""
+    import torch
+    from aesmc_amd import _kernels
+    k = _kernels.get()
+    dev = ctx.device
+    gen = torch.Generator(device=dev).manual_seed(0)
+
+    def timeit(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / reps
+
+    def leg(us, nbytes, **more):
+        gbps = nbytes / us / 1e3
+        return dict({"avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": nbytes,
+                     "achieved": round(gbps, 1), "frac": round(min(gbps / HBM_PEAK_GBPS, 1.0), 4)}, **more)
+
+    legs = {}
+    B, K = 4096, 8192
+    a, b, c = [torch.randn(B, K, device=dev, generator=gen) for _ in range(3)]
+    legs["K1_c3_combine_lse"] = leg(timeit(lambda: k.logweight_lse(a, b, c)), B * K * 16 + 4 * B,
+                                    shape="B=4096 K=8192 (configs[2])")
+    legs["K1_c3_lse_only"] = leg(timeit(lambda: k.logweight_lse(a, None, None, want_lw=False)), B * K * 4 + 4 * B,
+                                 shape="B=4096 K=8192, row log-sum-exp of one input")
+    del a, b, c
+    for label, (B, K, d) in (("c5", (64, 16384, 128)), ("c4", (1024, 4096, 10))):
+        x = torch.randn(B, K, d, device=dev, generator=gen)
+        u = torch.rand(B, device=dev, dtype=torch.float64, generator=gen)
+        for s in (1.0, 5.0):
+            lw = s * torch.randn(B, K, device=dev, generator=gen)
+            idx = k.ancestor_index(lw, u)
+            unique = (int((idx[:, 1:] != idx[:, :-1]).sum().item()) + B) / (B * K)
+            us = timeit(lambda: k.gather(x, idx))
+            moved = B * K * 8 + (1 + unique) * x.numel() * 4
+            legs["K3_{}_s{:g}".format(label, s)] = leg(
+                us, B * K * (8 + 8 * d), shape="B={} K={} d={}".format(B, K, d),
+                unique_ancestor_fraction=round(unique, 4), achieved_moved_bytes=round(moved / us / 1e3, 1),
+                frac_moved_bytes=round(min(moved / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4))
+        del x
+    for label, (B, K, d) in (("c2", (256, 1024, 10)), ("c4s", (128, 4096, 10)), ("c4", (1024, 4096, 10))):
+        x = torch.randn(B, K, d, device=dev, generator=gen)
+        u = torch.rand(B, device=dev, dtype=torch.float64, generator=gen)
+        lw = torch.randn(B, K, device=dev, generator=gen)
+        idx = k.ancestor_index(lw, u)
+        unique = (int((idx[:, 1:] != idx[:, :-1]).sum().item()) + B) / (B * K)
+        us = timeit(lambda: k.resample_step(lw, u, x, want_lse=True), reps=50)
+        moved = B * K * 12 + (1 + unique) * x.numel() * 4
+        legs["step_{}_s1".format(label)] = leg(
+            us, B * K * (20 + 8 * d) + 8 * B, shape="B={} K={} d={} (fused step: K2 + K3)".format(B, K, d),
+            unique_ancestor_fraction=round(unique, 4), achieved_moved_bytes=round(moved / us / 1e3, 1),
+            frac_moved_bytes=round(min(moved / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4))
+        del x
+    torch.cuda.empty_cache()
+    return legs
+
+
+def parity_block(ctx):
+    """float32 ancestor indices against the reference's own (fixtures captured from the imported
+    reference by oracle/capture_golden.py).  The reference builds the CDF in float32 (NumPy / SciPy),
+    this library in float64: float64 inputs agree exactly, float32 inputs
+    wherever no comparison sits within float32 rounding noise of flipping — the rate is stated here."""
+    import glob
+    import numpy as np
+    import torch
+    from aesmc_amd import _kernels
+    k = _kernels.get()
+    out = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "resampler_*.npz")) +
+                       glob.glob(os.path.join(ROOT, "tests", "golden", "lgssm10d_k1024_smc_f32.npz"))):
+        data = np.load(path)
+        name = os.path.basename(path)[:-4]
+        if "log_weight" in data.files:
+            cases = [(data["log_weight"], data["uniform"], data["out_idx"])]
+        else:
+            steps = len([f for f in data.files if f.startswith("out_idx_")])
+            cases = [(data["out_log_weights_{}".format(t)], data["uniform_{}".format(t)], data["out_idx_{}".format(t)])
+                     for t in range(steps)]
+        total = wrong = worst = 0
+        for lw, u, want in cases:
+            if not np.isfinite(lw).all() or lw.dtype not in (np.float32, np.float64):
+                continue
+            got = k.ancestor_index(torch.from_numpy(lw).to(ctx.device),
+                                   torch.from_numpy(np.asarray(u, dtype=np.float64).reshape(-1)).to(ctx.device))
+            delta = (got.cpu().numpy() - want.astype(np.int64))
+            total += delta.size
+            wrong += int((delta != 0).sum())
+            worst = max(worst, int(np.abs(delta).max()))
+        if total:
+            out[name] = {"dtype": str(cases[0][0].dtype), "num_particles": int(cases[0][0].shape[1]),
+                         "indices": total, "mismatches": wrong, "max_abs_delta": worst,
+                         "flip_rate": wrong / total}
+    k.read_flags(ctx.device)
+    return out
+
+
+# ---- main ----------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if needs_launcher(args):
+        sys.exit(self_launch(args, argv))
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    import aesmc_amd  # noqa: F401
+    from aesmc_amd import _kernels
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus {} must be launched with torch.distributed.run "
-                             "--nproc-per-node {}".format(args.gpus, args.gpus))
-    import torch.distributed as dist
-    import aesmc_amd
-    from aesmc_amd import _kernels, distributed
-
+        raise SystemExit("bench.py --gpus {} but WORLD_SIZE={}".format(args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    rccl_world = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -161,18 +574,10 @@ def main():
             warm = torch.zeros(1, device=device)
             dist.all_reduce(warm)          # creates the communicator now (and prints its banner)
             torch.cuda.synchronize()
+        rccl_world = dist.get_world_size()
+    assert _kernels.get().name == "hip"
+    ctx = Context(args, device, rank, world, use_dist)
 
-    description, kind, dim, B, K, T = WORKLOADS[args.workload]
-    algorithm = ALGORITHM.get(args.workload, "aesmc")
-    provider = _kernels.get()
-    assert provider.name == "hip"
-    model = build_model(kind, dim, device, aesmc_amd.state)
-    global_B = B * world
-    observations = model.simulate(T, global_B, seed=1)          # same data on every rank ...
-    observations = distributed.shard_observations(observations, rank, world)  # ... own rows only
-    parts = (model.initial, model.transition, model.emission, model.proposal)
-    np.random.seed(0)
-    torch.manual_seed(0)
     if args.tunableop == "on":
         # hipBLASLt's default pick for the callables' [B*K, d] x [d, d] maps runs at ~1.3 TB/s;
         # TunableOp (a stock PyTorch feature) times the candidates on first use and keeps the best.
@@ -188,171 +593,69 @@ def main():
                   file=sys.stderr)
             args.tunableop = "off"
 
-    if args.mode is None:  # the big forward-only shapes are device-bound and need the HBM for data
-        args.mode = "eager" if args.workload in FORWARD_ONLY else "graph"
-    grad_mode = torch.no_grad if args.workload in FORWARD_ONLY else torch.enable_grad
-    if args.workload in FORWARD_ONLY:
-        args.no_backward = True
-
-    def step(backward=False):
-        with grad_mode():
-            return _step(backward)
-
-    def _step(backward=False):
-        if use_dist:
-            loss = distributed.sharded_get_loss(observations, K, algorithm, *parts, global_batch_size=global_B,
-                                                rank=rank, world_size=world)
-        else:
-            loss = aesmc_amd.losses.get_loss(observations, K, algorithm, *parts)
-        if backward:
-            model.zero_grad(set_to_none=True)
-            loss.backward()
-            if use_dist:
-                distributed.all_reduce_gradients(list(model.parameters()))
-        return loss
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(fn, n):
-        """n calls of fn between barrier + synchronize on both sides; max over ranks."""
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            loss = fn()
-        barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if use_dist:
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        return float(dt.item()), float(loss.detach())
-
-    # ---- the step: one hipGraph replay of the whole ELBO (default) or the eager Python loop ------
-    shard = (global_B, rank, world) if use_dist else None
-    mode, graph_error, graphed = "eager", None, None
-    if args.mode == "graph":
-        try:
-            from aesmc_amd import graphs
-            with grad_mode():
-                # check_flags=False: replays run back to back; the device status word (NaN weights,
-                # degenerate rows, ...) is read once after each timed region instead of every step
-                graphed = graphs.GraphedLoss(observations, K, algorithm, *parts, shard=shard, check_flags=False)
-            mode = "hipgraph"
-        except Exception as error:  # capture is an optimisation: report and fall back to eager
-            graph_error = "{}: {}".format(type(error).__name__, error)
-            torch.cuda.synchronize()
-    forward = graphed if graphed is not None else step
-
-    for _ in range(args.warmup):
-        forward()
-    seconds, loss = timed(forward, args.steps)
-    if graphed is not None:
-        graphed.check()
-    ms_per_step = 1e3 * seconds / args.steps
-    value = global_B * K * T * args.steps / seconds
-
-    eager_value = None
-    if graphed is not None:  # the eager loop beside it, for the record
-        step()
-        n = max(1, args.steps // 2)
-        se, _ = timed(step, n)
-        eager_value = global_B * K * T * n / se
-
-    fwd_bwd = None
-    if not args.no_backward:
-        n = max(1, args.steps // 2)
-        train_step = graphed_train = None
-        if graphed is not None:
-            try:
-                from aesmc_amd import graphs
-                graphed_train = graphs.GraphedLoss(observations, K, algorithm, *parts, backward=True, shard=shard,
-                                                   check_flags=False)
-                params = list(model.parameters())
-
-                def train_step():
-                    out = graphed_train()
-                    if use_dist:
-                        distributed.all_reduce_gradients(params)
-                    return out
-            except Exception as error:
-                graph_error = "backward capture: {}: {}".format(type(error).__name__, error)
-                torch.cuda.synchronize()
-                train_step = graphed_train = None
-        if train_step is None:
-            def train_step():
-                return step(backward=True)
-        train_step()
-        sb, _ = timed(train_step, n)
-        if graphed_train is not None and train_step is not None:
-            graphed_train.check()
-        fwd_bwd = global_B * K * T * n / sb
-
-    # ---- per-kernel timing: the same steps again with HIP events around every launch ------------
-    provider.timer = _kernels.KernelTimer()
-    for _ in range(args.steps):
-        step()
-    kernels = provider.timer.summary()
-    provider.timer = None
-    # the roofline kernel: the resample gather (K3); a workload that never resamples (c3, IWAE) is
-    # what BASELINE.json uses to isolate the fused log-weight + log-sum-exp kernel (K1)
-    if "moved_GBps" in kernels.get("resample_step", {}):
-        name, label = "resample_step", "ancestor_index_inv_kernel with payload (fused step: K2 + K3)"
-    elif "resample_gather" in kernels:
-        name, label = "resample_gather", "resample_gather_kernel (K3)"
-    else:
-        name, label = "logweight_lse", "logweight_lse_kernel (K1)"
-    dominant = kernels.get(name)
-    roofline = None
-    if dominant:
-        achieved = dominant["GBps"]
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):  # PMC passes are separate rocprofv3 runs (tools/pmc_gather.py)
-            with open(pmc_path) as fh:
-                traffic = json.load(fh).get(args.workload, {}).get(name + "_bytes_per_launch")
-        roofline = {"kernel": label, "bound": "hbm", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic, "avg_launch_us": round(dominant["avg_us"], 2),
-                    "algorithmic_bytes_per_launch": dominant["bytes_per_launch"],
-                    "launches": dominant["launches"]}
-        if "unique_ancestor_fraction" in dominant:
-            # `achieved` prices a full read of the source (SURVEY.md 8(d)); with a collapsed particle
-            # system only the surviving rows are fetched, so it can exceed what HBM moved: the
-            # surviving fraction and the bytes that did move on these operands are stated beside it.
-            roofline["unique_ancestor_fraction"] = round(dominant["unique_ancestor_fraction"], 4)
-            roofline["achieved_moved_bytes"] = round(dominant["moved_GBps"], 1)
-            roofline["frac_moved_bytes"] = round(dominant["moved_GBps"] / HBM_PEAK_GBPS, 4)
+    extras_on = (args.extras or ("on" if world == 1 else "off")) == "on"
+    head = run_workload(ctx, args.workload, args.proposal, args.steps, args.warmup, scaling=args.scaling,
+                        want_backward=not args.no_backward, mode=args.mode, grad=args.grad)
+    description, kind, dim, B, K, T, model_kwargs = WORKLOADS[args.workload]
 
     out = {
-        "metric": "particle_steps_per_sec", "value": value, "unit": "particle-steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "metric": "particle_steps_per_sec", "value": head["value"], "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "{}: {}".format(args.workload, description), "batch_per_gpu": B,
-                   "global_batch": global_B, "num_particles": K, "num_timesteps": T, "state_dim": dim,
+        "config": {"workload": head["workload"], "proposal": head["proposal"],
+                   "batch_per_gpu": head["batch_per_gpu"], "global_batch": head["global_batch"],
+                   "num_particles": K, "num_timesteps": T, "state_dim": dim,
                    "parallelism": "batch-shard x{} (one RCCL all-reduce of sum log Z per ELBO)".format(world),
                    "pytorch": "TunableOp {} for the user callables' matmuls; distributions built with "
                               "validate_args=False".format(args.tunableop),
                    "hip_runtime": "DEBUG_CLR_GRAPH_PACKET_CAPTURE={} (0: captured memset nodes keep stream "
                                   "order on ROCm 7.0)".format(os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")),
-                   "step": "one forward ELBO, get_loss(..., '{}'), ".format(algorithm) +
-                           ("torch.no_grad()" if args.workload in FORWARD_ONLY else "autograd graph recorded") +
-                           (", all T timesteps replayed as one hipGraph" if mode == "hipgraph" else ", eager Python loop")},
-        "loss": loss,
-        "mode": mode, "graph_error": graph_error, "tunableop": args.tunableop,
-        "eager_particle_steps_per_sec": eager_value,
-        "fwd_bwd_particle_steps_per_sec": fwd_bwd,
-        "roofline": roofline,
-        "kernels": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()}
-                    for k, v in kernels.items()},
+                   "step": "one forward ELBO, get_loss(..., '{}'), ".format(head["algorithm"]) +
+                           ("autograd graph recorded" if head["grad"] == "on" else "torch.no_grad()") +
+                           (", all T timesteps replayed as one hipGraph" if head["mode"] == "hipgraph"
+                            else ", eager Python loop")},
+        "rccl_world_size": rccl_world,
+        "loss": head["loss"], "mode": head["mode"], "graph_error": head["graph_error"],
+        "tunableop": args.tunableop, "peak_memory_GB": head["peak_memory_GB"],
+        "eager_particle_steps_per_sec": head.get("eager_particle_steps_per_sec"),
+        "fwd_bwd_particle_steps_per_sec": head.get("fwd_bwd_particle_steps_per_sec"),
+        "fwd_bwd_error": head.get("fwd_bwd_error"),
+        "roofline": head.get("roofline"),
+        "kernels": head.get("kernels"),
     }
+
+    extras = {}
+    if world > 1 and args.scaling == "weak" and (args.extras or "on") == "on":
+        # the north-star curve beside the weak-scaling line: the workload's B rows split over the ranks
+        strong = run_workload(ctx, args.workload, args.proposal, args.steps, args.warmup, scaling="strong",
+                              want_backward=False, want_kernels=False)
+        extras["strong_scaling"] = {key: strong[key] for key in
+                                    ("value", "ms_per_step", "batch_per_gpu", "global_batch", "mode", "loss")}
+    if extras_on and world == 1:
+        def brief(result):
+            keep = ("workload", "proposal", "value", "ms_per_step", "loss", "mode", "grad", "graph_error",
+                    "eager_particle_steps_per_sec", "fwd_bwd_particle_steps_per_sec", "fwd_bwd_error",
+                    "peak_memory_GB", "roofline")
+            return {key: result.get(key) for key in keep}
+        if kind == "lgssm":
+            other = "stock" if args.proposal == "tuned" else "tuned"
+            extras["{}_proposal".format(other)] = brief(run_workload(
+                ctx, args.workload, other, args.steps, args.warmup, want_backward=False, mode=args.mode, grad=args.grad))
+        if args.workload != "c2":
+            extras["c2_hipgraph"] = brief(run_workload(ctx, "c2", args.proposal, 20, 5,
+                                                       want_backward=not args.no_backward))
+        extras["kernel_legs"] = kernel_legs(ctx)
+        extras["index_parity_vs_reference_fixtures"] = parity_block(ctx)
+    if extras:
+        out["extras"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(kind, dim, B, K, T, algorithm)
+        out["cpu_baseline"] = cpu_baseline(kind, dim, B, K, T, head["algorithm"],
+                                           args.proposal if kind == "lgssm" else "stock", model_kwargs)
     if use_dist:
         dist.barrier()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

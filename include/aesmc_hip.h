@@ -109,6 +109,11 @@ int aesmc_resample_gather_backward(int dtype, const void *grad_out, const int64_
                                    void *grad_src, int32_t *flags, int64_t B, int64_t K,
                                    int64_t row_elems, int index_is_sorted, void *stream);
 
+/* Tuning knob: which kernel serves index_is_sorted != 0.  0 (default): destination tiles, every
+ * row of grad_src written once, no zero fill; 1: source tiles behind a zero-fill launch (round 1's
+ * kernel, still the route for rows wider than 4 KiB).  Same sums up to association order. */
+int aesmc_set_sorted_backward_kernel(int which);
+
 /*
  * K4 — summed Normal log-density:
  *   out[b,k] = sum_{j<D} ( -((v-mu)^2) / (2 sigma^2) - log(sigma) - log(sqrt(2 pi)) )
@@ -188,6 +193,12 @@ int aesmc_normal_logweight_backward(int dtype, const aesmc_view3 *views, const v
 int aesmc_resample_step(int dtype, const void *log_w, const double *u, int64_t *out_idx, void *out_lse,
                         const void *src, void *dst, int32_t *flags, int64_t B, int64_t K,
                         int64_t row_bytes, int64_t src_stride_b, int64_t src_stride_k, void *stream);
+
+/* Tuning knob of the fused step: workgroups that share one batch row (each repeats the row's scan
+ * and writes 1/parts of the indices and of the payload; results do not depend on it).  0 (default)
+ * = chosen from B and K so that small batches still fill the 256 CUs; a power of two pins it.
+ * Process-wide; not part of the reference's interface. */
+int aesmc_set_step_parts(int parts);
 
 /* K6 — reparameterised Normal draw  out[b,k,j] = loc[b,k,j] + eps[b,k,j] * scale[b,k,j].
  *

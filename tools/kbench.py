@@ -56,10 +56,12 @@ def main(names):
             rows.append(("K3 gather s=1", us, B * K * (8 + 8 * d)))
             us = timeit(lambda: k.gather(x, idx5))
             rows.append(("K3 gather s=5", us, B * K * (8 + 8 * d)))
-            us = timeit(lambda: k.gather_backward(x, idx, sorted_index=True))
-            rows.append(("K3 backward s=1 (sorted path)", us, B * K * (8 + 8 * d)))
-            us = timeit(lambda: k.gather_backward(x, idx5, sorted_index=True))
-            rows.append(("K3 backward s=5 (sorted path)", us, B * K * (8 + 8 * d)))
+            for which, label in ((1, "source tiles + zero fill"), (0, "destination tiles")):
+                k._lib.aesmc_set_sorted_backward_kernel(which)
+                us = timeit(lambda: k.gather_backward(x, idx, sorted_index=True))
+                rows.append(("K3 backward s=1 ({})".format(label), us, B * K * (8 + 8 * d)))
+                us = timeit(lambda: k.gather_backward(x, idx5, sorted_index=True))
+                rows.append(("K3 backward s=5 ({})".format(label), us, B * K * (8 + 8 * d)))
             us = timeit(lambda: k.gather_backward(x, idx))
             rows.append(("K3 backward s=1 (atomic path)", us, B * K * (8 + 8 * d)))
             scale = torch.tensor(0.7, device=dev).expand(B, K, d)
@@ -74,7 +76,7 @@ def main(names):
             us = timeit(lambda: x.clone())
             rows.append(("torch clone [B,K,d] (copy roof)", us, B * K * 8 * d))
         for label, us, nbytes in rows:
-            print("  {:34s} {:9.2f} us  {:8.1f} GB/s".format(label, us, nbytes / us / 1e3))
+            print("  {:46s} {:9.2f} us  {:8.1f} GB/s".format(label, us, nbytes / us / 1e3))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
-"""Fused resampling step vs its parts at the BASELINE.json shapes (same timing method as
-tools/kbench.py).  Usage: python tools/stepbench.py [c2 c4 c4s c5]"""
+"""Fused resampling step vs its parts at the BASELINE.json shapes, and the step for every number
+of workgroups per batch row (`aesmc_set_step_parts`).  Timing: calls captured in one hipGraph and
+replayed (device time, no host gaps).  Usage: python tools/stepbench.py [c2 c4s c4 c5]"""
 import os
 import sys
 
@@ -36,6 +37,7 @@ def timeit(fn, reps=20, replays=5):
 
 def main(names):
     k = _kernels.get()
+    lib = k._lib
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(0)
     for name in names:
@@ -45,16 +47,30 @@ def main(names):
             lw = s * torch.randn(B, K, device=dev, generator=gen)
             u = torch.rand(B, device=dev, dtype=torch.float64, generator=gen)
             x = torch.randn(B, K, d, device=dev, generator=gen)
+            lib.aesmc_set_step_parts(0)
             t_k1 = timeit(lambda: k.logweight_lse(lw, None, None, want_lw=False, want_lse=True))
             t_k2 = timeit(lambda: k.ancestor_index(lw, u))
             idx = k.ancestor_index(lw, u)
             t_k3 = timeit(lambda: k.gather(x, idx))
             t_idx_lse = timeit(lambda: k.resample_step(lw, u, None, want_lse=True))
-            t_fused = timeit(lambda: k.resample_step(lw, u, x, want_lse=True))
-            print("  s={}: K1 {:.2f}  K2 {:.2f}  K3 {:.2f}  sum {:.2f} | step(idx+lse) {:.2f}  "
-                  "step(idx+lse+gather) {:.2f} us".format(s, t_k1, t_k2, t_k3, t_k1 + t_k2 + t_k3, t_idx_lse,
-                                                          t_fused))
+            unique = (int((idx[:, 1:] != idx[:, :-1]).sum()) + B) / (B * K)
+            print("  s={} unique={:.3f}: K1 {:.2f}  K2 {:.2f}  K3 {:.2f}  sum {:.2f} | step(idx+lse) {:.2f} us".format(
+                s, unique, t_k1, t_k2, t_k3, t_k1 + t_k2 + t_k3, t_idx_lse))
+            if k.resample_step(lw, u, x, want_lse=True) is None:
+                print("    fused step declines this payload")
+                continue
+            algorithmic = B * K * (20 + 8 * d) + 8 * B
+            moved = B * K * 12 + (1 + unique) * B * K * d * 4
+            want = k.resample_step(lw, u, x, want_lse=True)
+            for parts in (0, 1, 2, 4, 8):
+                lib.aesmc_set_step_parts(parts)
+                got = k.resample_step(lw, u, x, want_lse=True)
+                same = all(torch.equal(a, b) for a, b in zip(got, want))
+                t = timeit(lambda: k.resample_step(lw, u, x, want_lse=True))
+                print("    step(idx+lse+gather) parts={} : {:7.2f} us  {:6.2f} TB/s algorithmic  {:6.2f} TB/s moved  same={}".format(
+                    parts or "auto", t, algorithmic / t / 1e6, moved / t / 1e6, same))
+            lib.aesmc_set_step_parts(0)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["c2", "c4"])
+    main(sys.argv[1:] or ["c2", "c4s", "c4"])
