@@ -84,8 +84,10 @@ class KernelTimer:
                 entry[1][slot] = (fn, nbytes, keepalive)
 
     def summary(self, repeats=3):
+        provider = get()
+        provider.timer = None       # the replays (and the K7 call below) must not be noted again
         out = {}
-        for name, (count, sample) in self.launches.items():
+        for name, (count, sample) in list(self.launches.items()):
             torch.cuda.synchronize()
             for fn, _, _ in sample:  # warm
                 fn()
@@ -207,6 +209,43 @@ class HipKernels:
         if want_lw and not need_lw:
             lw = a
         return lw, lse
+
+    def logweight_accumulate(self, a, b, c, acc, want_lw=True, want_lse=False):
+        """K1 with the running sum over time of importance sampling: lw = a + b - c (b, c optional),
+        total = acc + lw, lse[b] = logsumexp_k total.  Returns (lw or None, total, lse or None)."""
+        _require_hip(a, "log-prob term")
+        tag = _tag(a, "log-prob term")
+        if a.dim() != 2:
+            raise ValueError("aesmc_amd: log-prob terms must be [batch_size, num_particles], got {}"
+                             .format(tuple(a.shape)))
+        for t in (b, c, acc):
+            if t is not None:
+                _require_hip(t, "log-prob term")
+                if t.shape != a.shape or t.dtype != a.dtype or t.device != a.device:
+                    raise ValueError("aesmc_amd: log-prob terms disagree: {} {} {} vs {} {} {}".format(
+                        tuple(t.shape), t.dtype, t.device, tuple(a.shape), a.dtype, a.device))
+        if acc is None:
+            raise ValueError("aesmc_amd: logweight_accumulate needs the running sum")
+        a, b, c, acc = [None if t is None else t.contiguous() for t in (a, b, c, acc)]
+        B, K = a.shape
+        need_lw = want_lw and not (b is None and c is None)
+        lw = torch.empty_like(a) if need_lw else None
+        total = torch.empty_like(a)
+        lse = torch.empty(B, dtype=a.dtype, device=a.device) if want_lse else None
+        if a.numel() == 0:
+            return (lw if need_lw else (a if want_lw else None)), total, lse
+        with _on_device(a.device):
+            args = (tag, _ptr(a), _ptr(b), _ptr(c), _ptr(acc), _ptr(lw), _ptr(total), _ptr(lse), B, K,
+                    self._stream(a))
+            _lib.check(self._lib.aesmc_logweight_accumulate(*args), "aesmc_logweight_accumulate")
+            if self.timer is not None:
+                esz = a.element_size()
+                terms = 3 + (b is not None) + (c is not None) + (lw is not None)
+                self.timer.note("logweight_accumulate", lambda: self._lib.aesmc_logweight_accumulate(*args),
+                                B * K * esz * terms + (B * esz if want_lse else 0), (a, b, c, acc, lw, total, lse))
+        if want_lw and not need_lw:
+            lw = a
+        return lw, total, lse
 
     def logweight_lse_backward(self, lw, lse, grad_lw, grad_lse, want_neg=True):
         _require_hip(lw, "lw")

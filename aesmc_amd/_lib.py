@@ -35,6 +35,7 @@ SIGNATURES = {
     "aesmc_version": (_i32, []),
     "aesmc_target_arch": (ctypes.c_char_p, []),
     "aesmc_logweight_lse": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "aesmc_logweight_accumulate": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_logweight_lse_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_ancestor_index": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "aesmc_ancestor_index_lds_max_particles": (_i64, []),

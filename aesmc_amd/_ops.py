@@ -37,6 +37,47 @@ class _LogWeightLSE(torch.autograd.Function):
                 ng if need_c else None)
 
 
+class _LogWeightAccumulate(torch.autograd.Function):
+    """(lw, total, lse) = (a + b - c, acc + lw, logsumexp_k total): K1 with the running sum over time
+    that importance sampling normalises (aesmc/inference.py:156-159)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, acc, want_lse):
+        ctx.set_materialize_grads(False)
+        lw, total, lse = _kernels.get().logweight_accumulate(a, b, c, acc, want_lw=True, want_lse=want_lse)
+        ctx.save_for_backward(total, lse)
+        ctx.has = (b is not None, c is not None)
+        if lw is a:
+            lw = a.view_as(a)
+        return lw, total, lse
+
+    @staticmethod
+    def backward(ctx, grad_lw, grad_total, grad_lse):
+        if grad_lw is None and grad_total is None and grad_lse is None:
+            return None, None, None, None, None
+        total, lse = ctx.saved_tensors
+        has_b, has_c = ctx.has
+        # d total / d lw = d total / d acc = 1;  d lse / d total = softmax(total)
+        if grad_lse is not None and lse is not None:
+            through, _ = _kernels.get().logweight_lse_backward(total, lse, grad_total, grad_lse, want_neg=False)
+        else:
+            through = grad_total
+        g = through if grad_lw is None else (grad_lw if through is None else through + grad_lw)
+        need_c = has_c and ctx.needs_input_grad[2]
+        return (g if ctx.needs_input_grad[0] else None,
+                g if (has_b and ctx.needs_input_grad[1]) else None,
+                (-g if g is not None else None) if need_c else None,
+                through if ctx.needs_input_grad[3] else None, None)
+
+
+def logweight_accumulate(a, b, c, acc, want_lse=False):
+    """One importance-sampling step's bookkeeping in one launch: returns (log_weight = a + b - c,
+    running sum acc + log_weight, its logsumexp over particles or None)."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (a, b, c, acc)):
+        return _LogWeightAccumulate.apply(a, b, c, acc, want_lse)
+    return _kernels.get().logweight_accumulate(a, b, c, acc, want_lw=True, want_lse=want_lse)
+
+
 class _ResampleGather(torch.autograd.Function):
     """value[b, idx[b,k], ...] with a segmented-sum backward; idx carries no gradient."""
 

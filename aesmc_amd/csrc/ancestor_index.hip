@@ -538,10 +538,12 @@ static int pick_threads(int64_t K, int chunk) {
   return (int)nt;
 }
 
-// Workgroups per batch row of the fused step.  One workgroup per row leaves CUs idle below ~1000
-// rows and is then capped by what ONE CU pulls from HBM (~24 GB/s: 160 KB of payload per row at
-// K=4096 d=10 take 7 us); sharing a row's output among `parts` workgroups (each repeating the cheap
-// scan) fills the chip.  0 = automatic; aesmc_set_step_parts() pins a value (tuning / tests).
+// Workgroups per batch row of the fused step.  One workgroup per row leaves half the CUs idle below
+// 256 rows; sharing a row's OUTPUT between two workgroups (each repeating the scan) fills them.
+// Measured (tools/stepbench.py, N(0,1) weights): B=128 K=4096 d=10: 16.6 us with 1, 15.2 with 2, 16.6
+// with 4, 22.8 with 8 workgroups per row; B=256 K=1024: 9.2 / 8.95 / 10.0 / 10.1; B=1024 K=4096:
+// 81.6 / 84.9 / 98.4 / 141.8 — the repeated scan (float64 exp + two scans per particle) costs more
+// than the shorter copy returns beyond two.  0 = automatic; aesmc_set_step_parts() pins a value.
 static int g_step_parts = 0;
 
 static int pick_parts(int64_t B, int nt, bool has_payload) {
@@ -549,9 +551,7 @@ static int pick_parts(int64_t B, int nt, bool has_payload) {
   if (limit > 8) limit = 8;
   if (g_step_parts > 0) return g_step_parts < limit ? g_step_parts : limit;
   if (!has_payload) return 1;
-  int parts = 1;
-  while (parts < limit && B * parts < 768) parts *= 2;
-  return parts;
+  return (B <= 256 && limit >= 2) ? 2 : 1;
 }
 
 template <typename T, int C>

@@ -17,7 +17,8 @@ constexpr int kBlock = 256;
 template <typename T, int TPR, bool VEC>
 __global__ __launch_bounds__(kBlock) void logweight_lse_kernel(
     const T *__restrict__ a, const T *__restrict__ b, const T *__restrict__ c, T *out_lw,
-    T *__restrict__ out_lse, int64_t B, int64_t K, int stream) {
+    T *__restrict__ out_lse, int64_t B, int64_t K, int stream, const T *__restrict__ acc_in,
+    T *__restrict__ out_acc) {
   constexpr int ROWS = kBlock / TPR;
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
@@ -37,6 +38,10 @@ __global__ __launch_bounds__(kBlock) void logweight_lse_kernel(
       const V *bv = b ? reinterpret_cast<const V *>(b + base) : nullptr;
       const V *cv = c ? reinterpret_cast<const V *>(c + base) : nullptr;
       V *ov = out_lw ? reinterpret_cast<V *>(out_lw + base) : nullptr;
+      // running sum over time (importance sampling, aesmc/inference.py:157): total = acc_in + lw is
+      // written to out_acc and is what the row log-sum-exp is taken of
+      const V *accv = acc_in ? reinterpret_cast<const V *>(acc_in + base) : nullptr;
+      V *oaccv = acc_in ? reinterpret_cast<V *>(out_acc + base) : nullptr;
       // U vectors per input in flight per lane before any arithmetic: the running (max, sum) pair
       // is a serial chain, so without this the loads of the next trip wait behind it.
       constexpr int U = 4;
@@ -82,6 +87,16 @@ __global__ __launch_bounds__(kBlock) void logweight_lse_kernel(
           const int64_t i = i0 + (int64_t)u * TPR;
           if (i < nvec) {
             if (ov) ov[i] = x[u];
+            if (accv) {
+              const V y = accv[i];
+              x[u].x = y.x + x[u].x;
+              x[u].y = y.y + x[u].y;
+              if constexpr (N == 4) {
+                x[u].z = y.z + x[u].z;
+                x[u].w = y.w + x[u].w;
+              }
+              oaccv[i] = x[u];
+            }
             T vals[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) vals[j] = Vec16<T>::get(x[u], j);
@@ -95,6 +110,10 @@ __global__ __launch_bounds__(kBlock) void logweight_lse_kernel(
         if (b) x += b[base + k];
         if (c) x -= c[base + k];
         if (out_lw) out_lw[base + k] = x;
+        if (acc_in) {
+          x = acc_in[base + k] + x;
+          out_acc[base + k] = x;
+        }
         st.push(x);
       }
     }
@@ -198,9 +217,10 @@ static inline bool aligned16(const void *p) { return p == nullptr || ((uintptr_t
 
 template <typename T>
 static int launch_fwd(const void *a, const void *b, const void *c, void *lw, void *lse, int64_t B,
-                      int64_t K, hipStream_t s) {
+                      int64_t K, hipStream_t s, const void *acc_in = nullptr, void *out_acc = nullptr) {
   constexpr int N = Vec16<T>::N;
-  const bool vec = (K % N == 0) && aligned16(a) && aligned16(b) && aligned16(c) && aligned16(lw);
+  const bool vec = (K % N == 0) && aligned16(a) && aligned16(b) && aligned16(c) && aligned16(lw) &&
+                   aligned16(acc_in) && aligned16(out_acc);
   const bool wide = use_whole_workgroup_per_row(B, K);
   const int rows = wide ? 1 : kBlock / kWave;
   const int64_t grid64 = (B + rows - 1) / rows;
@@ -211,18 +231,20 @@ static int launch_fwd(const void *a, const void *b, const void *c, void *lw, voi
   auto C = (const T *)c;
   auto L = (T *)lw;
   auto S = (T *)lse;
+  auto AI = (const T *)acc_in;
+  auto AO = (T *)out_acc;
   const int stream = stream_hint((uint64_t)B * (uint64_t)K * sizeof(T) *
-                                 (1 + (b != nullptr) + (c != nullptr) + (lw != nullptr)));
+                                 (1 + (b != nullptr) + (c != nullptr) + (lw != nullptr) + 2 * (acc_in != nullptr)));
   if (wide) {
     if (vec)
-      hipLaunchKernelGGL((logweight_lse_kernel<T, 256, true>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream);
+      hipLaunchKernelGGL((logweight_lse_kernel<T, 256, true>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream, AI, AO);
     else
-      hipLaunchKernelGGL((logweight_lse_kernel<T, 256, false>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream);
+      hipLaunchKernelGGL((logweight_lse_kernel<T, 256, false>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream, AI, AO);
   } else {
     if (vec)
-      hipLaunchKernelGGL((logweight_lse_kernel<T, 64, true>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream);
+      hipLaunchKernelGGL((logweight_lse_kernel<T, 64, true>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream, AI, AO);
     else
-      hipLaunchKernelGGL((logweight_lse_kernel<T, 64, false>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream);
+      hipLaunchKernelGGL((logweight_lse_kernel<T, 64, false>), grid, block, 0, s, A, Bp, C, L, S, B, K, stream, AI, AO);
   }
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
@@ -269,6 +291,21 @@ extern "C" int aesmc_logweight_lse(int dtype, const void *lp_a, const void *lp_b
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AESMC_F32) return aesmc::launch_fwd<float>(lp_a, lp_b, lp_c, out_lw, out_lse, B, K, s);
   if (dtype == AESMC_F64) return aesmc::launch_fwd<double>(lp_a, lp_b, lp_c, out_lw, out_lse, B, K, s);
+  return AESMC_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int aesmc_logweight_accumulate(int dtype, const void *lp_a, const void *lp_b, const void *lp_c,
+                                          const void *acc_in, void *out_lw, void *out_acc, void *out_lse,
+                                          int64_t B, int64_t K, void *stream) {
+  if (lp_a == nullptr || acc_in == nullptr || out_acc == nullptr || B < 0 || K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (B == 0) return AESMC_OK;
+  if (K == 0 && out_lse == nullptr) return AESMC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AESMC_F32)
+    return aesmc::launch_fwd<float>(lp_a, lp_b, lp_c, out_lw, out_lse, B, K, s, acc_in, out_acc);
+  if (dtype == AESMC_F64)
+    return aesmc::launch_fwd<double>(lp_a, lp_b, lp_c, out_lw, out_lse, B, K, s, acc_in, out_acc);
   return AESMC_ERR_INVALID_ARGUMENT;
 }
 

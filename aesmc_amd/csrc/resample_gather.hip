@@ -286,189 +286,198 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_sorted_kerne
   }
 }
 
-// Backward for SORTED indices, destination-centric (the one that runs; the kernel above stays as the
-// fallback for rows too wide to stage).  One workgroup owns a tile of TJ consecutive DESTINATION
-// rows j of one batch row.  Because idx is non-decreasing, the particles whose ancestor falls in
-// the tile form ONE contiguous range [p_lo, p_hi) of k, found by two cooperative 128-ary searches
-// (two rounds up to K = 16384).  The range is walked in chunks of TJ particles: indices and
-// gradient rows staged in LDS by coalesced 16-byte loads, every maximal piece of equal indices
-// summed by one lane per (piece, column) in k order and added to the tile's accumulator in LDS (a
-// chunk lying wholly inside one run is column-summed by all 256 lanes).  Finally the accumulator —
-// zero for rows without offspring — is stored with 16-byte stores.  Every destination row is written
-// exactly once: no zero-fill launch, no atomics, no look-back into other tiles, and a fixed
-// summation order (bitwise reproducible).  Each tile also checks its own slice of k for descents
-// and out-of-range entries, so every particle is checked once.
-constexpr int kDestBlock = 256;
-
-template <typename T, bool VEC>
-__global__ __launch_bounds__(kDestBlock) void resample_gather_bwd_dest_kernel(
+// Backward for SORTED indices without a zero-fill launch (the one that runs).  Same source tiles,
+// run detection and look-back as the kernel above, but every destination row is written exactly
+// once: idx being non-decreasing, the rows a tile is responsible for form ONE contiguous range
+//     ( idx[k0 - 1], idx[k0 + n - 1] ]        (from the row of the particle before the tile,
+//                                              exclusive, to the row of its last particle)
+// trimmed at either end: the first row belongs to it only when that run, begun in an earlier tile,
+// ends here; the last row only when its run ends here; the tile holding particle K - 1 also owns
+// everything up to row K - 1.  Rows of the range with a run ending here receive their sum, the
+// others — particles without offspring — zero.  Ranges of up to `cap` rows (the usual case: a tile
+// of 256 particles covers about 256 rows) are assembled in LDS and stored as one dense, coalesced
+// block; longer ranges (collapsed particle systems) mark the summed rows in an LDS bitmap and
+// store zeros to the rest directly.
+template <typename T, bool VEC_LOAD>
+__global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel(
     const T *__restrict__ grad_out, const int64_t *__restrict__ idx, T *__restrict__ grad_src,
-    int32_t *flags, uint32_t K, uint32_t D, uint32_t TJ, uint32_t tiles_per_row) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dest_smem[];
-  constexpr uint32_t N = Vec16<T>::N;
-  const uint32_t tile_elems = (TJ * D + N - 1) / N * N;
-  T *acc = reinterpret_cast<T *>(dest_smem);                   // [tile_elems] sums for the tile's rows
-  T *G = acc + tile_elems;                                     // [tile_elems + 2N] staged gradient rows
-  T *partials = G + tile_elems + 2 * N;                        // [256]
-  int *ids = reinterpret_cast<int *>(partials + kDestBlock);   // [TJ] chunk indices minus j0 (-1: skip)
-  int *tails = ids + TJ;                                       // [TJ] positions of piece tails, compacted
-  int *head_of = tails + TJ;                                   // [TJ] position of the piece head at or before i
-  int *sh = head_of + TJ;                                      // [16] scratch
+    int32_t *flags, uint32_t K, uint32_t D, uint32_t TK, uint32_t tiles_per_row, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char range_smem[];
+  T *G = reinterpret_cast<T *>(range_smem);                    // [TK * D] staged gradient rows
+  T *lead = G + (size_t)TK * D;                                // [D] rows of the first run before the tile
+  T *partials = lead + D;                                      // [256] per-lane partial sums of `lead`
+  T *acc = partials + kSortedBlock;                            // [cap * D] the tile's dense destination range
+  int *ids = reinterpret_cast<int *>(acc + (size_t)cap * D);   // [TK + 2]: before, tile, after
+  int *tails = ids + TK + 2;                                   // [TK] positions of run tails, compacted
+  int *head_of = tails + TK;                                   // [TK] position of the run head at or before i (-1: earlier tile)
+  int *wave_tails = head_of + TK;                              // [4] tails per wavefront
+  int *wave_head = wave_tails + 4;                             // [4] last head position per wavefront
+  int *shared_lo = wave_head + 4;                              // [1]
+  unsigned *has = reinterpret_cast<unsigned *>(shared_lo + 1); // [(K + 31) / 32] long ranges: rows that get a sum
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid % kWave, wave = tid / kWave;
   const uint32_t b = blockIdx.x / tiles_per_row;
-  const uint32_t j0 = (blockIdx.x - b * tiles_per_row) * TJ;
-  const uint32_t nj = min(TJ, K - j0);
+  const uint32_t k0 = (blockIdx.x - b * tiles_per_row) * TK;
+  const uint32_t n = min(TK, K - k0);
   const uint64_t row_base = (uint64_t)b * K;
   const int64_t *irow = idx + row_base;
   const T *grow = grad_out + row_base * D;
-  T *drow = grad_src + (row_base + j0) * D;
+  T *drow = grad_src + row_base * D;
 
-  for (uint32_t e = tid; e < nj * D; e += kDestBlock) acc[e] = T(0);
-
-  // ---- the promise: this tile's slice of k is in range and has no descent ------------------------
-  if (tid < nj) {
-    const uint32_t k = j0 + tid;
-    const int64_t a = irow[k];
-    int64_t before = __shfl_up(a, 1, kWave);
-    if (lane == 0) before = k > 0 ? irow[k - 1] : a;
-    int bad = 0;
-    if (a < before) bad |= AESMC_FLAG_UNSORTED_INDEX;
-    if ((uint64_t)a >= (uint64_t)K) bad |= AESMC_FLAG_INDEX_OUT_OF_RANGE;
-    if (bad) raise_flag(flags, bad);
-  }
-
-  // ---- [p_lo, p_hi): particles whose ancestor lies in [j0, j0 + nj) --------------------------------
-  // Lanes 0..127 count the entries below j0, lanes 128..255 those below j0 + nj.  A round probes
-  // the last entry of each of up to 128 equal blocks of the open range [lo, hi): `cnt` probes are
-  // below the target, so the count lies in [lo + cnt step, min(lo + cnt step + step - 1, hi)].
-  const uint32_t half = tid >> 7, t = tid & 127u;
-  const int64_t target = (int64_t)j0 + (half ? (int64_t)nj : 0);
-  uint32_t lo = 0, hi = K;
-  for (;;) {
-    // both halves iterate together until both ranges are closed (uniform exit through LDS)
-    const uint32_t n = hi - lo;
-    const uint32_t step = (n + 127u) / 128u;
-    bool below = false;
-    if (n > 0) {
-      const uint64_t q = (uint64_t)lo + (uint64_t)(t + 1) * step - 1;
-      below = q < hi && irow[q] < target;
+  // ---- 1. indices: the tile, the particle before it and the one after ---------------------------
+  int bad = 0;
+  for (uint32_t i = tid; i < n + 2; i += kSortedBlock) {
+    const int64_t k = (int64_t)k0 + i - 1;                     // ids[0] = particle k0 - 1, ids[n + 1] = k0 + n
+    int64_t a = (k < 0) ? -1 : (k >= (int64_t)K ? (int64_t)K : irow[k]);
+    if (k >= 0 && k < (int64_t)K && (uint64_t)a >= (uint64_t)K) {
+      bad |= AESMC_FLAG_INDEX_OUT_OF_RANGE;
+      a = a < 0 ? -1 : (int64_t)K;                             // contributes nothing, stays memory-safe
     }
-    const unsigned long long mask = __ballot(below);
-    if (lane == 0) sh[wave] = __popcll(mask);
-    __syncthreads();
-    const uint32_t cnt = (uint32_t)(sh[2 * half] + sh[2 * half + 1]);
-    if (n > 0) {
-      lo = lo + cnt * step;
-      hi = min(lo + step - 1, hi);
-    }
-    if (tid == 0) sh[4] = 0;
-    __syncthreads();
-    if (hi > lo && t == 0) sh[4] = 1;       // benign race: every writer stores 1
-    __syncthreads();
-    const int open = sh[4];
-    __syncthreads();
-    if (!open) break;
-  }
-  if (t == 0) sh[8 + half] = (int)lo;
-  __syncthreads();
-  const uint32_t p_lo = (uint32_t)sh[8], p_hi = (uint32_t)sh[9];
-
-  // ---- walk the range in chunks of TJ particles ------------------------------------------------------
-  const uint32_t cols = min(D, (uint32_t)kDestBlock), slots = kDestBlock / cols;
-  for (uint32_t p = p_lo; p < p_hi; p += TJ) {
-    const uint32_t np = min(TJ, p_hi - p);
-    __syncthreads();                                           // the previous chunk's LDS reads are done
-    if (tid < np) {
-      const int64_t a = irow[p + tid] - (int64_t)j0;
-      ids[tid] = (a >= 0 && a < (int64_t)nj) ? (int)a : -1;    // outside the tile only if the promise is broken
-    }
-    const uint64_t e_begin = (uint64_t)p * D;
-    uint32_t off = 0;
-    if constexpr (VEC) {
-      using V = typename Vec16<T>::type;
-      const uint64_t a0 = e_begin & ~(uint64_t)(N - 1);
-      off = (uint32_t)(e_begin - a0);
-      const uint32_t nv = (off + np * D + N - 1) / N;
-      const V *src = reinterpret_cast<const V *>(grow + a0);
-      V *dst = reinterpret_cast<V *>(G);
-      for (uint32_t v = tid; v < nv; v += kDestBlock) dst[v] = src[v];
-    } else {
-      for (uint32_t e = tid; e < np * D; e += kDestBlock) G[e] = grow[e_begin + e];
-    }
-    __syncthreads();
-    const bool live = tid < np;
-    const int mine = live ? ids[tid] : -2;
-    const bool is_head = live && (tid == 0 || ids[tid - 1] != mine);
-    const bool is_tail = live && (tid == np - 1 || ids[tid + 1] != mine);
-    const unsigned long long tail_mask = __ballot(is_tail);
-    const unsigned long long head_mask = __ballot(is_head);
-    const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);  // lanes <= mine
-    if (lane == 0) {
-      sh[wave] = __popcll(tail_mask);
-      sh[4 + wave] = head_mask ? (int)(wave * kWave + 63 - __clzll(head_mask)) : -1;
-    }
-    __syncthreads();
-    int tail_base = 0, head_before = 0;
-    for (uint32_t w = 0; w < wave; ++w) {
-      tail_base += sh[w];
-      if (sh[4 + w] >= 0) head_before = sh[4 + w];
-    }
-    const uint32_t pieces = (uint32_t)(sh[0] + sh[1] + sh[2] + sh[3]);
-    if (live) {
-      const unsigned long long heads_here = head_mask & upto;
-      head_of[tid] = heads_here ? (int)(wave * kWave + 63 - __clzll(heads_here)) : head_before;
-      if (is_tail) tails[tail_base + __popcll(tail_mask & upto) - 1] = (int)tid;
-    }
-    __syncthreads();
-    const T *rows = G + off;
-    if (pieces == 1 && np >= 64) {
-      // the whole chunk descends from one particle: column sums by all lanes, fixed order
-      const int id = ids[0];
-      const uint32_t slot = tid / cols, col = tid - slot * cols;
-      for (uint32_t cbase = 0; cbase < D; cbase += cols) {
-        const uint32_t c = cbase + col;
-        T a[4] = {T(0), T(0), T(0), T(0)};
-        if (slot < slots && c < D) {
-          uint32_t i = slot;
-          for (; i + 3 * slots < np; i += 4 * slots) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] += rows[(i + q * slots) * D + c];
-          }
-          for (; i < np; i += slots) a[0] += rows[i * D + c];
-        }
-        if (slot < slots) partials[slot * cols + col] = (a[0] + a[1]) + (a[2] + a[3]);
-        __syncthreads();
-        if (tid < cols && cbase + tid < D && id >= 0) {
-          T sum = T(0);
-          for (uint32_t s2 = 0; s2 < slots; ++s2) sum += partials[s2 * cols + tid];
-          acc[(uint32_t)id * D + cbase + tid] += sum;
-        }
-        __syncthreads();
-      }
-    } else {
-      const uint32_t total = pieces * D;
-      for (uint32_t e = tid; e < total; e += kDestBlock) {
-        const uint32_t piece = e / D, c = e - piece * D;
-        const int i = tails[piece];
-        const int id = ids[i];
-        if (id < 0) continue;
-        T sum = T(0);
-        for (int r = head_of[i]; r <= i; ++r) sum += rows[(uint32_t)r * D + c];
-        acc[(uint32_t)id * D + c] += sum;
-      }
-    }
+    ids[i] = (int)a;
   }
   __syncthreads();
+  const bool live = tid < n;                                   // TK <= 256: one particle per lane
+  const int mine = live ? ids[1 + tid] : -2;
+  const bool is_head = live && ids[tid] != mine;
+  const bool is_tail = live && ids[2 + tid] != mine;
+  if (live && mine < ids[tid]) bad |= AESMC_FLAG_UNSORTED_INDEX;
+  if (live && tid == n - 1 && k0 + n < K && ids[n + 1] < mine) bad |= AESMC_FLAG_UNSORTED_INDEX;
+  if (bad) raise_flag(flags, bad);
+  const unsigned long long tail_mask = __ballot(is_tail);
+  const unsigned long long head_mask = __ballot(is_head);
+  const unsigned long long below = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);  // lanes <= mine
+  if (lane == 0) {
+    wave_tails[wave] = __popcll(tail_mask);
+    wave_head[wave] = head_mask ? (int)(wave * kWave + 63 - __clzll(head_mask)) : -1;
+  }
+  __syncthreads();
+  int tail_base = 0, head_before = -1;
+  for (uint32_t w = 0; w < wave; ++w) {
+    tail_base += wave_tails[w];
+    if (wave_head[w] >= 0) head_before = wave_head[w];
+  }
+  const int num_tails = wave_tails[0] + wave_tails[1] + wave_tails[2] + wave_tails[3];
+  if (live) {
+    const unsigned long long heads_here = head_mask & below;
+    head_of[tid] = heads_here ? (int)(wave * kWave + 63 - __clzll(heads_here)) : head_before;
+    if (is_tail) tails[tail_base + __popcll(tail_mask & below) - 1] = (int)tid;
+  }
 
-  // ---- every row of the tile is written exactly once ---------------------------------------------------
-  if constexpr (VEC) {
-    using V = typename Vec16<T>::type;
-    V *dst = reinterpret_cast<V *>(drow);
-    const V *src = reinterpret_cast<const V *>(acc);
-    for (uint32_t v = tid; v < nj * D / N; v += kDestBlock) dst[v] = src[v];
+  // ---- the destination rows this tile writes: [jlo, jhi] -------------------------------------------
+  const int before = ids[0], first_id = ids[1], last_id = ids[n], after = ids[n + 1];
+  const bool has_lead = (k0 > 0) && (first_id == before) && first_id >= 0 && first_id < (int)K;
+  // the run entering from the left ends here unless the whole tile belongs to it and it flows on
+  const bool lead_ends_here = has_lead && !(last_id == first_id && after == last_id);
+  int jlo = (has_lead && lead_ends_here) ? before : before + 1;
+  int jhi = (k0 + n == K) ? (int)K - 1 : ((after == last_id) ? last_id - 1 : last_id);
+  if (jlo < 0) jlo = 0;
+  if (jhi > (int)K - 1) jhi = (int)K - 1;
+  const uint32_t L = jhi >= jlo ? (uint32_t)(jhi - jlo + 1) : 0u;
+  if (L == 0) return;                                          // wholly inside one run that flows on
+  const bool dense = L <= cap;
+  if (dense) {
+    for (uint32_t e = tid; e < L * D; e += kSortedBlock) acc[e] = T(0);
   } else {
-    for (uint32_t e = tid; e < nj * D; e += kDestBlock) drow[e] = acc[e];
+    for (uint32_t w = tid; w < (L + 31) / 32; w += kSortedBlock) has[w] = 0u;
+  }
+
+  // ---- 2. stage the gradient rows ------------------------------------------------------------------
+  const uint32_t ne = n * D;
+  if (num_tails > 0) {
+    if constexpr (VEC_LOAD) {
+      using V = typename Vec16<T>::type;
+      const V *src = reinterpret_cast<const V *>(grow + (uint64_t)k0 * D);
+      V *dst = reinterpret_cast<V *>(G);
+      for (uint32_t v = tid; v < ne / Vec16<T>::N; v += kSortedBlock) dst[v] = src[v];
+    } else {
+      for (uint32_t e = tid; e < ne; e += kSortedBlock) G[e] = grow[(uint64_t)k0 * D + e];
+    }
+  }
+
+  // ---- 3. rows of the first run that lie before the tile -----------------------------------------
+  if (has_lead && lead_ends_here) {
+    if (tid == 0) *shared_lo = -1;
+    __syncthreads();
+    const int64_t back = (int64_t)k0 - 1 - tid;                // lane's candidate for "last particle before the run"
+    if (tid > 0 && back >= -1) {
+      const bool differs = back < 0 || irow[back] != (int64_t)first_id;
+      if (differs && irow[back + 1] == (int64_t)first_id)
+        *shared_lo = (int)(back + 1);                          // unique lane (ids are sorted): the run's first particle
+    }
+    __syncthreads();
+    uint32_t lo;
+    if (*shared_lo >= 0) {
+      lo = (uint32_t)*shared_lo;
+    } else {                                                   // longer than the look-back: binary search the rest
+      uint32_t l = 0, h = k0 - kSortedBlock;
+      while (l < h) {
+        const uint32_t mid = (l + h) >> 1;
+        if (irow[mid] < (int64_t)first_id) l = mid + 1; else h = mid;
+      }
+      lo = l;
+    }
+    // `slots` lanes share a column and take every slots-th row; their partial sums are combined
+    // through LDS in slot order (fixed order: reproducible).  Control flow is workgroup-uniform.
+    const uint32_t cols = min(D, (uint32_t)kSortedBlock), slots = kSortedBlock / cols;
+    const uint32_t slot = tid / cols, col = tid - slot * cols;
+    for (uint32_t cbase = 0; cbase < D; cbase += cols) {
+      const uint32_t c = cbase + col;
+      T sum = T(0);
+      if (slot < slots && c < D) {
+        // eight independent accumulators keep eight global loads in flight on long runs
+        T a[8] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+        uint32_t i = lo + slot;
+        for (; (uint64_t)i + 7ull * slots < k0; i += 8 * slots) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a[q] += grow[(uint64_t)(i + q * slots) * D + c];
+        }
+        for (; i < k0; i += slots) a[0] += grow[(uint64_t)i * D + c];
+        sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      }
+      if (slot < slots) partials[slot * cols + col] = sum;
+      __syncthreads();
+      if (tid < cols && cbase + tid < D) {
+        T total = T(0);
+        for (uint32_t s2 = 0; s2 < slots; ++s2) total += partials[s2 * cols + tid];
+        lead[cbase + tid] = total;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  // ---- 4. one element per (tail, column) ---------------------------------------------------------
+  const uint32_t total = (uint32_t)num_tails * D;
+  for (uint32_t e = tid; e < total; e += kSortedBlock) {
+    const uint32_t t = e / D, c = e - t * D;
+    const int i = tails[t];
+    const int id = ids[1 + i];
+    if (id < jlo || id > jhi) continue;                        // out-of-range index (reported above)
+    const int h = head_of[i];
+    T sum = (h < 0 && has_lead) ? lead[c] : T(0);
+    for (int r = h < 0 ? 0 : h; r <= i; ++r) sum += G[(uint32_t)r * D + c];
+    if (dense) {
+      acc[(uint32_t)(id - jlo) * D + c] = sum;
+    } else {
+      drow[(uint64_t)id * D + c] = sum;
+      if (c == 0) atomicOr(&has[(uint32_t)(id - jlo) >> 5], 1u << ((uint32_t)(id - jlo) & 31u));
+    }
+  }
+  __syncthreads();
+
+  // ---- 5. the range goes out: sums where a run ended, zeros where a particle left no offspring --------
+  T *out = drow + (uint64_t)jlo * D;
+  if (dense) {
+    for (uint32_t e = tid; e < L * D; e += kSortedBlock) out[e] = acc[e];
+  } else {
+    const uint32_t cols = min(D, (uint32_t)kSortedBlock), per = kSortedBlock / cols;
+    const uint32_t sub = tid / cols, col = tid - sub * cols;
+    if (sub < per) {
+      for (uint32_t j = sub; j < L; j += per) {
+        if (has[j >> 5] & (1u << (j & 31u))) continue;
+        for (uint32_t c = col; c < D; c += cols) out[(uint64_t)j * D + c] = T(0);
+      }
+    }
   }
 }
 
@@ -502,8 +511,9 @@ static void launch_gather(const void *src, const int64_t *idx, void *dst, int32_
 
 using namespace aesmc;
 
-// 0: destination-centric kernel for sorted indices (default); 1: the source-tile kernel behind a
-// zero fill (kept for rows the first declines, and selectable for A/B timing: tools/kbench.py)
+// 0: the range kernel for sorted indices (default: every row written once, no zero fill); 1: the
+// source-tile kernel behind a zero fill (kept for rows the first declines, and selectable for A/B
+// timing: tools/kbench.py)
 static int g_sorted_backward_kernel = 0;
 extern "C" int aesmc_set_sorted_backward_kernel(int which) {
   if (which != 0 && which != 1) return AESMC_ERR_INVALID_ARGUMENT;
@@ -581,31 +591,34 @@ static bool launch_sorted_backward(const void *grad_out, const int64_t *idx, voi
   return true;
 }
 
-// The destination-centric kernel: needs no zero fill.  Declines rows too wide to stage (the caller
-// then zero-fills and runs one of the kernels above).
+// The range kernel: needs no zero fill.  Declines rows too wide to stage (the caller then zero-fills
+// and runs one of the kernels above).
 template <typename T>
-static bool launch_dest_backward(const void *grad_out, const int64_t *idx, void *grad_src,
-                                 int32_t *flags, int64_t B, int64_t K, int64_t D, hipStream_t s) {
+static bool launch_range_backward(const void *grad_out, const int64_t *idx, void *grad_src,
+                                  int32_t *flags, int64_t B, int64_t K, int64_t D, hipStream_t s) {
   constexpr int N = Vec16<T>::N;
   const int64_t row_bytes = D * (int64_t)sizeof(T);
-  int64_t TJ = (28 * 1024) / row_bytes;                        // accumulator + staging: 2 x 28 KiB, under the 64 KiB default cap
-  if (TJ > 256) TJ = 256;
-  if (TJ < 8) return false;
-  const bool vec = (((uintptr_t)grad_out & 15u) == 0) && (((uintptr_t)grad_src & 15u) == 0) &&
-                   ((K * D) % N == 0);
-  if (TJ >= K) TJ = K;
-  else if (vec) TJ -= TJ % N;                                  // every tile starts on a 16-byte boundary
-  const int64_t tiles = (K + TJ - 1) / TJ;
+  int64_t TK = (28 * 1024) / row_bytes;                        // staged rows: at most 28 KiB
+  if (TK > 256) TK = 256;
+  if (TK < 8) return false;
+  if (TK > K) TK = K;
+  int64_t cap = (24 * 1024) / row_bytes;                       // dense destination range: at most 24 KiB
+  if (cap > TK + TK / 2) cap = TK + TK / 2;                    // a tile of TK particles covers about TK rows
+  const int64_t tiles = (K + TK - 1) / TK;
   if (B * tiles > 0x7fffffffLL) return false;
-  const size_t tile_elems = (size_t)((TJ * D + N - 1) / N * N);
-  const size_t lds = (2 * tile_elems + 2 * N + kDestBlock) * sizeof(T) + (size_t)(3 * TJ + 16) * sizeof(int);
-  dim3 grid((unsigned)(B * tiles)), block(kDestBlock);
+  const size_t floats = (size_t)(TK * D + D + kSortedBlock + cap * D);
+  const size_t lds = floats * sizeof(T) + (size_t)(3 * TK + 2 + 9 + (K + 31) / 32) * sizeof(int);
+  if (lds > 64 * 1024) return false;                           // K beyond ~250 000 with wide rows
+  const bool vec = (((uintptr_t)grad_out & 15u) == 0) && ((K * D) % N == 0) && ((TK * D) % N == 0);
+  dim3 grid((unsigned)(B * tiles)), block(kSortedBlock);
   if (vec)
-    hipLaunchKernelGGL((resample_gather_bwd_dest_kernel<T, true>), grid, block, lds, s, (const T *)grad_out,
-                       idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D, (uint32_t)TJ, (uint32_t)tiles);
+    hipLaunchKernelGGL((resample_gather_bwd_range_kernel<T, true>), grid, block, lds, s, (const T *)grad_out,
+                       idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D, (uint32_t)TK, (uint32_t)tiles,
+                       (uint32_t)cap);
   else
-    hipLaunchKernelGGL((resample_gather_bwd_dest_kernel<T, false>), grid, block, lds, s, (const T *)grad_out,
-                       idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D, (uint32_t)TJ, (uint32_t)tiles);
+    hipLaunchKernelGGL((resample_gather_bwd_range_kernel<T, false>), grid, block, lds, s, (const T *)grad_out,
+                       idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D, (uint32_t)TK, (uint32_t)tiles,
+                       (uint32_t)cap);
   return true;
 }
 
@@ -623,8 +636,8 @@ extern "C" int aesmc_resample_gather_backward(int dtype, const void *grad_out, c
   const uint64_t re = (uint64_t)K * (uint64_t)row_elems;
   if (index_is_sorted && g_sorted_backward_kernel == 0) {
     const bool launched = dtype == AESMC_F32
-        ? launch_dest_backward<float>(grad_out, idx, grad_src, flags, B, K, row_elems, s)
-        : launch_dest_backward<double>(grad_out, idx, grad_src, flags, B, K, row_elems, s);
+        ? launch_range_backward<float>(grad_out, idx, grad_src, flags, B, K, row_elems, s)
+        : launch_range_backward<double>(grad_out, idx, grad_src, flags, B, K, row_elems, s);
     if (launched) return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
   }
   // the kernels below write only rows that have offspring: everything else must read as zero

@@ -193,6 +193,8 @@ def infer(inference_algorithm, observations, initial, transition, emission,
     indices = []
     log_weights = []
     step_lse = []
+    running = None        # importance sampling: sum over time of the log-weights so far (K1's accumulator)
+    running_lse = None
     feed = None
     device = None
 
@@ -243,17 +245,34 @@ def infer(inference_algorithm, observations, initial, transition, emission,
         if not isinstance(latent, dict) and not isinstance(observation, dict):
             log_weight_t = state.normal_log_weight(prior_dist, proposal_dist, latent, emission_dist,
                                                    observation)
+        # importance sampling over several timesteps normalises the SUM of the per-step weights
+        # (inference.py:156-159); K1 keeps that sum running, left to right as torch.sum over the
+        # reference's stack does, and hands out its row log-sum-exp with the last step
+        accumulate = (not use_smc) and time > 0 and (return_log_marginal_likelihood or return_log_weight)
+        last_step = time + 1 == num_timesteps
         if log_weight_t is not None:
             # K5 gave the log-weights only; their row log-sum-exp comes out of the next resampling
             # launch for free — or from K1 when no resampling follows
             # (importance sampling never needs the per-step value: it normalises the summed weights)
             pending = use_smc and time + 1 < num_timesteps
             lse_t = None if (pending or not use_smc) else _ops.row_logsumexp(log_weight_t)
+            if accumulate:
+                _, running, running_lse = _ops.logweight_accumulate(
+                    log_weight_t, None, None, running, want_lse=last_step and return_log_marginal_likelihood)
         else:
             log_q = state.log_prob(proposal_dist, latent)
             log_p = state.log_prob(prior_dist, latent)
             log_g = state.log_prob(emission_dist, observation)
-            log_weight_t, lse_t = _ops.logweight_lse(log_p, log_g, log_q)
+            if accumulate:
+                log_weight_t, running, running_lse = _ops.logweight_accumulate(
+                    log_p, log_g, log_q, running, want_lse=last_step and return_log_marginal_likelihood)
+                lse_t = None
+            else:
+                log_weight_t, lse_t = _ops.logweight_lse(log_p, log_g, log_q)
+        if not use_smc and time == 0:
+            running = log_weight_t      # the first (or only) step's weights start the running sum
+            if last_step:
+                running_lse = lse_t     # K1 route: already at hand
         log_weights.append(log_weight_t)
         step_lse.append(lse_t)
         device = log_weight_t.device
@@ -270,12 +289,13 @@ def infer(inference_algorithm, observations, initial, transition, emission,
             log_weight = log_weights[-1]
     else:
         if return_log_marginal_likelihood or return_log_weight:
-            # sum over time of the per-step weights (inference.py:157); a single step is its own sum
-            # (no stack + sum passes over [B,K]: 400 MB of traffic at B=4096 K=8192)
-            log_weight = log_weights[0] if num_timesteps == 1 else \
-                torch.sum(torch.stack(log_weights, dim=0), dim=0)
+            # sum over time of the per-step weights (inference.py:157): K1 kept it running, one
+            # launch per step and no [T,B,K] stack; a single step is its own sum
+            log_weight = running
         if return_log_marginal_likelihood:
-            log_marginal_likelihood = _ops.row_logsumexp(log_weight) - log_num_particles
+            if running_lse is None:      # one timestep on the K5 route: no launch has reduced the rows yet
+                running_lse = _ops.row_logsumexp(log_weight)
+            log_marginal_likelihood = running_lse - log_num_particles
         if return_latents:
             latents = originals
         if return_original_latents:

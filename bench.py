@@ -92,6 +92,9 @@ def parse(argv=None):
                     help="initialise the process group and take the sharded code path even with one rank (test hook)")
     ap.add_argument("--mode", default=None, choices=["graph", "eager"],
                     help="graph: replay the whole ELBO as one hipGraph (aesmc_amd.graphs); eager: Python loop")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print what would be launched (N > 1: the torch.distributed.run command and the "
+                         "environment it adds) as JSON and exit without touching the GPU")
     ap.add_argument("--grad", default=None, choices=["on", "off"],
                     help="record the autograd graph during the forward step (default: on where it fits in HBM)")
     return ap.parse_args(argv)
@@ -130,6 +133,10 @@ def self_launch(args, argv):
     """Nothing in this process has touched the GPU (importing torch does not): the N ranks are fresh
     children; their rank 0 prints the one JSON line on the stdout they inherit."""
     command = child_command(argv, args.gpus)
+    if args.dry_run:
+        added = {k: v for k, v in child_environment({}).items()}
+        print(json.dumps({"launch": command, "environment_defaults": added}))
+        return 0
     print("bench.py: launching {} ranks: {}".format(args.gpus, " ".join(command)), file=sys.stderr, flush=True)
     return subprocess.run(command, env=child_environment()).returncode
 
@@ -549,6 +556,11 @@ def main(argv=None):
     args = parse(argv)
     if needs_launcher(args):
         sys.exit(self_launch(args, argv))
+    if args.dry_run:
+        print(json.dumps({"launch": None, "rank": int(os.environ.get("RANK", "0")),
+                          "world_size": int(os.environ.get("WORLD_SIZE", "1")), "workload": args.workload,
+                          "scaling": args.scaling}))
+        return
 
     import numpy as np  # noqa: F401
     import torch

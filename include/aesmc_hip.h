@@ -59,6 +59,21 @@ int aesmc_logweight_lse(int dtype, const void *lp_a, const void *lp_b, const voi
                         void *out_lw, void *out_lse, int64_t B, int64_t K, void *stream);
 
 /*
+ * K1 with a running sum over time — importance sampling with more than one timestep normalises the
+ * SUM of the per-step log-weights (aesmc/inference.py:156-159: torch.sum of a stack of all T weight
+ * tensors, then torch.logsumexp).  One launch per step instead:
+ *   lw[b,k]      = lp_a + lp_b - lp_c          (as K1; out_lw may be NULL when the step's own
+ *                                               weights are not wanted)
+ *   out_acc[b,k] = acc_in[b,k] + lw[b,k]       (left to right over time: the order torch.sum takes
+ *                                               over the leading dim of the stack)
+ *   out_lse[b]   = log sum_k exp(out_acc[b,k]) (may be NULL; asked for at the last step only)
+ * out_acc may alias acc_in.  Same special values as K1.
+ */
+int aesmc_logweight_accumulate(int dtype, const void *lp_a, const void *lp_b, const void *lp_c,
+                               const void *acc_in, void *out_lw, void *out_acc, void *out_lse,
+                               int64_t B, int64_t K, void *stream);
+
+/*
  * K1 backward.  g[b,k] = grad_lw[b,k] + grad_lse[b] * exp(lw[b,k] - lse[b])   (either grad may be
  * NULL = zero).  Writes out_g (gradient w.r.t. lp_a and lp_b) and, if non-NULL, out_neg_g = -g
  * (gradient w.r.t. lp_c).  Replaces autograd of the ops listed under K1.
@@ -109,9 +124,9 @@ int aesmc_resample_gather_backward(int dtype, const void *grad_out, const int64_
                                    void *grad_src, int32_t *flags, int64_t B, int64_t K,
                                    int64_t row_elems, int index_is_sorted, void *stream);
 
-/* Tuning knob: which kernel serves index_is_sorted != 0.  0 (default): destination tiles, every
- * row of grad_src written once, no zero fill; 1: source tiles behind a zero-fill launch (round 1's
- * kernel, still the route for rows wider than 4 KiB).  Same sums up to association order. */
+/* Tuning knob: which kernel serves index_is_sorted != 0.  0 (default): every row of grad_src
+ * written once by the tile that owns its range, no zero fill; 1: the same tiles behind a zero-fill
+ * launch (round 1's kernel, still the route for rows wider than 3.5 KiB).  Identical sums. */
 int aesmc_set_sorted_backward_kernel(int which);
 
 /*

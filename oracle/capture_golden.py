@@ -81,8 +81,20 @@ def _margin(log_weights, uniforms):
     return float(worst)
 
 
-def capture_infer(name, meta, parts, observations, num_particles, algorithm):
-    """Runs the reference's infer (everything returned) and get_loss + backward under one tape."""
+def _flips_per_step(log_weights, uniforms, indices):
+    """Per resampling step: how many of the reference's indices differ from the float64-CDF contract
+    this library implements (oracle/kernel_oracle.py) on the reference's own log-weights."""
+    out = []
+    for lw, u, want in zip(log_weights, uniforms, indices):
+        mine, _ = kernel_oracle.ancestor_index(lw, np.asarray(u, dtype=np.float64).reshape(-1))
+        out.append(int((mine != want).sum()))
+    return out
+
+
+def capture_infer(name, meta, parts, observations, num_particles, algorithm, light=False):
+    """Runs the reference's infer (everything returned) and get_loss + backward under one tape.
+    `light`: large cases keep every input and the per-step log-weights / indices but not the T
+    latent tensors (twice [T,B,K,d])."""
     inference_algorithm = {"iwae": "is", "aesmc": "smc"}[algorithm]
     smc = inference_algorithm == "smc"
     with replay.record() as tape:
@@ -112,13 +124,15 @@ def capture_infer(name, meta, parts, observations, num_particles, algorithm):
         arrays["grad_" + pname] = _np(p.grad) if p.grad is not None else np.zeros(p.shape)
     for t, lw in enumerate(result["log_weights"]):
         arrays["out_log_weights_{}".format(t)] = _np(lw)
-    for t, x in enumerate(result["latents"]):
-        arrays["out_latents_{}".format(t)] = _np(x)
+    if not light:
+        for t, x in enumerate(result["latents"]):
+            arrays["out_latents_{}".format(t)] = _np(x)
     if smc:
         for t, a in enumerate(result["ancestral_indices"]):
             arrays["out_idx_{}".format(t)] = _np(a)
-        for t, x in enumerate(result["original_latents"]):
-            arrays["out_original_latents_{}".format(t)] = _np(x)
+        if not light:
+            for t, x in enumerate(result["original_latents"]):
+                arrays["out_original_latents_{}".format(t)] = _np(x)
     arrays["out_lml"] = _np(result["log_marginal_likelihood"])
     arrays["out_log_weight"] = _np(result["log_weight"])
     arrays["out_last_latent"] = _np(result["last_latent"])
@@ -130,6 +144,12 @@ def capture_infer(name, meta, parts, observations, num_particles, algorithm):
     if smc and len(observations) > 1:
         meta["margin"] = _margin([arrays["out_log_weights_{}".format(t)]
                                   for t in range(len(observations))], tape.uniforms)
+        if light:
+            steps = len(observations) - 1
+            meta["light"] = True
+            meta["flips_vs_float64_cdf"] = _flips_per_step(
+                [arrays["out_log_weights_{}".format(t)] for t in range(steps)], tape.uniforms,
+                [arrays["out_idx_{}".format(t)] for t in range(steps)])
     arrays["meta"] = np.array(json.dumps(meta))
     path = os.path.join(GOLDEN, name + ".npz")
     np.savez_compressed(path, **arrays)
@@ -175,7 +195,7 @@ def case_lgssm1d(name, algorithm, emission_scale, dtype, B=2, K=16, T=8, seed=1)
     capture_infer(name, meta, parts, observations, K, algorithm)
 
 
-def case_lgssm_nd(name, algorithm, dtype, dim=3, B=4, K=256, T=6, seed=3, proposal_scale=0.7):
+def case_lgssm_nd(name, algorithm, dtype, dim=3, B=4, K=256, T=6, seed=3, proposal_scale=0.7, light=False):
     model = my_models.LgssmNd(dim, proposal_scale=proposal_scale, seed=seed, dtype=dtype,
                               state=ref.state)
     observations = model.simulate(T, B, seed=seed + 100)
@@ -185,7 +205,7 @@ def case_lgssm_nd(name, algorithm, dtype, dim=3, B=4, K=256, T=6, seed=3, propos
     torch.manual_seed(seed + 1)
     meta = {"model": "lgssm_nd", "dtype": str(dtype).replace("torch.", ""), "batch_size": B,
             "dim": dim, "seed": seed, "proposal_scale": proposal_scale}
-    capture_infer(name, meta, parts, observations, K, algorithm)
+    capture_infer(name, meta, parts, observations, K, algorithm, light=light)
 
 
 def case_gaussian(name, B=8, K=64, seed=5):
@@ -243,10 +263,18 @@ def case_train(name, algorithm, seed=9):
     np.random.seed(seed + 1)
     dataloader = ref.train.get_synthetic_dataloader(*true_parts, num_timesteps, batch_size)
     losses = []
-    ref.train.train(dataloader, num_particles, algorithm, parts["initial"], parts["transition"],
-                    parts["emission"], parts["proposal"], num_epochs=2, num_iterations_per_epoch=2,
-                    optimizer_algorithm=torch.optim.SGD, optimizer_kwargs={"lr": 0.05},
-                    callback=lambda e, i, loss, *rest: losses.append(float(loss)))
+    # the tape holds every standard-normal block (data generation AND proposal sampling, in the order
+    # drawn) and every resampling uniform block of the whole run: a device whose generator differs
+    # from the CPU's (the MI355X) can replay the run draw for draw
+    with replay.record() as tape:
+        ref.train.train(dataloader, num_particles, algorithm, parts["initial"], parts["transition"],
+                        parts["emission"], parts["proposal"], num_epochs=2, num_iterations_per_epoch=2,
+                        optimizer_algorithm=torch.optim.SGD, optimizer_kwargs={"lr": 0.05},
+                        callback=lambda e, i, loss, *rest: losses.append(float(loss)))
+    for i, block in enumerate(tape.normals):
+        arrays["normal_{}".format(i)] = block
+    for i, block in enumerate(tape.uniforms):
+        arrays["uniform_{}".format(i)] = block
     for k, v in params.items():
         arrays["final_" + k] = _np(v)
     arrays["losses"] = np.array(losses)
@@ -332,6 +360,12 @@ def main():
     # the whole training loop
     case_train("train_iwae_gaussian", "iwae")
     case_train("train_aesmc_lgssm1d", "aesmc")
+    # round 2: the resampler at configs[4]'s particle count, and a configs[1]-like float32 run
+    # (d=10, K=1024, T=20) whose per-step log-weights pin the float32 flip rate on real weights
+    rng = np.random.RandomState(12)
+    case_resampler("resampler_k16384_f64", 2 * rng.randn(4, 16384), 31)
+    case_resampler("resampler_k16384_f32", (2 * rng.randn(4, 16384)).astype(np.float32), 32)
+    case_lgssm_nd("lgssm10d_k1024_smc_f32", "aesmc", f32, dim=10, B=2, K=1024, T=20, seed=11, light=True)
 
 
 if __name__ == "__main__":

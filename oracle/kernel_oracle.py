@@ -36,6 +36,16 @@ def logweight_lse(a, b=None, c=None):
     return lw, lse.astype(a.dtype)
 
 
+def logweight_accumulate(a, b, c, acc):
+    """K1 with the running sum of importance sampling (aesmc/inference.py:156-159: torch.sum over a
+    stack of the per-step weights, left to right): lw = a + b - c, total = acc + lw in the input
+    dtype, lse = logsumexp of total over axis 1.  Returns (lw, total, lse)."""
+    lw, _ = logweight_lse(a, b, c)
+    total = (acc + lw).astype(a.dtype, copy=False)
+    _, lse = logweight_lse(total)
+    return lw, total, lse
+
+
 def logweight_lse_backward(lw, lse, grad_lw, grad_lse):
     """K1 backward: g = grad_lw + grad_lse * softmax(lw); returns (g, -g)."""
     g = np.zeros_like(lw)

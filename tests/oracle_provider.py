@@ -25,6 +25,12 @@ class OracleKernels:
         return (torch.from_numpy(lw) if want_lw else None,
                 torch.from_numpy(lse) if want_lse else None)
 
+    def logweight_accumulate(self, a, b, c, acc, want_lw=True, want_lse=False):
+        arrays = [None if t is None else t.detach().numpy() for t in (a, b, c)]
+        lw, total, lse = kernel_oracle.logweight_accumulate(*arrays, acc.detach().numpy())
+        return (torch.from_numpy(lw) if want_lw else None, torch.from_numpy(total),
+                torch.from_numpy(lse) if want_lse else None)
+
     def logweight_lse_backward(self, lw, lse, grad_lw, grad_lse, want_neg=True):
         g, ng = kernel_oracle.logweight_lse_backward(
             lw.detach().numpy(), lse.detach().numpy(),

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import kernel_oracle
-from tests.golden_io import Golden, RESAMPLER_CASES
+from tests.golden_io import Golden, RESAMPLER_CASES, float32_flip_bound, mismatch_margin, FLOAT32_CDF_NOISE
 
 pytestmark = pytest.mark.gpu
 
@@ -109,8 +109,8 @@ def test_ancestor_index_golden(kernels, hip_device, name):
     if log_w.dtype == np.float64:
         assert mismatches == 0
     else:
-        assert np.abs(idx - case["out_idx"]).max() <= 1
-        assert mismatches <= 2e-3 * idx.size
+        assert mismatch_margin(log_w, u, idx, case["out_idx"]) <= FLOAT32_CDF_NOISE
+        assert mismatches <= float32_flip_bound(log_w.shape[1]) * idx.size
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -1006,3 +1006,150 @@ def test_many_short_rows(kernels, hip_device):
     np.testing.assert_allclose(ess.cpu().numpy(), want_ess, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(mean.cpu().numpy(), want_mean, rtol=2e-5, atol=2e-5)
     assert kernels.read_flags(hip_device) == 0
+
+
+# ---- round 2: workgroups sharing a row, the range backward, K1's running sum ------------------------
+@pytest.mark.parametrize("shape,row", [((2, 64), (4,)), ((3, 1024), (10,)), ((5, 4096), (10,)), ((2, 2048), (3, 4)),
+                                       ((4, 600), (4,)), ((1, 16384), (2,)), ((3, 1000), (1,))])
+def test_resample_step_does_not_depend_on_workgroups_per_row(kernels, hip_device, shape, row):
+    """`aesmc_set_step_parts`: a batch row shared by 1, 2, 4 or 8 workgroups gives the same indices,
+    log-sum-exp and payload bit for bit — including degenerate and NaN rows."""
+    B, K = shape
+    rng = np.random.RandomState(K + B)
+    lw = (rng.randn(B, K) * 2).astype(np.float32)
+    if B >= 3:
+        lw[1, :] = -np.inf
+        lw[2, K // 2] = np.nan
+    lw_d, u = dev(lw, hip_device), dev(rng.uniform(size=B), hip_device)
+    payload = dev(rng.randn(B, K, *row).astype(np.float32), hip_device)
+    lib = kernels._lib
+    try:
+        assert lib.aesmc_set_step_parts(3) != 0          # powers of two only
+        results = []
+        for parts in (1, 2, 4, 8, 0):
+            assert lib.aesmc_set_step_parts(parts) == 0
+            out = kernels.resample_step(lw_d, u, payload, want_lse=True)
+            assert out is not None
+            results.append(out)
+    finally:
+        lib.aesmc_set_step_parts(0)
+    kernels.read_flags(hip_device)
+    for idx, lse, moved in results[1:]:
+        assert torch.equal(idx, results[0][0]) and torch.equal(moved, results[0][2])
+        np.testing.assert_array_equal(lse.cpu().numpy(), results[0][1].cpu().numpy())
+    good = [b for b in range(B) if np.isfinite(lw[b]).any() and not np.isnan(lw[b]).any()]
+    want, _ = kernel_oracle.ancestor_index(lw[good], u.cpu().numpy()[good])
+    np.testing.assert_array_equal(results[0][0].cpu().numpy()[good], want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,scale", [((2, 16), 1.0), ((4, 100, 10), 1.0), ((2, 300, 10), 8.0), ((2, 1000, 6), 30.0),
+                                         ((1, 5000, 10), 1.0), ((1, 5000, 10), 40.0), ((3, 700, 128), 3.0),
+                                         ((2, 2049, 1), 2.0), ((300, 33, 4), 1.0), ((2, 600, 129), 0.0),
+                                         ((5, 1024, 16), 200.0), ((2, 4096, 10), 0.0), ((2, 4096, 10), 3.0)])
+def test_sorted_backward_kernels_agree_bit_for_bit(kernels, hip_device, dtype, shape, scale):
+    """The range kernel (every row of the gradient written once, no zero fill) and round 1's kernel
+    behind a zero fill sum the same rows in the same order: identical bits, also into a destination
+    that held garbage (nothing may rely on a previous fill)."""
+    rng = np.random.RandomState(shape[1] + int(scale) + 1)
+    go = dev(rng.randn(*shape).astype(dtype), hip_device)
+    idx = dev(sorted_indices(rng, shape[0], shape[1], scale), hip_device)
+    lib = kernels._lib
+    try:
+        outs = []
+        for which in (1, 0):
+            assert lib.aesmc_set_sorted_backward_kernel(which) == 0
+            torch.full(shape, float("nan"), dtype=go.dtype, device=hip_device)   # dirty the allocator's blocks
+            outs.append(kernels.gather_backward(go, idx, sorted_index=True))
+    finally:
+        lib.aesmc_set_sorted_backward_kernel(0)
+    assert kernels.read_flags(hip_device) == 0
+    assert torch.equal(outs[0], outs[1])
+    assert bool(torch.isfinite(outs[1]).all())
+
+
+def test_sorted_backward_range_kernel_edge_rows(kernels, hip_device):
+    """Ranges that start or end a batch row, runs spanning many tiles, a single survivor, the identity,
+    an out-of-range entry and a descent (both flagged, never fatal)."""
+    K, d = 1300, 3
+    rng = np.random.RandomState(1)
+    go = rng.randn(7, K, d)
+    idx = np.stack([np.zeros(K, np.int64), np.full(K, K - 1, np.int64), np.arange(K, dtype=np.int64),
+                    np.sort(rng.randint(0, K, size=K)).astype(np.int64),
+                    np.sort(rng.randint(K - 5, K, size=K)).astype(np.int64),
+                    np.sort(rng.randint(0, 3, size=K)).astype(np.int64),
+                    np.repeat(np.arange(0, K, 260), 260)[:K].astype(np.int64)])
+    got = kernels.gather_backward(dev(go, hip_device), dev(idx, hip_device), sorted_index=True).cpu().numpy()
+    want, _ = kernel_oracle.gather_backward(go, idx)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-10)
+    assert kernels.read_flags(hip_device) == 0
+    bad = idx.copy()
+    bad[3, K - 1] = K + 7                                  # beyond the row: contributes nothing
+    got = kernels.gather_backward(dev(go, hip_device), dev(bad, hip_device), sorted_index=True).cpu().numpy()
+    assert kernels.read_flags(hip_device) & kernel_oracle.FLAG_INDEX_OUT_OF_RANGE
+    want, _ = kernel_oracle.gather_backward(go, bad)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-10)
+    bad = idx.copy()
+    bad[3, 700] = 0
+    kernels.gather_backward(dev(go, hip_device), dev(bad, hip_device), sorted_index=True)
+    assert kernels.read_flags(hip_device) & 16
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (5, 64), (4, 1000), (7, 1024), (3, 1025), (2, 8192), (300, 33)])
+def test_logweight_accumulate_matches_oracle(kernels, hip_device, dtype, shape):
+    """K1 with the running sum of importance sampling: every sum is one IEEE add in the oracle's
+    order, so log-weights and totals are exact; the log-sum-exp of the total within K1's bar."""
+    rng = np.random.RandomState(shape[1])
+    a, b, c, acc = [(3 * rng.randn(*shape)).astype(dtype) for _ in range(4)]
+    args = [dev(x, hip_device) for x in (a, b, c, acc)]
+    lw, total, lse = kernels.logweight_accumulate(*args, want_lw=True, want_lse=True)
+    want_lw, want_total, want_lse = kernel_oracle.logweight_accumulate(a, b, c, acc)
+    np.testing.assert_array_equal(lw.cpu().numpy(), want_lw)
+    np.testing.assert_array_equal(total.cpu().numpy(), want_total)
+    rtol, atol = tol(dtype)
+    np.testing.assert_allclose(lse.cpu().numpy(), want_lse, rtol=rtol, atol=atol)
+    # the step's weights come from K5: a alone, nothing to combine
+    lw, total, lse = kernels.logweight_accumulate(args[0], None, None, args[3], want_lw=False, want_lse=False)
+    assert lw is None and lse is None
+    np.testing.assert_array_equal(total.cpu().numpy(), (acc + a).astype(dtype))
+
+
+def test_importance_sampling_running_sum_equals_the_stack_and_differentiates(hip_device):
+    """infer('is') over T = 5 steps: log_weight equals the left-to-right sum of the per-step weights
+    bit for bit (the order the reference's CPU torch.sum takes over the leading dim of its stack;
+    the device's own torch.sum associates differently, hence only allclose against that), log Z its
+    logsumexp, and the loss gradient equals autograd through the eager stack + sum + logsumexp."""
+    from aesmc_amd import inference
+    from aesmc_amd.testing import models, replay
+    B, K, T, d = 3, 50, 5, 2
+    for dtype in (torch.float64, torch.float32):
+        model = models.LgssmNd(d, seed=1, dtype=dtype, validate_args=False).to(hip_device)
+        observations = model.simulate(T, B, seed=2)
+        torch.manual_seed(0)
+        with replay.record() as tape:
+            out = inference.infer("is", observations, model.initial, model.transition, model.emission, model.proposal,
+                                  K, return_log_marginal_likelihood=True, return_log_weights=True, return_latents=False)
+        stacked = torch.sum(torch.stack(out["log_weights"], dim=0), dim=0)
+        running = out["log_weights"][0]
+        for step_weights in out["log_weights"][1:]:
+            running = running + step_weights
+        assert torch.equal(out["log_weight"], running)
+        torch.testing.assert_close(out["log_weight"], stacked, rtol=1e-6, atol=1e-5)
+        want_lml = torch.logsumexp(stacked, dim=1) - np.log(K)
+        torch.testing.assert_close(out["log_marginal_likelihood"], want_lml, rtol=1e-6, atol=1e-6)
+        model.zero_grad()
+        (-out["log_marginal_likelihood"].mean()).backward()
+        mine = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+        model.zero_grad()
+        with replay.replay(tape):
+            again = inference.infer("is", observations, model.initial, model.transition, model.emission,
+                                    model.proposal, K, return_log_weights=True, return_latents=False,
+                                    return_log_weight=False)
+        eager = torch.logsumexp(torch.sum(torch.stack(again["log_weights"], dim=0), dim=0), dim=1) - np.log(K)
+        (-eager.mean()).backward()
+        theirs = [p.grad for p in model.parameters() if p.grad is not None]
+        assert len(mine) == len(theirs) > 0
+        for g, h in zip(mine, theirs):
+            scale = float(h.abs().max()) + 1e-30
+            torch.testing.assert_close(g / scale, h / scale, rtol=0, atol=1e-5 if dtype == torch.float32 else 1e-12)
