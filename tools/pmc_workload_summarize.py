@@ -1,0 +1,71 @@
+"""Reads the FETCH_SIZE and WRITE_SIZE counter CSVs of one tools/pmc_workload.py run pair and merges
+the result into a traffic table (profiles/pmc_traffic.json):
+
+    { "<workload>:<proposal>": { "<kernel key>": {"hbm_bytes_per_launch", "fetch_bytes", "write_bytes",
+                                                  "algorithmic_bytes_per_launch", "launches", "source"} } }
+
+Calibration: the first three resample_gather_kernel dispatches are identity-index gathers whose read
+and write bytes are known exactly; their ratio to the raw counter gives the factor applied to every
+other dispatch (gfx950: FETCH_SIZE reads 0.50 of a coalesced stream, WRITE_SIZE is exact).
+Usage: python tools/pmc_workload_summarize.py <workload> <proposal> fetch.csv write.csv out.json"""
+import csv
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+KERNELS = {"resample_step": "ancestor_index_inv_kernel", "resample_gather": "resample_gather_kernel",
+           "normal_logweight": "normal_logweight", "normal_rsample": "normal_rsample"}
+
+
+def per_dispatch(path, counter, kernel):
+    rows = [r for r in csv.DictReader(open(path))
+            if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
+    rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    return [float(r["Counter_Value"]) * 1024.0 for r in rows]
+
+
+def main(workload, proposal, fetch_csv, write_csv, out_json):
+    description, kind, dim, B, K, T, _ = bench.WORKLOADS[workload]
+    payload = B * K * dim * 4
+    mean = lambda xs: sum(xs) / len(xs)
+    gather_fetch = per_dispatch(fetch_csv, "FETCH_SIZE", KERNELS["resample_gather"])
+    gather_write = per_dispatch(write_csv, "WRITE_SIZE", KERNELS["resample_gather"])
+    assert len(gather_fetch) >= 3 and len(gather_write) >= 3, (len(gather_fetch), len(gather_write))
+    f_factor = (payload + B * K * 8) / mean(gather_fetch[:3])
+    w_factor = payload / mean(gather_write[:3])
+    source = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) over tools/pmc_workload.py {} {}: the first "
+              "timesteps of bench.py's seeded workload; FETCH_SIZE x{:.3f}, WRITE_SIZE x{:.3f} as calibrated on "
+              "identity-index gathers of the same shape").format(workload, proposal, f_factor, w_factor)
+    entry = {"calibration": {"fetch_factor": f_factor, "write_factor": w_factor}}
+    algorithmic = {"resample_step": B * K * (20 + 8 * dim) + 8 * B, "resample_gather": B * K * (8 + 8 * dim)}
+    for key, kernel in KERNELS.items():
+        skip = 3 if key == "resample_gather" else 0
+        fetch = per_dispatch(fetch_csv, "FETCH_SIZE", kernel)[skip:]
+        write = per_dispatch(write_csv, "WRITE_SIZE", kernel)[skip:]
+        n = min(len(fetch), len(write))
+        if n == 0:
+            continue
+        if key == "resample_step":      # launches with a payload only (time 0 has none; K2 alone writes 12 B/particle)
+            pairs = [(f, w) for f, w in zip(fetch, write) if w * w_factor > 0.5 * payload]
+            if not pairs:
+                continue
+            fetch, write = [p[0] for p in pairs], [p[1] for p in pairs]
+            n = len(pairs)
+        f, w = mean(fetch[:n]) * f_factor, mean(write[:n]) * w_factor
+        entry[key] = {"hbm_bytes_per_launch": f + w, "fetch_bytes": f, "write_bytes": w, "launches": n,
+                      "source": source}
+        if key in algorithmic:
+            entry[key]["algorithmic_bytes_per_launch"] = algorithmic[key]
+    table = {}
+    if os.path.exists(out_json):
+        table = json.load(open(out_json))
+    table["{}:{}".format(workload, proposal)] = entry
+    json.dump(table, open(out_json, "w"), indent=1, sort_keys=True)
+    print(json.dumps({"{}:{}".format(workload, proposal): entry}, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:6])
