@@ -165,6 +165,14 @@ class HipKernels:
             word.zero_()
         return value
 
+    def discard_flags(self):
+        """Clears every device's status word without synchronising (an `infer` was abandoned half way:
+        what its kernels flagged must not surface in the next call).  Skipped during a capture."""
+        for index, word in list(self._flags.items()):
+            with torch.cuda.device(index):
+                if not torch.cuda.is_current_stream_capturing():
+                    word.zero_()
+
     def defer_support_check(self, valid):
         """ORs FLAG_VALUE_OUTSIDE_SUPPORT into the status word if any element of the boolean
         tensor `valid` is False — device-side, no synchronisation."""

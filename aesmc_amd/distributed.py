@@ -12,13 +12,16 @@ from numpy's global RandomState (same seed on every rank) and keeps its own rows
 `shard_scope`.
 """
 import contextlib
+import contextvars
 
 import torch
 import torch.distributed as dist
 
 from . import inference
 
-_ACTIVE_SHARD = None  # (global_batch_size, lo, hi) while inside shard_scope
+# (global_batch_size, lo, hi) while inside shard_scope; per thread / per context, so a sharded
+# evaluation in one thread does not re-slice the uniforms of another
+_ACTIVE_SHARD = contextvars.ContextVar("aesmc_amd_active_shard", default=None)
 
 
 def shard_bounds(global_batch_size, rank, world_size):
@@ -47,17 +50,16 @@ def shard_scope(global_batch_size, rank, world_size):
     """While active, the resampler's per-step uniforms are drawn for the whole global batch and
     sliced to this rank's rows, so a sharded run consumes numpy's RNG exactly like an unsharded
     one and produces the same ancestor indices row for row."""
-    global _ACTIVE_SHARD
     lo, hi = shard_bounds(global_batch_size, rank, world_size)
-    previous, _ACTIVE_SHARD = _ACTIVE_SHARD, (global_batch_size, lo, hi)
+    token = _ACTIVE_SHARD.set((global_batch_size, lo, hi))
     try:
         yield
     finally:
-        _ACTIVE_SHARD = previous
+        _ACTIVE_SHARD.reset(token)
 
 
 def active_shard():
-    return _ACTIVE_SHARD
+    return _ACTIVE_SHARD.get()
 
 
 def _group_is_live():
@@ -165,7 +167,8 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
                 optimizer.zero_grad(set_to_none=True)
                 shard = (observations[0].size(0) * world_size, rank, world_size)
                 graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
-                                             backward=True, shard=shard, group=group, check_flags=False)
+                                             backward=True, shard=shard, group=group, check_flags=False,
+                                             guard_gradients=True)
             loss = graphed(observations)            # local replay + the all-reduce of the loss
             all_reduce_gradients(parameters, group=group)
             optimizer.step()

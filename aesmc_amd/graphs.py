@@ -25,6 +25,12 @@ capture could not be closed.
 ROCm 7.0 caveat: captured memset nodes (PyTorch's reductions issue them) run out of stream order
 under the runtime's graph fast path; `import aesmc_amd` switches that path off through
 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 if the HIP runtime has not started yet (aesmc_amd/__init__.py).
+The runtime reads the variable at its FIRST HIP call — torch.cuda.is_available() already is one — so
+export it in the shell / launcher, or import aesmc_amd before anything touches the GPU.  A capture
+WITH backward refuses to start when the variable is known not to be in effect, and in every case
+verifies itself: the first `verify_replays` replays are compared with an eager evaluation on the
+same inputs and random draws (the fault shows from the third or fourth replay on, in the gradients
+only), and a mismatch raises.
 """
 import contextlib
 import gc
@@ -98,19 +104,28 @@ class GraphedLoss:
     """
 
     def __init__(self, observations, num_particles, algorithm, initial, transition, emission,
-                 proposal, backward=False, warmup=2, check_flags=True, shard=None, group=None):
+                 proposal, backward=False, warmup=2, check_flags=True, shard=None, group=None,
+                 verify_replays=4, guard_gradients=False):
         """`shard=(global_batch_size, rank, world_size)`: `observations` are this rank's rows of a
         batch sharded over the process group; the graph then holds the LOCAL share
         -sum_local(log Z_b) / global_batch_size (and its backward) and every call finishes with
-        the one all-reduce of the loss (gradients: `distributed.all_reduce_gradients`)."""
+        the one all-reduce of the loss (gradients: `distributed.all_reduce_gradients`).
+        `verify_replays` (backward only): replays compared with eager evaluations right after the
+        capture (0 switches the check off).  `guard_gradients` (backward only): the captured backward
+        ends by zeroing every gradient when the device status word is set (NaN log-weights, a
+        degenerate row, ...), so an optimiser step taken before the host has read the word cannot
+        poison the parameters."""
         import aesmc_amd
         if backward and aesmc_amd.HIPGRAPH_MEMSET_WORKAROUND in ("too-late", "preset:1"):
-            warnings.warn(
-                "aesmc_amd: capturing a backward pass into a hipGraph with {}=0 not in effect (the HIP "
-                "runtime was initialised before `import aesmc_amd`, or the variable is set to 1). On ROCm "
-                "7.0 captured memset nodes then run out of order and replayed gradients can be wrong; "
-                "import aesmc_amd (or set the variable) before the first GPU call.".format(
-                    aesmc_amd.HIPGRAPH_ENV), RuntimeWarning)
+            raise RuntimeError(
+                "aesmc_amd: refusing to capture a backward pass into a hipGraph: {}=0 is not in effect "
+                "(status '{}': the HIP runtime had started before `import aesmc_amd`, or the variable is "
+                "set to 1). On ROCm 7.0 captured memset nodes then run out of stream order and replayed "
+                "GRADIENTS go wrong from the third or fourth replay on while losses stay right. Export "
+                "{}=0 in the shell or launcher before Python starts, or import aesmc_amd before the first "
+                "GPU call (torch.cuda.is_available() is one).".format(
+                    aesmc_amd.HIPGRAPH_ENV, aesmc_amd.HIPGRAPH_MEMSET_WORKAROUND, aesmc_amd.HIPGRAPH_ENV))
+        self.guard_gradients = bool(guard_gradients and backward)
         first = observations[0]
         self.shard = shard
         self.group = group
@@ -174,6 +189,59 @@ class GraphedLoss:
                 ".item() / .cpu() / print of a device tensor, or host-side control flow on tensor "
                 "values. Original error: {}".format(error)) from error
         self.replays = 0
+        if backward and verify_replays > 0:
+            self._verify(verify_replays)
+
+    def _verify(self, replays):
+        """Replays the fresh graph `replays` times; before each, the random streams are noted and the
+        same evaluation is then repeated eagerly from that state.  Loss and every gradient must agree
+        (to 1e-4 of the largest entry: a user model may contain atomics; the hipGraph memset fault
+        this guards against is off by orders of magnitude).  Leaves both streams where they were."""
+        params = self.parameters
+        start_cuda, start_numpy = torch.cuda.get_rng_state(self.device), np.random.get_state()
+        static = [p.grad for p in params]
+        try:
+            for replay in range(replays):
+                cuda_state, numpy_state = torch.cuda.get_rng_state(self.device), np.random.get_state()
+                self._refill()
+                self.graph.replay()
+                graph_loss = self.static_loss.clone()
+                graph_grads = [None if g is None else g.clone() for g in static]
+                for p in params:
+                    p.grad = None
+                torch.cuda.set_rng_state(cuda_state, self.device)
+                np.random.set_state(numpy_state)
+                eager_loss = self._evaluate(refill=True)
+                problems = []
+                if not torch.allclose(graph_loss, eager_loss, rtol=1e-5, atol=1e-6, equal_nan=True):
+                    problems.append("loss {} vs {}".format(float(graph_loss), float(eager_loss)))
+                for position, (p, got) in enumerate(zip(params, graph_grads)):
+                    want = p.grad
+                    if (got is None) != (want is None):
+                        problems.append("parameter {}: gradient present in only one of the two".format(position))
+                    elif got is not None:
+                        bound = 1e-4 * float(want.abs().max()) + 1e-12
+                        worst = float((got - want).abs().max())
+                        if not worst <= bound:
+                            problems.append("parameter {} {}: max |difference| {:.3g} (largest entry {:.3g})".format(
+                                position, tuple(p.shape), worst, float(want.abs().max())))
+                for p, grad in zip(params, static):
+                    p.grad = grad
+                if problems:
+                    import aesmc_amd
+                    raise RuntimeError(
+                        "aesmc_amd: replay {} of a freshly captured loss + backward hipGraph does not reproduce "
+                        "the eager evaluation on the same inputs and random draws: {}. On ROCm 7.0 this is the "
+                        "signature of captured memset nodes running out of stream order; {} must be 0 when the "
+                        "HIP runtime starts (status here: '{}'). The graph must not be used.".format(
+                            replay + 1, "; ".join(problems), aesmc_amd.HIPGRAPH_ENV,
+                            aesmc_amd.HIPGRAPH_MEMSET_WORKAROUND))
+        finally:
+            for p, grad in zip(params, static):
+                p.grad = grad
+            torch.cuda.set_rng_state(start_cuda, self.device)
+            np.random.set_state(start_numpy)
+        inference._raise_for_flags(_kernels.get().read_flags(self.device))
 
     def _shard_scope(self):
         return distributed.shard_scope(*self.shard) if self.shard else contextlib.nullcontext()
@@ -189,8 +257,7 @@ class GraphedLoss:
             self._refill()
         if self.feed is not None:
             self.feed.begin()
-        previous, inference._FEED_OVERRIDE = inference._FEED_OVERRIDE, self.feed
-        try:
+        with inference.uniform_feed(self.feed):
             result = inference.infer(
                 {"iwae": "is", "aesmc": "smc"}[algorithm], self.static_observations, initial,
                 transition, emission, proposal, num_particles, return_log_marginal_likelihood=True,
@@ -199,8 +266,12 @@ class GraphedLoss:
             loss = -torch.sum(result["log_marginal_likelihood"]) / self.global_batch
             if self.backward:
                 loss.backward()
-        finally:
-            inference._FEED_OVERRIDE = previous
+                if self.guard_gradients:
+                    # on the device, no host sync: a step flagged by the kernels contributes nothing
+                    healthy = _kernels.get().flags(self.device) == 0
+                    for p in self.parameters:
+                        if p.grad is not None:
+                            p.grad.copy_(torch.where(healthy, p.grad, torch.zeros_like(p.grad)))
         return loss.detach()
 
     def check(self):

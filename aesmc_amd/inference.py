@@ -12,6 +12,8 @@ Differences from the reference that a caller can observe (all documented in DESI
     raised once at the end of `infer` instead of synchronising the device every timestep.
 """
 import collections.abc
+import contextlib
+import contextvars
 
 import numpy as np
 import torch
@@ -97,7 +99,32 @@ def draw_uniform_block(batch_size):
     return np.random.uniform(size=[global_batch, 1])[lo:hi].reshape(-1)
 
 
-_FEED_OVERRIDE = None  # set by graphs.GraphedLoss while it captures: a feed with static buffers
+# set by graphs.GraphedLoss while it captures or replays eagerly: a feed with static buffers.  Per
+# thread / per context: a capture in one thread does not hijack the uniforms of an infer() in another.
+_FEED_OVERRIDE = contextvars.ContextVar("aesmc_amd_feed_override", default=None)
+
+
+@contextlib.contextmanager
+def uniform_feed(feed):
+    """While active, `infer` takes its per-resample uniforms from `feed` (an object with `next()`
+    returning a float64 [batch_size] device tensor) instead of drawing them itself."""
+    token = _FEED_OVERRIDE.set(feed)
+    try:
+        yield
+    finally:
+        _FEED_OVERRIDE.reset(token)
+
+
+def check_device_status(device=None):
+    """Synchronising read-and-clear of the device status word: raises what `infer` would raise for
+    anything the kernels flagged since the last check (NaN log-weights -> FloatingPointError, a row
+    without a finite maximum or an ancestor index outside [0, num_particles) -> RuntimeError, a value
+    outside a distribution's support -> ValueError).  `infer` and `sample_ancestral_index` call it
+    themselves; the stand-alone `get_resampled_latents` / `state.resample` / `state.log_prob` only
+    SET flags (they never synchronise): call this after them, or let the next `infer` report."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    _raise_for_flags(_kernels.get().read_flags(device))
 
 
 def _raise_for_flags(flags):
@@ -128,10 +155,9 @@ def sample_ancestral_index(log_weight):
     if log_weight.is_cuda:
         uniforms = uniforms.to(log_weight.device)
     index = _ops.ancestor_index(log_weight, uniforms)
-    from . import _lib
-    flags = _kernels.get().read_flags(log_weight.device)
-    if flags & _lib.FLAG_NAN_LOG_WEIGHT:
-        raise FloatingPointError("log_weight contains nan element(s)")
+    # every bit raises — also one left behind by an earlier deferred check: an all -inf (or +inf) row
+    # yields indices equal to num_particles, where the reference fails inside np.digitize / torch.gather
+    _raise_for_flags(_kernels.get().read_flags(log_weight.device))
     return index
 
 
@@ -179,6 +205,49 @@ def infer(inference_algorithm, observations, initial, transition, emission,
     Returns a dict with keys log_marginal_likelihood [batch_size], latents, original_latents,
     log_weight [batch_size, num_particles], log_weights, ancestral_indices (None unless requested
     through the return_* flags) and last_latent (always).
+
+    Data-dependent failures are collected in one status word per device and raised at the end (see
+    `check_device_status`); the word is shared by every stream and thread using that device, so run
+    one `infer` per device at a time.  If the call is abandoned half way (an exception out of a user
+    callable), whatever the kernels had flagged so far is discarded with it, so the next call starts
+    clean.
+    """
+    try:
+        return _infer(inference_algorithm, observations, initial, transition, emission, proposal,
+                      num_particles, return_log_marginal_likelihood, return_latents,
+                      return_original_latents, return_log_weight, return_log_weights,
+                      return_ancestral_indices)
+    except BaseException:
+        _discard_pending_flags()
+        raise
+
+
+def _discard_pending_flags():
+    """Clears every device's status word (no synchronisation) unless a hipGraph capture is under way."""
+    try:
+        _kernels.get().discard_flags()
+    except Exception:       # never mask the exception that is propagating
+        pass
+
+
+def _infer(inference_algorithm, observations, initial, transition, emission,
+           proposal, num_particles, return_log_marginal_likelihood=False,
+           return_latents=True, return_original_latents=False,
+           return_log_weight=True, return_log_weights=False,
+           return_ancestral_indices=False):
+    """The body of `infer` (aesmc/inference.py:8-193).
+
+    observations: length-T sequence of [batch_size, ...] tensors (or dicts of them).
+    initial():                                   -> Distribution (or dict of them)
+    transition(previous_latents, time, previous_observations) -> Distribution
+    emission(latents, time, previous_observations)            -> Distribution
+    proposal(previous_latents, time, observations)            -> Distribution with rsample
+    All four are called with keyword arguments; at time 0 the proposal gets no previous_latents
+    and the emission no previous_observations.
+
+    Returns a dict with keys log_marginal_likelihood [batch_size], latents, original_latents,
+    log_weight [batch_size, num_particles], log_weights, ancestral_indices (None unless requested
+    through the return_* flags) and last_latent (always).
     """
     if inference_algorithm not in ("is", "smc"):
         raise ValueError("inference_algorithm must be either is or smc. currently = {}".format(
@@ -206,8 +275,7 @@ def infer(inference_algorithm, observations, initial, transition, emission,
             if use_smc:
                 previous = log_weights[-1]
                 if feed is None:
-                    feed = _FEED_OVERRIDE if _FEED_OVERRIDE is not None else \
-                        _UniformFeed(batch_size, num_timesteps - 1, previous.device)
+                    feed = _FEED_OVERRIDE.get() or _UniformFeed(batch_size, num_timesteps - 1, previous.device)
                 # K2; the same launch re-indexes the newest latent (what a Markov model reads) and
                 # returns the row log-sum-exp when the step before left it pending (K5 route)
                 newest = history[-1] if torch.is_tensor(history[-1]) else None
@@ -222,6 +290,11 @@ def infer(inference_algorithm, observations, initial, transition, emission,
                     ancestors = [state.resample(x, index) for x in history[:-1]]
                     ancestors.append(moved if moved is not None else state.resample(history[-1], index))
             else:
+                # Importance sampling: the SAME list object that `history.append(latent)` extends below,
+                # so transition(previous_latents=...) sees the current draw as previous_latents[-1] and
+                # evaluates p(x_t | x_t).  Deliberate bug-compatibility: the reference aliases its list
+                # the same way (`latents_bar += [latent]`, aesmc/inference.py:111, :118) and the golden
+                # fixtures pin it; a model that wants p(x_t | x_{t-1}) under 'is' reads [-2].
                 ancestors = history
             proposal_dist = proposal(previous_latents=ancestors, time=time,
                                      observations=observations)

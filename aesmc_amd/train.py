@@ -60,7 +60,12 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
     loop is then no longer bound by the host issuing each small kernel.  It needs what any capture
     needs (fixed minibatch shapes, tensor observations, callables that never synchronise with the
     host; see `aesmc_amd/graphs.py`) and its warm-up evaluations consume random numbers, so a
-    seeded run follows a different — equally distributed — trajectory than the eager loop."""
+    seeded run follows a different — equally distributed — trajectory than the eager loop.
+    The device status word (NaN log-weights, a degenerate row, ...) is then read every
+    `_FLAG_CHECK_INTERVAL` replays instead of every step; in between, the captured backward zeroes the
+    gradients of a flagged step on the device (`GraphedLoss(guard_gradients=True)`), so the optimiser
+    steps taken before the FloatingPointError / RuntimeError surfaces do not poison the parameters
+    (with a stateful optimiser they still decay its moments: restore a checkpoint if that matters)."""
     model_parts = (initial, transition, emission, proposal)
     optimizer = optimizer_algorithm(get_chained_params(*model_parts), **optimizer_kwargs)
     if hip_graph:
@@ -73,7 +78,7 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
                 # _FLAG_CHECK_INTERVAL replays and once at the end instead of after each replay, so
                 # the host can prepare the next minibatch while the GPU still works on this one
                 graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
-                                             backward=True, check_flags=False)
+                                             backward=True, check_flags=False, guard_gradients=True)
             loss = graphed(observations)     # refreshes every captured parameter's .grad in place
             optimizer.step()
             if graphed.replays % _FLAG_CHECK_INTERVAL == 0:

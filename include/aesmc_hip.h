@@ -159,18 +159,20 @@ int aesmc_normal_logprob_sum_backward(int dtype, const void *value, const void *
 
 /*
  * K5 — the whole log-weight of one SMC step when the prior / transition, the emission and the
- * proposal are all Normal with SCALAR scales (one value for the tensor, e.g. Normal(loc, 0.7)):
+ * proposal are all Normal:
  *   lw[b,k] = sum_j log N(x; mu_p, s_p) + sum_j log N(y; mu_g, s_g) - sum_j log N(x; mu_q, s_q)
- * `views` points to eight [B,K,D] views in this order:
+ * `views` points to eight [B,K,D] views (element strides, 0 = broadcast) in this order:
  *   0 x (latent, extent Dx)   1 mu_p   2 s_p      (prior or transition)
  *   3 y (observation, Dy)     4 mu_g   5 s_g      (emission)
  *   6 mu_q (extent Dx)        7 s_q               (proposal, evaluated at x)
  * Replaces three calls of K4 and the combine of K1 (aesmc/inference.py:112-126 via
- * aesmc/state.py:114-155); bit-identical to that route.  Scales may be scalars (the fast kernels)
- * or any [B,K,D] views (one general kernel, extents up to 64).  Returns AESMC_ERR_UNSUPPORTED for
- * extents above 64 with non-scalar scales, and for extents above 64 unless both are, are multiples of 16 bytes, take the
- * same lane team in K4 and all five rows are contiguous and 16-byte aligned: the caller then
- * takes the K4 + K1 route.
+ * aesmc/state.py:114-155); bit-identical to that route.
+ * Covered operands:
+ *   - extents Dx, Dy <= 64: any scales — one value for the whole tensor (all strides 0, e.g.
+ *     Normal(loc, 0.7): the fastest kernels), a per-dimension vector, or a full [B,K,D] view;
+ *   - extents above 64: scalar scales only, and only when Dx and Dy take the same lane team in K4,
+ *     each row is a multiple of 16 bytes, contiguous and 16-byte aligned.
+ * Anything else returns AESMC_ERR_UNSUPPORTED and the caller takes the K4 + K1 route (same numbers).
  */
 typedef struct aesmc_view3 {
   const void *ptr;

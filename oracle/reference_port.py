@@ -6,10 +6,10 @@ the resampler, the final stack of all weight tensors.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
 product package (aesmc_amd/) never does.
 
-Pinning: oracle/check_port_against_reference.py (run in the build container, where /root/reference
-is importable) proves this port bit-equal to the imported reference under replayed RNG, and the
-committed fixtures tests/golden/*.npz (captured from the reference by oracle/capture_golden.py)
-re-prove it wherever the tests run.  The arithmetic lives in unpinned third-party libraries
+Pinning: oracle/capture_golden.py (run in the build container, where /root/reference is importable)
+records the imported reference's inputs, random draws and outputs as tests/golden/*.npz;
+tests/test_oracle.py proves this port equal to those fixtures under the replayed draws wherever
+the tests run (indices exact, floats to the last place on the capture host).  The arithmetic lives in unpinned third-party libraries
 (reference setup.py:59 lists torch only; numpy / scipy are implicit): fixtures were captured with
 torch 2.10.0, numpy 2.2.6, scipy 1.15.3.
 

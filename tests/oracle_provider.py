@@ -15,6 +15,9 @@ class OracleKernels:
     def __init__(self):
         self._flags = 0
 
+    def discard_flags(self):
+        self._flags = 0
+
     def read_flags(self, device):
         flags, self._flags = self._flags, 0
         return flags

@@ -256,3 +256,81 @@ def test_distributed_train_on_a_one_rank_rccl_group_equals_single_process_traini
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_backward_capture_refuses_an_unprotected_runtime(hip_device):
+    """the hipGraph memset workaround must be in effect when the HIP runtime
+    starts.  In fresh processes: (a) the variable set to 1 -> GraphedLoss(backward=True) raises instead
+    of warning; (b) the runtime started before the import (torch.cuda.is_available() does that without
+    setting torch.cuda.is_initialized()) -> the package notices ('too-late') and the capture raises;
+    (c) imported first -> 'set', and the capture verifies itself against eager."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = """
+import sys, torch
+sys.path.insert(0, {root!r})
+{before}
+import aesmc_amd
+from aesmc_amd import graphs
+from aesmc_amd.testing import models
+print("STATUS", aesmc_amd.HIPGRAPH_MEMSET_WORKAROUND)
+dev = torch.device("cuda", 0)
+model = models.LgssmNd(2, seed=0, validate_args=False).to(dev)
+obs = model.simulate(3, 4, seed=0)
+try:
+    graphs.GraphedLoss(obs, 16, "aesmc", model.initial, model.transition, model.emission, model.proposal, backward=True)
+    print("CAPTURED")
+except RuntimeError as error:
+    print("REFUSED", str(error)[:80])
+"""
+    def run(before, env_value):
+        env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+        if env_value is not None:
+            env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = env_value
+        done = subprocess.run([sys.executable, "-c", body.format(root=root, before=before)], env=env,
+                              capture_output=True, text=True, timeout=600)
+        assert done.returncode == 0, done.stderr[-2000:]
+        return done.stdout
+    out = run("", "1")
+    assert "STATUS preset:1" in out and "REFUSED" in out
+    out = run("torch.cuda.is_available()", None)
+    assert "STATUS too-late" in out and "REFUSED" in out
+    out = run("", None)
+    assert "STATUS set" in out and "CAPTURED" in out
+
+
+def test_guarded_gradients_are_zero_on_a_flagged_replay(hip_device):
+    """`GraphedLoss(guard_gradients=True)` (what train(hip_graph=True) captures): a replay whose
+    kernels flag NaN log-weights leaves every gradient exactly zero — an optimiser step taken before
+    the host reads the status word cannot poison the parameters — and the check then raises; a
+    healthy replay's gradients equal the unguarded ones bit for bit."""
+    seed(0)
+    model = models.LgssmNd(3, seed=0, validate_args=False).to(hip_device)
+    parts = (model.initial, model.transition, model.emission, model.proposal)
+    observations = model.simulate(5, 8, seed=3)
+    params = list(model.parameters())
+    plain = graphs.GraphedLoss(observations, 64, "aesmc", *parts, backward=True)
+    seed(7)
+    plain(observations)
+    want = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    del plain
+    guarded = graphs.GraphedLoss(observations, 64, "aesmc", *parts, backward=True, guard_gradients=True,
+                                 check_flags=False)
+    seed(7)
+    guarded(observations)
+    guarded.check()
+    for p, g in zip(params, want):
+        assert torch.equal(p.grad, g)
+    poisoned = [o.clone() for o in observations]
+    poisoned[2][1, 0] = float("nan")
+    guarded(poisoned)
+    assert all(bool((p.grad == 0).all()) for p in params)
+    with pytest.raises(FloatingPointError):
+        guarded.check()
+    guarded(observations)                         # and the next healthy minibatch trains on
+    guarded.check()
+    assert any(bool((p.grad != 0).any()) for p in params)
