@@ -594,16 +594,30 @@ class HipKernels:
                                 (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, out, views))
         return out
 
-    def normal_logweight_backward(self, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, need):
+    def normal_logweight_backward(self, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, need,
+                                  lw=None, lse=None, grad_lse=None):
         """Gradients of `normal_logweight` in one launch: dense [B,K,*] tensors in the order
-        (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q), None where `need[i]` is false."""
+        (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q), None where `need[i]` is false.
+        With `lw`, `lse`, `grad_lse` the incoming gradient is K1's backward formed in place,
+        grad_lse[b] * exp(lw - lse[b]) (+ grad_lw if given): the per-step softmax term never goes
+        through HBM as a [B,K] tensor."""
         tag, x, loc_p, scale_p, sx, sp, ssp, Dx = self._normal_operands(x, loc_p, scale_p)
         _, y, loc_g, scale_g, sy, sg, ssg, Dy = self._normal_operands(y, loc_g, scale_g)
         _, _, loc_q, scale_q, _, sq, ssq, _ = self._normal_operands(x, loc_q, scale_q)
         if Dx < 1 or Dy < 1:
             return None
         B, K = x.shape[:2]
-        grad_lw = grad_lw.contiguous()
+        fused_lse = grad_lse is not None
+        if fused_lse:
+            lw, lse, grad_lse = lw.contiguous(), lse.contiguous(), grad_lse.contiguous()
+            if lw.shape != (B, K) or lse.shape != (B,) or grad_lse.shape != (B,) or \
+                    any(t.dtype != x.dtype or t.device != x.device for t in (lw, lse, grad_lse)):
+                raise ValueError("aesmc_amd: lw must be [{0}, {1}], lse and grad_lse [{0}], all {2} on {3}".format(
+                    B, K, x.dtype, x.device))
+        if grad_lw is not None:
+            grad_lw = grad_lw.contiguous()
+        elif not fused_lse:
+            raise ValueError("aesmc_amd: normal_logweight_backward needs grad_lw or (lw, lse, grad_lse)")
         make = lambda like, wanted: torch.empty(like.shape, dtype=like.dtype, device=like.device) if wanted else None
         outs = [make(x, need[0]), make(x, need[1]), make(x, need[2]), make(y, need[3]), make(y, need[4]),
                 make(y, need[5]), make(x, need[6]), make(x, need[7])]
@@ -614,19 +628,24 @@ class HipKernels:
             (x, sx), (loc_p, sp), (scale_p, ssp), (y, sy), (loc_g, sg), (scale_g, ssg), (loc_q, sq),
             (scale_q, ssq))])
         with _on_device(x.device):
-            args = (tag, views, _ptr(grad_lw), _ptr(gx), _ptr(gp), _ptr(gy), _ptr(gg), _ptr(gq), _ptr(gsp),
-                    _ptr(gsg), _ptr(gsq), B, K, Dx, Dy, self._stream(x))
-            status = self._lib.aesmc_normal_logweight_backward(*args)
+            tail = (_ptr(gx), _ptr(gp), _ptr(gy), _ptr(gg), _ptr(gq), _ptr(gsp), _ptr(gsg), _ptr(gsq), B, K, Dx, Dy,
+                    self._stream(x))
+            if fused_lse:
+                entry, name = self._lib.aesmc_normal_logweight_lse_backward, "aesmc_normal_logweight_lse_backward"
+                args = (tag, views, _ptr(lw), _ptr(lse), _ptr(grad_lse), _ptr(grad_lw)) + tail
+            else:
+                entry, name = self._lib.aesmc_normal_logweight_backward, "aesmc_normal_logweight_backward"
+                args = (tag, views, _ptr(grad_lw)) + tail
+            status = entry(*args)
             if status == 2:
                 return None
-            _lib.check(status, "aesmc_normal_logweight_backward")
+            _lib.check(status, name)
             if self.timer is not None:
                 live = [t for t in outs if t is not None]
-                nbytes = sum(self._unique_bytes(t) for t in (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q,
-                                                             grad_lw)) + sum(t.numel() * t.element_size() for t in live)
-                self.timer.note("normal_logweight_backward",
-                                lambda: self._lib.aesmc_normal_logweight_backward(*args), nbytes,
-                                (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, views) + tuple(live))
+                reads = [t for t in (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, lw) if t is not None]
+                nbytes = sum(self._unique_bytes(t) for t in reads) + sum(t.numel() * t.element_size() for t in live)
+                self.timer.note(name[6:], lambda: entry(*args), nbytes,
+                                tuple(reads) + (lse, grad_lse, views) + tuple(live))
         return outs
 
     def normal_rsample(self, eps, loc, scale):

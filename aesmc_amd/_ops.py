@@ -152,6 +152,50 @@ class _NormalLogWeight(torch.autograd.Function):
         return gx, g_loc_p, g_scale_p, g_y, g_loc_g, g_scale_g, g_loc_q, g_scale_q
 
 
+class _NormalLogWeightLSE(torch.autograd.Function):
+    """Ties a row log-sum-exp that some later launch produced (the next step's resampling kernel, or
+    K1 after the last step) to the operands of the K5 launch whose log-weights it reduces.  Forward
+    returns the value as it is; backward runs K5's backward with K1's softmax term formed in place
+    (`aesmc_normal_logweight_lse_backward`): one launch and one [B,K] round trip less per timestep
+    than K1's backward followed by K5's, same numbers bit for bit."""
+
+    @staticmethod
+    def forward(ctx, lse, lw, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
+        ctx.save_for_backward(lse, lw, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q)
+        return lse.view_as(lse)
+
+    @staticmethod
+    def backward(ctx, grad_lse):
+        lse, lw, x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q = ctx.saved_tensors
+        need = list(ctx.needs_input_grad[2:])
+        k = _kernels.get()
+        grad_lse = grad_lse.contiguous()
+        fused = k.normal_logweight_backward(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, None, need,
+                                            lw=lw, lse=lse, grad_lse=grad_lse)
+        if fused is None:   # not reached with today's kernels (the backward is elementwise); kept for safety
+            grad, _ = k.logweight_lse_backward(lw, lse, None, grad_lse, want_neg=False)
+            fused = k.normal_logweight_backward(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad, need)
+        return (None, None) + tuple(fused)
+
+
+def normal_log_weight_deferred(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
+    """K5 forward WITHOUT an autograd node: (log-weights [B,K] carrying no gradient, the operands
+    as given) — or None when K5 does not cover the operands.  For callers that differentiate the
+    log-weights only through their row log-sum-exp, which they attach with `attach_lse`."""
+    tensors = (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q)
+    if not _kernels.get().normal_logweight_covers(x, scale_p, y, scale_g, scale_q):
+        return None
+    lw = _kernels.get().normal_logweight(*[t.detach() for t in tensors])
+    if lw is None:
+        return None
+    return lw, tensors
+
+
+def attach_lse(lse, lw, operands):
+    """The row log-sum-exp `lse` [B] of `lw` as a differentiable function of K5's `operands`."""
+    return _NormalLogWeightLSE.apply(lse.detach(), lw, *operands)
+
+
 def normal_log_weight(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
     """[B,K] log-weight of one step for three Normal terms (kernel K5), or None if K5 does not
     cover the operands (the caller then sums three K4 terms through K1: same numbers)."""

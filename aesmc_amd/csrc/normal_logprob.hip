@@ -840,16 +840,25 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_bwd_kernel(
     View3 x, View3 mu_p, View3 sc_p, View3 y, View3 mu_g, View3 sc_g, View3 mu_q, View3 sc_q,
     const T *__restrict__ grad_lw, T *__restrict__ gx, T *__restrict__ gmu_p, T *__restrict__ gy,
     T *__restrict__ gmu_g, T *__restrict__ gmu_q, T *__restrict__ gs_p, T *__restrict__ gs_g,
-    T *__restrict__ gs_q, int64_t total_x, int64_t total_y, uint32_t K, uint32_t Dx, uint32_t Dy) {
+    T *__restrict__ gs_q, int64_t total_x, int64_t total_y, uint32_t K, uint32_t Dx, uint32_t Dy,
+    const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse) {
   const int64_t stride = (int64_t)gridDim.x * kLpBlock;
   const int64_t first = (int64_t)blockIdx.x * kLpBlock + threadIdx.x;
+  // The gradient arriving at the log-weights.  With `grad_lse` it is K1's backward evaluated in
+  // place — grad_lse[b] * exp(lw - lse[b]) (+ grad_lw when that is given too), the same operations
+  // in the same order as logweight_lse_bwd_kernel — so the [B,K] gradient never round-trips HBM.
+  auto incoming = [&](int64_t p, int64_t b) -> T {
+    T g = grad_lse != nullptr ? grad_lse[b] * Num<T>::exp(lw[p] - lse[b]) : T(0);
+    if (grad_lw != nullptr) g = grad_lse != nullptr ? g + grad_lw[p] : grad_lw[p];
+    return g;
+  };
   if (gx != nullptr || gmu_p != nullptr || gmu_q != nullptr || gs_p != nullptr || gs_q != nullptr) {
     for (int64_t e = first; e < total_x; e += stride) {
       const int64_t p = e / Dx;
       const uint32_t j = (uint32_t)(e - p * Dx);
       const int64_t b = p / K, k = p - b * K;
       const T v = load_view<T>(x, b, k, j);
-      const T g = grad_lw[p];
+      const T g = incoming(p, b);
       const T s_p = load_view<T>(sc_p, b, k, j), s_q = load_view<T>(sc_q, b, k, j);
       const T var_p = s_p * s_p, var_q = s_q * s_q;
       const T dp = v - load_view<T>(mu_p, b, k, j), dq = v - load_view<T>(mu_q, b, k, j);
@@ -868,7 +877,7 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_bwd_kernel(
       const int64_t p = e / Dy;
       const uint32_t j = (uint32_t)(e - p * Dy);
       const int64_t b = p / K, k = p - b * K;
-      const T g = grad_lw[p];
+      const T g = incoming(p, b);
       const T s_g = load_view<T>(sc_g, b, k, j);
       const T var_g = s_g * s_g;
       const T dg = load_view<T>(y, b, k, j) - load_view<T>(mu_g, b, k, j);
@@ -883,7 +892,8 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_bwd_kernel(
 template <typename T>
 static int launch_logweight_bwd(const View3 *v, const void *grad_lw, void *gx, void *gmu_p, void *gy,
                                 void *gmu_g, void *gmu_q, void *gs_p, void *gs_g, void *gs_q, int64_t B,
-                                int64_t K, int64_t Dx, int64_t Dy, hipStream_t s) {
+                                int64_t K, int64_t Dx, int64_t Dy, hipStream_t s, const void *lw = nullptr,
+                                const void *lse = nullptr, const void *grad_lse = nullptr) {
   const int64_t total_x = B * K * Dx, total_y = B * K * Dy;
   const int64_t most = total_x > total_y ? total_x : total_y;
   int64_t blocks = (most + kLpBlock - 1) / kLpBlock;
@@ -892,7 +902,7 @@ static int launch_logweight_bwd(const View3 *v, const void *grad_lw, void *gx, v
   hipLaunchKernelGGL((normal_logweight_bwd_kernel<T>), dim3((unsigned)blocks), dim3(kLpBlock), 0, s, v[0], v[1],
                      v[2], v[3], v[4], v[5], v[6], v[7], (const T *)grad_lw, (T *)gx, (T *)gmu_p, (T *)gy,
                      (T *)gmu_g, (T *)gmu_q, (T *)gs_p, (T *)gs_g, (T *)gs_q, total_x, total_y, (uint32_t)K,
-                     (uint32_t)Dx, (uint32_t)Dy);
+                     (uint32_t)Dx, (uint32_t)Dy, (const T *)lw, (const T *)lse, (const T *)grad_lse);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
@@ -980,5 +990,35 @@ extern "C" int aesmc_normal_logweight_backward(int dtype, const aesmc_view3 *vie
   if (dtype == AESMC_F64)
     return launch_logweight_bwd<double>(v, grad_lw, grad_x, grad_mu_p, grad_y, grad_mu_g, grad_mu_q, grad_s_p,
                                         grad_s_g, grad_s_q, B, K, Dx, Dy, s);
+  return AESMC_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int aesmc_normal_logweight_lse_backward(int dtype, const aesmc_view3 *views, const void *lw,
+                                                   const void *lse, const void *grad_lse, const void *grad_lw,
+                                                   void *grad_x, void *grad_mu_p, void *grad_y, void *grad_mu_g,
+                                                   void *grad_mu_q, void *grad_s_p, void *grad_s_g,
+                                                   void *grad_s_q, int64_t B, int64_t K, int64_t Dx,
+                                                   int64_t Dy, void *stream) {
+  using namespace aesmc;
+  if (views == nullptr || lw == nullptr || lse == nullptr || grad_lse == nullptr || B < 0 || K < 0 || Dx < 1 ||
+      Dy < 1)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  View3 v[8];
+  for (int i = 0; i < 8; ++i) {
+    if (views[i].ptr == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+    v[i].ptr = views[i].ptr;
+    v[i].st = Strides3{views[i].stride_b, views[i].stride_k, views[i].stride_d};
+  }
+  if (!grad_x && !grad_mu_p && !grad_y && !grad_mu_g && !grad_mu_q && !grad_s_p && !grad_s_g && !grad_s_q)
+    return AESMC_OK;
+  if (B == 0 || K == 0) return AESMC_OK;
+  if (K >= (1ll << 31) || B >= (1ll << 31) || Dx >= (1ll << 31) || Dy >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AESMC_F32)
+    return launch_logweight_bwd<float>(v, grad_lw, grad_x, grad_mu_p, grad_y, grad_mu_g, grad_mu_q, grad_s_p,
+                                       grad_s_g, grad_s_q, B, K, Dx, Dy, s, lw, lse, grad_lse);
+  if (dtype == AESMC_F64)
+    return launch_logweight_bwd<double>(v, grad_lw, grad_x, grad_mu_p, grad_y, grad_mu_g, grad_mu_q, grad_s_p,
+                                        grad_s_g, grad_s_q, B, K, Dx, Dy, s, lw, lse, grad_lse);
   return AESMC_ERR_INVALID_ARGUMENT;
 }

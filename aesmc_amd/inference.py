@@ -253,6 +253,12 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
         raise ValueError("inference_algorithm must be either is or smc. currently = {}".format(
             inference_algorithm))
     use_smc = inference_algorithm == "smc"
+    # SMC differentiates the log-weights only through their per-step row log-sum-exp unless the caller
+    # asks for the weights themselves (get_loss does not): then K5 runs without an autograd node and
+    # the log-sum-exp — produced by the NEXT step's resampling launch — is tied to K5's operands
+    # afterwards, its backward being K5's with K1's softmax term formed in place
+    fold_lse_backward = use_smc and not return_log_weight and not return_log_weights
+    deferred = {}         # timestep -> K5 operands whose log-sum-exp is still to be attached
     num_timesteps = len(observations)
     batch_size = _first_tensor(observations[0]).size(0)
     keep_originals = return_original_latents or return_latents
@@ -282,7 +288,8 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                 index, lse_previous, moved = _ops.resample_step(previous, feed.next(), newest,
                                                                 want_lse=step_lse[-1] is None)
                 if step_lse[-1] is None:
-                    step_lse[-1] = lse_previous
+                    step_lse[-1] = lse_previous if (time - 1) not in deferred else \
+                        _ops.attach_lse(lse_previous, previous, deferred.pop(time - 1))
                 indices.append(index)
                 if _HISTORY_MODE == "lazy":
                     ancestors = ResampledHistory(history, index, newest=moved)
@@ -316,8 +323,13 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
         # (K4 or the distribution's own log_prob) combined by K1
         log_weight_t = None
         if not isinstance(latent, dict) and not isinstance(observation, dict):
+            fold = fold_lse_backward and torch.is_grad_enabled()
             log_weight_t = state.normal_log_weight(prior_dist, proposal_dist, latent, emission_dist,
-                                                   observation)
+                                                   observation, defer_grad=fold)
+            if fold and log_weight_t is not None:
+                log_weight_t, operands = log_weight_t
+                if any(t.requires_grad for t in operands):
+                    deferred[time] = operands
         # importance sampling over several timesteps normalises the SUM of the per-step weights
         # (inference.py:156-159); K1 keeps that sum running, left to right as torch.sum over the
         # reference's stack does, and hands out its row log-sum-exp with the last step
@@ -329,6 +341,8 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
             # (importance sampling never needs the per-step value: it normalises the summed weights)
             pending = use_smc and time + 1 < num_timesteps
             lse_t = None if (pending or not use_smc) else _ops.row_logsumexp(log_weight_t)
+            if lse_t is not None and time in deferred:
+                lse_t = _ops.attach_lse(lse_t, log_weight_t, deferred.pop(time))
             if accumulate:
                 _, running, running_lse = _ops.logweight_accumulate(
                     log_weight_t, None, None, running, want_lse=last_step and return_log_marginal_likelihood)

@@ -172,12 +172,14 @@ def log_prob(distribution, value):
     return logp.reshape(value.size(0), value.size(1), -1).sum(dim=2)
 
 
-def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observation):
+def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observation, defer_grad=False):
     """One step's log-weight  log_prob(prior, latent) + log_prob(emission, observation)
     - log_prob(proposal, latent)  (aesmc/inference.py:112-126) in ONE kernel (K5) when all three
     distributions are plain Normals (any scales) on the HIP device; None otherwise — the
     caller then takes three `log_prob` calls, which give bit-identical numbers.  `observation` is
-    already expanded over particles.  Validation is what the three `log_prob` calls would do."""
+    already expanded over particles.  Validation is what the three `log_prob` calls would do.
+    `defer_grad`: return (log-weights without an autograd node, K5's operands) for a caller that
+    differentiates only through the row log-sum-exp (`_ops.attach_lse`)."""
     if not _FUSED_NORMAL:
         return None
     operands = []
@@ -198,6 +200,8 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
         elif distribution._validate_args:
             _validate_sample(distribution, value.transpose(0, 1))
     (_, _, _, (loc_p, scale_p)), (_, _, _, (loc_g, scale_g)), (_, _, _, (loc_q, scale_q)) = operands
+    if defer_grad:
+        return _ops.normal_log_weight_deferred(latent, loc_p, scale_p, observation, loc_g, scale_g, loc_q, scale_q)
     return _ops.normal_log_weight(latent, loc_p, scale_p, observation, loc_g, scale_g, loc_q, scale_q)
 
 

@@ -194,6 +194,20 @@ int aesmc_normal_logweight_backward(int dtype, const aesmc_view3 *views, const v
                                     void *grad_s_p, void *grad_s_g, void *grad_s_q, int64_t B, int64_t K,
                                     int64_t Dx, int64_t Dy, void *stream);
 
+/* K5 backward fused with K1's: the gradient of  lse[b] = logsumexp_k lw[b,k]  (and, optionally, of lw
+ * itself) with respect to K5's operands in one launch —
+ *   g[b,k] = grad_lse[b] * exp(lw[b,k] - lse[b])  (+ grad_lw[b,k] when grad_lw is not NULL)
+ * is formed per element where aesmc_normal_logweight_backward would read grad_lw, with K1's own
+ * operations, so the results equal aesmc_logweight_lse_backward followed by
+ * aesmc_normal_logweight_backward bit for bit, without the [B,K] round trip and the launch.
+ * `lw` is what aesmc_normal_logweight produced for `views`; lse, grad_lse are [B].  Replaces the
+ * autograd chain of aesmc/inference.py:112-132 for one timestep. */
+int aesmc_normal_logweight_lse_backward(int dtype, const aesmc_view3 *views, const void *lw, const void *lse,
+                                        const void *grad_lse, const void *grad_lw, void *grad_x,
+                                        void *grad_mu_p, void *grad_y, void *grad_mu_g, void *grad_mu_q,
+                                        void *grad_s_p, void *grad_s_g, void *grad_s_q, int64_t B, int64_t K,
+                                        int64_t Dx, int64_t Dy, void *stream);
+
 /* Fused resampling step — K2, plus two optional by-products of having the whole batch row in one
  * workgroup:
  *   out_lse[b] = logsumexp_k log_w[b,k]  (dtype of log_w; the row's term of log Z,

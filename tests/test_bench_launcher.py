@@ -58,8 +58,11 @@ def test_self_launch_runs_real_children_over_gloo_free_dry_run():
     """End to end through torch.distributed.run on this CPU box: the parent spawns two ranks, each
     parses the same flags, sees its RANK / WORLD_SIZE and (dry run) stops before the GPU."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    command = bench.child_command(["--gpus", "2", "--dry-run", "--scaling", "strong"], 2)
-    done = subprocess.run(command, env=bench.child_environment(env), capture_output=True, text=True, timeout=600)
+    for attempt in range(3):      # the probed rendezvous port can be taken before torchrun binds it
+        command = bench.child_command(["--gpus", "2", "--dry-run", "--scaling", "strong"], 2)
+        done = subprocess.run(command, env=bench.child_environment(env), capture_output=True, text=True, timeout=600)
+        if done.returncode == 0:
+            break
     assert done.returncode == 0, done.stderr[-2000:]
     plans = [json.loads(line) for line in done.stdout.splitlines() if line.startswith("{")]
     assert sorted(p["rank"] for p in plans) == [0, 1]
