@@ -60,12 +60,13 @@ def _on_device(device):
 
 class KernelTimer:
     """Optional per-kernel timing for bench.py's `roofline` leg.  While installed on the provider
-    it keeps a bounded random sample of the launches made (the ctypes call with its operands);
-    `summary()` then replays each kernel's sample back to back on the current stream between two
-    HIP events, so the figure is kernel time on the real operands without the host gaps that
-    surround a launch inside the (host-bound) timestep loop.  `bytes` is the ALGORITHMIC traffic
-    of a launch: what the operation must move, not what the hardware
-    happened to move."""
+    it keeps a bounded random sample of the launches made (the C-ABI entry point with its operands);
+    `summary()` then captures each kernel's sample, launched back to back, into one hipGraph and
+    times replays of it between two HIP events on the replaying stream: kernel time on the real
+    operands without host gaps (a 9 us kernel cannot be timed through ~10 us Python launches).  The
+    sample cycles through distinct operands, so caches are as cold as in the workload.  `bytes` is
+    the ALGORITHMIC traffic of a launch: what the operation must move, not
+    what the hardware happened to move."""
 
     def __init__(self, keep=24, seed=0):
         import random
@@ -74,6 +75,7 @@ class KernelTimer:
         self.launches = {}   # name -> [count, [(fn, nbytes, keepalive), ...]]
 
     def note(self, name, fn, nbytes, keepalive):
+        """`fn` = (entry point, argument tuple whose LAST element is the stream)."""
         entry = self.launches.setdefault(name, [0, []])
         entry[0] += 1
         if len(entry[1]) < self.keep:
@@ -88,17 +90,30 @@ class KernelTimer:
         provider.timer = None       # the replays (and the K7 call below) must not be noted again
         out = {}
         for name, (count, sample) in list(self.launches.items()):
+            def launch_all():
+                stream = torch.cuda.current_stream().cuda_stream
+                for (entry, args), _, _ in sample:
+                    entry(*(args[:-1] + (stream,)))
             torch.cuda.synchronize()
-            for fn, _, _ in sample:  # warm
-                fn()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):      # warm-up off the default stream, as capture requires
+                launch_all()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                launch_all()
+            graph.replay()
+            torch.cuda.synchronize()
             begin = torch.cuda.Event(enable_timing=True)
             end = torch.cuda.Event(enable_timing=True)
             begin.record()
             for _ in range(repeats):
-                for fn, _, _ in sample:
-                    fn()
+                graph.replay()
             end.record()
             torch.cuda.synchronize()
+            del graph
             seconds = begin.elapsed_time(end) * 1e-3 / (repeats * len(sample))
             nbytes = sum(n for _, n, _ in sample) / len(sample)
             out[name] = {"launches": count, "sampled": len(sample), "avg_us": 1e6 * seconds,
@@ -212,7 +227,7 @@ class HipKernels:
             if self.timer is not None:
                 esz = a.element_size()
                 terms = 1 + (b is not None) + (c is not None) + (lw is not None)
-                self.timer.note("logweight_lse", lambda: self._lib.aesmc_logweight_lse(*args),
+                self.timer.note("logweight_lse", (self._lib.aesmc_logweight_lse, args),
                                 B * K * esz * terms + B * esz, (a, b, c, lw, lse))
         if want_lw and not need_lw:
             lw = a
@@ -249,7 +264,7 @@ class HipKernels:
             if self.timer is not None:
                 esz = a.element_size()
                 terms = 3 + (b is not None) + (c is not None) + (lw is not None)
-                self.timer.note("logweight_accumulate", lambda: self._lib.aesmc_logweight_accumulate(*args),
+                self.timer.note("logweight_accumulate", (self._lib.aesmc_logweight_accumulate, args),
                                 B * K * esz * terms + (B * esz if want_lse else 0), (a, b, c, acc, lw, total, lse))
         if want_lw and not need_lw:
             lw = a
@@ -280,7 +295,7 @@ class HipKernels:
             if self.timer is not None:
                 terms = 2 + (grad_lw is not None) + (ng is not None)
                 self.timer.note("logweight_lse_backward",
-                                lambda: self._lib.aesmc_logweight_lse_backward(*args),
+                                (self._lib.aesmc_logweight_lse_backward, args),
                                 B * K * lw.element_size() * terms, (lw, lse, grad_lw, grad_lse, g, ng))
         return g, ng
 
@@ -307,7 +322,7 @@ class HipKernels:
                     self._stream(log_w))
             _lib.check(self._lib.aesmc_ancestor_index(*args), "aesmc_ancestor_index")
             if self.timer is not None:
-                self.timer.note("ancestor_index", lambda: self._lib.aesmc_ancestor_index(*args),
+                self.timer.note("ancestor_index", (self._lib.aesmc_ancestor_index, args),
                                 B * K * (log_w.element_size() + 8) + 8 * B, (log_w, u, idx, ws))
         idx._aesmc_sorted = True  # systematic resampling is monotone in k: lets K3's backward skip atomics
         return idx
@@ -388,7 +403,7 @@ class HipKernels:
                 nbytes = B * K * (log_w.element_size() + 8) + 8 * B
                 if dst is not None:  # K2's 12 B + K3's (8 + 2 row_bytes) per particle
                     nbytes += B * K * (8 + 2 * row_bytes)
-                self.timer.note("resample_step", lambda: self._lib.aesmc_resample_step(*args), nbytes,
+                self.timer.note("resample_step", (self._lib.aesmc_resample_step, args), nbytes,
                                 (log_w, u, idx, lse, payload, dst))
         idx._aesmc_sorted = True
         return idx, lse, dst
@@ -426,7 +441,7 @@ class HipKernels:
                     src.stride(0) * esz, src.stride(1) * esz, self._stream(src))
             _lib.check(self._lib.aesmc_resample_gather(*args), "aesmc_resample_gather")
             if self.timer is not None:
-                self.timer.note("resample_gather", lambda: self._lib.aesmc_resample_gather(*args),
+                self.timer.note("resample_gather", (self._lib.aesmc_resample_gather, args),
                                 B * K * (8 + 2 * row_elems * esz), (src, idx, dst))
         return dst
 
@@ -453,7 +468,7 @@ class HipKernels:
                        "aesmc_resample_gather_backward")
             if self.timer is not None:
                 self.timer.note("resample_gather_backward",
-                                lambda: self._lib.aesmc_resample_gather_backward(*args),
+                                (self._lib.aesmc_resample_gather_backward, args),
                                 B * K * (8 + 2 * row_elems * grad_out.element_size()),
                                 (grad_out, idx, grad_src))
         return grad_src
@@ -517,7 +532,7 @@ class HipKernels:
             _lib.check(self._lib.aesmc_normal_logprob_sum(*args), "aesmc_normal_logprob_sum")
             if self.timer is not None:
                 nbytes = sum(self._unique_bytes(t) for t in (value, loc, scale)) + out.numel() * out.element_size()
-                self.timer.note("normal_logprob_sum", lambda: self._lib.aesmc_normal_logprob_sum(*args),
+                self.timer.note("normal_logprob_sum", (self._lib.aesmc_normal_logprob_sum, args),
                                 nbytes, (value, loc, scale, out))
         return out
 
@@ -542,7 +557,7 @@ class HipKernels:
                 nbytes = sum(self._unique_bytes(t) for t in (value, loc, scale, grad_out)) + \
                     sum(o.numel() * o.element_size() for o in outs if o is not None)
                 self.timer.note("normal_logprob_sum_backward",
-                                lambda: self._lib.aesmc_normal_logprob_sum_backward(*args), nbytes,
+                                (self._lib.aesmc_normal_logprob_sum_backward, args), nbytes,
                                 (value, loc, scale, grad_out) + tuple(outs))
         return tuple(outs)
 
@@ -590,7 +605,7 @@ class HipKernels:
             if self.timer is not None:
                 nbytes = sum(self._unique_bytes(t) for t in (x, loc_p, y, loc_g, loc_q)) + \
                     out.numel() * out.element_size()
-                self.timer.note("normal_logweight", lambda: self._lib.aesmc_normal_logweight(*args), nbytes,
+                self.timer.note("normal_logweight", (self._lib.aesmc_normal_logweight, args), nbytes,
                                 (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, out, views))
         return out
 
@@ -644,7 +659,7 @@ class HipKernels:
                 live = [t for t in outs if t is not None]
                 reads = [t for t in (x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, lw) if t is not None]
                 nbytes = sum(self._unique_bytes(t) for t in reads) + sum(t.numel() * t.element_size() for t in live)
-                self.timer.note(name[6:], lambda: entry(*args), nbytes,
+                self.timer.note(name[6:], (entry, args), nbytes,
                                 tuple(reads) + (lse, grad_lse, views) + tuple(live))
         return outs
 
@@ -671,7 +686,7 @@ class HipKernels:
             _lib.check(status, "aesmc_normal_rsample")
             if self.timer is not None:
                 nbytes = sum(self._unique_bytes(t) for t in (eps, loc, scale)) + out.numel() * out.element_size()
-                self.timer.note("normal_rsample", lambda: self._lib.aesmc_normal_rsample(*args), nbytes,
+                self.timer.note("normal_rsample", (self._lib.aesmc_normal_rsample, args), nbytes,
                                 (eps, loc, scale, out, views))
         return out
     # ---- K7 ------------------------------------------------------------------------------------
@@ -717,7 +732,7 @@ class HipKernels:
             _lib.check(self._lib.aesmc_particle_summary(*args), "aesmc_particle_summary")
             if self.timer is not None:
                 nbytes = log_w.numel() * log_w.element_size() + (self._unique_bytes(value) if view is not None else 0)
-                self.timer.note("particle_summary", lambda: self._lib.aesmc_particle_summary(*args), nbytes,
+                self.timer.note("particle_summary", (self._lib.aesmc_particle_summary, args), nbytes,
                                 (log_w, value, view, log_ess, mean, second, ws))
         return log_ess, mean, second
 

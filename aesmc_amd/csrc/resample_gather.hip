@@ -294,10 +294,10 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_sorted_kerne
 // trimmed at either end: the first row belongs to it only when that run, begun in an earlier tile,
 // ends here; the last row only when its run ends here; the tile holding particle K - 1 also owns
 // everything up to row K - 1.  Rows of the range with a run ending here receive their sum, the
-// others — particles without offspring — zero.  Ranges of up to `cap` rows (the usual case: a tile
-// of 256 particles covers about 256 rows) are assembled in LDS and stored as one dense, coalesced
-// block; longer ranges (collapsed particle systems) mark the summed rows in an LDS bitmap and
-// store zeros to the rest directly.
+// others — particles without offspring — zero.  The sums are left in the staging buffer at their
+// run's last row; a small map (destination row -> staged row, `cap` entries of 16 bits in LDS, the
+// range is walked in pieces of `cap` rows) then lets the workgroup store the whole range as one
+// dense, coalesced stream.
 template <typename T, bool VEC_LOAD>
 __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel(
     const T *__restrict__ grad_out, const int64_t *__restrict__ idx, T *__restrict__ grad_src,
@@ -306,14 +306,14 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
   T *G = reinterpret_cast<T *>(range_smem);                    // [TK * D] staged gradient rows
   T *lead = G + (size_t)TK * D;                                // [D] rows of the first run before the tile
   T *partials = lead + D;                                      // [256] per-lane partial sums of `lead`
-  T *acc = partials + kSortedBlock;                            // [cap * D] the tile's dense destination range
-  int *ids = reinterpret_cast<int *>(acc + (size_t)cap * D);   // [TK + 2]: before, tile, after
+  int *ids = reinterpret_cast<int *>(partials + kSortedBlock); // [TK + 2]: before, tile, after
   int *tails = ids + TK + 2;                                   // [TK] positions of run tails, compacted
   int *head_of = tails + TK;                                   // [TK] position of the run head at or before i (-1: earlier tile)
   int *wave_tails = head_of + TK;                              // [4] tails per wavefront
   int *wave_head = wave_tails + 4;                             // [4] last head position per wavefront
   int *shared_lo = wave_head + 4;                              // [1]
-  unsigned *has = reinterpret_cast<unsigned *>(shared_lo + 1); // [(K + 31) / 32] long ranges: rows that get a sum
+  unsigned short *slot_of = reinterpret_cast<unsigned short *>(shared_lo + 1);  // [cap] staged row holding a
+                                                               // destination row's sum (0xffff: none)
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid % kWave, wave = tid / kWave;
   const uint32_t b = blockIdx.x / tiles_per_row;
@@ -374,12 +374,6 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
   if (jhi > (int)K - 1) jhi = (int)K - 1;
   const uint32_t L = jhi >= jlo ? (uint32_t)(jhi - jlo + 1) : 0u;
   if (L == 0) return;                                          // wholly inside one run that flows on
-  const bool dense = L <= cap;
-  if (dense) {
-    for (uint32_t e = tid; e < L * D; e += kSortedBlock) acc[e] = T(0);
-  } else {
-    for (uint32_t w = tid; w < (L + 31) / 32; w += kSortedBlock) has[w] = 0u;
-  }
 
   // ---- 2. stage the gradient rows ------------------------------------------------------------------
   const uint32_t ne = n * D;
@@ -446,36 +440,41 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
   }
   __syncthreads();
 
-  // ---- 4. one element per (tail, column) ---------------------------------------------------------
+  // ---- 4. one element per (tail, column): the run's sum replaces its last staged row ---------------
   const uint32_t total = (uint32_t)num_tails * D;
   for (uint32_t e = tid; e < total; e += kSortedBlock) {
     const uint32_t t = e / D, c = e - t * D;
     const int i = tails[t];
-    const int id = ids[1 + i];
-    if (id < jlo || id > jhi) continue;                        // out-of-range index (reported above)
     const int h = head_of[i];
     T sum = (h < 0 && has_lead) ? lead[c] : T(0);
     for (int r = h < 0 ? 0 : h; r <= i; ++r) sum += G[(uint32_t)r * D + c];
-    if (dense) {
-      acc[(uint32_t)(id - jlo) * D + c] = sum;
-    } else {
-      drow[(uint64_t)id * D + c] = sum;
-      if (c == 0) atomicOr(&has[(uint32_t)(id - jlo) >> 5], 1u << ((uint32_t)(id - jlo) & 31u));
-    }
+    G[(uint32_t)i * D + c] = sum;                              // only this lane touches column c of rows h..i
   }
-  __syncthreads();
 
   // ---- 5. the range goes out: sums where a run ended, zeros where a particle left no offspring --------
-  T *out = drow + (uint64_t)jlo * D;
-  if (dense) {
-    for (uint32_t e = tid; e < L * D; e += kSortedBlock) out[e] = acc[e];
-  } else {
-    const uint32_t cols = min(D, (uint32_t)kSortedBlock), per = kSortedBlock / cols;
-    const uint32_t sub = tid / cols, col = tid - sub * cols;
-    if (sub < per) {
-      for (uint32_t j = sub; j < L; j += per) {
-        if (has[j >> 5] & (1u << (j & 31u))) continue;
-        for (uint32_t c = col; c < D; c += cols) out[(uint64_t)j * D + c] = T(0);
+  const uint32_t qstep = kSortedBlock / D, rstep = kSortedBlock - qstep * D;
+  for (uint32_t piece = 0; piece < L; piece += cap) {
+    const uint32_t np = min(cap, L - piece);
+    const int first_row = jlo + (int)piece;
+    __syncthreads();
+    for (uint32_t j = tid; j < np; j += kSortedBlock) slot_of[j] = 0xffffu;
+    __syncthreads();
+    for (uint32_t t = tid; t < (uint32_t)num_tails; t += kSortedBlock) {
+      const int i = tails[t];
+      const int id = ids[1 + i];                               // ids outside [jlo, jhi]: out of range, reported above
+      if (id >= first_row && id < first_row + (int)np && id <= jhi) slot_of[id - first_row] = (unsigned short)i;
+    }
+    __syncthreads();
+    T *out = drow + (uint64_t)first_row * D;
+    uint32_t j = tid / D, c = tid - j * D;                     // element e = tid + m * 256 is (row j, column c)
+    for (uint32_t e = tid; e < np * D; e += kSortedBlock) {
+      const uint32_t slot = slot_of[j];
+      out[e] = slot != 0xffffu ? G[slot * D + c] : T(0);
+      j += qstep;
+      c += rstep;
+      if (c >= D) {
+        c -= D;
+        ++j;
       }
     }
   }
@@ -602,13 +601,11 @@ static bool launch_range_backward(const void *grad_out, const int64_t *idx, void
   if (TK > 256) TK = 256;
   if (TK < 8) return false;
   if (TK > K) TK = K;
-  int64_t cap = (24 * 1024) / row_bytes;                       // dense destination range: at most 24 KiB
-  if (cap > TK + TK / 2) cap = TK + TK / 2;                    // a tile of TK particles covers about TK rows
+  int64_t cap = K < 2048 ? K : 2048;                           // rows of the range mapped at a time (2 B each)
   const int64_t tiles = (K + TK - 1) / TK;
   if (B * tiles > 0x7fffffffLL) return false;
-  const size_t floats = (size_t)(TK * D + D + kSortedBlock + cap * D);
-  const size_t lds = floats * sizeof(T) + (size_t)(3 * TK + 2 + 9 + (K + 31) / 32) * sizeof(int);
-  if (lds > 64 * 1024) return false;                           // K beyond ~250 000 with wide rows
+  const size_t floats = (size_t)(TK * D + D + kSortedBlock);
+  const size_t lds = floats * sizeof(T) + (size_t)(3 * TK + 2 + 9) * sizeof(int) + (size_t)((cap + 1) / 2 * 2) * 2;
   const bool vec = (((uintptr_t)grad_out & 15u) == 0) && ((K * D) % N == 0) && ((TK * D) % N == 0);
   dim3 grid((unsigned)(B * tiles)), block(kSortedBlock);
   if (vec)

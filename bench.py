@@ -63,6 +63,8 @@ WORKLOADS = {
     "c5h": ("LGSSM d=128 B=64 K=16384 T=200, emission scale 0.05, SMC ELBO forward (configs[4] shape, healthy particle system)",
             "lgssm", 128, 64, 16384, 200, {"emission_scale": 0.05}),
 }
+WORKLOADS["tiny"] = ("LGSSM d=3 B=8 K=64 T=5 (test-sized: exercises every leg of this file in seconds)",
+                     "lgssm", 3, 8, 64, 5, {})
 ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
 NO_GRAD = {"c5", "c5h"}             # autograd retention of T x [B,K,128] temporaries exceeds HBM: forward under no_grad
 GRAPH_PARTICLES = 1 << 20           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
@@ -429,6 +431,9 @@ def roofline_of(stats, label, workload, proposal, key):
     traffic, source = traffic_record(workload, proposal, key)
     out["traffic"] = traffic
     out["traffic_source"] = source
+    if traffic:     # HBM bytes the counters saw per launch, over this run's launch time
+        out["achieved_traffic"] = round(traffic / stats["avg_us"] / 1e3, 1)
+        out["frac_traffic"] = round(min(traffic / stats["avg_us"] / 1e3 / HBM_PEAK_GBPS, 1.0), 4)
     if "unique_ancestor_fraction" in stats:
         out["unique_ancestor_fraction"] = round(stats["unique_ancestor_fraction"], 4)
         out["moved_bytes_per_launch"] = stats["moved_bytes_per_launch"]
@@ -455,17 +460,29 @@ def kernel_legs(ctx):
     dev = ctx.device
     gen = torch.Generator(device=dev).manual_seed(0)
 
-    def timeit(fn, reps=20):
-        for _ in range(3):
-            fn()
+    def timeit(fn, reps=20, replays=5):
+        """Device time per call: `reps` calls captured in one hipGraph, replayed between two HIP events
+        (no host gaps: the small launches here run shorter than Python can issue them)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(reps):
+                fn()
+        graph.replay()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(reps):
-            fn()
+        for _ in range(replays):
+            graph.replay()
         b.record()
         torch.cuda.synchronize()
-        return a.elapsed_time(b) * 1e3 / reps
+        return a.elapsed_time(b) * 1e3 / (reps * replays)
 
     def leg(us, nbytes, **more):
         gbps = nbytes / us / 1e3
@@ -500,7 +517,7 @@ def kernel_legs(ctx):
         lw = torch.randn(B, K, device=dev, generator=gen)
         idx = k.ancestor_index(lw, u)
         unique = (int((idx[:, 1:] != idx[:, :-1]).sum().item()) + B) / (B * K)
-        us = timeit(lambda: k.resample_step(lw, u, x, want_lse=True), reps=50)
+        us = timeit(lambda: k.resample_step(lw, u, x, want_lse=True))
         moved = B * K * 12 + (1 + unique) * x.numel() * 4
         legs["step_{}_s1".format(label)] = leg(
             us, B * K * (20 + 8 * d) + 8 * B, shape="B={} K={} d={} (fused step: K2 + K3)".format(B, K, d),

@@ -1049,8 +1049,10 @@ def test_resample_step_does_not_depend_on_workgroups_per_row(kernels, hip_device
                                          ((5, 1024, 16), 200.0), ((2, 4096, 10), 0.0), ((2, 4096, 10), 3.0)])
 def test_sorted_backward_kernels_agree_bit_for_bit(kernels, hip_device, dtype, shape, scale):
     """The range kernel (every row of the gradient written once, no zero fill) and round 1's kernel
-    behind a zero fill sum the same rows in the same order: identical bits, also into a destination
-    that held garbage (nothing may rely on a previous fill)."""
+    behind a zero fill sum the same rows in the same order when their tiles coincide (rows up to
+    112 bytes: 256 particles per tile in both): identical bits, also into a destination that held
+    garbage (nothing may rely on a previous fill).  Wider rows tile differently (28 vs 32 KiB of
+    staging), so a run crossing a tile boundary is associated differently: equal to rounding."""
     rng = np.random.RandomState(shape[1] + int(scale) + 1)
     go = dev(rng.randn(*shape).astype(dtype), hip_device)
     idx = dev(sorted_indices(rng, shape[0], shape[1], scale), hip_device)
@@ -1064,7 +1066,12 @@ def test_sorted_backward_kernels_agree_bit_for_bit(kernels, hip_device, dtype, s
     finally:
         lib.aesmc_set_sorted_backward_kernel(0)
     assert kernels.read_flags(hip_device) == 0
-    assert torch.equal(outs[0], outs[1])
+    row_bytes = int(np.prod(shape[2:])) * go.element_size()
+    if row_bytes <= 112:
+        assert torch.equal(outs[0], outs[1])
+    else:
+        rtol, atol = tol(dtype)
+        torch.testing.assert_close(outs[0], outs[1], rtol=50 * rtol, atol=200 * atol)
     assert bool(torch.isfinite(outs[1]).all())
 
 

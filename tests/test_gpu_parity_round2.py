@@ -252,3 +252,33 @@ def test_full_size_config4_shard_against_the_kalman_filter(hip_device, proposal)
     else:
         assert np.mean(unique) < 0.3, np.mean(unique)       # collapses
         assert gap.max() < 3.0 and -25.0 < gap.mean() < 0.5, gap
+
+
+@pytest.mark.parametrize("kind,B,K,T,d", [("lgssm", 4, 256, 6, 10), ("learned_scale", 3, 128, 4, 6), ("lgssm", 2, 64, 1, 3)])
+def test_folded_lse_backward_equals_the_two_launch_route_bit_for_bit(hip_device, kind, B, K, T, d):
+    """`get_loss` differentiates the log-weights only through their per-step log-sum-exp, so K5 runs
+    without an autograd node and K1's softmax gradient is formed inside K5's backward
+    (aesmc_normal_logweight_lse_backward).  The same ELBO asked for WITH the log-weights
+    (`infer(return_log_weight=True)`) takes K1's backward and K5's backward as two launches: every
+    parameter gradient of the two routes must be identical, and so must the loss."""
+    cls = {"lgssm": models.LgssmNd, "learned_scale": models.LearnedScaleSsm}[kind]
+    model = cls(d, seed=0, validate_args=False).to(hip_device)
+    observations = model.simulate(T, B, seed=1)
+    parts = (model.initial, model.transition, model.emission, model.proposal)
+    np.random.seed(1)
+    torch.manual_seed(1)
+    with replay.record() as tape:
+        loss = losses.get_loss(observations, K, "aesmc", *parts)
+    loss.backward()
+    folded = {name: p.grad.clone() for name, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    with replay.replay(tape):
+        out = inference.infer("smc", observations, *parts, K, return_log_marginal_likelihood=True,
+                              return_latents=False, return_log_weight=True)
+    unfolded_loss = -torch.mean(out["log_marginal_likelihood"])
+    unfolded_loss.backward()
+    assert torch.equal(loss.detach(), unfolded_loss.detach())
+    assert len(folded) > 0
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(folded[name], p.grad), (name, float((folded[name] - p.grad).abs().max()))
