@@ -45,7 +45,11 @@ static inline uint32_t pick_slices(int64_t B, int64_t K) {
   return (uint32_t)want;
 }
 
-template <typename T>
+// VEC: the values of a particle are dense and 16-byte aligned — a lane then owns kSumRegs CONSECUTIVE
+// columns and fetches them with 16-byte loads (TX = D / kSumRegs lanes per particle: 32 at D = 128, so
+// eight particles per pass and four passes in flight), instead of kSumRegs columns TX apart by 4-byte
+// loads.  Same sums in the same order per column.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(kSumBlock) void particle_summary_kernel(
     const T *__restrict__ log_w, const T *__restrict__ value, SumStrides sv, T *__restrict__ out_log_ess,
     T *__restrict__ out_mean, T *__restrict__ out_second, T *__restrict__ records, uint32_t K, uint32_t D,
@@ -114,10 +118,28 @@ __global__ __launch_bounds__(kSumBlock) void particle_summary_kernel(
           const uint32_t k = k0 + q * TY;
           const bool live = k < k_hi;
           e[q] = live ? Num<T>::exp(lw[k] - m) : T(0);
+          if constexpr (VEC) {
+            constexpr int N = Vec16<T>::N;
+            using V = typename Vec16<T>::type;
+            const uint32_t j = c0 + tx * kSumRegs;            // num_cols is a multiple of kSumRegs
+            if (live && j < num_cols) {
+              const V *src = reinterpret_cast<const V *>(vrow + (int64_t)k * sv.k + j);
 #pragma unroll
-          for (int r = 0; r < kSumRegs; ++r) {
-            const uint32_t j = c0 + r * TX + tx;
-            v[q][r] = (live && j < num_cols) ? vrow[(int64_t)k * sv.k + (int64_t)j * sv.d] : T(0);
+              for (int h = 0; h < kSumRegs / N; ++h) {
+                const V packed = src[h];
+#pragma unroll
+                for (int r = 0; r < N; ++r) v[q][h * N + r] = Vec16<T>::get(packed, r);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < kSumRegs; ++r) v[q][r] = T(0);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < kSumRegs; ++r) {
+              const uint32_t j = c0 + r * TX + tx;
+              v[q][r] = (live && j < num_cols) ? vrow[(int64_t)k * sv.k + (int64_t)j * sv.d] : T(0);
+            }
           }
         }
 #pragma unroll
@@ -163,8 +185,9 @@ __global__ __launch_bounds__(kSumBlock) void particle_summary_kernel(
     if (ty < TY) {
 #pragma unroll
       for (int r = 0; r < kSumRegs; ++r) {
-        partial[(ty * cols_per_sweep + r * TX + tx) * 2] = acc1[r];
-        partial[(ty * cols_per_sweep + r * TX + tx) * 2 + 1] = acc2[r];
+        const uint32_t col = VEC ? tx * kSumRegs + r : r * TX + tx;
+        partial[(ty * cols_per_sweep + col) * 2] = acc1[r];
+        partial[(ty * cols_per_sweep + col) * 2 + 1] = acc2[r];
       }
     }
     __syncthreads();
@@ -375,6 +398,11 @@ static int launch_summary(const void *log_w, const aesmc_view3 *value, void *out
                           hipStream_t s) {
   uint32_t TX = 1;
   if (value != nullptr) TX = (uint32_t)(D < kSumBlock ? D : kSumBlock);
+  // 16-byte loads: dense, aligned rows whose length is a whole number of lane shares
+  const bool vec = value != nullptr && D > kSmallD && D % kSumRegs == 0 && value->stride_d == 1 &&
+                   (reinterpret_cast<uintptr_t>(value->ptr) & 15u) == 0 &&
+                   (value->stride_b * (int64_t)sizeof(T)) % 16 == 0 && (value->stride_k * (int64_t)sizeof(T)) % 16 == 0;
+  if (vec) TX = (uint32_t)(D / kSumRegs < kSumBlock ? D / kSumRegs : kSumBlock);
   const uint32_t TY = kSumBlock / TX;
   size_t lds = (size_t)TY * TX * kSumRegs * 2 * sizeof(T);
   const size_t lds_weights = (size_t)kSumBlock * 2 * sizeof(T);
@@ -406,11 +434,16 @@ static int launch_summary(const void *log_w, const aesmc_view3 *value, void *out
                        static_cast<const T *>(log_w), v, sv, static_cast<T *>(out_log_ess),
                        static_cast<T *>(out_mean), static_cast<T *>(out_second), records, (uint32_t)K, cols, S,
                        dense ? 1 : 0, R);
-  } else
-  hipLaunchKernelGGL(particle_summary_kernel<T>, dim3((unsigned)(B * S)), dim3(kSumBlock), lds, s,
-                     static_cast<const T *>(log_w), v, sv, static_cast<T *>(out_log_ess),
-                     static_cast<T *>(out_mean), static_cast<T *>(out_second), records, (uint32_t)K, cols, TX,
-                     S);
+  } else if (vec)
+    hipLaunchKernelGGL((particle_summary_kernel<T, true>), dim3((unsigned)(B * S)), dim3(kSumBlock), lds, s,
+                       static_cast<const T *>(log_w), v, sv, static_cast<T *>(out_log_ess),
+                       static_cast<T *>(out_mean), static_cast<T *>(out_second), records, (uint32_t)K, cols, TX,
+                       S);
+  else
+    hipLaunchKernelGGL((particle_summary_kernel<T, false>), dim3((unsigned)(B * S)), dim3(kSumBlock), lds, s,
+                       static_cast<const T *>(log_w), v, sv, static_cast<T *>(out_log_ess),
+                       static_cast<T *>(out_mean), static_cast<T *>(out_second), records, (uint32_t)K, cols, TX,
+                       S);
   if (S > 1)
     hipLaunchKernelGGL(particle_summary_merge_kernel<T>, dim3((unsigned)B), dim3(kSumBlock), 0, s, records,
                        static_cast<T *>(out_log_ess), static_cast<T *>(out_mean),

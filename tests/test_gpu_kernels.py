@@ -777,7 +777,9 @@ def test_normal_rsample_transposed_noise(kernels, hip_device, dtype, K, B, rest,
 # ---- K7 ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("shape", [(1, 1, ()), (2, 16, ()), (3, 7, (1,)), (5, 64, (3,)), (4, 1000, (10,)),
-                                   (2, 33, (128,)), (3, 5, (2, 3)), (2, 300, (300,)), (1, 5000, (17,))])
+                                   (2, 33, (128,)), (3, 5, (2, 3)), (2, 300, (300,)), (1, 5000, (17,)),
+                                   (2, 2000, (128,)), (3, 600, (20,)), (1, 700, (1024,)), (1, 300, (2048,)),
+                                   (2, 257, (18,))])
 @pytest.mark.parametrize("scale", [1.0, 8.0])
 def test_particle_summary_matches_oracle(kernels, hip_device, dtype, shape, scale):
     B, K, tail = shape
