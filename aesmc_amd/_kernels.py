@@ -102,7 +102,9 @@ class KernelTimer:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: with a process group alive RCCL's watchdog thread may call the HIP runtime
+            # at any time; that must not invalidate this capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 launch_all()
             graph.replay()
             torch.cuda.synchronize()

@@ -471,7 +471,7 @@ def kernel_legs(ctx):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             for _ in range(reps):
                 fn()
         graph.replay()

@@ -70,7 +70,15 @@ def _run_rank(rank, world, port, out_dir):
         with replay.replay(_slice_tape(tape, lo, hi)), distributed.shard_scope(B, rank, world):
             result = inference.infer("smc", local_obs, *parts, K, return_ancestral_indices=True,
                                      return_latents=False)
+        # importance sampling over T steps: the running sum of K1 instead of a [T,B,K] stack
+        with replay.replay(_slice_tape(tape, lo, hi)):
+            iwae = distributed.sharded_get_loss(local_obs, K, "iwae", *parts, global_batch_size=B)
+        iwae_grads = [g.clone() for g in torch.autograd.grad(iwae, list(model.parameters()), allow_unused=True)
+                      if g is not None]
+        for g in iwae_grads:
+            dist.all_reduce(g)
         torch.save({"loss": loss.detach(), "grads": [p.grad.clone() for p in model.parameters()],
+                    "iwae_loss": iwae.detach(), "iwae_grads": iwae_grads,
                     "exact_loss": exact.detach(), "exact_grads": exact_grads,
                     "indices": result["ancestral_indices"], "rows": (lo, hi)},
                    os.path.join(out_dir, "rank{}.pt".format(rank)))
@@ -97,9 +105,17 @@ def test_two_rank_batch_shard_matches_single_process(tmp_path, oracle_backend):
         full = inference.infer("smc", observations, *parts, K, return_ancestral_indices=True,
                                return_latents=False)
 
+    with replay.replay(tape):
+        iwae = losses.get_loss(observations, K, "iwae", *parts)
+    iwae_grads = [g for g in torch.autograd.grad(iwae, list(model.parameters()), allow_unused=True) if g is not None]
+
     shards = [torch.load(os.path.join(str(tmp_path), "rank{}.pt".format(r))) for r in range(world)]
     assert shards[0]["rows"] == (0, 3) and shards[1]["rows"] == (3, 6)
     for shard in shards:
+        torch.testing.assert_close(shard["iwae_loss"], iwae.detach(), rtol=1e-12, atol=1e-12)
+        assert len(shard["iwae_grads"]) == len(iwae_grads) > 0
+        for got, want in zip(shard["iwae_grads"], iwae_grads):
+            torch.testing.assert_close(got, want, rtol=1e-10, atol=1e-12)
         torch.testing.assert_close(shard["loss"], loss.detach(), rtol=1e-12, atol=1e-12)
         assert torch.equal(shard["exact_loss"], loss.detach())       # all-gather + torch.mean: to the last bit
         for got, want in zip(shard["exact_grads"], [p.grad for p in model.parameters()]):
