@@ -49,7 +49,6 @@ SIGNATURES = {
     "aesmc_normal_logweight_lse_backward": (_i32, [_i32, ctypes.POINTER(View3)] + [_vp] * 12 + [_i64] * 4 + [_vp]),
     "aesmc_resample_step": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "aesmc_set_step_parts": (_i32, [_i32]),
-    "aesmc_set_step_preload": (_i32, [_i32]),
     "aesmc_set_sorted_backward_kernel": (_i32, [_i32]),
     "aesmc_particle_summary_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64]),
     "aesmc_particle_summary": (_i32, [_i32, _vp, ctypes.POINTER(View3), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,

@@ -250,7 +250,6 @@ struct StepPayload {
   int64_t stride_b, stride_k;  // bytes
   uint32_t ppp;                // G-byte pieces per particle row
   int G;                       // 4, 8 or 16
-  uint32_t stage_offset;       // preload variant: byte offset of the row image in dynamic LDS
 };
 
 template <int G>
@@ -267,21 +266,32 @@ __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *
   const uint32_t per_part = (row_chunks + parts - 1) / parts;
   const uint32_t begin = min(row_chunks, part * per_part);
   const uint32_t chunks = min(row_chunks, begin + per_part);
+  // A lane's chunks lie nt apart: (particle, piece) of a chunk's first piece advance by a constant
+  // (dk, dr) from one to the next — one integer division per lane instead of one per chunk.
+  const uint32_t step = nt * V;
+  const uint32_t dk = step / ppp, dr = step - dk * ppp;
+  uint32_t k = ((begin + tid) * V) / ppp;
+  uint32_t r = (begin + tid) * V - k * ppp;
   for (uint32_t c0 = begin; c0 < chunks; c0 += nt * U) {
     P piece[U][V];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t chunk = c0 + j * nt + tid;
-      const uint32_t p0 = (chunk < chunks ? chunk : 0u) * V;
-      uint32_t k = p0 / ppp;
-      uint32_t r = p0 - k * ppp;
+      const bool live = chunk < chunks;
+      uint32_t kk = live ? k : 0u, rr = live ? r : 0u;
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        piece[j][i] = *reinterpret_cast<const P *>(srow + (int64_t)anc[k] * stride_k + (uint64_t)r * G);
-        if (++r == ppp) {
-          r = 0;
-          ++k;
+        piece[j][i] = *reinterpret_cast<const P *>(srow + (int64_t)anc[kk] * stride_k + (uint64_t)rr * G);
+        if (++rr == ppp) {
+          rr = 0;
+          ++kk;
         }
+      }
+      k += dk;
+      r += dr;
+      if (r >= ppp) {
+        r -= ppp;
+        ++k;
       }
     }
 #pragma unroll
@@ -296,38 +306,7 @@ __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *
   }
 }
 
-// The same copy out of an LDS image of the batch row's payload (`stage`, dense rows of ppp * G bytes):
-// the preload variant of the step loads the whole row block while the scan runs, so the copy waits
-// for no dependent global load.
-template <int G>
-__device__ __forceinline__ void gather_row_from_stage(const int *anc, const char *stage, char *drow, uint32_t K,
-                                                      uint32_t ppp, uint32_t tid, uint32_t nt) {
-  constexpr int V = 16 / G;
-  using P = typename Piece<G>::type;
-  const uint32_t row_bytes = ppp * G;
-  const uint32_t chunks = (uint32_t)(((uint64_t)K * ppp) / V);
-  for (uint32_t chunk = tid; chunk < chunks; chunk += nt) {
-    const uint32_t p0 = chunk * V;
-    uint32_t k = p0 / ppp;
-    uint32_t r = p0 - k * ppp;
-    P piece[V];
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      piece[i] = *reinterpret_cast<const P *>(stage + (uint32_t)anc[k] * row_bytes + r * G);
-      if (++r == ppp) {
-        r = 0;
-        ++k;
-      }
-    }
-    uint4 packed;
-    __builtin_memcpy(&packed, piece, 16);
-    *reinterpret_cast<uint4 *>(drow + (uint64_t)chunk * 16) = packed;
-  }
-}
-
-constexpr int kPreChunks = 12;   // 16-byte chunks of payload a lane holds in registers across the scan
-
-template <typename T, int C, bool PRE = false>
+template <typename T, int C>
 __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
     int32_t *flags, int K, T *__restrict__ out_lse, StepPayload payload, int B, int parts) {
@@ -351,20 +330,6 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   const T *lw = log_w + row * (int64_t)K;
   int64_t *idx = out_idx + row * (int64_t)K;
   const int j0 = tid * C;                                         // nt * C >= K: one round
-
-  // ---- preload variant: the row's whole payload block goes into registers now, into LDS after the
-  // scan (its latency hides behind the scan's own loads, barriers and float64 arithmetic) -----------
-  uint4 pre[PRE ? kPreChunks : 1];
-  uint32_t pre_chunks = 0;
-  if constexpr (PRE) {
-    pre_chunks = (uint32_t)(((uint64_t)K * payload.ppp * payload.G) / 16);
-    const uint4 *src16 = reinterpret_cast<const uint4 *>(payload.src + row * payload.stride_b);
-#pragma unroll
-    for (int q = 0; q < kPreChunks; ++q) {
-      const uint32_t chunk = (uint32_t)q * nt + tid;
-      pre[q] = chunk < pre_chunks ? src16[chunk] : make_uint4(0u, 0u, 0u, 0u);
-    }
-  }
 
   // ---- load once, row max + NaN scan ---------------------------------------------------------
   T v[C];
@@ -566,23 +531,6 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     for (int i = 0; i < C; ++i) marker[j0 + i] = best[i];
   }
   char *drow = payload.dst + (uint64_t)row * K * payload.ppp * payload.G;
-  if constexpr (PRE) {
-    // the image sits behind the marker array and the per-wavefront slots (16-byte aligned on the host)
-    char *stage = reinterpret_cast<char *>(smem) + payload.stage_offset;
-#pragma unroll
-    for (int q = 0; q < kPreChunks; ++q) {
-      const uint32_t chunk = (uint32_t)q * nt + tid;
-      if (chunk < pre_chunks) reinterpret_cast<uint4 *>(stage)[chunk] = pre[q];
-    }
-    __syncthreads();
-    if (payload.G == 16)
-      gather_row_from_stage<16>(marker, stage, drow, K, payload.ppp, tid, nt);
-    else if (payload.G == 8)
-      gather_row_from_stage<8>(marker, stage, drow, K, payload.ppp, tid, nt);
-    else
-      gather_row_from_stage<4>(marker, stage, drow, K, payload.ppp, tid, nt);
-    return;
-  }
   __syncthreads();
   const char *srow = payload.src + row * payload.stride_b;
   if (payload.G == 16)
@@ -617,54 +565,27 @@ static int pick_parts(int64_t B, int nt, bool has_payload) {
   return (B <= 256 && limit >= 2) ? 2 : 1;
 }
 
-// Preload variant of the step (payload block of a batch row held in registers across the scan, then
-// in LDS): -1 automatic, 0 never, 1 whenever the operands allow.  aesmc_set_step_preload().
-static int g_step_preload = -1;
-
-template <typename T, int C, bool PRE>
-static int launch_inv_variant(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
-                              int64_t K, hipStream_t s, void *out_lse, const StepPayload &payload, int nt,
-                              size_t lds, int parts) {
+template <typename T, int C>
+static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
+                      int64_t K, hipStream_t s, void *out_lse = nullptr,
+                      const StepPayload &payload = StepPayload{nullptr, nullptr, 0, 0, 0, 0}) {
+  const int nt = pick_threads(K, C);
+  const size_t lds = (size_t)kScratchDoubles * sizeof(double) + (size_t)(nt * C + nt + 8) * sizeof(int);
   // raise the dynamic-LDS cap once per device and instantiation (a process may drive several GPUs)
   static bool attr_set[64] = {};
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return AESMC_ERR_LAUNCH;
   if (!attr_set[device]) {
-    if (hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C, PRE>,
+    if (hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return AESMC_ERR_LAUNCH;
     attr_set[device] = true;
   }
-  hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C, PRE>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
-                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts);
-  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
-}
-
-template <typename T, int C>
-static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
-                      int64_t K, hipStream_t s, void *out_lse = nullptr,
-                      const StepPayload &payload = StepPayload{nullptr, nullptr, 0, 0, 0, 0, 0}) {
-  const int nt = pick_threads(K, C);
-  size_t lds = (size_t)kScratchDoubles * sizeof(double) + (size_t)(nt * C + nt + 8) * sizeof(int);
-  // The preload variant needs the row block dense, 16-byte aligned and small enough for kPreChunks
-  // registers per lane; it replaces the sharing of a row between workgroups (each would load it all).
-  if (C <= 8 && payload.src != nullptr && g_step_preload != 0) {   // C > 8: the chunks would spill
-    const uint64_t row_block = (uint64_t)K * payload.ppp * (uint64_t)payload.G;
-    const bool dense = payload.stride_k == (int64_t)payload.ppp * payload.G;
-    const bool aligned = (((uintptr_t)payload.src) & 15u) == 0 && (payload.stride_b & 15) == 0;
-    const size_t stage_offset = (lds + 15) & ~(size_t)15;
-    const bool fits = row_block <= (uint64_t)nt * 16u * kPreChunks && stage_offset + row_block <= 160u * 1024u;
-    const bool wanted = g_step_preload == 1 || (B <= 512 && g_step_parts <= 0);
-    if (dense && aligned && fits && wanted) {
-      StepPayload staged = payload;
-      staged.stage_offset = (uint32_t)stage_offset;
-      return launch_inv_variant<T, C, true>(log_w, u, idx, flags, B, K, s, out_lse, staged, nt,
-                                            stage_offset + (size_t)row_block, 1);
-    }
-  }
   int parts = pick_parts(B, nt, payload.src != nullptr);
   while (parts > 1 && (nt % parts != 0 || B * parts > 0x7fffffffLL)) parts /= 2;
-  return launch_inv_variant<T, C, false>(log_w, u, idx, flags, B, K, s, out_lse, payload, nt, lds, parts);
+  hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
+                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
 template <typename T>
@@ -698,12 +619,6 @@ static int launch(const void *log_w, const double *u, int64_t *idx, int32_t *fla
 }  // namespace aesmc
 
 extern "C" int64_t aesmc_ancestor_index_lds_max_particles(void) { return aesmc::kInvMaxParticles; }
-
-extern "C" int aesmc_set_step_preload(int mode) {
-  if (mode < -1 || mode > 1) return AESMC_ERR_INVALID_ARGUMENT;
-  aesmc::g_step_preload = mode;
-  return AESMC_OK;
-}
 
 extern "C" int aesmc_set_step_parts(int parts) {
   if (parts < 0 || (parts & (parts - 1)) != 0) return AESMC_ERR_INVALID_ARGUMENT;
@@ -755,7 +670,7 @@ extern "C" int aesmc_resample_step(int dtype, const void *log_w, const double *u
     if (G < 4 || ((uintptr_t)dst & 15u) != 0 || ((uint64_t)K * (uint64_t)row_bytes) % 16 != 0)
       return AESMC_ERR_UNSUPPORTED;
     payload = StepPayload{(const char *)src, (char *)dst, src_stride_b, src_stride_k,
-                          (uint32_t)(row_bytes / G), (int)G, 0u};
+                          (uint32_t)(row_bytes / G), (int)G};
   }
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AESMC_F32) return launch_step<float>(log_w, u, out_idx, out_lse, flags, B, K, payload, s);

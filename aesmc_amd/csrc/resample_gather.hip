@@ -37,22 +37,33 @@ __global__ __launch_bounds__(kGatherBlock) void resample_gather_kernel(
 
   uint32_t kk[U][V], rr[U][V];
   bool live[U][V];
+  // (particle, piece) of a lane's first chunk by ONE 32-bit division (K * row_bytes < 2^32 is
+  // checked on the host); its other chunks lie 256 apart: a constant step (dk, dr) each
+  const uint32_t step = kGatherBlock * V;
+  const uint32_t dk = step / ppp, dr = step - dk * ppp;
+  const uint32_t first = ((cb * U) * kGatherBlock + threadIdx.x) * (uint32_t)V;
+  uint32_t k = first / ppp;
+  uint32_t r = first - k * ppp;
 #pragma unroll
   for (int j = 0; j < U; ++j) {
     const uint32_t chunk = (cb * U + j) * kGatherBlock + threadIdx.x;
     const uint64_t p0 = (uint64_t)chunk * V;
-    const uint64_t q0 = p0 < row_pieces ? p0 : 0;
-    uint32_t k = (uint32_t)(q0 / ppp);
-    uint32_t r = (uint32_t)(q0 - (uint64_t)k * ppp);
+    uint32_t k_i = k, r_i = r;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       live[j][i] = chunk < chunks_per_row && p0 + i < row_pieces;
-      kk[j][i] = live[j][i] ? k : 0;
-      rr[j][i] = r;
-      if (++r == ppp) {
-        r = 0;
-        ++k;
+      kk[j][i] = live[j][i] ? k_i : 0;
+      rr[j][i] = live[j][i] ? r_i : 0;
+      if (++r_i == ppp) {
+        r_i = 0;
+        ++k_i;
       }
+    }
+    k += dk;
+    r += dr;
+    if (r >= ppp) {
+      r -= ppp;
+      ++k;
     }
   }
   int64_t anc[U][V];
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_sorted_kerne
 template <typename T, bool VEC_LOAD>
 __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel(
     const T *__restrict__ grad_out, const int64_t *__restrict__ idx, T *__restrict__ grad_src,
-    int32_t *flags, uint32_t K, uint32_t D, uint32_t TK, uint32_t tiles_per_row, uint32_t cap) {
+    int32_t *flags, uint32_t K, uint32_t D, uint32_t TK, uint32_t tiles_per_row, uint32_t cap, int debug) {
   extern __shared__ __attribute__((aligned(16))) unsigned char range_smem[];
   T *G = reinterpret_cast<T *>(range_smem);                    // [TK * D] staged gradient rows
   T *lead = G + (size_t)TK * D;                                // [D] rows of the first run before the tile
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
   }
 
   // ---- 3. rows of the first run that lie before the tile -----------------------------------------
-  if (has_lead && lead_ends_here) {
+  if (has_lead && lead_ends_here && debug != 4) {
     if (tid == 0) *shared_lo = -1;
     __syncthreads();
     const int64_t back = (int64_t)k0 - 1 - tid;                // lane's candidate for "last particle before the run"
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
   __syncthreads();
 
   // ---- 4. one element per (tail, column): the run's sum replaces its last staged row ---------------
-  const uint32_t total = (uint32_t)num_tails * D;
+  const uint32_t total = debug == 3 ? 0u : (uint32_t)num_tails * D;
   for (uint32_t e = tid; e < total; e += kSortedBlock) {
     const uint32_t t = e / D, c = e - t * D;
     const int i = tails[t];
@@ -453,6 +464,7 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
 
   // ---- 5. the range goes out: sums where a run ended, zeros where a particle left no offspring --------
   const uint32_t qstep = kSortedBlock / D, rstep = kSortedBlock - qstep * D;
+  if (debug == 2) return;
   for (uint32_t piece = 0; piece < L; piece += cap) {
     const uint32_t np = min(cap, L - piece);
     const int first_row = jlo + (int)piece;
@@ -514,9 +526,11 @@ using namespace aesmc;
 // source-tile kernel behind a zero fill (kept for rows the first declines, and selectable for A/B
 // timing: tools/kbench.py)
 static int g_sorted_backward_kernel = 0;
+static int g_range_debug = 0;   // TEMPORARY timing experiments: 2 no output stage, 3 no sums, 4 no look-back
 extern "C" int aesmc_set_sorted_backward_kernel(int which) {
-  if (which != 0 && which != 1) return AESMC_ERR_INVALID_ARGUMENT;
-  g_sorted_backward_kernel = which;
+  if (which < 0 || which > 4) return AESMC_ERR_INVALID_ARGUMENT;
+  g_sorted_backward_kernel = which == 1 ? 1 : 0;
+  g_range_debug = which >= 2 ? which : 0;
   return AESMC_OK;
 }
 
@@ -611,11 +625,11 @@ static bool launch_range_backward(const void *grad_out, const int64_t *idx, void
   if (vec)
     hipLaunchKernelGGL((resample_gather_bwd_range_kernel<T, true>), grid, block, lds, s, (const T *)grad_out,
                        idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D, (uint32_t)TK, (uint32_t)tiles,
-                       (uint32_t)cap);
+                       (uint32_t)cap, g_range_debug);
   else
     hipLaunchKernelGGL((resample_gather_bwd_range_kernel<T, false>), grid, block, lds, s, (const T *)grad_out,
                        idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D, (uint32_t)TK, (uint32_t)tiles,
-                       (uint32_t)cap);
+                       (uint32_t)cap, g_range_debug);
   return true;
 }
 

@@ -231,11 +231,6 @@ int aesmc_resample_step(int dtype, const void *log_w, const double *u, int64_t *
  * Process-wide; not part of the reference's interface. */
 int aesmc_set_step_parts(int parts);
 
-/* Tuning knob of the fused step: the preload variant loads a batch row's whole payload block while
- * the scan runs and copies out of an LDS image of it (for dense, 16-byte aligned blocks of at most
- * 192 bytes per lane: e.g. K=1024 rows of 40 bytes).  -1 (default) = used for small batches, 0 =
- * never, 1 = whenever the operands allow.  Results do not depend on it. */
-int aesmc_set_step_preload(int mode);
 
 /* K6 — reparameterised Normal draw  out[b,k,j] = loc[b,k,j] + eps[b,k,j] * scale[b,k,j].
  *

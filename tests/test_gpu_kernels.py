@@ -1014,9 +1014,8 @@ def test_many_short_rows(kernels, hip_device):
 @pytest.mark.parametrize("shape,row", [((2, 64), (4,)), ((3, 1024), (10,)), ((5, 4096), (10,)), ((2, 2048), (3, 4)),
                                        ((4, 600), (4,)), ((1, 16384), (2,)), ((3, 1000), (1,))])
 def test_resample_step_does_not_depend_on_workgroups_per_row(kernels, hip_device, shape, row):
-    """`aesmc_set_step_parts` / `aesmc_set_step_preload`: a batch row shared by 1, 2, 4 or 8
-    workgroups, or copied out of an LDS image of its payload, gives the same indices, log-sum-exp and
-    payload bit for bit — including degenerate and NaN rows."""
+    """`aesmc_set_step_parts`: a batch row shared by 1, 2, 4 or 8 workgroups gives the same indices,
+    log-sum-exp and payload bit for bit — including degenerate and NaN rows."""
     B, K = shape
     rng = np.random.RandomState(K + B)
     lw = (rng.randn(B, K) * 2).astype(np.float32)
@@ -1029,15 +1028,13 @@ def test_resample_step_does_not_depend_on_workgroups_per_row(kernels, hip_device
     try:
         assert lib.aesmc_set_step_parts(3) != 0          # powers of two only
         results = []
-        assert lib.aesmc_set_step_preload(2) != 0
-        for preload, parts in ((0, 1), (0, 2), (0, 4), (0, 8), (1, 1), (-1, 0)):
-            assert lib.aesmc_set_step_parts(parts) == 0 and lib.aesmc_set_step_preload(preload) == 0
+        for parts in (1, 2, 4, 8, 0):
+            assert lib.aesmc_set_step_parts(parts) == 0
             out = kernels.resample_step(lw_d, u, payload, want_lse=True)
             assert out is not None
             results.append(out)
     finally:
         lib.aesmc_set_step_parts(0)
-        lib.aesmc_set_step_preload(-1)
     kernels.read_flags(hip_device)
     for idx, lse, moved in results[1:]:
         assert torch.equal(idx, results[0][0]) and torch.equal(moved, results[0][2])

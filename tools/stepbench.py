@@ -62,16 +62,14 @@ def main(names):
             algorithmic = B * K * (20 + 8 * d) + 8 * B
             moved = B * K * 12 + (1 + unique) * B * K * d * 4
             want = k.resample_step(lw, u, x, want_lse=True)
-            for preload, parts in ((-1, 0), (0, 1), (0, 2), (0, 4), (1, 1)):
-                lib.aesmc_set_step_preload(preload)
+            for parts in (0, 1, 2, 4):
                 lib.aesmc_set_step_parts(parts)
                 got = k.resample_step(lw, u, x, want_lse=True)
                 same = all(torch.equal(a, b) for a, b in zip(got, want))
                 t = timeit(lambda: k.resample_step(lw, u, x, want_lse=True))
-                print("    step(idx+lse+gather) preload={:>4} parts={:>4} : {:7.2f} us  {:6.2f} TB/s algorithmic  {:6.2f} TB/s moved  same={}".format(
-                    {-1: "auto", 0: "off", 1: "on"}[preload], parts or "auto", t, algorithmic / t / 1e6, moved / t / 1e6, same))
+                print("    step(idx+lse+gather) parts={:>4} : {:7.2f} us  {:6.2f} TB/s algorithmic  {:6.2f} TB/s moved  same={}".format(
+                    parts or "auto", t, algorithmic / t / 1e6, moved / t / 1e6, same))
             lib.aesmc_set_step_parts(0)
-            lib.aesmc_set_step_preload(-1)
 
 
 if __name__ == "__main__":
