@@ -297,6 +297,38 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_sorted_kerne
   }
 }
 
+// Output stage of the range kernel: `rows` destination rows of D elements, row j taken from staged
+// row slot_of[j] (0xffff: zeros), stored W elements at a time; a lane's pieces lie 256 apart, so
+// (row, piece) advance by a constant step instead of a division per piece.
+template <typename T, int W>
+__device__ __forceinline__ void store_range(T *__restrict__ out, const T *G, const unsigned short *slot_of,
+                                            uint32_t rows, uint32_t D, uint32_t tid) {
+  struct alignas(sizeof(T) * W) Pack {
+    T v[W];
+  };
+  const uint32_t per_row = D / W;
+  const uint32_t qstep = kSortedBlock / per_row, rstep = kSortedBlock - qstep * per_row;
+  uint32_t j = tid / per_row, r = tid - j * per_row;
+  const uint32_t total = rows * per_row;
+  for (uint32_t e = tid; e < total; e += kSortedBlock) {
+    const uint32_t slot = slot_of[j];
+    Pack p;
+    if (slot != 0xffffu) {
+      p = *reinterpret_cast<const Pack *>(G + slot * D + r * W);
+    } else {
+#pragma unroll
+      for (int i = 0; i < W; ++i) p.v[i] = T(0);
+    }
+    reinterpret_cast<Pack *>(out)[e] = p;
+    j += qstep;
+    r += rstep;
+    if (r >= per_row) {
+      r -= per_row;
+      ++j;
+    }
+  }
+}
+
 // Backward for SORTED indices without a zero-fill launch (the one that runs).  Same source tiles,
 // run detection and look-back as the kernel above, but every destination row is written exactly
 // once: idx being non-decreasing, the rows a tile is responsible for form ONE contiguous range
@@ -312,7 +344,7 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_sorted_kerne
 template <typename T, bool VEC_LOAD>
 __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel(
     const T *__restrict__ grad_out, const int64_t *__restrict__ idx, T *__restrict__ grad_src,
-    int32_t *flags, uint32_t K, uint32_t D, uint32_t TK, uint32_t tiles_per_row, uint32_t cap, int debug) {
+    int32_t *flags, uint32_t K, uint32_t D, uint32_t TK, uint32_t tiles_per_row, uint32_t cap, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char range_smem[];
   T *G = reinterpret_cast<T *>(range_smem);                    // [TK * D] staged gradient rows
   T *lead = G + (size_t)TK * D;                                // [D] rows of the first run before the tile
@@ -400,7 +432,7 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
   }
 
   // ---- 3. rows of the first run that lie before the tile -----------------------------------------
-  if (has_lead && lead_ends_here && debug != 4) {
+  if (has_lead && lead_ends_here) {
     if (tid == 0) *shared_lo = -1;
     __syncthreads();
     const int64_t back = (int64_t)k0 - 1 - tid;                // lane's candidate for "last particle before the run"
@@ -452,7 +484,7 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
   __syncthreads();
 
   // ---- 4. one element per (tail, column): the run's sum replaces its last staged row ---------------
-  const uint32_t total = debug == 3 ? 0u : (uint32_t)num_tails * D;
+  const uint32_t total = (uint32_t)num_tails * D;
   for (uint32_t e = tid; e < total; e += kSortedBlock) {
     const uint32_t t = e / D, c = e - t * D;
     const int i = tails[t];
@@ -463,8 +495,6 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
   }
 
   // ---- 5. the range goes out: sums where a run ended, zeros where a particle left no offspring --------
-  const uint32_t qstep = kSortedBlock / D, rstep = kSortedBlock - qstep * D;
-  if (debug == 2) return;
   for (uint32_t piece = 0; piece < L; piece += cap) {
     const uint32_t np = min(cap, L - piece);
     const int first_row = jlo + (int)piece;
@@ -478,17 +508,13 @@ __global__ __launch_bounds__(kSortedBlock) void resample_gather_bwd_range_kernel
     }
     __syncthreads();
     T *out = drow + (uint64_t)first_row * D;
-    uint32_t j = tid / D, c = tid - j * D;                     // element e = tid + m * 256 is (row j, column c)
-    for (uint32_t e = tid; e < np * D; e += kSortedBlock) {
-      const uint32_t slot = slot_of[j];
-      out[e] = slot != 0xffffu ? G[slot * D + c] : T(0);
-      j += qstep;
-      c += rstep;
-      if (c >= D) {
-        c -= D;
-        ++j;
-      }
-    }
+    // W elements per store: the widest of 16 / 8 / 4 bytes that divides a row (and the base address)
+    if (W == 4)
+      store_range<T, 4>(out, G, slot_of, np, D, tid);
+    else if (W == 2)
+      store_range<T, 2>(out, G, slot_of, np, D, tid);
+    else
+      store_range<T, 1>(out, G, slot_of, np, D, tid);
   }
 }
 
@@ -526,11 +552,9 @@ using namespace aesmc;
 // source-tile kernel behind a zero fill (kept for rows the first declines, and selectable for A/B
 // timing: tools/kbench.py)
 static int g_sorted_backward_kernel = 0;
-static int g_range_debug = 0;   // TEMPORARY timing experiments: 2 no output stage, 3 no sums, 4 no look-back
 extern "C" int aesmc_set_sorted_backward_kernel(int which) {
-  if (which < 0 || which > 4) return AESMC_ERR_INVALID_ARGUMENT;
-  g_sorted_backward_kernel = which == 1 ? 1 : 0;
-  g_range_debug = which >= 2 ? which : 0;
+  if (which != 0 && which != 1) return AESMC_ERR_INVALID_ARGUMENT;
+  g_sorted_backward_kernel = which;
   return AESMC_OK;
 }
 
@@ -621,15 +645,17 @@ static bool launch_range_backward(const void *grad_out, const int64_t *idx, void
   const size_t floats = (size_t)(TK * D + D + kSortedBlock);
   const size_t lds = floats * sizeof(T) + (size_t)(3 * TK + 2 + 9) * sizeof(int) + (size_t)((cap + 1) / 2 * 2) * 2;
   const bool vec = (((uintptr_t)grad_out & 15u) == 0) && ((K * D) % N == 0) && ((TK * D) % N == 0);
+  int W = (int)(16 / sizeof(T));                                // elements per store of the output stage
+  while (W > 1 && (D % W != 0 || ((uintptr_t)grad_src % (W * sizeof(T))) != 0)) W /= 2;
   dim3 grid((unsigned)(B * tiles)), block(kSortedBlock);
   if (vec)
     hipLaunchKernelGGL((resample_gather_bwd_range_kernel<T, true>), grid, block, lds, s, (const T *)grad_out,
                        idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D, (uint32_t)TK, (uint32_t)tiles,
-                       (uint32_t)cap, g_range_debug);
+                       (uint32_t)cap, W);
   else
     hipLaunchKernelGGL((resample_gather_bwd_range_kernel<T, false>), grid, block, lds, s, (const T *)grad_out,
                        idx, (T *)grad_src, flags, (uint32_t)K, (uint32_t)D, (uint32_t)TK, (uint32_t)tiles,
-                       (uint32_t)cap, g_range_debug);
+                       (uint32_t)cap, W);
   return true;
 }
 
