@@ -889,11 +889,159 @@ __global__ __launch_bounds__(kLpBlock) void normal_logweight_bwd_kernel(
   }
 }
 
+// K5 backward, the layout of a Markov model (what every timestep of the bench workloads runs): x, mu_p,
+// mu_q dense [B,K,Dx], mu_g dense [B,K,Dy], y dense or one row per batch element, every scale one
+// value for the whole tensor.  The generic kernel above addresses each element through strided views
+// with two 64-bit divisions and moves 4 bytes per access: 620 us for 1.36 GB at B=1024 K=4096 d=10
+// (2.2 TB/s).  Here a lane walks 16-byte vectors of the flat arrays — (particle, column) of a vector's
+// first element advance by a constant step per trip, no division in the loop — and every gradient is a
+// 16-byte store.  Element arithmetic is the generic kernel's, operation for operation: same bits.
+template <typename T>
+__global__ __launch_bounds__(kLpBlock) void normal_logweight_bwd_dense_kernel(
+    const T *__restrict__ x, const T *__restrict__ mu_p, const T *__restrict__ mu_q, const T *__restrict__ y,
+    const T *__restrict__ mu_g, const T *__restrict__ sc_p, const T *__restrict__ sc_g, const T *__restrict__ sc_q,
+    int64_t y_stride_b /* elements; y_dense: K * Dy */, int y_dense, const T *__restrict__ grad_lw,
+    const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse, T *__restrict__ gx,
+    T *__restrict__ gmu_p, T *__restrict__ gy, T *__restrict__ gmu_g, T *__restrict__ gmu_q, uint32_t vec_x,
+    uint32_t vec_y, uint32_t K, uint32_t Dx, uint32_t Dy) {
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const uint32_t stride = gridDim.x * kLpBlock;
+  const uint32_t first = blockIdx.x * kLpBlock + threadIdx.x;
+  auto incoming = [&](uint32_t p, uint32_t b) -> T {   // as in normal_logweight_bwd_kernel
+    T g = grad_lse != nullptr ? grad_lse[b] * Num<T>::exp(lw[p] - lse[b]) : T(0);
+    if (grad_lw != nullptr) g = grad_lse != nullptr ? g + grad_lw[p] : grad_lw[p];
+    return g;
+  };
+  auto put = [](V &v, int r, T value) {
+    if (r == 0) v.x = value;
+    else if (r == 1) v.y = value;
+    if constexpr (N == 4) {
+      if (r == 2) v.z = value;
+      else if (r == 3) v.w = value;
+    }
+  };
+  if (gx != nullptr || gmu_p != nullptr || gmu_q != nullptr) {
+    const T s_p = sc_p[0], s_q = sc_q[0];
+    const T var_p = s_p * s_p, var_q = s_q * s_q;
+    // element e = vector * N: particle p = e / Dx, column j; both advance by a constant per trip
+    const uint32_t step = stride * N;
+    const uint32_t dp_step = step / Dx, dj_step = step - dp_step * Dx;
+    uint32_t p = (first * N) / Dx, j = first * N - p * Dx;
+    for (uint32_t v = first; v < vec_x; v += stride) {
+      const V xv = reinterpret_cast<const V *>(x)[v];
+      const V pv = reinterpret_cast<const V *>(mu_p)[v];
+      const V qv = reinterpret_cast<const V *>(mu_q)[v];
+      V out_p, out_q, out_x;
+      uint32_t pp = p, jj = j;
+      T g = incoming(pp, pp / K);
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const T value = Vec16<T>::get(xv, r);
+        const T dp = value - Vec16<T>::get(pv, r), dq = value - Vec16<T>::get(qv, r);
+        const T gq = -g;                                  // log q enters the weight with a minus sign
+        const T gz_p = g * (dp / var_p);
+        const T gz_q = gq * (dq / var_q);
+        put(out_p, r, gz_p);
+        put(out_q, r, gz_q);
+        put(out_x, r, (-gz_p) + (-gz_q));
+        if (++jj == Dx && r + 1 < N) {
+          jj = 0;
+          ++pp;
+          g = incoming(pp, pp / K);
+        }
+      }
+      if (gmu_p) reinterpret_cast<V *>(gmu_p)[v] = out_p;
+      if (gmu_q) reinterpret_cast<V *>(gmu_q)[v] = out_q;
+      if (gx) reinterpret_cast<V *>(gx)[v] = out_x;
+      p += dp_step;
+      j += dj_step;
+      if (j >= Dx) {
+        j -= Dx;
+        ++p;
+      }
+    }
+  }
+  if (gy != nullptr || gmu_g != nullptr) {
+    const T s_g = sc_g[0];
+    const T var_g = s_g * s_g;
+    const uint32_t step = stride * N;
+    const uint32_t dp_step = step / Dy, dj_step = step - dp_step * Dy;
+    uint32_t p = (first * N) / Dy, j = first * N - p * Dy;
+    for (uint32_t v = first; v < vec_y; v += stride) {
+      const V gv = reinterpret_cast<const V *>(mu_g)[v];
+      V out_g, out_y;
+      uint32_t pp = p, jj = j;
+      uint32_t b = pp / K;
+      T g = incoming(pp, b);
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const T yv = y_dense ? y[(uint64_t)pp * Dy + jj] : y[(int64_t)b * y_stride_b + jj];
+        const T dg = yv - Vec16<T>::get(gv, r);
+        const T gz_g = g * (dg / var_g);
+        put(out_g, r, gz_g);
+        put(out_y, r, -gz_g);
+        if (++jj == Dy && r + 1 < N) {
+          jj = 0;
+          ++pp;
+          b = pp / K;
+          g = incoming(pp, b);
+        }
+      }
+      if (gmu_g) reinterpret_cast<V *>(gmu_g)[v] = out_g;
+      if (gy) reinterpret_cast<V *>(gy)[v] = out_y;
+      p += dp_step;
+      j += dj_step;
+      if (j >= Dy) {
+        j -= Dy;
+        ++p;
+      }
+    }
+  }
+}
+
+template <typename T>
+static bool launch_logweight_bwd_dense(const View3 *v, const void *grad_lw, void *gx, void *gmu_p, void *gy,
+                                       void *gmu_g, void *gmu_q, void *gs_p, void *gs_g, void *gs_q, int64_t B,
+                                       int64_t K, int64_t Dx, int64_t Dy, hipStream_t s, const void *lw,
+                                       const void *lse, const void *grad_lse) {
+  constexpr int N = Vec16<T>::N;
+  if (gs_p != nullptr || gs_g != nullptr || gs_q != nullptr) return false;       // scale gradients: generic kernel
+  if (!is_scalar(v[2].st) || !is_scalar(v[5].st) || !is_scalar(v[7].st)) return false;
+  const int64_t total_x = B * K * Dx, total_y = B * K * Dy;
+  if (total_x >= (1ll << 32) / 2 || total_y >= (1ll << 32) / 2 || total_x % N != 0 || total_y % N != 0) return false;
+  auto flat = [&](const View3 &view, int64_t D) {
+    return view.st.d == 1 && view.st.k == D && view.st.b == K * D && (reinterpret_cast<uintptr_t>(view.ptr) & 15u) == 0;
+  };
+  if (!flat(v[0], Dx) || !flat(v[1], Dx) || !flat(v[6], Dx) || !flat(v[4], Dy)) return false;
+  const bool y_dense = flat(v[3], Dy);
+  const bool y_rows = v[3].st.k == 0 && (v[3].st.d == 1 || Dy == 1);             // one observation row per batch element
+  if (!y_dense && !y_rows) return false;
+  if (gy != nullptr && !y_dense) return false;                                    // dense gy only for a dense y
+  for (void *out : {gx, gmu_p, gy, gmu_g, gmu_q})
+    if (out != nullptr && (reinterpret_cast<uintptr_t>(out) & 15u) != 0) return false;
+  const uint32_t vec_x = (uint32_t)(total_x / N), vec_y = (uint32_t)(total_y / N);
+  const uint32_t most = vec_x > vec_y ? vec_x : vec_y;
+  uint32_t blocks = (most + kLpBlock - 1) / kLpBlock;
+  if (blocks > 256u * 16u) blocks = 256u * 16u;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((normal_logweight_bwd_dense_kernel<T>), dim3(blocks), dim3(kLpBlock), 0, s,
+                     (const T *)v[0].ptr, (const T *)v[1].ptr, (const T *)v[6].ptr, (const T *)v[3].ptr,
+                     (const T *)v[4].ptr, (const T *)v[2].ptr, (const T *)v[5].ptr, (const T *)v[7].ptr,
+                     y_dense ? K * Dy : v[3].st.b, y_dense ? 1 : 0, (const T *)grad_lw, (const T *)lw,
+                     (const T *)lse, (const T *)grad_lse, (T *)gx, (T *)gmu_p, (T *)gy, (T *)gmu_g, (T *)gmu_q, vec_x,
+                     vec_y, (uint32_t)K, (uint32_t)Dx, (uint32_t)Dy);
+  return true;
+}
+
 template <typename T>
 static int launch_logweight_bwd(const View3 *v, const void *grad_lw, void *gx, void *gmu_p, void *gy,
                                 void *gmu_g, void *gmu_q, void *gs_p, void *gs_g, void *gs_q, int64_t B,
                                 int64_t K, int64_t Dx, int64_t Dy, hipStream_t s, const void *lw = nullptr,
                                 const void *lse = nullptr, const void *grad_lse = nullptr) {
+  if (launch_logweight_bwd_dense<T>(v, grad_lw, gx, gmu_p, gy, gmu_g, gmu_q, gs_p, gs_g, gs_q, B, K, Dx, Dy, s, lw,
+                                    lse, grad_lse))
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
   const int64_t total_x = B * K * Dx, total_y = B * K * Dy;
   const int64_t most = total_x > total_y ? total_x : total_y;
   int64_t blocks = (most + kLpBlock - 1) / kLpBlock;

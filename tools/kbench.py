@@ -71,6 +71,19 @@ def main(names):
             us = timeit(lambda: k.normal_logprob_sum_backward(x, loc, scale, go, True, True, False))
             rows.append(("K4 backward (value, loc)", us, B * K * (16 * d + 4)))
             y = torch.randn(B, d, device=dev, generator=gen).unsqueeze(1).expand(B, K, d)
+            # K5 and its backward in the layout of a Markov model's timestep: x, three dense locations,
+            # the observation one row per batch element, scalar scales
+            loc2, loc3 = [torch.randn(B, K, d, device=dev, generator=gen) for _ in range(2)]
+            us = timeit(lambda: k.normal_logweight(x, loc, scale, y, loc2, scale, loc3, scale))
+            rows.append(("K5 normal_logweight", us, B * K * (16 * d + 4)))
+            lw5 = k.normal_logweight(x, loc, scale, y, loc2, scale, loc3, scale)
+            _, lse5 = k.logweight_lse(lw5, None, None, want_lw=False)
+            need = [True, True, False, False, True, False, True, False]
+            us = timeit(lambda: k.normal_logweight_backward(x, loc, scale, y, loc2, scale, loc3, scale, go, need))
+            rows.append(("K5 backward (x, 3 locs), grad_lw given", us, B * K * (32 * d + 4)))
+            us = timeit(lambda: k.normal_logweight_backward(x, loc, scale, y, loc2, scale, loc3, scale, None, need,
+                                                             lw=lw5, lse=lse5, grad_lse=gl))
+            rows.append(("K5 backward fused with K1's (lse)", us, B * K * (32 * d + 4)))
             us = timeit(lambda: k.normal_logprob_sum(y, loc, scale))
             rows.append(("K4 (value = expanded obs)", us, B * K * (4 * d + 4)))
             us = timeit(lambda: x.clone())
