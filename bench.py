@@ -486,8 +486,13 @@ def kernel_legs(ctx):
 
     def leg(us, nbytes, **more):
         gbps = nbytes / us / 1e3
-        return dict({"avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": nbytes,
-                     "achieved": round(gbps, 1), "frac": round(min(gbps / HBM_PEAK_GBPS, 1.0), 4)}, **more)
+        out = dict({"avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": nbytes,
+                    "achieved": round(gbps, 1), "frac": round(min(gbps / HBM_PEAK_GBPS, 1.0), 4),
+                    "frac_algorithmic": round(gbps / HBM_PEAK_GBPS, 4), "pricing": "algorithmic"}, **more)
+        if out.get("unique_ancestor_fraction", 1.0) < 0.3:      # as roofline_of: a collapsed gather is priced by what moved
+            out["achieved"], out["frac"] = out["achieved_moved_bytes"], out["frac_moved_bytes"]
+            out["pricing"] = "moved bytes (collapsed indices)"
+        return out
 
     legs = {}
     B, K = 4096, 8192
