@@ -53,6 +53,8 @@ WORKLOADS = {
     "c2": ("LGSSM d=10 B=256 K=1024 T=50, SMC ELBO (configs[1])", "lgssm", 10, 256, 1024, 50, {}),
     "c3": ("one-step Gaussian IWAE d=1 B=4096 K=8192 T=1, no resampling (configs[2])", "gaussian", 1, 4096, 8192, 1, {}),
     "c4s": ("LGSSM d=10 B=128 K=4096 T=100, SMC ELBO (one GPU's shard of c4 at 8 GPUs)", "lgssm", 10, 128, 4096, 100, {}),
+    "c4x2": ("LGSSM d=10 B=512 K=4096 T=100, SMC ELBO (one GPU's shard of c4 at 2 GPUs, strong scaling)", "lgssm", 10, 512, 4096, 100, {}),
+    "c4x4": ("LGSSM d=10 B=256 K=4096 T=100, SMC ELBO (one GPU's shard of c4 at 4 GPUs, strong scaling)", "lgssm", 10, 256, 4096, 100, {}),
     "c4nl": ("nonlinear SSM + MLP proposal d=10 B=128 K=4096 T=100 (configs[3] per-GPU shard)", "nonlinear", 10, 128, 4096, 100, {}),
     "c4ls": ("nonlinear SSM, proposal net outputs loc and scale, learned vector transition scale, d=10 B=128 K=4096 T=100",
              "learned_scale", 10, 128, 4096, 100, {}),
