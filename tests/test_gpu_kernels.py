@@ -1162,3 +1162,46 @@ def test_importance_sampling_running_sum_equals_the_stack_and_differentiates(hip
         for g, h in zip(mine, theirs):
             scale = float(h.abs().max()) + 1e-30
             torch.testing.assert_close(g / scale, h / scale, rtol=0, atol=1e-5 if dtype == torch.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("B,K,dx,dy", [(3, 50, 4, 4), (2, 257, 10, 3), (1, 33, 128, 128), (40, 8192, 16, 16),
+                                       (7, 1000, 10, 10), (5, 64, 1, 1), (2, 6, 3, 2), (3, 5, 3, 3), (64, 4096, 10, 10)])
+def test_normal_logweight_backward_dense_kernel_equals_the_generic_one(kernels, hip_device, dtype, B, K, dx, dy):
+    """The Markov-model layout (dense x and locations, the observation one row per batch element,
+    scalar scales) takes `normal_logweight_bwd_dense_kernel`: 16-byte vectors, constant-step index
+    arithmetic.  The same values behind a strided view take the generic kernel.  Identical bits for every
+    gradient, with the gradient of the log-weights given and with K1's softmax term formed in place."""
+    gen = torch.Generator(device=hip_device).manual_seed(B + K + dx)
+    rand = lambda *shape: torch.randn(*shape, device=hip_device, dtype=dtype, generator=gen)
+    x, loc_p, loc_q, loc_g = rand(B, K, dx), rand(B, K, dx), rand(B, K, dx), rand(B, K, dy)
+    y = rand(B, dy).unsqueeze(1).expand(B, K, dy)
+    sp, sg, sq = [torch.tensor(v, device=hip_device, dtype=dtype) for v in (1.0, 0.5, 0.7)]
+    scales = (sp.expand(B, K, dx), sg.expand(B, K, dy), sq.expand(B, K, dx))
+    padded = torch.zeros(B, K, dx + 1, device=hip_device, dtype=dtype)
+    padded[:, :, :dx] = loc_p
+    strided = padded[:, :, :dx]                          # same values, rows dx + 1 apart: not the dense layout
+    assert torch.equal(strided, loc_p) and not strided.is_contiguous()
+    grad_lw, grad_lse = rand(B, K), rand(B)
+    lw = kernels.normal_logweight(x, loc_p, scales[0], y, loc_g, scales[1], loc_q, scales[2])
+    _, lse = kernels.logweight_lse(lw, None, None, want_lw=False)
+    need = [True, True, False, False, True, False, True, False]
+    for extra in (dict(), dict(lw=lw, lse=lse, grad_lse=grad_lse)):
+        given = None if extra else grad_lw
+        dense = kernels.normal_logweight_backward(x, loc_p, scales[0], y, loc_g, scales[1], loc_q, scales[2], given,
+                                                  need, **extra)
+        generic = kernels.normal_logweight_backward(x, strided, scales[0], y, loc_g, scales[1], loc_q, scales[2],
+                                                    given, need, **extra)
+        for wanted, a, b in zip(need, dense, generic):
+            assert (a is None) == (not wanted) and (b is None) == (not wanted)
+            if wanted:
+                assert torch.equal(a, b)
+        assert bool(torch.isfinite(dense[0]).all())
+    # and against K1's backward followed by the generic kernel (the two-launch route)
+    g, _ = kernels.logweight_lse_backward(lw, lse, None, grad_lse, want_neg=False)
+    two = kernels.normal_logweight_backward(x, strided, scales[0], y, loc_g, scales[1], loc_q, scales[2], g, need)
+    one = kernels.normal_logweight_backward(x, loc_p, scales[0], y, loc_g, scales[1], loc_q, scales[2], None, need,
+                                            lw=lw, lse=lse, grad_lse=grad_lse)
+    for wanted, a, b in zip(need, one, two):
+        if wanted:
+            assert torch.equal(a, b)
