@@ -521,3 +521,43 @@ def test_random_configurations_match_the_cpu_port(hip_device, seed_):
                 continue
             scale = float(q.grad.abs().max()) + 1e-300
             torch.testing.assert_close(p.grad.cpu() / scale, q.grad / scale, rtol=0, atol=1e-7, msg=str(label + (name,)))
+
+
+def test_status_word_hygiene(hip_device):
+    """(1) the stand-alone resampler raises for EVERY flag, not only NaN — an all -inf row
+    yields indices equal to num_particles, where the reference fails inside np.digitize;
+    (2) stand-alone helpers only SET flags and `inference.check_device_status` reads and raises;
+    (3) an `infer` abandoned by an exception out of a user callable takes what its kernels had
+    flagged with it: the next, healthy call does not raise a stale error."""
+    dead = torch.full((2, 8), float("-inf"), device=hip_device)
+    with pytest.raises(RuntimeError):
+        inference.sample_ancestral_index(dead)
+    inference.check_device_status(hip_device)                       # clean again
+
+    value = torch.arange(24, dtype=torch.float32, device=hip_device).reshape(2, 4, 3)
+    state.resample(value, torch.tensor([[0, 1, 9, 3], [0, 0, 0, 2]], device=hip_device))   # clamps, flags, no raise
+    with pytest.raises(RuntimeError):
+        inference.check_device_status(hip_device)
+    inference.check_device_status(hip_device)
+
+    model = models.LgssmNd(2, seed=0, validate_args=False).to(hip_device)
+    observations = model.simulate(4, 3, seed=0)
+
+    class Boom(Exception):
+        pass
+
+    def bad_emission(latents=None, time=None, previous_observations=None):
+        dist = model.emission(latents=latents, time=time)
+        if time == 0:      # NaN log-weights at time 0: flagged by the resampling launch of time 1
+            return state.set_batch_shape_mode(Normal(dist.loc * float("nan"), 1.0, validate_args=False),
+                                              Modes.FULLY_EXPANDED)
+        if time == 2:
+            torch.cuda.synchronize()
+            raise Boom()
+        return dist
+
+    with pytest.raises(Boom):
+        inference.infer("smc", observations, model.initial, model.transition, bad_emission, model.proposal, 16)
+    out = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal, 16,
+                          return_log_marginal_likelihood=True)
+    assert bool(torch.isfinite(out["log_marginal_likelihood"]).all())
