@@ -561,3 +561,49 @@ def test_status_word_hygiene(hip_device):
     out = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal, 16,
                           return_log_marginal_likelihood=True)
     assert bool(torch.isfinite(out["log_marginal_likelihood"]).all())
+
+
+def test_genealogy_gradients_take_the_sorted_kernel_and_match_torch(hip_device):
+    """`get_resampled_latents` (aesmc/inference.py:196-231) on K2's own indices: the composed lineage
+    is tagged sorted, so the backward of its T gathers is the atomic-free segmented sum (bitwise
+    reproducible from run to run), the promise holds (no UNSORTED flag) and the gradients equal
+    autograd through torch.gather on the same composition; untagged indices (the reference's own
+    genealogy test uses unsorted ones) keep the order-agnostic kernel and the same values."""
+    from aesmc_amd import _kernels, _ops
+    B, K, d, T = 3, 300, 5, 4
+    gen = torch.Generator(device=hip_device).manual_seed(1)
+    rand = lambda *shape: torch.randn(*shape, device=hip_device, dtype=torch.float64, generator=gen)
+    latents = [rand(B, K, d) for _ in range(T)]
+    weights = [rand(B, K, d) for _ in range(T)]
+    indices = [_ops.ancestor_index(rand(B, K), torch.rand(B, device=hip_device, dtype=torch.float64, generator=gen))
+               for _ in range(T - 1)]
+    assert all(getattr(i, "_aesmc_sorted", False) for i in indices)
+
+    def run(index_list):
+        leaves = [x.clone().requires_grad_() for x in latents]
+        out = inference.get_resampled_latents(leaves, index_list)
+        sum((o * w).sum() for o, w in zip(out, weights)).backward()
+        return [o.detach() for o in out], [x.grad for x in leaves]
+
+    values, grads = run(indices)
+    again_values, again_grads = run(indices)
+    untagged = [i.clone() for i in indices]                     # clones carry no tag
+    assert not any(getattr(i, "_aesmc_sorted", False) for i in untagged)
+    other_values, other_grads = run(untagged)
+    assert _kernels.get().read_flags(hip_device) == 0
+    # torch reference: compose the lineage with torch.gather, gather every latent, autograd
+    leaves = [x.clone().requires_grad_() for x in latents]
+    lineage = torch.arange(K, device=hip_device).unsqueeze(0).expand(B, K)
+    total = 0
+    want_values = [None] * T
+    for t in range(T - 1, -1, -1):
+        want_values[t] = torch.gather(leaves[t], 1, lineage[..., None].expand(B, K, d))
+        total = total + (want_values[t] * weights[t]).sum()
+        if t > 0:
+            lineage = torch.gather(indices[t - 1], 1, lineage)
+    total.backward()
+    for t in range(T):
+        assert torch.equal(values[t], want_values[t].detach())
+        assert torch.equal(again_grads[t], grads[t])            # no atomics: same bits twice
+        torch.testing.assert_close(grads[t], leaves[t].grad, rtol=1e-12, atol=1e-12)
+        torch.testing.assert_close(other_grads[t], leaves[t].grad, rtol=1e-12, atol=1e-12)
