@@ -26,6 +26,7 @@ namespace aesmc {
 
 constexpr int kMaxThreads = 1024;
 constexpr int kScratchDoubles = 64;  // per-workgroup LDS scratch (wavefront totals, reduce slots)
+constexpr int kScanSlot = 40;        // inv kernel: [0,16) maxima, [32,40) int flags / max-scan, [40,58) the scan's
 // Stored-CDF kernel (K > 32768): the row's float64 CDF lives in the caller's workspace with one
 // padding slot per 8 entries (lane t writes entries 8t..8t+7: a 72-byte lane stride keeps the
 // lanes of a wavefront in different memory channels); aesmc_workspace_bytes accounts for the pad.
@@ -258,7 +259,7 @@ __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *
                                                     uint32_t tid, uint32_t nt, uint32_t part,
                                                     uint32_t parts) {
   constexpr int V = 16 / G;
-  constexpr int U = 4;
+  constexpr int U = 5;                                       // chunks in flight per lane (K=1024 d=10: 10 per lane, two trips)
   using P = typename Piece<G>::type;
   const uint64_t row_pieces = (uint64_t)K * ppp;             // a multiple of V (checked on the host)
   const uint32_t row_chunks = (uint32_t)(row_pieces / V);
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     dm = fmax(dm, scratch[w]);
     has_nan |= scratch_i[w];
   }
-  __syncthreads();
+  // (no barrier here: the scan below publishes into scratch slots of its own, kScanSlot onwards)
   const bool degenerate = has_nan || !(dm > -__builtin_huge_val() && dm < __builtin_huge_val());
   if (degenerate) {  // same conventions as the reference: see include/aesmc_hip.h, K2
     if (tid == 0 && part == 0) {
@@ -414,13 +415,22 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   }
   double base = __shfl_up(incl, 1, kWave);
   if (lane == 0) base = 0.0;
-  if (lane == kWave - 1) scratch[wave] = incl;
+  double *scan = scratch + kScanSlot;                          // [16] wavefront totals, [16] / [17]: see below
+  if (lane == kWave - 1) scan[wave] = incl;
+  // The CDF's last entry is the normaliser, so that c[K-1] == 1.0 exactly (reference: c / max(c)).
+  // Its owner publishes the two terms only it has — its exclusive prefix inside the wavefront and
+  // its running sum up to particle K - 1 — BEFORE the barrier; every lane then adds the earlier
+  // wavefronts' totals in the owner's own order: the same value bit for bit, one barrier fewer.
+  const int last_wave = ((K - 1) / C) / kWave;
+  if (j0 <= K - 1 && K - 1 < j0 + C) {
+    scan[16] = base;
+    scan[17] = s[K - 1 - j0];
+  }
   __syncthreads();
-  for (int w = 0; w < wave; ++w) base += scratch[w];
-  // the CDF's last entry is the normaliser, so that c[K-1] == 1.0 exactly (reference: c / max(c))
-  if (j0 <= K - 1 && K - 1 < j0 + C) scratch[31] = base + s[K - 1 - j0];
-  __syncthreads();
-  const double total = scratch[31];
+  for (int w = 0; w < wave; ++w) base += scan[w];
+  double total = scan[16];
+  for (int w = 0; w < last_wave; ++w) total += scan[w];
+  total += scan[17];
   const double inv_total = 1.0 / total;
   // by-product: logsumexp of the row (the step's contribution to log Z), float64 inside
   if (out_lse != nullptr && tid == 0 && part == 0) out_lse[row] = (T)(dm + ::log(total));
