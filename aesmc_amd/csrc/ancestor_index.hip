@@ -334,6 +334,9 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   const T *lw = log_w + row * (int64_t)K;
   int64_t *idx = out_idx + row * (int64_t)K;
   const int j0 = tid * C;                                         // nt * C >= K: one round
+  // the row's uniform is needed only after the scan, but a load issued there (behind three barriers,
+  // which the compiler may not move it across) would stall every lane for a full memory latency
+  const double ub = u[row];
 
   // ---- load once, row max + NaN scan ---------------------------------------------------------
   T v[C];
@@ -436,7 +439,6 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   if (out_lse != nullptr && tid == 0 && part == 0) out_lse[row] = (T)(dm + ::log(total));
 
   // ---- first[j] = min{ k : (u + k) / K >= c[j] } ---------------------------------------------------
-  const double ub = u[row];
   const double dK = (double)K;
   const double inv_K = 1.0 / dK;
   int first[C];
