@@ -253,13 +253,14 @@ struct StepPayload {
   int G;                       // 4, 8 or 16
 };
 
-template <int G>
+template <int G, int U>
 __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *srow, char *drow,
                                                     uint32_t K, uint32_t ppp, int64_t stride_k,
                                                     uint32_t tid, uint32_t nt, uint32_t part,
                                                     uint32_t parts) {
   constexpr int V = 16 / G;
-  constexpr int U = 5;                                       // chunks in flight per lane (K=1024 d=10: 10 per lane, two trips)
+  // U chunks in flight per lane: 5 for the small kernels (K=1024 d=10 has 10 per lane: two trips), 4
+  // where a fifth would cost the 8-particles-per-lane kernel its third workgroup per CU (85 registers)
   using P = typename Piece<G>::type;
   const uint64_t row_pieces = (uint64_t)K * ppp;             // a multiple of V (checked on the host)
   const uint32_t row_chunks = (uint32_t)(row_pieces / V);
@@ -394,11 +395,11 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     const char *srow = payload.src + row * payload.stride_b;
     char *drow = payload.dst + (uint64_t)row * K * payload.ppp * payload.G;
     if (payload.G == 16)
-      gather_row_from_lds<16>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
+      gather_row_from_lds<16, (C <= 4 ? 5 : 4)>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
     else if (payload.G == 8)
-      gather_row_from_lds<8>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
+      gather_row_from_lds<8, (C <= 4 ? 5 : 4)>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
     else
-      gather_row_from_lds<4>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
+      gather_row_from_lds<4, (C <= 4 ? 5 : 4)>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
     return;
   }
 
@@ -549,11 +550,11 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   __syncthreads();
   const char *srow = payload.src + row * payload.stride_b;
   if (payload.G == 16)
-    gather_row_from_lds<16>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
+    gather_row_from_lds<16, (C <= 4 ? 5 : 4)>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
   else if (payload.G == 8)
-    gather_row_from_lds<8>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
+    gather_row_from_lds<8, (C <= 4 ? 5 : 4)>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
   else
-    gather_row_from_lds<4>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
+    gather_row_from_lds<4, (C <= 4 ? 5 : 4)>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
 }
 
 static int pick_threads(int64_t K, int chunk) {
