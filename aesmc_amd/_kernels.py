@@ -159,6 +159,7 @@ class HipKernels:
         self._lock = threading.Lock()
         self.timer = None  # set to a KernelTimer to time every launch (bench only)
         self.lds_max_particles = int(self._lib.aesmc_ancestor_index_lds_max_particles())
+        self._affine_max_dim = None
 
     # ---- deferred status word ---------------------------------------------------------------
     def flags(self, device):
@@ -691,6 +692,213 @@ class HipKernels:
                 self.timer.note("normal_rsample", (self._lib.aesmc_normal_rsample, args), nbytes,
                                 (eps, loc, scale, out, views))
         return out
+    # ---- K8 / K9 / K10: linear-Gaussian particle propagation -----------------------------------
+    @property
+    def affine_max_dim(self):
+        if self._affine_max_dim is None:
+            self._affine_max_dim = int(self._lib.aesmc_affine_max_dim())
+        return self._affine_max_dim
+
+    def affine_covers(self, source, weight, offset=None):
+        """Host-only test of what K8 / K9 / K10 assume about one affine location
+        `offset + source @ weight.T`: source [B,K,din] float32/64 on the HIP device, weight
+        [dout,din] with din, dout <= aesmc_affine_max_dim(), offset None, [dout] or [B,dout]."""
+        if not (torch.is_tensor(source) and torch.is_tensor(weight)):
+            return False
+        if not (source.is_cuda and source.dtype in _DTYPE_TAG and source.dim() == 3 and source.numel() > 0):
+            return False
+        if weight.dim() != 2 or weight.dtype != source.dtype or weight.device != source.device:
+            return False
+        dout, din = weight.shape
+        if din != source.size(2) or not (1 <= din <= self.affine_max_dim and 1 <= dout <= self.affine_max_dim):
+            return False
+        if offset is not None:
+            if not torch.is_tensor(offset) or offset.dtype != source.dtype or offset.device != source.device:
+                return False
+            if tuple(offset.shape) not in ((dout,), (source.size(0), dout)):
+                return False
+        return True
+
+    @staticmethod
+    def _dense16(t):
+        """`t` laid out contiguously from a 16-byte aligned address (what the tile loads assume)."""
+        t = t.contiguous()
+        if t.data_ptr() % 16:
+            t = t.clone(memory_format=torch.contiguous_format)
+        return t
+
+    @staticmethod
+    def _affine_map(weight, offset):
+        """(aesmc_affine_map, tensors it borrows).  weight may be any 2-D view (a transpose costs
+        nothing); offset is [dout] (shared by every batch row) or [B, dout]."""
+        dout, din = weight.shape
+        off_ptr, off_sb = 0, 0
+        if offset is not None:
+            if offset.stride(-1) != 1:
+                offset = offset.contiguous()
+            off_ptr = offset.data_ptr()
+            off_sb = offset.stride(0) if offset.dim() == 2 else 0
+        return _lib.AffineMap(weight.data_ptr(), weight.stride(0), weight.stride(1), off_ptr, off_sb, dout, din), \
+            (weight, offset)
+
+    def particle_affine(self, x1, w1, offset=None, x2=None, w2=None, base=None):
+        """K8: base + (offset + x1 @ w1.T + x2 @ w2.T) -> dense [B,K,dout]; x2 / w2, offset, base optional.
+        Every element is one fma chain (w1's terms, then w2's) started from the offset."""
+        if not self.affine_covers(x1, w1, offset) or (x2 is not None and not self.affine_covers(x2, w2)):
+            raise ValueError("aesmc_amd: particle_affine operands outside what kernel K8 covers")
+        tag = _DTYPE_TAG[x1.dtype]
+        B, K = x1.shape[:2]
+        dout = w1.size(0)
+        if x2 is not None and (x2.shape[:2] != x1.shape[:2] or w2.size(0) != dout or x2.dtype != x1.dtype):
+            raise ValueError("aesmc_amd: particle_affine inputs disagree")
+        x1 = self._dense16(x1)
+        x2 = None if x2 is None else self._dense16(x2)
+        if base is not None:
+            if base.shape != (B, K, dout) or base.dtype != x1.dtype or base.device != x1.device:
+                raise ValueError("aesmc_amd: particle_affine base must be [{}, {}, {}]".format(B, K, dout))
+            base = self._dense16(base)
+        out = torch.empty((B, K, dout), dtype=x1.dtype, device=x1.device)
+        m1, keep1 = self._affine_map(w1, offset)
+        m2, keep2 = self._affine_map(w2, None) if x2 is not None else (None, ())
+        with _on_device(x1.device):
+            args = (tag, _ptr(x1), ctypes.byref(m1), _ptr(x2), ctypes.byref(m2) if m2 is not None else None,
+                    _ptr(base), _ptr(out), B, K, self._stream(x1))
+            _lib.check(self._lib.aesmc_particle_affine(*args), "aesmc_particle_affine")
+            if self.timer is not None:
+                esz = x1.element_size()
+                nbytes = esz * B * K * (x1.size(2) + (x2.size(2) if x2 is not None else 0) +
+                                        dout * (2 if base is not None else 1))
+                self.timer.note("particle_affine", (self._lib.aesmc_particle_affine, args), nbytes,
+                                (x1, x2, base, out, m1, m2, keep1, keep2))
+        return out
+
+    def affine_rsample(self, source, weight, offset, eps, scale):
+        """K9: (offset + source @ weight.T) + eps * scale -> dense [B,K,dout]; `scale` holds one value."""
+        if not self.affine_covers(source, weight, offset):
+            raise ValueError("aesmc_amd: affine_rsample operands outside what kernel K9 covers")
+        tag = _DTYPE_TAG[source.dtype]
+        B, K = source.shape[:2]
+        dout = weight.size(0)
+        if eps.shape != (B, K, dout) or eps.dtype != source.dtype or eps.device != source.device:
+            raise ValueError("aesmc_amd: affine_rsample noise must be [{}, {}, {}] {}".format(B, K, dout, source.dtype))
+        if scale.numel() != 1 or scale.dtype != source.dtype or scale.device != source.device:
+            raise ValueError("aesmc_amd: affine_rsample takes one scale value on the device")
+        source, eps = self._dense16(source), self._dense16(eps)
+        out = torch.empty((B, K, dout), dtype=source.dtype, device=source.device)
+        amap, keep = self._affine_map(weight, offset)
+        with _on_device(source.device):
+            args = (tag, _ptr(source), ctypes.byref(amap), _ptr(eps), _ptr(scale), _ptr(out), B, K,
+                    self._stream(source))
+            _lib.check(self._lib.aesmc_affine_normal_rsample(*args), "aesmc_affine_normal_rsample")
+            if self.timer is not None:
+                nbytes = source.element_size() * B * K * (source.size(2) + 2 * dout)
+                self.timer.note("affine_normal_rsample", (self._lib.aesmc_affine_normal_rsample, args), nbytes,
+                                (source, eps, scale, out, amap, keep))
+        return out
+
+    def affine_logweight_covers(self, x_prev, x, y_rows, transition, emission, proposal, scales):
+        """Host-only test of K10's preconditions; each of transition / emission / proposal is
+        (weight, offset or None), y_rows the observation [B, dy], scales three one-value tensors."""
+        if not (torch.is_tensor(x) and torch.is_tensor(x_prev) and torch.is_tensor(y_rows)):
+            return False
+        if x_prev.shape != x.shape or x_prev.dtype != x.dtype or x_prev.device != x.device:
+            return False
+        if not (self.affine_covers(x_prev, *transition) and self.affine_covers(x, *emission) and
+                self.affine_covers(x_prev, *proposal)):
+            return False
+        dx = x.size(2)
+        if transition[0].size(0) != dx or proposal[0].size(0) != dx:
+            return False
+        if y_rows.dim() != 2 or y_rows.shape != (x.size(0), emission[0].size(0)) or \
+                y_rows.dtype != x.dtype or y_rows.device != x.device:
+            return False
+        return all(torch.is_tensor(s) and s.numel() == 1 and s.dtype == x.dtype and s.device == x.device
+                   for s in scales)
+
+    def affine_logweight(self, x_prev, x, y_rows, transition, emission, proposal, scales):
+        """K10: the step's log-weight [B,K] with the three locations affine in the particles (see
+        `affine_logweight_covers` for the operands)."""
+        if not self.affine_logweight_covers(x_prev, x, y_rows, transition, emission, proposal, scales):
+            raise ValueError("aesmc_amd: affine_logweight operands outside what kernel K10 covers")
+        tag = _DTYPE_TAG[x.dtype]
+        B, K, dx = x.shape
+        x_prev, x = self._dense16(x_prev), self._dense16(x)
+        if y_rows.stride(1) != 1:
+            y_rows = y_rows.contiguous()
+        out = torch.empty((B, K), dtype=x.dtype, device=x.device)
+        maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
+        with _on_device(x.device):
+            args = (tag, _ptr(x_prev), _ptr(x), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
+                    ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
+                    _ptr(scales[2]), _ptr(out), B, K, self._stream(x))
+            _lib.check(self._lib.aesmc_affine_normal_logweight(*args), "aesmc_affine_normal_logweight")
+            if self.timer is not None:
+                nbytes = x.element_size() * (B * K * (2 * dx + 1) + y_rows.numel())
+                self.timer.note("affine_normal_logweight", (self._lib.aesmc_affine_normal_logweight, args), nbytes,
+                                (x_prev, x, y_rows, out, maps, scales))
+        return out
+
+    def particle_affine_backward(self, grad, x, weight, need_x=True, need_weight=True):
+        """Adjoint of `offset + x @ weight.T` for grad [B,K,dout]: (grad_x = grad @ weight through K8 on the
+        transposed weight view, grad_weight [dout,din] = sum over particles of grad (outer) x through
+        the outer-sum kernel); entries not asked for are None."""
+        grad = self._dense16(grad)
+        gx = self.particle_affine(grad, weight.t()) if need_x else None
+        gw = self.outer_sum(grad, x) if need_weight else None
+        return gx, gw
+
+    def outer_sum(self, g, x):
+        """sum over all particles of g[b,k,:] (outer) x[b,k,:] -> [dout, din]: the weight gradient of an
+        affine location."""
+        g2, x2 = g.reshape(-1, g.size(-1)), x.reshape(-1, x.size(-1))
+        return torch.matmul(g2.t(), x2)
+
+    def affine_logweight_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need,
+                                  grad_lw=None, lw=None, lse=None, grad_lse=None):
+        """Gradients of `affine_logweight` with respect to its twelve operands, in the order
+        (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q); None where `need[i]` is false
+        or the operand is absent.  The incoming gradient is `grad_lw` [B,K] and / or K1's softmax term
+        grad_lse[b] * exp(lw - lse[b]) formed in place (`lw`, `lse`, `grad_lse`)."""
+        (A, off_p), (C, off_g), (Q, off_q) = transition, emission, proposal
+        s_p, s_g, s_q = scales
+        B, K, dx = x.shape
+        dy = y_rows.size(1)
+        loc_p = self.particle_affine(x_prev, A, off_p)
+        loc_g = self.particle_affine(x, C, off_g)
+        loc_q = self.particle_affine(x_prev, Q, off_q)
+        y_expanded = y_rows.unsqueeze(1).expand(B, K, dy)
+        want = [True, True, bool(need[9]), bool(need[2]), True, bool(need[10]), True, bool(need[11])]
+        outs = self.normal_logweight_backward(x, loc_p, s_p.expand_as(loc_p), y_expanded, loc_g,
+                                              s_g.expand_as(loc_g), loc_q, s_q.expand_as(loc_q), grad_lw, want,
+                                              lw=lw, lse=lse, grad_lse=grad_lse)
+        if outs is None:
+            raise RuntimeError("aesmc_amd: K5's backward declined operands of an affine step")
+        gx, g_loc_p, g_sp, g_y, g_loc_g, g_sg, g_loc_q, g_sq = outs
+        fold = lambda g, off: None if off is None else (g.sum(dim=1) if off.dim() == 2 else g.sum(dim=(0, 1)))
+        grads = [None] * 12
+        if need[0]:
+            grads[0] = self.particle_affine(g_loc_p, A.t(), None, g_loc_q, Q.t())
+        if need[1]:
+            grads[1] = self.particle_affine(g_loc_g, C.t(), base=gx)
+        if need[2]:
+            grads[2] = g_y.sum(dim=1)
+        if need[3]:
+            grads[3] = self.outer_sum(g_loc_p, x_prev)
+        if need[4] and off_p is not None:
+            grads[4] = fold(g_loc_p, off_p)
+        if need[5]:
+            grads[5] = self.outer_sum(g_loc_g, x)
+        if need[6] and off_g is not None:
+            grads[6] = fold(g_loc_g, off_g)
+        if need[7]:
+            grads[7] = self.outer_sum(g_loc_q, x_prev)
+        if need[8] and off_q is not None:
+            grads[8] = fold(g_loc_q, off_q)
+        for slot, g, s in ((9, g_sp, s_p), (10, g_sg, s_g), (11, g_sq, s_q)):
+            if need[slot]:
+                grads[slot] = g.sum().reshape(s.shape)
+        return grads
+
     # ---- K7 ------------------------------------------------------------------------------------
     def particle_summary(self, log_w, value=None, want_log_ess=False, want_mean=False, want_second=False):
         """(log_ess [B], mean [B,...], second moment [B,...]) under w = softmax(log_w, dim=1); entries

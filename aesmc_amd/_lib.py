@@ -30,6 +30,15 @@ class View3(ctypes.Structure):
                 ("stride_d", ctypes.c_int64)]
 
 
+class AffineMap(ctypes.Structure):
+    """`aesmc_affine_map` of include/aesmc_hip.h: loc = offset + weight @ x without materialising it."""
+    _fields_ = [("weight", ctypes.c_void_p), ("stride_out", ctypes.c_int64), ("stride_in", ctypes.c_int64),
+                ("offset", ctypes.c_void_p), ("offset_stride_b", ctypes.c_int64), ("dout", ctypes.c_int64),
+                ("din", ctypes.c_int64)]
+
+
+_map_p = ctypes.POINTER(AffineMap)
+
 # name -> (restype, argtypes); mirrors include/aesmc_hip.h one to one.
 SIGNATURES = {
     "aesmc_version": (_i32, []),
@@ -54,6 +63,11 @@ SIGNATURES = {
     "aesmc_particle_summary": (_i32, [_i32, _vp, ctypes.POINTER(View3), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
                                       _vp]),
     "aesmc_normal_rsample": (_i32, [_i32] + [ctypes.POINTER(View3)] * 3 + [_vp, _i64, _i64, _i64, _vp]),
+    "aesmc_affine_max_dim": (_i64, []),
+    "aesmc_particle_affine": (_i32, [_i32, _vp, _map_p, _vp, _map_p, _vp, _vp, _i64, _i64, _vp]),
+    "aesmc_affine_normal_rsample": (_i32, [_i32, _vp, _map_p, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "aesmc_affine_normal_logweight": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp,
+                                             _i64, _i64, _vp]),
 }
 
 _lib = None

@@ -192,8 +192,15 @@ def normal_log_weight_deferred(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scal
 
 
 def attach_lse(lse, lw, operands):
-    """The row log-sum-exp `lse` [B] of `lw` as a differentiable function of K5's `operands`."""
+    """The row log-sum-exp `lse` [B] of `lw` as a differentiable function of the `operands` of the
+    launch that produced `lw` (K5's eight views, or K10's AffineOperands)."""
+    if isinstance(operands, AffineOperands):
+        return _AffineLogWeightLSE.apply(lse.detach(), lw, *operands)
     return _NormalLogWeightLSE.apply(lse.detach(), lw, *operands)
+
+
+def operands_require_grad(operands):
+    return any(t is not None and t.requires_grad for t in operands)
 
 
 def normal_log_weight(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
@@ -305,3 +312,136 @@ def resample_gather(value, idx):
 def ancestor_index(log_weight, uniforms):
     """Systematic-resampling ancestor indices; never differentiable."""
     return _kernels.get().ancestor_index(log_weight.detach(), uniforms)
+
+
+# ---- linear-Gaussian particle propagation (K8 / K9 / K10) --------------------------------------------
+def _sum_to_offset(grad, offset_shape):
+    """Gradient of a location [B,K,dout] folded onto its offset: [dout] or [B, dout]."""
+    return grad.sum(dim=1) if len(offset_shape) == 2 else grad.sum(dim=(0, 1))
+
+
+class _ParticleAffine(torch.autograd.Function):
+    """x @ weight.T + offset through kernel K8; backward: the adjoint map through K8 on the transposed
+    weight view, the weight gradient through the outer-sum kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, offset):
+        ctx.save_for_backward(x, weight)
+        ctx.offset_shape = None if offset is None else tuple(offset.shape)
+        return _kernels.get().particle_affine(x, weight, offset)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        k = _kernels.get()
+        need_x, need_w, need_off = ctx.needs_input_grad
+        gx, gw = k.particle_affine_backward(grad, x, weight, need_x, need_w)
+        goff = _sum_to_offset(grad, ctx.offset_shape) if (need_off and ctx.offset_shape is not None) else None
+        return gx, gw, goff
+
+
+def particle_affine(x, weight, offset=None):
+    """[B,K,dout] location  offset + x @ weight.T  (kernel K8), differentiable in x, weight and offset."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, offset)):
+        return _ParticleAffine.apply(x, weight, offset)
+    return _kernels.get().particle_affine(x.detach(), weight.detach(), None if offset is None else offset.detach())
+
+
+class _AffineRsample(torch.autograd.Function):
+    """draw = (offset + source @ weight.T) + eps * scale in one launch (kernel K9)."""
+
+    @staticmethod
+    def forward(ctx, source, weight, offset, scale, eps):
+        ctx.save_for_backward(source, weight, eps if scale.requires_grad else None)
+        ctx.offset_shape = None if offset is None else tuple(offset.shape)
+        ctx.scale_shape = tuple(scale.shape)
+        return _kernels.get().affine_rsample(source, weight, offset, eps, scale)
+
+    @staticmethod
+    def backward(ctx, grad):
+        source, weight, eps = ctx.saved_tensors
+        need_src, need_w, need_off, need_scale, _ = ctx.needs_input_grad
+        gsrc, gw = _kernels.get().particle_affine_backward(grad, source, weight, need_src, need_w)
+        goff = _sum_to_offset(grad, ctx.offset_shape) if (need_off and ctx.offset_shape is not None) else None
+        gscale = (grad * eps).sum().reshape(ctx.scale_shape) if need_scale else None
+        return gsrc, gw, goff, gscale, None
+
+
+def affine_rsample(source, weight, offset, scale, eps):
+    """Reparameterised draw from Normal(offset + source @ weight.T, scale) given the noise (kernel K9)."""
+    tensors = (source, weight, offset, scale)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return _AffineRsample.apply(source, weight, offset, scale, eps)
+    return _kernels.get().affine_rsample(source.detach(), weight.detach(),
+                                         None if offset is None else offset.detach(), eps, scale.detach())
+
+
+class AffineOperands(tuple):
+    """The twelve operands of one K10 launch, in the order
+    (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q); offsets may be None."""
+
+    def requires_grad(self):
+        return any(t is not None and t.requires_grad for t in self)
+
+
+def _affine_logweight_grads(operands, need, grad_lw=None, lw=None, lse=None, grad_lse=None):
+    x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = operands
+    return _kernels.get().affine_logweight_backward(
+        x_prev, x, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q), list(need),
+        grad_lw=grad_lw, lw=lw, lse=lse, grad_lse=grad_lse)
+
+
+class _AffineLogWeight(torch.autograd.Function):
+    """K10 with the log-weights themselves differentiable."""
+
+    @staticmethod
+    def forward(ctx, *operands):
+        x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = operands
+        ctx.save_for_backward(*[t for t in operands if t is not None])
+        ctx.present = [t is not None for t in operands]
+        return _kernels.get().affine_logweight(x_prev, x, y_rows, (A, off_p), (C, off_g), (Q, off_q),
+                                               (s_p, s_g, s_q))
+
+    @staticmethod
+    def backward(ctx, grad):
+        saved = iter(ctx.saved_tensors)
+        operands = [next(saved) if present else None for present in ctx.present]
+        return tuple(_affine_logweight_grads(operands, ctx.needs_input_grad, grad_lw=grad.contiguous()))
+
+
+class _AffineLogWeightLSE(torch.autograd.Function):
+    """The counterpart of _NormalLogWeightLSE for a K10 launch: ties a row log-sum-exp produced by a
+    later launch to K10's operands; backward forms K1's softmax term where the step's gradient is
+    consumed."""
+
+    @staticmethod
+    def forward(ctx, lse, lw, *operands):
+        ctx.save_for_backward(lse, lw, *[t for t in operands if t is not None])
+        ctx.present = [t is not None for t in operands]
+        return lse.view_as(lse)
+
+    @staticmethod
+    def backward(ctx, grad_lse):
+        lse, lw = ctx.saved_tensors[:2]
+        saved = iter(ctx.saved_tensors[2:])
+        operands = [next(saved) if present else None for present in ctx.present]
+        grads = _affine_logweight_grads(operands, ctx.needs_input_grad[2:], lw=lw, lse=lse,
+                                        grad_lse=grad_lse.contiguous())
+        return (None, None) + tuple(grads)
+
+
+def affine_log_weight(operands):
+    """[B,K] log-weight of one step whose three terms are affine Normals (kernel K10)."""
+    if torch.is_grad_enabled() and operands.requires_grad():
+        return _AffineLogWeight.apply(*operands)
+    x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = [
+        None if t is None else t.detach() for t in operands]
+    return _kernels.get().affine_logweight(x_prev, x, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q))
+
+
+def affine_log_weight_deferred(operands):
+    """K10 forward WITHOUT an autograd node: (log-weights, operands) for `attach_lse`."""
+    x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = [
+        None if t is None else t.detach() for t in operands]
+    lw = _kernels.get().affine_logweight(x_prev, x, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q))
+    return lw, operands

@@ -1,0 +1,549 @@
+// K8 / K9 / K10: particle propagation for linear-Gaussian model terms.
+//
+// The reference's own state-space model (test/models/lgssm.py:40, :52, :74) and every LGSSM written
+// against its callable contract (aesmc/inference.py:20-46) build each step's distributions as
+//     Normal(loc = W x + c, scale)            x = previous_latents[-1] or latents[-1]  [B,K,d]
+// with one small matrix per term.  Through PyTorch that is, per timestep, three skinny matmuls
+// ([B*K, d] x [d, d]: 2 x 4 d bytes per particle each for ~2 d^2 flops — pure HBM traffic), a
+// broadcast add, and then `state.sample` / `state.log_prob` (aesmc/state.py:61-155) reading the
+// materialised locations back: at B=1024 K=4096 d=10 more than half of a step's device time.
+//
+// Here the location is never written to HBM.  One lane owns one particle; the tile's rows are staged
+// through LDS with 16-byte loads, the (at most 16 x 16) matrices sit zero-padded in LDS and are read
+// as broadcasts, and every location element is ONE chain of fused multiply-adds in a fixed order
+//     loc[j] = fma(W[j][d-1], x[d-1], ... fma(W[j][1], x[1], fma(W[j][0], x[0], c[j])) ...)
+// — the same chain in all three kernels, so the fused sample (K9), the fused log-weight (K10) and
+// a location materialised by K8 agree bit for bit, and oracle/smc_core.c restates it with fma().
+//
+//   K8  aesmc_particle_affine            out = base + (c + W1 x1 + W2 x2)        (materialise / adjoint)
+//   K9  aesmc_affine_normal_rsample      x' = (c + W x) + eps * scale           (state.sample)
+//   K10 aesmc_affine_normal_logweight    log N(x'; A x + a, s_p) + log N(y; C x' + g, s_g)
+//                                        - log N(x'; Q x + q, s_q)              (inference.py:112-126)
+//
+// Everything after the location follows K6 / K5 operation for operation (product rounded before the
+// sum; (-(diff^2)) / (2 sigma^2) - log sigma - log sqrt(2 pi); d-sums from j = 0 upwards; (p + g) - q).
+#include <algorithm>
+
+#include "common.hpp"
+namespace aesmc {
+
+constexpr int kLgBlock = 256;
+constexpr int kLgMaxDim = 16;
+
+__device__ __forceinline__ uint32_t lg_pad(uint32_t e) { return e + (e >> 5); }
+static inline size_t lg_tile_elems(size_t particles, size_t d) {
+  const size_t ne = particles * d;
+  return ne + (ne >> 5) + 1;
+}
+
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <typename T> struct LgConst;
+template <> struct LgConst<float> {
+  static __device__ __forceinline__ float half_log_2pi() { return 0.9189385332046727f; }
+};
+template <> struct LgConst<double> {
+  static __device__ __forceinline__ double half_log_2pi() { return 0.9189385332046727; }
+};
+
+// Device-side copy of aesmc_affine_map.
+struct LgMap {
+  const void *w;
+  int64_t sj, si;      // element strides of the weight [dout, din]
+  const void *off;     // nullptr, or off[b * off_sb + j]
+  int64_t off_sb;
+  int32_t dout, din;
+};
+
+// [np, d] rows, contiguous in HBM from `src`, into a padded LDS tile; 16-byte loads (src is 16-byte
+// aligned: tiles start at multiples of 256 particles).
+template <typename T>
+__device__ __forceinline__ void lg_stage_rows(const T *__restrict__ src, uint32_t ne, T *__restrict__ tile,
+                                              int stream) {
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const uint32_t nvec = ne / N;
+  for (uint32_t v = threadIdx.x; v < nvec; v += kLgBlock) {
+    const V t = load16(reinterpret_cast<const V *>(src) + v, stream);
+#pragma unroll
+    for (int r = 0; r < N; ++r) tile[lg_pad(v * N + r)] = Vec16<T>::get(t, r);
+  }
+  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[lg_pad(e)] = src[e];
+}
+
+template <typename T>
+__device__ __forceinline__ void lg_store_rows(T *__restrict__ dst, uint32_t ne, const T *__restrict__ tile) {
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const uint32_t nvec = ne / N;
+  for (uint32_t v = threadIdx.x; v < nvec; v += kLgBlock) {
+    V t;
+    T *tv = reinterpret_cast<T *>(&t);
+#pragma unroll
+    for (int r = 0; r < N; ++r) tv[r] = tile[lg_pad(v * N + r)];
+    reinterpret_cast<V *>(dst)[v] = t;
+  }
+  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) dst[e] = tile[lg_pad(e)];
+}
+
+// Weight [dout, din] (any strides) zero-padded and TRANSPOSED in LDS: wt[i * DP + j] = W[j][i], so the
+// DP weights that multiply input element i are one contiguous (broadcast) read.
+template <typename T, int DP>
+__device__ __forceinline__ void lg_stage_weight(const LgMap &m, T *__restrict__ wt) {
+  const T *w = reinterpret_cast<const T *>(m.w);
+  for (uint32_t e = threadIdx.x; e < DP * DP; e += kLgBlock) {
+    const int i = e / DP, j = e - i * DP;
+    wt[e] = (j < m.dout && i < m.din) ? w[(int64_t)j * m.sj + (int64_t)i * m.si] : T(0);
+  }
+}
+
+// Which batch row each of a lane's PPL particles lies in (flat particle index n = b K + k).  Lanes past
+// the tile's end take particle 0 of the tile: they compute on valid addresses and store nothing.
+template <int PPL>
+__device__ __forceinline__ void lg_rows(int64_t n0, uint32_t np, uint32_t K, uint32_t (&p)[PPL], bool (&live)[PPL],
+                                        uint32_t (&brow)[PPL]) {
+  const uint32_t b0 = (uint32_t)(n0 / K);
+  const uint32_t k0 = (uint32_t)(n0 - (int64_t)b0 * K);
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) {
+    const uint32_t q = threadIdx.x + r * kLgBlock;
+    live[r] = q < np;
+    p[r] = live[r] ? q : 0u;
+    brow[r] = b0 + (k0 + p[r]) / K;
+  }
+}
+
+// acc[j][r] = off[b(r)][j] for j < dout (the chain's starting value); zero without an offset.  Elements
+// j >= dout repeat the last one: their weights are zero and nothing reads them.
+template <typename T, int DP, int PPL>
+__device__ __forceinline__ void lg_offsets(const LgMap &m, const uint32_t (&brow)[PPL], T (&acc)[DP][PPL]) {
+  const T *off = reinterpret_cast<const T *>(m.off);
+  if (off != nullptr) {
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const T *row = off + (int64_t)brow[r] * m.off_sb;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) acc[j][r] = row[min(j, m.dout - 1)];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) acc[j][r] = T(0);
+  }
+}
+
+// acc[j][r] = fma(W[j][i], x[r][i], acc[j][r]) for i = 0 .. din-1 in turn, x read from a staged tile
+// (`base[r]` = the particle's first element in it).
+template <typename T, int DP, int PPL>
+__device__ __forceinline__ void lg_apply_tile(const T *__restrict__ wt, const T *__restrict__ tile,
+                                              const uint32_t (&base)[PPL], int din, T (&acc)[DP][PPL]) {
+#pragma unroll
+  for (int i = 0; i < DP; ++i) {
+    if (i < din) {
+      T xv[PPL];
+  #pragma unroll
+      for (int r = 0; r < PPL; ++r) xv[r] = tile[lg_pad(base[r] + i)];
+  #pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T w = wt[i * DP + j];
+  #pragma unroll
+        for (int r = 0; r < PPL; ++r) acc[j][r] = fma_t(w, xv[r], acc[j][r]);
+      }
+    }
+  }
+}
+
+// ---- K8 ----------------------------------------------------------------------------------------
+template <typename T, int DP, int PPL>
+__global__ __launch_bounds__(kLgBlock) void particle_affine_kernel(const T *__restrict__ x1, LgMap m1,
+                                                                    const T *__restrict__ x2, LgMap m2,
+                                                                    const T *__restrict__ base, T *__restrict__ out,
+                                                                    int64_t N, uint32_t K, int stream) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  const uint32_t d1 = m1.din, d2 = x2 != nullptr ? m2.din : 0, dout = m1.dout;
+  T *w1 = reinterpret_cast<T *>(lg_smem);
+  T *w2 = w1 + DP * DP;
+  T *t1 = w2 + DP * DP;
+  T *t2 = t1 + (TP * d1 + ((TP * d1) >> 5) + 1);
+  T *to = t2 + (TP * d2 + ((TP * d2) >> 5) + 1);
+  const int64_t n0 = (int64_t)blockIdx.x * TP;
+  const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+  lg_stage_weight<T, DP>(m1, w1);
+  lg_stage_rows(x1 + n0 * d1, np * d1, t1, stream);
+  if (x2 != nullptr) {
+    lg_stage_weight<T, DP>(m2, w2);
+    lg_stage_rows(x2 + n0 * d2, np * d2, t2, stream);
+  }
+  if (base != nullptr) lg_stage_rows(base + n0 * dout, np * dout, to, stream);
+  uint32_t p[PPL], brow[PPL], at[PPL];
+  bool live[PPL];
+  lg_rows<PPL>(n0, np, K, p, live, brow);
+  T acc[DP][PPL];
+  lg_offsets<T, DP, PPL>(m1, brow, acc);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) at[r] = p[r] * d1;
+  lg_apply_tile<T, DP, PPL>(w1, t1, at, (int)d1, acc);
+  if (x2 != nullptr) {
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) at[r] = p[r] * d2;
+    lg_apply_tile<T, DP, PPL>(w2, t2, at, (int)d2, acc);
+  }
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    if ((uint32_t)j < dout) {
+  #pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        if (live[r]) {
+          const uint32_t slot = lg_pad(p[r] * dout + j);
+          to[slot] = base != nullptr ? to[slot] + acc[j][r] : acc[j][r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  lg_store_rows(out + n0 * dout, np * dout, to);
+}
+
+// ---- K9 ----------------------------------------------------------------------------------------
+template <typename T, int DP, int PPL>
+__global__ __launch_bounds__(kLgBlock) void affine_rsample_kernel(const T *__restrict__ src, LgMap m,
+                                                                   const T *__restrict__ eps,
+                                                                   const T *__restrict__ scale_ptr,
+                                                                   T *__restrict__ out, int64_t N, uint32_t K,
+                                                                   int stream) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  const uint32_t din = m.din, dout = m.dout;
+  T *wl = reinterpret_cast<T *>(lg_smem);
+  T *ts = wl + DP * DP;
+  T *te = ts + (TP * din + ((TP * din) >> 5) + 1);   // the noise, then the draw in its place
+  const int64_t n0 = (int64_t)blockIdx.x * TP;
+  const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+  const T scale = scale_ptr[0];
+  lg_stage_weight<T, DP>(m, wl);
+  lg_stage_rows(src + n0 * din, np * din, ts, 0);
+  lg_stage_rows(eps + n0 * dout, np * dout, te, stream);
+  uint32_t p[PPL], brow[PPL], at[PPL];
+  bool live[PPL];
+  lg_rows<PPL>(n0, np, K, p, live, brow);
+  T acc[DP][PPL];
+  lg_offsets<T, DP, PPL>(m, brow, acc);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) at[r] = p[r] * din;
+  lg_apply_tile<T, DP, PPL>(wl, ts, at, (int)din, acc);
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    if ((uint32_t)j < dout) {
+  #pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        if (live[r]) {
+          const uint32_t slot = lg_pad(p[r] * dout + j);
+          te[slot] = acc[j][r] + te[slot] * scale;   // the product rounded before the sum, as K6
+        }
+      }
+    }
+  }
+  __syncthreads();
+  lg_store_rows(out + n0 * dout, np * dout, te);
+}
+
+// ---- K10 ---------------------------------------------------------------------------------------
+// Per term: q = sum_j (v_j - loc_j)^2 as one fma chain from 0 (j ascending), then
+//   log N = (-q) / (2 sigma^2) - d (log sigma + log sqrt(2 pi))
+// — ONE division per term and particle instead of PyTorch's one per element (K5 keeps those: it is
+// HBM-bound either way; this kernel would be VALU-bound on 2 d divisions per particle).
+template <typename T, int DP, int PPL>
+__global__ __launch_bounds__(kLgBlock) void affine_logweight_kernel(
+    const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
+    LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
+    T *__restrict__ out_lw, int64_t N, uint32_t K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  const uint32_t dx = mp.dout, dy = mg.dout;
+  T *wp = reinterpret_cast<T *>(lg_smem);
+  T *wg = wp + DP * DP;
+  T *wq = wg + DP * DP;
+  T *tprev = wq + DP * DP;
+  T *tx = tprev + (TP * dx + ((TP * dx) >> 5) + 1);
+  const int64_t n0 = (int64_t)blockIdx.x * TP;
+  const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+  const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
+  lg_stage_weight<T, DP>(mp, wp);
+  lg_stage_weight<T, DP>(mg, wg);
+  lg_stage_weight<T, DP>(mq, wq);
+  lg_stage_rows(xprev + n0 * dx, np * dx, tprev, 0);
+  lg_stage_rows(x + n0 * dx, np * dx, tx, 0);
+  uint32_t p[PPL], brow[PPL], at[PPL];
+  bool live[PPL];
+  lg_rows<PPL>(n0, np, K, p, live, brow);
+  T locp[DP][PPL], locq[DP][PPL], yv[DP][PPL];
+  lg_offsets<T, DP, PPL>(mp, brow, locp);
+  lg_offsets<T, DP, PPL>(mq, brow, locq);
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) {
+    const T *row = y + (int64_t)brow[r] * y_sb;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) yv[j][r] = row[min(j, (int)dy - 1)];
+  }
+  const T half_log_2pi = LgConst<T>::half_log_2pi();
+  const T two_var_p = T(2) * (s_p * s_p), const_p = T(dx) * (Num<T>::log(s_p) + half_log_2pi);
+  const T two_var_g = T(2) * (s_g * s_g), const_g = T(dy) * (Num<T>::log(s_g) + half_log_2pi);
+  const T two_var_q = T(2) * (s_q * s_q), const_q = T(dx) * (Num<T>::log(s_q) + half_log_2pi);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) at[r] = p[r] * dx;
+  // transition and proposal locations from x_prev, one pass over its elements
+#pragma unroll
+  for (int i = 0; i < DP; ++i) {
+    if ((uint32_t)i < dx) {
+      T xv[PPL];
+  #pragma unroll
+      for (int r = 0; r < PPL; ++r) xv[r] = tprev[lg_pad(at[r] + i)];
+  #pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T a = wp[i * DP + j], q = wq[i * DP + j];
+  #pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+          locp[j][r] = fma_t(a, xv[r], locp[j][r]);
+          locq[j][r] = fma_t(q, xv[r], locq[j][r]);
+        }
+      }
+    }
+  }
+  // squared distances of x to both; x kept for the emission map
+  T xx[DP][PPL], qp[PPL], qq[PPL], qg[PPL];
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) qp[r] = qq[r] = qg[r] = T(0);
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    if ((uint32_t)j < dx) {
+  #pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        xx[j][r] = tx[lg_pad(at[r] + j)];
+        const T dp = xx[j][r] - locp[j][r], dq = xx[j][r] - locq[j][r];
+        qp[r] = fma_t(dp, dp, qp[r]);
+        qq[r] = fma_t(dq, dq, qq[r]);
+      }
+    }
+  }
+  // emission location from x (locp's registers are free again)
+  lg_offsets<T, DP, PPL>(mg, brow, locp);
+#pragma unroll
+  for (int i = 0; i < DP; ++i) {
+    if ((uint32_t)i < dx) {
+  #pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T c = wg[i * DP + j];
+  #pragma unroll
+        for (int r = 0; r < PPL; ++r) locp[j][r] = fma_t(c, xx[i][r], locp[j][r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    if ((uint32_t)j < dy) {
+  #pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        const T dg = yv[j][r] - locp[j][r];
+        qg[r] = fma_t(dg, dg, qg[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) {
+    if (live[r]) {
+      const T lp = (-qp[r]) / two_var_p - const_p;
+      const T lg = (-qg[r]) / two_var_g - const_g;
+      const T lq = (-qq[r]) / two_var_q - const_q;
+      out_lw[n0 + p[r]] = (lp + lg) - lq;
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static inline bool lg_map_ok(const aesmc_affine_map *m) {
+  return m != nullptr && m->weight != nullptr && m->dout >= 1 && m->din >= 1 && m->dout <= kLgMaxDim &&
+         m->din <= kLgMaxDim;
+}
+static inline LgMap lg_map(const aesmc_affine_map *m) {
+  LgMap out;
+  out.w = m->weight; out.sj = m->stride_out; out.si = m->stride_in;
+  out.off = m->offset; out.off_sb = m->offset_stride_b;
+  out.dout = (int32_t)m->dout; out.din = (int32_t)m->din;
+  return out;
+}
+static inline int lg_pad_dim(int64_t d) { return (int)((d + 3) / 4 * 4); }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// PPL = 2 only while the tiles fit 64 KiB (two workgroups per CU); one particle per lane may take up to 144 KiB
+constexpr size_t kLgLdsBudget = 64 * 1024;
+constexpr size_t kLgLdsLimit = 144 * 1024;
+
+// Launches `KERNEL<T, DP, PPL>` with DP from `dp` (4, 8, 12, 16) and PPL from `ppl` (1, 2).  Tiles beyond
+// 64 KiB of LDS (float64 rows of 10 and more values) need the opt-in; it is per kernel and per device,
+// cheap, and only taken for those shapes.
+#define LG_LAUNCH(KERNEL, T, DP_, PPL_, grid, lds, stream, ...)                                              \
+  do {                                                                                                       \
+    if ((lds) > 64 * 1024)                                                                                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<T, DP_, PPL_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds));                     \
+    hipLaunchKernelGGL((KERNEL<T, DP_, PPL_>), grid, dim3(kLgBlock), lds, stream, __VA_ARGS__);              \
+  } while (0)
+#define LG_DISPATCH(KERNEL, T, dp, ppl, grid, lds, stream, ...)                                              \
+  do {                                                                                                       \
+    if (ppl == 2) {                                                                                          \
+      switch (dp) {                                                                                          \
+        case 4: LG_LAUNCH(KERNEL, T, 4, 2, grid, lds, stream, __VA_ARGS__); break;                           \
+        case 8: LG_LAUNCH(KERNEL, T, 8, 2, grid, lds, stream, __VA_ARGS__); break;                           \
+        case 12: LG_LAUNCH(KERNEL, T, 12, 2, grid, lds, stream, __VA_ARGS__); break;                         \
+        default: LG_LAUNCH(KERNEL, T, 16, 2, grid, lds, stream, __VA_ARGS__); break;                         \
+      }                                                                                                      \
+    } else {                                                                                                 \
+      switch (dp) {                                                                                          \
+        case 4: LG_LAUNCH(KERNEL, T, 4, 1, grid, lds, stream, __VA_ARGS__); break;                           \
+        case 8: LG_LAUNCH(KERNEL, T, 8, 1, grid, lds, stream, __VA_ARGS__); break;                           \
+        case 12: LG_LAUNCH(KERNEL, T, 12, 1, grid, lds, stream, __VA_ARGS__); break;                         \
+        default: LG_LAUNCH(KERNEL, T, 16, 1, grid, lds, stream, __VA_ARGS__); break;                         \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
+
+template <typename T>
+static int launch_particle_affine(const void *x1, const aesmc_affine_map *m1, const void *x2,
+                                  const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
+                                  hipStream_t stream) {
+  const int64_t N = B * K;
+  const int64_t d1 = m1->din, d2 = x2 != nullptr ? m2->din : 0, dout = m1->dout;
+  const int dp = lg_pad_dim(std::max(std::max(d1, d2), dout));
+  int ppl = sizeof(T) == 4 ? 2 : 1;
+  size_t lds = 0;
+  for (; ppl >= 1; --ppl) {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * (2 * (size_t)dp * dp + lg_tile_elems(tp, d1) + lg_tile_elems(tp, d2) + lg_tile_elems(tp, dout));
+    if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
+  }
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
+  if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
+  LgMap a = lg_map(m1), b = x2 != nullptr ? lg_map(m2) : a;
+  const int hint = stream_hint((uint64_t)N * (d1 + d2 + dout) * sizeof(T));
+  LG_DISPATCH(particle_affine_kernel, T, dp, ppl, dim3((unsigned)tiles), lds, stream, static_cast<const T *>(x1), a,
+              static_cast<const T *>(x2), b, static_cast<const T *>(base), static_cast<T *>(out), N, (uint32_t)K,
+              hint);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+template <typename T>
+static int launch_affine_rsample(const void *src, const aesmc_affine_map *m, const void *eps, const void *scale,
+                                 void *out, int64_t B, int64_t K, hipStream_t stream) {
+  const int64_t N = B * K;
+  const int dp = lg_pad_dim(std::max(m->din, m->dout));
+  int ppl = sizeof(T) == 4 ? 2 : 1;
+  size_t lds = 0;
+  for (; ppl >= 1; --ppl) {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * ((size_t)dp * dp + lg_tile_elems(tp, m->din) + lg_tile_elems(tp, m->dout));
+    if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
+  }
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
+  if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
+  const int hint = stream_hint((uint64_t)N * (m->din + 2 * m->dout) * sizeof(T));
+  LG_DISPATCH(affine_rsample_kernel, T, dp, ppl, dim3((unsigned)tiles), lds, stream, static_cast<const T *>(src),
+              lg_map(m), static_cast<const T *>(eps), static_cast<const T *>(scale), static_cast<T *>(out), N,
+              (uint32_t)K, hint);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+template <typename T>
+static int launch_affine_logweight(const void *xprev, const void *x, const void *y, int64_t y_sb,
+                                   const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
+                                   const void *sp, const void *sg, const void *sq, void *out, int64_t B, int64_t K,
+                                   hipStream_t stream) {
+  const int64_t N = B * K;
+  const int64_t dx = mp->dout, dy = mg->dout;
+  const int dp = lg_pad_dim(std::max(dx, dy));
+  int ppl = sizeof(T) == 4 ? 2 : 1;
+  size_t lds = 0;
+  for (; ppl >= 1; --ppl) {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * (3 * (size_t)dp * dp + 2 * lg_tile_elems(tp, dx));
+    if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
+  }
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
+  if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
+  LG_DISPATCH(affine_logweight_kernel, T, dp, ppl, dim3((unsigned)tiles), lds, stream, static_cast<const T *>(xprev),
+              static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), lg_map(mq),
+              static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),
+              static_cast<T *>(out), N, (uint32_t)K);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+}  // namespace aesmc
+
+using namespace aesmc;
+
+extern "C" int64_t aesmc_affine_max_dim(void) { return kLgMaxDim; }
+
+extern "C" int aesmc_particle_affine(int dtype, const void *x1, const aesmc_affine_map *m1, const void *x2,
+                                     const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
+                                     void *stream) {
+  if (x1 == nullptr || out == nullptr || m1 == nullptr || m1->weight == nullptr || B < 0 || K < 0 ||
+      (x2 != nullptr && (m2 == nullptr || m2->weight == nullptr)))
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!aligned16(x1) || !aligned16(out) || (x2 != nullptr && !aligned16(x2)) || (base != nullptr && !aligned16(base)))
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(m1) || (x2 != nullptr && (!lg_map_ok(m2) || m2->dout != m1->dout))) return AESMC_ERR_UNSUPPORTED;
+  if (B == 0 || K == 0) return AESMC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AESMC_F32 ? launch_particle_affine<float>(x1, m1, x2, m2, base, out, B, K, s)
+                            : launch_particle_affine<double>(x1, m1, x2, m2, base, out, B, K, s);
+}
+
+extern "C" int aesmc_affine_normal_rsample(int dtype, const void *source, const aesmc_affine_map *map,
+                                           const void *eps, const void *scale, void *out, int64_t B, int64_t K,
+                                           void *stream) {
+  if (source == nullptr || map == nullptr || map->weight == nullptr || eps == nullptr || scale == nullptr ||
+      out == nullptr || B < 0 || K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!aligned16(source) || !aligned16(eps) || !aligned16(out) || out == eps || out == source)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(map)) return AESMC_ERR_UNSUPPORTED;
+  if (B == 0 || K == 0) return AESMC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AESMC_F32 ? launch_affine_rsample<float>(source, map, eps, scale, out, B, K, s)
+                            : launch_affine_rsample<double>(source, map, eps, scale, out, B, K, s);
+}
+
+extern "C" int aesmc_affine_normal_logweight(int dtype, const void *x_prev, const void *x, const void *y,
+                                             int64_t y_stride_b, const aesmc_affine_map *transition,
+                                             const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+                                             const void *scale_p, const void *scale_g, const void *scale_q,
+                                             void *out_lw, int64_t B, int64_t K, void *stream) {
+  if (x_prev == nullptr || x == nullptr || y == nullptr || transition == nullptr || emission == nullptr ||
+      proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || out_lw == nullptr ||
+      B < 0 || K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!aligned16(x_prev) || !aligned16(x)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  // one latent extent: x' and x_prev are [B,K,dx]; the emission maps x' to the observation's dy values
+  const int64_t dx = transition->dout;
+  if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
+    return AESMC_ERR_UNSUPPORTED;
+  if (B == 0 || K == 0) return AESMC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AESMC_F32
+             ? launch_affine_logweight<float>(x_prev, x, y, y_stride_b, transition, emission, proposal, scale_p,
+                                              scale_g, scale_q, out_lw, B, K, s)
+             : launch_affine_logweight<double>(x_prev, x, y, y_stride_b, transition, emission, proposal, scale_p,
+                                               scale_g, scale_q, out_lw, B, K, s);
+}

@@ -328,7 +328,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                                                    observation, defer_grad=fold)
             if fold and log_weight_t is not None:
                 log_weight_t, operands = log_weight_t
-                if any(t.requires_grad for t in operands):
+                if _ops.operands_require_grad(operands):
                     deferred[time] = operands
         # importance sampling over several timesteps normalises the SUM of the per-step weights
         # (inference.py:156-159); K1 keeps that sum running, left to right as torch.sum over the

@@ -11,6 +11,7 @@ import torch
 
 from . import _kernels
 from . import _ops
+from .linear_gaussian import AffineNormal
 
 _VALIDATION_MODE = "deferred"
 
@@ -182,6 +183,13 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     differentiates only through the row log-sum-exp (`_ops.attach_lse`)."""
     if not _FUSED_NORMAL:
         return None
+    affine = _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, observation)
+    if affine is not None:
+        for distribution, value in ((prior_dist, latent), (emission_dist, observation), (proposal_dist, latent)):
+            _validate_sample(distribution, value)
+        if defer_grad:
+            return _ops.affine_log_weight_deferred(affine)
+        return _ops.affine_log_weight(affine)
     operands = []
     for distribution, value in ((prior_dist, latent), (emission_dist, observation),
                                 (proposal_dist, latent)):
@@ -203,6 +211,35 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     if defer_grad:
         return _ops.normal_log_weight_deferred(latent, loc_p, scale_p, observation, loc_g, scale_g, loc_q, scale_q)
     return _ops.normal_log_weight(latent, loc_p, scale_p, observation, loc_g, scale_g, loc_q, scale_q)
+
+
+def _same_tensor(a, b):
+    return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+                      and a.dtype == b.dtype)
+
+
+def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, observation):
+    """K10's operands when the step is linear-Gaussian — transition and proposal AffineNormal in the SAME
+    previous latent, emission AffineNormal in the latent being weighed, one scale value each, the
+    observation one row per batch element expanded over particles — else None."""
+    if not (type(prior_dist) is AffineNormal and type(proposal_dist) is AffineNormal and
+            type(emission_dist) is AffineNormal):
+        return None
+    if not (torch.is_tensor(latent) and torch.is_tensor(observation) and latent.dim() == 3 and
+            observation.dim() == 3 and observation.stride(1) == 0):
+        return None
+    x_prev = prior_dist.source
+    if not (_same_tensor(proposal_dist.source, x_prev) and _same_tensor(emission_dist.source, latent)):
+        return None
+    y_rows = observation[:, 0]
+    transition = (prior_dist.weight, prior_dist.offset)
+    emission = (emission_dist.weight, emission_dist.offset)
+    proposal = (proposal_dist.weight, proposal_dist.offset)
+    scales = (prior_dist.scale_param, emission_dist.scale_param, proposal_dist.scale_param)
+    if not _kernels.get().affine_logweight_covers(x_prev, latent, y_rows, transition, emission, proposal, scales):
+        return None
+    return _ops.AffineOperands((x_prev, latent, y_rows, transition[0], transition[1], emission[0], emission[1],
+                                proposal[0], proposal[1]) + scales)
 
 
 _FUSED_NORMAL = True
@@ -227,7 +264,15 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
     base = distribution
     if type(base) is torch.distributions.Independent:
         base = base.base_dist
-    if type(base) is not torch.distributions.Normal:
+    if type(base) is AffineNormal and len(sample_shape) == 0 and not swap_leading_dims:
+        # location + noise in one pass (K9); the noise is the call Normal.rsample makes
+        scale = base.scale_param
+        if scale.numel() == 1 and scale.dtype == base.source.dtype and scale.device == base.source.device and \
+                _kernels.get().affine_covers(base.source, base.weight, base.offset):
+            eps = torch.distributions.normal._standard_normal(base.batch_shape, dtype=base.source.dtype,
+                                                               device=base.source.device)
+            return _ops.affine_rsample(base.source, base.weight, base.offset, scale, eps)
+    if type(base) not in (torch.distributions.Normal, AffineNormal):
         return None
     loc, scale = base.loc, base.scale
     if not (loc.is_cuda and scale.device == loc.device and loc.dtype == scale.dtype and
@@ -255,7 +300,7 @@ def _fused_normal_views(distribution, value, missing):
     base = distribution
     if type(base) is torch.distributions.Independent:
         base = base.base_dist
-    if type(base) is not torch.distributions.Normal:
+    if type(base) not in (torch.distributions.Normal, AffineNormal):   # AffineNormal: .loc materialises (K8)
         return None
     if not (torch.is_tensor(value) and value.is_cuda and value.dim() >= 2 and
             value.dtype in (torch.float32, torch.float64)):

@@ -120,9 +120,13 @@ class LgssmNd(nn.Module):
     `initial`, `transition`, `emission`, `proposal`."""
 
     def __init__(self, dim, transition_scale=1.0, emission_scale=0.5, proposal_scale=0.7, seed=0,
-                 dtype=torch.float32, state=_default_state, validate_args=None):
+                 dtype=torch.float32, state=_default_state, validate_args=None, affine=False):
         super().__init__()
         self.validate_args = validate_args  # None = PyTorch default; False skips per-call host syncs
+        # affine=True: the callables return aesmc_amd.linear_gaussian.AffineNormal(source, weight, ...)
+        # in place of Normal(source @ weight.T + ..., ...) — the same distributions, their locations
+        # evaluated inside the sampling / weighting kernels instead of by matmuls beforehand
+        self.affine = bool(affine)
         gen = torch.Generator().manual_seed(seed)
         eye = torch.eye(dim, dtype=torch.float64)
         self.dim = dim
@@ -157,11 +161,20 @@ class LgssmNd(nn.Module):
     def initial(self):
         return self._tag(self._normal(self.loc0, self.scale0), "NOT_EXPANDED")
 
+    def _affine_normal(self, source, weight, scale, offset=None):
+        from ..linear_gaussian import AffineNormal
+        return AffineNormal(source, weight, scale, offset=offset, validate_args=self.validate_args)
+
     def transition(self, previous_latents=None, time=None, previous_observations=None):
+        if self.affine:
+            return self._tag(self._affine_normal(previous_latents[-1], self.A, self.transition_scale),
+                             "FULLY_EXPANDED")
         loc = previous_latents[-1] @ self.A.t()
         return self._tag(self._normal(loc, self.transition_scale), "FULLY_EXPANDED")
 
     def emission(self, latents=None, time=None, previous_observations=None):
+        if self.affine:
+            return self._tag(self._affine_normal(latents[-1], self.C, self.emission_scale), "FULLY_EXPANDED")
         loc = latents[-1] @ self.C.t()
         return self._tag(self._normal(loc, self.emission_scale), "FULLY_EXPANDED")
 
@@ -169,7 +182,11 @@ class LgssmNd(nn.Module):
         if time == 0:
             loc = observations[0] @ self.W0.t() + self.b0
             return self._tag(self._normal(loc, self.proposal_scale), "BATCH_EXPANDED")
-        loc = previous_latents[-1] @ self.Wx.t() + (observations[time] @ self.Wy.t() + self.b).unsqueeze(1)
+        from_observation = observations[time] @ self.Wy.t() + self.b      # [B, d]: shared by a row's particles
+        if self.affine:
+            return self._tag(self._affine_normal(previous_latents[-1], self.Wx, self.proposal_scale,
+                                                 offset=from_observation), "FULLY_EXPANDED")
+        loc = previous_latents[-1] @ self.Wx.t() + from_observation.unsqueeze(1)
         return self._tag(self._normal(loc, self.proposal_scale), "FULLY_EXPANDED")
 
     @torch.no_grad()

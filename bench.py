@@ -82,6 +82,11 @@ def parse(argv=None):
                     help="LGSSM workloads: 'tuned' = the model's locally optimal proposal in closed form (what "
                          "training converges towards: a healthy particle system); 'stock' = SURVEY.md 8(d)'s "
                          "untrained linear stand-in (collapses to ~14 %% surviving ancestors per step)")
+    ap.add_argument("--callables", default="affine", choices=["affine", "matmul"],
+                    help="LGSSM workloads: how the model's callables state their linear-Gaussian terms. 'affine': "
+                         "aesmc_amd.linear_gaussian.AffineNormal(source, weight, scale, offset) — the locations are "
+                         "evaluated inside the sampling / weighting kernels (K9 / K10); 'matmul': "
+                         "Normal(source @ weight.T + offset, scale) with PyTorch matmuls, as round 1 and 2 timed it")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--extras", default=None, choices=["on", "off"],
                     help="the extra blocks (stock proposal, configs[1] hipGraph, kernel legs, parity); default: on for N=1")
@@ -146,12 +151,14 @@ def self_launch(args, argv):
 
 
 # ---- models / CPU baseline -------------------------------------------------------------------------
-def build_model(kind, dim, device, state, proposal="stock", **model_kwargs):
+def build_model(kind, dim, device, state, proposal="stock", callables="matmul", **model_kwargs):
     from aesmc_amd.testing import models
     cls = {"lgssm": models.LgssmNd, "nonlinear": models.NonlinearSsm, "gaussian": models.GaussianIwae,
            "learned_scale": models.LearnedScaleSsm}[kind]
     if kind == "gaussian":
         return cls(state=state, validate_args=False).to(device)
+    if kind == "lgssm":
+        model_kwargs = dict(model_kwargs, affine=(callables == "affine"))
     # validate_args=False: no per-call host sync inside torch.distributions (standard practice)
     model = cls(dim, seed=0, state=state, validate_args=False, **model_kwargs).to(device)
     if proposal == "tuned" and hasattr(model, "tune_proposal"):
@@ -267,7 +274,7 @@ def traffic_record(workload, proposal, kernel):
 
 
 def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backward=True, want_kernels=True,
-                 mode=None, grad=None):
+                 mode=None, grad=None, callables=None):
     """Times `steps` forward ELBOs of one workload (after `warmup`), then forward+backward, then the
     per-kernel pass.  Returns a dict with the contract's numbers for this workload."""
     import numpy as np
@@ -280,6 +287,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
     algorithm = ALGORITHM.get(name, "aesmc")
     if kind != "lgssm":
         proposal = "stock"
+    callables = (callables or args.callables) if kind == "lgssm" else "matmul"
     if scaling == "strong":
         global_B = B
         lo, hi = distributed.shard_bounds(global_B, rank, world)
@@ -288,7 +296,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         global_B, local_B = B * world, B
     provider = _kernels.get()
     torch.cuda.reset_peak_memory_stats(device)
-    model = build_model(kind, dim, device, aesmc_amd.state, proposal, **model_kwargs)
+    model = build_model(kind, dim, device, aesmc_amd.state, proposal, callables, **model_kwargs)
     observations = model.simulate(T, global_B, seed=1)          # same data on every rank ...
     observations = distributed.shard_observations(observations, rank, world)  # ... own rows only
     parts = (model.initial, model.transition, model.emission, model.proposal)
@@ -340,6 +348,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         graphed.check()
     out = {
         "workload": "{}: {}".format(name, description), "proposal": proposal if kind == "lgssm" else None,
+        "callables": callables,
         "value": global_B * K * T * steps / seconds, "ms_per_step": 1e3 * seconds / steps, "loss": loss,
         "mode": ran_as, "graph_error": graph_error, "grad": grad, "scaling": scaling,
         "batch_per_gpu": local_B, "global_batch": global_B, "num_particles": K, "num_timesteps": T,
@@ -640,6 +649,10 @@ def main(argv=None):
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": head["workload"], "proposal": head["proposal"],
+                   "callables": {"affine": "AffineNormal(source, weight, scale, offset): locations evaluated inside "
+                                           "kernels K9 / K10 (aesmc_amd/linear_gaussian.py)",
+                                 "matmul": "Normal(source @ weight.T + offset, scale): PyTorch matmuls, then K6 / K5"
+                                 }[head["callables"]],
                    "batch_per_gpu": head["batch_per_gpu"], "global_batch": head["global_batch"],
                    "num_particles": K, "num_timesteps": T, "state_dim": dim,
                    "parallelism": "batch-shard x{} (one RCCL all-reduce of sum log Z per ELBO)".format(world),
@@ -670,7 +683,7 @@ def main(argv=None):
                                     ("value", "ms_per_step", "batch_per_gpu", "global_batch", "mode", "loss")}
     if extras_on and world == 1:
         def brief(result):
-            keep = ("workload", "proposal", "value", "ms_per_step", "loss", "mode", "grad", "graph_error",
+            keep = ("workload", "proposal", "callables", "value", "ms_per_step", "loss", "mode", "grad", "graph_error",
                     "eager_particle_steps_per_sec", "fwd_bwd_particle_steps_per_sec", "fwd_bwd_error",
                     "peak_memory_GB", "roofline")
             return {key: result.get(key) for key in keep}
@@ -678,6 +691,12 @@ def main(argv=None):
             other = "stock" if args.proposal == "tuned" else "tuned"
             extras["{}_proposal".format(other)] = brief(run_workload(
                 ctx, args.workload, other, args.steps, args.warmup, want_backward=False, mode=args.mode, grad=args.grad))
+        if kind == "lgssm" and args.callables == "affine" and dim <= 16:
+            # the same workload with the locations materialised by PyTorch matmuls (what rounds 1 and 2 timed)
+            extras["matmul_callables"] = brief(run_workload(
+                ctx, args.workload, args.proposal, max(2, args.steps // 2), min(args.warmup, 2),
+                want_backward=not args.no_backward, want_kernels=False, mode=args.mode, grad=args.grad,
+                callables="matmul"))
         if args.workload != "c2":
             extras["c2_hipgraph"] = brief(run_workload(ctx, "c2", args.proposal, 20, 5,
                                                        want_backward=not args.no_backward))

@@ -265,6 +265,62 @@ int aesmc_particle_summary(int dtype, const void *log_w, const aesmc_view3 *valu
                            void *out_mean, void *out_second, int64_t B, int64_t K, int64_t D, void *ws,
                            size_t ws_bytes, void *stream);
 
+/* ---- linear-Gaussian particle propagation (K8 / K9 / K10) ---------------------------------------
+ *
+ * An LGSSM written against the reference's callable contract (aesmc/inference.py:20-46) — its own
+ * test model included: test/models/lgssm.py:40 (transition, `mult * previous_latents[-1]`), :52
+ * (emission) and :66-77 (proposal, a Linear layer of [x_{t-1}, y_t]) — builds every step's
+ * distributions as Normal(loc = W x + c, scale) with x the [B,K,d] particles.  `aesmc_affine_map`
+ * describes one such location without materialising it:
+ *     loc[b,k,j] = offset[b, j] + sum_i weight[j, i] * x[b,k,i]         (dout, din <= aesmc_affine_max_dim())
+ * evaluated as ONE chain of fused multiply-adds per element, i ascending, starting from the offset
+ * (zero when offset == NULL) — the same chain in all three entry points below, so they agree bit for
+ * bit with each other (oracle/smc_core.c restates it with fma()).
+ */
+typedef struct aesmc_affine_map {
+  const void *weight;       /* [dout, din] by element strides; a transposed view is swapped strides */
+  int64_t stride_out, stride_in;
+  const void *offset;       /* NULL, or offset[b * offset_stride_b + j]: [dout] (stride 0) or [B, dout] */
+  int64_t offset_stride_b;
+  int64_t dout, din;
+} aesmc_affine_map;
+
+int64_t aesmc_affine_max_dim(void); /* 16: larger maps are proper GEMMs and stay library calls */
+
+/* K8 — materialise an affine location (or apply its adjoint):
+ *   out[b,k,:] = base[b,k,:] + (offset + W1 x1[b,k,:] + W2 x2[b,k,:])      x2 / m2 and base optional
+ * x1 [B,K,m1->din], x2 [B,K,m2->din], base and out [B,K,dout] dense and 16-byte aligned; m2 carries a
+ * weight only (its offset is ignored) and m2->dout == m1->dout.  The chain runs through W1's terms,
+ * then W2's; base is added last.  Replaces the `[B*K, d] x [d, d]` matmul (+ broadcast add) of the
+ * model callables named above, and — with transposed weight views — the input-gradient matmuls of
+ * their autograd.  out may alias base. */
+int aesmc_particle_affine(int dtype, const void *x1, const aesmc_affine_map *m1, const void *x2,
+                          const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
+                          void *stream);
+
+/* K9 — reparameterised draw from Normal(offset + W source, scale) without the location in HBM:
+ *   out[b,k,j] = loc[b,k,j] + eps[b,k,j] * scale          (product rounded before the sum, as K6)
+ * `scale` points to ONE value on the device; source [B,K,din], eps and out [B,K,dout] dense, 16-byte
+ * aligned, out distinct from both inputs.  Replaces the proposal's matmul + `state.sample`
+ * (aesmc/state.py:61-111) for t > 0; equals K8 followed by K6 bit for bit. */
+int aesmc_affine_normal_rsample(int dtype, const void *source, const aesmc_affine_map *map, const void *eps,
+                                const void *scale, void *out, int64_t B, int64_t K, void *stream);
+
+/* K10 — one SMC step's log-weight (aesmc/inference.py:112-126) for a linear-Gaussian model:
+ *   lw[b,k] = sum_j log N(x[b,k,j];  transition(x_prev[b,k,:])_j, scale_p)
+ *           + sum_j log N(y[b,j];    emission(x[b,k,:])_j,        scale_g)
+ *           - sum_j log N(x[b,k,j];  proposal(x_prev[b,k,:])_j,   scale_q)
+ * x_prev, x [B,K,dx] dense and 16-byte aligned; y[b * y_stride_b + j], j < dy = emission->dout (the
+ * observation, one row per batch element, not expanded over particles); the three scales point to ONE
+ * device value each.  transition and proposal map dx -> dx, emission dx -> dy.  Replaces the three
+ * matmuls of the callables and the three `state.log_prob` calls (aesmc/state.py:114-155) + combine;
+ * equals K8 x 3 followed by K5 bit for bit. */
+int aesmc_affine_normal_logweight(int dtype, const void *x_prev, const void *x, const void *y,
+                                  int64_t y_stride_b, const aesmc_affine_map *transition,
+                                  const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+                                  const void *scale_p, const void *scale_g, const void *scale_q, void *out_lw,
+                                  int64_t B, int64_t K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,3 +135,89 @@ void smc_oracle_logweight_lse(const double *a, const double *b, const double *c,
     }
   }
 }
+
+/* ---- linear-Gaussian particle propagation (kernels K8 / K9 / K10) ----------------------------------
+ *
+ * What the reference's LGSSM callables compute with PyTorch — test/models/lgssm.py:40 (transition:
+ * Normal(mult * previous_latents[-1], scale)), :52 (emission), :66-77 (proposal: a Linear layer of
+ * [x_{t-1}, y_t]) — followed by state.sample (aesmc/state.py:61-111), state.log_prob
+ * (aesmc/state.py:114-155) and the log-weight combine (aesmc/inference.py:112-126), for a model whose
+ * locations are affine in the particles:  loc[b,k,j] = off[b,j] + sum_i w[j,i] x[b,k,i].
+ * The kernels' contract fixes the arithmetic of the location to one chain of fused multiply-adds,
+ * i ascending, starting from the offset (0 without one); fmaf()/fma() of libm are exactly that.
+ * TYPE-generic through the macro below: _f32 works in float, _f64 in double.
+ */
+#define DEFINE_AFFINE(SUFFIX, T, FMA, LOG)                                                              \
+  static void chain_##SUFFIX(const T *w, int64_t sj, int64_t si, const T *x, int64_t dout, int64_t din, \
+                             T *acc) {                                                                  \
+    for (int64_t j = 0; j < dout; ++j)                                                                  \
+      for (int64_t i = 0; i < din; ++i) acc[j] = FMA(w[j * sj + i * si], x[i], acc[j]);                 \
+  }                                                                                                     \
+  /* K8: out = base + (off + W1 x1 + W2 x2); x2 / w2, off and base optional */                          \
+  void smc_oracle_particle_affine_##SUFFIX(const T *x1, const T *w1, int64_t w1_sj, int64_t w1_si,      \
+                                           int64_t d1, const T *x2, const T *w2, int64_t w2_sj,         \
+                                           int64_t w2_si, int64_t d2, const T *off, int64_t off_sb,     \
+                                           const T *base, T *out, int64_t B, int64_t K, int64_t dout) { \
+    T acc[64];                                                                                          \
+    for (int64_t b = 0; b < B; ++b)                                                                     \
+      for (int64_t k = 0; k < K; ++k) {                                                                 \
+        const int64_t n = b * K + k;                                                                    \
+        for (int64_t j = 0; j < dout; ++j) acc[j] = off ? off[b * off_sb + j] : (T)0;                   \
+        chain_##SUFFIX(w1, w1_sj, w1_si, x1 + n * d1, dout, d1, acc);                                   \
+        if (x2) chain_##SUFFIX(w2, w2_sj, w2_si, x2 + n * d2, dout, d2, acc);                           \
+        for (int64_t j = 0; j < dout; ++j) out[n * dout + j] = base ? base[n * dout + j] + acc[j] : acc[j]; \
+      }                                                                                                 \
+  }                                                                                                     \
+  /* K9: x' = loc + eps * scale, product rounded before the sum (torch's rsample: loc + eps * scale) */ \
+  void smc_oracle_affine_rsample_##SUFFIX(const T *src, const T *w, int64_t sj, int64_t si,             \
+                                          const T *off, int64_t off_sb, const T *eps, T scale, T *out,  \
+                                          int64_t B, int64_t K, int64_t dout, int64_t din) {            \
+    T acc[64];                                                                                          \
+    for (int64_t b = 0; b < B; ++b)                                                                     \
+      for (int64_t k = 0; k < K; ++k) {                                                                 \
+        const int64_t n = b * K + k;                                                                    \
+        for (int64_t j = 0; j < dout; ++j) acc[j] = off ? off[b * off_sb + j] : (T)0;                   \
+        chain_##SUFFIX(w, sj, si, src + n * din, dout, din, acc);                                       \
+        for (int64_t j = 0; j < dout; ++j) {                                                            \
+          const T noise = eps[n * dout + j] * scale;                                                    \
+          out[n * dout + j] = acc[j] + noise;                                                           \
+        }                                                                                               \
+      }                                                                                                 \
+  }                                                                                                     \
+  /* K10: per term the squared distance as one fma chain from 0 (j ascending), then                       \
+   * log N = (-q) / (2 sigma^2) - d (log sigma + log sqrt(2 pi)) — torch.distributions.Normal.log_prob   \
+   * (-((v - mu)^2) / (2 sigma^2) - log sigma - log sqrt(2 pi)) summed over j with the common factor     \
+   * taken out; the terms combine as (p + g) - q: aesmc/inference.py:125-126 */                          \
+  static T term_sum_##SUFFIX(const T *v, const T *loc, T sigma, int64_t d) {                            \
+    const T two_var = (T)2 * (sigma * sigma);                                                           \
+    const T constant = (T)d * (LOG(sigma) + (T)0.9189385332046727);                                     \
+    T q = (T)0;                                                                                         \
+    for (int64_t j = 0; j < d; ++j) {                                                                   \
+      const T diff = v[j] - loc[j];                                                                     \
+      q = FMA(diff, diff, q);                                                                           \
+    }                                                                                                   \
+    return (-q) / two_var - constant;                                                                   \
+  }                                                                                                     \
+  void smc_oracle_affine_logweight_##SUFFIX(                                                            \
+      const T *xprev, const T *x, const T *y, int64_t y_sb, const T *wp, const T *offp, int64_t offp_sb, \
+      const T *wg, const T *offg, int64_t offg_sb, const T *wq, const T *offq, int64_t offq_sb, T sp,   \
+      T sg, T sq, T *lw, int64_t B, int64_t K, int64_t dx, int64_t dy) {                                \
+    T loc[64];                                                                                          \
+    for (int64_t b = 0; b < B; ++b)                                                                     \
+      for (int64_t k = 0; k < K; ++k) {                                                                 \
+        const int64_t n = b * K + k;                                                                    \
+        for (int64_t j = 0; j < dx; ++j) loc[j] = offp ? offp[b * offp_sb + j] : (T)0;                  \
+        chain_##SUFFIX(wp, dx, 1, xprev + n * dx, dx, dx, loc);                                         \
+        const T sum_p = term_sum_##SUFFIX(x + n * dx, loc, sp, dx);                                     \
+        for (int64_t j = 0; j < dx; ++j) loc[j] = offq ? offq[b * offq_sb + j] : (T)0;                  \
+        chain_##SUFFIX(wq, dx, 1, xprev + n * dx, dx, dx, loc);                                         \
+        const T sum_q = term_sum_##SUFFIX(x + n * dx, loc, sq, dx);                                     \
+        for (int64_t j = 0; j < dy; ++j) loc[j] = offg ? offg[b * offg_sb + j] : (T)0;                  \
+        chain_##SUFFIX(wg, dx, 1, x + n * dx, dy, dx, loc);                                             \
+        const T sum_g = term_sum_##SUFFIX(y + b * y_sb, loc, sg, dy);                                   \
+        lw[n] = (sum_p + sum_g) - sum_q;                                                                \
+      }                                                                                                 \
+  }
+
+DEFINE_AFFINE(f32, float, fmaf, logf)
+DEFINE_AFFINE(f64, double, fma, log)

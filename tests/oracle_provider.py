@@ -68,3 +68,88 @@ class OracleKernels:
         lse = self.logweight_lse(log_w, None, None, want_lw=False, want_lse=True)[1] if want_lse else None
         moved = self.gather(payload, idx) if payload is not None else None
         return idx, lse, moved
+
+    # ---- linear-Gaussian particle propagation (K8 / K9 / K10) on the C oracle ----------------------
+    affine_max_dim = 16
+
+    def affine_covers(self, source, weight, offset=None):
+        if not (torch.is_tensor(source) and torch.is_tensor(weight) and source.dim() == 3 and weight.dim() == 2):
+            return False
+        if source.dtype not in (torch.float32, torch.float64) or weight.dtype != source.dtype:
+            return False
+        dout, din = weight.shape
+        if din != source.size(2) or max(dout, din) > self.affine_max_dim or source.numel() == 0:
+            return False
+        return offset is None or tuple(offset.shape) in ((dout,), (source.size(0), dout))
+
+    def affine_logweight_covers(self, x_prev, x, y_rows, transition, emission, proposal, scales):
+        if x_prev.shape != x.shape or y_rows.dim() != 2:
+            return False
+        if not (self.affine_covers(x_prev, *transition) and self.affine_covers(x, *emission) and
+                self.affine_covers(x_prev, *proposal)):
+            return False
+        dx = x.size(2)
+        return transition[0].size(0) == dx and proposal[0].size(0) == dx and \
+            y_rows.shape == (x.size(0), emission[0].size(0)) and all(s.numel() == 1 for s in scales)
+
+    @staticmethod
+    def _n(t):
+        return None if t is None else t.detach().contiguous().numpy()
+
+    def particle_affine(self, x1, w1, offset=None, x2=None, w2=None, base=None):
+        from oracle import c_oracle
+        return torch.from_numpy(c_oracle.particle_affine(self._n(x1), self._n(w1), self._n(x2), self._n(w2),
+                                                         self._n(offset), self._n(base)))
+
+    def affine_rsample(self, source, weight, offset, eps, scale):
+        from oracle import c_oracle
+        return torch.from_numpy(c_oracle.affine_rsample(self._n(source), self._n(weight), self._n(offset),
+                                                        self._n(eps), float(scale)))
+
+    def affine_logweight(self, x_prev, x, y_rows, transition, emission, proposal, scales):
+        from oracle import c_oracle
+        pair = lambda term: (self._n(term[0]), self._n(term[1]))
+        return torch.from_numpy(c_oracle.affine_logweight(
+            self._n(x_prev), self._n(x), self._n(y_rows), pair(transition), pair(emission), pair(proposal),
+            float(scales[0]), float(scales[1]), float(scales[2])))
+
+    def particle_affine_backward(self, grad, x, weight, need_x=True, need_weight=True):
+        g2, x2 = grad.reshape(-1, grad.size(-1)).double(), x.reshape(-1, x.size(-1)).double()
+        gx = (grad.double() @ weight.double()).to(grad.dtype) if need_x else None
+        gw = (g2.t() @ x2).to(grad.dtype) if need_weight else None
+        return gx, gw
+
+    def affine_logweight_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need,
+                                  grad_lw=None, lw=None, lse=None, grad_lse=None):
+        """The adjoint by PyTorch's own autograd over the float64 expression the kernel evaluates."""
+        operands = [x_prev, x, y_rows, transition[0], transition[1], emission[0], emission[1], proposal[0],
+                    proposal[1]] + list(scales)
+        with torch.enable_grad():
+            return self._affine_logweight_backward(operands, need, grad_lw, lw, lse, grad_lse)
+
+    @staticmethod
+    def _affine_logweight_backward(operands, need, grad_lw, lw, lse, grad_lse):
+        leaves = [None if t is None else t.detach().double().requires_grad_(True) for t in operands]
+        xp, xx, yy, A, op, C, og, Q, oq, sp, sg, sq = leaves
+
+        def loc(source, weight, offset):
+            out = source @ weight.t()
+            if offset is not None:
+                out = out + (offset.unsqueeze(1) if offset.dim() == 2 else offset)
+            return out
+
+        normal = torch.distributions.Normal
+        value = (normal(loc(xp, A, op), sp).log_prob(xx).sum(-1) +
+                 normal(loc(xx, C, og), sg).log_prob(yy.unsqueeze(1)).sum(-1) -
+                 normal(loc(xp, Q, oq), sq).log_prob(xx).sum(-1))
+        g = torch.zeros_like(value)
+        if grad_lw is not None:
+            g = g + grad_lw.double()
+        if grad_lse is not None:
+            g = g + grad_lse.double().unsqueeze(1) * torch.exp(lw.double() - lse.double().unsqueeze(1))
+        wanted = [i for i, t in enumerate(leaves) if t is not None and need[i]]
+        grads = torch.autograd.grad(value, [leaves[i] for i in wanted], grad_outputs=g, allow_unused=True)
+        out = [None] * 12
+        for i, grad in zip(wanted, grads):
+            out[i] = None if grad is None else grad.to(operands[i].dtype)
+        return out

@@ -1,0 +1,256 @@
+"""GPU parity tests of the linear-Gaussian propagation kernels (K8 particle_affine, K9
+affine_normal_rsample, K10 affine_normal_logweight), through the C ABI:
+
+  * K8 and K9 against oracle/smc_core.c BIT FOR BIT (the location is one fma chain in a fixed order,
+    the draw a rounded product plus a sum: libm's fmaf / fma restate both exactly);
+  * K10 against the C oracle within the rounding of the device's logf (everything else in it is
+    exactly rounded IEEE arithmetic in a fixed order) and within float rounding of the unfused
+    route on the device (K8 x 3 + K5, which divides per element where K10 divides once per term);
+  * K9 bit for bit against K8 + K6.
+Shapes cover ragged tails (particles not a multiple of the 256- / 512-particle tile), one particle
+per row, every padded extent class (4, 8, 12, 16), unequal latent / observation extents, transposed
+weight views, per-row, shared and absent offsets.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(3, 700, 10, 10), (2, 513, 5, 3), (5, 64, 16, 16), (4, 1, 1, 1), (1, 1000, 3, 7), (7, 300, 12, 2),
+          (2, 2048, 8, 8), (300, 5, 4, 4), (1, 1, 2, 16)]
+
+
+@pytest.fixture(scope="module")
+def kernels(hip_device):
+    from aesmc_amd import _kernels
+    provider = _kernels.get()
+    assert provider.name == "hip"
+    return provider
+
+
+def operands(B, K, dx, dy, dtype, device, seed):
+    rng = np.random.RandomState(seed)
+    r = lambda *shape: rng.randn(*shape).astype(dtype)
+    host = {"x_prev": r(B, K, dx), "x": r(B, K, dx), "eps": r(B, K, dx), "y": r(B, dy),
+            "A": (0.9 * np.eye(dx) + 0.1 * rng.randn(dx, dx)).astype(dtype),
+            "Q": (0.45 * np.eye(dx) + 0.1 * rng.randn(dx, dx)).astype(dtype), "C": (0.3 * rng.randn(dy, dx)).astype(dtype),
+            "off_q": r(B, dx), "off_g": r(dy), "s_p": np.asarray(1.0, dtype), "s_g": np.asarray(0.5, dtype),
+            "s_q": np.asarray(0.7, dtype)}
+    return host, {key: torch.from_numpy(np.ascontiguousarray(value)).to(device) for key, value in host.items()}
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_particle_affine_equals_the_c_oracle_bit_for_bit(kernels, hip_device, dtype, shape):
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=B * K + dx)
+    loc = kernels.particle_affine(o["x_prev"], o["Q"], o["off_q"])
+    np.testing.assert_array_equal(loc.cpu().numpy(), c_oracle.particle_affine(n["x_prev"], n["Q"], offset=n["off_q"]))
+    shared = kernels.particle_affine(o["x"], o["C"], o["off_g"])          # [dy] offset shared by all rows
+    np.testing.assert_array_equal(shared.cpu().numpy(), c_oracle.particle_affine(n["x"], n["C"], offset=n["off_g"]))
+    # two inputs through TRANSPOSED weight views on top of a base: the adjoint of the step's two maps
+    two = kernels.particle_affine(o["x_prev"], o["A"].t(), None, o["x"], o["Q"].t(), base=o["eps"])
+    want = c_oracle.particle_affine(n["x_prev"], n["A"].T.copy(), x2=n["x"], w2=n["Q"].T.copy(), base=n["eps"])
+    np.testing.assert_array_equal(two.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_affine_rsample_equals_the_c_oracle_and_the_unfused_route(kernels, hip_device, dtype, shape):
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=B + K + dx)
+    draw = kernels.affine_rsample(o["x_prev"], o["Q"], o["off_q"], o["eps"], o["s_q"])
+    want = c_oracle.affine_rsample(n["x_prev"], n["Q"], n["off_q"], n["eps"], float(n["s_q"]))
+    np.testing.assert_array_equal(draw.cpu().numpy(), want)
+    loc = kernels.particle_affine(o["x_prev"], o["Q"], o["off_q"])
+    assert torch.equal(draw, kernels.normal_rsample(o["eps"], loc, o["s_q"].expand_as(loc)))
+    bare = kernels.affine_rsample(o["x_prev"], o["Q"], None, o["eps"], o["s_q"])
+    np.testing.assert_array_equal(bare.cpu().numpy(),
+                                  c_oracle.affine_rsample(n["x_prev"], n["Q"], None, n["eps"], float(n["s_q"])))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_affine_logweight_matches_the_c_oracle_and_equals_the_unfused_route(kernels, hip_device, dtype, shape):
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=B * dx + K)
+    terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    lw = kernels.affine_logweight(o["x_prev"], o["x"], o["y"], *terms, scales)
+    want = c_oracle.affine_logweight(n["x_prev"], n["x"], n["y"], (n["A"], None), (n["C"], n["off_g"]),
+                                     (n["Q"], n["off_q"]), float(n["s_p"]), float(n["s_g"]), float(n["s_q"]))
+    rtol = 5e-7 if dtype == np.float32 else 1e-15   # the device's log(sigma) against glibc's, times d
+    np.testing.assert_allclose(lw.cpu().numpy(), want, rtol=rtol, atol=rtol * max(1.0, float(np.abs(want).max())))
+    loc_p = kernels.particle_affine(o["x_prev"], o["A"])
+    loc_g = kernels.particle_affine(o["x"], o["C"], o["off_g"])
+    loc_q = kernels.particle_affine(o["x_prev"], o["Q"], o["off_q"])
+    y_expanded = o["y"].unsqueeze(1).expand(B, K, dy)
+    route = kernels.normal_logweight(o["x"], loc_p, o["s_p"].expand_as(loc_p), y_expanded, loc_g,
+                                     o["s_g"].expand_as(loc_g), loc_q, o["s_q"].expand_as(loc_q))
+    assert route is not None
+    rtol = 2e-6 if dtype == np.float32 else 1e-14
+    scale = max(1.0, float(route.abs().max()))
+    assert float((lw - route).abs().max()) <= rtol * scale
+
+
+def test_full_size_affine_kernels_agree_with_library_matmul(kernels, hip_device):
+    """BASELINE configs[3]'s shape (B=1024, K=4096, d=10): the fused kernels against the float64
+    library route (size-independent property: a location is linear in its inputs)."""
+    B, K, d = 1024, 4096, 10
+    gen = torch.Generator(device=hip_device).manual_seed(3)
+    x_prev = torch.randn(B, K, d, device=hip_device, generator=gen)
+    eps = torch.randn(B, K, d, device=hip_device, generator=gen)
+    Q = 0.45 * torch.eye(d, device=hip_device) + 0.05 * torch.randn(d, d, device=hip_device, generator=gen)
+    off = torch.randn(B, d, device=hip_device, generator=gen)
+    scale = torch.tensor(0.7, device=hip_device)
+    draw = kernels.affine_rsample(x_prev, Q, off, eps, scale)
+    want = (x_prev.double() @ Q.double().t() + off.double().unsqueeze(1)) + eps.double() * 0.7
+    assert float((draw.double() - want).abs().max()) < 5e-6
+    loc = kernels.particle_affine(x_prev, Q, off)
+    assert torch.equal(draw, kernels.normal_rsample(eps, loc, scale.expand_as(loc)))
+    doubled = kernels.particle_affine(2 * x_prev, Q, 2 * off)     # exact: scaling by two commutes with rounding
+    assert torch.equal(doubled, 2 * loc)
+
+
+# ---- end to end: a model whose callables return AffineNormal against the CPU port of the reference ----
+from aesmc_amd import inference, losses  # noqa: E402
+from aesmc_amd.testing import models, replay  # noqa: E402
+
+
+def _parts(model):
+    return model.initial, model.transition, model.emission, model.proposal
+
+
+@pytest.mark.parametrize("B,K,T,d", [(3, 300, 4, 5), (2, 1024, 6, 10), (5, 64, 3, 16), (4, 17, 5, 1), (2, 600, 3, 3)])
+def test_affine_callables_match_the_cpu_port_draw_for_draw(hip_device, B, K, T, d):
+    """The CPU port of the reference runs the LGSSM with PLAIN Normal(matmul) callables and records its
+    draws; the product replays them on a model whose callables return AffineNormal (kernels K9 / K10,
+    K8 at time 0).  float64: ancestor indices exact, per-step log-weights and log Z to 1e-10."""
+    from oracle import reference_port
+    dtype = torch.float64
+    cpu_model = models.LgssmNd(d, seed=0, dtype=dtype, state=reference_port).tune_proposal()
+    observations = cpu_model.simulate(T, B, seed=1)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    flags = dict(return_log_marginal_likelihood=True, return_log_weights=True, return_ancestral_indices=True,
+                 return_original_latents=True)
+    with replay.record() as tape:
+        want = reference_port.infer("smc", observations, *_parts(cpu_model), K, **flags)
+    model = models.LgssmNd(d, seed=0, dtype=dtype, affine=True).to(hip_device).tune_proposal()
+    launches = _count_affine_launches()
+    with replay.replay(tape), launches:
+        got = inference.infer("smc", [o.to(hip_device) for o in observations], *_parts(model), K, **flags)
+    assert launches.count["affine_rsample"] == T - 1 and launches.count["affine_logweight"] == T - 1
+    for a, b in zip(got["ancestral_indices"], want["ancestral_indices"]):
+        assert torch.equal(a.cpu(), b)
+    for a, b in zip(got["log_weights"], want["log_weights"]):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-10, atol=1e-10)
+    for a, b in zip(got["latents"], want["latents"]):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(got["log_marginal_likelihood"].cpu(), want["log_marginal_likelihood"],
+                               rtol=1e-10, atol=1e-10)
+
+
+class _count_affine_launches:
+    """Counts the provider's K9 / K10 launches inside the context (the fused route must be the one taken)."""
+
+    def __init__(self):
+        self.count = {"affine_rsample": 0, "affine_logweight": 0}
+
+    def __enter__(self):
+        from aesmc_amd import _kernels
+        self.provider = _kernels.get()
+        self.saved = {name: getattr(self.provider, name) for name in self.count}
+        for name in self.count:
+            def spy(*args, _name=name, **kwargs):
+                self.count[_name] += 1
+                return self.saved[_name](*args, **kwargs)
+            setattr(self.provider, name, spy)
+        return self
+
+    def __exit__(self, *exc):
+        for name in self.count:
+            delattr(self.provider, name)
+        return False
+
+
+@pytest.mark.parametrize("algorithm,B,K,T,d", [("aesmc", 3, 300, 4, 5), ("aesmc", 2, 512, 5, 10), ("iwae", 3, 64, 3, 4)])
+def test_affine_callables_loss_and_gradients_match_the_cpu_port(hip_device, algorithm, B, K, T, d):
+    """get_loss + backward: the CPU port (plain callables, PyTorch autograd on the host) records its
+    draws, the GPU replays them through AffineNormal callables.  float64: loss to 1e-10, every
+    parameter gradient to 1e-8 of its largest entry."""
+    from oracle import reference_port
+    dtype = torch.float64
+    cpu_model = models.LgssmNd(d, seed=0, dtype=dtype, state=reference_port).tune_proposal()
+    observations = cpu_model.simulate(T, B, seed=1)
+    np.random.seed(11)
+    torch.manual_seed(11)
+    with replay.record() as tape:
+        want = reference_port.get_loss(observations, K, algorithm, *_parts(cpu_model))
+    want.backward()
+    model = models.LgssmNd(d, seed=0, dtype=dtype, affine=True).to(hip_device).tune_proposal()
+    with replay.replay(tape):
+        got = losses.get_loss([o.to(hip_device) for o in observations], K, algorithm, *_parts(model))
+    got.backward()
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-10, atol=1e-10)
+    expected = dict(cpu_model.named_parameters())
+    for name, parameter in model.named_parameters():
+        reference = expected[name].grad
+        if reference is None:
+            assert parameter.grad is None or float(parameter.grad.abs().max()) == 0.0, name
+            continue
+        assert parameter.grad is not None, name
+        scale = max(float(reference.abs().max()), 1e-30)
+        assert float((parameter.grad.cpu() - reference).abs().max()) <= 1e-8 * scale, name
+
+
+def test_affine_normal_is_the_normal_it_stands_for(hip_device):
+    """loc / scale / log_prob / rsample / expand of an AffineNormal equal those of
+    Normal(source @ weight.T + offset, scale) built from the materialised location."""
+    from aesmc_amd.linear_gaussian import AffineNormal
+    gen = torch.Generator(device=hip_device).manual_seed(5)
+    source = torch.randn(4, 33, 6, device=hip_device, dtype=torch.float64, generator=gen)
+    weight = torch.randn(5, 6, device=hip_device, dtype=torch.float64, generator=gen)
+    offset = torch.randn(4, 5, device=hip_device, dtype=torch.float64, generator=gen)
+    scale = torch.tensor(0.3, device=hip_device, dtype=torch.float64)
+    dist = AffineNormal(source, weight, scale, offset=offset)
+    plain = torch.distributions.Normal(source @ weight.t() + offset.unsqueeze(1), scale)
+    assert dist.batch_shape == plain.batch_shape and dist.event_shape == plain.event_shape
+    torch.testing.assert_close(dist.loc, plain.loc, rtol=1e-13, atol=1e-13)
+    torch.testing.assert_close(dist.mean, plain.mean, rtol=1e-13, atol=1e-13)
+    assert torch.equal(dist.scale, plain.scale.expand(plain.batch_shape))
+    value = torch.randn(4, 33, 5, device=hip_device, dtype=torch.float64, generator=gen)
+    torch.testing.assert_close(dist.log_prob(value), plain.log_prob(value), rtol=1e-12, atol=1e-12)
+    torch.manual_seed(3)
+    a = dist.rsample()
+    torch.manual_seed(3)
+    b = plain.rsample()
+    torch.testing.assert_close(a, b, rtol=1e-13, atol=1e-13)
+    assert dist.expand((2, 4, 33, 5)).batch_shape == (2, 4, 33, 5)
+    wide = AffineNormal(torch.randn(2, 8, 40, device=hip_device), torch.randn(24, 40, device=hip_device), 1.0)
+    assert wide.loc.shape == (2, 8, 24)     # beyond 16 x 16: the library's matmul
+
+
+def test_affine_callables_float32_agree_with_matmul_callables(hip_device):
+    """float32 at a configs[1]-like shape: the two ways of stating the model give the same ELBO to
+    float32 accuracy and ancestor indices that differ only where a CDF comparison sits within
+    rounding noise of flipping (the locations differ in their last bits: fma chain against the
+    library's matmul)."""
+    B, K, T, d = 16, 1024, 12, 10
+    results = {}
+    for affine in (False, True):
+        model = models.LgssmNd(d, seed=0, affine=affine).to(hip_device).tune_proposal()
+        observations = [o.to(hip_device) for o in model.simulate(T, B, seed=1)]
+        np.random.seed(2)
+        torch.manual_seed(2)
+        results[affine] = inference.infer("smc", observations, *_parts(model), K, return_log_marginal_likelihood=True,
+                                          return_ancestral_indices=True, return_latents=False)
+    a, b = results[False], results[True]
+    first = a["ancestral_indices"][0], b["ancestral_indices"][0]
+    agree = float((first[0] == first[1]).double().mean())
+    assert agree > 0.995 and int((first[0] - first[1]).abs().max()) <= 1
+    za, zb = a["log_marginal_likelihood"], b["log_marginal_likelihood"]
+    assert float(((za - zb).abs() / za.abs()).max().detach()) < 5e-3     # a flipped index moves a row's later weights

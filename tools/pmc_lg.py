@@ -1,0 +1,25 @@
+"""Workload for hardware-counter passes over the linear-Gaussian propagation kernels (rocprofv3 --pmc,
+one counter set per run): K8, K9, K10 (and their backward kernels when built) at B=1024 K=4096 d=10,
+3 launches each."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from aesmc_amd import _kernels
+from lgbench import operands
+
+k = _kernels.get()
+dev = torch.device("cuda", 0)
+shape = tuple(int(v) for v in os.environ.get("LG_SHAPE", "1024,4096,10,10").split(","))
+o = operands(*shape, torch.float32, dev)
+for _ in range(3):
+    k.particle_affine(o["x_prev"], o["Q"], o["off_q"])
+    k.affine_rsample(o["x_prev"], o["Q"], o["off_q"], o["eps"], o["s_q"])
+    k.affine_logweight(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
+                       (o["s_p"], o["s_g"], o["s_q"]))
+    if hasattr(k, "pmc_extra"):
+        k.pmc_extra(o)
+torch.cuda.synchronize()
+print("done")
