@@ -839,19 +839,38 @@ class HipKernels:
         return out
 
     def particle_affine_backward(self, grad, x, weight, need_x=True, need_weight=True):
-        """Adjoint of `offset + x @ weight.T` for grad [B,K,dout]: (grad_x = grad @ weight through K8 on the
-        transposed weight view, grad_weight [dout,din] = sum over particles of grad (outer) x through
-        the outer-sum kernel); entries not asked for are None."""
-        grad = self._dense16(grad)
-        gx = self.particle_affine(grad, weight.t()) if need_x else None
-        gw = self.outer_sum(grad, x) if need_weight else None
+        """K11, the adjoint of `offset + x @ weight.T` for grad [B,K,dout]: (grad_x = grad @ weight,
+        grad_weight [dout,din] = sum over particles of grad (outer) x — on the matrix cores, summed in a
+        fixed order); entries not asked for are None."""
+        if not (need_x or need_weight):
+            return None, None
+        if not self.affine_covers(x, weight) or grad.shape != x.shape[:2] + (weight.size(0),) or \
+                grad.dtype != x.dtype or grad.device != x.device:
+            raise ValueError("aesmc_amd: particle_affine_backward operands outside what kernel K11 covers")
+        tag = _DTYPE_TAG[x.dtype]
+        B, K, din = x.shape
+        dout = weight.size(0)
+        grad, x = self._dense16(grad), self._dense16(x)
+        gx = torch.empty_like(x) if need_x else None
+        gw = torch.empty((dout, din), dtype=x.dtype, device=x.device) if need_weight else None
+        ws_bytes = int(self._lib.aesmc_affine_backward_workspace_bytes(tag)) if need_weight else 0
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+        amap, keep = self._affine_map(weight, None)
+        with _on_device(x.device):
+            args = (tag, _ptr(grad), _ptr(x), ctypes.byref(amap), _ptr(gx), _ptr(gw), _ptr(ws), ws_bytes, B, K,
+                    self._stream(x))
+            _lib.check(self._lib.aesmc_particle_affine_backward(*args), "aesmc_particle_affine_backward")
+            if self.timer is not None:
+                nbytes = x.element_size() * B * K * (dout + (din if need_weight else 0) + (din if need_x else 0))
+                self.timer.note("particle_affine_backward", (self._lib.aesmc_particle_affine_backward, args), nbytes,
+                                (grad, x, gx, gw, ws, amap, keep))
         return gx, gw
 
     def outer_sum(self, g, x):
         """sum over all particles of g[b,k,:] (outer) x[b,k,:] -> [dout, din]: the weight gradient of an
-        affine location."""
-        g2, x2 = g.reshape(-1, g.size(-1)), x.reshape(-1, x.size(-1))
-        return torch.matmul(g2.t(), x2)
+        affine location (K11 without the input gradient).  The weight's values are not read."""
+        placeholder = torch.empty((g.size(2), x.size(2)), dtype=x.dtype, device=x.device)
+        return self.particle_affine_backward(g, x, placeholder, need_x=False, need_weight=True)[1]
 
     def affine_logweight_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need,
                                   grad_lw=None, lw=None, lse=None, grad_lse=None):

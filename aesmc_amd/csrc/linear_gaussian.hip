@@ -365,6 +365,132 @@ __global__ __launch_bounds__(kLgBlock) void affine_logweight_kernel(
   }
 }
 
+// ---- K11: the adjoint of an affine location ----------------------------------------------------------
+// The weight gradient  dW[j][i] = sum over particles of g[p][j] x[p][i]  is a contraction over the
+// particle index: it runs on the matrix cores (v_mfma_*_16x16x4: A = 4 particles x 16 values of g,
+// B = 4 particles x 16 values of x, f32 / f64 inputs and accumulation — exact IEEE fma chains), which
+// keeps the 16 x 16 accumulator in four registers per lane instead of d^2 per particle-owning lane.
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+  typedef float Acc __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ Acc fma(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+template <> struct Mfma<double> {
+  typedef double Acc __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ Acc fma(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+
+constexpr int kLgRecord = 256;        // one 16 x 16 partial per matrix and workgroup
+constexpr int kLgMaxGrid = 512;       // persistent workgroups of the reducing kernels (two per CU)
+
+// acc[j][i] += sum_{p < np} tg[p][j] * tx[p][i] over a staged tile; the four wavefronts take particles
+// 4 w .. 4 w + 3 of every group of 16 (fixed assignment: the sums are reproducible).
+template <typename T>
+__device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, uint32_t dg, const T *__restrict__ tx,
+                                                    uint32_t dxx, uint32_t np, typename Mfma<T>::Acc &acc) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t col = lane & 15u, quad = lane >> 4;
+  for (uint32_t p0 = wave * 4; p0 < np; p0 += 16) {
+    const uint32_t p = p0 + quad;
+    const bool live = p < np;
+    const T a = (live && col < dg) ? tg[lg_pad(p * dg + col)] : T(0);
+    const T b = (live && col < dxx) ? tx[lg_pad(p * dxx + col)] : T(0);
+    acc = Mfma<T>::fma(a, b, acc);
+  }
+}
+
+// The workgroup's four partial accumulators summed (wavefront 0 .. 3 in turn) into record[0 .. 255],
+// element j * 16 + i.  `scratch` holds 4 x 256 values.
+template <typename T>
+__device__ __forceinline__ void lg_outer_publish(const typename Mfma<T>::Acc &acc, T *__restrict__ scratch,
+                                                 T *__restrict__ record) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) scratch[wave * 256 + Mfma<T>::row(lane, r) * 16 + (lane & 15)] = acc[r];
+  __syncthreads();
+  const int e = threadIdx.x;
+  record[e] = ((scratch[e] + scratch[256 + e]) + scratch[512 + e]) + scratch[768 + e];
+  __syncthreads();
+}
+
+template <typename T, int DP, int PPL>
+__global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(const T *__restrict__ g,
+                                                                             const T *__restrict__ x, LgMap adjoint,
+                                                                             T *__restrict__ gx, T *__restrict__ ws,
+                                                                             int64_t N, int want_w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  const uint32_t dg = adjoint.din, dxx = adjoint.dout;     // g has the location's extent, x (and gx) the input's
+  T *wt = reinterpret_cast<T *>(lg_smem);
+  T *scratch = wt + DP * DP;                               // 4 x 256
+  T *tg = scratch + 4 * 256;
+  T *tx = tg + (TP * dg + ((TP * dg) >> 5) + 1);
+  typename Mfma<T>::Acc acc = {T(0), T(0), T(0), T(0)};
+  if (gx != nullptr) lg_stage_weight<T, DP>(adjoint, wt);
+  const int64_t tiles = (N + TP - 1) / TP;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_stage_rows(g + n0 * dg, np * dg, tg, 1);
+    if (want_w) lg_stage_rows(x + n0 * dxx, np * dxx, tx, 0);
+    __syncthreads();
+    T out[DP][PPL];
+    uint32_t p[PPL], at[PPL];
+    bool live[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const uint32_t q = threadIdx.x + r * kLgBlock;
+      live[r] = q < np;
+      p[r] = live[r] ? q : 0u;
+      at[r] = p[r] * dg;
+    }
+    if (gx != nullptr) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) out[j][r] = T(0);
+      lg_apply_tile<T, DP, PPL>(wt, tg, at, (int)dg, out);
+    }
+    if (want_w) lg_outer_accumulate<T>(tg, dg, tx, dxx, np, acc);
+    if (gx != nullptr) {
+      __syncthreads();                                     // every wavefront is done reading tx
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        if ((uint32_t)j < dxx) {
+#pragma unroll
+          for (int r = 0; r < PPL; ++r)
+            if (live[r]) tx[lg_pad(p[r] * dxx + j)] = out[j][r];
+        }
+      }
+      __syncthreads();
+      lg_store_rows(gx + n0 * dxx, np * dxx, tx);
+    }
+    __syncthreads();
+  }
+  if (want_w) lg_outer_publish<T>(acc, scratch, ws + (int64_t)blockIdx.x * kLgRecord);
+}
+
+// Sums the workgroups' records in workgroup order: out[m][j * din + i] = sum_b ws[b][m][j * 16 + i].
+struct LgFinish {
+  void *out[4];
+  int32_t rows[4], cols[4];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void lg_finish_kernel(const T *__restrict__ ws, int nblocks, int record, LgFinish f) {
+  const int m = blockIdx.x, e = threadIdx.x;
+  T sum = T(0);
+  for (int b = 0; b < nblocks; ++b) sum += ws[(int64_t)b * record + m * 256 + e];
+  const int j = e >> 4, i = e & 15;
+  T *out = reinterpret_cast<T *>(f.out[m]);
+  if (out != nullptr && j < f.rows[m] && i < f.cols[m]) out[j * f.cols[m] + i] = sum;
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 static inline bool lg_map_ok(const aesmc_affine_map *m) {
   return m != nullptr && m->weight != nullptr && m->dout >= 1 && m->din >= 1 && m->dout <= kLgMaxDim &&
@@ -485,9 +611,72 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
+template <typename T>
+static int launch_particle_affine_backward(const void *g, const void *x, const aesmc_affine_map *m, void *gx, void *gw,
+                                           void *ws, size_t ws_bytes, int64_t B, int64_t K, hipStream_t stream) {
+  const int64_t N = B * K;
+  const int64_t dout = m->dout, din = m->din;
+  const int dp = lg_pad_dim(std::max(dout, din));
+  int ppl = sizeof(T) == 4 ? 2 : 1;
+  size_t lds = 0;
+  for (; ppl >= 1; --ppl) {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * ((size_t)dp * dp + 4 * 256 + lg_tile_elems(tp, dout) + lg_tile_elems(tp, din));
+    if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
+  }
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
+  const int grid = (int)std::min<int64_t>(tiles, kLgMaxGrid);
+  if (gw != nullptr && ws_bytes < (size_t)grid * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;
+  LgMap adjoint;           // gx = g W: the map from the location's extent back to the input's
+  adjoint.w = m->weight; adjoint.sj = m->stride_in; adjoint.si = m->stride_out;
+  adjoint.off = nullptr; adjoint.off_sb = 0; adjoint.dout = (int32_t)din; adjoint.din = (int32_t)dout;
+  LG_DISPATCH(particle_affine_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream,
+              static_cast<const T *>(g), static_cast<const T *>(x), adjoint, static_cast<T *>(gx),
+              static_cast<T *>(ws), N, gw != nullptr ? 1 : 0);
+  if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  if (gw != nullptr) {
+    LgFinish f = {};
+    f.out[0] = gw; f.rows[0] = (int32_t)dout; f.cols[0] = (int32_t)din;
+    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(1), dim3(256), 0, stream, static_cast<const T *>(ws), grid,
+                       kLgRecord, f);
+    if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  }
+  return AESMC_OK;
+}
+
 }  // namespace aesmc
 
 using namespace aesmc;
+
+extern "C" size_t aesmc_affine_backward_workspace_bytes(int dtype) {
+  return (size_t)kLgMaxGrid * 4 * kLgRecord * (dtype == AESMC_F64 ? 8 : 4);
+}
+
+extern "C" int aesmc_particle_affine_backward(int dtype, const void *grad, const void *x, const aesmc_affine_map *map,
+                                              void *out_grad_x, void *out_grad_weight, void *ws, size_t ws_bytes,
+                                              int64_t B, int64_t K, void *stream) {
+  if (grad == nullptr || map == nullptr || map->weight == nullptr || B < 0 || K < 0 ||
+      (out_grad_weight != nullptr && (x == nullptr || ws == nullptr)))
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!aligned16(grad) || (x != nullptr && !aligned16(x)) || (out_grad_x != nullptr && !aligned16(out_grad_x)) ||
+      (ws != nullptr && !aligned16(ws)))
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(map)) return AESMC_ERR_UNSUPPORTED;
+  if (out_grad_x == nullptr && out_grad_weight == nullptr) return AESMC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0 || K == 0) {   // an empty sum: the weight gradient is zero
+    if (out_grad_weight != nullptr &&
+        !zero_fill_async(out_grad_weight, (size_t)(map->dout * map->din) * (dtype == AESMC_F64 ? 8 : 4), s))
+      return AESMC_ERR_LAUNCH;
+    return AESMC_OK;
+  }
+  return dtype == AESMC_F32
+             ? launch_particle_affine_backward<float>(grad, x, map, out_grad_x, out_grad_weight, ws, ws_bytes, B, K, s)
+             : launch_particle_affine_backward<double>(grad, x, map, out_grad_x, out_grad_weight, ws, ws_bytes, B, K, s);
+}
+
 
 extern "C" int64_t aesmc_affine_max_dim(void) { return kLgMaxDim; }
 

@@ -321,6 +321,20 @@ int aesmc_affine_normal_logweight(int dtype, const void *x_prev, const void *x, 
                                   const void *scale_p, const void *scale_g, const void *scale_q, void *out_lw,
                                   int64_t B, int64_t K, void *stream);
 
+/* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
+ *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])
+ *   out_grad_weight[j,i]   = sum_{b,k} grad[b,k,j] x[b,k,i]                 (dense [dout,din])
+ * either output may be NULL.  The weight gradient is a contraction over the particle index and runs
+ * on the matrix cores (f32 / f64 MFMA: exact fused multiply-adds), each workgroup leaving one 16 x 16
+ * partial in `ws` (aesmc_affine_backward_workspace_bytes(dtype) bytes, 16-byte aligned), summed in
+ * workgroup order by a second launch: reproducible run to run.  Replaces the input- and
+ * weight-gradient matmuls ([B*K,dout] x [dout,din] and [dout,B*K] x [B*K,din]) of the callables'
+ * autograd.  The offset's gradient is a plain sum of grad over particles, left to the caller. */
+size_t aesmc_affine_backward_workspace_bytes(int dtype);
+int aesmc_particle_affine_backward(int dtype, const void *grad, const void *x, const aesmc_affine_map *map,
+                                   void *out_grad_x, void *out_grad_weight, void *ws, size_t ws_bytes, int64_t B,
+                                   int64_t K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,3 +254,40 @@ def test_affine_callables_float32_agree_with_matmul_callables(hip_device):
     assert agree > 0.995 and int((first[0] - first[1]).abs().max()) <= 1
     za, zb = a["log_marginal_likelihood"], b["log_marginal_likelihood"]
     assert float(((za - zb).abs() / za.abs()).max().detach()) < 5e-3     # a flipped index moves a row's later weights
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", SHAPES + [(64, 4096, 10, 10)])
+def test_particle_affine_backward_matches_float64_matmuls(kernels, hip_device, dtype, shape):
+    """K11: grad_x = grad @ W is the K8 chain on the transposed weight (bit for bit the C oracle's);
+    grad_W = grad^T x summed over all particles on the matrix cores, against the float64 contraction
+    (float32: the fixed-order partial sums are within 1e-5 of the gradient's scale), and identical from
+    run to run."""
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=B + 3 * K)
+    grad = torch.from_numpy(np.random.RandomState(1).randn(B, K, dy).astype(dtype)).to(hip_device)
+    gx, gw = kernels.particle_affine_backward(grad, o["x"], o["C"])
+    want_gx = c_oracle.particle_affine(grad.cpu().numpy(), n["C"].T.copy())
+    np.testing.assert_array_equal(gx.cpu().numpy(), want_gx)
+    want_gw = grad.double().reshape(-1, dy).t() @ o["x"].double().reshape(-1, dx)
+    scale = max(1.0, float(want_gw.abs().max()))
+    tolerance = 1e-5 if dtype == np.float32 else 1e-13
+    assert float((gw.double() - want_gw).abs().max()) <= tolerance * scale
+    again = kernels.particle_affine_backward(grad, o["x"], o["C"], need_x=False)[1]
+    assert torch.equal(gw, again)
+    assert torch.equal(kernels.outer_sum(grad, o["x"]), gw)
+
+
+def test_particle_affine_operator_gradients(hip_device):
+    """autograd through aesmc_amd.linear_gaussian.particle_affine (K8 forward, K11 backward) against
+    PyTorch's own autograd over matmul, float64."""
+    from aesmc_amd.linear_gaussian import particle_affine
+    gen = torch.Generator(device=hip_device).manual_seed(9)
+    make = lambda *shape: torch.randn(*shape, device=hip_device, dtype=torch.float64, generator=gen).requires_grad_(True)
+    x, weight, offset = make(3, 257, 7), make(5, 7), make(3, 5)
+    out = particle_affine(x, weight, offset)
+    upstream = torch.randn(out.shape, device=hip_device, dtype=torch.float64, generator=gen)
+    got = torch.autograd.grad(out, (x, weight, offset), upstream)
+    ref = torch.autograd.grad(x @ weight.t() + offset.unsqueeze(1), (x, weight, offset), upstream)
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
