@@ -874,10 +874,77 @@ class HipKernels:
 
     def affine_logweight_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need,
                                   grad_lw=None, lw=None, lse=None, grad_lse=None):
-        """Gradients of `affine_logweight` with respect to its twelve operands, in the order
+        """K12: gradients of `affine_logweight` with respect to its twelve operands, in the order
         (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q); None where `need[i]` is false
         or the operand is absent.  The incoming gradient is `grad_lw` [B,K] and / or K1's softmax term
-        grad_lse[b] * exp(lw - lse[b]) formed in place (`lw`, `lse`, `grad_lse`)."""
+        grad_lse[b] * exp(lw - lse[b]) formed in place (`lw`, `lse`, `grad_lse`).  One pass over x_prev
+        and x; the weight gradients are summed on the matrix cores in a fixed order."""
+        if not self.affine_logweight_covers(x_prev, x, y_rows, transition, emission, proposal, scales):
+            raise ValueError("aesmc_amd: affine_logweight_backward operands outside what kernel K12 covers")
+        (A, off_p), (C, off_g), (Q, off_q) = transition, emission, proposal
+        tag = _DTYPE_TAG[x.dtype]
+        B, K, dx = x.shape
+        dy = y_rows.size(1)
+        fused_lse = grad_lse is not None
+        check = lambda t, shape, what: None if (t.shape == shape and t.dtype == x.dtype and t.device == x.device) \
+            else (_ for _ in ()).throw(ValueError("aesmc_amd: {} must be {} {} on {}".format(what, shape, x.dtype, x.device)))
+        if fused_lse:
+            lw, lse, grad_lse = lw.contiguous(), lse.contiguous(), grad_lse.contiguous()
+            check(lw, (B, K), "lw"), check(lse, (B,), "lse"), check(grad_lse, (B,), "grad_lse")
+        if grad_lw is not None:
+            grad_lw = grad_lw.contiguous()
+            check(grad_lw, (B, K), "grad_lw")
+        elif not fused_lse:
+            raise ValueError("aesmc_amd: affine_logweight_backward needs grad_lw or (lw, lse, grad_lse)")
+        x_prev, x = self._dense16(x_prev), self._dense16(x)
+        if y_rows.stride(1) != 1:
+            y_rows = y_rows.contiguous()
+        make = lambda shape, wanted: torch.empty(shape, dtype=x.dtype, device=x.device) if wanted else None
+        gx_prev, gx = make((B, K, dx), need[0]), make((B, K, dx), need[1])
+        u_p = make((B, K, dx), need[4] and off_p is not None)
+        u_g = make((B, K, dy), (need[6] and off_g is not None) or need[2])
+        u_q = make((B, K, dx), need[8] and off_q is not None)
+        gA, gC, gQ = make((dx, dx), need[3]), make((dy, dx), need[5]), make((dx, dx), need[7])
+        gscales = make((3,), need[9] or need[10] or need[11])
+        ws_bytes = int(self._lib.aesmc_affine_backward_workspace_bytes(tag))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        outs = _lib.AffineLogweightGrads(_ptr(gx_prev), _ptr(gx), _ptr(u_p), _ptr(u_g), _ptr(u_q), _ptr(gA), _ptr(gC),
+                                         _ptr(gQ), _ptr(gscales))
+        maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
+        with _on_device(x.device):
+            args = (tag, _ptr(x_prev), _ptr(x), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
+                    ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
+                    _ptr(scales[2]), _ptr(lw) if fused_lse else 0, _ptr(lse) if fused_lse else 0,
+                    _ptr(grad_lse) if fused_lse else 0, _ptr(grad_lw), ctypes.byref(outs), _ptr(ws), ws_bytes, B, K,
+                    self._stream(x))
+            _lib.check(self._lib.aesmc_affine_normal_logweight_backward(*args),
+                       "aesmc_affine_normal_logweight_backward")
+            if self.timer is not None:
+                dense = [t for t in (gx_prev, gx, u_p, u_g, u_q) if t is not None]
+                nbytes = x.element_size() * (B * K * (2 * dx + 1)) + sum(t.numel() * t.element_size() for t in dense)
+                self.timer.note("affine_normal_logweight_backward",
+                                (self._lib.aesmc_affine_normal_logweight_backward, args), nbytes,
+                                (x_prev, x, y_rows, lw, lse, grad_lse, grad_lw, outs, ws, maps, scales, gA, gC, gQ,
+                                 gscales) + tuple(dense))
+        fold = lambda u, off: u.sum(dim=1) if off.dim() == 2 else u.sum(dim=(0, 1))
+        grads = [gx_prev, gx, None, gA, None, gC, None, gQ, None, None, None, None]
+        if need[2]:
+            grads[2] = -u_g.sum(dim=1)
+        if u_p is not None:
+            grads[4] = fold(u_p, off_p)
+        if need[6] and off_g is not None:
+            grads[6] = fold(u_g, off_g)
+        if u_q is not None:
+            grads[8] = fold(u_q, off_q)
+        for slot, s in ((9, scales[0]), (10, scales[1]), (11, scales[2])):
+            if need[slot]:
+                grads[slot] = gscales[slot - 9].reshape(s.shape)
+        return grads
+
+    def affine_logweight_backward_unfused(self, x_prev, x, y_rows, transition, emission, proposal, scales, need,
+                                          grad_lw=None, lw=None, lse=None, grad_lse=None):
+        """The same gradients by the route K12 replaces — K8 x 3 to materialise the locations, K5's
+        backward, K8 on the transposed weights, K11's outer sums — kept as the cross-check of K12."""
         (A, off_p), (C, off_g), (Q, off_q) = transition, emission, proposal
         s_p, s_g, s_q = scales
         B, K, dx = x.shape

@@ -476,6 +476,217 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
   if (want_w) lg_outer_publish<T>(acc, scratch, ws + (int64_t)blockIdx.x * kLgRecord);
 }
 
+// ---- K12: backward of K10 in one pass ----------------------------------------------------------------
+// With g = the incoming gradient of lw[b,k] (grad_lw, and / or K1's softmax term grad_lse[b] exp(lw - lse[b])
+// formed here), diff_* = value - location and u_p = g diff_p / s_p^2, u_q = -g diff_q / s_q^2,
+// u_g = g diff_g / s_g^2 (the gradients with respect to the three locations):
+//   grad_x      = -u_p - u_q + C^T u_g          grad_x_prev = A^T u_p + Q^T u_q
+//   dA = sum u_p (x) x_prev    dQ = sum u_q (x) x_prev    dC = sum u_g (x) x        (matrix cores, as K11)
+//   ds_p = sum g (|diff_p|^2 / s_p^3 - dx / s_p),  ds_g likewise,  ds_q with the opposite sign
+// x_prev and x are read once, the two latent gradients written once; u_* reach HBM only when an
+// offset's gradient is wanted (the caller sums them over particles).
+template <typename T, int DP, int PPL>
+__device__ __forceinline__ void lg_apply_regs(const T *__restrict__ wt, const T (&in)[DP][PPL], int din,
+                                              T (&acc)[DP][PPL]) {
+#pragma unroll
+  for (int i = 0; i < DP; ++i) {
+    if (i < din) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T w = wt[i * DP + j];
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) acc[j][r] = fma_t(w, in[i][r], acc[j][r]);
+      }
+    }
+  }
+}
+
+template <typename T, int DP, int PPL>
+__device__ __forceinline__ void lg_rows_to_tile(const T (&v)[DP][PPL], uint32_t d, const uint32_t (&p)[PPL],
+                                                const bool (&live)[PPL], T *__restrict__ tile) {
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    if ((uint32_t)j < d) {
+#pragma unroll
+      for (int r = 0; r < PPL; ++r)
+        if (live[r]) tile[lg_pad(p[r] * d + j)] = v[j][r];
+    }
+  }
+}
+
+struct LgBackwardOut {
+  void *gxprev, *gx, *up, *ug, *uq, *ws;
+};
+
+template <typename T, int DP, int PPL>
+__global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
+    const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
+    LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
+    const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse,
+    const T *__restrict__ grad_lw, LgBackwardOut out, int64_t N, uint32_t K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  const uint32_t dx = mp.dout, dy = mg.dout;
+  T *wf = reinterpret_cast<T *>(lg_smem);        // [3][DP*DP] input-major: locations
+  T *wn = wf + 3 * DP * DP;                      // [3][DP*DP] output-major: adjoints
+  T *scratch = wn + 3 * DP * DP;                 // 4 x 256
+  T *tprev = scratch + 4 * 256;
+  T *tx = tprev + (TP * dx + ((TP * dx) >> 5) + 1);
+  const uint32_t dmax = dx > dy ? dx : dy;
+  T *tu = tx + (TP * dx + ((TP * dx) >> 5) + 1);  // [TP * max(dx, dy)]
+  (void)dmax;
+  {
+    lg_stage_weight<T, DP>(mp, wf);
+    lg_stage_weight<T, DP>(mg, wf + DP * DP);
+    lg_stage_weight<T, DP>(mq, wf + 2 * DP * DP);
+    LgMap t = mp;
+    t.sj = mp.si; t.si = mp.sj; t.dout = mp.din; t.din = mp.dout;
+    lg_stage_weight<T, DP>(t, wn);
+    t = mg; t.sj = mg.si; t.si = mg.sj; t.dout = mg.din; t.din = mg.dout;
+    lg_stage_weight<T, DP>(t, wn + DP * DP);
+    t = mq; t.sj = mq.si; t.si = mq.sj; t.dout = mq.din; t.din = mq.dout;
+    lg_stage_weight<T, DP>(t, wn + 2 * DP * DP);
+  }
+  const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
+  const T inv_var_p = T(1) / (s_p * s_p), inv_var_g = T(1) / (s_g * s_g), inv_var_q = T(1) / (s_q * s_q);
+  const T inv_s_p = T(1) / s_p, inv_s_g = T(1) / s_g, inv_s_q = T(1) / s_q;
+  typename Mfma<T>::Acc acc_a = {T(0), T(0), T(0), T(0)}, acc_c = acc_a, acc_q = acc_a;
+  T scale_acc[3] = {T(0), T(0), T(0)};
+  T *gxprev = reinterpret_cast<T *>(out.gxprev), *gx = reinterpret_cast<T *>(out.gx);
+  T *up_out = reinterpret_cast<T *>(out.up), *ug_out = reinterpret_cast<T *>(out.ug),
+    *uq_out = reinterpret_cast<T *>(out.uq);
+  const int64_t tiles = (N + TP - 1) / TP;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_stage_rows(xprev + n0 * dx, np * dx, tprev, 0);
+    lg_stage_rows(x + n0 * dx, np * dx, tx, 0);
+    uint32_t p[PPL], brow[PPL], at[PPL];
+    bool live[PPL];
+    lg_rows<PPL>(n0, np, K, p, live, brow);
+    T g[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const int64_t n = n0 + p[r];
+      T value = grad_lw != nullptr ? grad_lw[n] : T(0);
+      if (grad_lse != nullptr) value = value + grad_lse[brow[r]] * Num<T>::exp(lw[n] - lse[brow[r]]);
+      g[r] = live[r] ? value : T(0);
+      at[r] = p[r] * dx;
+    }
+    T up[DP][PPL], uq[DP][PPL], ug[DP][PPL];
+    lg_offsets<T, DP, PPL>(mp, brow, up);
+    lg_offsets<T, DP, PPL>(mq, brow, uq);
+    lg_offsets<T, DP, PPL>(mg, brow, ug);
+    T yv[DP][PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const T *row = y + (int64_t)brow[r] * y_sb;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) yv[j][r] = row[min(j, (int)dy - 1)];
+    }
+    __syncthreads();
+    // the three locations (K10's chains)
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      if ((uint32_t)i < dx) {
+        T xv[PPL];
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) xv[r] = tprev[lg_pad(at[r] + i)];
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const T a = wf[i * DP + j], q = wf[2 * DP * DP + i * DP + j];
+#pragma unroll
+          for (int r = 0; r < PPL; ++r) {
+            up[j][r] = fma_t(a, xv[r], up[j][r]);
+            uq[j][r] = fma_t(q, xv[r], uq[j][r]);
+          }
+        }
+      }
+    }
+    T xx[DP][PPL];
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) xx[j][r] = (uint32_t)j < dx ? tx[lg_pad(at[r] + min(j, (int)dx - 1))] : T(0);
+    lg_apply_regs<T, DP, PPL>(wf + DP * DP, xx, (int)dx, ug);
+    // locations -> gradients with respect to them; squared distances for the scales
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T qp = T(0), qq = T(0), qg = T(0);
+      const T gp = g[r] * inv_var_p, gq = g[r] * inv_var_q, gg = g[r] * inv_var_g;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const bool in_x = (uint32_t)j < dx, in_y = (uint32_t)j < dy;
+        const T dp = in_x ? xx[j][r] - up[j][r] : T(0);
+        const T dq = in_x ? xx[j][r] - uq[j][r] : T(0);
+        const T dg = in_y ? yv[j][r] - ug[j][r] : T(0);
+        qp = fma_t(dp, dp, qp);
+        qq = fma_t(dq, dq, qq);
+        qg = fma_t(dg, dg, qg);
+        up[j][r] = gp * dp;
+        uq[j][r] = -(gq * dq);
+        ug[j][r] = gg * dg;
+      }
+      scale_acc[0] += g[r] * (qp * inv_var_p * inv_s_p - T(dx) * inv_s_p);
+      scale_acc[1] += g[r] * (qg * inv_var_g * inv_s_g - T(dy) * inv_s_g);
+      scale_acc[2] -= g[r] * (qq * inv_var_q * inv_s_q - T(dx) * inv_s_q);
+    }
+    // latent gradients (held in registers until the tiles are free)
+    T gprev[DP][PPL], gcur[DP][PPL];
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        gprev[j][r] = T(0);
+        gcur[j][r] = -up[j][r] - uq[j][r];
+      }
+    if (gxprev != nullptr) {
+      lg_apply_regs<T, DP, PPL>(wn, up, (int)dx, gprev);
+      lg_apply_regs<T, DP, PPL>(wn + 2 * DP * DP, uq, (int)dx, gprev);
+    }
+    if (gx != nullptr) lg_apply_regs<T, DP, PPL>(wn + DP * DP, ug, (int)dy, gcur);
+    // weight gradients: one location's u at a time through the spare tile
+    lg_rows_to_tile<T, DP, PPL>(up, dx, p, live, tu);
+    __syncthreads();
+    if (up_out != nullptr) lg_store_rows(up_out + n0 * dx, np * dx, tu);
+    lg_outer_accumulate<T>(tu, dx, tprev, dx, np, acc_a);
+    __syncthreads();
+    lg_rows_to_tile<T, DP, PPL>(uq, dx, p, live, tu);
+    __syncthreads();
+    if (uq_out != nullptr) lg_store_rows(uq_out + n0 * dx, np * dx, tu);
+    lg_outer_accumulate<T>(tu, dx, tprev, dx, np, acc_q);
+    __syncthreads();
+    lg_rows_to_tile<T, DP, PPL>(ug, dy, p, live, tu);
+    __syncthreads();
+    if (ug_out != nullptr) lg_store_rows(ug_out + n0 * dy, np * dy, tu);
+    lg_outer_accumulate<T>(tu, dy, tx, dx, np, acc_c);
+    __syncthreads();
+    if (gxprev != nullptr) lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev);
+    if (gx != nullptr) lg_rows_to_tile<T, DP, PPL>(gcur, dx, p, live, tx);
+    __syncthreads();
+    if (gxprev != nullptr) lg_store_rows(gxprev + n0 * dx, np * dx, tprev);
+    if (gx != nullptr) lg_store_rows(gx + n0 * dx, np * dx, tx);
+    __syncthreads();
+  }
+  T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
+  lg_outer_publish<T>(acc_a, scratch, record);
+  lg_outer_publish<T>(acc_c, scratch, record + kLgRecord);
+  lg_outer_publish<T>(acc_q, scratch, record + 2 * kLgRecord);
+  // the three scale gradients: lanes -> wavefronts (shuffles) -> workgroup, fixed order
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    T v = scale_acc[m];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if ((threadIdx.x & 63) == 0) scratch[(threadIdx.x >> 6) * 4 + m] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLgRecord) {
+    const int m = threadIdx.x;
+    record[3 * kLgRecord + m] = m < 3 ? ((scratch[m] + scratch[4 + m]) + scratch[8 + m]) + scratch[12 + m] : T(0);
+  }
+}
+
 // Sums the workgroups' records in workgroup order: out[m][j * din + i] = sum_b ws[b][m][j * 16 + i].
 struct LgFinish {
   void *out[4];
@@ -645,9 +856,89 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
   return AESMC_OK;
 }
 
+template <typename T>
+static int launch_affine_logweight_backward(const void *xprev, const void *x, const void *y, int64_t y_sb,
+                                            const aesmc_affine_map *mp, const aesmc_affine_map *mg,
+                                            const aesmc_affine_map *mq, const void *sp, const void *sg, const void *sq,
+                                            const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
+                                            const aesmc_affine_logweight_grads *o, void *ws, size_t ws_bytes, int64_t B,
+                                            int64_t K, hipStream_t stream) {
+  const int64_t N = B * K;
+  const int64_t dx = mp->dout, dy = mg->dout;
+  const int dp = lg_pad_dim(std::max(dx, dy));
+  int ppl = 1;      // one particle per lane: two would spill (three locations' gradients and both latent gradients live)
+  size_t lds = 0;
+  for (; ppl >= 1; --ppl) {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * (6 * (size_t)dp * dp + 4 * 256 + 2 * lg_tile_elems(tp, dx) + lg_tile_elems(tp, std::max(dx, dy)));
+    if (lds <= (ppl > 1 ? (size_t)72 * 1024 : kLgLdsLimit)) break;
+  }
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
+  const int grid = (int)std::min<int64_t>(tiles, kLgMaxGrid);
+  if (ws_bytes < (size_t)grid * 4 * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;
+  LgBackwardOut out;
+  out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;
+  out.uq = o->grad_loc_q; out.ws = ws;
+  LG_DISPATCH(affine_logweight_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream,
+              static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp),
+              lg_map(mg), lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg),
+              static_cast<const T *>(sq), static_cast<const T *>(lw), static_cast<const T *>(lse),
+              static_cast<const T *>(grad_lse), static_cast<const T *>(grad_lw), out, N, (uint32_t)K);
+  if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  LgFinish f = {};
+  f.out[0] = o->grad_weight_p; f.rows[0] = (int32_t)dx; f.cols[0] = (int32_t)dx;
+  f.out[1] = o->grad_weight_g; f.rows[1] = (int32_t)dy; f.cols[1] = (int32_t)dx;
+  f.out[2] = o->grad_weight_q; f.rows[2] = (int32_t)dx; f.cols[2] = (int32_t)dx;
+  f.out[3] = o->grad_scales; f.rows[3] = 1; f.cols[3] = 3;
+  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(4), dim3(256), 0, stream, static_cast<const T *>(ws), grid,
+                     4 * kLgRecord, f);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
 }  // namespace aesmc
 
 using namespace aesmc;
+
+extern "C" int aesmc_affine_normal_logweight_backward(
+    int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
+    const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+    const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
+    const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream) {
+  if (x_prev == nullptr || x == nullptr || y == nullptr || transition == nullptr || emission == nullptr ||
+      proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || out == nullptr ||
+      ws == nullptr || B < 0 || K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lw == nullptr && grad_lse == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lse != nullptr && (lw == nullptr || lse == nullptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  const void *aligned[] = {x_prev, x, ws, out->grad_x_prev, out->grad_x, out->grad_loc_p, out->grad_loc_g,
+                           out->grad_loc_q};
+  for (const void *ptr : aligned)
+    if (ptr != nullptr && !aligned16(ptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  const int64_t dx = transition->dout;
+  if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
+    return AESMC_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0 || K == 0) {      // empty sums
+    const size_t esz = dtype == AESMC_F64 ? 8 : 4;
+    bool ok = true;
+    if (out->grad_weight_p != nullptr) ok = ok && zero_fill_async(out->grad_weight_p, (size_t)(dx * dx) * esz, s);
+    if (out->grad_weight_g != nullptr) ok = ok && zero_fill_async(out->grad_weight_g, (size_t)(emission->dout * dx) * esz, s);
+    if (out->grad_weight_q != nullptr) ok = ok && zero_fill_async(out->grad_weight_q, (size_t)(dx * dx) * esz, s);
+    if (out->grad_scales != nullptr) ok = ok && zero_fill_async(out->grad_scales, 3 * esz, s);
+    return ok ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
+  return dtype == AESMC_F32
+             ? launch_affine_logweight_backward<float>(x_prev, x, y, y_stride_b, transition, emission, proposal,
+                                                       scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
+                                                       ws_bytes, B, K, s)
+             : launch_affine_logweight_backward<double>(x_prev, x, y, y_stride_b, transition, emission, proposal,
+                                                        scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
+                                                        ws_bytes, B, K, s);
+}
+
 
 extern "C" size_t aesmc_affine_backward_workspace_bytes(int dtype) {
   return (size_t)kLgMaxGrid * 4 * kLgRecord * (dtype == AESMC_F64 ? 8 : 4);

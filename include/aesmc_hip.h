@@ -335,6 +335,36 @@ int aesmc_particle_affine_backward(int dtype, const void *grad, const void *x, c
                                    void *out_grad_x, void *out_grad_weight, void *ws, size_t ws_bytes, int64_t B,
                                    int64_t K, void *stream);
 
+/* K12 — backward of K10 in one pass over x_prev and x.  The incoming gradient of lw[b,k] is
+ *   g = grad_lw[b,k]  (NULL = 0)  +  grad_lse[b] * exp(lw[b,k] - lse[b])  (NULL = 0; K1's backward formed
+ *   in place: `lw` is what K10 produced, `lse` its row log-sum-exp — aesmc/inference.py:130-132)
+ * and every output pointer of `out` may be NULL (not wanted):
+ *   grad_x_prev, grad_x [B,K,dx]      gradients of the two latents (dense, 16-byte aligned);
+ *   grad_loc_p, grad_loc_q [B,K,dx], grad_loc_g [B,K,dy]
+ *                                     the gradients with respect to the three locations, written only
+ *                                     when an OFFSET's gradient is wanted (the caller sums over
+ *                                     particles; the observation's gradient is -sum_k grad_loc_g);
+ *   grad_weight_p, grad_weight_q [dx,dx], grad_weight_g [dy,dx]
+ *                                     weight gradients (matrix cores, partials in `ws` summed in
+ *                                     workgroup order by a second launch: reproducible);
+ *   grad_scales [3]                   d / d(scale_p, scale_g, scale_q).
+ * `ws`: aesmc_affine_backward_workspace_bytes(dtype) bytes.  Replaces, for one timestep, the autograd
+ * chain of aesmc/inference.py:112-132 through the callables' matmuls: K5's backward, three
+ * weight-gradient and three input-gradient matmuls and the adds between them. */
+typedef struct aesmc_affine_logweight_grads {
+  void *grad_x_prev, *grad_x;
+  void *grad_loc_p, *grad_loc_g, *grad_loc_q;
+  void *grad_weight_p, *grad_weight_g, *grad_weight_q;
+  void *grad_scales;
+} aesmc_affine_logweight_grads;
+
+int aesmc_affine_normal_logweight_backward(
+    int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
+    const void *grad_lse, const void *grad_lw, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes,
+    int64_t B, int64_t K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

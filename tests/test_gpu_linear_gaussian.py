@@ -291,3 +291,57 @@ def test_particle_affine_operator_gradients(hip_device):
     ref = torch.autograd.grad(x @ weight.t() + offset.unsqueeze(1), (x, weight, offset), upstream)
     for a, b in zip(got, ref):
         torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("via_lse", [False, True])
+@pytest.mark.parametrize("shape", SHAPES + [(16, 4096, 10, 10)])
+def test_affine_logweight_backward_matches_autograd_and_the_unfused_route(kernels, hip_device, dtype, via_lse, shape):
+    """K12 against (i) PyTorch's autograd over the float64 expression (every gradient: both latents,
+    the observation, three weights, three offsets, three scales) and (ii) the unfused device route
+    (K8 x 3, K5's backward, K8 transposed, K11).  With `via_lse` the incoming gradient is K1's softmax
+    term formed inside the kernel from (lw, lse, grad_lse)."""
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=2 * B + K + dy)
+    off_p = torch.from_numpy(np.random.RandomState(4).randn(dx).astype(dtype)).to(hip_device)
+    terms = ((o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    rng = np.random.RandomState(8)
+    need = [True] * 12
+    if via_lse:
+        lw = kernels.affine_logweight(o["x_prev"], o["x"], o["y"], *terms, scales)
+        _, lse = kernels.logweight_lse(lw, None, None, want_lw=False)
+        grad_lse = torch.from_numpy(rng.randn(B).astype(dtype)).to(hip_device)
+        incoming = dict(lw=lw, lse=lse, grad_lse=grad_lse)
+        g = grad_lse.double().unsqueeze(1) * torch.exp(lw.double() - lse.double().unsqueeze(1))
+    else:
+        grad_lw = torch.from_numpy(rng.randn(B, K).astype(dtype)).to(hip_device)
+        incoming = dict(grad_lw=grad_lw)
+        g = grad_lw.double()
+    got = kernels.affine_logweight_backward(o["x_prev"], o["x"], o["y"], *terms, scales, need, **incoming)
+    route = kernels.affine_logweight_backward_unfused(o["x_prev"], o["x"], o["y"], *terms, scales, need, **incoming)
+    # float64 autograd over the expression itself
+    leaves = [t.detach().double().requires_grad_(True) for t in
+              (o["x_prev"], o["x"], o["y"], o["A"], off_p, o["C"], o["off_g"], o["Q"], o["off_q"], *scales)]
+    xp, xx, yy, A, op, C, og, Q, oq, sp, sg, sq = leaves
+    normal = torch.distributions.Normal
+    value = (normal(xp @ A.t() + op, sp).log_prob(xx).sum(-1) +
+             normal(xx @ C.t() + og, sg).log_prob(yy.unsqueeze(1)).sum(-1) -
+             normal(xp @ Q.t() + oq.unsqueeze(1), sq).log_prob(xx).sum(-1))
+    want = torch.autograd.grad(value, leaves, grad_outputs=g)
+    names = ("x_prev", "x", "y", "A", "off_p", "C", "off_g", "Q", "off_q", "s_p", "s_g", "s_q")
+    tolerance = 2e-5 if dtype == np.float32 else 1e-11
+    for name, a, b, c in zip(names, got, want, route):
+        assert a is not None and a.shape == b.shape, name
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a.double() - b).abs().max()) <= tolerance * scale, (name, "vs autograd")
+        assert float((a.double() - c.double()).abs().max()) <= tolerance * scale, (name, "vs unfused route")
+    again = kernels.affine_logweight_backward(o["x_prev"], o["x"], o["y"], *terms, scales, need, **incoming)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)     # fixed summation order: reproducible
+    # only some gradients wanted: the others are not produced
+    some = [False] * 12
+    some[1] = some[7] = True
+    partial = kernels.affine_logweight_backward(o["x_prev"], o["x"], o["y"], *terms, scales, some, **incoming)
+    assert [t is not None for t in partial] == some
+    assert torch.equal(partial[1], got[1]) and torch.equal(partial[7], got[7])
