@@ -36,14 +36,30 @@ def build(force=False, verbose=True):
     """Compile every HIP source into one shared library; returns its path."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH,
-           "-ffp-contract=off",  # keep float64 CDF arithmetic as written (no fused a*b+c)
-           "-munsafe-fp-atomics",  # hardware float atomics for the gather backward
-           "-Wall", "-Wno-unused-function",
-           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH,
+             "-ffp-contract=off",  # keep float64 CDF arithmetic as written (no fused a*b+c)
+             "-munsafe-fp-atomics",  # hardware float atomics for the gather backward
+             "-Wall", "-Wno-unused-function"]
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in HEADERS)
+    jobs = []
+    for source in SOURCES:      # one hipcc per translation unit, side by side; unchanged ones are kept
+        src, obj = os.path.join(CSRC, source), os.path.join(objdir, source[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            continue
+        cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print("[aesmc_amd.build]", " ".join(cmd), flush=True)
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
+    link = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB_PATH] + \
+        [os.path.join(objdir, s[:-4] + ".o") for s in SOURCES]
     if verbose:
-        print("[aesmc_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        print("[aesmc_amd.build]", " ".join(link), flush=True)
+    subprocess.run(link, check=True)
     return LIB_PATH
 
 

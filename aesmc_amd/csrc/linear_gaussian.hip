@@ -208,48 +208,177 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_kernel(const T *__re
   lg_store_rows(out + n0 * dout, np * dout, to);
 }
 
+// ---- per-batch-row vectors (offsets, the observation) of a tile ------------------------------------------
+// A tile of TP consecutive particles spans the batch rows b0 .. b0 + nrows - 1.  When they are few
+// (K >= TP / 6, every BASELINE shape) their vectors are staged once per tile in an LDS table
+// tab[(slot * NA + a) * DP + j] and lanes pick theirs with broadcast reads; otherwise (tiny K) every
+// lane loads its own row's vectors from global memory.  Elements past a vector's length are zero in
+// the table, repeats of the last one from global memory: nothing reads them.
+constexpr int kLgRowsMax = 8;
+
+template <typename T> struct LgRowVec {
+  const T *ptr;      // nullptr: absent (zeros)
+  int64_t sb;        // element stride between batch rows (0: one vector shared by all)
+  int len;
+};
+
+template <typename T, int DP, int NA>
+__device__ __forceinline__ void lg_stage_table(const LgRowVec<T> (&vec)[NA], uint32_t b0, uint32_t nrows,
+                                               T *__restrict__ tab) {
+  for (uint32_t idx = threadIdx.x; idx < nrows * NA * DP; idx += kLgBlock) {
+    const uint32_t j = idx % DP, a = (idx / DP) % NA, row = idx / (DP * NA);
+    T value = T(0);
+#pragma unroll
+    for (int c = 0; c < NA; ++c)
+      if (a == (uint32_t)c && vec[c].ptr != nullptr && (int)j < vec[c].len)
+        value = vec[c].ptr[(int64_t)(b0 + row) * vec[c].sb + j];
+    tab[idx] = value;
+  }
+}
+
+// out[j][r] = vector A of the batch row of the lane's particle r.
+template <typename T, int DP, int PPL, int NA, int A>
+__device__ __forceinline__ void lg_row_values(const LgRowVec<T> (&vec)[NA], bool use_tab, const T *__restrict__ tab,
+                                              uint32_t b0, const uint32_t (&brow)[PPL], T (&out)[DP][PPL]) {
+  if (use_tab) {
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const T *row = tab + ((brow[r] - b0) * NA + A) * DP;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) out[j][r] = row[j];
+    }
+  } else if (vec[A].ptr != nullptr) {
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const T *row = vec[A].ptr + (int64_t)brow[r] * vec[A].sb;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) out[j][r] = row[min(j, vec[A].len - 1)];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) out[j][r] = T(0);
+  }
+}
+
+template <typename T> __device__ __forceinline__ LgRowVec<T> lg_offset_vec(const LgMap &m) {
+  LgRowVec<T> v;
+  v.ptr = reinterpret_cast<const T *>(m.off);
+  v.sb = m.off_sb;
+  v.len = m.dout;
+  return v;
+}
+
+// ---- persistent tiles with register prefetch ----------------------------------------------------------
+// A workgroup that loads a tile, waits, computes and stores keeps its share of HBM idle while it
+// computes: with two or three workgroups per CU the loaded latency (~6 us at these rates) is not
+// covered.  K9 / K10 therefore run a fixed grid of workgroups over the tiles; each holds the NEXT tile's
+// 16-byte vectors in registers, issued right after the current tile went into LDS, so the loads fly
+// during the arithmetic.  Barriers inside the loop wait for LDS traffic only (a full __syncthreads()
+// would also drain the prefetch).
+__device__ __forceinline__ void lg_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ void lg_prefetch(const T *__restrict__ src, uint32_t ne, int stream,
+                                            typename Vec16<T>::type (&regs)[NV]) {
+  using V = typename Vec16<T>::type;
+  const uint32_t nvec = ne / Vec16<T>::N;
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    const uint32_t v = threadIdx.x + s * kLgBlock;
+    if (v < nvec) regs[s] = load16(reinterpret_cast<const V *>(src) + v, stream);
+  }
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ void lg_commit(const T *__restrict__ src, uint32_t ne,
+                                          const typename Vec16<T>::type (&regs)[NV], T *__restrict__ tile) {
+  constexpr int N = Vec16<T>::N;
+  const uint32_t nvec = ne / N;
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    const uint32_t v = threadIdx.x + s * kLgBlock;
+    if (v < nvec) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) tile[lg_pad(v * N + r)] = Vec16<T>::get(regs[s], r);
+    }
+  }
+  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[lg_pad(e)] = src[e];   // last tile only
+}
+
 // ---- K9 ----------------------------------------------------------------------------------------
-template <typename T, int DP, int PPL>
-__global__ __launch_bounds__(kLgBlock) void affine_rsample_kernel(const T *__restrict__ src, LgMap m,
+template <typename T, int DP, int PPL, bool TAB>
+__global__ __launch_bounds__(kLgBlock, 3) void affine_rsample_kernel(const T *__restrict__ src, LgMap m,
                                                                    const T *__restrict__ eps,
                                                                    const T *__restrict__ scale_ptr,
                                                                    T *__restrict__ out, int64_t N, uint32_t K,
                                                                    int stream) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
+  constexpr int NV = (PPL * DP + Vec16<T>::N - 1) / Vec16<T>::N;
+  using V = typename Vec16<T>::type;
   const uint32_t din = m.din, dout = m.dout;
   T *wl = reinterpret_cast<T *>(lg_smem);
-  T *ts = wl + DP * DP;
+  T *tab = wl + DP * DP;                             // [kLgRowsMax][1][DP]
+  T *ts = tab + kLgRowsMax * DP;
   T *te = ts + (TP * din + ((TP * din) >> 5) + 1);   // the noise, then the draw in its place
-  const int64_t n0 = (int64_t)blockIdx.x * TP;
-  const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
   const T scale = scale_ptr[0];
   lg_stage_weight<T, DP>(m, wl);
-  lg_stage_rows(src + n0 * din, np * din, ts, 0);
-  lg_stage_rows(eps + n0 * dout, np * dout, te, stream);
-  uint32_t p[PPL], brow[PPL], at[PPL];
-  bool live[PPL];
-  lg_rows<PPL>(n0, np, K, p, live, brow);
-  T acc[DP][PPL];
-  lg_offsets<T, DP, PPL>(m, brow, acc);
-  __syncthreads();
+  const LgRowVec<T> vec[1] = {lg_offset_vec<T>(m)};
+  const int64_t tiles = (N + TP - 1) / TP;
+  V rs[NV], re[NV];
+  {
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_prefetch<T, NV>(src + n0 * din, np * din, 0, rs);
+    lg_prefetch<T, NV>(eps + n0 * dout, np * dout, stream, re);
+  }
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_commit<T, NV>(src + n0 * din, np * din, rs, ts);
+    lg_commit<T, NV>(eps + n0 * dout, np * dout, re, te);
+    uint32_t p[PPL], brow[PPL], at[PPL];
+    bool live[PPL];
+    lg_rows<PPL>(n0, np, K, p, live, brow);
+    const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
+    constexpr bool use_tab = TAB;      // the host guarantees nrows <= kLgRowsMax when it picks TAB
+    T acc[DP][PPL];
+    if (use_tab) lg_stage_table<T, DP, 1>(vec, b0, nrows, tab);
+    else lg_row_values<T, DP, PPL, 1, 0>(vec, false, tab, b0, brow, acc);
+    lg_lds_barrier();
+    const int64_t next = tile + gridDim.x;
+    if (next < tiles) {
+      const int64_t m0 = next * TP;
+      const uint32_t mp = (uint32_t)min((int64_t)TP, N - m0);
+      lg_prefetch<T, NV>(src + m0 * din, mp * din, 0, rs);
+      lg_prefetch<T, NV>(eps + m0 * dout, mp * dout, stream, re);
+    }
+    if (use_tab) lg_row_values<T, DP, PPL, 1, 0>(vec, true, tab, b0, brow, acc);
 #pragma unroll
-  for (int r = 0; r < PPL; ++r) at[r] = p[r] * din;
-  lg_apply_tile<T, DP, PPL>(wl, ts, at, (int)din, acc);
+    for (int r = 0; r < PPL; ++r) at[r] = p[r] * din;
+    lg_apply_tile<T, DP, PPL>(wl, ts, at, (int)din, acc);
 #pragma unroll
-  for (int j = 0; j < DP; ++j) {
-    if ((uint32_t)j < dout) {
-  #pragma unroll
-      for (int r = 0; r < PPL; ++r) {
-        if (live[r]) {
-          const uint32_t slot = lg_pad(p[r] * dout + j);
-          te[slot] = acc[j][r] + te[slot] * scale;   // the product rounded before the sum, as K6
+    for (int j = 0; j < DP; ++j) {
+      if ((uint32_t)j < dout) {
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+          if (live[r]) {
+            const uint32_t slot = lg_pad(p[r] * dout + j);
+            te[slot] = acc[j][r] + te[slot] * scale;   // the product rounded before the sum, as K6
+          }
         }
       }
     }
+    lg_lds_barrier();
+    lg_store_rows(out + n0 * dout, np * dout, te);
+    lg_lds_barrier();
   }
-  __syncthreads();
-  lg_store_rows(out + n0 * dout, np * dout, te);
 }
 
 // ---- K10 ---------------------------------------------------------------------------------------
@@ -257,111 +386,147 @@ __global__ __launch_bounds__(kLgBlock) void affine_rsample_kernel(const T *__res
 //   log N = (-q) / (2 sigma^2) - d (log sigma + log sqrt(2 pi))
 // — ONE division per term and particle instead of PyTorch's one per element (K5 keeps those: it is
 // HBM-bound either way; this kernel would be VALU-bound on 2 d divisions per particle).
-template <typename T, int DP, int PPL>
-__global__ __launch_bounds__(kLgBlock) void affine_logweight_kernel(
+template <typename T, int DP, int PPL, bool TAB, bool PREFETCH>
+__global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
     const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
     LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
     T *__restrict__ out_lw, int64_t N, uint32_t K) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
+  constexpr int NV = (PPL * DP + Vec16<T>::N - 1) / Vec16<T>::N;
+  using V = typename Vec16<T>::type;
   const uint32_t dx = mp.dout, dy = mg.dout;
   T *wp = reinterpret_cast<T *>(lg_smem);
   T *wg = wp + DP * DP;
   T *wq = wg + DP * DP;
-  T *tprev = wq + DP * DP;
+  T *tab = wq + DP * DP;                             // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
+  T *tprev = tab + kLgRowsMax * 4 * DP;
   T *tx = tprev + (TP * dx + ((TP * dx) >> 5) + 1);
-  const int64_t n0 = (int64_t)blockIdx.x * TP;
-  const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
   const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
   lg_stage_weight<T, DP>(mp, wp);
   lg_stage_weight<T, DP>(mg, wg);
   lg_stage_weight<T, DP>(mq, wq);
-  lg_stage_rows(xprev + n0 * dx, np * dx, tprev, 0);
-  lg_stage_rows(x + n0 * dx, np * dx, tx, 0);
-  uint32_t p[PPL], brow[PPL], at[PPL];
-  bool live[PPL];
-  lg_rows<PPL>(n0, np, K, p, live, brow);
-  T locp[DP][PPL], locq[DP][PPL], yv[DP][PPL];
-  lg_offsets<T, DP, PPL>(mp, brow, locp);
-  lg_offsets<T, DP, PPL>(mq, brow, locq);
-#pragma unroll
-  for (int r = 0; r < PPL; ++r) {
-    const T *row = y + (int64_t)brow[r] * y_sb;
-#pragma unroll
-    for (int j = 0; j < DP; ++j) yv[j][r] = row[min(j, (int)dy - 1)];
-  }
+  LgRowVec<T> vec[4] = {lg_offset_vec<T>(mp), lg_offset_vec<T>(mq), lg_offset_vec<T>(mg), {y, y_sb, (int)dy}};
   const T half_log_2pi = LgConst<T>::half_log_2pi();
   const T two_var_p = T(2) * (s_p * s_p), const_p = T(dx) * (Num<T>::log(s_p) + half_log_2pi);
   const T two_var_g = T(2) * (s_g * s_g), const_g = T(dy) * (Num<T>::log(s_g) + half_log_2pi);
   const T two_var_q = T(2) * (s_q * s_q), const_q = T(dx) * (Num<T>::log(s_q) + half_log_2pi);
-  __syncthreads();
+  const int64_t tiles = (N + TP - 1) / TP;
+  V rp[PREFETCH ? NV : 1], rx[PREFETCH ? NV : 1];
+  if constexpr (PREFETCH) {
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const uint32_t ne = (uint32_t)min((int64_t)TP, N - n0) * dx;
+    lg_prefetch<T, NV>(xprev + n0 * dx, ne, 0, rp);
+    lg_prefetch<T, NV>(x + n0 * dx, ne, 0, rx);
+  }
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    if constexpr (PREFETCH) {
+      lg_commit<T, NV>(xprev + n0 * dx, np * dx, rp, tprev);
+      lg_commit<T, NV>(x + n0 * dx, np * dx, rx, tx);
+    } else {
+      lg_stage_rows(xprev + n0 * dx, np * dx, tprev, 0);
+      lg_stage_rows(x + n0 * dx, np * dx, tx, 0);
+    }
+    uint32_t p[PPL], brow[PPL], at[PPL];
+    bool live[PPL];
+    lg_rows<PPL>(n0, np, K, p, live, brow);
+    const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
+    constexpr bool use_tab = TAB;      // the host guarantees nrows <= kLgRowsMax when it picks TAB
+    T locp[DP][PPL], locq[DP][PPL], locg[DP][PPL], yv[DP][PPL];
+    if (use_tab) {
+      lg_stage_table<T, DP, 4>(vec, b0, nrows, tab);
+    } else {    // tiny K: the global loads go out before the prefetch, so waiting for them does not drain it
+      lg_row_values<T, DP, PPL, 4, 0>(vec, false, tab, b0, brow, locp);
+      lg_row_values<T, DP, PPL, 4, 1>(vec, false, tab, b0, brow, locq);
+      lg_row_values<T, DP, PPL, 4, 2>(vec, false, tab, b0, brow, locg);
+      lg_row_values<T, DP, PPL, 4, 3>(vec, false, tab, b0, brow, yv);
+    }
+    lg_lds_barrier();
+    if constexpr (PREFETCH) {
+      const int64_t next = tile + gridDim.x;
+      if (next < tiles) {
+        const int64_t m0 = next * TP;
+        const uint32_t ne = (uint32_t)min((int64_t)TP, N - m0) * dx;
+        lg_prefetch<T, NV>(xprev + m0 * dx, ne, 0, rp);
+        lg_prefetch<T, NV>(x + m0 * dx, ne, 0, rx);
+      }
+    }
+    if (use_tab) {
+      lg_row_values<T, DP, PPL, 4, 0>(vec, true, tab, b0, brow, locp);
+      lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, locq);
+    }
 #pragma unroll
-  for (int r = 0; r < PPL; ++r) at[r] = p[r] * dx;
-  // transition and proposal locations from x_prev, one pass over its elements
+    for (int r = 0; r < PPL; ++r) at[r] = p[r] * dx;
+    // transition and proposal locations from x_prev, one pass over its elements
 #pragma unroll
-  for (int i = 0; i < DP; ++i) {
-    if ((uint32_t)i < dx) {
-      T xv[PPL];
-  #pragma unroll
-      for (int r = 0; r < PPL; ++r) xv[r] = tprev[lg_pad(at[r] + i)];
-  #pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        const T a = wp[i * DP + j], q = wq[i * DP + j];
-  #pragma unroll
-        for (int r = 0; r < PPL; ++r) {
-          locp[j][r] = fma_t(a, xv[r], locp[j][r]);
-          locq[j][r] = fma_t(q, xv[r], locq[j][r]);
+    for (int i = 0; i < DP; ++i) {
+      if ((uint32_t)i < dx) {
+        T xv[PPL];
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) xv[r] = tprev[lg_pad(at[r] + i)];
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const T a = wp[i * DP + j], q = wq[i * DP + j];
+#pragma unroll
+          for (int r = 0; r < PPL; ++r) {
+            locp[j][r] = fma_t(a, xv[r], locp[j][r]);
+            locq[j][r] = fma_t(q, xv[r], locq[j][r]);
+          }
         }
       }
     }
-  }
-  // squared distances of x to both; x kept for the emission map
-  T xx[DP][PPL], qp[PPL], qq[PPL], qg[PPL];
+    // squared distances of x to both; x kept for the emission map
+    T xx[DP][PPL], qp[PPL], qq[PPL], qg[PPL];
 #pragma unroll
-  for (int r = 0; r < PPL; ++r) qp[r] = qq[r] = qg[r] = T(0);
+    for (int r = 0; r < PPL; ++r) qp[r] = qq[r] = qg[r] = T(0);
 #pragma unroll
-  for (int j = 0; j < DP; ++j) {
-    if ((uint32_t)j < dx) {
-  #pragma unroll
-      for (int r = 0; r < PPL; ++r) {
-        xx[j][r] = tx[lg_pad(at[r] + j)];
-        const T dp = xx[j][r] - locp[j][r], dq = xx[j][r] - locq[j][r];
-        qp[r] = fma_t(dp, dp, qp[r]);
-        qq[r] = fma_t(dq, dq, qq[r]);
+    for (int j = 0; j < DP; ++j) {
+      if ((uint32_t)j < dx) {
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+          xx[j][r] = tx[lg_pad(at[r] + j)];
+          const T dp = xx[j][r] - locp[j][r], dq = xx[j][r] - locq[j][r];
+          qp[r] = fma_t(dp, dp, qp[r]);
+          qq[r] = fma_t(dq, dq, qq[r]);
+        }
       }
     }
-  }
-  // emission location from x (locp's registers are free again)
-  lg_offsets<T, DP, PPL>(mg, brow, locp);
+    // emission location from x
+    if (use_tab) lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, locg);
 #pragma unroll
-  for (int i = 0; i < DP; ++i) {
-    if ((uint32_t)i < dx) {
-  #pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        const T c = wg[i * DP + j];
-  #pragma unroll
-        for (int r = 0; r < PPL; ++r) locp[j][r] = fma_t(c, xx[i][r], locp[j][r]);
+    for (int i = 0; i < DP; ++i) {
+      if ((uint32_t)i < dx) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const T c = wg[i * DP + j];
+#pragma unroll
+          for (int r = 0; r < PPL; ++r) locg[j][r] = fma_t(c, xx[i][r], locg[j][r]);
+        }
       }
     }
-  }
 #pragma unroll
-  for (int j = 0; j < DP; ++j) {
-    if ((uint32_t)j < dy) {
-  #pragma unroll
-      for (int r = 0; r < PPL; ++r) {
-        const T dg = yv[j][r] - locp[j][r];
-        qg[r] = fma_t(dg, dg, qg[r]);
+    for (int j = 0; j < DP; ++j) {
+      if ((uint32_t)j < dy) {
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+          const T yj = use_tab ? tab[((brow[r] - b0) * 4 + 3) * DP + j] : yv[j][r];
+          const T dg = yj - locg[j][r];
+          qg[r] = fma_t(dg, dg, qg[r]);
+        }
       }
     }
-  }
 #pragma unroll
-  for (int r = 0; r < PPL; ++r) {
-    if (live[r]) {
-      const T lp = (-qp[r]) / two_var_p - const_p;
-      const T lg = (-qg[r]) / two_var_g - const_g;
-      const T lq = (-qq[r]) / two_var_q - const_q;
-      out_lw[n0 + p[r]] = (lp + lg) - lq;
+    for (int r = 0; r < PPL; ++r) {
+      if (live[r]) {
+        const T lp = (-qp[r]) / two_var_p - const_p;
+        const T lg = (-qg[r]) / two_var_g - const_g;
+        const T lq = (-qq[r]) / two_var_q - const_q;
+        out_lw[n0 + p[r]] = (lp + lg) - lq;
+      }
     }
+    lg_lds_barrier();     // every lane is done with the tiles before the next commit
   }
 }
 
@@ -693,13 +858,30 @@ struct LgFinish {
   int32_t rows[4], cols[4];
 };
 template <typename T>
-__global__ __launch_bounds__(256) void lg_finish_kernel(const T *__restrict__ ws, int nblocks, int record, LgFinish f) {
-  const int m = blockIdx.x, e = threadIdx.x;
+__global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ ws, int nblocks, int record, LgFinish f) {
+  // element e of matrix m: four lanes each sum a quarter of the workgroups' records (in workgroup order,
+  // eight loads in flight), then the quarters are added in order — fixed association, reproducible
+  __shared__ T part[4 * 256];
+  const int m = blockIdx.x, e = threadIdx.x & 255, seg = threadIdx.x >> 8;
+  const int per = (nblocks + 3) / 4, b0 = seg * per, b1 = min(nblocks, b0 + per);
   T sum = T(0);
-  for (int b = 0; b < nblocks; ++b) sum += ws[(int64_t)b * record + m * 256 + e];
-  const int j = e >> 4, i = e & 15;
-  T *out = reinterpret_cast<T *>(f.out[m]);
-  if (out != nullptr && j < f.rows[m] && i < f.cols[m]) out[j * f.cols[m] + i] = sum;
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(b + u) * record + m * 256 + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; b < b1; ++b) sum += ws[(int64_t)b * record + m * 256 + e];
+  part[seg * 256 + e] = sum;
+  __syncthreads();
+  if (seg == 0) {
+    const T total = ((part[e] + part[256 + e]) + part[512 + e]) + part[768 + e];
+    const int j = e >> 4, i = e & 15;
+    T *out = reinterpret_cast<T *>(f.out[m]);
+    if (out != nullptr && j < f.rows[m] && i < f.cols[m]) out[j * f.cols[m] + i] = total;
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -714,11 +896,28 @@ static inline LgMap lg_map(const aesmc_affine_map *m) {
   out.dout = (int32_t)m->dout; out.din = (int32_t)m->din;
   return out;
 }
-static inline int lg_pad_dim(int64_t d) { return (int)((d + 3) / 4 * 4); }
+// compile-time extents the kernels are built for: the smallest one that holds d (10 is there for the
+// BASELINE shapes: padding 10 to 12 costs 44 % more multiply-adds)
+static inline int lg_pad_dim(int64_t d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 10 ? 10 : d <= 12 ? 12 : 16; }
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // PPL = 2 only while the tiles fit 64 KiB (two workgroups per CU); one particle per lane may take up to 144 KiB
 constexpr size_t kLgLdsBudget = 64 * 1024;
+
+// Workgroups of a persistent launch: as many as are resident at once (by LDS; at most 8 per CU), so
+// each walks tiles blockIdx.x, blockIdx.x + grid, ... with the next one prefetched.
+static inline unsigned lg_persistent_grid(int64_t tiles, size_t lds_bytes) {
+  int device = 0, cus = 256;
+  if (hipGetDevice(&device) == hipSuccess) {
+    int value = 0;
+    if (hipDeviceGetAttribute(&value, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && value > 0)
+      cus = value;
+  }
+  int per_cu = (int)((size_t)160 * 1024 / (lds_bytes > 0 ? lds_bytes : 1));
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  const int64_t resident = (int64_t)cus * per_cu;
+  return (unsigned)(tiles < resident ? tiles : resident);
+}
 constexpr size_t kLgLdsLimit = 144 * 1024;
 
 // Launches `KERNEL<T, DP, PPL>` with DP from `dp` (4, 8, 12, 16) and PPL from `ppl` (1, 2).  Tiles beyond
@@ -727,7 +926,7 @@ constexpr size_t kLgLdsLimit = 144 * 1024;
 #define LG_LAUNCH(KERNEL, T, DP_, PPL_, grid, lds, stream, ...)                                              \
   do {                                                                                                       \
     if ((lds) > 64 * 1024)                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<T, DP_, PPL_>),                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL<T, DP_, PPL_>),                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds));                     \
     hipLaunchKernelGGL((KERNEL<T, DP_, PPL_>), grid, dim3(kLgBlock), lds, stream, __VA_ARGS__);              \
   } while (0)
@@ -737,6 +936,7 @@ constexpr size_t kLgLdsLimit = 144 * 1024;
       switch (dp) {                                                                                          \
         case 4: LG_LAUNCH(KERNEL, T, 4, 2, grid, lds, stream, __VA_ARGS__); break;                           \
         case 8: LG_LAUNCH(KERNEL, T, 8, 2, grid, lds, stream, __VA_ARGS__); break;                           \
+        case 10: LG_LAUNCH(KERNEL, T, 10, 2, grid, lds, stream, __VA_ARGS__); break;                         \
         case 12: LG_LAUNCH(KERNEL, T, 12, 2, grid, lds, stream, __VA_ARGS__); break;                         \
         default: LG_LAUNCH(KERNEL, T, 16, 2, grid, lds, stream, __VA_ARGS__); break;                         \
       }                                                                                                      \
@@ -744,6 +944,7 @@ constexpr size_t kLgLdsLimit = 144 * 1024;
       switch (dp) {                                                                                          \
         case 4: LG_LAUNCH(KERNEL, T, 4, 1, grid, lds, stream, __VA_ARGS__); break;                           \
         case 8: LG_LAUNCH(KERNEL, T, 8, 1, grid, lds, stream, __VA_ARGS__); break;                           \
+        case 10: LG_LAUNCH(KERNEL, T, 10, 1, grid, lds, stream, __VA_ARGS__); break;                         \
         case 12: LG_LAUNCH(KERNEL, T, 12, 1, grid, lds, stream, __VA_ARGS__); break;                         \
         default: LG_LAUNCH(KERNEL, T, 16, 1, grid, lds, stream, __VA_ARGS__); break;                         \
       }                                                                                                      \
@@ -775,6 +976,22 @@ static int launch_particle_affine(const void *x1, const aesmc_affine_map *m1, co
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
+// The persistent kernels with (`_tab`) and without the per-row LDS table, as three-parameter names for
+// the dispatch macro.
+template <typename T, int DP, int PPL>
+static constexpr auto affine_rsample_tab = &affine_rsample_kernel<T, DP, PPL, true>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_rsample_rows = &affine_rsample_kernel<T, DP, PPL, false>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_logweight_tab = &affine_logweight_kernel<T, DP, PPL, true, false>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_logweight_tab_prefetch = &affine_logweight_kernel<T, DP, PPL, true, true>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_logweight_rows = &affine_logweight_kernel<T, DP, PPL, false, false>;
+
+// Batch rows a tile of `tp` consecutive particles can span.
+static inline int64_t lg_rows_spanned(int64_t tp, int64_t K) { return (tp - 1) / K + 2; }
+
 template <typename T>
 static int launch_affine_rsample(const void *src, const aesmc_affine_map *m, const void *eps, const void *scale,
                                  void *out, int64_t B, int64_t K, hipStream_t stream) {
@@ -784,16 +1001,25 @@ static int launch_affine_rsample(const void *src, const aesmc_affine_map *m, con
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * ((size_t)dp * dp + lg_tile_elems(tp, m->din) + lg_tile_elems(tp, m->dout));
+    lds = sizeof(T) * ((size_t)dp * dp + (size_t)kLgRowsMax * dp + lg_tile_elems(tp, m->din) + lg_tile_elems(tp, m->dout));
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  bool tab = lg_rows_spanned((int64_t)kLgBlock * ppl, K) <= kLgRowsMax;
+  if (!tab && ppl == 2) {      // few particles per batch row: one particle per lane, rows from global memory
+    ppl = 1;
+    tab = lg_rows_spanned(kLgBlock, K) <= kLgRowsMax;
+  }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
   const int hint = stream_hint((uint64_t)N * (m->din + 2 * m->dout) * sizeof(T));
-  LG_DISPATCH(affine_rsample_kernel, T, dp, ppl, dim3((unsigned)tiles), lds, stream, static_cast<const T *>(src),
-              lg_map(m), static_cast<const T *>(eps), static_cast<const T *>(scale), static_cast<T *>(out), N,
-              (uint32_t)K, hint);
+  const unsigned grid = lg_persistent_grid(tiles, lds);
+  if (tab)
+    LG_DISPATCH(affine_rsample_tab, T, dp, ppl, dim3(grid), lds, stream, static_cast<const T *>(src), lg_map(m),
+                static_cast<const T *>(eps), static_cast<const T *>(scale), static_cast<T *>(out), N, (uint32_t)K, hint);
+  else
+    LG_DISPATCH(affine_rsample_rows, T, dp, 1, dim3(grid), lds, stream, static_cast<const T *>(src), lg_map(m),
+                static_cast<const T *>(eps), static_cast<const T *>(scale), static_cast<T *>(out), N, (uint32_t)K, hint);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
@@ -809,16 +1035,36 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (3 * (size_t)dp * dp + 2 * lg_tile_elems(tp, dx));
+    lds = sizeof(T) * (3 * (size_t)dp * dp + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems(tp, dx));
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  bool tab = lg_rows_spanned((int64_t)kLgBlock * ppl, K) <= kLgRowsMax;
+  if (!tab && ppl == 2) {
+    ppl = 1;
+    tab = lg_rows_spanned(kLgBlock, K) <= kLgRowsMax;
+  }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
-  LG_DISPATCH(affine_logweight_kernel, T, dp, ppl, dim3((unsigned)tiles), lds, stream, static_cast<const T *>(xprev),
-              static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), lg_map(mq),
-              static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),
-              static_cast<T *>(out), N, (uint32_t)K);
+  // persistent workgroups with the next tile prefetched (B=1024 K=4096 d=10: 106 us against 145 us with one
+  // tile per workgroup); AESMC_LG_PREFETCH=0 selects the latter: a measurement knob
+  static const bool prefetch = [] { const char *v = getenv("AESMC_LG_PREFETCH"); return v == nullptr || v[0] != '0'; }();
+  const unsigned grid = prefetch ? lg_persistent_grid(tiles, lds) : (unsigned)tiles;
+  if (tab && prefetch)
+    LG_DISPATCH(affine_logweight_tab_prefetch, T, dp, ppl, dim3(grid), lds, stream, static_cast<const T *>(xprev),
+                static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), lg_map(mq),
+                static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),
+                static_cast<T *>(out), N, (uint32_t)K);
+  else if (tab)
+    LG_DISPATCH(affine_logweight_tab, T, dp, ppl, dim3(grid), lds, stream, static_cast<const T *>(xprev),
+                static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), lg_map(mq),
+                static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),
+                static_cast<T *>(out), N, (uint32_t)K);
+  else
+    LG_DISPATCH(affine_logweight_rows, T, dp, 1, dim3(grid), lds, stream, static_cast<const T *>(xprev),
+                static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), lg_map(mq),
+                static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),
+                static_cast<T *>(out), N, (uint32_t)K);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
@@ -849,7 +1095,7 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
   if (gw != nullptr) {
     LgFinish f = {};
     f.out[0] = gw; f.rows[0] = (int32_t)dout; f.cols[0] = (int32_t)din;
-    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(1), dim3(256), 0, stream, static_cast<const T *>(ws), grid,
+    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(1), dim3(1024), 0, stream, static_cast<const T *>(ws), grid,
                        kLgRecord, f);
     if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
   }
@@ -891,7 +1137,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   f.out[1] = o->grad_weight_g; f.rows[1] = (int32_t)dy; f.cols[1] = (int32_t)dx;
   f.out[2] = o->grad_weight_q; f.rows[2] = (int32_t)dx; f.cols[2] = (int32_t)dx;
   f.out[3] = o->grad_scales; f.rows[3] = 1; f.cols[3] = 3;
-  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(4), dim3(256), 0, stream, static_cast<const T *>(ws), grid,
+  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(4), dim3(1024), 0, stream, static_cast<const T *>(ws), grid,
                      4 * kLgRecord, f);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
