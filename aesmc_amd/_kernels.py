@@ -917,8 +917,13 @@ class HipKernels:
                     _ptr(scales[2]), _ptr(lw) if fused_lse else 0, _ptr(lse) if fused_lse else 0,
                     _ptr(grad_lse) if fused_lse else 0, _ptr(grad_lw), ctypes.byref(outs), _ptr(ws), ws_bytes, B, K,
                     self._stream(x))
-            _lib.check(self._lib.aesmc_affine_normal_logweight_backward(*args),
-                       "aesmc_affine_normal_logweight_backward")
+            status = self._lib.aesmc_affine_normal_logweight_backward(*args)
+            if status == 2:     # too few particles per batch row for the fused kernel's row table
+                return self.affine_logweight_backward_unfused(
+                    x_prev, x, y_rows, transition, emission, proposal, scales, need, grad_lw=grad_lw,
+                    lw=lw if fused_lse else None, lse=lse if fused_lse else None,
+                    grad_lse=grad_lse if fused_lse else None)
+            _lib.check(status, "aesmc_affine_normal_logweight_backward")
             if self.timer is not None:
                 dense = [t for t in (gx_prev, gx, u_p, u_g, u_q) if t is not None]
                 nbytes = x.element_size() * (B * K * (2 * dx + 1)) + sum(t.numel() * t.element_size() for t in dense)

@@ -559,14 +559,22 @@ constexpr int kLgMaxGrid = 512;       // persistent workgroups of the reducing k
 template <typename T>
 __device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, uint32_t dg, const T *__restrict__ tx,
                                                     uint32_t dxx, uint32_t np, typename Mfma<T>::Acc &acc) {
+  // Lane (quad, col) feeds value `col` of particle 4 w + quad (+ 16 per trip).  Columns at or past a row's
+  // extent read the neighbouring row: that only reaches accumulator rows / columns >= the extents,
+  // which nobody reads, so there is no per-column mask; particles past the tile's end are masked.
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t col = lane & 15u, quad = lane >> 4;
+  const uint32_t col = lane & 15u;
+  uint32_t p = wave * 4 + (lane >> 4);
+  uint32_t eg = p * dg + col, ex = p * dxx + col;
+  const uint32_t step_g = 16 * dg, step_x = 16 * dxx;
   for (uint32_t p0 = wave * 4; p0 < np; p0 += 16) {
-    const uint32_t p = p0 + quad;
     const bool live = p < np;
-    const T a = (live && col < dg) ? tg[lg_pad(p * dg + col)] : T(0);
-    const T b = (live && col < dxx) ? tx[lg_pad(p * dxx + col)] : T(0);
+    const T a = live ? tg[lg_pad(eg)] : T(0);
+    const T b = live ? tx[lg_pad(ex)] : T(0);
     acc = Mfma<T>::fma(a, b, acc);
+    p += 16;
+    eg += step_g;
+    ex += step_x;
   }
 }
 
@@ -692,14 +700,13 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
   const uint32_t dx = mp.dout, dy = mg.dout;
-  T *wf = reinterpret_cast<T *>(lg_smem);        // [3][DP*DP] input-major: locations
+  T *wf = reinterpret_cast<T *>(lg_smem);        // [3][DP*DP] input-major: locations (p, g, q)
   T *wn = wf + 3 * DP * DP;                      // [3][DP*DP] output-major: adjoints
   T *scratch = wn + 3 * DP * DP;                 // 4 x 256
-  T *tprev = scratch + 4 * 256;
+  T *tab = scratch + 4 * 256;                    // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
+  T *tprev = tab + kLgRowsMax * 4 * DP;
   T *tx = tprev + (TP * dx + ((TP * dx) >> 5) + 1);
-  const uint32_t dmax = dx > dy ? dx : dy;
   T *tu = tx + (TP * dx + ((TP * dx) >> 5) + 1);  // [TP * max(dx, dy)]
-  (void)dmax;
   {
     lg_stage_weight<T, DP>(mp, wf);
     lg_stage_weight<T, DP>(mg, wf + DP * DP);
@@ -712,6 +719,7 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
     t = mq; t.sj = mq.si; t.si = mq.sj; t.dout = mq.din; t.din = mq.dout;
     lg_stage_weight<T, DP>(t, wn + 2 * DP * DP);
   }
+  const LgRowVec<T> vec[4] = {lg_offset_vec<T>(mp), lg_offset_vec<T>(mq), lg_offset_vec<T>(mg), {y, y_sb, (int)dy}};
   const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
   const T inv_var_p = T(1) / (s_p * s_p), inv_var_g = T(1) / (s_g * s_g), inv_var_q = T(1) / (s_q * s_q);
   const T inv_s_p = T(1) / s_p, inv_s_g = T(1) / s_g, inv_s_q = T(1) / s_q;
@@ -729,6 +737,8 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
     uint32_t p[PPL], brow[PPL], at[PPL];
     bool live[PPL];
     lg_rows<PPL>(n0, np, K, p, live, brow);
+    const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
+    lg_stage_table<T, DP, 4>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
     T g[PPL];
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
@@ -738,100 +748,88 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
       g[r] = live[r] ? value : T(0);
       at[r] = p[r] * dx;
     }
-    T up[DP][PPL], uq[DP][PPL], ug[DP][PPL];
-    lg_offsets<T, DP, PPL>(mp, brow, up);
-    lg_offsets<T, DP, PPL>(mq, brow, uq);
-    lg_offsets<T, DP, PPL>(mg, brow, ug);
-    T yv[DP][PPL];
-#pragma unroll
-    for (int r = 0; r < PPL; ++r) {
-      const T *row = y + (int64_t)brow[r] * y_sb;
-#pragma unroll
-      for (int j = 0; j < DP; ++j) yv[j][r] = row[min(j, (int)dy - 1)];
-    }
-    __syncthreads();
-    // the three locations (K10's chains)
-#pragma unroll
-    for (int i = 0; i < DP; ++i) {
-      if ((uint32_t)i < dx) {
-        T xv[PPL];
-#pragma unroll
-        for (int r = 0; r < PPL; ++r) xv[r] = tprev[lg_pad(at[r] + i)];
-#pragma unroll
-        for (int j = 0; j < DP; ++j) {
-          const T a = wf[i * DP + j], q = wf[2 * DP * DP + i * DP + j];
-#pragma unroll
-          for (int r = 0; r < PPL; ++r) {
-            up[j][r] = fma_t(a, xv[r], up[j][r]);
-            uq[j][r] = fma_t(q, xv[r], uq[j][r]);
-          }
-        }
-      }
-    }
-    T xx[DP][PPL];
-#pragma unroll
-    for (int j = 0; j < DP; ++j)
-#pragma unroll
-      for (int r = 0; r < PPL; ++r) xx[j][r] = (uint32_t)j < dx ? tx[lg_pad(at[r] + min(j, (int)dx - 1))] : T(0);
-    lg_apply_regs<T, DP, PPL>(wf + DP * DP, xx, (int)dx, ug);
-    // locations -> gradients with respect to them; squared distances for the scales
-#pragma unroll
-    for (int r = 0; r < PPL; ++r) {
-      T qp = T(0), qq = T(0), qg = T(0);
-      const T gp = g[r] * inv_var_p, gq = g[r] * inv_var_q, gg = g[r] * inv_var_g;
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        const bool in_x = (uint32_t)j < dx, in_y = (uint32_t)j < dy;
-        const T dp = in_x ? xx[j][r] - up[j][r] : T(0);
-        const T dq = in_x ? xx[j][r] - uq[j][r] : T(0);
-        const T dg = in_y ? yv[j][r] - ug[j][r] : T(0);
-        qp = fma_t(dp, dp, qp);
-        qq = fma_t(dq, dq, qq);
-        qg = fma_t(dg, dg, qg);
-        up[j][r] = gp * dp;
-        uq[j][r] = -(gq * dq);
-        ug[j][r] = gg * dg;
-      }
-      scale_acc[0] += g[r] * (qp * inv_var_p * inv_s_p - T(dx) * inv_s_p);
-      scale_acc[1] += g[r] * (qg * inv_var_g * inv_s_g - T(dy) * inv_s_g);
-      scale_acc[2] -= g[r] * (qq * inv_var_q * inv_s_q - T(dx) * inv_s_q);
-    }
-    // latent gradients (held in registers until the tiles are free)
-    T gprev[DP][PPL], gcur[DP][PPL];
+    lg_lds_barrier();
+    T xx[DP][PPL], u[DP][PPL], gprev[DP][PPL], gcur[DP][PPL];
 #pragma unroll
     for (int j = 0; j < DP; ++j)
 #pragma unroll
       for (int r = 0; r < PPL; ++r) {
+        xx[j][r] = (uint32_t)j < dx ? tx[lg_pad(at[r] + min(j, (int)dx - 1))] : T(0);
         gprev[j][r] = T(0);
-        gcur[j][r] = -up[j][r] - uq[j][r];
       }
-    if (gxprev != nullptr) {
-      lg_apply_regs<T, DP, PPL>(wn, up, (int)dx, gprev);
-      lg_apply_regs<T, DP, PPL>(wn + 2 * DP * DP, uq, (int)dx, gprev);
+    // ---- transition term: u = g (x - loc_p) / s_p^2
+    lg_row_values<T, DP, PPL, 4, 0>(vec, true, tab, b0, brow, u);
+    lg_apply_tile<T, DP, PPL>(wf, tprev, at, (int)dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_p;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dx ? xx[j][r] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = scaled * diff;
+        gcur[j][r] = -u[j][r];
+      }
+      scale_acc[0] += g[r] * (q * inv_var_p * inv_s_p - T(dx) * inv_s_p);
     }
-    if (gx != nullptr) lg_apply_regs<T, DP, PPL>(wn + DP * DP, ug, (int)dy, gcur);
-    // weight gradients: one location's u at a time through the spare tile
-    lg_rows_to_tile<T, DP, PPL>(up, dx, p, live, tu);
-    __syncthreads();
+    if (gxprev != nullptr) lg_apply_regs<T, DP, PPL>(wn, u, (int)dx, gprev);
+    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu);
+    lg_lds_barrier();
     if (up_out != nullptr) lg_store_rows(up_out + n0 * dx, np * dx, tu);
     lg_outer_accumulate<T>(tu, dx, tprev, dx, np, acc_a);
-    __syncthreads();
-    lg_rows_to_tile<T, DP, PPL>(uq, dx, p, live, tu);
-    __syncthreads();
+    lg_lds_barrier();
+    // ---- proposal term (enters the log-weight with a minus sign): u = -g (x - loc_q) / s_q^2
+    lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
+    lg_apply_tile<T, DP, PPL>(wf + 2 * DP * DP, tprev, at, (int)dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_q;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dx ? xx[j][r] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = -(scaled * diff);
+        gcur[j][r] = gcur[j][r] - u[j][r];
+      }
+      scale_acc[2] -= g[r] * (q * inv_var_q * inv_s_q - T(dx) * inv_s_q);
+    }
+    if (gxprev != nullptr) lg_apply_regs<T, DP, PPL>(wn + 2 * DP * DP, u, (int)dx, gprev);
+    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu);
+    lg_lds_barrier();
     if (uq_out != nullptr) lg_store_rows(uq_out + n0 * dx, np * dx, tu);
     lg_outer_accumulate<T>(tu, dx, tprev, dx, np, acc_q);
-    __syncthreads();
-    lg_rows_to_tile<T, DP, PPL>(ug, dy, p, live, tu);
-    __syncthreads();
+    lg_lds_barrier();
+    // ---- emission term: u = g (y - loc_g) / s_g^2
+    lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
+    lg_apply_regs<T, DP, PPL>(wf + DP * DP, xx, (int)dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_g;
+      const T *yrow = tab + ((brow[r] - b0) * 4 + 3) * DP;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dy ? yrow[j] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = scaled * diff;
+      }
+      scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
+    }
+    if (gx != nullptr) lg_apply_regs<T, DP, PPL>(wn + DP * DP, u, (int)dy, gcur);
+    lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu);
+    lg_lds_barrier();
     if (ug_out != nullptr) lg_store_rows(ug_out + n0 * dy, np * dy, tu);
     lg_outer_accumulate<T>(tu, dy, tx, dx, np, acc_c);
-    __syncthreads();
+    lg_lds_barrier();
+    // ---- the two latent gradients leave through the input tiles
     if (gxprev != nullptr) lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev);
     if (gx != nullptr) lg_rows_to_tile<T, DP, PPL>(gcur, dx, p, live, tx);
-    __syncthreads();
+    lg_lds_barrier();
     if (gxprev != nullptr) lg_store_rows(gxprev + n0 * dx, np * dx, tprev);
     if (gx != nullptr) lg_store_rows(gx + n0 * dx, np * dx, tx);
-    __syncthreads();
+    lg_lds_barrier();
   }
   T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
   lg_outer_publish<T>(acc_a, scratch, record);
@@ -1078,7 +1076,7 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * ((size_t)dp * dp + 4 * 256 + lg_tile_elems(tp, dout) + lg_tile_elems(tp, din));
+    lds = sizeof(T) * (16 + (size_t)dp * dp + 4 * 256 + lg_tile_elems(tp, dout) + lg_tile_elems(tp, din));
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
@@ -1112,14 +1110,15 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
-  int ppl = 1;      // one particle per lane: two would spill (three locations' gradients and both latent gradients live)
+  int ppl = 1;     // two particles per lane measured slower (B=1024 K=4096 d=10: 870 against 650 us: spills)
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (6 * (size_t)dp * dp + 4 * 256 + 2 * lg_tile_elems(tp, dx) + lg_tile_elems(tp, std::max(dx, dy)));
-    if (lds <= (ppl > 1 ? (size_t)72 * 1024 : kLgLdsLimit)) break;
+    lds = sizeof(T) * (16 + 6 * (size_t)dp * dp + 4 * 256 + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems(tp, dx) +
+                       lg_tile_elems(tp, std::max(dx, dy)));
+    if (lds <= (ppl > 1 ? (size_t)78 * 1024 : kLgLdsLimit) && lg_rows_spanned((int64_t)tp, K) <= kLgRowsMax) break;
   }
-  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   const int grid = (int)std::min<int64_t>(tiles, kLgMaxGrid);
   if (ws_bytes < (size_t)grid * 4 * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;

@@ -19,7 +19,12 @@ for _ in range(3):
     k.affine_rsample(o["x_prev"], o["Q"], o["off_q"], o["eps"], o["s_q"])
     k.affine_logweight(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
                        (o["s_p"], o["s_g"], o["s_q"]))
-    if hasattr(k, "pmc_extra"):
-        k.pmc_extra(o)
+    k.particle_affine_backward(o["eps"], o["x_prev"], o["Q"])
+    lw = k.affine_logweight(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
+                            (o["s_p"], o["s_g"], o["s_q"]))
+    lse = k.logweight_lse(lw, None, None, want_lw=False)[1]
+    need = [True, True, False, True, False, True, False, True, True, False, False, False]
+    k.affine_logweight_backward(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
+                                (o["s_p"], o["s_g"], o["s_q"]), need, lw=lw, lse=lse, grad_lse=torch.ones_like(lse))
 torch.cuda.synchronize()
 print("done")
