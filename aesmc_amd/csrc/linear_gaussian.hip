@@ -552,7 +552,7 @@ template <> struct Mfma<double> {
 };
 
 constexpr int kLgRecord = 256;        // one 16 x 16 partial per matrix and workgroup
-constexpr int kLgMaxGrid = 512;       // persistent workgroups of the reducing kernels (two per CU)
+constexpr int kLgMaxGrid = 1024;      // most persistent workgroups of the reducing kernels (one record each)
 
 // acc[j][i] += sum_{p < np} tg[p][j] * tx[p][i] over a staged tile; the four wavefronts take particles
 // 4 w .. 4 w + 3 of every group of 16 (fixed assignment: the sums are reproducible).
@@ -904,7 +904,7 @@ constexpr size_t kLgLdsBudget = 64 * 1024;
 
 // Workgroups of a persistent launch: as many as are resident at once (by LDS; at most 8 per CU), so
 // each walks tiles blockIdx.x, blockIdx.x + grid, ... with the next one prefetched.
-static inline unsigned lg_persistent_grid(int64_t tiles, size_t lds_bytes) {
+static inline unsigned lg_persistent_grid(int64_t tiles, size_t lds_bytes, int max_per_cu = 8) {
   int device = 0, cus = 256;
   if (hipGetDevice(&device) == hipSuccess) {
     int value = 0;
@@ -912,7 +912,7 @@ static inline unsigned lg_persistent_grid(int64_t tiles, size_t lds_bytes) {
       cus = value;
   }
   int per_cu = (int)((size_t)160 * 1024 / (lds_bytes > 0 ? lds_bytes : 1));
-  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  per_cu = per_cu < 1 ? 1 : (per_cu > max_per_cu ? max_per_cu : per_cu);
   const int64_t resident = (int64_t)cus * per_cu;
   return (unsigned)(tiles < resident ? tiles : resident);
 }
@@ -1081,7 +1081,7 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
-  const int grid = (int)std::min<int64_t>(tiles, kLgMaxGrid);
+  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds), kLgMaxGrid);
   if (gw != nullptr && ws_bytes < (size_t)grid * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;
   LgMap adjoint;           // gx = g W: the map from the location's extent back to the input's
   adjoint.w = m->weight; adjoint.sj = m->stride_in; adjoint.si = m->stride_out;
@@ -1120,7 +1120,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
-  const int grid = (int)std::min<int64_t>(tiles, kLgMaxGrid);
+  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, 2), kLgMaxGrid);   // two workgroups per CU: registers
   if (ws_bytes < (size_t)grid * 4 * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;
   LgBackwardOut out;
   out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;

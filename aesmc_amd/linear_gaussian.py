@@ -16,9 +16,11 @@ evaluated lazily.  The callables return it in place of `Normal(source @ weight.T
 nothing else in the contract changes.  `state.sample` then draws with kernel K9 (location + noise in
 one pass) and `infer` weighs a step whose transition, emission and proposal are all AffineNormal with
 kernel K10 (three locations and the log-weight from x_{t-1} and x_t alone); any other consumer reads
-`.loc`, which kernel K8 materialises once (one fma chain per element — the same chain K9 and K10 run,
-so all routes give the same numbers bit for bit).  Maps wider than 16 are proper GEMMs and go to the
-library (`torch.matmul`).
+`.loc`, which kernel K8 materialises once.  Every location element is one chain of fused multiply-adds
+in a fixed order — the same chain in K8, K9 and K10, so a draw is the same bit for bit whichever
+route produced it; K10's log-density divides once per term where PyTorch (and K5) divide per element,
+so its log-weights agree with the materialised route to rounding (float64: ~1e-15 relative).  Maps
+wider than 16 are proper GEMMs and go to the library (`torch.matmul`).
 
 `particle_affine(x, weight, offset)` is K8 as a differentiable operator for models that need the
 location itself (e.g. `tanh(particle_affine(x, A))` of a nonlinear transition).
@@ -34,9 +36,13 @@ def particle_affine(x, weight, offset=None):
     """x @ weight.T + offset (offset [dout], or [B, dout] broadcast over particles) for particles
     x [B,K,din]; differentiable in all three.  Kernel K8 when the map is at most 16 x 16, the
     library's matmul otherwise."""
-    if _kernels.get().affine_covers(x, weight, offset):
+    provider = _kernels.get()
+    if provider.affine_covers(x, weight, offset):
         return _ops.particle_affine(x, weight, offset)
-    out = torch.matmul(x, weight.t())
+    if provider.name == "hip" and not (torch.is_tensor(x) and x.is_cuda):
+        raise RuntimeError("aesmc_amd: particle_affine operand lives on '{}'; this package computes only on a "
+                           "HIP device (MI355X) and has no CPU fallback.".format(getattr(x, "device", None)))
+    out = torch.matmul(x, weight.t())      # wider than 16 x 16 (or not [B,K,d]): the library's GEMM, on the device
     if offset is not None:
         out = out + (offset.unsqueeze(1) if offset.dim() == 2 else offset)
     return out
@@ -69,7 +75,11 @@ class AffineNormal(torch.distributions.Normal):
         if not torch.is_tensor(scale):
             scale = torch.as_tensor(scale, dtype=source.dtype, device=source.device)
         batch_shape = torch.Size(tuple(source.shape[:-1]) + (dout,))
-        if torch.broadcast_shapes(tuple(scale.shape), tuple(batch_shape)) != batch_shape:
+        try:
+            fits = torch.broadcast_shapes(tuple(scale.shape), tuple(batch_shape)) == batch_shape
+        except RuntimeError:
+            fits = False
+        if not fits:
             raise ValueError("AffineNormal: scale {} does not broadcast to {}".format(
                 tuple(scale.shape), tuple(batch_shape)))
         self.source, self.weight, self.offset = source, weight, offset

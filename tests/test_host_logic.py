@@ -469,3 +469,95 @@ def test_public_surface_matches_the_reference_signature_table():
             else:
                 assert p.default is not inspect.Parameter.empty, (qualified, p.name)
         assert all(p.default is not inspect.Parameter.empty for p in mine[len(want):]), qualified
+
+
+# ---- linear-Gaussian callables (AffineNormal) on the oracle backend ------------------------------------
+def test_affine_normal_is_a_normal_with_a_lazy_location(oracle_backend):
+    from aesmc_amd.linear_gaussian import AffineNormal
+    torch.manual_seed(0)
+    source, weight = torch.randn(3, 7, 4, dtype=torch.float64), torch.randn(5, 4, dtype=torch.float64)
+    offset, scale = torch.randn(3, 5, dtype=torch.float64), torch.tensor(0.4, dtype=torch.float64)
+    dist = AffineNormal(source, weight, scale, offset=offset)
+    assert isinstance(dist, torch.distributions.Normal) and dist._loc is None      # nothing evaluated yet
+    assert dist.batch_shape == (3, 7, 5) and dist.event_shape == () and dist.has_rsample
+    plain = torch.distributions.Normal(source @ weight.t() + offset.unsqueeze(1), scale)
+    torch.testing.assert_close(dist.loc, plain.loc, rtol=1e-13, atol=1e-13)
+    value = torch.randn(3, 7, 5, dtype=torch.float64)
+    torch.testing.assert_close(dist.log_prob(value), plain.log_prob(value), rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(dist.entropy(), plain.entropy())
+    with pytest.raises(ValueError):
+        AffineNormal(source, torch.randn(5, 3, dtype=torch.float64), scale)           # weight does not map source
+    with pytest.raises(ValueError):
+        AffineNormal(source, weight, scale, offset=torch.randn(7, 5, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        AffineNormal(source, weight, torch.ones(2, dtype=torch.float64))
+    shared = AffineNormal(source, weight, 0.4, offset=torch.zeros(5, dtype=torch.float64))
+    assert shared.scale.shape == (3, 7, 5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("algorithm", ["aesmc", "iwae"])
+def test_affine_callables_give_the_loss_and_gradients_of_matmul_callables(oracle_backend, dtype, algorithm):
+    """The same LGSSM stated both ways — Normal(x @ W.T + c, s) and AffineNormal(x, W, s, c) — through
+    get_loss + backward on the oracle backend: the fused route must be the one taken (K9 / K10 launches
+    counted) and give the same numbers (float64: indices identical, loss 1e-12, gradients 1e-9)."""
+    from aesmc_amd import _kernels
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    calls = {"affine_rsample": 0, "affine_logweight": 0, "affine_logweight_backward": 0}
+    originals = {name: getattr(provider, name) for name in calls}
+    for name in calls:
+        def spy(*args, _name=name, **kwargs):
+            calls[_name] += 1
+            return originals[_name](*args, **kwargs)
+        setattr(provider, name, spy)
+    results = {}
+    T = 5
+    for affine in (False, True):
+        model = LgssmNd(3, dtype=dtype, affine=affine).tune_proposal()
+        observations = model.simulate(T, 4, seed=1)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        loss = losses.get_loss(observations, 32, algorithm, model.initial, model.transition, model.emission,
+                               model.proposal)
+        loss.backward()
+        results[affine] = (loss.detach(), {name: p.grad.clone() for name, p in model.named_parameters()
+                                           if p.grad is not None})
+    assert calls["affine_rsample"] == T - 1
+    # importance sampling hands `transition` the list that already holds the current draw (the reference's
+    # aliasing, DESIGN.md section 4 item 10): its source is x_t, the proposal's x_{t-1} — not one
+    # linear-Gaussian step, so the locations are materialised there
+    fused_steps = T - 1 if algorithm == "aesmc" else 0
+    assert calls["affine_logweight"] == fused_steps and calls["affine_logweight_backward"] == fused_steps
+    (loss_a, grads_a), (loss_b, grads_b) = results[False], results[True]
+    loss_tol, grad_tol = (1e-12, 1e-9) if dtype == torch.float64 else (2e-5, 2e-3)
+    assert abs(float(loss_a - loss_b)) <= loss_tol * max(1.0, abs(float(loss_a)))
+    assert sorted(grads_a) == sorted(grads_b)
+    for name in grads_a:
+        scale = max(float(grads_a[name].abs().max()), 1e-30)
+        assert float((grads_a[name] - grads_b[name]).abs().max()) <= grad_tol * scale, name
+
+
+def test_affine_normal_outside_the_fused_route_materialises_its_location(oracle_backend):
+    """A step whose three terms are not all AffineNormal in the right tensors (here: the emission reads
+    a COPY of the latent) takes the ordinary route: `.loc` is evaluated and the numbers are the same."""
+    from aesmc_amd.linear_gaussian import AffineNormal
+    from aesmc_amd.testing.models import LgssmNd
+
+    class CopyingEmission(LgssmNd):
+        def emission(self, latents=None, time=None, previous_observations=None):
+            return self._tag(AffineNormal(latents[-1].clone(), self.C, self.emission_scale), "FULLY_EXPANDED")
+
+    outs = []
+    for cls in (LgssmNd, CopyingEmission):
+        model = cls(2, dtype=torch.float64, affine=True)
+        observations = model.simulate(4, 3, seed=2)
+        torch.manual_seed(1)
+        np.random.seed(1)
+        outs.append(inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                                    model.proposal, 16, return_log_marginal_likelihood=True,
+                                    return_ancestral_indices=True))
+    for a, b in zip(outs[0]["ancestral_indices"], outs[1]["ancestral_indices"]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(outs[0]["log_marginal_likelihood"], outs[1]["log_marginal_likelihood"],
+                               rtol=1e-12, atol=1e-12)

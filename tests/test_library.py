@@ -58,6 +58,19 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.aesmc_resample_gather(None, None, None, None, 1, 1, 4, 4, 4, None) == 1
     assert lib.aesmc_resample_gather(8, 8, 8, None, 1, 1 << 31, 4, 4, 4, None) == 2   # unsupported size
     assert lib.aesmc_resample_gather_backward(5, 8, 8, 8, None, 1, 1, 1, 0, None) == 1   # bad dtype tag
+    # linear-Gaussian propagation: NULL operands, a misaligned base pointer, a map wider than 16
+    assert lib.aesmc_affine_max_dim() == 16
+    assert lib.aesmc_particle_affine(0, None, None, None, None, None, None, 1, 1, None) == 1
+    amap = _lib.AffineMap(16, 4, 1, 0, 0, 4, 4)
+    assert lib.aesmc_particle_affine(0, 8, ctypes.byref(amap), None, None, None, 16, 1, 1, None) == 1   # x1 misaligned
+    wide = _lib.AffineMap(16, 17, 1, 0, 0, 17, 17)
+    assert lib.aesmc_particle_affine(0, 16, ctypes.byref(wide), None, None, None, 32, 1, 1, None) == 2
+    assert lib.aesmc_particle_affine(0, 16, ctypes.byref(amap), None, None, None, 32, 0, 5, None) == 0   # B == 0: no-op
+    assert lib.aesmc_affine_normal_rsample(0, 16, ctypes.byref(amap), 32, 48, 32, 1, 1, None) == 1      # out aliases eps
+    assert lib.aesmc_affine_normal_logweight(0, None, None, None, 0, None, None, None, None, None, None, None, 1, 1,
+                                             None) == 1
+    assert lib.aesmc_affine_backward_workspace_bytes(0) == 1024 * 4 * 256 * 4
+    assert lib.aesmc_particle_affine_backward(0, 16, 32, ctypes.byref(amap), None, 48, None, 0, 1, 1, None) == 1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
@@ -75,6 +88,11 @@ def test_product_refuses_cpu_tensors_loudly():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         inference.infer("smc", model.simulate(3, 2), model.initial, model.transition, model.emission,
                         model.proposal, 4)
+    from aesmc_amd.linear_gaussian import AffineNormal, particle_affine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        particle_affine(torch.zeros(2, 3, 4), torch.zeros(4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        AffineNormal(torch.zeros(2, 3, 4), torch.zeros(4, 4), torch.tensor(1.0)).loc
 
 
 def test_missing_library_is_an_error_not_a_fallback(monkeypatch):
