@@ -567,14 +567,21 @@ __device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, ui
   uint32_t p = wave * 4 + (lane >> 4);
   uint32_t eg = p * dg + col, ex = p * dxx + col;
   const uint32_t step_g = 16 * dg, step_x = 16 * dxx;
-  for (uint32_t p0 = wave * 4; p0 < np; p0 += 16) {
-    const bool live = p < np;
-    const T a = live ? tg[lg_pad(eg)] : T(0);
-    const T b = live ? tx[lg_pad(ex)] : T(0);
-    acc = Mfma<T>::fma(a, b, acc);
-    p += 16;
-    eg += step_g;
-    ex += step_x;
+  // four trips' operands are fetched before their four multiply-accumulates: the LDS latency is paid
+  // once per group, not once per MFMA (the accumulator chain is sequential either way)
+  for (uint32_t p0 = wave * 4; p0 < np; p0 += 64) {
+    T a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool live = p + 16 * t < np;
+      a[t] = live ? tg[lg_pad(eg + t * step_g)] : T(0);
+      b[t] = live ? tx[lg_pad(ex + t * step_x)] : T(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
+    p += 64;
+    eg += 4 * step_g;
+    ex += 4 * step_x;
   }
 }
 

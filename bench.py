@@ -540,6 +540,33 @@ def kernel_legs(ctx):
             unique_ancestor_fraction=round(unique, 4), achieved_moved_bytes=round(moved / us / 1e3, 1),
             frac_moved_bytes=round(min(moved / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4))
         del x
+    # linear-Gaussian propagation (K9 draw, K10 log-weight, K12 its backward, K11 the draw's adjoint) on
+    # N(0,1) particles: algorithmic bytes = the [B,K,d] tensors each must read and write once
+    for label, (B, K, d) in (("c4", (1024, 4096, 10)), ("c2", (256, 1024, 10))):
+        make = lambda *shape: torch.randn(*shape, device=dev, generator=gen)
+        x_prev, x, eps, y, off = make(B, K, d), make(B, K, d), make(B, K, d), make(B, d), make(B, d)
+        eye = torch.eye(d, device=dev)
+        A, C, Q = 0.9 * eye + 0.01 * make(d, d), eye + 0.01 * make(d, d), 0.45 * eye + 0.01 * make(d, d)
+        scales = tuple(torch.tensor(v, device=dev) for v in (1.0, 0.5, 0.7))
+        terms = ((A, None), (C, None), (Q, off))
+        shape = "B={} K={} d={}".format(B, K, d)
+        N = B * K
+        legs["K9_{}_affine_rsample".format(label)] = leg(
+            timeit(lambda: k.affine_rsample(x_prev, Q, off, eps, scales[2])), 4 * N * 3 * d, shape=shape)
+        legs["K10_{}_affine_logweight".format(label)] = leg(
+            timeit(lambda: k.affine_logweight(x_prev, x, y, *terms, scales)), 4 * N * (2 * d + 1), shape=shape)
+        lw = k.affine_logweight(x_prev, x, y, *terms, scales)
+        lse = k.logweight_lse(lw, None, None, want_lw=False)[1]
+        grad_lse = torch.full_like(lse, -1.0 / B)
+        need = [True, True, False, True, False, True, False, True, True, False, False, False]
+        legs["K12_{}_affine_logweight_backward".format(label)] = leg(
+            timeit(lambda: k.affine_logweight_backward(x_prev, x, y, *terms, scales, need, lw=lw, lse=lse,
+                                                       grad_lse=grad_lse), reps=5),
+            4 * N * (5 * d + 1), shape=shape + " (x_prev, x, lw in; both latent gradients and the proposal "
+                                               "offset's per-particle gradient out)")
+        legs["K11_{}_affine_adjoint".format(label)] = leg(
+            timeit(lambda: k.particle_affine_backward(eps, x_prev, Q), reps=5), 4 * N * 3 * d, shape=shape)
+        del x_prev, x, eps, lw
     torch.cuda.empty_cache()
     return legs
 
