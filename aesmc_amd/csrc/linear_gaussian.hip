@@ -994,6 +994,10 @@ static constexpr auto affine_logweight_tab_prefetch = &affine_logweight_kernel<T
 template <typename T, int DP, int PPL>
 static constexpr auto affine_logweight_rows = &affine_logweight_kernel<T, DP, PPL, false, false>;
 
+// With 512-particle tiles a launch of fewer than ~1M particles leaves each CU with at most two or three
+// workgroups of one tile each: all latency.  256-particle tiles double the workgroups.
+static inline bool lg_few_tiles(int64_t N) { return N < ((int64_t)1 << 20); }
+
 // Batch rows a tile of `tp` consecutive particles can span.
 static inline int64_t lg_rows_spanned(int64_t tp, int64_t K) { return (tp - 1) / K + 2; }
 
@@ -1010,10 +1014,15 @@ static int launch_affine_rsample(const void *src, const aesmc_affine_map *m, con
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  if (ppl == 2 && lg_few_tiles(N)) ppl = 1;      // small launches: twice the workgroups, half the tile each
   bool tab = lg_rows_spanned((int64_t)kLgBlock * ppl, K) <= kLgRowsMax;
   if (!tab && ppl == 2) {      // few particles per batch row: one particle per lane, rows from global memory
     ppl = 1;
     tab = lg_rows_spanned(kLgBlock, K) <= kLgRowsMax;
+  }
+  {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * ((size_t)dp * dp + (size_t)kLgRowsMax * dp + lg_tile_elems(tp, m->din) + lg_tile_elems(tp, m->dout));
   }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
@@ -1044,10 +1053,15 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
+  if (ppl == 2 && lg_few_tiles(N)) ppl = 1;
   bool tab = lg_rows_spanned((int64_t)kLgBlock * ppl, K) <= kLgRowsMax;
   if (!tab && ppl == 2) {
     ppl = 1;
     tab = lg_rows_spanned(kLgBlock, K) <= kLgRowsMax;
+  }
+  {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * (3 * (size_t)dp * dp + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems(tp, dx));
   }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;

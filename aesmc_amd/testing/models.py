@@ -182,12 +182,27 @@ class LgssmNd(nn.Module):
         if time == 0:
             loc = observations[0] @ self.W0.t() + self.b0
             return self._tag(self._normal(loc, self.proposal_scale), "BATCH_EXPANDED")
-        from_observation = observations[time] @ self.Wy.t() + self.b      # [B, d]: shared by a row's particles
+        from_observation = self._observation_terms(observations, time)[time]   # [B, d]: shared by a row's particles
         if self.affine:
             return self._tag(self._affine_normal(previous_latents[-1], self.Wx, self.proposal_scale,
                                                  offset=from_observation), "FULLY_EXPANDED")
         loc = previous_latents[-1] @ self.Wx.t() + from_observation.unsqueeze(1)
         return self._tag(self._normal(loc, self.proposal_scale), "FULLY_EXPANDED")
+
+    def _observation_terms(self, observations, time):
+        """Wy y_t + b for every timestep in ONE matmul: the proposal is handed the whole observation
+        sequence at each step, so the first step that needs the term (time 1 of every `infer`) computes
+        it for all of them and the later steps of that run slice it — two small launches per timestep
+        less.  Never kept across runs (its autograd graph belongs to the run that made it)."""
+        cached = getattr(self, "_obs_terms", None)
+        if time == 1 or cached is None or cached[0] is not observations:
+            stacked = observations if torch.is_tensor(observations) else torch.stack(list(observations))
+            cached = (observations, stacked @ self.Wy.t() + self.b)
+        # dropped with the last step: a tensor that outlives the run keeps the run's autograd graph (and
+        # the parameters' AccumulateGrad nodes) alive, which a later hipGraph capture of a backward
+        # pass cannot tolerate (aesmc_amd/graphs.py)
+        self._obs_terms = None if time + 1 >= len(observations) else cached
+        return cached[1]
 
     @torch.no_grad()
     def tune_proposal(self):
