@@ -27,7 +27,8 @@ def main(workload, proposal, timesteps=6):
     description, kind, dim, B, K, T, model_kwargs = bench.WORKLOADS[workload]
     device = torch.device("cuda", 0)
     k = _kernels.get()
-    model = bench.build_model(kind, dim, device, aesmc_amd.state, proposal, **model_kwargs)
+    model = bench.build_model(kind, dim, device, aesmc_amd.state, proposal, os.environ.get("AESMC_CALLABLES", "affine"),
+                              **model_kwargs)
     observations = model.simulate(T, B, seed=1)[:timesteps]
     value = torch.randn(B, K, dim, device=device)
     identity = torch.arange(K, device=device).unsqueeze(0).expand(B, K).contiguous()

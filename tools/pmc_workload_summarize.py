@@ -17,7 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 KERNELS = {"resample_step": "ancestor_index_inv_kernel", "resample_gather": "resample_gather_kernel",
-           "normal_logweight": "normal_logweight", "normal_rsample": "normal_rsample"}
+           "normal_logweight": "normal_logweight", "normal_rsample": "normal_rsample",
+           "affine_normal_rsample": "affine_rsample_kernel", "affine_normal_logweight": "affine_logweight_kernel"}
 
 
 def per_dispatch(path, counter, kernel):
@@ -40,7 +41,8 @@ def main(workload, proposal, fetch_csv, write_csv, out_json):
               "timesteps of bench.py's seeded workload; FETCH_SIZE x{:.3f}, WRITE_SIZE x{:.3f} as calibrated on "
               "identity-index gathers of the same shape").format(workload, proposal, f_factor, w_factor)
     entry = {"calibration": {"fetch_factor": f_factor, "write_factor": w_factor}}
-    algorithmic = {"resample_step": B * K * (20 + 8 * dim) + 8 * B, "resample_gather": B * K * (8 + 8 * dim)}
+    algorithmic = {"resample_step": B * K * (20 + 8 * dim) + 8 * B, "resample_gather": B * K * (8 + 8 * dim),
+                   "affine_normal_rsample": B * K * 12 * dim, "affine_normal_logweight": B * K * (8 * dim + 4)}
     for key, kernel in KERNELS.items():
         skip = 3 if key == "resample_gather" else 0
         fetch = per_dispatch(fetch_csv, "FETCH_SIZE", kernel)[skip:]
