@@ -585,6 +585,41 @@ __device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, ui
   }
 }
 
+// The same sum over a wavefront's OWN 64 particles (lane = particle mapping of the one-particle-per-lane
+// kernels: rows 64 w .. 64 w + 63 of the tiles were written and are read by this wavefront alone), so the
+// caller needs no workgroup barrier around it — a wavefront-level fence orders its LDS writes and reads.
+template <typename T>
+__device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg, uint32_t dg,
+                                                        const T *__restrict__ tx, uint32_t dxx, uint32_t np,
+                                                        typename Mfma<T>::Acc &acc) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t col = lane & 15u;
+  uint32_t p = wave * 64 + (lane >> 4);
+  uint32_t eg = p * dg + col, ex = p * dxx + col;
+  const uint32_t step_g = 4 * dg, step_x = 4 * dxx;
+#pragma unroll
+  for (int group = 0; group < 4; ++group) {
+    T a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool live = p + 4 * t < np;
+      a[t] = live ? tg[lg_pad(eg + t * step_g)] : T(0);
+      b[t] = live ? tx[lg_pad(ex + t * step_x)] : T(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
+    p += 16;
+    eg += 4 * step_g;
+    ex += 4 * step_x;
+  }
+}
+
+__device__ __forceinline__ void lg_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
 // The workgroup's four partial accumulators summed (wavefront 0 .. 3 in turn) into record[0 .. 255],
 // element j * 16 + i.  `scratch` holds 4 x 256 values.
 template <typename T>
@@ -694,6 +729,23 @@ __device__ __forceinline__ void lg_rows_to_tile(const T (&v)[DP][PPL], uint32_t 
   }
 }
 
+// One particle per lane: a wavefront's rows of the u tile are its own, so only a launch that also
+// STORES the tile (cooperatively, all lanes) needs workgroup barriers around it.
+template <int PPL> __device__ __forceinline__ void lg_u_ready(bool stored) {
+  if (PPL != 1 || stored) lg_lds_barrier();
+  else lg_wave_fence();
+}
+template <int PPL> __device__ __forceinline__ void lg_u_done(bool stored) {
+  if (PPL != 1 || stored) lg_lds_barrier();
+  else lg_wave_fence();
+}
+template <typename T, int PPL>
+__device__ __forceinline__ void lg_outer_term(const T *__restrict__ tg, uint32_t dg, const T *__restrict__ tx,
+                                              uint32_t dxx, uint32_t np, typename Mfma<T>::Acc &acc) {
+  if (PPL == 1) lg_outer_accumulate_own<T>(tg, dg, tx, dxx, np, acc);
+  else lg_outer_accumulate<T>(tg, dg, tx, dxx, np, acc);
+}
+
 struct LgBackwardOut {
   void *gxprev, *gx, *up, *ug, *uq, *ws;
 };
@@ -782,10 +834,10 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
     }
     if (gxprev != nullptr) lg_apply_regs<T, DP, PPL>(wn, u, (int)dx, gprev);
     lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu);
-    lg_lds_barrier();
+    lg_u_ready<PPL>(up_out != nullptr);
     if (up_out != nullptr) lg_store_rows(up_out + n0 * dx, np * dx, tu);
-    lg_outer_accumulate<T>(tu, dx, tprev, dx, np, acc_a);
-    lg_lds_barrier();
+    lg_outer_term<T, PPL>(tu, dx, tprev, dx, np, acc_a);
+    lg_u_done<PPL>(up_out != nullptr);
     // ---- proposal term (enters the log-weight with a minus sign): u = -g (x - loc_q) / s_q^2
     lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
     lg_apply_tile<T, DP, PPL>(wf + 2 * DP * DP, tprev, at, (int)dx, u);
@@ -804,10 +856,10 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
     }
     if (gxprev != nullptr) lg_apply_regs<T, DP, PPL>(wn + 2 * DP * DP, u, (int)dx, gprev);
     lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu);
-    lg_lds_barrier();
+    lg_u_ready<PPL>(uq_out != nullptr);
     if (uq_out != nullptr) lg_store_rows(uq_out + n0 * dx, np * dx, tu);
-    lg_outer_accumulate<T>(tu, dx, tprev, dx, np, acc_q);
-    lg_lds_barrier();
+    lg_outer_term<T, PPL>(tu, dx, tprev, dx, np, acc_q);
+    lg_u_done<PPL>(uq_out != nullptr);
     // ---- emission term: u = g (y - loc_g) / s_g^2
     lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
     lg_apply_regs<T, DP, PPL>(wf + DP * DP, xx, (int)dx, u);
@@ -826,10 +878,10 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
     }
     if (gx != nullptr) lg_apply_regs<T, DP, PPL>(wn + DP * DP, u, (int)dy, gcur);
     lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu);
-    lg_lds_barrier();
+    lg_u_ready<PPL>(ug_out != nullptr);
     if (ug_out != nullptr) lg_store_rows(ug_out + n0 * dy, np * dy, tu);
-    lg_outer_accumulate<T>(tu, dy, tx, dx, np, acc_c);
-    lg_lds_barrier();
+    lg_outer_term<T, PPL>(tu, dy, tx, dx, np, acc_c);
+    lg_u_done<PPL>(ug_out != nullptr);
     // ---- the two latent gradients leave through the input tiles
     if (gxprev != nullptr) lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev);
     if (gx != nullptr) lg_rows_to_tile<T, DP, PPL>(gcur, dx, p, live, tx);
