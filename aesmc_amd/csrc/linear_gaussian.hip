@@ -30,10 +30,29 @@ namespace aesmc {
 constexpr int kLgBlock = 256;
 constexpr int kLgMaxDim = 16;
 
-__device__ __forceinline__ uint32_t lg_pad(uint32_t e) { return e + (e >> 5); }
-static inline size_t lg_tile_elems(size_t particles, size_t d) {
-  const size_t ne = particles * d;
-  return ne + (ne >> 5) + 1;
+// A staged tile keeps its rows apart by `rs` elements: rs = d, a flat copy of the [np, d] block in HBM,
+// unless the rows are whole 16-byte vectors of floats (d % 4 == 0), whose power-of-two-ish strides would
+// put a wavefront's row reads on a few LDS banks — those get one 16-byte pad per row (rs = d + 4).
+// Either way a 16-byte vector of the block is ONE 16-byte LDS access and a lane's element (p, i) sits at
+// p * rs + i: a row base per particle, immediate offsets per element, no per-element index arithmetic.
+struct LgLayout {
+  uint32_t rs;    // row stride in elements
+  uint32_t mul;   // padded rows: ceil(2^17 / (d / 4)), so (v * mul) >> 17 == v / (d / 4) for v < 2^15; else 0
+};
+template <typename T> __host__ __device__ __forceinline__ LgLayout lg_layout(uint32_t d) {
+  LgLayout l;
+  const bool padded = sizeof(T) == 4 && d != 0 && (d & 3u) == 0;
+  l.rs = padded ? d + 4 : d;
+  l.mul = padded ? (131072u + d / 4 - 1) / (d / 4) : 0u;
+  return l;
+}
+// vector v of the flat block -> vector slot in the tile
+__device__ __forceinline__ uint32_t lg_slot(uint32_t v, const LgLayout &l) {
+  return l.mul != 0 ? v + ((v * l.mul) >> 17) : v;
+}
+// elements a tile of `particles` rows occupies (+16: the matrix-core operand reads run past a row's end)
+template <typename T> static inline size_t lg_tile_elems(size_t particles, size_t d) {
+  return particles * lg_layout<T>((uint32_t)d).rs + 16;
 }
 
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -56,35 +75,28 @@ struct LgMap {
   int32_t dout, din;
 };
 
-// [np, d] rows, contiguous in HBM from `src`, into a padded LDS tile; 16-byte loads (src is 16-byte
-// aligned: tiles start at multiples of 256 particles).
+// [np, d] rows, contiguous in HBM from `src` (16-byte aligned: tiles start at multiples of 256
+// particles), into a tile: 16-byte loads, 16-byte LDS stores.
 template <typename T>
 __device__ __forceinline__ void lg_stage_rows(const T *__restrict__ src, uint32_t ne, T *__restrict__ tile,
-                                              int stream) {
+                                              const LgLayout &l, int stream) {
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const uint32_t nvec = ne / N;
-  for (uint32_t v = threadIdx.x; v < nvec; v += kLgBlock) {
-    const V t = load16(reinterpret_cast<const V *>(src) + v, stream);
-#pragma unroll
-    for (int r = 0; r < N; ++r) tile[lg_pad(v * N + r)] = Vec16<T>::get(t, r);
-  }
-  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[lg_pad(e)] = src[e];
+  for (uint32_t v = threadIdx.x; v < nvec; v += kLgBlock)
+    reinterpret_cast<V *>(tile)[lg_slot(v, l)] = load16(reinterpret_cast<const V *>(src) + v, stream);
+  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[e] = src[e];   // unpadded layouts only
 }
 
 template <typename T>
-__device__ __forceinline__ void lg_store_rows(T *__restrict__ dst, uint32_t ne, const T *__restrict__ tile) {
+__device__ __forceinline__ void lg_store_rows(T *__restrict__ dst, uint32_t ne, const T *__restrict__ tile,
+                                              const LgLayout &l) {
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const uint32_t nvec = ne / N;
-  for (uint32_t v = threadIdx.x; v < nvec; v += kLgBlock) {
-    V t;
-    T *tv = reinterpret_cast<T *>(&t);
-#pragma unroll
-    for (int r = 0; r < N; ++r) tv[r] = tile[lg_pad(v * N + r)];
-    reinterpret_cast<V *>(dst)[v] = t;
-  }
-  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) dst[e] = tile[lg_pad(e)];
+  for (uint32_t v = threadIdx.x; v < nvec; v += kLgBlock)
+    reinterpret_cast<V *>(dst)[v] = reinterpret_cast<const V *>(tile)[lg_slot(v, l)];
+  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) dst[e] = tile[e];
 }
 
 // Weight [dout, din] (any strides) zero-padded and TRANSPOSED in LDS: wt[i * DP + j] = W[j][i], so the
@@ -144,7 +156,7 @@ __device__ __forceinline__ void lg_apply_tile(const T *__restrict__ wt, const T 
     if (i < din) {
       T xv[PPL];
   #pragma unroll
-      for (int r = 0; r < PPL; ++r) xv[r] = tile[lg_pad(base[r] + i)];
+      for (int r = 0; r < PPL; ++r) xv[r] = tile[base[r] + i];
   #pragma unroll
       for (int j = 0; j < DP; ++j) {
         const T w = wt[i * DP + j];
@@ -167,17 +179,18 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_kernel(const T *__re
   T *w1 = reinterpret_cast<T *>(lg_smem);
   T *w2 = w1 + DP * DP;
   T *t1 = w2 + DP * DP;
-  T *t2 = t1 + (TP * d1 + ((TP * d1) >> 5) + 1);
-  T *to = t2 + (TP * d2 + ((TP * d2) >> 5) + 1);
+  const LgLayout l1 = lg_layout<T>(d1), l2 = lg_layout<T>(d2), lo = lg_layout<T>(dout);
+  T *t2 = t1 + (TP * l1.rs + 16);
+  T *to = t2 + (TP * l2.rs + 16);
   const int64_t n0 = (int64_t)blockIdx.x * TP;
   const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
   lg_stage_weight<T, DP>(m1, w1);
-  lg_stage_rows(x1 + n0 * d1, np * d1, t1, stream);
+  lg_stage_rows(x1 + n0 * d1, np * d1, t1, l1, stream);
   if (x2 != nullptr) {
     lg_stage_weight<T, DP>(m2, w2);
-    lg_stage_rows(x2 + n0 * d2, np * d2, t2, stream);
+    lg_stage_rows(x2 + n0 * d2, np * d2, t2, l2, stream);
   }
-  if (base != nullptr) lg_stage_rows(base + n0 * dout, np * dout, to, stream);
+  if (base != nullptr) lg_stage_rows(base + n0 * dout, np * dout, to, lo, stream);
   uint32_t p[PPL], brow[PPL], at[PPL];
   bool live[PPL];
   lg_rows<PPL>(n0, np, K, p, live, brow);
@@ -185,11 +198,11 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_kernel(const T *__re
   lg_offsets<T, DP, PPL>(m1, brow, acc);
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < PPL; ++r) at[r] = p[r] * d1;
+  for (int r = 0; r < PPL; ++r) at[r] = p[r] * l1.rs;
   lg_apply_tile<T, DP, PPL>(w1, t1, at, (int)d1, acc);
   if (x2 != nullptr) {
 #pragma unroll
-    for (int r = 0; r < PPL; ++r) at[r] = p[r] * d2;
+    for (int r = 0; r < PPL; ++r) at[r] = p[r] * l2.rs;
     lg_apply_tile<T, DP, PPL>(w2, t2, at, (int)d2, acc);
   }
 #pragma unroll
@@ -198,14 +211,14 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_kernel(const T *__re
   #pragma unroll
       for (int r = 0; r < PPL; ++r) {
         if (live[r]) {
-          const uint32_t slot = lg_pad(p[r] * dout + j);
+          const uint32_t slot = p[r] * lo.rs + j;
           to[slot] = base != nullptr ? to[slot] + acc[j][r] : acc[j][r];
         }
       }
     }
   }
   __syncthreads();
-  lg_store_rows(out + n0 * dout, np * dout, to);
+  lg_store_rows(out + n0 * dout, np * dout, to, lo);
 }
 
 // ---- per-batch-row vectors (offsets, the observation) of a tile ------------------------------------------
@@ -297,18 +310,17 @@ __device__ __forceinline__ void lg_prefetch(const T *__restrict__ src, uint32_t 
 
 template <typename T, int NV>
 __device__ __forceinline__ void lg_commit(const T *__restrict__ src, uint32_t ne,
-                                          const typename Vec16<T>::type (&regs)[NV], T *__restrict__ tile) {
+                                          const typename Vec16<T>::type (&regs)[NV], T *__restrict__ tile,
+                                          const LgLayout &l) {
   constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
   const uint32_t nvec = ne / N;
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
     const uint32_t v = threadIdx.x + s * kLgBlock;
-    if (v < nvec) {
-#pragma unroll
-      for (int r = 0; r < N; ++r) tile[lg_pad(v * N + r)] = Vec16<T>::get(regs[s], r);
-    }
+    if (v < nvec) reinterpret_cast<V *>(tile)[lg_slot(v, l)] = regs[s];
   }
-  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[lg_pad(e)] = src[e];   // last tile only
+  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[e] = src[e];   // last tile only
 }
 
 // ---- K9 ----------------------------------------------------------------------------------------
@@ -326,7 +338,8 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_rsample_kernel(const T *__
   T *wl = reinterpret_cast<T *>(lg_smem);
   T *tab = wl + DP * DP;                             // [kLgRowsMax][1][DP]
   T *ts = tab + kLgRowsMax * DP;
-  T *te = ts + (TP * din + ((TP * din) >> 5) + 1);   // the noise, then the draw in its place
+  const LgLayout ls = lg_layout<T>(din), le = lg_layout<T>(dout);
+  T *te = ts + (TP * ls.rs + 16);   // the noise, then the draw in its place
   const T scale = scale_ptr[0];
   lg_stage_weight<T, DP>(m, wl);
   const LgRowVec<T> vec[1] = {lg_offset_vec<T>(m)};
@@ -341,8 +354,8 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_rsample_kernel(const T *__
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    lg_commit<T, NV>(src + n0 * din, np * din, rs, ts);
-    lg_commit<T, NV>(eps + n0 * dout, np * dout, re, te);
+    lg_commit<T, NV>(src + n0 * din, np * din, rs, ts, ls);
+    lg_commit<T, NV>(eps + n0 * dout, np * dout, re, te, le);
     uint32_t p[PPL], brow[PPL], at[PPL];
     bool live[PPL];
     lg_rows<PPL>(n0, np, K, p, live, brow);
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_rsample_kernel(const T *__
     }
     if (use_tab) lg_row_values<T, DP, PPL, 1, 0>(vec, true, tab, b0, brow, acc);
 #pragma unroll
-    for (int r = 0; r < PPL; ++r) at[r] = p[r] * din;
+    for (int r = 0; r < PPL; ++r) at[r] = p[r] * ls.rs;
     lg_apply_tile<T, DP, PPL>(wl, ts, at, (int)din, acc);
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
@@ -369,14 +382,14 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_rsample_kernel(const T *__
 #pragma unroll
         for (int r = 0; r < PPL; ++r) {
           if (live[r]) {
-            const uint32_t slot = lg_pad(p[r] * dout + j);
+            const uint32_t slot = p[r] * le.rs + j;
             te[slot] = acc[j][r] + te[slot] * scale;   // the product rounded before the sum, as K6
           }
         }
       }
     }
     lg_lds_barrier();
-    lg_store_rows(out + n0 * dout, np * dout, te);
+    lg_store_rows(out + n0 * dout, np * dout, te, le);
     lg_lds_barrier();
   }
 }
@@ -401,7 +414,8 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
   T *wq = wg + DP * DP;
   T *tab = wq + DP * DP;                             // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
   T *tprev = tab + kLgRowsMax * 4 * DP;
-  T *tx = tprev + (TP * dx + ((TP * dx) >> 5) + 1);
+  const LgLayout lx = lg_layout<T>(dx);
+  T *tx = tprev + (TP * lx.rs + 16);
   const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
   lg_stage_weight<T, DP>(mp, wp);
   lg_stage_weight<T, DP>(mg, wg);
@@ -423,11 +437,11 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
     if constexpr (PREFETCH) {
-      lg_commit<T, NV>(xprev + n0 * dx, np * dx, rp, tprev);
-      lg_commit<T, NV>(x + n0 * dx, np * dx, rx, tx);
+      lg_commit<T, NV>(xprev + n0 * dx, np * dx, rp, tprev, lx);
+      lg_commit<T, NV>(x + n0 * dx, np * dx, rx, tx, lx);
     } else {
-      lg_stage_rows(xprev + n0 * dx, np * dx, tprev, 0);
-      lg_stage_rows(x + n0 * dx, np * dx, tx, 0);
+      lg_stage_rows(xprev + n0 * dx, np * dx, tprev, lx, 0);
+      lg_stage_rows(x + n0 * dx, np * dx, tx, lx, 0);
     }
     uint32_t p[PPL], brow[PPL], at[PPL];
     bool live[PPL];
@@ -458,14 +472,14 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
       lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, locq);
     }
 #pragma unroll
-    for (int r = 0; r < PPL; ++r) at[r] = p[r] * dx;
+    for (int r = 0; r < PPL; ++r) at[r] = p[r] * lx.rs;
     // transition and proposal locations from x_prev, one pass over its elements
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
       if ((uint32_t)i < dx) {
         T xv[PPL];
 #pragma unroll
-        for (int r = 0; r < PPL; ++r) xv[r] = tprev[lg_pad(at[r] + i)];
+        for (int r = 0; r < PPL; ++r) xv[r] = tprev[at[r] + i];
 #pragma unroll
         for (int j = 0; j < DP; ++j) {
           const T a = wp[i * DP + j], q = wq[i * DP + j];
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
       if ((uint32_t)j < dx) {
 #pragma unroll
         for (int r = 0; r < PPL; ++r) {
-          xx[j][r] = tx[lg_pad(at[r] + j)];
+          xx[j][r] = tx[at[r] + j];
           const T dp = xx[j][r] - locp[j][r], dq = xx[j][r] - locq[j][r];
           qp[r] = fma_t(dp, dp, qp[r]);
           qq[r] = fma_t(dq, dq, qq[r]);
@@ -559,6 +573,7 @@ constexpr int kLgMaxGrid = 1024;      // most persistent workgroups of the reduc
 template <typename T>
 __device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, uint32_t dg, const T *__restrict__ tx,
                                                     uint32_t dxx, uint32_t np, typename Mfma<T>::Acc &acc) {
+  // dg, dxx: the ROW STRIDES of the two tiles (LgLayout::rs)
   // Lane (quad, col) feeds value `col` of particle 4 w + quad (+ 16 per trip).  Columns at or past a row's
   // extent read the neighbouring row: that only reaches accumulator rows / columns >= the extents,
   // which nobody reads, so there is no per-column mask; particles past the tile's end are masked.
@@ -574,8 +589,8 @@ __device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, ui
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const bool live = p + 16 * t < np;
-      a[t] = live ? tg[lg_pad(eg + t * step_g)] : T(0);
-      b[t] = live ? tx[lg_pad(ex + t * step_x)] : T(0);
+      a[t] = live ? tg[eg + t * step_g] : T(0);
+      b[t] = live ? tx[ex + t * step_x] : T(0);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
@@ -592,6 +607,7 @@ template <typename T>
 __device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg, uint32_t dg,
                                                         const T *__restrict__ tx, uint32_t dxx, uint32_t np,
                                                         typename Mfma<T>::Acc &acc) {
+  // dg, dxx: the ROW STRIDES of the two tiles (LgLayout::rs)
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t col = lane & 15u;
   uint32_t p = wave * 64 + (lane >> 4);
@@ -603,8 +619,8 @@ __device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const bool live = p + 4 * t < np;
-      a[t] = live ? tg[lg_pad(eg + t * step_g)] : T(0);
-      b[t] = live ? tx[lg_pad(ex + t * step_x)] : T(0);
+      a[t] = live ? tg[eg + t * step_g] : T(0);
+      b[t] = live ? tx[ex + t * step_x] : T(0);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
@@ -645,15 +661,16 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
   T *wt = reinterpret_cast<T *>(lg_smem);
   T *scratch = wt + DP * DP;                               // 4 x 256
   T *tg = scratch + 4 * 256;
-  T *tx = tg + (TP * dg + ((TP * dg) >> 5) + 1);
+  const LgLayout lg = lg_layout<T>(dg), lxx = lg_layout<T>(dxx);
+  T *tx = tg + (TP * lg.rs + 16);
   typename Mfma<T>::Acc acc = {T(0), T(0), T(0), T(0)};
   if (gx != nullptr) lg_stage_weight<T, DP>(adjoint, wt);
   const int64_t tiles = (N + TP - 1) / TP;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    lg_stage_rows(g + n0 * dg, np * dg, tg, 1);
-    if (want_w) lg_stage_rows(x + n0 * dxx, np * dxx, tx, 0);
+    lg_stage_rows(g + n0 * dg, np * dg, tg, lg, 1);
+    if (want_w) lg_stage_rows(x + n0 * dxx, np * dxx, tx, lxx, 0);
     __syncthreads();
     T out[DP][PPL];
     uint32_t p[PPL], at[PPL];
@@ -663,7 +680,7 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
       const uint32_t q = threadIdx.x + r * kLgBlock;
       live[r] = q < np;
       p[r] = live[r] ? q : 0u;
-      at[r] = p[r] * dg;
+      at[r] = p[r] * lg.rs;
     }
     if (gx != nullptr) {
 #pragma unroll
@@ -672,7 +689,7 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
         for (int r = 0; r < PPL; ++r) out[j][r] = T(0);
       lg_apply_tile<T, DP, PPL>(wt, tg, at, (int)dg, out);
     }
-    if (want_w) lg_outer_accumulate<T>(tg, dg, tx, dxx, np, acc);
+    if (want_w) lg_outer_accumulate<T>(tg, lg.rs, tx, lxx.rs, np, acc);
     if (gx != nullptr) {
       __syncthreads();                                     // every wavefront is done reading tx
 #pragma unroll
@@ -680,11 +697,11 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
         if ((uint32_t)j < dxx) {
 #pragma unroll
           for (int r = 0; r < PPL; ++r)
-            if (live[r]) tx[lg_pad(p[r] * dxx + j)] = out[j][r];
+            if (live[r]) tx[p[r] * lxx.rs + j] = out[j][r];
         }
       }
       __syncthreads();
-      lg_store_rows(gx + n0 * dxx, np * dxx, tx);
+      lg_store_rows(gx + n0 * dxx, np * dxx, tx, lxx);
     }
     __syncthreads();
   }
@@ -718,13 +735,13 @@ __device__ __forceinline__ void lg_apply_regs(const T *__restrict__ wt, const T 
 
 template <typename T, int DP, int PPL>
 __device__ __forceinline__ void lg_rows_to_tile(const T (&v)[DP][PPL], uint32_t d, const uint32_t (&p)[PPL],
-                                                const bool (&live)[PPL], T *__restrict__ tile) {
+                                                const bool (&live)[PPL], T *__restrict__ tile, const LgLayout &l) {
 #pragma unroll
   for (int j = 0; j < DP; ++j) {
     if ((uint32_t)j < d) {
 #pragma unroll
       for (int r = 0; r < PPL; ++r)
-        if (live[r]) tile[lg_pad(p[r] * d + j)] = v[j][r];
+        if (live[r]) tile[p[r] * l.rs + j] = v[j][r];
     }
   }
 }
@@ -764,8 +781,9 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
   T *scratch = wn + 3 * DP * DP;                 // 4 x 256
   T *tab = scratch + 4 * 256;                    // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
   T *tprev = tab + kLgRowsMax * 4 * DP;
-  T *tx = tprev + (TP * dx + ((TP * dx) >> 5) + 1);
-  T *tu = tx + (TP * dx + ((TP * dx) >> 5) + 1);  // [TP * max(dx, dy)]
+  const LgLayout lx = lg_layout<T>(dx), ly = lg_layout<T>(dy);
+  T *tx = tprev + (TP * lx.rs + 16);
+  T *tu = tx + (TP * lx.rs + 16);  // [TP * max(dx, dy)]
   {
     lg_stage_weight<T, DP>(mp, wf);
     lg_stage_weight<T, DP>(mg, wf + DP * DP);
@@ -791,8 +809,8 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    lg_stage_rows(xprev + n0 * dx, np * dx, tprev, 0);
-    lg_stage_rows(x + n0 * dx, np * dx, tx, 0);
+    lg_stage_rows(xprev + n0 * dx, np * dx, tprev, lx, 0);
+    lg_stage_rows(x + n0 * dx, np * dx, tx, lx, 0);
     uint32_t p[PPL], brow[PPL], at[PPL];
     bool live[PPL];
     lg_rows<PPL>(n0, np, K, p, live, brow);
@@ -805,7 +823,7 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
       T value = grad_lw != nullptr ? grad_lw[n] : T(0);
       if (grad_lse != nullptr) value = value + grad_lse[brow[r]] * Num<T>::exp(lw[n] - lse[brow[r]]);
       g[r] = live[r] ? value : T(0);
-      at[r] = p[r] * dx;
+      at[r] = p[r] * lx.rs;
     }
     lg_lds_barrier();
     T xx[DP][PPL], u[DP][PPL], gprev[DP][PPL], gcur[DP][PPL];
@@ -813,7 +831,7 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
     for (int j = 0; j < DP; ++j)
 #pragma unroll
       for (int r = 0; r < PPL; ++r) {
-        xx[j][r] = (uint32_t)j < dx ? tx[lg_pad(at[r] + min(j, (int)dx - 1))] : T(0);
+        xx[j][r] = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] : T(0);
         gprev[j][r] = T(0);
       }
     // ---- transition term: u = g (x - loc_p) / s_p^2
@@ -833,10 +851,10 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
       scale_acc[0] += g[r] * (q * inv_var_p * inv_s_p - T(dx) * inv_s_p);
     }
     if (gxprev != nullptr) lg_apply_regs<T, DP, PPL>(wn, u, (int)dx, gprev);
-    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu);
+    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
     lg_u_ready<PPL>(up_out != nullptr);
-    if (up_out != nullptr) lg_store_rows(up_out + n0 * dx, np * dx, tu);
-    lg_outer_term<T, PPL>(tu, dx, tprev, dx, np, acc_a);
+    if (up_out != nullptr) lg_store_rows(up_out + n0 * dx, np * dx, tu, lx);
+    lg_outer_term<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_a);
     lg_u_done<PPL>(up_out != nullptr);
     // ---- proposal term (enters the log-weight with a minus sign): u = -g (x - loc_q) / s_q^2
     lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
@@ -855,10 +873,10 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
       scale_acc[2] -= g[r] * (q * inv_var_q * inv_s_q - T(dx) * inv_s_q);
     }
     if (gxprev != nullptr) lg_apply_regs<T, DP, PPL>(wn + 2 * DP * DP, u, (int)dx, gprev);
-    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu);
+    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
     lg_u_ready<PPL>(uq_out != nullptr);
-    if (uq_out != nullptr) lg_store_rows(uq_out + n0 * dx, np * dx, tu);
-    lg_outer_term<T, PPL>(tu, dx, tprev, dx, np, acc_q);
+    if (uq_out != nullptr) lg_store_rows(uq_out + n0 * dx, np * dx, tu, lx);
+    lg_outer_term<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_q);
     lg_u_done<PPL>(uq_out != nullptr);
     // ---- emission term: u = g (y - loc_g) / s_g^2
     lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
@@ -877,17 +895,17 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
       scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
     }
     if (gx != nullptr) lg_apply_regs<T, DP, PPL>(wn + DP * DP, u, (int)dy, gcur);
-    lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu);
+    lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu, ly);
     lg_u_ready<PPL>(ug_out != nullptr);
-    if (ug_out != nullptr) lg_store_rows(ug_out + n0 * dy, np * dy, tu);
-    lg_outer_term<T, PPL>(tu, dy, tx, dx, np, acc_c);
+    if (ug_out != nullptr) lg_store_rows(ug_out + n0 * dy, np * dy, tu, ly);
+    lg_outer_term<T, PPL>(tu, ly.rs, tx, lx.rs, np, acc_c);
     lg_u_done<PPL>(ug_out != nullptr);
     // ---- the two latent gradients leave through the input tiles
-    if (gxprev != nullptr) lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev);
-    if (gx != nullptr) lg_rows_to_tile<T, DP, PPL>(gcur, dx, p, live, tx);
+    if (gxprev != nullptr) lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev, lx);
+    if (gx != nullptr) lg_rows_to_tile<T, DP, PPL>(gcur, dx, p, live, tx, lx);
     lg_lds_barrier();
-    if (gxprev != nullptr) lg_store_rows(gxprev + n0 * dx, np * dx, tprev);
-    if (gx != nullptr) lg_store_rows(gx + n0 * dx, np * dx, tx);
+    if (gxprev != nullptr) lg_store_rows(gxprev + n0 * dx, np * dx, tprev, lx);
+    if (gx != nullptr) lg_store_rows(gx + n0 * dx, np * dx, tx, lx);
     lg_lds_barrier();
   }
   T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
@@ -1019,7 +1037,7 @@ static int launch_particle_affine(const void *x1, const aesmc_affine_map *m1, co
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (2 * (size_t)dp * dp + lg_tile_elems(tp, d1) + lg_tile_elems(tp, d2) + lg_tile_elems(tp, dout));
+    lds = sizeof(T) * (2 * (size_t)dp * dp + lg_tile_elems<T>(tp, d1) + lg_tile_elems<T>(tp, d2) + lg_tile_elems<T>(tp, dout));
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
@@ -1062,7 +1080,7 @@ static int launch_affine_rsample(const void *src, const aesmc_affine_map *m, con
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * ((size_t)dp * dp + (size_t)kLgRowsMax * dp + lg_tile_elems(tp, m->din) + lg_tile_elems(tp, m->dout));
+    lds = sizeof(T) * ((size_t)dp * dp + (size_t)kLgRowsMax * dp + lg_tile_elems<T>(tp, m->din) + lg_tile_elems<T>(tp, m->dout));
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
@@ -1074,7 +1092,7 @@ static int launch_affine_rsample(const void *src, const aesmc_affine_map *m, con
   }
   {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * ((size_t)dp * dp + (size_t)kLgRowsMax * dp + lg_tile_elems(tp, m->din) + lg_tile_elems(tp, m->dout));
+    lds = sizeof(T) * ((size_t)dp * dp + (size_t)kLgRowsMax * dp + lg_tile_elems<T>(tp, m->din) + lg_tile_elems<T>(tp, m->dout));
   }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
@@ -1101,7 +1119,7 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (3 * (size_t)dp * dp + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems(tp, dx));
+    lds = sizeof(T) * (3 * (size_t)dp * dp + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems<T>(tp, dx));
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
@@ -1113,7 +1131,7 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   }
   {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (3 * (size_t)dp * dp + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems(tp, dx));
+    lds = sizeof(T) * (3 * (size_t)dp * dp + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems<T>(tp, dx));
   }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
@@ -1149,7 +1167,7 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (16 + (size_t)dp * dp + 4 * 256 + lg_tile_elems(tp, dout) + lg_tile_elems(tp, din));
+    lds = sizeof(T) * (16 + (size_t)dp * dp + 4 * 256 + lg_tile_elems<T>(tp, dout) + lg_tile_elems<T>(tp, din));
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
@@ -1187,8 +1205,8 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (16 + 6 * (size_t)dp * dp + 4 * 256 + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems(tp, dx) +
-                       lg_tile_elems(tp, std::max(dx, dy)));
+    lds = sizeof(T) * (16 + 6 * (size_t)dp * dp + 4 * 256 + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems<T>(tp, dx) +
+                       std::max(lg_tile_elems<T>(tp, dx), lg_tile_elems<T>(tp, dy)));
     if (lds <= (ppl > 1 ? (size_t)78 * 1024 : kLgLdsLimit) && lg_rows_spanned((int64_t)tp, K) <= kLgRowsMax) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
