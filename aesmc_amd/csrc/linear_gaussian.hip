@@ -1211,7 +1211,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
-  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, 2), kLgMaxGrid);   // two workgroups per CU: registers
+  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, 2), kLgMaxGrid);   // two workgroups per CU: at three the kernel spills (measured: 678 against 562 us)
   if (ws_bytes < (size_t)grid * 4 * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;
   LgBackwardOut out;
   out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;
