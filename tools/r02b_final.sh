@@ -28,13 +28,17 @@ prof() {  # name, bench args...
   STATS=$(ls $OUT/g_prof_$NAME/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$STATS" ] && python tools/summarize_rocprof.py $STATS 30 > $OUT/g_rocprof_$NAME.csv
   rm -rf $OUT/g_prof_$NAME $OUT/g_prof_$NAME.log
-  head -9 $OUT/g_rocprof_$NAME.csv | cut -c1-130
+  head -14 $OUT/g_rocprof_$NAME.csv | cut -c1-130
 }
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "prof" ]; then
-  prof kernel_stats_c4 --steps 2 --warmup 1 --no-cpu-baseline --no-backward --extras off
-  prof fwd_bwd_c4 --steps 1 --warmup 1 --no-cpu-baseline --extras off
-  prof kernel_stats_c2 --workload c2 --steps 5 --warmup 1 --no-cpu-baseline --no-backward --extras off
-  prof bwd_c2 --workload c2 --steps 5 --warmup 1 --no-cpu-baseline --extras off
+  # TunableOp's picks are made in an unprofiled run first, so the traces hold no tuning trials
+  T4=/tmp/aesmc_tuned_c4.csv; T2=/tmp/aesmc_tuned_c2.csv
+  python bench.py --steps 1 --warmup 1 --no-cpu-baseline --extras off --tunableop-file $T4 > /dev/null 2>&1
+  python bench.py --workload c2 --steps 2 --warmup 1 --no-cpu-baseline --extras off --tunableop-file $T2 > /dev/null 2>&1
+  prof kernel_stats_c4 --steps 2 --warmup 1 --no-cpu-baseline --no-backward --extras off --tunableop-file $T4
+  prof fwd_bwd_c4 --steps 1 --warmup 1 --no-cpu-baseline --extras off --tunableop-file $T4
+  prof kernel_stats_c2 --workload c2 --steps 5 --warmup 1 --no-cpu-baseline --no-backward --extras off --tunableop-file $T2
+  prof bwd_c2 --workload c2 --steps 5 --warmup 1 --no-cpu-baseline --extras off --tunableop-file $T2
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "pmc" ]; then
   bash tools/pmc_lg.sh > /dev/null 2>&1
