@@ -39,7 +39,7 @@ def _slice_tape(tape, lo, hi):
     return replay.Tape(normals, tape.uniforms)  # uniforms stay global: shard_scope slices them
 
 
-def _run_rank(rank, world, port, out_dir):
+def _run_rank(rank, world, port, out_dir, affine=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,7 +49,7 @@ def _run_rank(rank, world, port, out_dir):
         from tests.oracle_provider import OracleKernels
         _kernels._swap_provider_for_tests(OracleKernels())
         torch.set_num_threads(1)
-        model = models.LgssmNd(D, seed=0, dtype=torch.float64)
+        model = models.LgssmNd(D, seed=0, dtype=torch.float64, affine=affine)
         observations = model.simulate(T, B, seed=1)
         tape = _tape_for(model, observations)
         lo, hi = distributed.shard_bounds(B, rank, world)
@@ -87,14 +87,17 @@ def _run_rank(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_batch_shard_matches_single_process(tmp_path, oracle_backend):
+@pytest.mark.parametrize("affine", [False, True])
+def test_two_rank_batch_shard_matches_single_process(tmp_path, oracle_backend, affine):
+    """`affine`: the model's callables return AffineNormal — the sharded run goes through the
+    linear-Gaussian route (K9 / K10 / K12 on the oracle backend) on every rank."""
     world = 2
     port = _free_port()
-    mp.spawn(_run_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_run_rank, args=(world, port, str(tmp_path), affine), nprocs=world, join=True)
 
     from aesmc_amd import inference, losses
     from aesmc_amd.testing import models, replay
-    model = models.LgssmNd(D, seed=0, dtype=torch.float64)
+    model = models.LgssmNd(D, seed=0, dtype=torch.float64, affine=affine)
     observations = model.simulate(T, B, seed=1)
     tape = _tape_for(model, observations)
     parts = (model.initial, model.transition, model.emission, model.proposal)

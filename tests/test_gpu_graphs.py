@@ -10,8 +10,8 @@ from aesmc_amd.testing import models
 pytestmark = pytest.mark.gpu
 
 
-def make(hip_device, dtype=torch.float32, d=3, B=8, T=6):
-    model = models.LgssmNd(d, seed=0, dtype=dtype, validate_args=False).to(hip_device)
+def make(hip_device, dtype=torch.float32, d=3, B=8, T=6, affine=False):
+    model = models.LgssmNd(d, seed=0, dtype=dtype, validate_args=False, affine=affine).to(hip_device)
     observations = model.simulate(T, B, seed=1)
     parts = (model.initial, model.transition, model.emission, model.proposal)
     return model, observations, parts
@@ -22,9 +22,11 @@ def seed(value):
     np.random.seed(value)
 
 
-@pytest.mark.parametrize("algorithm", ["aesmc", "iwae"])
-def test_graphed_forward_backward_equals_eager(hip_device, algorithm):
-    model, observations, parts = make(hip_device, dtype=torch.float64)
+@pytest.mark.parametrize("algorithm,affine", [("aesmc", False), ("iwae", False), ("aesmc", True)])
+def test_graphed_forward_backward_equals_eager(hip_device, algorithm, affine):
+    """`affine`: AffineNormal callables — K9 / K10 / K12 (with its workspace and second launch) inside
+    the captured graph."""
+    model, observations, parts = make(hip_device, dtype=torch.float64, affine=affine)
     K = 64
     seed(11)
     eager_loss = losses.get_loss(observations, K, algorithm, *parts)
