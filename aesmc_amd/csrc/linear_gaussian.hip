@@ -55,6 +55,19 @@ template <typename T> static inline size_t lg_tile_elems(size_t particles, size_
   return particles * lg_layout<T>((uint32_t)d).rs + 16;
 }
 
+// threadIdx.x through an opaque move: inside the persistent tile loops everything derived from the lane's
+// index is loop-invariant, and the compiler would hoist a hundred LDS addresses out of the loop and hold
+// them in registers for the whole kernel (measured: 223 VGPRs for 4-value rows); recomputing them per
+// tile costs a few adds.
+// The forward kernels keep the hoisting (they have registers to spare and run faster with it: K10
+// 99 against 130 us); the backward kernels set LG_OPAQUE_TID.
+template <bool OPAQUE> __device__ __forceinline__ uint32_t lg_tid_impl() {
+  uint32_t t = threadIdx.x;
+  if constexpr (OPAQUE) asm volatile("" : "+v"(t));
+  return t;
+}
+#define lg_tid() lg_tid_impl<LG_OPAQUE>()
+
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
@@ -77,25 +90,29 @@ struct LgMap {
 
 // [np, d] rows, contiguous in HBM from `src` (16-byte aligned: tiles start at multiples of 256
 // particles), into a tile: 16-byte loads, 16-byte LDS stores.
-template <typename T>
+template <typename T, bool LG_OPAQUE = false>
 __device__ __forceinline__ void lg_stage_rows(const T *__restrict__ src, uint32_t ne, T *__restrict__ tile,
                                               const LgLayout &l, int stream) {
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const uint32_t nvec = ne / N;
-  for (uint32_t v = threadIdx.x; v < nvec; v += kLgBlock)
+#pragma unroll 4
+  for (uint32_t v = lg_tid(); v < nvec; v += kLgBlock)
     reinterpret_cast<V *>(tile)[lg_slot(v, l)] = load16(reinterpret_cast<const V *>(src) + v, stream);
+#pragma unroll 1
   for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[e] = src[e];   // unpadded layouts only
 }
 
-template <typename T>
+template <typename T, bool LG_OPAQUE = false>
 __device__ __forceinline__ void lg_store_rows(T *__restrict__ dst, uint32_t ne, const T *__restrict__ tile,
                                               const LgLayout &l) {
   constexpr int N = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const uint32_t nvec = ne / N;
-  for (uint32_t v = threadIdx.x; v < nvec; v += kLgBlock)
+#pragma unroll 4
+  for (uint32_t v = lg_tid(); v < nvec; v += kLgBlock)
     reinterpret_cast<V *>(dst)[v] = reinterpret_cast<const V *>(tile)[lg_slot(v, l)];
+#pragma unroll 1
   for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) dst[e] = tile[e];
 }
 
@@ -104,6 +121,7 @@ __device__ __forceinline__ void lg_store_rows(T *__restrict__ dst, uint32_t ne, 
 template <typename T, int DP>
 __device__ __forceinline__ void lg_stage_weight(const LgMap &m, T *__restrict__ wt) {
   const T *w = reinterpret_cast<const T *>(m.w);
+#pragma unroll 1
   for (uint32_t e = threadIdx.x; e < DP * DP; e += kLgBlock) {
     const int i = e / DP, j = e - i * DP;
     wt[e] = (j < m.dout && i < m.din) ? w[(int64_t)j * m.sj + (int64_t)i * m.si] : T(0);
@@ -112,14 +130,14 @@ __device__ __forceinline__ void lg_stage_weight(const LgMap &m, T *__restrict__ 
 
 // Which batch row each of a lane's PPL particles lies in (flat particle index n = b K + k).  Lanes past
 // the tile's end take particle 0 of the tile: they compute on valid addresses and store nothing.
-template <int PPL>
+template <int PPL, bool LG_OPAQUE = false>
 __device__ __forceinline__ void lg_rows(int64_t n0, uint32_t np, uint32_t K, uint32_t (&p)[PPL], bool (&live)[PPL],
                                         uint32_t (&brow)[PPL]) {
   const uint32_t b0 = (uint32_t)(n0 / K);
   const uint32_t k0 = (uint32_t)(n0 - (int64_t)b0 * K);
 #pragma unroll
   for (int r = 0; r < PPL; ++r) {
-    const uint32_t q = threadIdx.x + r * kLgBlock;
+    const uint32_t q = lg_tid() + r * kLgBlock;
     live[r] = q < np;
     p[r] = live[r] ? q : 0u;
     brow[r] = b0 + (k0 + p[r]) / K;
@@ -163,6 +181,27 @@ __device__ __forceinline__ void lg_apply_tile(const T *__restrict__ wt, const T 
   #pragma unroll
         for (int r = 0; r < PPL; ++r) acc[j][r] = fma_t(w, xv[r], acc[j][r]);
       }
+    }
+  }
+}
+
+// The same chains as a LOOP over the input elements (two per trip): one column of weights live at a time
+// instead of the whole matrix, a few hundred bytes of code instead of DP^2 unrolled multiply-adds —
+// what the register-heavy backward kernel needs.  Same order of operations, same bits.
+template <typename T, int DP, int PPL>
+__device__ __forceinline__ void lg_apply_loop(const T *__restrict__ wt, const T *__restrict__ tile,
+                                              const uint32_t (&base)[PPL], uint32_t din, T (&acc)[DP][PPL]) {
+#pragma unroll 2
+  for (uint32_t i = 0; i < din; ++i) {
+    T xv[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) xv[r] = tile[base[r] + i];
+    const T *w = wt + i * DP;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const T wj = w[j];
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) acc[j][r] = fma_t(wj, xv[r], acc[j][r]);
     }
   }
 }
@@ -235,10 +274,11 @@ template <typename T> struct LgRowVec {
   int len;
 };
 
-template <typename T, int DP, int NA>
+template <typename T, int DP, int NA, bool LG_OPAQUE = false>
 __device__ __forceinline__ void lg_stage_table(const LgRowVec<T> (&vec)[NA], uint32_t b0, uint32_t nrows,
                                                T *__restrict__ tab) {
-  for (uint32_t idx = threadIdx.x; idx < nrows * NA * DP; idx += kLgBlock) {
+#pragma unroll 1
+  for (uint32_t idx = lg_tid(); idx < nrows * NA * DP; idx += kLgBlock) {
     const uint32_t j = idx % DP, a = (idx / DP) % NA, row = idx / (DP * NA);
     T value = T(0);
 #pragma unroll
@@ -296,19 +336,19 @@ __device__ __forceinline__ void lg_lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <typename T, int NV>
+template <typename T, int NV, bool LG_OPAQUE = false>
 __device__ __forceinline__ void lg_prefetch(const T *__restrict__ src, uint32_t ne, int stream,
                                             typename Vec16<T>::type (&regs)[NV]) {
   using V = typename Vec16<T>::type;
   const uint32_t nvec = ne / Vec16<T>::N;
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
-    const uint32_t v = threadIdx.x + s * kLgBlock;
+    const uint32_t v = lg_tid() + s * kLgBlock;
     if (v < nvec) regs[s] = load16(reinterpret_cast<const V *>(src) + v, stream);
   }
 }
 
-template <typename T, int NV>
+template <typename T, int NV, bool LG_OPAQUE = false>
 __device__ __forceinline__ void lg_commit(const T *__restrict__ src, uint32_t ne,
                                           const typename Vec16<T>::type (&regs)[NV], T *__restrict__ tile,
                                           const LgLayout &l) {
@@ -317,9 +357,10 @@ __device__ __forceinline__ void lg_commit(const T *__restrict__ src, uint32_t ne
   const uint32_t nvec = ne / N;
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
-    const uint32_t v = threadIdx.x + s * kLgBlock;
+    const uint32_t v = lg_tid() + s * kLgBlock;
     if (v < nvec) reinterpret_cast<V *>(tile)[lg_slot(v, l)] = regs[s];
   }
+#pragma unroll 1
   for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[e] = src[e];   // last tile only
 }
 
@@ -574,10 +615,11 @@ template <typename T>
 __device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, uint32_t dg, const T *__restrict__ tx,
                                                     uint32_t dxx, uint32_t np, typename Mfma<T>::Acc &acc) {
   // dg, dxx: the ROW STRIDES of the two tiles (LgLayout::rs)
+  constexpr bool LG_OPAQUE = true;
   // Lane (quad, col) feeds value `col` of particle 4 w + quad (+ 16 per trip).  Columns at or past a row's
   // extent read the neighbouring row: that only reaches accumulator rows / columns >= the extents,
   // which nobody reads, so there is no per-column mask; particles past the tile's end are masked.
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t tid = lg_tid(), lane = tid & 63u, wave = tid >> 6;
   const uint32_t col = lane & 15u;
   uint32_t p = wave * 4 + (lane >> 4);
   uint32_t eg = p * dg + col, ex = p * dxx + col;
@@ -603,30 +645,35 @@ __device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, ui
 // The same sum over a wavefront's OWN 64 particles (lane = particle mapping of the one-particle-per-lane
 // kernels: rows 64 w .. 64 w + 63 of the tiles were written and are read by this wavefront alone), so the
 // caller needs no workgroup barrier around it — a wavefront-level fence orders its LDS writes and reads.
-template <typename T>
+template <typename T, int PPL>
 __device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg, uint32_t dg,
                                                         const T *__restrict__ tx, uint32_t dxx, uint32_t np,
                                                         typename Mfma<T>::Acc &acc) {
-  // dg, dxx: the ROW STRIDES of the two tiles (LgLayout::rs)
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // dg, dxx: the ROW STRIDES of the two tiles (LgLayout::rs); a wavefront's lanes own particles
+  // 256 r + 64 w .. + 63 for r < PPL
+  constexpr bool LG_OPAQUE = true;
+  const uint32_t tid = lg_tid(), lane = tid & 63u, wave = tid >> 6;
   const uint32_t col = lane & 15u;
-  uint32_t p = wave * 64 + (lane >> 4);
-  uint32_t eg = p * dg + col, ex = p * dxx + col;
   const uint32_t step_g = 4 * dg, step_x = 4 * dxx;
 #pragma unroll
-  for (int group = 0; group < 4; ++group) {
-    T a[4], b[4];
+  for (int r = 0; r < PPL; ++r) {
+    uint32_t p = r * kLgBlock + wave * 64 + (lane >> 4);
+    uint32_t eg = p * dg + col, ex = p * dxx + col;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool live = p + 4 * t < np;
-      a[t] = live ? tg[eg + t * step_g] : T(0);
-      b[t] = live ? tx[ex + t * step_x] : T(0);
+    for (int group = 0; group < 4; ++group) {
+      T a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool live = p + 4 * t < np;
+        a[t] = live ? tg[eg + t * step_g] : T(0);
+        b[t] = live ? tx[ex + t * step_x] : T(0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
+      p += 16;
+      eg += 4 * step_g;
+      ex += 4 * step_x;
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
-    p += 16;
-    eg += 4 * step_g;
-    ex += 4 * step_x;
   }
 }
 
@@ -655,6 +702,7 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
                                                                              const T *__restrict__ x, LgMap adjoint,
                                                                              T *__restrict__ gx, T *__restrict__ ws,
                                                                              int64_t N, int want_w) {
+  constexpr bool LG_OPAQUE = true;   // see lg_tid_impl
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
   const uint32_t dg = adjoint.din, dxx = adjoint.dout;     // g has the location's extent, x (and gx) the input's
@@ -669,15 +717,15 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    lg_stage_rows(g + n0 * dg, np * dg, tg, lg, 1);
-    if (want_w) lg_stage_rows(x + n0 * dxx, np * dxx, tx, lxx, 0);
+    lg_stage_rows<T, true>(g + n0 * dg, np * dg, tg, lg, 1);
+    if (want_w) lg_stage_rows<T, true>(x + n0 * dxx, np * dxx, tx, lxx, 0);
     __syncthreads();
     T out[DP][PPL];
     uint32_t p[PPL], at[PPL];
     bool live[PPL];
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
-      const uint32_t q = threadIdx.x + r * kLgBlock;
+      const uint32_t q = lg_tid() + r * kLgBlock;
       live[r] = q < np;
       p[r] = live[r] ? q : 0u;
       at[r] = p[r] * lg.rs;
@@ -701,7 +749,7 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
         }
       }
       __syncthreads();
-      lg_store_rows(gx + n0 * dxx, np * dxx, tx, lxx);
+      lg_store_rows<T, true>(gx + n0 * dxx, np * dxx, tx, lxx);
     }
     __syncthreads();
   }
@@ -746,21 +794,11 @@ __device__ __forceinline__ void lg_rows_to_tile(const T (&v)[DP][PPL], uint32_t 
   }
 }
 
-// One particle per lane: a wavefront's rows of the u tile are its own, so only a launch that also
-// STORES the tile (cooperatively, all lanes) needs workgroup barriers around it.
-template <int PPL> __device__ __forceinline__ void lg_u_ready(bool stored) {
-  if (PPL != 1 || stored) lg_lds_barrier();
+// A wavefront's rows of the u tile are its own (lane = particle), so only a launch that also STORES the
+// tile (cooperatively, all lanes) needs workgroup barriers around it.
+__device__ __forceinline__ void lg_u_ready(bool stored) {
+  if (stored) lg_lds_barrier();
   else lg_wave_fence();
-}
-template <int PPL> __device__ __forceinline__ void lg_u_done(bool stored) {
-  if (PPL != 1 || stored) lg_lds_barrier();
-  else lg_wave_fence();
-}
-template <typename T, int PPL>
-__device__ __forceinline__ void lg_outer_term(const T *__restrict__ tg, uint32_t dg, const T *__restrict__ tx,
-                                              uint32_t dxx, uint32_t np, typename Mfma<T>::Acc &acc) {
-  if (PPL == 1) lg_outer_accumulate_own<T>(tg, dg, tx, dxx, np, acc);
-  else lg_outer_accumulate<T>(tg, dg, tx, dxx, np, acc);
 }
 
 struct LgBackwardOut {
@@ -768,7 +806,7 @@ struct LgBackwardOut {
 };
 
 template <typename T, int DP, int PPL>
-__global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
+__global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_backward_kernel(
     const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
     LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
     const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse,
@@ -809,13 +847,13 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    lg_stage_rows(xprev + n0 * dx, np * dx, tprev, lx, 0);
-    lg_stage_rows(x + n0 * dx, np * dx, tx, lx, 0);
+    lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+    lg_stage_rows<T, true>(x + n0 * dx, np * dx, tx, lx, 0);
     uint32_t p[PPL], brow[PPL], at[PPL];
     bool live[PPL];
-    lg_rows<PPL>(n0, np, K, p, live, brow);
+    lg_rows<PPL, true>(n0, np, K, p, live, brow);
     const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
-    lg_stage_table<T, DP, 4>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
+    lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
     T g[PPL];
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
@@ -826,61 +864,64 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
       at[r] = p[r] * lx.rs;
     }
     lg_lds_barrier();
-    T xx[DP][PPL], u[DP][PPL], gprev[DP][PPL], gcur[DP][PPL];
+    T u[DP][PPL], gprev[DP][PPL], gcur[DP][PPL];
+    uint32_t au[PPL], ay[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      au[r] = p[r] * lx.rs;
+      ay[r] = p[r] * ly.rs;
+    }
 #pragma unroll
     for (int j = 0; j < DP; ++j)
 #pragma unroll
-      for (int r = 0; r < PPL; ++r) {
-        xx[j][r] = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] : T(0);
-        gprev[j][r] = T(0);
-      }
+      for (int r = 0; r < PPL; ++r) gprev[j][r] = T(0);
     // ---- transition term: u = g (x - loc_p) / s_p^2
     lg_row_values<T, DP, PPL, 4, 0>(vec, true, tab, b0, brow, u);
-    lg_apply_tile<T, DP, PPL>(wf, tprev, at, (int)dx, u);
+    lg_apply_loop<T, DP, PPL>(wf, tprev, at, dx, u);
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
       T q = T(0);
       const T scaled = g[r] * inv_var_p;
 #pragma unroll
       for (int j = 0; j < DP; ++j) {
-        const T diff = (uint32_t)j < dx ? xx[j][r] - u[j][r] : T(0);
+        const T diff = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] - u[j][r] : T(0);
         q = fma_t(diff, diff, q);
         u[j][r] = scaled * diff;
         gcur[j][r] = -u[j][r];
       }
       scale_acc[0] += g[r] * (q * inv_var_p * inv_s_p - T(dx) * inv_s_p);
     }
-    if (gxprev != nullptr) lg_apply_regs<T, DP, PPL>(wn, u, (int)dx, gprev);
     lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
-    lg_u_ready<PPL>(up_out != nullptr);
-    if (up_out != nullptr) lg_store_rows(up_out + n0 * dx, np * dx, tu, lx);
-    lg_outer_term<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_a);
-    lg_u_done<PPL>(up_out != nullptr);
+    lg_u_ready(up_out != nullptr);
+    if (up_out != nullptr) lg_store_rows<T, true>(up_out + n0 * dx, np * dx, tu, lx);
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_a);
+    lg_u_ready(up_out != nullptr);
     // ---- proposal term (enters the log-weight with a minus sign): u = -g (x - loc_q) / s_q^2
     lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
-    lg_apply_tile<T, DP, PPL>(wf + 2 * DP * DP, tprev, at, (int)dx, u);
+    lg_apply_loop<T, DP, PPL>(wf + 2 * DP * DP, tprev, at, dx, u);
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
       T q = T(0);
       const T scaled = g[r] * inv_var_q;
 #pragma unroll
       for (int j = 0; j < DP; ++j) {
-        const T diff = (uint32_t)j < dx ? xx[j][r] - u[j][r] : T(0);
+        const T diff = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] - u[j][r] : T(0);
         q = fma_t(diff, diff, q);
         u[j][r] = -(scaled * diff);
         gcur[j][r] = gcur[j][r] - u[j][r];
       }
       scale_acc[2] -= g[r] * (q * inv_var_q * inv_s_q - T(dx) * inv_s_q);
     }
-    if (gxprev != nullptr) lg_apply_regs<T, DP, PPL>(wn + 2 * DP * DP, u, (int)dx, gprev);
     lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
-    lg_u_ready<PPL>(uq_out != nullptr);
-    if (uq_out != nullptr) lg_store_rows(uq_out + n0 * dx, np * dx, tu, lx);
-    lg_outer_term<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_q);
-    lg_u_done<PPL>(uq_out != nullptr);
+    lg_u_ready(uq_out != nullptr);
+    if (uq_out != nullptr) lg_store_rows<T, true>(uq_out + n0 * dx, np * dx, tu, lx);
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn + 2 * DP * DP, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_q);
+    lg_u_ready(uq_out != nullptr);
     // ---- emission term: u = g (y - loc_g) / s_g^2
     lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
-    lg_apply_regs<T, DP, PPL>(wf + DP * DP, xx, (int)dx, u);
+    lg_apply_loop<T, DP, PPL>(wf + DP * DP, tx, at, dx, u);
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
       T q = T(0);
@@ -894,18 +935,18 @@ __global__ __launch_bounds__(kLgBlock, 2) void affine_logweight_backward_kernel(
       }
       scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
     }
-    if (gx != nullptr) lg_apply_regs<T, DP, PPL>(wn + DP * DP, u, (int)dy, gcur);
     lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu, ly);
-    lg_u_ready<PPL>(ug_out != nullptr);
-    if (ug_out != nullptr) lg_store_rows(ug_out + n0 * dy, np * dy, tu, ly);
-    lg_outer_term<T, PPL>(tu, ly.rs, tx, lx.rs, np, acc_c);
-    lg_u_done<PPL>(ug_out != nullptr);
+    lg_u_ready(ug_out != nullptr);
+    if (ug_out != nullptr) lg_store_rows<T, true>(ug_out + n0 * dy, np * dy, tu, ly);
+    if (gx != nullptr) lg_apply_loop<T, DP, PPL>(wn + DP * DP, tu, ay, dy, gcur);
+    lg_outer_accumulate_own<T, PPL>(tu, ly.rs, tx, lx.rs, np, acc_c);
+    lg_lds_barrier();
     // ---- the two latent gradients leave through the input tiles
     if (gxprev != nullptr) lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev, lx);
     if (gx != nullptr) lg_rows_to_tile<T, DP, PPL>(gcur, dx, p, live, tx, lx);
     lg_lds_barrier();
-    if (gxprev != nullptr) lg_store_rows(gxprev + n0 * dx, np * dx, tprev, lx);
-    if (gx != nullptr) lg_store_rows(gx + n0 * dx, np * dx, tx, lx);
+    if (gxprev != nullptr) lg_store_rows<T, true>(gxprev + n0 * dx, np * dx, tprev, lx);
+    if (gx != nullptr) lg_store_rows<T, true>(gx + n0 * dx, np * dx, tx, lx);
     lg_lds_barrier();
   }
   T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
@@ -1201,7 +1242,9 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
-  int ppl = 1;     // two particles per lane measured slower (B=1024 K=4096 d=10: 870 against 650 us: spills)
+  static const int forced = [] { const char *v = getenv("AESMC_LG_BWD_PPL"); return v != nullptr ? atoi(v) : 0; }();   // measurement knob
+  int ppl = (sizeof(T) == 4 && dp <= 12 && !lg_few_tiles(N)) ? 2 : 1;
+  if (forced == 1 || forced == 2) ppl = (sizeof(T) == 4 && dp <= 12) ? forced : 1;
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
@@ -1211,7 +1254,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
-  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, 2), kLgMaxGrid);   // two workgroups per CU: at three the kernel spills (measured: 678 against 562 us)
+  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, ppl == 2 ? 2 : 3), kLgMaxGrid);   // what the registers allow
   if (ws_bytes < (size_t)grid * 4 * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;
   LgBackwardOut out;
   out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;
