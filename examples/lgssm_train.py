@@ -3,6 +3,7 @@ d-dimensional linear-Gaussian state-space model with the AESMC objective on the 
 summarise the filtering posterior.
 
     python examples/lgssm_train.py [--dim 10] [--particles 1024] [--batch 256] [--steps 200] [--graph]
+                                   [--callables affine|matmul]
 
 `--graph` runs the optimisation loop on one captured hipGraph (aesmc_amd.train(..., hip_graph=True)).
 """
@@ -27,6 +28,9 @@ def main():
     ap.add_argument("--timesteps", type=int, default=20)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--callables", default="affine", choices=["affine", "matmul"],
+                    help="affine: the model's callables return aesmc_amd.linear_gaussian.AffineNormal (locations "
+                         "evaluated inside the sampling / weighting kernels); matmul: Normal(x @ W.T + c, s)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-tunableop", action="store_true",
                     help="keep PyTorch's default GEMM picks for the model's matmuls (slower on MI355X: see DESIGN.md 6)")
@@ -40,7 +44,7 @@ def main():
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     truth = models.LgssmNd(args.dim, seed=1, validate_args=False).to(device)
-    model = models.LgssmNd(args.dim, seed=0, validate_args=False).to(device)
+    model = models.LgssmNd(args.dim, seed=0, validate_args=False, affine=args.callables == "affine").to(device)
     with torch.no_grad():                       # start from a poor proposal
         for p in (model.W0, model.Wx, model.Wy):
             p.mul_(0.3)
