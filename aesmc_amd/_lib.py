@@ -75,6 +75,8 @@ SIGNATURES = {
     "aesmc_affine_normal_rsample": (_i32, [_i32, _vp, _map_p, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_backward_workspace_bytes": (_sz, [_i32]),
     "aesmc_particle_affine_backward": (_i32, [_i32, _vp, _vp, _map_p, _vp, _vp, _vp, _sz, _i64, _i64, _vp]),
+    "aesmc_particle_mlp_max_hidden": (_i64, []),
+    "aesmc_particle_mlp": (_i32, [_i32, _vp, _map_p, _map_p, _vp, _i64, _i64, _vp]),
     "aesmc_affine_normal_logweight_backward": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p] + [_vp] * 7 +
                                                       [ctypes.POINTER(AffineLogweightGrads), _vp, _sz, _i64, _i64, _vp]),
     "aesmc_affine_normal_logweight": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp,

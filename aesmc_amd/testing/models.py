@@ -252,9 +252,12 @@ class NonlinearSsm(nn.Module):
     [x_{t-1}, y_t] (config 4 of BASELINE.json: 'nonlinear SSM with learned proposal net')."""
 
     def __init__(self, dim, hidden=64, transition_scale=1.0, emission_scale=0.5, proposal_scale=0.7,
-                 seed=0, dtype=torch.float32, state=_default_state, validate_args=None):
+                 seed=0, dtype=torch.float32, state=_default_state, validate_args=None, fused=False):
         super().__init__()
         self.validate_args = validate_args
+        # fused=True: the d x d maps through aesmc_amd.linear_gaussian (particle_affine / AffineNormal:
+        # kernel K8) and the proposal net through particle_mlp (kernel K13) instead of PyTorch matmuls
+        self.fused = bool(fused)
         gen = torch.Generator().manual_seed(seed)
         eye = torch.eye(dim, dtype=torch.float64)
         self.dim = dim
@@ -283,21 +286,40 @@ class NonlinearSsm(nn.Module):
     def initial(self):
         return self._tag(self._normal(self.loc0, self.scale0), "NOT_EXPANDED")
 
+    def _linear(self, x, weight):
+        if self.fused:
+            from ..linear_gaussian import particle_affine
+            return particle_affine(x, weight)
+        return x @ weight.t()
+
     def transition(self, previous_latents=None, time=None, previous_observations=None):
-        loc = torch.tanh(previous_latents[-1] @ self.A.t())
+        loc = torch.tanh(self._linear(previous_latents[-1], self.A))
         return self._tag(self._normal(loc, self.transition_scale), "FULLY_EXPANDED")
 
     def emission(self, latents=None, time=None, previous_observations=None):
+        if self.fused:
+            from ..linear_gaussian import AffineNormal
+            return self._tag(AffineNormal(latents[-1], self.C, self.emission_scale, validate_args=self.validate_args),
+                             "FULLY_EXPANDED")
         return self._tag(self._normal(latents[-1] @ self.C.t(), self.emission_scale),
                          "FULLY_EXPANDED")
+
+    def _proposal_loc(self, x_prev, y_now):
+        """The net of [x_{t-1}, y_t]: fused, its first layer splits into the particles' columns (inside
+        the kernel) and the observation's columns + bias (one [B,H] row offset)."""
+        first, second = self.net[0], self.net[2]
+        if self.fused:
+            from ..linear_gaussian import particle_mlp
+            from_observation = y_now @ first.weight[:, self.dim:].t() + first.bias
+            return particle_mlp(x_prev, first.weight[:, :self.dim], from_observation, second.weight, second.bias)
+        expanded = y_now.unsqueeze(1).expand(-1, x_prev.size(1), -1)
+        return self.net(torch.cat([x_prev, expanded], dim=2))
 
     def proposal(self, previous_latents=None, time=None, observations=None):
         if time == 0:
             return self._tag(self._normal(self.net0(observations[0]), self.proposal_scale),
                              "BATCH_EXPANDED")
-        x_prev = previous_latents[-1]
-        y_now = observations[time].unsqueeze(1).expand(-1, x_prev.size(1), -1)
-        loc = self.net(torch.cat([x_prev, y_now], dim=2))
+        loc = self._proposal_loc(previous_latents[-1], observations[time])
         return self._tag(self._normal(loc, self.proposal_scale), "FULLY_EXPANDED")
 
     @torch.no_grad()

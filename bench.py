@@ -162,6 +162,8 @@ def build_model(kind, dim, device, state, proposal="stock", callables="matmul", 
         return cls(state=state, validate_args=False).to(device)
     if kind == "lgssm":
         model_kwargs = dict(model_kwargs, affine=(callables == "affine"))
+    if kind == "nonlinear":     # d x d maps through K8, the proposal net through K13
+        model_kwargs = dict(model_kwargs, fused=(callables == "affine"))
     # validate_args=False: no per-call host sync inside torch.distributions (standard practice)
     model = cls(dim, seed=0, state=state, validate_args=False, **model_kwargs).to(device)
     if proposal == "tuned" and hasattr(model, "tune_proposal"):
@@ -290,7 +292,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
     algorithm = ALGORITHM.get(name, "aesmc")
     if kind != "lgssm":
         proposal = "stock"
-    callables = (callables or args.callables) if kind == "lgssm" else "matmul"
+    callables = (callables or args.callables) if kind in ("lgssm", "nonlinear") else "matmul"
     if scaling == "strong":
         global_B = B
         lo, hi = distributed.shard_bounds(global_B, rank, world)
@@ -730,6 +732,12 @@ def main(argv=None):
         if args.workload != "c2":
             extras["c2_hipgraph"] = brief(run_workload(ctx, "c2", args.proposal, 20, 5,
                                                        want_backward=not args.no_backward))
+        if args.workload == "c4":
+            # BASELINE.json configs[3]'s model (nonlinear SSM, learned proposal net) on one GPU's shard of it:
+            # the d x d maps through K8 and the net through K13, and the same with PyTorch matmuls
+            for label, how in (("c4nl_fused", "affine"), ("c4nl_matmul", "matmul")):
+                extras[label] = brief(run_workload(ctx, "c4nl", "stock", 10, 3, want_backward=not args.no_backward,
+                                                   want_kernels=False, callables=how))
         extras["kernel_legs"] = kernel_legs(ctx)
         extras["index_parity_vs_reference_fixtures"] = parity_block(ctx)
     if extras:

@@ -365,6 +365,20 @@ int aesmc_affine_normal_logweight_backward(
     const void *grad_lse, const void *grad_lw, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes,
     int64_t B, int64_t K, void *stream);
 
+/* K13 — a learned proposal net over the particles: the two-layer tanh MLP
+ *   out[b,k,:] = layer2->offset + W2 tanh( layer1->offset[b,:] + W1 x[b,k,:] )
+ * with W1 [H, din] (din <= 16, H <= aesmc_particle_mlp_max_hidden() = 64), W2 [dout, H] (dout <= 16);
+ * layer1->offset is [H] or [B, H] (the per-row part of the first layer: its bias and the observation's
+ * columns of the weight applied to y_t), layer2->offset [dout] or NULL.  x, out dense and 16-byte
+ * aligned.  Replaces, in a model whose proposal is such a net of [x_{t-1}, y_t] (BASELINE.json's
+ * nonlinear state-space model; the reference's own proposal at test/models/lgssm.py:66-77 is its
+ * one-layer case), torch.cat + Linear + tanh + Linear: two GEMMs with [B,K,H] round trips through HBM.
+ * Returns AESMC_ERR_UNSUPPORTED (caller keeps the PyTorch expression) beyond those extents or with
+ * fewer than ~43 particles per batch row. */
+int64_t aesmc_particle_mlp_max_hidden(void);
+int aesmc_particle_mlp(int dtype, const void *x, const aesmc_affine_map *layer1, const aesmc_affine_map *layer2,
+                       void *out, int64_t B, int64_t K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
