@@ -561,3 +561,27 @@ def test_affine_normal_outside_the_fused_route_materialises_its_location(oracle_
         assert torch.equal(a, b)
     torch.testing.assert_close(outs[0]["log_marginal_likelihood"], outs[1]["log_marginal_likelihood"],
                                rtol=1e-12, atol=1e-12)
+
+
+def test_fused_nonlinear_model_equals_the_plain_one(oracle_backend):
+    """BASELINE.json's nonlinear model with `fused=True` (d x d maps through particle_affine / AffineNormal,
+    the proposal net through particle_mlp — K8 / K13, here on the oracle backend) against the same
+    model with PyTorch matmuls: float64 loss and every gradient."""
+    from aesmc_amd.testing.models import NonlinearSsm
+    results = []
+    for fused in (False, True):
+        model = NonlinearSsm(3, hidden=12, dtype=torch.float64, fused=fused)
+        observations = model.simulate(4, 3, seed=2)
+        torch.manual_seed(9)
+        np.random.seed(9)
+        loss = losses.get_loss(observations, 24, "aesmc", model.initial, model.transition, model.emission,
+                               model.proposal)
+        loss.backward()
+        results.append((loss.detach(), {name: p.grad.clone() for name, p in model.named_parameters()
+                                        if p.grad is not None}))
+    (loss_a, grads_a), (loss_b, grads_b) = results
+    assert abs(float(loss_a - loss_b)) <= 1e-12 * max(1.0, abs(float(loss_a)))
+    assert sorted(grads_a) == sorted(grads_b)
+    for name in grads_a:
+        scale = max(float(grads_a[name].abs().max()), 1e-30)
+        assert float((grads_a[name] - grads_b[name]).abs().max()) <= 1e-9 * scale, name
