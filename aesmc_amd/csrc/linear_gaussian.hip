@@ -1,4 +1,4 @@
-// K8 / K9 / K10: particle propagation for linear-Gaussian model terms.
+// K8 - K13: particle propagation for linear-Gaussian model terms (and a learned proposal net).
 //
 // The reference's own state-space model (test/models/lgssm.py:40, :52, :74) and every LGSSM written
 // against its callable contract (aesmc/inference.py:20-46) build each step's distributions as
@@ -12,16 +12,20 @@
 // through LDS with 16-byte loads, the (at most 16 x 16) matrices sit zero-padded in LDS and are read
 // as broadcasts, and every location element is ONE chain of fused multiply-adds in a fixed order
 //     loc[j] = fma(W[j][d-1], x[d-1], ... fma(W[j][1], x[1], fma(W[j][0], x[0], c[j])) ...)
-// — the same chain in all three kernels, so the fused sample (K9), the fused log-weight (K10) and
-// a location materialised by K8 agree bit for bit, and oracle/smc_core.c restates it with fma().
+// — the same chain in every kernel of this file, so a location is the same bit for bit whether K9 / K10 /
+// K12 evaluate it in passing or K8 materialises it, and oracle/smc_core.c restates it with fma().
 //
 //   K8  aesmc_particle_affine            out = base + (c + W1 x1 + W2 x2)        (materialise / adjoint)
 //   K9  aesmc_affine_normal_rsample      x' = (c + W x) + eps * scale           (state.sample)
 //   K10 aesmc_affine_normal_logweight    log N(x'; A x + a, s_p) + log N(y; C x' + g, s_g)
 //                                        - log N(x'; Q x + q, s_q)              (inference.py:112-126)
+//   K11 aesmc_particle_affine_backward   grad W, grad x of a location           (weight gradients: MFMA)
+//   K12 aesmc_affine_normal_logweight_backward   K10's backward in one pass
+//   K13 aesmc_particle_mlp               b2 + W2 tanh(c1 + W1 x)                (a learned proposal net)
 //
-// Everything after the location follows K6 / K5 operation for operation (product rounded before the
-// sum; (-(diff^2)) / (2 sigma^2) - log sigma - log sqrt(2 pi); d-sums from j = 0 upwards; (p + g) - q).
+// After the location, K9 follows K6 operation for operation (product rounded before the sum); K10 takes
+// PyTorch's per-element log-density with the common factors out of the d-sum (one division per term:
+// see the kernel) and combines the terms as (p + g) - q, as K5 does.
 #include <algorithm>
 
 #include "common.hpp"
