@@ -1208,6 +1208,12 @@ static constexpr auto affine_logweight_rows = &affine_logweight_kernel<T, DP, PP
 // workgroups of one tile each: all latency.  256-particle tiles double the workgroups.
 static inline bool lg_few_tiles(int64_t N) { return N < ((int64_t)1 << 20); }
 
+// AESMC_LG_FWD_PPL=1: one particle per lane in K9 / K10 whatever the size (a measurement knob).
+static inline int lg_forward_ppl() {
+  static const int v = [] { const char *e = getenv("AESMC_LG_FWD_PPL"); return e != nullptr ? atoi(e) : 0; }();
+  return v;
+}
+
 // Batch rows a tile of `tp` consecutive particles can span.
 static inline int64_t lg_rows_spanned(int64_t tp, int64_t K) { return (tp - 1) / K + 2; }
 
@@ -1224,7 +1230,7 @@ static int launch_affine_rsample(const void *src, const aesmc_affine_map *m, con
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
-  if (ppl == 2 && lg_few_tiles(N)) ppl = 1;      // small launches: twice the workgroups, half the tile each
+  if (ppl == 2 && (lg_few_tiles(N) || lg_forward_ppl() == 1)) ppl = 1;      // small launches: twice the workgroups, half the tile each
   bool tab = lg_rows_spanned((int64_t)kLgBlock * ppl, K) <= kLgRowsMax;
   if (!tab && ppl == 2) {      // few particles per batch row: one particle per lane, rows from global memory
     ppl = 1;
@@ -1263,7 +1269,7 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
     if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
-  if (ppl == 2 && lg_few_tiles(N)) ppl = 1;
+  if (ppl == 2 && (lg_few_tiles(N) || lg_forward_ppl() == 1)) ppl = 1;
   bool tab = lg_rows_spanned((int64_t)kLgBlock * ppl, K) <= kLgRowsMax;
   if (!tab && ppl == 2) {
     ppl = 1;
