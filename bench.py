@@ -736,7 +736,7 @@ def main(argv=None):
             # BASELINE.json configs[3]'s model (nonlinear SSM, learned proposal net) on one GPU's shard of it:
             # the d x d maps through K8 and the net through K13, and the same with PyTorch matmuls
             for label, how in (("c4nl_fused", "affine"), ("c4nl_matmul", "matmul")):
-                extras[label] = brief(run_workload(ctx, "c4nl", "stock", 10, 3, want_backward=not args.no_backward,
+                extras[label] = brief(run_workload(ctx, "c4nl", "stock", 10, 3, want_backward=False,
                                                    want_kernels=False, callables=how))
         extras["kernel_legs"] = kernel_legs(ctx)
         extras["index_parity_vs_reference_fixtures"] = parity_block(ctx)
