@@ -838,12 +838,13 @@ class HipKernels:
                                 (x_prev, x, y_rows, out, maps, scales))
         return out
 
-    def particle_affine_backward(self, grad, x, weight, need_x=True, need_weight=True):
+    def particle_affine_backward(self, grad, x, weight, need_x=True, need_weight=True, need_offset=False):
         """K11, the adjoint of `offset + x @ weight.T` for grad [B,K,dout]: (grad_x = grad @ weight,
         grad_weight [dout,din] = sum over particles of grad (outer) x — on the matrix cores, summed in a
-        fixed order); entries not asked for are None."""
-        if not (need_x or need_weight):
-            return None, None
+        fixed order —, grad_offset [B,dout] = sum over each row's particles of grad); entries not asked
+        for are None."""
+        if not (need_x or need_weight or need_offset):
+            return None, None, None
         if not self.affine_covers(x, weight) or grad.shape != x.shape[:2] + (weight.size(0),) or \
                 grad.dtype != x.dtype or grad.device != x.device:
             raise ValueError("aesmc_amd: particle_affine_backward operands outside what kernel K11 covers")
@@ -851,20 +852,25 @@ class HipKernels:
         B, K, din = x.shape
         dout = weight.size(0)
         grad, x = self._dense16(grad), self._dense16(x)
+        in_kernel_offset = need_offset and (256 - 1) // K + 2 <= 8      # the kernel's row table: >= ~43 particles per row
         gx = torch.empty_like(x) if need_x else None
         gw = torch.empty((dout, din), dtype=x.dtype, device=x.device) if need_weight else None
-        ws_bytes = int(self._lib.aesmc_affine_backward_workspace_bytes(tag)) if need_weight else 0
+        goff = torch.empty((B, dout), dtype=x.dtype, device=x.device) if in_kernel_offset else None
+        reduces = need_weight or in_kernel_offset
+        ws_bytes = int(self._lib.aesmc_affine_backward_workspace_bytes(tag, B, K)) if reduces else 0
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
         amap, keep = self._affine_map(weight, None)
         with _on_device(x.device):
-            args = (tag, _ptr(grad), _ptr(x), ctypes.byref(amap), _ptr(gx), _ptr(gw), _ptr(ws), ws_bytes, B, K,
-                    self._stream(x))
+            args = (tag, _ptr(grad), _ptr(x), ctypes.byref(amap), _ptr(gx), _ptr(gw), _ptr(goff), _ptr(ws), ws_bytes,
+                    B, K, self._stream(x))
             _lib.check(self._lib.aesmc_particle_affine_backward(*args), "aesmc_particle_affine_backward")
             if self.timer is not None:
                 nbytes = x.element_size() * B * K * (dout + (din if need_weight else 0) + (din if need_x else 0))
                 self.timer.note("particle_affine_backward", (self._lib.aesmc_particle_affine_backward, args), nbytes,
-                                (grad, x, gx, gw, ws, amap, keep))
-        return gx, gw
+                                (grad, x, gx, gw, goff, ws, amap, keep))
+        if need_offset and goff is None:
+            goff = grad.sum(dim=1)
+        return gx, gw, goff
 
     def outer_sum(self, g, x):
         """sum over all particles of g[b,k,:] (outer) x[b,k,:] -> [dout, din]: the weight gradient of an
@@ -901,15 +907,15 @@ class HipKernels:
             y_rows = y_rows.contiguous()
         make = lambda shape, wanted: torch.empty(shape, dtype=x.dtype, device=x.device) if wanted else None
         gx_prev, gx = make((B, K, dx), need[0]), make((B, K, dx), need[1])
-        u_p = make((B, K, dx), need[4] and off_p is not None)
-        u_g = make((B, K, dy), (need[6] and off_g is not None) or need[2])
-        u_q = make((B, K, dx), need[8] and off_q is not None)
+        rows_p = make((B, dx), need[4] and off_p is not None)      # location gradients summed over each row's particles
+        rows_g = make((B, dy), (need[6] and off_g is not None) or need[2])
+        rows_q = make((B, dx), need[8] and off_q is not None)
         gA, gC, gQ = make((dx, dx), need[3]), make((dy, dx), need[5]), make((dx, dx), need[7])
         gscales = make((3,), need[9] or need[10] or need[11])
-        ws_bytes = int(self._lib.aesmc_affine_backward_workspace_bytes(tag))
+        ws_bytes = int(self._lib.aesmc_affine_backward_workspace_bytes(tag, B, K))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-        outs = _lib.AffineLogweightGrads(_ptr(gx_prev), _ptr(gx), _ptr(u_p), _ptr(u_g), _ptr(u_q), _ptr(gA), _ptr(gC),
-                                         _ptr(gQ), _ptr(gscales))
+        outs = _lib.AffineLogweightGrads(_ptr(gx_prev), _ptr(gx), 0, 0, 0, _ptr(gA), _ptr(gC), _ptr(gQ), _ptr(gscales),
+                                         _ptr(rows_p), _ptr(rows_g), _ptr(rows_q))
         maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
         with _on_device(x.device):
             args = (tag, _ptr(x_prev), _ptr(x), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
@@ -925,22 +931,22 @@ class HipKernels:
                     grad_lse=grad_lse if fused_lse else None)
             _lib.check(status, "aesmc_affine_normal_logweight_backward")
             if self.timer is not None:
-                dense = [t for t in (gx_prev, gx, u_p, u_g, u_q) if t is not None]
+                dense = [t for t in (gx_prev, gx) if t is not None]
                 nbytes = x.element_size() * (B * K * (2 * dx + 1)) + sum(t.numel() * t.element_size() for t in dense)
                 self.timer.note("affine_normal_logweight_backward",
                                 (self._lib.aesmc_affine_normal_logweight_backward, args), nbytes,
                                 (x_prev, x, y_rows, lw, lse, grad_lse, grad_lw, outs, ws, maps, scales, gA, gC, gQ,
-                                 gscales) + tuple(dense))
-        fold = lambda u, off: u.sum(dim=1) if off.dim() == 2 else u.sum(dim=(0, 1))
+                                 gscales, rows_p, rows_g, rows_q) + tuple(dense))
+        fold = lambda rows, off: rows if off.dim() == 2 else rows.sum(dim=0)     # a shared [d] offset: all rows
         grads = [gx_prev, gx, None, gA, None, gC, None, gQ, None, None, None, None]
         if need[2]:
-            grads[2] = -u_g.sum(dim=1)
-        if u_p is not None:
-            grads[4] = fold(u_p, off_p)
+            grads[2] = -rows_g
+        if rows_p is not None:
+            grads[4] = fold(rows_p, off_p)
         if need[6] and off_g is not None:
-            grads[6] = fold(u_g, off_g)
-        if u_q is not None:
-            grads[8] = fold(u_q, off_q)
+            grads[6] = fold(rows_g, off_g)
+        if rows_q is not None:
+            grads[8] = fold(rows_q, off_q)
         for slot, s in ((9, scales[0]), (10, scales[1]), (11, scales[2])):
             if need[slot]:
                 grads[slot] = gscales[slot - 9].reshape(s.shape)

@@ -44,7 +44,7 @@ class AffineLogweightGrads(ctypes.Structure):
     """`aesmc_affine_logweight_grads` of include/aesmc_hip.h: K12's optional outputs."""
     _fields_ = [(name, ctypes.c_void_p) for name in (
         "grad_x_prev", "grad_x", "grad_loc_p", "grad_loc_g", "grad_loc_q", "grad_weight_p", "grad_weight_g",
-        "grad_weight_q", "grad_scales")]
+        "grad_weight_q", "grad_scales", "grad_offset_p", "grad_offset_g", "grad_offset_q")]
 
 # name -> (restype, argtypes); mirrors include/aesmc_hip.h one to one.
 SIGNATURES = {
@@ -73,8 +73,8 @@ SIGNATURES = {
     "aesmc_affine_max_dim": (_i64, []),
     "aesmc_particle_affine": (_i32, [_i32, _vp, _map_p, _vp, _map_p, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_normal_rsample": (_i32, [_i32, _vp, _map_p, _vp, _vp, _vp, _i64, _i64, _vp]),
-    "aesmc_affine_backward_workspace_bytes": (_sz, [_i32]),
-    "aesmc_particle_affine_backward": (_i32, [_i32, _vp, _vp, _map_p, _vp, _vp, _vp, _sz, _i64, _i64, _vp]),
+    "aesmc_affine_backward_workspace_bytes": (_sz, [_i32, _i64, _i64]),
+    "aesmc_particle_affine_backward": (_i32, [_i32, _vp, _vp, _map_p, _vp, _vp, _vp, _vp, _sz, _i64, _i64, _vp]),
     "aesmc_particle_mlp_max_hidden": (_i64, []),
     "aesmc_particle_mlp": (_i32, [_i32, _vp, _map_p, _map_p, _vp, _i64, _i64, _vp]),
     "aesmc_affine_normal_logweight_backward": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p] + [_vp] * 7 +

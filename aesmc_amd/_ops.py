@@ -315,10 +315,6 @@ def ancestor_index(log_weight, uniforms):
 
 
 # ---- linear-Gaussian particle propagation (K8 / K9 / K10) --------------------------------------------
-def _sum_to_offset(grad, offset_shape):
-    """Gradient of a location [B,K,dout] folded onto its offset: [dout] or [B, dout]."""
-    return grad.sum(dim=1) if len(offset_shape) == 2 else grad.sum(dim=(0, 1))
-
 
 class _ParticleAffine(torch.autograd.Function):
     """x @ weight.T + offset through kernel K8; backward: the adjoint map through K8 on the transposed
@@ -335,8 +331,9 @@ class _ParticleAffine(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         k = _kernels.get()
         need_x, need_w, need_off = ctx.needs_input_grad
-        gx, gw = k.particle_affine_backward(grad, x, weight, need_x, need_w)
-        goff = _sum_to_offset(grad, ctx.offset_shape) if (need_off and ctx.offset_shape is not None) else None
+        need_off = need_off and ctx.offset_shape is not None
+        gx, gw, rows = k.particle_affine_backward(grad.contiguous(), x, weight, need_x, need_w, need_off)
+        goff = None if not need_off else (rows if len(ctx.offset_shape) == 2 else rows.sum(dim=0))
         return gx, gw, goff
 
 
@@ -361,8 +358,10 @@ class _AffineRsample(torch.autograd.Function):
     def backward(ctx, grad):
         source, weight, eps = ctx.saved_tensors
         need_src, need_w, need_off, need_scale, _ = ctx.needs_input_grad
-        gsrc, gw = _kernels.get().particle_affine_backward(grad, source, weight, need_src, need_w)
-        goff = _sum_to_offset(grad, ctx.offset_shape) if (need_off and ctx.offset_shape is not None) else None
+        need_off = need_off and ctx.offset_shape is not None
+        gsrc, gw, rows = _kernels.get().particle_affine_backward(grad.contiguous(), source, weight, need_src, need_w,
+                                                                need_off)
+        goff = None if not need_off else (rows if len(ctx.offset_shape) == 2 else rows.sum(dim=0))
         gscale = (grad * eps).sum().reshape(ctx.scale_shape) if need_scale else None
         return gsrc, gw, goff, gscale, None
 

@@ -684,6 +684,66 @@ __global__ __launch_bounds__(kLgBlock) void particle_mlp_kernel(const T *__restr
   }
 }
 
+// ---- per-batch-row sums of a tile (offset gradients) -------------------------------------------------------
+// The gradient of an offset c[b] is the sum over the row's particles of the gradient of the location.
+// A tile spans the batch rows b0 .. b0 + nrows - 1 (nrows <= kLgRowsMax: the callers' table condition);
+// 16 lane groups sum 1/16 of the tile's particles each, column by column, flushing at row boundaries,
+// then one lane per (row slot, column) adds the 16 partials in order and leaves the tile's record
+//   out[slot * 16 + j]                                   (fixed order: reproducible)
+// for a second launch to add up the few tiles that cover each batch row.  `part` holds 16 x 8 x 16 values.
+constexpr int kLgRowPart = 16 * kLgRowsMax * 16;
+template <typename T>
+__device__ __forceinline__ void lg_row_sums(const T *__restrict__ tile, uint32_t rs, uint32_t d, uint32_t np,
+                                            uint32_t k0, uint32_t K, T *__restrict__ part, T *__restrict__ out) {
+  const uint32_t t = lg_tid_impl<true>(), j = t & 15u, c = t >> 4;
+#pragma unroll 1
+  for (uint32_t i = t; i < (uint32_t)kLgRowPart; i += kLgBlock) part[i] = T(0);
+  lg_lds_barrier();
+  const uint32_t chunk = (np + 15) / 16, p0 = c * chunk, p1 = min(np, p0 + chunk);
+  if (j < d && p0 < p1) {
+    uint32_t slot = (k0 + p0) / K;
+    uint32_t next = (slot + 1) * K - k0;        // first particle of the next batch row, tile-relative
+    T acc = T(0);
+#pragma unroll 1
+    for (uint32_t p = p0; p < p1; ++p) {
+      if (p >= next) {
+        part[(c * kLgRowsMax + slot) * 16 + j] = acc;
+        acc = T(0);
+        ++slot;
+        next += K;
+      }
+      acc += tile[p * rs + j];
+    }
+    part[(c * kLgRowsMax + slot) * 16 + j] = acc;
+  }
+  lg_lds_barrier();
+  if (t < (uint32_t)kLgRowsMax * 16) {
+    const uint32_t slot = t >> 4;
+    T sum = T(0);
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) sum += part[(cc * kLgRowsMax + slot) * 16 + j];
+    out[t] = sum;
+  }
+}
+
+// goff[b][j] = sum over the tiles that cover batch row b of their records (tile order).
+template <typename T>
+__global__ __launch_bounds__(256) void lg_row_finish_kernel(const T *__restrict__ ws, int terms, int term,
+                                                             T *__restrict__ goff, int64_t B, uint32_t K, uint32_t TP,
+                                                             uint32_t d, T sign) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t b = idx >> 4;
+  const uint32_t j = (uint32_t)(idx & 15);
+  if (b >= B || j >= d) return;
+  const int64_t first = b * K / TP, last = ((b + 1) * K - 1) / TP;
+  T sum = T(0);
+  for (int64_t tile = first; tile <= last; ++tile) {
+    const int64_t b0 = tile * TP / K;
+    sum += ws[((tile * terms + term) * kLgRowsMax + (b - b0)) * 16 + j];
+  }
+  goff[b * d + j] = sign * sum;
+}
+
 // ---- K11: the adjoint of an affine location ----------------------------------------------------------
 // The weight gradient  dW[j][i] = sum over particles of g[p][j] x[p][i]  is a contraction over the
 // particle index: it runs on the matrix cores (v_mfma_*_16x16x4: A = 4 particles x 16 values of g,
@@ -800,14 +860,15 @@ template <typename T, int DP, int PPL>
 __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(const T *__restrict__ g,
                                                                              const T *__restrict__ x, LgMap adjoint,
                                                                              T *__restrict__ gx, T *__restrict__ ws,
-                                                                             int64_t N, int want_w) {
+                                                                             T *__restrict__ row_ws, int64_t N,
+                                                                             uint32_t K, int want_w) {
   constexpr bool LG_OPAQUE = true;   // see lg_tid_impl
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
   const uint32_t dg = adjoint.din, dxx = adjoint.dout;     // g has the location's extent, x (and gx) the input's
   T *wt = reinterpret_cast<T *>(lg_smem);
-  T *scratch = wt + DP * DP;                               // 4 x 256
-  T *tg = scratch + 4 * 256;
+  T *scratch = wt + DP * DP;                               // 4 x 256 (records) / 16 x 8 x 16 (row sums)
+  T *tg = scratch + kLgRowPart;
   const LgLayout lg = lg_layout<T>(dg), lxx = lg_layout<T>(dxx);
   T *tx = tg + (TP * lg.rs + 16);
   typename Mfma<T>::Acc acc = {T(0), T(0), T(0), T(0)};
@@ -819,6 +880,12 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
     lg_stage_rows<T, true>(g + n0 * dg, np * dg, tg, lg, 1);
     if (want_w) lg_stage_rows<T, true>(x + n0 * dxx, np * dxx, tx, lxx, 0);
     __syncthreads();
+    if (row_ws != nullptr) {      // the offset's gradient: per-row sums of the incoming gradient
+      const uint32_t b0 = (uint32_t)(n0 / K);
+      lg_row_sums<T>(tg, lg.rs, dg, np, (uint32_t)(n0 - (int64_t)b0 * K), K, scratch,
+                     row_ws + tile * (kLgRowsMax * 16));
+      lg_lds_barrier();
+    }
     T out[DP][PPL];
     uint32_t p[PPL], at[PPL];
     bool live[PPL];
@@ -902,6 +969,8 @@ __device__ __forceinline__ void lg_u_ready(bool stored) {
 
 struct LgBackwardOut {
   void *gxprev, *gx, *up, *ug, *uq, *ws;
+  void *rows;        // nullptr, or the tiles' row-sum records [tile][3 terms p, g, q][kLgRowsMax][16]
+  int row_terms;     // bit 0 / 1 / 2: term p / g / q wants its row sums
 };
 
 template <typename T, int DP, int PPL>
@@ -915,8 +984,8 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
   const uint32_t dx = mp.dout, dy = mg.dout;
   T *wf = reinterpret_cast<T *>(lg_smem);        // [3][DP*DP] input-major: locations (p, g, q)
   T *wn = wf + 3 * DP * DP;                      // [3][DP*DP] output-major: adjoints
-  T *scratch = wn + 3 * DP * DP;                 // 4 x 256
-  T *tab = scratch + 4 * 256;                    // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
+  T *scratch = wn + 3 * DP * DP;                 // 4 x 256 (records) / 16 x 8 x 16 (row sums)
+  T *tab = scratch + kLgRowPart;                 // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
   T *tprev = tab + kLgRowsMax * 4 * DP;
   const LgLayout lx = lg_layout<T>(dx), ly = lg_layout<T>(dy);
   T *tx = tprev + (TP * lx.rs + 16);
@@ -942,6 +1011,8 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
   T *gxprev = reinterpret_cast<T *>(out.gxprev), *gx = reinterpret_cast<T *>(out.gx);
   T *up_out = reinterpret_cast<T *>(out.up), *ug_out = reinterpret_cast<T *>(out.ug),
     *uq_out = reinterpret_cast<T *>(out.uq);
+  T *rows = reinterpret_cast<T *>(out.rows);
+  const int row_terms = rows != nullptr ? out.row_terms : 0;
   const int64_t tiles = (N + TP - 1) / TP;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
@@ -953,6 +1024,7 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
     lg_rows<PPL, true>(n0, np, K, p, live, brow);
     const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
     lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
+    const uint32_t k0_tile = (uint32_t)(n0 - (int64_t)b0 * K);
     T g[PPL];
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
@@ -991,11 +1063,12 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
       scale_acc[0] += g[r] * (q * inv_var_p * inv_s_p - T(dx) * inv_s_p);
     }
     lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
-    lg_u_ready(up_out != nullptr);
+    lg_u_ready(up_out != nullptr || (row_terms & 1));
     if (up_out != nullptr) lg_store_rows<T, true>(up_out + n0 * dx, np * dx, tu, lx);
+    if (row_terms & 1) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 0) * (kLgRowsMax * 16));
     if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn, tu, au, dx, gprev);
     lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_a);
-    lg_u_ready(up_out != nullptr);
+    lg_u_ready(up_out != nullptr || (row_terms & 1));
     // ---- proposal term (enters the log-weight with a minus sign): u = -g (x - loc_q) / s_q^2
     lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
     lg_apply_loop<T, DP, PPL>(wf + 2 * DP * DP, tprev, at, dx, u);
@@ -1013,11 +1086,12 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
       scale_acc[2] -= g[r] * (q * inv_var_q * inv_s_q - T(dx) * inv_s_q);
     }
     lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
-    lg_u_ready(uq_out != nullptr);
+    lg_u_ready(uq_out != nullptr || (row_terms & 4));
     if (uq_out != nullptr) lg_store_rows<T, true>(uq_out + n0 * dx, np * dx, tu, lx);
+    if (row_terms & 4) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 2) * (kLgRowsMax * 16));
     if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn + 2 * DP * DP, tu, au, dx, gprev);
     lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_q);
-    lg_u_ready(uq_out != nullptr);
+    lg_u_ready(uq_out != nullptr || (row_terms & 4));
     // ---- emission term: u = g (y - loc_g) / s_g^2
     lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
     lg_apply_loop<T, DP, PPL>(wf + DP * DP, tx, at, dx, u);
@@ -1035,8 +1109,9 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
       scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
     }
     lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu, ly);
-    lg_u_ready(ug_out != nullptr);
+    lg_u_ready(ug_out != nullptr || (row_terms & 2));
     if (ug_out != nullptr) lg_store_rows<T, true>(ug_out + n0 * dy, np * dy, tu, ly);
+    if (row_terms & 2) lg_row_sums<T>(tu, ly.rs, dy, np, k0_tile, K, scratch, rows + (tile * 3 + 1) * (kLgRowsMax * 16));
     if (gx != nullptr) lg_apply_loop<T, DP, PPL>(wn + DP * DP, tu, ay, dy, gcur);
     lg_outer_accumulate_own<T, PPL>(tu, ly.rs, tx, lx.rs, np, acc_c);
     lg_lds_barrier();
@@ -1303,9 +1378,17 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
+// Workspace of the reducing kernels: kLgMaxGrid records of 4 x 256 values (weight-gradient partials), then
+// one 8 x 16 record per 256-particle tile and term (offset-gradient row sums).
+static inline size_t lg_record_elems() { return (size_t)kLgMaxGrid * 4 * kLgRecord; }
+static inline size_t lg_row_elems(int64_t N, int terms) {
+  return (size_t)((N + kLgBlock - 1) / kLgBlock) * terms * kLgRowsMax * 16;
+}
+
 template <typename T>
 static int launch_particle_affine_backward(const void *g, const void *x, const aesmc_affine_map *m, void *gx, void *gw,
-                                           void *ws, size_t ws_bytes, int64_t B, int64_t K, hipStream_t stream) {
+                                           void *goff, void *ws, size_t ws_bytes, int64_t B, int64_t K,
+                                           hipStream_t stream) {
   const int64_t N = B * K;
   const int64_t dout = m->dout, din = m->din;
   const int dp = lg_pad_dim(std::max(dout, din));
@@ -1313,25 +1396,38 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (16 + (size_t)dp * dp + 4 * 256 + lg_tile_elems<T>(tp, dout) + lg_tile_elems<T>(tp, din));
-    if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit)) break;
+    lds = sizeof(T) * (16 + (size_t)dp * dp + kLgRowPart + lg_tile_elems<T>(tp, dout) + lg_tile_elems<T>(tp, din));
+    if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit) &&
+        (goff == nullptr || lg_rows_spanned((int64_t)tp, K) <= kLgRowsMax))
+      break;
   }
-  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;
-  const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;     // offset gradient with fewer than ~43 particles per row: caller sums
+  const int64_t tp = (int64_t)kLgBlock * ppl;
+  const int64_t tiles = (N + tp - 1) / tp;
   const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds), kLgMaxGrid);
-  if (gw != nullptr && ws_bytes < (size_t)grid * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;
+  const size_t need = (gw != nullptr || goff != nullptr) ? lg_record_elems() + lg_row_elems(N, 1) : 0;
+  if (ws_bytes < need * sizeof(T)) return AESMC_ERR_WORKSPACE;
+  T *records = static_cast<T *>(ws);
+  T *rows = goff != nullptr ? records + lg_record_elems() : nullptr;
   LgMap adjoint;           // gx = g W: the map from the location's extent back to the input's
   adjoint.w = m->weight; adjoint.sj = m->stride_in; adjoint.si = m->stride_out;
   adjoint.off = nullptr; adjoint.off_sb = 0; adjoint.dout = (int32_t)din; adjoint.din = (int32_t)dout;
   LG_DISPATCH(particle_affine_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream,
-              static_cast<const T *>(g), static_cast<const T *>(x), adjoint, static_cast<T *>(gx),
-              static_cast<T *>(ws), N, gw != nullptr ? 1 : 0);
+              static_cast<const T *>(g), static_cast<const T *>(x), adjoint, static_cast<T *>(gx), records, rows, N,
+              (uint32_t)K, gw != nullptr ? 1 : 0);
   if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
   if (gw != nullptr) {
     LgFinish f = {};
     f.out[0] = gw; f.rows[0] = (int32_t)dout; f.cols[0] = (int32_t)din;
-    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(1), dim3(1024), 0, stream, static_cast<const T *>(ws), grid,
+    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(1), dim3(1024), 0, stream, static_cast<const T *>(records), grid,
                        kLgRecord, f);
+    if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  }
+  if (goff != nullptr) {
+    const int64_t threads = B * 16;
+    hipLaunchKernelGGL(lg_row_finish_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const T *>(rows), 1, 0, static_cast<T *>(goff), B, (uint32_t)K, (uint32_t)tp,
+                       (uint32_t)dout, T(1));
     if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
   }
   return AESMC_OK;
@@ -1353,17 +1449,21 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
-    lds = sizeof(T) * (16 + 6 * (size_t)dp * dp + 4 * 256 + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems<T>(tp, dx) +
+    lds = sizeof(T) * (16 + 6 * (size_t)dp * dp + kLgRowPart + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems<T>(tp, dx) +
                        std::max(lg_tile_elems<T>(tp, dx), lg_tile_elems<T>(tp, dy)));
     if (lds <= (ppl > 1 ? (size_t)78 * 1024 : kLgLdsLimit) && lg_rows_spanned((int64_t)tp, K) <= kLgRowsMax) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, ppl == 2 ? 2 : 3), kLgMaxGrid);   // what the registers allow
-  if (ws_bytes < (size_t)grid * 4 * kLgRecord * sizeof(T)) return AESMC_ERR_WORKSPACE;
+  const int row_terms = (o->grad_offset_p != nullptr ? 1 : 0) | (o->grad_offset_g != nullptr ? 2 : 0) |
+                        (o->grad_offset_q != nullptr ? 4 : 0);
+  const size_t need = lg_record_elems() + (row_terms != 0 ? lg_row_elems(N, 3) : 0);
+  if (ws_bytes < need * sizeof(T)) return AESMC_ERR_WORKSPACE;
+  T *row_ws = row_terms != 0 ? static_cast<T *>(ws) + lg_record_elems() : nullptr;
   LgBackwardOut out;
   out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;
-  out.uq = o->grad_loc_q; out.ws = ws;
+  out.uq = o->grad_loc_q; out.ws = ws; out.rows = row_ws; out.row_terms = row_terms;
   LG_DISPATCH(affine_logweight_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream,
               static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp),
               lg_map(mg), lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg),
@@ -1377,7 +1477,18 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   f.out[3] = o->grad_scales; f.rows[3] = 1; f.cols[3] = 3;
   hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(4), dim3(1024), 0, stream, static_cast<const T *>(ws), grid,
                      4 * kLgRecord, f);
-  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  void *const goff[3] = {o->grad_offset_p, o->grad_offset_g, o->grad_offset_q};
+  const int64_t extent[3] = {dx, dy, dx};
+  for (int term = 0; term < 3; ++term) {
+    if (goff[term] == nullptr) continue;
+    const int64_t threads = B * 16;
+    hipLaunchKernelGGL(lg_row_finish_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const T *>(row_ws), 3, term, static_cast<T *>(goff[term]), B, (uint32_t)K,
+                       (uint32_t)(kLgBlock * ppl), (uint32_t)extent[term], T(1));
+    if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  }
+  return AESMC_OK;
 }
 
 template <typename T>
@@ -1477,32 +1588,39 @@ extern "C" int aesmc_affine_normal_logweight_backward(
 }
 
 
-extern "C" size_t aesmc_affine_backward_workspace_bytes(int dtype) {
-  return (size_t)kLgMaxGrid * 4 * kLgRecord * (dtype == AESMC_F64 ? 8 : 4);
+extern "C" size_t aesmc_affine_backward_workspace_bytes(int dtype, int64_t B, int64_t K) {
+  const int64_t N = (B > 0 && K > 0) ? B * K : 0;
+  return (lg_record_elems() + lg_row_elems(N, 3)) * (dtype == AESMC_F64 ? 8 : 4);
 }
 
 extern "C" int aesmc_particle_affine_backward(int dtype, const void *grad, const void *x, const aesmc_affine_map *map,
-                                              void *out_grad_x, void *out_grad_weight, void *ws, size_t ws_bytes,
-                                              int64_t B, int64_t K, void *stream) {
+                                              void *out_grad_x, void *out_grad_weight, void *out_grad_offset, void *ws,
+                                              size_t ws_bytes, int64_t B, int64_t K, void *stream) {
+  const bool reduces = out_grad_weight != nullptr || out_grad_offset != nullptr;
   if (grad == nullptr || map == nullptr || map->weight == nullptr || B < 0 || K < 0 ||
-      (out_grad_weight != nullptr && (x == nullptr || ws == nullptr)))
+      (out_grad_weight != nullptr && x == nullptr) || (reduces && ws == nullptr))
     return AESMC_ERR_INVALID_ARGUMENT;
   if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
   if (!aligned16(grad) || (x != nullptr && !aligned16(x)) || (out_grad_x != nullptr && !aligned16(out_grad_x)) ||
       (ws != nullptr && !aligned16(ws)))
     return AESMC_ERR_INVALID_ARGUMENT;
   if (!lg_map_ok(map)) return AESMC_ERR_UNSUPPORTED;
-  if (out_grad_x == nullptr && out_grad_weight == nullptr) return AESMC_OK;
+  if (out_grad_x == nullptr && !reduces) return AESMC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (B == 0 || K == 0) {   // an empty sum: the weight gradient is zero
+  if (B == 0 || K == 0) {   // empty sums: the weight gradient is zero, there are no rows
     if (out_grad_weight != nullptr &&
         !zero_fill_async(out_grad_weight, (size_t)(map->dout * map->din) * (dtype == AESMC_F64 ? 8 : 4), s))
+      return AESMC_ERR_LAUNCH;
+    if (out_grad_offset != nullptr && B > 0 &&
+        !zero_fill_async(out_grad_offset, (size_t)(B * map->dout) * (dtype == AESMC_F64 ? 8 : 4), s))
       return AESMC_ERR_LAUNCH;
     return AESMC_OK;
   }
   return dtype == AESMC_F32
-             ? launch_particle_affine_backward<float>(grad, x, map, out_grad_x, out_grad_weight, ws, ws_bytes, B, K, s)
-             : launch_particle_affine_backward<double>(grad, x, map, out_grad_x, out_grad_weight, ws, ws_bytes, B, K, s);
+             ? launch_particle_affine_backward<float>(grad, x, map, out_grad_x, out_grad_weight, out_grad_offset, ws,
+                                                      ws_bytes, B, K, s)
+             : launch_particle_affine_backward<double>(grad, x, map, out_grad_x, out_grad_weight, out_grad_offset, ws,
+                                                       ws_bytes, B, K, s);
 }
 
 

@@ -330,14 +330,16 @@ int aesmc_affine_normal_logweight(int dtype, const void *x_prev, const void *x, 
  *   out_grad_weight[j,i]   = sum_{b,k} grad[b,k,j] x[b,k,i]                 (dense [dout,din])
  * either output may be NULL.  The weight gradient is a contraction over the particle index and runs
  * on the matrix cores (f32 / f64 MFMA: exact fused multiply-adds), each workgroup leaving one 16 x 16
- * partial in `ws` (aesmc_affine_backward_workspace_bytes(dtype) bytes, 16-byte aligned), summed in
- * workgroup order by a second launch: reproducible run to run.  Replaces the input- and
- * weight-gradient matmuls ([B*K,dout] x [dout,din] and [dout,B*K] x [B*K,din]) of the callables'
- * autograd.  The offset's gradient is a plain sum of grad over particles, left to the caller. */
-size_t aesmc_affine_backward_workspace_bytes(int dtype);
+ * partial in `ws` (aesmc_affine_backward_workspace_bytes(dtype, B, K) bytes, 16-byte aligned), summed in
+ * workgroup order by a second launch: reproducible run to run.
+ *   out_grad_offset[b,j]   = sum_k grad[b,k,j]                              (dense [B,dout]; NULL: not wanted)
+ * Replaces the input- and weight-gradient matmuls ([B*K,dout] x [dout,din] and [dout,B*K] x [B*K,din]) and
+ * the broadcast-add's reduction of the callables' autograd.  AESMC_ERR_UNSUPPORTED when the offset
+ * gradient is asked for with fewer than ~43 particles per batch row (the caller sums grad itself). */
+size_t aesmc_affine_backward_workspace_bytes(int dtype, int64_t B, int64_t K);
 int aesmc_particle_affine_backward(int dtype, const void *grad, const void *x, const aesmc_affine_map *map,
-                                   void *out_grad_x, void *out_grad_weight, void *ws, size_t ws_bytes, int64_t B,
-                                   int64_t K, void *stream);
+                                   void *out_grad_x, void *out_grad_weight, void *out_grad_offset, void *ws,
+                                   size_t ws_bytes, int64_t B, int64_t K, void *stream);
 
 /* K12 — backward of K10 in one pass over x_prev and x.  The incoming gradient of lw[b,k] is
  *   g = grad_lw[b,k]  (NULL = 0)  +  grad_lse[b] * exp(lw[b,k] - lse[b])  (NULL = 0; K1's backward formed
@@ -351,8 +353,13 @@ int aesmc_particle_affine_backward(int dtype, const void *grad, const void *x, c
  *   grad_weight_p, grad_weight_q [dx,dx], grad_weight_g [dy,dx]
  *                                     weight gradients (matrix cores, partials in `ws` summed in
  *                                     workgroup order by a second launch: reproducible);
- *   grad_scales [3]                   d / d(scale_p, scale_g, scale_q).
- * `ws`: aesmc_affine_backward_workspace_bytes(dtype) bytes.  Replaces, for one timestep, the autograd
+ *   grad_scales [3]                   d / d(scale_p, scale_g, scale_q);
+ *   grad_offset_p, grad_offset_q [B,dx], grad_offset_g [B,dy]
+ *                                     the location gradients summed over each batch row's particles —
+ *                                     the gradient of a [B, d] offset (a shared [d] offset: sum the
+ *                                     rows; the observation: minus grad_offset_g) — per tile in a fixed
+ *                                     order, the tiles of a row added up by one more small launch.
+ * `ws`: aesmc_affine_backward_workspace_bytes(dtype, B, K) bytes.  Replaces, for one timestep, the autograd
  * chain of aesmc/inference.py:112-132 through the callables' matmuls: K5's backward, three
  * weight-gradient and three input-gradient matmuls and the adds between them. */
 typedef struct aesmc_affine_logweight_grads {
@@ -360,6 +367,7 @@ typedef struct aesmc_affine_logweight_grads {
   void *grad_loc_p, *grad_loc_g, *grad_loc_q;
   void *grad_weight_p, *grad_weight_g, *grad_weight_q;
   void *grad_scales;
+  void *grad_offset_p, *grad_offset_g, *grad_offset_q;
 } aesmc_affine_logweight_grads;
 
 int aesmc_affine_normal_logweight_backward(

@@ -113,11 +113,12 @@ class OracleKernels:
             self._n(x_prev), self._n(x), self._n(y_rows), pair(transition), pair(emission), pair(proposal),
             float(scales[0]), float(scales[1]), float(scales[2])))
 
-    def particle_affine_backward(self, grad, x, weight, need_x=True, need_weight=True):
+    def particle_affine_backward(self, grad, x, weight, need_x=True, need_weight=True, need_offset=False):
         g2, x2 = grad.reshape(-1, grad.size(-1)).double(), x.reshape(-1, x.size(-1)).double()
         gx = (grad.double() @ weight.double()).to(grad.dtype) if need_x else None
         gw = (g2.t() @ x2).to(grad.dtype) if need_weight else None
-        return gx, gw
+        goff = grad.double().sum(dim=1).to(grad.dtype) if need_offset else None
+        return gx, gw, goff
 
     def affine_logweight_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need,
                                   grad_lw=None, lw=None, lse=None, grad_lse=None):

@@ -266,7 +266,11 @@ def test_particle_affine_backward_matches_float64_matmuls(kernels, hip_device, d
     B, K, dx, dy = shape
     n, o = operands(B, K, dx, dy, dtype, hip_device, seed=B + 3 * K)
     grad = torch.from_numpy(np.random.RandomState(1).randn(B, K, dy).astype(dtype)).to(hip_device)
-    gx, gw = kernels.particle_affine_backward(grad, o["x"], o["C"])
+    gx, gw, goff = kernels.particle_affine_backward(grad, o["x"], o["C"], need_offset=True)
+    want_off = grad.double().sum(dim=1)
+    assert float((goff.double() - want_off).abs().max()) <= (1e-5 if dtype == np.float32 else 1e-13) * \
+        max(1.0, float(want_off.abs().max()))
+    assert torch.equal(goff, kernels.particle_affine_backward(grad, o["x"], o["C"], False, False, True)[2])
     want_gx = c_oracle.particle_affine(grad.cpu().numpy(), n["C"].T.copy())
     np.testing.assert_array_equal(gx.cpu().numpy(), want_gx)
     want_gw = grad.double().reshape(-1, dy).t() @ o["x"].double().reshape(-1, dx)
