@@ -69,10 +69,10 @@ WORKLOADS["tiny"] = ("LGSSM d=3 B=8 K=64 T=5 (test-sized: exercises every leg of
                      "lgssm", 3, 8, 64, 5, {})
 ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
 NO_GRAD = {"c5", "c5h"}             # autograd retention of T x [B,K,128] temporaries exceeds HBM: forward under no_grad
-GRAPH_PARTICLES = 1 << 21           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
-                                    # (measured with the affine callables: B=512 K=4096 19.3 ms as a graph, 22.6 ms eager;
-                                    #  B=1024 K=4096 39.5 ms as a graph, 31.8 ms eager — the eager loop recycles its
-                                    #  per-step temporaries, a captured graph gives every one its own address)
+GRAPH_PARTICLES = 1 << 20           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
+                                    # (above it a captured graph does not pay: B=512 K=4096 19-30 ms as a graph from run
+                                    #  to run against 22.6 ms eager, B=1024 39.5 against 31 ms — the eager loop recycles
+                                    #  its per-step temporaries, a captured graph gives every one its own address)
 
 
 def parse(argv=None):
