@@ -863,7 +863,12 @@ class HipKernels:
         with _on_device(x.device):
             args = (tag, _ptr(grad), _ptr(x), ctypes.byref(amap), _ptr(gx), _ptr(gw), _ptr(goff), _ptr(ws), ws_bytes,
                     B, K, self._stream(x))
-            _lib.check(self._lib.aesmc_particle_affine_backward(*args), "aesmc_particle_affine_backward")
+            status = self._lib.aesmc_particle_affine_backward(*args)
+            if status == 2 and goff is not None:     # the row sums do not fit this shape: the caller's reduction instead
+                goff = None
+                args = args[:6] + (0,) + args[7:]
+                status = self._lib.aesmc_particle_affine_backward(*args)
+            _lib.check(status, "aesmc_particle_affine_backward")
             if self.timer is not None:
                 nbytes = x.element_size() * B * K * (dout + (din if need_weight else 0) + (din if need_x else 0))
                 self.timer.note("particle_affine_backward", (self._lib.aesmc_particle_affine_backward, args), nbytes,

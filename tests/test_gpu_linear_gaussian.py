@@ -436,3 +436,53 @@ def test_fused_nonlinear_model_matches_the_cpu_port_with_gradients(hip_device, a
             continue
         scale = max(float(reference.abs().max()), 1e-30)
         assert float((parameter.grad.cpu() - reference).abs().max()) <= 1e-8 * scale, name
+
+
+def test_random_shapes_through_every_linear_gaussian_kernel(kernels, hip_device):
+    """60 random (B, K, dx, dy) — batch rows from 1 to 3000 particles, every extent 1..16, tiles ending
+    anywhere, table and per-lane row paths, one and two particles per lane — through K8 / K9 (bitwise
+    against the C oracle), K10 (tolerance), K11 / K12 (float64 autograd, incl. offset and scale gradients)."""
+    rng = np.random.RandomState(2024)
+    for case in range(60):
+        B = int(rng.randint(1, 40))
+        K = int(rng.choice([1, 2, 7, 33, 64, 85, 86, 100, 255, 256, 257, 511, 513, 1000, 3000]))
+        if B * K > 60000:
+            B = max(1, 60000 // K)
+        dx, dy = int(rng.randint(1, 17)), int(rng.randint(1, 17))
+        dtype = np.float64 if case % 3 == 0 else np.float32
+        n, o = operands(B, K, dx, dy, dtype, hip_device, seed=1000 + case)
+        tag = (case, B, K, dx, dy, dtype.__name__)
+        draw = kernels.affine_rsample(o["x_prev"], o["Q"], o["off_q"], o["eps"], o["s_q"])
+        want = c_oracle.affine_rsample(n["x_prev"], n["Q"], n["off_q"], n["eps"], float(n["s_q"]))
+        assert np.array_equal(draw.cpu().numpy(), want), tag
+        terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+        scales = (o["s_p"], o["s_g"], o["s_q"])
+        lw = kernels.affine_logweight(o["x_prev"], o["x"], o["y"], *terms, scales)
+        want = c_oracle.affine_logweight(n["x_prev"], n["x"], n["y"], (n["A"], None), (n["C"], n["off_g"]),
+                                         (n["Q"], n["off_q"]), float(n["s_p"]), float(n["s_g"]), float(n["s_q"]))
+        rtol = 1e-6 if dtype == np.float32 else 1e-14
+        assert float(np.abs(lw.cpu().numpy() - want).max()) <= rtol * max(1.0, float(np.abs(want).max())), tag
+        grad_lw = torch.from_numpy(rng.randn(B, K).astype(dtype)).to(hip_device)
+        need = [True] * 12
+        need[4] = False       # no transition offset in `terms`
+        got = kernels.affine_logweight_backward(o["x_prev"], o["x"], o["y"], *terms, scales, need, grad_lw=grad_lw)
+        leaves = [t.detach().double().requires_grad_(True) for t in
+                  (o["x_prev"], o["x"], o["y"], o["A"], o["C"], o["off_g"], o["Q"], o["off_q"], *scales)]
+        xp, xx, yy, A, C, og, Q, oq, sp, sg, sq = leaves
+        normal = torch.distributions.Normal
+        value = (normal(xp @ A.t(), sp).log_prob(xx).sum(-1) +
+                 normal(xx @ C.t() + og, sg).log_prob(yy.unsqueeze(1)).sum(-1) -
+                 normal(xp @ Q.t() + oq.unsqueeze(1), sq).log_prob(xx).sum(-1))
+        ref = torch.autograd.grad(value, leaves, grad_outputs=grad_lw.double())
+        picks = (0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11)
+        tolerance = 5e-5 if dtype == np.float32 else 1e-10
+        for slot, want_grad in zip(picks, ref):
+            scale = max(1.0, float(want_grad.abs().max()))
+            assert float((got[slot].double() - want_grad).abs().max()) <= tolerance * scale, (tag, slot)
+        grad = torch.from_numpy(rng.randn(B, K, dx).astype(dtype)).to(hip_device)
+        gx, gw, goff = kernels.particle_affine_backward(grad, o["x_prev"], o["Q"], True, True, True)
+        assert float((gx.double() - grad.double() @ o["Q"].double()).abs().max()) <= tolerance * 10, tag
+        want_w = grad.double().reshape(-1, dx).t() @ o["x_prev"].double().reshape(-1, dx)
+        assert float((gw.double() - want_w).abs().max()) <= tolerance * max(1.0, float(want_w.abs().max())), tag
+        want_off = grad.double().sum(dim=1)
+        assert float((goff.double() - want_off).abs().max()) <= tolerance * max(1.0, float(want_off.abs().max())), tag
