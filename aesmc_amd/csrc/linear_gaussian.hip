@@ -726,24 +726,6 @@ __device__ __forceinline__ void lg_row_sums(const T *__restrict__ tile, uint32_t
   }
 }
 
-// goff[b][j] = sum over the tiles that cover batch row b of their records (tile order).
-template <typename T>
-__global__ __launch_bounds__(256) void lg_row_finish_kernel(const T *__restrict__ ws, int terms, int term,
-                                                             T *__restrict__ goff, int64_t B, uint32_t K, uint32_t TP,
-                                                             uint32_t d, T sign) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t b = idx >> 4;
-  const uint32_t j = (uint32_t)(idx & 15);
-  if (b >= B || j >= d) return;
-  const int64_t first = b * K / TP, last = ((b + 1) * K - 1) / TP;
-  T sum = T(0);
-  for (int64_t tile = first; tile <= last; ++tile) {
-    const int64_t b0 = tile * TP / K;
-    sum += ws[((tile * terms + term) * kLgRowsMax + (b - b0)) * 16 + j];
-  }
-  goff[b * d + j] = sign * sum;
-}
-
 // ---- K11: the adjoint of an affine location ----------------------------------------------------------
 // The weight gradient  dW[j][i] = sum over particles of g[p][j] x[p][i]  is a contraction over the
 // particle index: it runs on the matrix cores (v_mfma_*_16x16x4: A = 4 particles x 16 values of g,
@@ -1146,9 +1128,34 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
 struct LgFinish {
   void *out[4];
   int32_t rows[4], cols[4];
+  // offset gradients: goff[t][b][j] = sum over the tiles covering batch row b of their row-sum records
+  const void *row_ws;     // [tile][row_terms][kLgRowsMax][16], or nullptr
+  void *goff[3];
+  int32_t goff_d[3];
+  int32_t row_terms, matrices, row_blocks;    // records per tile; matrix blocks; row blocks per term (64 rows each)
+  int64_t B;
+  uint32_t K, TP;
 };
 template <typename T>
 __global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ ws, int nblocks, int record, LgFinish f) {
+  if ((int)blockIdx.x >= f.matrices) {
+    // ---- one lane per (batch row, column): the few tiles that cover the row, in tile order
+    const int r = (int)blockIdx.x - f.matrices, term = r / f.row_blocks;
+    T *goff = reinterpret_cast<T *>(f.goff[term]);
+    if (goff == nullptr) return;
+    const int64_t b = (int64_t)(r - term * f.row_blocks) * 64 + (threadIdx.x >> 4);
+    const uint32_t j = threadIdx.x & 15u, d = (uint32_t)f.goff_d[term];
+    if (b >= f.B || j >= d) return;
+    const T *rows = reinterpret_cast<const T *>(f.row_ws);
+    const int64_t first = b * f.K / f.TP, last = ((b + 1) * f.K - 1) / f.TP;
+    T sum = T(0);
+    for (int64_t tile = first; tile <= last; ++tile) {
+      const int64_t b0 = tile * f.TP / f.K;
+      sum += rows[((tile * f.row_terms + term) * kLgRowsMax + (b - b0)) * 16 + j];
+    }
+    goff[b * d + j] = sum;
+    return;
+  }
   // element e of matrix m: four lanes each sum a quarter of the workgroups' records (in workgroup order,
   // eight loads in flight), then the quarters are added in order — fixed association, reproducible
   __shared__ T part[4 * 256];
@@ -1416,18 +1423,15 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
               static_cast<const T *>(g), static_cast<const T *>(x), adjoint, static_cast<T *>(gx), records, rows, N,
               (uint32_t)K, gw != nullptr ? 1 : 0);
   if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
-  if (gw != nullptr) {
+  if (gw != nullptr || goff != nullptr) {      // one finishing launch: the weight gradient's records, the rows' tiles
     LgFinish f = {};
     f.out[0] = gw; f.rows[0] = (int32_t)dout; f.cols[0] = (int32_t)din;
-    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(1), dim3(1024), 0, stream, static_cast<const T *>(records), grid,
-                       kLgRecord, f);
-    if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
-  }
-  if (goff != nullptr) {
-    const int64_t threads = B * 16;
-    hipLaunchKernelGGL(lg_row_finish_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
-                       static_cast<const T *>(rows), 1, 0, static_cast<T *>(goff), B, (uint32_t)K, (uint32_t)tp,
-                       (uint32_t)dout, T(1));
+    f.matrices = gw != nullptr ? 1 : 0;
+    f.row_ws = rows; f.goff[0] = goff; f.goff_d[0] = (int32_t)dout; f.row_terms = 1;
+    f.row_blocks = goff != nullptr ? (int32_t)((B + 63) / 64) : 0;
+    f.B = B; f.K = (uint32_t)K; f.TP = (uint32_t)tp;
+    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(f.matrices + f.row_blocks)), dim3(1024), 0, stream,
+                       static_cast<const T *>(records), grid, kLgRecord, f);
     if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
   }
   return AESMC_OK;
@@ -1475,20 +1479,15 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   f.out[1] = o->grad_weight_g; f.rows[1] = (int32_t)dy; f.cols[1] = (int32_t)dx;
   f.out[2] = o->grad_weight_q; f.rows[2] = (int32_t)dx; f.cols[2] = (int32_t)dx;
   f.out[3] = o->grad_scales; f.rows[3] = 1; f.cols[3] = 3;
-  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(4), dim3(1024), 0, stream, static_cast<const T *>(ws), grid,
-                     4 * kLgRecord, f);
-  if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
-  void *const goff[3] = {o->grad_offset_p, o->grad_offset_g, o->grad_offset_q};
-  const int64_t extent[3] = {dx, dy, dx};
-  for (int term = 0; term < 3; ++term) {
-    if (goff[term] == nullptr) continue;
-    const int64_t threads = B * 16;
-    hipLaunchKernelGGL(lg_row_finish_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
-                       static_cast<const T *>(row_ws), 3, term, static_cast<T *>(goff[term]), B, (uint32_t)K,
-                       (uint32_t)(kLgBlock * ppl), (uint32_t)extent[term], T(1));
-    if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
-  }
-  return AESMC_OK;
+  f.matrices = 4;
+  f.row_ws = row_ws; f.row_terms = 3;
+  f.goff[0] = o->grad_offset_p; f.goff[1] = o->grad_offset_g; f.goff[2] = o->grad_offset_q;
+  f.goff_d[0] = (int32_t)dx; f.goff_d[1] = (int32_t)dy; f.goff_d[2] = (int32_t)dx;
+  f.row_blocks = row_terms != 0 ? (int32_t)((B + 63) / 64) : 0;
+  f.B = B; f.K = (uint32_t)K; f.TP = (uint32_t)(kLgBlock * ppl);
+  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(4 + 3 * f.row_blocks)), dim3(1024), 0, stream,
+                     static_cast<const T *>(ws), grid, 4 * kLgRecord, f);   // one finishing launch for everything
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
 template <typename T>
