@@ -38,8 +38,9 @@ class Golden:
     def observations(self, device):
         return [torch.from_numpy(o).to(device) for o in self.series("obs")]
 
-    def build_parts(self, state, device):
-        """This package's counterpart model, loaded with the fixture's parameters."""
+    def build_parts(self, state, device, affine=False):
+        """This package's counterpart model, loaded with the fixture's parameters (`affine`: the d-dimensional
+        LGSSM with its callables returning AffineNormal — the same model, stated for kernels K9 / K10 / K12)."""
         meta, dtype = self.meta, self.dtype
         if meta["model"] == "lgssm1d":
             parts = {
@@ -54,7 +55,7 @@ class Golden:
                      "proposal": models.GaussianInferenceNetwork(0.0, 0.0, 1.0)}
         elif meta["model"] == "lgssm_nd":
             model = models.LgssmNd(meta["dim"], proposal_scale=meta["proposal_scale"],
-                                   seed=meta["seed"], dtype=dtype, state=state)
+                                   seed=meta["seed"], dtype=dtype, state=state, affine=affine)
             parts = {"initial": model.initial, "transition": model.transition,
                      "emission": model.emission, "proposal": model.proposal, "model": model}
         else:

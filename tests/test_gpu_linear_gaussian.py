@@ -486,3 +486,56 @@ def test_random_shapes_through_every_linear_gaussian_kernel(kernels, hip_device)
         assert float((gw.double() - want_w).abs().max()) <= tolerance * max(1.0, float(want_w.abs().max())), tag
         want_off = grad.double().sum(dim=1)
         assert float((goff.double() - want_off).abs().max()) <= tolerance * max(1.0, float(want_off.abs().max())), tag
+
+
+@pytest.mark.parametrize("name", ["lgssm3d_smc_f64", "lgssm10d_smc_f64", "lgssm3d_smc_f32"])
+def test_affine_route_reproduces_the_reference_s_own_fixtures(hip_device, name):
+    """The fixtures captured from the imported reference (oracle/capture_golden.py: its `infer` on the
+    d-dimensional LGSSM, every draw recorded) replayed through the SAME model stated with AffineNormal
+    callables: float64 — every ancestor index of the reference, per-step log-weights and latents to
+    1e-11, log Z to 1e-10, loss and parameter gradients; float32 — to float32 rounding where the indices
+    agree (a CDF comparison within rounding noise may flip, as for any float32 implementation)."""
+    from tests.golden_io import Golden
+    from aesmc_amd import state as amd_state
+    case = Golden(name)
+    f64 = case.dtype == torch.float64
+    parts, named = case.build_parts(amd_state, hip_device, affine=True)
+    observations = case.observations(hip_device)
+    launches = _count_affine_launches()
+    with replay.replay(case.tape()), launches:
+        result = inference.infer("smc", observations, parts["initial"], parts["transition"], parts["emission"],
+                                 parts["proposal"], case.meta["num_particles"], return_log_marginal_likelihood=True,
+                                 return_latents=True, return_original_latents=True, return_log_weights=True,
+                                 return_ancestral_indices=True)
+    steps = len(observations)
+    assert launches.count["affine_rsample"] == steps - 1 and launches.count["affine_logweight"] == steps - 1
+    got_idx = [a.cpu().numpy() for a in result["ancestral_indices"]]
+    want_idx = case.series("out_idx")
+    exact = all((g == w).all() for g, w in zip(got_idx, want_idx))
+    if f64:
+        assert exact
+    else:
+        assert np.mean([(g == w).mean() for g, w in zip(got_idx, want_idx)]) >= 0.999
+    tol = dict(rtol=1e-11, atol=1e-11) if f64 else dict(rtol=1e-5, atol=1e-5)
+    if exact:
+        for got, want in zip(result["log_weights"], case.series("out_log_weights")):
+            np.testing.assert_allclose(got.detach().cpu().numpy(), want, **tol)
+        for got, want in zip(result["original_latents"], case.series("out_original_latents")):
+            np.testing.assert_allclose(got.detach().cpu().numpy(), want, **tol)
+        for got, want in zip(result["latents"], case.series("out_latents")):
+            np.testing.assert_allclose(got.detach().cpu().numpy(), want, **tol)
+    lml, want = result["log_marginal_likelihood"].detach().cpu().numpy(), case["out_lml"]
+    bound = ((1e-10 if f64 else 1e-4) if exact else 0.05) * (1 + np.abs(want))
+    assert (np.abs(lml - want) <= bound).all()
+    with replay.replay(case.tape()):
+        loss = losses.get_loss(observations, case.meta["num_particles"], "aesmc", parts["initial"],
+                               parts["transition"], parts["emission"], parts["proposal"])
+    loss.backward()
+    assert abs(loss.item() - float(case["out_loss"])) <= ((1e-10 if f64 else 1e-4) if exact else 0.05) * \
+        (1 + abs(float(case["out_loss"])))
+    if exact:
+        for pname, parameter in named.items():
+            want = case["grad_" + pname]
+            scale = np.abs(want).max() + 1e-30
+            np.testing.assert_allclose(parameter.grad.cpu().numpy() / scale, want / scale, rtol=0,
+                                       atol=1e-8 if f64 else 1e-3)

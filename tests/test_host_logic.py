@@ -585,3 +585,31 @@ def test_fused_nonlinear_model_equals_the_plain_one(oracle_backend):
     for name in grads_a:
         scale = max(float(grads_a[name].abs().max()), 1e-30)
         assert float((grads_a[name] - grads_b[name]).abs().max()) <= 1e-9 * scale, name
+
+
+@pytest.mark.parametrize("name", ["lgssm3d_smc_f64", "lgssm10d_smc_f64"])
+def test_affine_route_reproduces_the_reference_fixtures_on_host(oracle_backend, name):
+    """The reference-captured LGSSM fixtures through the model stated with AffineNormal callables (the C
+    oracle standing in for kernels K8 - K12): every ancestor index of the reference, log-weights, log Z,
+    loss and parameter gradients — the linear-Gaussian route pinned to the reference's own outputs."""
+    case = Golden(name)
+    parts, named = case.build_parts(state, torch.device("cpu"), affine=True)
+    observations = case.observations(torch.device("cpu"))
+    with replay.replay(case.tape()):
+        result = inference.infer("smc", observations, parts["initial"], parts["transition"], parts["emission"],
+                                 parts["proposal"], case.meta["num_particles"], return_log_marginal_likelihood=True,
+                                 return_latents=False, return_log_weights=True, return_ancestral_indices=True)
+    for got, want in zip(result["ancestral_indices"], case.series("out_idx")):
+        np.testing.assert_array_equal(got.numpy(), want)
+    for got, want in zip(result["log_weights"], case.series("out_log_weights")):
+        np.testing.assert_allclose(got.detach().numpy(), want, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(result["log_marginal_likelihood"].detach().numpy(), case["out_lml"], rtol=1e-10, atol=1e-10)
+    with replay.replay(case.tape()):
+        loss = losses.get_loss(observations, case.meta["num_particles"], "aesmc", parts["initial"],
+                               parts["transition"], parts["emission"], parts["proposal"])
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(case["out_loss"]), rtol=1e-10)
+    for pname, p in named.items():
+        want = case["grad_" + pname]
+        scale = np.abs(want).max() + 1e-30
+        np.testing.assert_allclose(p.grad.numpy() / scale, want / scale, rtol=0, atol=1e-9)
