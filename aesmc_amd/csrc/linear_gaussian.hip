@@ -911,24 +911,11 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(cons
 //   grad_x      = -u_p - u_q + C^T u_g          grad_x_prev = A^T u_p + Q^T u_q
 //   dA = sum u_p (x) x_prev    dQ = sum u_q (x) x_prev    dC = sum u_g (x) x        (matrix cores, as K11)
 //   ds_p = sum g (|diff_p|^2 / s_p^3 - dx / s_p),  ds_g likewise,  ds_q with the opposite sign
-// x_prev and x are read once, the two latent gradients written once; u_* reach HBM only when an
-// offset's gradient is wanted (the caller sums them over particles).
-template <typename T, int DP, int PPL>
-__device__ __forceinline__ void lg_apply_regs(const T *__restrict__ wt, const T (&in)[DP][PPL], int din,
-                                              T (&acc)[DP][PPL]) {
-#pragma unroll
-  for (int i = 0; i < DP; ++i) {
-    if (i < din) {
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        const T w = wt[i * DP + j];
-#pragma unroll
-        for (int r = 0; r < PPL; ++r) acc[j][r] = fma_t(w, in[i][r], acc[j][r]);
-      }
-    }
-  }
-}
-
+// x_prev and x are read once, the two latent gradients written once.  The three terms are taken in turn —
+// location (a loop over the input elements: one column of weights live at a time), u, its adjoint, u
+// through one spare LDS tile for the outer products (each wavefront over its own particles' rows:
+// wavefront fences, no workgroup barriers) and, where an offset's gradient is wanted, for the per-row sums
+// (lg_row_sums) — so a lane holds one u, the two latent gradients and little else.
 template <typename T, int DP, int PPL>
 __device__ __forceinline__ void lg_rows_to_tile(const T (&v)[DP][PPL], uint32_t d, const uint32_t (&p)[PPL],
                                                 const bool (&live)[PPL], T *__restrict__ tile, const LgLayout &l) {
