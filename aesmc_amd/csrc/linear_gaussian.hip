@@ -35,24 +35,28 @@ constexpr int kLgBlock = 256;
 constexpr int kLgMaxDim = 16;
 
 // A staged tile keeps its rows apart by `rs` elements: rs = d, a flat copy of the [np, d] block in HBM,
-// unless the rows are whole 16-byte vectors of floats (d % 4 == 0), whose power-of-two-ish strides would
-// put a wavefront's row reads on a few LDS banks — those get one 16-byte pad per row (rs = d + 4).
-// Either way a 16-byte vector of the block is ONE 16-byte LDS access and a lane's element (p, i) sits at
-// p * rs + i: a row base per particle, immediate offsets per element, no per-element index arithmetic.
+// unless the rows are whole 16-byte vectors of floats (d % 4 == 0), whose strides would put a
+// wavefront's row reads on very few LDS banks (d = 12 padded to 16: two banks) — those get one or two
+// 16-byte pads per row so that rs / 4 is odd (rs = 12, 12, 20, 20 for d = 4, 8, 12, 16: the best a
+// 16-byte-aligned row can do, 8 banks).  Either way a 16-byte vector of the block is ONE 16-byte LDS access
+// and a lane's element (p, i) sits at p * rs + i: a row base per particle, immediate offsets per
+// element, no per-element index arithmetic.
 struct LgLayout {
   uint32_t rs;    // row stride in elements
   uint32_t mul;   // padded rows: ceil(2^17 / (d / 4)), so (v * mul) >> 17 == v / (d / 4) for v < 2^15; else 0
+  uint32_t padv;  // padded rows: 16-byte pads per row (1 or 2)
 };
 template <typename T> __host__ __device__ __forceinline__ LgLayout lg_layout(uint32_t d) {
   LgLayout l;
   const bool padded = sizeof(T) == 4 && d != 0 && (d & 3u) == 0;
-  l.rs = padded ? d + 4 : d;
+  l.padv = padded ? ((((d >> 2) + 1) & 1u) ? 1u : 2u) : 0u;      // d / 4 + pads odd
+  l.rs = d + 4 * l.padv;
   l.mul = padded ? (131072u + d / 4 - 1) / (d / 4) : 0u;
   return l;
 }
 // vector v of the flat block -> vector slot in the tile
 __device__ __forceinline__ uint32_t lg_slot(uint32_t v, const LgLayout &l) {
-  return l.mul != 0 ? v + ((v * l.mul) >> 17) : v;
+  return l.mul != 0 ? v + ((v * l.mul) >> 17) * l.padv : v;
 }
 // elements a tile of `particles` rows occupies (+16: the matrix-core operand reads run past a row's end)
 template <typename T> static inline size_t lg_tile_elems(size_t particles, size_t d) {

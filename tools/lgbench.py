@@ -15,7 +15,9 @@ import aesmc_amd  # noqa: E402
 from aesmc_amd import _kernels  # noqa: E402
 
 SHAPES = {"c4": (1024, 4096, 10, 10), "c2": (256, 1024, 10, 10), "c4s": (128, 4096, 10, 10),
-          "d16": (1024, 4096, 16, 16), "d4": (1024, 4096, 4, 3)}
+          "d16": (1024, 4096, 16, 16), "d4": (1024, 4096, 4, 3), "d2": (1024, 4096, 2, 2), "d6": (1024, 4096, 6, 6),
+          "d8": (1024, 4096, 8, 8), "d12": (1024, 4096, 12, 12), "d1": (4096, 8192, 1, 1),
+          "k64": (16384, 64, 10, 10), "k16": (65536, 16, 10, 10)}
 
 
 def operands(B, K, dx, dy, dtype, device, seed=0):
@@ -31,7 +33,7 @@ def operands(B, K, dx, dy, dtype, device, seed=0):
             "s_q": torch.tensor(0.7, dtype=dtype, device=device)}
 
 
-def graph_time(fn, repeats=20):
+def graph_time(fn, repeats=10):
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -82,6 +84,21 @@ def bench(name, dtype=torch.float32):
         lambda: (lambda o: k.affine_logweight(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]),
                                               (o["Q"], o["off_q"]), (o["s_p"], o["s_g"], o["s_q"])))(nxt()),
         esz * N * (2 * dx + 1))
+    run("K11 particle_affine_backward", lambda: (lambda o: k.particle_affine_backward(o["eps"], o["x_prev"], o["Q"], True, True, True))(nxt()),
+        esz * N * 3 * dx)
+    lws = [k.affine_logweight(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
+                              (o["s_p"], o["s_g"], o["s_q"])) for o in sets]
+    lses = [k.logweight_lse(lw, None, None, want_lw=False)[1] for lw in lws]
+    need = [True, True, False, True, False, True, False, True, True, False, False, False]
+
+    def k12():
+        i = (state["i"] + 1) % len(sets)
+        state["i"] = i
+        o = sets[i]
+        return k.affine_logweight_backward(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]),
+                                           (o["Q"], o["off_q"]), (o["s_p"], o["s_g"], o["s_q"]), need, lw=lws[i],
+                                           lse=lses[i], grad_lse=torch.ones_like(lses[i]))
+    run("K12 affine_logweight_backward", k12, esz * N * (4 * dx + 1))
     return out
 
 
