@@ -423,6 +423,14 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         else:
             key, label = "logweight_lse", "logweight_lse_kernel (K1)"
         out["roofline"] = roofline_of(kernels.get(key), label, name, proposal, key)
+        # the propagation kernels either side of it (K9 draws x_t, K10 weighs it), priced the same way
+        others = [roofline_of(kernels.get(k), l, name, proposal, k) for k, l in (
+            ("affine_normal_rsample", "affine_rsample_kernel (K9)"),
+            ("affine_normal_logweight", "affine_logweight_kernel (K10)")) if k in kernels]
+        if out["roofline"] is not None and others:
+            out["roofline"]["path_kernels"] = [
+                {f: o[f] for f in ("kernel", "avg_launch_us", "achieved", "frac", "algorithmic_bytes_per_launch",
+                                   "traffic", "frac_traffic", "launches") if f in o} for o in others]
     del graphed, forward, step, model, observations
     import gc
     gc.collect()
