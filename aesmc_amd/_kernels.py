@@ -1001,6 +1001,113 @@ class HipKernels:
                 grads[slot] = g.sum().reshape(s.shape)
         return grads
 
+    # ---- K14: the whole backward of a step whose x_t is the proposal's reparameterised draw ------
+    def affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
+                             grad_lse=None, grad_x=None, grad_lw=None):
+        """K14: gradients of one SMC step (log-weights `lw` of K10, their row log-sum-exp `lse`) whose x IS the
+        draw  loc_q(x_prev) + s_q eps  of K9 from the same proposal operands, with respect to
+        (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q) — x's own slot is always None: the
+        gradient `grad_x` that arrives at x from later steps and the step's own gradient at x travel on
+        through the draw inside the kernel (K12 + K11 + the accumulations between them, one pass)."""
+        if not self.affine_logweight_covers(x_prev, x, y_rows, transition, emission, proposal, scales):
+            raise ValueError("aesmc_amd: affine_step_backward operands outside what kernel K14 covers")
+        if need[1]:
+            raise ValueError("aesmc_amd: affine_step_backward: x is the proposal's draw and has no gradient slot")
+        (A, off_p), (C, off_g), (Q, off_q) = transition, emission, proposal
+        tag = _DTYPE_TAG[x.dtype]
+        B, K, dx = x.shape
+        dy = y_rows.size(1)
+        check = lambda t, shape, what: None if (t.shape == shape and t.dtype == x.dtype and t.device == x.device) \
+            else (_ for _ in ()).throw(ValueError("aesmc_amd: {} must be {} {} on {}".format(what, shape, x.dtype, x.device)))
+        fused_lse = grad_lse is not None
+        if fused_lse:
+            lw, lse, grad_lse = lw.contiguous(), lse.contiguous(), grad_lse.contiguous()
+            check(lw, (B, K), "lw"), check(lse, (B,), "lse"), check(grad_lse, (B,), "grad_lse")
+        if grad_lw is not None:
+            grad_lw = grad_lw.contiguous()
+            check(grad_lw, (B, K), "grad_lw")
+        if grad_x is not None:
+            grad_x = self._dense16(grad_x)
+            check(grad_x, (B, K, dx), "grad_x")
+        if not fused_lse and grad_lw is None and grad_x is None:
+            raise ValueError("aesmc_amd: affine_step_backward needs a gradient: (lw, lse, grad_lse), grad_lw or grad_x")
+        x_prev, x = self._dense16(x_prev), self._dense16(x)
+        if y_rows.stride(1) != 1:
+            y_rows = y_rows.contiguous()
+        make = lambda shape, wanted: torch.empty(shape, dtype=x.dtype, device=x.device) if wanted else None
+        gx_prev = make((B, K, dx), need[0])
+        rows_p = make((B, dx), need[4] and off_p is not None)
+        rows_g = make((B, dy), (need[6] and off_g is not None) or need[2])
+        rows_q = make((B, dx), need[8] and off_q is not None)
+        gA, gC, gQ = make((dx, dx), need[3]), make((dy, dx), need[5]), make((dx, dx), need[7])
+        gscales = make((3,), need[9] or need[10] or need[11])
+        ws_bytes = int(self._lib.aesmc_affine_backward_workspace_bytes(tag, B, K))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        outs = _lib.AffineLogweightGrads(_ptr(gx_prev), 0, 0, 0, 0, _ptr(gA), _ptr(gC), _ptr(gQ), _ptr(gscales),
+                                         _ptr(rows_p), _ptr(rows_g), _ptr(rows_q))
+        maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
+        with _on_device(x.device):
+            args = (tag, _ptr(x_prev), _ptr(x), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
+                    ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
+                    _ptr(scales[2]), _ptr(lw) if fused_lse else 0, _ptr(lse) if fused_lse else 0,
+                    _ptr(grad_lse) if fused_lse else 0, _ptr(grad_lw), _ptr(grad_x), ctypes.byref(outs), _ptr(ws),
+                    ws_bytes, B, K, self._stream(x))
+            status = self._lib.aesmc_affine_step_backward(*args)
+            if status == 2:     # too few particles per batch row for the fused kernel's row table
+                return self.affine_step_backward_unfused(
+                    x_prev, x, y_rows, transition, emission, proposal, scales, need, lw if fused_lse else None,
+                    lse if fused_lse else None, grad_lse=grad_lse if fused_lse else None, grad_x=grad_x,
+                    grad_lw=grad_lw)
+            _lib.check(status, "aesmc_affine_step_backward")
+            if self.timer is not None:
+                nbytes = x.element_size() * B * K * (2 * dx + 1 + (dx if grad_x is not None else 0) +
+                                                     (dx if gx_prev is not None else 0))
+                self.timer.note("affine_step_backward", (self._lib.aesmc_affine_step_backward, args), nbytes,
+                                (x_prev, x, y_rows, lw, lse, grad_lse, grad_lw, grad_x, outs, ws, maps, scales, gA, gC,
+                                 gQ, gscales, rows_p, rows_g, rows_q, gx_prev))
+        fold = lambda rows, off: rows if off.dim() == 2 else rows.sum(dim=0)
+        grads = [gx_prev, None, None, gA, None, gC, None, gQ, None, None, None, None]
+        if need[2]:
+            grads[2] = -rows_g
+        if rows_p is not None:
+            grads[4] = fold(rows_p, off_p)
+        if need[6] and off_g is not None:
+            grads[6] = fold(rows_g, off_g)
+        if rows_q is not None:
+            grads[8] = fold(rows_q, off_q)
+        for slot, s in ((9, scales[0]), (10, scales[1]), (11, scales[2])):
+            if need[slot]:
+                grads[slot] = gscales[slot - 9].reshape(s.shape)
+        return grads
+
+    def affine_step_backward_unfused(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
+                                     grad_lse=None, grad_x=None, grad_lw=None):
+        """The same gradients by the launches K14 replaces — K12 (with x's gradient), the accumulation, K11 for
+        the draw — the route for shapes K14 declines and its cross-check."""
+        (Q, off_q) = proposal
+        inner = list(need)
+        inner[1] = True
+        if grad_lse is None and grad_lw is None:      # only later steps' gradient arrives
+            grad_lw = torch.zeros(x.shape[:2], dtype=x.dtype, device=x.device)
+        grads = self.affine_logweight_backward(x_prev, x, y_rows, transition, emission, proposal, scales, inner,
+                                               grad_lw=grad_lw, lw=lw, lse=lse, grad_lse=grad_lse)
+        total = grads[1] if grad_x is None else grads[1] + grad_x
+        grads[1] = None
+        want_off = bool(need[8]) and off_q is not None
+        gsrc, gw, rows = self.particle_affine_backward(total.contiguous(), x_prev, Q, bool(need[0]), bool(need[7]),
+                                                       want_off)
+        add = lambda a, b: b if a is None else a + b
+        if need[0]:
+            grads[0] = add(grads[0], gsrc)
+        if need[7]:
+            grads[7] = add(grads[7], gw)
+        if want_off:
+            grads[8] = add(grads[8], rows if off_q.dim() == 2 else rows.sum(dim=0))
+        if need[11]:
+            eps = (x - self.particle_affine(x_prev, Q, off_q)) / scales[2]
+            grads[11] = add(grads[11], (total * eps).sum().reshape(scales[2].shape))
+        return grads
+
     # ---- K13: two-layer tanh net over the particles ---------------------------------------------
     def particle_mlp_covers(self, x, weight1, offset1, weight2, bias2=None):
         """Host-only test of K13's preconditions: x [B,K,din] (din <= 16), weight1 [H,din] (H <= 64),

@@ -429,6 +429,46 @@ class _AffineLogWeightLSE(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _AffineStep(torch.autograd.Function):
+    """One SMC step of a linear-Gaussian model as ONE autograd node: inputs the step's operands (x_t only
+    as a value: it is the proposal's reparameterised draw of the same x_{t-1}), outputs the row
+    log-sum-exp of the step's log-weights and x_t itself — the tensor every later consumer (the next
+    resampling gather, the callables, the returned latents) reads.  Backward (kernel K14) therefore
+    receives both the ELBO's gradient at the log-sum-exp and whatever arrives at x_t from later steps,
+    and carries them through the densities AND the draw to x_{t-1} and the parameters in one pass: the
+    draw's own node (K11), K12's x_t gradient and the two [B,K,d] accumulations autograd would put between
+    them never run."""
+
+    @staticmethod
+    def forward(ctx, lw, x_value, *operands):
+        lse = _kernels.get().logweight_lse(lw, None, None, want_lw=False)[1]
+        ctx.save_for_backward(lw, lse, x_value, *[t for t in operands if t is not None])
+        ctx.present = [t is not None for t in operands]
+        return lse, x_value.view_as(x_value)
+
+    @staticmethod
+    def backward(ctx, grad_lse, grad_x):
+        lw, lse, x_value = ctx.saved_tensors[:3]
+        saved = iter(ctx.saved_tensors[3:])
+        operands = [next(saved) if present else None for present in ctx.present]
+        x_prev, _, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = operands
+        need = list(ctx.needs_input_grad[2:])
+        need[1] = False
+        grads = _kernels.get().affine_step_backward(
+            x_prev, x_value, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q), need, lw, lse,
+            grad_lse=None if grad_lse is None else grad_lse.contiguous(), grad_x=grad_x)
+        return (None, None) + tuple(grads)
+
+
+def affine_step(lw, operands):
+    """(row log-sum-exp [B], x_t) of a K10 step whose x_t is the proposal's draw, tied to the step's
+    operands by one autograd node (see _AffineStep).  `operands[1]` (x_t) enters as a value."""
+    x_value = operands[1].detach()
+    inputs = list(operands)
+    inputs[1] = None
+    return _AffineStep.apply(lw, x_value, *inputs)
+
+
 def affine_log_weight(operands):
     """[B,K] log-weight of one step whose three terms are affine Normals (kernel K10)."""
     if torch.is_grad_enabled() and operands.requires_grad():

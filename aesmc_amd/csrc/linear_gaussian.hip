@@ -944,10 +944,12 @@ struct LgBackwardOut {
   void *gxprev, *gx, *up, *ug, *uq, *ws;
   void *rows;        // nullptr, or the tiles' row-sum records [tile][3 terms p, g, q][kLgRowsMax][16]
   int row_terms;     // bit 0 / 1 / 2: term p / g / q wants its row sums
+  const void *gx_in; // step kernel only: the gradient that arrives at x_t from later steps, or nullptr
+  int want_scale_q;  // step kernel only: the proposal scale's gradient is wanted (costs the proposal's location)
 };
 
 template <typename T, int DP, int PPL>
-__global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_backward_kernel(
+__global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_logweight_backward_kernel(
     const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
     LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
     const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse,
@@ -1081,6 +1083,7 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
       }
       scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
     }
+    if (lx.rs != ly.rs) lg_lds_barrier();     // the u tile changes layout: rows of other wavefronts move under it
     lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu, ly);
     lg_u_ready(ug_out != nullptr || (row_terms & 2));
     if (ug_out != nullptr) lg_store_rows<T, true>(ug_out + n0 * dy, np * dy, tu, ly);
@@ -1101,6 +1104,184 @@ __global__ __launch_bounds__(kLgBlock, PPL == 2 ? 2 : 3) void affine_logweight_b
   lg_outer_publish<T>(acc_c, scratch, record + kLgRecord);
   lg_outer_publish<T>(acc_q, scratch, record + 2 * kLgRecord);
   // the three scale gradients: lanes -> wavefronts (shuffles) -> workgroup, fixed order
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    T v = scale_acc[m];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if ((threadIdx.x & 63) == 0) scratch[(threadIdx.x >> 6) * 4 + m] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLgRecord) {
+    const int m = threadIdx.x;
+    record[3 * kLgRecord + m] = m < 3 ? ((scratch[m] + scratch[4 + m]) + scratch[8 + m]) + scratch[12 + m] : T(0);
+  }
+}
+
+// K12 for a step whose x_t IS the proposal's reparameterised draw, x_t = loc_q(x_{t-1}) + s_q eps (kernel K9):
+// the whole step's backward in one pass.  With w = gx_in + dL/dx_t through the transition and emission
+// densities, the draw carries w to the proposal's parameters and to x_{t-1}; the proposal's own density
+// depends on them only through eps = (x_t - loc_q) / s_q, which the draw holds fixed — its location terms
+// cancel identically and only -d log s_q survives.  So: the emission term first (its adjoint starts w), the
+// transition term (w -= u_p), then w itself takes the place K12 gives u_q: grad W_q = sum w (x) x_{t-1},
+// grad offset_q = row sums of w, grad x_{t-1} = A^T u_p + Q^T w, grad s_q = sum g d / s_q + w . eps.  Neither
+// a gradient for x_t nor K9's own backward launch (K11) nor the two [B,K,d] accumulations between them exist.
+template <typename T, int DP, int PPL>
+__global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_step_backward_kernel(
+    const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
+    LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
+    const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse,
+    const T *__restrict__ grad_lw, LgBackwardOut out, int64_t N, uint32_t K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  const uint32_t dx = mp.dout, dy = mg.dout;
+  T *wf = reinterpret_cast<T *>(lg_smem);        // [3][DP*DP] input-major: locations (p, g, q)
+  T *wn = wf + 3 * DP * DP;                      // [3][DP*DP] output-major: adjoints
+  T *scratch = wn + 3 * DP * DP;
+  T *tab = scratch + kLgRowPart;                 // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
+  T *tprev = tab + kLgRowsMax * 4 * DP;
+  const LgLayout lx = lg_layout<T>(dx), ly = lg_layout<T>(dy);
+  T *tx = tprev + (TP * lx.rs + 16);
+  T *tu = tx + (TP * lx.rs + 16);
+  const bool want_sq = out.want_scale_q != 0;
+  {
+    lg_stage_weight<T, DP>(mp, wf);
+    lg_stage_weight<T, DP>(mg, wf + DP * DP);
+    if (want_sq) lg_stage_weight<T, DP>(mq, wf + 2 * DP * DP);
+    LgMap t = mp;
+    t.sj = mp.si; t.si = mp.sj; t.dout = mp.din; t.din = mp.dout;
+    lg_stage_weight<T, DP>(t, wn);
+    t = mg; t.sj = mg.si; t.si = mg.sj; t.dout = mg.din; t.din = mg.dout;
+    lg_stage_weight<T, DP>(t, wn + DP * DP);
+    t = mq; t.sj = mq.si; t.si = mq.sj; t.dout = mq.din; t.din = mq.dout;
+    lg_stage_weight<T, DP>(t, wn + 2 * DP * DP);
+  }
+  const LgRowVec<T> vec[4] = {lg_offset_vec<T>(mp), lg_offset_vec<T>(mq), lg_offset_vec<T>(mg), {y, y_sb, (int)dy}};
+  const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
+  const T inv_var_p = T(1) / (s_p * s_p), inv_var_g = T(1) / (s_g * s_g);
+  const T inv_s_p = T(1) / s_p, inv_s_g = T(1) / s_g, inv_s_q = T(1) / s_q;
+  typename Mfma<T>::Acc acc_a = {T(0), T(0), T(0), T(0)}, acc_c = acc_a, acc_q = acc_a;
+  T scale_acc[3] = {T(0), T(0), T(0)};
+  T *gxprev = reinterpret_cast<T *>(out.gxprev);
+  const T *gx_in = reinterpret_cast<const T *>(out.gx_in);
+  T *rows = reinterpret_cast<T *>(out.rows);
+  const int row_terms = rows != nullptr ? out.row_terms : 0;
+  const int64_t tiles = (N + TP - 1) / TP;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+    lg_stage_rows<T, true>(x + n0 * dx, np * dx, tx, lx, 0);
+    if (gx_in != nullptr) lg_stage_rows<T, true>(gx_in + n0 * dx, np * dx, tu, lx, 0);
+    uint32_t p[PPL], brow[PPL], at[PPL];
+    bool live[PPL];
+    lg_rows<PPL, true>(n0, np, K, p, live, brow);
+    const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
+    lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
+    const uint32_t k0_tile = (uint32_t)(n0 - (int64_t)b0 * K);
+    T g[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const int64_t n = n0 + p[r];
+      T value = grad_lw != nullptr ? grad_lw[n] : T(0);
+      if (grad_lse != nullptr) value = value + grad_lse[brow[r]] * Num<T>::exp(lw[n] - lse[brow[r]]);
+      g[r] = live[r] ? value : T(0);
+      at[r] = p[r] * lx.rs;
+    }
+    lg_lds_barrier();
+    T u[DP][PPL], gprev[DP][PPL], w[DP][PPL];
+    uint32_t au[PPL], ay[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      au[r] = p[r] * lx.rs;
+      ay[r] = p[r] * ly.rs;
+    }
+    // a lane's row of the spare tile is its own particle's: read before the lane overwrites it below
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        gprev[j][r] = T(0);
+        w[j][r] = (gx_in != nullptr && (uint32_t)j < dx && live[r]) ? tu[au[r] + min(j, (int)dx - 1)] : T(0);
+      }
+    if (gx_in != nullptr && lx.rs != ly.rs) lg_lds_barrier();   // the tile changes layout under the other wavefronts
+    // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u
+    lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
+    lg_apply_loop<T, DP, PPL>(wf + DP * DP, tx, at, dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_g;
+      const T *yrow = tab + ((brow[r] - b0) * 4 + 3) * DP;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dy ? yrow[j] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = scaled * diff;
+      }
+      scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
+    }
+    lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu, ly);
+    lg_u_ready((row_terms & 2) != 0);
+    if (row_terms & 2) lg_row_sums<T>(tu, ly.rs, dy, np, k0_tile, K, scratch, rows + (tile * 3 + 1) * (kLgRowsMax * 16));
+    lg_apply_loop<T, DP, PPL>(wn + DP * DP, tu, ay, dy, w);
+    lg_outer_accumulate_own<T, PPL>(tu, ly.rs, tx, lx.rs, np, acc_c);
+    if (lx.rs != ly.rs) lg_lds_barrier();     // back to the latent's layout
+    else lg_u_ready((row_terms & 2) != 0);
+    // ---- transition term: u = g (x - loc_p) / s_p^2;  w -= u
+    lg_row_values<T, DP, PPL, 4, 0>(vec, true, tab, b0, brow, u);
+    lg_apply_loop<T, DP, PPL>(wf, tprev, at, dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_p;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = scaled * diff;
+        w[j][r] = w[j][r] - u[j][r];
+      }
+      scale_acc[0] += g[r] * (q * inv_var_p * inv_s_p - T(dx) * inv_s_p);
+    }
+    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
+    lg_u_ready((row_terms & 1) != 0);
+    if (row_terms & 1) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 0) * (kLgRowsMax * 16));
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_a);
+    lg_u_ready((row_terms & 1) != 0);
+    // ---- the draw: w reaches the proposal's parameters and x_{t-1};  grad s_q = g d / s_q + w . eps
+    if (want_sq) {
+      lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
+      lg_apply_loop<T, DP, PPL>(wf + 2 * DP * DP, tprev, at, dx, u);
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        T dot = T(0);
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const T diff = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] - u[j][r] : T(0);
+          dot = fma_t(w[j][r], diff, dot);
+        }
+        if (live[r]) scale_acc[2] += g[r] * (T(dx) * inv_s_q) + dot * inv_s_q;   // a spare lane's w is particle 0's
+      }
+    }
+    lg_rows_to_tile<T, DP, PPL>(w, dx, p, live, tu, lx);
+    lg_u_ready((row_terms & 4) != 0);
+    if (row_terms & 4) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 2) * (kLgRowsMax * 16));
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn + 2 * DP * DP, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_q);
+    lg_lds_barrier();
+    if (gxprev != nullptr) {
+      lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev, lx);
+      lg_lds_barrier();
+      lg_store_rows<T, true>(gxprev + n0 * dx, np * dx, tprev, lx);
+    }
+    lg_lds_barrier();
+  }
+  T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
+  lg_outer_publish<T>(acc_a, scratch, record);
+  lg_outer_publish<T>(acc_c, scratch, record + kLgRecord);
+  lg_outer_publish<T>(acc_q, scratch, record + 2 * kLgRecord);
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     T v = scale_acc[m];
@@ -1434,7 +1615,8 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
                                             const aesmc_affine_map *mq, const void *sp, const void *sg, const void *sq,
                                             const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
                                             const aesmc_affine_logweight_grads *o, void *ws, size_t ws_bytes, int64_t B,
-                                            int64_t K, hipStream_t stream) {
+                                            int64_t K, hipStream_t stream, bool step = false,
+                                            const void *gx_in = nullptr) {
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
@@ -1450,7 +1632,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
-  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, ppl == 2 ? 2 : 3), kLgMaxGrid);   // what the registers allow
+  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, (ppl == 2 || sizeof(T) == 8) ? 2 : 3), kLgMaxGrid);   // what the registers allow
   const int row_terms = (o->grad_offset_p != nullptr ? 1 : 0) | (o->grad_offset_g != nullptr ? 2 : 0) |
                         (o->grad_offset_q != nullptr ? 4 : 0);
   const size_t need = lg_record_elems() + (row_terms != 0 ? lg_row_elems(N, 3) : 0);
@@ -1459,11 +1641,18 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   LgBackwardOut out;
   out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;
   out.uq = o->grad_loc_q; out.ws = ws; out.rows = row_ws; out.row_terms = row_terms;
-  LG_DISPATCH(affine_logweight_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream,
-              static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp),
-              lg_map(mg), lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg),
-              static_cast<const T *>(sq), static_cast<const T *>(lw), static_cast<const T *>(lse),
-              static_cast<const T *>(grad_lse), static_cast<const T *>(grad_lw), out, N, (uint32_t)K);
+  out.gx_in = gx_in; out.want_scale_q = o->grad_scales != nullptr ? 1 : 0;
+#define LG_BACKWARD_ARGS                                                                                            \
+  static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), \
+      lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),               \
+      static_cast<const T *>(lw), static_cast<const T *>(lse), static_cast<const T *>(grad_lse),                    \
+      static_cast<const T *>(grad_lw), out, N, (uint32_t)K
+  if (step) {
+    LG_DISPATCH(affine_step_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
+  } else {
+    LG_DISPATCH(affine_logweight_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
+  }
+#undef LG_BACKWARD_ARGS
   if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
   LgFinish f = {};
   f.out[0] = o->grad_weight_p; f.rows[0] = (int32_t)dx; f.cols[0] = (int32_t)dx;
@@ -1575,6 +1764,51 @@ extern "C" int aesmc_affine_normal_logweight_backward(
              : launch_affine_logweight_backward<double>(x_prev, x, y, y_stride_b, transition, emission, proposal,
                                                         scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
                                                         ws_bytes, B, K, s);
+}
+
+
+extern "C" int aesmc_affine_step_backward(
+    int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
+    const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+    const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
+    const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K,
+    void *stream) {
+  if (out == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  // the draw leaves no gradient for x_t and the location gradients have no meaning here
+  if (out->grad_x != nullptr || out->grad_loc_p != nullptr || out->grad_loc_g != nullptr || out->grad_loc_q != nullptr)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (x_prev == nullptr || x == nullptr || y == nullptr || transition == nullptr || emission == nullptr ||
+      proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || ws == nullptr || B < 0 ||
+      K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lw == nullptr && grad_lse == nullptr && grad_x == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lse != nullptr && (lw == nullptr || lse == nullptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  const void *aligned[] = {x_prev, x, ws, grad_x, out->grad_x_prev};
+  for (const void *ptr : aligned)
+    if (ptr != nullptr && !aligned16(ptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_x != nullptr && (grad_x == out->grad_x_prev)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  const int64_t dx = transition->dout;
+  if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
+    return AESMC_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0 || K == 0) {      // empty sums
+    const size_t esz = dtype == AESMC_F64 ? 8 : 4;
+    bool ok = true;
+    if (out->grad_weight_p != nullptr) ok = ok && zero_fill_async(out->grad_weight_p, (size_t)(dx * dx) * esz, s);
+    if (out->grad_weight_g != nullptr) ok = ok && zero_fill_async(out->grad_weight_g, (size_t)(emission->dout * dx) * esz, s);
+    if (out->grad_weight_q != nullptr) ok = ok && zero_fill_async(out->grad_weight_q, (size_t)(dx * dx) * esz, s);
+    if (out->grad_scales != nullptr) ok = ok && zero_fill_async(out->grad_scales, 3 * esz, s);
+    return ok ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
+  return dtype == AESMC_F32
+             ? launch_affine_logweight_backward<float>(x_prev, x, y, y_stride_b, transition, emission, proposal,
+                                                       scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
+                                                       ws_bytes, B, K, s, true, grad_x)
+             : launch_affine_logweight_backward<double>(x_prev, x, y, y_stride_b, transition, emission, proposal,
+                                                        scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
+                                                        ws_bytes, B, K, s, true, grad_x);
 }
 
 

@@ -321,7 +321,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
         # log-weight = log prior/transition + log emission - log proposal (inference.py:97-98,
         # :125-126): one kernel when all three are Normal (K5), else three summed log-densities
         # (K4 or the distribution's own log_prob) combined by K1
-        log_weight_t = None
+        log_weight_t = step_lse_now = None
         if not isinstance(latent, dict) and not isinstance(observation, dict):
             fold = fold_lse_backward and torch.is_grad_enabled()
             log_weight_t = state.normal_log_weight(prior_dist, proposal_dist, latent, emission_dist,
@@ -329,7 +329,16 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
             if fold and log_weight_t is not None:
                 log_weight_t, operands = log_weight_t
                 if _ops.operands_require_grad(operands):
-                    deferred[time] = operands
+                    if getattr(operands, "is_draw", False):
+                        # a linear-Gaussian step whose latent is the proposal's own draw: ONE autograd node
+                        # for the step (K14).  It hands back x_t as its output — the tensor every later
+                        # consumer reads — and the row log-sum-exp (K1 now, not the next resampling launch)
+                        step_lse_now, latent = _ops.affine_step(log_weight_t, operands)
+                        history[-1] = latent
+                        if keep_originals:
+                            originals[-1] = latent
+                    else:
+                        deferred[time] = operands
         # importance sampling over several timesteps normalises the SUM of the per-step weights
         # (inference.py:156-159); K1 keeps that sum running, left to right as torch.sum over the
         # reference's stack does, and hands out its row log-sum-exp with the last step
@@ -340,7 +349,10 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
             # launch for free — or from K1 when no resampling follows
             # (importance sampling never needs the per-step value: it normalises the summed weights)
             pending = use_smc and time + 1 < num_timesteps
-            lse_t = None if (pending or not use_smc) else _ops.row_logsumexp(log_weight_t)
+            if step_lse_now is not None:
+                lse_t = step_lse_now
+            else:
+                lse_t = None if (pending or not use_smc) else _ops.row_logsumexp(log_weight_t)
             if lse_t is not None and time in deferred:
                 lse_t = _ops.attach_lse(lse_t, log_weight_t, deferred.pop(time))
             if accumulate:

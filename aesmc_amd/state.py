@@ -238,8 +238,11 @@ def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, obse
     scales = (prior_dist.scale_param, emission_dist.scale_param, proposal_dist.scale_param)
     if not _kernels.get().affine_logweight_covers(x_prev, latent, y_rows, transition, emission, proposal, scales):
         return None
-    return _ops.AffineOperands((x_prev, latent, y_rows, transition[0], transition[1], emission[0], emission[1],
-                                proposal[0], proposal[1]) + scales)
+    operands = _ops.AffineOperands((x_prev, latent, y_rows, transition[0], transition[1], emission[0], emission[1],
+                                    proposal[0], proposal[1]) + scales)
+    # the latent is this very proposal's reparameterised draw (K9 tagged it): the step can be one autograd node
+    operands.is_draw = getattr(latent, "_aesmc_draw_of", None) is proposal_dist
+    return operands
 
 
 _FUSED_NORMAL = True
@@ -271,7 +274,9 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
                 _kernels.get().affine_covers(base.source, base.weight, base.offset):
             eps = torch.distributions.normal._standard_normal(base.batch_shape, dtype=base.source.dtype,
                                                                device=base.source.device)
-            return _ops.affine_rsample(base.source, base.weight, base.offset, scale, eps)
+            draw = _ops.affine_rsample(base.source, base.weight, base.offset, scale, eps)
+            draw._aesmc_draw_of = base      # lets `infer` differentiate the whole step in one node (K14)
+            return draw
     if type(base) not in (torch.distributions.Normal, AffineNormal):
         return None
     loc, scale = base.loc, base.scale

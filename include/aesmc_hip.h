@@ -377,6 +377,28 @@ int aesmc_affine_normal_logweight_backward(
     const void *grad_lse, const void *grad_lw, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes,
     int64_t B, int64_t K, void *stream);
 
+/* K14 — the whole backward of one SMC step whose x_t IS the proposal's reparameterised draw
+ *   x_t = loc_q(x_{t-1}) + scale_q * eps        (what K9 produced from the same `proposal` map and `x_prev`),
+ * i.e. of aesmc/inference.py:106-132 for a linear-Gaussian model: K12 plus the backward of the draw (K11)
+ * plus the accumulations autograd puts between them, in one pass.  `grad_x` [B,K,dx] (dense, 16-byte
+ * aligned, or NULL) is the gradient arriving at x_t from later timesteps (the next step's resampling
+ * gather); g is formed as in K12.  With
+ *   w = grad_x + d/dx_t of g * (log p(x_t | x_{t-1}) + log g(y_t | x_t))
+ * the draw carries w to the proposal's parameters and to x_{t-1}; the proposal's density itself depends on
+ * them only through eps, which the draw holds fixed, so of its terms only -dx log scale_q survives:
+ *   grad_x_prev   = A^T u_p + Q^T w                 (u_p: K12's transition location-gradient)
+ *   grad_weight_q = sum_{b,k} w (x) x_{t-1},  grad_offset_q[b] = sum_k w,
+ *   grad_scales[2] = sum_{b,k} ( g dx / scale_q + w . eps ),   eps = (x_t - loc_q) / scale_q
+ * and the transition's and emission's gradients are K12's.  `out->grad_x` and the three `grad_loc_*`
+ * must be NULL (x_t gets no gradient of its own: it is not an independent variable here).  Same
+ * workspace, same reproducible finishing launch and same AESMC_ERR_UNSUPPORTED shapes as K12. */
+int aesmc_affine_step_backward(
+    int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
+    const void *grad_lse, const void *grad_lw, const void *grad_x, const aesmc_affine_logweight_grads *out,
+    void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream);
+
 /* K13 — a learned proposal net over the particles: the two-layer tanh MLP
  *   out[b,k,:] = layer2->offset + W2 tanh( layer1->offset[b,:] + W1 x[b,k,:] )
  * with W1 [H, din] (din <= 16, H <= aesmc_particle_mlp_max_hidden() = 64), W2 [dout, H] (dout <= 16);

@@ -155,6 +155,45 @@ class OracleKernels:
             out[i] = None if grad is None else grad.to(operands[i].dtype)
         return out
 
+    def affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
+                             grad_lse=None, grad_x=None, grad_lw=None):
+        """K14's contract by PyTorch's autograd in float64: x is rebuilt as the proposal's draw
+        loc_q(x_prev) + s_q eps with eps = (x - loc_q) / s_q held fixed, so every path through it is
+        differentiated; x's own slot stays None."""
+        operands = [x_prev, x, y_rows, transition[0], transition[1], emission[0], emission[1], proposal[0],
+                    proposal[1]] + list(scales)
+        with torch.enable_grad():
+            leaves = [None if t is None else t.detach().double().requires_grad_(True) for t in operands]
+            xp, xx, yy, A, op, C, og, Q, oq, sp, sg, sq = leaves
+
+            def loc(source, weight, offset):
+                out = source @ weight.t()
+                if offset is not None:
+                    out = out + (offset.unsqueeze(1) if offset.dim() == 2 else offset)
+                return out
+
+            with torch.no_grad():
+                eps = (xx - loc(xp, Q, oq)) / sq
+            draw = loc(xp, Q, oq) + sq * eps
+            normal = torch.distributions.Normal
+            value = (normal(loc(xp, A, op), sp).log_prob(draw).sum(-1) +
+                     normal(loc(draw, C, og), sg).log_prob(yy.unsqueeze(1)).sum(-1) -
+                     normal(loc(xp, Q, oq), sq).log_prob(draw).sum(-1))
+            g = torch.zeros_like(value)
+            if grad_lw is not None:
+                g = g + grad_lw.double()
+            if grad_lse is not None:
+                g = g + grad_lse.double().unsqueeze(1) * torch.exp(lw.double() - lse.double().unsqueeze(1))
+            total = (value * g).sum()
+            if grad_x is not None:
+                total = total + (draw * grad_x.double()).sum()
+            wanted = [i for i, t in enumerate(leaves) if t is not None and need[i] and i != 1]
+            grads = torch.autograd.grad(total, [leaves[i] for i in wanted], allow_unused=True)
+        out = [None] * 12
+        for i, grad in zip(wanted, grads):
+            out[i] = None if grad is None else grad.to(operands[i].dtype)
+        return out
+
     # ---- K13 on the C oracle ------------------------------------------------------------------------
     def particle_mlp_covers(self, x, weight1, offset1, weight2, bias2=None):
         return torch.is_tensor(x) and x.dim() == 3 and x.dtype in (torch.float32, torch.float64) and \

@@ -351,6 +351,139 @@ def test_affine_logweight_backward_matches_autograd_and_the_unfused_route(kernel
     assert torch.equal(partial[1], got[1]) and torch.equal(partial[7], got[7])
 
 
+# ---- K14: the whole backward of a step whose latent is the proposal's draw ----------------------------------
+def _step_reference(o, off_p, x, g, grad_x):
+    """float64 autograd over the step with x rebuilt as the draw loc_q(x_prev) + s_q eps (eps held fixed)."""
+    leaves = [t.detach().double().requires_grad_(True) for t in
+              (o["x_prev"], o["y"], o["A"], off_p, o["C"], o["off_g"], o["Q"], o["off_q"], o["s_p"], o["s_g"], o["s_q"])]
+    xp, yy, A, op, C, og, Q, oq, sp, sg, sq = leaves
+    loc_q = xp @ Q.t() + oq.unsqueeze(1)
+    with torch.no_grad():
+        eps = (x.double() - loc_q) / sq
+    draw = loc_q + sq * eps
+    normal = torch.distributions.Normal
+    value = (normal(xp @ A.t() + op, sp).log_prob(draw).sum(-1) +
+             normal(draw @ C.t() + og, sg).log_prob(yy.unsqueeze(1)).sum(-1) -
+             normal(loc_q, sq).log_prob(draw).sum(-1))
+    total = (value * g).sum()
+    if grad_x is not None:
+        total = total + (draw * grad_x.double()).sum()
+    grads = torch.autograd.grad(total, leaves)
+    slots = (0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)
+    out = [None] * 12
+    for slot, grad in zip(slots, grads):
+        out[slot] = grad
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("with_grad_x", [False, True])
+@pytest.mark.parametrize("shape", SHAPES + [(16, 4096, 10, 10)])
+def test_step_backward_matches_autograd_and_the_launches_it_replaces(kernels, hip_device, dtype, with_grad_x, shape):
+    """K14 against (i) PyTorch's float64 autograd over the step with x_t rebuilt as the proposal's draw and
+    (ii) the launches it replaces (K12 with x_t's gradient, the accumulation, K11 through the draw):
+    every gradient — x_{t-1}, observation, three weights, three offsets, three scales — and None for x_t."""
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=3 * B + K + dx)
+    off_p = torch.from_numpy(np.random.RandomState(4).randn(dx).astype(dtype)).to(hip_device)
+    terms = ((o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    x = kernels.affine_rsample(o["x_prev"], o["Q"], o["off_q"], o["eps"], o["s_q"])      # the draw (K9)
+    lw = kernels.affine_logweight(o["x_prev"], x, o["y"], *terms, scales)
+    _, lse = kernels.logweight_lse(lw, None, None, want_lw=False)
+    rng = np.random.RandomState(9)
+    grad_lse = torch.from_numpy(rng.randn(B).astype(dtype)).to(hip_device)
+    grad_x = torch.from_numpy(rng.randn(B, K, dx).astype(dtype)).to(hip_device) if with_grad_x else None
+    need = [True] * 12
+    need[1] = False
+    got = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse,
+                                       grad_x=grad_x)
+    route = kernels.affine_step_backward_unfused(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse,
+                                                 grad_lse=grad_lse, grad_x=grad_x)
+    g = grad_lse.double().unsqueeze(1) * torch.exp(lw.double() - lse.double().unsqueeze(1))
+    want = _step_reference(o, off_p, x, g, grad_x)
+    names = ("x_prev", "x", "y", "A", "off_p", "C", "off_g", "Q", "off_q", "s_p", "s_g", "s_q")
+    tolerance = 3e-5 if dtype == np.float32 else 1e-11
+    assert got[1] is None and route[1] is None
+    for name, a, b, c in zip(names, got, want, route):
+        if name == "x":
+            continue
+        assert a is not None and a.shape == b.shape, name
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a.double() - b).abs().max()) <= tolerance * scale, (name, "vs autograd")
+        assert float((a.double() - c.double()).abs().max()) <= tolerance * scale, (name, "vs the launches it replaces")
+    again = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse,
+                                         grad_x=grad_x)
+    for a, b in zip(got, again):
+        assert (a is None and b is None) or torch.equal(a, b)     # fixed summation order: reproducible
+    some = [False] * 12
+    some[0] = some[7] = True            # no scale gradient: the kernel skips the proposal's location
+    partial = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, some, lw, lse, grad_lse=grad_lse,
+                                           grad_x=grad_x)
+    assert [t is not None for t in partial] == some
+    assert torch.equal(partial[0], got[0]) and torch.equal(partial[7], got[7])
+    if with_grad_x:                     # only later steps' gradient arrives (the ELBO term absent)
+        only = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_x=grad_x)
+        want_only = _step_reference(o, off_p, x, torch.zeros(B, K, dtype=torch.float64, device=hip_device), grad_x)
+        for name, a, b in zip(names, only, want_only):
+            if name != "x":
+                assert float((a.double() - b).abs().max()) <= tolerance * max(1.0, float(b.abs().max())), name
+
+
+def test_step_backward_validates_its_arguments(kernels, hip_device):
+    n, o = operands(2, 300, 4, 3, np.float32, hip_device, seed=1)
+    terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    lw = kernels.affine_logweight(o["x_prev"], o["x"], o["y"], *terms, scales)
+    _, lse = kernels.logweight_lse(lw, None, None, want_lw=False)
+    need = [True] * 12
+    with pytest.raises(ValueError):      # x has no gradient slot
+        kernels.affine_step_backward(o["x_prev"], o["x"], o["y"], *terms, scales, need, lw, lse,
+                                     grad_lse=torch.ones(2, device=hip_device))
+    need[1] = False
+    with pytest.raises(ValueError):      # no gradient at all
+        kernels.affine_step_backward(o["x_prev"], o["x"], o["y"], *terms, scales, need, lw, lse)
+    with pytest.raises(ValueError):
+        kernels.affine_step_backward(o["x_prev"], o["x"], o["y"], *terms, scales, need, lw, lse,
+                                     grad_lse=torch.ones(3, device=hip_device))
+
+
+def test_a_linear_gaussian_smc_step_is_one_backward_launch(hip_device):
+    """get_loss + backward over AffineNormal callables: every step from the second on is K10 forward and ONE
+    K14 launch backward — no K12, no backward of the draw — and x_t keeps reaching the callers as a tensor
+    that requires grad (latents returned by `infer` still differentiate)."""
+    from aesmc_amd import _kernels, inference, losses
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    calls = {"affine_step_backward": 0, "affine_logweight_backward": 0, "particle_affine_backward": 0}
+    originals = {name: getattr(provider, name) for name in calls}
+    for name in calls:
+        def spy(*args, _name=name, **kwargs):
+            calls[_name] += 1
+            return originals[_name](*args, **kwargs)
+        setattr(provider, name, spy)
+    try:
+        T = 6
+        model = LgssmNd(5, dtype=torch.float64, affine=True).tune_proposal().to(hip_device)
+        observations = model.simulate(T, 3, seed=2)
+        torch.manual_seed(3)
+        np.random.seed(3)
+        loss = losses.get_loss(observations, 300, "aesmc", model.initial, model.transition, model.emission,
+                               model.proposal)
+        loss.backward()
+        assert calls["affine_step_backward"] == T - 1 and calls["affine_logweight_backward"] == 0
+        assert calls["particle_affine_backward"] == 1       # time 0's emission location only
+        torch.manual_seed(3)
+        np.random.seed(3)
+        result = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal,
+                                 300, return_log_marginal_likelihood=True, return_latents=True, return_log_weight=False)
+        assert all(latent.requires_grad for latent in result["latents"][1:])
+        torch.testing.assert_close(-result["log_marginal_likelihood"].mean(), loss.detach(), rtol=1e-12, atol=1e-12)
+    finally:
+        for name, fn in originals.items():
+            setattr(provider, name, fn)
+
+
 # ---- K13: the proposal net ------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("shape", [(3, 700, 10, 64, 10), (2, 513, 5, 16, 3), (5, 64, 16, 33, 16), (1, 1000, 3, 7, 7),

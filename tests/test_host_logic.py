@@ -504,7 +504,8 @@ def test_affine_callables_give_the_loss_and_gradients_of_matmul_callables(oracle
     from aesmc_amd import _kernels
     from aesmc_amd.testing.models import LgssmNd
     provider = _kernels.get()
-    calls = {"affine_rsample": 0, "affine_logweight": 0, "affine_logweight_backward": 0}
+    calls = {"affine_rsample": 0, "affine_logweight": 0, "affine_logweight_backward": 0, "affine_step_backward": 0,
+             "particle_affine_backward": 0}
     originals = {name: getattr(provider, name) for name in calls}
     for name in calls:
         def spy(*args, _name=name, **kwargs):
@@ -528,7 +529,12 @@ def test_affine_callables_give_the_loss_and_gradients_of_matmul_callables(oracle
     # aliasing): its source is x_t, the proposal's x_{t-1} — not one
     # linear-Gaussian step, so the locations are materialised there
     fused_steps = T - 1 if algorithm == "aesmc" else 0
-    assert calls["affine_logweight"] == fused_steps and calls["affine_logweight_backward"] == fused_steps
+    # every such step's latent is the proposal's own draw: its whole backward is one K14 launch — no K12, and
+    # no backward launch of the draw (K11) either
+    assert calls["affine_logweight"] == fused_steps and calls["affine_step_backward"] == fused_steps
+    if algorithm == "aesmc":
+        # (the one K11 launch left is time 0's emission location, materialised for K5)
+        assert calls["affine_logweight_backward"] == 0 and calls["particle_affine_backward"] == 1
     (loss_a, grads_a), (loss_b, grads_b) = results[False], results[True]
     loss_tol, grad_tol = (1e-12, 1e-9) if dtype == torch.float64 else (2e-5, 2e-3)
     assert abs(float(loss_a - loss_b)) <= loss_tol * max(1.0, abs(float(loss_a)))

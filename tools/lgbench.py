@@ -99,6 +99,17 @@ def bench(name, dtype=torch.float32):
                                            (o["Q"], o["off_q"]), (o["s_p"], o["s_g"], o["s_q"]), need, lw=lws[i],
                                            lse=lses[i], grad_lse=torch.ones_like(lses[i]))
     run("K12 affine_logweight_backward", k12, esz * N * (4 * dx + 1))
+    need14 = list(need)
+    need14[1] = False
+
+    def k14():
+        i = (state["i"] + 1) % len(sets)
+        state["i"] = i
+        o = sets[i]
+        return k.affine_step_backward(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]),
+                                      (o["Q"], o["off_q"]), (o["s_p"], o["s_g"], o["s_q"]), need14, lws[i], lses[i],
+                                      grad_lse=torch.ones_like(lses[i]), grad_x=o["eps"])
+    run("K14 affine_step_backward", k14, esz * N * (4 * dx + 1))
     return out
 
 
