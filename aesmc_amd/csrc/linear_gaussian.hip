@@ -196,10 +196,10 @@ __device__ __forceinline__ void lg_apply_tile(const T *__restrict__ wt, const T 
 // The same chains as a LOOP over the input elements (two per trip): one column of weights live at a time
 // instead of the whole matrix, a few hundred bytes of code instead of DP^2 unrolled multiply-adds —
 // what the register-heavy backward kernel needs.  Same order of operations, same bits.
-template <typename T, int DP, int PPL>
+template <typename T, int DP, int PPL, int UNROLL = 2>
 __device__ __forceinline__ void lg_apply_loop(const T *__restrict__ wt, const T *__restrict__ tile,
                                               const uint32_t (&base)[PPL], uint32_t din, T (&acc)[DP][PPL]) {
-#pragma unroll 2
+#pragma unroll UNROLL
   for (uint32_t i = 0; i < din; ++i) {
     T xv[PPL];
 #pragma unroll
@@ -790,7 +790,9 @@ __device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, ui
 // The same sum over a wavefront's OWN 64 particles (lane = particle mapping of the one-particle-per-lane
 // kernels: rows 64 w .. 64 w + 63 of the tiles were written and are read by this wavefront alone), so the
 // caller needs no workgroup barrier around it — a wavefront-level fence orders its LDS writes and reads.
-template <typename T, int PPL>
+// ONES: the lanes of column 15 feed 1 instead of tx's (unused, extent < 16) column, so acc[j][15] gathers
+// sum_p tg[p][j] — the tile's column sums at no extra pass (lg_flush_column_sums).
+template <typename T, int PPL, bool ONES = false>
 __device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg, uint32_t dg,
                                                         const T *__restrict__ tx, uint32_t dxx, uint32_t np,
                                                         typename Mfma<T>::Acc &acc) {
@@ -804,6 +806,21 @@ __device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg
   for (int r = 0; r < PPL; ++r) {
     uint32_t p = r * kLgBlock + wave * 64 + (lane >> 4);
     uint32_t eg = p * dg + col, ex = p * dxx + col;
+    if (np == (uint32_t)(PPL * kLgBlock)) {      // a whole tile (all but the last): no particle masks
+#pragma unroll
+      for (int group = 0; group < 4; ++group) {
+        T a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a[t] = tg[eg + (4 * group + t) * step_g];
+          b[t] = tx[ex + (4 * group + t) * step_x];
+          if (ONES) b[t] = col == 15u ? T(1) : b[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
+      }
+      continue;
+    }
 #pragma unroll
     for (int group = 0; group < 4; ++group) {
       T a[4], b[4];
@@ -812,12 +829,32 @@ __device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg
         const bool live = p + 4 * t < np;
         a[t] = live ? tg[eg + t * step_g] : T(0);
         b[t] = live ? tx[ex + t * step_x] : T(0);
+        if (ONES) b[t] = col == 15u ? T(1) : b[t];      // a particle past the end contributes a = 0
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
       p += 16;
       eg += 4 * step_g;
       ex += 4 * step_x;
+    }
+  }
+}
+
+// A tile that lies inside one batch row needs no row bookkeeping: its column sums are what the ONES
+// accumulate gathered in column 15 since the last flush.  Each wavefront writes its 16 sums to slot
+// `wave` of the tile's row-sum record and clears them; the finishing launch adds the four slots (same
+// test there: lg_single_row).  No barrier, no pass over the tile.
+__host__ __device__ __forceinline__ bool lg_single_row(int64_t n0, uint32_t np, uint32_t K) {
+  return (uint32_t)(n0 % K) + np <= K;
+}
+template <typename T>
+__device__ __forceinline__ void lg_flush_column_sums(typename Mfma<T>::Acc &acc, T *__restrict__ record, bool keep) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((lane & 15) == 15) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (keep) record[wave * 16 + Mfma<T>::row(lane, r)] = acc[r];
+      acc[r] = T(0);
     }
   }
 }
@@ -1126,7 +1163,11 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
 // transition term (w -= u_p), then w itself takes the place K12 gives u_q: grad W_q = sum w (x) x_{t-1},
 // grad offset_q = row sums of w, grad x_{t-1} = A^T u_p + Q^T w, grad s_q = sum g d / s_q + w . eps.  Neither
 // a gradient for x_t nor K9's own backward launch (K11) nor the two [B,K,d] accumulations between them exist.
-template <typename T, int DP, int PPL>
+#ifndef LG_STEP_UNROLL
+#define LG_STEP_UNROLL 2
+#endif
+// EXACT: both extents equal DP (the host checks) — every extent test, row stride and LDS offset folds.
+template <typename T, int DP, int PPL, bool EXACT>
 __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_step_backward_kernel(
     const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
     LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
@@ -1134,7 +1175,9 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
     const T *__restrict__ grad_lw, LgBackwardOut out, int64_t N, uint32_t K) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
-  const uint32_t dx = mp.dout, dy = mg.dout;
+  constexpr int kUnroll = EXACT ? LG_STEP_UNROLL : 2;
+  constexpr bool ONES = EXACT && DP < 16;      // the latent has no column 15: it carries the column sums
+  const uint32_t dx = EXACT ? (uint32_t)DP : (uint32_t)mp.dout, dy = EXACT ? (uint32_t)DP : (uint32_t)mg.dout;
   T *wf = reinterpret_cast<T *>(lg_smem);        // [3][DP*DP] input-major: locations (p, g, q)
   T *wn = wf + 3 * DP * DP;                      // [3][DP*DP] output-major: adjoints
   T *scratch = wn + 3 * DP * DP;
@@ -1179,6 +1222,9 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
     const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
     lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
     const uint32_t k0_tile = (uint32_t)(n0 - (int64_t)b0 * K);
+    // offsets' gradients: a tile inside one batch row takes its sums from the matrix cores' spare column
+    const bool column_sums = ONES && lg_single_row(n0, np, K);
+    const int row_pass = column_sums ? 0 : row_terms;      // the terms that need the pass over the tile
     T g[PPL];
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
@@ -1207,7 +1253,7 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
     if (gx_in != nullptr && lx.rs != ly.rs) lg_lds_barrier();   // the tile changes layout under the other wavefronts
     // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u
     lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
-    lg_apply_loop<T, DP, PPL>(wf + DP * DP, tx, at, dx, u);
+    lg_apply_loop<T, DP, PPL, kUnroll>(wf + DP * DP, tx, at, dx, u);
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
       T q = T(0);
@@ -1222,15 +1268,16 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
       scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
     }
     lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu, ly);
-    lg_u_ready((row_terms & 2) != 0);
-    if (row_terms & 2) lg_row_sums<T>(tu, ly.rs, dy, np, k0_tile, K, scratch, rows + (tile * 3 + 1) * (kLgRowsMax * 16));
-    lg_apply_loop<T, DP, PPL>(wn + DP * DP, tu, ay, dy, w);
-    lg_outer_accumulate_own<T, PPL>(tu, ly.rs, tx, lx.rs, np, acc_c);
+    lg_u_ready((row_pass & 2) != 0);
+    if (row_pass & 2) lg_row_sums<T>(tu, ly.rs, dy, np, k0_tile, K, scratch, rows + (tile * 3 + 1) * (kLgRowsMax * 16));
+    lg_apply_loop<T, DP, PPL, kUnroll>(wn + DP * DP, tu, ay, dy, w);
+    lg_outer_accumulate_own<T, PPL, ONES>(tu, ly.rs, tx, lx.rs, np, acc_c);
+    if (ONES) lg_flush_column_sums<T>(acc_c, rows + (tile * 3 + 1) * (kLgRowsMax * 16), column_sums && (row_terms & 2));
     if (lx.rs != ly.rs) lg_lds_barrier();     // back to the latent's layout
-    else lg_u_ready((row_terms & 2) != 0);
+    else lg_u_ready((row_pass & 2) != 0);
     // ---- transition term: u = g (x - loc_p) / s_p^2;  w -= u
     lg_row_values<T, DP, PPL, 4, 0>(vec, true, tab, b0, brow, u);
-    lg_apply_loop<T, DP, PPL>(wf, tprev, at, dx, u);
+    lg_apply_loop<T, DP, PPL, kUnroll>(wf, tprev, at, dx, u);
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
       T q = T(0);
@@ -1245,15 +1292,16 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
       scale_acc[0] += g[r] * (q * inv_var_p * inv_s_p - T(dx) * inv_s_p);
     }
     lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
-    lg_u_ready((row_terms & 1) != 0);
-    if (row_terms & 1) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 0) * (kLgRowsMax * 16));
-    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn, tu, au, dx, gprev);
-    lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_a);
-    lg_u_ready((row_terms & 1) != 0);
+    lg_u_ready((row_pass & 1) != 0);
+    if (row_pass & 1) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 0) * (kLgRowsMax * 16));
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL, kUnroll>(wn, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL, ONES>(tu, lx.rs, tprev, lx.rs, np, acc_a);
+    if (ONES) lg_flush_column_sums<T>(acc_a, rows + (tile * 3 + 0) * (kLgRowsMax * 16), column_sums && (row_terms & 1));
+    lg_u_ready((row_pass & 1) != 0);
     // ---- the draw: w reaches the proposal's parameters and x_{t-1};  grad s_q = g d / s_q + w . eps
     if (want_sq) {
       lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
-      lg_apply_loop<T, DP, PPL>(wf + 2 * DP * DP, tprev, at, dx, u);
+      lg_apply_loop<T, DP, PPL, kUnroll>(wf + 2 * DP * DP, tprev, at, dx, u);
 #pragma unroll
       for (int r = 0; r < PPL; ++r) {
         T dot = T(0);
@@ -1266,17 +1314,41 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
       }
     }
     lg_rows_to_tile<T, DP, PPL>(w, dx, p, live, tu, lx);
-    lg_u_ready((row_terms & 4) != 0);
-    if (row_terms & 4) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 2) * (kLgRowsMax * 16));
-    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn + 2 * DP * DP, tu, au, dx, gprev);
-    lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_q);
-    lg_lds_barrier();
-    if (gxprev != nullptr) {
-      lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev, lx);
+    lg_u_ready((row_pass & 4) != 0);
+    if (row_pass & 4) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 2) * (kLgRowsMax * 16));
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL, kUnroll>(wn + 2 * DP * DP, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL, ONES>(tu, lx.rs, tprev, lx.rs, np, acc_q);
+    if (ONES) lg_flush_column_sums<T>(acc_q, rows + (tile * 3 + 2) * (kLgRowsMax * 16), column_sums && (row_terms & 4));
+    if constexpr (EXACT && (DP * sizeof(T)) % 8 == 0) {
+      // rows of whole 8-byte pairs: each lane stores its own particles' rows (a wavefront's stores cover
+      // one contiguous span) — no trip through the tile, no barriers around it
+      if (gxprev != nullptr) {
+        typedef T Pair __attribute__((ext_vector_type(8 / sizeof(T))));
+        constexpr int PER = 8 / sizeof(T);
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+          if (live[r]) {
+            Pair *dst = reinterpret_cast<Pair *>(gxprev + (n0 + p[r]) * DP);
+#pragma unroll
+            for (int j = 0; j < DP / PER; ++j) {
+              Pair v;
+#pragma unroll
+              for (int e = 0; e < PER; ++e) v[e] = gprev[j * PER + e][r];
+              dst[j] = v;
+            }
+          }
+        }
+      }
       lg_lds_barrier();
-      lg_store_rows<T, true>(gxprev + n0 * dx, np * dx, tprev, lx);
+    } else {
+      lg_lds_barrier();
+      if (gxprev != nullptr) {
+        lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev, lx);
+        lg_lds_barrier();
+        lg_store_rows<T, true>(gxprev + n0 * dx, np * dx, tprev, lx);
+      }
+      lg_lds_barrier();
     }
-    lg_lds_barrier();
   }
   T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
   lg_outer_publish<T>(acc_a, scratch, record);
@@ -1305,7 +1377,8 @@ struct LgFinish {
   void *goff[3];
   int32_t goff_d[3];
   int32_t row_terms, matrices, row_blocks;    // records per tile; matrix blocks; row blocks per term (64 rows each)
-  int64_t B;
+  int32_t column_sums;                        // single-row tiles hold four wavefront sums (lg_flush_column_sums)
+  int64_t B, N;
   uint32_t K, TP;
 };
 template <typename T>
@@ -1322,8 +1395,12 @@ __global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ w
     const int64_t first = b * f.K / f.TP, last = ((b + 1) * f.K - 1) / f.TP;
     T sum = T(0);
     for (int64_t tile = first; tile <= last; ++tile) {
-      const int64_t b0 = tile * f.TP / f.K;
-      sum += rows[((tile * f.row_terms + term) * kLgRowsMax + (b - b0)) * 16 + j];
+      const int64_t n0 = tile * f.TP, b0 = n0 / f.K;
+      const T *record = rows + (tile * f.row_terms + term) * (kLgRowsMax * 16);
+      if (f.column_sums && lg_single_row(n0, (uint32_t)min((int64_t)f.TP, f.N - n0), f.K))
+        sum += ((record[j] + record[16 + j]) + record[32 + j]) + record[48 + j];     // the four wavefronts' sums
+      else
+        sum += record[(b - b0) * 16 + j];
     }
     goff[b * d + j] = sum;
     return;
@@ -1609,6 +1686,11 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
   return AESMC_OK;
 }
 
+template <typename T, int DP, int PPL>
+static constexpr auto affine_step_backward_exact = &affine_step_backward_kernel<T, DP, PPL, true>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_step_backward_any = &affine_step_backward_kernel<T, DP, PPL, false>;
+
 template <typename T>
 static int launch_affine_logweight_backward(const void *xprev, const void *x, const void *y, int64_t y_sb,
                                             const aesmc_affine_map *mp, const aesmc_affine_map *mg,
@@ -1647,8 +1729,10 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
       lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),               \
       static_cast<const T *>(lw), static_cast<const T *>(lse), static_cast<const T *>(grad_lse),                    \
       static_cast<const T *>(grad_lw), out, N, (uint32_t)K
-  if (step) {
-    LG_DISPATCH(affine_step_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
+  if (step && dx == dp && dy == dp) {
+    LG_DISPATCH(affine_step_backward_exact, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
+  } else if (step) {
+    LG_DISPATCH(affine_step_backward_any, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
   } else {
     LG_DISPATCH(affine_logweight_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
   }
@@ -1664,7 +1748,8 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   f.goff[0] = o->grad_offset_p; f.goff[1] = o->grad_offset_g; f.goff[2] = o->grad_offset_q;
   f.goff_d[0] = (int32_t)dx; f.goff_d[1] = (int32_t)dy; f.goff_d[2] = (int32_t)dx;
   f.row_blocks = row_terms != 0 ? (int32_t)((B + 63) / 64) : 0;
-  f.B = B; f.K = (uint32_t)K; f.TP = (uint32_t)(kLgBlock * ppl);
+  f.B = B; f.N = N; f.K = (uint32_t)K; f.TP = (uint32_t)(kLgBlock * ppl);
+  f.column_sums = (step && dx == dp && dy == dp && dp < 16) ? 1 : 0;
   hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(4 + 3 * f.row_blocks)), dim3(1024), 0, stream,
                      static_cast<const T *>(ws), grid, 4 * kLgRecord, f);   // one finishing launch for everything
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;

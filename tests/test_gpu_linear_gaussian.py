@@ -378,11 +378,14 @@ def _step_reference(o, off_p, x, g, grad_x):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("with_grad_x", [False, True])
-@pytest.mark.parametrize("shape", SHAPES + [(16, 4096, 10, 10)])
+@pytest.mark.parametrize("shape", SHAPES + [(16, 4096, 10, 10), (300, 4096, 10, 10), (520, 2100, 8, 8), (2, 2048, 12, 12)])
 def test_step_backward_matches_autograd_and_the_launches_it_replaces(kernels, hip_device, dtype, with_grad_x, shape):
     """K14 against (i) PyTorch's float64 autograd over the step with x_t rebuilt as the proposal's draw and
     (ii) the launches it replaces (K12 with x_t's gradient, the accumulation, K11 through the draw):
-    every gradient — x_{t-1}, observation, three weights, three offsets, three scales — and None for x_t."""
+    every gradient — x_{t-1}, observation, three weights, three offsets, three scales — and None for x_t.
+    The last shapes reach the two-particles-per-lane launch (2^20 particles and more) with exact extents:
+    offsets' gradients out of the matrix cores' spare column where a tile lies inside one batch row
+    (K = 4096) and by the pass over the tile where it does not (K = 2100)."""
     B, K, dx, dy = shape
     n, o = operands(B, K, dx, dy, dtype, hip_device, seed=3 * B + K + dx)
     off_p = torch.from_numpy(np.random.RandomState(4).randn(dx).astype(dtype)).to(hip_device)

@@ -110,6 +110,14 @@ def bench(name, dtype=torch.float32):
                                       (o["Q"], o["off_q"]), (o["s_p"], o["s_g"], o["s_q"]), need14, lws[i], lses[i],
                                       grad_lse=torch.ones_like(lses[i]), grad_x=o["eps"])
     run("K14 affine_step_backward", k14, esz * N * (4 * dx + 1))
+    if os.environ.get("LGBENCH_VARIANTS"):
+        full = list(need14)
+        for slots, label in (((8,), "K14 without offset_q"), ((8, 9, 10, 11), "K14 without offset_q, scales")):
+            need14[:] = full
+            for slot in slots:
+                need14[slot] = False
+            run(label, k14, esz * N * (4 * dx + 1))
+        need14[:] = full
     return out
 
 
