@@ -194,6 +194,8 @@ def normal_log_weight_deferred(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scal
 def attach_lse(lse, lw, operands):
     """The row log-sum-exp `lse` [B] of `lw` as a differentiable function of the `operands` of the
     launch that produced `lw` (K5's eight views, or K10's AffineOperands)."""
+    if isinstance(operands, PendingStep):
+        return operands.bind(lse.detach())
     if isinstance(operands, AffineOperands):
         return _AffineLogWeightLSE.apply(lse.detach(), lw, *operands)
     return _NormalLogWeightLSE.apply(lse.detach(), lw, *operands)
@@ -429,44 +431,77 @@ class _AffineLogWeightLSE(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
-class _AffineStep(torch.autograd.Function):
-    """One SMC step of a linear-Gaussian model as ONE autograd node: inputs the step's operands (x_t only
-    as a value: it is the proposal's reparameterised draw of the same x_{t-1}), outputs the row
-    log-sum-exp of the step's log-weights and x_t itself — the tensor every later consumer (the next
-    resampling gather, the callables, the returned latents) reads.  Backward (kernel K14) therefore
-    receives both the ELBO's gradient at the log-sum-exp and whatever arrives at x_t from later steps,
-    and carries them through the densities AND the draw to x_{t-1} and the parameters in one pass: the
-    draw's own node (K11), K12's x_t gradient and the two [B,K,d] accumulations autograd would put between
-    them never run."""
+class PendingStep:
+    """The link between a step's autograd node (_AffineStep, made when the step is weighed) and its row
+    log-sum-exp, which the NEXT resampling launch produces: `carrier` is the node's [B] output that takes
+    the log-sum-exp's gradient back to the node, `box[0]` the values once `bind` has seen them."""
+    __slots__ = ("carrier", "box")
+
+    def __init__(self):
+        self.carrier = None
+        self.box = [None]       # what the node keeps: the values only (the carrier would close a reference cycle)
+
+    def bind(self, lse):
+        self.box[0] = lse
+        return _BindLse.apply(self.carrier, lse)
+
+
+class _BindLse(torch.autograd.Function):
+    """lse [B] (values from the launch that reduced the rows) as a function of a step node's carrier."""
 
     @staticmethod
-    def forward(ctx, lw, x_value, *operands):
-        lse = _kernels.get().logweight_lse(lw, None, None, want_lw=False)[1]
-        ctx.save_for_backward(lw, lse, x_value, *[t for t in operands if t is not None])
+    def forward(ctx, carrier, lse):
+        return lse.view_as(lse)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None
+
+
+class _AffineStep(torch.autograd.Function):
+    """One SMC step of a linear-Gaussian model as ONE autograd node: inputs the step's operands (x_t only
+    as a value: it is the proposal's reparameterised draw of the same x_{t-1}), outputs x_t itself — the
+    tensor every later consumer (the next resampling gather, the callables, the returned latents) reads —
+    and a [B] carrier that stands for the row log-sum-exp of the step's log-weights until the launch
+    that reduces the rows (the next resampling step) has produced it (PendingStep.bind).  Backward
+    (kernel K14) therefore receives both the ELBO's gradient at the log-sum-exp and whatever arrives at
+    x_t from later steps, and carries them through the densities AND the draw to x_{t-1} and the
+    parameters in one pass: the draw's own node (K11), K12's x_t gradient and the two [B,K,d]
+    accumulations autograd would put between them never run."""
+
+    @staticmethod
+    def forward(ctx, lw, x_value, pending, *operands):
+        ctx.lse_box = pending.box
+        ctx.save_for_backward(lw, x_value, *[t for t in operands if t is not None])
         ctx.present = [t is not None for t in operands]
-        return lse, x_value.view_as(x_value)
+        return lw.new_empty((lw.size(0),)), x_value.view_as(x_value)     # the carrier's values are never read
 
     @staticmethod
     def backward(ctx, grad_lse, grad_x):
-        lw, lse, x_value = ctx.saved_tensors[:3]
-        saved = iter(ctx.saved_tensors[3:])
+        lw, x_value = ctx.saved_tensors[:2]
+        saved = iter(ctx.saved_tensors[2:])
         operands = [next(saved) if present else None for present in ctx.present]
         x_prev, _, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = operands
-        need = list(ctx.needs_input_grad[2:])
+        need = list(ctx.needs_input_grad[3:])
         need[1] = False
+        lse = ctx.lse_box[0]
+        if grad_lse is not None and lse is None:
+            raise RuntimeError("aesmc_amd internal error: a step's log-sum-exp received a gradient but was never bound")
         grads = _kernels.get().affine_step_backward(
             x_prev, x_value, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q), need, lw, lse,
             grad_lse=None if grad_lse is None else grad_lse.contiguous(), grad_x=grad_x)
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)
 
 
 def affine_step(lw, operands):
-    """(row log-sum-exp [B], x_t) of a K10 step whose x_t is the proposal's draw, tied to the step's
-    operands by one autograd node (see _AffineStep).  `operands[1]` (x_t) enters as a value."""
-    x_value = operands[1].detach()
+    """(PendingStep, x_t) of a K10 step whose x_t is the proposal's draw: one autograd node ties x_t and —
+    once `attach_lse` binds it — the row log-sum-exp of `lw` to the step's operands (see _AffineStep).
+    `operands[1]` (x_t) enters as a value."""
+    pending = PendingStep()
     inputs = list(operands)
     inputs[1] = None
-    return _AffineStep.apply(lw, x_value, *inputs)
+    pending.carrier, x_t = _AffineStep.apply(lw, operands[1].detach(), pending, *inputs)
+    return pending, x_t
 
 
 def affine_log_weight(operands):

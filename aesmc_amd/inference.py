@@ -258,7 +258,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
     # the log-sum-exp — produced by the NEXT step's resampling launch — is tied to K5's operands
     # afterwards, its backward being K5's with K1's softmax term formed in place
     fold_lse_backward = use_smc and not return_log_weight and not return_log_weights
-    deferred = {}         # timestep -> K5 operands whose log-sum-exp is still to be attached
+    deferred = {}         # timestep -> what its log-sum-exp is still to be attached to: K5 / K10 operands, or a step node
     num_timesteps = len(observations)
     batch_size = _first_tensor(observations[0]).size(0)
     keep_originals = return_original_latents or return_latents
@@ -321,7 +321,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
         # log-weight = log prior/transition + log emission - log proposal (inference.py:97-98,
         # :125-126): one kernel when all three are Normal (K5), else three summed log-densities
         # (K4 or the distribution's own log_prob) combined by K1
-        log_weight_t = step_lse_now = None
+        log_weight_t = None
         if not isinstance(latent, dict) and not isinstance(observation, dict):
             fold = fold_lse_backward and torch.is_grad_enabled()
             log_weight_t = state.normal_log_weight(prior_dist, proposal_dist, latent, emission_dist,
@@ -332,8 +332,8 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                     if getattr(operands, "is_draw", False):
                         # a linear-Gaussian step whose latent is the proposal's own draw: ONE autograd node
                         # for the step (K14).  It hands back x_t as its output — the tensor every later
-                        # consumer reads — and the row log-sum-exp (K1 now, not the next resampling launch)
-                        step_lse_now, latent = _ops.affine_step(log_weight_t, operands)
+                        # consumer reads; the row log-sum-exp is bound to it when a launch has produced it
+                        deferred[time], latent = _ops.affine_step(log_weight_t, operands)
                         history[-1] = latent
                         if keep_originals:
                             originals[-1] = latent
@@ -349,10 +349,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
             # launch for free — or from K1 when no resampling follows
             # (importance sampling never needs the per-step value: it normalises the summed weights)
             pending = use_smc and time + 1 < num_timesteps
-            if step_lse_now is not None:
-                lse_t = step_lse_now
-            else:
-                lse_t = None if (pending or not use_smc) else _ops.row_logsumexp(log_weight_t)
+            lse_t = None if (pending or not use_smc) else _ops.row_logsumexp(log_weight_t)
             if lse_t is not None and time in deferred:
                 lse_t = _ops.attach_lse(lse_t, log_weight_t, deferred.pop(time))
             if accumulate:

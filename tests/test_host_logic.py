@@ -619,3 +619,27 @@ def test_affine_route_reproduces_the_reference_fixtures_on_host(oracle_backend, 
         want = case["grad_" + pname]
         scale = np.abs(want).max() + 1e-30
         np.testing.assert_allclose(p.grad.numpy() / scale, want / scale, rtol=0, atol=1e-9)
+
+
+def test_a_forward_pass_leaves_no_reference_cycles_behind(oracle_backend):
+    """An ELBO that is evaluated with autograd on and then dropped (no backward) must free its graph by
+    reference counting alone: a cycle through a step node would keep every step's [B,K,d] tensors alive
+    until the cyclic collector happens to run."""
+    import gc
+    from aesmc_amd import _ops
+    from aesmc_amd.testing.models import LgssmNd
+    model = LgssmNd(3, dtype=torch.float64, affine=True).tune_proposal()
+    observations = model.simulate(4, 3, seed=1)
+    gc.collect()
+    gc.set_debug(gc.DEBUG_SAVEALL)
+    try:
+        loss = losses.get_loss(observations, 16, "aesmc", model.initial, model.transition, model.emission,
+                               model.proposal)
+        assert loss.requires_grad
+        del loss
+        gc.collect()
+        leaked = [o for o in gc.garbage if isinstance(o, (_ops.PendingStep, torch.Tensor))]
+    finally:
+        gc.set_debug(0)
+        gc.garbage.clear()
+    assert not leaked, leaked

@@ -1,5 +1,5 @@
 """Workload for hardware-counter passes over the linear-Gaussian propagation kernels (rocprofv3 --pmc,
-one counter set per run): K8, K9, K10 (and their backward kernels when built) at B=1024 K=4096 d=10,
+one counter set per run): K8 .. K12 and K14 at B=1024 K=4096 d=10,
 3 launches each."""
 import os
 import sys
@@ -26,5 +26,8 @@ for _ in range(3):
     need = [True, True, False, True, False, True, False, True, True, False, False, False]
     k.affine_logweight_backward(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
                                 (o["s_p"], o["s_g"], o["s_q"]), need, lw=lw, lse=lse, grad_lse=torch.ones_like(lse))
+    need[1] = False
+    k.affine_step_backward(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
+                           (o["s_p"], o["s_g"], o["s_q"]), need, lw, lse, grad_lse=torch.ones_like(lse), grad_x=o["eps"])
 torch.cuda.synchronize()
 print("done")
