@@ -772,8 +772,9 @@ class HipKernels:
                                 (x1, x2, base, out, m1, m2, keep1, keep2))
         return out
 
-    def affine_rsample(self, source, weight, offset, eps, scale):
-        """K9: (offset + source @ weight.T) + eps * scale -> dense [B,K,dout]; `scale` holds one value."""
+    def affine_rsample(self, source, weight, offset, eps, scale, out=None):
+        """K9: (offset + source @ weight.T) + eps * scale -> dense [B,K,dout]; `scale` holds one value.
+        `out`: a dense, 16-byte aligned [B,K,dout] tensor to write instead of a new one."""
         if not self.affine_covers(source, weight, offset):
             raise ValueError("aesmc_amd: affine_rsample operands outside what kernel K9 covers")
         tag = _DTYPE_TAG[source.dtype]
@@ -784,7 +785,10 @@ class HipKernels:
         if scale.numel() != 1 or scale.dtype != source.dtype or scale.device != source.device:
             raise ValueError("aesmc_amd: affine_rsample takes one scale value on the device")
         source, eps = self._dense16(source), self._dense16(eps)
-        out = torch.empty((B, K, dout), dtype=source.dtype, device=source.device)
+        if out is None:
+            out = torch.empty((B, K, dout), dtype=source.dtype, device=source.device)
+        else:
+            self._check_out(out, (B, K, dout), source, "affine_rsample")
         amap, keep = self._affine_map(weight, offset)
         with _on_device(source.device):
             args = (tag, _ptr(source), ctypes.byref(amap), _ptr(eps), _ptr(scale), _ptr(out), B, K,
@@ -794,6 +798,40 @@ class HipKernels:
                 nbytes = source.element_size() * B * K * (source.size(2) + 2 * dout)
                 self.timer.note("affine_normal_rsample", (self._lib.aesmc_affine_normal_rsample, args), nbytes,
                                 (source, eps, scale, out, amap, keep))
+        return out
+
+    @staticmethod
+    def _check_out(out, shape, like, what):
+        if not (torch.is_tensor(out) and tuple(out.shape) == tuple(shape) and out.dtype == like.dtype and
+                out.device == like.device and out.is_contiguous() and out.data_ptr() % 16 == 0):
+            raise ValueError("aesmc_amd: {}: `out` must be a dense, 16-byte aligned {} {} tensor on {}".format(
+                what, tuple(shape), like.dtype, like.device))
+
+    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x):
+        """K15: the proposal's draw and the step's log-weight in one launch.  Writes
+        x = loc_q(x_prev) + eps * s_q into `out_x` (K9's bits) and returns K10's log-weight [B,K] of
+        (x_prev, x, y_rows) (K10's bits)."""
+        if not self.affine_logweight_covers(x_prev, eps, y_rows, transition, emission, proposal, scales):
+            raise ValueError("aesmc_amd: affine_propagate operands outside what kernel K15 covers")
+        tag = _DTYPE_TAG[eps.dtype]
+        B, K, dx = eps.shape
+        self._check_out(out_x, (B, K, dx), eps, "affine_propagate")
+        x_prev, eps = self._dense16(x_prev), self._dense16(eps)
+        if out_x.data_ptr() == x_prev.data_ptr():
+            raise ValueError("aesmc_amd: affine_propagate cannot write the draw over x_prev")
+        if y_rows.stride(1) != 1:
+            y_rows = y_rows.contiguous()
+        out = torch.empty((B, K), dtype=eps.dtype, device=eps.device)
+        maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
+        with _on_device(eps.device):
+            args = (tag, _ptr(x_prev), _ptr(eps), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
+                    ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
+                    _ptr(scales[2]), _ptr(out_x), _ptr(out), B, K, self._stream(eps))
+            _lib.check(self._lib.aesmc_affine_normal_propagate(*args), "aesmc_affine_normal_propagate")
+            if self.timer is not None:
+                nbytes = eps.element_size() * (B * K * (3 * dx + 1) + y_rows.numel())
+                self.timer.note("affine_normal_propagate", (self._lib.aesmc_affine_normal_propagate, args), nbytes,
+                                (x_prev, eps, y_rows, out, out_x, maps, scales))
         return out
 
     def affine_logweight_covers(self, x_prev, x, y_rows, transition, emission, proposal, scales):

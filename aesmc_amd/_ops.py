@@ -368,6 +368,29 @@ class _AffineRsample(torch.autograd.Function):
         return gsrc, gw, goff, gscale, None
 
 
+class _DeferredAffineRsample(torch.autograd.Function):
+    """The draw of `_AffineRsample` with its VALUES still to come: forward only allocates the [B,K,dout]
+    result — the launch that weighs the step (K15) or, failing that, K9 fills it before anything reads
+    it (state.materialise_draw) — while the backward is the draw's own, valid whenever it runs."""
+
+    @staticmethod
+    def forward(ctx, source, weight, offset, scale, eps):
+        ctx.save_for_backward(source, weight, eps if scale.requires_grad else None)
+        ctx.offset_shape = None if offset is None else tuple(offset.shape)
+        ctx.scale_shape = tuple(scale.shape)
+        return torch.empty(source.shape[:2] + (weight.size(0),), dtype=source.dtype, device=source.device)
+
+    backward = staticmethod(_AffineRsample.backward)
+
+
+def affine_rsample_deferred(source, weight, offset, scale, eps):
+    """An uninitialised [B,K,dout] tensor standing for the reparameterised draw (values: K15 or K9, later)."""
+    tensors = (source, weight, offset, scale)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return _DeferredAffineRsample.apply(source, weight, offset, scale, eps)
+    return torch.empty(source.shape[:2] + (weight.size(0),), dtype=source.dtype, device=source.device)
+
+
 def affine_rsample(source, weight, offset, scale, eps):
     """Reparameterised draw from Normal(offset + source @ weight.T, scale) given the noise (kernel K9)."""
     tensors = (source, weight, offset, scale)
@@ -519,6 +542,15 @@ def affine_log_weight_deferred(operands):
         None if t is None else t.detach() for t in operands]
     lw = _kernels.get().affine_logweight(x_prev, x, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q))
     return lw, operands
+
+
+def affine_propagate(operands, eps):
+    """K15, no autograd node: fills operands[1] (the deferred draw x_t) from the noise `eps` and returns the
+    step's log-weights [B,K] — K9 and K10 in one launch, the same bits as the two."""
+    x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = [
+        None if t is None else t.detach() for t in operands]
+    return _kernels.get().affine_propagate(x_prev, eps, y_rows, (A, off_p), (C, off_g), (Q, off_q),
+                                           (s_p, s_g, s_q), out_x=x)
 
 
 # ---- K13: a two-layer tanh net over the particles --------------------------------------------------------

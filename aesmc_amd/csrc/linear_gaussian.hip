@@ -448,11 +448,15 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_rsample_kernel(const T *__
 //   log N = (-q) / (2 sigma^2) - d (log sigma + log sqrt(2 pi))
 // — ONE division per term and particle instead of PyTorch's one per element (K5 keeps those: it is
 // HBM-bound either way; this kernel would be VALU-bound on 2 d divisions per particle).
-template <typename T, int DP, int PPL, bool TAB, bool PREFETCH>
+// DRAW (K15): `x` holds the proposal's NOISE instead of x_t; the kernel forms the draw
+//   x_t = loc_q + eps * scale_q        (K9's arithmetic on K9's chain: the same bits)
+// from the proposal location it computes anyway, writes it to `out_x` through the tile and weighs it —
+// one pass over x_{t-1} and the noise instead of K9's and K10's two passes over three arrays.
+template <typename T, int DP, int PPL, bool TAB, bool PREFETCH, bool DRAW = false>
 __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
     const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
     LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
-    T *__restrict__ out_lw, int64_t N, uint32_t K) {
+    T *__restrict__ out_lw, int64_t N, uint32_t K, T *__restrict__ out_x) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
   constexpr int NV = (PPL * DP + Vec16<T>::N - 1) / Vec16<T>::N;
@@ -549,7 +553,12 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
       if ((uint32_t)j < dx) {
 #pragma unroll
         for (int r = 0; r < PPL; ++r) {
-          xx[j][r] = tx[at[r] + j];
+          if constexpr (DRAW) {
+            xx[j][r] = locq[j][r] + tx[at[r] + j] * s_q;      // the product rounded before the sum, as K9 / K6
+            if (live[r]) tx[at[r] + j] = xx[j][r];             // the lane's own row: the draw leaves through the tile
+          } else {
+            xx[j][r] = tx[at[r] + j];
+          }
           const T dp = xx[j][r] - locp[j][r], dq = xx[j][r] - locq[j][r];
           qp[r] = fma_t(dp, dp, qp[r]);
           qq[r] = fma_t(dq, dq, qq[r]);
@@ -590,6 +599,10 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
       }
     }
     lg_lds_barrier();     // every lane is done with the tiles before the next commit
+    if constexpr (DRAW) {
+      lg_store_rows(out_x + n0 * dx, np * dx, tx, lx);
+      lg_lds_barrier();
+    }
   }
 }
 
@@ -1534,6 +1547,12 @@ template <typename T, int DP, int PPL>
 static constexpr auto affine_logweight_tab_prefetch = &affine_logweight_kernel<T, DP, PPL, true, true>;
 template <typename T, int DP, int PPL>
 static constexpr auto affine_logweight_rows = &affine_logweight_kernel<T, DP, PPL, false, false>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_propagate_tab = &affine_logweight_kernel<T, DP, PPL, true, false, true>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_propagate_tab_prefetch = &affine_logweight_kernel<T, DP, PPL, true, true, true>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_propagate_rows = &affine_logweight_kernel<T, DP, PPL, false, false, true>;
 
 // With 512-particle tiles a launch of fewer than ~1M particles leaves each CU with at most two or three
 // workgroups of one tile each: all latency.  256-particle tiles double the workgroups.
@@ -1588,7 +1607,8 @@ template <typename T>
 static int launch_affine_logweight(const void *xprev, const void *x, const void *y, int64_t y_sb,
                                    const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                    const void *sp, const void *sg, const void *sq, void *out, int64_t B, int64_t K,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, void *out_x = nullptr) {
+  // out_x != nullptr: `x` is the proposal's noise and the draw is formed here (K15)
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
@@ -1616,21 +1636,20 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   // tile per workgroup); AESMC_LG_PREFETCH=0 selects the latter: a measurement knob
   static const bool prefetch = [] { const char *v = getenv("AESMC_LG_PREFETCH"); return v == nullptr || v[0] != '0'; }();
   const unsigned grid = prefetch ? lg_persistent_grid(tiles, lds) : (unsigned)tiles;
-  if (tab && prefetch)
-    LG_DISPATCH(affine_logweight_tab_prefetch, T, dp, ppl, dim3(grid), lds, stream, static_cast<const T *>(xprev),
-                static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), lg_map(mq),
-                static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),
-                static_cast<T *>(out), N, (uint32_t)K);
-  else if (tab)
-    LG_DISPATCH(affine_logweight_tab, T, dp, ppl, dim3(grid), lds, stream, static_cast<const T *>(xprev),
-                static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), lg_map(mq),
-                static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),
-                static_cast<T *>(out), N, (uint32_t)K);
-  else
-    LG_DISPATCH(affine_logweight_rows, T, dp, 1, dim3(grid), lds, stream, static_cast<const T *>(xprev),
-                static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), lg_map(mq),
-                static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),
-                static_cast<T *>(out), N, (uint32_t)K);
+#define LG_LOGWEIGHT_ARGS                                                                                          \
+  static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), \
+      lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),              \
+      static_cast<T *>(out), N, (uint32_t)K, static_cast<T *>(out_x)
+  if (out_x != nullptr) {
+    if (tab && prefetch) LG_DISPATCH(affine_propagate_tab_prefetch, T, dp, ppl, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
+    else if (tab) LG_DISPATCH(affine_propagate_tab, T, dp, ppl, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
+    else LG_DISPATCH(affine_propagate_rows, T, dp, 1, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
+  } else {
+    if (tab && prefetch) LG_DISPATCH(affine_logweight_tab_prefetch, T, dp, ppl, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
+    else if (tab) LG_DISPATCH(affine_logweight_tab, T, dp, ppl, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
+    else LG_DISPATCH(affine_logweight_rows, T, dp, 1, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
+  }
+#undef LG_LOGWEIGHT_ARGS
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
@@ -1965,6 +1984,30 @@ extern "C" int aesmc_affine_normal_rsample(int dtype, const void *source, const 
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == AESMC_F32 ? launch_affine_rsample<float>(source, map, eps, scale, out, B, K, s)
                             : launch_affine_rsample<double>(source, map, eps, scale, out, B, K, s);
+}
+
+extern "C" int aesmc_affine_normal_propagate(int dtype, const void *x_prev, const void *eps, const void *y,
+                                             int64_t y_stride_b, const aesmc_affine_map *transition,
+                                             const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+                                             const void *scale_p, const void *scale_g, const void *scale_q,
+                                             void *out_x, void *out_lw, int64_t B, int64_t K, void *stream) {
+  if (x_prev == nullptr || eps == nullptr || y == nullptr || transition == nullptr || emission == nullptr ||
+      proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || out_lw == nullptr ||
+      out_x == nullptr || B < 0 || K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!aligned16(x_prev) || !aligned16(eps) || !aligned16(out_x) || out_x == x_prev) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  const int64_t dx = transition->dout;
+  if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
+    return AESMC_ERR_UNSUPPORTED;
+  if (B == 0 || K == 0) return AESMC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AESMC_F32
+             ? launch_affine_logweight<float>(x_prev, eps, y, y_stride_b, transition, emission, proposal, scale_p,
+                                              scale_g, scale_q, out_lw, B, K, s, out_x)
+             : launch_affine_logweight<double>(x_prev, eps, y, y_stride_b, transition, emission, proposal, scale_p,
+                                               scale_g, scale_q, out_lw, B, K, s, out_x);
 }
 
 extern "C" int aesmc_affine_normal_logweight(int dtype, const void *x_prev, const void *x, const void *y,

@@ -213,10 +213,11 @@ def infer(inference_algorithm, observations, initial, transition, emission,
     clean.
     """
     try:
-        return _infer(inference_algorithm, observations, initial, transition, emission, proposal,
-                      num_particles, return_log_marginal_likelihood, return_latents,
-                      return_original_latents, return_log_weight, return_log_weights,
-                      return_ancestral_indices)
+        with state.deferring_draws():
+            return _infer(inference_algorithm, observations, initial, transition, emission, proposal,
+                          num_particles, return_log_marginal_likelihood, return_latents,
+                          return_original_latents, return_log_weight, return_log_weights,
+                          return_ancestral_indices)
     except BaseException:
         _discard_pending_flags()
         raise
@@ -339,6 +340,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                             originals[-1] = latent
                     else:
                         deferred[time] = operands
+        state.materialise_draw(latent)      # a deferred draw that K15 did not fill gets its values now (K9)
         # importance sampling over several timesteps normalises the SUM of the per-step weights
         # (inference.py:156-159); K1 keeps that sum running, left to right as torch.sum over the
         # reference's stack does, and hands out its row log-sum-exp with the last step

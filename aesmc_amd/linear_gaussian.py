@@ -66,11 +66,20 @@ class AffineNormal(torch.distributions.Normal):
     weight: [dout, din]; offset: None, [dout], or [batch_size, dout] (one row per batch element,
     shared by its particles — e.g. the observation's part of a proposal's mean);
     scale: tensor (or Python number) broadcastable to [..., dout]; the fused kernels take one value.
+    defer_draw: for a PROPOSAL whose model is linear-Gaussian throughout.  `infer` draws x_t from it
+        (aesmc/inference.py:106) and only then asks the transition and emission callables for their
+        distributions of x_t; when those are AffineNormals too, nothing needs x_t's values before the step
+        is weighed, and with `defer_draw=True` the draw is left to that launch (kernel K15: K9 and K10 in
+        one pass over x_{t-1} and the noise — the same bits as the two).  The noise is drawn where
+        `rsample` would draw it, so the RNG stream is unchanged; `infer` fills the values with K9 instead
+        whenever the step turns out not to be weighed that way.  The promise the model makes by setting
+        it: its transition and emission callables do not READ the values of the newest latent they are
+        handed (building an AffineNormal on it does not).
     """
 
     arg_constraints = {"scale": constraints.positive}
 
-    def __init__(self, source, weight, scale, offset=None, validate_args=None):
+    def __init__(self, source, weight, scale, offset=None, validate_args=None, defer_draw=False):
         if not (torch.is_tensor(source) and torch.is_tensor(weight)):
             raise TypeError("AffineNormal: source and weight must be tensors")
         if weight.dim() != 2 or source.dim() < 1 or source.size(-1) != weight.size(1):
@@ -95,6 +104,7 @@ class AffineNormal(torch.distributions.Normal):
                 tuple(scale.shape), tuple(batch_shape)))
         self.source, self.weight, self.offset = source, weight, offset
         self.scale_param = scale
+        self.defer_draw = bool(defer_draw)
         self._loc = None
         torch.distributions.Distribution.__init__(self, batch_shape, validate_args=validate_args)
 

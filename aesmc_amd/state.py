@@ -7,6 +7,9 @@ user's initial / transition / emission / proposal callables return.
 import enum
 import warnings
 
+import contextlib
+import contextvars
+
 import torch
 
 from . import _kernels
@@ -184,6 +187,20 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     if not _FUSED_NORMAL:
         return None
     affine = _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, observation)
+    noise = getattr(latent, "_aesmc_pending_noise", None) if torch.is_tensor(latent) else None
+    if noise is not None:
+        # a deferred draw: K15 forms it together with the log-weight when the step is linear-Gaussian in this
+        # very proposal and the log-weights need no autograd node of their own; else K9 forms it now
+        fused = affine is not None and affine.is_draw and (
+            defer_grad or not (torch.is_grad_enabled() and affine.requires_grad()))
+        if not fused:
+            materialise_draw(latent)
+        else:
+            log_weight = _ops.affine_propagate(affine, noise)
+            del latent._aesmc_pending_noise
+            for distribution, value in ((prior_dist, latent), (emission_dist, observation), (proposal_dist, latent)):
+                _validate_sample(distribution, value)
+            return (log_weight, affine) if defer_grad else log_weight
     if affine is not None:
         for distribution, value in ((prior_dist, latent), (emission_dist, observation), (proposal_dist, latent)):
             _validate_sample(distribution, value)
@@ -211,6 +228,37 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     if defer_grad:
         return _ops.normal_log_weight_deferred(latent, loc_p, scale_p, observation, loc_g, scale_g, loc_q, scale_q)
     return _ops.normal_log_weight(latent, loc_p, scale_p, observation, loc_g, scale_g, loc_q, scale_q)
+
+
+# set by `infer` for its own duration: only there is a deferred draw guaranteed to be filled before use
+_DEFER_DRAWS = contextvars.ContextVar("aesmc_amd_defer_draws", default=False)
+
+
+@contextlib.contextmanager
+def deferring_draws():
+    token = _DEFER_DRAWS.set(True)
+    try:
+        yield
+    finally:
+        _DEFER_DRAWS.reset(token)
+
+
+def materialise_draw(latent):
+    """Fills a deferred draw (AffineNormal(..., defer_draw=True) sampled by `sample`) with its values by
+    kernel K9 if no launch has produced them yet; anything else passes through.  `infer` calls it before
+    any route other than K15 touches the latent."""
+    if isinstance(latent, dict):
+        for value in latent.values():
+            materialise_draw(value)
+        return latent
+    eps = getattr(latent, "_aesmc_pending_noise", None) if torch.is_tensor(latent) else None
+    if eps is not None:
+        base = latent._aesmc_draw_of
+        offset = None if base.offset is None else base.offset.detach()
+        _kernels.get().affine_rsample(base.source.detach(), base.weight.detach(), offset, eps,
+                                      base.scale_param.detach(), out=latent.detach())
+        del latent._aesmc_pending_noise
+    return latent
 
 
 def _same_tensor(a, b):
@@ -274,7 +322,13 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
                 _kernels.get().affine_covers(base.source, base.weight, base.offset):
             eps = torch.distributions.normal._standard_normal(base.batch_shape, dtype=base.source.dtype,
                                                                device=base.source.device)
-            draw = _ops.affine_rsample(base.source, base.weight, base.offset, scale, eps)
+            if base.defer_draw and _DEFER_DRAWS.get():
+                # the values come with the launch that weighs the step (K15), or from K9 the moment anything
+                # else needs them (`materialise_draw`)
+                draw = _ops.affine_rsample_deferred(base.source, base.weight, base.offset, scale, eps)
+                draw._aesmc_pending_noise = eps
+            else:
+                draw = _ops.affine_rsample(base.source, base.weight, base.offset, scale, eps)
             draw._aesmc_draw_of = base      # lets `infer` differentiate the whole step in one node (K14)
             return draw
     if type(base) not in (torch.distributions.Normal, AffineNormal):

@@ -120,9 +120,12 @@ class LgssmNd(nn.Module):
     `initial`, `transition`, `emission`, `proposal`."""
 
     def __init__(self, dim, transition_scale=1.0, emission_scale=0.5, proposal_scale=0.7, seed=0,
-                 dtype=torch.float32, state=_default_state, validate_args=None, affine=False):
+                 dtype=torch.float32, state=_default_state, validate_args=None, affine=False, defer_draw=None):
         super().__init__()
         self.validate_args = validate_args  # None = PyTorch default; False skips per-call host syncs
+        # defer_draw (default: on with affine): the proposal leaves its draw to the launch that weighs the
+        # step (K15) — this model's transition and emission never read the newest latent's values
+        self.defer_draw = bool(affine) if defer_draw is None else bool(defer_draw)
         # affine=True: the callables return aesmc_amd.linear_gaussian.AffineNormal(source, weight, ...)
         # in place of Normal(source @ weight.T + ..., ...) — the same distributions, their locations
         # evaluated inside the sampling / weighting kernels instead of by matmuls beforehand
@@ -161,9 +164,10 @@ class LgssmNd(nn.Module):
     def initial(self):
         return self._tag(self._normal(self.loc0, self.scale0), "NOT_EXPANDED")
 
-    def _affine_normal(self, source, weight, scale, offset=None):
+    def _affine_normal(self, source, weight, scale, offset=None, defer_draw=False):
         from ..linear_gaussian import AffineNormal
-        return AffineNormal(source, weight, scale, offset=offset, validate_args=self.validate_args)
+        return AffineNormal(source, weight, scale, offset=offset, validate_args=self.validate_args,
+                            defer_draw=defer_draw)
 
     def transition(self, previous_latents=None, time=None, previous_observations=None):
         if self.affine:
@@ -185,7 +189,8 @@ class LgssmNd(nn.Module):
         from_observation = self._observation_terms(observations, time)[time]   # [B, d]: shared by a row's particles
         if self.affine:
             return self._tag(self._affine_normal(previous_latents[-1], self.Wx, self.proposal_scale,
-                                                 offset=from_observation), "FULLY_EXPANDED")
+                                                 offset=from_observation, defer_draw=self.defer_draw),
+                             "FULLY_EXPANDED")
         loc = previous_latents[-1] @ self.Wx.t() + from_observation.unsqueeze(1)
         return self._tag(self._normal(loc, self.proposal_scale), "FULLY_EXPANDED")
 

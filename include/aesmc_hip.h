@@ -325,6 +325,20 @@ int aesmc_affine_normal_logweight(int dtype, const void *x_prev, const void *x, 
                                   const void *scale_p, const void *scale_g, const void *scale_q, void *out_lw,
                                   int64_t B, int64_t K, void *stream);
 
+/* K15 — K9 and K10 in one pass: the proposal's reparameterised draw and the step's log-weight together,
+ *   out_x[b,k,:] = loc_q(x_prev[b,k,:]) + eps[b,k,:] * scale_q         (K9's arithmetic, the same bits)
+ *   out_lw[b,k]  = K10's log-weight of (x_prev, out_x, y)              (the same bits as K10 on out_x)
+ * from one read of x_prev and of the noise `eps` [B,K,dx] (dense, 16-byte aligned; out_x likewise and
+ * distinct from x_prev; it MAY be the noise's own buffer).  For a model whose transition, emission and
+ * proposal are all affine Normals nothing between aesmc/inference.py:106 (`state.sample(proposal)`) and
+ * :125-126 (the log-weight) needs x_t's VALUES — the callables only describe distributions in terms of
+ * it — so the draw can wait for the launch that weighs it: 520 MB per step at B=1024 K=4096 d=10
+ * instead of K9's 503 + K10's 352. */
+int aesmc_affine_normal_propagate(int dtype, const void *x_prev, const void *eps, const void *y, int64_t y_stride_b,
+                                  const aesmc_affine_map *transition, const aesmc_affine_map *emission,
+                                  const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+                                  const void *scale_q, void *out_x, void *out_lw, int64_t B, int64_t K, void *stream);
+
 /* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
  *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])
  *   out_grad_weight[j,i]   = sum_{b,k} grad[b,k,j] x[b,k,i]                 (dense [dout,din])

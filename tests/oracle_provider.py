@@ -101,10 +101,24 @@ class OracleKernels:
         return torch.from_numpy(c_oracle.particle_affine(self._n(x1), self._n(w1), self._n(x2), self._n(w2),
                                                          self._n(offset), self._n(base)))
 
-    def affine_rsample(self, source, weight, offset, eps, scale):
+    def affine_rsample(self, source, weight, offset, eps, scale, out=None):
         from oracle import c_oracle
-        return torch.from_numpy(c_oracle.affine_rsample(self._n(source), self._n(weight), self._n(offset),
+        draw = torch.from_numpy(c_oracle.affine_rsample(self._n(source), self._n(weight), self._n(offset),
                                                         self._n(eps), float(scale)))
+        if out is None:
+            return draw
+        out.copy_(draw)
+        return out
+
+    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x):
+        """K15 on the C oracle: its draw, then its log-weight of that draw."""
+        from oracle import c_oracle
+        pair = lambda term: (self._n(term[0]), self._n(term[1]))
+        out_x.copy_(torch.from_numpy(c_oracle.affine_rsample(self._n(x_prev), self._n(proposal[0]), self._n(proposal[1]),
+                                                             self._n(eps), float(scales[2]))))
+        return torch.from_numpy(c_oracle.affine_logweight(
+            self._n(x_prev), self._n(out_x), self._n(y_rows), pair(transition), pair(emission), pair(proposal),
+            float(scales[0]), float(scales[1]), float(scales[2])))
 
     def affine_logweight(self, x_prev, x, y_rows, transition, emission, proposal, scales):
         from oracle import c_oracle

@@ -351,6 +351,65 @@ def test_affine_logweight_backward_matches_autograd_and_the_unfused_route(kernel
     assert torch.equal(partial[1], got[1]) and torch.equal(partial[7], got[7])
 
 
+# ---- K15: the draw and its log-weight in one launch -----------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", SHAPES + [(16, 4096, 10, 10), (300, 4096, 10, 10), (520, 2100, 8, 8), (40, 30, 6, 9)])
+def test_affine_propagate_equals_the_draw_kernel_then_the_weight_kernel_bit_for_bit(kernels, hip_device, dtype, shape):
+    """K15 against K9 followed by K10 on the device — the same chains, so the same bits, for the draw and
+    for the log-weight (one and two particles per lane, table and per-lane row paths, ragged tails) — and,
+    through them, against the C oracle; the draw may be written over the noise's own buffer."""
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=5 * B + K + dy)
+    off_p = torch.from_numpy(np.random.RandomState(6).randn(dx).astype(dtype)).to(hip_device)
+    terms = ((o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    draw = kernels.affine_rsample(o["x_prev"], o["Q"], o["off_q"], o["eps"], o["s_q"])
+    lw = kernels.affine_logweight(o["x_prev"], draw, o["y"], *terms, scales)
+    out_x = torch.full_like(draw, float("nan"))
+    got = kernels.affine_propagate(o["x_prev"], o["eps"], o["y"], *terms, scales, out_x=out_x)
+    assert torch.equal(out_x, draw)
+    assert torch.equal(got, lw)
+    want = c_oracle.affine_rsample(n["x_prev"], n["Q"], n["off_q"], n["eps"], float(n["s_q"]))
+    assert np.array_equal(out_x.cpu().numpy(), want)
+    noise = o["eps"].clone()
+    again = kernels.affine_propagate(o["x_prev"], noise, o["y"], *terms, scales, out_x=noise)     # in place
+    assert torch.equal(noise, draw) and torch.equal(again, lw)
+    with pytest.raises(ValueError):
+        kernels.affine_propagate(o["x_prev"], o["eps"], o["y"], *terms, scales, out_x=o["x_prev"])
+    with pytest.raises(ValueError):
+        kernels.affine_propagate(o["x_prev"], o["eps"], o["y"], *terms, scales, out_x=out_x[:, :, :-1])
+
+
+@pytest.mark.parametrize("grad", [False, True])
+def test_a_deferred_draw_gives_the_very_same_run_on_the_device(hip_device, grad):
+    """defer_draw on the proposal (K15 draws and weighs) against the immediate draw (K9, then K10): every
+    number of the run identical — latents, ancestors, evidence, gradients, RNG consumption."""
+    from aesmc_amd import inference
+    from aesmc_amd.testing.models import LgssmNd
+    runs = {}
+    for defer in (False, True):
+        model = LgssmNd(10, dtype=torch.float32, affine=True, defer_draw=defer).tune_proposal().to(hip_device)
+        observations = model.simulate(5, 4, seed=3)
+        torch.manual_seed(11)
+        np.random.seed(11)
+        with torch.set_grad_enabled(grad):
+            out = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal,
+                                  1300, return_log_marginal_likelihood=True, return_latents=True,
+                                  return_log_weight=not grad, return_ancestral_indices=True)
+        if grad:
+            (-out["log_marginal_likelihood"].mean()).backward()
+        after = (torch.rand(1, device=hip_device).item(), np.random.uniform())
+        runs[defer] = (out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, after)
+    (a, grads_a, rng_a), (b, grads_b, rng_b) = runs[False], runs[True]
+    assert rng_a == rng_b
+    assert torch.equal(a["log_marginal_likelihood"], b["log_marginal_likelihood"])
+    for x, y in zip(a["latents"] + a["ancestral_indices"], b["latents"] + b["ancestral_indices"]):
+        assert torch.equal(x, y)
+    assert sorted(grads_a) == sorted(grads_b) and (not grad or grads_a)
+    for name in grads_a:
+        assert torch.equal(grads_a[name], grads_b[name]), name
+
+
 # ---- K14: the whole backward of a step whose latent is the proposal's draw ----------------------------------
 def _step_reference(o, off_p, x, g, grad_x):
     """float64 autograd over the step with x rebuilt as the draw loc_q(x_prev) + s_q eps (eps held fixed)."""

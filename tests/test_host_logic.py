@@ -504,8 +504,8 @@ def test_affine_callables_give_the_loss_and_gradients_of_matmul_callables(oracle
     from aesmc_amd import _kernels
     from aesmc_amd.testing.models import LgssmNd
     provider = _kernels.get()
-    calls = {"affine_rsample": 0, "affine_logweight": 0, "affine_logweight_backward": 0, "affine_step_backward": 0,
-             "particle_affine_backward": 0}
+    calls = {"affine_rsample": 0, "affine_logweight": 0, "affine_propagate": 0, "affine_logweight_backward": 0,
+             "affine_step_backward": 0, "particle_affine_backward": 0}
     originals = {name: getattr(provider, name) for name in calls}
     for name in calls:
         def spy(*args, _name=name, **kwargs):
@@ -524,14 +524,17 @@ def test_affine_callables_give_the_loss_and_gradients_of_matmul_callables(oracle
         loss.backward()
         results[affine] = (loss.detach(), {name: p.grad.clone() for name, p in model.named_parameters()
                                            if p.grad is not None})
-    assert calls["affine_rsample"] == T - 1
+    # (the model's proposal defers its draw: under SMC one launch draws and weighs, K15; importance sampling's
+    # aliased transition is not such a step and K9 fills the draw)
+    assert calls["affine_rsample"] + calls["affine_propagate"] == T - 1
     # importance sampling hands `transition` the list that already holds the current draw (the reference's
     # aliasing): its source is x_t, the proposal's x_{t-1} — not one
     # linear-Gaussian step, so the locations are materialised there
     fused_steps = T - 1 if algorithm == "aesmc" else 0
     # every such step's latent is the proposal's own draw: its whole backward is one K14 launch — no K12, and
     # no backward launch of the draw (K11) either
-    assert calls["affine_logweight"] == fused_steps and calls["affine_step_backward"] == fused_steps
+    assert calls["affine_propagate"] == fused_steps and calls["affine_logweight"] == 0
+    assert calls["affine_step_backward"] == fused_steps
     if algorithm == "aesmc":
         # (the one K11 launch left is time 0's emission location, materialised for K5)
         assert calls["affine_logweight_backward"] == 0 and calls["particle_affine_backward"] == 1
@@ -546,7 +549,8 @@ def test_affine_callables_give_the_loss_and_gradients_of_matmul_callables(oracle
 
 def test_affine_normal_outside_the_fused_route_materialises_its_location(oracle_backend):
     """A step whose three terms are not all AffineNormal in the right tensors (here: the emission reads
-    a COPY of the latent) takes the ordinary route: `.loc` is evaluated and the numbers are the same."""
+    a COPY of the latent) takes the ordinary route: `.loc` is evaluated and the numbers are the same.
+    Such an emission READS the newest latent's values, so its model must not set `defer_draw`."""
     from aesmc_amd.linear_gaussian import AffineNormal
     from aesmc_amd.testing.models import LgssmNd
 
@@ -556,7 +560,7 @@ def test_affine_normal_outside_the_fused_route_materialises_its_location(oracle_
 
     outs = []
     for cls in (LgssmNd, CopyingEmission):
-        model = cls(2, dtype=torch.float64, affine=True)
+        model = cls(2, dtype=torch.float64, affine=True, defer_draw=False)
         observations = model.simulate(4, 3, seed=2)
         torch.manual_seed(1)
         np.random.seed(1)
@@ -643,3 +647,76 @@ def test_a_forward_pass_leaves_no_reference_cycles_behind(oracle_backend):
         gc.set_debug(0)
         gc.garbage.clear()
     assert not leaked, leaked
+
+
+@pytest.mark.parametrize("algorithm,grad", [("smc", False), ("smc", True), ("is", False)])
+def test_a_deferred_draw_gives_the_very_same_run(oracle_backend, algorithm, grad):
+    """AffineNormal(..., defer_draw=True) on the proposal: the draw is produced by the launch that weighs
+    the step (K15) — or by K9 when the step is not weighed that way (importance sampling's aliased
+    transition; log-weights that need their own autograd node) — and every number of the run is the one
+    the immediate draw gives: latents, log-weights, ancestors, evidence, gradients, RNG consumption."""
+    from aesmc_amd import _kernels
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    calls = {"affine_propagate": 0, "affine_rsample": 0}
+    originals = {name: getattr(provider, name) for name in calls}
+    for name in calls:
+        def spy(*args, _name=name, **kwargs):
+            calls[_name] += 1
+            return originals[_name](*args, **kwargs)
+        setattr(provider, name, spy)
+    T, runs = 4, {}
+    try:
+        for defer in (False, True):
+            for name in calls:
+                calls[name] = 0
+            model = LgssmNd(3, dtype=torch.float64, affine=True, defer_draw=defer).tune_proposal()
+            observations = model.simulate(T, 4, seed=3)
+            torch.manual_seed(11)
+            np.random.seed(11)
+            with torch.set_grad_enabled(grad):
+                out = inference.infer(algorithm, observations, model.initial, model.transition, model.emission,
+                                      model.proposal, 24, return_log_marginal_likelihood=True,
+                                      return_latents=True, return_log_weight=not grad,
+                                      return_ancestral_indices=algorithm == "smc")
+            if grad:
+                (-out["log_marginal_likelihood"].mean()).backward()
+            after = (torch.rand(1).item(), np.random.uniform())       # where the two RNG streams stand afterwards
+            runs[defer] = (out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+                           after, dict(calls))
+    finally:
+        for name, fn in originals.items():
+            setattr(provider, name, fn)
+    (a, grads_a, rng_a, calls_a), (b, grads_b, rng_b, calls_b) = runs[False], runs[True]
+    assert calls_a == {"affine_propagate": 0, "affine_rsample": T - 1}
+    if algorithm == "smc":      # every step from the second on: one launch draws and weighs
+        assert calls_b == {"affine_propagate": T - 1, "affine_rsample": 0}
+    else:                       # not a linear-Gaussian step in the proposal's x_{t-1}: K9 fills the draw
+        assert calls_b == {"affine_propagate": 0, "affine_rsample": T - 1}
+    assert rng_a == rng_b
+    assert torch.equal(a["log_marginal_likelihood"], b["log_marginal_likelihood"])
+    for x, y in zip(a["latents"], b["latents"]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["last_latent"], b["last_latent"])
+    if not grad:
+        assert torch.equal(a["log_weight"], b["log_weight"])
+    if algorithm == "smc":
+        for x, y in zip(a["ancestral_indices"], b["ancestral_indices"]):
+            assert torch.equal(x, y)
+    assert sorted(grads_a) == sorted(grads_b) and (not grad or grads_a)
+    for name in grads_a:
+        assert torch.equal(grads_a[name], grads_b[name]), name
+
+
+def test_a_deferred_draw_outside_infer_is_drawn_at_once(oracle_backend):
+    """`state.sample` honours `defer_draw` only inside `infer` (which guarantees the values are filled
+    before anything reads them); a direct call draws immediately."""
+    from aesmc_amd.linear_gaussian import AffineNormal
+    source = torch.randn(3, 7, 4, dtype=torch.float64)
+    weight = torch.randn(4, 4, dtype=torch.float64)
+    scale = torch.tensor(0.5, dtype=torch.float64)
+    torch.manual_seed(2)
+    now = state.sample(AffineNormal(source, weight, scale, defer_draw=True), 3, 7)
+    torch.manual_seed(2)
+    ref = state.sample(AffineNormal(source, weight, scale), 3, 7)
+    assert not hasattr(now, "_aesmc_pending_noise") and torch.equal(now, ref)
