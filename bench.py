@@ -425,6 +425,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         out["roofline"] = roofline_of(kernels.get(key), label, name, proposal, key)
         # the propagation kernels either side of it (K9 draws x_t, K10 weighs it), priced the same way
         others = [roofline_of(kernels.get(k), l, name, proposal, k) for k, l in (
+            ("affine_normal_propagate", "affine_logweight_kernel, DRAW (K15: the draw and its log-weight)"),
             ("affine_normal_rsample", "affine_rsample_kernel (K9)"),
             ("affine_normal_logweight", "affine_logweight_kernel (K10)")) if k in kernels]
         if out["roofline"] is not None and others:

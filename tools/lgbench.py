@@ -84,6 +84,15 @@ def bench(name, dtype=torch.float32):
         lambda: (lambda o: k.affine_logweight(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]),
                                               (o["Q"], o["off_q"]), (o["s_p"], o["s_g"], o["s_q"])))(nxt()),
         esz * N * (2 * dx + 1))
+    outs = [torch.empty_like(o["x"]) for o in sets]
+
+    def k15():
+        i = (state["i"] + 1) % len(sets)
+        state["i"] = i
+        o = sets[i]
+        return k.affine_propagate(o["x_prev"], o["eps"], o["y"], (o["A"], None), (o["C"], o["off_g"]),
+                                  (o["Q"], o["off_q"]), (o["s_p"], o["s_g"], o["s_q"]), out_x=outs[i])
+    run("K15 affine_propagate", k15, esz * N * (3 * dx + 1))
     run("K11 particle_affine_backward", lambda: (lambda o: k.particle_affine_backward(o["eps"], o["x_prev"], o["Q"], True, True, True))(nxt()),
         esz * N * 3 * dx)
     lws = [k.affine_logweight(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),

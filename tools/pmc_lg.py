@@ -1,5 +1,5 @@
 """Workload for hardware-counter passes over the linear-Gaussian propagation kernels (rocprofv3 --pmc,
-one counter set per run): K8 .. K12 and K14 at B=1024 K=4096 d=10,
+one counter set per run): K8 .. K12, K14, K15 at B=1024 K=4096 d=10,
 3 launches each."""
 import os
 import sys
@@ -26,6 +26,8 @@ for _ in range(3):
     need = [True, True, False, True, False, True, False, True, True, False, False, False]
     k.affine_logweight_backward(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
                                 (o["s_p"], o["s_g"], o["s_q"]), need, lw=lw, lse=lse, grad_lse=torch.ones_like(lse))
+    k.affine_propagate(o["x_prev"], o["eps"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
+                       (o["s_p"], o["s_g"], o["s_q"]), out_x=torch.empty_like(o["x"]))
     need[1] = False
     k.affine_step_backward(o["x_prev"], o["x"], o["y"], (o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]),
                            (o["s_p"], o["s_g"], o["s_q"]), need, lw, lse, grad_lse=torch.ones_like(lse), grad_x=o["eps"])

@@ -18,7 +18,8 @@ import bench
 
 KERNELS = {"resample_step": "ancestor_index_inv_kernel", "resample_gather": "resample_gather_kernel",
            "normal_logweight": "normal_logweight", "normal_rsample": "normal_rsample",
-           "affine_normal_rsample": "affine_rsample_kernel", "affine_normal_logweight": "affine_logweight_kernel"}
+           "affine_normal_rsample": "affine_rsample_kernel", "affine_normal_logweight": "affine_logweight_kernel",
+           "affine_normal_propagate": "affine_logweight_kernel"}      # K15 = K10's kernel in DRAW mode: it also writes x_t
 
 
 def per_dispatch(path, counter, kernel):
@@ -42,7 +43,8 @@ def main(workload, proposal, fetch_csv, write_csv, out_json):
               "identity-index gathers of the same shape").format(workload, proposal, f_factor, w_factor)
     entry = {"calibration": {"fetch_factor": f_factor, "write_factor": w_factor}}
     algorithmic = {"resample_step": B * K * (20 + 8 * dim) + 8 * B, "resample_gather": B * K * (8 + 8 * dim),
-                   "affine_normal_rsample": B * K * 12 * dim, "affine_normal_logweight": B * K * (8 * dim + 4)}
+                   "affine_normal_rsample": B * K * 12 * dim, "affine_normal_logweight": B * K * (8 * dim + 4),
+                   "affine_normal_propagate": B * K * (12 * dim + 4)}
     for key, kernel in KERNELS.items():
         skip = 3 if key == "resample_gather" else 0
         fetch = per_dispatch(fetch_csv, "FETCH_SIZE", kernel)[skip:]
@@ -50,7 +52,14 @@ def main(workload, proposal, fetch_csv, write_csv, out_json):
         n = min(len(fetch), len(write))
         if n == 0:
             continue
-        if key == "resample_step":      # launches with a payload only (time 0 has none; K2 alone writes 12 B/particle)
+        if key == "affine_normal_logweight":      # K10 proper writes the log-weights only
+            pairs = [(f, w) for f, w in zip(fetch, write) if w * w_factor <= 0.5 * payload]
+            if not pairs:
+                continue
+            fetch, write = [p[0] for p in pairs], [p[1] for p in pairs]
+            n = len(pairs)
+        if key in ("resample_step", "affine_normal_propagate"):
+            # launches with a payload only (time 0 has none; K2 alone writes 12 B/particle); K15: the draw
             pairs = [(f, w) for f, w in zip(fetch, write) if w * w_factor > 0.5 * payload]
             if not pairs:
                 continue
