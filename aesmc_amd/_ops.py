@@ -359,7 +359,7 @@ class _AffineRsample(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         source, weight, eps = ctx.saved_tensors
-        need_src, need_w, need_off, need_scale, _ = ctx.needs_input_grad
+        need_src, need_w, need_off, need_scale = ctx.needs_input_grad[:4]
         need_off = need_off and ctx.offset_shape is not None
         gsrc, gw, rows = _kernels.get().particle_affine_backward(grad.contiguous(), source, weight, need_src, need_w,
                                                                 need_off)
@@ -374,21 +374,31 @@ class _DeferredAffineRsample(torch.autograd.Function):
     it (state.materialise_draw) — while the backward is the draw's own, valid whenever it runs."""
 
     @staticmethod
-    def forward(ctx, source, weight, offset, scale, eps):
+    def forward(ctx, source, weight, offset, scale, eps, poison):
         ctx.save_for_backward(source, weight, eps if scale.requires_grad else None)
         ctx.offset_shape = None if offset is None else tuple(offset.shape)
         ctx.scale_shape = tuple(scale.shape)
-        return torch.empty(source.shape[:2] + (weight.size(0),), dtype=source.dtype, device=source.device)
+        return _placeholder(source, weight, poison)
 
-    backward = staticmethod(_AffineRsample.backward)
+    @staticmethod
+    def backward(ctx, grad):
+        return _AffineRsample.backward(ctx, grad) + (None,)
 
 
-def affine_rsample_deferred(source, weight, offset, scale, eps):
-    """An uninitialised [B,K,dout] tensor standing for the reparameterised draw (values: K15 or K9, later)."""
+def _placeholder(source, weight, poison):
+    shape = source.shape[:2] + (weight.size(0),)
+    if poison:      # anything that reads the values before they exist sees NaN, not stale memory
+        return torch.full(shape, float("nan"), dtype=source.dtype, device=source.device)
+    return torch.empty(shape, dtype=source.dtype, device=source.device)
+
+
+def affine_rsample_deferred(source, weight, offset, scale, eps, poison=True):
+    """A [B,K,dout] tensor standing for the reparameterised draw whose values come later (K15 or K9).
+    `poison`: filled with NaN until then (one fill launch) instead of left uninitialised."""
     tensors = (source, weight, offset, scale)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        return _DeferredAffineRsample.apply(source, weight, offset, scale, eps)
-    return torch.empty(source.shape[:2] + (weight.size(0),), dtype=source.dtype, device=source.device)
+        return _DeferredAffineRsample.apply(source, weight, offset, scale, eps, poison)
+    return _placeholder(source, weight, poison)
 
 
 def affine_rsample(source, weight, offset, scale, eps):

@@ -74,7 +74,10 @@ class AffineNormal(torch.distributions.Normal):
         `rsample` would draw it, so the RNG stream is unchanged; `infer` fills the values with K9 instead
         whenever the step turns out not to be weighed that way.  The promise the model makes by setting
         it: its transition and emission callables do not READ the values of the newest latent they are
-        handed (building an AffineNormal on it does not).
+        handed (building an AffineNormal on it does not).  With argument validation on (PyTorch's
+        default) the latent holds NaN until its values exist, so a callable that reads it anyway fails
+        at once (a NaN parameter, or the NaN log-weight check of `infer`); `validate_args=False` skips
+        that fill.
     """
 
     arg_constraints = {"scale": constraints.positive}

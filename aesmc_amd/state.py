@@ -325,7 +325,10 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
             if base.defer_draw and _DEFER_DRAWS.get():
                 # the values come with the launch that weighs the step (K15), or from K9 the moment anything
                 # else needs them (`materialise_draw`)
-                draw = _ops.affine_rsample_deferred(base.source, base.weight, base.offset, scale, eps)
+                # (with argument validation on — PyTorch's default — the placeholder is NaN until then, so a
+                # callable that breaks the promise and reads it fails loudly; validate_args=False skips the fill)
+                draw = _ops.affine_rsample_deferred(base.source, base.weight, base.offset, scale, eps,
+                                                    poison=bool(base._validate_args))
                 draw._aesmc_pending_noise = eps
             else:
                 draw = _ops.affine_rsample(base.source, base.weight, base.offset, scale, eps)

@@ -720,3 +720,21 @@ def test_a_deferred_draw_outside_infer_is_drawn_at_once(oracle_backend):
     torch.manual_seed(2)
     ref = state.sample(AffineNormal(source, weight, scale), 3, 7)
     assert not hasattr(now, "_aesmc_pending_noise") and torch.equal(now, ref)
+
+
+def test_a_callable_that_reads_a_deferred_draw_fails_loudly(oracle_backend):
+    """`defer_draw=True` is the model's promise not to read the newest latent inside its callables; one
+    that does (here: an emission that copies it) meets NaN under PyTorch's default argument validation
+    and the run raises instead of weighing stale memory."""
+    from aesmc_amd.linear_gaussian import AffineNormal
+    from aesmc_amd.testing.models import LgssmNd
+
+    class CopyingEmission(LgssmNd):
+        def emission(self, latents=None, time=None, previous_observations=None):
+            return self._tag(AffineNormal(latents[-1].clone(), self.C, self.emission_scale), "FULLY_EXPANDED")
+
+    model = CopyingEmission(2, dtype=torch.float64, affine=True, defer_draw=True)
+    observations = model.simulate(3, 3, seed=2)
+    with pytest.raises((ValueError, FloatingPointError)):
+        inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal, 16,
+                        return_log_marginal_likelihood=True)
