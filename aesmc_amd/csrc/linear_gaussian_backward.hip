@@ -1,0 +1,995 @@
+// K11, K12, K14: the backward kernels of the linear-Gaussian particle propagation (see linear_gaussian.hip
+// for the forward kernels, the arithmetic contract and the reference call sites).  The weight gradients are
+// contractions over the particle index and run on the matrix cores; everything per particle stays on the
+// vector ALUs, one lane = one particle.
+#include "linear_gaussian.hpp"
+namespace aesmc {
+
+// ---- per-batch-row sums of a tile (offset gradients) -------------------------------------------------------
+// The gradient of an offset c[b] is the sum over the row's particles of the gradient of the location.
+// A tile spans the batch rows b0 .. b0 + nrows - 1 (nrows <= kLgRowsMax: the callers' table condition);
+// 16 lane groups sum 1/16 of the tile's particles each, column by column, flushing at row boundaries,
+// then one lane per (row slot, column) adds the 16 partials in order and leaves the tile's record
+//   out[slot * 16 + j]                                   (fixed order: reproducible)
+// for a second launch to add up the few tiles that cover each batch row.  `part` holds 16 x 8 x 16 values.
+constexpr int kLgRowPart = 16 * kLgRowsMax * 16;
+template <typename T>
+__device__ __forceinline__ void lg_row_sums(const T *__restrict__ tile, uint32_t rs, uint32_t d, uint32_t np,
+                                            uint32_t k0, uint32_t K, T *__restrict__ part, T *__restrict__ out) {
+  const uint32_t t = lg_tid_impl<true>(), j = t & 15u, c = t >> 4;
+#pragma unroll 1
+  for (uint32_t i = t; i < (uint32_t)kLgRowPart; i += kLgBlock) part[i] = T(0);
+  lg_lds_barrier();
+  const uint32_t chunk = (np + 15) / 16, p0 = c * chunk, p1 = min(np, p0 + chunk);
+  if (j < d && p0 < p1) {
+    uint32_t slot = (k0 + p0) / K;
+    uint32_t next = (slot + 1) * K - k0;        // first particle of the next batch row, tile-relative
+    T acc = T(0);
+#pragma unroll 1
+    for (uint32_t p = p0; p < p1; ++p) {
+      if (p >= next) {
+        part[(c * kLgRowsMax + slot) * 16 + j] = acc;
+        acc = T(0);
+        ++slot;
+        next += K;
+      }
+      acc += tile[p * rs + j];
+    }
+    part[(c * kLgRowsMax + slot) * 16 + j] = acc;
+  }
+  lg_lds_barrier();
+  if (t < (uint32_t)kLgRowsMax * 16) {
+    const uint32_t slot = t >> 4;
+    T sum = T(0);
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) sum += part[(cc * kLgRowsMax + slot) * 16 + j];
+    out[t] = sum;
+  }
+}
+
+// ---- K11: the adjoint of an affine location ----------------------------------------------------------
+// The weight gradient  dW[j][i] = sum over particles of g[p][j] x[p][i]  is a contraction over the
+// particle index: it runs on the matrix cores (v_mfma_*_16x16x4: A = 4 particles x 16 values of g,
+// B = 4 particles x 16 values of x, f32 / f64 inputs and accumulation — exact IEEE fma chains), which
+// keeps the 16 x 16 accumulator in four registers per lane instead of d^2 per particle-owning lane.
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+  typedef float Acc __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ Acc fma(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+template <> struct Mfma<double> {
+  typedef double Acc __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ Acc fma(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+
+constexpr int kLgRecord = 256;        // one 16 x 16 partial per matrix and workgroup
+constexpr int kLgMaxGrid = 1024;      // most persistent workgroups of the reducing kernels (one record each)
+
+// acc[j][i] += sum_{p < np} tg[p][j] * tx[p][i] over a staged tile; the four wavefronts take particles
+// 4 w .. 4 w + 3 of every group of 16 (fixed assignment: the sums are reproducible).
+template <typename T>
+__device__ __forceinline__ void lg_outer_accumulate(const T *__restrict__ tg, uint32_t dg, const T *__restrict__ tx,
+                                                    uint32_t dxx, uint32_t np, typename Mfma<T>::Acc &acc) {
+  // dg, dxx: the ROW STRIDES of the two tiles (LgLayout::rs)
+  constexpr bool LG_OPAQUE = true;
+  // Lane (quad, col) feeds value `col` of particle 4 w + quad (+ 16 per trip).  Columns at or past a row's
+  // extent read the neighbouring row: that only reaches accumulator rows / columns >= the extents,
+  // which nobody reads, so there is no per-column mask; particles past the tile's end are masked.
+  const uint32_t tid = lg_tid(), lane = tid & 63u, wave = tid >> 6;
+  const uint32_t col = lane & 15u;
+  uint32_t p = wave * 4 + (lane >> 4);
+  uint32_t eg = p * dg + col, ex = p * dxx + col;
+  const uint32_t step_g = 16 * dg, step_x = 16 * dxx;
+  // four trips' operands are fetched before their four multiply-accumulates: the LDS latency is paid
+  // once per group, not once per MFMA (the accumulator chain is sequential either way)
+  for (uint32_t p0 = wave * 4; p0 < np; p0 += 64) {
+    T a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool live = p + 16 * t < np;
+      a[t] = live ? tg[eg + t * step_g] : T(0);
+      b[t] = live ? tx[ex + t * step_x] : T(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
+    p += 64;
+    eg += 4 * step_g;
+    ex += 4 * step_x;
+  }
+}
+
+// The same sum over a wavefront's OWN 64 particles (lane = particle mapping of the one-particle-per-lane
+// kernels: rows 64 w .. 64 w + 63 of the tiles were written and are read by this wavefront alone), so the
+// caller needs no workgroup barrier around it — a wavefront-level fence orders its LDS writes and reads.
+// ONES: the lanes of column 15 feed 1 instead of tx's (unused, extent < 16) column, so acc[j][15] gathers
+// sum_p tg[p][j] — the tile's column sums at no extra pass (lg_flush_column_sums).
+template <typename T, int PPL, bool ONES = false>
+__device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg, uint32_t dg,
+                                                        const T *__restrict__ tx, uint32_t dxx, uint32_t np,
+                                                        typename Mfma<T>::Acc &acc) {
+  // dg, dxx: the ROW STRIDES of the two tiles (LgLayout::rs); a wavefront's lanes own particles
+  // 256 r + 64 w .. + 63 for r < PPL
+  constexpr bool LG_OPAQUE = true;
+  const uint32_t tid = lg_tid(), lane = tid & 63u, wave = tid >> 6;
+  const uint32_t col = lane & 15u;
+  const uint32_t step_g = 4 * dg, step_x = 4 * dxx;
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) {
+    uint32_t p = r * kLgBlock + wave * 64 + (lane >> 4);
+    uint32_t eg = p * dg + col, ex = p * dxx + col;
+    if (np == (uint32_t)(PPL * kLgBlock)) {      // a whole tile (all but the last): no particle masks
+#pragma unroll
+      for (int group = 0; group < 4; ++group) {
+        T a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a[t] = tg[eg + (4 * group + t) * step_g];
+          b[t] = tx[ex + (4 * group + t) * step_x];
+          if (ONES) b[t] = col == 15u ? T(1) : b[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
+      }
+      continue;
+    }
+#pragma unroll
+    for (int group = 0; group < 4; ++group) {
+      T a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool live = p + 4 * t < np;
+        a[t] = live ? tg[eg + t * step_g] : T(0);
+        b[t] = live ? tx[ex + t * step_x] : T(0);
+        if (ONES) b[t] = col == 15u ? T(1) : b[t];      // a particle past the end contributes a = 0
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = Mfma<T>::fma(a[t], b[t], acc);
+      p += 16;
+      eg += 4 * step_g;
+      ex += 4 * step_x;
+    }
+  }
+}
+
+// A tile that lies inside one batch row needs no row bookkeeping: its column sums are what the ONES
+// accumulate gathered in column 15 since the last flush.  Each wavefront writes its 16 sums to slot
+// `wave` of the tile's row-sum record and clears them; the finishing launch adds the four slots (same
+// test there: lg_single_row).  No barrier, no pass over the tile.
+__host__ __device__ __forceinline__ bool lg_single_row(int64_t n0, uint32_t np, uint32_t K) {
+  return (uint32_t)(n0 % K) + np <= K;
+}
+template <typename T>
+__device__ __forceinline__ void lg_flush_column_sums(typename Mfma<T>::Acc &acc, T *__restrict__ record, bool keep) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((lane & 15) == 15) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (keep) record[wave * 16 + Mfma<T>::row(lane, r)] = acc[r];
+      acc[r] = T(0);
+    }
+  }
+}
+
+__device__ __forceinline__ void lg_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// The workgroup's four partial accumulators summed (wavefront 0 .. 3 in turn) into record[0 .. 255],
+// element j * 16 + i.  `scratch` holds 4 x 256 values.
+template <typename T>
+__device__ __forceinline__ void lg_outer_publish(const typename Mfma<T>::Acc &acc, T *__restrict__ scratch,
+                                                 T *__restrict__ record) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) scratch[wave * 256 + Mfma<T>::row(lane, r) * 16 + (lane & 15)] = acc[r];
+  __syncthreads();
+  const int e = threadIdx.x;
+  record[e] = ((scratch[e] + scratch[256 + e]) + scratch[512 + e]) + scratch[768 + e];
+  __syncthreads();
+}
+
+template <typename T, int DP, int PPL>
+__global__ __launch_bounds__(kLgBlock) void particle_affine_backward_kernel(const T *__restrict__ g,
+                                                                             const T *__restrict__ x, LgMap adjoint,
+                                                                             T *__restrict__ gx, T *__restrict__ ws,
+                                                                             T *__restrict__ row_ws, int64_t N,
+                                                                             uint32_t K, int want_w) {
+  constexpr bool LG_OPAQUE = true;   // see lg_tid_impl
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  const uint32_t dg = adjoint.din, dxx = adjoint.dout;     // g has the location's extent, x (and gx) the input's
+  T *wt = reinterpret_cast<T *>(lg_smem);
+  T *scratch = wt + DP * DP;                               // 4 x 256 (records) / 16 x 8 x 16 (row sums)
+  T *tg = scratch + kLgRowPart;
+  const LgLayout lg = lg_layout<T>(dg), lxx = lg_layout<T>(dxx);
+  T *tx = tg + (TP * lg.rs + 16);
+  typename Mfma<T>::Acc acc = {T(0), T(0), T(0), T(0)};
+  if (gx != nullptr) lg_stage_weight<T, DP>(adjoint, wt);
+  const int64_t tiles = (N + TP - 1) / TP;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_stage_rows<T, true>(g + n0 * dg, np * dg, tg, lg, 1);
+    if (want_w) lg_stage_rows<T, true>(x + n0 * dxx, np * dxx, tx, lxx, 0);
+    __syncthreads();
+    if (row_ws != nullptr) {      // the offset's gradient: per-row sums of the incoming gradient
+      const uint32_t b0 = (uint32_t)(n0 / K);
+      lg_row_sums<T>(tg, lg.rs, dg, np, (uint32_t)(n0 - (int64_t)b0 * K), K, scratch,
+                     row_ws + tile * (kLgRowsMax * 16));
+      lg_lds_barrier();
+    }
+    T out[DP][PPL];
+    uint32_t p[PPL], at[PPL];
+    bool live[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const uint32_t q = lg_tid() + r * kLgBlock;
+      live[r] = q < np;
+      p[r] = live[r] ? q : 0u;
+      at[r] = p[r] * lg.rs;
+    }
+    if (gx != nullptr) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) out[j][r] = T(0);
+      lg_apply_tile<T, DP, PPL>(wt, tg, at, (int)dg, out);
+    }
+    if (want_w) lg_outer_accumulate<T>(tg, lg.rs, tx, lxx.rs, np, acc);
+    if (gx != nullptr) {
+      __syncthreads();                                     // every wavefront is done reading tx
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        if ((uint32_t)j < dxx) {
+#pragma unroll
+          for (int r = 0; r < PPL; ++r)
+            if (live[r]) tx[p[r] * lxx.rs + j] = out[j][r];
+        }
+      }
+      __syncthreads();
+      lg_store_rows<T, true>(gx + n0 * dxx, np * dxx, tx, lxx);
+    }
+    __syncthreads();
+  }
+  if (want_w) lg_outer_publish<T>(acc, scratch, ws + (int64_t)blockIdx.x * kLgRecord);
+}
+
+// ---- K12: backward of K10 in one pass ----------------------------------------------------------------
+// With g = the incoming gradient of lw[b,k] (grad_lw, and / or K1's softmax term grad_lse[b] exp(lw - lse[b])
+// formed here), diff_* = value - location and u_p = g diff_p / s_p^2, u_q = -g diff_q / s_q^2,
+// u_g = g diff_g / s_g^2 (the gradients with respect to the three locations):
+//   grad_x      = -u_p - u_q + C^T u_g          grad_x_prev = A^T u_p + Q^T u_q
+//   dA = sum u_p (x) x_prev    dQ = sum u_q (x) x_prev    dC = sum u_g (x) x        (matrix cores, as K11)
+//   ds_p = sum g (|diff_p|^2 / s_p^3 - dx / s_p),  ds_g likewise,  ds_q with the opposite sign
+// x_prev and x are read once, the two latent gradients written once.  The three terms are taken in turn —
+// location (a loop over the input elements: one column of weights live at a time), u, its adjoint, u
+// through one spare LDS tile for the outer products (each wavefront over its own particles' rows:
+// wavefront fences, no workgroup barriers) and, where an offset's gradient is wanted, for the per-row sums
+// (lg_row_sums) — so a lane holds one u, the two latent gradients and little else.
+template <typename T, int DP, int PPL>
+__device__ __forceinline__ void lg_rows_to_tile(const T (&v)[DP][PPL], uint32_t d, const uint32_t (&p)[PPL],
+                                                const bool (&live)[PPL], T *__restrict__ tile, const LgLayout &l) {
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    if ((uint32_t)j < d) {
+#pragma unroll
+      for (int r = 0; r < PPL; ++r)
+        if (live[r]) tile[p[r] * l.rs + j] = v[j][r];
+    }
+  }
+}
+
+// A wavefront's rows of the u tile are its own (lane = particle), so only a launch that also STORES the
+// tile (cooperatively, all lanes) needs workgroup barriers around it.
+__device__ __forceinline__ void lg_u_ready(bool stored) {
+  if (stored) lg_lds_barrier();
+  else lg_wave_fence();
+}
+
+struct LgBackwardOut {
+  void *gxprev, *gx, *up, *ug, *uq, *ws;
+  void *rows;        // nullptr, or the tiles' row-sum records [tile][3 terms p, g, q][kLgRowsMax][16]
+  int row_terms;     // bit 0 / 1 / 2: term p / g / q wants its row sums
+  const void *gx_in; // step kernel only: the gradient that arrives at x_t from later steps, or nullptr
+  int want_scale_q;  // step kernel only: the proposal scale's gradient is wanted (costs the proposal's location)
+};
+
+template <typename T, int DP, int PPL>
+__global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_logweight_backward_kernel(
+    const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
+    LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
+    const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse,
+    const T *__restrict__ grad_lw, LgBackwardOut out, int64_t N, uint32_t K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  const uint32_t dx = mp.dout, dy = mg.dout;
+  T *wf = reinterpret_cast<T *>(lg_smem);        // [3][DP*DP] input-major: locations (p, g, q)
+  T *wn = wf + 3 * DP * DP;                      // [3][DP*DP] output-major: adjoints
+  T *scratch = wn + 3 * DP * DP;                 // 4 x 256 (records) / 16 x 8 x 16 (row sums)
+  T *tab = scratch + kLgRowPart;                 // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
+  T *tprev = tab + kLgRowsMax * 4 * DP;
+  const LgLayout lx = lg_layout<T>(dx), ly = lg_layout<T>(dy);
+  T *tx = tprev + (TP * lx.rs + 16);
+  T *tu = tx + (TP * lx.rs + 16);  // [TP * max(dx, dy)]
+  {
+    lg_stage_weight<T, DP>(mp, wf);
+    lg_stage_weight<T, DP>(mg, wf + DP * DP);
+    lg_stage_weight<T, DP>(mq, wf + 2 * DP * DP);
+    LgMap t = mp;
+    t.sj = mp.si; t.si = mp.sj; t.dout = mp.din; t.din = mp.dout;
+    lg_stage_weight<T, DP>(t, wn);
+    t = mg; t.sj = mg.si; t.si = mg.sj; t.dout = mg.din; t.din = mg.dout;
+    lg_stage_weight<T, DP>(t, wn + DP * DP);
+    t = mq; t.sj = mq.si; t.si = mq.sj; t.dout = mq.din; t.din = mq.dout;
+    lg_stage_weight<T, DP>(t, wn + 2 * DP * DP);
+  }
+  const LgRowVec<T> vec[4] = {lg_offset_vec<T>(mp), lg_offset_vec<T>(mq), lg_offset_vec<T>(mg), {y, y_sb, (int)dy}};
+  const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
+  const T inv_var_p = T(1) / (s_p * s_p), inv_var_g = T(1) / (s_g * s_g), inv_var_q = T(1) / (s_q * s_q);
+  const T inv_s_p = T(1) / s_p, inv_s_g = T(1) / s_g, inv_s_q = T(1) / s_q;
+  typename Mfma<T>::Acc acc_a = {T(0), T(0), T(0), T(0)}, acc_c = acc_a, acc_q = acc_a;
+  T scale_acc[3] = {T(0), T(0), T(0)};
+  T *gxprev = reinterpret_cast<T *>(out.gxprev), *gx = reinterpret_cast<T *>(out.gx);
+  T *up_out = reinterpret_cast<T *>(out.up), *ug_out = reinterpret_cast<T *>(out.ug),
+    *uq_out = reinterpret_cast<T *>(out.uq);
+  T *rows = reinterpret_cast<T *>(out.rows);
+  const int row_terms = rows != nullptr ? out.row_terms : 0;
+  const int64_t tiles = (N + TP - 1) / TP;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+    lg_stage_rows<T, true>(x + n0 * dx, np * dx, tx, lx, 0);
+    uint32_t p[PPL], brow[PPL], at[PPL];
+    bool live[PPL];
+    lg_rows<PPL, true>(n0, np, K, p, live, brow);
+    const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
+    lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
+    const uint32_t k0_tile = (uint32_t)(n0 - (int64_t)b0 * K);
+    T g[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const int64_t n = n0 + p[r];
+      T value = grad_lw != nullptr ? grad_lw[n] : T(0);
+      if (grad_lse != nullptr) value = value + grad_lse[brow[r]] * Num<T>::exp(lw[n] - lse[brow[r]]);
+      g[r] = live[r] ? value : T(0);
+      at[r] = p[r] * lx.rs;
+    }
+    lg_lds_barrier();
+    T u[DP][PPL], gprev[DP][PPL], gcur[DP][PPL];
+    uint32_t au[PPL], ay[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      au[r] = p[r] * lx.rs;
+      ay[r] = p[r] * ly.rs;
+    }
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) gprev[j][r] = T(0);
+    // ---- transition term: u = g (x - loc_p) / s_p^2
+    lg_row_values<T, DP, PPL, 4, 0>(vec, true, tab, b0, brow, u);
+    lg_apply_loop<T, DP, PPL>(wf, tprev, at, dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_p;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = scaled * diff;
+        gcur[j][r] = -u[j][r];
+      }
+      scale_acc[0] += g[r] * (q * inv_var_p * inv_s_p - T(dx) * inv_s_p);
+    }
+    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
+    lg_u_ready(up_out != nullptr || (row_terms & 1));
+    if (up_out != nullptr) lg_store_rows<T, true>(up_out + n0 * dx, np * dx, tu, lx);
+    if (row_terms & 1) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 0) * (kLgRowsMax * 16));
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_a);
+    lg_u_ready(up_out != nullptr || (row_terms & 1));
+    // ---- proposal term (enters the log-weight with a minus sign): u = -g (x - loc_q) / s_q^2
+    lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
+    lg_apply_loop<T, DP, PPL>(wf + 2 * DP * DP, tprev, at, dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_q;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = -(scaled * diff);
+        gcur[j][r] = gcur[j][r] - u[j][r];
+      }
+      scale_acc[2] -= g[r] * (q * inv_var_q * inv_s_q - T(dx) * inv_s_q);
+    }
+    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
+    lg_u_ready(uq_out != nullptr || (row_terms & 4));
+    if (uq_out != nullptr) lg_store_rows<T, true>(uq_out + n0 * dx, np * dx, tu, lx);
+    if (row_terms & 4) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 2) * (kLgRowsMax * 16));
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL>(wn + 2 * DP * DP, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL>(tu, lx.rs, tprev, lx.rs, np, acc_q);
+    lg_u_ready(uq_out != nullptr || (row_terms & 4));
+    // ---- emission term: u = g (y - loc_g) / s_g^2
+    lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
+    lg_apply_loop<T, DP, PPL>(wf + DP * DP, tx, at, dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_g;
+      const T *yrow = tab + ((brow[r] - b0) * 4 + 3) * DP;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dy ? yrow[j] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = scaled * diff;
+      }
+      scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
+    }
+    if (lx.rs != ly.rs) lg_lds_barrier();     // the u tile changes layout: rows of other wavefronts move under it
+    lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu, ly);
+    lg_u_ready(ug_out != nullptr || (row_terms & 2));
+    if (ug_out != nullptr) lg_store_rows<T, true>(ug_out + n0 * dy, np * dy, tu, ly);
+    if (row_terms & 2) lg_row_sums<T>(tu, ly.rs, dy, np, k0_tile, K, scratch, rows + (tile * 3 + 1) * (kLgRowsMax * 16));
+    if (gx != nullptr) lg_apply_loop<T, DP, PPL>(wn + DP * DP, tu, ay, dy, gcur);
+    lg_outer_accumulate_own<T, PPL>(tu, ly.rs, tx, lx.rs, np, acc_c);
+    lg_lds_barrier();
+    // ---- the two latent gradients leave through the input tiles
+    if (gxprev != nullptr) lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev, lx);
+    if (gx != nullptr) lg_rows_to_tile<T, DP, PPL>(gcur, dx, p, live, tx, lx);
+    lg_lds_barrier();
+    if (gxprev != nullptr) lg_store_rows<T, true>(gxprev + n0 * dx, np * dx, tprev, lx);
+    if (gx != nullptr) lg_store_rows<T, true>(gx + n0 * dx, np * dx, tx, lx);
+    lg_lds_barrier();
+  }
+  T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
+  lg_outer_publish<T>(acc_a, scratch, record);
+  lg_outer_publish<T>(acc_c, scratch, record + kLgRecord);
+  lg_outer_publish<T>(acc_q, scratch, record + 2 * kLgRecord);
+  // the three scale gradients: lanes -> wavefronts (shuffles) -> workgroup, fixed order
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    T v = scale_acc[m];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if ((threadIdx.x & 63) == 0) scratch[(threadIdx.x >> 6) * 4 + m] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLgRecord) {
+    const int m = threadIdx.x;
+    record[3 * kLgRecord + m] = m < 3 ? ((scratch[m] + scratch[4 + m]) + scratch[8 + m]) + scratch[12 + m] : T(0);
+  }
+}
+
+// K12 for a step whose x_t IS the proposal's reparameterised draw, x_t = loc_q(x_{t-1}) + s_q eps (kernel K9):
+// the whole step's backward in one pass.  With w = gx_in + dL/dx_t through the transition and emission
+// densities, the draw carries w to the proposal's parameters and to x_{t-1}; the proposal's own density
+// depends on them only through eps = (x_t - loc_q) / s_q, which the draw holds fixed — its location terms
+// cancel identically and only -d log s_q survives.  So: the emission term first (its adjoint starts w), the
+// transition term (w -= u_p), then w itself takes the place K12 gives u_q: grad W_q = sum w (x) x_{t-1},
+// grad offset_q = row sums of w, grad x_{t-1} = A^T u_p + Q^T w, grad s_q = sum g d / s_q + w . eps.  Neither
+// a gradient for x_t nor K9's own backward launch (K11) nor the two [B,K,d] accumulations between them exist.
+#ifndef LG_STEP_UNROLL
+#define LG_STEP_UNROLL 2
+#endif
+// EXACT: both extents equal DP (the host checks) — every extent test, row stride and LDS offset folds.
+template <typename T, int DP, int PPL, bool EXACT>
+__global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_step_backward_kernel(
+    const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
+    LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
+    const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse,
+    const T *__restrict__ grad_lw, LgBackwardOut out, int64_t N, uint32_t K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  constexpr uint32_t TP = kLgBlock * PPL;
+  constexpr int kUnroll = EXACT ? LG_STEP_UNROLL : 2;
+  constexpr bool ONES = EXACT && DP < 16;      // the latent has no column 15: it carries the column sums
+  const uint32_t dx = EXACT ? (uint32_t)DP : (uint32_t)mp.dout, dy = EXACT ? (uint32_t)DP : (uint32_t)mg.dout;
+  T *wf = reinterpret_cast<T *>(lg_smem);        // [3][DP*DP] input-major: locations (p, g, q)
+  T *wn = wf + 3 * DP * DP;                      // [3][DP*DP] output-major: adjoints
+  T *scratch = wn + 3 * DP * DP;
+  T *tab = scratch + kLgRowPart;                 // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
+  T *tprev = tab + kLgRowsMax * 4 * DP;
+  const LgLayout lx = lg_layout<T>(dx), ly = lg_layout<T>(dy);
+  T *tx = tprev + (TP * lx.rs + 16);
+  T *tu = tx + (TP * lx.rs + 16);
+  const bool want_sq = out.want_scale_q != 0;
+  {
+    lg_stage_weight<T, DP>(mp, wf);
+    lg_stage_weight<T, DP>(mg, wf + DP * DP);
+    if (want_sq) lg_stage_weight<T, DP>(mq, wf + 2 * DP * DP);
+    LgMap t = mp;
+    t.sj = mp.si; t.si = mp.sj; t.dout = mp.din; t.din = mp.dout;
+    lg_stage_weight<T, DP>(t, wn);
+    t = mg; t.sj = mg.si; t.si = mg.sj; t.dout = mg.din; t.din = mg.dout;
+    lg_stage_weight<T, DP>(t, wn + DP * DP);
+    t = mq; t.sj = mq.si; t.si = mq.sj; t.dout = mq.din; t.din = mq.dout;
+    lg_stage_weight<T, DP>(t, wn + 2 * DP * DP);
+  }
+  const LgRowVec<T> vec[4] = {lg_offset_vec<T>(mp), lg_offset_vec<T>(mq), lg_offset_vec<T>(mg), {y, y_sb, (int)dy}};
+  const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
+  const T inv_var_p = T(1) / (s_p * s_p), inv_var_g = T(1) / (s_g * s_g);
+  const T inv_s_p = T(1) / s_p, inv_s_g = T(1) / s_g, inv_s_q = T(1) / s_q;
+  typename Mfma<T>::Acc acc_a = {T(0), T(0), T(0), T(0)}, acc_c = acc_a, acc_q = acc_a;
+  T scale_acc[3] = {T(0), T(0), T(0)};
+  T *gxprev = reinterpret_cast<T *>(out.gxprev);
+  const T *gx_in = reinterpret_cast<const T *>(out.gx_in);
+  T *rows = reinterpret_cast<T *>(out.rows);
+  const int row_terms = rows != nullptr ? out.row_terms : 0;
+  const int64_t tiles = (N + TP - 1) / TP;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+    lg_stage_rows<T, true>(x + n0 * dx, np * dx, tx, lx, 0);
+    if (gx_in != nullptr) lg_stage_rows<T, true>(gx_in + n0 * dx, np * dx, tu, lx, 0);
+    uint32_t p[PPL], brow[PPL], at[PPL];
+    bool live[PPL];
+    lg_rows<PPL, true>(n0, np, K, p, live, brow);
+    const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
+    lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
+    const uint32_t k0_tile = (uint32_t)(n0 - (int64_t)b0 * K);
+    // offsets' gradients: a tile inside one batch row takes its sums from the matrix cores' spare column
+    const bool column_sums = ONES && lg_single_row(n0, np, K);
+    const int row_pass = column_sums ? 0 : row_terms;      // the terms that need the pass over the tile
+    T g[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const int64_t n = n0 + p[r];
+      T value = grad_lw != nullptr ? grad_lw[n] : T(0);
+      if (grad_lse != nullptr) value = value + grad_lse[brow[r]] * Num<T>::exp(lw[n] - lse[brow[r]]);
+      g[r] = live[r] ? value : T(0);
+      at[r] = p[r] * lx.rs;
+    }
+    lg_lds_barrier();
+    T u[DP][PPL], gprev[DP][PPL], w[DP][PPL];
+    uint32_t au[PPL], ay[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      au[r] = p[r] * lx.rs;
+      ay[r] = p[r] * ly.rs;
+    }
+    // a lane's row of the spare tile is its own particle's: read before the lane overwrites it below
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        gprev[j][r] = T(0);
+        w[j][r] = (gx_in != nullptr && (uint32_t)j < dx && live[r]) ? tu[au[r] + min(j, (int)dx - 1)] : T(0);
+      }
+    if (gx_in != nullptr && lx.rs != ly.rs) lg_lds_barrier();   // the tile changes layout under the other wavefronts
+    // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u
+    lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
+    lg_apply_loop<T, DP, PPL, kUnroll>(wf + DP * DP, tx, at, dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_g;
+      const T *yrow = tab + ((brow[r] - b0) * 4 + 3) * DP;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dy ? yrow[j] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = scaled * diff;
+      }
+      scale_acc[1] += g[r] * (q * inv_var_g * inv_s_g - T(dy) * inv_s_g);
+    }
+    lg_rows_to_tile<T, DP, PPL>(u, dy, p, live, tu, ly);
+    lg_u_ready((row_pass & 2) != 0);
+    if (row_pass & 2) lg_row_sums<T>(tu, ly.rs, dy, np, k0_tile, K, scratch, rows + (tile * 3 + 1) * (kLgRowsMax * 16));
+    lg_apply_loop<T, DP, PPL, kUnroll>(wn + DP * DP, tu, ay, dy, w);
+    lg_outer_accumulate_own<T, PPL, ONES>(tu, ly.rs, tx, lx.rs, np, acc_c);
+    if (ONES) lg_flush_column_sums<T>(acc_c, rows + (tile * 3 + 1) * (kLgRowsMax * 16), column_sums && (row_terms & 2));
+    if (lx.rs != ly.rs) lg_lds_barrier();     // back to the latent's layout
+    else lg_u_ready((row_pass & 2) != 0);
+    // ---- transition term: u = g (x - loc_p) / s_p^2;  w -= u
+    lg_row_values<T, DP, PPL, 4, 0>(vec, true, tab, b0, brow, u);
+    lg_apply_loop<T, DP, PPL, kUnroll>(wf, tprev, at, dx, u);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      T q = T(0);
+      const T scaled = g[r] * inv_var_p;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const T diff = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] - u[j][r] : T(0);
+        q = fma_t(diff, diff, q);
+        u[j][r] = scaled * diff;
+        w[j][r] = w[j][r] - u[j][r];
+      }
+      scale_acc[0] += g[r] * (q * inv_var_p * inv_s_p - T(dx) * inv_s_p);
+    }
+    lg_rows_to_tile<T, DP, PPL>(u, dx, p, live, tu, lx);
+    lg_u_ready((row_pass & 1) != 0);
+    if (row_pass & 1) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 0) * (kLgRowsMax * 16));
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL, kUnroll>(wn, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL, ONES>(tu, lx.rs, tprev, lx.rs, np, acc_a);
+    if (ONES) lg_flush_column_sums<T>(acc_a, rows + (tile * 3 + 0) * (kLgRowsMax * 16), column_sums && (row_terms & 1));
+    lg_u_ready((row_pass & 1) != 0);
+    // ---- the draw: w reaches the proposal's parameters and x_{t-1};  grad s_q = g d / s_q + w . eps
+    if (want_sq) {
+      lg_row_values<T, DP, PPL, 4, 1>(vec, true, tab, b0, brow, u);
+      lg_apply_loop<T, DP, PPL, kUnroll>(wf + 2 * DP * DP, tprev, at, dx, u);
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        T dot = T(0);
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const T diff = (uint32_t)j < dx ? tx[at[r] + min(j, (int)dx - 1)] - u[j][r] : T(0);
+          dot = fma_t(w[j][r], diff, dot);
+        }
+        if (live[r]) scale_acc[2] += g[r] * (T(dx) * inv_s_q) + dot * inv_s_q;   // a spare lane's w is particle 0's
+      }
+    }
+    lg_rows_to_tile<T, DP, PPL>(w, dx, p, live, tu, lx);
+    lg_u_ready((row_pass & 4) != 0);
+    if (row_pass & 4) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 2) * (kLgRowsMax * 16));
+    if (gxprev != nullptr) lg_apply_loop<T, DP, PPL, kUnroll>(wn + 2 * DP * DP, tu, au, dx, gprev);
+    lg_outer_accumulate_own<T, PPL, ONES>(tu, lx.rs, tprev, lx.rs, np, acc_q);
+    if (ONES) lg_flush_column_sums<T>(acc_q, rows + (tile * 3 + 2) * (kLgRowsMax * 16), column_sums && (row_terms & 4));
+    if constexpr (EXACT && (DP * sizeof(T)) % 8 == 0) {
+      // rows of whole 8-byte pairs: each lane stores its own particles' rows (a wavefront's stores cover
+      // one contiguous span) — no trip through the tile, no barriers around it
+      if (gxprev != nullptr) {
+        typedef T Pair __attribute__((ext_vector_type(8 / sizeof(T))));
+        constexpr int PER = 8 / sizeof(T);
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+          if (live[r]) {
+            Pair *dst = reinterpret_cast<Pair *>(gxprev + (n0 + p[r]) * DP);
+#pragma unroll
+            for (int j = 0; j < DP / PER; ++j) {
+              Pair v;
+#pragma unroll
+              for (int e = 0; e < PER; ++e) v[e] = gprev[j * PER + e][r];
+              dst[j] = v;
+            }
+          }
+        }
+      }
+      lg_lds_barrier();
+    } else {
+      lg_lds_barrier();
+      if (gxprev != nullptr) {
+        lg_rows_to_tile<T, DP, PPL>(gprev, dx, p, live, tprev, lx);
+        lg_lds_barrier();
+        lg_store_rows<T, true>(gxprev + n0 * dx, np * dx, tprev, lx);
+      }
+      lg_lds_barrier();
+    }
+  }
+  T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
+  lg_outer_publish<T>(acc_a, scratch, record);
+  lg_outer_publish<T>(acc_c, scratch, record + kLgRecord);
+  lg_outer_publish<T>(acc_q, scratch, record + 2 * kLgRecord);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    T v = scale_acc[m];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if ((threadIdx.x & 63) == 0) scratch[(threadIdx.x >> 6) * 4 + m] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLgRecord) {
+    const int m = threadIdx.x;
+    record[3 * kLgRecord + m] = m < 3 ? ((scratch[m] + scratch[4 + m]) + scratch[8 + m]) + scratch[12 + m] : T(0);
+  }
+}
+
+// Sums the workgroups' records in workgroup order: out[m][j * din + i] = sum_b ws[b][m][j * 16 + i].
+struct LgFinish {
+  void *out[4];
+  int32_t rows[4], cols[4];
+  // offset gradients: goff[t][b][j] = sum over the tiles covering batch row b of their row-sum records
+  const void *row_ws;     // [tile][row_terms][kLgRowsMax][16], or nullptr
+  void *goff[3];
+  int32_t goff_d[3];
+  int32_t row_terms, matrices, row_blocks;    // records per tile; matrix blocks; row blocks per term (64 rows each)
+  int32_t column_sums;                        // single-row tiles hold four wavefront sums (lg_flush_column_sums)
+  int64_t B, N;
+  uint32_t K, TP;
+};
+template <typename T>
+__global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ ws, int nblocks, int record, LgFinish f) {
+  if ((int)blockIdx.x >= f.matrices) {
+    // ---- one lane per (batch row, column): the few tiles that cover the row, in tile order
+    const int r = (int)blockIdx.x - f.matrices, term = r / f.row_blocks;
+    T *goff = reinterpret_cast<T *>(f.goff[term]);
+    if (goff == nullptr) return;
+    const int64_t b = (int64_t)(r - term * f.row_blocks) * 64 + (threadIdx.x >> 4);
+    const uint32_t j = threadIdx.x & 15u, d = (uint32_t)f.goff_d[term];
+    if (b >= f.B || j >= d) return;
+    const T *rows = reinterpret_cast<const T *>(f.row_ws);
+    const int64_t first = b * f.K / f.TP, last = ((b + 1) * f.K - 1) / f.TP;
+    T sum = T(0);
+    for (int64_t tile = first; tile <= last; ++tile) {
+      const int64_t n0 = tile * f.TP, b0 = n0 / f.K;
+      const T *record = rows + (tile * f.row_terms + term) * (kLgRowsMax * 16);
+      if (f.column_sums && lg_single_row(n0, (uint32_t)min((int64_t)f.TP, f.N - n0), f.K))
+        sum += ((record[j] + record[16 + j]) + record[32 + j]) + record[48 + j];     // the four wavefronts' sums
+      else
+        sum += record[(b - b0) * 16 + j];
+    }
+    goff[b * d + j] = sum;
+    return;
+  }
+  // element e of matrix m: four lanes each sum a quarter of the workgroups' records (in workgroup order,
+  // eight loads in flight), then the quarters are added in order — fixed association, reproducible
+  __shared__ T part[4 * 256];
+  const int m = blockIdx.x, e = threadIdx.x & 255, seg = threadIdx.x >> 8;
+  const int per = (nblocks + 3) / 4, b0 = seg * per, b1 = min(nblocks, b0 + per);
+  T sum = T(0);
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(b + u) * record + m * 256 + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; b < b1; ++b) sum += ws[(int64_t)b * record + m * 256 + e];
+  part[seg * 256 + e] = sum;
+  __syncthreads();
+  if (seg == 0) {
+    const T total = ((part[e] + part[256 + e]) + part[512 + e]) + part[768 + e];
+    const int j = e >> 4, i = e & 15;
+    T *out = reinterpret_cast<T *>(f.out[m]);
+    if (out != nullptr && j < f.rows[m] && i < f.cols[m]) out[j * f.cols[m] + i] = total;
+  }
+}
+
+// Workspace of the reducing kernels: kLgMaxGrid records of 4 x 256 values (weight-gradient partials), then
+// one 8 x 16 record per 256-particle tile and term (offset-gradient row sums).
+static inline size_t lg_record_elems() { return (size_t)kLgMaxGrid * 4 * kLgRecord; }
+static inline size_t lg_row_elems(int64_t N, int terms) {
+  return (size_t)((N + kLgBlock - 1) / kLgBlock) * terms * kLgRowsMax * 16;
+}
+
+template <typename T>
+static int launch_particle_affine_backward(const void *g, const void *x, const aesmc_affine_map *m, void *gx, void *gw,
+                                           void *goff, void *ws, size_t ws_bytes, int64_t B, int64_t K,
+                                           hipStream_t stream) {
+  const int64_t N = B * K;
+  const int64_t dout = m->dout, din = m->din;
+  const int dp = lg_pad_dim(std::max(dout, din));
+  int ppl = sizeof(T) == 4 ? 2 : 1;
+  size_t lds = 0;
+  for (; ppl >= 1; --ppl) {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * (16 + (size_t)dp * dp + kLgRowPart + lg_tile_elems<T>(tp, dout) + lg_tile_elems<T>(tp, din));
+    if (lds <= (ppl > 1 ? kLgLdsBudget : kLgLdsLimit) &&
+        (goff == nullptr || lg_rows_spanned((int64_t)tp, K) <= kLgRowsMax))
+      break;
+  }
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;     // offset gradient with fewer than ~43 particles per row: caller sums
+  const int64_t tp = (int64_t)kLgBlock * ppl;
+  const int64_t tiles = (N + tp - 1) / tp;
+  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds), kLgMaxGrid);
+  const size_t need = (gw != nullptr || goff != nullptr) ? lg_record_elems() + lg_row_elems(N, 1) : 0;
+  if (ws_bytes < need * sizeof(T)) return AESMC_ERR_WORKSPACE;
+  T *records = static_cast<T *>(ws);
+  T *rows = goff != nullptr ? records + lg_record_elems() : nullptr;
+  LgMap adjoint;           // gx = g W: the map from the location's extent back to the input's
+  adjoint.w = m->weight; adjoint.sj = m->stride_in; adjoint.si = m->stride_out;
+  adjoint.off = nullptr; adjoint.off_sb = 0; adjoint.dout = (int32_t)din; adjoint.din = (int32_t)dout;
+  LG_DISPATCH(particle_affine_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream,
+              static_cast<const T *>(g), static_cast<const T *>(x), adjoint, static_cast<T *>(gx), records, rows, N,
+              (uint32_t)K, gw != nullptr ? 1 : 0);
+  if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  if (gw != nullptr || goff != nullptr) {      // one finishing launch: the weight gradient's records, the rows' tiles
+    LgFinish f = {};
+    f.out[0] = gw; f.rows[0] = (int32_t)dout; f.cols[0] = (int32_t)din;
+    f.matrices = gw != nullptr ? 1 : 0;
+    f.row_ws = rows; f.goff[0] = goff; f.goff_d[0] = (int32_t)dout; f.row_terms = 1;
+    f.row_blocks = goff != nullptr ? (int32_t)((B + 63) / 64) : 0;
+    f.B = B; f.K = (uint32_t)K; f.TP = (uint32_t)tp;
+    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(f.matrices + f.row_blocks)), dim3(1024), 0, stream,
+                       static_cast<const T *>(records), grid, kLgRecord, f);
+    if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  }
+  return AESMC_OK;
+}
+
+template <typename T, int DP, int PPL>
+static constexpr auto affine_step_backward_exact = &affine_step_backward_kernel<T, DP, PPL, true>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_step_backward_any = &affine_step_backward_kernel<T, DP, PPL, false>;
+
+template <typename T>
+static int launch_affine_logweight_backward(const void *xprev, const void *x, const void *y, int64_t y_sb,
+                                            const aesmc_affine_map *mp, const aesmc_affine_map *mg,
+                                            const aesmc_affine_map *mq, const void *sp, const void *sg, const void *sq,
+                                            const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
+                                            const aesmc_affine_logweight_grads *o, void *ws, size_t ws_bytes, int64_t B,
+                                            int64_t K, hipStream_t stream, bool step = false,
+                                            const void *gx_in = nullptr) {
+  const int64_t N = B * K;
+  const int64_t dx = mp->dout, dy = mg->dout;
+  const int dp = lg_pad_dim(std::max(dx, dy));
+  static const int forced = [] { const char *v = getenv("AESMC_LG_BWD_PPL"); return v != nullptr ? atoi(v) : 0; }();   // measurement knob
+  int ppl = (sizeof(T) == 4 && dp <= 12 && !lg_few_tiles(N)) ? 2 : 1;
+  if (forced == 1 || forced == 2) ppl = (sizeof(T) == 4 && dp <= 12) ? forced : 1;
+  size_t lds = 0;
+  for (; ppl >= 1; --ppl) {
+    const size_t tp = (size_t)kLgBlock * ppl;
+    lds = sizeof(T) * (16 + 6 * (size_t)dp * dp + kLgRowPart + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems<T>(tp, dx) +
+                       std::max(lg_tile_elems<T>(tp, dx), lg_tile_elems<T>(tp, dy)));
+    if (lds <= (ppl > 1 ? (size_t)78 * 1024 : kLgLdsLimit) && lg_rows_spanned((int64_t)tp, K) <= kLgRowsMax) break;
+  }
+  if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
+  const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
+  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, (ppl == 2 || sizeof(T) == 8) ? 2 : 3), kLgMaxGrid);   // what the registers allow
+  const int row_terms = (o->grad_offset_p != nullptr ? 1 : 0) | (o->grad_offset_g != nullptr ? 2 : 0) |
+                        (o->grad_offset_q != nullptr ? 4 : 0);
+  const size_t need = lg_record_elems() + (row_terms != 0 ? lg_row_elems(N, 3) : 0);
+  if (ws_bytes < need * sizeof(T)) return AESMC_ERR_WORKSPACE;
+  T *row_ws = row_terms != 0 ? static_cast<T *>(ws) + lg_record_elems() : nullptr;
+  LgBackwardOut out;
+  out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;
+  out.uq = o->grad_loc_q; out.ws = ws; out.rows = row_ws; out.row_terms = row_terms;
+  out.gx_in = gx_in; out.want_scale_q = o->grad_scales != nullptr ? 1 : 0;
+#define LG_BACKWARD_ARGS                                                                                            \
+  static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), \
+      lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),               \
+      static_cast<const T *>(lw), static_cast<const T *>(lse), static_cast<const T *>(grad_lse),                    \
+      static_cast<const T *>(grad_lw), out, N, (uint32_t)K
+  if (step && dx == dp && dy == dp) {
+    LG_DISPATCH(affine_step_backward_exact, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
+  } else if (step) {
+    LG_DISPATCH(affine_step_backward_any, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
+  } else {
+    LG_DISPATCH(affine_logweight_backward_kernel, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
+  }
+#undef LG_BACKWARD_ARGS
+  if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
+  LgFinish f = {};
+  f.out[0] = o->grad_weight_p; f.rows[0] = (int32_t)dx; f.cols[0] = (int32_t)dx;
+  f.out[1] = o->grad_weight_g; f.rows[1] = (int32_t)dy; f.cols[1] = (int32_t)dx;
+  f.out[2] = o->grad_weight_q; f.rows[2] = (int32_t)dx; f.cols[2] = (int32_t)dx;
+  f.out[3] = o->grad_scales; f.rows[3] = 1; f.cols[3] = 3;
+  f.matrices = 4;
+  f.row_ws = row_ws; f.row_terms = 3;
+  f.goff[0] = o->grad_offset_p; f.goff[1] = o->grad_offset_g; f.goff[2] = o->grad_offset_q;
+  f.goff_d[0] = (int32_t)dx; f.goff_d[1] = (int32_t)dy; f.goff_d[2] = (int32_t)dx;
+  f.row_blocks = row_terms != 0 ? (int32_t)((B + 63) / 64) : 0;
+  f.B = B; f.N = N; f.K = (uint32_t)K; f.TP = (uint32_t)(kLgBlock * ppl);
+  f.column_sums = (step && dx == dp && dy == dp && dp < 16) ? 1 : 0;
+  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(4 + 3 * f.row_blocks)), dim3(1024), 0, stream,
+                     static_cast<const T *>(ws), grid, 4 * kLgRecord, f);   // one finishing launch for everything
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+}  // namespace aesmc
+
+using namespace aesmc;
+
+extern "C" int aesmc_affine_normal_logweight_backward(
+    int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
+    const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+    const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
+    const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream) {
+  if (x_prev == nullptr || x == nullptr || y == nullptr || transition == nullptr || emission == nullptr ||
+      proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || out == nullptr ||
+      ws == nullptr || B < 0 || K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lw == nullptr && grad_lse == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lse != nullptr && (lw == nullptr || lse == nullptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  const void *aligned[] = {x_prev, x, ws, out->grad_x_prev, out->grad_x, out->grad_loc_p, out->grad_loc_g,
+                           out->grad_loc_q};
+  for (const void *ptr : aligned)
+    if (ptr != nullptr && !aligned16(ptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  const int64_t dx = transition->dout;
+  if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
+    return AESMC_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0 || K == 0) {      // empty sums
+    const size_t esz = dtype == AESMC_F64 ? 8 : 4;
+    bool ok = true;
+    if (out->grad_weight_p != nullptr) ok = ok && zero_fill_async(out->grad_weight_p, (size_t)(dx * dx) * esz, s);
+    if (out->grad_weight_g != nullptr) ok = ok && zero_fill_async(out->grad_weight_g, (size_t)(emission->dout * dx) * esz, s);
+    if (out->grad_weight_q != nullptr) ok = ok && zero_fill_async(out->grad_weight_q, (size_t)(dx * dx) * esz, s);
+    if (out->grad_scales != nullptr) ok = ok && zero_fill_async(out->grad_scales, 3 * esz, s);
+    return ok ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
+  return dtype == AESMC_F32
+             ? launch_affine_logweight_backward<float>(x_prev, x, y, y_stride_b, transition, emission, proposal,
+                                                       scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
+                                                       ws_bytes, B, K, s)
+             : launch_affine_logweight_backward<double>(x_prev, x, y, y_stride_b, transition, emission, proposal,
+                                                        scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
+                                                        ws_bytes, B, K, s);
+}
+
+
+extern "C" int aesmc_affine_step_backward(
+    int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
+    const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+    const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
+    const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K,
+    void *stream) {
+  if (out == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  // the draw leaves no gradient for x_t and the location gradients have no meaning here
+  if (out->grad_x != nullptr || out->grad_loc_p != nullptr || out->grad_loc_g != nullptr || out->grad_loc_q != nullptr)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (x_prev == nullptr || x == nullptr || y == nullptr || transition == nullptr || emission == nullptr ||
+      proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || ws == nullptr || B < 0 ||
+      K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lw == nullptr && grad_lse == nullptr && grad_x == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lse != nullptr && (lw == nullptr || lse == nullptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  const void *aligned[] = {x_prev, x, ws, grad_x, out->grad_x_prev};
+  for (const void *ptr : aligned)
+    if (ptr != nullptr && !aligned16(ptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_x != nullptr && (grad_x == out->grad_x_prev)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  const int64_t dx = transition->dout;
+  if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
+    return AESMC_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0 || K == 0) {      // empty sums
+    const size_t esz = dtype == AESMC_F64 ? 8 : 4;
+    bool ok = true;
+    if (out->grad_weight_p != nullptr) ok = ok && zero_fill_async(out->grad_weight_p, (size_t)(dx * dx) * esz, s);
+    if (out->grad_weight_g != nullptr) ok = ok && zero_fill_async(out->grad_weight_g, (size_t)(emission->dout * dx) * esz, s);
+    if (out->grad_weight_q != nullptr) ok = ok && zero_fill_async(out->grad_weight_q, (size_t)(dx * dx) * esz, s);
+    if (out->grad_scales != nullptr) ok = ok && zero_fill_async(out->grad_scales, 3 * esz, s);
+    return ok ? AESMC_OK : AESMC_ERR_LAUNCH;
+  }
+  return dtype == AESMC_F32
+             ? launch_affine_logweight_backward<float>(x_prev, x, y, y_stride_b, transition, emission, proposal,
+                                                       scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
+                                                       ws_bytes, B, K, s, true, grad_x)
+             : launch_affine_logweight_backward<double>(x_prev, x, y, y_stride_b, transition, emission, proposal,
+                                                        scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
+                                                        ws_bytes, B, K, s, true, grad_x);
+}
+
+
+extern "C" size_t aesmc_affine_backward_workspace_bytes(int dtype, int64_t B, int64_t K) {
+  const int64_t N = (B > 0 && K > 0) ? B * K : 0;
+  return (lg_record_elems() + lg_row_elems(N, 3)) * (dtype == AESMC_F64 ? 8 : 4);
+}
+
+extern "C" int aesmc_particle_affine_backward(int dtype, const void *grad, const void *x, const aesmc_affine_map *map,
+                                              void *out_grad_x, void *out_grad_weight, void *out_grad_offset, void *ws,
+                                              size_t ws_bytes, int64_t B, int64_t K, void *stream) {
+  const bool reduces = out_grad_weight != nullptr || out_grad_offset != nullptr;
+  if (grad == nullptr || map == nullptr || map->weight == nullptr || B < 0 || K < 0 ||
+      (out_grad_weight != nullptr && x == nullptr) || (reduces && ws == nullptr))
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!aligned16(grad) || (x != nullptr && !aligned16(x)) || (out_grad_x != nullptr && !aligned16(out_grad_x)) ||
+      (ws != nullptr && !aligned16(ws)))
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(map)) return AESMC_ERR_UNSUPPORTED;
+  if (out_grad_x == nullptr && !reduces) return AESMC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0 || K == 0) {   // empty sums: the weight gradient is zero, there are no rows
+    if (out_grad_weight != nullptr &&
+        !zero_fill_async(out_grad_weight, (size_t)(map->dout * map->din) * (dtype == AESMC_F64 ? 8 : 4), s))
+      return AESMC_ERR_LAUNCH;
+    if (out_grad_offset != nullptr && B > 0 &&
+        !zero_fill_async(out_grad_offset, (size_t)(B * map->dout) * (dtype == AESMC_F64 ? 8 : 4), s))
+      return AESMC_ERR_LAUNCH;
+    return AESMC_OK;
+  }
+  return dtype == AESMC_F32
+             ? launch_particle_affine_backward<float>(grad, x, map, out_grad_x, out_grad_weight, out_grad_offset, ws,
+                                                      ws_bytes, B, K, s)
+             : launch_particle_affine_backward<double>(grad, x, map, out_grad_x, out_grad_weight, out_grad_offset, ws,
+                                                       ws_bytes, B, K, s);
+}
+
+
