@@ -88,7 +88,8 @@ def parse(argv=None):
     ap.add_argument("--callables", default="affine", choices=["affine", "matmul"],
                     help="LGSSM workloads: how the model's callables state their linear-Gaussian terms. 'affine': "
                          "aesmc_amd.linear_gaussian.AffineNormal(source, weight, scale, offset) — the locations are "
-                         "evaluated inside the sampling / weighting kernels (K9 / K10); 'matmul': "
+                         "evaluated inside the sampling / weighting kernels, the proposal's draw deferred to the launch that "
+                         "weighs it (K15; a step's backward: K14); 'matmul': "
                          "Normal(source @ weight.T + offset, scale) with PyTorch matmuls, as round 1 and 2 timed it")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--extras", default=None, choices=["on", "off"],
@@ -690,8 +691,9 @@ def main(argv=None):
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": head["workload"], "proposal": head["proposal"],
-                   "callables": {"affine": "AffineNormal(source, weight, scale, offset): locations evaluated inside "
-                                           "kernels K9 / K10 (aesmc_amd/linear_gaussian.py)",
+                   "callables": {"affine": "AffineNormal(source, weight, scale, offset), the proposal's with defer_draw=True: "
+                                           "draw and log-weight in one kernel (K15), a step's backward in one (K14) "
+                                           "(aesmc_amd/linear_gaussian.py)",
                                  "matmul": "Normal(source @ weight.T + offset, scale): PyTorch matmuls, then K6 / K5"
                                  }[head["callables"]],
                    "batch_per_gpu": head["batch_per_gpu"], "global_batch": head["global_batch"],
