@@ -807,12 +807,15 @@ class HipKernels:
             raise ValueError("aesmc_amd: {}: `out` must be a dense, 16-byte aligned {} {} tensor on {}".format(
                 what, tuple(shape), like.dtype, like.device))
 
-    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x):
+    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x, checked=False):
         """K15: the proposal's draw and the step's log-weight in one launch.  Writes
         x = loc_q(x_prev) + eps * s_q into `out_x` (K9's bits) and returns K10's log-weight [B,K] of
         (x_prev, x, y_rows) (K10's bits)."""
-        if not self.affine_logweight_covers(x_prev, eps, y_rows, transition, emission, proposal, scales):
+        # `checked`: the caller has just run affine_logweight_covers on these operands (x_t in eps's place)
+        if not checked and not self.affine_logweight_covers(x_prev, eps, y_rows, transition, emission, proposal, scales):
             raise ValueError("aesmc_amd: affine_propagate operands outside what kernel K15 covers")
+        if eps.shape != x_prev.shape or eps.dtype != x_prev.dtype or eps.device != x_prev.device:
+            raise ValueError("aesmc_amd: affine_propagate noise must match x_prev")
         tag = _DTYPE_TAG[eps.dtype]
         B, K, dx = eps.shape
         self._check_out(out_x, (B, K, dx), eps, "affine_propagate")

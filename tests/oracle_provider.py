@@ -110,7 +110,7 @@ class OracleKernels:
         out.copy_(draw)
         return out
 
-    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x):
+    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x, checked=False):
         """K15 on the C oracle: its draw, then its log-weight of that draw."""
         from oracle import c_oracle
         pair = lambda term: (self._n(term[0]), self._n(term[1]))
