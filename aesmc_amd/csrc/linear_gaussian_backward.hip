@@ -480,12 +480,15 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
 // transition term (w -= u_p), then w itself takes the place K12 gives u_q: grad W_q = sum w (x) x_{t-1},
 // grad offset_q = row sums of w, grad x_{t-1} = A^T u_p + Q^T w, grad s_q = sum g d / s_q + w . eps.  Neither
 // a gradient for x_t nor K9's own backward launch (K11) nor the two [B,K,d] accumulations between them exist.
+#ifndef LG_STEP_WAVES
+#define LG_STEP_WAVES 3
+#endif
 #ifndef LG_STEP_UNROLL
 #define LG_STEP_UNROLL 2
 #endif
 // EXACT: both extents equal DP (the host checks) — every extent test, row stride and LDS offset folds.
 template <typename T, int DP, int PPL, bool EXACT>
-__global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_step_backward_kernel(
+__global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STEP_WAVES) void affine_step_backward_kernel(
     const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
     LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
     const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse,
@@ -817,6 +820,9 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   const int dp = lg_pad_dim(std::max(dx, dy));
   static const int forced = [] { const char *v = getenv("AESMC_LG_BWD_PPL"); return v != nullptr ? atoi(v) : 0; }();   // measurement knob
   int ppl = (sizeof(T) == 4 && dp <= 12 && !lg_few_tiles(N)) ? 2 : 1;
+  // the step kernel is latency-bound: one particle per lane and three workgroups per CU where the registers
+  // allow it without spills (d = 10: 322 -> 300 us; d = 8: no difference; d = 12: 448 -> 477, kept at two)
+  if (step && dp <= 10) ppl = 1;
   if (forced == 1 || forced == 2) ppl = (sizeof(T) == 4 && dp <= 12) ? forced : 1;
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
@@ -827,7 +833,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
-  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, (ppl == 2 || sizeof(T) == 8) ? 2 : 3), kLgMaxGrid);   // what the registers allow
+  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, (ppl == 2 || sizeof(T) == 8) ? 2 : (step ? LG_STEP_WAVES : 3)), kLgMaxGrid);   // what the registers allow
   const int row_terms = (o->grad_offset_p != nullptr ? 1 : 0) | (o->grad_offset_g != nullptr ? 2 : 0) |
                         (o->grad_offset_q != nullptr ? 4 : 0);
   const size_t need = lg_record_elems() + (row_terms != 0 ? lg_row_elems(N, 3) : 0);
