@@ -199,6 +199,11 @@ class HipKernels:
 
     @staticmethod
     def _stream(t):
+        # the raw handle of torch's current stream on t's device (torch.cuda.current_stream builds a Stream
+        # object around the same call: 3 us of host time per launch)
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw is not None:
+            return raw(t.device.index if t.device.index is not None else torch.cuda.current_device())
         return torch.cuda.current_stream(t.device).cuda_stream
 
     # ---- K1 ------------------------------------------------------------------------------------

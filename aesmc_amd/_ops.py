@@ -261,7 +261,9 @@ class _ResampleStep(torch.autograd.Function):
     payload[b, idx[b,k]] differentiates into the payload by the sorted segmented sum."""
 
     @staticmethod
-    def forward(ctx, log_w, uniforms, payload, want_lse):
+    def forward(ctx, log_w, uniforms, payload, want_lse, carrier=None):
+        # `carrier`: a step node's [B] stand-in for this very log-sum-exp (PendingStep): the gradient of `lse`
+        # goes to it instead of into the log-weights
         ctx.set_materialize_grads(False)
         out = _kernels.get().resample_step(log_w, uniforms, payload, want_lse)
         if out is None:
@@ -275,32 +277,43 @@ class _ResampleStep(torch.autograd.Function):
     def backward(ctx, _grad_idx, grad_lse, grad_moved):
         log_w, lse, idx = ctx.saved_tensors
         k = _kernels.get()
-        grad_w = grad_payload = None
-        if ctx.needs_input_grad[0] and lse is not None and grad_lse is not None:
+        grad_w = grad_payload = grad_carrier = None
+        if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4]:
+            grad_carrier = grad_lse
+        elif ctx.needs_input_grad[0] and lse is not None and grad_lse is not None:
             grad_w, _ = k.logweight_lse_backward(log_w, lse, None, grad_lse, want_neg=False)
         if ctx.needs_input_grad[2] and grad_moved is not None:
             grad_payload = k.gather_backward(grad_moved, idx, sorted_index=True)
-        return grad_w, None, grad_payload, None
+        return grad_w, None, grad_payload, None, grad_carrier
 
 
-def resample_step(log_weight, uniforms, payload=None, want_lse=False):
+def resample_step(log_weight, uniforms, payload=None, want_lse=False, pending=None):
     """One resampling step: (ancestor indices [B,K], logsumexp over particles [B] or None,
     payload[b, idx[b,k], ...] or None).  One launch when the fused kernel covers the operands;
-    `moved` is None when it does not cover the payload (the caller gathers with the indices)."""
+    `moved` is None when it does not cover the payload (the caller gathers with the indices).
+    `pending` (with want_lse): the PendingStep of the step that produced `log_weight` — the log-sum-exp
+    comes back bound to it (its gradient reaches that step's node), with no autograd node of its own."""
     k = _kernels.get()
     if not k.step_covers(log_weight):
         idx = ancestor_index(log_weight, uniforms)
-        return idx, (row_logsumexp(log_weight) if want_lse else None), None
+        lse = row_logsumexp(log_weight) if want_lse else None
+        return idx, (pending.bind(lse.detach()) if (pending is not None and lse is not None) else lse), None
     if payload is not None and not k.step_covers(log_weight, payload):
         payload = None
+    bind = pending is not None and want_lse and torch.is_grad_enabled()
     wants_grad = torch.is_grad_enabled() and (
-        (want_lse and log_weight.requires_grad) or
+        bind or (want_lse and log_weight.requires_grad) or
         (payload is not None and payload.requires_grad and payload.is_floating_point()))
-    if wants_grad:
+    if wants_grad and bind:
+        idx, lse, moved = _ResampleStep.apply(log_weight, uniforms, payload, want_lse, pending.carrier)
+        pending.box[0] = lse.detach()
+    elif wants_grad:
         idx, lse, moved = _ResampleStep.apply(log_weight, uniforms, payload, want_lse)
     else:
         idx, lse, moved = k.resample_step(log_weight.detach(), uniforms,
                                           None if payload is None else payload.detach(), want_lse)
+        if pending is not None and lse is not None:
+            lse = pending.bind(lse)
     idx._aesmc_sorted = True
     return idx, lse, moved
 
@@ -504,6 +517,7 @@ class _AffineStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lw, x_value, pending, *operands):
+        ctx.set_materialize_grads(False)      # an output nobody differentiated arrives as None, not as zeros
         ctx.lse_box = pending.box
         ctx.save_for_backward(lw, x_value, *[t for t in operands if t is not None])
         ctx.present = [t is not None for t in operands]

@@ -286,11 +286,17 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                 # K2; the same launch re-indexes the newest latent (what a Markov model reads) and
                 # returns the row log-sum-exp when the step before left it pending (K5 route)
                 newest = history[-1] if torch.is_tensor(history[-1]) else None
+                entry = deferred.get(time - 1) if step_lse[-1] is None else None
+                pending = entry if isinstance(entry, _ops.PendingStep) else None    # a step node awaits this lse
                 index, lse_previous, moved = _ops.resample_step(previous, feed.next(), newest,
-                                                                want_lse=step_lse[-1] is None)
+                                                                want_lse=step_lse[-1] is None, pending=pending)
                 if step_lse[-1] is None:
-                    step_lse[-1] = lse_previous if (time - 1) not in deferred else \
-                        _ops.attach_lse(lse_previous, previous, deferred.pop(time - 1))
+                    if pending is not None:
+                        del deferred[time - 1]
+                        step_lse[-1] = lse_previous
+                    else:
+                        step_lse[-1] = lse_previous if (time - 1) not in deferred else \
+                            _ops.attach_lse(lse_previous, previous, deferred.pop(time - 1))
                 indices.append(index)
                 if _HISTORY_MODE == "lazy":
                     ancestors = ResampledHistory(history, index, newest=moved)
