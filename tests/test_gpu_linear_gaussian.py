@@ -734,3 +734,47 @@ def test_affine_route_reproduces_the_reference_s_own_fixtures(hip_device, name):
             scale = np.abs(want).max() + 1e-30
             np.testing.assert_allclose(parameter.grad.cpu().numpy() / scale, want / scale, rtol=0,
                                        atol=1e-8 if f64 else 1e-3)
+
+
+def test_full_size_step_is_the_same_by_every_route(hip_device):
+    """BASELINE.json's north-star shape (B=1024, K=4096, d=10; four timesteps): the run whose proposal
+    defers its draw (K15 forward, K14 backward) against the run that draws at once (K9, K10, K14) and the
+    one with matmul callables (PyTorch matmuls, K6 / K5, autograd): the first two identical in every bit —
+    ancestors, latents, evidence, gradients — the third within float32 rounding: the first step's ancestor
+    indices equal except where a CDF comparison sits inside that rounding, evidence and gradients close."""
+    from aesmc_amd import inference
+    from aesmc_amd.testing.models import LgssmNd
+    B, K, T = 1024, 4096, 4
+    runs = {}
+    for name, kwargs in (("deferred", dict(affine=True, defer_draw=True)), ("immediate", dict(affine=True, defer_draw=False)),
+                         ("matmul", dict(affine=False))):
+        model = LgssmNd(10, dtype=torch.float32, validate_args=False, **kwargs).tune_proposal().to(hip_device)
+        observations = model.simulate(T, B, seed=5)
+        torch.manual_seed(21)
+        np.random.seed(21)
+        out = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal, K,
+                              return_log_marginal_likelihood=True, return_log_weight=False, return_latents=False,
+                              return_ancestral_indices=True)
+        (-out["log_marginal_likelihood"].mean()).backward()
+        runs[name] = (out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        del model, observations
+    (a, ga), (b, gb), (c, gc) = runs["deferred"], runs["immediate"], runs["matmul"]
+    assert torch.equal(a["log_marginal_likelihood"], b["log_marginal_likelihood"])
+    assert torch.equal(a["last_latent"], b["last_latent"])
+    for x, y in zip(a["ancestral_indices"], b["ancestral_indices"]):
+        assert torch.equal(x, y)
+    assert sorted(ga) == sorted(gb) and ga
+    for name in ga:
+        assert torch.equal(ga[name], gb[name]), name
+    # against the matmul statement of the same model: float32 rounding apart
+    # (a flipped ancestor puts a different particle into that slot for good, so later steps differ in more places:
+    # the first resampling step is the one bounded by CDF rounding alone)
+    first = int((a["ancestral_indices"][0] != c["ancestral_indices"][0]).sum())
+    assert first <= 2e-3 * B * K, first
+    differing = sum(int((x != y).sum()) for x, y in zip(a["ancestral_indices"], c["ancestral_indices"]))
+    assert differing <= 5e-2 * (T - 1) * B * K, differing
+    torch.testing.assert_close(a["log_marginal_likelihood"], c["log_marginal_likelihood"], rtol=1e-3, atol=1e-2)
+    assert sorted(ga) == sorted(gc)
+    for name in ga:
+        scale = max(float(gc[name].abs().max()), 1e-30)
+        assert float((ga[name] - gc[name]).abs().max()) <= 5e-2 * scale, name
