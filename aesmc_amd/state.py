@@ -262,8 +262,13 @@ def materialise_draw(latent):
 
 
 def _same_tensor(a, b):
-    return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
-                      and a.dtype == b.dtype)
+    """One operand for the fused step: the same storage view AND the same autograd identity — `x` and
+    `x.detach()` (a stop-gradient into one callable) share memory but not gradients, and the fused backward
+    has one gradient slot per operand."""
+    if a is b:
+        return True
+    return (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype
+            and a.requires_grad == b.requires_grad and a.grad_fn is b.grad_fn)
 
 
 def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, observation):

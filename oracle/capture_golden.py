@@ -33,8 +33,8 @@ import aesmc as ref  # noqa: E402  (the reference)
 import aesmc.state  # noqa: E402,F401
 import aesmc.math  # noqa: E402,F401
 
-from aesmc_amd.testing import models as my_models  # noqa: E402
 from aesmc_amd.testing import replay  # noqa: E402
+from oracle import fixture_models  # noqa: E402  (frozen: see its docstring)
 from oracle import kernel_oracle  # noqa: E402
 
 
@@ -196,8 +196,7 @@ def case_lgssm1d(name, algorithm, emission_scale, dtype, B=2, K=16, T=8, seed=1)
 
 
 def case_lgssm_nd(name, algorithm, dtype, dim=3, B=4, K=256, T=6, seed=3, proposal_scale=0.7, light=False):
-    model = my_models.LgssmNd(dim, proposal_scale=proposal_scale, seed=seed, dtype=dtype,
-                              state=ref.state)
+    model = fixture_models.FixtureLgssmNd(dim, ref.state, proposal_scale=proposal_scale, seed=seed, dtype=dtype)
     observations = model.simulate(T, B, seed=seed + 100)
     parts = {"initial": model.initial, "transition": model.transition, "emission": model.emission,
              "proposal": model.proposal, "model": model}
@@ -322,7 +321,11 @@ def case_api_signatures():
     print("api_signatures.json: {} entries".format(len(table)))
 
 
-def main():
+def main(out_dir=None):
+    """Writes every fixture into `out_dir` (default: tests/golden/)."""
+    global GOLDEN
+    if out_dir is not None:
+        GOLDEN = out_dir
     os.makedirs(GOLDEN, exist_ok=True)
     case_api_signatures()
     f32, f64 = torch.float32, torch.float64
@@ -366,7 +369,9 @@ def main():
     case_resampler("resampler_k16384_f64", 2 * rng.randn(4, 16384), 31)
     case_resampler("resampler_k16384_f32", (2 * rng.randn(4, 16384)).astype(np.float32), 32)
     case_lgssm_nd("lgssm10d_k1024_smc_f32", "aesmc", f32, dim=10, B=2, K=1024, T=20, seed=11, light=True)
+    # round 3: a float32 run of the reference at the north-star particle count (d=10, K=4096)
+    case_lgssm_nd("lgssm10d_k4096_smc_f32", "aesmc", f32, dim=10, B=2, K=4096, T=10, seed=13, light=True)
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

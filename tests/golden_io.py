@@ -38,9 +38,11 @@ class Golden:
     def observations(self, device):
         return [torch.from_numpy(o).to(device) for o in self.series("obs")]
 
-    def build_parts(self, state, device, affine=False):
+    def build_parts(self, state, device, affine=False, frozen=False):
         """This package's counterpart model, loaded with the fixture's parameters (`affine`: the d-dimensional
-        LGSSM with its callables returning AffineNormal — the same model, stated for kernels K9 / K10 / K12)."""
+        LGSSM with its callables returning AffineNormal — the same model, stated for kernels K9 / K10 / K12;
+        `frozen`: the very callables the fixture was generated with, oracle/fixture_models.py — what the CPU
+        port must reproduce to the last place)."""
         meta, dtype = self.meta, self.dtype
         if meta["model"] == "lgssm1d":
             parts = {
@@ -53,6 +55,12 @@ class Golden:
             parts = {"initial": models.GaussianPrior(0.0, meta["prior_std"]), "transition": None,
                      "emission": models.GaussianLikelihood(1.0),
                      "proposal": models.GaussianInferenceNetwork(0.0, 0.0, 1.0)}
+        elif meta["model"] == "lgssm_nd" and frozen:
+            from oracle import fixture_models
+            model = fixture_models.FixtureLgssmNd(meta["dim"], state, proposal_scale=meta["proposal_scale"],
+                                                  seed=meta["seed"], dtype=dtype)
+            parts = {"initial": model.initial, "transition": model.transition,
+                     "emission": model.emission, "proposal": model.proposal, "model": model}
         elif meta["model"] == "lgssm_nd":
             model = models.LgssmNd(meta["dim"], proposal_scale=meta["proposal_scale"],
                                    seed=meta["seed"], dtype=dtype, state=state, affine=affine)
@@ -81,7 +89,7 @@ RESAMPLER_CASES = ["resampler_k1000_s1_f64", "resampler_k1000_s5_f64", "resample
                    "resampler_k1_f64", "resampler_degenerate_f64", "resampler_k16384_f64",
                    "resampler_k16384_f32"]
 # large fixtures that keep inputs, per-step log-weights and indices but not the latents
-LIGHT_INFER_CASES = ["lgssm10d_k1024_smc_f32"]
+LIGHT_INFER_CASES = ["lgssm10d_k1024_smc_f32", "lgssm10d_k4096_smc_f32"]
 TRAIN_CASES = ["train_iwae_gaussian", "train_aesmc_lgssm1d"]
 
 

@@ -547,6 +547,43 @@ def test_affine_callables_give_the_loss_and_gradients_of_matmul_callables(oracle
         assert float((grads_a[name] - grads_b[name]).abs().max()) <= grad_tol * scale, name
 
 
+@pytest.mark.parametrize("which", ["proposal", "emission"])
+def test_a_detached_source_keeps_a_step_off_the_fused_route(oracle_backend, which):
+    """`x` and `x.detach()` share storage but not gradients.  A model that stops the gradient into
+    its proposal (or emission) by building it on the detached latent must NOT be weighed as one fused
+    linear-Gaussian step (one gradient slot per operand): its gradients must equal the matmul statement's."""
+    from aesmc_amd.testing.models import LgssmNd
+
+    class Detached(LgssmNd):
+        def proposal(self, previous_latents=None, time=None, observations=None):
+            if time > 0 and which == "proposal":
+                previous_latents = [previous_latents[-1].detach()]
+            return super().proposal(previous_latents=previous_latents, time=time, observations=observations)
+
+        def emission(self, latents=None, time=None, previous_observations=None):
+            if which == "emission":
+                latents = [latents[-1].detach()]
+            return super().emission(latents=latents, time=time, previous_observations=previous_observations)
+
+    results = {}
+    for affine in (False, True):
+        model = Detached(3, dtype=torch.float64, affine=affine, defer_draw=False).tune_proposal()
+        observations = model.simulate(4, 3, seed=1)
+        torch.manual_seed(7)
+        np.random.seed(7)
+        loss = losses.get_loss(observations, 16, "aesmc", model.initial, model.transition, model.emission,
+                               model.proposal)
+        loss.backward()
+        results[affine] = (loss.detach(), {name: p.grad.clone() for name, p in model.named_parameters()
+                                           if p.grad is not None})
+    (loss_a, grads_a), (loss_b, grads_b) = results[False], results[True]
+    assert abs(float(loss_a - loss_b)) <= 1e-12 * max(1.0, abs(float(loss_a)))
+    assert sorted(grads_a) == sorted(grads_b)
+    for name in grads_a:
+        scale = max(float(grads_a[name].abs().max()), 1e-30)
+        assert float((grads_a[name] - grads_b[name]).abs().max()) <= 1e-9 * scale, name
+
+
 def test_affine_normal_outside_the_fused_route_materialises_its_location(oracle_backend):
     """A step whose three terms are not all AffineNormal in the right tensors (here: the emission reads
     a COPY of the latent) takes the ordinary route: `.loc` is evaluated and the numbers are the same.
