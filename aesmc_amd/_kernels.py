@@ -812,10 +812,14 @@ class HipKernels:
             raise ValueError("aesmc_amd: {}: `out` must be a dense, 16-byte aligned {} {} tensor on {}".format(
                 what, tuple(shape), like.dtype, like.device))
 
-    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x, checked=False):
+    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x, checked=False,
+                         ancestors=None):
         """K15: the proposal's draw and the step's log-weight in one launch.  Writes
         x = loc_q(x_prev) + eps * s_q into `out_x` (K9's bits) and returns K10's log-weight [B,K] of
-        (x_prev, x, y_rows) (K10's bits)."""
+        (x_prev, x, y_rows) (K10's bits).  `ancestors` (int64 [B,K]): `x_prev` is the UN-resampled latent and
+        its rows are fetched through the indices inside the launch — x_prev[b, ancestors[b,k]] is never
+        written; None comes back when the launch does not cover the shape (fewer than ~43 particles per
+        batch row): the caller gathers, then calls again without `ancestors`."""
         # `checked`: the caller has just run affine_logweight_covers on these operands (x_t in eps's place)
         if not checked and not self.affine_logweight_covers(x_prev, eps, y_rows, transition, emission, proposal, scales):
             raise ValueError("aesmc_amd: affine_propagate operands outside what kernel K15 covers")
@@ -827,19 +831,36 @@ class HipKernels:
         x_prev, eps = self._dense16(x_prev), self._dense16(eps)
         if out_x.data_ptr() == x_prev.data_ptr():
             raise ValueError("aesmc_amd: affine_propagate cannot write the draw over x_prev")
+        if ancestors is not None:
+            self._check_index(x_prev, ancestors)
+            if ancestors.shape != (B, K):
+                raise ValueError("aesmc_amd: affine_propagate ancestors must be [{}, {}]".format(B, K))
+            ancestors = ancestors.contiguous()
         if y_rows.stride(1) != 1:
             y_rows = y_rows.contiguous()
         out = torch.empty((B, K), dtype=eps.dtype, device=eps.device)
         maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
         with _on_device(eps.device):
-            args = (tag, _ptr(x_prev), _ptr(eps), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
+            tail = (_ptr(eps), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
                     ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
-                    _ptr(scales[2]), _ptr(out_x), _ptr(out), B, K, self._stream(eps))
-            _lib.check(self._lib.aesmc_affine_normal_propagate(*args), "aesmc_affine_normal_propagate")
+                    _ptr(scales[2]), _ptr(out_x), _ptr(out))
+            if ancestors is not None:
+                entry, name = self._lib.aesmc_affine_normal_propagate_resampled, "affine_normal_propagate_resampled"
+                args = (tag, _ptr(x_prev), _ptr(ancestors)) + tail + (_ptr(self.flags(eps.device)), B, K,
+                                                                      self._stream(eps))
+                status = entry(*args)
+                if status == 2:
+                    return None
+            else:
+                entry, name = self._lib.aesmc_affine_normal_propagate, "affine_normal_propagate"
+                args = (tag, _ptr(x_prev)) + tail + (B, K, self._stream(eps))
+                status = entry(*args)
+            _lib.check(status, "aesmc_" + name)
             if self.timer is not None:
                 nbytes = eps.element_size() * (B * K * (3 * dx + 1) + y_rows.numel())
-                self.timer.note("affine_normal_propagate", (self._lib.aesmc_affine_normal_propagate, args), nbytes,
-                                (x_prev, eps, y_rows, out, out_x, maps, scales))
+                if ancestors is not None:
+                    nbytes += 8 * B * K
+                self.timer.note(name, (entry, args), nbytes, (x_prev, ancestors, eps, y_rows, out, out_x, maps, scales))
         return out
 
     def affine_logweight_covers(self, x_prev, x, y_rows, transition, emission, proposal, scales):

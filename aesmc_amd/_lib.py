@@ -22,6 +22,7 @@ FLAG_UNSORTED_INDEX = 16
 F32, F64 = 0, 1
 
 _vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+_u64 = ctypes.c_uint64
 
 
 class View3(ctypes.Structure):
@@ -85,6 +86,9 @@ SIGNATURES = {
                                           [ctypes.POINTER(AffineLogweightGrads), _vp, _sz, _i64, _i64, _vp]),
     "aesmc_affine_normal_logweight": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp,
                                              _i64, _i64, _vp]),
+    "aesmc_affine_normal_propagate_resampled": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp,
+                                                       _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "aesmc_philox_normal_fill": (_i32, [_vp, _i64, _u64, _u64, _i64, _i32, _vp]),
 }
 
 _lib = None

@@ -8,6 +8,7 @@ Gradient contract of the reference that these preserve:
 import torch
 
 from . import _kernels
+from ._lazy import LazyResampled
 
 
 class _LogWeightLSE(torch.autograd.Function):
@@ -354,6 +355,8 @@ class _ParticleAffine(torch.autograd.Function):
 
 def particle_affine(x, weight, offset=None):
     """[B,K,dout] location  offset + x @ weight.T  (kernel K8), differentiable in x, weight and offset."""
+    if type(x) is LazyResampled:
+        x = x.materialise()
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, offset)):
         return _ParticleAffine.apply(x, weight, offset)
     return _kernels.get().particle_affine(x.detach(), weight.detach(), None if offset is None else offset.detach())
@@ -405,17 +408,51 @@ def _placeholder(source, weight, poison):
     return torch.empty(shape, dtype=source.dtype, device=source.device)
 
 
+class _DeferredAffineRsampleResampled(torch.autograd.Function):
+    """_DeferredAffineRsample whose source is x_{t-1}[ancestors] not gathered yet: the node keeps (x_{t-1},
+    ancestors) and gathers only if its backward ever runs (the fused step differentiates the draw itself;
+    this node serves any OTHER differentiable use of the draw)."""
+
+    @staticmethod
+    def forward(ctx, source, ancestors, weight, offset, scale, eps, poison):
+        ctx.save_for_backward(source, ancestors, weight, eps if scale.requires_grad else None)
+        ctx.offset_shape = None if offset is None else tuple(offset.shape)
+        ctx.scale_shape = tuple(scale.shape)
+        return _placeholder(source, weight, poison)
+
+    @staticmethod
+    def backward(ctx, grad):
+        source, ancestors, weight, eps = ctx.saved_tensors
+        k = _kernels.get()
+        need_src, _, need_w, need_off, need_scale = ctx.needs_input_grad[:5]
+        need_off = need_off and ctx.offset_shape is not None
+        gsrc, gw, rows = k.particle_affine_backward(grad.contiguous(), k.gather(source, ancestors), weight, need_src,
+                                                    need_w, need_off)
+        if gsrc is not None:
+            gsrc = k.gather_backward(gsrc, ancestors, sorted_index=bool(getattr(ancestors, "_aesmc_sorted", False)))
+        goff = None if not need_off else (rows if len(ctx.offset_shape) == 2 else rows.sum(dim=0))
+        gscale = (grad * eps).sum().reshape(ctx.scale_shape) if need_scale else None
+        return gsrc, None, gw, goff, gscale, None, None
+
+
 def affine_rsample_deferred(source, weight, offset, scale, eps, poison=True):
     """A [B,K,dout] tensor standing for the reparameterised draw whose values come later (K15 or K9).
     `poison`: filled with NaN until then (one fill launch) instead of left uninitialised."""
     tensors = (source, weight, offset, scale)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        pending = source.pending if type(source) is LazyResampled else None
+        if pending is not None:
+            return _DeferredAffineRsampleResampled.apply(pending[0], pending[1], weight, offset, scale, eps, poison)
+        if type(source) is LazyResampled:
+            source = source.materialise()
         return _DeferredAffineRsample.apply(source, weight, offset, scale, eps, poison)
     return _placeholder(source, weight, poison)
 
 
 def affine_rsample(source, weight, offset, scale, eps):
     """Reparameterised draw from Normal(offset + source @ weight.T, scale) given the noise (kernel K9)."""
+    if type(source) is LazyResampled:
+        source = source.materialise()
     tensors = (source, weight, offset, scale)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         return _AffineRsample.apply(source, weight, offset, scale, eps)
@@ -425,10 +462,22 @@ def affine_rsample(source, weight, offset, scale, eps):
 
 class AffineOperands(tuple):
     """The twelve operands of one K10 launch, in the order
-    (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q); offsets may be None."""
+    (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q); offsets may be None.
+    `pending_gather` = (x_{t-1}, ancestors) when x_prev is a LazyResampled nothing has gathered yet: the
+    launch fetches its rows through the indices (aesmc_affine_normal_propagate_resampled)."""
+    pending_gather = None
+    is_draw = False
 
     def requires_grad(self):
         return any(t is not None and t.requires_grad for t in self)
+
+    def gathered(self):
+        """The same operands with x_prev as a real tensor (gathered now if it had not been)."""
+        if self.pending_gather is None and type(self[0]) is not LazyResampled:
+            return self
+        out = AffineOperands((self[0].materialise(),) + tuple(self[1:]))
+        out.is_draw = self.is_draw
+        return out
 
 
 def _affine_logweight_grads(operands, need, grad_lw=None, lw=None, lse=None, grad_lse=None):
@@ -516,28 +565,36 @@ class _AffineStep(torch.autograd.Function):
     accumulations autograd would put between them never run."""
 
     @staticmethod
-    def forward(ctx, lw, x_value, pending, *operands):
+    def forward(ctx, lw, x_value, pending, ancestors, *operands):
+        # `ancestors` (or None): operands[0] is the UN-resampled x_{t-1}; the step read its rows through them
         ctx.set_materialize_grads(False)      # an output nobody differentiated arrives as None, not as zeros
         ctx.lse_box = pending.box
-        ctx.save_for_backward(lw, x_value, *[t for t in operands if t is not None])
+        ctx.save_for_backward(lw, x_value, ancestors, *[t for t in operands if t is not None])
         ctx.present = [t is not None for t in operands]
         return lw.new_empty((lw.size(0),)), x_value.view_as(x_value)     # the carrier's values are never read
 
     @staticmethod
     def backward(ctx, grad_lse, grad_x):
-        lw, x_value = ctx.saved_tensors[:2]
-        saved = iter(ctx.saved_tensors[2:])
+        lw, x_value, ancestors = ctx.saved_tensors[:3]
+        saved = iter(ctx.saved_tensors[3:])
         operands = [next(saved) if present else None for present in ctx.present]
         x_prev, _, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = operands
-        need = list(ctx.needs_input_grad[3:])
+        need = list(ctx.needs_input_grad[4:])
         need[1] = False
         lse = ctx.lse_box[0]
         if grad_lse is not None and lse is None:
             raise RuntimeError("aesmc_amd internal error: a step's log-sum-exp received a gradient but was never bound")
-        grads = _kernels.get().affine_step_backward(
+        k = _kernels.get()
+        if ancestors is not None:
+            x_prev = k.gather(x_prev, ancestors)      # the resampled latent exists for the length of this backward step
+        grads = k.affine_step_backward(
             x_prev, x_value, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q), need, lw, lse,
             grad_lse=None if grad_lse is None else grad_lse.contiguous(), grad_x=grad_x)
-        return (None, None, None) + tuple(grads)
+        if ancestors is not None and grads[0] is not None:
+            # torch.gather's backward (state.py:179): children's gradients summed into their ancestors; K2's
+            # indices are non-decreasing along k, so this is the atomic-free segmented sum
+            grads[0] = k.gather_backward(grads[0], ancestors, sorted_index=True)
+        return (None, None, None, None) + tuple(grads)
 
 
 def affine_step(lw, operands):
@@ -547,7 +604,12 @@ def affine_step(lw, operands):
     pending = PendingStep()
     inputs = list(operands)
     inputs[1] = None
-    pending.carrier, x_t = _AffineStep.apply(lw, operands[1].detach(), pending, *inputs)
+    ancestors = None
+    if operands.pending_gather is not None:       # the launch fetched x_{t-1}'s rows through the ancestors
+        inputs[0], ancestors = operands.pending_gather
+    elif type(inputs[0]) is LazyResampled:
+        inputs[0] = inputs[0].materialise()
+    pending.carrier, x_t = _AffineStep.apply(lw, operands[1].detach(), pending, ancestors, *inputs)
     return pending, x_t
 
 
@@ -570,11 +632,22 @@ def affine_log_weight_deferred(operands):
 
 def affine_propagate(operands, eps):
     """K15, no autograd node: fills operands[1] (the deferred draw x_t) from the noise `eps` and returns the
-    step's log-weights [B,K] — K9 and K10 in one launch, the same bits as the two."""
-    x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = [
-        None if t is None else t.detach() for t in operands]
-    return _kernels.get().affine_propagate(x_prev, eps, y_rows, (A, off_p), (C, off_g), (Q, off_q),
-                                           (s_p, s_g, s_q), out_x=x, checked=True)    # state._affine_step_operands did
+    step's log-weights [B,K] — K9 and K10 in one launch, the same bits as the two.  With
+    `operands.pending_gather` the launch also performs the resampling gather of x_{t-1} on the way in; if it
+    declines the shape, the gather happens first (and `operands.pending_gather` is cleared)."""
+    x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = [None if t is None else t.detach() for t in operands[1:]]
+    k = _kernels.get()
+    if operands.pending_gather is not None:
+        source, ancestors = operands.pending_gather
+        lw = k.affine_propagate(source.detach(), eps, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q),
+                                out_x=x, checked=True, ancestors=ancestors)
+        if lw is not None:
+            return lw
+        operands.pending_gather = None
+    x_prev = operands[0]
+    x_prev = (x_prev.materialise() if type(x_prev) is LazyResampled else x_prev).detach()
+    return k.affine_propagate(x_prev, eps, y_rows, (A, off_p), (C, off_g), (Q, off_q),
+                              (s_p, s_g, s_q), out_x=x, checked=True)    # state._affine_step_operands did
 
 
 # ---- K13: a two-layer tanh net over the particles --------------------------------------------------------
@@ -613,6 +686,8 @@ class _ParticleMlp(torch.autograd.Function):
 def particle_mlp(x, weight1, offset1, weight2, bias2=None):
     """bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T over particles x [B,K,din]; kernel K13 when it
     covers the shape, the PyTorch expression otherwise (same numbers to rounding)."""
+    if type(x) is LazyResampled:
+        x = x.materialise()
     k = _kernels.get()
     if not k.particle_mlp_covers(x, weight1, offset1, weight2, bias2):
         return _mlp_reference(x, weight1, offset1, weight2, bias2)

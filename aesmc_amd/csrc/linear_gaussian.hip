@@ -164,11 +164,17 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_rsample_kernel(const T *__
 //   x_t = loc_q + eps * scale_q        (K9's arithmetic on K9's chain: the same bits)
 // from the proposal location it computes anyway, writes it to `out_x` through the tile and weighs it —
 // one pass over x_{t-1} and the noise instead of K9's and K10's two passes over three arrays.
-template <typename T, int DP, int PPL, bool TAB, bool PREFETCH, bool DRAW = false>
+// GATHER (with DRAW, TAB and PREFETCH): `xprev` is the UN-resampled x_{t-1} and the tile's rows are fetched
+// through the ancestor indices `gat.idx` — the resampled latent (aesmc/inference.py:102-111) is never written:
+// the indices of tile t+2 are in flight while the rows of tile t+1 are, while tile t computes.
+template <typename T, int DP, int PPL, bool TAB, bool PREFETCH, bool DRAW = false, int GATHER = 0>
 __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
     const T *__restrict__ xprev, const T *__restrict__ x, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg,
     LgMap mq, const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr,
-    T *__restrict__ out_lw, int64_t N, uint32_t K, T *__restrict__ out_x) {
+    T *__restrict__ out_lw, int64_t N, uint32_t K, T *__restrict__ out_x, LgGather gat) {
+  // GATHER: 0, or the bytes per piece of a gathered row (4, 8, 16)
+  static_assert(!GATHER || (TAB && PREFETCH), "the gathering variant is the persistent one");
+  constexpr int PB = GATHER ? GATHER : 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
   constexpr int NV = (PPL * DP + Vec16<T>::N - 1) / Vec16<T>::N;
@@ -191,8 +197,24 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
   const T two_var_g = T(2) * (s_g * s_g), const_g = T(dy) * (Num<T>::log(s_g) + half_log_2pi);
   const T two_var_q = T(2) * (s_q * s_q), const_q = T(dx) * (Num<T>::log(s_q) + half_log_2pi);
   const int64_t tiles = (N + TP - 1) / TP;
-  V rp[PREFETCH ? NV : 1], rx[PREFETCH ? NV : 1];
-  if constexpr (PREFETCH) {
+  V rp[(PREFETCH && !GATHER) ? NV : 1], rx[PREFETCH ? NV : 1];
+  constexpr int NW = NV * 4;
+  uint32_t rg[GATHER ? NW : 1];
+  int64_t ranc[GATHER ? PPL : 1];
+  uint32_t *anc = reinterpret_cast<uint32_t *>(tx + (TP * lx.rs + 16));      // [TP], GATHER only
+  const char *xprev_bytes = reinterpret_cast<const char *>(xprev);
+  if constexpr (GATHER) {
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lg_anc_prefetch<PPL, true>(gat, n0, np, ranc);
+    lg_anc_commit<PPL, true>(gat, n0, np, K, ranc, anc);
+    lg_lds_barrier();
+    lg_gather_prefetch<NW, PB, true>(xprev_bytes, gat, anc, np, rg);
+    lg_prefetch<T, NV>(x + n0 * dx, np * dx, 0, rx);
+    const int64_t m0 = n0 + (int64_t)gridDim.x * TP;
+    if (m0 < N) lg_anc_prefetch<PPL, true>(gat, m0, (uint32_t)min((int64_t)TP, N - m0), ranc);
+    lg_lds_barrier();      // every lane has read its ancestors before the loop's first commit replaces them
+  } else if constexpr (PREFETCH) {
     const int64_t n0 = (int64_t)blockIdx.x * TP;
     const uint32_t ne = (uint32_t)min((int64_t)TP, N - n0) * dx;
     lg_prefetch<T, NV>(xprev + n0 * dx, ne, 0, rp);
@@ -201,7 +223,12 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    if constexpr (PREFETCH) {
+    if constexpr (GATHER) {
+      lg_gather_commit<T, NW, PB, true>(gat, np, rg, tprev, lx);
+      lg_commit<T, NV>(x + n0 * dx, np * dx, rx, tx, lx);
+      const int64_t m0 = (tile + gridDim.x) * TP;
+      if (m0 < N) lg_anc_commit<PPL, true>(gat, m0, (uint32_t)min((int64_t)TP, N - m0), K, ranc, anc);
+    } else if constexpr (PREFETCH) {
       lg_commit<T, NV>(xprev + n0 * dx, np * dx, rp, tprev, lx);
       lg_commit<T, NV>(x + n0 * dx, np * dx, rx, tx, lx);
     } else {
@@ -223,7 +250,17 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
       lg_row_values<T, DP, PPL, 4, 3>(vec, false, tab, b0, brow, yv);
     }
     lg_lds_barrier();
-    if constexpr (PREFETCH) {
+    if constexpr (GATHER) {
+      const int64_t next = tile + gridDim.x;
+      if (next < tiles) {
+        const int64_t m0 = next * TP;
+        const uint32_t mp_ = (uint32_t)min((int64_t)TP, N - m0);
+        lg_gather_prefetch<NW, PB, true>(xprev_bytes, gat, anc, mp_, rg);
+        lg_prefetch<T, NV>(x + m0 * dx, mp_ * dx, 0, rx);
+        const int64_t nn0 = (next + gridDim.x) * TP;
+        if (nn0 < N) lg_anc_prefetch<PPL, true>(gat, nn0, (uint32_t)min((int64_t)TP, N - nn0), ranc);
+      }
+    } else if constexpr (PREFETCH) {
       const int64_t next = tile + gridDim.x;
       if (next < tiles) {
         const int64_t m0 = next * TP;
@@ -456,6 +493,12 @@ template <typename T, int DP, int PPL>
 static constexpr auto affine_propagate_tab_prefetch = &affine_logweight_kernel<T, DP, PPL, true, true, true>;
 template <typename T, int DP, int PPL>
 static constexpr auto affine_propagate_rows = &affine_logweight_kernel<T, DP, PPL, false, false, true>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_propagate_gather4 = &affine_logweight_kernel<T, DP, PPL, true, true, true, 4>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_propagate_gather8 = &affine_logweight_kernel<T, DP, PPL, true, true, true, 8>;
+template <typename T, int DP, int PPL>
+static constexpr auto affine_propagate_gather16 = &affine_logweight_kernel<T, DP, PPL, true, true, true, 16>;
 
 template <typename T>
 static int launch_affine_rsample(const void *src, const aesmc_affine_map *m, const void *eps, const void *scale,
@@ -497,8 +540,10 @@ template <typename T>
 static int launch_affine_logweight(const void *xprev, const void *x, const void *y, int64_t y_sb,
                                    const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                    const void *sp, const void *sg, const void *sq, void *out, int64_t B, int64_t K,
-                                   hipStream_t stream, void *out_x = nullptr) {
+                                   hipStream_t stream, void *out_x = nullptr, const int64_t *anc_idx = nullptr,
+                                   int32_t *flags = nullptr) {
   // out_x != nullptr: `x` is the proposal's noise and the draw is formed here (K15)
+  // anc_idx != nullptr (with out_x): `xprev` is the un-resampled latent, its rows fetched through the indices
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
@@ -519,9 +564,12 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   {
     const size_t tp = (size_t)kLgBlock * ppl;
     lds = sizeof(T) * (3 * (size_t)dp * dp + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems<T>(tp, dx));
+    if (anc_idx != nullptr) lds += tp * sizeof(uint32_t);
   }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
+  const LgGather gat = lg_gather(anc_idx, flags, (size_t)dx * sizeof(T));
+  if (anc_idx != nullptr && (!tab || N > 0x7fffffffLL || out_x == nullptr)) return AESMC_ERR_UNSUPPORTED;
   // persistent workgroups with the next tile prefetched (B=1024 K=4096 d=10: 106 us against 145 us with one
   // tile per workgroup); AESMC_LG_PREFETCH=0 selects the latter: a measurement knob
   static const bool prefetch = [] { const char *v = getenv("AESMC_LG_PREFETCH"); return v == nullptr || v[0] != '0'; }();
@@ -529,8 +577,13 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
 #define LG_LOGWEIGHT_ARGS                                                                                          \
   static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), \
       lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),              \
-      static_cast<T *>(out), N, (uint32_t)K, static_cast<T *>(out_x)
-  if (out_x != nullptr) {
+      static_cast<T *>(out), N, (uint32_t)K, static_cast<T *>(out_x), gat
+  if (anc_idx != nullptr) {
+    const dim3 pgrid(lg_persistent_grid(tiles, lds));
+    if (gat.pb == 16) LG_DISPATCH(affine_propagate_gather16, T, dp, ppl, pgrid, lds, stream, LG_LOGWEIGHT_ARGS);
+    else if (gat.pb == 8) LG_DISPATCH(affine_propagate_gather8, T, dp, ppl, pgrid, lds, stream, LG_LOGWEIGHT_ARGS);
+    else LG_DISPATCH(affine_propagate_gather4, T, dp, ppl, pgrid, lds, stream, LG_LOGWEIGHT_ARGS);
+  } else if (out_x != nullptr) {
     if (tab && prefetch) LG_DISPATCH(affine_propagate_tab_prefetch, T, dp, ppl, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
     else if (tab) LG_DISPATCH(affine_propagate_tab, T, dp, ppl, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
     else LG_DISPATCH(affine_propagate_rows, T, dp, 1, dim3(grid), lds, stream, LG_LOGWEIGHT_ARGS);
@@ -656,6 +709,31 @@ extern "C" int aesmc_affine_normal_propagate(int dtype, const void *x_prev, cons
                                               scale_g, scale_q, out_lw, B, K, s, out_x)
              : launch_affine_logweight<double>(x_prev, eps, y, y_stride_b, transition, emission, proposal, scale_p,
                                                scale_g, scale_q, out_lw, B, K, s, out_x);
+}
+
+extern "C" int aesmc_affine_normal_propagate_resampled(
+    int dtype, const void *x_src, const int64_t *ancestors, const void *eps, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, int32_t *flags,
+    int64_t B, int64_t K, void *stream) {
+  if (x_src == nullptr || ancestors == nullptr || eps == nullptr || y == nullptr || transition == nullptr ||
+      emission == nullptr || proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr ||
+      out_lw == nullptr || out_x == nullptr || B < 0 || K < 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!aligned16(x_src) || !aligned16(eps) || !aligned16(out_x) || out_x == x_src || (((uintptr_t)ancestors) & 7u) != 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  const int64_t dx = transition->dout;
+  if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
+    return AESMC_ERR_UNSUPPORTED;
+  if (B == 0 || K == 0) return AESMC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AESMC_F32
+             ? launch_affine_logweight<float>(x_src, eps, y, y_stride_b, transition, emission, proposal, scale_p,
+                                              scale_g, scale_q, out_lw, B, K, s, out_x, ancestors, flags)
+             : launch_affine_logweight<double>(x_src, eps, y, y_stride_b, transition, emission, proposal, scale_p,
+                                               scale_g, scale_q, out_lw, B, K, s, out_x, ancestors, flags);
 }
 
 extern "C" int aesmc_affine_normal_logweight(int dtype, const void *x_prev, const void *x, const void *y,

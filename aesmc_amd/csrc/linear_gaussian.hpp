@@ -294,6 +294,107 @@ __device__ __forceinline__ void lg_commit(const T *__restrict__ src, uint32_t ne
   for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[e] = src[e];   // last tile only
 }
 
+// ---- rows fetched through ancestor indices -------------------------------------------------------------
+// The resampled latent  x_{t-1}[b, idx[b,k], :]  (aesmc/inference.py:102-111, state.py:179) need not exist in
+// HBM for a kernel that stages x_{t-1} through LDS anyway: the tile's rows are fetched from where their
+// ancestors lie.  `anc[p]` (LDS, one uint32 per particle of the tile) holds the flat source particle
+// b K + idx[b,k]; a row is moved in pieces of `pb` bytes (16 when rows are whole 16-byte vectors, else 8,
+// else 4: the widest unit that never straddles a row), piece v = tid + 256 s of the tile's np * ppr.
+// Registers: NW 32-bit words per lane (the same budget as the flat 16-byte prefetch of a tile).
+struct LgGather {
+  const int64_t *idx;   // [B, K] ancestor indices; nullptr: no gather
+  int32_t *flags;       // status word (out-of-range indices)
+  uint32_t ppr;         // pieces per row
+  uint32_t pb;          // bytes per piece: 4, 8 or 16
+  uint32_t row_bytes;
+};
+
+// the flat source particle of each of the lane's particles of the tile at n0: raw indices -> registers
+template <int PPL, bool LG_OPAQUE = false>
+__device__ __forceinline__ void lg_anc_prefetch(const LgGather &g, int64_t n0, uint32_t np, int64_t (&raw)[PPL]) {
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) {
+    const uint32_t q = lg_tid() + r * kLgBlock;
+    raw[r] = q < np ? g.idx[n0 + q] : 0;
+  }
+}
+template <int PPL, bool LG_OPAQUE = false>
+__device__ __forceinline__ void lg_anc_commit(const LgGather &g, int64_t n0, uint32_t np, uint32_t K,
+                                              const int64_t (&raw)[PPL], uint32_t *__restrict__ anc) {
+  const uint32_t b0 = (uint32_t)(n0 / K);
+  const uint32_t k0 = (uint32_t)(n0 - (int64_t)b0 * K);
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) {
+    const uint32_t q = lg_tid() + r * kLgBlock;
+    if (q < np) {
+      int64_t a = raw[r];
+      if (a < 0 || a >= (int64_t)K) {     // K2 writes K for a degenerate row (flagged there); never fault on it
+        raise_flag(g.flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
+        a = a < 0 ? 0 : (int64_t)K - 1;
+      }
+      anc[q] = (b0 + (k0 + q) / K) * K + (uint32_t)a;
+    }
+  }
+}
+
+template <int PB> struct LgPiece;
+template <> struct LgPiece<4> { using type = uint32_t; };
+template <> struct LgPiece<8> { using type = uint2; };
+template <> struct LgPiece<16> { using type = uint4; };
+
+// PB: bytes per piece (compile time: one kernel per unit, no three-way code inside the tile loop)
+template <int NW, int PB, bool LG_OPAQUE = false>
+__device__ __forceinline__ void lg_gather_prefetch(const char *__restrict__ src, const LgGather &g,
+                                                   const uint32_t *__restrict__ anc, uint32_t np,
+                                                   uint32_t (&regs)[NW]) {
+  using P = typename LgPiece<PB>::type;
+  constexpr int W = PB / 4;
+  const uint32_t npieces = np * g.ppr;
+  const uint32_t step_p = kLgBlock / g.ppr, step_q = kLgBlock - step_p * g.ppr;
+  uint32_t p = lg_tid() / g.ppr, q = lg_tid() - p * g.ppr, v = lg_tid();
+#pragma unroll
+  for (int s = 0; s < NW / W; ++s) {
+    if (v < npieces) {
+      const P x = *reinterpret_cast<const P *>(src + (uint64_t)anc[p] * g.row_bytes + q * (uint32_t)PB);
+      __builtin_memcpy(&regs[W * s], &x, PB);
+    }
+    v += kLgBlock; p += step_p; q += step_q;
+    if (q >= g.ppr) { q -= g.ppr; ++p; }
+  }
+}
+
+// the pieces into the tile: row p starts at element p * rs (16-byte aligned whenever PB == 16)
+template <typename T, int NW, int PB, bool LG_OPAQUE = false>
+__device__ __forceinline__ void lg_gather_commit(const LgGather &g, uint32_t np, const uint32_t (&regs)[NW],
+                                                 T *__restrict__ tile, const LgLayout &l) {
+  using P = typename LgPiece<PB>::type;
+  constexpr int W = PB / 4;
+  char *base = reinterpret_cast<char *>(tile);
+  const uint32_t npieces = np * g.ppr, row_pitch = l.rs * (uint32_t)sizeof(T);
+  const uint32_t step_p = kLgBlock / g.ppr, step_q = kLgBlock - step_p * g.ppr;
+  uint32_t p = lg_tid() / g.ppr, q = lg_tid() - p * g.ppr, v = lg_tid();
+#pragma unroll
+  for (int s = 0; s < NW / W; ++s) {
+    if (v < npieces) {
+      P x;
+      __builtin_memcpy(&x, &regs[W * s], PB);
+      *reinterpret_cast<P *>(base + p * row_pitch + q * (uint32_t)PB) = x;
+    }
+    v += kLgBlock; p += step_p; q += step_q;
+    if (q >= g.ppr) { q -= g.ppr; ++p; }
+  }
+}
+
+static inline LgGather lg_gather(const int64_t *idx, int32_t *flags, size_t row_bytes) {
+  LgGather g;
+  g.idx = idx;
+  g.flags = flags;
+  g.pb = row_bytes % 16 == 0 ? 16u : row_bytes % 8 == 0 ? 8u : 4u;
+  g.ppr = (uint32_t)(row_bytes / g.pb);
+  g.row_bytes = (uint32_t)row_bytes;
+  return g;
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 static inline bool lg_map_ok(const aesmc_affine_map *m) {
   return m != nullptr && m->weight != nullptr && m->dout >= 1 && m->din >= 1 && m->dout <= kLgMaxDim &&
@@ -340,6 +441,15 @@ constexpr size_t kLgLdsLimit = 144 * 1024;
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds));                     \
     hipLaunchKernelGGL((KERNEL<T, DP_, PPL_>), grid, dim3(kLgBlock), lds, stream, __VA_ARGS__);              \
   } while (0)
+#ifdef AESMC_LG_FAST_BUILD   /* experiments only: one extent, so a translation unit compiles in seconds */
+#define LG_DISPATCH(KERNEL, T, dp, ppl, grid, lds, stream, ...)                                              \
+  do {                                                                                                       \
+    if constexpr (sizeof(T) == 4) {                                                                          \
+      if (ppl == 2) LG_LAUNCH(KERNEL, T, 10, 2, grid, lds, stream, __VA_ARGS__);                             \
+      else LG_LAUNCH(KERNEL, T, 10, 1, grid, lds, stream, __VA_ARGS__);                                      \
+    }                                                                                                        \
+  } while (0)
+#else
 #define LG_DISPATCH(KERNEL, T, dp, ppl, grid, lds, stream, ...)                                              \
   do {                                                                                                       \
     if (ppl == 2) {                                                                                          \
@@ -360,6 +470,7 @@ constexpr size_t kLgLdsLimit = 144 * 1024;
       }                                                                                                      \
     }                                                                                                        \
   } while (0)
+#endif
 
 // With 512-particle tiles a launch of fewer than ~1M particles leaves each CU with at most two or three
 // workgroups of one tile each: all latency.  256-particle tiles double the workgroups.

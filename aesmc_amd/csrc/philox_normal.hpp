@@ -1,0 +1,94 @@
+// Standard-normal noise drawn inside a kernel from the stream PyTorch's own generator would have produced.
+//
+// The reference draws a step's particles with `Normal.rsample` (aesmc/state.py:98), i.e. one
+// `torch.empty(shape).normal_()` per timestep.  On a HIP device that call is ATen's
+// `distribution_elementwise_grid_stride_kernel` over Philox4x32-10 (rocRAND's `hiprand_normal4`):
+//
+//   G      = 256 * min(#CU * (maxThreadsPerCU / 256), ceil(numel / 256))      threads of the launch
+//   thread t, trip c:  (r0, r1, r2, r3) = Philox4x32-10(counter = (offset / 4 + c, 0, t, 0), key = seed)
+//                      (n0, n1) = box_muller(r0, r1),  (n2, n3) = box_muller(r2, r3)
+//   element e = t + G * (4 c + i)  receives  n_i                                i = 0 .. 3
+//   the generator's offset then advances by 4 * ceil(numel / (4 G))
+//
+// so a value is a pure function of (seed, offset, G, e): any kernel that knows those four can form the
+// noise where it is consumed instead of reading it back from HBM — the same bits, and the generator is
+// advanced by what `normal_` would have consumed (aesmc_amd/_philox.py), so everything drawn afterwards
+// is unchanged too.  `tests/test_gpu_philox.py` holds this against `torch.empty(n).normal_()` bit for bit.
+//
+// Box-Muller as rocRAND writes it (rocrand_normal.h `box_muller`):
+//   u = 2^-32 + r0 * 2^-32,  v = 2^-32 * 2pi + r1 * (2^-32 * 2pi),  s = sqrtf(-2 logf(u)),
+//   (sin v * s, cos v * s) with the hardware sine / cosine (`__sincosf`).
+// The library this file is part of is compiled with -ffp-contract=off; rocRAND inside PyTorch is compiled
+// with hipcc's default (contraction on), which fuses the two affine maps into one fma each: written out here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aesmc {
+
+struct PhiloxStream {
+  uint32_t key0, key1;      // seed
+  uint32_t base_lo, base_hi;  // offset / 4: the counter of a thread's first trip
+  uint32_t threads;         // G
+};
+
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+// the four raw words of (thread t, trip c)
+__device__ __forceinline__ uint4 philox_words(const PhiloxStream &s, uint32_t t, uint32_t c) {
+  const uint32_t lo = s.base_lo + c;
+  const uint32_t hi = s.base_hi + (lo < s.base_lo ? 1u : 0u);
+  return philox4x32_10(lo, hi, t, 0u, s.key0, s.key1);
+}
+
+// FUSED = false (separate multiply and add) exists for the probe that established which one PyTorch's build
+// of rocRAND uses (aesmc_philox_normal_fill's `variant`).
+template <bool FUSED = true> __device__ __forceinline__ float2 box_muller_f32(uint32_t x, uint32_t y) {
+  float u, v;
+  if constexpr (FUSED) {
+    u = __builtin_fmaf((float)x, 2.3283064e-10f, 2.3283064e-10f);
+    v = __builtin_fmaf((float)y, 1.46291807e-09f, 1.46291807e-09f);
+  } else {
+    u = 2.3283064e-10f + ((float)x * 2.3283064e-10f);
+    v = 1.46291807e-09f + ((float)y * 1.46291807e-09f);
+  }
+  const float s = __builtin_sqrtf(-2.0f * __builtin_logf(u));
+  float2 out;
+  // `normal_`'s own transform, rand * std + mean with std = 1 and mean = 0, follows: it turns -0.0 into +0.0
+  out.x = (__ocml_native_sin_f32(v) * s) * 1.0f + 0.0f;
+  out.y = (__ocml_native_cos_f32(v) * s) * 1.0f + 0.0f;
+  return out;
+}
+
+// (n0, n1, n2, n3) of (thread t, trip c): what ATen's kernel hands its elements t + G (4c + i)
+template <bool FUSED = true>
+__device__ __forceinline__ float4 philox_normal4(const PhiloxStream &s, uint32_t t, uint32_t c) {
+  const uint4 w = philox_words(s, t, c);
+  const float2 a = box_muller_f32<FUSED>(w.x, w.y), b = box_muller_f32<FUSED>(w.z, w.w);
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+
+// One element on its own (edges of a tile): element e of the tensor.
+__device__ __forceinline__ float philox_normal_element(const PhiloxStream &s, uint64_t e) {
+  const uint64_t m = e / s.threads;
+  const uint32_t t = (uint32_t)(e - m * s.threads);
+  const float4 n = philox_normal4(s, t, (uint32_t)(m >> 2));
+  const uint32_t i = (uint32_t)m & 3u;
+  return i == 0 ? n.x : i == 1 ? n.y : i == 2 ? n.z : n.w;
+}
+
+}  // namespace aesmc

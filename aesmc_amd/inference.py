@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _kernels
+from . import _lazy
 from . import _ops
 from . import state
 
@@ -34,15 +35,36 @@ def set_history_mode(mode):
     _HISTORY_MODE = mode
 
 
+import os as _os
+_LAZY_GATHER = _os.environ.get("AESMC_LAZY_GATHER", "1") != "0"      # measurement knob; see set_lazy_gather
+
+
+def set_lazy_gather(enabled):
+    """On (default): the newest latent is handed to the callables un-gathered (`_lazy.LazyResampled`) and a
+    linear-Gaussian step fetches its rows through the ancestor indices inside the launch that weighs it.
+    Off: the resampling launch always re-indexes the newest latent (rounds 1-2)."""
+    global _LAZY_GATHER
+    _LAZY_GATHER = bool(enabled)
+
+
 class ResampledHistory(collections.abc.Sequence):
     """Read-only view of [resample(x, index) for x in latents] whose entries are gathered (K3)
     when first read.  Markov models read only [-1], so a step costs one gather, not `time`."""
 
-    def __init__(self, latents, index, newest=None):
+    def __init__(self, latents, index, newest=None, lazy_newest=False):
         self._latents = list(latents)
         self._index = index
-        # `newest`: the last entry already re-indexed (the fused step copies it along the way)
+        # `newest`: the last entry already re-indexed (the fused step copies it along the way);
+        # `lazy_newest`: hand the last entry out as a LazyResampled — gathered only if something reads its
+        # values (a linear-Gaussian step fetches the rows through the ancestors inside its own launch)
         self._cache = {} if newest is None else {len(self._latents) - 1: newest}
+        if newest is None and lazy_newest and self._latents:
+            self._cache[len(self._latents) - 1] = _lazy.LazyResampled(self._latents[-1], index)
+
+    def newest_was_read(self):
+        """Did anything need the VALUES of the lazily resampled newest entry?"""
+        entry = self._cache.get(len(self._latents) - 1)
+        return type(entry) is _lazy.LazyResampled and entry.pending is None
 
     def __len__(self):
         return len(self._latents)
@@ -273,6 +295,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
     running_lse = None
     feed = None
     device = None
+    lazy_gather = _LAZY_GATHER
 
     for time in range(num_timesteps):
         if time == 0:
@@ -288,7 +311,13 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                 newest = history[-1] if torch.is_tensor(history[-1]) else None
                 entry = deferred.get(time - 1) if step_lse[-1] is None else None
                 pending = entry if isinstance(entry, _ops.PendingStep) else None    # a step node awaits this lse
-                index, lse_previous, moved = _ops.resample_step(previous, feed.next(), newest,
+                # Leave the newest latent un-gathered (`lazy_gather`) while the model's callables only describe
+                # distributions in terms of it: the launch that weighs the step fetches the rows itself.  The
+                # first time a step reads the values after all, the remaining steps go back to gathering inside
+                # the resampling launch (one launch and one read of the indices cheaper than K2, then K3).
+                lazy_step = lazy_gather and newest is not None and _HISTORY_MODE == "lazy" and \
+                    newest.dim() == 3 and newest.is_floating_point()
+                index, lse_previous, moved = _ops.resample_step(previous, feed.next(), None if lazy_step else newest,
                                                                 want_lse=step_lse[-1] is None, pending=pending)
                 if step_lse[-1] is None:
                     if pending is not None:
@@ -299,7 +328,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                             _ops.attach_lse(lse_previous, previous, deferred.pop(time - 1))
                 indices.append(index)
                 if _HISTORY_MODE == "lazy":
-                    ancestors = ResampledHistory(history, index, newest=moved)
+                    ancestors = ResampledHistory(history, index, newest=moved, lazy_newest=lazy_step)
                 else:
                     ancestors = [state.resample(x, index) for x in history[:-1]]
                     ancestors.append(moved if moved is not None else state.resample(history[-1], index))
@@ -347,6 +376,8 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                     else:
                         deferred[time] = operands
         state.materialise_draw(latent)      # a deferred draw that K15 did not fill gets its values now (K9)
+        if lazy_gather and use_smc and time > 0 and isinstance(ancestors, ResampledHistory) and ancestors.newest_was_read():
+            lazy_gather = False
         # importance sampling over several timesteps normalises the SUM of the per-step weights
         # (inference.py:156-159); K1 keeps that sum running, left to right as torch.sum over the
         # reference's stack does, and hands out its row log-sum-exp with the last step

@@ -14,6 +14,7 @@ import torch
 
 from . import _kernels
 from . import _ops
+from ._lazy import LazyResampled
 from .linear_gaussian import AffineNormal
 
 _VALIDATION_MODE = "deferred"
@@ -149,6 +150,8 @@ def log_prob(distribution, value):
     of distributions sums its members' log-densities (the reference's dict branch is unreachable:
     it names an undefined variable, state.py:130; this is the evident intent).
     """
+    if type(value) is LazyResampled:
+        value = value.materialise()
     if isinstance(distribution, dict):
         total = None
         for key, dist in distribution.items():
@@ -196,12 +199,14 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
         if not fused:
             materialise_draw(latent)
         else:
+            # (a previous latent that nothing has gathered yet is fetched through the ancestors by this launch)
             log_weight = _ops.affine_propagate(affine, noise)
             del latent._aesmc_pending_noise
             for distribution, value in ((prior_dist, latent), (emission_dist, observation), (proposal_dist, latent)):
                 _validate_sample(distribution, value)
             return (log_weight, affine) if defer_grad else log_weight
     if affine is not None:
+        affine = affine.gathered()      # every other route reads x_{t-1}[ancestors] as a tensor
         for distribution, value in ((prior_dist, latent), (emission_dist, observation), (proposal_dist, latent)):
             _validate_sample(distribution, value)
         if defer_grad:
@@ -262,6 +267,14 @@ def materialise_draw(latent):
 
 
 def _same_tensor(a, b):
+    if a is b:
+        return True
+    if type(a) is LazyResampled or type(b) is LazyResampled:
+        return False
+    return _same_storage_and_history(a, b)
+
+
+def _same_storage_and_history(a, b):
     """One operand for the fused step: the same storage view AND the same autograd identity — `x` and
     `x.detach()` (a stop-gradient into one callable) share memory but not gradients, and the fused backward
     has one gradient slot per operand."""
@@ -284,6 +297,11 @@ def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, obse
     x_prev = prior_dist.source
     if not (_same_tensor(proposal_dist.source, x_prev) and _same_tensor(emission_dist.source, latent)):
         return None
+    pending = None
+    if type(x_prev) is LazyResampled:
+        pending = x_prev.pending        # (x_{t-1}, ancestors) while nothing has gathered them
+        if pending is None:
+            x_prev = x_prev.materialise()
     y_rows = observation[:, 0]
     transition = (prior_dist.weight, prior_dist.offset)
     emission = (emission_dist.weight, emission_dist.offset)
@@ -295,6 +313,7 @@ def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, obse
                                     proposal[0], proposal[1]) + scales)
     # the latent is this very proposal's reparameterised draw (K9 tagged it): the step can be one autograd node
     operands.is_draw = getattr(latent, "_aesmc_draw_of", None) is proposal_dist
+    operands.pending_gather = pending
     return operands
 
 
@@ -327,6 +346,8 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
                 _kernels.get().affine_covers(base.source, base.weight, base.offset):
             eps = torch.distributions.normal._standard_normal(base.batch_shape, dtype=base.source.dtype,
                                                                device=base.source.device)
+            if not (base.defer_draw and _DEFER_DRAWS.get()) and type(base.source) is LazyResampled:
+                base.source.materialise()       # K9 reads x_{t-1}[ancestors]
             if base.defer_draw and _DEFER_DRAWS.get():
                 # the values come with the launch that weighs the step (K15), or from K9 the moment anything
                 # else needs them (`materialise_draw`)
@@ -400,6 +421,8 @@ def resample(value, ancestral_index):
         return {key: resample(item, ancestral_index) for key, item in value.items()}
     if not torch.is_tensor(value):
         raise AttributeError("value must be a dict or a torch.Tensor. Got: {}".format(value))
+    if type(value) is LazyResampled:
+        value = value.materialise()
     assert ancestral_index.size() == value.size()[:2]
     return _ops.resample_gather(value, ancestral_index)
 

@@ -339,6 +339,21 @@ int aesmc_affine_normal_propagate(int dtype, const void *x_prev, const void *eps
                                   const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
                                   const void *scale_q, void *out_x, void *out_lw, int64_t B, int64_t K, void *stream);
 
+/* K15 through the ancestor indices — the resampling gather folded into the propagation:
+ *   x_prev[b,k,:] = x_src[b, ancestors[b,k], :]      (aesmc/inference.py:102-111, state.py:179 `torch.gather`)
+ * is formed while the tile is staged and never written: K15 of that x_prev, the same bits as
+ * aesmc_resample_gather followed by aesmc_affine_normal_propagate.  `x_src` [B,K,dx] dense and 16-byte
+ * aligned, `ancestors` int64 [B,K] (what aesmc_ancestor_index / aesmc_resample_step wrote); an index outside
+ * [0, K) is clamped and raises AESMC_FLAG_INDEX_OUT_OF_RANGE in `flags` (may be NULL).  One read of the
+ * surviving rows of x_src and of the noise, one write of x_t: 8 dx + 4 dx + 12 B per particle instead of the
+ * gather's 8 dx + 8 plus K15's 12 dx + 4.  AESMC_ERR_UNSUPPORTED (caller: gather, then K15) with fewer than
+ * ~43 particles per batch row or B K >= 2^31. */
+int aesmc_affine_normal_propagate_resampled(
+    int dtype, const void *x_src, const int64_t *ancestors, const void *eps, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, int32_t *flags,
+    int64_t B, int64_t K, void *stream);
+
 /* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
  *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])
  *   out_grad_weight[j,i]   = sum_{b,k} grad[b,k,j] x[b,k,i]                 (dense [dout,din])
@@ -426,6 +441,18 @@ int aesmc_affine_step_backward(
 int64_t aesmc_particle_mlp_max_hidden(void);
 int aesmc_particle_mlp(int dtype, const void *x, const aesmc_affine_map *layer1, const aesmc_affine_map *layer2,
                        void *out, int64_t B, int64_t K, void *stream);
+
+/* Noise — the float32 tensor `torch.empty(numel).normal_()` holds on this device for a generator at
+ * (seed, offset): out[e], e < numel.  Replaces, inside a kernel or on its own, the `_standard_normal` draw of
+ * `Normal.rsample` (aesmc/state.py:98; torch/distributions/normal.py rsample) WITHOUT leaving PyTorch's
+ * stream: ATen's launch geometry (`threads` = 256 * min(#CU * maxThreadsPerCU / 256, ceil(numel / 256)), the
+ * caller computes it from the device properties), rocRAND's Philox4x32-10 and Box-Muller restated
+ * (csrc/philox_normal.hpp).  The caller advances the generator by 4 * ceil(numel / (4 * threads)), what
+ * `normal_` would have consumed.  offset must be a multiple of 4 (PyTorch's always is).  `variant` 0 is
+ * the product (Box-Muller's affine maps as fused multiply-adds, as PyTorch's build of rocRAND has them);
+ * 1 = separate multiply and add, kept for the test that shows which of the two PyTorch's build uses. */
+int aesmc_philox_normal_fill(void *out, int64_t numel, uint64_t seed, uint64_t offset, int64_t threads, int variant,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -110,9 +110,13 @@ class OracleKernels:
         out.copy_(draw)
         return out
 
-    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x, checked=False):
-        """K15 on the C oracle: its draw, then its log-weight of that draw."""
+    def affine_propagate(self, x_prev, eps, y_rows, transition, emission, proposal, scales, out_x, checked=False,
+                         ancestors=None):
+        """K15 on the C oracle: its draw, then its log-weight of that draw (with `ancestors`: of the gathered
+        x_prev — the composition the fused launch must equal)."""
         from oracle import c_oracle
+        if ancestors is not None:
+            x_prev = self.gather(x_prev, ancestors)
         pair = lambda term: (self._n(term[0]), self._n(term[1]))
         out_x.copy_(torch.from_numpy(c_oracle.affine_rsample(self._n(x_prev), self._n(proposal[0]), self._n(proposal[1]),
                                                              self._n(eps), float(scales[2]))))

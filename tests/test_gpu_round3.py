@@ -1,0 +1,226 @@
+"""GPU parity tests added in round 3:
+
+  * the noise a kernel draws for itself IS `torch.empty(n).normal_()` — bit for bit, whatever the seed, the
+    offset and the size, and the generator ends where PyTorch's own call would leave it;
+  * the propagation launch that fetches x_{t-1} through the ancestor indices equals the resampling gather
+    followed by the plain launch bit for bit (draw and log-weight), healthy and collapsed ancestries, ragged
+    shapes, every piece width, out-of-range indices flagged and clamped;
+  * a whole `infer` with the lazily resampled latent equals the run that gathers every step — every number.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_linear_gaussian import operands
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kernels(hip_device):
+    from aesmc_amd import _kernels
+    provider = _kernels.get()
+    assert provider.name == "hip"
+    return provider
+
+
+# ---- noise -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,warm", [(0, 0), (1234, 3), (2 ** 40 + 17, 1)])
+def test_philox_fill_is_torch_normal_bit_for_bit(kernels, hip_device, seed, warm):
+    """aesmc_philox_normal_fill(seed, offset) against torch.empty(n).normal_() from the same generator state:
+    every bit of every element, sizes below / at / across ATen's launch geometry (one thread per element, one
+    trip, several trips with a ragged last one), and the offset PyTorch's call leaves behind predicted."""
+    from aesmc_amd import _philox
+    generator = torch.cuda.default_generators[hip_device.index]
+    torch.manual_seed(seed)
+    for _ in range(warm):
+        torch.randn(1000, device=hip_device)
+    for numel in (1, 7, 255, 256, 1000, 2 ** 19 - 1, 2 ** 19 + 5, 5 * 2 ** 19 + 123, 256 * 1024 * 10,
+                  1024 * 4096 * 10):
+        offset = generator.get_offset()
+        want = torch.empty(numel, device=hip_device).normal_()
+        threads = _philox.launch_threads(numel, hip_device)
+        assert generator.get_offset() == offset + _philox.consumed(numel, threads), numel
+        got = torch.empty(numel, device=hip_device)
+        status = kernels._lib.aesmc_philox_normal_fill(got.data_ptr(), numel, generator.initial_seed(), offset, threads,
+                                                       0, torch.cuda.current_stream().cuda_stream)
+        assert status == 0
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), numel
+
+
+def test_reserving_noise_leaves_the_generator_where_normal_would(hip_device):
+    """_philox.reserve(n) = the bookkeeping of torch.empty(n).normal_() without the launch: same descriptor,
+    same offset afterwards, so everything drawn later is unchanged."""
+    from aesmc_amd import _philox
+    torch.manual_seed(77)
+    torch.randn(10, device=hip_device)
+    state = torch.cuda.get_rng_state(hip_device)
+    reserved = _philox.reserve(3 * 4096 * 10, hip_device)
+    after_reserve = torch.randn(5, device=hip_device)
+    torch.cuda.set_rng_state(state, hip_device)
+    drawn = torch.empty(3 * 4096 * 10, device=hip_device).normal_()
+    after_draw = torch.randn(5, device=hip_device)
+    assert torch.equal(after_reserve, after_draw)
+    got = torch.empty_like(drawn)
+    from aesmc_amd import _kernels
+    status = _kernels.get()._lib.aesmc_philox_normal_fill(got.data_ptr(), got.numel(), reserved.seed, reserved.offset,
+                                                          reserved.threads, 0, torch.cuda.current_stream().cuda_stream)
+    assert status == 0 and torch.equal(got, drawn)
+
+
+# ---- propagation through the ancestor indices --------------------------------------------------------
+def _ancestors(B, K, device, seed, spread):
+    """Sorted ancestor indices as systematic resampling makes them: `spread` = 1 healthy, large = collapsed."""
+    from aesmc_amd import _ops
+    gen = torch.Generator().manual_seed(seed)
+    lw = (spread * torch.randn(B, K, generator=gen, dtype=torch.float64)).to(device)
+    u = torch.rand(B, generator=gen, dtype=torch.float64).to(device)
+    return _ops.ancestor_index(lw, u)
+
+
+GATHER_SHAPES = [(3, 700, 10, 10), (2, 513, 5, 3), (5, 64, 16, 16), (1, 1000, 3, 7), (7, 300, 12, 2), (2, 2048, 8, 8),
+                 (16, 4096, 10, 10), (300, 4096, 10, 10), (520, 2100, 8, 8), (40, 60, 6, 9), (3, 50, 1, 1), (2, 999, 9, 4)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("spread", [1.0, 6.0])
+@pytest.mark.parametrize("shape", GATHER_SHAPES)
+def test_propagate_through_ancestors_equals_gather_then_propagate(kernels, hip_device, dtype, spread, shape):
+    """aesmc_affine_normal_propagate_resampled == aesmc_resample_gather, then aesmc_affine_normal_propagate: the
+    draw and the log-weight bit for bit (rows of 4-, 8- and 16-byte pieces, one and two particles per lane,
+    tiles that straddle batch rows, ragged tails, N(0,1) and heavily collapsed weights)."""
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=3 * B + K + dx)
+    idx = _ancestors(B, K, hip_device, seed=B + K, spread=spread)
+    off_p = torch.from_numpy(np.random.RandomState(6).randn(dx).astype(dtype)).to(hip_device)
+    terms = ((o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    moved = kernels.gather(o["x_prev"], idx)
+    want_x = torch.full_like(moved, float("nan"))
+    want_lw = kernels.affine_propagate(moved, o["eps"], o["y"], *terms, scales, out_x=want_x)
+    got_x = torch.full_like(moved, float("nan"))
+    got_lw = kernels.affine_propagate(o["x_prev"], o["eps"], o["y"], *terms, scales, out_x=got_x, ancestors=idx)
+    assert got_lw is not None, "the gathering launch declined a shape it should cover"
+    assert torch.equal(got_x, want_x)
+    assert torch.equal(got_lw, want_lw)
+    assert kernels.read_flags(hip_device) == 0
+
+
+def test_propagate_through_ancestors_declines_tiny_rows_and_clamps_bad_indices(kernels, hip_device):
+    from aesmc_amd import _lib
+    B, K, dx, dy = 300, 5, 4, 4        # fewer than ~43 particles per batch row: the caller gathers first
+    n, o = operands(B, K, dx, dy, np.float32, hip_device, seed=1)
+    idx = _ancestors(B, K, hip_device, seed=2, spread=1.0)
+    terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    out_x = torch.empty_like(o["x_prev"])
+    assert kernels.affine_propagate(o["x_prev"], o["eps"], o["y"], *terms, scales, out_x=out_x, ancestors=idx) is None
+    B, K, dx, dy = 4, 600, 10, 10
+    n, o = operands(B, K, dx, dy, np.float32, hip_device, seed=4)
+    idx = _ancestors(B, K, hip_device, seed=5, spread=1.0)
+    bad = idx.clone()
+    bad[1, 17] = K          # what K2 writes for a degenerate row
+    bad[2, 0] = -3
+    clamped = idx.clone()
+    clamped[1, 17] = K - 1
+    clamped[2, 0] = 0
+    terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    want_x, got_x = torch.empty_like(o["x_prev"]), torch.empty_like(o["x_prev"])
+    want = kernels.affine_propagate(o["x_prev"], o["eps"], o["y"], *terms, scales, out_x=want_x, ancestors=clamped)
+    assert kernels.read_flags(hip_device) == 0
+    got = kernels.affine_propagate(o["x_prev"], o["eps"], o["y"], *terms, scales, out_x=got_x, ancestors=bad)
+    assert kernels.read_flags(hip_device) == _lib.FLAG_INDEX_OUT_OF_RANGE
+    assert torch.equal(got, want) and torch.equal(got_x, want_x)
+
+
+@pytest.mark.parametrize("grad", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_a_lazily_resampled_run_is_the_eagerly_gathered_run(hip_device, grad, dtype):
+    """`infer` with the newest latent left un-gathered (the propagation launch fetches the rows) against the
+    run whose resampling launch re-indexes it every step: latents, ancestors, evidence, gradients and both RNG
+    streams identical; and the lazy run really launched no gather for the steps it fused."""
+    from aesmc_amd import _kernels, inference
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    runs = {}
+    for lazy in (False, True):
+        inference.set_lazy_gather(lazy)
+        calls = {"gather": 0, "propagate_ancestors": 0}
+        real_gather, real_propagate = provider.gather, provider.affine_propagate
+
+        def gather_spy(*args, **kwargs):
+            calls["gather"] += 1
+            return real_gather(*args, **kwargs)
+
+        def propagate_spy(*args, **kwargs):
+            calls["propagate_ancestors"] += kwargs.get("ancestors") is not None
+            return real_propagate(*args, **kwargs)
+
+        provider.gather, provider.affine_propagate = gather_spy, propagate_spy
+        try:
+            model = LgssmNd(10, dtype=dtype, affine=True).tune_proposal().to(hip_device)
+            observations = model.simulate(6, 4, seed=3)
+            torch.manual_seed(11)
+            np.random.seed(11)
+            with torch.set_grad_enabled(grad):
+                out = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                                      model.proposal, 1300, return_log_marginal_likelihood=True, return_latents=False,
+                                      return_log_weight=not grad, return_ancestral_indices=True,
+                                      return_original_latents=True)
+            if grad:
+                (-out["log_marginal_likelihood"].mean()).backward()
+        finally:
+            provider.gather, provider.affine_propagate = real_gather, real_propagate
+            inference.set_lazy_gather(True)
+        after = (torch.rand(1, device=hip_device).item(), np.random.uniform())
+        runs[lazy] = (out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, after, calls)
+    (a, grads_a, rng_a, calls_a), (b, grads_b, rng_b, calls_b) = runs[False], runs[True]
+    assert rng_a == rng_b
+    assert torch.equal(a["log_marginal_likelihood"], b["log_marginal_likelihood"])
+    for x, y in zip(a["original_latents"] + a["ancestral_indices"], b["original_latents"] + b["ancestral_indices"]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["last_latent"], b["last_latent"])
+    assert sorted(grads_a) == sorted(grads_b) and (not grad or grads_a)
+    for name in grads_a:
+        assert torch.equal(grads_a[name], grads_b[name]), name
+    assert calls_a["propagate_ancestors"] == 0 and calls_b["propagate_ancestors"] == 5
+    if not grad:
+        assert calls_b["gather"] == 0
+
+
+def test_a_model_that_reads_the_resampled_latent_gets_the_gathered_values(hip_device):
+    """Callables that do arithmetic on previous_latents[-1] (the reference's own style, test/models/lgssm.py:40)
+    materialise the lazy entry — the same numbers as the eager gather — and after the first such step `infer`
+    goes back to gathering inside the resampling launch."""
+    from aesmc_amd import _kernels, inference
+    from aesmc_amd._lazy import LazyResampled
+    from aesmc_amd.testing.models import LgssmNd
+    seen = []
+
+    class Spy(LgssmNd):
+        def transition(self, previous_latents=None, time=None, previous_observations=None):
+            seen.append(type(previous_latents[-1]) is LazyResampled)
+            return super().transition(previous_latents=previous_latents, time=time,
+                                      previous_observations=previous_observations)
+
+    outs = {}
+    for lazy in (False, True):
+        inference.set_lazy_gather(lazy)
+        try:
+            model = Spy(5, dtype=torch.float64, affine=False).to(hip_device)
+            observations = model.simulate(5, 3, seed=2)
+            torch.manual_seed(4)
+            np.random.seed(4)
+            del seen[:]
+            outs[lazy] = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                                         model.proposal, 300, return_log_marginal_likelihood=True,
+                                         return_ancestral_indices=True)
+            if lazy:
+                assert seen == [True, False, False, False]
+        finally:
+            inference.set_lazy_gather(True)
+    assert torch.equal(outs[False]["log_marginal_likelihood"], outs[True]["log_marginal_likelihood"])
+    for x, y in zip(outs[False]["latents"] + outs[False]["ancestral_indices"],
+                    outs[True]["latents"] + outs[True]["ancestral_indices"]):
+        assert torch.equal(x, y)
