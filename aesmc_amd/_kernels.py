@@ -120,13 +120,22 @@ class KernelTimer:
             nbytes = sum(n for _, n, _ in sample) / len(sample)
             out[name] = {"launches": count, "sampled": len(sample), "avg_us": 1e6 * seconds,
                          "bytes_per_launch": nbytes, "GBps": nbytes / seconds / 1e9}
-            if name in ("resample_gather", "resample_step"):
+            if name in ("resample_gather", "resample_step", "affine_normal_propagate_resampled"):
                 # The algorithmic figure counts a full read of the source (and, for the fused step,
                 # K3's re-read of the indices, which it skips); only rows that still have offspring
                 # are actually fetched.  Report how many that was on these operands and the bytes
                 # that had to move.
                 fractions, moved, ess = [], [], []
                 for _, _, keep in sample:
+                    if name == "affine_normal_propagate_resampled":
+                        # (x_src, ancestors, eps, y, lw, x_t, ...): the gather's read side is the surviving rows
+                        idx, dst = keep[1], keep[5]
+                        rows = idx.numel()
+                        unique = int((idx[:, 1:] != idx[:, :-1]).sum().item()) + idx.size(0)
+                        payload = dst.numel() * dst.element_size() / rows
+                        fractions.append(unique / rows)
+                        moved.append(rows * (8 + dst.element_size() + 2 * payload) + unique * payload)
+                        continue
                     idx, dst = (keep[1], keep[2]) if name == "resample_gather" else (keep[2], keep[5])
                     if dst is None:
                         continue

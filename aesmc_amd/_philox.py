@@ -39,6 +39,8 @@ def reserve(numel, device):
     """The stream descriptor of the next `torch.empty(numel, device=device).normal_()` — and the generator
     advanced as if that call had been made."""
     index = device.index if device.index is not None else torch.cuda.current_device()
+    if not torch.cuda.default_generators:
+        torch.cuda.init()
     generator = torch.cuda.default_generators[index]
     threads = launch_threads(numel, device)
     offset = generator.get_offset()

@@ -198,22 +198,18 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
   const T two_var_q = T(2) * (s_q * s_q), const_q = T(dx) * (Num<T>::log(s_q) + half_log_2pi);
   const int64_t tiles = (N + TP - 1) / TP;
   V rp[(PREFETCH && !GATHER) ? NV : 1], rx[PREFETCH ? NV : 1];
-  constexpr int NW = NV * 4;
-  uint32_t rg[GATHER ? NW : 1];
+  constexpr int MAXQ = (DP * (int)sizeof(T) + PB - 1) / PB;      // pieces that hold a row of this extent class
+  uint32_t rg[GATHER ? PPL * MAXQ * (PB / 4) : 1];
   int64_t ranc[GATHER ? PPL : 1];
-  uint32_t *anc = reinterpret_cast<uint32_t *>(tx + (TP * lx.rs + 16));      // [TP], GATHER only
   const char *xprev_bytes = reinterpret_cast<const char *>(xprev);
   if constexpr (GATHER) {
     const int64_t n0 = (int64_t)blockIdx.x * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
     lg_anc_prefetch<PPL, true>(gat, n0, np, ranc);
-    lg_anc_commit<PPL, true>(gat, n0, np, K, ranc, anc);
-    lg_lds_barrier();
-    lg_gather_prefetch<NW, PB, true>(xprev_bytes, gat, anc, np, rg);
+    lg_gather_prefetch<PPL, MAXQ, PB, true>(xprev_bytes, gat, n0, np, K, ranc, rg);
     lg_prefetch<T, NV>(x + n0 * dx, np * dx, 0, rx);
     const int64_t m0 = n0 + (int64_t)gridDim.x * TP;
     if (m0 < N) lg_anc_prefetch<PPL, true>(gat, m0, (uint32_t)min((int64_t)TP, N - m0), ranc);
-    lg_lds_barrier();      // every lane has read its ancestors before the loop's first commit replaces them
   } else if constexpr (PREFETCH) {
     const int64_t n0 = (int64_t)blockIdx.x * TP;
     const uint32_t ne = (uint32_t)min((int64_t)TP, N - n0) * dx;
@@ -224,10 +220,8 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
     if constexpr (GATHER) {
-      lg_gather_commit<T, NW, PB, true>(gat, np, rg, tprev, lx);
+      lg_gather_commit<T, PPL, MAXQ, PB, true>(gat, np, rg, tprev, lx);
       lg_commit<T, NV>(x + n0 * dx, np * dx, rx, tx, lx);
-      const int64_t m0 = (tile + gridDim.x) * TP;
-      if (m0 < N) lg_anc_commit<PPL, true>(gat, m0, (uint32_t)min((int64_t)TP, N - m0), K, ranc, anc);
     } else if constexpr (PREFETCH) {
       lg_commit<T, NV>(xprev + n0 * dx, np * dx, rp, tprev, lx);
       lg_commit<T, NV>(x + n0 * dx, np * dx, rx, tx, lx);
@@ -255,7 +249,7 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
       if (next < tiles) {
         const int64_t m0 = next * TP;
         const uint32_t mp_ = (uint32_t)min((int64_t)TP, N - m0);
-        lg_gather_prefetch<NW, PB, true>(xprev_bytes, gat, anc, mp_, rg);
+        lg_gather_prefetch<PPL, MAXQ, PB, true>(xprev_bytes, gat, m0, mp_, K, ranc, rg);      // its indices came a tile ago
         lg_prefetch<T, NV>(x + m0 * dx, mp_ * dx, 0, rx);
         const int64_t nn0 = (next + gridDim.x) * TP;
         if (nn0 < N) lg_anc_prefetch<PPL, true>(gat, nn0, (uint32_t)min((int64_t)TP, N - nn0), ranc);
@@ -564,7 +558,6 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   {
     const size_t tp = (size_t)kLgBlock * ppl;
     lds = sizeof(T) * (3 * (size_t)dp * dp + (size_t)kLgRowsMax * 4 * dp + 2 * lg_tile_elems<T>(tp, dx));
-    if (anc_idx != nullptr) lds += tp * sizeof(uint32_t);
   }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;

@@ -296,11 +296,11 @@ __device__ __forceinline__ void lg_commit(const T *__restrict__ src, uint32_t ne
 
 // ---- rows fetched through ancestor indices -------------------------------------------------------------
 // The resampled latent  x_{t-1}[b, idx[b,k], :]  (aesmc/inference.py:102-111, state.py:179) need not exist in
-// HBM for a kernel that stages x_{t-1} through LDS anyway: the tile's rows are fetched from where their
-// ancestors lie.  `anc[p]` (LDS, one uint32 per particle of the tile) holds the flat source particle
-// b K + idx[b,k]; a row is moved in pieces of `pb` bytes (16 when rows are whole 16-byte vectors, else 8,
-// else 4: the widest unit that never straddles a row), piece v = tid + 256 s of the tile's np * ppr.
-// Registers: NW 32-bit words per lane (the same budget as the flat 16-byte prefetch of a tile).
+// HBM for a kernel that stages x_{t-1} through LDS anyway: every lane fetches the rows of ITS OWN particles
+// (tid + 256 r) from where their ancestors lie — the lane loads its particles' indices itself, one tile
+// earlier still, so no index ever goes through LDS — in pieces of PB bytes (16 when rows are whole 16-byte
+// vectors, else 8, else 4: the widest unit that never straddles a row; compile time), at immediate offsets
+// from one 64-bit row address per particle, and parks them in the tile at its own slot.
 struct LgGather {
   const int64_t *idx;   // [B, K] ancestor indices; nullptr: no gather
   int32_t *flags;       // status word (out-of-range indices)
@@ -309,7 +309,12 @@ struct LgGather {
   uint32_t row_bytes;
 };
 
-// the flat source particle of each of the lane's particles of the tile at n0: raw indices -> registers
+template <int PB> struct LgPiece;
+template <> struct LgPiece<4> { using type = uint32_t; };
+template <> struct LgPiece<8> { using type = uint2; };
+template <> struct LgPiece<16> { using type = uint4; };
+
+// the raw indices of the lane's particles of the tile at n0 -> registers
 template <int PPL, bool LG_OPAQUE = false>
 __device__ __forceinline__ void lg_anc_prefetch(const LgGather &g, int64_t n0, uint32_t np, int64_t (&raw)[PPL]) {
 #pragma unroll
@@ -318,9 +323,14 @@ __device__ __forceinline__ void lg_anc_prefetch(const LgGather &g, int64_t n0, u
     raw[r] = q < np ? g.idx[n0 + q] : 0;
   }
 }
-template <int PPL, bool LG_OPAQUE = false>
-__device__ __forceinline__ void lg_anc_commit(const LgGather &g, int64_t n0, uint32_t np, uint32_t K,
-                                              const int64_t (&raw)[PPL], uint32_t *__restrict__ anc) {
+
+// MAXQ pieces of PB bytes hold a row of the kernel's extent class; regs: PPL * MAXQ * PB / 4 words
+template <int PPL, int MAXQ, int PB, bool LG_OPAQUE = false>
+__device__ __forceinline__ void lg_gather_prefetch(const char *__restrict__ src, const LgGather &g, int64_t n0,
+                                                   uint32_t np, uint32_t K, const int64_t (&raw)[PPL],
+                                                   uint32_t (&regs)[PPL * MAXQ * (PB / 4)]) {
+  using P = typename LgPiece<PB>::type;
+  constexpr int W = PB / 4;
   const uint32_t b0 = (uint32_t)(n0 / K);
   const uint32_t k0 = (uint32_t)(n0 - (int64_t)b0 * K);
 #pragma unroll
@@ -332,56 +342,41 @@ __device__ __forceinline__ void lg_anc_commit(const LgGather &g, int64_t n0, uin
         raise_flag(g.flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
         a = a < 0 ? 0 : (int64_t)K - 1;
       }
-      anc[q] = (b0 + (k0 + q) / K) * K + (uint32_t)a;
-    }
-  }
-}
-
-template <int PB> struct LgPiece;
-template <> struct LgPiece<4> { using type = uint32_t; };
-template <> struct LgPiece<8> { using type = uint2; };
-template <> struct LgPiece<16> { using type = uint4; };
-
-// PB: bytes per piece (compile time: one kernel per unit, no three-way code inside the tile loop)
-template <int NW, int PB, bool LG_OPAQUE = false>
-__device__ __forceinline__ void lg_gather_prefetch(const char *__restrict__ src, const LgGather &g,
-                                                   const uint32_t *__restrict__ anc, uint32_t np,
-                                                   uint32_t (&regs)[NW]) {
-  using P = typename LgPiece<PB>::type;
-  constexpr int W = PB / 4;
-  const uint32_t npieces = np * g.ppr;
-  const uint32_t step_p = kLgBlock / g.ppr, step_q = kLgBlock - step_p * g.ppr;
-  uint32_t p = lg_tid() / g.ppr, q = lg_tid() - p * g.ppr, v = lg_tid();
+      const uint64_t row = (uint64_t)(b0 + (k0 + q) / K) * K + (uint64_t)a;
+      const char *at = src + row * g.row_bytes;
 #pragma unroll
-  for (int s = 0; s < NW / W; ++s) {
-    if (v < npieces) {
-      const P x = *reinterpret_cast<const P *>(src + (uint64_t)anc[p] * g.row_bytes + q * (uint32_t)PB);
-      __builtin_memcpy(&regs[W * s], &x, PB);
+      for (int c = 0; c < MAXQ; ++c) {
+        if ((uint32_t)c < g.ppr) {
+          const P x = *reinterpret_cast<const P *>(at + c * PB);
+          __builtin_memcpy(&regs[(r * MAXQ + c) * W], &x, PB);
+        }
+      }
     }
-    v += kLgBlock; p += step_p; q += step_q;
-    if (q >= g.ppr) { q -= g.ppr; ++p; }
   }
 }
 
-// the pieces into the tile: row p starts at element p * rs (16-byte aligned whenever PB == 16)
-template <typename T, int NW, int PB, bool LG_OPAQUE = false>
-__device__ __forceinline__ void lg_gather_commit(const LgGather &g, uint32_t np, const uint32_t (&regs)[NW],
-                                                 T *__restrict__ tile, const LgLayout &l) {
+// the lane's rows into the tile: row p starts at element p * rs (16-byte aligned whenever PB == 16)
+template <typename T, int PPL, int MAXQ, int PB, bool LG_OPAQUE = false>
+__device__ __forceinline__ void lg_gather_commit(const LgGather &g, uint32_t np,
+                                                 const uint32_t (&regs)[PPL * MAXQ * (PB / 4)], T *__restrict__ tile,
+                                                 const LgLayout &l) {
   using P = typename LgPiece<PB>::type;
   constexpr int W = PB / 4;
   char *base = reinterpret_cast<char *>(tile);
-  const uint32_t npieces = np * g.ppr, row_pitch = l.rs * (uint32_t)sizeof(T);
-  const uint32_t step_p = kLgBlock / g.ppr, step_q = kLgBlock - step_p * g.ppr;
-  uint32_t p = lg_tid() / g.ppr, q = lg_tid() - p * g.ppr, v = lg_tid();
+  const uint32_t row_pitch = l.rs * (uint32_t)sizeof(T);
 #pragma unroll
-  for (int s = 0; s < NW / W; ++s) {
-    if (v < npieces) {
-      P x;
-      __builtin_memcpy(&x, &regs[W * s], PB);
-      *reinterpret_cast<P *>(base + p * row_pitch + q * (uint32_t)PB) = x;
+  for (int r = 0; r < PPL; ++r) {
+    const uint32_t q = lg_tid() + r * kLgBlock;
+    if (q < np) {
+#pragma unroll
+      for (int c = 0; c < MAXQ; ++c) {
+        if ((uint32_t)c < g.ppr) {
+          P x;
+          __builtin_memcpy(&x, &regs[(r * MAXQ + c) * W], PB);
+          *reinterpret_cast<P *>(base + q * row_pitch + c * PB) = x;
+        }
+      }
     }
-    v += kLgBlock; p += step_p; q += step_q;
-    if (q >= g.ppr) { q -= g.ppr; ++p; }
   }
 }
 

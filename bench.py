@@ -417,7 +417,10 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         # the roofline kernel: the resample gather (K3, or the fused step that contains it); a workload
         # that never resamples (c3, IWAE) is what BASELINE.json uses to isolate the fused log-weight
         # + log-sum-exp kernel (K1)
-        if "moved_GBps" in kernels.get("resample_step", {}):
+        if "affine_normal_propagate_resampled" in kernels:
+            key, label = "affine_normal_propagate_resampled", \
+                "affine_logweight_kernel, DRAW + GATHER (the resample gather inside the propagation launch: K3 + K15)"
+        elif "moved_GBps" in kernels.get("resample_step", {}):
             key, label = "resample_step", "ancestor_index_inv_kernel with payload (fused step: K2 + K3)"
         elif "resample_gather" in kernels:
             key, label = "resample_gather", "resample_gather_kernel (K3)"
@@ -426,6 +429,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         out["roofline"] = roofline_of(kernels.get(key), label, name, proposal, key)
         # the propagation kernels either side of it (K9 draws x_t, K10 weighs it), priced the same way
         others = [roofline_of(kernels.get(k), l, name, proposal, k) for k, l in (
+            ("resample_step" if key != "resample_step" else "-", "ancestor_index_inv_kernel (K2: ancestor indices + row log-sum-exp)"),
             ("affine_normal_propagate", "affine_logweight_kernel, DRAW (K15: the draw and its log-weight)"),
             ("affine_normal_rsample", "affine_rsample_kernel (K9)"),
             ("affine_normal_logweight", "affine_logweight_kernel (K10)")) if k in kernels]

@@ -31,6 +31,7 @@ def test_philox_fill_is_torch_normal_bit_for_bit(kernels, hip_device, seed, warm
     every bit of every element, sizes below / at / across ATen's launch geometry (one thread per element, one
     trip, several trips with a ragged last one), and the offset PyTorch's call leaves behind predicted."""
     from aesmc_amd import _philox
+    torch.cuda.init()
     generator = torch.cuda.default_generators[hip_device.index]
     torch.manual_seed(seed)
     for _ in range(warm):
