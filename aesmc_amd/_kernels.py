@@ -120,21 +120,25 @@ class KernelTimer:
             nbytes = sum(n for _, n, _ in sample) / len(sample)
             out[name] = {"launches": count, "sampled": len(sample), "avg_us": 1e6 * seconds,
                          "bytes_per_launch": nbytes, "GBps": nbytes / seconds / 1e9}
-            if name in ("resample_gather", "resample_step", "affine_normal_propagate_resampled"):
+            if name in ("resample_gather", "resample_step", "affine_normal_propagate_resampled",
+                        "affine_normal_propagate_drawn"):
                 # The algorithmic figure counts a full read of the source (and, for the fused step,
                 # K3's re-read of the indices, which it skips); only rows that still have offspring
                 # are actually fetched.  Report how many that was on these operands and the bytes
                 # that had to move.
                 fractions, moved, ess = [], [], []
                 for _, _, keep in sample:
-                    if name == "affine_normal_propagate_resampled":
+                    if name in ("affine_normal_propagate_resampled", "affine_normal_propagate_drawn"):
                         # (x_src, ancestors, eps, y, lw, x_t, ...): the gather's read side is the surviving rows
                         idx, dst = keep[1], keep[5]
+                        if idx is None:
+                            continue
                         rows = idx.numel()
                         unique = int((idx[:, 1:] != idx[:, :-1]).sum().item()) + idx.size(0)
                         payload = dst.numel() * dst.element_size() / rows
                         fractions.append(unique / rows)
-                        moved.append(rows * (8 + dst.element_size() + 2 * payload) + unique * payload)
+                        noise_rows = 2 if name == "affine_normal_propagate_resampled" else 1     # eps read + x_t written
+                        moved.append(rows * (8 + dst.element_size() + noise_rows * payload) + unique * payload)
                         continue
                     idx, dst = (keep[1], keep[2]) if name == "resample_gather" else (keep[2], keep[5])
                     if dst is None:
@@ -870,6 +874,62 @@ class HipKernels:
                 if ancestors is not None:
                     nbytes += 8 * B * K
                 self.timer.note(name, (entry, args), nbytes, (x_prev, ancestors, eps, y_rows, out, out_x, maps, scales))
+        return out
+
+    def philox_normal(self, stream_desc, shape, device):
+        """The float32 tensor `torch.empty(shape).normal_()` would have held for the generator state
+        `stream_desc` (an `_philox.NoiseStream`) — for a draw that was left to a kernel which then did not run."""
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        if out.numel() != stream_desc.numel:
+            raise ValueError("aesmc_amd: noise of {} elements asked from a reservation of {}".format(
+                out.numel(), stream_desc.numel))
+        if out.numel() == 0:
+            return out
+        with _on_device(out.device):
+            args = (_ptr(out), out.numel(), stream_desc.seed, stream_desc.offset, stream_desc.threads, 0,
+                    self._stream(out))
+            _lib.check(self._lib.aesmc_philox_normal_fill(*args), "aesmc_philox_normal_fill")
+            if self.timer is not None:
+                self.timer.note("philox_normal_fill", (self._lib.aesmc_philox_normal_fill, args), 4 * out.numel(), (out,))
+        return out
+
+    def affine_propagate_drawn(self, x_src, noise, y_rows, transition, emission, proposal, scales, out_x,
+                               ancestors=None):
+        """K16: K15 with the resampling gather (`ancestors`, or None) AND the noise inside the launch — `noise`
+        is an `_philox.NoiseStream`, the reservation of the `normal_` call that did not happen.  Returns the
+        log-weights [B,K], or None when the launch does not cover the shape (the caller materialises the
+        noise with `philox_normal` and takes `affine_propagate`)."""
+        if x_src.dtype != torch.float32:
+            return None
+        B, K, dx = x_src.shape
+        if noise.numel != B * K * dx:
+            raise ValueError("aesmc_amd: affine_propagate_drawn: the reservation does not match x_src")
+        self._check_out(out_x, (B, K, dx), x_src, "affine_propagate_drawn")
+        x_src = self._dense16(x_src)
+        if out_x.data_ptr() == x_src.data_ptr():
+            raise ValueError("aesmc_amd: affine_propagate_drawn cannot write the draw over x_src")
+        if ancestors is not None:
+            self._check_index(x_src, ancestors)
+            if ancestors.shape != (B, K):
+                raise ValueError("aesmc_amd: affine_propagate_drawn ancestors must be [{}, {}]".format(B, K))
+            ancestors = ancestors.contiguous()
+        if y_rows.stride(1) != 1:
+            y_rows = y_rows.contiguous()
+        out = torch.empty((B, K), dtype=x_src.dtype, device=x_src.device)
+        maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
+        with _on_device(x_src.device):
+            args = (_ptr(x_src), _ptr(ancestors), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
+                    ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
+                    _ptr(scales[2]), _ptr(out_x), _ptr(out), _ptr(self.flags(x_src.device)), B, K, noise.seed,
+                    noise.offset, noise.threads, self._stream(x_src))
+            status = self._lib.aesmc_affine_normal_propagate_drawn(*args)
+            if status == 2:
+                return None
+            _lib.check(status, "aesmc_affine_normal_propagate_drawn")
+            if self.timer is not None:
+                nbytes = 4 * (B * K * (2 * dx + 1) + y_rows.numel()) + (8 * B * K if ancestors is not None else 0)
+                self.timer.note("affine_normal_propagate_drawn", (self._lib.aesmc_affine_normal_propagate_drawn, args),
+                                nbytes, (x_src, ancestors, None, y_rows, out, out_x, maps, scales))
         return out
 
     def affine_logweight_covers(self, x_prev, x, y_rows, transition, emission, proposal, scales):

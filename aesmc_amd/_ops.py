@@ -8,6 +8,7 @@ Gradient contract of the reference that these preserve:
 import torch
 
 from . import _kernels
+from . import _philox
 from ._lazy import LazyResampled
 
 
@@ -375,13 +376,17 @@ class _AffineRsample(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         source, weight, eps = ctx.saved_tensors
-        need_src, need_w, need_off, need_scale = ctx.needs_input_grad[:4]
-        need_off = need_off and ctx.offset_shape is not None
-        gsrc, gw, rows = _kernels.get().particle_affine_backward(grad.contiguous(), source, weight, need_src, need_w,
-                                                                need_off)
-        goff = None if not need_off else (rows if len(ctx.offset_shape) == 2 else rows.sum(dim=0))
-        gscale = (grad * eps).sum().reshape(ctx.scale_shape) if need_scale else None
-        return gsrc, gw, goff, gscale, None
+        return _affine_rsample_backward(ctx, grad, source, weight, eps)
+
+
+def _affine_rsample_backward(ctx, grad, source, weight, eps):
+    need_src, need_w, need_off, need_scale = ctx.needs_input_grad[:4]
+    need_off = need_off and ctx.offset_shape is not None
+    gsrc, gw, rows = _kernels.get().particle_affine_backward(grad.contiguous(), source, weight, need_src, need_w,
+                                                            need_off)
+    goff = None if not need_off else (rows if len(ctx.offset_shape) == 2 else rows.sum(dim=0))
+    gscale = (grad * eps).sum().reshape(ctx.scale_shape) if need_scale else None
+    return gsrc, gw, goff, gscale, None
 
 
 class _DeferredAffineRsample(torch.autograd.Function):
@@ -391,13 +396,19 @@ class _DeferredAffineRsample(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, source, weight, offset, scale, eps, poison):
-        ctx.save_for_backward(source, weight, eps if scale.requires_grad else None)
+        reserved = isinstance(eps, _philox.NoiseStream)      # the noise left to a kernel: formed again if ever needed
+        ctx.save_for_backward(source, weight, eps if (scale.requires_grad and not reserved) else None)
+        ctx.reserved = eps if (scale.requires_grad and reserved) else None
         ctx.offset_shape = None if offset is None else tuple(offset.shape)
         ctx.scale_shape = tuple(scale.shape)
         return _placeholder(source, weight, poison)
 
     @staticmethod
     def backward(ctx, grad):
+        if ctx.reserved is not None:
+            source, weight, _ = ctx.saved_tensors
+            eps = _kernels.get().philox_normal(ctx.reserved, tuple(grad.shape), grad.device)
+            return _affine_rsample_backward(ctx, grad, source, weight, eps) + (None,)
         return _AffineRsample.backward(ctx, grad) + (None,)
 
 
@@ -415,7 +426,9 @@ class _DeferredAffineRsampleResampled(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, source, ancestors, weight, offset, scale, eps, poison):
-        ctx.save_for_backward(source, ancestors, weight, eps if scale.requires_grad else None)
+        reserved = isinstance(eps, _philox.NoiseStream)
+        ctx.save_for_backward(source, ancestors, weight, eps if (scale.requires_grad and not reserved) else None)
+        ctx.reserved = eps if (scale.requires_grad and reserved) else None
         ctx.offset_shape = None if offset is None else tuple(offset.shape)
         ctx.scale_shape = tuple(scale.shape)
         return _placeholder(source, weight, poison)
@@ -424,6 +437,8 @@ class _DeferredAffineRsampleResampled(torch.autograd.Function):
     def backward(ctx, grad):
         source, ancestors, weight, eps = ctx.saved_tensors
         k = _kernels.get()
+        if ctx.reserved is not None:
+            eps = k.philox_normal(ctx.reserved, tuple(grad.shape), grad.device)
         need_src, _, need_w, need_off, need_scale = ctx.needs_input_grad[:5]
         need_off = need_off and ctx.offset_shape is not None
         gsrc, gw, rows = k.particle_affine_backward(grad.contiguous(), k.gather(source, ancestors), weight, need_src,
@@ -637,6 +652,18 @@ def affine_propagate(operands, eps):
     declines the shape, the gather happens first (and `operands.pending_gather` is cleared)."""
     x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = [None if t is None else t.detach() for t in operands[1:]]
     k = _kernels.get()
+    if isinstance(eps, _philox.NoiseStream):
+        # the noise was only RESERVED in PyTorch's generator: K16 forms it (and, if pending, the gather) in the launch
+        if operands.pending_gather is not None:
+            source, ancestors = operands.pending_gather
+        else:
+            x_prev = operands[0]
+            source, ancestors = (x_prev.materialise() if type(x_prev) is LazyResampled else x_prev), None
+        lw = k.affine_propagate_drawn(source.detach(), eps, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q),
+                                      out_x=x, ancestors=ancestors)
+        if lw is not None:
+            return lw
+        eps = k.philox_normal(eps, tuple(x.shape), x.device)      # not a shape K16 covers: the values as a tensor
     if operands.pending_gather is not None:
         source, ancestors = operands.pending_gather
         lw = k.affine_propagate(source.detach(), eps, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q),

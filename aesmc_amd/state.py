@@ -14,6 +14,7 @@ import torch
 
 from . import _kernels
 from . import _ops
+from . import _philox
 from ._lazy import LazyResampled
 from .linear_gaussian import AffineNormal
 
@@ -248,6 +249,34 @@ def deferring_draws():
         _DEFER_DRAWS.reset(token)
 
 
+_TORCH_STANDARD_NORMAL = torch.distributions.normal._standard_normal
+_KERNEL_NOISE = __import__("os").environ.get("AESMC_KERNEL_NOISE", "1") != "0"      # measurement knob
+
+
+def set_kernel_noise(enabled):
+    """On (default): a deferred draw's float32 noise is formed inside the propagation launch from PyTorch's own
+    Philox stream (same values, same generator state afterwards as `_standard_normal`); off: `_standard_normal`
+    materialises it first (rounds 1-2)."""
+    global _KERNEL_NOISE
+    _KERNEL_NOISE = bool(enabled)
+
+
+def _kernel_noise_applies(source):
+    """Float32 on the HIP device, PyTorch's `_standard_normal` in place (tests replay recorded noise through
+    it), outside a hipGraph capture (a captured generator state lives on the device)."""
+    return (_KERNEL_NOISE and source.is_cuda and source.dtype == torch.float32 and _kernels.get().name == "hip" and
+            torch.distributions.normal._standard_normal is _TORCH_STANDARD_NORMAL and
+            not torch.cuda.is_current_stream_capturing())
+
+
+def _noise_tensor(noise, latent):
+    """The noise of a deferred draw as a tensor: what was drawn, or — for a reservation — what PyTorch would
+    have drawn (aesmc_philox_normal_fill)."""
+    if isinstance(noise, _philox.NoiseStream):
+        return _kernels.get().philox_normal(noise, tuple(latent.shape), latent.device)
+    return noise
+
+
 def materialise_draw(latent):
     """Fills a deferred draw (AffineNormal(..., defer_draw=True) sampled by `sample`) with its values by
     kernel K9 if no launch has produced them yet; anything else passes through.  `infer` calls it before
@@ -260,7 +289,7 @@ def materialise_draw(latent):
     if eps is not None:
         base = latent._aesmc_draw_of
         offset = None if base.offset is None else base.offset.detach()
-        _kernels.get().affine_rsample(base.source.detach(), base.weight.detach(), offset, eps,
+        _kernels.get().affine_rsample(base.source.detach(), base.weight.detach(), offset, _noise_tensor(eps, latent),
                                       base.scale_param.detach(), out=latent.detach())
         del latent._aesmc_pending_noise
     return latent
@@ -344,11 +373,19 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
         scale = base.scale_param
         if scale.numel() == 1 and scale.dtype == base.source.dtype and scale.device == base.source.device and \
                 _kernels.get().affine_covers(base.source, base.weight, base.offset):
-            eps = torch.distributions.normal._standard_normal(base.batch_shape, dtype=base.source.dtype,
-                                                               device=base.source.device)
-            if not (base.defer_draw and _DEFER_DRAWS.get()) and type(base.source) is LazyResampled:
+            deferred = base.defer_draw and _DEFER_DRAWS.get()
+            if deferred and _kernel_noise_applies(base.source):
+                # the draw is left to the launch that weighs the step AND so is its noise: reserve, in PyTorch's
+                # own generator, exactly what `_standard_normal` would have consumed here — the kernel forms the
+                # same values from (seed, offset) — so the stream and everything drawn after it are unchanged
+                eps = _philox.reserve(base.source.numel() // base.source.size(-1) * base.weight.size(0),
+                                      base.source.device)
+            else:
+                eps = torch.distributions.normal._standard_normal(base.batch_shape, dtype=base.source.dtype,
+                                                                   device=base.source.device)
+            if not deferred and type(base.source) is LazyResampled:
                 base.source.materialise()       # K9 reads x_{t-1}[ancestors]
-            if base.defer_draw and _DEFER_DRAWS.get():
+            if deferred:
                 # the values come with the launch that weighs the step (K15), or from K9 the moment anything
                 # else needs them (`materialise_draw`)
                 # (with argument validation on — PyTorch's default — the placeholder is NaN until then, so a

@@ -354,6 +354,24 @@ int aesmc_affine_normal_propagate_resampled(
     const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, int32_t *flags,
     int64_t B, int64_t K, void *stream);
 
+/* K16 — K15 through the ancestor indices with the noise drawn INSIDE the launch:
+ *   eps = the float32 tensor `torch.empty([B,K,dx]).normal_()` holds for a generator at (seed, offset) — see
+ *         aesmc_philox_normal_fill below: ATen's launch geometry `threads`, rocRAND's Philox4x32-10 + Box-Muller
+ *   x_prev[b,k,:] = x_src[b, ancestors[b,k], :]        (ancestors NULL: x_prev = x_src)
+ *   out_x, out_lw = aesmc_affine_normal_propagate(x_prev, eps, ...)        — the same bits
+ * Replaces, for one SMC step of a linear-Gaussian model, aesmc/inference.py:102-126: `state.resample` of the
+ * newest latent (state.py:179), `state.sample(proposal)` (state.py:98: `_standard_normal`, loc + eps * scale)
+ * and the three `state.log_prob` calls.  Neither the noise nor the resampled latent nor any location touches
+ * HBM: 8 + 4 dx bytes in, 4 dx + 4 out per particle.  The caller advances the generator by
+ * 4 * ceil(B K dx / (4 threads)), as `normal_` would.  float32 only (PyTorch draws float64 noise by another
+ * route).  AESMC_ERR_UNSUPPORTED (caller: aesmc_philox_normal_fill, then the launches above) with fewer than
+ * 128 particles per batch row (64 below 2^20 particles), dx = 1, or B K dx >= 2^32. */
+int aesmc_affine_normal_propagate_drawn(
+    const void *x_src, const int64_t *ancestors, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, int32_t *flags,
+    int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, void *stream);
+
 /* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
  *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])
  *   out_grad_weight[j,i]   = sum_{b,k} grad[b,k,j] x[b,k,i]                 (dense [dout,din])

@@ -225,3 +225,148 @@ def test_a_model_that_reads_the_resampled_latent_gets_the_gathered_values(hip_de
     for x, y in zip(outs[False]["latents"] + outs[False]["ancestral_indices"],
                     outs[True]["latents"] + outs[True]["ancestral_indices"]):
         assert torch.equal(x, y)
+
+
+# ---- K16: the gather AND the noise inside the propagation launch -----------------------------------------------
+DRAWN_SHAPES = [(3, 700, 10, 10), (16, 4096, 10, 10), (300, 4096, 10, 10), (520, 2100, 8, 8), (7, 300, 12, 2),
+                (2, 2048, 8, 8), (2, 999, 9, 4), (5, 130, 16, 16), (2, 513, 5, 3), (1, 1000, 3, 7), (64, 16384, 2, 2),
+                # sizes around ATen's launch geometry (G = 2^19 thread ids): one element per thread, a wrap of a
+                # few elements into the next window, ragged last blocks, a second trip with one window only
+                (1, 52428, 10, 10), (1, 52429, 10, 3), (5, 52430, 10, 10), (3, 174763, 3, 3), (1, 209716, 10, 10),
+                (9, 65536, 4, 4)]
+
+
+@pytest.mark.parametrize("gather", [True, False])
+@pytest.mark.parametrize("shape", DRAWN_SHAPES)
+def test_propagate_with_the_noise_inside_equals_normal_then_gather_then_propagate(kernels, hip_device, gather, shape):
+    """aesmc_affine_normal_propagate_drawn == torch's own normal_(), aesmc_resample_gather, then
+    aesmc_affine_normal_propagate — draw and log-weight bit for bit, and the generator where normal_ leaves it."""
+    from aesmc_amd import _philox
+    B, K, dx, dy = shape
+    n, o = operands(min(B, 8), min(K, 64), dx, dy, np.float32, hip_device, seed=3 * B + K + dx)
+    gen = torch.Generator(device=hip_device).manual_seed(B + K)
+    x_prev = torch.randn(B, K, dx, device=hip_device, generator=gen)
+    y = torch.randn(B, dy, device=hip_device, generator=gen)
+    off_q = torch.randn(B, dx, device=hip_device, generator=gen)
+    idx = _ancestors(B, K, hip_device, seed=B + K, spread=1.0) if gather else None
+    off_p = torch.from_numpy(np.random.RandomState(6).randn(dx).astype(np.float32)).to(hip_device)
+    terms = ((o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], off_q))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    torch.manual_seed(1000 + K)
+    torch.randn(17, device=hip_device)                      # some offset into the stream
+    state = torch.cuda.get_rng_state(hip_device)
+    eps = torch.empty(B, K, dx, device=hip_device).normal_()
+    after_normal = torch.cuda.default_generators[hip_device.index].get_offset()
+    torch.cuda.set_rng_state(state, hip_device)
+    reservation = _philox.reserve(B * K * dx, hip_device)
+    assert torch.cuda.default_generators[hip_device.index].get_offset() == after_normal
+    moved = kernels.gather(x_prev, idx) if gather else x_prev
+    want_x = torch.full_like(moved, float("nan"))
+    want_lw = kernels.affine_propagate(moved, eps, y, *terms, scales, out_x=want_x)
+    got_x = torch.full_like(moved, float("nan"))
+    got_lw = kernels.affine_propagate_drawn(x_prev, reservation, y, *terms, scales, out_x=got_x, ancestors=idx)
+    assert got_lw is not None, "the launch declined a shape it should cover"
+    assert torch.equal(got_x, want_x)
+    assert torch.equal(got_lw, want_lw)
+    assert kernels.read_flags(hip_device) == 0
+    assert torch.equal(kernels.philox_normal(reservation, (B, K, dx), hip_device), eps)
+
+
+def test_propagate_with_the_noise_inside_declines_what_it_does_not_cover(kernels, hip_device):
+    from aesmc_amd import _philox
+    for B, K, dx, dy in ((300, 50, 4, 4), (3, 700, 1, 1)):      # short batch rows; one value per particle
+        n, o = operands(B, K, dx, dy, np.float32, hip_device, seed=1)
+        terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+        scales = (o["s_p"], o["s_g"], o["s_q"])
+        reservation = _philox.reserve(B * K * dx, hip_device)
+        out_x = torch.empty_like(o["x_prev"])
+        assert kernels.affine_propagate_drawn(o["x_prev"], reservation, o["y"], *terms, scales, out_x=out_x) is None
+    n, o = operands(4, 600, 10, 10, np.float64, hip_device, seed=1)       # float64: PyTorch draws it by another route
+    terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    reservation = _philox.reserve(4 * 600 * 10, hip_device)
+    assert kernels.affine_propagate_drawn(o["x_prev"], reservation, o["y"], *terms, (o["s_p"], o["s_g"], o["s_q"]),
+                                          out_x=torch.empty_like(o["x_prev"])) is None
+
+
+@pytest.mark.parametrize("grad", [False, True])
+@pytest.mark.parametrize("learn_scales", [False, True])
+def test_a_run_whose_kernels_draw_the_noise_is_the_run_that_lets_torch_draw_it(hip_device, grad, learn_scales):
+    """`infer` with the deferred draws' noise formed inside K16 from PyTorch's Philox stream against the run in
+    which `_standard_normal` materialises it: latents, ancestors, evidence, gradients (also of learned scales)
+    identical bit for bit, and both random streams end in the same state."""
+    from aesmc_amd import _kernels, inference, state
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    runs = {}
+    for inside in (False, True):
+        state.set_kernel_noise(inside)
+        calls = {"drawn": 0}
+        real = provider.affine_propagate_drawn
+
+        def spy(*args, **kwargs):
+            out = real(*args, **kwargs)
+            calls["drawn"] += out is not None
+            return out
+
+        provider.affine_propagate_drawn = spy
+        try:
+            model = LgssmNd(10, dtype=torch.float32, affine=True).tune_proposal().to(hip_device)
+            if learn_scales:
+                for name in ("transition_scale", "emission_scale", "proposal_scale"):
+                    value = getattr(model, name).detach().clone()
+                    delattr(model, name)
+                    model.register_parameter(name, torch.nn.Parameter(value))
+            observations = model.simulate(6, 4, seed=3)
+            torch.manual_seed(11)
+            np.random.seed(11)
+            with torch.set_grad_enabled(grad):
+                out = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                                      model.proposal, 1300, return_log_marginal_likelihood=True, return_latents=False,
+                                      return_log_weight=not grad, return_ancestral_indices=True,
+                                      return_original_latents=True)
+            if grad:
+                (-out["log_marginal_likelihood"].mean()).backward()
+        finally:
+            provider.affine_propagate_drawn = real
+            state.set_kernel_noise(True)
+        after = (torch.rand(1, device=hip_device).item(), np.random.uniform())
+        runs[inside] = (out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, after, calls)
+    (a, grads_a, rng_a, calls_a), (b, grads_b, rng_b, calls_b) = runs[False], runs[True]
+    assert calls_a["drawn"] == 0 and calls_b["drawn"] == 5
+    assert rng_a == rng_b
+    assert torch.equal(a["log_marginal_likelihood"], b["log_marginal_likelihood"])
+    for x, y in zip(a["original_latents"] + a["ancestral_indices"], b["original_latents"] + b["ancestral_indices"]):
+        assert torch.equal(x, y)
+    assert sorted(grads_a) == sorted(grads_b) and (not grad or grads_a)
+    if grad and learn_scales:
+        assert "proposal_scale" in grads_a
+    for name in grads_a:
+        assert torch.equal(grads_a[name], grads_b[name]), name
+
+
+def test_replayed_noise_bypasses_the_kernel_noise(hip_device):
+    """A test harness that replays recorded normals through torch.distributions.normal._standard_normal must see
+    them used: with that function replaced, nothing is reserved and the noise arrives as the tensor it returns."""
+    from aesmc_amd import _kernels, inference
+    from aesmc_amd.testing import replay
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    model = LgssmNd(10, dtype=torch.float32, affine=True).tune_proposal().to(hip_device)
+    observations = model.simulate(4, 3, seed=3)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    with replay.record() as tape, torch.no_grad():
+        first = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal,
+                                700, return_log_marginal_likelihood=True)
+    assert len(tape.normals) == 4
+    calls = {"drawn": 0}
+    real = provider.affine_propagate_drawn
+    provider.affine_propagate_drawn = lambda *a, **k: calls.__setitem__("drawn", calls["drawn"] + 1) or real(*a, **k)
+    try:
+        with replay.replay(tape), torch.no_grad():
+            again = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                                    model.proposal, 700, return_log_marginal_likelihood=True)
+    finally:
+        provider.affine_propagate_drawn = real
+    assert calls["drawn"] == 0
+    assert torch.equal(first["log_marginal_likelihood"], again["log_marginal_likelihood"])
