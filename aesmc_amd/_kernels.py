@@ -1139,7 +1139,7 @@ class HipKernels:
 
     # ---- K14: the whole backward of a step whose x_t is the proposal's reparameterised draw ------
     def affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
-                             grad_lse=None, grad_x=None, grad_lw=None):
+                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None):
         """K14: gradients of one SMC step (log-weights `lw` of K10, their row log-sum-exp `lse`) whose x IS the
         draw  loc_q(x_prev) + s_q eps  of K9 from the same proposal operands, with respect to
         (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q) — x's own slot is always None: the
@@ -1167,6 +1167,13 @@ class HipKernels:
             check(grad_x, (B, K, dx), "grad_x")
         if not fused_lse and grad_lw is None and grad_x is None:
             raise ValueError("aesmc_amd: affine_step_backward needs a gradient: (lw, lse, grad_lse), grad_lw or grad_x")
+        if ancestors is not None:
+            # `x_prev` is the un-resampled latent: the kernel fetches x_prev[b, ancestors[b,k]] itself and slot 0 of
+            # the result is the gradient of those RESAMPLED rows (the caller sums children into ancestors)
+            self._check_index(x_prev, ancestors)
+            if ancestors.shape != (B, K):
+                raise ValueError("aesmc_amd: affine_step_backward ancestors must be [{}, {}]".format(B, K))
+            ancestors = ancestors.contiguous()
         x_prev, x = self._dense16(x_prev), self._dense16(x)
         if y_rows.stride(1) != 1:
             y_rows = y_rows.contiguous()
@@ -1183,12 +1190,20 @@ class HipKernels:
                                          _ptr(rows_p), _ptr(rows_g), _ptr(rows_q))
         maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
         with _on_device(x.device):
-            args = (tag, _ptr(x_prev), _ptr(x), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
-                    ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
-                    _ptr(scales[2]), _ptr(lw) if fused_lse else 0, _ptr(lse) if fused_lse else 0,
-                    _ptr(grad_lse) if fused_lse else 0, _ptr(grad_lw), _ptr(grad_x), ctypes.byref(outs), _ptr(ws),
-                    ws_bytes, B, K, self._stream(x))
-            status = self._lib.aesmc_affine_step_backward(*args)
+            middle = (_ptr(x), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
+                      ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
+                      _ptr(scales[2]), _ptr(lw) if fused_lse else 0, _ptr(lse) if fused_lse else 0,
+                      _ptr(grad_lse) if fused_lse else 0, _ptr(grad_lw), _ptr(grad_x), ctypes.byref(outs), _ptr(ws),
+                      ws_bytes)
+            if ancestors is not None:
+                entry = self._lib.aesmc_affine_step_backward_resampled
+                args = (tag, _ptr(x_prev), _ptr(ancestors)) + middle + (_ptr(self.flags(x.device)), B, K, self._stream(x))
+            else:
+                entry = self._lib.aesmc_affine_step_backward
+                args = (tag, _ptr(x_prev)) + middle + (B, K, self._stream(x))
+            status = entry(*args)
+            if status == 2 and ancestors is not None:       # the unfused route wants the resampled rows as a tensor
+                x_prev, ancestors = self.gather(x_prev, ancestors), None
             if status == 2:     # too few particles per batch row for the fused kernel's row table
                 return self.affine_step_backward_unfused(
                     x_prev, x, y_rows, transition, emission, proposal, scales, need, lw if fused_lse else None,
@@ -1198,9 +1213,11 @@ class HipKernels:
             if self.timer is not None:
                 nbytes = x.element_size() * B * K * (2 * dx + 1 + (dx if grad_x is not None else 0) +
                                                      (dx if gx_prev is not None else 0))
-                self.timer.note("affine_step_backward", (self._lib.aesmc_affine_step_backward, args), nbytes,
-                                (x_prev, x, y_rows, lw, lse, grad_lse, grad_lw, grad_x, outs, ws, maps, scales, gA, gC,
-                                 gQ, gscales, rows_p, rows_g, rows_q, gx_prev))
+                if ancestors is not None:
+                    nbytes += 8 * B * K
+                self.timer.note("affine_step_backward" + ("_resampled" if ancestors is not None else ""), (entry, args),
+                                nbytes, (x_prev, ancestors, x, y_rows, lw, lse, grad_lse, grad_lw, grad_x, outs, ws, maps,
+                                         scales, gA, gC, gQ, gscales, rows_p, rows_g, rows_q, gx_prev))
         fold = lambda rows, off: rows if off.dim() == 2 else rows.sum(dim=0)
         grads = [gx_prev, None, None, gA, None, gC, None, gQ, None, None, None, None]
         if need[2]:

@@ -600,11 +600,9 @@ class _AffineStep(torch.autograd.Function):
         if grad_lse is not None and lse is None:
             raise RuntimeError("aesmc_amd internal error: a step's log-sum-exp received a gradient but was never bound")
         k = _kernels.get()
-        if ancestors is not None:
-            x_prev = k.gather(x_prev, ancestors)      # the resampled latent exists for the length of this backward step
         grads = k.affine_step_backward(
             x_prev, x_value, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q), need, lw, lse,
-            grad_lse=None if grad_lse is None else grad_lse.contiguous(), grad_x=grad_x)
+            grad_lse=None if grad_lse is None else grad_lse.contiguous(), grad_x=grad_x, ancestors=ancestors)
         if ancestors is not None and grads[0] is not None:
             # torch.gather's backward (state.py:179): children's gradients summed into their ancestors; K2's
             # indices are non-decreasing along k, so this is the atomic-free segmented sum

@@ -380,6 +380,58 @@ __device__ __forceinline__ void lg_gather_commit(const LgGather &g, uint32_t np,
   }
 }
 
+// A tile's rows through the ancestors straight into the tile (no register double buffer): for kernels that do
+// not prefetch a tile ahead.  The piece width is a launch-uniform branch here (one kernel for all three).
+template <typename T, int PPL, int DP, bool LG_OPAQUE = false>
+__device__ __forceinline__ void lg_gather_stage(const char *__restrict__ src, const LgGather &g, int64_t n0,
+                                                uint32_t np, uint32_t K, const int64_t (&raw)[PPL],
+                                                T *__restrict__ tile, const LgLayout &l) {
+  char *base = reinterpret_cast<char *>(tile);
+  const uint32_t row_pitch = l.rs * (uint32_t)sizeof(T);
+  const uint32_t b0 = (uint32_t)(n0 / K);
+  const uint32_t k0 = (uint32_t)(n0 - (int64_t)b0 * K);
+  constexpr int BYTES = DP * (int)sizeof(T);
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) {
+    const uint32_t q = lg_tid() + r * kLgBlock;
+    if (q < np) {
+      int64_t a = raw[r];
+      if (a < 0 || a >= (int64_t)K) {
+        raise_flag(g.flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
+        a = a < 0 ? 0 : (int64_t)K - 1;
+      }
+      const uint64_t row = (uint64_t)(b0 + (k0 + q) / K) * K + (uint64_t)a;
+      const char *at = src + row * g.row_bytes;
+      char *to = base + q * row_pitch;
+      if (g.pb == 16) {
+        uint4 x[(BYTES + 15) / 16];
+#pragma unroll
+        for (int c = 0; c < (BYTES + 15) / 16; ++c)
+          if ((uint32_t)c < g.ppr) x[c] = *reinterpret_cast<const uint4 *>(at + c * 16);
+#pragma unroll
+        for (int c = 0; c < (BYTES + 15) / 16; ++c)
+          if ((uint32_t)c < g.ppr) *reinterpret_cast<uint4 *>(to + c * 16) = x[c];
+      } else if (g.pb == 8) {
+        uint2 x[(BYTES + 7) / 8];
+#pragma unroll
+        for (int c = 0; c < (BYTES + 7) / 8; ++c)
+          if ((uint32_t)c < g.ppr) x[c] = *reinterpret_cast<const uint2 *>(at + c * 8);
+#pragma unroll
+        for (int c = 0; c < (BYTES + 7) / 8; ++c)
+          if ((uint32_t)c < g.ppr) *reinterpret_cast<uint2 *>(to + c * 8) = x[c];
+      } else {
+        uint32_t x[BYTES / 4];
+#pragma unroll
+        for (int c = 0; c < BYTES / 4; ++c)
+          if ((uint32_t)c < g.ppr) x[c] = *reinterpret_cast<const uint32_t *>(at + c * 4);
+#pragma unroll
+        for (int c = 0; c < BYTES / 4; ++c)
+          if ((uint32_t)c < g.ppr) *reinterpret_cast<uint32_t *>(to + c * 4) = x[c];
+      }
+    }
+  }
+}
+
 static inline LgGather lg_gather(const int64_t *idx, int32_t *flags, size_t row_bytes) {
   LgGather g;
   g.idx = idx;

@@ -300,6 +300,7 @@ struct LgBackwardOut {
   int row_terms;     // bit 0 / 1 / 2: term p / g / q wants its row sums
   const void *gx_in; // step kernel only: the gradient that arrives at x_t from later steps, or nullptr
   int want_scale_q;  // step kernel only: the proposal scale's gradient is wanted (costs the proposal's location)
+  LgGather gat;      // step kernel only: `xprev` is the un-resampled latent, its rows fetched through gat.idx
 };
 
 template <typename T, int DP, int PPL>
@@ -530,10 +531,24 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
   T *rows = reinterpret_cast<T *>(out.rows);
   const int row_terms = rows != nullptr ? out.row_terms : 0;
   const int64_t tiles = (N + TP - 1) / TP;
+  // through the ancestors (the forward step never wrote x_{t-1}[ancestors]: neither does this): a lane fetches
+  // the rows of its own particles; their indices are loaded one tile ahead
+  const bool gathers = out.gat.idx != nullptr;
+  int64_t ranc[PPL];
+  if (gathers && (int64_t)blockIdx.x < tiles) {
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    lg_anc_prefetch<PPL, true>(out.gat, n0, (uint32_t)min((int64_t)TP, N - n0), ranc);
+  }
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+    if (gathers) {
+      lg_gather_stage<T, PPL, DP, true>(reinterpret_cast<const char *>(xprev), out.gat, n0, np, K, ranc, tprev, lx);
+      const int64_t m0 = (tile + gridDim.x) * TP;
+      if (m0 < N) lg_anc_prefetch<PPL, true>(out.gat, m0, (uint32_t)min((int64_t)TP, N - m0), ranc);
+    } else {
+      lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+    }
     lg_stage_rows<T, true>(x + n0 * dx, np * dx, tx, lx, 0);
     if (gx_in != nullptr) lg_stage_rows<T, true>(gx_in + n0 * dx, np * dx, tu, lx, 0);
     uint32_t p[PPL], brow[PPL], at[PPL];
@@ -814,7 +829,8 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
                                             const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
                                             const aesmc_affine_logweight_grads *o, void *ws, size_t ws_bytes, int64_t B,
                                             int64_t K, hipStream_t stream, bool step = false,
-                                            const void *gx_in = nullptr) {
+                                            const void *gx_in = nullptr, const int64_t *anc_idx = nullptr,
+                                            int32_t *flags = nullptr) {
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
@@ -843,6 +859,8 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;
   out.uq = o->grad_loc_q; out.ws = ws; out.rows = row_ws; out.row_terms = row_terms;
   out.gx_in = gx_in; out.want_scale_q = o->grad_scales != nullptr ? 1 : 0;
+  out.gat = lg_gather(anc_idx, flags, (size_t)dx * sizeof(T));
+  if (anc_idx != nullptr && (!step || N > 0x7fffffffLL)) return AESMC_ERR_UNSUPPORTED;
 #define LG_BACKWARD_ARGS                                                                                            \
   static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), \
       lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),               \
@@ -918,8 +936,40 @@ extern "C" int aesmc_affine_normal_logweight_backward(
 }
 
 
+static int affine_step_backward_entry(
+    int dtype, const void *x_prev, const int64_t *ancestors, int32_t *flags, const void *x, const void *y,
+    int64_t y_stride_b, const aesmc_affine_map *transition,
+    const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+    const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
+    const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K,
+    void *stream);
+
 extern "C" int aesmc_affine_step_backward(
     int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
+    const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+    const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
+    const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K,
+    void *stream) {
+  return affine_step_backward_entry(dtype, x_prev, nullptr, nullptr, x, y, y_stride_b, transition, emission, proposal,
+                                    scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, grad_x, out, ws, ws_bytes, B,
+                                    K, stream);
+}
+
+extern "C" int aesmc_affine_step_backward_resampled(
+    int dtype, const void *x_src, const int64_t *ancestors, const void *x, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
+    const void *grad_lse, const void *grad_lw, const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws,
+    size_t ws_bytes, int32_t *flags, int64_t B, int64_t K, void *stream) {
+  if (ancestors == nullptr || (((uintptr_t)ancestors) & 7u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
+  return affine_step_backward_entry(dtype, x_src, ancestors, flags, x, y, y_stride_b, transition, emission, proposal,
+                                    scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, grad_x, out, ws, ws_bytes, B,
+                                    K, stream);
+}
+
+static int affine_step_backward_entry(
+    int dtype, const void *x_prev, const int64_t *ancestors, int32_t *flags, const void *x, const void *y,
+    int64_t y_stride_b, const aesmc_affine_map *transition,
     const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
     const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
     const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K,
@@ -956,10 +1006,10 @@ extern "C" int aesmc_affine_step_backward(
   return dtype == AESMC_F32
              ? launch_affine_logweight_backward<float>(x_prev, x, y, y_stride_b, transition, emission, proposal,
                                                        scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
-                                                       ws_bytes, B, K, s, true, grad_x)
+                                                       ws_bytes, B, K, s, true, grad_x, ancestors, flags)
              : launch_affine_logweight_backward<double>(x_prev, x, y, y_stride_b, transition, emission, proposal,
                                                         scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
-                                                        ws_bytes, B, K, s, true, grad_x);
+                                                        ws_bytes, B, K, s, true, grad_x, ancestors, flags);
 }
 
 

@@ -189,7 +189,10 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
 #pragma unroll
   for (int r = 0; r < PPL; ++r) {
     const uint32_t slot = tid + r * kLgBlock;
-    seg[r] = slot / RUNP;
+    // RUNP is a multiple of the wavefront: a wavefront's lanes share their window, so everything picked by it
+    // (first particle, count, batch row) is uniform and lives on the scalar unit
+    static_assert(RUNP % kWave == 0, "a window's rows are whole wavefronts");
+    seg[r] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot / RUNP));
     row[r] = slot - seg[r] * RUNP;
   }
   uint32_t rg[PPL * MAXQ * W];
@@ -199,8 +202,14 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
       const bool live = row[r] < pick(it.count, seg[r]);
-      const int64_t n = (int64_t)pick(it.nf, seg[r]) + row[r];
-      ranc[r] = live ? (gat.idx != nullptr ? gat.idx[n] : (int64_t)(n % K)) : 0;
+      const uint32_t first = pick(it.nf, seg[r]);
+      const int64_t n = (int64_t)first + row[r];
+      if (gat.idx != nullptr) {
+        ranc[r] = live ? gat.idx[n] : 0;
+      } else {      // no resampling in front of this step: a particle is its own ancestor
+        const uint32_t k0 = first % K;
+        ranc[r] = (k0 + row[r]) >= K ? (int64_t)(k0 + row[r] - K) : (int64_t)(k0 + row[r]);
+      }
     }
   };
   // the rows of x_{t-1} they point at -> registers
@@ -208,13 +217,14 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
       if (row[r] < pick(it.count, seg[r])) {
-        const uint32_t n = pick(it.nf, seg[r]) + row[r];
+        const uint32_t first = pick(it.nf, seg[r]);       // uniform per window: its divisions run on the scalar unit
+        const uint32_t b0 = first / K, k0 = first - b0 * K;
         int64_t a = ranc[r];
         if (a < 0 || a >= (int64_t)K) {
           raise_flag(gat.flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
           a = a < 0 ? 0 : (int64_t)K - 1;
         }
-        const uint64_t source = (uint64_t)(n / K) * K + (uint64_t)a;
+        const uint64_t source = (uint64_t)(b0 + ((k0 + row[r]) >= K ? 1u : 0u)) * K + (uint64_t)a;
         const char *at = src_bytes + source * gat.row_bytes;
 #pragma unroll
         for (int c = 0; c < MAXQ; ++c) {

@@ -446,6 +446,20 @@ int aesmc_affine_step_backward(
     const void *grad_lse, const void *grad_lw, const void *grad_x, const aesmc_affine_logweight_grads *out,
     void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream);
 
+/* K14 through the ancestor indices: `x_src` is the UN-resampled x_{t-1} and the step's x_prev its rows
+ * x_src[b, ancestors[b,k], :] fetched while the tile is staged (the forward step — aesmc_affine_normal_propagate_
+ * resampled / _drawn — never wrote them, neither does the backward).  Everything else as
+ * aesmc_affine_step_backward; `out->grad_x_prev` is the gradient with respect to the RESAMPLED rows
+ * ([B,K,dx], one per child): the caller sums children into their ancestors (aesmc_resample_gather_backward),
+ * which is torch.gather's backward (aesmc/state.py:179).  An ancestor outside [0, K) is clamped and raises
+ * AESMC_FLAG_INDEX_OUT_OF_RANGE in `flags` (may be NULL). */
+int aesmc_affine_step_backward_resampled(
+    int dtype, const void *x_src, const int64_t *ancestors, const void *x, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
+    const void *grad_lse, const void *grad_lw, const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws,
+    size_t ws_bytes, int32_t *flags, int64_t B, int64_t K, void *stream);
+
 /* K13 — a learned proposal net over the particles: the two-layer tanh MLP
  *   out[b,k,:] = layer2->offset + W2 tanh( layer1->offset[b,:] + W1 x[b,k,:] )
  * with W1 [H, din] (din <= 16, H <= aesmc_particle_mlp_max_hidden() = 64), W2 [dout, H] (dout <= 16);

@@ -174,10 +174,12 @@ class OracleKernels:
         return out
 
     def affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
-                             grad_lse=None, grad_x=None, grad_lw=None):
+                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None):
         """K14's contract by PyTorch's autograd in float64: x is rebuilt as the proposal's draw
         loc_q(x_prev) + s_q eps with eps = (x - loc_q) / s_q held fixed, so every path through it is
         differentiated; x's own slot stays None."""
+        if ancestors is not None:       # slot 0 of the result: the gradient of the RESAMPLED rows
+            x_prev = self.gather(x_prev, ancestors)
         operands = [x_prev, x, y_rows, transition[0], transition[1], emission[0], emission[1], proposal[0],
                     proposal[1]] + list(scales)
         with torch.enable_grad():

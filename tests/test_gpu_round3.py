@@ -158,6 +158,8 @@ def test_a_lazily_resampled_run_is_the_eagerly_gathered_run(hip_device, grad, dt
             calls["propagate_ancestors"] += kwargs.get("ancestors") is not None
             return real_propagate(*args, **kwargs)
 
+        from aesmc_amd import state
+        state.set_kernel_noise(False)       # this test is about the gather alone: torch draws the noise
         provider.gather, provider.affine_propagate = gather_spy, propagate_spy
         try:
             model = LgssmNd(10, dtype=dtype, affine=True).tune_proposal().to(hip_device)
@@ -174,6 +176,7 @@ def test_a_lazily_resampled_run_is_the_eagerly_gathered_run(hip_device, grad, dt
         finally:
             provider.gather, provider.affine_propagate = real_gather, real_propagate
             inference.set_lazy_gather(True)
+            state.set_kernel_noise(True)
         after = (torch.rand(1, device=hip_device).item(), np.random.uniform())
         runs[lazy] = (out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, after, calls)
     (a, grads_a, rng_a, calls_a), (b, grads_b, rng_b, calls_b) = runs[False], runs[True]
@@ -370,3 +373,33 @@ def test_replayed_noise_bypasses_the_kernel_noise(hip_device):
         provider.affine_propagate_drawn = real
     assert calls["drawn"] == 0
     assert torch.equal(first["log_marginal_likelihood"], again["log_marginal_likelihood"])
+
+
+# ---- K14 through the ancestor indices ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(3, 700, 10, 10), (2, 513, 5, 3), (5, 64, 16, 16), (7, 300, 12, 2), (2, 2048, 8, 8),
+                                   (16, 4096, 10, 10), (300, 4096, 10, 10), (520, 2100, 8, 8), (2, 999, 9, 4)])
+def test_step_backward_through_ancestors_equals_gather_then_step_backward(kernels, hip_device, dtype, shape):
+    """aesmc_affine_step_backward_resampled(x_src, ancestors) == aesmc_resample_gather, then
+    aesmc_affine_step_backward: every gradient bit for bit (the gradient of the resampled rows included)."""
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=3 * B + K + dx)
+    idx = _ancestors(B, K, hip_device, seed=B + K, spread=2.0)
+    off_p = torch.from_numpy(np.random.RandomState(4).randn(dx).astype(dtype)).to(hip_device)
+    terms = ((o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    moved = kernels.gather(o["x_prev"], idx)
+    x = kernels.affine_rsample(moved, o["Q"], o["off_q"], o["eps"], o["s_q"])
+    lw = kernels.affine_logweight(moved, x, o["y"], *terms, scales)
+    _, lse = kernels.logweight_lse(lw, None, None, want_lw=False)
+    rng = np.random.RandomState(9)
+    grad_lse = torch.from_numpy(rng.randn(B).astype(dtype)).to(hip_device)
+    grad_x = torch.from_numpy(rng.randn(B, K, dx).astype(dtype)).to(hip_device)
+    need = [True] * 12
+    need[1] = False
+    want = kernels.affine_step_backward(moved, x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse, grad_x=grad_x)
+    got = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse,
+                                       grad_x=grad_x, ancestors=idx)
+    for a, b in zip(got, want):
+        assert (a is None and b is None) or torch.equal(a, b)
+    assert kernels.read_flags(hip_device) == 0
