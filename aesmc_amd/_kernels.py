@@ -173,6 +173,8 @@ class HipKernels:
         self.timer = None  # set to a KernelTimer to time every launch (bench only)
         self.lds_max_particles = int(self._lib.aesmc_ancestor_index_lds_max_particles())
         self._affine_max_dim = None
+        self._map_cache = {}        # id(weight) -> (weight, its aesmc_affine_map, (shape, strides))
+        self._covers_last = None    # the operands of the last step `affine_logweight_covers` accepted
 
     # ---- deferred status word ---------------------------------------------------------------
     def flags(self, device):
@@ -745,19 +747,33 @@ class HipKernels:
             t = t.clone(memory_format=torch.contiguous_format)
         return t
 
-    @staticmethod
-    def _affine_map(weight, offset):
+    def _affine_map(self, weight, offset, slot=None):
         """(aesmc_affine_map, tensors it borrows).  weight may be any 2-D view (a transpose costs
-        nothing); offset is [dout] (shared by every batch row) or [B, dout]."""
-        dout, din = weight.shape
+        nothing); offset is [dout] (shared by every batch row) or [B, dout].  `slot` (the hot per-timestep
+        launchers pass the map's position in their argument list): the struct made for this weight tensor in
+        this position is kept — a model hands the same parameters in at every timestep — and only its offset
+        fields rewritten; the C entry points have read it by the time they return."""
         off_ptr, off_sb = 0, 0
         if offset is not None:
             if offset.stride(-1) != 1:
                 offset = offset.contiguous()
             off_ptr = offset.data_ptr()
             off_sb = offset.stride(0) if offset.dim() == 2 else 0
-        return _lib.AffineMap(weight.data_ptr(), weight.stride(0), weight.stride(1), off_ptr, off_sb, dout, din), \
-            (weight, offset)
+        cached = slot is not None and self.timer is None      # (the timer keeps the structs of the launches it sampled)
+        if cached:
+            entry = self._map_cache.get((id(weight), slot))
+            if entry is not None and entry[0] is weight and entry[1].weight == weight.data_ptr() and \
+                    entry[2] == (weight.shape, weight.stride()):
+                amap = entry[1]
+                amap.offset, amap.offset_stride_b = off_ptr, off_sb
+                return amap, (weight, offset)
+        dout, din = weight.shape
+        amap = _lib.AffineMap(weight.data_ptr(), weight.stride(0), weight.stride(1), off_ptr, off_sb, dout, din)
+        if cached:
+            if len(self._map_cache) > 64:
+                self._map_cache.clear()
+            self._map_cache[(id(weight), slot)] = (weight, amap, (weight.shape, weight.stride()))
+        return amap, (weight, offset)
 
     def particle_affine(self, x1, w1, offset=None, x2=None, w2=None, base=None):
         """K8: base + (offset + x1 @ w1.T + x2 @ w2.T) -> dense [B,K,dout]; x2 / w2, offset, base optional.
@@ -852,7 +868,7 @@ class HipKernels:
         if y_rows.stride(1) != 1:
             y_rows = y_rows.contiguous()
         out = torch.empty((B, K), dtype=eps.dtype, device=eps.device)
-        maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
+        maps = [self._affine_map(*term, slot=slot) for slot, term in enumerate((transition, emission, proposal))]
         with _on_device(eps.device):
             tail = (_ptr(eps), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
                     ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
@@ -887,7 +903,7 @@ class HipKernels:
             return out
         with _on_device(out.device):
             args = (_ptr(out), out.numel(), stream_desc.seed, stream_desc.offset, stream_desc.threads, 0,
-                    self._stream(out))
+                    _ptr(stream_desc.state), self._stream(out))
             _lib.check(self._lib.aesmc_philox_normal_fill(*args), "aesmc_philox_normal_fill")
             if self.timer is not None:
                 self.timer.note("philox_normal_fill", (self._lib.aesmc_philox_normal_fill, args), 4 * out.numel(), (out,))
@@ -916,12 +932,12 @@ class HipKernels:
         if y_rows.stride(1) != 1:
             y_rows = y_rows.contiguous()
         out = torch.empty((B, K), dtype=x_src.dtype, device=x_src.device)
-        maps = [self._affine_map(*term) for term in (transition, emission, proposal)]
+        maps = [self._affine_map(*term, slot=slot) for slot, term in enumerate((transition, emission, proposal))]
         with _on_device(x_src.device):
             args = (_ptr(x_src), _ptr(ancestors), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
                     ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
                     _ptr(scales[2]), _ptr(out_x), _ptr(out), _ptr(self.flags(x_src.device)), B, K, noise.seed,
-                    noise.offset, noise.threads, self._stream(x_src))
+                    noise.offset, noise.threads, _ptr(noise.state), self._stream(x_src))
             status = self._lib.aesmc_affine_normal_propagate_drawn(*args)
             if status == 2:
                 return None
@@ -937,6 +953,18 @@ class HipKernels:
         (weight, offset or None), y_rows the observation [B, dy], scales three one-value tensors."""
         if not (torch.is_tensor(x) and torch.is_tensor(x_prev) and torch.is_tensor(y_rows)):
             return False
+        last = self._covers_last
+        if last is not None and last[0] is transition[0] and last[1] is emission[0] and last[2] is proposal[0] and \
+                last[3] is scales[0] and last[4] is scales[1] and last[5] is scales[2]:
+            # the very parameter tensors of the step accepted last (a model's next timestep): what can differ are
+            # the per-step operands — shapes, dtypes and devices of x_{t-1}, x_t, the observation and the offsets
+            shape, dtype, device = last[6]
+            weight = transition[0]
+            if x.shape == shape and x_prev.shape == shape and x.dtype == dtype and x_prev.dtype == dtype and \
+                    x.device == device and x_prev.device == device and weight.dtype == dtype and weight.device == device \
+                    and y_rows.dtype == dtype and y_rows.device == device and y_rows.shape == last[7] and \
+                    self._offsets_signature(transition[1], emission[1], proposal[1], dtype, device) == last[8]:
+                return True
         if x_prev.shape != x.shape or x_prev.dtype != x.dtype or x_prev.device != x.device:
             return False
         if not (self.affine_covers(x_prev, *transition) and self.affine_covers(x, *emission) and
@@ -948,8 +976,27 @@ class HipKernels:
         if y_rows.dim() != 2 or y_rows.shape != (x.size(0), emission[0].size(0)) or \
                 y_rows.dtype != x.dtype or y_rows.device != x.device:
             return False
-        return all(torch.is_tensor(s) and s.numel() == 1 and s.dtype == x.dtype and s.device == x.device
-                   for s in scales)
+        if not all(torch.is_tensor(s) and s.numel() == 1 and s.dtype == x.dtype and s.device == x.device
+                   for s in scales):
+            return False
+        signature = self._offsets_signature(transition[1], emission[1], proposal[1], x.dtype, x.device)
+        if signature is not None:
+            self._covers_last = (transition[0], emission[0], proposal[0], scales[0], scales[1], scales[2],
+                                 (x.shape, x.dtype, x.device), y_rows.shape, signature)
+        return True
+
+    @staticmethod
+    def _offsets_signature(off_p, off_g, off_q, dtype, device):
+        """Shapes of the three offsets (None where absent) when they are tensors of `dtype` on `device`, else None."""
+        out = []
+        for offset in (off_p, off_g, off_q):
+            if offset is None:
+                out.append(None)
+            elif torch.is_tensor(offset) and offset.dtype == dtype and offset.device == device:
+                out.append(offset.shape)
+            else:
+                return None
+        return tuple(out)
 
     def affine_logweight(self, x_prev, x, y_rows, transition, emission, proposal, scales):
         """K10: the step's log-weight [B,K] with the three locations affine in the particles (see

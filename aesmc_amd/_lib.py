@@ -91,8 +91,8 @@ SIGNATURES = {
     "aesmc_affine_normal_propagate_resampled": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp,
                                                        _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_normal_propagate_drawn": (_i32, [_vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp, _vp,
-                                                   _vp, _i64, _i64, _u64, _u64, _i64, _vp]),
-    "aesmc_philox_normal_fill": (_i32, [_vp, _i64, _u64, _u64, _i64, _i32, _vp]),
+                                                   _vp, _i64, _i64, _u64, _u64, _i64, _vp, _vp]),
+    "aesmc_philox_normal_fill": (_i32, [_vp, _i64, _u64, _u64, _i64, _i32, _vp, _vp]),
 }
 
 _lib = None

@@ -304,9 +304,16 @@ def resample_step(log_weight, uniforms, payload=None, want_lse=False, pending=No
         payload = None
     bind = pending is not None and want_lse and torch.is_grad_enabled()
     wants_grad = torch.is_grad_enabled() and (
-        bind or (want_lse and log_weight.requires_grad) or
+        (want_lse and log_weight.requires_grad and not bind) or
         (payload is not None and payload.requires_grad and payload.is_floating_point()))
-    if wants_grad and bind:
+    if bind and not wants_grad:
+        # the log-sum-exp belongs to a step node: no autograd node here at all — `infer` ties the VALUE to the
+        # node's carrier once, for all timesteps together (bind_rows)
+        idx, lse, moved = k.resample_step(log_weight.detach(), uniforms, None if payload is None else payload.detach(),
+                                          want_lse)
+        pending.box[0] = lse
+        lse = LseOf(lse, pending)
+    elif wants_grad and bind:
         idx, lse, moved = _ResampleStep.apply(log_weight, uniforms, payload, want_lse, pending.carrier)
         pending.box[0] = lse.detach()
     elif wants_grad:
@@ -389,29 +396,6 @@ def _affine_rsample_backward(ctx, grad, source, weight, eps):
     return gsrc, gw, goff, gscale, None
 
 
-class _DeferredAffineRsample(torch.autograd.Function):
-    """The draw of `_AffineRsample` with its VALUES still to come: forward only allocates the [B,K,dout]
-    result — the launch that weighs the step (K15) or, failing that, K9 fills it before anything reads
-    it (state.materialise_draw) — while the backward is the draw's own, valid whenever it runs."""
-
-    @staticmethod
-    def forward(ctx, source, weight, offset, scale, eps, poison):
-        reserved = isinstance(eps, _philox.NoiseStream)      # the noise left to a kernel: formed again if ever needed
-        ctx.save_for_backward(source, weight, eps if (scale.requires_grad and not reserved) else None)
-        ctx.reserved = eps if (scale.requires_grad and reserved) else None
-        ctx.offset_shape = None if offset is None else tuple(offset.shape)
-        ctx.scale_shape = tuple(scale.shape)
-        return _placeholder(source, weight, poison)
-
-    @staticmethod
-    def backward(ctx, grad):
-        if ctx.reserved is not None:
-            source, weight, _ = ctx.saved_tensors
-            eps = _kernels.get().philox_normal(ctx.reserved, tuple(grad.shape), grad.device)
-            return _affine_rsample_backward(ctx, grad, source, weight, eps) + (None,)
-        return _AffineRsample.backward(ctx, grad) + (None,)
-
-
 def _placeholder(source, weight, poison):
     shape = source.shape[:2] + (weight.size(0),)
     if poison:      # anything that reads the values before they exist sees NaN, not stale memory
@@ -419,48 +403,12 @@ def _placeholder(source, weight, poison):
     return torch.empty(shape, dtype=source.dtype, device=source.device)
 
 
-class _DeferredAffineRsampleResampled(torch.autograd.Function):
-    """_DeferredAffineRsample whose source is x_{t-1}[ancestors] not gathered yet: the node keeps (x_{t-1},
-    ancestors) and gathers only if its backward ever runs (the fused step differentiates the draw itself;
-    this node serves any OTHER differentiable use of the draw)."""
-
-    @staticmethod
-    def forward(ctx, source, ancestors, weight, offset, scale, eps, poison):
-        reserved = isinstance(eps, _philox.NoiseStream)
-        ctx.save_for_backward(source, ancestors, weight, eps if (scale.requires_grad and not reserved) else None)
-        ctx.reserved = eps if (scale.requires_grad and reserved) else None
-        ctx.offset_shape = None if offset is None else tuple(offset.shape)
-        ctx.scale_shape = tuple(scale.shape)
-        return _placeholder(source, weight, poison)
-
-    @staticmethod
-    def backward(ctx, grad):
-        source, ancestors, weight, eps = ctx.saved_tensors
-        k = _kernels.get()
-        if ctx.reserved is not None:
-            eps = k.philox_normal(ctx.reserved, tuple(grad.shape), grad.device)
-        need_src, _, need_w, need_off, need_scale = ctx.needs_input_grad[:5]
-        need_off = need_off and ctx.offset_shape is not None
-        gsrc, gw, rows = k.particle_affine_backward(grad.contiguous(), k.gather(source, ancestors), weight, need_src,
-                                                    need_w, need_off)
-        if gsrc is not None:
-            gsrc = k.gather_backward(gsrc, ancestors, sorted_index=bool(getattr(ancestors, "_aesmc_sorted", False)))
-        goff = None if not need_off else (rows if len(ctx.offset_shape) == 2 else rows.sum(dim=0))
-        gscale = (grad * eps).sum().reshape(ctx.scale_shape) if need_scale else None
-        return gsrc, None, gw, goff, gscale, None, None
-
-
-def affine_rsample_deferred(source, weight, offset, scale, eps, poison=True):
-    """A [B,K,dout] tensor standing for the reparameterised draw whose values come later (K15 or K9).
-    `poison`: filled with NaN until then (one fill launch) instead of left uninitialised."""
-    tensors = (source, weight, offset, scale)
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        pending = source.pending if type(source) is LazyResampled else None
-        if pending is not None:
-            return _DeferredAffineRsampleResampled.apply(pending[0], pending[1], weight, offset, scale, eps, poison)
-        if type(source) is LazyResampled:
-            source = source.materialise()
-        return _DeferredAffineRsample.apply(source, weight, offset, scale, eps, poison)
+def affine_rsample_deferred(source, weight, poison=True):
+    """A [B,K,dout] tensor standing for the reparameterised draw whose values come later (K16 / K15, or K9).
+    `poison`: filled with NaN until then (one fill launch) instead of left uninitialised.  It carries NO
+    autograd node: the fused step differentiates the draw inside its own node (K14), and when the step turns
+    out not to be fused, `state.materialise_draw` draws differentiably (K9) and copies the result in — which
+    ties this very tensor to the draw's operands for every use that follows."""
     return _placeholder(source, weight, poison)
 
 
@@ -541,6 +489,14 @@ class _AffineLogWeightLSE(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class LseOf:
+    """A step's row log-sum-exp as a plain value plus the step node it belongs to (see bind_rows)."""
+    __slots__ = ("value", "pending")
+
+    def __init__(self, value, pending):
+        self.value, self.pending = value, pending
+
+
 class PendingStep:
     """The link between a step's autograd node (_AffineStep, made when the step is weighed) and its row
     log-sum-exp, which the NEXT resampling launch produces: `carrier` is the node's [B] output that takes
@@ -554,6 +510,28 @@ class PendingStep:
     def bind(self, lse):
         self.box[0] = lse
         return _BindLse.apply(self.carrier, lse)
+
+
+class _BindRows(torch.autograd.Function):
+    """stack [T,B] of per-step row log-sum-exps whose rows `positions` are VALUES produced by resampling launches
+    for steps that own a `_AffineStep` node: the gradient of row positions[i] goes to carriers[i] (one node per
+    ELBO instead of one per timestep); the other rows differentiate through `stack` as they are."""
+
+    @staticmethod
+    def forward(ctx, stack, positions, *carriers):
+        ctx.positions = positions
+        return stack.view_as(stack)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (grad, None) + tuple(grad[position] for position in ctx.positions)
+
+
+def bind_rows(stack, bound):
+    """`bound`: [(row, PendingStep)] — ties those rows of the [T,B] stack to their steps' nodes."""
+    if not bound or not torch.is_grad_enabled():
+        return stack
+    return _BindRows.apply(stack, [row for row, _ in bound], *[pending.carrier for _, pending in bound])
 
 
 class _BindLse(torch.autograd.Function):
@@ -648,7 +626,9 @@ def affine_propagate(operands, eps):
     step's log-weights [B,K] — K9 and K10 in one launch, the same bits as the two.  With
     `operands.pending_gather` the launch also performs the resampling gather of x_{t-1} on the way in; if it
     declines the shape, the gather happens first (and `operands.pending_gather` is cleared)."""
-    x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = [None if t is None else t.detach() for t in operands[1:]]
+    # (no autograd node is made here and the launcher only takes addresses: the operands go in as they are)
+    x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = operands[1:]
+    x = x.detach()
     k = _kernels.get()
     if isinstance(eps, _philox.NoiseStream):
         # the noise was only RESERVED in PyTorch's generator: K16 forms it (and, if pending, the gather) in the launch
@@ -657,7 +637,7 @@ def affine_propagate(operands, eps):
         else:
             x_prev = operands[0]
             source, ancestors = (x_prev.materialise() if type(x_prev) is LazyResampled else x_prev), None
-        lw = k.affine_propagate_drawn(source.detach(), eps, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q),
+        lw = k.affine_propagate_drawn(source, eps, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q),
                                       out_x=x, ancestors=ancestors)
         if lw is not None:
             return lw

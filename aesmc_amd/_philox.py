@@ -8,10 +8,20 @@ by what `normal_` would have consumed, and returns the stream descriptor a kerne
 values where it consumes them.  Everything drawn afterwards — by PyTorch or by this package — is unchanged.
 """
 import collections
+import contextlib
+import contextvars
 
 import torch
 
-NoiseStream = collections.namedtuple("NoiseStream", "seed offset threads numel")
+# `state`: None, or — inside a hipGraph capture — the device tensor [seed, offset] the captured launches read when
+# they run; `offset` is then relative to it
+NoiseStream = collections.namedtuple("NoiseStream", "seed offset threads numel state", defaults=(None,))
+
+# how much of the generator was consumed through this module (eager): `reserved` by launches that draw inside
+# kernels, `replaceable` by `state.sample`'s own torch draws, which a capture replaces by the fill kernel.  A
+# GraphedLoss compares their sum over one warm-up evaluation with what the generator actually advanced by: equal
+# means every draw of the captured region is one this module can place itself.
+COUNTERS = {"reserved": 0, "replaceable": 0}
 
 _BLOCK = 256
 _GEOMETRY = {}
@@ -35,15 +45,72 @@ def consumed(numel, threads):
     return 4 * ((numel - 1) // (threads * 4) + 1)
 
 
-def reserve(numel, device):
-    """The stream descriptor of the next `torch.empty(numel, device=device).normal_()` — and the generator
-    advanced as if that call had been made."""
+def _generator(device):
     index = device.index if device.index is not None else torch.cuda.current_device()
     if not torch.cuda.default_generators:
         torch.cuda.init()
-    generator = torch.cuda.default_generators[index]
+    return torch.cuda.default_generators[index]
+
+
+def reserve(numel, device):
+    """The stream descriptor of the next `torch.empty(numel, device=device).normal_()` — and the generator
+    advanced as if that call had been made.  Inside a hipGraph capture under `graph_noise_scope` the descriptor
+    points at the scope's device-resident generator state instead (see GraphNoise)."""
     threads = launch_threads(numel, device)
+    used = consumed(numel, threads)
+    scope = _GRAPH_NOISE.get()
+    if scope is not None and torch.cuda.is_current_stream_capturing():
+        stream = NoiseStream(0, scope.consumed, threads, numel, scope.state)
+        scope.consumed += used
+        return stream
+    generator = _generator(device)
     offset = generator.get_offset()
     stream = NoiseStream(generator.initial_seed(), offset, threads, numel)
-    generator.set_offset(offset + consumed(numel, threads))
+    generator.set_offset(offset + used)
+    COUNTERS["reserved"] += used
     return stream
+
+
+class GraphNoise:
+    """The generator state of one captured ELBO (aesmc_amd/graphs.py).  PyTorch hands its own captured kernels
+    (seed, offset) through device memory it refreshes before every replay; the launches of this package that draw
+    inside kernels do the same with a buffer of their own: `upload()` before a replay writes the generator's
+    current (seed, offset), the captured launches add the offsets they were captured with (`consumed` so far in
+    the region), and `advance()` afterwards moves the generator by the region's total — exactly what the eager
+    evaluation consumes, in the same order."""
+
+    def __init__(self, device):
+        self.device = device
+        self.host = torch.zeros(2, dtype=torch.int64, pin_memory=True)
+        self.state = torch.zeros(2, dtype=torch.int64, device=device)
+        self.consumed = 0
+
+    def upload(self):
+        generator = _generator(self.device)
+        self.host[0] = _as_int64(generator.initial_seed())
+        self.host[1] = generator.get_offset()
+        self.state.copy_(self.host, non_blocking=True)
+
+    def advance(self):
+        generator = _generator(self.device)
+        generator.set_offset(generator.get_offset() + self.consumed)
+
+
+def _as_int64(value):
+    return value - (1 << 64) if value >= (1 << 63) else value
+
+
+_GRAPH_NOISE = contextvars.ContextVar("aesmc_amd_graph_noise", default=None)
+
+
+def graph_noise():
+    return _GRAPH_NOISE.get()
+
+
+@contextlib.contextmanager
+def graph_noise_scope(scope):
+    token = _GRAPH_NOISE.set(scope)
+    try:
+        yield scope
+    finally:
+        _GRAPH_NOISE.reset(token)

@@ -46,8 +46,9 @@ template <typename T, int DP, int PPL, int PB>
 __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kernel(
     const T *__restrict__ xsrc, const T *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg, LgMap mq,
     const T *__restrict__ sp_ptr, const T *__restrict__ sg_ptr, const T *__restrict__ sq_ptr, T *__restrict__ out_lw,
-    int64_t N, uint32_t K, uint32_t Bn, T *__restrict__ out_x, LgGather gat, PhiloxStream ps, LgNoisePlan plan) {
+    int64_t N, uint32_t K, uint32_t Bn, T *__restrict__ out_x, LgGather gat, PhiloxStream ps_in, LgNoisePlan plan) {
   static_assert(sizeof(T) == 4, "the in-kernel noise is torch's float32 stream");
+  const PhiloxStream ps = philox_resolve(ps_in);
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL, RUNP = TP / 4;
   constexpr int MAXQ = (DP * (int)sizeof(T) + PB - 1) / PB;
@@ -392,7 +393,8 @@ static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_id
                                          const aesmc_affine_map *mp, const aesmc_affine_map *mg,
                                          const aesmc_affine_map *mq, const void *sp, const void *sg, const void *sq,
                                          void *out_x, void *out_lw, int32_t *flags, int64_t B, int64_t K,
-                                         uint64_t seed, uint64_t offset, int64_t threads, hipStream_t stream) {
+                                         uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *rng_state,
+                                         hipStream_t stream) {
   using T = float;
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
@@ -425,12 +427,7 @@ static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_id
   plan.trips = (uint32_t)((numel + 4ull * (uint64_t)threads - 1) / (4ull * (uint64_t)threads));
   const uint64_t items = (uint64_t)plan.trips * plan.blocks;
   if (items > 0x7fffffffull) return AESMC_ERR_UNSUPPORTED;
-  PhiloxStream ps;
-  ps.key0 = (uint32_t)seed;
-  ps.key1 = (uint32_t)(seed >> 32);
-  ps.base_lo = (uint32_t)(offset >> 2);
-  ps.base_hi = (uint32_t)(offset >> 34);
-  ps.threads = (uint32_t)threads;
+  const PhiloxStream ps = philox_stream(seed, offset, threads, rng_state);
   const LgGather gat = lg_gather(anc_idx, flags, (size_t)dx * sizeof(T));
   const dim3 grid(lg_persistent_grid((int64_t)items, lds, 2));
 #define LG_NOISE_ARGS                                                                                                \
@@ -481,12 +478,13 @@ extern "C" int aesmc_affine_normal_propagate_drawn(
     const void *x_src, const int64_t *ancestors, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
     const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
     const void *scale_q, void *out_x, void *out_lw, int32_t *flags, int64_t B, int64_t K, uint64_t seed,
-    uint64_t offset, int64_t threads, void *stream) {
+    uint64_t offset, int64_t threads, const uint64_t *rng_state, void *stream) {
   if (x_src == nullptr || y == nullptr || transition == nullptr || emission == nullptr || proposal == nullptr ||
       scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || out_lw == nullptr || out_x == nullptr || B < 0 ||
       K < 0 || threads <= 0 || (threads % 256) != 0 || threads > 0x7fffffffLL || (offset & 3u) != 0)
     return AESMC_ERR_INVALID_ARGUMENT;
-  if (!aligned16(x_src) || !aligned16(out_x) || out_x == x_src || (((uintptr_t)ancestors) & 7u) != 0)
+  if (!aligned16(x_src) || !aligned16(out_x) || out_x == x_src || (((uintptr_t)ancestors) & 7u) != 0 ||
+      (((uintptr_t)rng_state) & 7u) != 0)
     return AESMC_ERR_INVALID_ARGUMENT;
   if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
   const int64_t dx = transition->dout;
@@ -494,6 +492,6 @@ extern "C" int aesmc_affine_normal_propagate_drawn(
     return AESMC_ERR_UNSUPPORTED;
   if (B == 0 || K == 0) return AESMC_OK;
   return launch_affine_propagate_noise(x_src, ancestors, y, y_stride_b, transition, emission, proposal, scale_p,
-                                       scale_g, scale_q, out_x, out_lw, flags, B, K, seed, offset, threads,
+                                       scale_g, scale_q, out_x, out_lw, flags, B, K, seed, offset, threads, rng_state,
                                        static_cast<hipStream_t>(stream));
 }

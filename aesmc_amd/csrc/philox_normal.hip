@@ -10,7 +10,8 @@ namespace aesmc {
 
 template <bool FUSED>
 __global__ __launch_bounds__(256) void philox_normal_fill_kernel(float *__restrict__ out, int64_t numel,
-                                                                 PhiloxStream s) {
+                                                                 PhiloxStream stream) {
+  const PhiloxStream s = philox_resolve(stream);
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint64_t G = s.threads;
   const uint64_t span = 4 * G;
@@ -27,18 +28,14 @@ __global__ __launch_bounds__(256) void philox_normal_fill_kernel(float *__restri
 }  // namespace aesmc
 
 extern "C" int aesmc_philox_normal_fill(void *out, int64_t numel, uint64_t seed, uint64_t offset, int64_t threads,
-                                        int variant, void *stream) {
+                                        int variant, const uint64_t *rng_state, void *stream) {
   using namespace aesmc;
   if (out == nullptr || numel < 0 || threads <= 0 || (threads % 256) != 0 || threads > 0x7fffffffLL ||
       (offset & 3u) != 0)
     return AESMC_ERR_INVALID_ARGUMENT;
   if (numel == 0) return AESMC_OK;
-  PhiloxStream s;
-  s.key0 = (uint32_t)seed;
-  s.key1 = (uint32_t)(seed >> 32);
-  s.base_lo = (uint32_t)(offset >> 2);
-  s.base_hi = (uint32_t)(offset >> 34);
-  s.threads = (uint32_t)threads;
+  if ((((uintptr_t)rng_state) & 7u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
+  const PhiloxStream s = philox_stream(seed, offset, threads, rng_state);
   const dim3 grid((unsigned)(threads / 256));
   hipStream_t hs = static_cast<hipStream_t>(stream);
   if (variant == 0)

@@ -30,7 +30,34 @@ struct PhiloxStream {
   uint32_t key0, key1;      // seed
   uint32_t base_lo, base_hi;  // offset / 4: the counter of a thread's first trip
   uint32_t threads;         // G
+  // hipGraph replays: (seed, offset) live in device memory, refreshed by the host before each replay; the
+  // launch's own offset above is then relative to it (what the captured region consumed before this launch)
+  const uint64_t *state;
 };
+
+static inline PhiloxStream philox_stream(uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *state) {
+  PhiloxStream s;
+  s.key0 = (uint32_t)seed;
+  s.key1 = (uint32_t)(seed >> 32);
+  s.base_lo = (uint32_t)(offset >> 2);
+  s.base_hi = (uint32_t)(offset >> 34);
+  s.threads = (uint32_t)threads;
+  s.state = state;
+  return s;
+}
+
+// first thing in a kernel: the stream with a device-resident generator state folded in
+__device__ __forceinline__ PhiloxStream philox_resolve(PhiloxStream s) {
+  if (s.state != nullptr) {
+    const uint64_t seed = s.state[0];
+    const uint64_t base = (s.state[1] >> 2) + (((uint64_t)s.base_hi << 32) | s.base_lo);
+    s.key0 = (uint32_t)seed;
+    s.key1 = (uint32_t)(seed >> 32);
+    s.base_lo = (uint32_t)base;
+    s.base_hi = (uint32_t)(base >> 32);
+  }
+  return s;
+}
 
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1) {

@@ -41,6 +41,7 @@ import torch
 import torch.distributed as dist
 
 from . import _kernels
+from . import _philox
 from . import distributed
 from . import inference
 
@@ -156,12 +157,23 @@ class GraphedLoss:
         kernels.flags(self.device)                       # allocate the status word before capture
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
+        self.noise = None
         with torch.cuda.stream(side):                    # warm-up on a side stream, as PyTorch asks
             for _ in range(warmup):
+                generator = _philox._generator(self.device)
+                before, counted = generator.get_offset(), sum(_philox.COUNTERS.values())
                 self._evaluate(refill=True)
+                advanced, counted = generator.get_offset() - before, sum(_philox.COUNTERS.values()) - counted
                 if backward:
                     for p in self.parameters:
                         p.grad = None
+            # Launches that draw their noise inside kernels need the generator state on the device during replays
+            # (`_philox.GraphNoise`).  That is only sound when EVERY draw of the evaluation is one this package
+            # places itself — PyTorch's own captured draws would not see what ours consumed: the generator must have
+            # advanced by exactly what went through `_philox` in the last warm-up evaluation.  Otherwise the capture
+            # runs with PyTorch drawing all the noise, as in rounds 1-2.
+            if warmup > 0 and _philox.COUNTERS["reserved"] > 0 and advanced == counted and counted > 0:
+                self.noise = _philox.GraphNoise(self.device)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         inference._raise_for_flags(kernels.read_flags(self.device))
@@ -176,7 +188,7 @@ class GraphedLoss:
         error_mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         try:
             with torch.cuda.graph(self.graph, capture_error_mode=error_mode):
-                self.static_loss = self._evaluate(refill=False)
+                self.static_loss = self._evaluate(refill=False, capturing=True)
         except RuntimeError as error:
             if "captur" not in str(error).lower():
                 raise
@@ -203,8 +215,7 @@ class GraphedLoss:
         try:
             for replay in range(replays):
                 cuda_state, numpy_state = torch.cuda.get_rng_state(self.device), np.random.get_state()
-                self._refill()
-                self.graph.replay()
+                self._replay()
                 graph_loss = self.static_loss.clone()
                 graph_grads = [None if g is None else g.clone() for g in static]
                 for p in params:
@@ -251,13 +262,37 @@ class GraphedLoss:
             with self._shard_scope():
                 self.feed.refill_and_upload()
 
-    def _evaluate(self, refill):
+    def _replay(self):
+        """One replay with the random inputs it needs in place: the uniforms (drawn and uploaded), the generator
+        state the noise-drawing launches read, and the generator moved on by what they consume."""
+        self._refill()      # stream order keeps the upload behind the previous replay's reads
+        if self.noise is not None:
+            self.noise.upload()
+        self.graph.replay()
+        if self.noise is not None:
+            self.noise.advance()
+
+    def _evaluate(self, refill, capturing=False):
         num_particles, algorithm, initial, transition, emission, proposal = self._args
         if refill:
             self._refill()
         if self.feed is not None:
             self.feed.begin()
-        with inference.uniform_feed(self.feed):
+        from . import state
+        noise_scope = contextlib.nullcontext()
+        noise_was = state._KERNEL_NOISE
+        if capturing:
+            if self.noise is not None:
+                noise_scope = _philox.graph_noise_scope(self.noise)
+            else:
+                state.set_kernel_noise(False)       # every draw through PyTorch's own captured generator state
+        try:
+            return self._evaluate_body(noise_scope, num_particles, algorithm, initial, transition, emission, proposal)
+        finally:
+            state.set_kernel_noise(noise_was)
+
+    def _evaluate_body(self, noise_scope, num_particles, algorithm, initial, transition, emission, proposal):
+        with noise_scope, inference.uniform_feed(self.feed):
             result = inference.infer(
                 {"iwae": "is", "aesmc": "smc"}[algorithm], self.static_observations, initial,
                 transition, emission, proposal, num_particles, return_log_marginal_likelihood=True,
@@ -286,8 +321,7 @@ class GraphedLoss:
         if observations is not None:
             for static, fresh in zip(self.static_observations, observations):
                 static.copy_(fresh, non_blocking=True)
-        self._refill()      # stream order keeps the upload behind the previous replay's reads
-        self.graph.replay()
+        self._replay()
         self.replays += 1
         if self.check_flags:
             self.check()

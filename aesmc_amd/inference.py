@@ -92,8 +92,11 @@ class _UniformFeed:
         if device.type == "cuda":
             self.host = torch.empty((max(num_draws, 1), batch_size), dtype=torch.float64,
                                     pin_memory=True)
+            self.host_np = self.host.numpy()      # the same pinned memory: a draw is written straight into it
             self.dev = torch.empty((max(num_draws, 1), batch_size), dtype=torch.float64,
                                    device=device)
+            self.host_rows = list(self.host.unbind(0))
+            self.dev_rows = list(self.dev.unbind(0))
         else:
             self.host = self.dev = None
 
@@ -101,11 +104,12 @@ class _UniformFeed:
         draw = draw_uniform_block(self.batch_size)
         if self.host is None:
             return torch.from_numpy(draw)
-        slot = self.cursor % self.host.size(0)
+        slot = self.cursor % len(self.host_rows)
         self.cursor += 1
-        self.host[slot].copy_(torch.from_numpy(draw))
-        self.dev[slot].copy_(self.host[slot], non_blocking=True)
-        return self.dev[slot]
+        self.host_np[slot] = draw
+        row = self.dev_rows[slot]
+        row.copy_(self.host_rows[slot], non_blocking=True)
+        return row
 
 
 def draw_uniform_block(batch_size):
@@ -296,6 +300,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
     feed = None
     device = None
     lazy_gather = _LAZY_GATHER
+    bound_rows = []       # (timestep, PendingStep): rows of the log-sum-exp stack that are values owned by step nodes
 
     for time in range(num_timesteps):
         if time == 0:
@@ -322,6 +327,9 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                 if step_lse[-1] is None:
                     if pending is not None:
                         del deferred[time - 1]
+                        if isinstance(lse_previous, _ops.LseOf):     # a value; tied to its step's node at the end
+                            bound_rows.append((time - 1, lse_previous.pending))
+                            lse_previous = lse_previous.value
                         step_lse[-1] = lse_previous
                     else:
                         step_lse[-1] = lse_previous if (time - 1) not in deferred else \
@@ -417,7 +425,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
     if use_smc:
         if return_log_marginal_likelihood:
             log_marginal_likelihood = torch.sum(
-                torch.stack(step_lse, dim=0) - log_num_particles, dim=0)
+                _ops.bind_rows(torch.stack(step_lse, dim=0), bound_rows) - log_num_particles, dim=0)
         if return_latents:
             latents = get_resampled_latents(originals, indices)
         if return_log_weight:

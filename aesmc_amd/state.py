@@ -263,10 +263,29 @@ def set_kernel_noise(enabled):
 
 def _kernel_noise_applies(source):
     """Float32 on the HIP device, PyTorch's `_standard_normal` in place (tests replay recorded noise through
-    it), outside a hipGraph capture (a captured generator state lives on the device)."""
+    it), and — inside a hipGraph capture — a `_philox.GraphNoise` scope to hold the generator state on the device
+    (graphs.GraphedLoss opens one when every draw of the ELBO is one this package can place itself)."""
     return (_KERNEL_NOISE and source.is_cuda and source.dtype == torch.float32 and _kernels.get().name == "hip" and
             torch.distributions.normal._standard_normal is _TORCH_STANDARD_NORMAL and
-            not torch.cuda.is_current_stream_capturing())
+            (_philox.graph_noise() is not None or not torch.cuda.is_current_stream_capturing()))
+
+
+def _standard_normal(shape, dtype, device):
+    """`torch.distributions.normal._standard_normal` as `Normal.rsample` calls it (aesmc/state.py:98) — except
+    inside a hipGraph capture that holds the generator state itself (`_philox.GraphNoise`): there the same values
+    come from aesmc_philox_normal_fill, so that every draw of the captured region sits at the offset the eager
+    evaluation gives it.  Outside a capture the call is only counted (see `_philox.COUNTERS`)."""
+    draw = torch.distributions.normal._standard_normal
+    if draw is _TORCH_STANDARD_NORMAL and dtype == torch.float32 and device.type == "cuda" and _KERNEL_NOISE and \
+            _kernels.get().name == "hip":
+        numel = 1
+        for size in shape:
+            numel *= size
+        if numel > 0:
+            if _philox.graph_noise() is not None and torch.cuda.is_current_stream_capturing():
+                return _kernels.get().philox_normal(_philox.reserve(numel, device), tuple(shape), device)
+            _philox.COUNTERS["replaceable"] += _philox.consumed(numel, _philox.launch_threads(numel, device))
+    return draw(shape, dtype=dtype, device=device)
 
 
 def _noise_tensor(noise, latent):
@@ -288,10 +307,18 @@ def materialise_draw(latent):
     eps = getattr(latent, "_aesmc_pending_noise", None) if torch.is_tensor(latent) else None
     if eps is not None:
         base = latent._aesmc_draw_of
-        offset = None if base.offset is None else base.offset.detach()
-        _kernels.get().affine_rsample(base.source.detach(), base.weight.detach(), offset, _noise_tensor(eps, latent),
-                                      base.scale_param.detach(), out=latent.detach())
         del latent._aesmc_pending_noise
+        eps = _noise_tensor(eps, latent)
+        operands = (base.source, base.weight, base.offset, base.scale_param)
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in operands):
+            # the placeholder has no autograd node of its own (`_ops.affine_rsample_deferred`): draw through the
+            # differentiable operator and copy in — the in-place copy makes THIS tensor a function of the draw's
+            # operands for everything that uses it from here on
+            latent.copy_(_ops.affine_rsample(base.source, base.weight, base.offset, base.scale_param, eps))
+        else:
+            offset = None if base.offset is None else base.offset.detach()
+            _kernels.get().affine_rsample(base.source.detach(), base.weight.detach(), offset, eps,
+                                          base.scale_param.detach(), out=latent.detach())
     return latent
 
 
@@ -381,8 +408,7 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
                 eps = _philox.reserve(base.source.numel() // base.source.size(-1) * base.weight.size(0),
                                       base.source.device)
             else:
-                eps = torch.distributions.normal._standard_normal(base.batch_shape, dtype=base.source.dtype,
-                                                                   device=base.source.device)
+                eps = _standard_normal(base.batch_shape, dtype=base.source.dtype, device=base.source.device)
             if not deferred and type(base.source) is LazyResampled:
                 base.source.materialise()       # K9 reads x_{t-1}[ancestors]
             if deferred:
@@ -390,8 +416,7 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
                 # else needs them (`materialise_draw`)
                 # (with argument validation on — PyTorch's default — the placeholder is NaN until then, so a
                 # callable that breaks the promise and reads it fails loudly; validate_args=False skips the fill)
-                draw = _ops.affine_rsample_deferred(base.source, base.weight, base.offset, scale, eps,
-                                                    poison=bool(base._validate_args))
+                draw = _ops.affine_rsample_deferred(base.source, base.weight, poison=bool(base._validate_args))
                 draw._aesmc_pending_noise = eps
             else:
                 draw = _ops.affine_rsample(base.source, base.weight, base.offset, scale, eps)
@@ -406,7 +431,7 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
     shape = base._extended_shape(torch.Size(sample_shape))
     if len(shape) < 2:
         return None
-    eps = torch.distributions.normal._standard_normal(shape, dtype=loc.dtype, device=loc.device)
+    eps = _standard_normal(shape, dtype=loc.dtype, device=loc.device)
     if loc.shape != shape:
         loc = loc.expand(shape)
     if scale.shape != shape:

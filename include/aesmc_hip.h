@@ -364,13 +364,16 @@ int aesmc_affine_normal_propagate_resampled(
  * and the three `state.log_prob` calls.  Neither the noise nor the resampled latent nor any location touches
  * HBM: 8 + 4 dx bytes in, 4 dx + 4 out per particle.  The caller advances the generator by
  * 4 * ceil(B K dx / (4 threads)), as `normal_` would.  float32 only (PyTorch draws float64 noise by another
- * route).  AESMC_ERR_UNSUPPORTED (caller: aesmc_philox_normal_fill, then the launches above) with fewer than
+ * route).  `rng_state` (NULL outside a hipGraph): two uint64 in DEVICE memory, (seed, offset), read by the kernel
+ * when it runs — a captured launch replays with whatever generator state the host uploaded before the replay;
+ * `seed` is then ignored and `offset` is relative to it (what the captured region had consumed before this
+ * launch).  AESMC_ERR_UNSUPPORTED (caller: aesmc_philox_normal_fill, then the launches above) with fewer than
  * 128 particles per batch row (64 below 2^20 particles), dx = 1, or B K dx >= 2^32. */
 int aesmc_affine_normal_propagate_drawn(
     const void *x_src, const int64_t *ancestors, const void *y, int64_t y_stride_b,
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, int32_t *flags,
-    int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, void *stream);
+    int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *rng_state, void *stream);
 
 /* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
  *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])
@@ -482,9 +485,10 @@ int aesmc_particle_mlp(int dtype, const void *x, const aesmc_affine_map *layer1,
  * (csrc/philox_normal.hpp).  The caller advances the generator by 4 * ceil(numel / (4 * threads)), what
  * `normal_` would have consumed.  offset must be a multiple of 4 (PyTorch's always is).  `variant` 0 is
  * the product (Box-Muller's affine maps as fused multiply-adds, as PyTorch's build of rocRAND has them);
- * 1 = separate multiply and add, kept for the test that shows which of the two PyTorch's build uses. */
+ * 1 = separate multiply and add, kept for the test that shows which of the two PyTorch's build uses.
+ * `rng_state`: as for aesmc_affine_normal_propagate_drawn (NULL outside a hipGraph). */
 int aesmc_philox_normal_fill(void *out, int64_t numel, uint64_t seed, uint64_t offset, int64_t threads, int variant,
-                             void *stream);
+                             const uint64_t *rng_state, void *stream);
 
 #ifdef __cplusplus
 }

@@ -44,7 +44,7 @@ def test_philox_fill_is_torch_normal_bit_for_bit(kernels, hip_device, seed, warm
         assert generator.get_offset() == offset + _philox.consumed(numel, threads), numel
         got = torch.empty(numel, device=hip_device)
         status = kernels._lib.aesmc_philox_normal_fill(got.data_ptr(), numel, generator.initial_seed(), offset, threads,
-                                                       0, torch.cuda.current_stream().cuda_stream)
+                                                       0, None, torch.cuda.current_stream().cuda_stream)
         assert status == 0
         assert torch.equal(got.view(torch.int32), want.view(torch.int32)), numel
 
@@ -65,7 +65,7 @@ def test_reserving_noise_leaves_the_generator_where_normal_would(hip_device):
     got = torch.empty_like(drawn)
     from aesmc_amd import _kernels
     status = _kernels.get()._lib.aesmc_philox_normal_fill(got.data_ptr(), got.numel(), reserved.seed, reserved.offset,
-                                                          reserved.threads, 0, torch.cuda.current_stream().cuda_stream)
+                                                          reserved.threads, 0, None, torch.cuda.current_stream().cuda_stream)
     assert status == 0 and torch.equal(got, drawn)
 
 

@@ -29,7 +29,7 @@ for seed, warm in ((0, 0), (1234, 3), (2 ** 40 + 17, 1)):
         row = [seed, numel, threads, offset, after, predicted == after]
         for variant in (0, 1):
             got = torch.empty(numel, device=device)
-            status = lib.aesmc_philox_normal_fill(got.data_ptr(), numel, gen.initial_seed(), offset, threads, variant,
+            status = lib.aesmc_philox_normal_fill(got.data_ptr(), numel, gen.initial_seed(), offset, threads, variant, None,
                                                   torch.cuda.current_stream().cuda_stream)
             assert status == 0, status
             same = (got.view(torch.int32) == want.view(torch.int32))
