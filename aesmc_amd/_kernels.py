@@ -892,6 +892,12 @@ class HipKernels:
                 self.timer.note(name, (entry, args), nbytes, (x_prev, ancestors, eps, y_rows, out, out_x, maps, scales))
         return out
 
+    # Below ~2M particles a launch has too few work items to hide a workgroup's start-up behind (measured: B=128
+    # K=4096 d=10: 47 us against 10 + 26 us for the noise as its own launch followed by K15 through the
+    # ancestors; B=512 K=4096: 97 against 105): the noise is then materialised by aesmc_philox_normal_fill —
+    # the same values — and the step takes the launches that read it.
+    DRAWN_MIN_PARTICLES = int(__import__("os").environ.get("AESMC_K16_MIN_PARTICLES", str(1 << 21)))
+
     def philox_normal(self, stream_desc, shape, device):
         """The float32 tensor `torch.empty(shape).normal_()` would have held for the generator state
         `stream_desc` (an `_philox.NoiseStream`) — for a draw that was left to a kernel which then did not run."""
@@ -918,6 +924,8 @@ class HipKernels:
         if x_src.dtype != torch.float32:
             return None
         B, K, dx = x_src.shape
+        if B * K < self.DRAWN_MIN_PARTICLES:
+            return None
         if noise.numel != B * K * dx:
             raise ValueError("aesmc_amd: affine_propagate_drawn: the reservation does not match x_src")
         self._check_out(out_x, (B, K, dx), x_src, "affine_propagate_drawn")
@@ -1307,51 +1315,6 @@ class HipKernels:
             eps = (x - self.particle_affine(x_prev, Q, off_q)) / scales[2]
             grads[11] = add(grads[11], (total * eps).sum().reshape(scales[2].shape))
         return grads
-
-    # ---- K13: two-layer tanh net over the particles ---------------------------------------------
-    def particle_mlp_covers(self, x, weight1, offset1, weight2, bias2=None):
-        """Host-only test of K13's preconditions: x [B,K,din] (din <= 16), weight1 [H,din] (H <= 64),
-        offset1 [H] or [B,H], weight2 [dout,H] (dout <= 16), bias2 [dout] or None; at least ~43
-        particles per batch row (the kernel stages the rows' offsets per 256-particle tile)."""
-        if not (torch.is_tensor(x) and x.is_cuda and x.dtype in _DTYPE_TAG and x.dim() == 3 and x.numel() > 0):
-            return False
-        tensors = [weight1, offset1, weight2] + ([bias2] if bias2 is not None else [])
-        if not all(torch.is_tensor(t) and t.dtype == x.dtype and t.device == x.device for t in tensors):
-            return False
-        if weight1.dim() != 2 or weight2.dim() != 2:
-            return False
-        H, din = weight1.shape
-        dout = weight2.size(0)
-        if din != x.size(2) or weight2.size(1) != H or not (1 <= din <= 16 and 1 <= dout <= 16 and 1 <= H <= 64):
-            return False
-        if tuple(offset1.shape) not in ((H,), (x.size(0), H)):
-            return False
-        if bias2 is not None and tuple(bias2.shape) != (dout,):
-            return False
-        return (256 - 1) // x.size(1) + 2 <= 8
-
-    def particle_mlp(self, x, weight1, offset1, weight2, bias2=None):
-        """K13: bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T -> dense [B,K,dout]; None when the kernel
-        declines the shape (the caller keeps the PyTorch expression)."""
-        if not self.particle_mlp_covers(x, weight1, offset1, weight2, bias2):
-            return None
-        tag = _DTYPE_TAG[x.dtype]
-        B, K = x.shape[:2]
-        x = self._dense16(x)
-        out = torch.empty((B, K, weight2.size(0)), dtype=x.dtype, device=x.device)
-        m1, keep1 = self._affine_map(weight1, offset1)
-        m2, keep2 = self._affine_map(weight2, bias2)
-        with _on_device(x.device):
-            args = (tag, _ptr(x), ctypes.byref(m1), ctypes.byref(m2), _ptr(out), B, K, self._stream(x))
-            status = self._lib.aesmc_particle_mlp(*args)
-            if status == 2:
-                return None
-            _lib.check(status, "aesmc_particle_mlp")
-            if self.timer is not None:
-                nbytes = x.element_size() * B * K * (x.size(2) + out.size(2))
-                self.timer.note("particle_mlp", (self._lib.aesmc_particle_mlp, args), nbytes,
-                                (x, out, m1, m2, keep1, keep2))
-        return out
 
     # ---- K7 ------------------------------------------------------------------------------------
     def particle_summary(self, log_w, value=None, want_log_ess=False, want_mean=False, want_second=False):

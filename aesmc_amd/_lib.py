@@ -65,8 +65,6 @@ SIGNATURES = {
     "aesmc_normal_logweight_backward": (_i32, [_i32, ctypes.POINTER(View3)] + [_vp] * 9 + [_i64] * 4 + [_vp]),
     "aesmc_normal_logweight_lse_backward": (_i32, [_i32, ctypes.POINTER(View3)] + [_vp] * 12 + [_i64] * 4 + [_vp]),
     "aesmc_resample_step": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
-    "aesmc_set_step_parts": (_i32, [_i32]),
-    "aesmc_set_sorted_backward_kernel": (_i32, [_i32]),
     "aesmc_particle_summary_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64]),
     "aesmc_particle_summary": (_i32, [_i32, _vp, ctypes.POINTER(View3), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz,
                                       _vp]),
@@ -76,8 +74,6 @@ SIGNATURES = {
     "aesmc_affine_normal_rsample": (_i32, [_i32, _vp, _map_p, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_backward_workspace_bytes": (_sz, [_i32, _i64, _i64]),
     "aesmc_particle_affine_backward": (_i32, [_i32, _vp, _vp, _map_p, _vp, _vp, _vp, _vp, _sz, _i64, _i64, _vp]),
-    "aesmc_particle_mlp_max_hidden": (_i64, []),
-    "aesmc_particle_mlp": (_i32, [_i32, _vp, _map_p, _map_p, _vp, _i64, _i64, _vp]),
     "aesmc_affine_normal_logweight_backward": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p] + [_vp] * 7 +
                                                       [ctypes.POINTER(AffineLogweightGrads), _vp, _sz, _i64, _i64, _vp]),
     "aesmc_affine_normal_propagate": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp, _vp,
@@ -93,6 +89,13 @@ SIGNATURES = {
     "aesmc_affine_normal_propagate_drawn": (_i32, [_vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp, _vp,
                                                    _vp, _i64, _i64, _u64, _u64, _i64, _vp, _vp]),
     "aesmc_philox_normal_fill": (_i32, [_vp, _i64, _u64, _u64, _i64, _i32, _vp, _vp]),
+}
+
+# measurement / test hooks the library also exports; deliberately NOT in include/aesmc_hip.h (process-wide
+# switches are not something a binder of the C ABI should see): which variant of two equivalent kernels runs
+TEST_HOOKS = {
+    "aesmc_test_set_step_parts": (_i32, [_i32]),
+    "aesmc_test_set_sorted_backward_kernel": (_i32, [_i32]),
 }
 
 _lib = None
@@ -112,7 +115,7 @@ def load():
             "aesmc_amd: HIP library not built ({} missing). Run `python -m aesmc_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.".format(LIB_PATH))
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (restype, argtypes) in SIGNATURES.items():
+    for name, (restype, argtypes) in list(SIGNATURES.items()) + list(TEST_HOOKS.items()):
         fn = getattr(lib, name)  # AttributeError here == the library does not export the symbol
         fn.restype = restype
         fn.argtypes = argtypes

@@ -653,54 +653,3 @@ def affine_propagate(operands, eps):
     x_prev = (x_prev.materialise() if type(x_prev) is LazyResampled else x_prev).detach()
     return k.affine_propagate(x_prev, eps, y_rows, (A, off_p), (C, off_g), (Q, off_q),
                               (s_p, s_g, s_q), out_x=x, checked=True)    # state._affine_step_operands did
-
-
-# ---- K13: a two-layer tanh net over the particles --------------------------------------------------------
-def _mlp_reference(x, weight1, offset1, weight2, bias2):
-    hidden = torch.matmul(x, weight1.t()) + (offset1.unsqueeze(1) if offset1.dim() == 2 else offset1)
-    out = torch.matmul(torch.tanh(hidden), weight2.t())
-    return out if bias2 is None else out + bias2
-
-
-class _ParticleMlp(torch.autograd.Function):
-    """Forward: kernel K13 (the hidden layer never leaves registers).  Backward: PyTorch's autograd over
-    the same expression, re-evaluated from the saved inputs — the gradient GEMMs of a 64-wide layer
-    are proper library work; what K13 removes is the forward pass's [B,K,H] traffic."""
-
-    @staticmethod
-    def forward(ctx, x, weight1, offset1, weight2, bias2):
-        out = _kernels.get().particle_mlp(x, weight1, offset1, weight2, bias2)
-        if out is None:
-            raise _Declined()
-        ctx.save_for_backward(x, weight1, offset1, weight2, bias2)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad):
-        saved = ctx.saved_tensors
-        with torch.enable_grad():
-            leaves = [None if t is None else t.detach().requires_grad_(need)
-                      for t, need in zip(saved, ctx.needs_input_grad)]
-            out = _mlp_reference(*leaves)
-            wanted = [t for t, need in zip(leaves, ctx.needs_input_grad) if t is not None and need]
-            grads = iter(torch.autograd.grad(out, wanted, grad))
-        return tuple(next(grads) if (t is not None and need) else None
-                     for t, need in zip(leaves, ctx.needs_input_grad))
-
-
-def particle_mlp(x, weight1, offset1, weight2, bias2=None):
-    """bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T over particles x [B,K,din]; kernel K13 when it
-    covers the shape, the PyTorch expression otherwise (same numbers to rounding)."""
-    if type(x) is LazyResampled:
-        x = x.materialise()
-    k = _kernels.get()
-    if not k.particle_mlp_covers(x, weight1, offset1, weight2, bias2):
-        return _mlp_reference(x, weight1, offset1, weight2, bias2)
-    tensors = (x, weight1, offset1, weight2, bias2)
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        try:
-            return _ParticleMlp.apply(*tensors)
-        except _Declined:
-            return _mlp_reference(*tensors)
-    out = k.particle_mlp(*[None if t is None else t.detach() for t in tensors])
-    return out if out is not None else _mlp_reference(*tensors)

@@ -570,8 +570,13 @@ static int pick_threads(int64_t K, int chunk) {
 // Measured (tools/stepbench.py, N(0,1) weights): B=128 K=4096 d=10: 16.6 us with 1, 15.2 with 2, 16.6
 // with 4, 22.8 with 8 workgroups per row; B=256 K=1024: 9.2 / 8.95 / 10.0 / 10.1; B=1024 K=4096:
 // 81.6 / 84.9 / 98.4 / 141.8 — the repeated scan (float64 exp + two scans per particle) costs more
-// than the shorter copy returns beyond two.  0 = automatic; aesmc_set_step_parts() pins a value.
-static int g_step_parts = 0;
+// than the shorter copy returns beyond two.  0 = automatic; AESMC_STEP_PARTS in the environment (or the test
+// hook aesmc_test_set_step_parts, which is not part of the C ABI of include/aesmc_hip.h) pins a value.
+static int g_step_parts = [] {
+  const char *v = getenv("AESMC_STEP_PARTS");
+  const int parts = v != nullptr ? atoi(v) : 0;
+  return (parts > 0 && (parts & (parts - 1)) == 0) ? parts : 0;
+}();
 
 static int pick_parts(int64_t B, int nt, bool has_payload) {
   int limit = nt / kWave;                        // at least one wavefront of index stores per part
@@ -636,7 +641,7 @@ static int launch(const void *log_w, const double *u, int64_t *idx, int32_t *fla
 
 extern "C" int64_t aesmc_ancestor_index_lds_max_particles(void) { return aesmc::kInvMaxParticles; }
 
-extern "C" int aesmc_set_step_parts(int parts) {
+extern "C" int aesmc_test_set_step_parts(int parts) {
   if (parts < 0 || (parts & (parts - 1)) != 0) return AESMC_ERR_INVALID_ARGUMENT;
   aesmc::g_step_parts = parts;
   return AESMC_OK;

@@ -1,4 +1,4 @@
-// K8 - K10, K13, K15: particle propagation for linear-Gaussian model terms (and a learned proposal net);
+// K8 - K10, K15: particle propagation for linear-Gaussian model terms;
 // their backward kernels K11, K12, K14 live in linear_gaussian_backward.hip, shared pieces in linear_gaussian.hpp.
 //
 // The reference's own state-space model (test/models/lgssm.py:40, :52, :74) and every LGSSM written
@@ -22,7 +22,6 @@
 //                                        - log N(x'; Q x + q, s_q)              (inference.py:112-126)
 //   K11 aesmc_particle_affine_backward   grad W, grad x of a location           (weight gradients: MFMA)
 //   K12 aesmc_affine_normal_logweight_backward   K10's backward in one pass
-//   K13 aesmc_particle_mlp               b2 + W2 tanh(c1 + W1 x)                (a learned proposal net)
 //
 // After the location, K9 follows K6 operation for operation (product rounded before the sum); K10 takes
 // PyTorch's per-element log-density with the common factors out of the d-sum (one division per term:
@@ -349,101 +348,6 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
   }
 }
 
-// ---- K13: a learned proposal net over the particles ----------------------------------------------------
-//   out[b,k,:] = b2 + W2 tanh( c1[b,:] + W1 x[b,k,:] )          W1 [H, din], W2 [dout, H], H <= 64
-// — the two-layer tanh MLP of [x_{t-1}, y_t] that BASELINE.json's nonlinear state-space model uses as its
-// proposal (the y_t part of the first layer and its bias arrive as the per-row offset c1).  Through
-// PyTorch this is a concatenation, two GEMMs and a tanh with [B,K,H] round trips through HBM between
-// them; here the hidden layer lives in registers (one particle per lane, H accumulators), both weight
-// matrices in LDS.  Chains as everywhere in this file: fused multiply-adds, inputs ascending, started
-// from the offset / bias; tanh is the device library's (the one torch.tanh calls).
-template <typename T> __device__ __forceinline__ T lg_tanh(T x);
-template <> __device__ __forceinline__ float lg_tanh<float>(float x) { return ::tanhf(x); }
-template <> __device__ __forceinline__ double lg_tanh<double>(double x) { return ::tanh(x); }
-
-template <typename T, int DP>
-__global__ __launch_bounds__(kLgBlock) void particle_mlp_kernel(const T *__restrict__ x, LgMap m1, LgMap m2,
-                                                                 T *__restrict__ out, int64_t N, uint32_t K,
-                                                                 uint32_t HP) {
-  // HP: the hidden width rounded up to a multiple of 16; the hidden layer is taken 16 units at a time
-  // (first-layer chains, tanh, their share of the second-layer chains), so a lane holds 16 hidden values
-  // and the output accumulators, whatever H is
-  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
-  constexpr uint32_t TP = kLgBlock;
-  const uint32_t din = m1.din, hid = m1.dout, dout = m2.dout;
-  T *w1 = reinterpret_cast<T *>(lg_smem);         // [DP][HP]: w1[i * HP + h] = W1[h][i]
-  T *w2 = w1 + DP * HP;                           // [HP][DP]: w2[h * DP + o] = W2[o][h]
-  T *tab = w2 + HP * DP;                          // [kLgRowsMax][HP]: the rows' first-layer offsets
-  T *tx = tab + kLgRowsMax * HP;
-  const LgLayout lx = lg_layout<T>(din), lo = lg_layout<T>(dout);
-  T *to = tx + (TP * lx.rs + 16);
-  {
-    const T *a = reinterpret_cast<const T *>(m1.w), *b = reinterpret_cast<const T *>(m2.w);
-#pragma unroll 1
-    for (uint32_t e = threadIdx.x; e < DP * HP; e += kLgBlock) {
-      const uint32_t i = e / HP, h = e - i * HP;
-      w1[e] = (h < hid && i < din) ? a[(int64_t)h * m1.sj + (int64_t)i * m1.si] : T(0);
-    }
-#pragma unroll 1
-    for (uint32_t e = threadIdx.x; e < HP * DP; e += kLgBlock) {
-      const uint32_t h = e / DP, o = e - h * DP;
-      w2[e] = (h < hid && o < dout) ? b[(int64_t)o * m2.sj + (int64_t)h * m2.si] : T(0);
-    }
-  }
-  const T *off1 = reinterpret_cast<const T *>(m1.off), *off2 = reinterpret_cast<const T *>(m2.off);
-  const int64_t tiles = (N + TP - 1) / TP;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t n0 = tile * TP;
-    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    lg_stage_rows(x + n0 * din, np * din, tx, lx, 0);
-    const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
-#pragma unroll 1
-    for (uint32_t idx = threadIdx.x; idx < nrows * HP; idx += kLgBlock) {     // the host guarantees nrows <= kLgRowsMax
-      const uint32_t row = idx / HP, h = idx - row * HP;
-      tab[idx] = (off1 != nullptr && h < hid) ? off1[(int64_t)(b0 + row) * m1.off_sb + h] : T(0);
-    }
-    __syncthreads();
-    const uint32_t q = threadIdx.x;
-    const bool live = q < np;
-    const uint32_t p = live ? q : 0u;
-    const uint32_t k0 = (uint32_t)(n0 - (int64_t)b0 * K);
-    const T *orow = tab + ((k0 + p) / K) * HP;
-    const uint32_t base = p * lx.rs;
-    T acc[DP];
-#pragma unroll
-    for (int o = 0; o < DP; ++o) acc[o] = (off2 != nullptr && (uint32_t)o < dout) ? off2[o] : T(0);
-#pragma unroll 1
-    for (uint32_t c = 0; c < HP; c += 16) {
-      T hidden[16];
-#pragma unroll
-      for (int h = 0; h < 16; ++h) hidden[h] = orow[c + h];
-#pragma unroll 2
-      for (uint32_t i = 0; i < din; ++i) {
-        const T xv = tx[base + i];
-        const T *w = w1 + i * HP + c;
-#pragma unroll
-        for (int h = 0; h < 16; ++h) hidden[h] = fma_t(w[h], xv, hidden[h]);
-      }
-#pragma unroll
-      for (int h = 0; h < 16; ++h) hidden[h] = lg_tanh<T>(hidden[h]);
-#pragma unroll
-      for (int h = 0; h < 16; ++h) {
-        const T *w = w2 + (c + h) * DP;
-#pragma unroll
-        for (int o = 0; o < DP; ++o) acc[o] = fma_t(w[o], hidden[h], acc[o]);
-      }
-    }
-    if (live) {
-#pragma unroll
-      for (int o = 0; o < DP; ++o)
-        if ((uint32_t)o < dout) to[p * lo.rs + o] = acc[o];
-    }
-    __syncthreads();
-    lg_store_rows(out + n0 * dout, np * dout, to, lo);
-    __syncthreads();
-  }
-}
-
 template <typename T>
 static int launch_particle_affine(const void *x1, const aesmc_affine_map *m1, const void *x2,
                                   const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
@@ -589,62 +493,9 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
-template <typename T>
-static int launch_particle_mlp(const void *x, const aesmc_affine_map *m1, const aesmc_affine_map *m2, void *out,
-                               int64_t B, int64_t K, hipStream_t stream) {
-  const int64_t N = B * K;
-  const int64_t din = m1->din, hid = m1->dout, dout = m2->dout;
-  const int dp = lg_pad_dim(std::max(din, dout));
-  const uint32_t hp = (uint32_t)((hid + 15) / 16 * 16);
-  if (lg_rows_spanned(kLgBlock, K) > kLgRowsMax) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per row
-  const size_t lds = sizeof(T) * (2 * (size_t)dp * hp + (size_t)kLgRowsMax * hp + lg_tile_elems<T>(kLgBlock, din) +
-                                  lg_tile_elems<T>(kLgBlock, dout));
-  if (lds > kLgLdsLimit) return AESMC_ERR_UNSUPPORTED;
-  const int64_t tiles = (N + kLgBlock - 1) / kLgBlock;
-  const unsigned grid = lg_persistent_grid(tiles, lds, 8);
-  const T *xp = static_cast<const T *>(x);
-  T *op = static_cast<T *>(out);
-#define LG_MLP_CASE(DP_)                                                                                            \
-  do {                                                                                                              \
-    if (lds > 64 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&particle_mlp_kernel<T, DP_>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-    hipLaunchKernelGGL((particle_mlp_kernel<T, DP_>), dim3(grid), dim3(kLgBlock), lds, stream, xp, lg_map(m1),      \
-                       lg_map(m2), op, N, (uint32_t)K, hp);                                                         \
-  } while (0)
-  switch (dp) {
-    case 4: LG_MLP_CASE(4); break;
-    case 8: LG_MLP_CASE(8); break;
-    case 10: LG_MLP_CASE(10); break;
-    case 12: LG_MLP_CASE(12); break;
-    default: LG_MLP_CASE(16); break;
-  }
-#undef LG_MLP_CASE
-  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
-}
-
 }  // namespace aesmc
 
 using namespace aesmc;
-
-extern "C" int64_t aesmc_particle_mlp_max_hidden(void) { return 64; }
-
-extern "C" int aesmc_particle_mlp(int dtype, const void *x, const aesmc_affine_map *layer1,
-                                  const aesmc_affine_map *layer2, void *out, int64_t B, int64_t K, void *stream) {
-  if (x == nullptr || out == nullptr || layer1 == nullptr || layer2 == nullptr || layer1->weight == nullptr ||
-      layer2->weight == nullptr || B < 0 || K < 0)
-    return AESMC_ERR_INVALID_ARGUMENT;
-  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
-  if (!aligned16(x) || !aligned16(out) || x == out) return AESMC_ERR_INVALID_ARGUMENT;
-  if (layer1->din < 1 || layer1->din > kLgMaxDim || layer2->dout < 1 || layer2->dout > kLgMaxDim ||
-      layer1->dout < 1 || layer1->dout > 64 || layer2->din != layer1->dout)
-    return AESMC_ERR_UNSUPPORTED;
-  if (B == 0 || K == 0) return AESMC_OK;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == AESMC_F32 ? launch_particle_mlp<float>(x, layer1, layer2, out, B, K, s)
-                            : launch_particle_mlp<double>(x, layer1, layer2, out, B, K, s);
-}
-
 
 extern "C" int64_t aesmc_affine_max_dim(void) { return kLgMaxDim; }
 

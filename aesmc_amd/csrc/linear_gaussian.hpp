@@ -1,4 +1,4 @@
-// Shared pieces of the linear-Gaussian propagation kernels (linear_gaussian.hip: K8, K9, K10 / K15, K13;
+// Shared pieces of the linear-Gaussian propagation kernels (linear_gaussian.hip: K8, K9, K10 / K15;
 // linear_gaussian_backward.hip: K11, K12, K14): tile layout and staging, the fma-chain maps, the per-row
 // vectors of a tile, register prefetch, and the host-side launch helpers.  See linear_gaussian.hip.
 #pragma once
@@ -464,13 +464,21 @@ constexpr size_t kLgLdsBudget = 64 * 1024;
 
 // Workgroups of a persistent launch: as many as are resident at once (by LDS; at most 8 per CU), so
 // each walks tiles blockIdx.x, blockIdx.x + grid, ... with the next one prefetched.
-static inline unsigned lg_persistent_grid(int64_t tiles, size_t lds_bytes, int max_per_cu = 8) {
-  int device = 0, cus = 256;
-  if (hipGetDevice(&device) == hipSuccess) {
+static inline int lg_cu_count() {
+  // per device, asked once (a launch per timestep must not pay two runtime calls for a constant)
+  static int cached[64] = {};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return 256;
+  if (cached[device] == 0) {
     int value = 0;
-    if (hipDeviceGetAttribute(&value, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && value > 0)
-      cus = value;
+    cached[device] = (hipDeviceGetAttribute(&value, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+                      value > 0) ? value : 256;
   }
+  return cached[device];
+}
+
+static inline unsigned lg_persistent_grid(int64_t tiles, size_t lds_bytes, int max_per_cu = 8) {
+  const int cus = lg_cu_count();
   int per_cu = (int)((size_t)160 * 1024 / (lds_bytes > 0 ? lds_bytes : 1));
   per_cu = per_cu < 1 ? 1 : (per_cu > max_per_cu ? max_per_cu : per_cu);
   const int64_t resident = (int64_t)cus * per_cu;
@@ -481,12 +489,27 @@ constexpr size_t kLgLdsLimit = 144 * 1024;
 // Launches `KERNEL<T, DP, PPL>` with DP from `dp` (4, 8, 12, 16) and PPL from `ppl` (1, 2).  Tiles beyond
 // 64 KiB of LDS (float64 rows of 10 and more values) need the opt-in; it is per kernel and per device,
 // cheap, and only taken for those shapes.
+// (the opt-in is raised to the limit once per kernel and device — `lg_raise_lds_limit` remembers — and a failure
+// surfaces as a launch error of that launch)
+static inline bool lg_raise_lds_limit(const void *kernel, bool (&done)[64]) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return false;
+  if (!done[device]) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    done[device] = true;
+  }
+  return true;
+}
 #define LG_LAUNCH(KERNEL, T, DP_, PPL_, grid, lds, stream, ...)                                              \
   do {                                                                                                       \
-    if ((lds) > 64 * 1024)                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL<T, DP_, PPL_>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds));                     \
-    hipLaunchKernelGGL((KERNEL<T, DP_, PPL_>), grid, dim3(kLgBlock), lds, stream, __VA_ARGS__);              \
+    bool lds_ok = true;                                                                                      \
+    if ((lds) > 64 * 1024) {                                                                                 \
+      static bool raised[64] = {};                                                                           \
+      lds_ok = lg_raise_lds_limit(reinterpret_cast<const void *>(KERNEL<T, DP_, PPL_>), raised);             \
+    }                                                                                                        \
+    /* (an empty grid is an invalid launch: the caller's hipGetLastError() reports AESMC_ERR_LAUNCH) */      \
+    hipLaunchKernelGGL((KERNEL<T, DP_, PPL_>), lds_ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream,   \
+                       __VA_ARGS__);                                                                         \
   } while (0)
 #ifdef AESMC_LG_FAST_BUILD   /* experiments only: one extent, so a translation unit compiles in seconds */
 #define LG_DISPATCH(KERNEL, T, dp, ppl, grid, lds, stream, ...)                                              \

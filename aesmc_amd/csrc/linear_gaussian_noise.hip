@@ -15,12 +15,15 @@
 // reads back the rows of ITS particles.  Nothing else crosses lanes: x_{t-1}'s rows are fetched by the lane
 // that owns the particle through the particle's ancestor (prefetched one item ahead, the index two ahead),
 // and x_t leaves from registers.
+#include <type_traits>
+
 #include "linear_gaussian.hpp"
 #include "philox_normal.hpp"
 
 namespace aesmc {
 
 struct LgNoisePlan {
+  int32_t probe;        // measurement only (AESMC_K16_PROBE): 1 = the noise role draws nothing, 2 = the particle role skips its arithmetic
   uint64_t numel;       // B K d
   uint64_t magic;       // ceil(2^40 / d): (v * magic) >> 40 == v / d for v < 2^32
   uint32_t L;           // thread ids per block (elements per window): 256 S - (d - 1)
@@ -88,8 +91,8 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       } else {
         const uint64_t hi = min(lo + it.tl, plan.numel);
         const uint64_t nf = lg_div_d(lo + dx - 1, plan.magic), nl = lg_div_d(hi + dx - 1, plan.magic);
-        it.nf[i] = (uint32_t)nf;
         it.count[i] = (uint32_t)(nl - nf);
+        it.nf[i] = nl != nf ? (uint32_t)nf : 0u;       // (a window that owns no particle points at a valid one)
         it.head[i] = (uint32_t)(nf * dx - lo);
       }
     }
@@ -140,7 +143,9 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       if (j >= it.tl + dx - 1) break;
       const uint64_t t = (uint64_t)it.t0 + j;
       float n4[4];
-      if (t < G) {
+      if (plan.probe == 1) {
+        n4[0] = n4[1] = n4[2] = n4[3] = 0.5f;
+      } else if (t < G) {
         const float4 n = philox_normal4(ps, (uint32_t)t, it.c);
         n4[0] = n.x; n4[1] = n.y; n4[2] = n.z; n4[3] = n.w;
       } else {      // past the last thread id: the elements belong to the next window's first thread ids
@@ -196,20 +201,30 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
     seg[r] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot / RUNP));
     row[r] = slot - seg[r] * RUNP;
   }
+  // (generic over "are there ancestor indices": as a runtime branch around the index loads it made the compiler
+  // wait for each of them on the spot)
+  auto particles = [&](auto has_idx) {
   uint32_t rg[PPL * MAXQ * W];
   int64_t ranc[PPL];
+  // Idle lanes (a window holds fewer particles than it has rows) DUPLICATE the window's last particle: same
+  // loads, same arithmetic, same stores of the same values to the same addresses.  No lane-dependent branch
+  // surrounds a load or a store then, so the loads stay in flight across the arithmetic instead of being waited
+  // for at the end of an `if` (measured: four exposed memory round trips per item with the branches in place).
+  // (A window without any particle — past the tensor's end — is wavefront-uniform: those wavefronts skip.)
+  auto row_of = [&](const Item &it, int r) {
+    const uint32_t count = pick(it.count, seg[r]);
+    return min(row[r], count != 0 ? count - 1 : 0u);
+  };
   // the lane's ancestors of `it`'s particles -> registers
   auto anc_prefetch = [&](const Item &it) {
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
-      const bool live = row[r] < pick(it.count, seg[r]);
-      const uint32_t first = pick(it.nf, seg[r]);
-      const int64_t n = (int64_t)first + row[r];
-      if (gat.idx != nullptr) {
-        ranc[r] = live ? gat.idx[n] : 0;
+      const uint32_t first = pick(it.nf, seg[r]), rr = row_of(it, r);
+      if constexpr (decltype(has_idx)::value) {
+        ranc[r] = gat.idx[(int64_t)first + rr];       // (an empty window reads particle `first` = 0: valid, unused)
       } else {      // no resampling in front of this step: a particle is its own ancestor
         const uint32_t k0 = first % K;
-        ranc[r] = (k0 + row[r]) >= K ? (int64_t)(k0 + row[r] - K) : (int64_t)(k0 + row[r]);
+        ranc[r] = (k0 + rr) >= K ? (int64_t)(k0 + rr - K) : (int64_t)(k0 + rr);
       }
     }
   };
@@ -217,23 +232,20 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
   auto rows_prefetch = [&](const Item &it) {
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
-      if (row[r] < pick(it.count, seg[r])) {
-        const uint32_t first = pick(it.nf, seg[r]);       // uniform per window: its divisions run on the scalar unit
-        const uint32_t b0 = first / K, k0 = first - b0 * K;
-        int64_t a = ranc[r];
-        if (a < 0 || a >= (int64_t)K) {
-          raise_flag(gat.flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
-          a = a < 0 ? 0 : (int64_t)K - 1;
-        }
-        const uint64_t source = (uint64_t)(b0 + ((k0 + row[r]) >= K ? 1u : 0u)) * K + (uint64_t)a;
-        const char *at = src_bytes + source * gat.row_bytes;
+      const uint32_t first = pick(it.nf, seg[r]), rr = row_of(it, r);      // uniform per window: scalar divisions
+      const uint32_t b0 = first / K, k0 = first - b0 * K;
+      int64_t a = ranc[r];
+      if (a < 0 || a >= (int64_t)K) {
+        raise_flag(gat.flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
+        a = a < 0 ? 0 : (int64_t)K - 1;
+      }
+      const uint64_t source = (uint64_t)(b0 + ((k0 + rr) >= K ? 1u : 0u)) * K + (uint64_t)a;
+      const char *at = src_bytes + source * gat.row_bytes;
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c) {
-          if ((uint32_t)c < gat.ppr) {
-            const P x = *reinterpret_cast<const P *>(at + c * PB);
-            __builtin_memcpy(&rg[(r * MAXQ + c) * W], &x, PB);
-          }
-        }
+      for (int c = 0; c < MAXQ; ++c) {
+        // (pieces past the row's end — an extent below the kernel's class — re-read its last piece: no branch)
+        const P x = *reinterpret_cast<const P *>(at + min((uint32_t)c, gat.ppr - 1) * PB);
+        __builtin_memcpy(&rg[(r * MAXQ + c) * W], &x, PB);
       }
     }
   };
@@ -255,14 +267,12 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       const uint32_t row_pitch = lx.rs * (uint32_t)sizeof(T);
 #pragma unroll
       for (int r = 0; r < PPL; ++r) {
-        if (row[r] < pick(cur.count, seg[r])) {
 #pragma unroll
-          for (int c = 0; c < MAXQ; ++c) {
-            if ((uint32_t)c < gat.ppr) {
-              P x;
-              __builtin_memcpy(&x, &rg[(r * MAXQ + c) * W], PB);
-              *reinterpret_cast<P *>(base + (tid + r * kLgBlock) * row_pitch + c * PB) = x;
-            }
+        for (int c = 0; c < MAXQ; ++c) {
+          if ((uint32_t)c < gat.ppr) {
+            P x;
+            __builtin_memcpy(&x, &rg[(r * MAXQ + c) * W], PB);
+            *reinterpret_cast<P *>(base + (tid + r * kLgBlock) * row_pitch + c * PB) = x;
           }
         }
       }
@@ -278,15 +288,25 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
     bool live[PPL];
     uint32_t at[PPL], trow[PPL];
     int64_t n_of[PPL];
+    uint32_t an[PPL];       // the particle's row in the noise tile (an idle lane: the particle it duplicates)
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
-      const uint32_t first = pick(cur.nf, seg[r]);
-      live[r] = row[r] < pick(cur.count, seg[r]);
-      at[r] = (live[r] ? tid + r * kLgBlock : seg[r] * RUNP) * lx.rs;     // idle lanes compute on a valid row, store nothing
-      n_of[r] = (int64_t)first + row[r];
+      const uint32_t first = pick(cur.nf, seg[r]), rr = row_of(cur, r);
+      live[r] = pick(cur.count, seg[r]) != 0;                             // wavefront-uniform
+      at[r] = (tid + r * kLgBlock) * lx.rs;                               // x_{t-1}: the lane's own slot
+      an[r] = (seg[r] * RUNP + rr) * lx.rs;
+      n_of[r] = (int64_t)first + rr;
       const uint32_t k0 = first - (first / K) * K;
-      const uint32_t rel = (k0 + (live[r] ? row[r] : 0u)) >= K ? 1u : 0u;
-      trow[r] = ((seg[r] * kLgSegRows + rel) * 4) * DP;
+      trow[r] = ((seg[r] * kLgSegRows + ((k0 + rr) >= K ? 1u : 0u)) * 4) * DP;
+    }
+    if (plan.probe == 2) {
+#pragma unroll
+      for (int r = 0; r < PPL; ++r)
+        if (live[r]) out_lw[n_of[r]] = tprev[at[r]] + tx[an[r]];
+      lg_lds_barrier();
+      slot ^= 1u;
+      cur = nxt;
+      continue;
     }
     T locp[DP][PPL], locq[DP][PPL], locg[DP][PPL];
 #pragma unroll
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       if ((uint32_t)j < dx) {
 #pragma unroll
         for (int r = 0; r < PPL; ++r) {
-          xx[j][r] = locq[j][r] + tx[at[r] + j] * s_q;      // the product rounded before the sum, as K9 / K6
+          xx[j][r] = locq[j][r] + tx[an[r] + j] * s_q;      // the product rounded before the sum, as K9 / K6
           const T dp = xx[j][r] - locp[j][r], dq = xx[j][r] - locq[j][r];
           qp[r] = fma_t(dp, dp, qp[r]);
           qq[r] = fma_t(dq, dq, qq[r]);
@@ -387,6 +407,9 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
     slot ^= 1u;
     cur = nxt;
   }
+  };
+  if (gat.idx != nullptr) particles(std::true_type{});
+  else particles(std::false_type{});
 }
 
 static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_idx, const void *y, int64_t y_sb,
@@ -417,6 +440,8 @@ static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_id
   const uint32_t runp = (uint32_t)(kLgBlock * ppl / 4);
   if ((uint64_t)K < runp) return AESMC_ERR_UNSUPPORTED;        // a run of particles may span two batch rows, not more
   LgNoisePlan plan;
+  static const int probe = [] { const char *v = getenv("AESMC_K16_PROBE"); return v != nullptr ? atoi(v) : 0; }();
+  plan.probe = probe;
   plan.numel = numel;
   plan.magic = ((1ull << 40) + (uint64_t)dx - 1) / (uint64_t)dx;
   plan.small_magic = (uint32_t)(((1u << 20) + (uint32_t)dx - 1) / (uint32_t)dx);
@@ -436,9 +461,10 @@ static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_id
       (uint32_t)K, (uint32_t)B, static_cast<T *>(out_x), gat, ps, plan
 #define LG_NOISE_LAUNCH(DP_, PPL_, PB_)                                                                              \
   do {                                                                                                               \
-    if (lds > 64 * 1024)                                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&affine_propagate_noise_kernel<T, DP_, PPL_, PB_>),   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+    static bool raised[64] = {};                                                                                     \
+    if (lds > 64 * 1024 &&                                                                                           \
+        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_noise_kernel<T, DP_, PPL_, PB_>), raised)) \
+      return AESMC_ERR_LAUNCH;                                                                                       \
     hipLaunchKernelGGL((affine_propagate_noise_kernel<T, DP_, PPL_, PB_>), grid, dim3(kNoiseThreads), lds, stream,   \
                        LG_NOISE_ARGS);                                                                               \
   } while (0)

@@ -551,8 +551,13 @@ using namespace aesmc;
 // 0: the range kernel for sorted indices (default: every row written once, no zero fill); 1: the
 // source-tile kernel behind a zero fill (kept for rows the first declines, and selectable for A/B
 // timing: tools/kbench.py)
-static int g_sorted_backward_kernel = 0;
-extern "C" int aesmc_set_sorted_backward_kernel(int which) {
+// (a measurement / test hook, not part of the C ABI of include/aesmc_hip.h: AESMC_SORTED_BACKWARD_KERNEL in the
+// environment sets the default, aesmc_test_set_sorted_backward_kernel switches inside one process)
+static int g_sorted_backward_kernel = [] {
+  const char *v = getenv("AESMC_SORTED_BACKWARD_KERNEL");
+  return (v != nullptr && v[0] == '1') ? 1 : 0;
+}();
+extern "C" int aesmc_test_set_sorted_backward_kernel(int which) {
   if (which != 0 && which != 1) return AESMC_ERR_INVALID_ARGUMENT;
   g_sorted_backward_kernel = which;
   return AESMC_OK;

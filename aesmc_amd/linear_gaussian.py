@@ -48,17 +48,6 @@ def particle_affine(x, weight, offset=None):
     return out
 
 
-def particle_mlp(x, weight1, offset1, weight2, bias2=None):
-    """A learned proposal net over the particles:  bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T  for
-    x [B,K,din], weight1 [H,din], offset1 [H] or [B,H] (e.g. the observation's columns of the first
-    layer applied to y_t, plus its bias), weight2 [dout,H].  Kernel K13 (din, dout <= 16, H <= 64: the
-    hidden layer stays in registers); otherwise, and for the backward pass, PyTorch's own ops."""
-    if _kernels.get().name == "hip" and not (torch.is_tensor(x) and x.is_cuda):
-        raise RuntimeError("aesmc_amd: particle_mlp operand lives on '{}'; this package computes only on a "
-                           "HIP device (MI355X) and has no CPU fallback.".format(getattr(x, "device", None)))
-    return _ops.particle_mlp(x, weight1, offset1, weight2, bias2)
-
-
 class AffineNormal(torch.distributions.Normal):
     """Normal(loc = source @ weight.T + offset, scale) with the location evaluated on demand.
 

@@ -163,7 +163,7 @@ def build_model(kind, dim, device, state, proposal="stock", callables="matmul", 
         return cls(state=state, validate_args=False).to(device)
     if kind == "lgssm":
         model_kwargs = dict(model_kwargs, affine=(callables == "affine"))
-    if kind == "nonlinear":     # d x d maps through K8, the proposal net through K13
+    if kind == "nonlinear":     # d x d maps through K8 (the proposal net stays PyTorch's)
         model_kwargs = dict(model_kwargs, fused=(callables == "affine"))
     # validate_args=False: no per-call host sync inside torch.distributions (standard practice)
     model = cls(dim, seed=0, state=state, validate_args=False, **model_kwargs).to(device)
@@ -417,7 +417,10 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         # the roofline kernel: the resample gather (K3, or the fused step that contains it); a workload
         # that never resamples (c3, IWAE) is what BASELINE.json uses to isolate the fused log-weight
         # + log-sum-exp kernel (K1)
-        if "affine_normal_propagate_resampled" in kernels:
+        if "affine_normal_propagate_drawn" in kernels:
+            key, label = "affine_normal_propagate_drawn", \
+                "affine_propagate_noise_kernel (K16: the resample gather, the proposal's noise and draw, the log-weight)"
+        elif "affine_normal_propagate_resampled" in kernels:
             key, label = "affine_normal_propagate_resampled", \
                 "affine_logweight_kernel, DRAW + GATHER (the resample gather inside the propagation launch: K3 + K15)"
         elif "moved_GBps" in kernels.get("resample_step", {}):
@@ -430,6 +433,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         # the propagation kernels either side of it (K9 draws x_t, K10 weighs it), priced the same way
         others = [roofline_of(kernels.get(k), l, name, proposal, k) for k, l in (
             ("resample_step" if key != "resample_step" else "-", "ancestor_index_inv_kernel (K2: ancestor indices + row log-sum-exp)"),
+            ("philox_normal_fill", "philox_normal_fill_kernel (the step's noise, torch's Philox stream)"),
             ("affine_normal_propagate", "affine_logweight_kernel, DRAW (K15: the draw and its log-weight)"),
             ("affine_normal_rsample", "affine_rsample_kernel (K9)"),
             ("affine_normal_logweight", "affine_logweight_kernel (K10)")) if k in kernels]
@@ -629,6 +633,35 @@ def parity_block(ctx):
     return out
 
 
+def fixture_parity_block(ctx):
+    """Every float32 SMC run captured from the reference (tests/golden/), replayed on the device draw for draw
+    with the bench's own model statement (AffineNormal callables): what the device ACHIEVES, free-running and
+    teacher-forced (aesmc_amd/testing/parity.py) — per-step index agreement, per-step log-weight error with the
+    reference's ancestors substituted, |delta log Z|."""
+    from aesmc_amd import state
+    from aesmc_amd.testing import parity
+    from tests.golden_io import Golden
+    out = {}
+    for name in ("lgssm10d_k1024_smc_f32", "lgssm10d_k4096_smc_f32", "lgssm3d_smc_f32", "c1_lgssm1d_smc_f32"):
+        try:
+            case = Golden(name)
+        except FileNotFoundError:
+            continue
+        affine = case.meta["model"] == "lgssm_nd"
+        parts, _ = case.build_parts(state, ctx.device, affine=affine)
+        steps = case.meta["num_timesteps"] - 1
+        reference = {"log_weights": case.series("out_log_weights"), "indices": case.series("out_idx")[:steps],
+                     "lml": case["out_lml"]}
+        got = parity.float32_fixture_parity(parts, case.observations(ctx.device), case.meta["num_particles"],
+                                            case.tape(), reference)
+        got = {k: ([round(x, 6) if isinstance(x, float) else x for x in v] if isinstance(v, list) else v)
+               for k, v in got.items()}
+        got["num_particles"], got["num_timesteps"], got["callables"] = case.meta["num_particles"], steps + 1, \
+            "affine" if affine else "reference style"
+        out[name] = got
+    return out
+
+
 # ---- main ----------------------------------------------------------------------------------------------
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
@@ -696,8 +729,10 @@ def main(argv=None):
         "data": "synthetic",
         "config": {"workload": head["workload"], "proposal": head["proposal"],
                    "callables": {"affine": "AffineNormal(source, weight, scale, offset), the proposal's with defer_draw=True: "
-                                           "draw and log-weight in one kernel (K15), a step's backward in one (K14) "
-                                           "(aesmc_amd/linear_gaussian.py)",
+                                           "resampling gather, draw (noise from torch's Philox stream, inside the launch) "
+                                           "and log-weight in one kernel (K16; below 2M particles K15 through the "
+                                           "ancestors behind a noise launch), a step's backward in one (K14, through the "
+                                           "ancestors) (aesmc_amd/linear_gaussian.py)",
                                  "matmul": "Normal(source @ weight.T + offset, scale): PyTorch matmuls, then K6 / K5"
                                  }[head["callables"]],
                    "batch_per_gpu": head["batch_per_gpu"], "global_batch": head["global_batch"],
@@ -748,13 +783,24 @@ def main(argv=None):
             extras["c2_hipgraph"] = brief(run_workload(ctx, "c2", args.proposal, 20, 5,
                                                        want_backward=not args.no_backward))
         if args.workload == "c4":
-            # BASELINE.json configs[3]'s model (nonlinear SSM, learned proposal net) on one GPU's shard of it:
-            # the d x d maps through K8 and the net through K13, and the same with PyTorch matmuls
-            for label, how in (("c4nl_fused", "affine"), ("c4nl_matmul", "matmul")):
-                extras[label] = brief(run_workload(ctx, "c4nl", "stock", 10, 3, want_backward=False,
-                                                   want_kernels=False, callables=how))
+            # BASELINE.json configs[3]'s model (nonlinear SSM, learned proposal net) on one GPU's shard of it, forward
+            # AND backward: the d x d maps through K8 / K11; the proposal net is the user's PyTorch module
+            extras["c4nl"] = brief(run_workload(ctx, "c4nl", "stock", 5, 2, want_backward=not args.no_backward,
+                                                want_kernels=False, callables="affine"))
+            # What one GPU's shard of the north-star batch costs on THIS device (global B = 1024 split over N GPUs:
+            # B / N rows here): the strong-scaling curve, the one all-reduce of sum log Z per ELBO aside.
+            # projected_efficiency = t(B = 1024) / (N * t(B / N)).
+            projection = {}
+            for shard_name, n in (("c4x2", 2), ("c4x4", 4), ("c4s", 8)):
+                shard = run_workload(ctx, shard_name, args.proposal, 5, 2, want_backward=False, want_kernels=False)
+                projection["N={}".format(n)] = {
+                    "batch_per_gpu": shard["batch_per_gpu"], "ms_per_elbo": round(shard["ms_per_step"], 3),
+                    "mode": shard["mode"], "particle_steps_per_sec_per_gpu": shard["value"],
+                    "projected_efficiency": round(head["ms_per_step"] / (n * shard["ms_per_step"]), 3)}
+            extras["strong_scaling_projection"] = projection
         extras["kernel_legs"] = kernel_legs(ctx)
         extras["index_parity_vs_reference_fixtures"] = parity_block(ctx)
+        extras["fp32_fixture_parity"] = fixture_parity_block(ctx)
     if extras:
         out["extras"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -124,11 +124,6 @@ int aesmc_resample_gather_backward(int dtype, const void *grad_out, const int64_
                                    void *grad_src, int32_t *flags, int64_t B, int64_t K,
                                    int64_t row_elems, int index_is_sorted, void *stream);
 
-/* Tuning knob: which kernel serves index_is_sorted != 0.  0 (default): every row of grad_src
- * written once by the tile that owns its range, no zero fill; 1: the same tiles behind a zero-fill
- * launch (round 1's kernel, still the route for rows wider than 3.5 KiB).  Identical sums. */
-int aesmc_set_sorted_backward_kernel(int which);
-
 /*
  * K4 — summed Normal log-density:
  *   out[b,k] = sum_{j<D} ( -((v-mu)^2) / (2 sigma^2) - log(sigma) - log(sqrt(2 pi)) )
@@ -224,13 +219,6 @@ int aesmc_normal_logweight_lse_backward(int dtype, const aesmc_view3 *views, con
 int aesmc_resample_step(int dtype, const void *log_w, const double *u, int64_t *out_idx, void *out_lse,
                         const void *src, void *dst, int32_t *flags, int64_t B, int64_t K,
                         int64_t row_bytes, int64_t src_stride_b, int64_t src_stride_k, void *stream);
-
-/* Tuning knob of the fused step: workgroups that share one batch row (each repeats the row's scan
- * and writes 1/parts of the indices and of the payload; results do not depend on it).  0 (default)
- * = chosen from B and K so that small batches still fill the 256 CUs; a power of two pins it.
- * Process-wide; not part of the reference's interface. */
-int aesmc_set_step_parts(int parts);
-
 
 /* K6 — reparameterised Normal draw  out[b,k,j] = loc[b,k,j] + eps[b,k,j] * scale[b,k,j].
  *
@@ -462,20 +450,6 @@ int aesmc_affine_step_backward_resampled(
     const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
     const void *grad_lse, const void *grad_lw, const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws,
     size_t ws_bytes, int32_t *flags, int64_t B, int64_t K, void *stream);
-
-/* K13 — a learned proposal net over the particles: the two-layer tanh MLP
- *   out[b,k,:] = layer2->offset + W2 tanh( layer1->offset[b,:] + W1 x[b,k,:] )
- * with W1 [H, din] (din <= 16, H <= aesmc_particle_mlp_max_hidden() = 64), W2 [dout, H] (dout <= 16);
- * layer1->offset is [H] or [B, H] (the per-row part of the first layer: its bias and the observation's
- * columns of the weight applied to y_t), layer2->offset [dout] or NULL.  x, out dense and 16-byte
- * aligned.  Replaces, in a model whose proposal is such a net of [x_{t-1}, y_t] (BASELINE.json's
- * nonlinear state-space model; the reference's own proposal at test/models/lgssm.py:66-77 is its
- * one-layer case), torch.cat + Linear + tanh + Linear: two GEMMs with [B,K,H] round trips through HBM.
- * Returns AESMC_ERR_UNSUPPORTED (caller keeps the PyTorch expression) beyond those extents or with
- * fewer than ~43 particles per batch row. */
-int64_t aesmc_particle_mlp_max_hidden(void);
-int aesmc_particle_mlp(int dtype, const void *x, const aesmc_affine_map *layer1, const aesmc_affine_map *layer2,
-                       void *out, int64_t B, int64_t K, void *stream);
 
 /* Noise — the float32 tensor `torch.empty(numel).normal_()` holds on this device for a generator at
  * (seed, offset): out[e], e < numel.  Replaces, inside a kernel or on its own, the `_standard_normal` draw of

@@ -213,14 +213,3 @@ class OracleKernels:
         for i, grad in zip(wanted, grads):
             out[i] = None if grad is None else grad.to(operands[i].dtype)
         return out
-
-    # ---- K13 on the C oracle ------------------------------------------------------------------------
-    def particle_mlp_covers(self, x, weight1, offset1, weight2, bias2=None):
-        return torch.is_tensor(x) and x.dim() == 3 and x.dtype in (torch.float32, torch.float64) and \
-            weight1.dim() == 2 and weight1.size(1) == x.size(2) <= 16 and weight1.size(0) <= 64 and \
-            weight2.dim() == 2 and weight2.size(1) == weight1.size(0) and weight2.size(0) <= 16
-
-    def particle_mlp(self, x, weight1, offset1, weight2, bias2=None):
-        from oracle import c_oracle
-        return torch.from_numpy(c_oracle.particle_mlp(self._n(x), self._n(weight1), self._n(offset1), self._n(weight2),
-                                                      self._n(bias2)))

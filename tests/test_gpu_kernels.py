@@ -1014,7 +1014,7 @@ def test_many_short_rows(kernels, hip_device):
 @pytest.mark.parametrize("shape,row", [((2, 64), (4,)), ((3, 1024), (10,)), ((5, 4096), (10,)), ((2, 2048), (3, 4)),
                                        ((4, 600), (4,)), ((1, 16384), (2,)), ((3, 1000), (1,))])
 def test_resample_step_does_not_depend_on_workgroups_per_row(kernels, hip_device, shape, row):
-    """`aesmc_set_step_parts`: a batch row shared by 1, 2, 4 or 8 workgroups gives the same indices,
+    """`aesmc_test_set_step_parts`: a batch row shared by 1, 2, 4 or 8 workgroups gives the same indices,
     log-sum-exp and payload bit for bit — including degenerate and NaN rows."""
     B, K = shape
     rng = np.random.RandomState(K + B)
@@ -1026,15 +1026,15 @@ def test_resample_step_does_not_depend_on_workgroups_per_row(kernels, hip_device
     payload = dev(rng.randn(B, K, *row).astype(np.float32), hip_device)
     lib = kernels._lib
     try:
-        assert lib.aesmc_set_step_parts(3) != 0          # powers of two only
+        assert lib.aesmc_test_set_step_parts(3) != 0          # powers of two only
         results = []
         for parts in (1, 2, 4, 8, 0):
-            assert lib.aesmc_set_step_parts(parts) == 0
+            assert lib.aesmc_test_set_step_parts(parts) == 0
             out = kernels.resample_step(lw_d, u, payload, want_lse=True)
             assert out is not None
             results.append(out)
     finally:
-        lib.aesmc_set_step_parts(0)
+        lib.aesmc_test_set_step_parts(0)
     kernels.read_flags(hip_device)
     for idx, lse, moved in results[1:]:
         assert torch.equal(idx, results[0][0]) and torch.equal(moved, results[0][2])
@@ -1062,11 +1062,11 @@ def test_sorted_backward_kernels_agree_bit_for_bit(kernels, hip_device, dtype, s
     try:
         outs = []
         for which in (1, 0):
-            assert lib.aesmc_set_sorted_backward_kernel(which) == 0
+            assert lib.aesmc_test_set_sorted_backward_kernel(which) == 0
             torch.full(shape, float("nan"), dtype=go.dtype, device=hip_device)   # dirty the allocator's blocks
             outs.append(kernels.gather_backward(go, idx, sorted_index=True))
     finally:
-        lib.aesmc_set_sorted_backward_kernel(0)
+        lib.aesmc_test_set_sorted_backward_kernel(0)
     assert kernels.read_flags(hip_device) == 0
     row_bytes = int(np.prod(shape[2:])) * go.element_size()
     if row_bytes <= 112:

@@ -546,57 +546,11 @@ def test_a_linear_gaussian_smc_step_is_one_backward_launch(hip_device):
             setattr(provider, name, fn)
 
 
-# ---- K13: the proposal net ------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("shape", [(3, 700, 10, 64, 10), (2, 513, 5, 16, 3), (5, 64, 16, 33, 16), (1, 1000, 3, 7, 7),
-                                   (4, 300, 1, 1, 1), (128, 4096, 10, 64, 10)])
-def test_particle_mlp_matches_the_c_oracle_and_the_pytorch_expression(kernels, hip_device, dtype, shape):
-    """K13 against oracle/smc_core.c (same fma chains; the device's tanh against libm's: a few ulp) and
-    against the PyTorch expression it replaces (cat + Linear + tanh + Linear)."""
-    B, K, din, hid, dout = shape
-    rng = np.random.RandomState(B + K + hid)
-    r = lambda *s_: rng.randn(*s_).astype(dtype)
-    x, w1, off1, w2, b2 = r(B, K, din), (r(hid, din) / np.sqrt(din)).astype(dtype), r(B, hid), \
-        (r(dout, hid) / np.sqrt(hid)).astype(dtype), r(dout)
-    dev = lambda a: torch.from_numpy(a).to(hip_device)
-    out = kernels.particle_mlp(dev(x), dev(w1), dev(off1), dev(w2), dev(b2))
-    assert out is not None and out.shape == (B, K, dout)
-    tolerance = 3e-6 if dtype == np.float32 else 1e-14
-    if B * K <= 4096:
-        want = c_oracle.particle_mlp(x, w1, off1, w2, b2)
-        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=tolerance, atol=tolerance * 4)
-    ref = torch.tanh(dev(x).double() @ dev(w1).double().t() + dev(off1).double().unsqueeze(1)) @ dev(w2).double().t() \
-        + dev(b2).double()
-    assert float((out.double() - ref).abs().max()) <= 4 * tolerance * max(1.0, float(ref.abs().max()))
-    shared = kernels.particle_mlp(dev(x), dev(w1), dev(off1[0]), dev(w2), None)     # [H] offset, no output bias
-    ref = torch.tanh(dev(x).double() @ dev(w1).double().t() + dev(off1[0]).double()) @ dev(w2).double().t()
-    assert float((shared.double() - ref).abs().max()) <= 4 * tolerance * max(1.0, float(ref.abs().max()))
-
-
-def test_particle_mlp_operator_gradients_and_fallbacks(hip_device):
-    from aesmc_amd.linear_gaussian import particle_mlp
-    gen = torch.Generator(device=hip_device).manual_seed(4)
-    make = lambda *shape: torch.randn(*shape, device=hip_device, dtype=torch.float64, generator=gen).requires_grad_(True)
-    x, w1, off1, w2, b2 = make(3, 300, 6), make(20, 6), make(3, 20), make(4, 20), make(4)
-    out = particle_mlp(x, w1, off1, w2, b2)
-    upstream = torch.randn(out.shape, device=hip_device, dtype=torch.float64, generator=gen)
-    got = torch.autograd.grad(out, (x, w1, off1, w2, b2), upstream)
-    ref_out = torch.tanh(x @ w1.t() + off1.unsqueeze(1)) @ w2.t() + b2
-    ref = torch.autograd.grad(ref_out, (x, w1, off1, w2, b2), upstream)
-    torch.testing.assert_close(out, ref_out, rtol=1e-12, atol=1e-12)
-    for a, b in zip(got, ref):
-        torch.testing.assert_close(a, b, rtol=1e-11, atol=1e-11)
-    wide = particle_mlp(make(2, 64, 6), make(100, 6), make(100), make(4, 100))     # beyond 64 hidden units: PyTorch
-    assert wide.shape == (2, 64, 4)
-    few = particle_mlp(make(50, 8, 6), w1, make(50, 20), w2, b2)                     # 8 particles per row: PyTorch
-    assert few.shape == (50, 8, 4)
-
-
 @pytest.mark.parametrize("algorithm,B,K,T,d", [("aesmc", 3, 300, 4, 5), ("aesmc", 2, 512, 3, 10)])
 def test_fused_nonlinear_model_matches_the_cpu_port_with_gradients(hip_device, algorithm, B, K, T, d):
-    """BASELINE.json's nonlinear state-space model with its maps through K8 and its proposal net through
-    K13 (`fused=True`) against the CPU port running the plain PyTorch callables, draws replayed:
-    float64 loss to 1e-10, every parameter gradient to 1e-8 of its largest entry."""
+    """BASELINE.json's nonlinear state-space model with its d x d maps through K8 (`fused=True`; the proposal net
+    stays PyTorch's) against the CPU port running the plain PyTorch callables, draws replayed: float64 loss to
+    1e-10, every parameter gradient to 1e-8 of its largest entry."""
     from oracle import reference_port
     dtype = torch.float64
     cpu_model = models.NonlinearSsm(d, hidden=24, seed=0, dtype=dtype, state=reference_port)
@@ -607,21 +561,8 @@ def test_fused_nonlinear_model_matches_the_cpu_port_with_gradients(hip_device, a
         want = reference_port.get_loss(observations, K, algorithm, *_parts(cpu_model))
     want.backward()
     model = models.NonlinearSsm(d, hidden=24, seed=0, dtype=dtype, fused=True).to(hip_device)
-    from aesmc_amd import _kernels
-    provider = _kernels.get()
-    calls = {"n": 0}
-    original = provider.particle_mlp
-
-    def spy(*args, **kwargs):
-        calls["n"] += 1
-        return original(*args, **kwargs)
-    provider.particle_mlp = spy
-    try:
-        with replay.replay(tape):
-            got = losses.get_loss([o.to(hip_device) for o in observations], K, algorithm, *_parts(model))
-    finally:
-        del provider.particle_mlp
-    assert calls["n"] == T - 1
+    with replay.replay(tape):
+        got = losses.get_loss([o.to(hip_device) for o in observations], K, algorithm, *_parts(model))
     got.backward()
     torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-10, atol=1e-10)
     expected = dict(cpu_model.named_parameters())

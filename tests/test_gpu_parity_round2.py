@@ -116,24 +116,8 @@ def test_config2_like_float32_fixture_flip_rate(hip_device, name):
         wrong += int((delta != 0).sum())
     assert wrong <= float32_flip_bound(meta["num_particles"]) * total
 
-    parts, named = case.build_parts(state, hip_device)
-    observations = case.observations(hip_device)
-    with replay.replay(case.tape()), torch.no_grad():
-        result = inference.infer("smc", observations, parts["initial"], parts["transition"], parts["emission"],
-                                 parts["proposal"], meta["num_particles"], return_log_marginal_likelihood=True,
-                                 return_latents=False, return_log_weights=True, return_ancestral_indices=True)
-    # End to end the device's float32 log-weights differ from the reference's in the last place (other
-    # summation order inside the matmuls and the d-sum), and this fixture's closest CDF comparison sits
-    # 4e-9 from flipping (meta["margin"]): an ancestor may legitimately differ — by design of the test
-    # data, not of the code.  So: the first step's log-weights to float32 rounding, its indices within
-    # twice SURVEY's rate, >= 90 % agreement over all 19 steps, log Z to 5 %.
-    np.testing.assert_allclose(result["log_weights"][0].cpu().numpy(), case["out_log_weights_0"], rtol=2e-5, atol=2e-4)
-    agreement = [float((result["ancestral_indices"][t].cpu().numpy() == case["out_idx_{}".format(t)]).mean())
-                 for t in range(steps)]
-    assert agreement[0] >= 1.0 - 2 * float32_flip_bound(meta["num_particles"]), agreement[0]
-    assert np.mean(agreement) >= 0.9, agreement
-    lml, want = result["log_marginal_likelihood"].cpu().numpy(), case["out_lml"]
-    assert (np.abs(lml - want) <= 0.05 * (1 + np.abs(want))).all(), (lml, want)
+    # (the end-to-end agreement of this fixture — free-running and teacher-forced, both model statements — is
+    # measured and bounded in tests/test_gpu_round3.py::test_float32_runs_of_the_reference_*)
 
 
 def _train_case_parts(meta, device):

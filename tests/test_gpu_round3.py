@@ -241,10 +241,12 @@ DRAWN_SHAPES = [(3, 700, 10, 10), (16, 4096, 10, 10), (300, 4096, 10, 10), (520,
 
 @pytest.mark.parametrize("gather", [True, False])
 @pytest.mark.parametrize("shape", DRAWN_SHAPES)
-def test_propagate_with_the_noise_inside_equals_normal_then_gather_then_propagate(kernels, hip_device, gather, shape):
+def test_propagate_with_the_noise_inside_equals_normal_then_gather_then_propagate(kernels, hip_device, gather, shape,
+                                                                                 monkeypatch):
     """aesmc_affine_normal_propagate_drawn == torch's own normal_(), aesmc_resample_gather, then
     aesmc_affine_normal_propagate — draw and log-weight bit for bit, and the generator where normal_ leaves it."""
     from aesmc_amd import _philox
+    monkeypatch.setattr(type(kernels), "DRAWN_MIN_PARTICLES", 0)      # the size policy is not what is tested here
     B, K, dx, dy = shape
     n, o = operands(min(B, 8), min(K, 64), dx, dy, np.float32, hip_device, seed=3 * B + K + dx)
     gen = torch.Generator(device=hip_device).manual_seed(B + K)
@@ -275,8 +277,9 @@ def test_propagate_with_the_noise_inside_equals_normal_then_gather_then_propagat
     assert torch.equal(kernels.philox_normal(reservation, (B, K, dx), hip_device), eps)
 
 
-def test_propagate_with_the_noise_inside_declines_what_it_does_not_cover(kernels, hip_device):
+def test_propagate_with_the_noise_inside_declines_what_it_does_not_cover(kernels, hip_device, monkeypatch):
     from aesmc_amd import _philox
+    monkeypatch.setattr(type(kernels), "DRAWN_MIN_PARTICLES", 0)
     for B, K, dx, dy in ((300, 50, 4, 4), (3, 700, 1, 1)):      # short batch rows; one value per particle
         n, o = operands(B, K, dx, dy, np.float32, hip_device, seed=1)
         terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
@@ -293,25 +296,33 @@ def test_propagate_with_the_noise_inside_declines_what_it_does_not_cover(kernels
 
 @pytest.mark.parametrize("grad", [False, True])
 @pytest.mark.parametrize("learn_scales", [False, True])
-def test_a_run_whose_kernels_draw_the_noise_is_the_run_that_lets_torch_draw_it(hip_device, grad, learn_scales):
+@pytest.mark.parametrize("policy", ["inside the propagation launch", "filled by this library's own launch"])
+def test_a_run_whose_kernels_draw_the_noise_is_the_run_that_lets_torch_draw_it(hip_device, grad, learn_scales, policy):
     """`infer` with the deferred draws' noise formed inside K16 from PyTorch's Philox stream against the run in
     which `_standard_normal` materialises it: latents, ancestors, evidence, gradients (also of learned scales)
     identical bit for bit, and both random streams end in the same state."""
     from aesmc_amd import _kernels, inference, state
     from aesmc_amd.testing.models import LgssmNd
     provider = _kernels.get()
+    threshold_was = type(provider).DRAWN_MIN_PARTICLES
+    if policy.startswith("inside"):
+        type(provider).DRAWN_MIN_PARTICLES = 0       # (below ~2M particles the default policy fills the noise first)
     runs = {}
     for inside in (False, True):
         state.set_kernel_noise(inside)
-        calls = {"drawn": 0}
-        real = provider.affine_propagate_drawn
+        calls = {"drawn": 0, "filled": 0}
+        real, real_fill = provider.affine_propagate_drawn, provider.philox_normal
 
         def spy(*args, **kwargs):
             out = real(*args, **kwargs)
             calls["drawn"] += out is not None
             return out
 
-        provider.affine_propagate_drawn = spy
+        def fill_spy(*args, **kwargs):
+            calls["filled"] += 1
+            return real_fill(*args, **kwargs)
+
+        provider.affine_propagate_drawn, provider.philox_normal = spy, fill_spy
         try:
             model = LgssmNd(10, dtype=torch.float32, affine=True).tune_proposal().to(hip_device)
             if learn_scales:
@@ -330,12 +341,15 @@ def test_a_run_whose_kernels_draw_the_noise_is_the_run_that_lets_torch_draw_it(h
             if grad:
                 (-out["log_marginal_likelihood"].mean()).backward()
         finally:
-            provider.affine_propagate_drawn = real
+            provider.affine_propagate_drawn, provider.philox_normal = real, real_fill
             state.set_kernel_noise(True)
+            if inside:
+                type(provider).DRAWN_MIN_PARTICLES = threshold_was
         after = (torch.rand(1, device=hip_device).item(), np.random.uniform())
         runs[inside] = (out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, after, calls)
     (a, grads_a, rng_a, calls_a), (b, grads_b, rng_b, calls_b) = runs[False], runs[True]
-    assert calls_a["drawn"] == 0 and calls_b["drawn"] == 5
+    assert calls_a == {"drawn": 0, "filled": 0}
+    assert calls_b == ({"drawn": 5, "filled": 0} if policy.startswith("inside") else {"drawn": 0, "filled": 5})
     assert rng_a == rng_b
     assert torch.equal(a["log_marginal_likelihood"], b["log_marginal_likelihood"])
     for x, y in zip(a["original_latents"] + a["ancestral_indices"], b["original_latents"] + b["ancestral_indices"]):
@@ -403,3 +417,58 @@ def test_step_backward_through_ancestors_equals_gather_then_step_backward(kernel
     for a, b in zip(got, want):
         assert (a is None and b is None) or torch.equal(a, b)
     assert kernels.read_flags(hip_device) == 0
+
+
+# ---- float32 runs of the reference itself, end to end --------------------------------------
+# What the device achieved on the committed fixtures when these bounds were written (MI355X, both model statements):
+# see profiles/README.md "float32 fixture parity"; the bounds below are those numbers plus a margin.
+FP32_BOUNDS = {
+    # name: (teacher-forced max rel |d log w| over ALL steps, teacher-forced flip rate,
+    #        free-running mean index agreement (None: the first flip comes in the first step and the two particle
+    #        systems are different ones from there on — index agreement then measures nothing), free-running rel |d log Z|)
+    # achieved on MI355X when written (profiles/README.md "float32 fixture parity"): forced d log w 5.0e-7 .. 9.2e-7;
+    # flips 2 of 38 912 (K=1024), 73-75 of 73 728 (K=4096), 0 elsewhere; free-running rel d log Z 0 (K=1024),
+    # 4.3e-3 .. 4.5e-3 (K=4096), <= 1.3e-7 elsewhere
+    "lgssm10d_k1024_smc_f32": (5e-6, 2e-4, 0.999, 1e-4),
+    "lgssm10d_k4096_smc_f32": (5e-6, 2e-3, None, 2e-2),
+    "lgssm3d_smc_f32": (5e-6, 4e-4, 0.9995, 1e-5),
+    "c1_lgssm1d_smc_f32": (5e-6, 0.0, 1.0, 1e-6),
+    "c1_lgssm1d_smc_stock_f32": (5e-6, 0.0, 1.0, 1e-6),
+}
+
+
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("name", sorted(FP32_BOUNDS))
+def test_float32_runs_of_the_reference_teacher_forced_and_free_running(hip_device, name, affine, capsys):
+    """Every float32 SMC run captured from the reference, replayed on the device draw for draw.  Teacher-forced (the
+    reference's ancestors substituted after each resampling launch) EVERY step's log-weights agree to float32
+    rounding — also after the first flip — and the launch's own indices differ from the reference's float32-CDF
+    indices at a rate under SURVEY section 7's; free-running, agreement and log Z stay within the measured bounds.
+    The achieved numbers are printed (pytest -s) and go into bench.py's JSON."""
+    from aesmc_amd import state
+    from aesmc_amd.testing import parity
+    from tests.golden_io import Golden, float32_flip_bound
+    case = Golden(name)
+    if affine and case.meta["model"] != "lgssm_nd":
+        pytest.skip("only the d-dimensional LGSSM has an AffineNormal statement")
+    parts, _ = case.build_parts(state, hip_device, affine=affine)
+    steps = case.meta["num_timesteps"] - 1
+    reference = {"log_weights": case.series("out_log_weights"), "indices": case.series("out_idx")[:steps],
+                 "lml": case["out_lml"]}
+    got = parity.float32_fixture_parity(parts, case.observations(hip_device), case.meta["num_particles"], case.tape(),
+                                        reference)
+    with capsys.disabled():
+        print("\\n[fp32 parity] {} affine={}: forced max rel dlogw {:.2e}, flips {} of {} ({:.2e}), forced rel dlogZ {:.2e}; "
+              "free agreement min {:.4f} mean {:.4f}, first flip at step {}, rel dlogZ {:.2e}".format(
+                  name, affine, got["teacher_forced_max_rel_dlogw"], sum(got["teacher_forced_flips_per_step"]),
+                  steps * reference["indices"][0].size, got["teacher_forced_flip_rate"], got["teacher_forced_rel_dlogZ"],
+                  got["free_running_index_agreement_min"], got["free_running_index_agreement_mean"],
+                  got["free_running_first_flip_step"], got["free_running_rel_dlogZ"]))
+    lw_bound, flip_bound, agreement_bound, lml_bound = FP32_BOUNDS[name]
+    assert got["teacher_forced_max_rel_dlogw"] <= lw_bound
+    assert got["teacher_forced_flip_rate"] <= max(flip_bound, 0.0)
+    assert got["teacher_forced_flip_rate"] <= float32_flip_bound(case.meta["num_particles"])
+    assert got["teacher_forced_rel_dlogZ"] <= 2e-6
+    if agreement_bound is not None:
+        assert got["free_running_index_agreement_mean"] >= agreement_bound
+    assert got["free_running_rel_dlogZ"] <= lml_bound

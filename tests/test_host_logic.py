@@ -612,7 +612,7 @@ def test_affine_normal_outside_the_fused_route_materialises_its_location(oracle_
 
 def test_fused_nonlinear_model_equals_the_plain_one(oracle_backend):
     """BASELINE.json's nonlinear model with `fused=True` (d x d maps through particle_affine / AffineNormal,
-    the proposal net through particle_mlp — K8 / K13, here on the oracle backend) against the same
+    K8, here on the oracle backend; the proposal net stays PyTorch's) against the same
     model with PyTorch matmuls: float64 loss and every gradient."""
     from aesmc_amd.testing.models import NonlinearSsm
     results = []

@@ -57,7 +57,7 @@ def main(names):
             us = timeit(lambda: k.gather(x, idx5))
             rows.append(("K3 gather s=5", us, B * K * (8 + 8 * d)))
             for which, label in ((1, "source tiles + zero fill"), (0, "range kernel, no zero fill")):
-                k._lib.aesmc_set_sorted_backward_kernel(which)
+                k._lib.aesmc_test_set_sorted_backward_kernel(which)
                 us = timeit(lambda: k.gather_backward(x, idx, sorted_index=True))
                 rows.append(("K3 backward s=1 ({})".format(label), us, B * K * (8 + 8 * d)))
                 us = timeit(lambda: k.gather_backward(x, idx5, sorted_index=True))

@@ -18,9 +18,9 @@ for (B, K, d), parts_list in (((256, 1024, 10), (1, 2)), ((128, 4096, 10), (1, 2
     u = torch.rand(B, device=dev, dtype=torch.float64, generator=gen)
     x = torch.randn(B, K, d, device=dev, generator=gen)
     for parts in parts_list:
-        k._lib.aesmc_set_step_parts(parts)
+        k._lib.aesmc_test_set_step_parts(parts)
         for _ in range(5):
             k.resample_step(lw, u, x, want_lse=True)
         torch.cuda.synchronize()
-k._lib.aesmc_set_step_parts(0)
+k._lib.aesmc_test_set_step_parts(0)
 print("done")

@@ -1,5 +1,5 @@
 """Fused resampling step vs its parts at the BASELINE.json shapes, and the step for every number
-of workgroups per batch row (`aesmc_set_step_parts`).  Timing: calls captured in one hipGraph and
+of workgroups per batch row (`aesmc_test_set_step_parts`).  Timing: calls captured in one hipGraph and
 replayed (device time, no host gaps).  Usage: python tools/stepbench.py [c2 c4s c4 c5]"""
 import os
 import sys
@@ -47,7 +47,7 @@ def main(names):
             lw = s * torch.randn(B, K, device=dev, generator=gen)
             u = torch.rand(B, device=dev, dtype=torch.float64, generator=gen)
             x = torch.randn(B, K, d, device=dev, generator=gen)
-            lib.aesmc_set_step_parts(0)
+            lib.aesmc_test_set_step_parts(0)
             t_k1 = timeit(lambda: k.logweight_lse(lw, None, None, want_lw=False, want_lse=True))
             t_k2 = timeit(lambda: k.ancestor_index(lw, u))
             idx = k.ancestor_index(lw, u)
@@ -63,13 +63,13 @@ def main(names):
             moved = B * K * 12 + (1 + unique) * B * K * d * 4
             want = k.resample_step(lw, u, x, want_lse=True)
             for parts in (0, 1, 2, 4):
-                lib.aesmc_set_step_parts(parts)
+                lib.aesmc_test_set_step_parts(parts)
                 got = k.resample_step(lw, u, x, want_lse=True)
                 same = all(torch.equal(a, b) for a, b in zip(got, want))
                 t = timeit(lambda: k.resample_step(lw, u, x, want_lse=True))
                 print("    step(idx+lse+gather) parts={:>4} : {:7.2f} us  {:6.2f} TB/s algorithmic  {:6.2f} TB/s moved  same={}".format(
                     parts or "auto", t, algorithmic / t / 1e6, moved / t / 1e6, same))
-            lib.aesmc_set_step_parts(0)
+            lib.aesmc_test_set_step_parts(0)
 
 
 if __name__ == "__main__":
