@@ -69,10 +69,11 @@ WORKLOADS["tiny"] = ("LGSSM d=3 B=8 K=64 T=5 (test-sized: exercises every leg of
                      "lgssm", 3, 8, 64, 5, {})
 ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
 NO_GRAD = {"c5", "c5h"}             # autograd retention of T x [B,K,128] temporaries exceeds HBM: forward under no_grad
-GRAPH_PARTICLES = 1 << 20           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
-                                    # (above it a captured graph does not pay: B=512 K=4096 19-30 ms as a graph from run
-                                    #  to run against 22.6 ms eager, B=1024 39.5 against 31 ms — the eager loop recycles
-                                    #  its per-step temporaries, a captured graph gives every one its own address)
+GRAPH_PARTICLES = 1 << 21           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
+                                    # (round 3, with neither the noise nor the resampled latent in HBM: B=512 K=4096
+                                    #  12.1 ms as a graph against 13.7 ms eager; B=1024 29.0 against 21 ms — above 2M
+                                    #  particles the loop is device-bound and the eager allocator's recycling of the
+                                    #  per-step tensors beats a graph that gives every one its own address)
 
 
 def parse(argv=None):
@@ -718,9 +719,17 @@ def main(argv=None):
             args.tunableop = "off"
 
     extras_on = (args.extras or ("on" if world == 1 else "off")) == "on"
+    seconds = {}          # wall time of every section of this run (the default run must stay within minutes)
+    clock = [time.perf_counter()]
+
+    def lap(label):
+        now = time.perf_counter()
+        seconds[label] = round(now - clock[0], 1)
+        clock[0] = now
     head = run_workload(ctx, args.workload, args.proposal, args.steps, args.warmup, scaling=args.scaling,
                         want_backward=not args.no_backward, mode=args.mode, grad=args.grad)
     description, kind, dim, B, K, T, model_kwargs = WORKLOADS[args.workload]
+    lap("headline workload")
 
     out = {
         "metric": "particle_steps_per_sec", "value": head["value"], "unit": "particle-steps/s",
@@ -772,16 +781,20 @@ def main(argv=None):
         if kind == "lgssm":
             other = "stock" if args.proposal == "tuned" else "tuned"
             extras["{}_proposal".format(other)] = brief(run_workload(
-                ctx, args.workload, other, args.steps, args.warmup, want_backward=False, mode=args.mode, grad=args.grad))
+                ctx, args.workload, other, max(2, args.steps // 2), min(args.warmup, 2), want_backward=False,
+                want_kernels=False, mode=args.mode, grad=args.grad))
+            lap("other proposal")
         if kind == "lgssm" and args.callables == "affine" and dim <= 16:
             # the same workload with the locations materialised by PyTorch matmuls (what rounds 1 and 2 timed)
             extras["matmul_callables"] = brief(run_workload(
-                ctx, args.workload, args.proposal, max(2, args.steps // 2), min(args.warmup, 2),
+                ctx, args.workload, args.proposal, 3, 1,
                 want_backward=not args.no_backward, want_kernels=False, mode=args.mode, grad=args.grad,
                 callables="matmul"))
+            lap("matmul callables")
         if args.workload != "c2":
             extras["c2_hipgraph"] = brief(run_workload(ctx, "c2", args.proposal, 20, 5,
                                                        want_backward=not args.no_backward))
+            lap("c2")
         if args.workload == "c4":
             # BASELINE.json configs[3]'s model (nonlinear SSM, learned proposal net) on one GPU's shard of it, forward
             # AND backward: the d x d maps through K8 / K11; the proposal net is the user's PyTorch module
@@ -798,14 +811,19 @@ def main(argv=None):
                     "mode": shard["mode"], "particle_steps_per_sec_per_gpu": shard["value"],
                     "projected_efficiency": round(head["ms_per_step"] / (n * shard["ms_per_step"]), 3)}
             extras["strong_scaling_projection"] = projection
+            lap("c4nl + strong-scaling projection")
         extras["kernel_legs"] = kernel_legs(ctx)
+        lap("kernel legs")
         extras["index_parity_vs_reference_fixtures"] = parity_block(ctx)
         extras["fp32_fixture_parity"] = fixture_parity_block(ctx)
-    if extras:
-        out["extras"] = extras
+        lap("parity blocks")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kind, dim, B, K, T, head["algorithm"],
                                            args.proposal if kind == "lgssm" else "stock", model_kwargs)
+        lap("cpu baseline")
+    if extras:
+        extras["bench_seconds"] = seconds
+        out["extras"] = extras
     if use_dist:
         dist.barrier()
     if rank == 0:

@@ -429,7 +429,9 @@ FP32_BOUNDS = {
     # achieved on MI355X when written (profiles/README.md "float32 fixture parity"): forced d log w 5.0e-7 .. 9.2e-7;
     # flips 2 of 38 912 (K=1024), 73-75 of 73 728 (K=4096), 0 elsewhere; free-running rel d log Z 0 (K=1024),
     # 4.3e-3 .. 4.5e-3 (K=4096), <= 1.3e-7 elsewhere
-    "lgssm10d_k1024_smc_f32": (5e-6, 2e-4, 0.999, 1e-4),
+    # (K=1024: the free-running numbers depend on which GEMM computes the callables' small matmuls — under bench.py's
+    #  TunableOp picks 4 indices flip instead of 2 and log Z moves by 1.6e-3 — so they are bounded like K=4096's)
+    "lgssm10d_k1024_smc_f32": (5e-6, 3e-4, None, 2e-2),
     "lgssm10d_k4096_smc_f32": (5e-6, 2e-3, None, 2e-2),
     "lgssm3d_smc_f32": (5e-6, 4e-4, 0.9995, 1e-5),
     "c1_lgssm1d_smc_f32": (5e-6, 0.0, 1.0, 1e-6),

@@ -2,20 +2,7 @@
 set -u
 OUT=gpurun_out
 mkdir -p $OUT
-timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/r03i_gpu.txt 2>&1; tail -6 $OUT/r03i_gpu.txt
-for cfg in "c4x2 graph" "c4 graph"; do
-set -- $cfg
-timeout -k 10 300 python bench.py --workload $1 --mode $2 --steps 5 --warmup 2 --no-cpu-baseline --extras off --no-backward > $OUT/r03i_$1_$2.json 2> $OUT/r03i_$1_$2.err
-python - <<PY
-import json
-try:
-    d = json.loads(open("$OUT/r03i_$1_$2.json").read())
-    print("$1 $2", d["value"], d["ms_per_step"], d.get("mode"), d.get("graph_error"))
-except Exception as e:
-    print("no json", e); print(open("$OUT/r03i_$1_$2.err").read()[-800:])
-PY
-done
-/usr/bin/time -v python bench.py > $OUT/r03i_bench_default.json 2> $OUT/r03i_bench_default.err; grep "Elapsed\|Maximum resident" $OUT/r03i_bench_default.err
+start=$(date +%s); python bench.py > $OUT/r03i_bench_default.json 2> $OUT/r03i_bench_default.err; echo "default bench wall: $(( $(date +%s) - start )) s"
 python - <<PY
 import json
 d = json.loads(open("$OUT/r03i_bench_default.json").read())
