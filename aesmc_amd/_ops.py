@@ -9,7 +9,7 @@ import torch
 
 from . import _kernels
 from . import _philox
-from ._lazy import LazyResampled
+from ._lazy import LazyParticles, LazyResampled
 
 
 class _LogWeightLSE(torch.autograd.Function):
@@ -363,7 +363,7 @@ class _ParticleAffine(torch.autograd.Function):
 
 def particle_affine(x, weight, offset=None):
     """[B,K,dout] location  offset + x @ weight.T  (kernel K8), differentiable in x, weight and offset."""
-    if type(x) is LazyResampled:
+    if isinstance(x, LazyParticles):
         x = x.materialise()
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, offset)):
         return _ParticleAffine.apply(x, weight, offset)
@@ -396,25 +396,9 @@ def _affine_rsample_backward(ctx, grad, source, weight, eps):
     return gsrc, gw, goff, gscale, None
 
 
-def _placeholder(source, weight, poison):
-    shape = source.shape[:2] + (weight.size(0),)
-    if poison:      # anything that reads the values before they exist sees NaN, not stale memory
-        return torch.full(shape, float("nan"), dtype=source.dtype, device=source.device)
-    return torch.empty(shape, dtype=source.dtype, device=source.device)
-
-
-def affine_rsample_deferred(source, weight, poison=True):
-    """A [B,K,dout] tensor standing for the reparameterised draw whose values come later (K16 / K15, or K9).
-    `poison`: filled with NaN until then (one fill launch) instead of left uninitialised.  It carries NO
-    autograd node: the fused step differentiates the draw inside its own node (K14), and when the step turns
-    out not to be fused, `state.materialise_draw` draws differentiably (K9) and copies the result in — which
-    ties this very tensor to the draw's operands for every use that follows."""
-    return _placeholder(source, weight, poison)
-
-
 def affine_rsample(source, weight, offset, scale, eps):
     """Reparameterised draw from Normal(offset + source @ weight.T, scale) given the noise (kernel K9)."""
-    if type(source) is LazyResampled:
+    if isinstance(source, LazyParticles):
         source = source.materialise()
     tensors = (source, weight, offset, scale)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
@@ -436,10 +420,17 @@ class AffineOperands(tuple):
 
     def gathered(self):
         """The same operands with x_prev as a real tensor (gathered now if it had not been)."""
-        if self.pending_gather is None and type(self[0]) is not LazyResampled:
+        if self.pending_gather is None and not isinstance(self[0], LazyParticles):
             return self
         out = AffineOperands((self[0].materialise(),) + tuple(self[1:]))
         out.is_draw = self.is_draw
+        return out
+
+    def with_latent(self, x_t):
+        """The same operands with the latent being weighed (slot 1) replaced — a lazy draw by the tensor that
+        receives / holds its values."""
+        out = AffineOperands((self[0], x_t) + tuple(self[2:]))
+        out.is_draw, out.pending_gather = self.is_draw, self.pending_gather
         return out
 
 
@@ -598,7 +589,7 @@ def affine_step(lw, operands):
     ancestors = None
     if operands.pending_gather is not None:       # the launch fetched x_{t-1}'s rows through the ancestors
         inputs[0], ancestors = operands.pending_gather
-    elif type(inputs[0]) is LazyResampled:
+    elif isinstance(inputs[0], LazyParticles):
         inputs[0] = inputs[0].materialise()
     pending.carrier, x_t = _AffineStep.apply(lw, operands[1].detach(), pending, ancestors, *inputs)
     return pending, x_t
@@ -636,7 +627,7 @@ def affine_propagate(operands, eps):
             source, ancestors = operands.pending_gather
         else:
             x_prev = operands[0]
-            source, ancestors = (x_prev.materialise() if type(x_prev) is LazyResampled else x_prev), None
+            source, ancestors = (x_prev.materialise() if isinstance(x_prev, LazyParticles) else x_prev), None
         lw = k.affine_propagate_drawn(source, eps, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q),
                                       out_x=x, ancestors=ancestors)
         if lw is not None:
@@ -650,6 +641,6 @@ def affine_propagate(operands, eps):
             return lw
         operands.pending_gather = None
     x_prev = operands[0]
-    x_prev = (x_prev.materialise() if type(x_prev) is LazyResampled else x_prev).detach()
+    x_prev = (x_prev.materialise() if isinstance(x_prev, LazyParticles) else x_prev).detach()
     return k.affine_propagate(x_prev, eps, y_rows, (A, off_p), (C, off_g), (Q, off_q),
                               (s_p, s_g, s_q), out_x=x, checked=True)    # state._affine_step_operands did

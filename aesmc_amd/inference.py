@@ -47,6 +47,19 @@ def set_lazy_gather(enabled):
     _LAZY_GATHER = bool(enabled)
 
 
+@contextlib.contextmanager
+def lazy_gather(enabled):
+    """`set_lazy_gather(enabled)` for the duration of a `with` block.  With it off the callables are handed plain
+    tensors, so a model written with PyTorch arithmetic (`x @ W.t() + c`) is evaluated by PyTorch itself — what the
+    tests use as the independent statement of such a model."""
+    global _LAZY_GATHER
+    previous, _LAZY_GATHER = _LAZY_GATHER, bool(enabled)
+    try:
+        yield
+    finally:
+        _LAZY_GATHER = previous
+
+
 class ResampledHistory(collections.abc.Sequence):
     """Read-only view of [resample(x, index) for x in latents] whose entries are gathered (K3)
     when first read.  Markov models read only [-1], so a step costs one gather, not `time`."""
@@ -377,13 +390,18 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                         # a linear-Gaussian step whose latent is the proposal's own draw: ONE autograd node
                         # for the step (K14).  It hands back x_t as its output — the tensor every later
                         # consumer reads; the row log-sum-exp is bound to it when a launch has produced it
-                        deferred[time], latent = _ops.affine_step(log_weight_t, operands)
-                        history[-1] = latent
-                        if keep_originals:
-                            originals[-1] = latent
+                        deferred[time], x_t = _ops.affine_step(log_weight_t, operands)
+                        if isinstance(latent, _lazy.LazyParticles):
+                            latent.resolve(x_t)     # whoever still holds the lazy draw reads this tensor
+                        latent = x_t
                     else:
                         deferred[time] = operands
-        state.materialise_draw(latent)      # a deferred draw that K15 did not fill gets its values now (K9)
+        # the latent as a tensor from here on: a lazy draw the fused launch formed resolves to that tensor, one that
+        # no launch formed is drawn now (K9)
+        latent = state.materialise_draw(latent)
+        history[-1] = latent
+        if keep_originals:
+            originals[-1] = latent
         if lazy_gather and use_smc and time > 0 and isinstance(ancestors, ResampledHistory) and ancestors.newest_was_read():
             lazy_gather = False
         # importance sampling over several timesteps normalises the SUM of the per-step weights

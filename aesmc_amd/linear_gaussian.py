@@ -29,6 +29,7 @@ import torch
 from torch.distributions import constraints
 
 from . import _kernels
+from . import _lazy
 from . import _ops
 
 
@@ -48,6 +49,46 @@ def particle_affine(x, weight, offset=None):
     return out
 
 
+class _Terms:
+    """A linear-Gaussian term as the fused kernels take it: loc = offset + source @ weight.T, one scale value."""
+    __slots__ = ("source", "weight", "offset", "scale_param", "_validate_args")
+
+    def __init__(self, source, weight, offset, scale_param, validate_args):
+        self.source, self.weight, self.offset, self.scale_param = source, weight, offset, scale_param
+        self._validate_args = validate_args
+
+    def same_terms(self, other):
+        return other is not None and self.source is other.source and self.weight is other.weight and \
+            self.offset is other.offset and self.scale_param is other.scale_param
+
+
+def affine_terms(distribution):
+    """The (source, weight, offset, scale_param) of a distribution that IS a linear-Gaussian term of the particles —
+    an `AffineNormal`, or a plain `torch.distributions.Normal` whose location is an affine expression recorded on a
+    lazy latent (`_lazy.LazyAffine`: the model wrote `Normal(x @ W.t() + c, s)` in the reference's own style,
+    test/models/lgssm.py:40) and whose scale is one value — else None."""
+    if type(distribution) is AffineNormal:
+        return distribution
+    if type(distribution) is not torch.distributions.Normal:
+        return None
+    cached = distribution.__dict__.get("_aesmc_terms")
+    if cached is not None:
+        return cached if cached.source is not None and distribution.loc.is_pending else None
+    loc = distribution.__dict__.get("loc")
+    if type(loc) is not _lazy.LazyAffine or not loc.is_pending:
+        return None
+    scale = distribution.__dict__.get("scale")
+    if not torch.is_tensor(scale) or isinstance(scale, _lazy.LazyParticles):
+        return None
+    if scale.numel() != 1:
+        if any(stride != 0 for stride in scale.stride()):      # one value, expanded by Normal's broadcast_all?
+            return None
+        scale = scale[(0,) * scale.dim()]
+    terms = _Terms(loc.source, loc.weight, loc.offset, scale, distribution._validate_args)
+    distribution.__dict__["_aesmc_terms"] = terms
+    return terms
+
+
 class AffineNormal(torch.distributions.Normal):
     """Normal(loc = source @ weight.T + offset, scale) with the location evaluated on demand.
 
@@ -55,23 +96,18 @@ class AffineNormal(torch.distributions.Normal):
     weight: [dout, din]; offset: None, [dout], or [batch_size, dout] (one row per batch element,
     shared by its particles — e.g. the observation's part of a proposal's mean);
     scale: tensor (or Python number) broadcastable to [..., dout]; the fused kernels take one value.
-    defer_draw: for a PROPOSAL whose model is linear-Gaussian throughout.  `infer` draws x_t from it
-        (aesmc/inference.py:106) and only then asks the transition and emission callables for their
-        distributions of x_t; when those are AffineNormals too, nothing needs x_t's values before the step
-        is weighed, and with `defer_draw=True` the draw is left to that launch (kernel K15: K9 and K10 in
-        one pass over x_{t-1} and the noise — the same bits as the two).  The noise is drawn where
-        `rsample` would draw it, so the RNG stream is unchanged; `infer` fills the values with K9 instead
-        whenever the step turns out not to be weighed that way.  The promise the model makes by setting
-        it: its transition and emission callables do not READ the values of the newest latent they are
-        handed (building an AffineNormal on it does not).  With argument validation on (PyTorch's
-        default) the latent holds NaN until its values exist, so a callable that reads it anyway fails
-        at once (a NaN parameter, or the NaN log-weight check of `infer`); `validate_args=False` skips
-        that fill.
+    defer_draw: None (default) / True — inside `infer`, a PROPOSAL's draw is not formed when `state.sample` is called
+        (aesmc/inference.py:106) but left to the launch that weighs the step (K16 / K15: the draw, its noise and the
+        log-weight in one pass): `state.sample` returns a `_lazy.LazyDraw`, a tensor without values.  The noise is
+        drawn (or reserved in PyTorch's generator) where `rsample` would draw it, so the RNG stream is unchanged.
+        Anything that READS the newest latent's values — a callable doing arithmetic on `latents[-1]` other than the
+        affine maps the fused kernels evaluate themselves, a step that turns out not to be linear-Gaussian — gets
+        the draw formed on the spot (K9), differentiably: no promise is asked of the model.  False — draw at once.
     """
 
     arg_constraints = {"scale": constraints.positive}
 
-    def __init__(self, source, weight, scale, offset=None, validate_args=None, defer_draw=False):
+    def __init__(self, source, weight, scale, offset=None, validate_args=None, defer_draw=None):
         if not (torch.is_tensor(source) and torch.is_tensor(weight)):
             raise TypeError("AffineNormal: source and weight must be tensors")
         if weight.dim() != 2 or source.dim() < 1 or source.size(-1) != weight.size(1):
@@ -95,9 +131,13 @@ class AffineNormal(torch.distributions.Normal):
                 tuple(scale.shape), tuple(batch_shape)))
         self.source, self.weight, self.offset = source, weight, offset
         self.scale_param = scale
-        self.defer_draw = bool(defer_draw)
+        self.defer_draw = defer_draw
         self._loc = None
         torch.distributions.Distribution.__init__(self, batch_shape, validate_args=validate_args)
+
+    def same_terms(self, other):
+        return other is self or (other is not None and self.source is other.source and self.weight is other.weight and
+                                 self.offset is other.offset and self.scale_param is other.scale_param)
 
     @property
     def loc(self):

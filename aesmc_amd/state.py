@@ -15,8 +15,9 @@ import torch
 from . import _kernels
 from . import _ops
 from . import _philox
-from ._lazy import LazyResampled
-from .linear_gaussian import AffineNormal
+from ._lazy import LazyAffine, LazyDraw, LazyParticles, LazyResampled
+from ._lazy import real as _lazy_real
+from .linear_gaussian import AffineNormal, affine_terms
 
 _VALIDATION_MODE = "deferred"
 
@@ -151,7 +152,7 @@ def log_prob(distribution, value):
     of distributions sums its members' log-densities (the reference's dict branch is unreachable:
     it names an undefined variable, state.py:130; this is the evident intent).
     """
-    if type(value) is LazyResampled:
+    if isinstance(value, LazyParticles):
         value = value.materialise()
     if isinstance(distribution, dict):
         total = None
@@ -191,21 +192,28 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     if not _FUSED_NORMAL:
         return None
     affine = _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, observation)
-    noise = getattr(latent, "_aesmc_pending_noise", None) if torch.is_tensor(latent) else None
-    if noise is not None:
-        # a deferred draw: K15 forms it together with the log-weight when the step is linear-Gaussian in this
+    if type(latent) is LazyDraw and latent.is_pending:
+        # a deferred draw: K16 / K15 forms it together with the log-weight when the step is linear-Gaussian in this
         # very proposal and the log-weights need no autograd node of their own; else K9 forms it now
         fused = affine is not None and affine.is_draw and (
             defer_grad or not (torch.is_grad_enabled() and affine.requires_grad()))
-        if not fused:
-            materialise_draw(latent)
-        else:
+        if fused:
             # (a previous latent that nothing has gathered yet is fetched through the ancestors by this launch)
-            log_weight = _ops.affine_propagate(affine, noise)
-            del latent._aesmc_pending_noise
-            for distribution, value in ((prior_dist, latent), (emission_dist, observation), (proposal_dist, latent)):
-                _validate_sample(distribution, value)
+            x_t = torch.empty(latent.shape, dtype=latent.dtype, device=latent.device)
+            log_weight = _ops.affine_propagate(affine.with_latent(x_t), latent.noise)
+            latent.resolve(x_t)
+            affine = affine.with_latent(x_t)
+            for distribution in (prior_dist, emission_dist, proposal_dist):
+                _validate_sample(distribution, observation if distribution is emission_dist else x_t)
             return (log_weight, affine) if defer_grad else log_weight
+        x_t = latent.materialise()
+        if affine is not None:
+            affine = affine.with_latent(x_t)
+        latent = x_t
+    elif isinstance(latent, LazyParticles):
+        latent = latent.materialise()
+        if affine is not None:
+            affine = affine.with_latent(latent)
     if affine is not None:
         affine = affine.gathered()      # every other route reads x_{t-1}[ancestors] as a tensor
         for distribution, value in ((prior_dist, latent), (emission_dist, observation), (proposal_dist, latent)):
@@ -297,35 +305,17 @@ def _noise_tensor(noise, latent):
 
 
 def materialise_draw(latent):
-    """Fills a deferred draw (AffineNormal(..., defer_draw=True) sampled by `sample`) with its values by
-    kernel K9 if no launch has produced them yet; anything else passes through.  `infer` calls it before
-    any route other than K15 touches the latent."""
+    """The latent with its values: a draw that was left to the launch that weighs the step (`LazyDraw`) and that no
+    such launch has formed is drawn now (K9, differentiable); anything else passes through.  Dict-aware."""
     if isinstance(latent, dict):
-        for value in latent.values():
-            materialise_draw(value)
-        return latent
-    eps = getattr(latent, "_aesmc_pending_noise", None) if torch.is_tensor(latent) else None
-    if eps is not None:
-        base = latent._aesmc_draw_of
-        del latent._aesmc_pending_noise
-        eps = _noise_tensor(eps, latent)
-        operands = (base.source, base.weight, base.offset, base.scale_param)
-        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in operands):
-            # the placeholder has no autograd node of its own (`_ops.affine_rsample_deferred`): draw through the
-            # differentiable operator and copy in — the in-place copy makes THIS tensor a function of the draw's
-            # operands for everything that uses it from here on
-            latent.copy_(_ops.affine_rsample(base.source, base.weight, base.offset, base.scale_param, eps))
-        else:
-            offset = None if base.offset is None else base.offset.detach()
-            _kernels.get().affine_rsample(base.source.detach(), base.weight.detach(), offset, eps,
-                                          base.scale_param.detach(), out=latent.detach())
-    return latent
+        return {key: materialise_draw(value) for key, value in latent.items()}
+    return latent.materialise() if isinstance(latent, LazyParticles) else latent
 
 
 def _same_tensor(a, b):
     if a is b:
         return True
-    if type(a) is LazyResampled or type(b) is LazyResampled:
+    if isinstance(a, LazyParticles) or isinstance(b, LazyParticles):
         return False
     return _same_storage_and_history(a, b)
 
@@ -341,17 +331,20 @@ def _same_storage_and_history(a, b):
 
 
 def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, observation):
-    """K10's operands when the step is linear-Gaussian — transition and proposal AffineNormal in the SAME
-    previous latent, emission AffineNormal in the latent being weighed, one scale value each, the
-    observation one row per batch element expanded over particles — else None."""
-    if not (type(prior_dist) is AffineNormal and type(proposal_dist) is AffineNormal and
-            type(emission_dist) is AffineNormal):
+    """K10's operands when the step is linear-Gaussian — transition and proposal linear-Gaussian terms
+    (`linear_gaussian.affine_terms`: an AffineNormal, or a plain Normal whose location is a recorded
+    `x @ W.t() + c`) in the SAME previous latent, the emission one in the latent being weighed, one scale value
+    each, the observation one row per batch element expanded over particles — else None."""
+    prior, proposal, emission = affine_terms(prior_dist), affine_terms(proposal_dist), affine_terms(emission_dist)
+    if prior is None or proposal is None or emission is None:
         return None
     if not (torch.is_tensor(latent) and torch.is_tensor(observation) and latent.dim() == 3 and
             observation.dim() == 3 and observation.stride(1) == 0):
         return None
-    x_prev = prior_dist.source
-    if not (_same_tensor(proposal_dist.source, x_prev) and _same_tensor(emission_dist.source, latent)):
+    x_prev = prior.source
+    if not (_same_tensor(proposal.source, x_prev) and _same_tensor(emission.source, latent)):
+        return None
+    if type(x_prev) is LazyDraw or type(x_prev) is LazyAffine:
         return None
     pending = None
     if type(x_prev) is LazyResampled:
@@ -359,16 +352,18 @@ def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, obse
         if pending is None:
             x_prev = x_prev.materialise()
     y_rows = observation[:, 0]
-    transition = (prior_dist.weight, prior_dist.offset)
-    emission = (emission_dist.weight, emission_dist.offset)
-    proposal = (proposal_dist.weight, proposal_dist.offset)
-    scales = (prior_dist.scale_param, emission_dist.scale_param, proposal_dist.scale_param)
-    if not _kernels.get().affine_logweight_covers(x_prev, latent, y_rows, transition, emission, proposal, scales):
+    transition_map = (prior.weight, prior.offset)
+    emission_map = (emission.weight, emission.offset)
+    proposal_map = (proposal.weight, proposal.offset)
+    scales = (prior.scale_param, emission.scale_param, proposal.scale_param)
+    if not _kernels.get().affine_logweight_covers(x_prev, latent, y_rows, transition_map, emission_map, proposal_map,
+                                                  scales):
         return None
-    operands = _ops.AffineOperands((x_prev, latent, y_rows, transition[0], transition[1], emission[0], emission[1],
-                                    proposal[0], proposal[1]) + scales)
-    # the latent is this very proposal's reparameterised draw (K9 tagged it): the step can be one autograd node
-    operands.is_draw = getattr(latent, "_aesmc_draw_of", None) is proposal_dist
+    operands = _ops.AffineOperands((x_prev, latent, y_rows, transition_map[0], transition_map[1], emission_map[0],
+                                    emission_map[1], proposal_map[0], proposal_map[1]) + scales)
+    # the latent is this very proposal's reparameterised draw: the step can be one autograd node
+    draw_of = latent.terms if type(latent) is LazyDraw else getattr(latent, "_aesmc_draw_of", None)
+    operands.is_draw = draw_of is not None and draw_of.same_terms(proposal)
     operands.pending_gather = pending
     return operands
 
@@ -395,36 +390,32 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
     base = distribution
     if type(base) is torch.distributions.Independent:
         base = base.base_dist
-    if type(base) is AffineNormal and len(sample_shape) == 0 and not swap_leading_dims:
-        # location + noise in one pass (K9); the noise is the call Normal.rsample makes
-        scale = base.scale_param
-        if scale.numel() == 1 and scale.dtype == base.source.dtype and scale.device == base.source.device and \
-                _kernels.get().affine_covers(base.source, base.weight, base.offset):
-            deferred = base.defer_draw and _DEFER_DRAWS.get()
-            if deferred and _kernel_noise_applies(base.source):
-                # the draw is left to the launch that weighs the step AND so is its noise: reserve, in PyTorch's
-                # own generator, exactly what `_standard_normal` would have consumed here — the kernel forms the
-                # same values from (seed, offset) — so the stream and everything drawn after it are unchanged
-                eps = _philox.reserve(base.source.numel() // base.source.size(-1) * base.weight.size(0),
-                                      base.source.device)
-            else:
-                eps = _standard_normal(base.batch_shape, dtype=base.source.dtype, device=base.source.device)
-            if not deferred and type(base.source) is LazyResampled:
-                base.source.materialise()       # K9 reads x_{t-1}[ancestors]
-            if deferred:
-                # the values come with the launch that weighs the step (K15), or from K9 the moment anything
-                # else needs them (`materialise_draw`)
-                # (with argument validation on — PyTorch's default — the placeholder is NaN until then, so a
-                # callable that breaks the promise and reads it fails loudly; validate_args=False skips the fill)
-                draw = _ops.affine_rsample_deferred(base.source, base.weight, poison=bool(base._validate_args))
-                draw._aesmc_pending_noise = eps
-            else:
-                draw = _ops.affine_rsample(base.source, base.weight, base.offset, scale, eps)
-            draw._aesmc_draw_of = base      # lets `infer` differentiate the whole step in one node (K14)
+    terms = affine_terms(base) if len(sample_shape) == 0 and not swap_leading_dims else None
+    if terms is not None:
+        # a linear-Gaussian term (AffineNormal, or Normal(x @ W.t() + c, s) recorded on a lazy latent): location +
+        # noise in one pass (K9), or — inside `infer` — left to the launch that weighs the step (K16 / K15)
+        scale = terms.scale_param
+        if scale.numel() == 1 and scale.dtype == terms.source.dtype and scale.device == terms.source.device and \
+                _kernels.get().affine_covers(terms.source, terms.weight, terms.offset):
+            source = terms.source
+            if _DEFER_DRAWS.get() and getattr(terms, "defer_draw", None) is not False:
+                if _kernel_noise_applies(source):
+                    # the draw's NOISE is left to that launch too: reserve, in PyTorch's own generator, exactly what
+                    # `_standard_normal` would have consumed here — the kernel forms the same values from (seed,
+                    # offset) — so the stream and everything drawn after it are unchanged
+                    eps = _philox.reserve(source.numel() // source.size(-1) * terms.weight.size(0), source.device)
+                else:
+                    eps = _standard_normal(base.batch_shape, dtype=source.dtype, device=source.device)
+                # holds no values: whoever reads them gets the draw (K9); a model that only describes distributions
+                # in terms of it — `Normal(latents[-1] @ C.t(), s)` — never does
+                return LazyDraw(terms, eps)
+            eps = _standard_normal(base.batch_shape, dtype=source.dtype, device=source.device)
+            draw = _ops.affine_rsample(source, terms.weight, terms.offset, scale, eps)
+            draw._aesmc_draw_of = terms      # lets `infer` differentiate the whole step in one node (K14)
             return draw
     if type(base) not in (torch.distributions.Normal, AffineNormal):
         return None
-    loc, scale = base.loc, base.scale
+    loc, scale = _lazy_real(base.loc), base.scale
     if not (loc.is_cuda and scale.device == loc.device and loc.dtype == scale.dtype and
             loc.dtype in (torch.float32, torch.float64)):
         return None
@@ -456,7 +447,7 @@ def _fused_normal_views(distribution, value, missing):
             value.dtype in (torch.float32, torch.float64)):
         return None
     views = []
-    for param in (base.loc, base.scale):
+    for param in (_lazy_real(base.loc), base.scale):
         if param.dtype != value.dtype:
             return None
         if param.device != value.device:
@@ -483,7 +474,7 @@ def resample(value, ancestral_index):
         return {key: resample(item, ancestral_index) for key, item in value.items()}
     if not torch.is_tensor(value):
         raise AttributeError("value must be a dict or a torch.Tensor. Got: {}".format(value))
-    if type(value) is LazyResampled:
+    if isinstance(value, LazyParticles):
         value = value.materialise()
     assert ancestral_index.size() == value.size()[:2]
     return _ops.resample_gather(value, ancestral_index)

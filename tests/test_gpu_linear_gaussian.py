@@ -246,8 +246,10 @@ def test_affine_callables_float32_agree_with_matmul_callables(hip_device):
         observations = [o.to(hip_device) for o in model.simulate(T, B, seed=1)]
         np.random.seed(2)
         torch.manual_seed(2)
-        results[affine] = inference.infer("smc", observations, *_parts(model), K, return_log_marginal_likelihood=True,
-                                          return_ancestral_indices=True, return_latents=False)
+        with inference.lazy_gather(affine):      # the matmul statement evaluated by PyTorch itself
+            results[affine] = inference.infer("smc", observations, *_parts(model), K,
+                                              return_log_marginal_likelihood=True, return_ancestral_indices=True,
+                                              return_latents=False)
     a, b = results[False], results[True]
     first = a["ancestral_indices"][0], b["ancestral_indices"][0]
     agree = float((first[0] == first[1]).double().mean())
@@ -693,9 +695,10 @@ def test_full_size_step_is_the_same_by_every_route(hip_device):
         observations = model.simulate(T, B, seed=5)
         torch.manual_seed(21)
         np.random.seed(21)
-        out = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal, K,
-                              return_log_marginal_likelihood=True, return_log_weight=False, return_latents=False,
-                              return_ancestral_indices=True)
+        with inference.lazy_gather(name != "matmul"):      # the matmul statement evaluated by PyTorch itself
+            out = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal,
+                                  K, return_log_marginal_likelihood=True, return_log_weight=False, return_latents=False,
+                                  return_ancestral_indices=True)
         (-out["log_marginal_likelihood"].mean()).backward()
         runs[name] = (out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
         del model, observations
