@@ -759,7 +759,10 @@ class HipKernels:
                 offset = offset.contiguous()
             off_ptr = offset.data_ptr()
             off_sb = offset.stride(0) if offset.dim() == 2 else 0
-        cached = slot is not None and self.timer is None      # (the timer keeps the structs of the launches it sampled)
+        # (the timer keeps the structs of the launches it sampled; a view such as `A.t()` — a tensor with an autograd
+        #  history — is never kept: a cache that outlives the step would keep that step's autograd graph alive, which
+        #  a later hipGraph capture of a backward pass cannot tolerate)
+        cached = slot is not None and self.timer is None and weight.grad_fn is None
         if cached:
             entry = self._map_cache.get((id(weight), slot))
             if entry is not None and entry[0] is weight and entry[1].weight == weight.data_ptr() and \
@@ -988,7 +991,10 @@ class HipKernels:
                    for s in scales):
             return False
         signature = self._offsets_signature(transition[1], emission[1], proposal[1], x.dtype, x.device)
-        if signature is not None:
+        kept = (transition[0], emission[0], proposal[0]) + tuple(scales)
+        if any(t.grad_fn is not None for t in kept):      # views with an autograd history are not kept (see _affine_map)
+            self._covers_last = None
+        elif signature is not None:
             self._covers_last = (transition[0], emission[0], proposal[0], scales[0], scales[1], scales[2],
                                  (x.shape, x.dtype, x.device), y_rows.shape, signature)
         return True

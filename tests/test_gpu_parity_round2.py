@@ -254,12 +254,14 @@ def test_folded_lse_backward_equals_the_two_launch_route_bit_for_bit(hip_device,
     parts = (model.initial, model.transition, model.emission, model.proposal)
     np.random.seed(1)
     torch.manual_seed(1)
-    with replay.record() as tape:
+    # (plain tensors to the callables: this test is about K5 — locations materialised by PyTorch — not about the
+    #  linear-Gaussian kernels a recorded `x @ W.t()` would reach)
+    with replay.record() as tape, inference.lazy_gather(False):
         loss = losses.get_loss(observations, K, "aesmc", *parts)
     loss.backward()
     folded = {name: p.grad.clone() for name, p in model.named_parameters() if p.grad is not None}
     model.zero_grad()
-    with replay.replay(tape):
+    with replay.replay(tape), inference.lazy_gather(False):
         out = inference.infer("smc", observations, *parts, K, return_log_marginal_likelihood=True,
                               return_latents=False, return_log_weight=True)
     unfolded_loss = -torch.mean(out["log_marginal_likelihood"])
