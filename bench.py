@@ -97,8 +97,11 @@ def parse(argv=None):
                     help="the extra blocks (stock proposal, configs[1] hipGraph, kernel legs, parity); default: on for N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-backward", action="store_true")
-    ap.add_argument("--tunableop", default="on", choices=["on", "off"],
-                    help="PyTorch TunableOp for the user callables' matmuls (tunes each GEMM shape once, in warm-up)")
+    ap.add_argument("--tunableop", default="off", choices=["on", "off"],
+                    help="PyTorch TunableOp for the user callables' matmuls (tunes each GEMM shape once, in warm-up). "
+                         "Off by default since round 3: the per-timestep matmuls of a model written `x @ W.t() + c` are "
+                         "recorded on the lazy latents and evaluated inside the fused kernels, and tuning the one "
+                         "[B*K, d] x [d, d] product left at time 0 took 200 s of the default run")
     ap.add_argument("--tunableop-file", default=None,
                     help="keep TunableOp's picks in this CSV: a later run that finds it skips the tuning trials "
                          "(used to profile without them)")
@@ -798,7 +801,7 @@ def main(argv=None):
         if args.workload == "c4":
             # BASELINE.json configs[3]'s model (nonlinear SSM, learned proposal net) on one GPU's shard of it, forward
             # AND backward: the d x d maps through K8 / K11; the proposal net is the user's PyTorch module
-            extras["c4nl"] = brief(run_workload(ctx, "c4nl", "stock", 5, 2, want_backward=not args.no_backward,
+            extras["c4nl"] = brief(run_workload(ctx, "c4nl", "stock", 3, 1, want_backward=not args.no_backward,
                                                 want_kernels=False, callables="affine"))
             # What one GPU's shard of the north-star batch costs on THIS device (global B = 1024 split over N GPUs:
             # B / N rows here): the strong-scaling curve, the one all-reduce of sum log Z per ELBO aside.
@@ -806,10 +809,20 @@ def main(argv=None):
             projection = {}
             for shard_name, n in (("c4x2", 2), ("c4x4", 4), ("c4s", 8)):
                 shard = run_workload(ctx, shard_name, args.proposal, 5, 2, want_backward=False, want_kernels=False)
-                projection["N={}".format(n)] = {
-                    "batch_per_gpu": shard["batch_per_gpu"], "ms_per_elbo": round(shard["ms_per_step"], 3),
-                    "mode": shard["mode"], "particle_steps_per_sec_per_gpu": shard["value"],
-                    "projected_efficiency": round(head["ms_per_step"] / (n * shard["ms_per_step"]), 3)}
+                entry = {"batch_per_gpu": shard["batch_per_gpu"], "ms_per_elbo": round(shard["ms_per_step"], 3),
+                         "mode": shard["mode"], "particle_steps_per_sec_per_gpu": shard["value"]}
+                if n == 2:
+                    # 2M particles sit on the boundary between the two modes, and a hipGraph captured late in a long
+                    # process has run 12 - 17 ms there: the eager loop is timed beside it and the better one counts
+                    eager = run_workload(ctx, shard_name, args.proposal, 5, 2, want_backward=False, want_kernels=False,
+                                         mode="eager")
+                    entry["ms_per_elbo_eager"] = round(eager["ms_per_step"], 3)
+                    entry["ms_per_elbo_hipgraph"] = entry["ms_per_elbo"]
+                    if eager["ms_per_step"] < shard["ms_per_step"]:
+                        entry.update(ms_per_elbo=round(eager["ms_per_step"], 3), mode=eager["mode"],
+                                     particle_steps_per_sec_per_gpu=eager["value"])
+                entry["projected_efficiency"] = round(head["ms_per_step"] / (n * entry["ms_per_elbo"]), 3)
+                projection["N={}".format(n)] = entry
             extras["strong_scaling_projection"] = projection
             lap("c4nl + strong-scaling projection")
         extras["kernel_legs"] = kernel_legs(ctx)
