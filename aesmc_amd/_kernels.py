@@ -373,7 +373,7 @@ class HipKernels:
         return all((x * esz) % 4 == 0 for x in (payload.stride(0), payload.stride(1))) and \
             payload.data_ptr() % 4 == 0
 
-    def resample_step(self, log_w, u, payload=None, want_lse=False):
+    def resample_step(self, log_w, u, payload=None, want_lse=False, want_child_end=False):
         """The fused step: (idx, lse, resampled payload) from one launch — idx as `ancestor_index`,
         lse = logsumexp over particles [B] when `want_lse`, payload[b, idx[b,k]] as `gather` when a
         payload tensor [B,K,...] is given (else None).  Returns None when the launch does not cover
@@ -414,11 +414,21 @@ class HipKernels:
         lse = torch.empty((B,), dtype=log_w.dtype, device=log_w.device) if want_lse else None
         if idx.numel() == 0:
             return None
+        child_end = None
         with _on_device(log_w.device):
             flags = self.flags(log_w.device)
-            args = (tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(lse), _ptr(payload if dst is not None else None),
-                    _ptr(dst), _ptr(flags), B, K, row_bytes, sb, sk, self._stream(log_w))
-            status = self._lib.aesmc_resample_step(*args)
+            if want_child_end and dst is None:
+                # the children ranges ride along (aesmc_resample_step_ranges): where each particle's children end, for
+                # the propagation's backward, which sums a particle's children itself (`idx._aesmc_child_end`)
+                child_end = torch.empty((B, K), dtype=torch.int32, device=log_w.device)
+                entry = self._lib.aesmc_resample_step_ranges
+                args = (tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(lse), _ptr(child_end), _ptr(flags), B, K,
+                        self._stream(log_w))
+            else:
+                entry = self._lib.aesmc_resample_step
+                args = (tag, _ptr(log_w), _ptr(u), _ptr(idx), _ptr(lse), _ptr(payload if dst is not None else None),
+                        _ptr(dst), _ptr(flags), B, K, row_bytes, sb, sk, self._stream(log_w))
+            status = entry(*args)
             if status == 2:
                 return None
             _lib.check(status, "aesmc_resample_step")
@@ -426,9 +436,12 @@ class HipKernels:
                 nbytes = B * K * (log_w.element_size() + 8) + 8 * B
                 if dst is not None:  # K2's 12 B + K3's (8 + 2 row_bytes) per particle
                     nbytes += B * K * (8 + 2 * row_bytes)
-                self.timer.note("resample_step", (self._lib.aesmc_resample_step, args), nbytes,
-                                (log_w, u, idx, lse, payload, dst))
+                if child_end is not None:
+                    nbytes += 4 * B * K
+                self.timer.note("resample_step", (entry, args), nbytes, (log_w, u, idx, lse, payload, dst, child_end))
         idx._aesmc_sorted = True
+        if child_end is not None:
+            idx._aesmc_child_end = child_end
         return idx, lse, dst
 
     # ---- K3 ------------------------------------------------------------------------------------
@@ -496,6 +509,16 @@ class HipKernels:
                                 (grad_out, idx, grad_src))
         return grad_src
 
+
+    def gather_backward_ranges(self, child_grad, child_end):
+        """grad_src[b,k] = sum of child_grad[b, child_end[b,k-1] : child_end[b,k]] — torch.gather's backward stated with
+        the children ranges instead of the indices (only for shapes the fused backward declines)."""
+        B, K = child_end.shape
+        ends = child_end.to(torch.int64)
+        position = torch.arange(K, device=child_end.device).unsqueeze(0).expand(B, K).contiguous()
+        # the ancestor of position k is the number of particles whose children end at or before k
+        index = torch.searchsorted(ends, position, right=True).clamp_(max=K - 1)
+        return self.gather_backward(child_grad, index, sorted_index=True)
 
     # ---- K4 ------------------------------------------------------------------------------------
     @staticmethod
@@ -1200,7 +1223,7 @@ class HipKernels:
 
     # ---- K14: the whole backward of a step whose x_t is the proposal's reparameterised draw ------
     def affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
-                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None):
+                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None, child_grad=None, child_end=None):
         """K14: gradients of one SMC step (log-weights `lw` of K10, their row log-sum-exp `lse`) whose x IS the
         draw  loc_q(x_prev) + s_q eps  of K9 from the same proposal operands, with respect to
         (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q) — x's own slot is always None: the
@@ -1226,8 +1249,19 @@ class HipKernels:
         if grad_x is not None:
             grad_x = self._dense16(grad_x)
             check(grad_x, (B, K, dx), "grad_x")
-        if not fused_lse and grad_lw is None and grad_x is None:
+        if not fused_lse and grad_lw is None and grad_x is None and child_grad is None:
             raise ValueError("aesmc_amd: affine_step_backward needs a gradient: (lw, lse, grad_lse), grad_lw or grad_x")
+        if child_grad is not None:
+            # the NEXT step's gradient of the rows it resampled from x (one row per child) and its children ranges: the
+            # kernel sums each particle's children itself — torch.gather's backward, where it is consumed
+            if ancestors is None:
+                raise ValueError("aesmc_amd: affine_step_backward folds the children's gradient only through ancestors")
+            check(child_grad, (B, K, dx), "child_grad")
+            child_grad = self._dense16(child_grad)
+            if child_end is None or child_end.shape != (B, K) or child_end.dtype != torch.int32 or \
+                    child_end.device != x.device:
+                raise ValueError("aesmc_amd: affine_step_backward child_end must be int32 [{}, {}] on {}".format(B, K, x.device))
+            child_end = child_end.contiguous()
         if ancestors is not None:
             # `x_prev` is the un-resampled latent: the kernel fetches x_prev[b, ancestors[b,k]] itself and slot 0 of
             # the result is the gradient of those RESAMPLED rows (the caller sums children into ancestors)
@@ -1254,15 +1288,19 @@ class HipKernels:
             middle = (_ptr(x), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
                       ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
                       _ptr(scales[2]), _ptr(lw) if fused_lse else 0, _ptr(lse) if fused_lse else 0,
-                      _ptr(grad_lse) if fused_lse else 0, _ptr(grad_lw), _ptr(grad_x), ctypes.byref(outs), _ptr(ws),
-                      ws_bytes)
+                      _ptr(grad_lse) if fused_lse else 0, _ptr(grad_lw), _ptr(grad_x))
+            tail = (ctypes.byref(outs), _ptr(ws), ws_bytes)
             if ancestors is not None:
                 entry = self._lib.aesmc_affine_step_backward_resampled
-                args = (tag, _ptr(x_prev), _ptr(ancestors)) + middle + (_ptr(self.flags(x.device)), B, K, self._stream(x))
+                args = (tag, _ptr(x_prev), _ptr(ancestors)) + middle + (_ptr(child_grad), _ptr(child_end)) + tail + \
+                    (_ptr(self.flags(x.device)), B, K, self._stream(x))
             else:
                 entry = self._lib.aesmc_affine_step_backward
-                args = (tag, _ptr(x_prev)) + middle + (B, K, self._stream(x))
+                args = (tag, _ptr(x_prev)) + middle + tail + (B, K, self._stream(x))
             status = entry(*args)
+            if status == 2 and child_grad is not None:      # the unfused route takes the summed gradient as a tensor
+                summed = self.gather_backward_ranges(child_grad, child_end)
+                grad_x, child_grad, child_end = (summed if grad_x is None else grad_x + summed), None, None
             if status == 2 and ancestors is not None:       # the unfused route wants the resampled rows as a tensor
                 x_prev, ancestors = self.gather(x_prev, ancestors), None
             if status == 2:     # too few particles per batch row for the fused kernel's row table
@@ -1276,9 +1314,12 @@ class HipKernels:
                                                      (dx if gx_prev is not None else 0))
                 if ancestors is not None:
                     nbytes += 8 * B * K
+                if child_grad is not None:
+                    nbytes += x.element_size() * B * K * dx + 4 * B * K
                 self.timer.note("affine_step_backward" + ("_resampled" if ancestors is not None else ""), (entry, args),
-                                nbytes, (x_prev, ancestors, x, y_rows, lw, lse, grad_lse, grad_lw, grad_x, outs, ws, maps,
-                                         scales, gA, gC, gQ, gscales, rows_p, rows_g, rows_q, gx_prev))
+                                nbytes, (x_prev, ancestors, x, y_rows, lw, lse, grad_lse, grad_lw, grad_x, child_grad,
+                                         child_end, outs, ws, maps, scales, gA, gC, gQ, gscales, rows_p, rows_g, rows_q,
+                                         gx_prev))
         fold = lambda rows, off: rows if off.dim() == 2 else rows.sum(dim=0)
         grads = [gx_prev, None, None, gA, None, gC, None, gQ, None, None, None, None]
         if need[2]:

@@ -80,8 +80,9 @@ SIGNATURES = {
                                              _i64, _i64, _vp]),
     "aesmc_affine_step_backward": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p] + [_vp] * 8 +
                                           [ctypes.POINTER(AffineLogweightGrads), _vp, _sz, _i64, _i64, _vp]),
-    "aesmc_affine_step_backward_resampled": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p] + [_vp] * 8 +
+    "aesmc_affine_step_backward_resampled": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p] + [_vp] * 10 +
                                                     [ctypes.POINTER(AffineLogweightGrads), _vp, _sz, _vp, _i64, _i64, _vp]),
+    "aesmc_resample_step_ranges": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_normal_logweight": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp,
                                              _i64, _i64, _vp]),
     "aesmc_affine_normal_propagate_resampled": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp,

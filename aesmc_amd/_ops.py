@@ -289,7 +289,7 @@ class _ResampleStep(torch.autograd.Function):
         return grad_w, None, grad_payload, None, grad_carrier
 
 
-def resample_step(log_weight, uniforms, payload=None, want_lse=False, pending=None):
+def resample_step(log_weight, uniforms, payload=None, want_lse=False, pending=None, want_child_end=False):
     """One resampling step: (ancestor indices [B,K], logsumexp over particles [B] or None,
     payload[b, idx[b,k], ...] or None).  One launch when the fused kernel covers the operands;
     `moved` is None when it does not cover the payload (the caller gathers with the indices).
@@ -310,7 +310,7 @@ def resample_step(log_weight, uniforms, payload=None, want_lse=False, pending=No
         # the log-sum-exp belongs to a step node: no autograd node here at all — `infer` ties the VALUE to the
         # node's carrier once, for all timesteps together (bind_rows)
         idx, lse, moved = k.resample_step(log_weight.detach(), uniforms, None if payload is None else payload.detach(),
-                                          want_lse)
+                                          want_lse, want_child_end=want_child_end)
         pending.box[0] = lse
         lse = LseOf(lse, pending)
     elif wants_grad and bind:
@@ -488,6 +488,24 @@ class LseOf:
         self.value, self.pending = value, pending
 
 
+class StepLink:
+    """What lets two consecutive steps' autograd nodes skip torch.gather's backward between them.  Step t+1 read the
+    rows of x_t through ancestors; its backward (K14) has the gradient of those rows, one per CHILD.  Instead of
+    summing children into ancestors in a launch of its own and handing the sum to autograd, it leaves the per-child
+    gradient HERE and returns no gradient for x_t; step t's backward — which autograd runs later, x_t being its
+    output — picks it up and sums each particle's children while it consumes them.  Sound as long as nothing else can
+    ask autograd for the gradient of x_t itself: `infer` arranges this only when it hands the latents to nobody
+    (return_latents = return_original_latents = False, what `losses.get_loss` asks for)."""
+    __slots__ = ("deposit",)
+
+    def __init__(self):
+        self.deposit = None
+
+    def take(self):
+        deposit, self.deposit = self.deposit, None
+        return deposit
+
+
 class PendingStep:
     """The link between a step's autograd node (_AffineStep, made when the step is weighed) and its row
     log-sum-exp, which the NEXT resampling launch produces: `carrier` is the node's [B] output that takes
@@ -549,40 +567,56 @@ class _AffineStep(torch.autograd.Function):
     accumulations autograd would put between them never run."""
 
     @staticmethod
-    def forward(ctx, lw, x_value, pending, ancestors, *operands):
+    def forward(ctx, lw, x_value, pending, ancestors, links, *operands):
         # `ancestors` (or None): operands[0] is the UN-resampled x_{t-1}; the step read its rows through them
+        # `links` = (this step's StepLink or None, the previous step's StepLink + children ranges or None)
         ctx.set_materialize_grads(False)      # an output nobody differentiated arrives as None, not as zeros
         ctx.lse_box = pending.box
-        ctx.save_for_backward(lw, x_value, ancestors, *[t for t in operands if t is not None])
+        ctx.own_link, ctx.parent_link = links
+        child_end = None if ctx.parent_link is None else ctx.parent_link[1]
+        ctx.save_for_backward(lw, x_value, ancestors, child_end, *[t for t in operands if t is not None])
         ctx.present = [t is not None for t in operands]
         return lw.new_empty((lw.size(0),)), x_value.view_as(x_value)     # the carrier's values are never read
 
     @staticmethod
     def backward(ctx, grad_lse, grad_x):
-        lw, x_value, ancestors = ctx.saved_tensors[:3]
-        saved = iter(ctx.saved_tensors[3:])
+        lw, x_value, ancestors, parent_child_end = ctx.saved_tensors[:4]
+        saved = iter(ctx.saved_tensors[4:])
         operands = [next(saved) if present else None for present in ctx.present]
         x_prev, _, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q = operands
-        need = list(ctx.needs_input_grad[4:])
+        need = list(ctx.needs_input_grad[5:])
         need[1] = False
         lse = ctx.lse_box[0]
         if grad_lse is not None and lse is None:
             raise RuntimeError("aesmc_amd internal error: a step's log-sum-exp received a gradient but was never bound")
         k = _kernels.get()
+        # what the NEXT step left for this one: the gradient of the rows it resampled from x_t, per child
+        child = ctx.own_link.take() if ctx.own_link is not None else None
+        if child is not None and ancestors is None:     # (this step did not go through ancestors itself: sum here)
+            summed = k.gather_backward_ranges(child[0], child[1])
+            grad_x, child = (summed if grad_x is None else grad_x + summed), None
         grads = k.affine_step_backward(
             x_prev, x_value, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q), need, lw, lse,
-            grad_lse=None if grad_lse is None else grad_lse.contiguous(), grad_x=grad_x, ancestors=ancestors)
+            grad_lse=None if grad_lse is None else grad_lse.contiguous(), grad_x=grad_x, ancestors=ancestors,
+            child_grad=None if child is None else child[0], child_end=None if child is None else child[1])
         if ancestors is not None and grads[0] is not None:
-            # torch.gather's backward (state.py:179): children's gradients summed into their ancestors; K2's
-            # indices are non-decreasing along k, so this is the atomic-free segmented sum
-            grads[0] = k.gather_backward(grads[0], ancestors, sorted_index=True)
-        return (None, None, None, None) + tuple(grads)
+            if ctx.parent_link is not None:
+                # the previous step's node sums these children into their ancestors itself (StepLink): no launch here,
+                # and no gradient for x_{t-1} through autograd
+                ctx.parent_link[0].deposit = (grads[0], parent_child_end)
+                grads[0] = None
+            else:
+                # torch.gather's backward (state.py:179): children's gradients summed into their ancestors; K2's
+                # indices are non-decreasing along k, so this is the atomic-free segmented sum
+                grads[0] = k.gather_backward(grads[0], ancestors, sorted_index=True)
+        return (None, None, None, None, None) + tuple(grads)
 
 
-def affine_step(lw, operands):
+def affine_step(lw, operands, fold_gather_backward=False):
     """(PendingStep, x_t) of a K10 step whose x_t is the proposal's draw: one autograd node ties x_t and —
     once `attach_lse` binds it — the row log-sum-exp of `lw` to the step's operands (see _AffineStep).
-    `operands[1]` (x_t) enters as a value."""
+    `operands[1]` (x_t) enters as a value.  `fold_gather_backward`: consecutive such steps hand the gather's
+    backward from node to node (StepLink) — only when nobody outside `infer` holds the latents."""
     pending = PendingStep()
     inputs = list(operands)
     inputs[1] = None
@@ -591,7 +625,18 @@ def affine_step(lw, operands):
         inputs[0], ancestors = operands.pending_gather
     elif isinstance(inputs[0], LazyParticles):
         inputs[0] = inputs[0].materialise()
-    pending.carrier, x_t = _AffineStep.apply(lw, operands[1].detach(), pending, ancestors, *inputs)
+    own_link = parent_link = None
+    if fold_gather_backward:
+        own_link = StepLink()
+        if ancestors is not None:
+            previous = getattr(inputs[0], "_aesmc_step_link", None)      # x_{t-1} is the previous step's output
+            child_end = getattr(ancestors, "_aesmc_child_end", None)
+            if previous is not None and child_end is not None:
+                parent_link = (previous, child_end)
+    pending.carrier, x_t = _AffineStep.apply(lw, operands[1].detach(), pending, ancestors, (own_link, parent_link),
+                                             *inputs)
+    if own_link is not None:
+        x_t._aesmc_step_link = own_link
     return pending, x_t
 
 

@@ -314,7 +314,8 @@ __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *
 template <typename T, int C>
 __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
-    int32_t *flags, int K, T *__restrict__ out_lse, StepPayload payload, int B, int parts) {
+    int32_t *flags, int K, T *__restrict__ out_lse, StepPayload payload, int B, int parts,
+    int32_t *__restrict__ out_child_end) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *scratch = smem;                                        // [64]
   int *scratch_i = reinterpret_cast<int *>(scratch + 32);
@@ -387,7 +388,10 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     }
     if (owns_idx)
       for (int i = 0; i < C; ++i)
-        if (j0 + i < K) idx[j0 + i] = (int64_t)K;
+        if (j0 + i < K) {
+          idx[j0 + i] = (int64_t)K;
+          if (out_child_end != nullptr) out_child_end[row * (int64_t)K + j0 + i] = 0;     // nobody has children
+        }
     if (payload.src == nullptr) return;
     // the unfused route would clamp the out-of-range index K to K - 1 in K3: same bytes here
     for (int k = tid; k < nt * C; k += nt) marker[k] = K - 1;
@@ -461,6 +465,14 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     } else {
       first[i] = K;
     }
+  }
+  // By-product for the gather's backward: first[j] = how many positions precede the CDF at j = where the children
+  // of particles 0..j end, so the children of particle j are the positions [first[j-1], first[j]) — one run, because
+  // the indices are non-decreasing.  (aesmc_affine_step_backward_resampled sums a particle's children with it.)
+  if (out_child_end != nullptr && owns_idx) {
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+      if (j0 + i < K) out_child_end[row * (int64_t)K + j0 + i] = first[i];
   }
   if (lane == 0) first_of_lane[wave] = first[0];            // the next wavefront's first entry, via LDS
   if constexpr (C % 4 == 0) {
@@ -589,7 +601,8 @@ static int pick_parts(int64_t B, int nt, bool has_payload) {
 template <typename T, int C>
 static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
                       int64_t K, hipStream_t s, void *out_lse = nullptr,
-                      const StepPayload &payload = StepPayload{nullptr, nullptr, 0, 0, 0, 0}) {
+                      const StepPayload &payload = StepPayload{nullptr, nullptr, 0, 0, 0, 0},
+                      int32_t *child_end = nullptr) {
   const int nt = pick_threads(K, C);
   const size_t lds = (size_t)kScratchDoubles * sizeof(double) + (size_t)(nt * C + nt + 8) * sizeof(int);
   // raise the dynamic-LDS cap once per device and instantiation (a process may drive several GPUs)
@@ -605,18 +618,18 @@ static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t 
   int parts = pick_parts(B, nt, payload.src != nullptr);
   while (parts > 1 && (nt % parts != 0 || B * parts > 0x7fffffffLL)) parts /= 2;
   hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
-                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts);
+                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts, child_end);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
 template <typename T>
 static int launch_step(const void *log_w, const double *u, int64_t *idx, void *out_lse, int32_t *flags,
-                       int64_t B, int64_t K, const StepPayload &payload, hipStream_t s) {
-  if (K <= 512) return launch_inv<T, 2>(log_w, u, idx, flags, B, K, s, out_lse, payload);
-  if (K <= 2048) return launch_inv<T, 4>(log_w, u, idx, flags, B, K, s, out_lse, payload);
-  if (K <= 8192) return launch_inv<T, 8>(log_w, u, idx, flags, B, K, s, out_lse, payload);
-  if (K <= 16384) return launch_inv<T, 16>(log_w, u, idx, flags, B, K, s, out_lse, payload);
-  if (K <= kInvMaxParticles) return launch_inv<T, 32>(log_w, u, idx, flags, B, K, s, out_lse, payload);
+                       int64_t B, int64_t K, const StepPayload &payload, hipStream_t s, int32_t *child_end = nullptr) {
+  if (K <= 512) return launch_inv<T, 2>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
+  if (K <= 2048) return launch_inv<T, 4>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
+  if (K <= 8192) return launch_inv<T, 8>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
+  if (K <= 16384) return launch_inv<T, 16>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
+  if (K <= kInvMaxParticles) return launch_inv<T, 32>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
   return AESMC_ERR_UNSUPPORTED;
 }
 
@@ -696,5 +709,21 @@ extern "C" int aesmc_resample_step(int dtype, const void *log_w, const double *u
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AESMC_F32) return launch_step<float>(log_w, u, out_idx, out_lse, flags, B, K, payload, s);
   if (dtype == AESMC_F64) return launch_step<double>(log_w, u, out_idx, out_lse, flags, B, K, payload, s);
+  return AESMC_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int aesmc_resample_step_ranges(int dtype, const void *log_w, const double *u, int64_t *out_idx,
+                                          void *out_lse, int32_t *out_child_end, int32_t *flags, int64_t B,
+                                          int64_t K, void *stream) {
+  using namespace aesmc;
+  if (log_w == nullptr || u == nullptr || out_idx == nullptr || out_child_end == nullptr || B < 0 || K < 0 ||
+      (((uintptr_t)out_child_end) & 3u) != 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (B == 0 || K == 0) return AESMC_OK;
+  if (K > kInvMaxParticles || B > 0x7fffffffLL) return AESMC_ERR_UNSUPPORTED;
+  const StepPayload none{nullptr, nullptr, 0, 0, 0, 0};
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AESMC_F32) return launch_step<float>(log_w, u, out_idx, out_lse, flags, B, K, none, s, out_child_end);
+  if (dtype == AESMC_F64) return launch_step<double>(log_w, u, out_idx, out_lse, flags, B, K, none, s, out_child_end);
   return AESMC_ERR_INVALID_ARGUMENT;
 }

@@ -55,6 +55,38 @@ template <bool OPAQUE> __device__ __forceinline__ uint32_t lg_tid_impl() {
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// ---- two particles per lane on the packed fp32 pipe ------------------------------------------------------------
+// A lane that owns two particles keeps element j of both in ONE 64-bit register pair and advances both chains with one
+// v_pk_fma_f32.  The weight that multiplies them is one float of a pair read from LDS (weights j, j+1 of input i lie
+// side by side), selected by the instruction's op_sel bits — written as inline assembly because the compiler, left to
+// vectorise `acc[j][r] = fma(w, x[r], acc[j][r])` itself, pairs DIFFERENT weights instead (A's and Q's, from two LDS
+// arrays) and spends a v_mov per multiply-add putting them side by side (measured: 299 v_mov beside 330 v_pk_fma in
+// K16's loop).  Same operation, same operands, same rounding as fmaf: the same bits.
+typedef float lg_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lg_f2 lg_pk_fma_lo(lg_f2 w, lg_f2 x, lg_f2 acc) {      // acc + w.x * x
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(x));
+  return acc;
+}
+__device__ __forceinline__ lg_f2 lg_pk_fma_hi(lg_f2 w, lg_f2 x, lg_f2 acc) {      // acc + w.y * x
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(x));
+  return acc;
+}
+template <typename T, int PPL> struct LgPacked { static constexpr bool value = false; };
+template <> struct LgPacked<float, 2> { static constexpr bool value = true; };
+
+// acc[j] (both particles) += W[j][i] * x_i (both particles) for the DP outputs of input element i; `wrow` = wt + i * DP
+template <int DP>
+__device__ __forceinline__ void lg_pk_column(const float *__restrict__ wrow, lg_f2 xv, lg_f2 (&acc)[DP]) {
+  static_assert(DP % 2 == 0, "weights are read in pairs");
+  const lg_f2 *w2 = reinterpret_cast<const lg_f2 *>(wrow);
+#pragma unroll
+  for (int jj = 0; jj < DP / 2; ++jj) {
+    const lg_f2 w = w2[jj];
+    acc[2 * jj] = lg_pk_fma_lo(w, xv, acc[2 * jj]);
+    acc[2 * jj + 1] = lg_pk_fma_hi(w, xv, acc[2 * jj + 1]);
+  }
+}
+
 template <typename T> struct LgConst;
 template <> struct LgConst<float> {
   static __device__ __forceinline__ float half_log_2pi() { return 0.9189385332046727f; }
@@ -153,6 +185,20 @@ __device__ __forceinline__ void lg_offsets(const LgMap &m, const uint32_t (&brow
 template <typename T, int DP, int PPL>
 __device__ __forceinline__ void lg_apply_tile(const T *__restrict__ wt, const T *__restrict__ tile,
                                               const uint32_t (&base)[PPL], int din, T (&acc)[DP][PPL]) {
+  if constexpr (LgPacked<T, PPL>::value) {
+    lg_f2 pk[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) pk[j] = lg_f2{acc[j][0], acc[j][1]};
+#pragma unroll
+    for (int i = 0; i < DP; ++i)
+      if (i < din) lg_pk_column<DP>(wt + i * DP, lg_f2{tile[base[0] + i], tile[base[1] + i]}, pk);
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      acc[j][0] = pk[j].x;
+      acc[j][1] = pk[j].y;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < DP; ++i) {
     if (i < din) {

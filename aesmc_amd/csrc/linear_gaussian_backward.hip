@@ -301,7 +301,14 @@ struct LgBackwardOut {
   const void *gx_in; // step kernel only: the gradient that arrives at x_t from later steps, or nullptr
   int want_scale_q;  // step kernel only: the proposal scale's gradient is wanted (costs the proposal's location)
   LgGather gat;      // step kernel only: `xprev` is the un-resampled latent, its rows fetched through gat.idx
+  // step kernel only: the NEXT step's gradient with respect to the rows it resampled from x_t, one row per child
+  // [B,K,dx], and where each particle's children end (child_end[b,k] = number of children of particles 0..k of row b):
+  // torch.gather's backward (the sum of a particle's children) is formed here, where it is consumed
+  const void *child_grad;
+  const int32_t *child_end;
 };
+
+constexpr int kLgChildLimit = 32;   // children a lane sums by itself; longer runs (a collapsed system) take the wavefront
 
 template <typename T, int DP, int PPL>
 __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_logweight_backward_kernel(
@@ -481,6 +488,25 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) voi
 // transition term (w -= u_p), then w itself takes the place K12 gives u_q: grad W_q = sum w (x) x_{t-1},
 // grad offset_q = row sums of w, grad x_{t-1} = A^T u_p + Q^T w, grad s_q = sum g d / s_q + w . eps.  Neither
 // a gradient for x_t nor K9's own backward launch (K11) nor the two [B,K,d] accumulations between them exist.
+// One row of the next step's per-child gradient, for the lane that owns the children's ancestor.
+template <typename T, int DP, bool EXACT>
+__device__ __forceinline__ void lg_child_row(const T *__restrict__ row, uint32_t dx, T (&v)[DP]) {
+  if constexpr (EXACT && (DP * sizeof(T)) % 8 == 0) {      // rows of whole 8-byte pairs, 8-byte aligned
+    typedef T Pair __attribute__((ext_vector_type(8 / sizeof(T))));
+    constexpr int PER = 8 / sizeof(T);
+    const Pair *src = reinterpret_cast<const Pair *>(row);
+#pragma unroll
+    for (int j = 0; j < DP / PER; ++j) {
+      const Pair q = src[j];
+#pragma unroll
+      for (int e = 0; e < PER; ++e) v[j * PER + e] = q[e];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) v[j] = (uint32_t)j < dx ? row[min(j, (int)dx - 1)] : T(0);
+  }
+}
+
 #ifndef LG_STEP_WAVES
 #define LG_STEP_WAVES 3
 #endif
@@ -539,9 +565,52 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     const int64_t n0 = (int64_t)blockIdx.x * TP;
     lg_anc_prefetch<PPL, true>(out.gat, n0, (uint32_t)min((int64_t)TP, N - n0), ranc);
   }
+  // the children of the lane's particles (the gather's backward folded in, below): where their rows begin and end in
+  // the next step's per-child gradient — loaded one tile ahead, like the ancestors
+  const bool folds = out.child_grad != nullptr;
+  const T *child_rows = reinterpret_cast<const T *>(out.child_grad);
+  int32_t cstart[PPL], cend[PPL];
+  auto child_ranges = [&](int64_t n0, uint32_t np) {
+    const uint32_t k0 = (uint32_t)(n0 % K);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const uint32_t q = lg_tid_impl<true>() + r * kLgBlock;
+      const bool lives = q < np;
+      const int64_t n = n0 + (lives ? q : 0u);
+      const bool first_of_row = (k0 + (lives ? q : 0u)) % K == 0;
+      // (no lane-dependent branch around the loads: a particle without a predecessor re-reads its own entry)
+      const int32_t e = out.child_end[n], b = out.child_end[first_of_row ? n : n - 1];
+      cend[r] = lives ? min(max(e, 0), (int32_t)K) : 0;
+      cstart[r] = min(max(first_of_row ? 0 : b, 0), cend[r]);
+    }
+  };
+  if (folds && (int64_t)blockIdx.x < tiles) {
+    const int64_t n0 = (int64_t)blockIdx.x * TP;
+    child_ranges(n0, (uint32_t)min((int64_t)TP, N - n0));
+  }
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    // ---- the first two children's rows of each particle go out before anything else of the tile (most particles
+    // have no more); their ranges came a tile ago, the next tile's are sent for right behind them
+    T child_a[PPL][DP], child_b[PPL][DP];
+    int32_t own_start[PPL], own_end[PPL];
+    if (folds) {
+      const uint32_t b0_ = (uint32_t)(n0 / K), k0_ = (uint32_t)(n0 - (int64_t)b0_ * K);
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        const uint32_t q = lg_tid_impl<true>() + r * kLgBlock;
+        const uint32_t brow_r = b0_ + (k0_ + (q < np ? q : 0u)) / K;
+        const T *rows = child_rows + (int64_t)brow_r * K * dx;
+        own_start[r] = cstart[r];
+        own_end[r] = cend[r];
+        const int32_t c0 = min(own_start[r], (int32_t)K - 1), c1 = min(own_start[r] + 1, (int32_t)K - 1);
+        lg_child_row<T, DP, EXACT>(rows + (int64_t)c0 * dx, dx, child_a[r]);
+        lg_child_row<T, DP, EXACT>(rows + (int64_t)c1 * dx, dx, child_b[r]);
+      }
+      const int64_t m0 = (tile + gridDim.x) * TP;
+      if (m0 < N) child_ranges(m0, (uint32_t)min((int64_t)TP, N - m0));
+    }
     if (gathers) {
       lg_gather_stage<T, PPL, DP, true>(reinterpret_cast<const char *>(xprev), out.gat, n0, np, K, ranc, tprev, lx);
       const int64_t m0 = (tile + gridDim.x) * TP;
@@ -586,6 +655,64 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
         w[j][r] = (gx_in != nullptr && (uint32_t)j < dx && live[r]) ? tu[au[r] + min(j, (int)dx - 1)] : T(0);
       }
     if (gx_in != nullptr && lx.rs != ly.rs) lg_lds_barrier();   // the tile changes layout under the other wavefronts
+    if (folds) {
+      // ---- the gather's backward folded in: w += sum of the particle's children's rows ------------------------
+      // Ancestor indices are non-decreasing along k, so a particle's children are ONE run of rows of the next
+      // step's per-child gradient.  The lane adds its run in k order (fixed, so reproducible; the stand-alone
+      // segmented-sum kernel associates differently: equal to rounding); a run longer than kLgChildLimit is shared
+      // out over the wavefront.  The first two rows are in registers already (sent for at the top of the tile).
+      const int lane = (int)(threadIdx.x & (kWave - 1));
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        const int32_t start = own_start[r], end = own_end[r];
+        const T *rows = child_rows + (int64_t)brow[r] * K * dx;
+        T acc[DP];
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          acc[j] = start < end ? child_a[r][j] : T(0);
+          if (start + 1 < end) acc[j] = acc[j] + child_b[r][j];
+        }
+        const int32_t own_last = min(end, start + kLgChildLimit);
+        // two rows in flight per trip; added in k order: ((c0 + c1) + c2) + ...
+        for (int32_t c = start + 2; c < own_last; c += 2) {
+          T a[DP], b[DP];
+          const bool two = c + 1 < own_last;
+          lg_child_row<T, DP, EXACT>(rows + (int64_t)c * dx, dx, a);
+          lg_child_row<T, DP, EXACT>(rows + (int64_t)(two ? c + 1 : c) * dx, dx, b);
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+            acc[j] = acc[j] + a[j];
+            if (two) acc[j] = acc[j] + b[j];
+          }
+        }
+        uint64_t todo = __ballot(own_last < end);
+        while (todo != 0) {        // wavefront-uniform: every lane helps the lane whose run is long
+          const int leader = __ffsll((long long)todo) - 1;
+          const int32_t from = __shfl(own_last, leader, kWave), to = __shfl(end, leader, kWave);
+          const uint32_t leader_row = (uint32_t)__shfl((int)brow[r], leader, kWave);
+          const T *lrows = child_rows + (int64_t)leader_row * K * dx;
+          T part[DP];
+#pragma unroll
+          for (int j = 0; j < DP; ++j) part[j] = T(0);
+          for (int32_t c = from + lane; c < to; c += kWave) {
+            T row[DP];
+            lg_child_row<T, DP, EXACT>(lrows + (int64_t)c * dx, dx, row);
+#pragma unroll
+            for (int j = 0; j < DP; ++j) part[j] += row[j];
+          }
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) part[j] += __shfl_xor(part[j], off, kWave);
+            if (lane == leader) acc[j] += part[j];
+          }
+          todo &= todo - 1;
+        }
+#pragma unroll
+        for (int j = 0; j < DP; ++j)
+          if ((uint32_t)j < dx && live[r]) w[j][r] = w[j][r] + acc[j];
+      }
+    }
     // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u
     lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, u);
     lg_apply_loop<T, DP, PPL, kUnroll>(wf + DP * DP, tx, at, dx, u);
@@ -830,7 +957,8 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
                                             const aesmc_affine_logweight_grads *o, void *ws, size_t ws_bytes, int64_t B,
                                             int64_t K, hipStream_t stream, bool step = false,
                                             const void *gx_in = nullptr, const int64_t *anc_idx = nullptr,
-                                            int32_t *flags = nullptr) {
+                                            int32_t *flags = nullptr, const void *child_grad = nullptr,
+                                            const int32_t *child_end = nullptr) {
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
@@ -860,6 +988,9 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   out.uq = o->grad_loc_q; out.ws = ws; out.rows = row_ws; out.row_terms = row_terms;
   out.gx_in = gx_in; out.want_scale_q = o->grad_scales != nullptr ? 1 : 0;
   out.gat = lg_gather(anc_idx, flags, (size_t)dx * sizeof(T));
+  out.child_grad = child_grad;
+  out.child_end = child_end;
+  if ((child_grad != nullptr) != (child_end != nullptr) || (child_grad != nullptr && !step)) return AESMC_ERR_UNSUPPORTED;
   if (anc_idx != nullptr && (!step || N > 0x7fffffffLL)) return AESMC_ERR_UNSUPPORTED;
 #define LG_BACKWARD_ARGS                                                                                            \
   static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), \
@@ -941,8 +1072,8 @@ static int affine_step_backward_entry(
     int64_t y_stride_b, const aesmc_affine_map *transition,
     const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
     const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
-    const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K,
-    void *stream);
+    const void *grad_x, const void *child_grad, const int32_t *child_end, const aesmc_affine_logweight_grads *out,
+    void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream);
 
 extern "C" int aesmc_affine_step_backward(
     int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
@@ -951,20 +1082,24 @@ extern "C" int aesmc_affine_step_backward(
     const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K,
     void *stream) {
   return affine_step_backward_entry(dtype, x_prev, nullptr, nullptr, x, y, y_stride_b, transition, emission, proposal,
-                                    scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, grad_x, out, ws, ws_bytes, B,
-                                    K, stream);
+                                    scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, grad_x, nullptr, nullptr, out,
+                                    ws, ws_bytes, B, K, stream);
 }
 
 extern "C" int aesmc_affine_step_backward_resampled(
     int dtype, const void *x_src, const int64_t *ancestors, const void *x, const void *y, int64_t y_stride_b,
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
-    const void *grad_lse, const void *grad_lw, const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws,
-    size_t ws_bytes, int32_t *flags, int64_t B, int64_t K, void *stream) {
+    const void *grad_lse, const void *grad_lw, const void *grad_x, const void *child_grad, const int32_t *child_end,
+    const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int32_t *flags, int64_t B, int64_t K,
+    void *stream) {
   if (ancestors == nullptr || (((uintptr_t)ancestors) & 7u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
+  if ((child_grad == nullptr) != (child_end == nullptr) || (((uintptr_t)child_end) & 3u) != 0 ||
+      (child_grad != nullptr && child_grad == (out != nullptr ? out->grad_x_prev : nullptr)))
+    return AESMC_ERR_INVALID_ARGUMENT;
   return affine_step_backward_entry(dtype, x_src, ancestors, flags, x, y, y_stride_b, transition, emission, proposal,
-                                    scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, grad_x, out, ws, ws_bytes, B,
-                                    K, stream);
+                                    scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, grad_x, child_grad, child_end,
+                                    out, ws, ws_bytes, B, K, stream);
 }
 
 static int affine_step_backward_entry(
@@ -972,8 +1107,8 @@ static int affine_step_backward_entry(
     int64_t y_stride_b, const aesmc_affine_map *transition,
     const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
     const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
-    const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int64_t B, int64_t K,
-    void *stream) {
+    const void *grad_x, const void *child_grad, const int32_t *child_end, const aesmc_affine_logweight_grads *out,
+    void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream) {
   if (out == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
   // the draw leaves no gradient for x_t and the location gradients have no meaning here
   if (out->grad_x != nullptr || out->grad_loc_p != nullptr || out->grad_loc_g != nullptr || out->grad_loc_q != nullptr)
@@ -982,7 +1117,8 @@ static int affine_step_backward_entry(
       proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || ws == nullptr || B < 0 ||
       K < 0)
     return AESMC_ERR_INVALID_ARGUMENT;
-  if (grad_lw == nullptr && grad_lse == nullptr && grad_x == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  if (grad_lw == nullptr && grad_lse == nullptr && grad_x == nullptr && child_grad == nullptr)
+    return AESMC_ERR_INVALID_ARGUMENT;
   if (grad_lse != nullptr && (lw == nullptr || lse == nullptr)) return AESMC_ERR_INVALID_ARGUMENT;
   if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
   const void *aligned[] = {x_prev, x, ws, grad_x, out->grad_x_prev};
@@ -1006,10 +1142,12 @@ static int affine_step_backward_entry(
   return dtype == AESMC_F32
              ? launch_affine_logweight_backward<float>(x_prev, x, y, y_stride_b, transition, emission, proposal,
                                                        scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
-                                                       ws_bytes, B, K, s, true, grad_x, ancestors, flags)
+                                                       ws_bytes, B, K, s, true, grad_x, ancestors, flags, child_grad,
+                                                       child_end)
              : launch_affine_logweight_backward<double>(x_prev, x, y, y_stride_b, transition, emission, proposal,
                                                         scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
-                                                        ws_bytes, B, K, s, true, grad_x, ancestors, flags);
+                                                        ws_bytes, B, K, s, true, grad_x, ancestors, flags, child_grad,
+                                                       child_end);
 }
 
 

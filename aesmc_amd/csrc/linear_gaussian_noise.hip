@@ -316,6 +316,27 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
         locp[j][r] = tab[trow[r] + 0 * DP + j];
         locq[j][r] = tab[trow[r] + 1 * DP + j];
       }
+    if constexpr (LgPacked<T, PPL>::value) {      // both particles of the lane per multiply-add (linear_gaussian.hpp)
+      lg_f2 ap[DP], aq[DP];
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        ap[j] = lg_f2{locp[j][0], locp[j][1]};
+        aq[j] = lg_f2{locq[j][0], locq[j][1]};
+      }
+#pragma unroll
+      for (int i = 0; i < DP; ++i) {
+        if ((uint32_t)i < dx) {
+          const lg_f2 xv = lg_f2{tprev[at[0] + i], tprev[at[1] + i]};
+          lg_pk_column<DP>(wp + i * DP, xv, ap);
+          lg_pk_column<DP>(wq + i * DP, xv, aq);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        locp[j][0] = ap[j].x; locp[j][1] = ap[j].y;
+        locq[j][0] = aq[j].x; locq[j][1] = aq[j].y;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
       if ((uint32_t)i < dx) {
@@ -332,6 +353,7 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
           }
         }
       }
+    }
     }
     T xx[DP][PPL], qp[PPL], qq[PPL], qg[PPL];
 #pragma unroll
@@ -373,6 +395,18 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
     for (int r = 0; r < PPL; ++r)
 #pragma unroll
       for (int j = 0; j < DP; ++j) locg[j][r] = tab[trow[r] + 2 * DP + j];
+    if constexpr (LgPacked<T, PPL>::value) {
+      lg_f2 ag[DP];
+#pragma unroll
+      for (int j = 0; j < DP; ++j) ag[j] = lg_f2{locg[j][0], locg[j][1]};
+#pragma unroll
+      for (int i = 0; i < DP; ++i)
+        if ((uint32_t)i < dx) lg_pk_column<DP>(wg + i * DP, lg_f2{xx[i][0], xx[i][1]}, ag);
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        locg[j][0] = ag[j].x; locg[j][1] = ag[j].y;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
       if ((uint32_t)i < dx) {
@@ -383,6 +417,7 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
           for (int r = 0; r < PPL; ++r) locg[j][r] = fma_t(c, xx[i][r], locg[j][r]);
         }
       }
+    }
     }
 #pragma unroll
     for (int j = 0; j < DP; ++j) {

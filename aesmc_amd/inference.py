@@ -60,6 +60,22 @@ def lazy_gather(enabled):
         _LAZY_GATHER = previous
 
 
+_FOLD_GATHER_BACKWARD = _os.environ.get("AESMC_FOLD_GATHER_BACKWARD", "1") != "0"      # measurement knob
+
+
+@contextlib.contextmanager
+def fold_gather_backward(enabled):
+    """On (default): consecutive linear-Gaussian steps hand torch.gather's backward from autograd node to autograd
+    node (`_ops.StepLink`; only when `infer` returns the latents to nobody).  Off: each step's backward sums the
+    children's gradients into their ancestors in a launch of its own (rounds 2-3a) — the tests' comparison run."""
+    global _FOLD_GATHER_BACKWARD
+    previous, _FOLD_GATHER_BACKWARD = _FOLD_GATHER_BACKWARD, bool(enabled)
+    try:
+        yield
+    finally:
+        _FOLD_GATHER_BACKWARD = previous
+
+
 class ResampledHistory(collections.abc.Sequence):
     """Read-only view of [resample(x, index) for x in latents] whose entries are gathered (K3)
     when first read.  Markov models read only [-1], so a step costs one gather, not `time`."""
@@ -313,6 +329,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
     feed = None
     device = None
     lazy_gather = _LAZY_GATHER
+    fold_children = _FOLD_GATHER_BACKWARD and use_smc and not keep_originals
     bound_rows = []       # (timestep, PendingStep): rows of the log-sum-exp stack that are values owned by step nodes
 
     for time in range(num_timesteps):
@@ -335,8 +352,12 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                 # the resampling launch (one launch and one read of the indices cheaper than K2, then K3).
                 lazy_step = lazy_gather and newest is not None and _HISTORY_MODE == "lazy" and \
                     newest.dim() == 3 and newest.is_floating_point()
+                # (with the latents handed to nobody, consecutive linear-Gaussian steps pass the gather's backward from
+                #  node to node — `_ops.StepLink` — and the resampling launch writes the children ranges it needs)
+                fold_gather = lazy_step and pending is not None and fold_children and torch.is_grad_enabled()
                 index, lse_previous, moved = _ops.resample_step(previous, feed.next(), None if lazy_step else newest,
-                                                                want_lse=step_lse[-1] is None, pending=pending)
+                                                                want_lse=step_lse[-1] is None, pending=pending,
+                                                                want_child_end=fold_gather)
                 if step_lse[-1] is None:
                     if pending is not None:
                         del deferred[time - 1]
@@ -390,7 +411,8 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                         # a linear-Gaussian step whose latent is the proposal's own draw: ONE autograd node
                         # for the step (K14).  It hands back x_t as its output — the tensor every later
                         # consumer reads; the row log-sum-exp is bound to it when a launch has produced it
-                        deferred[time], x_t = _ops.affine_step(log_weight_t, operands)
+                        deferred[time], x_t = _ops.affine_step(log_weight_t, operands,
+                                                               fold_gather_backward=fold_children)
                         if isinstance(latent, _lazy.LazyParticles):
                             latent.resolve(x_t)     # whoever still holds the lazy draw reads this tensor
                         latent = x_t

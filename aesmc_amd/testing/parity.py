@@ -26,7 +26,7 @@ def _run(parts, observations, num_particles, tape, forced_indices=None):
     own = []
     real = _ops.resample_step
 
-    def forcing(log_weight, uniforms, payload=None, want_lse=False, pending=None):
+    def forcing(log_weight, uniforms, payload=None, want_lse=False, pending=None, **unused):
         index, lse, moved = real(log_weight, uniforms, None, want_lse=want_lse, pending=pending)
         own.append(index)
         step = len(own) - 1

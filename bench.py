@@ -69,11 +69,11 @@ WORKLOADS["tiny"] = ("LGSSM d=3 B=8 K=64 T=5 (test-sized: exercises every leg of
                      "lgssm", 3, 8, 64, 5, {})
 ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
 NO_GRAD = {"c5", "c5h"}             # autograd retention of T x [B,K,128] temporaries exceeds HBM: forward under no_grad
-GRAPH_PARTICLES = 1 << 21           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
-                                    # (round 3, with neither the noise nor the resampled latent in HBM: B=512 K=4096
-                                    #  12.1 ms as a graph against 13.7 ms eager; B=1024 29.0 against 21 ms — above 2M
-                                    #  particles the loop is device-bound and the eager allocator's recycling of the
-                                    #  per-step tensors beats a graph that gives every one its own address)
+GRAPH_PARTICLES = 1 << 20           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
+                                    # (above it a captured graph does not pay and is erratic: B=512 K=4096 12.1, 16.8
+                                    #  and 27.6 ms as a graph in three runs of round 3 against 13.7 ms eager, B=1024 29.0
+                                    #  against 21 ms — the loop is device-bound there and the eager allocator's
+                                    #  recycling of the per-step tensors beats a graph that gives every one its own address)
 
 
 def parse(argv=None):
@@ -811,16 +811,6 @@ def main(argv=None):
                 shard = run_workload(ctx, shard_name, args.proposal, 5, 2, want_backward=False, want_kernels=False)
                 entry = {"batch_per_gpu": shard["batch_per_gpu"], "ms_per_elbo": round(shard["ms_per_step"], 3),
                          "mode": shard["mode"], "particle_steps_per_sec_per_gpu": shard["value"]}
-                if n == 2:
-                    # 2M particles sit on the boundary between the two modes, and a hipGraph captured late in a long
-                    # process has run 12 - 17 ms there: the eager loop is timed beside it and the better one counts
-                    eager = run_workload(ctx, shard_name, args.proposal, 5, 2, want_backward=False, want_kernels=False,
-                                         mode="eager")
-                    entry["ms_per_elbo_eager"] = round(eager["ms_per_step"], 3)
-                    entry["ms_per_elbo_hipgraph"] = entry["ms_per_elbo"]
-                    if eager["ms_per_step"] < shard["ms_per_step"]:
-                        entry.update(ms_per_elbo=round(eager["ms_per_step"], 3), mode=eager["mode"],
-                                     particle_steps_per_sec_per_gpu=eager["value"])
                 entry["projected_efficiency"] = round(head["ms_per_step"] / (n * entry["ms_per_elbo"]), 3)
                 projection["N={}".format(n)] = entry
             extras["strong_scaling_projection"] = projection

@@ -220,6 +220,15 @@ int aesmc_resample_step(int dtype, const void *log_w, const double *u, int64_t *
                         const void *src, void *dst, int32_t *flags, int64_t B, int64_t K,
                         int64_t row_bytes, int64_t src_stride_b, int64_t src_stride_k, void *stream);
 
+/* K2 with the children ranges as a by-product: aesmc_resample_step without a payload, plus
+ *   out_child_end[b,k] = #{k' : out_idx[b,k'] <= k}      (int32 [B,K])
+ * — the ancestor indices are non-decreasing along k, so the children of particle k are the positions
+ * [out_child_end[b,k-1], out_child_end[b,k]) (0 for k = 0): what torch.gather's backward (aesmc/state.py:179) sums
+ * per particle, handed to aesmc_affine_step_backward_resampled so that it forms those sums where it consumes them.
+ * The scan has the value in a register anyway: 4 more bytes per particle written. */
+int aesmc_resample_step_ranges(int dtype, const void *log_w, const double *u, int64_t *out_idx, void *out_lse,
+                               int32_t *out_child_end, int32_t *flags, int64_t B, int64_t K, void *stream);
+
 /* K6 — reparameterised Normal draw  out[b,k,j] = loc[b,k,j] + eps[b,k,j] * scale[b,k,j].
  *
  * Replaces the broadcast multiply and the add that follow the noise draw in
@@ -443,13 +452,20 @@ int aesmc_affine_step_backward(
  * aesmc_affine_step_backward; `out->grad_x_prev` is the gradient with respect to the RESAMPLED rows
  * ([B,K,dx], one per child): the caller sums children into their ancestors (aesmc_resample_gather_backward),
  * which is torch.gather's backward (aesmc/state.py:179).  An ancestor outside [0, K) is clamped and raises
- * AESMC_FLAG_INDEX_OUT_OF_RANGE in `flags` (may be NULL). */
+ * AESMC_FLAG_INDEX_OUT_OF_RANGE in `flags` (may be NULL).
+ * `child_grad` / `child_end` (both or neither; NULL = none): the gradient that reaches x_t from the NEXT step when
+ * that step, too, resampled through ancestors — its `out->grad_x_prev`, one row per CHILD [B,K,dx] — and the next
+ * resampling step's children ranges (aesmc_resample_step_ranges).  The kernel then adds, to whatever `grad_x`
+ * brings, the sum of each particle's children's rows (in k order: the stand-alone segmented-sum kernel's bits for
+ * runs of up to 32 children; longer runs — a collapsed particle system — are shared out over the wavefront):
+ * torch.gather's backward without its launch and without the [B,K,dx] round trip of the summed gradient. */
 int aesmc_affine_step_backward_resampled(
     int dtype, const void *x_src, const int64_t *ancestors, const void *x, const void *y, int64_t y_stride_b,
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
-    const void *grad_lse, const void *grad_lw, const void *grad_x, const aesmc_affine_logweight_grads *out, void *ws,
-    size_t ws_bytes, int32_t *flags, int64_t B, int64_t K, void *stream);
+    const void *grad_lse, const void *grad_lw, const void *grad_x, const void *child_grad, const int32_t *child_end,
+    const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int32_t *flags, int64_t B, int64_t K,
+    void *stream);
 
 /* Noise — the float32 tensor `torch.empty(numel).normal_()` holds on this device for a generator at
  * (seed, offset): out[e], e < numel.  Replaces, inside a kernel or on its own, the `_standard_normal` draw of

@@ -62,9 +62,14 @@ class OracleKernels:
     def step_covers(self, log_w, payload=None):
         return log_w.dim() == 2 and log_w.numel() > 0 and (payload is None or torch.is_tensor(payload))
 
-    def resample_step(self, log_w, u, payload=None, want_lse=False):
+    def resample_step(self, log_w, u, payload=None, want_lse=False, want_child_end=False):
         """The fused step as the composition it must equal: K2, then K1's row log-sum-exp and K3."""
         idx = self.ancestor_index(log_w, u)
+        if want_child_end and payload is None:      # child_end[b,k] = #{k' : idx[b,k'] <= k}
+            K = idx.size(1)
+            counts = torch.zeros(idx.size(0), K + 1, dtype=torch.int64).scatter_add_(
+                1, idx.clamp(max=K), torch.ones_like(idx))
+            idx._aesmc_child_end = counts[:, :K].cumsum(dim=1).to(torch.int32)
         lse = self.logweight_lse(log_w, None, None, want_lw=False, want_lse=True)[1] if want_lse else None
         moved = self.gather(payload, idx) if payload is not None else None
         return idx, lse, moved
@@ -173,11 +178,27 @@ class OracleKernels:
             out[i] = None if grad is None else grad.to(operands[i].dtype)
         return out
 
+    def gather_backward_ranges(self, child_grad, child_end):
+        B, K = child_end.shape
+        out = torch.zeros_like(child_grad)
+        ends = child_end.to(torch.int64)
+        for b in range(B):
+            start = 0
+            for k in range(K):
+                end = int(ends[b, k])
+                if end > start:
+                    out[b, k] = child_grad[b, start:end].sum(dim=0)
+                start = max(start, end)
+        return out
+
     def affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
-                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None):
+                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None, child_grad=None, child_end=None):
         """K14's contract by PyTorch's autograd in float64: x is rebuilt as the proposal's draw
         loc_q(x_prev) + s_q eps with eps = (x - loc_q) / s_q held fixed, so every path through it is
         differentiated; x's own slot stays None."""
+        if child_grad is not None:      # the next step's per-child gradient: summed into its ancestors, then as grad_x
+            summed = self.gather_backward_ranges(child_grad, child_end)
+            grad_x = summed if grad_x is None else grad_x + summed
         if ancestors is not None:       # slot 0 of the result: the gradient of the RESAMPLED rows
             x_prev = self.gather(x_prev, ancestors)
         operands = [x_prev, x, y_rows, transition[0], transition[1], emission[0], emission[1], proposal[0],

@@ -690,12 +690,15 @@ def test_full_size_step_is_the_same_by_every_route(hip_device):
     B, K, T = 1024, 4096, 4
     runs = {}
     for name, kwargs in (("deferred", dict(affine=True, defer_draw=True)), ("immediate", dict(affine=True, defer_draw=False)),
-                         ("matmul", dict(affine=False))):
+                         ("matmul", dict(affine=False)), ("linked", dict(affine=True, defer_draw=True))):
         model = LgssmNd(10, dtype=torch.float32, validate_args=False, **kwargs).tune_proposal().to(hip_device)
         observations = model.simulate(T, B, seed=5)
         torch.manual_seed(21)
         np.random.seed(21)
-        with inference.lazy_gather(name != "matmul"):      # the matmul statement evaluated by PyTorch itself
+        # "linked": consecutive steps' nodes hand the gather's backward on (the default; K14 adds a particle's
+        # children in k order, the stand-alone segmented sum associates differently) — the bit-for-bit comparison
+        # of the routes is made with every step launching that sum itself
+        with inference.lazy_gather(name != "matmul"), inference.fold_gather_backward(name == "linked"):
             out = inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal,
                                   K, return_log_marginal_likelihood=True, return_log_weight=False, return_latents=False,
                                   return_ancestral_indices=True)
@@ -710,6 +713,14 @@ def test_full_size_step_is_the_same_by_every_route(hip_device):
     assert sorted(ga) == sorted(gb) and ga
     for name in ga:
         assert torch.equal(ga[name], gb[name]), name
+    # the default route (linked step nodes): the same forward pass in every bit, gradients to float32 rounding
+    d, gd = runs["linked"]
+    assert torch.equal(a["log_marginal_likelihood"], d["log_marginal_likelihood"])
+    assert torch.equal(a["last_latent"], d["last_latent"])
+    assert sorted(ga) == sorted(gd)
+    for name in ga:
+        scale = max(float(ga[name].abs().max()), 1e-30)
+        assert float((ga[name] - gd[name]).abs().max()) <= 2e-5 * scale, (name, "linked step nodes")
     # against the matmul statement of the same model: float32 rounding apart
     # (a flipped ancestor puts a different particle into that slot for good, so later steps differ in more places:
     # the first resampling step is the one bounded by CDF rounding alone)

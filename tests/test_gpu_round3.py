@@ -469,6 +469,224 @@ def test_step_backward_through_ancestors_equals_gather_then_step_backward(kernel
     assert kernels.read_flags(hip_device) == 0
 
 
+# ---- torch.gather's backward inside K14 ----------------------------------------------------
+def _next_resampling(kernels, B, K, device, seed, spread, dtype=torch.float64):
+    """The NEXT step's resampling launch with the children ranges as its by-product: (indices, child_end)."""
+    gen = torch.Generator().manual_seed(seed)
+    lw = (spread * torch.randn(B, K, generator=gen, dtype=torch.float64)).to(dtype).to(device)
+    u = torch.rand(B, generator=gen, dtype=torch.float64).to(device)
+    plain = kernels.resample_step(lw, u, None, want_lse=True)
+    ranged = kernels.resample_step(lw, u, None, want_lse=True, want_child_end=True)
+    assert torch.equal(plain[0], ranged[0]) and torch.equal(plain[1], ranged[1])
+    return ranged[0], ranged[0]._aesmc_child_end
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("spread", [0.0, 1.0, 9.0])
+@pytest.mark.parametrize("shape", [(3, 700), (2, 513), (5, 64), (300, 4096), (16, 10000), (2, 30000), (7, 2), (4, 1)])
+def test_the_resampling_launch_says_where_each_particles_children_end(kernels, hip_device, dtype, spread, shape):
+    """aesmc_resample_step_ranges: the indices and the row log-sum-exp of aesmc_resample_step, bit for bit, and
+    child_end[b,k] = #{k' : idx[b,k'] <= k} — uniform, N(0,1) and collapsed weights, every particles-per-lane
+    instantiation, K = 1."""
+    B, K = shape
+    idx, child_end = _next_resampling(kernels, B, K, hip_device, seed=B + K, spread=spread, dtype=dtype)
+    assert child_end.dtype == torch.int32 and child_end.shape == (B, K)
+    host = idx.cpu().numpy()
+    want = np.stack([np.searchsorted(host[b], np.arange(K), side="right") for b in range(B)])
+    assert np.array_equal(child_end.cpu().numpy(), want)
+    assert int(child_end[:, -1].min()) == K == int(child_end[:, -1].max())
+    assert kernels.read_flags(hip_device) == 0
+
+
+def test_a_degenerate_row_has_no_children(kernels, hip_device):
+    """A row of -inf weights: the launch flags it, its indices are K (as without the ranges) and nobody has children."""
+    from aesmc_amd import _lib
+    B, K = 3, 600
+    lw = torch.randn(B, K, dtype=torch.float64, device=hip_device)
+    lw[1] = float("-inf")
+    u = torch.full((B,), 0.3, dtype=torch.float64, device=hip_device)
+    idx, _, _ = kernels.resample_step(lw, u, None, want_lse=False, want_child_end=True)
+    assert kernels.read_flags(hip_device) & _lib.FLAG_DEGENERATE_ROW
+    child_end = idx._aesmc_child_end
+    assert int(child_end[1].abs().max()) == 0 and bool((idx[1] == K).all())
+    assert int(child_end[0, -1]) == K and int(child_end[2, -1]) == K
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("spread", [1.0, 9.0])
+@pytest.mark.parametrize("with_grad_x", [False, True])
+@pytest.mark.parametrize("shape", [(3, 700, 10, 10), (2, 513, 5, 3), (5, 64, 16, 16), (7, 300, 12, 2), (2, 2048, 8, 8),
+                                   (16, 4096, 10, 10), (300, 4096, 10, 10), (520, 2100, 8, 8), (2, 999, 9, 4)])
+def test_step_backward_sums_the_children_of_its_particles_itself(kernels, hip_device, dtype, spread, with_grad_x, shape):
+    """aesmc_affine_step_backward_resampled(child_grad, child_end) == aesmc_resample_gather_backward of the next
+    step's per-child gradient, added to whatever else reaches x_t, then the same entry point with the sum as
+    `grad_x`: every gradient to rounding (a particle's children are added in k order here, in the segmented-sum
+    kernel's order there), healthy and collapsed next-step ancestries (runs longer than a lane takes alone), and
+    against the sum taken in float64."""
+    B, K, dx, dy = shape
+    n, o = operands(B, K, dx, dy, dtype, hip_device, seed=3 * B + K + dx)
+    idx = _ancestors(B, K, hip_device, seed=B + K, spread=2.0)
+    off_p = torch.from_numpy(np.random.RandomState(4).randn(dx).astype(dtype)).to(hip_device)
+    terms = ((o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    moved = kernels.gather(o["x_prev"], idx)
+    x = kernels.affine_rsample(moved, o["Q"], o["off_q"], o["eps"], o["s_q"])
+    lw = kernels.affine_logweight(moved, x, o["y"], *terms, scales)
+    _, lse = kernels.logweight_lse(lw, None, None, want_lw=False)
+    rng = np.random.RandomState(9)
+    grad_lse = torch.from_numpy(rng.randn(B).astype(dtype)).to(hip_device)
+    grad_x = torch.from_numpy(rng.randn(B, K, dx).astype(dtype)).to(hip_device) if with_grad_x else None
+    child_grad = torch.from_numpy(rng.randn(B, K, dx).astype(dtype)).to(hip_device)
+    idx_next, child_end = _next_resampling(kernels, B, K, hip_device, seed=7 * B + K, spread=spread)
+    summed = kernels.gather_backward(child_grad, idx_next, sorted_index=True)
+    flat = (idx_next + K * torch.arange(B, device=hip_device).unsqueeze(1)).reshape(-1)
+    exact = torch.zeros(B * K, dx, dtype=torch.float64, device=hip_device).index_add_(
+        0, flat, child_grad.double().reshape(B * K, dx)).view(B, K, dx)
+    need = [True] * 12
+    need[1] = False
+    arrives = summed if grad_x is None else grad_x + summed
+    want = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse,
+                                        grad_x=arrives, ancestors=idx)
+    arrives64 = (exact if grad_x is None else grad_x.double() + exact).to(arrives.dtype)
+    want64 = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse,
+                                          grad_x=arrives64, ancestors=idx)
+    got = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse,
+                                       grad_x=grad_x, ancestors=idx, child_grad=child_grad, child_end=child_end)
+    again = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse,
+                                         grad_x=grad_x, ancestors=idx, child_grad=child_grad, child_end=child_end)
+    tolerance = 3e-5 if dtype == np.float32 else 1e-11
+    names = ("x_prev", "x", "y", "A", "off_p", "C", "off_g", "Q", "off_q", "s_p", "s_g", "s_q")
+    longest = int((child_end[:, 1:] - child_end[:, :-1]).max()) if K > 1 else K
+    assert spread < 5 or longest > 32, "the collapsed case is meant to reach runs the wavefront shares out"
+    for name, a, b, c, d in zip(names, got, want, want64, again):
+        if name == "x":
+            assert a is None and b is None
+            continue
+        assert torch.equal(a, d), (name, "not reproducible")
+        scale = max(1.0, float(c.abs().max())) * (1.0 + np.sqrt(longest))
+        assert float((a.double() - b.double()).abs().max()) <= tolerance * scale, (name, "vs the launch it replaces")
+        assert float((a.double() - c.double()).abs().max()) <= tolerance * scale, (name, "vs the float64 sum")
+    assert kernels.read_flags(hip_device) == 0
+    # only the children's gradient arrives (no ELBO term of this step, nothing else at x_t)
+    only = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, ancestors=idx,
+                                        child_grad=child_grad, child_end=child_end)
+    want_only = kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_x=summed,
+                                             ancestors=idx)
+    for name, a, b in zip(names, only, want_only):
+        if name != "x":
+            scale = max(1.0, float(b.abs().max())) * (1.0 + np.sqrt(longest))
+            assert float((a.double() - b.double()).abs().max()) <= tolerance * scale, (name, "children only")
+
+
+def test_step_backward_declines_children_without_ancestors(kernels, hip_device):
+    n, o = operands(2, 300, 4, 3, np.float32, hip_device, seed=1)
+    terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    lw = kernels.affine_logweight(o["x_prev"], o["x"], o["y"], *terms, scales)
+    _, lse = kernels.logweight_lse(lw, None, None, want_lw=False)
+    need = [True] * 12
+    need[1] = False
+    _, child_end = _next_resampling(kernels, 2, 300, hip_device, seed=3, spread=1.0)
+    with pytest.raises(ValueError):
+        kernels.affine_step_backward(o["x_prev"], o["x"], o["y"], *terms, scales, need, lw, lse,
+                                     child_grad=torch.ones_like(o["x"]), child_end=child_end)
+    idx = _ancestors(2, 300, hip_device, seed=5, spread=1.0)
+    with pytest.raises(ValueError):      # ranges of another shape / dtype
+        kernels.affine_step_backward(o["x_prev"], o["x"], o["y"], *terms, scales, need, lw, lse, ancestors=idx,
+                                     child_grad=torch.ones_like(o["x"]), child_end=child_end.long())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("learn_scales", [False, True])
+def test_a_loss_whose_steps_hand_the_gather_backward_on_is_the_loss_that_launches_it(hip_device, dtype, learn_scales):
+    """get_loss + backward with consecutive steps' nodes linked (`_ops.StepLink`: K14 sums each particle's children
+    while it consumes them) against the run whose every step launches the segmented sum: the loss bit for bit,
+    every parameter gradient to rounding, and the linked run launches the gather's backward once (for x_0, whose
+    producer is not a step node) instead of T - 1 times.  A second backward through the retained graph gives the
+    same gradients (the deposits are taken, not kept)."""
+    from aesmc_amd import _kernels, inference, losses
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    T, B, K = 7, 3, 1500
+    runs = {}
+    for fold in (False, True):
+        calls = {"gather_backward": 0, "with_children": 0}
+        real_gb, real_sb = provider.gather_backward, provider.affine_step_backward
+
+        def gb_spy(*args, **kwargs):
+            calls["gather_backward"] += 1
+            return real_gb(*args, **kwargs)
+
+        def sb_spy(*args, **kwargs):
+            calls["with_children"] += kwargs.get("child_grad") is not None
+            return real_sb(*args, **kwargs)
+
+        provider.gather_backward, provider.affine_step_backward = gb_spy, sb_spy
+        try:
+            model = LgssmNd(10, dtype=dtype, affine=True).tune_proposal().to(hip_device)
+            if learn_scales:
+                for name in ("transition_scale", "emission_scale", "proposal_scale"):
+                    value = getattr(model, name).detach().clone()
+                    delattr(model, name)
+                    model.register_parameter(name, torch.nn.Parameter(value))
+            observations = model.simulate(T, B, seed=3)
+            torch.manual_seed(11)
+            np.random.seed(11)
+            with inference.fold_gather_backward(fold):
+                loss = losses.get_loss(observations, K, "aesmc", model.initial, model.transition, model.emission,
+                                       model.proposal)
+                loss.backward(retain_graph=True)
+                first = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+                counted = dict(calls)
+                for p in model.parameters():
+                    p.grad = None
+                loss.backward()
+                second = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            provider.gather_backward, provider.affine_step_backward = real_gb, real_sb
+        runs[fold] = (loss.detach(), first, second, counted)
+    (loss_a, grads_a, again_a, calls_a), (loss_b, grads_b, again_b, calls_b) = runs[False], runs[True]
+    assert torch.equal(loss_a, loss_b)
+    assert calls_a == {"gather_backward": T - 1, "with_children": 0}
+    assert calls_b == {"gather_backward": 1, "with_children": T - 2}
+    assert sorted(grads_a) == sorted(grads_b) and grads_a
+    tolerance = 2e-4 if dtype == torch.float32 else 1e-10
+    for name in grads_a:
+        scale = max(1.0, float(grads_a[name].abs().max()))
+        assert float((grads_a[name] - grads_b[name]).abs().max()) <= tolerance * scale, name
+        assert torch.equal(grads_b[name], again_b[name]), (name, "second backward")
+        assert torch.equal(grads_a[name], again_a[name]), (name, "second backward, unlinked")
+
+
+def test_latents_handed_to_the_caller_keep_every_step_its_own_gather_backward(hip_device):
+    """`infer(return_original_latents=True)`: somebody outside may differentiate x_t itself, so no step hands its
+    gather's backward to its predecessor — x_t's gradient is the full one (checked against the unlinked run)."""
+    from aesmc_amd import _kernels, inference
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    grads = {}
+    for fold in (False, True):
+        calls = {"with_children": 0}
+        real_sb = provider.affine_step_backward
+        provider.affine_step_backward = lambda *a, **k: (calls.__setitem__(
+            "with_children", calls["with_children"] + (k.get("child_grad") is not None)), real_sb(*a, **k))[1]
+        try:
+            model = LgssmNd(10, dtype=torch.float64, affine=True).tune_proposal().to(hip_device)
+            observations = model.simulate(5, 2, seed=3)
+            torch.manual_seed(2)
+            np.random.seed(2)
+            with inference.fold_gather_backward(fold):
+                out = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                                      model.proposal, 900, return_log_marginal_likelihood=True, return_latents=False,
+                                      return_log_weight=False, return_original_latents=True)
+            middle = out["original_latents"][2]
+            grads[fold] = torch.autograd.grad(out["log_marginal_likelihood"].sum(), middle)[0]
+        finally:
+            provider.affine_step_backward = real_sb
+        assert calls["with_children"] == 0
+    assert torch.equal(grads[False], grads[True])
+
+
 # ---- float32 runs of the reference itself, end to end (VERDICT r02 item 6) --------------------------------------
 # What the device achieved on the committed fixtures when these bounds were written (MI355X, both model statements):
 # see profiles/README.md "float32 fixture parity"; the bounds below are those numbers plus a margin.

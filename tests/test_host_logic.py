@@ -845,3 +845,57 @@ def test_a_reference_style_model_reaches_the_fused_route_unedited(oracle_backend
     assert not isinstance(out, _lazy.LazyParticles) and not y.is_pending and torch.equal(out, torch.tanh(moved))
     dist = torch.distributions.Normal(_lazy.LazyResampled(source, index) @ weight.t(), torch.tensor(0.5, dtype=torch.float64))
     assert type(dist.loc) is _lazy.LazyAffine and dist.loc.is_pending and dist.batch_shape == (2, 5, 4)
+
+
+def test_linked_step_nodes_give_the_gradients_of_unlinked_ones(oracle_backend):
+    """Host logic of the folded gather backward (`_ops.StepLink`) on the oracle backend: with consecutive step nodes
+    handing the per-child gradient on, the loss and every gradient equal those of the run whose every step sums
+    children into ancestors itself; the linked run asks for one stand-alone sum (x_0's) instead of T - 1; handing the
+    latents to the caller switches the linking off."""
+    from aesmc_amd import _kernels
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    T, results = 6, {}
+    for fold in (False, True):
+        calls = {"gather_backward": 0, "with_children": 0}
+        real_gb, real_sb = provider.gather_backward, provider.affine_step_backward
+
+        def gb_spy(*args, **kwargs):
+            calls["gather_backward"] += 1
+            return real_gb(*args, **kwargs)
+
+        def sb_spy(*args, **kwargs):
+            calls["with_children"] += kwargs.get("child_grad") is not None
+            return real_sb(*args, **kwargs)
+
+        provider.gather_backward, provider.affine_step_backward = gb_spy, sb_spy
+        try:
+            model = LgssmNd(3, dtype=torch.float64, affine=True).tune_proposal()
+            observations = model.simulate(T, 4, seed=1)
+            torch.manual_seed(5)
+            np.random.seed(5)
+            with inference.fold_gather_backward(fold):
+                loss = losses.get_loss(observations, 48, "aesmc", model.initial, model.transition, model.emission,
+                                       model.proposal)
+                loss.backward()
+                grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+                counted = dict(calls)
+                torch.manual_seed(5)
+                np.random.seed(5)
+                kept = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                                       model.proposal, 48, return_log_marginal_likelihood=True, return_latents=False,
+                                       return_log_weight=False, return_original_latents=True)
+                before = calls["with_children"]
+                kept["log_marginal_likelihood"].sum().backward()
+                assert calls["with_children"] == before
+        finally:
+            provider.gather_backward, provider.affine_step_backward = real_gb, real_sb
+        results[fold] = (loss.detach(), grads, counted)
+    (loss_a, grads_a, calls_a), (loss_b, grads_b, calls_b) = results[False], results[True]
+    assert torch.equal(loss_a, loss_b)
+    assert calls_a == {"gather_backward": T - 1, "with_children": 0}
+    assert calls_b == {"gather_backward": 1, "with_children": T - 2}
+    assert sorted(grads_a) == sorted(grads_b) and grads_a
+    for name in grads_a:
+        scale = max(float(grads_a[name].abs().max()), 1e-30)
+        assert float((grads_a[name] - grads_b[name]).abs().max()) <= 1e-10 * scale, name
