@@ -306,6 +306,8 @@ struct LgBackwardOut {
   // torch.gather's backward (the sum of a particle's children) is formed here, where it is consumed
   const void *child_grad;
   const int32_t *child_end;
+  int child_stage;   // a fourth LDS tile exists: the tile's children rows — one contiguous block — are staged through it
+  int child_align;   // rows per 16 bytes' worth of alignment: a staged block starts at a multiple of this many rows
 };
 
 constexpr int kLgChildLimit = 32;   // children a lane sums by itself; longer runs (a collapsed system) take the wavefront
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
   const LgLayout lx = lg_layout<T>(dx), ly = lg_layout<T>(dy);
   T *tx = tprev + (TP * lx.rs + 16);
   T *tu = tx + (TP * lx.rs + 16);
+  T *tchild = tu + (TP * max(lx.rs, ly.rs) + 16);      // only with out.child_stage
   const bool want_sq = out.want_scale_q != 0;
   {
     lg_stage_weight<T, DP>(mp, wf);
@@ -565,51 +568,65 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     const int64_t n0 = (int64_t)blockIdx.x * TP;
     lg_anc_prefetch<PPL, true>(out.gat, n0, (uint32_t)min((int64_t)TP, N - n0), ranc);
   }
-  // the children of the lane's particles (the gather's backward folded in, below): where their rows begin and end in
-  // the next step's per-child gradient — loaded one tile ahead, like the ancestors
+  // The children of the lane's particles (the gather's backward folded in, below), as FLAT row numbers b K + c of the
+  // next step's per-child gradient: where each particle's run begins and ends, and where the whole tile's does — the
+  // indices are non-decreasing, so a tile's children are one contiguous block of rows.  Loaded one tile ahead, like
+  // the ancestors.
   const bool folds = out.child_grad != nullptr;
+  const bool stages = folds && out.child_stage != 0;
   const T *child_rows = reinterpret_cast<const T *>(out.child_grad);
-  int32_t cstart[PPL], cend[PPL];
-  auto child_ranges = [&](int64_t n0, uint32_t np) {
+  // (RAW entries are kept across the tile: turning them into row numbers where they are loaded would make the
+  //  wavefront wait for the loads on the spot)
+  int32_t raw_end[PPL], raw_before[PPL], raw_tile_before = 0, raw_tile_end = 0;
+  auto child_ranges_prefetch = [&](int64_t n0, uint32_t np) {
     const uint32_t k0 = (uint32_t)(n0 % K);
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
-      const uint32_t q = lg_tid_impl<true>() + r * kLgBlock;
-      const bool lives = q < np;
-      const int64_t n = n0 + (lives ? q : 0u);
-      const bool first_of_row = (k0 + (lives ? q : 0u)) % K == 0;
+      const uint32_t q = lg_tid_impl<true>() + r * kLgBlock, qq = q < np ? q : 0u;
+      const int64_t n = n0 + qq;
       // (no lane-dependent branch around the loads: a particle without a predecessor re-reads its own entry)
-      const int32_t e = out.child_end[n], b = out.child_end[first_of_row ? n : n - 1];
-      cend[r] = lives ? min(max(e, 0), (int32_t)K) : 0;
-      cstart[r] = min(max(first_of_row ? 0 : b, 0), cend[r]);
+      raw_end[r] = out.child_end[n];
+      raw_before[r] = out.child_end[(k0 + qq) % K == 0 ? n : n - 1];
     }
+    raw_tile_before = out.child_end[k0 == 0 ? n0 : n0 - 1];      // uniform addresses: every lane the same two entries
+    raw_tile_end = out.child_end[n0 + np - 1];
+  };
+  // flat row numbers [lo, hi) of particle q of the tile that starts at n0, from its two entries
+  auto child_range = [&](int64_t n0, uint32_t q, bool lives, int32_t before, int32_t end_, uint32_t &lo, uint32_t &hi) {
+    const uint32_t b0 = (uint32_t)(n0 / K), k0 = (uint32_t)(n0 - (int64_t)b0 * K);
+    const uint32_t kk = k0 + q, rel = kk / K;
+    const bool first_of_row = kk - rel * K == 0;
+    const uint32_t base = (b0 + rel) * K;
+    const uint32_t end = lives ? (uint32_t)min(max(end_, 0), (int32_t)K) : 0u;
+    hi = base + end;
+    lo = base + min((uint32_t)max(first_of_row ? 0 : before, 0), end);
   };
   if (folds && (int64_t)blockIdx.x < tiles) {
     const int64_t n0 = (int64_t)blockIdx.x * TP;
-    child_ranges(n0, (uint32_t)min((int64_t)TP, N - n0));
+    child_ranges_prefetch(n0, (uint32_t)min((int64_t)TP, N - n0));
   }
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    // ---- the first two children's rows of each particle go out before anything else of the tile (most particles
-    // have no more); their ranges came a tile ago, the next tile's are sent for right behind them
-    T child_a[PPL][DP], child_b[PPL][DP];
-    int32_t own_start[PPL], own_end[PPL];
+    uint32_t own_lo[PPL], own_hi[PPL], staged_lo = 0, staged_hi = 0;      // staged rows: [staged_lo, staged_hi)
     if (folds) {
-      const uint32_t b0_ = (uint32_t)(n0 / K), k0_ = (uint32_t)(n0 - (int64_t)b0_ * K);
 #pragma unroll
       for (int r = 0; r < PPL; ++r) {
         const uint32_t q = lg_tid_impl<true>() + r * kLgBlock;
-        const uint32_t brow_r = b0_ + (k0_ + (q < np ? q : 0u)) / K;
-        const T *rows = child_rows + (int64_t)brow_r * K * dx;
-        own_start[r] = cstart[r];
-        own_end[r] = cend[r];
-        const int32_t c0 = min(own_start[r], (int32_t)K - 1), c1 = min(own_start[r] + 1, (int32_t)K - 1);
-        lg_child_row<T, DP, EXACT>(rows + (int64_t)c0 * dx, dx, child_a[r]);
-        lg_child_row<T, DP, EXACT>(rows + (int64_t)c1 * dx, dx, child_b[r]);
+        child_range(n0, q < np ? q : 0u, q < np, raw_before[r], raw_end[r], own_lo[r], own_hi[r]);
+      }
+      if (stages) {
+        // the block starts at a row whose address is a multiple of 16 bytes; what does not fit the tile (a tile whose
+        // particles have more than TP children between them) is fetched by the lanes themselves
+        uint32_t tile_lo, tile_hi, unused;
+        child_range(n0, 0u, true, raw_tile_before, raw_tile_before, tile_lo, unused);
+        child_range(n0, np - 1, true, raw_tile_end, raw_tile_end, unused, tile_hi);
+        staged_lo = tile_lo & ~((uint32_t)out.child_align - 1u);
+        staged_hi = tile_hi > staged_lo ? min(tile_hi, staged_lo + TP) : staged_lo;
+        lg_stage_rows<T, true>(child_rows + (int64_t)staged_lo * dx, (staged_hi - staged_lo) * dx, tchild, lx, 0);
       }
       const int64_t m0 = (tile + gridDim.x) * TP;
-      if (m0 < N) child_ranges(m0, (uint32_t)min((int64_t)TP, N - m0));
+      if (m0 < N) child_ranges_prefetch(m0, (uint32_t)min((int64_t)TP, N - m0));
     }
     if (gathers) {
       lg_gather_stage<T, PPL, DP, true>(reinterpret_cast<const char *>(xprev), out.gat, n0, np, K, ranc, tprev, lx);
@@ -657,46 +674,55 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     if (gx_in != nullptr && lx.rs != ly.rs) lg_lds_barrier();   // the tile changes layout under the other wavefronts
     if (folds) {
       // ---- the gather's backward folded in: w += sum of the particle's children's rows ------------------------
-      // Ancestor indices are non-decreasing along k, so a particle's children are ONE run of rows of the next
-      // step's per-child gradient.  The lane adds its run in k order (fixed, so reproducible; the stand-alone
-      // segmented-sum kernel associates differently: equal to rounding); a run longer than kLgChildLimit is shared
-      // out over the wavefront.  The first two rows are in registers already (sent for at the top of the tile).
+      // The lane adds its run in k order (fixed, so reproducible; the stand-alone segmented-sum kernel associates
+      // differently: equal to rounding) — out of the staged block where the rows are there, from HBM otherwise; a run
+      // longer than kLgChildLimit (a collapsed particle system) is shared out over the wavefront.
       const int lane = (int)(threadIdx.x & (kWave - 1));
 #pragma unroll
       for (int r = 0; r < PPL; ++r) {
-        const int32_t start = own_start[r], end = own_end[r];
-        const T *rows = child_rows + (int64_t)brow[r] * K * dx;
+        const uint32_t lo = own_lo[r], hi = own_hi[r];
+        const uint32_t own_last = min(hi, lo + (uint32_t)kLgChildLimit);
         T acc[DP];
 #pragma unroll
-        for (int j = 0; j < DP; ++j) {
-          acc[j] = start < end ? child_a[r][j] : T(0);
-          if (start + 1 < end) acc[j] = acc[j] + child_b[r][j];
-        }
-        const int32_t own_last = min(end, start + kLgChildLimit);
-        // two rows in flight per trip; added in k order: ((c0 + c1) + c2) + ...
-        for (int32_t c = start + 2; c < own_last; c += 2) {
+        for (int j = 0; j < DP; ++j) acc[j] = T(0);
+        uint32_t c = lo;
+        // (lo >= staged_lo when the ranges are what the resampling launch wrote: the block begins with the tile's first run)
+        const uint32_t in_lds = lo >= staged_lo ? min(own_last, staged_hi) : lo;
+        // two rows in flight per trip, added in k order: ((0 + c0) + c1) + c2 ...  (a trip's second row, where the run
+        // has none, is re-read and added as zero: no branch between the loads and the adds)
+        for (; c < in_lds; c += 2) {
           T a[DP], b[DP];
-          const bool two = c + 1 < own_last;
-          lg_child_row<T, DP, EXACT>(rows + (int64_t)c * dx, dx, a);
-          lg_child_row<T, DP, EXACT>(rows + (int64_t)(two ? c + 1 : c) * dx, dx, b);
+          const bool two = c + 1 < in_lds;
+          lg_child_row<T, DP, EXACT>(tchild + (c - staged_lo) * lx.rs, dx, a);
+          lg_child_row<T, DP, EXACT>(tchild + ((two ? c + 1 : c) - staged_lo) * lx.rs, dx, b);
 #pragma unroll
           for (int j = 0; j < DP; ++j) {
             acc[j] = acc[j] + a[j];
-            if (two) acc[j] = acc[j] + b[j];
+            acc[j] = acc[j] + (two ? b[j] : T(0));
           }
         }
-        uint64_t todo = __ballot(own_last < end);
+        c = min(c, max(in_lds, lo));
+        for (; c < own_last; c += 2) {
+          T a[DP], b[DP];
+          const bool two = c + 1 < own_last;
+          lg_child_row<T, DP, EXACT>(child_rows + (int64_t)c * dx, dx, a);
+          lg_child_row<T, DP, EXACT>(child_rows + (int64_t)(two ? c + 1 : c) * dx, dx, b);
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+            acc[j] = acc[j] + a[j];
+            acc[j] = acc[j] + (two ? b[j] : T(0));
+          }
+        }
+        uint64_t todo = __ballot(own_last < hi);
         while (todo != 0) {        // wavefront-uniform: every lane helps the lane whose run is long
           const int leader = __ffsll((long long)todo) - 1;
-          const int32_t from = __shfl(own_last, leader, kWave), to = __shfl(end, leader, kWave);
-          const uint32_t leader_row = (uint32_t)__shfl((int)brow[r], leader, kWave);
-          const T *lrows = child_rows + (int64_t)leader_row * K * dx;
+          const uint32_t from = (uint32_t)__shfl((int)own_last, leader, kWave), to = (uint32_t)__shfl((int)hi, leader, kWave);
           T part[DP];
 #pragma unroll
           for (int j = 0; j < DP; ++j) part[j] = T(0);
-          for (int32_t c = from + lane; c < to; c += kWave) {
+          for (uint32_t cc = from + lane; cc < to; cc += kWave) {
             T row[DP];
-            lg_child_row<T, DP, EXACT>(lrows + (int64_t)c * dx, dx, row);
+            lg_child_row<T, DP, EXACT>(child_rows + (int64_t)cc * dx, dx, row);
 #pragma unroll
             for (int j = 0; j < DP; ++j) part[j] += row[j];
           }
@@ -976,6 +1002,17 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
     if (lds <= (ppl > 1 ? (size_t)78 * 1024 : kLgLdsLimit) && lg_rows_spanned((int64_t)tp, K) <= kLgRowsMax) break;
   }
   if (ppl < 1) return AESMC_ERR_UNSUPPORTED;   // fewer than ~43 particles per batch row: the caller takes the unfused route
+  // the children's rows go through a tile of their own where that costs no resident workgroup (else lanes fetch them)
+  bool child_stage = false;
+  if (child_grad != nullptr) {
+    const int per_cu = (ppl == 2 || sizeof(T) == 8) ? 2 : (step ? LG_STEP_WAVES : 3);
+    const size_t with_tile = lds + sizeof(T) * lg_tile_elems<T>((size_t)kLgBlock * ppl, dx);
+    static const bool off = [] { const char *v = getenv("AESMC_LG_CHILD_STAGE"); return v != nullptr && atoi(v) == 0; }();
+    if (!off && with_tile * per_cu <= (size_t)160 * 1024 && with_tile <= kLgLdsLimit) {
+      child_stage = true;
+      lds = with_tile;
+    }
+  }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, (ppl == 2 || sizeof(T) == 8) ? 2 : (step ? LG_STEP_WAVES : 3)), kLgMaxGrid);   // what the registers allow
   const int row_terms = (o->grad_offset_p != nullptr ? 1 : 0) | (o->grad_offset_g != nullptr ? 2 : 0) |
@@ -990,6 +1027,12 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   out.gat = lg_gather(anc_idx, flags, (size_t)dx * sizeof(T));
   out.child_grad = child_grad;
   out.child_end = child_end;
+  out.child_stage = child_stage ? 1 : 0;
+  {
+    size_t row_bytes = (size_t)dx * sizeof(T), align = 1;
+    while ((row_bytes * align) % 16 != 0) align *= 2;
+    out.child_align = (int)align;
+  }
   if ((child_grad != nullptr) != (child_end != nullptr) || (child_grad != nullptr && !step)) return AESMC_ERR_UNSUPPORTED;
   if (anc_idx != nullptr && (!step || N > 0x7fffffffLL)) return AESMC_ERR_UNSUPPORTED;
 #define LG_BACKWARD_ARGS                                                                                            \

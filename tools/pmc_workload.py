@@ -7,9 +7,9 @@ shape (MI355X_MICROARCH.md, HBM section: FETCH_SIZE under-reports wide coalesced
 gfx950 — the factor is measured, not assumed).
 
 Usage: python tools/pmc_workload.py <workload> <proposal> [timesteps]
-Dispatch order (resample_gather_kernel): 3 calibration launches.  Then `timesteps` steps of infer:
-timesteps - 1 launches of ancestor_index_inv_kernel (fused step) or of K2 + K3 where the step does
-not cover the payload."""
+Dispatch order (resample_gather_kernel): 3 calibration launches.  Then `timesteps` steps of get_loss:
+timesteps - 1 launches of ancestor_index_inv_kernel (K2; with the newest latent as its payload where the
+model reads the resampled values) and of the propagation kernel (K16 / K15 / K9 + K10)."""
 import os
 import sys
 
@@ -38,14 +38,13 @@ def main(workload, proposal, timesteps=6):
     torch.cuda.synchronize()
     np.random.seed(0)
     torch.manual_seed(0)
-    with torch.no_grad():
-        out = aesmc_amd.inference.infer("smc", observations, model.initial, model.transition, model.emission,
-                                        model.proposal, K, return_log_marginal_likelihood=True, return_latents=False,
-                                        return_ancestral_indices=True)
+    # as bench.py's step: a forward ELBO with the autograd graph recorded (the resampling launch then also writes the
+    # children ranges the backward uses)
+    loss = aesmc_amd.losses.get_loss(observations, K, "aesmc", model.initial, model.transition, model.emission,
+                                     model.proposal)
     torch.cuda.synchronize()
-    unique = [(int((i[:, 1:] != i[:, :-1]).sum()) + B) / (B * K) for i in out["ancestral_indices"]]
-    print("workload {} proposal {} B={} K={} d={}: unique-ancestor fraction per step {}".format(
-        workload, proposal, B, K, dim, [round(x, 3) for x in unique]))
+    print("workload {} proposal {} B={} K={} d={}: loss {:.4f} over {} timesteps".format(
+        workload, proposal, B, K, dim, float(loss), timesteps))
 
 
 if __name__ == "__main__":

@@ -19,7 +19,8 @@ import bench
 KERNELS = {"resample_step": "ancestor_index_inv_kernel", "resample_gather": "resample_gather_kernel",
            "normal_logweight": "normal_logweight", "normal_rsample": "normal_rsample",
            "affine_normal_rsample": "affine_rsample_kernel", "affine_normal_logweight": "affine_logweight_kernel",
-           "affine_normal_propagate": "affine_logweight_kernel"}      # K15 = K10's kernel in DRAW mode: it also writes x_t
+           "affine_normal_propagate": "affine_logweight_kernel",      # K15 = K10's kernel in DRAW mode: it also writes x_t
+           "affine_normal_propagate_drawn": "affine_propagate_noise_kernel"}      # K16
 
 
 def per_dispatch(path, counter, kernel):
@@ -44,7 +45,8 @@ def main(workload, proposal, fetch_csv, write_csv, out_json):
     entry = {"calibration": {"fetch_factor": f_factor, "write_factor": w_factor}}
     algorithmic = {"resample_step": B * K * (20 + 8 * dim) + 8 * B, "resample_gather": B * K * (8 + 8 * dim),
                    "affine_normal_rsample": B * K * 12 * dim, "affine_normal_logweight": B * K * (8 * dim + 4),
-                   "affine_normal_propagate": B * K * (12 * dim + 4)}
+                   "affine_normal_propagate": B * K * (12 * dim + 4),
+                   "affine_normal_propagate_drawn": B * K * (8 * dim + 12)}      # indices, surviving rows in; x_t, lw out
     for key, kernel in KERNELS.items():
         skip = 3 if key == "resample_gather" else 0
         fetch = per_dispatch(fetch_csv, "FETCH_SIZE", kernel)[skip:]
@@ -61,6 +63,12 @@ def main(workload, proposal, fetch_csv, write_csv, out_json):
         if key in ("resample_step", "affine_normal_propagate"):
             # launches with a payload only (time 0 has none; K2 alone writes 12 B/particle); K15: the draw
             pairs = [(f, w) for f, w in zip(fetch, write) if w * w_factor > 0.5 * payload]
+            if not pairs and key == "resample_step":
+                # round 3: the newest latent stays un-gathered (the propagation launch fetches the rows): K2 alone,
+                # 4 B in, 8 B of indices out per particle (+ 4 B of children ranges when a backward will follow)
+                pairs = list(zip(fetch, write))
+                ranges = mean(write) * w_factor > 10 * B * K
+                algorithmic = dict(algorithmic, resample_step=B * K * (12 + (4 if ranges else 0)) + 8 * B)
             if not pairs:
                 continue
             fetch, write = [p[0] for p in pairs], [p[1] for p in pairs]
