@@ -179,17 +179,15 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
   constexpr int NV = (PPL * DP + Vec16<T>::N - 1) / Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const uint32_t dx = mp.dout, dy = mg.dout;
-  T *wp = reinterpret_cast<T *>(lg_smem);
-  T *wg = wp + DP * DP;
-  T *wq = wg + DP * DP;
-  T *tab = wq + DP * DP;                             // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
+  T *wpq = reinterpret_cast<T *>(lg_smem);            // [DP][DP][2]: the transition's and the proposal's weight, interleaved
+  T *wg = wpq + 2 * DP * DP;
+  T *tab = wg + DP * DP;                             // [kLgRowsMax][4][DP]: offsets p, q, g and the observation
   T *tprev = tab + kLgRowsMax * 4 * DP;
   const LgLayout lx = lg_layout<T>(dx);
   T *tx = tprev + (TP * lx.rs + 16);
   const T s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
-  lg_stage_weight<T, DP>(mp, wp);
+  lg_stage_weight_pair<T, DP>(mp, mq, wpq);
   lg_stage_weight<T, DP>(mg, wg);
-  lg_stage_weight<T, DP>(mq, wq);
   LgRowVec<T> vec[4] = {lg_offset_vec<T>(mp), lg_offset_vec<T>(mq), lg_offset_vec<T>(mg), {y, y_sb, (int)dy}};
   const T half_log_2pi = LgConst<T>::half_log_2pi();
   const T two_var_p = T(2) * (s_p * s_p), const_p = T(dx) * (Num<T>::log(s_p) + half_log_2pi);
@@ -269,27 +267,6 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
 #pragma unroll
     for (int r = 0; r < PPL; ++r) at[r] = p[r] * lx.rs;
     // transition and proposal locations from x_prev, one pass over its elements
-    if constexpr (LgPacked<T, PPL>::value) {      // both particles of the lane per multiply-add (linear_gaussian.hpp)
-      lg_f2 ap[DP], aq[DP];
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        ap[j] = lg_f2{locp[j][0], locp[j][1]};
-        aq[j] = lg_f2{locq[j][0], locq[j][1]};
-      }
-#pragma unroll
-      for (int i = 0; i < DP; ++i) {
-        if ((uint32_t)i < dx) {
-          const lg_f2 xv = lg_f2{tprev[at[0] + i], tprev[at[1] + i]};
-          lg_pk_column<DP>(wp + i * DP, xv, ap);
-          lg_pk_column<DP>(wq + i * DP, xv, aq);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        locp[j][0] = ap[j].x; locp[j][1] = ap[j].y;
-        locq[j][0] = aq[j].x; locq[j][1] = aq[j].y;
-      }
-    } else {
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
       if ((uint32_t)i < dx) {
@@ -298,7 +275,7 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
         for (int r = 0; r < PPL; ++r) xv[r] = tprev[at[r] + i];
 #pragma unroll
         for (int j = 0; j < DP; ++j) {
-          const T a = wp[i * DP + j], q = wq[i * DP + j];
+          const T a = wpq[(i * DP + j) * 2], q = wpq[(i * DP + j) * 2 + 1];
 #pragma unroll
           for (int r = 0; r < PPL; ++r) {
             locp[j][r] = fma_t(a, xv[r], locp[j][r]);
@@ -306,7 +283,6 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
           }
         }
       }
-    }
     }
     // squared distances of x to both; x kept for the emission map
     T xx[DP][PPL], qp[PPL], qq[PPL], qg[PPL];
@@ -331,18 +307,6 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
     }
     // emission location from x
     if (use_tab) lg_row_values<T, DP, PPL, 4, 2>(vec, true, tab, b0, brow, locg);
-    if constexpr (LgPacked<T, PPL>::value) {
-      lg_f2 ag[DP];
-#pragma unroll
-      for (int j = 0; j < DP; ++j) ag[j] = lg_f2{locg[j][0], locg[j][1]};
-#pragma unroll
-      for (int i = 0; i < DP; ++i)
-        if ((uint32_t)i < dx) lg_pk_column<DP>(wg + i * DP, lg_f2{xx[i][0], xx[i][1]}, ag);
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        locg[j][0] = ag[j].x; locg[j][1] = ag[j].y;
-      }
-    } else {
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
       if ((uint32_t)i < dx) {
@@ -353,7 +317,6 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
           for (int r = 0; r < PPL; ++r) locg[j][r] = fma_t(c, xx[i][r], locg[j][r]);
         }
       }
-    }
     }
 #pragma unroll
     for (int j = 0; j < DP; ++j) {

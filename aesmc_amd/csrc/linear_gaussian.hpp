@@ -144,6 +144,22 @@ __device__ __forceinline__ void lg_stage_weight(const LgMap &m, T *__restrict__ 
   }
 }
 
+// Two weights INTERLEAVED: wt[(i * DP + j) * 2 + which] = W_which[j][i].  A kernel that applies both maps to the same
+// input (the transition's and the proposal's locations of x_{t-1}) reads the two weights of (i, j) as one 8-byte pair —
+// what the compiler's own pairing of the two multiply-adds onto v_pk_fma_f32 wants side by side (from two separate
+// arrays it spent a v_mov per multiply-add on putting them there).
+template <typename T, int DP>
+__device__ __forceinline__ void lg_stage_weight_pair(const LgMap &m0, const LgMap &m1, T *__restrict__ wt) {
+#pragma unroll 1
+  for (uint32_t e = threadIdx.x; e < 2 * DP * DP; e += kLgBlock) {
+    const uint32_t which = e & 1u, ij = e >> 1;
+    const int i = ij / DP, j = ij - i * DP;
+    const LgMap &m = which ? m1 : m0;
+    const T *w = reinterpret_cast<const T *>(m.w);
+    wt[e] = (j < m.dout && i < m.din) ? w[(int64_t)j * m.sj + (int64_t)i * m.si] : T(0);
+  }
+}
+
 // Which batch row each of a lane's PPL particles lies in (flat particle index n = b K + k).  Lanes past
 // the tile's end take particle 0 of the tile: they compute on valid addresses and store nothing.
 template <int PPL, bool LG_OPAQUE = false>

@@ -137,6 +137,10 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       }
       held[trip] = value;
     }
+    const bool flat = lx.rs == dx;      // workgroup-uniform
+    uint32_t limit[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) limit[i] = it.count[i] * dx;
 #pragma unroll 1
     for (uint32_t s = 0; s < plan.S; ++s) {
       const uint32_t j = tid + s * kLgBlock;
@@ -155,12 +159,22 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
           n4[i] = e < plan.numel ? philox_normal_element(ps, e) : 0.0f;
         }
       }
+      if (flat) {
+        // rows of the tile lie end to end (rs == d): element v of a window's run is at v — one unsigned comparison
+        // places a normal (j < head wraps around to a huge v), instead of a division into (row, column)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (j >= it.head[i]) {
+        for (int i = 0; i < 4; ++i) {
           const uint32_t v = j - it.head[i];
-          const uint32_t rr = (v * plan.small_magic) >> 20, col = v - rr * dx;
-          if (rr < it.count[i]) tx[(i * RUNP + rr) * lx.rs + col] = n4[i];
+          if (v < limit[i]) tx[i * RUNP * dx + v] = n4[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (j >= it.head[i]) {
+            const uint32_t v = j - it.head[i];
+            const uint32_t rr = (v * plan.small_magic) >> 20, col = v - rr * dx;
+            if (rr < it.count[i]) tx[(i * RUNP + rr) * lx.rs + col] = n4[i];
+          }
         }
       }
     }
