@@ -42,6 +42,7 @@ def build(force=False, verbose=True):
              "-ffp-contract=off",  # keep float64 CDF arithmetic as written (no fused a*b+c)
              "-munsafe-fp-atomics",  # hardware float atomics for the gather backward
              "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("AESMC_HIPCC_FLAGS", "").split()      # experiments (e.g. -DAESMC_K16_PROBES); empty in a product build
     objdir = os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
     newest_header = max(os.path.getmtime(h) for h in HEADERS)

@@ -23,7 +23,8 @@
 namespace aesmc {
 
 struct LgNoisePlan {
-  int32_t probe;        // measurement only (AESMC_K16_PROBE): 1 = the noise role draws nothing, 2 = the particle role skips its arithmetic
+  int32_t probe;        // 0 in a product build; with -DAESMC_K16_PROBES and AESMC_K16_PROBE in the environment: 1 = the noise role
+                        // draws nothing, 2 = the particle role skips its arithmetic (timing only: the output is wrong)
   uint64_t numel;       // B K d
   uint64_t magic;       // ceil(2^40 / d): (v * magic) >> 40 == v / d for v < 2^32
   uint32_t L;           // thread ids per block (elements per window): 256 S - (d - 1)
@@ -489,8 +490,12 @@ static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_id
   const uint32_t runp = (uint32_t)(kLgBlock * ppl / 4);
   if ((uint64_t)K < runp) return AESMC_ERR_UNSUPPORTED;        // a run of particles may span two batch rows, not more
   LgNoisePlan plan;
+#ifdef AESMC_K16_PROBES      /* timing experiments only (build with AESMC_HIPCC_FLAGS=-DAESMC_K16_PROBES): a probed launch's OUTPUT IS WRONG */
   static const int probe = [] { const char *v = getenv("AESMC_K16_PROBE"); return v != nullptr ? atoi(v) : 0; }();
   plan.probe = probe;
+#else
+  plan.probe = 0;
+#endif
   plan.numel = numel;
   plan.magic = ((1ull << 40) + (uint64_t)dx - 1) / (uint64_t)dx;
   plan.small_magic = (uint32_t)(((1u << 20) + (uint32_t)dx - 1) / (uint32_t)dx);

@@ -20,7 +20,9 @@ KERNELS = {"resample_step": "ancestor_index_inv_kernel", "resample_gather": "res
            "normal_logweight": "normal_logweight", "normal_rsample": "normal_rsample",
            "affine_normal_rsample": "affine_rsample_kernel", "affine_normal_logweight": "affine_logweight_kernel",
            "affine_normal_propagate": "affine_logweight_kernel",      # K15 = K10's kernel in DRAW mode: it also writes x_t
-           "affine_normal_propagate_drawn": "affine_propagate_noise_kernel"}      # K16
+           "affine_normal_propagate_drawn": "affine_propagate_noise_kernel",      # K16
+           "affine_normal_propagate_resampled": "affine_logweight_kernel",      # K15 fetching x_{t-1} through the ancestors
+           "philox_normal_fill": "philox_normal_fill_kernel"}
 
 
 def per_dispatch(path, counter, kernel):
@@ -46,7 +48,8 @@ def main(workload, proposal, fetch_csv, write_csv, out_json):
     algorithmic = {"resample_step": B * K * (20 + 8 * dim) + 8 * B, "resample_gather": B * K * (8 + 8 * dim),
                    "affine_normal_rsample": B * K * 12 * dim, "affine_normal_logweight": B * K * (8 * dim + 4),
                    "affine_normal_propagate": B * K * (12 * dim + 4),
-                   "affine_normal_propagate_drawn": B * K * (8 * dim + 12)}      # indices, surviving rows in; x_t, lw out
+                   "affine_normal_propagate_drawn": B * K * (8 * dim + 12),      # indices, surviving rows in; x_t, lw out
+                   "affine_normal_propagate_resampled": B * K * (12 * dim + 12), "philox_normal_fill": B * K * 4 * dim}
     for key, kernel in KERNELS.items():
         skip = 3 if key == "resample_gather" else 0
         fetch = per_dispatch(fetch_csv, "FETCH_SIZE", kernel)[skip:]
@@ -60,7 +63,7 @@ def main(workload, proposal, fetch_csv, write_csv, out_json):
                 continue
             fetch, write = [p[0] for p in pairs], [p[1] for p in pairs]
             n = len(pairs)
-        if key in ("resample_step", "affine_normal_propagate"):
+        if key in ("resample_step", "affine_normal_propagate", "affine_normal_propagate_resampled"):
             # launches with a payload only (time 0 has none; K2 alone writes 12 B/particle); K15: the draw
             pairs = [(f, w) for f, w in zip(fetch, write) if w * w_factor > 0.5 * payload]
             if not pairs and key == "resample_step":
