@@ -493,7 +493,10 @@ class HipKernels:
         row_elems = 1
         for s in grad_out.shape[2:]:
             row_elems *= s
-        grad_src = torch.empty_like(grad_out)
+        # The sorted-index kernel writes every row of the result exactly once — if the promise holds.  Indices K2 wrote
+        # itself keep it by construction; a tag that was only INHERITED (a lineage composed from tagged indices, or one a
+        # caller set) starts from zeros, so that a false promise leaves zero rows behind its flag, not stale memory.
+        grad_src = torch.zeros_like(grad_out) if sorted_index == "inherited" else torch.empty_like(grad_out)
         if grad_src.numel() == 0:
             return grad_src
         with _on_device(grad_out.device):

@@ -88,7 +88,7 @@ class _ResampleGather(torch.autograd.Function):
         out = _kernels.get().gather(value, idx)
         ctx.save_for_backward(idx)
         # set only by kernel K2 on its own outputs; any other index tensor takes the general path
-        ctx.sorted_index = bool(getattr(idx, "_aesmc_sorted", False))
+        ctx.sorted_index = getattr(idx, "_aesmc_sorted", False)      # False, True (K2 wrote it) or "inherited"
         ctx.mark_non_differentiable(idx)
         return out
 

@@ -143,7 +143,7 @@ def all_reduce_gradients(parameters, group=None):
 
 def train(dataloader, num_particles, algorithm, initial, transition, emission, proposal, num_epochs,
           num_iterations_per_epoch=None, optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
-          callback=None, group=None, hip_graph=False):
+          callback=None, group=None, hip_graph=False, verify_replays=4):
     """`train.train` (aesmc/train.py:22-41) with one process per GPU: every rank's `dataloader`
     yields ITS OWN rows of each minibatch (equal counts on all ranks), the loss is the mean over
     the global batch (one all-reduce of sum log Z, `sharded_get_loss`) and the parameter gradients
@@ -168,7 +168,7 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
                 shard = (observations[0].size(0) * world_size, rank, world_size)
                 graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
                                              backward=True, shard=shard, group=group, check_flags=False,
-                                             guard_gradients=True)
+                                             guard_gradients=True, verify_replays=verify_replays)
             loss = graphed(observations)            # local replay + the all-reduce of the loss
             all_reduce_gradients(parameters, group=group)
             optimizer.step()

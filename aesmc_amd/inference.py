@@ -229,16 +229,18 @@ def get_resampled_latents(latents, ancestral_indices):
     # non-decreasing maps is non-decreasing, so every lineage built from K2's own outputs is sorted
     # too: the tag sends the backward of these gathers to the atomic-free segmented-sum kernel
     # (which re-checks the promise).  Indices of any other origin stay untagged.
+    # ("inherited": the promise follows from the tags of other tensors, not from the kernel that wrote this one — the
+    #  backward then starts from a zeroed gradient, so a false tag costs a flag and zero rows, never stale memory)
     monotone = all(getattr(index, "_aesmc_sorted", False) for index in ancestral_indices)
     if monotone:
-        lineage._aesmc_sorted = True
+        lineage._aesmc_sorted = "inherited"
     resampled = [None] * len(latents)
     for time in range(len(latents) - 1, -1, -1):
         resampled[time] = state.resample(latents[time], lineage)
         if time > 0:
             lineage = _ops.resample_gather(ancestral_indices[time - 1], lineage)
             if monotone:
-                lineage._aesmc_sorted = True
+                lineage._aesmc_sorted = "inherited"
     return resampled
 
 

@@ -46,7 +46,7 @@ def _minibatches(dataloader, num_epochs, limit):
 def train(dataloader, num_particles, algorithm, initial, transition, emission,
           proposal, num_epochs, num_iterations_per_epoch=None,
           optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
-          callback=None, hip_graph=False):
+          callback=None, hip_graph=False, verify_replays=4):
     """Fits the model parts by stochastic gradient descent on `losses.get_loss`.
 
     A single optimiser (`optimizer_algorithm(params, **optimizer_kwargs)`) owns the parameters of
@@ -61,6 +61,8 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
     needs (fixed minibatch shapes, tensor observations, callables that never synchronise with the
     host; see `aesmc_amd/graphs.py`) and its warm-up evaluations consume random numbers, so a
     seeded run follows a different — equally distributed — trajectory than the eager loop.
+    The fresh graph is checked against eager evaluations before it is used (`verify_replays` of them, each a full
+    eager forward + backward with its memory peak; 0 switches the check off — see `graphs.GraphedLoss`).
     The device status word (NaN log-weights, a degenerate row, ...) is then read every
     `_FLAG_CHECK_INTERVAL` replays instead of every step; in between, the captured backward zeroes the
     gradients of a flagged step on the device (`GraphedLoss(guard_gradients=True)`), so the optimiser
@@ -78,7 +80,8 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
                 # _FLAG_CHECK_INTERVAL replays and once at the end instead of after each replay, so
                 # the host can prepare the next minibatch while the GPU still works on this one
                 graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
-                                             backward=True, check_flags=False, guard_gradients=True)
+                                             backward=True, check_flags=False, guard_gradients=True,
+                                             verify_replays=verify_replays)
             loss = graphed(observations)     # refreshes every captured parameter's .grad in place
             optimizer.step()
             if graphed.replays % _FLAG_CHECK_INTERVAL == 0:

@@ -607,3 +607,42 @@ def test_genealogy_gradients_take_the_sorted_kernel_and_match_torch(hip_device):
         assert torch.equal(again_grads[t], grads[t])            # no atomics: same bits twice
         torch.testing.assert_close(grads[t], leaves[t].grad, rtol=1e-12, atol=1e-12)
         torch.testing.assert_close(other_grads[t], leaves[t].grad, rtol=1e-12, atol=1e-12)
+
+
+def test_a_falsely_tagged_index_leaves_zero_rows_and_a_flag_not_stale_memory(hip_device):
+    """the sorted-index backward writes each row of the gradient exactly once IF the indices are
+    non-decreasing.  A tag that was inherited (here: set by hand on an unsorted index) starts from a zeroed
+    gradient: the result is finite (zeros where no tile wrote), the flag is raised, and K2's own outputs — sorted by
+    construction — keep the path without the fill."""
+    from aesmc_amd import _kernels, _lib, _ops
+    provider = _kernels.get()
+    provider.read_flags(hip_device)
+    B, K, d = 2, 700, 5
+    gen = torch.Generator(device=hip_device).manual_seed(3)
+    grad = torch.randn(B, K, d, device=hip_device, generator=gen)
+    index = torch.randint(0, K, (B, K), device=hip_device, generator=gen)        # not sorted
+    index._aesmc_sorted = "inherited"
+    poison = torch.full((B, K, d), float("nan"), device=hip_device)               # what recycled memory may hold
+    del poison
+    first = provider.gather_backward(grad, index, sorted_index="inherited")
+    assert provider.read_flags(hip_device) & _lib.FLAG_UNSORTED_INDEX
+    second = provider.gather_backward(grad, index, sorted_index="inherited")
+    assert provider.read_flags(hip_device) & _lib.FLAG_UNSORTED_INDEX
+    # (finite, not reproducible: tiles of an unsorted index claim overlapping destination ranges — the flag says so)
+    assert bool(torch.isfinite(first).all()) and bool(torch.isfinite(second).all())
+    # through autograd the tag travels with the index tensor
+    value = torch.randn(B, K, d, device=hip_device, generator=gen, requires_grad=True)
+    _ops.resample_gather(value, index).sum().backward()
+    assert bool(torch.isfinite(value.grad).all())
+    assert provider.read_flags(hip_device) & _lib.FLAG_UNSORTED_INDEX
+    # a correct inherited tag: the same numbers as the untagged kernel
+    lw = torch.randn(B, K, device=hip_device, dtype=torch.float64, generator=gen)
+    own = _ops.ancestor_index(lw, torch.rand(B, device=hip_device, dtype=torch.float64, generator=gen))
+    inherited = own.clone()
+    inherited._aesmc_sorted = "inherited"
+    a = provider.gather_backward(grad, own, sorted_index=True)
+    b = provider.gather_backward(grad, inherited, sorted_index="inherited")
+    c = provider.gather_backward(grad, own.clone(), sorted_index=False)
+    assert torch.equal(a, b)
+    torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5)
+    assert provider.read_flags(hip_device) == 0
