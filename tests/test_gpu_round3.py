@@ -286,7 +286,8 @@ DRAWN_SHAPES = [(3, 700, 10, 10), (16, 4096, 10, 10), (300, 4096, 10, 10), (520,
                 # sizes around ATen's launch geometry (G = 2^19 thread ids): one element per thread, a wrap of a
                 # few elements into the next window, ragged last blocks, a second trip with one window only
                 (1, 52428, 10, 10), (1, 52429, 10, 3), (5, 52430, 10, 10), (3, 174763, 3, 3), (1, 209716, 10, 10),
-                (9, 65536, 4, 4)]
+                (9, 65536, 4, 4),
+                (1024, 4096, 10, 10)]      # the north-star shape itself
 
 
 @pytest.mark.parametrize("gather", [True, False])
@@ -685,6 +686,80 @@ def test_latents_handed_to_the_caller_keep_every_step_its_own_gather_backward(hi
             provider.affine_step_backward = real_sb
         assert calls["with_children"] == 0
     assert torch.equal(grads[False], grads[True])
+
+
+# ---- the headline route against the CPU port at the north-star batch --------------------------------------------------
+def test_the_north_star_shape_matches_the_cpu_port_draw_for_draw(hip_device):
+    """B=1024, K=4096, d=10 — the north-star shape — three timesteps, float64: the CPU port of the reference (plain `Normal(matmul)` callables,
+    PyTorch autograd on the host) records its draws; the product replays them through the route `get_loss` takes at
+    the bench shape — K2 with the children ranges, propagation through the ancestors over persistent workgroups that
+    walk several tiles each, K14 with the gather's backward folded in.  Every ancestor index equal, loss to 1e-10,
+    every parameter gradient to 1e-8 of its largest entry.  (The float32 launch that also draws the noise is held to
+    this route bit for bit at the north-star shape by test_propagate_with_the_noise_inside_...[shape17].)"""
+    from aesmc_amd import _kernels, inference, losses
+    from aesmc_amd.testing import models, replay
+    from oracle import reference_port
+    B, K, T, d = 1024, 4096, 3, 10
+    dtype = torch.float64
+    cpu_model = models.LgssmNd(d, seed=0, dtype=dtype, state=reference_port).tune_proposal()
+    observations = cpu_model.simulate(T, B, seed=1)
+    parts = lambda m: (m.initial, m.transition, m.emission, m.proposal)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    want_indices, real_sampler = [], reference_port.sample_ancestral_index
+
+    def sampler_spy(log_weight):
+        want_indices.append(real_sampler(log_weight))
+        return want_indices[-1]
+
+    reference_port.sample_ancestral_index = sampler_spy
+    try:
+        with replay.record() as tape:
+            want = reference_port.get_loss(observations, K, "aesmc", *parts(cpu_model))
+    finally:
+        reference_port.sample_ancestral_index = real_sampler
+    want.backward()
+    model = models.LgssmNd(d, seed=0, dtype=dtype, affine=True).to(hip_device).tune_proposal()
+    device_observations = [o.to(hip_device) for o in observations]
+    provider = _kernels.get()
+    calls = {"with_children": 0, "through_ancestors": 0}
+    got_indices = []
+    real_sb, real_prop, real_step = provider.affine_step_backward, provider.affine_propagate, provider.resample_step
+
+    def step_spy(*args, **kwargs):
+        out = real_step(*args, **kwargs)
+        got_indices.append(out[0])
+        return out
+
+    def sb_spy(*args, **kwargs):
+        calls["with_children"] += kwargs.get("child_grad") is not None
+        return real_sb(*args, **kwargs)
+
+    def prop_spy(*args, **kwargs):
+        calls["through_ancestors"] += kwargs.get("ancestors") is not None
+        return real_prop(*args, **kwargs)
+
+    provider.affine_step_backward, provider.affine_propagate, provider.resample_step = sb_spy, prop_spy, step_spy
+    try:
+        with replay.replay(tape):
+            got = losses.get_loss(device_observations, K, "aesmc", *parts(model))
+        got.backward()
+    finally:
+        provider.affine_step_backward, provider.affine_propagate, provider.resample_step = real_sb, real_prop, real_step
+    assert calls["with_children"] == T - 2 and calls["through_ancestors"] == T - 1
+    assert len(got_indices) == len(want_indices) == T - 1
+    for a, b in zip(got_indices, want_indices):
+        assert torch.equal(a.cpu(), b)
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-10, atol=1e-10)
+    expected = dict(cpu_model.named_parameters())
+    for name, parameter in model.named_parameters():
+        reference = expected[name].grad
+        if reference is None:
+            assert parameter.grad is None or float(parameter.grad.abs().max()) == 0.0, name
+            continue
+        assert parameter.grad is not None, name
+        scale = max(float(reference.abs().max()), 1e-30)
+        assert float((parameter.grad.cpu() - reference).abs().max()) <= 1e-8 * scale, name
 
 
 # ---- float32 runs of the reference itself, end to end (VERDICT r02 item 6) --------------------------------------

@@ -51,7 +51,8 @@ def main():
     torch.cuda.synchronize()
     prof.disable()
     stats = pstats.Stats(prof)
-    stats.sort_stats("cumulative").print_stats(45)
+    stats.sort_stats("cumulative").print_stats(60)
+    stats.sort_stats("tottime").print_stats(45)
 
 
 if __name__ == "__main__":
