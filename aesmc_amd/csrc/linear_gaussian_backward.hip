@@ -311,6 +311,8 @@ struct LgBackwardOut {
 };
 
 constexpr int kLgChildLimit = 32;   // children a lane sums by itself; longer runs (a collapsed system) take the wavefront
+                                    // (8: the bench shape's healthy ancestry 338 -> 348 us, a collapsed one 456 -> 437)
+constexpr int kLgChildTrip = 2;     // of them per trip out of the staged block (4: 338 -> 350 us at the bench shape)
 
 template <typename T, int DP, int PPL>
 __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_logweight_backward_kernel(
@@ -688,17 +690,18 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
         uint32_t c = lo;
         // (lo >= staged_lo when the ranges are what the resampling launch wrote: the block begins with the tile's first run)
         const uint32_t in_lds = lo >= staged_lo ? min(own_last, staged_hi) : lo;
-        // two rows in flight per trip, added in k order: ((0 + c0) + c1) + c2 ...  (a trip's second row, where the run
-        // has none, is re-read and added as zero: no branch between the loads and the adds)
-        for (; c < in_lds; c += 2) {
-          T a[DP], b[DP];
-          const bool two = c + 1 < in_lds;
-          lg_child_row<T, DP, EXACT>(tchild + (c - staged_lo) * lx.rs, dx, a);
-          lg_child_row<T, DP, EXACT>(tchild + ((two ? c + 1 : c) - staged_lo) * lx.rs, dx, b);
+        // kLgChildTrip rows in flight per trip, added in k order: ((0 + c0) + c1) + c2 ...  (rows past the run's end are
+        // re-reads of its last one, added as zero: no branch between the loads and the adds)
+        for (; c < in_lds; c += kLgChildTrip) {
+          T row[kLgChildTrip][DP];
 #pragma unroll
-          for (int j = 0; j < DP; ++j) {
-            acc[j] = acc[j] + a[j];
-            acc[j] = acc[j] + (two ? b[j] : T(0));
+          for (int i = 0; i < kLgChildTrip; ++i)
+            lg_child_row<T, DP, EXACT>(tchild + (min(c + i, in_lds - 1) - staged_lo) * lx.rs, dx, row[i]);
+#pragma unroll
+          for (int i = 0; i < kLgChildTrip; ++i) {
+            const bool there = c + i < in_lds;
+#pragma unroll
+            for (int j = 0; j < DP; ++j) acc[j] = acc[j] + (there ? row[i][j] : T(0));
           }
         }
         c = min(c, max(in_lds, lo));

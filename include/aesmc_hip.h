@@ -456,8 +456,8 @@ int aesmc_affine_step_backward(
  * `child_grad` / `child_end` (both or neither; NULL = none): the gradient that reaches x_t from the NEXT step when
  * that step, too, resampled through ancestors — its `out->grad_x_prev`, one row per CHILD [B,K,dx] — and the next
  * resampling step's children ranges (aesmc_resample_step_ranges).  The kernel then adds, to whatever `grad_x`
- * brings, the sum of each particle's children's rows (in k order: the stand-alone segmented-sum kernel's bits for
- * runs of up to 32 children; longer runs — a collapsed particle system — are shared out over the wavefront):
+ * brings, the sum of each particle's children's rows (a lane adds its own particle's run in k order; what lies beyond
+ * the first 32 children of a run — a collapsed particle system — is shared out over the wavefront, in a fixed order):
  * torch.gather's backward without its launch and without the [B,K,dx] round trip of the summed gradient. */
 int aesmc_affine_step_backward_resampled(
     int dtype, const void *x_src, const int64_t *ancestors, const void *x, const void *y, int64_t y_stride_b,
