@@ -470,9 +470,18 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
   // of particles 0..j end, so the children of particle j are the positions [first[j-1], first[j]) — one run, because
   // the indices are non-decreasing.  (aesmc_affine_step_backward_resampled sums a particle's children with it.)
   if (out_child_end != nullptr && owns_idx) {
+    int32_t *ends = out_child_end + row * (int64_t)K + j0;
+    // a lane's C entries are consecutive: whole 16-byte stores where the row allows (K a multiple of 4 keeps every
+    // lane's first entry on a 16-byte boundary), else entry by entry
+    if (C % 4 == 0 && (K & 3) == 0 && j0 + C <= K && (reinterpret_cast<uintptr_t>(out_child_end) & 15u) == 0) {
 #pragma unroll
-    for (int i = 0; i < C; ++i)
-      if (j0 + i < K) out_child_end[row * (int64_t)K + j0 + i] = first[i];
+      for (int q = 0; q < C / 4; ++q)
+        reinterpret_cast<int4 *>(ends)[q] = make_int4(first[4 * q], first[4 * q + 1], first[4 * q + 2], first[4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < C; ++i)
+        if (j0 + i < K) ends[i] = first[i];
+    }
   }
   if (lane == 0) first_of_lane[wave] = first[0];            // the next wavefront's first entry, via LDS
   if constexpr (C % 4 == 0) {

@@ -434,6 +434,14 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         else:
             key, label = "logweight_lse", "logweight_lse_kernel (K1)"
         out["roofline"] = roofline_of(kernels.get(key), label, name, proposal, key)
+        if out["roofline"] is not None and use_smc_path(algorithm):
+            # the WHOLE hot path against SURVEY.md 8(d)'s algorithmic figure (36 + 8 d B per particle-step: K1 16 +
+            # K2 12 + K3 8 d + 8) over the timed ELBOs — what the fused launches are for (round 2: 0.24 of the peak)
+            per_step = 36 + 8 * dim
+            rate = per_step * B * K * T / (out["ms_per_step"] * 1e-3) / 1e9
+            out["roofline"]["whole_path"] = {"algorithmic_bytes_per_particle_step": per_step, "achieved": round(rate, 1),
+                                             "frac": round(rate / HBM_PEAK_GBPS, 4), "unit": "GB/s",
+                                             "over": "ms_per_step of the timed region (this rank's rows)"}
         # the propagation kernels either side of it (K9 draws x_t, K10 weighs it), priced the same way
         others = [roofline_of(kernels.get(k), l, name, proposal, k) for k, l in (
             ("resample_step" if key != "resample_step" else "-", "ancestor_index_inv_kernel (K2: ancestor indices + row log-sum-exp)"),
@@ -450,6 +458,10 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def use_smc_path(algorithm):
+    return algorithm == "aesmc"
 
 
 def roofline_of(stats, label, workload, proposal, key):
