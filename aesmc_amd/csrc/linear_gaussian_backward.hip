@@ -566,9 +566,62 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
   // the rows of its own particles; their indices are loaded one tile ahead
   const bool gathers = out.gat.idx != nullptr;
   int64_t ranc[PPL];
-  if (gathers && (int64_t)blockIdx.x < tiles) {
+  // Exact extents with rows of whole 8-byte pairs: the NEXT tile's rows of x_t (16-byte vectors) and of x_{t-1}
+  // (8-byte pieces through the ancestors) wait in registers while this tile is worked on, as in the forward kernels —
+  // the tile's first barrier then waits for LDS stores, not for HBM.
+  constexpr bool PREF = EXACT && (DP * sizeof(T)) % 8 == 0;
+  constexpr int GQ = PREF ? (int)(DP * sizeof(T) / 8) : 1;
+  constexpr int NVX = PREF ? (int)((PPL * DP + Vec16<T>::N - 1) / Vec16<T>::N) : 1;
+  uint32_t rg[PPL * GQ * 2];
+  typename Vec16<T>::type rx[NVX];
+  LgGather gat8 = out.gat;
+  gat8.pb = 8;
+  gat8.ppr = (uint32_t)GQ;
+  const char *xprev_bytes = reinterpret_cast<const char *>(xprev);
+  // ... and so do the tile's per-row vectors (offsets, observation: a few values per lane) and what the particles'
+  // share of the log-sum-exp's gradient is made of
+  constexpr int kTabTrips = PREF ? (kLgRowsMax * 4 * DP + kLgBlock - 1) / kLgBlock : 1;
+  T held_tab[kTabTrips], held_lw[PPL], held_glw[PPL], held_lse[PPL], held_glse[PPL];
+  auto small_prefetch = [&](int64_t n0, uint32_t np) {
+    const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
+    const uint32_t k0 = (uint32_t)(n0 - (int64_t)b0 * K);
+#pragma unroll
+    for (int trip = 0; trip < kTabTrips; ++trip) {
+      const uint32_t idx = lg_tid_impl<true>() + trip * kLgBlock;
+      const uint32_t j = idx % DP, a = (idx / DP) % 4, row = idx / (DP * 4);
+      T value = T(0);
+      if (idx < nrows * 4 * DP) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (a == (uint32_t)c && vec[c].ptr != nullptr && (int)j < vec[c].len)
+            value = vec[c].ptr[(int64_t)(b0 + row) * vec[c].sb + j];
+      }
+      held_tab[trip] = value;
+    }
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const uint32_t q = lg_tid_impl<true>() + r * kLgBlock, qq = q < np ? q : 0u;
+      const int64_t n = n0 + qq;
+      const uint32_t b = b0 + (k0 + qq) / K;
+      held_glw[r] = grad_lw != nullptr ? grad_lw[n] : T(0);
+      held_lw[r] = grad_lse != nullptr ? lw[n] : T(0);
+      held_lse[r] = grad_lse != nullptr ? lse[b] : T(0);
+      held_glse[r] = grad_lse != nullptr ? grad_lse[b] : T(0);
+    }
+  };
+  if ((int64_t)blockIdx.x < tiles) {
     const int64_t n0 = (int64_t)blockIdx.x * TP;
-    lg_anc_prefetch<PPL, true>(out.gat, n0, (uint32_t)min((int64_t)TP, N - n0), ranc);
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    if (gathers) lg_anc_prefetch<PPL, true>(out.gat, n0, np, ranc);
+    if constexpr (PREF) {
+      small_prefetch(n0, np);
+      lg_prefetch<T, NVX, true>(x + n0 * dx, np * dx, 0, rx);
+      if (gathers) {
+        lg_gather_prefetch<PPL, GQ, 8, true>(xprev_bytes, gat8, n0, np, K, ranc, rg);
+        const int64_t m0 = n0 + (int64_t)gridDim.x * TP;
+        if (m0 < N) lg_anc_prefetch<PPL, true>(out.gat, m0, (uint32_t)min((int64_t)TP, N - m0), ranc);
+      }
+    }
   }
   // The children of the lane's particles (the gather's backward folded in, below), as FLAT row numbers b K + c of the
   // next step's per-child gradient: where each particle's run begins and ends, and where the whole tile's does — the
@@ -630,20 +683,34 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
       const int64_t m0 = (tile + gridDim.x) * TP;
       if (m0 < N) child_ranges_prefetch(m0, (uint32_t)min((int64_t)TP, N - m0));
     }
-    if (gathers) {
-      lg_gather_stage<T, PPL, DP, true>(reinterpret_cast<const char *>(xprev), out.gat, n0, np, K, ranc, tprev, lx);
-      const int64_t m0 = (tile + gridDim.x) * TP;
-      if (m0 < N) lg_anc_prefetch<PPL, true>(out.gat, m0, (uint32_t)min((int64_t)TP, N - m0), ranc);
+    if constexpr (PREF) {
+      if (gathers) lg_gather_commit<T, PPL, GQ, 8, true>(gat8, np, rg, tprev, lx);
+      else lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+      lg_commit<T, NVX, true>(x + n0 * dx, np * dx, rx, tx, lx);
     } else {
-      lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+      if (gathers) {
+        lg_gather_stage<T, PPL, DP, true>(xprev_bytes, out.gat, n0, np, K, ranc, tprev, lx);
+        const int64_t m0 = (tile + gridDim.x) * TP;
+        if (m0 < N) lg_anc_prefetch<PPL, true>(out.gat, m0, (uint32_t)min((int64_t)TP, N - m0), ranc);
+      } else {
+        lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
+      }
+      lg_stage_rows<T, true>(x + n0 * dx, np * dx, tx, lx, 0);
     }
-    lg_stage_rows<T, true>(x + n0 * dx, np * dx, tx, lx, 0);
     if (gx_in != nullptr) lg_stage_rows<T, true>(gx_in + n0 * dx, np * dx, tu, lx, 0);
     uint32_t p[PPL], brow[PPL], at[PPL];
     bool live[PPL];
     lg_rows<PPL, true>(n0, np, K, p, live, brow);
     const uint32_t b0 = (uint32_t)(n0 / K), nrows = (uint32_t)((n0 + np - 1) / K) - b0 + 1;
-    lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
+    if constexpr (PREF) {
+#pragma unroll
+      for (int trip = 0; trip < kTabTrips; ++trip) {
+        const uint32_t idx = lg_tid_impl<true>() + trip * kLgBlock;
+        if (idx < nrows * 4 * DP) tab[idx] = held_tab[trip];
+      }
+    } else {
+      lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
+    }
     const uint32_t k0_tile = (uint32_t)(n0 - (int64_t)b0 * K);
     // offsets' gradients: a tile inside one batch row takes its sums from the matrix cores' spare column
     const bool column_sums = ONES && lg_single_row(n0, np, K);
@@ -652,12 +719,32 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
       const int64_t n = n0 + p[r];
-      T value = grad_lw != nullptr ? grad_lw[n] : T(0);
-      if (grad_lse != nullptr) value = value + grad_lse[brow[r]] * Num<T>::exp(lw[n] - lse[brow[r]]);
+      T value;
+      if constexpr (PREF) {
+        value = held_glw[r];
+        if (grad_lse != nullptr) value = value + held_glse[r] * Num<T>::exp(held_lw[r] - held_lse[r]);
+      } else {
+        value = grad_lw != nullptr ? grad_lw[n] : T(0);
+        if (grad_lse != nullptr) value = value + grad_lse[brow[r]] * Num<T>::exp(lw[n] - lse[brow[r]]);
+      }
       g[r] = live[r] ? value : T(0);
       at[r] = p[r] * lx.rs;
     }
     lg_lds_barrier();
+    if constexpr (PREF) {      // the next tile's rows go out now and fly during this tile's arithmetic
+      const int64_t next = tile + gridDim.x;
+      if (next < tiles) {
+        const int64_t m0 = next * TP;
+        const uint32_t mp_ = (uint32_t)min((int64_t)TP, N - m0);
+        small_prefetch(m0, mp_);
+        lg_prefetch<T, NVX, true>(x + m0 * dx, mp_ * dx, 0, rx);
+        if (gathers) {
+          lg_gather_prefetch<PPL, GQ, 8, true>(xprev_bytes, gat8, m0, mp_, K, ranc, rg);      // its indices came a tile ago
+          const int64_t nn0 = (next + gridDim.x) * TP;
+          if (nn0 < N) lg_anc_prefetch<PPL, true>(out.gat, nn0, (uint32_t)min((int64_t)TP, N - nn0), ranc);
+        }
+      }
+    }
     T u[DP][PPL], gprev[DP][PPL], w[DP][PPL];
     uint32_t au[PPL], ay[PPL];
 #pragma unroll
