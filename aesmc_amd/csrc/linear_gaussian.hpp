@@ -356,6 +356,31 @@ __device__ __forceinline__ void lg_commit(const T *__restrict__ src, uint32_t ne
   for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[e] = src[e];   // last tile only
 }
 
+// [ne] elements, contiguous from a 16-byte aligned `src`, into a tile whose layout is FLAT (rs == d), by loads that
+// write LDS directly (gfx950 global_load_lds_dwordx4: wave-uniform LDS base + lane x 16 bytes, per-lane source
+// address) — no registers in between, so a block can be sent for long before it is needed; the LDS writes are
+// complete once the workgroup has passed a barrier that waits for its vector-memory counter.
+template <typename T>
+__device__ __forceinline__ void lg_stage_rows_async(const T *__restrict__ src, uint32_t ne, T *__restrict__ tile) {
+  constexpr uint32_t N = Vec16<T>::N;
+  const uint32_t nvec = ne / N;
+  const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~(uint32_t)(kWave - 1)));
+  const uint32_t lane = threadIdx.x & (uint32_t)(kWave - 1);
+#pragma unroll 1
+  for (uint32_t v0 = wave_base; v0 < nvec; v0 += kLgBlock) {      // wave-uniform trip count
+    const uint32_t v = v0 + lane;
+#if defined(__HIP_DEVICE_COMPILE__)      /* (the builtin exists in the device pass only; the host pass never runs this body) */
+    if (v < nvec)
+      __builtin_amdgcn_global_load_lds(src + (size_t)v * N, (__attribute__((address_space(3))) void *)(tile + (size_t)v0 * N),
+                                       16, 0, 0);
+#else
+    (void)v;
+#endif
+  }
+#pragma unroll 1
+  for (uint32_t e = nvec * N + threadIdx.x; e < ne; e += kLgBlock) tile[e] = src[e];      // the array's last rows only
+}
+
 // ---- rows fetched through ancestor indices -------------------------------------------------------------
 // The resampled latent  x_{t-1}[b, idx[b,k], :]  (aesmc/inference.py:102-111, state.py:179) need not exist in
 // HBM for a kernel that stages x_{t-1} through LDS anyway: every lane fetches the rows of ITS OWN particles

@@ -312,7 +312,7 @@ struct LgBackwardOut {
 
 constexpr int kLgChildLimit = 32;   // children a lane sums by itself; longer runs (a collapsed system) take the wavefront
                                     // (8: the bench shape's healthy ancestry 338 -> 348 us, a collapsed one 456 -> 437)
-constexpr int kLgChildTrip = 2;     // of them per trip out of the staged block (4: 338 -> 350 us at the bench shape)
+constexpr int kLgChildTrip = 1;     // of them per trip out of the staged block (2: the same time, ten more registers; 4: slower)
 
 template <typename T, int DP, int PPL>
 __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_logweight_backward_kernel(
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
   // (RAW entries are kept across the tile: turning them into row numbers where they are loaded would make the
   //  wavefront wait for the loads on the spot)
   int32_t raw_end[PPL], raw_before[PPL], raw_tile_before = 0, raw_tile_end = 0;
-  auto child_ranges_prefetch = [&](int64_t n0, uint32_t np) {
+  auto lane_raw_prefetch = [&](int64_t n0, uint32_t np) {
     const uint32_t k0 = (uint32_t)(n0 % K);
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
@@ -643,7 +643,9 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
       raw_end[r] = out.child_end[n];
       raw_before[r] = out.child_end[(k0 + qq) % K == 0 ? n : n - 1];
     }
-    raw_tile_before = out.child_end[k0 == 0 ? n0 : n0 - 1];      // uniform addresses: every lane the same two entries
+  };
+  auto tile_raw_prefetch = [&](int64_t n0, uint32_t np) {      // uniform addresses: every lane the same two entries
+    raw_tile_before = out.child_end[n0 % K == 0 ? n0 : n0 - 1];
     raw_tile_end = out.child_end[n0 + np - 1];
   };
   // flat row numbers [lo, hi) of particle q of the tile that starts at n0, from its two entries
@@ -656,33 +658,37 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     hi = base + end;
     lo = base + min((uint32_t)max(first_of_row ? 0 : before, 0), end);
   };
+  // the block of rows a tile's children occupy, from the tile's two entries: it starts at a row whose address is a
+  // multiple of 16 bytes and holds a whole number of 16-byte vectors; what does not fit the LDS tile (a tile whose
+  // particles have more than TP children between them) is fetched by the lanes themselves
+  auto staged_range = [&](int64_t n0, uint32_t np, uint32_t &lo, uint32_t &hi) {
+    uint32_t tile_lo, tile_hi, unused;
+    child_range(n0, 0u, true, raw_tile_before, raw_tile_before, tile_lo, unused);
+    child_range(n0, np - 1, true, raw_tile_end, raw_tile_end, unused, tile_hi);
+    const uint32_t align = (uint32_t)out.child_align;
+    lo = tile_lo & ~(align - 1u);
+    hi = tile_hi > lo ? min(min((tile_hi + align - 1u) & ~(align - 1u), (uint32_t)N), lo + TP) : lo;
+  };
+  // Where the tile's layout is flat (rows end to end: every extent that is not a multiple of 4), the NEXT tile's block
+  // is sent for as soon as this tile's sums have been taken from the LDS tile — loads that write LDS directly, its two
+  // entries having come a tile earlier still — and lands during the rest of this tile's arithmetic.
+  const bool ahead = PREF && stages && lx.mul == 0;
+  uint32_t cur_lo = 0, cur_hi = 0, nxt_lo = 0, nxt_hi = 0;
   if (folds && (int64_t)blockIdx.x < tiles) {
     const int64_t n0 = (int64_t)blockIdx.x * TP;
-    child_ranges_prefetch(n0, (uint32_t)min((int64_t)TP, N - n0));
+    const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
+    lane_raw_prefetch(n0, np);
+    tile_raw_prefetch(n0, np);
+    if (ahead) {
+      staged_range(n0, np, cur_lo, cur_hi);
+      lg_stage_rows<T, true>(child_rows + (int64_t)cur_lo * dx, (cur_hi - cur_lo) * dx, tchild, lx, 0);
+      const int64_t m0 = n0 + (int64_t)gridDim.x * TP;
+      if (m0 < N) tile_raw_prefetch(m0, (uint32_t)min((int64_t)TP, N - m0));
+    }
   }
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TP;
     const uint32_t np = (uint32_t)min((int64_t)TP, N - n0);
-    uint32_t own_lo[PPL], own_hi[PPL], staged_lo = 0, staged_hi = 0;      // staged rows: [staged_lo, staged_hi)
-    if (folds) {
-#pragma unroll
-      for (int r = 0; r < PPL; ++r) {
-        const uint32_t q = lg_tid_impl<true>() + r * kLgBlock;
-        child_range(n0, q < np ? q : 0u, q < np, raw_before[r], raw_end[r], own_lo[r], own_hi[r]);
-      }
-      if (stages) {
-        // the block starts at a row whose address is a multiple of 16 bytes; what does not fit the tile (a tile whose
-        // particles have more than TP children between them) is fetched by the lanes themselves
-        uint32_t tile_lo, tile_hi, unused;
-        child_range(n0, 0u, true, raw_tile_before, raw_tile_before, tile_lo, unused);
-        child_range(n0, np - 1, true, raw_tile_end, raw_tile_end, unused, tile_hi);
-        staged_lo = tile_lo & ~((uint32_t)out.child_align - 1u);
-        staged_hi = tile_hi > staged_lo ? min(tile_hi, staged_lo + TP) : staged_lo;
-        lg_stage_rows<T, true>(child_rows + (int64_t)staged_lo * dx, (staged_hi - staged_lo) * dx, tchild, lx, 0);
-      }
-      const int64_t m0 = (tile + gridDim.x) * TP;
-      if (m0 < N) child_ranges_prefetch(m0, (uint32_t)min((int64_t)TP, N - m0));
-    }
     if constexpr (PREF) {
       if (gathers) lg_gather_commit<T, PPL, GQ, 8, true>(gat8, np, rg, tprev, lx);
       else lg_stage_rows<T, true>(xprev + n0 * dx, np * dx, tprev, lx, 0);
@@ -711,6 +717,31 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     } else {
       lg_stage_table<T, DP, 4, true>(vec, b0, nrows, tab);      // the host guarantees nrows <= kLgRowsMax
     }
+    // (after the commits above: the registers that held this tile's rows are free for the next tile's block of children)
+    uint32_t own_lo[PPL], own_hi[PPL], staged_lo = 0, staged_hi = 0;      // staged rows: [staged_lo, staged_hi)
+    if (folds) {
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        const uint32_t q = lg_tid_impl<true>() + r * kLgBlock;
+        child_range(n0, q < np ? q : 0u, q < np, raw_before[r], raw_end[r], own_lo[r], own_hi[r]);
+      }
+      const int64_t m0 = (tile + gridDim.x) * TP;
+      const uint32_t mp_ = m0 < N ? (uint32_t)min((int64_t)TP, N - m0) : 0u;
+      if (ahead) {
+        staged_lo = cur_lo;
+        staged_hi = cur_hi;
+        if (m0 < N) {
+          staged_range(m0, mp_, nxt_lo, nxt_hi);
+          const int64_t mm0 = m0 + (int64_t)gridDim.x * TP;
+          if (mm0 < N) tile_raw_prefetch(mm0, (uint32_t)min((int64_t)TP, N - mm0));
+        }
+      } else if (stages) {
+        staged_range(n0, np, staged_lo, staged_hi);
+        lg_stage_rows<T, true>(child_rows + (int64_t)staged_lo * dx, (staged_hi - staged_lo) * dx, tchild, lx, 0);
+        if (m0 < N) tile_raw_prefetch(m0, mp_);
+      }
+      if (m0 < N) lane_raw_prefetch(m0, mp_);
+    }
     const uint32_t k0_tile = (uint32_t)(n0 - (int64_t)b0 * K);
     // offsets' gradients: a tile inside one batch row takes its sums from the matrix cores' spare column
     const bool column_sums = ONES && lg_single_row(n0, np, K);
@@ -730,21 +761,10 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
       g[r] = live[r] ? value : T(0);
       at[r] = p[r] * lx.rs;
     }
+    // (the block of children sent for during the last tile writes LDS from the vector-memory side: it has landed once
+    //  that counter is drained — the register prefetches committed above have drained it anyway)
+    if (ahead) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lg_lds_barrier();
-    if constexpr (PREF) {      // the next tile's rows go out now and fly during this tile's arithmetic
-      const int64_t next = tile + gridDim.x;
-      if (next < tiles) {
-        const int64_t m0 = next * TP;
-        const uint32_t mp_ = (uint32_t)min((int64_t)TP, N - m0);
-        small_prefetch(m0, mp_);
-        lg_prefetch<T, NVX, true>(x + m0 * dx, mp_ * dx, 0, rx);
-        if (gathers) {
-          lg_gather_prefetch<PPL, GQ, 8, true>(xprev_bytes, gat8, m0, mp_, K, ranc, rg);      // its indices came a tile ago
-          const int64_t nn0 = (next + gridDim.x) * TP;
-          if (nn0 < N) lg_anc_prefetch<PPL, true>(out.gat, nn0, (uint32_t)min((int64_t)TP, N - nn0), ranc);
-        }
-      }
-    }
     T u[DP][PPL], gprev[DP][PPL], w[DP][PPL];
     uint32_t au[PPL], ay[PPL];
 #pragma unroll
@@ -792,16 +812,11 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
           }
         }
         c = min(c, max(in_lds, lo));
-        for (; c < own_last; c += 2) {
-          T a[DP], b[DP];
-          const bool two = c + 1 < own_last;
+        for (; c < own_last; ++c) {      // (rows the tile had no room for)
+          T a[DP];
           lg_child_row<T, DP, EXACT>(child_rows + (int64_t)c * dx, dx, a);
-          lg_child_row<T, DP, EXACT>(child_rows + (int64_t)(two ? c + 1 : c) * dx, dx, b);
 #pragma unroll
-          for (int j = 0; j < DP; ++j) {
-            acc[j] = acc[j] + a[j];
-            acc[j] = acc[j] + (two ? b[j] : T(0));
-          }
+          for (int j = 0; j < DP; ++j) acc[j] = acc[j] + a[j];
         }
         uint64_t todo = __ballot(own_last < hi);
         while (todo != 0) {        // wavefront-uniform: every lane helps the lane whose run is long
@@ -827,6 +842,28 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
 #pragma unroll
         for (int j = 0; j < DP; ++j)
           if ((uint32_t)j < dx && live[r]) w[j][r] = w[j][r] + acc[j];
+      }
+    }
+    if constexpr (PREF) {
+      const int64_t next = tile + gridDim.x;
+      if (ahead) {
+        // every wavefront has taken its sums: the LDS tile is free for the next tile's block
+        lg_lds_barrier();
+        if (next < tiles) lg_stage_rows_async<T>(child_rows + (int64_t)nxt_lo * dx, (nxt_hi - nxt_lo) * dx, tchild);
+        cur_lo = nxt_lo;
+        cur_hi = nxt_hi;
+      }
+      // the next tile's rows go out now and fly during the rest of this tile's arithmetic
+      if (next < tiles) {
+        const int64_t m0 = next * TP;
+        const uint32_t mp_ = (uint32_t)min((int64_t)TP, N - m0);
+        small_prefetch(m0, mp_);
+        lg_prefetch<T, NVX, true>(x + m0 * dx, mp_ * dx, 0, rx);
+        if (gathers) {
+          lg_gather_prefetch<PPL, GQ, 8, true>(xprev_bytes, gat8, m0, mp_, K, ranc, rg);      // its indices came a tile ago
+          const int64_t nn0 = (next + gridDim.x) * TP;
+          if (nn0 < N) lg_anc_prefetch<PPL, true>(out.gat, nn0, (uint32_t)min((int64_t)TP, N - nn0), ranc);
+        }
       }
     }
     // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u
