@@ -197,12 +197,15 @@ class LgssmNd(nn.Module):
     def _observation_terms(self, observations, time):
         """Wy y_t + b for every timestep in ONE matmul: the proposal is handed the whole observation
         sequence at each step, so the first step that needs the term (time 1 of every `infer`) computes
-        it for all of them and the later steps of that run slice it — two small launches per timestep
+        it for all of them and the later steps of that run take their row — two small launches per timestep
         less.  Never kept across runs (its autograd graph belongs to the run that made it)."""
         cached = getattr(self, "_obs_terms", None)
         if time == 1 or cached is None or cached[0] is not observations:
             stacked = observations if torch.is_tensor(observations) else torch.stack(list(observations))
-            cached = (observations, stacked @ self.Wy.t() + self.b)
+            # one row per timestep as views of ONE unbind: its backward is a single stack of the rows' gradients, where
+            # indexing the [T, B, d] tensor at every step costs a zero fill, a copy and an accumulation of that tensor per
+            # step (18 us of the backward's 360 per timestep at the bench shape)
+            cached = (observations, (stacked @ self.Wy.t() + self.b).unbind(0))
         # dropped with the last step: a tensor that outlives the run keeps the run's autograd graph (and
         # the parameters' AccumulateGrad nodes) alive, which a later hipGraph capture of a backward
         # pass cannot tolerate (aesmc_amd/graphs.py)
