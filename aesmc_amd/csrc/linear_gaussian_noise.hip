@@ -24,7 +24,7 @@ namespace aesmc {
 
 struct LgNoisePlan {
   int32_t probe;        // 0 in a product build; with -DAESMC_K16_PROBES and AESMC_K16_PROBE in the environment: 1 = the noise role
-                        // draws nothing, 2 = the particle role skips its arithmetic (timing only: the output is wrong)
+                        // draws nothing, 2 = the particle role skips its arithmetic, 3 = both (timing only: the output is wrong)
   uint64_t numel;       // B K d
   uint64_t magic;       // ceil(2^40 / d): (v * magic) >> 40 == v / d for v < 2^32
   uint32_t L;           // thread ids per block (elements per window): 256 S - (d - 1)
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       if (j >= it.tl + dx - 1) break;
       const uint64_t t = (uint64_t)it.t0 + j;
       float n4[4];
-      if (plan.probe == 1) {
+      if (plan.probe & 1) {
         n4[0] = n4[1] = n4[2] = n4[3] = 0.5f;
       } else if (t < G) {
         const float4 n = philox_normal4(ps, (uint32_t)t, it.c);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       const uint32_t k0 = first - (first / K) * K;
       trow[r] = ((seg[r] * kLgSegRows + ((k0 + rr) >= K ? 1u : 0u)) * 4) * DP;
     }
-    if (plan.probe == 2) {
+    if (plan.probe & 2) {
 #pragma unroll
       for (int r = 0; r < PPL; ++r)
         if (live[r]) out_lw[n_of[r]] = tprev[at[r]] + tx[an[r]];
