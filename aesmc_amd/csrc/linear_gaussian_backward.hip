@@ -996,11 +996,12 @@ struct LgFinish {
   int64_t B, N;
   uint32_t K, TP;
 };
+constexpr int kLgFinishSplit = 4;      // workgroups per matrix of the finishing launch
 template <typename T>
 __global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ ws, int nblocks, int record, LgFinish f) {
-  if ((int)blockIdx.x >= f.matrices) {
+  if ((int)blockIdx.x >= f.matrices * kLgFinishSplit) {
     // ---- one lane per (batch row, column): the few tiles that cover the row, in tile order
-    const int r = (int)blockIdx.x - f.matrices, term = r / f.row_blocks;
+    const int r = (int)blockIdx.x - f.matrices * kLgFinishSplit, term = r / f.row_blocks;
     T *goff = reinterpret_cast<T *>(f.goff[term]);
     if (goff == nullptr) return;
     const int64_t b = (int64_t)(r - term * f.row_blocks) * 64 + (threadIdx.x >> 4);
@@ -1008,23 +1009,34 @@ __global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ w
     if (b >= f.B || j >= d) return;
     const T *rows = reinterpret_cast<const T *>(f.row_ws);
     const int64_t first = b * f.K / f.TP, last = ((b + 1) * f.K - 1) / f.TP;
-    T sum = T(0);
-    for (int64_t tile = first; tile <= last; ++tile) {
+    // (eight tiles' records in flight, then added in tile order: the same association as one at a time)
+    auto tile_value = [&](int64_t tile) {
       const int64_t n0 = tile * f.TP, b0 = n0 / f.K;
       const T *record = rows + (tile * f.row_terms + term) * (kLgRowsMax * 16);
       if (f.column_sums && lg_single_row(n0, (uint32_t)min((int64_t)f.TP, f.N - n0), f.K))
-        sum += ((record[j] + record[16 + j]) + record[32 + j]) + record[48 + j];     // the four wavefronts' sums
-      else
-        sum += record[(b - b0) * 16 + j];
+        return ((record[j] + record[16 + j]) + record[32 + j]) + record[48 + j];     // the four wavefronts' sums
+      return record[(b - b0) * 16 + j];
+    };
+    T sum = T(0);
+    int64_t tile = first;
+    for (; tile + 8 <= last + 1; tile += 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = tile_value(tile + u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
     }
+    for (; tile <= last; ++tile) sum += tile_value(tile);
     goff[b * d + j] = sum;
     return;
   }
-  // element e of matrix m: four lanes each sum a quarter of the workgroups' records (in workgroup order,
-  // eight loads in flight), then the quarters are added in order — fixed association, reproducible
-  __shared__ T part[4 * 256];
-  const int m = blockIdx.x, e = threadIdx.x & 255, seg = threadIdx.x >> 8;
-  const int per = (nblocks + 3) / 4, b0 = seg * per, b1 = min(nblocks, b0 + per);
+  // element e of matrix m: a matrix is shared out over kLgFinishSplit workgroups (64 elements each); sixteen lanes per
+  // element each sum a sixteenth of the workgroups' records (in workgroup order, eight loads in flight), then the
+  // sixteenths are added in order — fixed association, reproducible
+  __shared__ T part[16 * 64];
+  const int m = blockIdx.x / kLgFinishSplit, lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int e = (blockIdx.x - m * kLgFinishSplit) * 64 + lane;
+  const int per = (nblocks + 15) / 16, b0 = seg * per, b1 = min(nblocks, b0 + per);
   T sum = T(0);
   int b = b0;
   for (; b + 8 <= b1; b += 8) {
@@ -1035,10 +1047,12 @@ __global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ w
     for (int u = 0; u < 8; ++u) sum += v[u];
   }
   for (; b < b1; ++b) sum += ws[(int64_t)b * record + m * 256 + e];
-  part[seg * 256 + e] = sum;
+  part[seg * 64 + lane] = sum;
   __syncthreads();
   if (seg == 0) {
-    const T total = ((part[e] + part[256 + e]) + part[512 + e]) + part[768 + e];
+    T total = part[lane];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) total += part[q * 64 + lane];
     const int j = e >> 4, i = e & 15;
     T *out = reinterpret_cast<T *>(f.out[m]);
     if (out != nullptr && j < f.rows[m] && i < f.cols[m]) out[j * f.cols[m] + i] = total;
@@ -1090,7 +1104,7 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
     f.row_ws = rows; f.goff[0] = goff; f.goff_d[0] = (int32_t)dout; f.row_terms = 1;
     f.row_blocks = goff != nullptr ? (int32_t)((B + 63) / 64) : 0;
     f.B = B; f.K = (uint32_t)K; f.TP = (uint32_t)tp;
-    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(f.matrices + f.row_blocks)), dim3(1024), 0, stream,
+    hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(f.matrices * kLgFinishSplit + f.row_blocks)), dim3(1024), 0, stream,
                        static_cast<const T *>(records), grid, kLgRecord, f);
     if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
   }
@@ -1188,7 +1202,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   f.row_blocks = row_terms != 0 ? (int32_t)((B + 63) / 64) : 0;
   f.B = B; f.N = N; f.K = (uint32_t)K; f.TP = (uint32_t)(kLgBlock * ppl);
   f.column_sums = (step && dx == dp && dy == dp && dp < 16) ? 1 : 0;
-  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(4 + 3 * f.row_blocks)), dim3(1024), 0, stream,
+  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(4 * kLgFinishSplit + 3 * f.row_blocks)), dim3(1024), 0, stream,
                      static_cast<const T *>(ws), grid, 4 * kLgRecord, f);   // one finishing launch for everything
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
