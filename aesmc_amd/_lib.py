@@ -51,6 +51,7 @@ class AffineLogweightGrads(ctypes.Structure):
 SIGNATURES = {
     "aesmc_version": (_i32, []),
     "aesmc_target_arch": (ctypes.c_char_p, []),
+    "aesmc_host_device_pointer": (_i32, [_vp, ctypes.POINTER(ctypes.c_void_p)]),
     "aesmc_logweight_lse": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_logweight_accumulate": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_logweight_lse_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),

@@ -109,6 +109,37 @@ class ResampledHistory(collections.abc.Sequence):
         return self._cache[position]
 
 
+_ZERO_COPY_UNIFORMS = _os.environ.get("AESMC_ZERO_COPY_UNIFORMS", "1") != "0"      # measurement knob
+
+
+class _MappedBlock:
+    """`__cuda_array_interface__` of a pinned host block at the address the device maps it to."""
+
+    def __init__(self, address, shape, keepalive):
+        self.keepalive = keepalive
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(address), False),
+                                         "version": 2, "strides": None}
+
+
+def _mapped_view(pinned, device):
+    """A device tensor that IS the pinned float64 block `pinned` (no copy), or None when the device cannot address it
+    (aesmc_host_device_pointer) or this PyTorch cannot wrap the address."""
+    import ctypes
+    from . import _lib
+    try:
+        address = ctypes.c_void_p()
+        status = _lib.load().aesmc_host_device_pointer(ctypes.c_void_p(pinned.data_ptr()), ctypes.byref(address))
+        if status != 0 or not address.value:
+            return None
+        view = torch.as_tensor(_MappedBlock(address.value, pinned.shape, pinned), device=device)
+        if view.data_ptr() != address.value or view.dtype != torch.float64 or tuple(view.shape) != tuple(pinned.shape):
+            return None
+        view._aesmc_pinned = pinned      # the device view must not outlive the host block
+        return view
+    except Exception:
+        return None
+
+
 class _UniformFeed:
     """Per-resample uniforms: drawn from numpy's global RandomState one [batch_size, 1] block per
     timestep (the reference's RNG consumption, aesmc/inference.py:250) and shipped to the device
@@ -118,14 +149,22 @@ class _UniformFeed:
         self.device = device
         self.batch_size = batch_size
         self.cursor = 0
+        self.mapped_rows = None
         if device.type == "cuda":
             self.host = torch.empty((max(num_draws, 1), batch_size), dtype=torch.float64,
                                     pin_memory=True)
             self.host_np = self.host.numpy()      # the same pinned memory: a draw is written straight into it
-            self.dev = torch.empty((max(num_draws, 1), batch_size), dtype=torch.float64,
-                                   device=device)
-            self.host_rows = list(self.host.unbind(0))
-            self.dev_rows = list(self.dev.unbind(0))
+            # the resampling launch reads its 8 bytes per row straight out of that pinned block when the device can
+            # address it (one slot per timestep, written once before the launch that reads it): no copy launch per step
+            mapped = _mapped_view(self.host, device) if _ZERO_COPY_UNIFORMS else None
+            if mapped is not None:
+                self.mapped_rows = list(mapped.unbind(0))
+                self.dev = mapped
+            else:
+                self.dev = torch.empty((max(num_draws, 1), batch_size), dtype=torch.float64,
+                                       device=device)
+                self.host_rows = list(self.host.unbind(0))
+                self.dev_rows = list(self.dev.unbind(0))
         else:
             self.host = self.dev = None
 
@@ -133,9 +172,11 @@ class _UniformFeed:
         draw = draw_uniform_block(self.batch_size)
         if self.host is None:
             return torch.from_numpy(draw)
-        slot = self.cursor % len(self.host_rows)
+        slot = self.cursor % len(self.host_np)
         self.cursor += 1
         self.host_np[slot] = draw
+        if self.mapped_rows is not None:
+            return self.mapped_rows[slot]
         row = self.dev_rows[slot]
         row.copy_(self.host_rows[slot], non_blocking=True)
         return row

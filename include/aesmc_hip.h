@@ -46,6 +46,13 @@ extern "C" {
 int aesmc_version(void);             /* 10000*major + 100*minor + patch */
 const char *aesmc_target_arch(void); /* "gfx950" */
 
+/* The address kernels can use for a pointer into PINNED host memory (hipHostMalloc / PyTorch pin_memory=True), or
+ * AESMC_ERR_UNSUPPORTED when it is not mapped into the device's address space.  aesmc/inference.py:250 draws one
+ * uniform per batch row on the host before every resampling step: with this, `u` of aesmc_ancestor_index /
+ * aesmc_resample_step may point at the pinned block the host wrote them into — 8 bytes per row read over the host
+ * link — instead of at a device copy made by a launch of its own per timestep. */
+int aesmc_host_device_pointer(const void *host_ptr, void **device_ptr);
+
 /*
  * K1 — fused log-weight combine + per-row log-sum-exp.
  *   lw[b,k]  = lp_a[b,k] + lp_b[b,k] - lp_c[b,k]           (lp_b / lp_c may be NULL: term dropped)
