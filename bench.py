@@ -211,6 +211,9 @@ def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_
     while cost(b, t) / rate > budget_s and t > 10:
         t -= 5
     dt, loss = run(b, t)
+    while 2.5 * dt <= budget_s and 2 * b <= B:      # the estimate was pessimistic: a sample of about budget_s / 2 ... budget_s
+        b *= 2
+        dt, loss = run(b, t)
     return {"value": b * K * t / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
             "sample": "1 forward ELBO, B={} K={} T={} d={} ({} proposal) in {:.1f} s on {} of {} host cores; "
                       "oracle/reference_port.py (PyTorch-CPU + NumPy, keeps the reference's O(T^2) "
