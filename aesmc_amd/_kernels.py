@@ -921,11 +921,11 @@ class HipKernels:
                 self.timer.note(name, (entry, args), nbytes, (x_prev, ancestors, eps, y_rows, out, out_x, maps, scales))
         return out
 
-    # Below ~2M particles a launch has too few work items to hide a workgroup's start-up behind (measured: B=128
-    # K=4096 d=10: 47 us against 10 + 26 us for the noise as its own launch followed by K15 through the
-    # ancestors; B=512 K=4096: 97 against 105): the noise is then materialised by aesmc_philox_normal_fill —
-    # the same values — and the step takes the launches that read it.
-    DRAWN_MIN_PARTICLES = int(__import__("os").environ.get("AESMC_K16_MIN_PARTICLES", str(1 << 21)))
+    # Below ~1M particles a launch has too few work items to hide a workgroup's start-up behind (measured, whole ELBOs
+    # as hipGraphs: B=128 K=4096 d=10 4.48 ms with the noise as its own launch followed by K15 through the ancestors
+    # against 6.06 with K16; B=256 K=4096: 6.63 against 6.46; B=512: 105 against 97 us per step): the noise is then
+    # materialised by aesmc_philox_normal_fill — the same values — and the step takes the launches that read it.
+    DRAWN_MIN_PARTICLES = int(__import__("os").environ.get("AESMC_K16_MIN_PARTICLES", str(1 << 20)))
 
     def philox_normal(self, stream_desc, shape, device):
         """The float32 tensor `torch.empty(shape).normal_()` would have held for the generator state

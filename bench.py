@@ -757,7 +757,7 @@ def main(argv=None):
         "config": {"workload": head["workload"], "proposal": head["proposal"],
                    "callables": {"affine": "AffineNormal(source, weight, scale, offset), the proposal's with defer_draw=True: "
                                            "resampling gather, draw (noise from torch's Philox stream, inside the launch) "
-                                           "and log-weight in one kernel (K16; below 2M particles K15 through the "
+                                           "and log-weight in one kernel (K16; below 1M particles K15 through the "
                                            "ancestors behind a noise launch), a step's backward in one (K14, through the "
                                            "ancestors) (aesmc_amd/linear_gaussian.py)",
                                  "matmul": "Normal(source @ weight.T + offset, scale): PyTorch matmuls, then K6 / K5"

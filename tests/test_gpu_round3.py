@@ -357,7 +357,7 @@ def test_a_run_whose_kernels_draw_the_noise_is_the_run_that_lets_torch_draw_it(h
     provider = _kernels.get()
     threshold_was = type(provider).DRAWN_MIN_PARTICLES
     if policy.startswith("inside"):
-        type(provider).DRAWN_MIN_PARTICLES = 0       # (below ~2M particles the default policy fills the noise first)
+        type(provider).DRAWN_MIN_PARTICLES = 0       # (below ~1M particles the default policy fills the noise first)
     runs = {}
     for inside in (False, True):
         state.set_kernel_noise(inside)
