@@ -817,3 +817,35 @@ def test_float32_runs_of_the_reference_teacher_forced_and_free_running(hip_devic
     if agreement_bound is not None:
         assert got["free_running_index_agreement_mean"] >= agreement_bound
     assert got["free_running_rel_dlogZ"] <= lml_bound
+
+
+def test_uniforms_read_from_the_pinned_block_are_the_uniforms_copied_to_the_device(hip_device):
+    """The resampling launch reading its per-row uniforms out of the pinned block the host wrote them into
+    (`aesmc_host_device_pointer`, no copy launch per timestep) against the run that copies each block to the device:
+    the same ancestors, evidence and latents; and the mapped view really is the host block."""
+    from aesmc_amd import inference
+    from aesmc_amd.testing.models import LgssmNd
+    feed = inference._UniformFeed(16, 3, hip_device)
+    assert feed.mapped_rows is not None, "the device does not map PyTorch's pinned memory: the copy path is in use"
+    np.random.seed(5)
+    row = feed.next()
+    assert row.is_cuda and np.array_equal(row.cpu().numpy(), feed.host_np[0])
+    runs = {}
+    for mapped in (False, True):
+        was = inference._ZERO_COPY_UNIFORMS
+        inference._ZERO_COPY_UNIFORMS = mapped
+        try:
+            model = LgssmNd(10, dtype=torch.float32, affine=True).tune_proposal().to(hip_device)
+            observations = model.simulate(12, 5, seed=3)
+            torch.manual_seed(11)
+            np.random.seed(11)
+            with torch.no_grad():
+                runs[mapped] = inference.infer("smc", observations, model.initial, model.transition, model.emission,
+                                               model.proposal, 900, return_log_marginal_likelihood=True,
+                                               return_ancestral_indices=True)
+        finally:
+            inference._ZERO_COPY_UNIFORMS = was
+    a, b = runs[False], runs[True]
+    assert torch.equal(a["log_marginal_likelihood"], b["log_marginal_likelihood"])
+    for x, y in zip(a["ancestral_indices"] + a["latents"], b["ancestral_indices"] + b["latents"]):
+        assert torch.equal(x, y)
