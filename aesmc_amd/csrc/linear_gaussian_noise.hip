@@ -266,10 +266,14 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
   };
 
   Item cur = locate(blockIdx.x < items ? blockIdx.x : 0);
+  Item ahead = cur;       // the item after `cur` (located once: its ancestors are sent for an item before its rows are)
   if (blockIdx.x < items) {
     anc_prefetch(cur);
     rows_prefetch(cur);
-    if (blockIdx.x + gridDim.x < items) anc_prefetch(locate(blockIdx.x + gridDim.x));
+    if (blockIdx.x + gridDim.x < items) {
+      ahead = locate(blockIdx.x + gridDim.x);
+      anc_prefetch(ahead);
+    }
   }
   lg_lds_barrier();       // the first item's noise and table are there; so are the maps
   uint32_t slot = 0;
@@ -295,9 +299,12 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
     const uint32_t next = item + gridDim.x;
     Item nxt = cur;
     if (next < items) {
-      nxt = locate(next);
+      nxt = ahead;
       rows_prefetch(nxt);                                        // its ancestors came an item ago
-      if (next + gridDim.x < items) anc_prefetch(locate(next + gridDim.x));
+      if (next + gridDim.x < items) {
+        ahead = locate(next + gridDim.x);
+        anc_prefetch(ahead);
+      }
     }
     // ---- the lane's particles ----------------------------------------------------------------------------
     bool live[PPL];
