@@ -8,7 +8,8 @@ print("roofline", {k: d["roofline"].get(k) for k in ("kernel", "avg_launch_us", 
 e = d.get("extras", {})
 print("projection", e.get("strong_scaling_projection"))
 print("seconds", e.get("bench_seconds"))
-for k in ("stock_proposal", "matmul_callables", "c2_hipgraph", "c2_eager", "c4nl"):
+for k in ("stock_proposal", "matmul_callables", "c2_hipgraph", "c4nl"):
     v = e.get(k) or {}
-    print(k, v.get("value"), v.get("ms_per_step"), v.get("fwd_bwd_particle_steps_per_sec"), v.get("mode"))
+    print(k, v.get("value"), v.get("ms_per_step"), v.get("fwd_bwd_particle_steps_per_sec"), v.get("mode"),
+          "eager loop:", v.get("eager_particle_steps_per_sec"))
 print("cpu", d.get("cpu_baseline"))
