@@ -1,15 +1,13 @@
 #!/bin/bash
-# A whole-ELBO hipGraph at B=512 K=4096 (one GPU's shard at N=2), forward only, with the runtime's packet-capture fast
-# path on and off: replay time and the loss against the eager loop's.
+# Kernel trace of one workload's forward + backward (default: configs[3]'s nonlinear model on a one-GPU shard):
+#   tools/shard_probe.sh [workload] [extra bench.py flags]
 set -u
+W=${1:-c4nl}; shift || true
 OUT=gpurun_out
-for PC in 1 0; do
-  for i in 1 2; do
-    DEBUG_CLR_GRAPH_PACKET_CAPTURE=$PC timeout -k 10 300 python bench.py --workload c4x2 --mode graph --steps 10 --warmup 3 --extras off --no-cpu-baseline --no-backward > $OUT/r04_pc${PC}_$i.json 2> $OUT/r04_pc${PC}_$i.err
-    python -c "
-import json; d=json.loads(open('$OUT/r04_pc${PC}_$i.json').read().strip().splitlines()[-1]); print('packet capture $PC run $i:', d['mode'], round(d['ms_per_step'],3), 'loss', d['loss'], d.get('graph_error'))" || tail -3 $OUT/r04_pc${PC}_$i.err
-  done
-done
-timeout -k 10 300 python bench.py --workload c4x2 --mode eager --steps 10 --warmup 3 --extras off --no-cpu-baseline --no-backward > $OUT/r04_eager.json 2>/dev/null
-python -c "
-import json; d=json.loads(open('$OUT/r04_eager.json').read().strip().splitlines()[-1]); print('eager:', round(d['ms_per_step'],3), 'loss', d['loss'])"
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/probe_$W -- \
+   python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --extras off "$@" > $GRAFT_REPO_ROOT/$OUT/probe_$W.log 2>&1)
+STATS=$(ls $OUT/probe_$W/*/*kernel_stats.csv | head -1)
+python tools/summarize_rocprof.py $STATS 22 > $OUT/probe_rocprof_$W.csv
+rm -rf $OUT/probe_$W
+cut -c1-150 $OUT/probe_rocprof_$W.csv
+tail -1 $OUT/probe_$W.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['mode'], round(d['ms_per_step'],2), d['value'], d.get('fwd_bwd_particle_steps_per_sec'))"
