@@ -1226,12 +1226,22 @@ class HipKernels:
 
     # ---- K14: the whole backward of a step whose x_t is the proposal's reparameterised draw ------
     def affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
-                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None, child_grad=None, child_end=None):
+                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None, child_grad=None, child_end=None,
+                             chain=None):
         """K14: gradients of one SMC step (log-weights `lw` of K10, their row log-sum-exp `lse`) whose x IS the
         draw  loc_q(x_prev) + s_q eps  of K9 from the same proposal operands, with respect to
         (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q) — x's own slot is always None: the
         gradient `grad_x` that arrives at x from later steps and the step's own gradient at x travel on
-        through the draw inside the kernel (K12 + K11 + the accumulations between them, one pass)."""
+        through the draw inside the kernel (K12 + K11 + the accumulations between them, one pass).
+        `chain` (a dict, only through ancestors): {"carry": (workspace, records) of the step run before this one with the
+        SAME A, C, Q and scales, or None; "defer": leave this step's sums for those parameters as records}.  A
+        deferring call returns None in their slots and sets chain["left"] = (workspace, records) for the next call
+        to carry; a carrying call's gradients for them include everything carried.  Where the kernel declines the
+        shape, what was carried is collected and added here and nothing is left (chain["left"] = None)."""
+        if chain is not None:
+            chain["left"] = None
+            if ancestors is None:
+                raise ValueError("aesmc_amd: affine_step_backward chains the weights' gradients only through ancestors")
         if not self.affine_logweight_covers(x_prev, x, y_rows, transition, emission, proposal, scales):
             raise ValueError("aesmc_amd: affine_step_backward operands outside what kernel K14 covers")
         if need[1]:
@@ -1280,8 +1290,11 @@ class HipKernels:
         rows_p = make((B, dx), need[4] and off_p is not None)
         rows_g = make((B, dy), (need[6] and off_g is not None) or need[2])
         rows_q = make((B, dx), need[8] and off_q is not None)
-        gA, gC, gQ = make((dx, dx), need[3]), make((dy, dx), need[5]), make((dx, dx), need[7])
-        gscales = make((3,), need[9] or need[10] or need[11])
+        carry = chain["carry"] if chain is not None else None
+        defer = chain is not None and bool(chain["defer"])
+        gA, gC, gQ = (make((dx, dx), need[3] and not defer), make((dy, dx), need[5] and not defer),
+                      make((dx, dx), need[7] and not defer))
+        gscales = make((3,), (need[9] or need[10] or need[11]) and not defer)
         ws_bytes = int(self._lib.aesmc_affine_backward_workspace_bytes(tag, B, K))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         outs = _lib.AffineLogweightGrads(_ptr(gx_prev), 0, 0, 0, 0, _ptr(gA), _ptr(gC), _ptr(gQ), _ptr(gscales),
@@ -1293,10 +1306,14 @@ class HipKernels:
                       _ptr(scales[2]), _ptr(lw) if fused_lse else 0, _ptr(lse) if fused_lse else 0,
                       _ptr(grad_lse) if fused_lse else 0, _ptr(grad_lw), _ptr(grad_x))
             tail = (ctypes.byref(outs), _ptr(ws), ws_bytes)
+            link = None
+            if chain is not None:
+                link = _lib.AffineChain(_ptr(carry[0]) if carry is not None else 0, carry[1] if carry is not None else 0,
+                                        (2 if (need[9] or need[10] or need[11]) else 1) if defer else 0, 0)
             if ancestors is not None:
                 entry = self._lib.aesmc_affine_step_backward_resampled
                 args = (tag, _ptr(x_prev), _ptr(ancestors)) + middle + (_ptr(child_grad), _ptr(child_end)) + tail + \
-                    (_ptr(self.flags(x.device)), B, K, self._stream(x))
+                    (_ptr(self.flags(x.device)), ctypes.byref(link) if link is not None else None, B, K, self._stream(x))
             else:
                 entry = self._lib.aesmc_affine_step_backward
                 args = (tag, _ptr(x_prev)) + middle + tail + (B, K, self._stream(x))
@@ -1307,11 +1324,19 @@ class HipKernels:
             if status == 2 and ancestors is not None:       # the unfused route wants the resampled rows as a tensor
                 x_prev, ancestors = self.gather(x_prev, ancestors), None
             if status == 2:     # too few particles per batch row for the fused kernel's row table
-                return self.affine_step_backward_unfused(
+                grads = self.affine_step_backward_unfused(
                     x_prev, x, y_rows, transition, emission, proposal, scales, need, lw if fused_lse else None,
                     lse if fused_lse else None, grad_lse=grad_lse if fused_lse else None, grad_x=grad_x,
                     grad_lw=grad_lw)
+                if carry is not None:      # what the steps before left: finished here, added to this step's own
+                    carried = self.affine_backward_collect(carry, x.dtype, x.device, dx, dy, need, scales)
+                    for slot, value in enumerate(carried):
+                        if value is not None:
+                            grads[slot] = value if grads[slot] is None else grads[slot] + value
+                return grads
             _lib.check(status, "aesmc_affine_step_backward")
+            if defer:
+                chain["left"] = (ws, int(link.records))
             if self.timer is not None:
                 nbytes = x.element_size() * B * K * (2 * dx + 1 + (dx if grad_x is not None else 0) +
                                                      (dx if gx_prev is not None else 0))
@@ -1322,7 +1347,7 @@ class HipKernels:
                 self.timer.note("affine_step_backward" + ("_resampled" if ancestors is not None else ""), (entry, args),
                                 nbytes, (x_prev, ancestors, x, y_rows, lw, lse, grad_lse, grad_lw, grad_x, child_grad,
                                          child_end, outs, ws, maps, scales, gA, gC, gQ, gscales, rows_p, rows_g, rows_q,
-                                         gx_prev))
+                                         gx_prev, link, carry))
         fold = lambda rows, off: rows if off.dim() == 2 else rows.sum(dim=0)
         grads = [gx_prev, None, None, gA, None, gC, None, gQ, None, None, None, None]
         if need[2]:
@@ -1334,9 +1359,30 @@ class HipKernels:
         if rows_q is not None:
             grads[8] = fold(rows_q, off_q)
         for slot, s in ((9, scales[0]), (10, scales[1]), (11, scales[2])):
+            if need[slot] and gscales is not None:
+                grads[slot] = gscales[slot - 9].reshape(s.shape)
+        return grads
+
+    def affine_backward_collect(self, left, dtype, device, dx, dy, need, scales):
+        """The weights' and scales' gradients (a 12-slot list like affine_step_backward's, None elsewhere) out of the
+        records a deferring K14 call left — `left` = its chain["left"] — when no later call carried them on."""
+        ws, records = left
+        make = lambda shape, wanted: torch.empty(shape, dtype=dtype, device=device) if wanted else None
+        gA, gC, gQ = make((dx, dx), need[3]), make((dy, dx), need[5]), make((dx, dx), need[7])
+        gscales = make((3,), need[9] or need[10] or need[11])
+        outs = _lib.AffineLogweightGrads(0, 0, 0, 0, 0, _ptr(gA), _ptr(gC), _ptr(gQ), _ptr(gscales), 0, 0, 0)
+        with _on_device(device):
+            args = (_DTYPE_TAG[dtype], _ptr(ws), records, dx, dy, ctypes.byref(outs), self._stream(ws))
+            _lib.check(self._lib.aesmc_affine_backward_collect(*args), "aesmc_affine_backward_collect")
+            if self.timer is not None:
+                self.timer.note("affine_backward_collect", (self._lib.aesmc_affine_backward_collect, args),
+                                records * 1024 * (8 if dtype == torch.float64 else 4), (ws, outs, gA, gC, gQ, gscales))
+        grads = [None, None, None, gA, None, gC, None, gQ, None, None, None, None]
+        for slot, s in ((9, scales[0]), (10, scales[1]), (11, scales[2])):
             if need[slot]:
                 grads[slot] = gscales[slot - 9].reshape(s.shape)
         return grads
+
 
     def affine_step_backward_unfused(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
                                      grad_lse=None, grad_x=None, grad_lw=None):

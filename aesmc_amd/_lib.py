@@ -47,6 +47,12 @@ class AffineLogweightGrads(ctypes.Structure):
         "grad_x_prev", "grad_x", "grad_loc_p", "grad_loc_g", "grad_loc_q", "grad_weight_p", "grad_weight_g",
         "grad_weight_q", "grad_scales", "grad_offset_p", "grad_offset_g", "grad_offset_q")]
 
+class AffineChain(ctypes.Structure):
+    """`aesmc_affine_chain` of include/aesmc_hip.h: how K14's weight gradients join those of the steps around it."""
+    _fields_ = [("carry", ctypes.c_void_p), ("carry_records", ctypes.c_int32), ("defer", ctypes.c_int32),
+                ("records", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/aesmc_hip.h one to one.
 SIGNATURES = {
     "aesmc_version": (_i32, []),
@@ -82,7 +88,9 @@ SIGNATURES = {
     "aesmc_affine_step_backward": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p] + [_vp] * 8 +
                                           [ctypes.POINTER(AffineLogweightGrads), _vp, _sz, _i64, _i64, _vp]),
     "aesmc_affine_step_backward_resampled": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p] + [_vp] * 10 +
-                                                    [ctypes.POINTER(AffineLogweightGrads), _vp, _sz, _vp, _i64, _i64, _vp]),
+                                                    [ctypes.POINTER(AffineLogweightGrads), _vp, _sz, _vp,
+                                                     ctypes.POINTER(AffineChain), _i64, _i64, _vp]),
+    "aesmc_affine_backward_collect": (_i32, [_i32, _vp, _i32, _i64, _i64, ctypes.POINTER(AffineLogweightGrads), _vp]),
     "aesmc_resample_step_ranges": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_normal_logweight": (_i32, [_i32, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp,
                                              _i64, _i64, _vp]),

@@ -495,15 +495,38 @@ class StepLink:
     gradient HERE and returns no gradient for x_t; step t's backward — which autograd runs later, x_t being its
     output — picks it up and sums each particle's children while it consumes them.  Sound as long as nothing else can
     ask autograd for the gradient of x_t itself: `infer` arranges this only when it hands the latents to nobody
-    (return_latents = return_original_latents = False, what `losses.get_loss` asks for)."""
-    __slots__ = ("deposit",)
+    (return_latents = return_original_latents = False, what `losses.get_loss` asks for).
 
-    def __init__(self):
+    The same hand-over carries the gradients of what the two steps SHARE: a time-homogeneous model passes the same A, C,
+    Q and scales to every step and autograd only wants the sum over the steps, so step t+1's backward leaves its sums
+    for them unfinished (`carry`: K14's per-workgroup records) and step t's launch starts from them — no finishing
+    launch and no accumulation per step, one of each per run of steps (`shared`: the parameters this link's step
+    received, what the next step compares its own with)."""
+    __slots__ = ("deposit", "carry", "shared")
+
+    def __init__(self, shared=None):
         self.deposit = None
+        self.carry = None
+        self.shared = shared
 
     def take(self):
         deposit, self.deposit = self.deposit, None
         return deposit
+
+    def take_carry(self):
+        carry, self.carry = self.carry, None
+        return carry
+
+
+def _same_parameter(a, b):
+    """Do two steps' operands stand for ONE parameter in autograd's eyes — the same tensor, or the same view of the
+    same base (x @ W.t() makes a new view object per call) — so that the sum of their gradients may reach either?"""
+    if a is b:
+        return True
+    if a is None or b is None or a._base is None or a._base is not b._base:
+        return False
+    return (a.shape == b.shape and a.stride() == b.stride() and a.storage_offset() == b.storage_offset() and
+            a.requires_grad == b.requires_grad and type(a.grad_fn) is type(b.grad_fn))
 
 
 class PendingStep:
@@ -572,7 +595,7 @@ class _AffineStep(torch.autograd.Function):
         # `links` = (this step's StepLink or None, the previous step's StepLink + children ranges or None)
         ctx.set_materialize_grads(False)      # an output nobody differentiated arrives as None, not as zeros
         ctx.lse_box = pending.box
-        ctx.own_link, ctx.parent_link = links
+        ctx.own_link, ctx.parent_link, ctx.defer_shared = links
         child_end = None if ctx.parent_link is None else ctx.parent_link[1]
         ctx.save_for_backward(lw, x_value, ancestors, child_end, *[t for t in operands if t is not None])
         ctx.present = [t is not None for t in operands]
@@ -592,13 +615,28 @@ class _AffineStep(torch.autograd.Function):
         k = _kernels.get()
         # what the NEXT step left for this one: the gradient of the rows it resampled from x_t, per child
         child = ctx.own_link.take() if ctx.own_link is not None else None
+        carry = ctx.own_link.take_carry() if ctx.own_link is not None else None
         if child is not None and ancestors is None:     # (this step did not go through ancestors itself: sum here)
             summed = k.gather_backward_ranges(child[0], child[1])
             grad_x, child = (summed if grad_x is None else grad_x + summed), None
+        # the parameters shared with the steps around: start from what the next step left, leave the sums to the step
+        # before (StepLink) — only this run's first step finishes them
+        chain = None
+        if ancestors is not None and (carry is not None or ctx.defer_shared):
+            chain = {"carry": carry, "defer": ctx.defer_shared}
+        elif carry is not None:      # (no launch of this step's can take them: finished on their own)
+            dx, dy = x_value.size(2), y_rows.size(1)
+            carried = k.affine_backward_collect(carry, x_value.dtype, x_value.device, dx, dy, need, (s_p, s_g, s_q))
         grads = k.affine_step_backward(
             x_prev, x_value, y_rows, (A, off_p), (C, off_g), (Q, off_q), (s_p, s_g, s_q), need, lw, lse,
             grad_lse=None if grad_lse is None else grad_lse.contiguous(), grad_x=grad_x, ancestors=ancestors,
-            child_grad=None if child is None else child[0], child_end=None if child is None else child[1])
+            child_grad=None if child is None else child[0], child_end=None if child is None else child[1], chain=chain)
+        if chain is None and carry is not None:
+            for slot, value in enumerate(carried):
+                if value is not None:
+                    grads[slot] = value if grads[slot] is None else grads[slot] + value
+        if chain is not None and chain["left"] is not None:
+            ctx.parent_link[0].carry = chain["left"]
         if ancestors is not None and grads[0] is not None:
             if ctx.parent_link is not None:
                 # the previous step's node sums these children into their ancestors itself (StepLink): no launch here,
@@ -610,6 +648,10 @@ class _AffineStep(torch.autograd.Function):
                 # indices are non-decreasing along k, so this is the atomic-free segmented sum
                 grads[0] = k.gather_backward(grads[0], ancestors, sorted_index=True)
         return (None, None, None, None, None) + tuple(grads)
+
+
+_SHARED_SLOTS = (3, 5, 7, 9, 10, 11)      # A, C, Q, s_p, s_g, s_q among a step's operands
+_CHAIN_SHARED = True                      # (test hook: False = every step finishes and returns its own sums)
 
 
 def affine_step(lw, operands, fold_gather_backward=False):
@@ -626,15 +668,20 @@ def affine_step(lw, operands, fold_gather_backward=False):
     elif isinstance(inputs[0], LazyParticles):
         inputs[0] = inputs[0].materialise()
     own_link = parent_link = None
+    defer_shared = False
     if fold_gather_backward:
-        own_link = StepLink()
+        shared = tuple(inputs[slot] for slot in _SHARED_SLOTS)
+        own_link = StepLink(shared)
         if ancestors is not None:
             previous = getattr(inputs[0], "_aesmc_step_link", None)      # x_{t-1} is the previous step's output
             child_end = getattr(ancestors, "_aesmc_child_end", None)
             if previous is not None and child_end is not None:
                 parent_link = (previous, child_end)
-    pending.carrier, x_t = _AffineStep.apply(lw, operands[1].detach(), pending, ancestors, (own_link, parent_link),
-                                             *inputs)
+                defer_shared = _CHAIN_SHARED and previous.shared is not None and torch.is_grad_enabled() and \
+                    any(t is not None and t.requires_grad for t in shared) and \
+                    all(_same_parameter(a, b) for a, b in zip(shared, previous.shared))
+    pending.carrier, x_t = _AffineStep.apply(lw, operands[1].detach(), pending, ancestors,
+                                             (own_link, parent_link, defer_shared), *inputs)
     if own_link is not None:
         x_t._aesmc_step_link = own_link
     return pending, x_t

@@ -164,14 +164,27 @@ __device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg
 __host__ __device__ __forceinline__ bool lg_single_row(int64_t n0, uint32_t np, uint32_t K) {
   return (uint32_t)(n0 % K) + np <= K;
 }
+// (`slot`: 4 x 16 values in LDS, the four wavefronts' sums of one term; lg_store_column_sums adds them at the tile's end)
 template <typename T>
-__device__ __forceinline__ void lg_flush_column_sums(typename Mfma<T>::Acc &acc, T *__restrict__ record, bool keep) {
+__device__ __forceinline__ void lg_flush_column_sums(typename Mfma<T>::Acc &acc, T *__restrict__ slot, bool keep) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((lane & 15) == 15) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (keep) record[wave * 16 + Mfma<T>::row(lane, r)] = acc[r];
+      if (keep) slot[wave * 16 + Mfma<T>::row(lane, r)] = acc[r];
       acc[r] = T(0);
+    }
+  }
+}
+// Behind the barrier that ends the tile: the tile's record of each wanted term, record[j] = the four wavefronts' sums
+// added in wavefront order (what the finishing launch used to add, from four times the bytes).
+template <typename T>
+__device__ __forceinline__ void lg_store_column_sums(const T *__restrict__ slots, T *__restrict__ records, int terms) {
+  if (threadIdx.x < 48) {
+    const int t = threadIdx.x >> 4, j = threadIdx.x & 15;
+    if ((terms >> t) & 1) {
+      const T *c = slots + t * 64 + j;
+      records[t * (kLgRowsMax * 16) + j] = ((c[0] + c[16]) + c[32]) + c[48];
     }
   }
 }
@@ -308,6 +321,10 @@ struct LgBackwardOut {
   const int32_t *child_end;
   int child_stage;   // a fourth LDS tile exists: the tile's children rows — one contiguous block — are staged through it
   int child_align;   // rows per 16 bytes' worth of alignment: a staged block starts at a multiple of this many rows
+  // step kernel only: the records an earlier launch with the same parameters left in ITS workspace (aesmc_affine_chain):
+  // workgroup w adds records w, w + grid, ... to its own, so the weights' gradients of a run of steps are finished once
+  const void *carry;
+  int carry_records;
 };
 
 constexpr int kLgChildLimit = 32;   // children a lane sums by itself; longer runs (a collapsed system) take the wavefront
@@ -887,7 +904,7 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     if (row_pass & 2) lg_row_sums<T>(tu, ly.rs, dy, np, k0_tile, K, scratch, rows + (tile * 3 + 1) * (kLgRowsMax * 16));
     lg_apply_loop<T, DP, PPL, kUnroll>(wn + DP * DP, tu, ay, dy, w);
     lg_outer_accumulate_own<T, PPL, ONES>(tu, ly.rs, tx, lx.rs, np, acc_c);
-    if (ONES) lg_flush_column_sums<T>(acc_c, rows + (tile * 3 + 1) * (kLgRowsMax * 16), column_sums && (row_terms & 2));
+    if (ONES) lg_flush_column_sums<T>(acc_c, scratch + 64, column_sums && (row_terms & 2));
     if (lx.rs != ly.rs) lg_lds_barrier();     // back to the latent's layout
     else lg_u_ready((row_pass & 2) != 0);
     // ---- transition term: u = g (x - loc_p) / s_p^2;  w -= u
@@ -911,7 +928,7 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     if (row_pass & 1) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 0) * (kLgRowsMax * 16));
     if (gxprev != nullptr) lg_apply_loop<T, DP, PPL, kUnroll>(wn, tu, au, dx, gprev);
     lg_outer_accumulate_own<T, PPL, ONES>(tu, lx.rs, tprev, lx.rs, np, acc_a);
-    if (ONES) lg_flush_column_sums<T>(acc_a, rows + (tile * 3 + 0) * (kLgRowsMax * 16), column_sums && (row_terms & 1));
+    if (ONES) lg_flush_column_sums<T>(acc_a, scratch, column_sums && (row_terms & 1));
     lg_u_ready((row_pass & 1) != 0);
     // ---- the draw: w reaches the proposal's parameters and x_{t-1};  grad s_q = g d / s_q + w . eps
     if (want_sq) {
@@ -933,7 +950,7 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     if (row_pass & 4) lg_row_sums<T>(tu, lx.rs, dx, np, k0_tile, K, scratch, rows + (tile * 3 + 2) * (kLgRowsMax * 16));
     if (gxprev != nullptr) lg_apply_loop<T, DP, PPL, kUnroll>(wn + 2 * DP * DP, tu, au, dx, gprev);
     lg_outer_accumulate_own<T, PPL, ONES>(tu, lx.rs, tprev, lx.rs, np, acc_q);
-    if (ONES) lg_flush_column_sums<T>(acc_q, rows + (tile * 3 + 2) * (kLgRowsMax * 16), column_sums && (row_terms & 4));
+    if (ONES) lg_flush_column_sums<T>(acc_q, scratch + 128, column_sums && (row_terms & 4));
     if constexpr (EXACT && (DP * sizeof(T)) % 8 == 0) {
       // rows of whole 8-byte pairs: each lane stores its own particles' rows (a wavefront's stores cover
       // one contiguous span) — no trip through the tile, no barriers around it
@@ -964,6 +981,10 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
       }
       lg_lds_barrier();
     }
+    // (scratch[0 .. 191] is written next by this tile's successor's flushes, several barriers on, or by wavefront 0's
+    //  own part of the closing records)
+    if (ONES && column_sums && row_terms != 0)
+      lg_store_column_sums<T>(scratch, rows + tile * 3 * (kLgRowsMax * 16), row_terms);
   }
   T *record = reinterpret_cast<T *>(out.ws) + (int64_t)blockIdx.x * 4 * kLgRecord;
   lg_outer_publish<T>(acc_a, scratch, record);
@@ -981,6 +1002,23 @@ __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : LG_STE
     const int m = threadIdx.x;
     record[3 * kLgRecord + m] = m < 3 ? ((scratch[m] + scratch[4 + m]) + scratch[8 + m]) + scratch[12 + m] : T(0);
   }
+  if (out.carry != nullptr && threadIdx.x < kLgRecord) {
+    // (each lane wrote the four elements it now reads: no barrier; the records carried are added in record order)
+    const T *carry = reinterpret_cast<const T *>(out.carry);
+    T own[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) own[m] = record[m * kLgRecord + threadIdx.x];
+    for (int r = blockIdx.x; r < out.carry_records; r += gridDim.x) {
+      const T *c = carry + (int64_t)r * 4 * kLgRecord + threadIdx.x;
+      T v[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) v[m] = c[m * kLgRecord];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) own[m] += v[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) record[m * kLgRecord + threadIdx.x] = own[m];
+  }
 }
 
 // Sums the workgroups' records in workgroup order: out[m][j * din + i] = sum_b ws[b][m][j * 16 + i].
@@ -991,12 +1029,13 @@ struct LgFinish {
   const void *row_ws;     // [tile][row_terms][kLgRowsMax][16], or nullptr
   void *goff[3];
   int32_t goff_d[3];
-  int32_t row_terms, matrices, row_blocks;    // records per tile; matrix blocks; row blocks per term (64 rows each)
-  int32_t column_sums;                        // single-row tiles hold four wavefront sums (lg_flush_column_sums)
+  int32_t row_terms, matrices, row_blocks;    // records per tile; matrix blocks; row blocks per term (kLgFinishRows rows each)
+  int32_t column_sums;                        // single-row tiles hold their sums in slot 0 (lg_store_column_sums)
   int64_t B, N;
   uint32_t K, TP;
 };
 constexpr int kLgFinishSplit = 4;      // workgroups per matrix of the finishing launch
+constexpr int kLgFinishRows = 64;      // batch rows per workgroup of its row part (16, four times the workgroups: 14 -> 18 us at c4)
 template <typename T>
 __global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ ws, int nblocks, int record, LgFinish f) {
   if ((int)blockIdx.x >= f.matrices * kLgFinishSplit) {
@@ -1004,27 +1043,35 @@ __global__ __launch_bounds__(1024) void lg_finish_kernel(const T *__restrict__ w
     const int r = (int)blockIdx.x - f.matrices * kLgFinishSplit, term = r / f.row_blocks;
     T *goff = reinterpret_cast<T *>(f.goff[term]);
     if (goff == nullptr) return;
-    const int64_t b = (int64_t)(r - term * f.row_blocks) * 64 + (threadIdx.x >> 4);
+    if (threadIdx.x >= 16 * kLgFinishRows) return;
+    const int64_t b = (int64_t)(r - term * f.row_blocks) * kLgFinishRows + (threadIdx.x >> 4);
     const uint32_t j = threadIdx.x & 15u, d = (uint32_t)f.goff_d[term];
     if (b >= f.B || j >= d) return;
     const T *rows = reinterpret_cast<const T *>(f.row_ws);
     const int64_t first = b * f.K / f.TP, last = ((b + 1) * f.K - 1) / f.TP;
-    // (eight tiles' records in flight, then added in tile order: the same association as one at a time)
+    // (sixteen tiles' records in flight, then added in tile order: the same association as one at a time)
     auto tile_value = [&](int64_t tile) {
       const int64_t n0 = tile * f.TP, b0 = n0 / f.K;
       const T *record = rows + (tile * f.row_terms + term) * (kLgRowsMax * 16);
       if (f.column_sums && lg_single_row(n0, (uint32_t)min((int64_t)f.TP, f.N - n0), f.K))
-        return ((record[j] + record[16 + j]) + record[32 + j]) + record[48 + j];     // the four wavefronts' sums
+        return record[j];     // (slot 0 whichever row it is: lg_store_column_sums)
       return record[(b - b0) * 16 + j];
     };
     T sum = T(0);
     int64_t tile = first;
-    for (; tile + 8 <= last + 1; tile += 8) {
-      T v[8];
+    for (; tile + 16 <= last + 1; tile += 16) {
+      T v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = tile_value(tile + u);
+      for (int u = 0; u < 16; ++u) v[u] = tile_value(tile + u);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) sum += v[u];
+      for (int u = 0; u < 16; ++u) sum += v[u];
+    }
+    for (; tile + 4 <= last + 1; tile += 4) {
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = tile_value(tile + u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sum += v[u];
     }
     for (; tile <= last; ++tile) sum += tile_value(tile);
     goff[b * d + j] = sum;
@@ -1102,7 +1149,7 @@ static int launch_particle_affine_backward(const void *g, const void *x, const a
     f.out[0] = gw; f.rows[0] = (int32_t)dout; f.cols[0] = (int32_t)din;
     f.matrices = gw != nullptr ? 1 : 0;
     f.row_ws = rows; f.goff[0] = goff; f.goff_d[0] = (int32_t)dout; f.row_terms = 1;
-    f.row_blocks = goff != nullptr ? (int32_t)((B + 63) / 64) : 0;
+    f.row_blocks = goff != nullptr ? (int32_t)((B + kLgFinishRows - 1) / kLgFinishRows) : 0;
     f.B = B; f.K = (uint32_t)K; f.TP = (uint32_t)tp;
     hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(f.matrices * kLgFinishSplit + f.row_blocks)), dim3(1024), 0, stream,
                        static_cast<const T *>(records), grid, kLgRecord, f);
@@ -1125,7 +1172,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
                                             int64_t K, hipStream_t stream, bool step = false,
                                             const void *gx_in = nullptr, const int64_t *anc_idx = nullptr,
                                             int32_t *flags = nullptr, const void *child_grad = nullptr,
-                                            const int32_t *child_end = nullptr) {
+                                            const int32_t *child_end = nullptr, aesmc_affine_chain *chain = nullptr) {
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
@@ -1164,7 +1211,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   LgBackwardOut out;
   out.gxprev = o->grad_x_prev; out.gx = o->grad_x; out.up = o->grad_loc_p; out.ug = o->grad_loc_g;
   out.uq = o->grad_loc_q; out.ws = ws; out.rows = row_ws; out.row_terms = row_terms;
-  out.gx_in = gx_in; out.want_scale_q = o->grad_scales != nullptr ? 1 : 0;
+  out.gx_in = gx_in; out.want_scale_q = (o->grad_scales != nullptr || (chain != nullptr && chain->defer > 1)) ? 1 : 0;
   out.gat = lg_gather(anc_idx, flags, (size_t)dx * sizeof(T));
   out.child_grad = child_grad;
   out.child_end = child_end;
@@ -1174,6 +1221,9 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
     while ((row_bytes * align) % 16 != 0) align *= 2;
     out.child_align = (int)align;
   }
+  out.carry = chain != nullptr ? chain->carry : nullptr;
+  out.carry_records = chain != nullptr && chain->carry != nullptr ? chain->carry_records : 0;
+  if (chain != nullptr && !step) return AESMC_ERR_UNSUPPORTED;
   if ((child_grad != nullptr) != (child_end != nullptr) || (child_grad != nullptr && !step)) return AESMC_ERR_UNSUPPORTED;
   if (anc_idx != nullptr && (!step || N > 0x7fffffffLL)) return AESMC_ERR_UNSUPPORTED;
 #define LG_BACKWARD_ARGS                                                                                            \
@@ -1195,15 +1245,35 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   f.out[1] = o->grad_weight_g; f.rows[1] = (int32_t)dy; f.cols[1] = (int32_t)dx;
   f.out[2] = o->grad_weight_q; f.rows[2] = (int32_t)dx; f.cols[2] = (int32_t)dx;
   f.out[3] = o->grad_scales; f.rows[3] = 1; f.cols[3] = 3;
-  f.matrices = 4;
+  // (a deferring call leaves the weights' and scales' sums as records in `ws` for the call that carries them on)
+  const bool defer = chain != nullptr && chain->defer != 0;
+  if (chain != nullptr) chain->records = grid;
+  f.matrices = defer ? 0 : 4;
   f.row_ws = row_ws; f.row_terms = 3;
   f.goff[0] = o->grad_offset_p; f.goff[1] = o->grad_offset_g; f.goff[2] = o->grad_offset_q;
   f.goff_d[0] = (int32_t)dx; f.goff_d[1] = (int32_t)dy; f.goff_d[2] = (int32_t)dx;
-  f.row_blocks = row_terms != 0 ? (int32_t)((B + 63) / 64) : 0;
+  f.row_blocks = row_terms != 0 ? (int32_t)((B + kLgFinishRows - 1) / kLgFinishRows) : 0;
   f.B = B; f.N = N; f.K = (uint32_t)K; f.TP = (uint32_t)(kLgBlock * ppl);
   f.column_sums = (step && dx == dp && dy == dp && dp < 16) ? 1 : 0;
-  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(4 * kLgFinishSplit + 3 * f.row_blocks)), dim3(1024), 0, stream,
+  const unsigned finishing = (unsigned)(f.matrices * kLgFinishSplit + 3 * f.row_blocks);
+  if (finishing == 0) return AESMC_OK;
+  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3(finishing), dim3(1024), 0, stream,
                      static_cast<const T *>(ws), grid, 4 * kLgRecord, f);   // one finishing launch for everything
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+// The finishing launch alone, for records a deferring call left behind and nobody carried on.
+template <typename T>
+static int launch_affine_collect(const void *ws, int records, int64_t dx, int64_t dy,
+                                 const aesmc_affine_logweight_grads *o, hipStream_t stream) {
+  LgFinish f = {};
+  f.out[0] = o->grad_weight_p; f.rows[0] = (int32_t)dx; f.cols[0] = (int32_t)dx;
+  f.out[1] = o->grad_weight_g; f.rows[1] = (int32_t)dy; f.cols[1] = (int32_t)dx;
+  f.out[2] = o->grad_weight_q; f.rows[2] = (int32_t)dx; f.cols[2] = (int32_t)dx;
+  f.out[3] = o->grad_scales; f.rows[3] = 1; f.cols[3] = 3;
+  f.matrices = 4;
+  hipLaunchKernelGGL(lg_finish_kernel<T>, dim3((unsigned)(4 * kLgFinishSplit)), dim3(1024), 0, stream,
+                     static_cast<const T *>(ws), records, 4 * kLgRecord, f);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
@@ -1257,7 +1327,7 @@ static int affine_step_backward_entry(
     const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
     const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
     const void *grad_x, const void *child_grad, const int32_t *child_end, const aesmc_affine_logweight_grads *out,
-    void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream);
+    void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream, aesmc_affine_chain *chain);
 
 extern "C" int aesmc_affine_step_backward(
     int dtype, const void *x_prev, const void *x, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
@@ -1267,7 +1337,7 @@ extern "C" int aesmc_affine_step_backward(
     void *stream) {
   return affine_step_backward_entry(dtype, x_prev, nullptr, nullptr, x, y, y_stride_b, transition, emission, proposal,
                                     scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, grad_x, nullptr, nullptr, out,
-                                    ws, ws_bytes, B, K, stream);
+                                    ws, ws_bytes, B, K, stream, nullptr);
 }
 
 extern "C" int aesmc_affine_step_backward_resampled(
@@ -1275,15 +1345,25 @@ extern "C" int aesmc_affine_step_backward_resampled(
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
     const void *grad_lse, const void *grad_lw, const void *grad_x, const void *child_grad, const int32_t *child_end,
-    const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int32_t *flags, int64_t B, int64_t K,
-    void *stream) {
+    const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int32_t *flags, aesmc_affine_chain *chain,
+    int64_t B, int64_t K, void *stream) {
   if (ancestors == nullptr || (((uintptr_t)ancestors) & 7u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
+  if (chain != nullptr) {
+    chain->records = 0;
+    if (chain->carry != nullptr && (chain->carry_records <= 0 || chain->carry_records > kLgMaxGrid || chain->carry == ws ||
+                                    !aligned16(chain->carry)))
+      return AESMC_ERR_INVALID_ARGUMENT;
+    if (chain->defer != 0 && out != nullptr &&
+        (out->grad_weight_p != nullptr || out->grad_weight_g != nullptr || out->grad_weight_q != nullptr ||
+         out->grad_scales != nullptr))
+      return AESMC_ERR_INVALID_ARGUMENT;      // a deferring call writes none of them
+  }
   if ((child_grad == nullptr) != (child_end == nullptr) || (((uintptr_t)child_end) & 3u) != 0 ||
       (child_grad != nullptr && child_grad == (out != nullptr ? out->grad_x_prev : nullptr)))
     return AESMC_ERR_INVALID_ARGUMENT;
   return affine_step_backward_entry(dtype, x_src, ancestors, flags, x, y, y_stride_b, transition, emission, proposal,
                                     scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, grad_x, child_grad, child_end,
-                                    out, ws, ws_bytes, B, K, stream);
+                                    out, ws, ws_bytes, B, K, stream, chain);
 }
 
 static int affine_step_backward_entry(
@@ -1292,7 +1372,7 @@ static int affine_step_backward_entry(
     const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
     const void *scale_q, const void *lw, const void *lse, const void *grad_lse, const void *grad_lw,
     const void *grad_x, const void *child_grad, const int32_t *child_end, const aesmc_affine_logweight_grads *out,
-    void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream) {
+    void *ws, size_t ws_bytes, int64_t B, int64_t K, void *stream, aesmc_affine_chain *chain) {
   if (out == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
   // the draw leaves no gradient for x_t and the location gradients have no meaning here
   if (out->grad_x != nullptr || out->grad_loc_p != nullptr || out->grad_loc_g != nullptr || out->grad_loc_q != nullptr)
@@ -1314,6 +1394,8 @@ static int affine_step_backward_entry(
   if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
     return AESMC_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((B == 0 || K == 0) && chain != nullptr && (chain->carry != nullptr || chain->defer != 0))
+    return AESMC_ERR_UNSUPPORTED;      // nothing to launch: the caller collects what it carries
   if (B == 0 || K == 0) {      // empty sums
     const size_t esz = dtype == AESMC_F64 ? 8 : 4;
     bool ok = true;
@@ -1327,11 +1409,22 @@ static int affine_step_backward_entry(
              ? launch_affine_logweight_backward<float>(x_prev, x, y, y_stride_b, transition, emission, proposal,
                                                        scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
                                                        ws_bytes, B, K, s, true, grad_x, ancestors, flags, child_grad,
-                                                       child_end)
+                                                       child_end, chain)
              : launch_affine_logweight_backward<double>(x_prev, x, y, y_stride_b, transition, emission, proposal,
                                                         scale_p, scale_g, scale_q, lw, lse, grad_lse, grad_lw, out, ws,
                                                         ws_bytes, B, K, s, true, grad_x, ancestors, flags, child_grad,
-                                                       child_end);
+                                                        child_end, chain);
+}
+
+extern "C" int aesmc_affine_backward_collect(int dtype, const void *ws, int32_t records, int64_t dx, int64_t dy,
+                                             const aesmc_affine_logweight_grads *out, void *stream) {
+  if (ws == nullptr || out == nullptr || records <= 0 || records > kLgMaxGrid || dx < 1 || dx > kLgMaxDim || dy < 1 ||
+      dy > kLgMaxDim || !aligned16(ws))
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32 && dtype != AESMC_F64) return AESMC_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AESMC_F32 ? launch_affine_collect<float>(ws, records, dx, dy, out, s)
+                            : launch_affine_collect<double>(ws, records, dx, dy, out, s);
 }
 
 

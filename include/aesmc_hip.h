@@ -465,14 +465,34 @@ int aesmc_affine_step_backward(
  * resampling step's children ranges (aesmc_resample_step_ranges).  The kernel then adds, to whatever `grad_x`
  * brings, the sum of each particle's children's rows (a lane adds its own particle's run in k order; what lies beyond
  * the first 32 children of a run — a collapsed particle system — is shared out over the wavefront, in a fixed order):
- * torch.gather's backward without its launch and without the [B,K,dx] round trip of the summed gradient. */
+ * torch.gather's backward without its launch and without the [B,K,dx] round trip of the summed gradient.
+ * `chain` (may be NULL): consecutive steps of a time-homogeneous model share A, C, Q and the scales, and autograd only
+ * ever wants the SUM of their gradients over the steps (aesmc/inference.py:60-135 calls the same callables every
+ * step).  A call with `chain->defer` non-zero leaves its sums as per-workgroup records in `ws` (grad_weight_* and
+ * grad_scales of `out` must be NULL; `chain->records` receives their count; defer = 2 where the scales' gradients are
+ * wanted in the end, which costs the proposal's location as a non-NULL grad_scales does) instead of finishing them; the next call
+ * names that workspace in `chain->carry` / `carry_records` and each of its workgroups starts from the records it is
+ * handed (record w, w + grid, ... in that order), so the run of steps is finished once, by its last call — or by
+ * aesmc_affine_backward_collect.  The row sums (offset gradients: per step) are finished by every call. */
+typedef struct {
+  const void *carry;      /* in: workspace of the call whose records this one continues, or NULL */
+  int32_t carry_records;  /* in: how many records it holds (what that call left in `records`) */
+  int32_t defer;          /* in: non-zero = leave this call's sums as records in `ws` (2: the scales' among them) */
+  int32_t records;        /* out: records this call left in `ws` */
+} aesmc_affine_chain;
 int aesmc_affine_step_backward_resampled(
     int dtype, const void *x_src, const int64_t *ancestors, const void *x, const void *y, int64_t y_stride_b,
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, const void *lw, const void *lse,
     const void *grad_lse, const void *grad_lw, const void *grad_x, const void *child_grad, const int32_t *child_end,
-    const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int32_t *flags, int64_t B, int64_t K,
-    void *stream);
+    const aesmc_affine_logweight_grads *out, void *ws, size_t ws_bytes, int32_t *flags, aesmc_affine_chain *chain,
+    int64_t B, int64_t K, void *stream);
+
+/* The finishing launch of K14 alone: grad_weight_p / _g / _q and grad_scales of `out` (each may be NULL) from the
+ * `records` records a deferring aesmc_affine_step_backward_resampled call left in `ws` — for a run of steps whose last
+ * call could not carry them on. */
+int aesmc_affine_backward_collect(int dtype, const void *ws, int32_t records, int64_t dx, int64_t dy,
+                                  const aesmc_affine_logweight_grads *out, void *stream);
 
 /* Noise — the float32 tensor `torch.empty(numel).normal_()` holds on this device for a generator at
  * (seed, offset): out[e], e < numel.  Replaces, inside a kernel or on its own, the `_standard_normal` draw of

@@ -48,6 +48,9 @@ class OracleKernels:
         out._aesmc_sorted = True
         return out
 
+    def affine_backward_collect(self, left, dtype, device, dx, dy, need, scales):
+        return list(left[0])
+
     def gather(self, src, idx):
         assert idx.size() == src.size()[:2]
         out, flags = kernel_oracle.gather(src.detach().numpy(), idx.numpy())
@@ -192,10 +195,28 @@ class OracleKernels:
         return out
 
     def affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
-                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None, child_grad=None, child_end=None):
+                             grad_lse=None, grad_x=None, grad_lw=None, ancestors=None, child_grad=None, child_end=None,
+                             chain=None):
         """K14's contract by PyTorch's autograd in float64: x is rebuilt as the proposal's draw
         loc_q(x_prev) + s_q eps with eps = (x - loc_q) / s_q held fixed, so every path through it is
-        differentiated; x's own slot stays None."""
+        differentiated; x's own slot stays None.  `chain`: the shared parameters' gradients are handed from call to
+        call (here: as the list of them) instead of being returned by every call."""
+        if chain is not None:
+            own = OracleKernels.affine_step_backward(self, x_prev, x, y_rows, transition, emission, proposal, scales, need,
+                                                     lw, lse, grad_lse=grad_lse, grad_x=grad_x, grad_lw=grad_lw,
+                                                     ancestors=ancestors, child_grad=child_grad, child_end=child_end)
+            shared = (3, 5, 7, 9, 10, 11)
+            if chain["carry"] is not None:
+                for slot in shared:
+                    carried = chain["carry"][0][slot]
+                    if carried is not None:
+                        own[slot] = carried if own[slot] is None else own[slot] + carried
+            chain["left"] = None
+            if chain["defer"]:
+                chain["left"] = ([own[slot] if slot in shared else None for slot in range(12)], 1)
+                for slot in shared:
+                    own[slot] = None
+            return own
         if child_grad is not None:      # the next step's per-child gradient: summed into its ancestors, then as grad_x
             summed = self.gather_backward_ranges(child_grad, child_end)
             grad_x = summed if grad_x is None else grad_x + summed

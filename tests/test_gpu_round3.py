@@ -849,3 +849,83 @@ def test_uniforms_read_from_the_pinned_block_are_the_uniforms_copied_to_the_devi
     assert torch.equal(a["log_marginal_likelihood"], b["log_marginal_likelihood"])
     for x, y in zip(a["ancestral_indices"] + a["latents"], b["ancestral_indices"] + b["latents"]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(3, 700, 10, 10), (2, 513, 5, 3), (5, 64, 16, 16), (300, 4096, 10, 10), (520, 2100, 8, 8),
+                                   (1024, 4096, 10, 10)])
+def test_steps_that_share_their_parameters_finish_their_gradients_once(kernels, hip_device, dtype, shape):
+    """aesmc_affine_chain: a deferring call writes no weight / scale gradient and leaves records; collected on their
+    own (aesmc_affine_backward_collect) they are bit for bit what the call gives when it finishes them itself; a
+    second call that carries them returns the two steps' sum (to rounding: the steps are added record by record
+    before the workgroups are, not after), reproducibly; the per-step outputs (the gradient of x_{t-1}'s rows, the
+    offsets' and y's) of a chained call are bit for bit the unchained call's."""
+    B, K, dx, dy = shape
+    if dtype == np.float64 and B * K > (1 << 21):
+        pytest.skip("the float32 case covers the full size")
+    names = ("x_prev", "x", "y", "A", "off_p", "C", "off_g", "Q", "off_q", "s_p", "s_g", "s_q")
+    shared = ("A", "C", "Q", "s_p", "s_g", "s_q")
+    need = [True] * 12
+    need[1] = False
+    steps = []
+    for step in range(2):
+        n, o = operands(B, K, dx, dy, dtype, hip_device, seed=3 * B + K + dx + 100 * step)
+        if step == 1:       # the same parameters as the step before, everything else its own
+            for name in shared + ("off_g",):
+                o[name] = steps[0]["o"][name]
+        idx = _ancestors(B, K, hip_device, seed=B + K + step, spread=2.0)
+        terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+        scales = (o["s_p"], o["s_g"], o["s_q"])
+        moved = kernels.gather(o["x_prev"], idx)
+        x = kernels.affine_rsample(moved, o["Q"], o["off_q"], o["eps"], o["s_q"])
+        lw = kernels.affine_logweight(moved, x, o["y"], *terms, scales)
+        _, lse = kernels.logweight_lse(lw, None, None, want_lw=False)
+        grad_lse = torch.from_numpy(np.random.RandomState(9 + step).randn(B).astype(dtype)).to(hip_device)
+        call = lambda chain, o=o, x=x, terms=terms, scales=scales, lw=lw, lse=lse, grad_lse=grad_lse, idx=idx: \
+            kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=grad_lse,
+                                         ancestors=idx, chain=chain)
+        steps.append({"o": o, "call": call, "alone": call(None)})
+    later, earlier = steps[1], steps[0]      # backward order: the later step runs first and defers
+    chain = {"carry": None, "defer": True}
+    deferred = later["call"](chain)
+    left = chain["left"]
+    if left is None:
+        pytest.skip("K14 declines the shape: nothing is deferred (the unfused route returns every gradient)")
+    assert left[1] >= 1
+    for name, got, alone in zip(names, deferred, later["alone"]):
+        if name in shared:
+            assert got is None, name
+        elif alone is not None:
+            assert torch.equal(got, alone), name
+    collected = kernels.affine_backward_collect(left, deferred[0].dtype, hip_device, dx, dy, need,
+                                                (later["o"]["s_p"], later["o"]["s_g"], later["o"]["s_q"]))
+    for name, got, alone in zip(names, collected, later["alone"]):
+        if name in shared:
+            assert torch.equal(got, alone), (name, "collected")
+    results = []
+    for _ in range(2):
+        chain = {"carry": left, "defer": False}
+        results.append(earlier["call"](chain))
+        assert chain["left"] is None
+    tolerance = 2e-5 if dtype == np.float32 else 1e-12
+    for name, got, again, a, b in zip(names, results[0], results[1], earlier["alone"], later["alone"]):
+        if name == "x" or a is None:
+            continue
+        assert torch.equal(got, again), (name, "not reproducible")
+        if name in shared:
+            want = a.double() + b.double()
+            # (sums of B K terms of either sign: the bound is on the terms' size, which the sum of the two results' does not show)
+            scale = max(1.0, float(want.abs().max()), float(a.abs().max()), float(b.abs().max())) * np.sqrt(B * K / 4096.0 + 1.0)
+            assert float((got.double() - want).abs().max()) <= tolerance * scale, name
+        else:
+            assert torch.equal(got, a), name
+    # carrying AND deferring (a step in the middle of a run): records again, which collect to the same sums
+    chain = {"carry": left, "defer": True}
+    middle = earlier["call"](chain)
+    assert all(middle[names.index(name)] is None for name in shared)
+    both = kernels.affine_backward_collect(chain["left"], deferred[0].dtype, hip_device, dx, dy, need,
+                                           (earlier["o"]["s_p"], earlier["o"]["s_g"], earlier["o"]["s_q"]))
+    for name, got, want in zip(names, both, results[0]):
+        if name in shared:
+            assert torch.equal(got, want), (name, "carried and deferred")
+    assert kernels.read_flags(hip_device) == 0

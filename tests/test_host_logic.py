@@ -899,3 +899,48 @@ def test_linked_step_nodes_give_the_gradients_of_unlinked_ones(oracle_backend):
     for name in grads_a:
         scale = max(float(grads_a[name].abs().max()), 1e-30)
         assert float((grads_a[name] - grads_b[name]).abs().max()) <= 1e-10 * scale, name
+
+
+def test_shared_parameters_are_finished_once_per_run_of_steps(oracle_backend):
+    """Host logic of the chained weight gradients (`_ops.StepLink.carry`): steps that receive the same A, C, Q and
+    scales leave their sums to the step before, the run's first step returns the total — the same gradients as when
+    every step returns its own; a model whose steps do NOT share a parameter keeps every step's own."""
+    from aesmc_amd import _kernels, _ops
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    T, results = 6, {}
+    for chained in (False, True):
+        seen = []
+        real = provider.affine_step_backward
+
+        def spy(*args, **kwargs):
+            chain = kwargs.get("chain")
+            seen.append(None if chain is None else (chain["carry"] is not None, bool(chain["defer"])))
+            return real(*args, **kwargs)
+
+        provider.affine_step_backward = spy
+        previous, _ops._CHAIN_SHARED = _ops._CHAIN_SHARED, chained
+        try:
+            model = LgssmNd(3, dtype=torch.float64, affine=True).tune_proposal()
+            observations = model.simulate(T, 4, seed=1)
+            torch.manual_seed(5)
+            np.random.seed(5)
+            loss = losses.get_loss(observations, 48, "aesmc", model.initial, model.transition, model.emission,
+                                   model.proposal)
+            loss.backward()
+            results[chained] = ({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, list(seen))
+        finally:
+            provider.affine_step_backward, _ops._CHAIN_SHARED = real, previous
+    (plain, seen_plain), (chained, seen_chained) = results[False], results[True]
+    assert seen_plain == [None] * (T - 1)
+    # backward order: the last step defers, the middle ones carry and defer, the first carries and finishes
+    assert seen_chained == [(False, True)] + [(True, True)] * (T - 3) + [(True, False)]
+    assert sorted(plain) == sorted(chained) and plain
+    for name in plain:
+        scale = max(float(plain[name].abs().max()), 1e-30)
+        assert float((plain[name] - chained[name]).abs().max()) <= 1e-10 * scale, name
+    # two tensors that only LOOK alike are two parameters
+    a, b = torch.zeros(3, 3, requires_grad=True), torch.zeros(3, 3, requires_grad=True)
+    assert _ops._same_parameter(a, a) and not _ops._same_parameter(a, b)
+    assert _ops._same_parameter(a.t(), a.t()) and not _ops._same_parameter(a.t(), b.t())
+    assert not _ops._same_parameter(a.t(), a.detach().t())
