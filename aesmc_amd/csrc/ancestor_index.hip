@@ -311,8 +311,11 @@ __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *
 // (Holding the kernel to 64 registers — four 512-lane workgroups per CU instead of three, so that
 // 1024 batch rows are resident at once — was measured and bought nothing: 78.4 vs 77.7 us at B=1024
 // K=4096, with a 20-byte spill.)
-template <typename T, int C>
-__global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
+// PAYLOAD = false: the instantiation without the tail (K2 alone, what a step whose propagation kernel fetches the rows
+// itself launches).  Without the copy's chunks in flight it is held to 64 registers: eight wavefronts per SIMD, so four
+// 512-lane workgroups per CU and 1024 batch rows resident at once instead of 768 and a second round.
+template <typename T, int C, bool PAYLOAD>
+__global__ __launch_bounds__(kMaxThreads, (PAYLOAD || C > 8) ? 1 : 8) void ancestor_index_inv_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
     int32_t *flags, int K, T *__restrict__ out_lse, StepPayload payload, int B, int parts,
     int32_t *__restrict__ out_child_end) {
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
           idx[j0 + i] = (int64_t)K;
           if (out_child_end != nullptr) out_child_end[row * (int64_t)K + j0 + i] = 0;     // nobody has children
         }
-    if (payload.src == nullptr) return;
+    if (!PAYLOAD || payload.src == nullptr) return;
     // the unfused route would clamp the out-of-range index K to K - 1 in K3: same bytes here
     for (int k = tid; k < nt * C; k += nt) marker[k] = K - 1;
     __syncthreads();
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(kMaxThreads) void ancestor_index_inv_kernel(
     for (int i = 0; i < C; ++i)
       if (j0 + i < K) idx[j0 + i] = (int64_t)best[i];
   }
-  if (payload.src == nullptr) return;
+  if (!PAYLOAD || payload.src == nullptr) return;
 
   // ---- fused step: the payload rows follow their ancestors ------------------------------------
   // Every lane read its marker slots before the last barrier, so they can now hold the indices.
@@ -619,15 +622,21 @@ static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t 
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return AESMC_ERR_LAUNCH;
   if (!attr_set[device]) {
-    if (hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C>,
+    if (hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return AESMC_ERR_LAUNCH;
     attr_set[device] = true;
   }
   int parts = pick_parts(B, nt, payload.src != nullptr);
   while (parts > 1 && (nt % parts != 0 || B * parts > 0x7fffffffLL)) parts /= 2;
-  hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
-                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts, child_end);
+  if (payload.src != nullptr)
+    hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C, true>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
+                       (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts, child_end);
+  else
+    hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C, false>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
+                       (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts, child_end);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
