@@ -9,7 +9,8 @@ gfx950 — the factor is measured, not assumed).
 Usage: python tools/pmc_workload.py <workload> <proposal> [timesteps]
 Dispatch order (resample_gather_kernel): 3 calibration launches.  Then `timesteps` steps of get_loss:
 timesteps - 1 launches of ancestor_index_inv_kernel (K2; with the newest latent as its payload where the
-model reads the resampled values) and of the propagation kernel (K16 / K15 / K9 + K10)."""
+model reads the resampled values) and of the propagation kernel (K16 / K15 / K9 + K10), then the backward:
+timesteps - 1 launches of affine_step_backward_kernel (K14)."""
 import os
 import sys
 
@@ -42,6 +43,8 @@ def main(workload, proposal, timesteps=6):
     # children ranges the backward uses)
     loss = aesmc_amd.losses.get_loss(observations, K, "aesmc", model.initial, model.transition, model.emission,
                                      model.proposal)
+    if os.environ.get("AESMC_PMC_BACKWARD", "1") != "0":
+        loss.backward()      # K14 per timestep (the middle ones with the next step's children folded in)
     torch.cuda.synchronize()
     print("workload {} proposal {} B={} K={} d={}: loss {:.4f} over {} timesteps".format(
         workload, proposal, B, K, dim, float(loss), timesteps))

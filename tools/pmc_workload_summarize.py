@@ -22,7 +22,8 @@ KERNELS = {"resample_step": "ancestor_index_inv_kernel", "resample_gather": "res
            "affine_normal_propagate": "affine_logweight_kernel",      # K15 = K10's kernel in DRAW mode: it also writes x_t
            "affine_normal_propagate_drawn": "affine_propagate_noise_kernel",      # K16
            "affine_normal_propagate_resampled": "affine_logweight_kernel",      # K15 fetching x_{t-1} through the ancestors
-           "philox_normal_fill": "philox_normal_fill_kernel"}
+           "philox_normal_fill": "philox_normal_fill_kernel",
+           "affine_step_backward_resampled": "affine_step_backward_kernel"}      # K14 (pmc_workload.py with a backward)
 
 
 def per_dispatch(path, counter, kernel):
@@ -49,11 +50,16 @@ def main(workload, proposal, fetch_csv, write_csv, out_json):
                    "affine_normal_rsample": B * K * 12 * dim, "affine_normal_logweight": B * K * (8 * dim + 4),
                    "affine_normal_propagate": B * K * (12 * dim + 4),
                    "affine_normal_propagate_drawn": B * K * (8 * dim + 12),      # indices, surviving rows in; x_t, lw out
-                   "affine_normal_propagate_resampled": B * K * (12 * dim + 12), "philox_normal_fill": B * K * 4 * dim}
+                   "affine_normal_propagate_resampled": B * K * (12 * dim + 12), "philox_normal_fill": B * K * 4 * dim,
+                   # K14 with the children folded in: ancestors, x_{t-1} rows, x_t, lw, the next step's per-child gradient and
+                   # ranges in; the gradient of the resampled rows out
+                   "affine_step_backward_resampled": B * K * (16 * dim + 16)}
     for key, kernel in KERNELS.items():
         skip = 3 if key == "resample_gather" else 0
         fetch = per_dispatch(fetch_csv, "FETCH_SIZE", kernel)[skip:]
         write = per_dispatch(write_csv, "WRITE_SIZE", kernel)[skip:]
+        if key == "affine_step_backward_resampled":      # (backward order: the last timestep's launch has no children to fold)
+            fetch, write = fetch[1:], write[1:]
         n = min(len(fetch), len(write))
         if n == 0:
             continue
