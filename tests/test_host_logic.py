@@ -944,3 +944,60 @@ def test_shared_parameters_are_finished_once_per_run_of_steps(oracle_backend):
     assert _ops._same_parameter(a, a) and not _ops._same_parameter(a, b)
     assert _ops._same_parameter(a.t(), a.t()) and not _ops._same_parameter(a.t(), b.t())
     assert not _ops._same_parameter(a.t(), a.detach().t())
+
+
+def test_steps_with_their_own_parameters_keep_their_own_gradients(oracle_backend):
+    """A time-inhomogeneous model (a transition matrix per timestep): consecutive steps share C, Q and the scales but
+    not A, so no step may leave its sums to its neighbour — every A_t gets its own gradient, equal to the unlinked
+    run's; two steps in the middle that DO share every parameter chain between themselves only."""
+    from aesmc_amd import _kernels, _ops
+    from aesmc_amd.testing.models import LgssmNd
+
+    class PerStep(LgssmNd):
+        def __init__(self, T, shared_pair):
+            super().__init__(3, dtype=torch.float64, affine=True)
+            mats = [torch.nn.Parameter(self.A.detach().clone() * (1.0 - 0.01 * t)) for t in range(T)]
+            if shared_pair:
+                mats[3] = mats[2]
+            self.As = torch.nn.ParameterList(mats)
+
+        def transition(self, previous_latents=None, time=None, previous_observations=None):
+            return self._tag(self._affine_normal(previous_latents[-1], self.As[time], self.transition_scale),
+                             "FULLY_EXPANDED")
+
+    provider = _kernels.get()
+    T = 6
+    for shared_pair in (False, True):
+        results = {}
+        for fold in (False, True):
+            seen = []
+            real = provider.affine_step_backward
+
+            def spy(*args, **kwargs):
+                chain = kwargs.get("chain")
+                seen.append(None if chain is None else (chain["carry"] is not None, bool(chain["defer"])))
+                return real(*args, **kwargs)
+
+            provider.affine_step_backward = spy
+            try:
+                torch.manual_seed(0)
+                model = PerStep(T, shared_pair).tune_proposal()
+                observations = model.simulate(T, 4, seed=1)
+                torch.manual_seed(5)
+                np.random.seed(5)
+                with inference.fold_gather_backward(fold):
+                    loss = losses.get_loss(observations, 48, "aesmc", model.initial, model.transition, model.emission,
+                                           model.proposal)
+                    loss.backward()
+            finally:
+                provider.affine_step_backward = real
+            results[fold] = ({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, seen)
+        (plain, _), (linked, seen) = results[False], results[True]
+        if shared_pair:      # backward order t = 5, 4, 3, 2, 1: only step 3 may leave its sums (to step 2)
+            assert seen == [None, None, (False, True), (True, False), None]
+        else:
+            assert seen == [None] * (T - 1)
+        assert sorted(plain) == sorted(linked) and any(name.startswith("As.") for name in plain)
+        for name in plain:
+            scale = max(float(plain[name].abs().max()), 1e-30)
+            assert float((plain[name] - linked[name]).abs().max()) <= 1e-10 * scale, name
