@@ -204,6 +204,36 @@ def _as_offset(affine, other):
     return None
 
 
+def reaches_by_views(view, base, hops):
+    """Does autograd take `view`'s gradient to `base` through exactly `hops` single-input view nodes (or is there no
+    autograd between them at all)?  A view cut off from its base (made under no_grad, or of a detached alias) fails."""
+    if not base.requires_grad and not view.requires_grad:
+        return True
+    if base.requires_grad != view.requires_grad:
+        return False
+    fn = view.grad_fn
+    for _ in range(hops):
+        if fn is None or len(fn.next_functions) != 1:
+            return False
+        fn = fn.next_functions[0][0]
+    if fn is None:
+        return False
+    return fn is base.grad_fn if base.grad_fn is not None else getattr(fn, "variable", None) is base
+
+
+def _own_tensor(view, hops=2):
+    """The tensor a view is ALL of, when it is: `x @ W.t()` hands this module `W.t()`, a new view object per call, and
+    `W.t().t()` is W itself — the same storage, geometry and autograd identity (the two transposes' backward is the
+    identity).  The model's own parameter object is what the per-step caches and the chained weight gradients
+    (`_ops.StepLink`) recognise from one timestep to the next."""
+    base = view._base
+    if base is not None and type(base) in (torch.Tensor, torch.nn.Parameter) and base.shape == view.shape and \
+            base.stride() == view.stride() and base.storage_offset() == view.storage_offset() and \
+            base.dtype == view.dtype and reaches_by_views(view, base, hops):
+        return base
+    return view
+
+
 _EYES = {}
 
 
@@ -223,9 +253,10 @@ def _record(func, args, kwargs):
         return NotImplemented
     if name in ("matmul", "__matmul__") and len(args) == 2:
         x, w = args
-        if _is_particles(x) and _plain(w) and w.dim() == 2 and _small_map(w.t(), x._lazy_shape[2]) and \
-                w.dtype == x.dtype and w.device == x.device:
-            return LazyAffine(x, w.t())
+        if _is_particles(x) and _plain(w) and w.dim() == 2 and w.dtype == x.dtype and w.device == x.device:
+            weight = _own_tensor(w.t())
+            if _small_map(weight, x._lazy_shape[2]):
+                return LazyAffine(x, weight)
         return NotImplemented
     if name == "linear":
         x = args[0] if args else kwargs.get("input")

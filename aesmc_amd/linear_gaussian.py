@@ -83,7 +83,14 @@ def affine_terms(distribution):
     if scale.numel() != 1:
         if any(stride != 0 for stride in scale.stride()):      # one value, expanded by Normal's broadcast_all?
             return None
-        scale = scale[(0,) * scale.dim()]
+        # the one-value tensor that was expanded, where it is at hand (the model's own buffer or parameter: the same
+        # object every timestep, which the per-step caches recognise; expand's backward is the sum the kernels form)
+        base = scale._base
+        if base is not None and base.numel() == 1 and base.dtype == scale.dtype and \
+                type(base) in (torch.Tensor, torch.nn.Parameter) and _lazy.reaches_by_views(scale, base, 1):
+            scale = base
+        else:
+            scale = scale[(0,) * scale.dim()]
     terms = _Terms(loc.source, loc.weight, loc.offset, scale, distribution._validate_args)
     distribution.__dict__["_aesmc_terms"] = terms
     return terms

@@ -1001,3 +1001,33 @@ def test_steps_with_their_own_parameters_keep_their_own_gradients(oracle_backend
         for name in plain:
             scale = max(float(plain[name].abs().max()), 1e-30)
             assert float((plain[name] - linked[name]).abs().max()) <= 1e-10 * scale, name
+
+
+def test_recorded_locations_name_the_models_own_tensors():
+    """`x @ W.t()` reaches the recording as a new view per call; what is kept is W itself when the view is all of it
+    (the same object every timestep: the per-step caches and the chained weight gradients compare by identity) — and a
+    view that is NOT all of W, or that differs from it in autograd's eyes, stays the view."""
+    from aesmc_amd import _lazy
+    W = torch.nn.Parameter(torch.randn(3, 3))
+    assert _lazy._own_tensor(W.t().t()) is W
+    assert _lazy._own_tensor(W.t()) is not W and _lazy._own_tensor(W[:2].t().t()) is not W
+    with torch.no_grad():
+        cut = W.t()
+    assert _lazy._own_tensor(cut.t()) is not W          # no gradient may reach W through it
+    plain = torch.randn(3, 3)
+    assert _lazy._own_tensor(plain) is plain
+    # an expanded one-value scale: the value's own tensor
+    from aesmc_amd import linear_gaussian
+    scale = torch.tensor(0.7)
+    x = _lazy.LazyResampled(torch.randn(2, 5, 3), torch.zeros(2, 5, dtype=torch.int64))
+    dist = torch.distributions.Normal(x @ W.t(), scale, validate_args=False)
+    terms = linear_gaussian.affine_terms(dist)
+    assert terms is not None and terms.weight is W and terms.scale_param is scale
+    learned = torch.nn.Parameter(torch.tensor(0.7))
+    terms = linear_gaussian.affine_terms(torch.distributions.Normal(x @ W.t(), learned, validate_args=False))
+    assert terms.scale_param is learned
+    with torch.no_grad():
+        cut_off = learned.expand(2, 5, 3)
+    fake = torch.distributions.Normal(x @ W.t(), 1.0, validate_args=False)
+    fake.scale = cut_off             # an expanded view autograd does not connect to the parameter: stays a view
+    assert linear_gaussian.affine_terms(fake).scale_param is not learned

@@ -1,7 +1,8 @@
 """Host cost of one timestep of the eager ELBO loop: the headline model at a size whose kernels are
 negligible (B=8, K=64), timed and profiled (cProfile) on the GPU box.
 
-    python tools/host_overhead.py [--grad 1]
+    python tools/host_overhead.py [--grad 1] [--affine 0]      (--affine 0: callables in the reference's own style,
+                                                                 Normal(x @ W.t() + c, s), recorded on the lazy latents)
 """
 import argparse
 import cProfile
@@ -23,10 +24,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grad", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--affine", type=int, default=1)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     T = 100
-    model = LgssmNd(10, dtype=torch.float32, affine=True, validate_args=False).tune_proposal().to(dev)
+    model = LgssmNd(10, dtype=torch.float32, affine=bool(args.affine), validate_args=False).tune_proposal().to(dev)
     observations = model.simulate(T, 8, seed=1)
     np.random.seed(0)
     torch.manual_seed(0)
