@@ -738,6 +738,40 @@ class HipKernels:
                 self.timer.note("normal_rsample", (self._lib.aesmc_normal_rsample, args), nbytes,
                                 (eps, loc, scale, out, views))
         return out
+
+    # Below this many elements the noise launch + K6 pair is as fast (both are launch-latency bound) and the drawn
+    # kernel's 4-byte accesses buy nothing.
+    RSAMPLE_DRAWN_MIN_ELEMENTS = int(__import__("os").environ.get("AESMC_RSAMPLE_DRAWN_MIN", str(1 << 18)))
+
+    def normal_rsample_drawn(self, noise, loc, scale, shape):
+        """K6 with the noise formed in the launch: loc + n * scale -> dense float32 [B,K,*] of `shape`, n being the
+        tensor `torch.empty(shape).normal_()` would have held for the reservation `noise` (an `_philox.NoiseStream`);
+        loc and scale are views already expanded to `shape`.  None where the launch does not apply (the caller draws
+        the noise with `philox_normal` and takes `normal_rsample`)."""
+        if loc.dtype != torch.float32 or len(shape) < 2:
+            return None
+        numel = 1
+        for extent in shape:
+            numel *= int(extent)
+        if numel < self.RSAMPLE_DRAWN_MIN_ELEMENTS or numel >= (1 << 32) or numel != noise.numel:
+            return None
+        (loc, sm, D), (scale, ss, _) = [self._view3(t) for t in (loc, scale)]
+        B, K = int(shape[0]), int(shape[1])
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=loc.device)
+        with _on_device(loc.device):
+            views = [_lib.View3(_ptr(t), *st) for t, st in ((loc, sm), (scale, ss))]
+            args = (_DTYPE_TAG[torch.float32], ctypes.byref(views[0]), ctypes.byref(views[1]), _ptr(out), B, K, D,
+                    noise.seed, noise.offset, noise.threads, 0, _ptr(noise.state), self._stream(loc))
+            status = self._lib.aesmc_normal_rsample_drawn(*args)
+            if status == 2:
+                return None
+            _lib.check(status, "aesmc_normal_rsample_drawn")
+            if self.timer is not None:
+                nbytes = self._unique_bytes(loc) + self._unique_bytes(scale) + 4 * numel
+                self.timer.note("normal_rsample_drawn", (self._lib.aesmc_normal_rsample_drawn, args), nbytes,
+                                (loc, scale, out, views))
+        return out
+
     # ---- K8 / K9 / K10: linear-Gaussian particle propagation -----------------------------------
     @property
     def affine_max_dim(self):

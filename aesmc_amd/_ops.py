@@ -238,6 +238,35 @@ class _NormalRsample(torch.autograd.Function):
         return None, grad_loc, grad_scale
 
 
+class _NormalRsampleDrawn(torch.autograd.Function):
+    """draw = loc + n * scale with the noise n formed in the launch (K6 drawn); only for a scale that needs no
+    gradient (its gradient is grad * n, and n is not kept)."""
+
+    @staticmethod
+    def forward(ctx, noise, loc, scale, shape):
+        out = _kernels.get().normal_rsample_drawn(noise, loc, scale, shape)
+        if out is None:
+            raise _Declined()
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return None, grad, None, None
+
+
+def normal_rsample_drawn(noise, loc, scale, shape):
+    """K6 with the noise of the reservation `noise` formed in the launch, or None where that launch does not apply
+    (nothing has been launched then: the caller materialises the noise)."""
+    if torch.is_grad_enabled() and scale.requires_grad:
+        return None
+    if torch.is_grad_enabled() and loc.requires_grad:
+        try:
+            return _NormalRsampleDrawn.apply(noise, loc, scale.detach(), shape)
+        except _Declined:
+            return None
+    return _kernels.get().normal_rsample_drawn(noise, loc.detach(), scale.detach(), shape)
+
+
 def normal_rsample(eps, loc, scale):
     """Reparameterised Normal draw from standard-normal noise `eps` [B,K,*] (kernel K6)."""
     if torch.is_grad_enabled() and (loc.requires_grad or scale.requires_grad):

@@ -14,6 +14,7 @@
 // which every later consumer would read with a stride of B rows; the draw is instead written
 // straight into [B,K,...] order through an LDS tile, so the time-0 latent is dense from the start.
 #include "common.hpp"
+#include "philox_normal.hpp"
 
 namespace aesmc {
 
@@ -205,7 +206,78 @@ static int launch_rsample(const aesmc_view3 &eps_view, const aesmc_view3 &loc, c
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
+// K6 with the NOISE formed in the launch (philox_normal.hpp): thread t of the G that ATen's `normal_` would have
+// launched forms, trip by trip, the four normals that call hands the elements t + G (4 c + i), and leaves
+// loc + n * scale there — the noise tensor is neither written nor read.  A wavefront's lanes hold consecutive
+// elements (4-byte accesses, contiguous across the wavefront); an element's (b, k, j) advance by constants from one
+// normal to the next, so the strided views of loc and scale cost no division per element.
+template <bool FUSED>
+__global__ __launch_bounds__(kRsBlock) void normal_rsample_drawn_kernel(
+    const float *__restrict__ loc, const float *__restrict__ scale, float *__restrict__ out, uint64_t n, uint32_t K,
+    uint32_t D, RsStrides sm, RsStrides ss, PhiloxStream stream) {
+  const PhiloxStream s = philox_resolve(stream);
+  const uint32_t t = blockIdx.x * (uint32_t)kRsBlock + threadIdx.x;
+  const uint64_t G = s.threads;
+  if (t >= G) return;
+  const uint32_t step_row = (uint32_t)(G / D), dj = (uint32_t)(G - (uint64_t)step_row * D);
+  const uint32_t db = step_row / K, dk = step_row - db * K;
+  const uint32_t row0 = t / D;
+  uint32_t j = t - row0 * D, b = row0 / K, k = row0 - b * K;
+  uint64_t e = t;
+  for (uint32_t c = 0; e < n; ++c) {
+    const float4 four = philox_normal4<FUSED>(s, t, c);
+    const float normal[4] = {four.x, four.y, four.z, four.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (e < n) {
+        const float mu = loc[(int64_t)b * sm.b + (int64_t)k * sm.k + (int64_t)j * sm.d];
+        const float sigma = scale[(int64_t)b * ss.b + (int64_t)k * ss.k + (int64_t)j * ss.d];
+        out[e] = mu + normal[i] * sigma;
+      }
+      e += G;
+      j += dj;
+      k += dk;
+      b += db;
+      if (j >= D) {
+        j -= D;
+        ++k;
+      }
+      if (k >= K) {
+        k -= K;
+        ++b;
+      }
+    }
+  }
+}
+
 }  // namespace aesmc
+
+extern "C" int aesmc_normal_rsample_drawn(int dtype, const aesmc_view3 *loc, const aesmc_view3 *scale, void *out,
+                                          int64_t B, int64_t K, int64_t D, uint64_t seed, uint64_t offset,
+                                          int64_t threads, int variant, const uint64_t *rng_state, void *stream) {
+  using namespace aesmc;
+  if (!loc || !scale || !out || !loc->ptr || !scale->ptr || B < 0 || K < 0 || D < 0 || threads <= 0 ||
+      (threads % 256) != 0 || threads > 0x7fffffffLL || (offset & 3u) != 0 || (((uintptr_t)rng_state) & 7u) != 0)
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (dtype != AESMC_F32) return dtype == AESMC_F64 ? AESMC_ERR_UNSUPPORTED : AESMC_ERR_INVALID_ARGUMENT;
+  if (B == 0 || K == 0 || D == 0) return AESMC_OK;
+  if (K >= (1ll << 31) || D >= (1ll << 31) || B >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
+  const uint64_t n = (uint64_t)B * (uint64_t)K * (uint64_t)D;
+  if (n >= (1ull << 32)) return AESMC_ERR_UNSUPPORTED;
+  const PhiloxStream ps = philox_stream(seed, offset, threads, rng_state);
+  const RsStrides sm{loc->stride_b, loc->stride_k, loc->stride_d}, ss{scale->stride_b, scale->stride_k, scale->stride_d};
+  const dim3 grid((unsigned)(threads / 256));
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (variant == 0)
+    hipLaunchKernelGGL(normal_rsample_drawn_kernel<true>, grid, dim3(kRsBlock), 0, hs, static_cast<const float *>(loc->ptr),
+                       static_cast<const float *>(scale->ptr), static_cast<float *>(out), n, (uint32_t)K, (uint32_t)D, sm,
+                       ss, ps);
+  else
+    hipLaunchKernelGGL(normal_rsample_drawn_kernel<false>, grid, dim3(kRsBlock), 0, hs, static_cast<const float *>(loc->ptr),
+                       static_cast<const float *>(scale->ptr), static_cast<float *>(out), n, (uint32_t)K, (uint32_t)D, sm,
+                       ss, ps);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
 
 extern "C" int aesmc_normal_rsample(int dtype, const aesmc_view3 *eps, const aesmc_view3 *loc,
                                     const aesmc_view3 *scale, void *out, int64_t B, int64_t K, int64_t D,

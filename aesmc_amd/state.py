@@ -422,11 +422,22 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
     shape = base._extended_shape(torch.Size(sample_shape))
     if len(shape) < 2:
         return None
-    eps = _standard_normal(shape, dtype=loc.dtype, device=loc.device)
     if loc.shape != shape:
         loc = loc.expand(shape)
     if scale.shape != shape:
         scale = scale.expand(shape)
+    if not swap_leading_dims and loc.dtype == torch.float32 and _kernel_noise_applies(loc) and \
+            _kernels.get().RSAMPLE_DRAWN_MIN_ELEMENTS <= loc.numel() < (1 << 32) and \
+            not (torch.is_grad_enabled() and scale.requires_grad):
+        # the noise is formed where it is used: reserved in PyTorch's generator (the stream moves as `normal_` would
+        # move it), drawn by the launch that adds loc — the same values, no noise tensor
+        noise = _philox.reserve(loc.numel(), loc.device)
+        draw = _ops.normal_rsample_drawn(noise, loc, scale, shape)
+        if draw is not None:
+            return draw
+        eps = _kernels.get().philox_normal(noise, tuple(shape), loc.device)      # (declined: the values as a tensor)
+    else:
+        eps = _standard_normal(shape, dtype=loc.dtype, device=loc.device)
     if swap_leading_dims:
         eps, loc, scale = eps.transpose(0, 1), loc.transpose(0, 1), scale.transpose(0, 1)
     return _ops.normal_rsample(eps, loc, scale)

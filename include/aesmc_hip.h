@@ -251,6 +251,17 @@ int aesmc_normal_rsample(int dtype, const aesmc_view3 *eps, const aesmc_view3 *l
                          const aesmc_view3 *scale, void *out, int64_t B, int64_t K, int64_t D,
                          void *stream);
 
+/* K6 with the noise formed in the launch: out[b,k,j] = loc[b,k,j] + n[b,k,j] * scale[b,k,j], where n is element
+ * (b K + k) D + j of the float32 tensor `torch.empty([B,K,D]).normal_()` would hold on this device for a generator at
+ * (seed, offset) with ATen's launch geometry `threads` (see aesmc_philox_normal_fill: the same stream, the same
+ * Box-Muller, `variant` and `rng_state` as there) — `Normal.rsample` of aesmc/state.py:98 without the noise tensor's
+ * round trip through HBM; the caller advances the generator by what `normal_` would have consumed.  float32 only
+ * (AESMC_ERR_UNSUPPORTED for float64 and for B K D >= 2^32); `out` is dense [B,K,D], loc and scale [B,K,D] views by
+ * element strides (0 = broadcast).  The [K,B,D] noise order of a BATCH_EXPANDED draw is not offered here. */
+int aesmc_normal_rsample_drawn(int dtype, const aesmc_view3 *loc, const aesmc_view3 *scale, void *out, int64_t B,
+                               int64_t K, int64_t D, uint64_t seed, uint64_t offset, int64_t threads, int variant,
+                               const uint64_t *rng_state, void *stream);
+
 /* K7 — weighted particle summaries of a batch row in one pass:
  *   w = softmax_k(log_w[b,:]);  out_mean[b,j] = sum_k w[k] value[b,k,j];
  *   out_second[b,j] = sum_k w[k] value[b,k,j]^2;  out_log_ess[b] = 2 lse(log_w) - lse(2 log_w).

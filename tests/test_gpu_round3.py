@@ -929,3 +929,65 @@ def test_steps_that_share_their_parameters_finish_their_gradients_once(kernels, 
         if name in shared:
             assert torch.equal(got, want), (name, "carried and deferred")
     assert kernels.read_flags(hip_device) == 0
+
+
+@pytest.mark.parametrize("shape", [(64, 4096, 10), (3, 70001, 5), (128, 4096, 1), (7, 1999, 33), (2, 40000, 128),
+                                   (1024, 4096, 10), (5, 300, 7)])
+@pytest.mark.parametrize("layout", ["dense", "row_loc", "column_scale", "dense_scale"])
+def test_a_plain_normals_draw_forms_its_noise_in_the_launch(kernels, hip_device, shape, layout):
+    """`state.sample` of a FULLY_EXPANDED Normal with tensor parameters: above a quarter of a million elements the
+    noise is formed inside the launch that adds the location (aesmc_normal_rsample_drawn) — the draw equals, bit for
+    bit, what `torch.empty(shape).normal_()` followed by K6 gives under the same seed, the generator ends where
+    `normal_` would have left it, and the gradient reaches the location."""
+    from aesmc_amd import _philox, state
+    B, K, D = shape
+    gen = torch.Generator().manual_seed(B + K + D)
+    loc = torch.randn(B, K, D, generator=gen).to(hip_device)
+    scale = torch.tensor(0.7, device=hip_device)
+    if layout == "row_loc":
+        loc = torch.randn(B, 1, D, generator=gen).to(hip_device).expand(B, K, D)
+    elif layout == "column_scale":
+        scale = (torch.rand(D, generator=gen) + 0.5).to(hip_device)
+    elif layout == "dense_scale":
+        scale = (torch.rand(B, K, D, generator=gen) + 0.5).to(hip_device)
+    loc = loc.clone().requires_grad_(True) if layout == "dense" else loc
+    dist = state.set_batch_shape_mode(torch.distributions.Normal(loc, scale, validate_args=False),
+                                      state.BatchShapeMode.FULLY_EXPANDED)
+    calls = {"drawn": 0}
+    real = kernels.normal_rsample_drawn
+
+    def spy(*args, **kwargs):
+        calls["drawn"] += 1
+        return real(*args, **kwargs)
+
+    kernels.normal_rsample_drawn = spy
+    try:
+        torch.manual_seed(11)
+        draw = state.sample(dist, B, K)
+        after = torch.cuda.default_generators[hip_device.index or 0].get_offset()
+    finally:
+        kernels.normal_rsample_drawn = real
+    expected = 1 if B * K * D >= kernels.RSAMPLE_DRAWN_MIN_ELEMENTS else 0      # (small draws keep the two launches)
+    assert calls["drawn"] == expected and draw.shape == (B, K, D) and draw.is_contiguous()
+    torch.manual_seed(11)
+    eps = torch.empty(B, K, D, device=hip_device).normal_()
+    assert torch.cuda.default_generators[hip_device.index or 0].get_offset() == after
+    want = loc.detach() + eps * scale
+    assert torch.equal(draw.detach(), want)
+    if layout == "dense":
+        weights = torch.randn(B, K, D, generator=gen).to(hip_device)
+        (draw * weights).sum().backward()
+        assert torch.equal(loc.grad, weights)
+    # a scale that wants its gradient keeps the noise: the launch is not taken
+    learned = torch.tensor(0.7, device=hip_device, requires_grad=True)
+    kept = state.set_batch_shape_mode(torch.distributions.Normal(loc.detach(), learned, validate_args=False),
+                                      state.BatchShapeMode.FULLY_EXPANDED)
+    kernels.normal_rsample_drawn = spy
+    try:
+        torch.manual_seed(11)
+        again = state.sample(kept, B, K)
+    finally:
+        kernels.normal_rsample_drawn = real
+    assert calls["drawn"] == expected and torch.equal(again.detach(), loc.detach() + eps * learned.detach())
+    again.sum().backward()
+    assert float((learned.grad - eps.sum()).abs()) <= 1e-3 * max(1.0, float(eps.abs().sum()) ** 0.5)
