@@ -203,8 +203,8 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
             log_weight = _ops.affine_propagate(affine.with_latent(x_t), latent.noise)
             latent.resolve(x_t)
             affine = affine.with_latent(x_t)
-            for distribution in (prior_dist, emission_dist, proposal_dist):
-                _validate_sample(distribution, observation if distribution is emission_dist else x_t)
+            # (what `_validate_sample` would check is settled: the three are Normals — real support — whose batch
+            #  shapes `_affine_step_operands` matched against the very tensors the launch wrote and read)
             return (log_weight, affine) if defer_grad else log_weight
         x_t = latent.materialise()
         if affine is not None:
