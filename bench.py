@@ -65,6 +65,9 @@ WORKLOADS = {
     "c5h": ("LGSSM d=128 B=64 K=16384 T=200, emission scale 0.05, SMC ELBO forward (configs[4] shape, healthy particle system)",
             "lgssm", 128, 64, 16384, 200, {"emission_scale": 0.05}),
 }
+for _rows in (320, 384, 448, 640, 768):      # intermediate shards of the north-star shape (graph-replay / host-bound studies)
+    WORKLOADS["c4b%d" % _rows] = ("LGSSM d=10 B=%d K=4096 T=100, SMC ELBO (a part of c4's batch)" % _rows, "lgssm", 10,
+                                  _rows, 4096, 100, {})
 WORKLOADS["tiny"] = ("LGSSM d=3 B=8 K=64 T=5 (test-sized: exercises every leg of this file in seconds)",
                      "lgssm", 3, 8, 64, 5, {})
 ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
