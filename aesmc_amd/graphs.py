@@ -56,30 +56,35 @@ class _StaticUniformFeed:
         self.num_draws = max(num_draws, 1)
         self.host = [torch.empty((self.num_draws, batch_size), dtype=torch.float64, pin_memory=True)
                      for _ in range(2)]
+        # the pinned blocks as the device addresses them: the upload is a copy kernel on the replay's stream (no DMA
+        # engine hand-over in front of every replay)
+        self.mapped = [inference._mapped_view(block, device) if device.type == "cuda" else None for block in self.host]
+        self.host_rows = [block.numpy() for block in self.host]      # the same pinned memory: draws are written into it
         self.uploaded = [None, None]    # event after the last upload out of each pinned block
         self.turn = 0
         self.dev = torch.empty((self.num_draws, batch_size), dtype=torch.float64, device=device)
         self.cursor = 0
 
     def refill_and_upload(self):
-        """Draws this evaluation's T-1 blocks — ONE numpy call, which consumes the global
-        RandomState exactly like T-1 successive np.random.uniform(size=[B, 1]) calls of the eager
-        loop (inside `distributed.shard_scope`: global batch, own rows kept) — and enqueues the
-        host -> device copy ahead of the replay, outside the graph (a pinned-memory copy node inside a
-        capture trips the host allocator's event tracking)."""
+        """Draws this evaluation's T-1 blocks — one `np.random.uniform(size=[B, 1])` per timestep, the reference's own
+        consumption of the global RandomState (aesmc/inference.py:250; inside `distributed.shard_scope`: global batch,
+        own rows kept), written straight into the pinned block — and enqueues the host -> device copy ahead of the
+        replay, outside the graph (a pinned-memory copy node inside a capture trips the host allocator's event
+        tracking).  Row by row on purpose: drawn as ONE [T-1, B, 1] array the block is a host allocation of
+        hundreds of KB made and freed per replay, and on this stack each such allocation beside a process with >8 GB
+        of device memory stalled the device (and writes to pinned memory) for 60-80 ms every few replays
+        (`tools/graph_probe.py`) — what made replays above ~1.3M particles look slower than the eager loop."""
         slot = self.turn
         self.turn ^= 1
         if self.uploaded[slot] is not None:
             self.uploaded[slot].synchronize()   # two evaluations ago: long done
-        shard = distributed.active_shard()
-        if shard is None:
-            block = np.random.uniform(size=[self.num_draws, self.batch_size, 1])[:, :, 0]
+        rows = self.host_rows[slot]
+        for row in range(self.num_draws):
+            rows[row] = inference.draw_uniform_block(self.batch_size)
+        if self.mapped[slot] is not None:
+            self.dev.copy_(self.mapped[slot])
         else:
-            global_batch, lo, hi = shard
-            assert hi - lo == self.batch_size, "shard_scope does not match the local batch"
-            block = np.random.uniform(size=[self.num_draws, global_batch, 1])[:, lo:hi, 0]
-        self.host[slot].copy_(torch.from_numpy(np.ascontiguousarray(block)))
-        self.dev.copy_(self.host[slot], non_blocking=True)
+            self.dev.copy_(self.host[slot], non_blocking=True)
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(self.dev.device))
         self.uploaded[slot] = event

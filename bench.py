@@ -72,7 +72,7 @@ WORKLOADS["tiny"] = ("LGSSM d=3 B=8 K=64 T=5 (test-sized: exercises every leg of
                      "lgssm", 3, 8, 64, 5, {})
 ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
 NO_GRAD = {"c5", "c5h"}             # autograd retention of T x [B,K,128] temporaries exceeds HBM: forward under no_grad
-GRAPH_PARTICLES = 1 << 20           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
+GRAPH_PARTICLES = 1 << 21           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
                                     # (above it a captured graph does not pay and is erratic: B=512 K=4096 12.1, 16.8
                                     #  and 27.6 ms as a graph in three runs of round 3 against 13.7 ms eager, B=1024 29.0
                                     #  against 21 ms — the loop is device-bound there and the eager allocator's
@@ -833,6 +833,11 @@ def main(argv=None):
                 projection["N={}".format(n)] = entry
             extras["strong_scaling_projection"] = projection
             lap("c4nl + strong-scaling projection")
+            if head["mode"] == "eager":
+                # the same ELBO captured once and replayed (aesmc_amd.graphs.GraphedLoss): what is left of the host
+                extras["c4_hipgraph"] = brief(run_workload(ctx, "c4", args.proposal, 5, 2, want_kernels=False, mode="graph",
+                                                           want_backward=not args.no_backward))
+                lap("c4 as a hipGraph")
         extras["kernel_legs"] = kernel_legs(ctx)
         lap("kernel legs")
         extras["index_parity_vs_reference_fixtures"] = parity_block(ctx)
