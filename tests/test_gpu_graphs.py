@@ -336,3 +336,36 @@ def test_guarded_gradients_are_zero_on_a_flagged_replay(hip_device):
     guarded(observations)                         # and the next healthy minibatch trains on
     guarded.check()
     assert any(bool((p.grad != 0).any()) for p in params)
+
+
+@pytest.mark.gpu
+def test_a_replay_draws_its_uniforms_one_timestep_at_a_time(hip_device):
+    """The uniforms of a replay are drawn as T - 1 calls of `np.random.uniform(size=[B, 1])` — the reference's own
+    consumption of the global RandomState (aesmc/inference.py:250), the numbers the eager loop draws — and never as
+    one [T-1, B, 1] array: a host allocation of hundreds of KB made and freed before every replay stalled the device
+    for tens of milliseconds on the MI355X stack (profiles/README.md, tools/graph_probe.py)."""
+    T, B, K = 12, 8, 64
+    model = models.LgssmNd(3, dtype=torch.float32, affine=True, validate_args=False).tune_proposal().to(hip_device)
+    observations = model.simulate(T, B, seed=1)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    graphed = graphs.GraphedLoss(observations, K, "aesmc", model.initial, model.transition, model.emission, model.proposal)
+    sizes = []
+    real = np.random.uniform
+
+    def spy(*args, **kwargs):
+        sizes.append(tuple(kwargs.get("size", args[2] if len(args) > 2 else ())))
+        return real(*args, **kwargs)
+
+    np.random.uniform = spy
+    try:
+        np.random.seed(5)
+        torch.manual_seed(5)
+        replayed = float(graphed())
+    finally:
+        np.random.uniform = real
+    assert sizes == [(B, 1)] * (T - 1)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    eager = float(losses.get_loss(observations, K, "aesmc", model.initial, model.transition, model.emission, model.proposal))
+    assert abs(replayed - eager) <= 1e-5 * max(1.0, abs(eager))
