@@ -373,8 +373,9 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
     }
 
     if graphed is not None:  # the eager loop beside it, for the record
-        step()
-        n = max(1, steps // 2)
+        for _ in range(2):      # (its first passes beside the capture's pool grow the allocator: not what a loop costs)
+            step()
+        n = max(2, steps // 2)
         se, _ = ctx.timed(step, n)
         out["eager_particle_steps_per_sec"] = global_B * K * T * n / se
 
