@@ -557,6 +557,14 @@ static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_id
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
+// the second form of this launch (linear_gaussian_fused.hip: the maps on the matrix cores); AESMC_ERR_UNSUPPORTED
+// for what it does not cover
+int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, const void *y, int64_t y_sb,
+                                  const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
+                                  const void *sp, const void *sg, const void *sq, void *out_x, void *out_lw,
+                                  int32_t *flags, int64_t B, int64_t K, uint64_t seed, uint64_t offset,
+                                  int64_t threads, const uint64_t *rng_state, hipStream_t stream);
+
 }  // namespace aesmc
 
 using namespace aesmc;
@@ -578,6 +586,14 @@ extern "C" int aesmc_affine_normal_propagate_drawn(
   if (transition->din != dx || proposal->dout != dx || proposal->din != dx || emission->din != dx)
     return AESMC_ERR_UNSUPPORTED;
   if (B == 0 || K == 0) return AESMC_OK;
+  // AESMC_K16_FORM=roles: the first form whatever the shape (a measurement knob; both forms give the same bits)
+  static const bool first_form = [] { const char *v = getenv("AESMC_K16_FORM"); return v != nullptr && v[0] == 'r'; }();
+  if (!first_form) {
+    const int status = launch_affine_propagate_fused(x_src, ancestors, y, y_stride_b, transition, emission, proposal,
+                                                     scale_p, scale_g, scale_q, out_x, out_lw, flags, B, K, seed, offset,
+                                                     threads, rng_state, static_cast<hipStream_t>(stream));
+    if (status != AESMC_ERR_UNSUPPORTED) return status;
+  }
   return launch_affine_propagate_noise(x_src, ancestors, y, y_stride_b, transition, emission, proposal, scale_p,
                                        scale_g, scale_q, out_x, out_lw, flags, B, K, seed, offset, threads, rng_state,
                                        static_cast<hipStream_t>(stream));
