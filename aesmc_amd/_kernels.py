@@ -955,11 +955,12 @@ class HipKernels:
                 self.timer.note(name, (entry, args), nbytes, (x_prev, ancestors, eps, y_rows, out, out_x, maps, scales))
         return out
 
-    # Below ~1M particles a launch has too few work items to hide a workgroup's start-up behind (measured, whole ELBOs
-    # as hipGraphs: B=128 K=4096 d=10 4.48 ms with the noise as its own launch followed by K15 through the ancestors
-    # against 6.06 with K16; B=256 K=4096: 6.63 against 6.46; B=512: 105 against 97 us per step): the noise is then
-    # materialised by aesmc_philox_normal_fill — the same values — and the step takes the launches that read it.
-    DRAWN_MIN_PARTICLES = int(__import__("os").environ.get("AESMC_K16_MIN_PARTICLES", str(1 << 20)))
+    # Below ~0.5M particles a launch has too few work items to hide a workgroup's start-up behind (measured, one launch
+    # each, hipGraph-timed, d=10, profiles/r04_k16bench_sweep.txt: B=128 K=4096 29.8 us for K16 against 9.7 + 25.8 for
+    # the noise as its own launch followed by K15 through the ancestors; B=256 K=1024 24.6 against 6.7 + 14.2): the
+    # noise is then materialised by aesmc_philox_normal_fill — the same values — and the step takes the launches that
+    # read it.  (Round 3's form of K16 needed 1M particles to win.)
+    DRAWN_MIN_PARTICLES = int(__import__("os").environ.get("AESMC_K16_MIN_PARTICLES", str(1 << 19)))
 
     def philox_normal(self, stream_desc, shape, device):
         """The float32 tensor `torch.empty(shape).normal_()` would have held for the generator state

@@ -41,7 +41,8 @@ def launch_threads(numel, device):
 
 
 def consumed(numel, threads):
-    """What one `normal_` of `numel` float32 elements adds to the generator's offset."""
+    """What one `normal_` of `numel` FLOAT32 elements adds to the generator's offset (float64 draws take another
+    route in ATen: callers reserve noise for float32 tensors only, `state.sample` / `_kernels` check the dtype)."""
     return 4 * ((numel - 1) // (threads * 4) + 1)
 
 
@@ -79,17 +80,32 @@ class GraphNoise:
     the region), and `advance()` afterwards moves the generator by the region's total — exactly what the eager
     evaluation consumes, in the same order."""
 
+    SLOTS = 4
+
     def __init__(self, device):
         self.device = device
-        self.host = torch.zeros(2, dtype=torch.int64, pin_memory=True)
+        # The host runs ahead of the device (replays are enqueued without a sync): every upload writes a pinned slot of
+        # its own and is followed by an event; a slot is rewritten only after the copy that last read it has completed.
+        # (One slot rewritten per replay — round 3 — let replay n read the offset of replay n + 1: two optimiser steps
+        # then drew the same noise.)
+        self.host = torch.zeros((self.SLOTS, 2), dtype=torch.int64, pin_memory=True)
+        self.copied = [None] * self.SLOTS
+        self.turn = 0
         self.state = torch.zeros(2, dtype=torch.int64, device=device)
         self.consumed = 0
 
     def upload(self):
         generator = _generator(self.device)
-        self.host[0] = _as_int64(generator.initial_seed())
-        self.host[1] = generator.get_offset()
-        self.state.copy_(self.host, non_blocking=True)
+        slot = self.turn
+        self.turn = (self.turn + 1) % self.SLOTS
+        if self.copied[slot] is not None:
+            self.copied[slot].synchronize()        # SLOTS uploads ago: long done unless the host is that far ahead
+        self.host[slot, 0] = _as_int64(generator.initial_seed())
+        self.host[slot, 1] = generator.get_offset()
+        self.state.copy_(self.host[slot], non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(self.device))
+        self.copied[slot] = event
 
     def advance(self):
         generator = _generator(self.device)

@@ -68,8 +68,13 @@ __device__ __forceinline__ uint64_t fused_stamp() {
   return t;
 }
 #define FUSED_STAMP(k) do { if (plan.stamps != nullptr) { const uint64_t now_ = fused_stamp(); acc_[k] += now_ - last_; last_ = now_; } } while (0)
-#define FUSED_STAMP_INIT uint64_t acc_[16] = {}; uint64_t last_ = plan.stamps != nullptr ? fused_stamp() : 0
-#define FUSED_STAMP_FLUSH(role) do { if (plan.stamps != nullptr && (threadIdx.x & 255u) == 0) { for (int k_ = 0; k_ < 16; ++k_) plan.stamps[((size_t)blockIdx.x * 2 + (role)) * 16 + k_] = acc_[k_]; } } while (0)
+__device__ __forceinline__ uint64_t fused_realtime() {
+  uint64_t t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define FUSED_STAMP_INIT uint64_t acc_[16] = {}; uint64_t last_ = plan.stamps != nullptr ? fused_stamp() : 0; const uint64_t real0_ = fused_realtime(), cyc0_ = last_
+#define FUSED_STAMP_FLUSH(role) do { if (plan.stamps != nullptr && (threadIdx.x & 255u) == 0) { acc_[14] = fused_stamp() - cyc0_; acc_[15] = fused_realtime() - real0_; for (int k_ = 0; k_ < 16; ++k_) plan.stamps[((size_t)blockIdx.x * 2 + (role)) * 16 + k_] = acc_[k_]; } } while (0)
 #else
 #define FUSED_STAMP(k) do { } while (0)
 #define FUSED_STAMP_INIT do { } while (0)
@@ -603,6 +608,9 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
   // 32-bit element arithmetic throughout (window bounds run up to numel + 4 G + L; byte offsets up to 8 N)
   if (numel >= (1ull << 29) || (uint64_t)threads >= (1ull << 24)) return AESMC_ERR_UNSUPPORTED;
   const int ks = (int)((std::max(dx, dy) + 3) / 4);
+  // extents above 12: the first form is faster (rows of 16 values put a wavefront's noise reads on two LDS banks
+  // here: 371 against 337 us at B=1024 K=4096 d=16, profiles/r04_k16bench_sweep.txt)
+  if (ks > 3) return AESMC_ERR_UNSUPPORTED;
   FusedPlan plan;
   plan.numel = (uint32_t)numel;
   plan.G = (uint32_t)threads;
@@ -643,8 +651,7 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
   switch (ks) {
     case 1: return fused_launch_g<1, 0, 0>(FUSED_ARGS);
     case 2: return fused_launch_g<2, 0, 0>(FUSED_ARGS);
-    case 3: return fused_launch_g<3, 0, 0>(FUSED_ARGS);
-    default: return fused_launch_g<4, 0, 0>(FUSED_ARGS);
+    default: return fused_launch_g<3, 0, 0>(FUSED_ARGS);
   }
 #endif
 #undef FUSED_ARGS

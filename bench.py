@@ -10,9 +10,10 @@ workload is the north-star shape of BASELINE.json: LGSSM d=10, B=1024, K=4096, T
 N > 1: `python bench.py --gpus N` starts N fresh children itself (python -m
 torch.distributed.run, one rank per GPU, RCCL) before anything touches the GPU; it also runs as a
 child of an external torchrun (RANK / WORLD_SIZE in the environment).  Batch rows shard over the
-ranks; the only collective on the data path is the all-reduce of sum_b log Z_b.  `--scaling weak`
-(default): every rank owns the workload's B rows; `--scaling strong`: the workload's B rows are
-split over the ranks (the north-star curve: global B=1024 on 1, 2, 4, 8 GPUs).
+ranks; the only collective on the data path is the all-reduce of sum_b log Z_b.  `--scaling strong`
+(the default for c4, BASELINE.json's north-star shape): the workload's B rows are split over the ranks;
+`--scaling weak` (the default elsewhere): every rank owns the workload's B rows.  The other curve rides in
+`extras`, the all-reduce's own time in `allreduce_us_per_elbo`.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     : the resampling kernel (fused step K2+K3; K3 alone where the step does not cover the
@@ -95,7 +96,10 @@ def parse(argv=None):
                          "evaluated inside the sampling / weighting kernels, the proposal's draw deferred to the launch that "
                          "weighs it (K15; a step's backward: K14); 'matmul': "
                          "Normal(source @ weight.T + offset, scale) with PyTorch matmuls, as round 1 and 2 timed it")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1 only. strong: the workload's B rows are split over the ranks (value = B K T / wall: the "
+                         "north-star curve of c4, B=1024 over 8 GPUs); weak: every rank owns B rows.  Default: strong for "
+                         "c4 — the shape BASELINE.json's scaling target names — weak elsewhere")
     ap.add_argument("--extras", default=None, choices=["on", "off"],
                     help="the extra blocks (stock proposal, configs[1] hipGraph, kernel legs, parity); default: on for N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,6 +148,14 @@ def child_environment(base=None):
     return env
 
 
+def resolve_scaling(args, world):
+    """The curve `--gpus N` headlines: BASELINE.json's north star splits c4's B=1024 rows over the GPUs (strong);
+    the other workloads keep their B per GPU.  With one GPU the two coincide."""
+    if args.scaling is not None:
+        return args.scaling
+    return "strong" if (world > 1 and args.workload == "c4") else "weak"
+
+
 def needs_launcher(args, environ=None):
     environ = os.environ if environ is None else environ
     return args.gpus > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
@@ -155,7 +167,8 @@ def self_launch(args, argv):
     command = child_command(argv, args.gpus)
     if args.dry_run:
         added = {k: v for k, v in child_environment({}).items()}
-        print(json.dumps({"launch": command, "environment_defaults": added}))
+        print(json.dumps({"launch": command, "environment_defaults": added, "scaling": resolve_scaling(args, args.gpus),
+                          "workload": args.workload}))
         return 0
     print("bench.py: launching {} ranks: {}".format(args.gpus, " ".join(command)), file=sys.stderr, flush=True)
     return subprocess.run(command, env=child_environment()).returncode
@@ -694,7 +707,7 @@ def main(argv=None):
     if args.dry_run:
         print(json.dumps({"launch": None, "rank": int(os.environ.get("RANK", "0")),
                           "world_size": int(os.environ.get("WORLD_SIZE", "1")), "workload": args.workload,
-                          "scaling": args.scaling}))
+                          "scaling": resolve_scaling(args, int(os.environ.get("WORLD_SIZE", "1")))}))
         return
 
     import numpy as np  # noqa: F401
@@ -708,11 +721,12 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench.py --gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    args.scaling = resolve_scaling(args, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
-    rccl_world = None
+    rccl_world, allreduce_us = None, None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -722,6 +736,15 @@ def main(argv=None):
             dist.all_reduce(warm)          # creates the communicator now (and prints its banner)
             torch.cuda.synchronize()
         rccl_world = dist.get_world_size()
+        # what the data path's one collective costs: the all-reduce of sum_b log Z_b, once per ELBO
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        a.record()
+        for _ in range(50):
+            dist.all_reduce(warm)
+        b.record()
+        torch.cuda.synchronize()
+        allreduce_us = round(a.elapsed_time(b) * 1e3 / 50, 2)
     assert _kernels.get().name == "hip"
     ctx = Context(args, device, rank, world, use_dist)
 
@@ -777,7 +800,7 @@ def main(argv=None):
                            ("autograd graph recorded" if head["grad"] == "on" else "torch.no_grad()") +
                            (", all T timesteps replayed as one hipGraph" if head["mode"] == "hipgraph"
                             else ", eager Python loop")},
-        "rccl_world_size": rccl_world,
+        "rccl_world_size": rccl_world, "allreduce_us_per_elbo": allreduce_us,
         "loss": head["loss"], "mode": head["mode"], "graph_error": head["graph_error"],
         "tunableop": args.tunableop, "peak_memory_GB": head["peak_memory_GB"],
         "eager_particle_steps_per_sec": head.get("eager_particle_steps_per_sec"),
@@ -788,12 +811,14 @@ def main(argv=None):
     }
 
     extras = {}
-    if world > 1 and args.scaling == "weak" and (args.extras or "on") == "on":
-        # the north-star curve beside the weak-scaling line: the workload's B rows split over the ranks
-        strong = run_workload(ctx, args.workload, args.proposal, args.steps, args.warmup, scaling="strong",
+    if world > 1 and (args.extras or "on") == "on":
+        # the other curve beside the headline: weak scaling (every rank owns the workload's B rows) under a strong
+        # headline, the split of the workload's B rows under a weak one
+        other = "weak" if args.scaling == "strong" else "strong"
+        beside = run_workload(ctx, args.workload, args.proposal, args.steps, args.warmup, scaling=other,
                               want_backward=False, want_kernels=False)
-        extras["strong_scaling"] = {key: strong[key] for key in
-                                    ("value", "ms_per_step", "batch_per_gpu", "global_batch", "mode", "loss")}
+        extras[other + "_scaling"] = {key: beside[key] for key in
+                                      ("value", "ms_per_step", "batch_per_gpu", "global_batch", "mode", "loss")}
     if extras_on and world == 1:
         def brief(result):
             keep = ("workload", "proposal", "callables", "value", "ms_per_step", "loss", "mode", "grad", "graph_error",

@@ -15,7 +15,11 @@ import bench  # noqa: E402
 def test_launcher_is_needed_only_outside_a_process_group():
     many = bench.parse(["--gpus", "8"])
     one = bench.parse([])
-    assert one.gpus == 1 and one.workload == "c4" and one.proposal == "tuned" and one.scaling == "weak"
+    assert one.gpus == 1 and one.workload == "c4" and one.proposal == "tuned" and one.scaling is None
+    # the north-star curve is the headline of `--gpus N`: c4's B=1024 rows split over the ranks
+    assert bench.resolve_scaling(many, 8) == "strong" and bench.resolve_scaling(one, 1) == "weak"
+    assert bench.resolve_scaling(bench.parse(["--gpus", "8", "--workload", "c2"]), 8) == "weak"
+    assert bench.resolve_scaling(bench.parse(["--gpus", "8", "--scaling", "weak"]), 8) == "weak"
     assert bench.needs_launcher(many, {}) is True
     assert bench.needs_launcher(many, {"WORLD_SIZE": "8", "RANK": "3"}) is False     # child of torchrun
     assert bench.needs_launcher(one, {}) is False
@@ -45,13 +49,14 @@ def test_dry_run_prints_the_launch_without_a_gpu():
     assert done.returncode == 0, done.stderr
     plan = json.loads(done.stdout.strip().splitlines()[-1])
     assert plan["launch"][1:3] == ["-m", "torch.distributed.run"] and "--dry-run" in plan["launch"]
+    assert plan["scaling"] == "strong" and plan["workload"] == "c4"
     # the same command line as a child of torchrun: no second launch
     done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
                           env=dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), capture_output=True, text=True,
                           timeout=300)
     assert done.returncode == 0, done.stderr
     plan = json.loads(done.stdout.strip().splitlines()[-1])
-    assert plan == {"launch": None, "rank": 1, "world_size": 2, "workload": "c4", "scaling": "weak"}
+    assert plan == {"launch": None, "rank": 1, "world_size": 2, "workload": "c4", "scaling": "strong"}
 
 
 def test_self_launch_runs_real_children_over_gloo_free_dry_run():

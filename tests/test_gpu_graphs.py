@@ -369,3 +369,38 @@ def test_a_replay_draws_its_uniforms_one_timestep_at_a_time(hip_device):
     torch.manual_seed(5)
     eager = float(losses.get_loss(observations, K, "aesmc", model.initial, model.transition, model.emission, model.proposal))
     assert abs(replayed - eager) <= 1e-5 * max(1.0, abs(eager))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algorithm", ["aesmc", "iwae"])
+def test_back_to_back_replays_each_read_their_own_generator_offset(hip_device, algorithm):
+    """Replays enqueued without a host sync in between (check_flags=False: what `train(hip_graph=True)` and
+    `distributed.train` do) must each see the generator offset of THEIR evaluation: the pinned word the upload
+    copies from is one of a ring of slots, none rewritten before its copy has completed.  The state the device held
+    during each replay is cloned on the stream right after it and compared with the offsets the generator had
+    before each replay.  ('iwae' has no uniform feed whose event would hold the host back at all.)"""
+    from aesmc_amd import _philox, state
+    T, B, K = (6, 8, 64) if algorithm == "aesmc" else (1, 16, 256)
+    if algorithm == "aesmc":
+        model = models.LgssmNd(3, dtype=torch.float32, affine=True, validate_args=False).tune_proposal().to(hip_device)
+        parts = (model.initial, model.transition, model.emission, model.proposal)
+    else:
+        model = models.GaussianIwae(state=state, validate_args=False).to(hip_device)
+        parts = (model.prior, None, model.likelihood, model.inference_network)
+    observations = model.simulate(T, B, seed=1)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    graphed = graphs.GraphedLoss(observations, K, algorithm, *parts, check_flags=False)
+    if graphed.noise is None:
+        pytest.skip("this model's draws go through PyTorch's own captured generator state")
+    generator = torch.cuda.default_generators[hip_device.index]
+    busy = torch.empty(64 << 20, device=hip_device)
+    before, seen = [], []
+    for _ in range(3 * _philox.GraphNoise.SLOTS):
+        busy.normal_()                       # device work in front: the host gets well ahead of the replays
+        before.append(generator.get_offset())
+        graphed()
+        seen.append(graphed.noise.state.clone())
+    torch.cuda.synchronize()
+    assert [int(s[1]) for s in seen] == before
+    assert len(set(before)) == len(before)          # and every replay advanced the generator

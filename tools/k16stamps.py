@@ -54,6 +54,8 @@ for mask in [int(v) for v in sys.argv[4:]] or [0]:
     for role, names in ((0, P_NAMES), (1, N_NAMES)):
         med = table[:, role, :len(names)].median(dim=0).values
         total = float(med.sum())
-        print("  {} wavefront: {:.0f} cycles in all".format("particle" if role == 0 else "noise", total))
+        cyc, real = float(table[:, role, 14].median()), float(table[:, role, 15].median())
+        print("  {} wavefront: {:.0f} cycles in all; shader clock {:.2f} GHz ({:.0f} cycles in {:.1f} us of the 100 MHz counter)".format(
+            "particle" if role == 0 else "noise", total, cyc / max(real, 1) * 0.1, cyc, real / 100))
         for name, value in zip(names, med.tolist()):
             print("    {:42s} {:10.0f}  {:5.1f} %".format(name, value, 100 * value / max(total, 1)))
