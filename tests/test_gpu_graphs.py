@@ -386,7 +386,7 @@ def test_back_to_back_replays_each_read_their_own_generator_offset(hip_device, a
         parts = (model.initial, model.transition, model.emission, model.proposal)
     else:
         model = models.GaussianIwae(state=state, validate_args=False).to(hip_device)
-        parts = (model.prior, None, model.likelihood, model.inference_network)
+        parts = (model.initial, None, model.emission, model.proposal)
     observations = model.simulate(T, B, seed=1)
     np.random.seed(3)
     torch.manual_seed(3)
