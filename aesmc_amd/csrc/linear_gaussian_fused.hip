@@ -35,7 +35,6 @@ namespace aesmc {
 typedef float fz4 __attribute__((ext_vector_type(4)));
 typedef fz4 fz4_a4 __attribute__((aligned(4)));      // a 16-byte global access at 4-byte alignment (hardware: unaligned mode)
 
-constexpr int kFusedThreads = 512;
 constexpr uint32_t kRunP = 128;                       // rows per window: two chunks of 64
 constexpr uint32_t kTabF = 4 * 2 * 4 * 16;            // floats per table slot: [window][row 0/1][p, q, g, y][16]
 
@@ -81,13 +80,28 @@ __device__ __forceinline__ uint64_t fused_realtime() {
 #define FUSED_STAMP_FLUSH(role) do { } while (0)
 #endif
 
+// acc += w * x with the weight in a SCALAR register (one per wavefront: the launch's maps are the same for every
+// particle).  Written as an instruction because the compiler, left to itself, pairs two outputs per v_pk_fma_f32 and
+// spends two s_mov per multiply-add on putting their weights side by side.
+typedef const float __attribute__((address_space(4))) fused_cfloat;
+__device__ __forceinline__ float fused_fmac_s(float acc, float w, float x) {
+  asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(x));
+  return acc;
+}
+
 struct FusedWin {
   uint32_t nf, count, head, b0, k0;      // first particle, particles, elements in front of the first, its batch row, its k
   uint32_t c, t0, tl;                    // the item's trip, first thread id and thread-id count
 };
 
-template <int KS, int DXC, int DYC, bool GATHER>
-__global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kernel(
+// Workgroup: four particle wavefronts and four noise wavefronts, two workgroups per CU (four wavefronts per SIMD).
+// (Measured and not kept: SIX noise wavefronts for the scalar-weight form, which fits 96 registers — ten wavefronts
+// per workgroup, five per SIMD, a lane's draws cut from five calls per item to four / three: 167 us against 127 at
+// B=1024 K=4096 d=10 — the particle wavefronts are the critical path and lose issue slots to the extra noise ones.)
+template <bool SCALARW> constexpr int fused_threads() { return 512; }
+
+template <int KS, int DXC, int DYC, bool GATHER, bool SCALARW>
+__global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_fused_kernel(
     const float *__restrict__ xsrc, const float *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg, LgMap mq,
     const float *__restrict__ sp_ptr, const float *__restrict__ sg_ptr, const float *__restrict__ sq_ptr,
     float *__restrict__ out_lw, uint32_t K, uint32_t Bn, float *__restrict__ out_x,
@@ -159,11 +173,16 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
     // item before they are written).  Wavefront nw covers entries [64 nw, 64 nw + 64) of each 256-entry trip: window
     // nw / 2 + 2 trip, batch row nw & 1 — uniform; the lane picks the vector (lane >> 4) and the element (lane & 15).
     // `row` = the window's first batch row out of the item's record.
+    constexpr uint32_t NW = (uint32_t)fused_threads<SCALARW>() / 64u - 4u, NL = 64u * NW;       // noise wavefronts, their lanes
     const uint32_t nw = w - 4u, tab_a = lane >> 4, tab_j = lane & 15u;
+    // the table's eight 64-entry blocks (window = block / 2, batch row = block & 1) go round the wavefronts
     auto table_load = [&](const uint32_t (&row)[2], float (&held)[2]) {
 #pragma unroll
       for (int trip = 0; trip < 2; ++trip) {
-        const uint32_t b = row[trip] + (nw & 1u);
+        const uint32_t block = nw + NW * trip;
+        held[trip] = 0.0f;
+        if (block >= 8u) continue;       // uniform
+        const uint32_t b = row[trip] + (block & 1u);
         const bool row_ok = row[trip] != ~0u && b < Bn;      // uniform
         const float *base = vec[0].ptr + (int64_t)b * vec[0].sb;
         int len = vec[0].ptr != nullptr ? vec[0].len : 0;
@@ -237,25 +256,26 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
       // two Philox calls per trip: two independent dependency chains for the vector ALU to interleave; no lane-
       // dependent branch (a lane past the span draws a value that lands on the spare word)
 #pragma unroll 1
-      for (uint32_t s = 0; s < plan.S; s += 2) {
-        const uint32_t j0 = tid + s * 256u, j1 = j0 + 256u;
+      for (uint32_t s = 0; s * NL < r.span; s += 2) {
+        const uint32_t j0 = tid + s * NL, j1 = j0 + NL;
         float4 a0, b0, a1, b1;
         bool w0, w1 = false;
         draw(j0, a0, b0, w0);
-        const bool two = s + 1 < plan.S && s * 256u + 256u < r.span;      // uniform
+        const bool two = (s + 1) * NL < r.span;      // uniform
         if (two) draw(j1, a1, b1, w1);
         place(j0, a0, b0, w0);
         if (two) place(j1, a1, b1, w1);
       }
 #pragma unroll
-      for (int trip = 0; trip < 2; ++trip) tab[tid + trip * 256u] = held[trip];
+      for (int trip = 0; trip < 2; ++trip)
+        if (nw + NW * trip < 8u) tab[64u * (nw + NW * trip) + lane] = held[trip];
     };
     float held[2], held_next[2];
     FUSED_STAMP_INIT;
     {
       const Record first = locate(min(blockIdx.x, last_item)), second = locate(min(blockIdx.x + gridDim.x, last_item));
-      const uint32_t rows0[2] = {first.row[nw >> 1], first.row[(nw >> 1) + 2]};
-      const uint32_t rows1[2] = {second.row[nw >> 1], second.row[(nw >> 1) + 2]};
+      const uint32_t rows0[2] = {first.row[nw >> 1], first.row[((nw + NW) >> 1) & 3u]};
+      const uint32_t rows1[2] = {second.row[nw >> 1], second.row[((nw + NW) >> 1) & 3u]};
       table_load(rows0, held);
       table_load(rows1, held_next);
       draw_item(first, 0, held);
@@ -270,7 +290,7 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
       {
         const uint32_t *rec = ring + ((it + 2u) & 3u) * 16u;      // the record of item + 2 strides
         const uint32_t rows[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)rec[12 + (nw >> 1)]),
-                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[14 + (nw >> 1)])};
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[12 + (((nw + NW) >> 1) & 3u)])};
         table_load(rows, held_next);
       }
       FUSED_STAMP(1);
@@ -296,7 +316,7 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
   // the maps as matrix operands A[m = output j][k = input i]: lane holds W[n][4 s + g] of k-step s
   float aq[KS], ap[KS], ag[KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
+  for (int s = 0; s < (SCALARW ? 0 : KS); ++s) {
     const uint32_t i = 4u * s + g;
     const float *wq = reinterpret_cast<const float *>(mq.w), *wp = reinterpret_cast<const float *>(mp.w),
                 *wg = reinterpret_cast<const float *>(mg.w);
@@ -304,11 +324,14 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
     ap[s] = (n < dx && i < dx) ? wp[(int64_t)n * mp.sj + (int64_t)i * mp.si] : 0.0f;
     ag[s] = (n < dy && i < dx) ? wg[(int64_t)n * mg.sj + (int64_t)i * mg.si] : 0.0f;
   }
+  // (the step's constants through readfirstlane: wavefront-uniform values the compiler would otherwise keep in nine
+  //  vector registers for the whole loop)
+  auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
   const float s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
   const float half_log_2pi = LgConst<float>::half_log_2pi();
-  const float two_var_p = 2.0f * (s_p * s_p), const_p = (float)dx * (Num<float>::log(s_p) + half_log_2pi);
-  const float two_var_g = 2.0f * (s_g * s_g), const_g = (float)dy * (Num<float>::log(s_g) + half_log_2pi);
-  const float two_var_q = 2.0f * (s_q * s_q), const_q = (float)dx * (Num<float>::log(s_q) + half_log_2pi);
+  const float two_var_p = uniform(2.0f * (s_p * s_p)), const_p = uniform((float)dx * (Num<float>::log(s_p) + half_log_2pi));
+  const float two_var_g = uniform(2.0f * (s_g * s_g)), const_g = uniform((float)dy * (Num<float>::log(s_g) + half_log_2pi));
+  const float two_var_q = uniform(2.0f * (s_q * s_q)), const_q = uniform((float)dx * (Num<float>::log(s_q) + half_log_2pi));
 
   // row of tile T (0..7) this lane feeds as matrix operand, clamped to the window's last particle
   auto tile_row = [&](const FusedWin &win, int T) { return min(16u * (uint32_t)T + n, win.count != 0 ? win.count - 1 : 0u); };
@@ -339,7 +362,8 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
   };
   uint32_t bad = 0;       // out-of-range indices seen by this lane: reported once, after the loop (no atomic inside it)
   const uint32_t Kdx = K * dx;
-  auto rows_load = [&](const FusedWin &win, int c, u32x2 raw, float (&x)[DP]) {
+  constexpr int XN = SCALARW ? DXC : DP;      // a row's registers (the matrix form pads to whole k-steps)
+  auto rows_load = [&](const FusedWin &win, int c, u32x2 raw, float (&x)[XN]) {
     const uint32_t r = lane_row(win, c);
     uint32_t a = raw[0];
     // K2 writes K for a degenerate row (flagged there); never fault on it
@@ -354,7 +378,7 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
       constexpr int PW = DXC % 4 == 0 ? 4 : 2;
       const float *at = xsrc + (base + __umul24(a, dx));
 #pragma unroll
-      for (int e0 = 0; e0 < DP; e0 += PW) {
+      for (int e0 = 0; e0 < XN; e0 += PW) {
         if (e0 >= DXC) {
 #pragma unroll
           for (int e = 0; e < PW; ++e) x[e0 + e] = 0.0f;
@@ -370,7 +394,7 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < DP; ++e)
+      for (int e = 0; e < XN; ++e)
         x[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off + 4u * e, 0, 0));
     }
   };
@@ -380,7 +404,7 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
   FusedWin nxt = window(min(blockIdx.x + stride, last_item), w);
   FusedWin ahd = window(min(blockIdx.x + 2 * stride, last_item), w);
   u32x2 araw[2];
-  float xr[2][DP];
+  float xr[2][XN];
 #pragma unroll
   for (int c = 0; c < 2; ++c) araw[c] = anc_load(cur, c);
 #pragma unroll
@@ -402,6 +426,118 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
       asm volatile("" : "+v"(ln));
       g = ln >> 4;
       n = ln & 15u;
+      if constexpr (SCALARW) {
+        // ---- the maps on the vector ALU with their weights in scalar registers (rows of W contiguous in memory: scalar
+        //      loads fetch them, nothing is staged): lane = particle from the first instruction on, no transposes; LDS
+        //      holds the chunk's rows of x_t on their way out only.  Same chains, same order (input ascending, started
+        //      from the offset), same bits as the matrix-core form below.
+        float xin[DP];
+#pragma unroll
+        for (int j = 0; j < DP; ++j) xin[j] = j < XN ? xr[c][j < XN ? j : 0] : 0.0f;
+        if (!(probe & 8u)) rows_load(nxt, c, araw[c], xr[c]);
+        if (!(probe & 16u)) araw[c] = anc_load(ahd, c);
+        FUSED_STAMP(1);
+        const uint32_t rl = 64u * c + ln;
+        const uint32_t rr = lane_row(cur, c);
+        const bool live = rl < cur.count;
+        const float *trow = tab + ((cur.k0 + rr) >= K ? 64u : 0u);
+        // (the pointers through an opaque move per chunk: the 3 d^2 weights are loop-invariant, and hoisted out of the
+        //  item loop they would be spilled into vector registers and read back lane by lane)
+        unsigned long long wq_a = (unsigned long long)mq.w, wp_a = (unsigned long long)mp.w, wg_a = (unsigned long long)mg.w;
+        asm volatile("" : "+s"(wq_a), "+s"(wp_a), "+s"(wg_a));
+        // Two outputs at a time (two independent chains back to back), their 2 din weights — two rows of W, contiguous —
+        // in scalar registers; the NEXT pair's rows are sent for before this pair's multiply-adds (scalar loads come
+        // back out of order, so the only wait there is waits for all of them: it must sit behind a block of work).
+        auto chain = [&](unsigned long long base, const float *offsets, uint32_t dout, const float (&in)[DP], float (&acc)[DP]) {
+          fused_cfloat *W = (fused_cfloat *)base;
+#pragma unroll
+          for (int v = 0; v < KS; ++v) {
+            const fz4 o4 = *reinterpret_cast<const fz4 *>(offsets + 4 * v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * v + e] = o4[e];
+          }
+          constexpr int DIN = DXC;       // (this path is instantiated for compile-time extents only)
+          float wa[2 * DIN], wb[2 * DIN];
+#pragma unroll
+          for (int e = 0; e < 2 * DIN; ++e) wa[e] = W[e];
+#pragma unroll
+          for (int jb = 0; jb < DP; jb += 2) {
+            if ((uint32_t)jb >= dout) break;
+            float (&cur_w)[2 * DIN] = (jb & 2) ? wb : wa;
+            float (&next_w)[2 * DIN] = (jb & 2) ? wa : wb;
+            if ((uint32_t)(jb + 2) < dout) {
+#pragma unroll
+              for (int e = 0; e < 2 * DIN; ++e) next_w[e] = W[(jb + 2) * DIN + min(e, (int)(dout - jb - 2) * DIN - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) {
+              acc[jb] = fused_fmac_s(acc[jb], cur_w[i], in[i]);
+              if ((uint32_t)(jb + 1) < dout) acc[jb + 1] = fused_fmac_s(acc[jb + 1], cur_w[DIN + i], in[i]);
+            }
+          }
+        };
+        float locq[DP], locp[DP];
+        float xx[DP], qp = 0.0f, qq = 0.0f, qg = 0.0f;
+        if (!(probe & 2u)) {
+          chain(wq_a, trow + 16, dx, xin, locq);
+          chain(wp_a, trow, dx, xin, locp);
+          FUSED_STAMP(2);
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+            if ((uint32_t)j < dx) {
+              xx[j] = locq[j] + tx[rr * dx + j] * s_q;      // the product rounded before the sum, as K9 / K6
+              const float ep = xx[j] - locp[j], eq = xx[j] - locq[j];
+              qp = fma_t(ep, ep, qp);
+              qq = fma_t(eq, eq, qq);
+            } else {
+              xx[j] = 0.0f;
+            }
+          }
+          FUSED_STAMP(3);
+          float locg[DP];
+          chain(wg_a, trow + 32, dy, xx, locg);
+          FUSED_STAMP(4);
+#pragma unroll
+          for (int v = 0; v < KS; ++v) {
+            const fz4 y4 = *reinterpret_cast<const fz4 *>(trow + 48 + 4 * v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if ((uint32_t)(4 * v + e) < dy) {
+                const float eg = y4[e] - locg[4 * v + e];
+                qg = fma_t(eg, eg, qg);
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < DP; ++j)
+            if ((uint32_t)j < dx) scr_q[ln * dx + j] = xx[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < DP; ++j) qp += xin[j];
+        }
+        if (live) {
+          const float lp = (-qp) / two_var_p - const_p;
+          const float lg = (-qg) / two_var_g - const_g;
+          const float lq = (-qq) / two_var_q - const_q;
+          out_lw[cur.nf + rl] = (lp + lg) - lq;
+        }
+        FUSED_STAMP(5);
+        if (!(probe & 4u)) {
+          const uint32_t rows = cur.count > 64u * c ? min(cur.count - 64u * c, 64u) : 0u;
+          const uint32_t words = rows * dx;
+          float *run = out_x + (size_t)(cur.nf + 64u * c) * dx;
+#pragma unroll
+          for (int u = 0; u < KS; ++u) {
+            const uint32_t q = ln + 64u * u;
+            if (4u * q + 4u <= words)
+              *reinterpret_cast<fz4_a4 *>(run + 4u * q) = *reinterpret_cast<const fz4 *>(scr_q + 4u * q);
+          }
+          if ((words & 3u) != 0u && ln < (words & 3u)) {
+            const uint32_t e = (words & ~3u) + ln;
+            run[e] = scr_q[e];
+          }
+        }
+      } else {
       // ---- proposal and transition locations of the chunk's 4 tiles on the matrix cores: D[j][particle] (lanes hold
       //      4 consecutive j of one particle) -> the wavefront's scratch rows [particle][RS].  Two tiles at a time:
       //      four independent accumulation chains keep the matrix pipe issuing back to back (one tile's three
@@ -412,10 +548,10 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
       float bx[4][KS];
       if (probe & 2u) {
 #pragma unroll
-        for (int j = 0; j < DP; ++j) probe_keep += xr[c][j];
+        for (int j = 0; j < XN; ++j) probe_keep += xr[c][j];
       } else {
 #pragma unroll
-        for (int j = 0; j < DP; ++j)
+        for (int j = 0; j < XN; ++j)
           if ((uint32_t)j < dx) scr_p[ln * dx + j] = xr[c][j];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -555,6 +691,8 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
           run[e] = scr_q[e];
         }
       }
+    
+      }
     }
     const FusedWin far = window(min(item + 3 * stride, last_item), w);
     publish(it + 3u, far, w);
@@ -572,7 +710,7 @@ __global__ __launch_bounds__(kFusedThreads, 4) void affine_propagate_fused_kerne
 #endif
 }
 
-template <int KS, int DXC, int DYC>
+template <int KS, int DXC, int DYC, bool SCALARW>
 static int fused_launch_g(dim3 grid, size_t lds, hipStream_t stream, const float *xsrc, const float *y, int64_t y_sb,
                           const LgMap &mp, const LgMap &mg, const LgMap &mq, const float *sp, const float *sg,
                           const float *sq, float *out_lw, uint32_t K, uint32_t Bn, float *out_x, const int64_t *anc,
@@ -580,15 +718,15 @@ static int fused_launch_g(dim3 grid, size_t lds, hipStream_t stream, const float
   static bool raised[2][64] = {};
   if (anc != nullptr) {
     if (lds > 64 * 1024 &&
-        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_fused_kernel<KS, DXC, DYC, true>), raised[0]))
+        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_fused_kernel<KS, DXC, DYC, true, SCALARW>), raised[0]))
       return AESMC_ERR_LAUNCH;
-    hipLaunchKernelGGL((affine_propagate_fused_kernel<KS, DXC, DYC, true>), grid, dim3(kFusedThreads), lds, stream, xsrc,
+    hipLaunchKernelGGL((affine_propagate_fused_kernel<KS, DXC, DYC, true, SCALARW>), grid, dim3(fused_threads<SCALARW>()), lds, stream, xsrc,
                        y, y_sb, mp, mg, mq, sp, sg, sq, out_lw, K, Bn, out_x, anc, flags, ps, plan);
   } else {
     if (lds > 64 * 1024 &&
-        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_fused_kernel<KS, DXC, DYC, false>), raised[1]))
+        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_fused_kernel<KS, DXC, DYC, false, SCALARW>), raised[1]))
       return AESMC_ERR_LAUNCH;
-    hipLaunchKernelGGL((affine_propagate_fused_kernel<KS, DXC, DYC, false>), grid, dim3(kFusedThreads), lds, stream, xsrc,
+    hipLaunchKernelGGL((affine_propagate_fused_kernel<KS, DXC, DYC, false, SCALARW>), grid, dim3(fused_threads<SCALARW>()), lds, stream, xsrc,
                        y, y_sb, mp, mg, mq, sp, sg, sq, out_lw, K, Bn, out_x, anc, flags, ps, plan);
   }
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
@@ -643,15 +781,24 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
   grid, lds, stream, static_cast<const float *>(xsrc), static_cast<const float *>(y), y_sb, p, gm, q,                  \
       static_cast<const float *>(sp), static_cast<const float *>(sg), static_cast<const float *>(sq),                  \
       static_cast<float *>(out_lw), (uint32_t)K, (uint32_t)B, static_cast<float *>(out_x), anc_idx, flags, ps, plan
+  // the maps' weights as scalar operands: rows of W contiguous ([dout, din] row-major, what an nn.Linear holds);
+  // AESMC_K16_MAPS=matrix keeps the matrix-core form (a measurement knob; both give the same bits)
+  static const bool matrix_only = [] { const char *v = getenv("AESMC_K16_MAPS"); return v != nullptr && v[0] == 'm'; }();
+  const auto rows_contiguous = [](const aesmc_affine_map *m) {
+    return m->stride_in == 1 && m->stride_out == m->din && (reinterpret_cast<uintptr_t>(m->weight) & 3u) == 0;
+  };
+  const bool scalar_w = !matrix_only && rows_contiguous(mp) && rows_contiguous(mg) && rows_contiguous(mq);
 #ifdef AESMC_LG_FAST_BUILD
-  if (ks == 3 && dx == 10 && dy == 10) return fused_launch_g<3, 10, 10>(FUSED_ARGS);
+  if (ks == 3 && dx == 10 && dy == 10)
+    return scalar_w ? fused_launch_g<3, 10, 10, true>(FUSED_ARGS) : fused_launch_g<3, 10, 10, false>(FUSED_ARGS);
   return AESMC_ERR_UNSUPPORTED;
 #else
-  if (ks == 3 && dx == 10 && dy == 10) return fused_launch_g<3, 10, 10>(FUSED_ARGS);
+  if (ks == 3 && dx == 10 && dy == 10)
+    return scalar_w ? fused_launch_g<3, 10, 10, true>(FUSED_ARGS) : fused_launch_g<3, 10, 10, false>(FUSED_ARGS);
   switch (ks) {
-    case 1: return fused_launch_g<1, 0, 0>(FUSED_ARGS);
-    case 2: return fused_launch_g<2, 0, 0>(FUSED_ARGS);
-    default: return fused_launch_g<3, 0, 0>(FUSED_ARGS);
+    case 1: return fused_launch_g<1, 0, 0, false>(FUSED_ARGS);
+    case 2: return fused_launch_g<2, 0, 0, false>(FUSED_ARGS);
+    default: return fused_launch_g<3, 0, 0, false>(FUSED_ARGS);
   }
 #endif
 #undef FUSED_ARGS
