@@ -88,6 +88,18 @@ __device__ __forceinline__ float fused_fmac_s(float acc, float w, float x) {
   asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(x));
   return acc;
 }
+// five inputs of two chains in one statement (the compiler pads every asm statement's end with an s_nop: one per
+// ten multiply-adds instead of one each)
+__device__ __forceinline__ void fused_fmac_s5x2(float &a0, float &a1, const float *w0, const float *w1, const float *x) {
+  asm("v_fmac_f32 %0, %2, %12\n\tv_fmac_f32 %1, %7, %12\n\t"
+      "v_fmac_f32 %0, %3, %13\n\tv_fmac_f32 %1, %8, %13\n\t"
+      "v_fmac_f32 %0, %4, %14\n\tv_fmac_f32 %1, %9, %14\n\t"
+      "v_fmac_f32 %0, %5, %15\n\tv_fmac_f32 %1, %10, %15\n\t"
+      "v_fmac_f32 %0, %6, %16\n\tv_fmac_f32 %1, %11, %16"
+      : "+v"(a0), "+v"(a1)
+      : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w0[3]), "s"(w0[4]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "s"(w1[3]),
+        "s"(w1[4]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]));
+}
 
 struct FusedWin {
   uint32_t nf, count, head, b0, k0;      // first particle, particles, elements in front of the first, its batch row, its k
@@ -175,6 +187,19 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
     // `row` = the window's first batch row out of the item's record.
     constexpr uint32_t NW = (uint32_t)fused_threads<SCALARW>() / 64u - 4u, NL = 64u * NW;       // noise wavefronts, their lanes
     const uint32_t nw = w - 4u, tab_a = lane >> 4, tab_j = lane & 15u;
+    // (which vector a lane reads, where and how long it is: fixed for the launch)
+    const float *tab_src = vec[0].ptr;
+    int64_t tab_sb = vec[0].sb;
+    int tab_len = vec[0].ptr != nullptr ? vec[0].len : 0;
+#pragma unroll
+    for (int cidx = 1; cidx < 4; ++cidx) {
+      const bool mine = tab_a == (uint32_t)cidx;
+      tab_src = mine ? vec[cidx].ptr : tab_src;
+      tab_sb = mine ? vec[cidx].sb : tab_sb;
+      tab_len = mine ? (vec[cidx].ptr != nullptr ? vec[cidx].len : 0) : tab_len;
+    }
+    const bool tab_live = (int)tab_j < tab_len;
+    tab_src += tab_live ? tab_j : 0u;
     // the table's eight 64-entry blocks (window = block / 2, batch row = block & 1) go round the wavefronts
     auto table_load = [&](const uint32_t (&row)[2], float (&held)[2]) {
 #pragma unroll
@@ -184,16 +209,8 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         if (block >= 8u) continue;       // uniform
         const uint32_t b = row[trip] + (block & 1u);
         const bool row_ok = row[trip] != ~0u && b < Bn;      // uniform
-        const float *base = vec[0].ptr + (int64_t)b * vec[0].sb;
-        int len = vec[0].ptr != nullptr ? vec[0].len : 0;
-#pragma unroll
-        for (int cidx = 1; cidx < 4; ++cidx) {
-          const bool mine = tab_a == (uint32_t)cidx;
-          base = mine ? vec[cidx].ptr + (int64_t)b * vec[cidx].sb : base;
-          len = mine ? (vec[cidx].ptr != nullptr ? vec[cidx].len : 0) : len;
-        }
         float value = 0.0f;
-        if (row_ok && (int)tab_j < len) value = base[tab_j];
+        if (row_ok && tab_live) value = tab_src[(int64_t)b * tab_sb];
         held[trip] = value;
       }
     };
@@ -253,8 +270,19 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
           if (__any(wraps)) second = philox_normal4(ps, tt, r.c + 1);      // (uniform branch, rarely taken)
         }
       };
-      // two Philox calls per trip: two independent dependency chains for the vector ALU to interleave; no lane-
-      // dependent branch (a lane past the span draws a value that lands on the spare word)
+      // A lane's calls are independent dependency chains (ten Philox rounds, then Box-Muller's logarithm, root, sine and
+      // cosine): with the extent known at compile time all of an item's calls are written out as one straight line for the
+      // vector ALU to interleave (one call at a time a noise wavefront issued an instruction every ~7 cycles even with
+      // the SIMD to itself).  No lane-dependent branch: a lane past the span draws a value that lands on the spare word.
+      constexpr uint32_t SC = DXC != 0 ? ((kRunP + 1u) * (uint32_t)DXC - 1u) / 256u : 0u;      // == plan.S
+      if (SC != 0 && NL == 256u && r.t0 + r.span <= G && !(probe & 1u)) {      // (uniform; no thread id wraps: all but a trip's last block)
+        float4 drawn[SC != 0 ? SC : 1];
+#pragma unroll
+        for (uint32_t s = 0; s < SC; ++s) drawn[s] = philox_normal4(ps, r.t0 + tid + s * NL, r.c);
+#pragma unroll
+        for (uint32_t s = 0; s < SC; ++s) place(tid + s * NL, drawn[s], drawn[s], false);
+      } else {
+      // two Philox calls per trip
 #pragma unroll 1
       for (uint32_t s = 0; s * NL < r.span; s += 2) {
         const uint32_t j0 = tid + s * NL, j1 = j0 + NL;
@@ -265,6 +293,7 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         if (two) draw(j1, a1, b1, w1);
         place(j0, a0, b0, w0);
         if (two) place(j1, a1, b1, w1);
+      }
       }
 #pragma unroll
       for (int trip = 0; trip < 2; ++trip)
@@ -468,6 +497,13 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
             if ((uint32_t)(jb + 2) < dout) {
 #pragma unroll
               for (int e = 0; e < 2 * DIN; ++e) next_w[e] = W[(jb + 2) * DIN + min(e, (int)(dout - jb - 2) * DIN - 1)];
+            }
+            if constexpr (DIN % 5 == 0) {
+              if ((uint32_t)(jb + 1) < dout) {
+#pragma unroll
+                for (int i0 = 0; i0 < DIN; i0 += 5) fused_fmac_s5x2(acc[jb], acc[jb + 1], cur_w + i0, cur_w + DIN + i0, in + i0);
+                continue;
+              }
             }
 #pragma unroll
             for (int i = 0; i < DIN; ++i) {

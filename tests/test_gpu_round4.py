@@ -129,3 +129,79 @@ def test_configs3_nonlinear_model_at_its_own_size(hip_device):
     reference = want["log_marginal_likelihood"].double()
     err = float(((got["log_marginal_likelihood"].cpu().double() - reference).abs() / (1 + reference.abs())).max())
     assert first_agree >= 0.995 and err < 1e-2, (first_agree, err)
+
+
+@pytest.mark.parametrize("shape", [(9, 4099, 10, 10), (3, 20000, 10, 10), (4, 9000, 7, 5)])
+def test_both_forms_of_the_fused_launch_give_the_same_bits(kernels, hip_device, shape, monkeypatch):
+    """The fused propagation launch evaluates the three maps on the vector ALU with scalar-register weights when the
+    rows of every weight are contiguous, and on the matrix cores otherwise (strided views, extents it has no
+    exact instantiation for).  Same chains, same order: the two forms and the unfused route (gather, torch's
+    normal_, K15) agree bit for bit."""
+    from aesmc_amd import _philox
+    monkeypatch.setattr(type(kernels), "DRAWN_MIN_PARTICLES", 0)
+    B, K, dx, dy = shape
+    n, o = operands(4, 32, dx, dy, np.float32, hip_device, seed=K)
+    gen = torch.Generator(device=hip_device).manual_seed(K)
+    x_prev = torch.randn(B, K, dx, device=hip_device, generator=gen)
+    y = torch.randn(B, dy, device=hip_device, generator=gen)
+    off_q = torch.randn(B, dx, device=hip_device, generator=gen)
+    idx = _ancestors(B, K, hip_device, seed=K, spread=1.0)
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    strided = {name: o[name].t().contiguous().t() for name in ("A", "C", "Q")}       # same values, columns contiguous
+    assert all(not strided[name].is_contiguous() or strided[name].shape[0] == 1 for name in strided)
+    results = []
+    for weights in (o, strided):
+        terms = ((weights["A"], None), (weights["C"], o["off_g"]), (weights["Q"], off_q))
+        torch.manual_seed(5)
+        state = torch.cuda.get_rng_state(hip_device)
+        eps = torch.empty(B, K, dx, device=hip_device).normal_()
+        torch.cuda.set_rng_state(state, hip_device)
+        reservation = _philox.reserve(B * K * dx, hip_device)
+        got_x = torch.full_like(x_prev, float("nan"))
+        got_lw = kernels.affine_propagate_drawn(x_prev, reservation, y, *terms, scales, out_x=got_x, ancestors=idx)
+        assert got_lw is not None
+        results.append((got_x, got_lw))
+    moved = kernels.gather(x_prev, idx)
+    want_x = torch.full_like(moved, float("nan"))
+    want_lw = kernels.affine_propagate(moved, eps, y, (o["A"], None), (o["C"], o["off_g"]), (o["Q"], off_q), scales,
+                                       out_x=want_x)
+    for got_x, got_lw in results:
+        assert torch.equal(got_x, want_x)
+        assert torch.equal(got_lw, want_lw)
+    assert kernels.read_flags(hip_device) == 0
+
+
+@pytest.mark.parametrize("strided", [False, True])
+def test_the_fused_launch_flags_and_survives_ancestors_out_of_range(kernels, hip_device, strided, monkeypatch):
+    """Ancestors that torch.gather would reject — K (what the resampling launch writes for a degenerate row), a
+    negative one, one beyond 2^32 — are flagged (AESMC_FLAG_INDEX_OUT_OF_RANGE, raised as a RuntimeError by `infer`)
+    and clamped: no fault, and every particle with a valid ancestor gets exactly the value of a clean run."""
+    from aesmc_amd import _philox
+    monkeypatch.setattr(type(kernels), "DRAWN_MIN_PARTICLES", 0)
+    B, K, dx, dy = 5, 4096, 10, 10
+    n, o = operands(4, 32, dx, dy, np.float32, hip_device, seed=2)
+    weights = {name: (o[name].t().contiguous().t() if strided else o[name]) for name in ("A", "C", "Q")}
+    gen = torch.Generator(device=hip_device).manual_seed(9)
+    x_prev = torch.randn(B, K, dx, device=hip_device, generator=gen)
+    y = torch.randn(B, dy, device=hip_device, generator=gen)
+    terms = ((weights["A"], None), (weights["C"], o["off_g"]), (weights["Q"], None))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    idx = _ancestors(B, K, hip_device, seed=4, spread=1.0)
+    bad = idx.clone()
+    bad[1, 17] = K
+    bad[2, 4000] = -1
+    bad[4, 63] = (1 << 33) + 5
+    outs = []
+    for ancestors in (idx, bad):
+        torch.manual_seed(8)
+        reservation = _philox.reserve(B * K * dx, hip_device)
+        out_x = torch.full_like(x_prev, float("nan"))
+        lw = kernels.affine_propagate_drawn(x_prev, reservation, y, *terms, scales, out_x=out_x, ancestors=ancestors)
+        assert lw is not None
+        outs.append((out_x, lw, kernels.read_flags(hip_device)))
+    (clean_x, clean_lw, clean_flags), (bad_x, bad_lw, bad_flags) = outs
+    assert clean_flags == 0 and bad_flags != 0
+    assert bool(torch.isfinite(bad_x).all()) and bool(torch.isfinite(bad_lw).all())
+    valid = torch.ones(B, K, dtype=torch.bool, device=hip_device)
+    valid[1, 17] = valid[2, 4000] = valid[4, 63] = False
+    assert torch.equal(bad_x[valid], clean_x[valid]) and torch.equal(bad_lw[valid], clean_lw[valid])
