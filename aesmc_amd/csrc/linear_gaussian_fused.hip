@@ -460,11 +460,9 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         //      loads fetch them, nothing is staged): lane = particle from the first instruction on, no transposes; LDS
         //      holds the chunk's rows of x_t on their way out only.  Same chains, same order (input ascending, started
         //      from the offset), same bits as the matrix-core form below.
-        float xin[DP];
-#pragma unroll
-        for (int j = 0; j < DP; ++j) xin[j] = j < XN ? xr[c][j < XN ? j : 0] : 0.0f;
-        if (!(probe & 8u)) rows_load(nxt, c, araw[c], xr[c]);
-        if (!(probe & 16u)) araw[c] = anc_load(ahd, c);
+        // (the chunk's rows are read where the prefetch left them; the next item's are sent for once the two chains that
+        //  read them are done)
+        float (&xin)[XN] = xr[c];
         FUSED_STAMP(1);
         const uint32_t rl = 64u * c + ln;
         const uint32_t rr = lane_row(cur, c);
@@ -477,7 +475,7 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         // Two outputs at a time (two independent chains back to back), their 2 din weights — two rows of W, contiguous —
         // in scalar registers; the NEXT pair's rows are sent for before this pair's multiply-adds (scalar loads come
         // back out of order, so the only wait there is waits for all of them: it must sit behind a block of work).
-        auto chain = [&](unsigned long long base, const float *offsets, uint32_t dout, const float (&in)[DP], float (&acc)[DP]) {
+        auto chain = [&](unsigned long long base, const float *offsets, uint32_t dout, const float *in, float (&acc)[DP]) {
           fused_cfloat *W = (fused_cfloat *)base;
 #pragma unroll
           for (int v = 0; v < KS; ++v) {
@@ -517,6 +515,8 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         if (!(probe & 2u)) {
           chain(wq_a, trow + 16, dx, xin, locq);
           chain(wp_a, trow, dx, xin, locp);
+          if (!(probe & 8u)) rows_load(nxt, c, araw[c], xr[c]);
+          if (!(probe & 16u)) araw[c] = anc_load(ahd, c);
           FUSED_STAMP(2);
 #pragma unroll
           for (int j = 0; j < DP; ++j) {
@@ -549,7 +549,9 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
             if ((uint32_t)j < dx) scr_q[ln * dx + j] = xx[j];
         } else {
 #pragma unroll
-          for (int j = 0; j < DP; ++j) qp += xin[j];
+          for (int j = 0; j < XN; ++j) qp += xin[j];
+          if (!(probe & 8u)) rows_load(nxt, c, araw[c], xr[c]);
+          if (!(probe & 16u)) araw[c] = anc_load(ahd, c);
         }
         if (live) {
           const float lp = (-qp) / two_var_p - const_p;

@@ -97,9 +97,10 @@ template <bool FUSED = true> __device__ __forceinline__ float2 box_muller_f32(ui
   }
   const float s = __builtin_sqrtf(-2.0f * __builtin_logf(u));
   float2 out;
-  // `normal_`'s own transform, rand * std + mean with std = 1 and mean = 0, follows: it turns -0.0 into +0.0
-  out.x = (__ocml_native_sin_f32(v) * s) * 1.0f + 0.0f;
-  out.y = (__ocml_native_cos_f32(v) * s) * 1.0f + 0.0f;
+  // `normal_`'s own transform, rand * std + mean with std = 1 and mean = 0, follows: the sum turns -0.0 into +0.0
+  // (the product with 1.0f changes no value and is left out)
+  out.x = (__ocml_native_sin_f32(v) * s) + 0.0f;
+  out.y = (__ocml_native_cos_f32(v) * s) + 0.0f;
   return out;
 }
 
