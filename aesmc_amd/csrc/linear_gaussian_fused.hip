@@ -35,6 +35,7 @@ namespace aesmc {
 typedef float fz4 __attribute__((ext_vector_type(4)));
 typedef fz4 fz4_a4 __attribute__((aligned(4)));      // a 16-byte global access at 4-byte alignment (hardware: unaligned mode)
 
+constexpr int kFusedParticlePriority = 0;
 constexpr uint32_t kRunP = 128;                       // rows per window: two chunks of 64
 constexpr uint32_t kTabF = 4 * 2 * 4 * 16;            // floats per table slot: [window][row 0/1][p, q, g, y][16]
 
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
   uint32_t ln = lane, g = lane >> 4, n = lane & 15u;
   // the particle wavefronts are the launch's critical path (the noise wavefronts wait a fifth of their time at the
   // barrier): they win the arbitration for issue slots
-  __builtin_amdgcn_s_setprio(2);
+  if (kFusedParticlePriority != 0) __builtin_amdgcn_s_setprio(kFusedParticlePriority);
   float *scr_q = scratch + w * (2u * 64u * RS);
   float *scr_p = scr_q + 64u * RS;
   // the maps as matrix operands A[m = output j][k = input i]: lane holds W[n][4 s + g] of k-step s
