@@ -35,7 +35,6 @@ namespace aesmc {
 typedef float fz4 __attribute__((ext_vector_type(4)));
 typedef fz4 fz4_a4 __attribute__((aligned(4)));      // a 16-byte global access at 4-byte alignment (hardware: unaligned mode)
 
-constexpr int kFusedParticlePriority = 0;
 constexpr uint32_t kRunP = 128;                       // rows per window: two chunks of 64
 constexpr uint32_t kTabF = 4 * 2 * 4 * 16;            // floats per table slot: [window][row 0/1][p, q, g, y][16]
 
@@ -338,9 +337,9 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
   // (g, n, ln are refreshed through an opaque move per chunk: everything derived from the lane's index is loop-
   // invariant, and the compiler would otherwise hold dozens of LDS addresses in registers across the whole loop)
   uint32_t ln = lane, g = lane >> 4, n = lane & 15u;
-  // the particle wavefronts are the launch's critical path (the noise wavefronts wait a fifth of their time at the
-  // barrier): they win the arbitration for issue slots
-  if (kFusedParticlePriority != 0) __builtin_amdgcn_s_setprio(kFusedParticlePriority);
+  // (s_setprio for the particle wavefronts — measured with 2 and without: 120.6 against 120.6-121.1 us — is left out.
+  //  Also measured and not kept: both chunks of a window through every phase together — four chains per scalar
+  //  weight pair instead of two, a weight fetched once per item — needs more registers than 128: 45 spilled.)
   float *scr_q = scratch + w * (2u * 64u * RS);
   float *scr_p = scr_q + 64u * RS;
   // the maps as matrix operands A[m = output j][k = input i]: lane holds W[n][4 s + g] of k-step s
