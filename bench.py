@@ -468,7 +468,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         # + log-sum-exp kernel (K1)
         if "affine_normal_propagate_drawn" in kernels:
             key, label = "affine_normal_propagate_drawn", \
-                "affine_propagate_noise_kernel (K16: the resample gather, the proposal's noise and draw, the log-weight)"
+                "affine_propagate_fused_kernel (K16: the resample gather, the proposal's noise and draw, the log-weight)"
         elif "affine_normal_propagate_resampled" in kernels:
             key, label = "affine_normal_propagate_resampled", \
                 "affine_logweight_kernel, DRAW + GATHER (the resample gather inside the propagation launch: K3 + K15)"
@@ -809,7 +809,7 @@ def main(argv=None):
         "config": {"workload": head["workload"], "proposal": head["proposal"],
                    "callables": {"affine": "AffineNormal(source, weight, scale, offset), the proposal's with defer_draw=True: "
                                            "resampling gather, draw (noise from torch's Philox stream, inside the launch) "
-                                           "and log-weight in one kernel (K16; below 1M particles K15 through the "
+                                           "and log-weight in one kernel (K16; below 0.5M particles K15 through the "
                                            "ancestors behind a noise launch), a step's backward in one (K14, through the "
                                            "ancestors) (aesmc_amd/linear_gaussian.py)",
                                  "matmul": "Normal(source @ weight.T + offset, scale): PyTorch matmuls, then K6 / K5"
