@@ -105,6 +105,39 @@ def ancestor_index_reference_dtype(log_w, u):
     return idx
 
 
+def ancestor_index_float32_cdf(log_w, u):
+    """K2's opt-in mode for float32 rows (aesmc_set_float32_cdf(1)): `ancestor_index_reference_dtype` restated without
+    SciPy — the row's logsumexp formed in float64 and rounded to float32 (SciPy returns the float32 of a pairwise
+    float32 sum: the one step restated only to its result), np.exp on the float32 difference as the float32 of the
+    float64 exponential, np.cumsum's sequential float32 sum, the float32 division by the last entry, float64
+    positions (aesmc/inference.py:253-264, aesmc/math.py:21-26,48-49).  Returns (idx, flags) like `ancestor_index`."""
+    log_w = np.asarray(log_w, dtype=np.float32)
+    B, K = log_w.shape
+    u = np.asarray(u, dtype=np.float64).reshape(B)
+    idx = np.empty((B, K), dtype=np.int64)
+    flags = 0
+    pos_k = np.arange(0, K)
+    for b in range(B):
+        row = log_w[b]
+        if np.isnan(row).any():
+            flags |= FLAG_NAN_LOG_WEIGHT
+            idx[b] = K
+            continue
+        m = np.float64(row.max()) if K else 0.0
+        if not np.isfinite(m):
+            flags |= FLAG_DEGENERATE_ROW
+            idx[b] = K
+            continue
+        lse32 = np.float32(m + np.log(np.exp(row.astype(np.float64) - m).sum()))
+        with np.errstate(under="ignore"):
+            w32 = np.exp((row - lse32).astype(np.float64)).astype(np.float32)
+        c32 = np.cumsum(w32, dtype=np.float32)           # left to right, every partial sum rounded to float32
+        c32 = c32 / c32[-1]
+        pos = (u[b] + pos_k) / K
+        idx[b] = np.searchsorted(c32.astype(np.float64), pos, side="right")
+    return idx, flags
+
+
 def normal_logprob_sum(value, loc, scale):
     """K4: torch.distributions.Normal(loc, scale).log_prob(value) in PyTorch's operation order
     (normal.py log_prob: -((v - mu)**2) / (2 * var) - log(scale) - log(sqrt(2 pi))), summed over
