@@ -64,8 +64,6 @@ SIGNATURES = {
     "aesmc_ancestor_index": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "aesmc_ancestor_index_lds_max_particles": (_i64, []),
     "aesmc_workspace_bytes": (_sz, [_i64, _i64]),
-    "aesmc_set_float32_cdf": (_i32, [_i32]),
-    "aesmc_get_float32_cdf": (_i32, []),
     "aesmc_resample_gather": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "aesmc_resample_gather_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "aesmc_normal_logprob_sum": (_i32, [_i32, _vp, _vp, _vp, _vp] + [_i64] * 12 + [_vp]),

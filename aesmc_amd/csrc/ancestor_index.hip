@@ -22,9 +22,6 @@
 // division in exact rational arithmetic in tests/test_oracle.py).
 #include "common.hpp"
 
-#include <atomic>
-#include <type_traits>
-
 namespace aesmc {
 
 constexpr int kMaxThreads = 1024;
@@ -317,14 +314,7 @@ __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *
 // PAYLOAD = false: the instantiation without the tail (K2 alone, what a step whose propagation kernel fetches the rows
 // itself launches).  Without the copy's chunks in flight it is held to 64 registers: eight wavefronts per SIMD, so four
 // 512-lane workgroups per CU and 1024 batch rows resident at once instead of 768 and a second round.
-//
-// SEQ32 (float32 rows only, opt-in: aesmc_set_float32_cdf): the CDF in the REFERENCE's own arithmetic instead of
-// float64 — w_j = float32(exp(lw_j - lse)) with lse rounded to float32, np.cumsum's left-to-right float32 running sum,
-// a float32 division by its last entry (aesmc/inference.py:253-258, aesmc/math.py:21-26,48-49) — so that the rounding of
-// the reference's CDF, which moves ~1e-3 of its float32 indices against the float64 contract, is reproduced and not
-// merely bounded.  The running sum is inherently serial: it walks the row lane by lane (a lane's C adds under a one-lane
-// EXEC mask, the carry passed on through v_readlane), wavefront after wavefront.
-template <typename T, int C, bool PAYLOAD, bool SEQ32 = false>
+template <typename T, int C, bool PAYLOAD>
 __global__ __launch_bounds__(kMaxThreads, (PAYLOAD || C > 8) ? 1 : 8) void ancestor_index_inv_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx,
     int32_t *flags, int K, T *__restrict__ out_lse, StepPayload payload, int B, int parts,
@@ -456,35 +446,6 @@ __global__ __launch_bounds__(kMaxThreads, (PAYLOAD || C > 8) ? 1 : 8) void ances
   // by-product: logsumexp of the row (the step's contribution to log Z), float64 inside
   if (out_lse != nullptr && tid == 0 && part == 0) out_lse[row] = (T)(dm + ::log(total));
 
-  // ---- SEQ32: the reference's float32 CDF, in its order ------------------------------------------
-  float c32[SEQ32 ? C : 1];
-  float total32 = 1.0f;
-  if constexpr (SEQ32) {
-    const float lse32 = (float)(dm + ::log(total));              // scipy's logsumexp, rounded as its float32 result is
-#pragma unroll
-    for (int i = 0; i < C; ++i)   // (the short exp takes the few-ulp positive arguments a row with one heavy particle gives)
-      c32[i] = (j0 + i < K) ? (float)exp_nonpositive((double)((float)v[i] - lse32)) : 0.0f;
-    float *carry = reinterpret_cast<float *>(scratch + 60);
-    float run32 = 0.0f;
-    for (int w = 0; w < nwaves; ++w) {
-      if (wave == w) {
-        if (w > 0) run32 = *carry;
-#pragma unroll 1
-        for (int l = 0; l < kWave; ++l) {
-          if (lane == l) {
-            c32[0] = run32 + c32[0];
-#pragma unroll
-            for (int i = 1; i < C; ++i) c32[i] = c32[i - 1] + c32[i];
-          }
-          run32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c32[C - 1]), l));
-        }
-        if (lane == 0) *carry = run32;
-      }
-      __syncthreads();
-    }
-    total32 = *carry;          // entries past K - 1 added +0: this is c[K-1], the row's maximum
-  }
-
   // ---- first[j] = min{ k : (u + k) / K >= c[j] } ---------------------------------------------------
   const double dK = (double)K;
   const double inv_K = 1.0 / dK;
@@ -492,9 +453,7 @@ __global__ __launch_bounds__(kMaxThreads, (PAYLOAD || C > 8) ? 1 : 8) void ances
 #pragma unroll
   for (int i = 0; i < C; ++i) {
     if (j0 + i < K) {
-      double c;
-      if constexpr (SEQ32) c = (double)(c32[i] / total32);      // the reference's float32 entry, compared in float64
-      else c = divide_with_reciprocal(base + s[i], total, inv_total);
+      const double c = divide_with_reciprocal(base + s[i], total, inv_total);
       // c <= (u + k) / K  <=>  k >= c K - u, up to the rounding of the position and of this
       // product: both are below K * 2^-52, so unless c K - u sits within K * 1e-15 of an integer
       // its ceiling IS the answer; only that rare case is settled against the exact positions.
@@ -651,34 +610,6 @@ static int pick_parts(int64_t B, int nt, bool has_payload) {
   return (B <= 256 && limit >= 2) ? 2 : 1;
 }
 
-// How float32 rows build their CDF: 0 = float64 inside (the K2 contract, independent of the scan's order), 1 = the
-// reference's own float32 arithmetic in its own order (the SEQ32 instantiation above).  Process-wide, set through
-// aesmc_set_float32_cdf or AESMC_FLOAT32_CDF=reference in the environment; float64 rows are not affected (their
-// contract already is the reference's result), nor are rows beyond the LDS kernel's range.
-static std::atomic<int> g_float32_cdf{[] {
-  const char *v = getenv("AESMC_FLOAT32_CDF");
-  return (v != nullptr && (v[0] == 'r' || v[0] == '1')) ? 1 : 0;
-}()};
-
-template <typename T, int C, bool PAYLOAD, bool SEQ32>
-static int launch_inv_as(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B, int64_t K,
-                         hipStream_t s, void *out_lse, const StepPayload &payload, int32_t *child_end, int nt, int parts,
-                         size_t lds) {
-  // raise the dynamic-LDS cap once per device and instantiation (a process may drive several GPUs)
-  static bool attr_set[64] = {};
-  int device = 0;
-  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return AESMC_ERR_LAUNCH;
-  if (!attr_set[device]) {
-    if (hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C, PAYLOAD, SEQ32>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return AESMC_ERR_LAUNCH;
-    attr_set[device] = true;
-  }
-  hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C, PAYLOAD, SEQ32>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
-                     (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts, child_end);
-  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
-}
-
 template <typename T, int C>
 static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t *flags, int64_t B,
                       int64_t K, hipStream_t s, void *out_lse = nullptr,
@@ -686,17 +617,27 @@ static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t 
                       int32_t *child_end = nullptr) {
   const int nt = pick_threads(K, C);
   const size_t lds = (size_t)kScratchDoubles * sizeof(double) + (size_t)(nt * C + nt + 8) * sizeof(int);
+  // raise the dynamic-LDS cap once per device and instantiation (a process may drive several GPUs)
+  static bool attr_set[64] = {};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return AESMC_ERR_LAUNCH;
+  if (!attr_set[device]) {
+    if (hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ancestor_index_inv_kernel<T, C, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return AESMC_ERR_LAUNCH;
+    attr_set[device] = true;
+  }
   int parts = pick_parts(B, nt, payload.src != nullptr);
   while (parts > 1 && (nt % parts != 0 || B * parts > 0x7fffffffLL)) parts /= 2;
-  if constexpr (std::is_same<T, float>::value) {
-    if (g_float32_cdf.load(std::memory_order_relaxed) == 1)
-      return payload.src != nullptr
-                 ? launch_inv_as<T, C, true, true>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end, nt, parts, lds)
-                 : launch_inv_as<T, C, false, true>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end, nt, parts, lds);
-  }
-  return payload.src != nullptr
-             ? launch_inv_as<T, C, true, false>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end, nt, parts, lds)
-             : launch_inv_as<T, C, false, false>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end, nt, parts, lds);
+  if (payload.src != nullptr)
+    hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C, true>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
+                       (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts, child_end);
+  else
+    hipLaunchKernelGGL((ancestor_index_inv_kernel<T, C, false>), dim3((unsigned)(B * parts)), dim3(nt), lds, s,
+                       (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, payload, (int)B, parts, child_end);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
 template <typename T>
@@ -730,14 +671,6 @@ static int launch(const void *log_w, const double *u, int64_t *idx, int32_t *fla
 }  // namespace aesmc
 
 extern "C" int64_t aesmc_ancestor_index_lds_max_particles(void) { return aesmc::kInvMaxParticles; }
-
-extern "C" int aesmc_set_float32_cdf(int mode) {
-  if (mode != 0 && mode != 1) return AESMC_ERR_INVALID_ARGUMENT;
-  aesmc::g_float32_cdf.store(mode, std::memory_order_relaxed);
-  return AESMC_OK;
-}
-
-extern "C" int aesmc_get_float32_cdf(void) { return aesmc::g_float32_cdf.load(std::memory_order_relaxed); }
 
 extern "C" int aesmc_test_set_step_parts(int parts) {
   if (parts < 0 || (parts & (parts - 1)) != 0) return AESMC_ERR_INVALID_ARGUMENT;

@@ -60,22 +60,6 @@ def lazy_gather(enabled):
         _LAZY_GATHER = previous
 
 
-def set_float32_cdf(mode):
-    """How float32 log-weights become the CDF systematic resampling inverts (process-wide; float64 log-weights are
-    not affected).  'float64' (default): float64 inside, independent of summation order — within the stated bound of
-    the reference's float32 indices.  'reference': the reference's own float32 arithmetic in its own order
-    (aesmc/inference.py:253-258: np.exp(lw - logsumexp), np.cumsum, division by the row maximum), a serial pass per
-    row that reproduces the rounding of its CDF.  Returns the previous mode.  (include/aesmc_hip.h:
-    aesmc_set_float32_cdf.)"""
-    if mode not in ("float64", "reference"):
-        raise ValueError("float32 CDF mode must be 'float64' or 'reference', got {}".format(mode))
-    from . import _lib
-    lib = _lib.load()
-    previous = "reference" if lib.aesmc_get_float32_cdf() == 1 else "float64"
-    _lib.check(lib.aesmc_set_float32_cdf(1 if mode == "reference" else 0), "aesmc_set_float32_cdf")
-    return previous
-
-
 _FOLD_GATHER_BACKWARD = _os.environ.get("AESMC_FOLD_GATHER_BACKWARD", "1") != "0"      # measurement knob
 
 

@@ -47,8 +47,8 @@ extern "C" {
  *   100 (0.1.0)  rounds 1-2.
  *   200 (0.2.0)  removed aesmc_particle_mlp / aesmc_particle_mlp_max_hidden (the user's MLP stays in PyTorch);
  *                aesmc_set_step_parts / aesmc_set_sorted_backward_kernel became test hooks outside this header
- *                (aesmc_test_*); added aesmc_set_float32_cdf / aesmc_get_float32_cdf; aesmc_affine_normal_propagate_drawn
- *                keeps its signature and now runs the fused launch (gather + noise + draw + log-weight terms). */
+ *                (aesmc_test_*); aesmc_affine_normal_propagate_drawn keeps its signature and now runs the fused launch
+ *                (gather + noise + draw + log-weight terms in one kernel). */
 int aesmc_version(void);
 const char *aesmc_target_arch(void); /* "gfx950" */
 
@@ -113,20 +113,6 @@ int aesmc_ancestor_index(int dtype, const void *log_w, const double *u, int64_t 
                          void *stream);
 int64_t aesmc_ancestor_index_lds_max_particles(void);
 size_t aesmc_workspace_bytes(int64_t B, int64_t K);
-
-/*
- * How FLOAT32 rows build the CDF above (process-wide; float64 rows and K beyond
- * aesmc_ancestor_index_lds_max_particles() are not affected).  mode 0, the default: float64 inside, as stated above.
- * mode 1: the reference's own float32 arithmetic in its own order — w[j] = float32(exp(lw[j] - lse)) with the row's
- * logsumexp rounded to float32, np.cumsum's left-to-right float32 running sum, a float32 division by its last entry,
- * compared with the float64 positions (aesmc/inference.py:253-264 with aesmc/math.py:21-26,48-49 on float32 input).
- * It reproduces the rounding of the reference's float32 CDF (tests/test_gpu_round4.py counts the indices that still
- * differ: scipy's pairwise float32 sum inside logsumexp is the part restated only to its float32 result), at the
- * price of a serial pass over the row.  AESMC_FLOAT32_CDF=reference in the environment selects mode 1 at load.
- * Returns AESMC_ERR_INVALID_ARGUMENT for another mode.
- */
-int aesmc_set_float32_cdf(int mode);
-int aesmc_get_float32_cdf(void);
 
 /*
  * K3 — resample gather:  dst[b,k,:] = src[b, idx[b,k], :]  with `row_bytes` contiguous bytes per

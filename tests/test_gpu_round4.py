@@ -205,125 +205,3 @@ def test_the_fused_launch_flags_and_survives_ancestors_out_of_range(kernels, hip
     valid = torch.ones(B, K, dtype=torch.bool, device=hip_device)
     valid[1, 17] = valid[2, 4000] = valid[4, 63] = False
     assert torch.equal(bad_x[valid], clean_x[valid]) and torch.equal(bad_lw[valid], clean_lw[valid])
-
-
-# ---- K2's opt-in float32 CDF in the reference's order --------------------------------------------
-@pytest.fixture
-def float32_cdf_reference():
-    from aesmc_amd import inference
-    previous = inference.set_float32_cdf("reference")
-    yield
-    inference.set_float32_cdf(previous)
-
-
-def _dev(array, device):
-    return torch.from_numpy(np.ascontiguousarray(array)).to(device)
-
-
-@pytest.mark.parametrize("shape,scale", [((1, 1), 1.0), ((3, 7), 1.0), ((5, 64), 3.0), ((4, 129), 1.0), ((6, 1000), 1.0),
-                                         ((3, 1024), 5.0), ((64, 4096), 1.0), ((2, 8191), 2.0), ((2, 16384), 1.0),
-                                         ((2, 32768), 1.0), ((300, 50), 30.0)])
-def test_float32_cdf_in_the_reference_order_equals_its_oracle(kernels, hip_device, float32_cdf_reference, shape, scale):
-    """aesmc_set_float32_cdf(1): the indices are those of oracle/kernel_oracle.py:ancestor_index_float32_cdf bit for
-    bit — float32 weights, a left-to-right float32 running sum, a float32 division — including rows with -inf
-    entries, one heavy particle (exp of a few-ulp positive argument) and weights that underflow float32; float64 rows
-    keep the float64 contract under the same setting."""
-    from oracle import kernel_oracle
-    rng = np.random.RandomState(shape[1] + 1)
-    log_w = (scale * rng.randn(*shape)).astype(np.float32)
-    if shape[1] > 4:
-        log_w[0, 1] = -np.inf
-        log_w[-1, :] = -200.0
-        log_w[-1, shape[1] // 2] = 3.0                       # the rest underflows next to it
-    u = rng.uniform(size=shape[0])
-    kernels.read_flags(hip_device)
-    idx = kernels.ancestor_index(_dev(log_w, hip_device), _dev(u, hip_device)).cpu().numpy()
-    want, want_flags = kernel_oracle.ancestor_index_float32_cdf(log_w, u)
-    np.testing.assert_array_equal(idx, want)
-    assert kernels.read_flags(hip_device) == want_flags
-    wide = log_w.astype(np.float64)
-    idx64 = kernels.ancestor_index(_dev(wide, hip_device), _dev(u, hip_device)).cpu().numpy()
-    np.testing.assert_array_equal(idx64, kernel_oracle.ancestor_index(wide, u)[0])
-
-
-def test_float32_cdf_mode_flags_special_rows_like_the_default(kernels, hip_device, float32_cdf_reference):
-    from oracle import kernel_oracle
-    log_w = np.random.RandomState(3).randn(4, 300).astype(np.float32)
-    log_w[1, 7] = np.nan
-    log_w[2, :] = -np.inf
-    u = np.array([0.1, 0.2, 0.3, 0.4])
-    kernels.read_flags(hip_device)
-    idx = kernels.ancestor_index(_dev(log_w, hip_device), _dev(u, hip_device)).cpu().numpy()
-    want, want_flags = kernel_oracle.ancestor_index_float32_cdf(log_w, u)
-    np.testing.assert_array_equal(idx, want)
-    assert kernels.read_flags(hip_device) == want_flags != 0
-
-
-@pytest.mark.parametrize("name", ["resampler_k1000_s1_f32", "resampler_k4096_f32", "resampler_k16384_f32"])
-def test_float32_cdf_mode_against_the_reference_fixtures(kernels, hip_device, name, capsys):
-    """The experiment's criterion on the resampler fixtures captured from the reference: indices that differ from
-    the reference's own drop at least tenfold against the float64 CDF (21 -> 1 of 16 384 at K=4096, 382 -> 8 of 65 536
-    at K=16384 when written), and what is left sits where SciPy's float32 logsumexp / NumPy's float32 exp round
-    differently from their float64 restatement."""
-    from aesmc_amd import inference
-    from tests.golden_io import Golden
-    case = Golden(name)
-    log_w, u = case["log_weight"], case["uniform"].reshape(-1)
-    default = kernels.ancestor_index(_dev(log_w, hip_device), _dev(u, hip_device)).cpu().numpy()
-    previous = inference.set_float32_cdf("reference")
-    try:
-        ordered = kernels.ancestor_index(_dev(log_w, hip_device), _dev(u, hip_device)).cpu().numpy()
-    finally:
-        inference.set_float32_cdf(previous)
-    before, after = int((default != case["out_idx"]).sum()), int((ordered != case["out_idx"]).sum())
-    with capsys.disabled():
-        print("\n[float32 cdf] {}: indices differing from the reference's: float64 CDF {}, reference-order float32 CDF {} "
-              "of {}".format(name, before, after, default.size))
-    assert before == case.meta["mismatches_vs_float64_cdf"]
-    assert after * 10 <= max(before, 9)
-
-
-@pytest.mark.parametrize("name", ["lgssm10d_k1024_smc_f32", "lgssm10d_k4096_smc_f32", "lgssm3d_smc_f32"])
-def test_float32_cdf_mode_on_the_reference_runs_teacher_forced(hip_device, float32_cdf_reference, name, capsys):
-    """The same on whole float32 SMC runs of the reference replayed draw for draw: teacher-forced flips 73-76 -> 5 of
-    73 728 at K=4096 (the kill criterion was <= 7), and the free-running log Z then lands within 1e-3 of the
-    reference's, where the float64 CDF's first flip moves it by 4e-3."""
-    from aesmc_amd import state
-    from aesmc_amd.testing import parity
-    from tests.golden_io import Golden
-    case = Golden(name)
-    parts, _ = case.build_parts(state, hip_device, affine=True)
-    steps = case.meta["num_timesteps"] - 1
-    reference = {"log_weights": case.series("out_log_weights"), "indices": case.series("out_idx")[:steps],
-                 "lml": case["out_lml"]}
-    got = parity.float32_fixture_parity(parts, case.observations(hip_device), case.meta["num_particles"], case.tape(),
-                                        reference)
-    flips = sum(got["teacher_forced_flips_per_step"])
-    with capsys.disabled():
-        print("\n[float32 cdf] {}: teacher-forced flips {} of {}, free-running rel dlogZ {:.2e}, first flip at step {}".format(
-            name, flips, steps * reference["indices"][0].size, got["free_running_rel_dlogZ"],
-            got["free_running_first_flip_step"]))
-    assert flips <= {"lgssm10d_k4096_smc_f32": 25, "lgssm10d_k1024_smc_f32": 2, "lgssm3d_smc_f32": 0}[name]
-    assert got["teacher_forced_max_rel_dlogw"] <= 5e-6
-
-
-@pytest.mark.parametrize("B,K,d", [(5, 1000, 3), (130, 4096, 10), (300, 640, 4)])
-def test_float32_cdf_mode_in_the_fused_step(kernels, hip_device, float32_cdf_reference, B, K, d):
-    """The resampling STEP (indices + logsumexp + payload rows + children ranges in one launch) under the same
-    setting: same indices as the stand-alone launch, rows gathered through them, ranges consistent with them."""
-    from oracle import kernel_oracle
-    rng = np.random.RandomState(B + K)
-    log_w = (2.0 * rng.randn(B, K)).astype(np.float32)
-    u = rng.uniform(size=B)
-    value = rng.randn(B, K, d).astype(np.float32)
-    want, _ = kernel_oracle.ancestor_index_float32_cdf(log_w, u)
-    idx, lse, moved = kernels.resample_step(_dev(log_w, hip_device), _dev(u, hip_device), _dev(value, hip_device),
-                                            want_lse=True)
-    np.testing.assert_array_equal(idx.cpu().numpy(), want)
-    np.testing.assert_array_equal(moved.cpu().numpy(), kernel_oracle.gather(value, want)[0])
-    np.testing.assert_allclose(lse.cpu().numpy(), kernel_oracle.logweight_lse(log_w)[1], rtol=2e-6, atol=2e-6)
-    idx2, _, _ = kernels.resample_step(_dev(log_w, hip_device), _dev(u, hip_device), None, want_child_end=True)
-    np.testing.assert_array_equal(idx2.cpu().numpy(), want)
-    ends = idx2._aesmc_child_end.cpu().numpy()
-    counts = np.stack([np.bincount(want[b], minlength=K) for b in range(B)])
-    np.testing.assert_array_equal(ends, np.cumsum(counts, axis=1))
