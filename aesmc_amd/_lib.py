@@ -107,6 +107,7 @@ SIGNATURES = {
 TEST_HOOKS = {
     "aesmc_test_set_step_parts": (_i32, [_i32]),
     "aesmc_test_set_sorted_backward_kernel": (_i32, [_i32]),
+    "aesmc_test_set_step_backward": (_i32, [_i32, _i32]),
 }
 
 _lib = None

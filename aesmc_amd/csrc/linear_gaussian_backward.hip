@@ -2,7 +2,7 @@
 // for the forward kernels, the arithmetic contract and the reference call sites).  The weight gradients are
 // contractions over the particle index and run on the matrix cores; everything per particle stays on the
 // vector ALUs, one lane = one particle.
-#include "linear_gaussian.hpp"
+#include "linear_gaussian_backward.hpp"
 namespace aesmc {
 
 // ---- per-batch-row sums of a tile (offset gradients) -------------------------------------------------------
@@ -47,29 +47,6 @@ __device__ __forceinline__ void lg_row_sums(const T *__restrict__ tile, uint32_t
   }
 }
 
-// ---- K11: the adjoint of an affine location ----------------------------------------------------------
-// The weight gradient  dW[j][i] = sum over particles of g[p][j] x[p][i]  is a contraction over the
-// particle index: it runs on the matrix cores (v_mfma_*_16x16x4: A = 4 particles x 16 values of g,
-// B = 4 particles x 16 values of x, f32 / f64 inputs and accumulation — exact IEEE fma chains), which
-// keeps the 16 x 16 accumulator in four registers per lane instead of d^2 per particle-owning lane.
-template <typename T> struct Mfma;
-template <> struct Mfma<float> {
-  typedef float Acc __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ Acc fma(float a, float b, Acc c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
-};
-template <> struct Mfma<double> {
-  typedef double Acc __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ Acc fma(double a, double b, Acc c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
-};
-
-constexpr int kLgRecord = 256;        // one 16 x 16 partial per matrix and workgroup
-constexpr int kLgMaxGrid = 1024;      // most persistent workgroups of the reducing kernels (one record each)
 
 // acc[j][i] += sum_{p < np} tg[p][j] * tx[p][i] over a staged tile; the four wavefronts take particles
 // 4 w .. 4 w + 3 of every group of 16 (fixed assignment: the sums are reproducible).
@@ -155,58 +132,6 @@ __device__ __forceinline__ void lg_outer_accumulate_own(const T *__restrict__ tg
       ex += 4 * step_x;
     }
   }
-}
-
-// A tile that lies inside one batch row needs no row bookkeeping: its column sums are what the ONES
-// accumulate gathered in column 15 since the last flush.  Each wavefront writes its 16 sums to slot
-// `wave` of the tile's row-sum record and clears them; the finishing launch adds the four slots (same
-// test there: lg_single_row).  No barrier, no pass over the tile.
-__host__ __device__ __forceinline__ bool lg_single_row(int64_t n0, uint32_t np, uint32_t K) {
-  return (uint32_t)(n0 % K) + np <= K;
-}
-// (`slot`: 4 x 16 values in LDS, the four wavefronts' sums of one term; lg_store_column_sums adds them at the tile's end)
-template <typename T>
-__device__ __forceinline__ void lg_flush_column_sums(typename Mfma<T>::Acc &acc, T *__restrict__ slot, bool keep) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((lane & 15) == 15) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (keep) slot[wave * 16 + Mfma<T>::row(lane, r)] = acc[r];
-      acc[r] = T(0);
-    }
-  }
-}
-// Behind the barrier that ends the tile: the tile's record of each wanted term, record[j] = the four wavefronts' sums
-// added in wavefront order (what the finishing launch used to add, from four times the bytes).
-template <typename T>
-__device__ __forceinline__ void lg_store_column_sums(const T *__restrict__ slots, T *__restrict__ records, int terms) {
-  if (threadIdx.x < 48) {
-    const int t = threadIdx.x >> 4, j = threadIdx.x & 15;
-    if ((terms >> t) & 1) {
-      const T *c = slots + t * 64 + j;
-      records[t * (kLgRowsMax * 16) + j] = ((c[0] + c[16]) + c[32]) + c[48];
-    }
-  }
-}
-
-__device__ __forceinline__ void lg_wave_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-}
-
-// The workgroup's four partial accumulators summed (wavefront 0 .. 3 in turn) into record[0 .. 255],
-// element j * 16 + i.  `scratch` holds 4 x 256 values.
-template <typename T>
-__device__ __forceinline__ void lg_outer_publish(const typename Mfma<T>::Acc &acc, T *__restrict__ scratch,
-                                                 T *__restrict__ record) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) scratch[wave * 256 + Mfma<T>::row(lane, r) * 16 + (lane & 15)] = acc[r];
-  __syncthreads();
-  const int e = threadIdx.x;
-  record[e] = ((scratch[e] + scratch[256 + e]) + scratch[512 + e]) + scratch[768 + e];
-  __syncthreads();
 }
 
 template <typename T, int DP, int PPL>
@@ -307,29 +232,6 @@ __device__ __forceinline__ void lg_u_ready(bool stored) {
   else lg_wave_fence();
 }
 
-struct LgBackwardOut {
-  void *gxprev, *gx, *up, *ug, *uq, *ws;
-  void *rows;        // nullptr, or the tiles' row-sum records [tile][3 terms p, g, q][kLgRowsMax][16]
-  int row_terms;     // bit 0 / 1 / 2: term p / g / q wants its row sums
-  const void *gx_in; // step kernel only: the gradient that arrives at x_t from later steps, or nullptr
-  int want_scale_q;  // step kernel only: the proposal scale's gradient is wanted (costs the proposal's location)
-  LgGather gat;      // step kernel only: `xprev` is the un-resampled latent, its rows fetched through gat.idx
-  // step kernel only: the NEXT step's gradient with respect to the rows it resampled from x_t, one row per child
-  // [B,K,dx], and where each particle's children end (child_end[b,k] = number of children of particles 0..k of row b):
-  // torch.gather's backward (the sum of a particle's children) is formed here, where it is consumed
-  const void *child_grad;
-  const int32_t *child_end;
-  int child_stage;   // a fourth LDS tile exists: the tile's children rows — one contiguous block — are staged through it
-  int child_align;   // rows per 16 bytes' worth of alignment: a staged block starts at a multiple of this many rows
-  // step kernel only: the records an earlier launch with the same parameters left in ITS workspace (aesmc_affine_chain):
-  // workgroup w adds records w, w + grid, ... to its own, so the weights' gradients of a run of steps are finished once
-  const void *carry;
-  int carry_records;
-};
-
-constexpr int kLgChildLimit = 32;   // children a lane sums by itself; longer runs (a collapsed system) take the wavefront
-                                    // (8: the bench shape's healthy ancestry 338 -> 348 us, a collapsed one 456 -> 437)
-constexpr int kLgChildTrip = 1;     // of them per trip out of the staged block (2: the same time, ten more registers; 4: slower)
 
 template <typename T, int DP, int PPL>
 __global__ __launch_bounds__(kLgBlock, (PPL == 2 || sizeof(T) == 8) ? 2 : 3) void affine_logweight_backward_kernel(
@@ -1177,11 +1079,15 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
   static const int forced = [] { const char *v = getenv("AESMC_LG_BWD_PPL"); return v != nullptr ? atoi(v) : 0; }();   // measurement knob
+  // rows of ten float32 values, tiles inside one batch row, an nn.Linear's weights: the second form of the step kernel
+  bool rows_form = false;
+  if constexpr (sizeof(T) == 4) rows_form = step && N % kLgBlock == 0 && affine_step_backward_rows_covers(mp, mg, mq, B, K);
   int ppl = (sizeof(T) == 4 && dp <= 12 && !lg_few_tiles(N)) ? 2 : 1;
   // the step kernel is latency-bound: one particle per lane and three workgroups per CU where the registers
   // allow it without spills (d = 10: 322 -> 300 us; d = 8: no difference; d = 12: 448 -> 477, kept at two)
   if (step && dp <= 10) ppl = 1;
   if (forced == 1 || forced == 2) ppl = (sizeof(T) == 4 && dp <= 12) ? forced : 1;
+  if (rows_form) ppl = 1;
   size_t lds = 0;
   for (; ppl >= 1; --ppl) {
     const size_t tp = (size_t)kLgBlock * ppl;
@@ -1202,7 +1108,10 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
     }
   }
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
-  const int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, (ppl == 2 || sizeof(T) == 8) ? 2 : (step ? LG_STEP_WAVES : 3)), kLgMaxGrid);   // what the registers allow
+  const int forced_grid = step ? affine_step_backward_forced_grid() : 0;      // test hook (aesmc_test_set_step_backward)
+  int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, (ppl == 2 || sizeof(T) == 8) ? 2 : (step ? LG_STEP_WAVES : 3)), kLgMaxGrid);   // what the registers allow
+  if (rows_form) grid = (int)affine_step_backward_rows_grid(B, K);
+  if (forced_grid > 0) grid = (int)std::min<int64_t>(std::min<int64_t>(forced_grid, tiles), kLgMaxGrid);
   const int row_terms = (o->grad_offset_p != nullptr ? 1 : 0) | (o->grad_offset_g != nullptr ? 2 : 0) |
                         (o->grad_offset_q != nullptr ? 4 : 0);
   const size_t need = lg_record_elems() + (row_terms != 0 ? lg_row_elems(N, 3) : 0);
@@ -1231,7 +1140,17 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
       lg_map(mq), static_cast<const T *>(sp), static_cast<const T *>(sg), static_cast<const T *>(sq),               \
       static_cast<const T *>(lw), static_cast<const T *>(lse), static_cast<const T *>(grad_lse),                    \
       static_cast<const T *>(grad_lw), out, N, (uint32_t)K
-  if (step && dx == dp && dy == dp) {
+  if (rows_form) {
+    if constexpr (sizeof(T) == 4) {
+      const int status = launch_affine_step_backward_rows(
+          static_cast<const float *>(xprev), static_cast<const float *>(x), static_cast<const float *>(y), y_sb, lg_map(mp),
+          lg_map(mg), lg_map(mq), static_cast<const float *>(sp), static_cast<const float *>(sg),
+          static_cast<const float *>(sq), static_cast<const float *>(lw), static_cast<const float *>(lse),
+          static_cast<const float *>(grad_lse), static_cast<const float *>(grad_lw), out, N, (uint32_t)K, (unsigned)grid,
+          stream);
+      if (status != AESMC_OK) return status;
+    }
+  } else if (step && dx == dp && dy == dp) {
     LG_DISPATCH(affine_step_backward_exact, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);
   } else if (step) {
     LG_DISPATCH(affine_step_backward_any, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);

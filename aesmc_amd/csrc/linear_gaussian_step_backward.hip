@@ -1,0 +1,582 @@
+// K14 for rows of ten float32 values (the BASELINE shapes): the whole backward of a linear-Gaussian SMC step whose x_t
+// is the proposal's reparameterised draw — affine_step_backward_kernel's arithmetic (linear_gaussian_backward.hip: the
+// same fma chains, the same matrix-core accumulation order, the same records: every output equal bit for bit when the
+// two run on the same grid), rearranged the way the forward step was (linear_gaussian_fused.hip):
+//   * a wavefront works on its own 64 particles from the rows' arrival to the gradient's store: the rows of x_{t-1}
+//     (through the ancestors) and of x_t come straight into the lane's registers, one tile ahead; what the matrix cores
+//     need transposed (u, x) goes through an LDS area only this wavefront touches — no workgroup barrier inside a tile
+//     (one at its end, where the four wavefronts' column sums meet, when an offset's gradient is wanted);
+//   * the weights are SCALAR operands (s_load + v_fmac_f32 v, s, v): the launch's maps are the same for every particle,
+//     so neither LDS reads nor vector registers are spent on them; offsets, the observation, lse and its gradient are
+//     per batch row, a tile lies inside one row (K a multiple of 256): scalar loads as well;
+//   * the children's rows (the gather's backward, folded in) are one contiguous block per WAVEFRONT, sent for a tile
+//     ahead by loads that write LDS directly; a lane sums its run out of it in k order.
+// Reference: autograd of aesmc/state.py:114-155,179 and aesmc/inference.py:108-130 for one timestep.
+#include "linear_gaussian_backward.hpp"
+
+#include <atomic>
+
+namespace aesmc {
+
+typedef const float __attribute__((address_space(4))) sb_cfloat;
+typedef float sb_f2 __attribute__((ext_vector_type(2)));
+typedef float sb_f4 __attribute__((ext_vector_type(4)));
+typedef sb_f4 sb_f4_a4 __attribute__((aligned(4)));      // a 16-byte global access at 4-byte alignment (hardware: unaligned mode)
+typedef sb_f2 sb_f2_a4 __attribute__((aligned(4)));
+
+constexpr int kSbD = 10;                 // the rows' extent
+constexpr int kSbChildRows = 96;         // rows of a wavefront's staged block of children (mean 64; what does not fit: from HBM)
+constexpr int kSbTile = 64 * kSbD + 16;  // a wavefront's u / x area (+16: the matrix-core operand reads run past a row's end)
+constexpr int kSbWave = 2 * kSbTile + kSbChildRows * kSbD;      // floats per wavefront
+constexpr int kSbSlots = 2 * 192;        // the tile's column sums (three terms x four wavefronts x 16), two tiles' worth
+constexpr size_t kSbLds = sizeof(float) * (kSbSlots + 4 * (size_t)kSbWave);
+constexpr int kSbPerCu = 3;              // workgroups per CU (= wavefronts per SIMD) the registers allow
+static_assert(kSbLds * kSbPerCu <= 160 * 1024, "LDS of the resident workgroups");
+
+// acc_j += W[j][i] x_i, two outputs' chains side by side, five inputs per statement (see linear_gaussian_fused.hip)
+__device__ __forceinline__ void sb_fmac_s5x2(float &a0, float &a1, const float *w0, const float *w1, const float *x) {
+  asm("v_fmac_f32 %0, %2, %12\n\tv_fmac_f32 %1, %7, %12\n\t"
+      "v_fmac_f32 %0, %3, %13\n\tv_fmac_f32 %1, %8, %13\n\t"
+      "v_fmac_f32 %0, %4, %14\n\tv_fmac_f32 %1, %9, %14\n\t"
+      "v_fmac_f32 %0, %5, %15\n\tv_fmac_f32 %1, %10, %15\n\t"
+      "v_fmac_f32 %0, %6, %16\n\tv_fmac_f32 %1, %11, %16"
+      : "+v"(a0), "+v"(a1)
+      : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w0[3]), "s"(w0[4]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "s"(w1[3]),
+        "s"(w1[4]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]));
+}
+// the adjoint's step: acc_i += W[j][i] u_j then acc_i += W[j+1][i] u_{j+1} for five i — rows j, j + 1 of W as they lie
+__device__ __forceinline__ void sb_fmac_t5x2(float *acc, const float *w0, const float *w1, float u0, float u1) {
+  asm("v_fmac_f32 %0, %5, %15\n\tv_fmac_f32 %1, %6, %15\n\tv_fmac_f32 %2, %7, %15\n\tv_fmac_f32 %3, %8, %15\n\t"
+      "v_fmac_f32 %4, %9, %15\n\t"
+      "v_fmac_f32 %0, %10, %16\n\tv_fmac_f32 %1, %11, %16\n\tv_fmac_f32 %2, %12, %16\n\tv_fmac_f32 %3, %13, %16\n\t"
+      "v_fmac_f32 %4, %14, %16"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4])
+      : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w0[3]), "s"(w0[4]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "s"(w1[3]),
+        "s"(w1[4]), "v"(u0), "v"(u1));
+}
+
+__device__ __forceinline__ float sb_uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// a row of ten values at 8-byte alignment
+__device__ __forceinline__ void sb_load_row(const float *__restrict__ src, float (&v)[kSbD]) {
+  const sb_f4 a = *reinterpret_cast<const sb_f4_a4 *>(src);
+  const sb_f4 b = *reinterpret_cast<const sb_f4_a4 *>(src + 4);
+  const sb_f2 c = *reinterpret_cast<const sb_f2_a4 *>(src + 8);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  v[8] = c[0]; v[9] = c[1];
+}
+__device__ __forceinline__ void sb_store_row(float *__restrict__ dst, const float (&v)[kSbD]) {
+  sb_f4 a, b;
+  sb_f2 c;
+  a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+  b[0] = v[4]; b[1] = v[5]; b[2] = v[6]; b[3] = v[7];
+  c[0] = v[8]; c[1] = v[9];
+  *reinterpret_cast<sb_f4_a4 *>(dst) = a;
+  *reinterpret_cast<sb_f4_a4 *>(dst + 4) = b;
+  *reinterpret_cast<sb_f2_a4 *>(dst + 8) = c;
+}
+// the same row in LDS: 8-byte pieces (rows of 40 bytes)
+__device__ __forceinline__ void sb_lds_row(const float *row, float (&v)[kSbD]) {
+#pragma unroll
+  for (int j = 0; j < kSbD / 2; ++j) {
+    const sb_f2 q = reinterpret_cast<const sb_f2 *>(row)[j];
+    v[2 * j] = q[0];
+    v[2 * j + 1] = q[1];
+  }
+}
+__device__ __forceinline__ void sb_lds_put(float *row, const float (&v)[kSbD]) {
+#pragma unroll
+  for (int j = 0; j < kSbD / 2; ++j) {
+    sb_f2 q;
+    q[0] = v[2 * j];
+    q[1] = v[2 * j + 1];
+    reinterpret_cast<sb_f2 *>(row)[j] = q;
+  }
+}
+
+// acc[j][i] += sum over the wavefront's 64 particles of tg[p][j] tx[p][i]: lg_outer_accumulate_own's whole-tile branch
+// with ONES (the lanes of column 15 feed 1: acc[j][15] gathers the column sums of tg), on the wavefront's own area
+__device__ __forceinline__ void sb_outer(const float *tg, const float *tx, uint32_t lane, Mfma<float>::Acc &acc) {
+  const uint32_t col = lane & 15u, e = (lane >> 4) * kSbD + col;
+#pragma unroll
+  for (int group = 0; group < 4; ++group) {
+    float a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a[t] = tg[e + (4 * group + t) * 4 * kSbD];
+      b[t] = tx[e + (4 * group + t) * 4 * kSbD];
+      b[t] = col == 15u ? 1.0f : b[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = Mfma<float>::fma(a[t], b[t], acc);
+  }
+}
+
+// The launch's operands.  The kernel reads them where it uses them, through the kernel-argument segment (scalar loads
+// out of the constant cache), instead of holding a hundred scalar registers of pointers across the tile loop — those
+// registers are what the weights' rows travel in.
+struct SbArgs {
+  const float *xprev, *x, *y;
+  int64_t y_sb;
+  const float *wp, *wg, *wq, *offp, *offg, *offq;
+  int64_t offp_sb, offg_sb, offq_sb;
+  const float *sp, *sg, *sq;
+  const float *lw_src, *glw_src, *lse, *grad_lse;      // (lw_src / glw_src: a readable stand-in when the term is absent)
+  float *gxprev;
+  const float *gx_in;
+  float *rows, *ws;
+  const float *carry;
+  const float *child_rows;
+  const int32_t *child_end;
+  const int64_t *anc;
+  int32_t *flags;
+  int64_t N, tiles;
+  uint32_t K;
+  int32_t row_terms, want_sq, has_lse, has_glw, carry_records;
+};
+typedef const SbArgs __attribute__((address_space(4))) sb_cargs;
+
+template <bool GATHER, bool FOLDS>
+__global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_kernel(SbArgs unused_by_name) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
+  constexpr int D = kSbD;
+  // the argument block, re-derived (opaquely) wherever it is read: a field is loaded where it is used, never hoisted
+  unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+#define SB_A() ([&]() -> sb_cargs * { asm volatile("" : "+s"(ka)); return (sb_cargs *)ka; }())
+  float *slots = reinterpret_cast<float *>(sb_smem);
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));      // (what derives from the lane's index is recomputed per tile, not held across the loop)
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float *tu = slots + kSbSlots + wave * kSbWave, *tx = tu + kSbTile, *tc = tx + kSbTile;
+  float inv_var_p, inv_var_g, inv_s_p, inv_s_g, inv_s_q;
+  {
+    sb_cargs *A = SB_A();
+    const float s_p = ((sb_cfloat *)A->sp)[0], s_g = ((sb_cfloat *)A->sg)[0], s_q = ((sb_cfloat *)A->sq)[0];
+    inv_var_p = sb_uniform(1.0f / (s_p * s_p));
+    inv_var_g = sb_uniform(1.0f / (s_g * s_g));
+    inv_s_p = sb_uniform(1.0f / s_p);
+    inv_s_g = sb_uniform(1.0f / s_g);
+    inv_s_q = sb_uniform(1.0f / s_q);
+  }
+  Mfma<float>::Acc acc_a = {0.0f, 0.0f, 0.0f, 0.0f}, acc_c = acc_a, acc_q = acc_a;
+  float scale_acc[3] = {0.0f, 0.0f, 0.0f};
+  const uint32_t step = gridDim.x;
+  int bad = 0;
+
+  // ---- what waits in registers for the NEXT tile ----------------------------------------------------------------
+  float xp_n[D], xt_n[D], lw_n = 0.0f, glw_n = 0.0f;
+  int64_t anc_n = 0;                                   // the tile after the next one's ancestors (raw)
+  int32_t rb_c = 0, re_c = 0, rb_n = 0, re_n = 0;      // child_end entries (before the lane's particle, at it): this tile's, the next one's
+  uint32_t blk_lo = 0, blk_hi = 0;                     // the staged block of THIS tile: flat rows [blk_lo, blk_hi)
+  auto anc_load = [&](uint32_t tile) -> int64_t { return SB_A()->anc[(uint64_t)tile * kLgBlock + tid]; };
+  auto raw_load = [&](uint32_t tile, int32_t &before, int32_t &end) {
+    sb_cargs *A = SB_A();
+    const uint32_t n = tile * kLgBlock + tid, K = A->K;
+    const int32_t *child_end = A->child_end;
+    end = child_end[n];
+    before = child_end[n % K == 0u ? n : n - 1u];      // (no branch around the load: a row's first particle re-reads its own entry)
+  };
+  auto rows_prefetch = [&](uint32_t tile, int64_t araw) {
+    sb_cargs *A = SB_A();
+    const uint32_t n = tile * kLgBlock + tid, K = A->K;
+    const float *src;
+    if constexpr (GATHER) {
+      int64_t a = araw;
+      if (a < 0 || a >= (int64_t)K) {      // K2 writes K for a degenerate row (flagged there); never fault on it
+        bad = 1;
+        a = a < 0 ? 0 : (int64_t)K - 1;
+      }
+      const uint32_t b = (tile * kLgBlock) / K;
+      src = A->xprev + ((uint64_t)(b * K + (uint32_t)a)) * D;
+    } else {
+      src = A->xprev + (uint64_t)n * D;
+    }
+    sb_load_row(src, xp_n);
+    sb_load_row(A->x + (uint64_t)n * D, xt_n);
+    lw_n = A->lw_src[n];
+    glw_n = A->glw_src[n];
+  };
+  // flat rows [lo, hi) of the children of the lane's particle of `tile`, from its two entries (child_range of the first form)
+  auto child_range = [&](uint32_t tile, int32_t before, int32_t end_, uint32_t &lo, uint32_t &hi) {
+    const uint32_t K = SB_A()->K;
+    const uint32_t n0 = tile * kLgBlock;
+    const uint32_t b0 = n0 / K, k0 = n0 - b0 * K;
+    const bool first_of_row = k0 + tid == 0u;
+    const uint32_t base = b0 * K;
+    const uint32_t end = (uint32_t)min(max(end_, 0), (int32_t)K);
+    hi = base + end;
+    lo = base + min((uint32_t)max(first_of_row ? 0 : before, 0), end);
+  };
+  // the wavefront's block: from its first particle's run to its last one's, begun at an even row (16 bytes), cut at
+  // kSbChildRows; sent for by loads that write LDS directly
+  auto block_send = [&](uint32_t lo, uint32_t hi, uint32_t &blo, uint32_t &bhi) {
+    sb_cargs *A = SB_A();
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)lo, 0), last = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+    blo = first & ~1u;
+    bhi = last > blo ? min(min((last + 1u) & ~1u, (uint32_t)A->N), blo + (uint32_t)kSbChildRows) : blo;
+    const uint32_t nvec = (bhi - blo) * D / 4;      // an even number of rows: whole 16-byte vectors
+    const float *src = A->child_rows + (uint64_t)blo * D;
+#pragma unroll 1
+    for (uint32_t v0 = 0; v0 < nvec; v0 += 64) {
+      const uint32_t v = v0 + lane;
+      if (v < nvec)
+        __builtin_amdgcn_global_load_lds(src + (size_t)v * 4, (__attribute__((address_space(3))) void *)(tc + (size_t)v0 * 4), 16, 0, 0);
+    }
+  };
+
+  const uint32_t tiles = (uint32_t)SB_A()->tiles;      // (the host: K, hence N, a multiple of 256; N < 2^31)
+  const uint32_t first_tile = blockIdx.x;
+  if (first_tile < tiles) {
+    if constexpr (FOLDS) {
+      raw_load(first_tile, rb_c, re_c);
+      if (first_tile + step < tiles) raw_load(first_tile + step, rb_n, re_n);
+      uint32_t lo, hi;
+      child_range(first_tile, rb_c, re_c, lo, hi);
+      block_send(lo, hi, blk_lo, blk_hi);
+      asm volatile("" ::: "memory");
+    }
+    int64_t a0 = 0;
+    if constexpr (GATHER) {
+      a0 = anc_load(first_tile);
+      if (first_tile + step < tiles) anc_n = anc_load(first_tile + step);
+    }
+    rows_prefetch(first_tile, a0);
+  }
+  float g_old[D];      // the last tile's gradient rows: stored behind the next tile's first wait, not in front of it
+#pragma unroll
+  for (int j = 0; j < D; ++j) g_old[j] = 0.0f;
+  uint32_t old_tile = 0xffffffffu, trip = 0;
+
+  for (uint32_t tile = first_tile; tile < tiles; tile += step) {
+    // everything sent for during the last tile has landed (the block of children writes LDS from the vector-memory side)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t b;
+    float g;
+    float xp[D], xt[D], w[D];
+    {
+      sb_cargs *A = SB_A();
+      float *gxprev = A->gxprev;
+      if (old_tile != 0xffffffffu && gxprev != nullptr) sb_store_row(gxprev + ((uint64_t)old_tile * kLgBlock + tid) * D, g_old);
+      b = (tile * kLgBlock) / A->K;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        xp[j] = xp_n[j];
+        xt[j] = xt_n[j];
+      }
+      g = A->has_glw ? glw_n : 0.0f;
+      if (A->has_lse) {
+        const float lse_b = ((sb_cfloat *)A->lse)[b], glse_b = ((sb_cfloat *)A->grad_lse)[b];
+        g = g + glse_b * Num<float>::exp(lw_n - lse_b);
+      }
+      // ---- w = the gradient arriving at x_t: from later steps' densities (gx_in) and from the particle's children ----
+      const float *gx_in = A->gx_in;
+      if (gx_in != nullptr) {
+        sb_load_row(gx_in + ((uint64_t)tile * kLgBlock + tid) * D, w);
+      } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) w[j] = 0.0f;
+      }
+    }
+    if constexpr (FOLDS) {
+      const float *child_rows = SB_A()->child_rows;
+      uint32_t lo, hi;
+      child_range(tile, rb_c, re_c, lo, hi);
+      const uint32_t own_last = min(hi, lo + (uint32_t)kLgChildLimit);
+      float acc[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc[j] = 0.0f;
+      uint32_t c = lo;
+      const uint32_t in_lds = lo >= blk_lo ? min(own_last, blk_hi) : lo;
+      for (; c < in_lds; ++c) {      // in k order: ((0 + c0) + c1) + c2 ...
+        float row[D];
+        sb_lds_row(tc + (c - blk_lo) * D, row);
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc[j] = acc[j] + row[j];
+      }
+      c = min(c, max(in_lds, lo));
+      for (; c < own_last; ++c) {      // (rows the block had no room for)
+        float row[D];
+        sb_load_row(child_rows + (uint64_t)c * D, row);
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc[j] = acc[j] + row[j];
+      }
+      uint64_t todo = __ballot(own_last < hi);
+      while (todo != 0) {        // wavefront-uniform: every lane helps the lane whose run is long (a collapsed system)
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t from = (uint32_t)__shfl((int)own_last, leader, kWave), to = (uint32_t)__shfl((int)hi, leader, kWave);
+        float part[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) part[j] = 0.0f;
+        for (uint32_t cc = from + lane; cc < to; cc += kWave) {
+          float row[D];
+          sb_load_row(child_rows + (uint64_t)cc * D, row);
+#pragma unroll
+          for (int j = 0; j < D; ++j) part[j] += row[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+#pragma unroll
+          for (int off = kWave / 2; off > 0; off >>= 1) part[j] += __shfl_xor(part[j], off, kWave);
+          if ((int)lane == leader) acc[j] += part[j];
+        }
+        todo &= todo - 1;
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) w[j] = w[j] + acc[j];
+    }
+    // ---- the next tile's inputs go out now and fly during this tile's arithmetic ------------------------------------
+    {
+      const uint32_t next = tile + step, after = next + step;
+      asm volatile("" ::: "memory");
+      if (next < tiles) {
+        if constexpr (FOLDS) {
+          // (this wavefront has taken its sums out of its block: the area is free; a wavefront's LDS accesses keep their order)
+          lg_wave_fence();
+          uint32_t lo, hi;
+          child_range(next, rb_n, re_n, lo, hi);
+          block_send(lo, hi, blk_lo, blk_hi);
+          asm volatile("" ::: "memory");
+          rb_c = rb_n;
+          re_c = re_n;
+          if (after < tiles) raw_load(after, rb_n, re_n);
+        }
+        rows_prefetch(next, anc_n);
+        if constexpr (GATHER) {
+          if (after < tiles) anc_n = anc_load(after);
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+    // acc_j = offset_j + sum_i W[j][i] in_i (ascending i): a location.  The weights are scalar operands, two rows of
+    // ten at a time, the next two sent for before this pair's multiply-adds.
+    auto chain = [&](const float *wptr, const float *off_ptr, int64_t off_sb, const float (&in)[D], float (&acc)[D]) {
+      sb_cfloat *W = (sb_cfloat *)wptr;
+      if (off_ptr != nullptr) {
+        sb_cfloat *off = (sb_cfloat *)off_ptr + (int64_t)b * off_sb;
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc[j] = off[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc[j] = 0.0f;
+      }
+      float wa[2 * D], wb[2 * D];
+#pragma unroll
+      for (int e = 0; e < 2 * D; ++e) wa[e] = W[e];
+#pragma unroll
+      for (int jb = 0; jb < D; jb += 2) {
+        float (&cur)[2 * D] = (jb & 2) ? wb : wa;
+        float (&nxt)[2 * D] = (jb & 2) ? wa : wb;
+        if (jb + 2 < D) {
+#pragma unroll
+          for (int e = 0; e < 2 * D; ++e) nxt[e] = W[(jb + 2) * D + e];
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < D; i0 += 5) sb_fmac_s5x2(acc[jb], acc[jb + 1], cur + i0, cur + D + i0, in + i0);
+      }
+    };
+    // acc_i += sum_j W[j][i] u_j (ascending j): an adjoint
+    auto adjoint = [&](const float *wptr, const float (&u)[D], float (&acc)[D]) {
+      sb_cfloat *W = (sb_cfloat *)wptr;
+      float wa[2 * D], wb[2 * D];
+#pragma unroll
+      for (int e = 0; e < 2 * D; ++e) wa[e] = W[e];
+#pragma unroll
+      for (int jb = 0; jb < D; jb += 2) {
+        float (&cur)[2 * D] = (jb & 2) ? wb : wa;
+        float (&nxt)[2 * D] = (jb & 2) ? wa : wb;
+        if (jb + 2 < D) {
+#pragma unroll
+          for (int e = 0; e < 2 * D; ++e) nxt[e] = W[(jb + 2) * D + e];
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < D; i0 += 5) sb_fmac_t5x2(acc + i0, cur + i0, cur + D + i0, u[jb], u[jb + 1]);
+      }
+    };
+    float *slot = slots + (trip & 1u) * 192;
+    ++trip;
+    float u[D], gprev[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) gprev[j] = 0.0f;
+    // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u ----------------------------------------------------------
+    {
+      sb_cargs *A = SB_A();
+      chain(A->wg, A->offg, A->offg_sb, xt, u);
+      sb_cfloat *yrow = (sb_cfloat *)A->y + (int64_t)b * A->y_sb;
+      float q = 0.0f;
+      const float scaled = g * inv_var_g;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float diff = yrow[j] - u[j];
+        q = fma_t(diff, diff, q);
+        u[j] = scaled * diff;
+      }
+      scale_acc[1] += g * (q * inv_var_g * inv_s_g - (float)D * inv_s_g);
+      sb_lds_put(tu + lane * D, u);
+      sb_lds_put(tx + lane * D, xt);
+      lg_wave_fence();
+      adjoint(A->wg, u, w);
+      sb_outer(tu, tx, lane, acc_c);
+      lg_flush_column_sums<float>(acc_c, slot + 64, (A->row_terms & 2) != 0);
+      lg_wave_fence();
+    }
+    // ---- transition term: u = g (x - loc_p) / s_p^2;  w -= u ------------------------------------------------------------
+    {
+      sb_cargs *A = SB_A();
+      chain(A->wp, A->offp, A->offp_sb, xp, u);
+      float q = 0.0f;
+      const float scaled = g * inv_var_p;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float diff = xt[j] - u[j];
+        q = fma_t(diff, diff, q);
+        u[j] = scaled * diff;
+        w[j] = w[j] - u[j];
+      }
+      scale_acc[0] += g * (q * inv_var_p * inv_s_p - (float)D * inv_s_p);
+      sb_lds_put(tu + lane * D, u);
+      sb_lds_put(tx + lane * D, xp);
+      lg_wave_fence();
+      if (A->gxprev != nullptr) adjoint(A->wp, u, gprev);
+      sb_outer(tu, tx, lane, acc_a);
+      lg_flush_column_sums<float>(acc_a, slot, (A->row_terms & 1) != 0);
+      lg_wave_fence();
+    }
+    // ---- the draw: w reaches the proposal's parameters and x_{t-1};  grad s_q = g d / s_q + w . eps ----------------------
+    {
+      sb_cargs *A = SB_A();
+      if (A->want_sq) {
+        chain(A->wq, A->offq, A->offq_sb, xp, u);
+        float dot = 0.0f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const float diff = xt[j] - u[j];
+          dot = fma_t(w[j], diff, dot);
+        }
+        scale_acc[2] += g * ((float)D * inv_s_q) + dot * inv_s_q;
+      }
+      sb_lds_put(tu + lane * D, w);
+      lg_wave_fence();
+      if (A->gxprev != nullptr) adjoint(A->wq, w, gprev);
+      sb_outer(tu, tx, lane, acc_q);
+      const int row_terms = A->rows != nullptr ? A->row_terms : 0;
+      lg_flush_column_sums<float>(acc_q, slot + 128, (row_terms & 4) != 0);
+      lg_wave_fence();
+#pragma unroll
+      for (int j = 0; j < D; ++j) g_old[j] = gprev[j];
+      old_tile = tile;
+      if (row_terms != 0) {      // the four wavefronts' column sums meet: the tile's record of each wanted term
+        lg_lds_barrier();
+        lg_store_column_sums<float>(slot, A->rows + (uint64_t)tile * 3 * (kLgRowsMax * 16), row_terms);
+      }
+    }
+  }
+  sb_cargs *A = SB_A();
+  if (old_tile != 0xffffffffu && A->gxprev != nullptr) sb_store_row(A->gxprev + ((uint64_t)old_tile * kLgBlock + tid) * D, g_old);
+  if (bad) raise_flag(A->flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
+  __syncthreads();      // the wavefronts' areas become the records' scratch
+  float *scratch = slots + kSbSlots;
+  float *record = A->ws + (int64_t)blockIdx.x * 4 * kLgRecord;
+  lg_outer_publish<float>(acc_a, scratch, record);
+  lg_outer_publish<float>(acc_c, scratch, record + kLgRecord);
+  lg_outer_publish<float>(acc_q, scratch, record + 2 * kLgRecord);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    float v = scale_acc[m];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if ((threadIdx.x & 63) == 0) scratch[(threadIdx.x >> 6) * 4 + m] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLgRecord) {
+    const int m = threadIdx.x;
+    record[3 * kLgRecord + m] = m < 3 ? ((scratch[m] + scratch[4 + m]) + scratch[8 + m]) + scratch[12 + m] : 0.0f;
+  }
+  const float *carry = A->carry;
+  if (carry != nullptr && threadIdx.x < kLgRecord) {
+    // (each lane wrote the four elements it now reads: no barrier; the records carried are added in record order)
+    float own[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) own[m] = record[m * kLgRecord + threadIdx.x];
+    const int carry_records = A->carry_records;
+    for (int r = blockIdx.x; r < carry_records; r += gridDim.x) {
+      const float *c = carry + (int64_t)r * 4 * kLgRecord + threadIdx.x;
+      float v[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) v[m] = c[m * kLgRecord];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) own[m] += v[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) record[m * kLgRecord + threadIdx.x] = own[m];
+  }
+#undef SB_A
+#endif
+}
+
+// 0: this form where it covers the call; 1: always the first form (tiles through LDS).  AESMC_K14_FORM=tiles in the
+// environment, or the test hook below (not part of the C ABI of include/aesmc_hip.h).
+static std::atomic<int> g_sb_form{[] { const char *v = getenv("AESMC_K14_FORM"); return (v != nullptr && v[0] == 't') ? 1 : 0; }()};
+static std::atomic<int> g_sb_grid{0};      // > 0: workgroups of either form's launch (the records' association follows the grid)
+int affine_step_backward_forced_grid() { return g_sb_grid.load(std::memory_order_relaxed); }
+
+// Does this form cover the call?  Rows of ten float32 values on both sides, every tile of 256 particles inside one
+// batch row, weights whose rows are contiguous (what an nn.Linear holds), 32-bit row numbers.
+bool affine_step_backward_rows_covers(const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
+                                      int64_t B, int64_t K) {
+  if (g_sb_form.load(std::memory_order_relaxed) == 1) return false;
+  const auto rows_contiguous = [](const aesmc_affine_map *m) {
+    return m->stride_in == 1 && m->stride_out == m->din && (reinterpret_cast<uintptr_t>(m->weight) & 3u) == 0 &&
+           (m->offset == nullptr || (reinterpret_cast<uintptr_t>(m->offset) & 3u) == 0);
+  };
+  return mp->dout == kSbD && mp->din == kSbD && mg->dout == kSbD && mg->din == kSbD && mq->dout == kSbD &&
+         mq->din == kSbD && K % kLgBlock == 0 && B * K > 0 && B * K < (1ll << 31) && rows_contiguous(mp) &&
+         rows_contiguous(mg) && rows_contiguous(mq);
+}
+
+unsigned affine_step_backward_rows_grid(int64_t B, int64_t K) {
+  const int64_t tiles = B * K / kLgBlock;
+  return (unsigned)std::min<int64_t>(lg_persistent_grid(tiles, kSbLds, kSbPerCu), kLgMaxGrid);
+}
+
+int launch_affine_step_backward_rows(const float *xprev, const float *x, const float *y, int64_t y_sb, const LgMap &mp,
+                                     const LgMap &mg, const LgMap &mq, const float *sp, const float *sg, const float *sq,
+                                     const float *lw, const float *lse, const float *grad_lse, const float *grad_lw,
+                                     const LgBackwardOut &out, int64_t N, uint32_t K, unsigned grid, hipStream_t stream) {
+  const bool gathers = out.gat.idx != nullptr, folds = out.child_grad != nullptr;
+  SbArgs a = {};
+  a.xprev = xprev; a.x = x; a.y = y; a.y_sb = y_sb;
+  a.wp = static_cast<const float *>(mp.w); a.wg = static_cast<const float *>(mg.w); a.wq = static_cast<const float *>(mq.w);
+  a.offp = static_cast<const float *>(mp.off); a.offg = static_cast<const float *>(mg.off); a.offq = static_cast<const float *>(mq.off);
+  a.offp_sb = mp.off_sb; a.offg_sb = mg.off_sb; a.offq_sb = mq.off_sb;
+  a.sp = sp; a.sg = sg; a.sq = sq;
+  a.lw_src = grad_lse != nullptr ? lw : x; a.glw_src = grad_lw != nullptr ? grad_lw : x;      // (x: N readable values)
+  a.lse = lse; a.grad_lse = grad_lse;
+  a.gxprev = static_cast<float *>(out.gxprev); a.gx_in = static_cast<const float *>(out.gx_in);
+  a.rows = static_cast<float *>(out.rows); a.ws = static_cast<float *>(out.ws);
+  a.carry = static_cast<const float *>(out.carry);
+  a.child_rows = static_cast<const float *>(out.child_grad); a.child_end = out.child_end;
+  a.anc = out.gat.idx; a.flags = out.gat.flags;
+  a.N = N; a.tiles = N / kLgBlock; a.K = K;
+  a.row_terms = out.rows != nullptr ? out.row_terms : 0; a.want_sq = out.want_scale_q;
+  a.has_lse = grad_lse != nullptr ? 1 : 0; a.has_glw = grad_lw != nullptr ? 1 : 0;
+  a.carry_records = out.carry != nullptr ? out.carry_records : 0;
+  if (gathers && folds) hipLaunchKernelGGL((affine_step_backward_rows_kernel<true, true>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
+  else if (gathers) hipLaunchKernelGGL((affine_step_backward_rows_kernel<true, false>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
+  else if (folds) hipLaunchKernelGGL((affine_step_backward_rows_kernel<false, true>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
+  else hipLaunchKernelGGL((affine_step_backward_rows_kernel<false, false>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}
+
+}  // namespace aesmc
+
+extern "C" int aesmc_test_set_step_backward(int form, int grid) {
+  if ((form != 0 && form != 1) || grid < 0 || grid > aesmc::kLgMaxGrid) return AESMC_ERR_INVALID_ARGUMENT;
+  aesmc::g_sb_form.store(form, std::memory_order_relaxed);
+  aesmc::g_sb_grid.store(grid, std::memory_order_relaxed);
+  return AESMC_OK;
+}

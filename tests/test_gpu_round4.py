@@ -205,3 +205,67 @@ def test_the_fused_launch_flags_and_survives_ancestors_out_of_range(kernels, hip
     valid = torch.ones(B, K, dtype=torch.bool, device=hip_device)
     valid[1, 17] = valid[2, 4000] = valid[4, 63] = False
     assert torch.equal(bad_x[valid], clean_x[valid]) and torch.equal(bad_lw[valid], clean_lw[valid])
+
+
+# ---- K14's second form (rows in registers, scalar weights) against its first, bit for bit ---------
+def _step_backward_both_forms(kernels, call, grid=0):
+    """`call()` under the first form (tiles through LDS) and under the second, both on `grid` workgroups (0: each
+    form's own); every gradient returned by both, as bytes."""
+    lib = kernels._lib
+    results = []
+    try:
+        for form in (1, 0):
+            assert lib.aesmc_test_set_step_backward(form, grid) == 0
+            grads = call()
+            torch.cuda.synchronize()
+            results.append([None if g is None else g.detach().cpu().numpy().copy() for g in grads])
+    finally:
+        lib.aesmc_test_set_step_backward(0, 0)
+    return results
+
+
+@pytest.mark.parametrize("arrives", ["nothing", "grad_x", "children", "children_collapsed", "children_and_grad_x"])
+@pytest.mark.parametrize("shape", [(1024, 4096), (3, 256), (5, 1024), (130, 512)])
+def test_both_forms_of_the_step_backward_give_the_same_bits(kernels, hip_device, shape, arrives):
+    """aesmc_affine_step_backward_resampled for rows of ten float32 values: the form that keeps a wavefront's rows in
+    registers and reads the weights as scalar operands (linear_gaussian_step_backward.hip) equals the form that stages
+    tiles through LDS in every output bit — particle gradients, the three weight gradients, the offsets' row sums, the
+    scales — on the same grid (the records' association follows the grid), with and without the gather's backward
+    folded in, for a healthy and a collapsed next-step ancestry (runs longer than a lane sums by itself)."""
+    from tests.test_gpu_round3 import _next_resampling
+    B, K = shape
+    _, o = operands(B, K, 10, 10, np.float32, hip_device, seed=B + K)
+    off_p = torch.from_numpy(np.random.RandomState(4).randn(10).astype(np.float32)).to(hip_device)
+    terms = ((o["A"], off_p if B % 2 else None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    scales = (o["s_p"], o["s_g"], o["s_q"])
+    anc = _ancestors(B, K, hip_device, seed=3, spread=1.0)
+    moved = kernels.gather(o["x_prev"], anc)
+    x = kernels.affine_rsample(moved, o["Q"], o["off_q"], o["eps"], o["s_q"])
+    lw = kernels.affine_logweight(moved, x, o["y"], *terms, scales)
+    lse = kernels.logweight_lse(lw, None, None, want_lw=False)[1]
+    rng = np.random.RandomState(B)
+    glse = torch.from_numpy(rng.randn(B).astype(np.float32)).to(hip_device)
+    extra = {"ancestors": anc}
+    if arrives in ("grad_x", "children_and_grad_x"):
+        extra["grad_x"] = torch.from_numpy(rng.randn(B, K, 10).astype(np.float32)).to(hip_device)
+    if arrives.startswith("children"):
+        _, child_end = _next_resampling(kernels, B, K, hip_device, seed=7 * B + K,
+                                        spread=6.0 if arrives == "children_collapsed" else 1.0)
+        extra["child_grad"] = torch.from_numpy(rng.randn(B, K, 10).astype(np.float32)).to(hip_device)
+        extra["child_end"] = child_end
+    need = [True, False, False, True, terms[0][1] is not None, True, True, True, True, True, True, True]
+    call = lambda: kernels.affine_step_backward(o["x_prev"], x, o["y"], *terms, scales, need, lw, lse, grad_lse=glse, **extra)
+    tiles = B * K // 256
+    first, second = _step_backward_both_forms(kernels, call, grid=min(tiles, 768))
+    assert len(first) == len(second)
+    for slot, (a, b) in enumerate(zip(first, second)):
+        assert (a is None) == (b is None), slot
+        if a is not None:
+            assert a.tobytes() == b.tobytes(), (slot, float(np.abs(a - b).max()))
+    # and on its own grid: the same particle gradients, the sums to rounding
+    own = [None if g is None else g.detach().cpu().numpy() for g in call()]
+    np.testing.assert_array_equal(own[0], first[0])
+    for slot in range(3, 12):
+        if own[slot] is not None:
+            scale = max(float(np.abs(first[slot]).max()), 1e-30)
+            assert float(np.abs(own[slot] - first[slot]).max()) <= 2e-5 * scale, slot
