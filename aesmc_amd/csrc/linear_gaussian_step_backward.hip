@@ -29,9 +29,17 @@ constexpr int kSbChildRows = 96;         // rows of a wavefront's staged block o
 constexpr int kSbTile = 64 * kSbD + 16;  // a wavefront's u / x area (+16: the matrix-core operand reads run past a row's end)
 constexpr int kSbWave = 2 * kSbTile + kSbChildRows * kSbD;      // floats per wavefront
 constexpr int kSbSlots = 2 * 192;        // the tile's column sums (three terms x four wavefronts x 16), two tiles' worth
-constexpr size_t kSbLds = sizeof(float) * (kSbSlots + 4 * (size_t)kSbWave);
+constexpr int kSbOnes = 15 * 4 * kSbD + 8;      // 1.0 wherever a lane of column 15 reads its "x" operand (sb_outer)
+constexpr size_t kSbLds = sizeof(float) * (kSbSlots + kSbOnes + 4 * (size_t)kSbWave);
 constexpr int kSbPerCu = 3;              // workgroups per CU (= wavefronts per SIMD) the registers allow
 static_assert(kSbLds * kSbPerCu <= 160 * 1024, "LDS of the resident workgroups");
+
+// tile / tpr with mul = floor(2^32 / tpr): the high product is the quotient or one less (tile < 2^23)
+__device__ __forceinline__ uint32_t sb_row_of(uint32_t tile, uint32_t tpr, uint32_t mul) {
+  uint32_t q = __umulhi(tile, mul);
+  q += (tile - q * tpr >= tpr) ? 1u : 0u;
+  return q;
+}
 
 // acc_j += W[j][i] x_i, two outputs' chains side by side, five inputs per statement (see linear_gaussian_fused.hip)
 __device__ __forceinline__ void sb_fmac_s5x2(float &a0, float &a1, const float *w0, const float *w1, const float *x) {
@@ -99,16 +107,18 @@ __device__ __forceinline__ void sb_lds_put(float *row, const float (&v)[kSbD]) {
 
 // acc[j][i] += sum over the wavefront's 64 particles of tg[p][j] tx[p][i]: lg_outer_accumulate_own's whole-tile branch
 // with ONES (the lanes of column 15 feed 1: acc[j][15] gathers the column sums of tg), on the wavefront's own area
-__device__ __forceinline__ void sb_outer(const float *tg, const float *tx, uint32_t lane, Mfma<float>::Acc &acc) {
+// (`ones`: an area holding 1.0 at every offset the sixteen reads use — the lanes of column 15 read it instead of tx)
+__device__ __forceinline__ void sb_outer(const float *tg, const float *tx, const float *ones, uint32_t lane,
+                                         Mfma<float>::Acc &acc) {
   const uint32_t col = lane & 15u, e = (lane >> 4) * kSbD + col;
+  const float *ta = tg + e, *tb = col == 15u ? ones : tx + e;
 #pragma unroll
   for (int group = 0; group < 4; ++group) {
     float a[4], b[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      a[t] = tg[e + (4 * group + t) * 4 * kSbD];
-      b[t] = tx[e + (4 * group + t) * 4 * kSbD];
-      b[t] = col == 15u ? 1.0f : b[t];
+      a[t] = ta[(4 * group + t) * 4 * kSbD];
+      b[t] = tb[(4 * group + t) * 4 * kSbD];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = Mfma<float>::fma(a[t], b[t], acc);
@@ -134,7 +144,7 @@ struct SbArgs {
   const int64_t *anc;
   int32_t *flags;
   int64_t N, tiles;
-  uint32_t K;
+  uint32_t K, tpr, tpr_mul;      // tiles per batch row (K / 256) and floor(2^32 / tpr)
   int32_t row_terms, want_sq, has_lse, has_glw, carry_records;
 };
 typedef const SbArgs __attribute__((address_space(4))) sb_cargs;
@@ -152,7 +162,10 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
   asm volatile("" : "+v"(tid));      // (what derives from the lane's index is recomputed per tile, not held across the loop)
   const uint32_t lane = tid & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float *tu = slots + kSbSlots + wave * kSbWave, *tx = tu + kSbTile, *tc = tx + kSbTile;
+  float *ones = slots + kSbSlots;
+  float *tu = ones + kSbOnes + wave * kSbWave, *tx = tu + kSbTile, *tc = tx + kSbTile;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)kSbOnes; i += kLgBlock) ones[i] = 1.0f;
+  __syncthreads();
   float inv_var_p, inv_var_g, inv_s_p, inv_s_g, inv_s_q;
   {
     sb_cargs *A = SB_A();
@@ -176,10 +189,11 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
   auto anc_load = [&](uint32_t tile) -> int64_t { return SB_A()->anc[(uint64_t)tile * kLgBlock + tid]; };
   auto raw_load = [&](uint32_t tile, int32_t &before, int32_t &end) {
     sb_cargs *A = SB_A();
-    const uint32_t n = tile * kLgBlock + tid, K = A->K;
+    const uint32_t n = tile * kLgBlock + tid;
     const int32_t *child_end = A->child_end;
     end = child_end[n];
-    before = child_end[n % K == 0u ? n : n - 1u];      // (no branch around the load: a row's first particle re-reads its own entry)
+    const uint32_t k0 = (tile - sb_row_of(tile, A->tpr, A->tpr_mul) * A->tpr) * kLgBlock;
+    before = child_end[k0 + tid == 0u ? n : n - 1u];      // (no branch around the load: a row's first particle re-reads its own entry)
   };
   auto rows_prefetch = [&](uint32_t tile, int64_t araw) {
     sb_cargs *A = SB_A();
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
         bad = 1;
         a = a < 0 ? 0 : (int64_t)K - 1;
       }
-      const uint32_t b = (tile * kLgBlock) / K;
+      const uint32_t b = sb_row_of(tile, A->tpr, A->tpr_mul);
       src = A->xprev + ((uint64_t)(b * K + (uint32_t)a)) * D;
     } else {
       src = A->xprev + (uint64_t)n * D;
@@ -203,9 +217,10 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
   };
   // flat rows [lo, hi) of the children of the lane's particle of `tile`, from its two entries (child_range of the first form)
   auto child_range = [&](uint32_t tile, int32_t before, int32_t end_, uint32_t &lo, uint32_t &hi) {
-    const uint32_t K = SB_A()->K;
+    sb_cargs *A = SB_A();
+    const uint32_t K = A->K;
     const uint32_t n0 = tile * kLgBlock;
-    const uint32_t b0 = n0 / K, k0 = n0 - b0 * K;
+    const uint32_t b0 = sb_row_of(tile, A->tpr, A->tpr_mul), k0 = n0 - b0 * K;
     const bool first_of_row = k0 + tid == 0u;
     const uint32_t base = b0 * K;
     const uint32_t end = (uint32_t)min(max(end_, 0), (int32_t)K);
@@ -254,7 +269,15 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
 
   for (uint32_t tile = first_tile; tile < tiles; tile += step) {
     // everything sent for during the last tile has landed (the block of children writes LDS from the vector-memory side)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the prefetched registers are operands of the wait: the compiler then asks for them in front of it and never
+    //  again behind it, where its own wait would also cover the stores that follow)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(xp_n[0]), "+v"(xp_n[1]), "+v"(xp_n[2]), "+v"(xp_n[3]), "+v"(xp_n[4]), "+v"(xp_n[5]), "+v"(xp_n[6]),
+                   "+v"(xp_n[7]), "+v"(xp_n[8]), "+v"(xp_n[9]), "+v"(xt_n[0]), "+v"(xt_n[1]), "+v"(xt_n[2]), "+v"(xt_n[3]),
+                   "+v"(xt_n[4]), "+v"(xt_n[5]), "+v"(xt_n[6]), "+v"(xt_n[7]), "+v"(xt_n[8]), "+v"(xt_n[9]), "+v"(lw_n),
+                   "+v"(glw_n), "+v"(rb_n), "+v"(re_n), "+v"(anc_n)
+                 :
+                 : "memory");
     uint32_t b;
     float g;
     float xp[D], xt[D], w[D];
@@ -262,7 +285,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       sb_cargs *A = SB_A();
       float *gxprev = A->gxprev;
       if (old_tile != 0xffffffffu && gxprev != nullptr) sb_store_row(gxprev + ((uint64_t)old_tile * kLgBlock + tid) * D, g_old);
-      b = (tile * kLgBlock) / A->K;
+      b = sb_row_of(tile, A->tpr, A->tpr_mul);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         xp[j] = xp_n[j];
@@ -332,7 +355,12 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
     // ---- the next tile's inputs go out now and fly during this tile's arithmetic ------------------------------------
     {
       const uint32_t next = tile + step, after = next + step;
-      asm volatile("" ::: "memory");
+      // (w is complete here: nothing that waits for a load of THIS tile may sink behind the loads sent for the next one,
+      //  where its wait would be a wait for all of them)
+      asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]),
+                        "+v"(w[9]), "+v"(g)
+                   :
+                   : "memory");
       if (next < tiles) {
         if constexpr (FOLDS) {
           // (this wavefront has taken its sums out of its block: the area is free; a wavefront's LDS accesses keep their order)
@@ -420,7 +448,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       sb_lds_put(tx + lane * D, xt);
       lg_wave_fence();
       adjoint(A->wg, u, w);
-      sb_outer(tu, tx, lane, acc_c);
+      sb_outer(tu, tx, ones, lane, acc_c);
       lg_flush_column_sums<float>(acc_c, slot + 64, (A->row_terms & 2) != 0);
       lg_wave_fence();
     }
@@ -442,7 +470,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       sb_lds_put(tx + lane * D, xp);
       lg_wave_fence();
       if (A->gxprev != nullptr) adjoint(A->wp, u, gprev);
-      sb_outer(tu, tx, lane, acc_a);
+      sb_outer(tu, tx, ones, lane, acc_a);
       lg_flush_column_sums<float>(acc_a, slot, (A->row_terms & 1) != 0);
       lg_wave_fence();
     }
@@ -462,7 +490,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       sb_lds_put(tu + lane * D, w);
       lg_wave_fence();
       if (A->gxprev != nullptr) adjoint(A->wq, w, gprev);
-      sb_outer(tu, tx, lane, acc_q);
+      sb_outer(tu, tx, ones, lane, acc_q);
       const int row_terms = A->rows != nullptr ? A->row_terms : 0;
       lg_flush_column_sums<float>(acc_q, slot + 128, (row_terms & 4) != 0);
       lg_wave_fence();
@@ -470,7 +498,8 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       for (int j = 0; j < D; ++j) g_old[j] = gprev[j];
       old_tile = tile;
       if (row_terms != 0) {      // the four wavefronts' column sums meet: the tile's record of each wanted term
-        lg_lds_barrier();
+        // (LDS stores only: a release fence here would also wait for the next tile's block, which is on its way into LDS)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         lg_store_column_sums<float>(slot, A->rows + (uint64_t)tile * 3 * (kLgRowsMax * 16), row_terms);
       }
     }
@@ -479,7 +508,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
   if (old_tile != 0xffffffffu && A->gxprev != nullptr) sb_store_row(A->gxprev + ((uint64_t)old_tile * kLgBlock + tid) * D, g_old);
   if (bad) raise_flag(A->flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
   __syncthreads();      // the wavefronts' areas become the records' scratch
-  float *scratch = slots + kSbSlots;
+  float *scratch = slots + kSbSlots + kSbOnes;
   float *record = A->ws + (int64_t)blockIdx.x * 4 * kLgRecord;
   lg_outer_publish<float>(acc_a, scratch, record);
   lg_outer_publish<float>(acc_c, scratch, record + kLgRecord);
@@ -562,6 +591,8 @@ int launch_affine_step_backward_rows(const float *xprev, const float *x, const f
   a.child_rows = static_cast<const float *>(out.child_grad); a.child_end = out.child_end;
   a.anc = out.gat.idx; a.flags = out.gat.flags;
   a.N = N; a.tiles = N / kLgBlock; a.K = K;
+  a.tpr = K / kLgBlock; a.tpr_mul = (uint32_t)((1ull << 32) / a.tpr);      // (tpr == 1: 2^32 does not fit, the quotient's fixup covers it)
+  if (a.tpr == 1) a.tpr_mul = 0xffffffffu;
   a.row_terms = out.rows != nullptr ? out.row_terms : 0; a.want_sq = out.want_scale_q;
   a.has_lse = grad_lse != nullptr ? 1 : 0; a.has_glw = grad_lw != nullptr ? 1 : 0;
   a.carry_records = out.carry != nullptr ? out.carry_records : 0;
