@@ -146,7 +146,13 @@ struct SbArgs {
   int64_t N, tiles;
   uint32_t K, tpr, tpr_mul;      // tiles per batch row (K / 256) and floor(2^32 / tpr)
   int32_t row_terms, want_sq, has_lse, has_glw, carry_records;
+  uint32_t probe;      // timing experiments only (-DAESMC_K14_PROBES + AESMC_K14_PROBE): a probed launch's OUTPUT IS WRONG
 };
+#ifdef AESMC_K14_PROBES
+#define SB_PROBE(bit) ((probe & (bit)) != 0u)
+#else
+#define SB_PROBE(bit) false
+#endif
 typedef const SbArgs __attribute__((address_space(4))) sb_cargs;
 
 template <bool GATHER, bool FOLDS>
@@ -180,6 +186,8 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
   float scale_acc[3] = {0.0f, 0.0f, 0.0f};
   const uint32_t step = gridDim.x;
   int bad = 0;
+  const uint32_t probe = SB_A()->probe;
+  (void)probe;
 
   // ---- what waits in registers for the NEXT tile ----------------------------------------------------------------
   float xp_n[D], xt_n[D], lw_n = 0.0f, glw_n = 0.0f;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
     {
       sb_cargs *A = SB_A();
       float *gxprev = A->gxprev;
-      if (old_tile != 0xffffffffu && gxprev != nullptr) sb_store_row(gxprev + ((uint64_t)old_tile * kLgBlock + tid) * D, g_old);
+      if (old_tile != 0xffffffffu && gxprev != nullptr && !SB_PROBE(32u)) sb_store_row(gxprev + ((uint64_t)old_tile * kLgBlock + tid) * D, g_old);
       b = sb_row_of(tile, A->tpr, A->tpr_mul);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
         for (int j = 0; j < D; ++j) w[j] = 0.0f;
       }
     }
-    if constexpr (FOLDS) {
+    if (FOLDS && !SB_PROBE(1u)) {
       const float *child_rows = SB_A()->child_rows;
       uint32_t lo, hi;
       child_range(tile, rb_c, re_c, lo, hi);
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
           re_c = re_n;
           if (after < tiles) raw_load(after, rb_n, re_n);
         }
-        rows_prefetch(next, anc_n);
+        if (!SB_PROBE(64u)) rows_prefetch(next, anc_n);
         if constexpr (GATHER) {
           if (after < tiles) anc_n = anc_load(after);
         }
@@ -433,7 +441,8 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
     // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u ----------------------------------------------------------
     {
       sb_cargs *A = SB_A();
-      chain(A->wg, A->offg, A->offg_sb, xt, u);
+      if (!SB_PROBE(2u)) chain(A->wg, A->offg, A->offg_sb, xt, u);
+      else for (int j = 0; j < D; ++j) u[j] = xt[j];
       sb_cfloat *yrow = (sb_cfloat *)A->y + (int64_t)b * A->y_sb;
       float q = 0.0f;
       const float scaled = g * inv_var_g;
@@ -444,18 +453,22 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
         u[j] = scaled * diff;
       }
       scale_acc[1] += g * (q * inv_var_g * inv_s_g - (float)D * inv_s_g);
-      sb_lds_put(tu + lane * D, u);
-      sb_lds_put(tx + lane * D, xt);
+      if (!SB_PROBE(16u)) {
+        sb_lds_put(tu + lane * D, u);
+        sb_lds_put(tx + lane * D, xt);
+      }
       lg_wave_fence();
-      adjoint(A->wg, u, w);
-      sb_outer(tu, tx, ones, lane, acc_c);
+      if (!SB_PROBE(4u)) adjoint(A->wg, u, w);
+      else for (int j = 0; j < D; ++j) w[j] += u[j];
+      if (!SB_PROBE(8u)) sb_outer(tu, tx, ones, lane, acc_c);
       lg_flush_column_sums<float>(acc_c, slot + 64, (A->row_terms & 2) != 0);
       lg_wave_fence();
     }
     // ---- transition term: u = g (x - loc_p) / s_p^2;  w -= u ------------------------------------------------------------
     {
       sb_cargs *A = SB_A();
-      chain(A->wp, A->offp, A->offp_sb, xp, u);
+      if (!SB_PROBE(2u)) chain(A->wp, A->offp, A->offp_sb, xp, u);
+      else for (int j = 0; j < D; ++j) u[j] = xp[j];
       float q = 0.0f;
       const float scaled = g * inv_var_p;
 #pragma unroll
@@ -466,11 +479,14 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
         w[j] = w[j] - u[j];
       }
       scale_acc[0] += g * (q * inv_var_p * inv_s_p - (float)D * inv_s_p);
-      sb_lds_put(tu + lane * D, u);
-      sb_lds_put(tx + lane * D, xp);
+      if (!SB_PROBE(16u)) {
+        sb_lds_put(tu + lane * D, u);
+        sb_lds_put(tx + lane * D, xp);
+      }
       lg_wave_fence();
-      if (A->gxprev != nullptr) adjoint(A->wp, u, gprev);
-      sb_outer(tu, tx, ones, lane, acc_a);
+      if (A->gxprev != nullptr && !SB_PROBE(4u)) adjoint(A->wp, u, gprev);
+      else for (int j = 0; j < D; ++j) gprev[j] += u[j];
+      if (!SB_PROBE(8u)) sb_outer(tu, tx, ones, lane, acc_a);
       lg_flush_column_sums<float>(acc_a, slot, (A->row_terms & 1) != 0);
       lg_wave_fence();
     }
@@ -478,7 +494,8 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
     {
       sb_cargs *A = SB_A();
       if (A->want_sq) {
-        chain(A->wq, A->offq, A->offq_sb, xp, u);
+        if (!SB_PROBE(2u)) chain(A->wq, A->offq, A->offq_sb, xp, u);
+        else for (int j = 0; j < D; ++j) u[j] = xp[j];
         float dot = 0.0f;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -487,10 +504,11 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
         }
         scale_acc[2] += g * ((float)D * inv_s_q) + dot * inv_s_q;
       }
-      sb_lds_put(tu + lane * D, w);
+      if (!SB_PROBE(16u)) sb_lds_put(tu + lane * D, w);
       lg_wave_fence();
-      if (A->gxprev != nullptr) adjoint(A->wq, w, gprev);
-      sb_outer(tu, tx, ones, lane, acc_q);
+      if (A->gxprev != nullptr && !SB_PROBE(4u)) adjoint(A->wq, w, gprev);
+      else for (int j = 0; j < D; ++j) gprev[j] += w[j];
+      if (!SB_PROBE(8u)) sb_outer(tu, tx, ones, lane, acc_q);
       const int row_terms = A->rows != nullptr ? A->row_terms : 0;
       lg_flush_column_sums<float>(acc_q, slot + 128, (row_terms & 4) != 0);
       lg_wave_fence();
@@ -596,6 +614,9 @@ int launch_affine_step_backward_rows(const float *xprev, const float *x, const f
   a.row_terms = out.rows != nullptr ? out.row_terms : 0; a.want_sq = out.want_scale_q;
   a.has_lse = grad_lse != nullptr ? 1 : 0; a.has_glw = grad_lw != nullptr ? 1 : 0;
   a.carry_records = out.carry != nullptr ? out.carry_records : 0;
+#ifdef AESMC_K14_PROBES
+  { const char *v = getenv("AESMC_K14_PROBE"); a.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
+#endif
   if (gathers && folds) hipLaunchKernelGGL((affine_step_backward_rows_kernel<true, true>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
   else if (gathers) hipLaunchKernelGGL((affine_step_backward_rows_kernel<true, false>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
   else if (folds) hipLaunchKernelGGL((affine_step_backward_rows_kernel<false, true>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
