@@ -74,7 +74,14 @@ class LazyParticles(torch.Tensor):
 
     def materialise(self):
         if self._lazy_real is None:
-            self._lazy_real = self._lazy_compute()
+            # The values are kept for every later reader.  A first reader under torch.no_grad() (a logging or
+            # diagnostic look at latents[-1] inside a callable) must not leave them without their history: the
+            # reference's eager tensors carry it whoever looks first.
+            if not torch.is_grad_enabled() and self._lazy_requires_grad():
+                with torch.enable_grad():
+                    self._lazy_real = self._lazy_compute()
+            else:
+                self._lazy_real = self._lazy_compute()
         return self._lazy_real
 
     def resolve(self, real):

@@ -6,6 +6,8 @@ picks from the device properties, and of the element index (csrc/philox_normal.h
 does the bookkeeping half of such a call WITHOUT launching it: it reads (seed, offset), advances the generator
 by what `normal_` would have consumed, and returns the stream descriptor a kernel needs to form the same
 values where it consumes them.  Everything drawn afterwards — by PyTorch or by this package — is unchanged.
+`verified(device)` checks these assumptions against the installed PyTorch once per device (tests:
+tests/test_gpu_round3.py, the Philox tests).
 """
 import collections
 import contextlib
@@ -44,6 +46,55 @@ def consumed(numel, threads):
     """What one `normal_` of `numel` FLOAT32 elements adds to the generator's offset (float64 draws take another
     route in ATen: callers reserve noise for float32 tensors only, `state.sample` / `_kernels` check the dtype)."""
     return 4 * ((numel - 1) // (threads * 4) + 1)
+
+
+_VERIFIED = {}
+
+
+def verified(device):
+    """One check per device, on first use: does the installed PyTorch / ROCm still draw `normal_` the way this module
+    assumes (ATen's launch geometry, its offset accounting, rocRAND's Box-Muller)?  Two sizes (one trip, several
+    trips) are drawn by PyTorch under a forked generator and formed again by aesmc_philox_normal_fill from the
+    reservation `reserve` would have made; the values must be equal bit for bit and the generator must have advanced
+    by `consumed`.  If not, noise is left to PyTorch for the rest of the process (`state.set_kernel_noise(False)`):
+    slower, never wrong.  Inside a hipGraph capture nothing can be checked; the warm-up evaluations in front of a
+    capture have run it."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    ok = _VERIFIED.get(index)
+    if ok is None:
+        if torch.cuda.is_current_stream_capturing():
+            return True
+        _VERIFIED[index] = True          # (the check itself draws through this module's callers)
+        ok = _self_check(torch.device("cuda", index))
+        _VERIFIED[index] = ok
+        if not ok:
+            import warnings
+            from . import state
+            state.set_kernel_noise(False)
+            warnings.warn("aesmc_amd: torch.empty(n).normal_() on {} does not match this build's restatement of "
+                          "PyTorch's Philox stream (launch geometry, offset accounting or Box-Muller changed); noise "
+                          "is drawn by PyTorch itself from here on".format(device), RuntimeWarning)
+    return ok
+
+
+def _self_check(device):
+    from . import _kernels
+    provider = _kernels.get()
+    if provider.name != "hip":
+        return True
+    generator = _generator(device)
+    with torch.random.fork_rng(devices=[device.index]):
+        generator.manual_seed(0x5eed)
+        for numel in (1000, 4 * launch_threads(1 << 30, device) * 2 + 17):
+            before = generator.get_offset()
+            want = torch.empty(numel, dtype=torch.float32, device=device).normal_()
+            threads = launch_threads(numel, device)
+            if generator.get_offset() - before != consumed(numel, threads):
+                return False
+            got = provider.philox_normal(NoiseStream(generator.initial_seed(), before, threads, numel), (numel,), device)
+            if not torch.equal(got, want):
+                return False
+    return True
 
 
 def _generator(device):

@@ -13,7 +13,7 @@
 // so a value is a pure function of (seed, offset, G, e): any kernel that knows those four can form the
 // noise where it is consumed instead of reading it back from HBM — the same bits, and the generator is
 // advanced by what `normal_` would have consumed (aesmc_amd/_philox.py), so everything drawn afterwards
-// is unchanged too.  `tests/test_gpu_philox.py` holds this against `torch.empty(n).normal_()` bit for bit.
+// is unchanged too.  `tests/test_gpu_round3.py` (the Philox tests) holds this against `torch.empty(n).normal_()` bit for bit.
 //
 // Box-Muller as rocRAND writes it (rocrand_normal.h `box_muller`):
 //   u = 2^-32 + r0 * 2^-32,  v = 2^-32 * 2pi + r1 * (2^-32 * 2pi),  s = sqrtf(-2 logf(u)),

@@ -275,7 +275,8 @@ def _kernel_noise_applies(source):
     (graphs.GraphedLoss opens one when every draw of the ELBO is one this package can place itself)."""
     return (_KERNEL_NOISE and source.is_cuda and source.dtype == torch.float32 and _kernels.get().name == "hip" and
             torch.distributions.normal._standard_normal is _TORCH_STANDARD_NORMAL and
-            (_philox.graph_noise() is not None or not torch.cuda.is_current_stream_capturing()))
+            (_philox.graph_noise() is not None or not torch.cuda.is_current_stream_capturing()) and
+            _philox.verified(source.device))
 
 
 def _standard_normal(shape, dtype, device):
@@ -285,7 +286,7 @@ def _standard_normal(shape, dtype, device):
     evaluation gives it.  Outside a capture the call is only counted (see `_philox.COUNTERS`)."""
     draw = torch.distributions.normal._standard_normal
     if draw is _TORCH_STANDARD_NORMAL and dtype == torch.float32 and device.type == "cuda" and _KERNEL_NOISE and \
-            _kernels.get().name == "hip":
+            _kernels.get().name == "hip" and _philox.verified(device):
         numel = 1
         for size in shape:
             numel *= size

@@ -845,6 +845,15 @@ def test_a_reference_style_model_reaches_the_fused_route_unedited(oracle_backend
     assert not isinstance(out, _lazy.LazyParticles) and not y.is_pending and torch.equal(out, torch.tanh(moved))
     dist = torch.distributions.Normal(_lazy.LazyResampled(source, index) @ weight.t(), torch.tensor(0.5, dtype=torch.float64))
     assert type(dist.loc) is _lazy.LazyAffine and dist.loc.is_pending and dist.batch_shape == (2, 5, 4)
+    # a first reader under no_grad (a diagnostic look inside a callable) does not cost later readers their gradient
+    leaf = source.clone().requires_grad_(True)
+    z = _lazy.LazyResampled(leaf, index)
+    with torch.no_grad():
+        peek = torch.tanh(z)
+    assert not peek.requires_grad and not z.is_pending
+    (z.materialise() * 2.0).sum().backward()
+    want = torch.zeros_like(source).scatter_add_(1, index.unsqueeze(-1).expand_as(source), torch.full_like(source, 2.0))
+    torch.testing.assert_close(leaf.grad, want, rtol=0, atol=0)
 
 
 def test_linked_step_nodes_give_the_gradients_of_unlinked_ones(oracle_backend):
@@ -1031,3 +1040,16 @@ def test_recorded_locations_name_the_models_own_tensors():
     fake = torch.distributions.Normal(x @ W.t(), 1.0, validate_args=False)
     fake.scale = cut_off             # an expanded view autograd does not connect to the parameter: stays a view
     assert linear_gaussian.affine_terms(fake).scale_param is not learned
+
+
+def test_the_deprecated_particle_mlp_is_the_pytorch_expression():
+    import warnings
+    from aesmc_amd import linear_gaussian
+    g = torch.Generator().manual_seed(3)
+    x, w1, o1 = torch.randn(2, 5, 3, generator=g), torch.randn(7, 3, generator=g), torch.randn(2, 7, generator=g)
+    w2, b2 = torch.randn(4, 7, generator=g), torch.randn(4, generator=g)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        got = linear_gaussian.particle_mlp(x, w1, o1, w2, b2)
+    assert any(issubclass(w.category, DeprecationWarning) for w in seen)
+    torch.testing.assert_close(got, torch.tanh(x @ w1.t() + o1.unsqueeze(1)) @ w2.t() + b2)
