@@ -175,6 +175,7 @@ class HipKernels:
         self._affine_max_dim = None
         self._map_cache = {}        # id(weight) -> (weight, its aesmc_affine_map, (shape, strides))
         self._covers_last = None    # the operands of the last step `affine_logweight_covers` accepted
+        self._wide_dim = None       # aesmc_affine_wide_dim(): the extent K17 / K18 are built for
 
     # ---- deferred status word ---------------------------------------------------------------
     def flags(self, device):
@@ -977,6 +978,60 @@ class HipKernels:
             _lib.check(self._lib.aesmc_philox_normal_fill(*args), "aesmc_philox_normal_fill")
             if self.timer is not None:
                 self.timer.note("philox_normal_fill", (self._lib.aesmc_philox_normal_fill, args), 4 * out.numel(), (out,))
+        return out
+
+    def affine_propagate_wide(self, x_src, eps, y_rows, transition, emission, proposal, scales, out_x, ancestors=None):
+        """K17 + K18: a linear-Gaussian step whose rows hold 128 float32 values (BASELINE.json configs[4]) on the fp32
+        matrix cores — the draw `loc_q(x_prev) + eps * s_q` into `out_x` (the C oracle's bits) and the step's
+        log-weights [B,K] (its values to rounding), x_prev = x_src[b, ancestors[b,k]] when `ancestors` is given.
+        None when the launch does not cover the operands (other extents, strided weights, K not a multiple of 32)."""
+        if x_src.dtype != torch.float32 or x_src.dim() != 3:
+            return None
+        B, K, dx = x_src.shape
+        wide = self._wide_dim
+        if wide is None:
+            wide = self._wide_dim = int(self._lib.aesmc_affine_wide_dim())
+        if dx != wide or y_rows.dim() != 2 or y_rows.size(1) != wide or K % 32 != 0 or B * K == 0:
+            return None
+        if eps.shape != x_src.shape or eps.dtype != x_src.dtype or eps.device != x_src.device:
+            raise ValueError("aesmc_amd: affine_propagate_wide noise must match x_src")
+        for weight, offset in (transition, emission, proposal):
+            if tuple(weight.shape) != (wide, wide) or not weight.is_contiguous() or weight.data_ptr() % 16 or \
+                    weight.dtype != torch.float32:
+                return None
+            if offset is not None and (offset.dtype != torch.float32 or offset.stride(-1) != 1 or offset.data_ptr() % 16 or
+                                       (offset.dim() == 2 and offset.stride(0) % 4)):
+                return None
+        if any(scale.numel() != 1 for scale in scales):
+            return None
+        self._check_out(out_x, (B, K, dx), x_src, "affine_propagate_wide")
+        x_src, eps = self._dense16(x_src), self._dense16(eps)
+        if out_x.data_ptr() in (x_src.data_ptr(), eps.data_ptr()):
+            raise ValueError("aesmc_amd: affine_propagate_wide cannot write the draw over its inputs")
+        if ancestors is not None:
+            self._check_index(x_src, ancestors)
+            if ancestors.shape != (B, K):
+                raise ValueError("aesmc_amd: affine_propagate_wide ancestors must be [{}, {}]".format(B, K))
+            ancestors = ancestors.contiguous()
+        if y_rows.stride(1) != 1 or y_rows.stride(0) % 4 or y_rows.data_ptr() % 16:
+            y_rows = y_rows.contiguous()
+        out = torch.empty((B, K), dtype=torch.float32, device=x_src.device)
+        ws_bytes = int(self._lib.aesmc_affine_wide_workspace_bytes(B, K))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_src.device)
+        maps = [self._affine_map(*term, slot=slot) for slot, term in enumerate((transition, emission, proposal))]
+        with _on_device(x_src.device):
+            args = (_ptr(x_src), _ptr(ancestors), _ptr(eps), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
+                    ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
+                    _ptr(scales[2]), _ptr(out_x), _ptr(out), _ptr(ws), ws_bytes, _ptr(self.flags(x_src.device)), B, K,
+                    self._stream(x_src))
+            status = self._lib.aesmc_affine_normal_propagate_wide(*args)
+            if status == 2:
+                return None
+            _lib.check(status, "aesmc_affine_normal_propagate_wide")
+            if self.timer is not None:
+                nbytes = 4 * (B * K * (3 * dx + 1) + y_rows.numel()) + (8 * B * K if ancestors is not None else 0)
+                self.timer.note("affine_normal_propagate_wide", (self._lib.aesmc_affine_normal_propagate_wide, args),
+                                nbytes, (x_src, ancestors, eps, y_rows, out, out_x, ws, maps, scales))
         return out
 
     def affine_propagate_drawn(self, x_src, noise, y_rows, transition, emission, proposal, scales, out_x,

@@ -48,7 +48,8 @@ extern "C" {
  *   200 (0.2.0)  removed aesmc_particle_mlp / aesmc_particle_mlp_max_hidden (the user's MLP stays in PyTorch);
  *                aesmc_set_step_parts / aesmc_set_sorted_backward_kernel became test hooks outside this header
  *                (aesmc_test_*); aesmc_affine_normal_propagate_drawn keeps its signature and now runs the fused launch
- *                (gather + noise + draw + log-weight terms in one kernel). */
+ *                (gather + noise + draw + log-weight terms in one kernel); added aesmc_affine_normal_propagate_wide
+ *                (+ aesmc_affine_wide_dim, aesmc_affine_wide_workspace_bytes). */
 int aesmc_version(void);
 const char *aesmc_target_arch(void); /* "gfx950" */
 
@@ -395,6 +396,28 @@ int aesmc_affine_normal_propagate_drawn(
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, int32_t *flags,
     int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *rng_state, void *stream);
+
+/* K17 + K18 — one SMC step of a linear-Gaussian model whose latent and observation rows hold 128 float32 values
+ * (BASELINE.json configs[4]), the three 128 x 128 maps on the fp32 matrix cores:
+ *   x_prev[b,k,:] = x_src[b, ancestors[b,k], :]                              (ancestors NULL: x_prev = x_src)
+ *   out_x  = (offset_q + Q x_prev) + eps * s_q                               (each location ONE fma chain per element,
+ *   out_lw = (log N(out_x; offset_p + A x_prev, s_p) + log N(y; offset_g + C out_x, s_g)) - log N(out_x; loc_q, s_q)
+ *                                                                             inputs ascending: out_x has the C oracle's bits)
+ * Replaces aesmc/inference.py:102-126 for one timestep: `state.resample` of the newest latent (state.py:179),
+ * `state.sample(proposal)` given its noise `eps` [B,K,128] (state.py:98) and the three `state.log_prob` calls
+ * (state.py:114-155) — three library GEMMs, their offsets' broadcast adds, the draw and the log-weight kernel before.
+ * Weights [128,128] row-major contiguous (what an nn.Linear holds), offsets NULL / [128] / [B,128], scales one value
+ * each, K a multiple of 32; `ws`: aesmc_affine_wide_workspace_bytes(B, K) bytes (two sums per particle between the two
+ * launches).  The squared distances are summed per lane and then over a particle's four lanes: equal to the C oracle's
+ * single chain to rounding (2e-6 relative in the tests), not bit for bit.  AESMC_ERR_UNSUPPORTED for every other shape
+ * (the caller keeps the route through aesmc_normal_rsample / aesmc_normal_logweight). */
+int64_t aesmc_affine_wide_dim(void);      /* 128 */
+size_t aesmc_affine_wide_workspace_bytes(int64_t B, int64_t K);
+int aesmc_affine_normal_propagate_wide(
+    const void *x_src, const int64_t *ancestors, const void *eps, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, void *ws, size_t ws_bytes,
+    int32_t *flags, int64_t B, int64_t K, void *stream);
 
 /* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
  *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])

@@ -17,7 +17,8 @@ _fp = ctypes.POINTER(ctypes.c_float)
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        source = os.path.join(HERE, "smc_core.c")
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(source):      # (stale: rebuilt)
             subprocess.run(["make", "-s", "-C", HERE], check=True)
         lib = ctypes.CDLL(LIB)
         lib.smc_oracle_ancestor_index.restype = ctypes.c_int

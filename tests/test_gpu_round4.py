@@ -269,3 +269,58 @@ def test_both_forms_of_the_step_backward_give_the_same_bits(kernels, hip_device,
         if own[slot] is not None:
             scale = max(float(np.abs(first[slot]).max()), 1e-30)
             assert float(np.abs(own[slot] - first[slot]).max()) <= 2e-5 * scale, slot
+
+
+# ---- configs[4]'s extent (rows of 128 values) on the fp32 matrix cores: K17 + K18 -----------------
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("shape", [(2, 64), (3, 320), (5, 1024), (2, 16384)])
+def test_the_wide_step_equals_the_c_oracle(kernels, hip_device, shape, gather):
+    """aesmc_affine_normal_propagate_wide against oracle/smc_core.c at d = 128: x_t bit for bit (the gather of the
+    ancestor rows, one fma chain per element started from the offset — 32 matrix-core k-steps —, eps * s rounded
+    before the sum), the log-weight to 2e-6 relative (the squared distances are summed in another order than the
+    oracle's single chain: three sums of 128 terms each ~ 1e2 .. 1e4).  Offsets: per batch row, shared, absent."""
+    B, K = shape
+    d = 128
+    rng = np.random.RandomState(B * K)
+    r = lambda *s: rng.randn(*s).astype(np.float32)
+    host = {"x_prev": r(B, K, d), "eps": r(B, K, d), "y": r(B, d),
+            "A": (0.9 * np.eye(d) + 0.05 * rng.randn(d, d)).astype(np.float32),
+            "Q": (0.45 * np.eye(d) + 0.05 * rng.randn(d, d)).astype(np.float32),
+            "C": (0.1 * rng.randn(d, d)).astype(np.float32), "off_q": r(B, d), "off_g": r(d)}
+    o = {key: torch.from_numpy(value).to(hip_device) for key, value in host.items()}
+    s_p, s_g, s_q = (torch.tensor(v, dtype=torch.float32, device=hip_device) for v in (1.0, 0.5, 0.7))
+    terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    anc = _ancestors(B, K, hip_device, seed=B + K, spread=2.0) if gather else None
+    out_x = torch.empty(B, K, d, device=hip_device)
+    kernels.read_flags(hip_device)
+    lw = kernels.affine_propagate_wide(o["x_prev"], o["eps"], o["y"], *terms, (s_p, s_g, s_q), out_x, ancestors=anc)
+    assert lw is not None, "the wide launch declined the shape it is built for"
+    moved = host["x_prev"] if anc is None else c_oracle.gather(host["x_prev"], anc.cpu().numpy())[0]
+    want_x = c_oracle.affine_rsample(moved, host["Q"], host["off_q"], host["eps"], 0.7)
+    np.testing.assert_array_equal(out_x.cpu().numpy(), want_x)
+    want_lw = c_oracle.affine_logweight(moved, want_x, host["y"], (host["A"], None), (host["C"], host["off_g"]),
+                                        (host["Q"], host["off_q"]), 1.0, 0.5, 0.7)
+    got = lw.cpu().numpy()
+    assert np.isfinite(got).all()
+    scale = np.maximum(np.abs(want_lw), 1.0)
+    assert float((np.abs(got - want_lw) / scale).max()) <= 2e-6 * 4
+    assert kernels.read_flags(hip_device) == 0
+
+
+def test_the_wide_step_declines_what_it_does_not_cover_and_survives_bad_ancestors(kernels, hip_device):
+    d = 128
+    g = torch.Generator(device=hip_device).manual_seed(0)
+    x = torch.randn(2, 64, d, device=hip_device, generator=g)
+    y = torch.randn(2, d, device=hip_device, generator=g)
+    W = torch.randn(d, d, device=hip_device, generator=g) * 0.05
+    one = torch.tensor(1.0, device=hip_device)
+    out = torch.empty_like(x)
+    terms = ((W, None), (W, None), (W, None))
+    assert kernels.affine_propagate_wide(x[:, :40], x[:, :40], y, *terms, (one, one, one), out[:, :40].contiguous()) is None
+    assert kernels.affine_propagate_wide(x, x, y, (W.t(), None), (W, None), (W, None), (one, one, one), out) is None
+    anc = torch.zeros(2, 64, dtype=torch.int64, device=hip_device)
+    anc[0, 3], anc[1, 5] = 64, -1
+    kernels.read_flags(hip_device)
+    lw = kernels.affine_propagate_wide(x, torch.zeros_like(x), y, *terms, (one, one, one), out, ancestors=anc)
+    assert lw is not None and torch.isfinite(lw).all()
+    assert kernels.read_flags(hip_device) != 0
