@@ -980,6 +980,31 @@ class HipKernels:
                 self.timer.note("philox_normal_fill", (self._lib.aesmc_philox_normal_fill, args), 4 * out.numel(), (out,))
         return out
 
+    def affine_wide_covers(self, source, weight, offset=None, scale=None):
+        """Host-only test of what K17 / K18 assume about one location `offset + source @ weight.T`: source [B,K,128]
+        float32 on the HIP device with K a multiple of 32, weight [128,128] as an nn.Linear holds it, offset None,
+        [128] or [B,128], scale (if given) one value."""
+        if not (torch.is_tensor(weight) and weight.dim() == 2 and weight.dtype == torch.float32 and weight.is_cuda):
+            return False
+        wide = self._wide_dim
+        if wide is None:
+            wide = self._wide_dim = int(self._lib.aesmc_affine_wide_dim())
+        shape = tuple(source.shape)
+        if len(shape) != 3 or shape[2] != wide or tuple(weight.shape) != (wide, wide) or source.dtype != torch.float32 or \
+                source.device != weight.device or shape[1] % 32 != 0 or shape[0] * shape[1] == 0:
+            return False
+        if not weight.is_contiguous() or weight.data_ptr() % 16:
+            return False
+        if offset is not None:
+            if not torch.is_tensor(offset) or offset.dtype != torch.float32 or offset.device != weight.device or \
+                    tuple(offset.shape) not in ((wide,), (shape[0], wide)) or offset.stride(-1) != 1 or \
+                    offset.data_ptr() % 16 or (offset.dim() == 2 and offset.stride(0) % 4):
+                return False
+        if scale is not None and not (torch.is_tensor(scale) and scale.numel() == 1 and scale.dtype == torch.float32 and
+                                      scale.device == weight.device):
+            return False
+        return True
+
     def affine_propagate_wide(self, x_src, eps, y_rows, transition, emission, proposal, scales, out_x, ancestors=None):
         """K17 + K18: a linear-Gaussian step whose rows hold 128 float32 values (BASELINE.json configs[4]) on the fp32
         matrix cores — the draw `loc_q(x_prev) + eps * s_q` into `out_x` (the C oracle's bits) and the step's

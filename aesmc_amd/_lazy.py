@@ -179,6 +179,12 @@ class LazyDraw(LazyParticles):
         from . import _ops, state
         terms = self.terms
         eps = state._noise_tensor(self.noise, self)
+        if getattr(self, "wide", False):
+            # rows too wide for K9 (a draw deferred for K17 that no launch formed after all): the location as
+            # `particle_affine` evaluates it, then K6 — what `Normal(loc, scale).rsample` does with the same noise
+            from .linear_gaussian import particle_affine
+            loc = particle_affine(real(terms.source), terms.weight, terms.offset)
+            return _ops.normal_rsample(eps, loc, terms.scale_param.expand_as(loc))
         return _ops.affine_rsample(real(terms.source), terms.weight, terms.offset, terms.scale_param, eps)
 
 

@@ -191,6 +191,10 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     differentiates only through the row log-sum-exp (`_ops.attach_lse`)."""
     if not _FUSED_NORMAL:
         return None
+    if type(latent) is LazyDraw and latent.is_pending and getattr(latent, "wide", False):
+        log_weight = _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation)
+        if log_weight is not None:
+            return log_weight
     affine = _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, observation)
     if type(latent) is LazyDraw and latent.is_pending:
         # a deferred draw: K16 / K15 forms it together with the log-weight when the step is linear-Gaussian in this
@@ -369,6 +373,45 @@ def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, obse
     return operands
 
 
+def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation):
+    """A linear-Gaussian step on rows of 128 values whose latent is this proposal's deferred draw, forward only: K17 +
+    K18 form the draw (through the ancestors when nothing has gathered x_{t-1} yet) and the log-weights; the draw
+    resolves to the tensor they wrote.  None when the step is not of that kind (the caller's other routes apply)."""
+    if torch.is_grad_enabled() or not (torch.is_tensor(observation) and observation.dim() == 3 and
+                                       observation.stride(1) == 0):
+        return None
+    prior, proposal, emission = affine_terms(prior_dist), affine_terms(proposal_dist), affine_terms(emission_dist)
+    if prior is None or proposal is None or emission is None or not latent.terms.same_terms(proposal):
+        return None
+    x_prev = prior.source
+    if not (_same_tensor(proposal.source, x_prev) and _same_tensor(emission.source, latent)):
+        return None
+    if type(x_prev) in (LazyDraw, LazyAffine) or not torch.is_tensor(latent.noise):
+        return None
+    provider = _kernels.get()
+    scales = (prior.scale_param, emission.scale_param, proposal.scale_param)
+    if not (provider.affine_wide_covers(x_prev, prior.weight, prior.offset, scales[0]) and
+            provider.affine_wide_covers(latent, emission.weight, emission.offset, scales[1]) and
+            provider.affine_wide_covers(x_prev, proposal.weight, proposal.offset, scales[2])):
+        return None
+    ancestors = None
+    if type(x_prev) is LazyResampled:
+        if x_prev.pending is not None:
+            x_prev, ancestors = x_prev.pending        # (x_{t-1}, ancestors): fetched inside the launch
+        else:
+            x_prev = x_prev.materialise()
+    y_rows = observation[:, 0]
+    x_t = torch.empty(latent.shape, dtype=torch.float32, device=y_rows.device)
+    log_weight = provider.affine_propagate_wide(x_prev.detach(), latent.noise, y_rows, (prior.weight.detach(), prior.offset),
+                                                (emission.weight.detach(), emission.offset),
+                                                (proposal.weight.detach(), proposal.offset), scales, x_t,
+                                                ancestors=ancestors)
+    if log_weight is None:
+        return None
+    latent.resolve(x_t)
+    return log_weight
+
+
 _FUSED_NORMAL = True
 
 
@@ -413,6 +456,16 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
             eps = _standard_normal(base.batch_shape, dtype=source.dtype, device=source.device)
             draw = _ops.affine_rsample(source, terms.weight, terms.offset, scale, eps)
             draw._aesmc_draw_of = terms      # lets `infer` differentiate the whole step in one node (K14)
+            return draw
+        if _DEFER_DRAWS.get() and not torch.is_grad_enabled() and getattr(terms, "defer_draw", None) is not False and \
+                _kernels.get().name == "hip" and _kernels.get().affine_wide_covers(terms.source, terms.weight, terms.offset,
+                                                                                 scale):
+            # rows of 128 values (BASELINE.json configs[4]), forward only: the draw is left to the launch that weighs
+            # the step (K17: both maps of x_{t-1} on the matrix cores, the draw, two of the three densities); its noise
+            # is drawn here, by the very call `rsample` makes
+            eps = _standard_normal(base.batch_shape, dtype=terms.source.dtype, device=terms.source.device)
+            draw = LazyDraw(terms, eps)
+            draw.wide = True
             return draw
     if type(base) not in (torch.distributions.Normal, AffineNormal):
         return None
