@@ -47,6 +47,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_FP32_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak (v_mfma_f32_16x16x4_f32; MI355X_MICROARCH.md: 155 TF measured)
 
 # name: description, model kind, d, B (per GPU under weak scaling), K, T, model keyword arguments
 WORKLOADS = {
@@ -651,6 +652,27 @@ def kernel_legs(ctx):
         legs["K11_{}_affine_adjoint".format(label)] = leg(
             timeit(lambda: k.particle_affine_backward(eps, x_prev, Q), reps=5), 4 * N * 3 * d, shape=shape)
         del x_prev, x, eps, lw
+    # configs[4]'s extent: the step on the fp32 matrix cores (K17 + K18), priced against their dense peak
+    B, K, d = 64, 16384, 128
+    make = lambda *shape: torch.randn(*shape, device=dev, generator=gen)
+    x_prev, eps, y, off = make(B, K, d), make(B, K, d), make(B, d), make(B, d)
+    eye = torch.eye(d, device=dev)
+    A, C, Q = 0.9 * eye + 0.01 * make(d, d), 0.1 * make(d, d), 0.45 * eye + 0.01 * make(d, d)
+    scales = tuple(torch.tensor(v, device=dev) for v in (1.0, 0.5, 0.7))
+    idx = k.ancestor_index(torch.randn(B, K, device=dev, generator=gen), torch.rand(B, device=dev, dtype=torch.float64,
+                                                                                   generator=gen))
+    out_x = torch.empty_like(x_prev)
+    wide = lambda: k.affine_propagate_wide(x_prev, eps, y, (A, None), (C, None), (Q, off), scales, out_x, ancestors=idx)
+    if wide() is not None:
+        us = timeit(wide, reps=5)
+        flops = 3 * 2.0 * B * K * d * d
+        nbytes = 4 * B * K * (3 * d + 1) + 8 * B * K
+        legs["K17_K18_c5_wide_step"] = {
+            "avg_launch_us": round(us, 1), "shape": "B={} K={} d={} (gather + draw from given noise + log-weight, two launches)".format(B, K, d),
+            "bound": "mfma", "flops_per_step": flops, "achieved": round(flops / us / 1e6, 1), "unit": "TFLOP/s",
+            "peak": MFMA_FP32_PEAK_TFLOPS, "frac": round(flops / us / 1e6 / MFMA_FP32_PEAK_TFLOPS, 4),
+            "algorithmic_bytes_per_step": nbytes, "hbm_GBps": round(nbytes / us / 1e3, 1)}
+    del x_prev, eps, out_x
     torch.cuda.empty_cache()
     return legs
 
