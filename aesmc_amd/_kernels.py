@@ -1009,6 +1009,9 @@ class HipKernels:
         """K17 + K18: a linear-Gaussian step whose rows hold 128 float32 values (BASELINE.json configs[4]) on the fp32
         matrix cores — the draw `loc_q(x_prev) + eps * s_q` into `out_x` (the C oracle's bits) and the step's
         log-weights [B,K] (its values to rounding), x_prev = x_src[b, ancestors[b,k]] when `ancestors` is given.
+        `eps`: the noise [B,K,128], or an `_philox.NoiseStream` — the reservation of the `normal_` call that did not
+        happen: the launch then forms the noise itself (None when the shape does not allow it: the caller materialises
+        it with `philox_normal`).
         None when the launch does not cover the operands (other extents, strided weights, K not a multiple of 32)."""
         if x_src.dtype != torch.float32 or x_src.dim() != 3:
             return None
@@ -1018,7 +1021,13 @@ class HipKernels:
             wide = self._wide_dim = int(self._lib.aesmc_affine_wide_dim())
         if dx != wide or y_rows.dim() != 2 or y_rows.size(1) != wide or K % 32 != 0 or B * K == 0:
             return None
-        if eps.shape != x_src.shape or eps.dtype != x_src.dtype or eps.device != x_src.device:
+        drawn = not torch.is_tensor(eps)      # an `_philox.NoiseStream`: the launch forms the noise itself
+        if drawn:
+            if eps.numel != x_src.numel():
+                raise ValueError("aesmc_amd: affine_propagate_wide: the reservation does not match x_src")
+            if eps.threads % wide or K % (4 * (eps.threads // wide)):
+                return None
+        elif eps.shape != x_src.shape or eps.dtype != x_src.dtype or eps.device != x_src.device:
             raise ValueError("aesmc_amd: affine_propagate_wide noise must match x_src")
         for weight, offset in (transition, emission, proposal):
             if tuple(weight.shape) != (wide, wide) or not weight.is_contiguous() or weight.data_ptr() % 16 or \
@@ -1030,8 +1039,10 @@ class HipKernels:
         if any(scale.numel() != 1 for scale in scales):
             return None
         self._check_out(out_x, (B, K, dx), x_src, "affine_propagate_wide")
-        x_src, eps = self._dense16(x_src), self._dense16(eps)
-        if out_x.data_ptr() in (x_src.data_ptr(), eps.data_ptr()):
+        x_src = self._dense16(x_src)
+        if not drawn:
+            eps = self._dense16(eps)
+        if out_x.data_ptr() == x_src.data_ptr() or (not drawn and out_x.data_ptr() == eps.data_ptr()):
             raise ValueError("aesmc_amd: affine_propagate_wide cannot write the draw over its inputs")
         if ancestors is not None:
             self._check_index(x_src, ancestors)
@@ -1045,10 +1056,11 @@ class HipKernels:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_src.device)
         maps = [self._affine_map(*term, slot=slot) for slot, term in enumerate((transition, emission, proposal))]
         with _on_device(x_src.device):
-            args = (_ptr(x_src), _ptr(ancestors), _ptr(eps), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
-                    ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
-                    _ptr(scales[2]), _ptr(out_x), _ptr(out), _ptr(ws), ws_bytes, _ptr(self.flags(x_src.device)), B, K,
-                    self._stream(x_src))
+            noise = (eps.seed, eps.offset, eps.threads, _ptr(eps.state)) if drawn else (0, 0, 256, 0)
+            args = (_ptr(x_src), _ptr(ancestors), 0 if drawn else _ptr(eps), _ptr(y_rows), y_rows.stride(0),
+                    ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]),
+                    _ptr(scales[1]), _ptr(scales[2]), _ptr(out_x), _ptr(out), _ptr(ws), ws_bytes,
+                    _ptr(self.flags(x_src.device)), B, K) + noise + (self._stream(x_src),)
             status = self._lib.aesmc_affine_normal_propagate_wide(*args)
             if status == 2:
                 return None

@@ -101,7 +101,7 @@ SIGNATURES = {
     "aesmc_affine_wide_dim": (_i64, []),
     "aesmc_affine_wide_workspace_bytes": (_sz, [_i64, _i64]),
     "aesmc_affine_normal_propagate_wide": (_i32, [_vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp, _vp,
-                                                  _vp, _sz, _vp, _i64, _i64, _vp]),
+                                                  _vp, _sz, _vp, _i64, _i64, _u64, _u64, _i64, _vp, _vp]),
     "aesmc_philox_normal_fill": (_i32, [_vp, _i64, _u64, _u64, _i64, _i32, _vp, _vp]),
     "aesmc_normal_rsample_drawn": (_i32, [_i32, ctypes.POINTER(View3), ctypes.POINTER(View3), _vp, _i64, _i64, _i64, _u64, _u64, _i64, _i32, _vp, _vp]),
 }

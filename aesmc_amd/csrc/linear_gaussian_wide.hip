@@ -22,6 +22,7 @@
 // lane (g, n) with outputs 16 mt + 4 g + r of particle n: the element-wise part (draw, residuals) runs in that layout
 // on 16-byte pieces, a particle's four lanes add their sums through two cross-lane steps.
 #include "linear_gaussian.hpp"
+#include "philox_normal.hpp"
 
 namespace aesmc {
 
@@ -47,6 +48,10 @@ struct WideArgs {
   int32_t *flags;
   int64_t N;
   uint32_t K;
+  // K17 with the noise formed in the launch (eps == nullptr): torch's Philox stream (philox_normal.hpp) and Q = G / 128,
+  // the particles one trip's four outputs lie apart
+  PhiloxStream ps;
+  uint32_t Q;
 };
 
 // the maps' weights into LDS, permuted per row (see the header)
@@ -118,8 +123,14 @@ __device__ __forceinline__ float wide_particle_sum(float v, uint32_t lane) {
   return ((v0 + v1) + v2) + v3;
 }
 
-// K17
-template <bool GATHER>
+// K17.  DRAWN: the noise is element e of what `torch.empty([B,K,128]).normal_()` would hold, formed here (as K16 forms
+// its own).  ATen gives thread t the elements t + G (4 c + i), i = 0 .. 3, of its c-th Philox call; G is a multiple of
+// 128, so those are ONE output j = t % 128 of four particles Q = G / 128 apart.  A tile therefore takes its 32
+// particles as 8 consecutive ones from each of the four quarters of a trip (matrix tile nt, column n: quarter
+// 2 nt + (n >> 3), particle (n & 7) of the eight) — columns are independent, any 16 particles make a matrix tile — and a
+// call's four normals all land in this wavefront: the two lanes n and n ^ 8 that hold the same outputs of the same
+// eight particles share the calls (two of a group's four outputs each) and swap what the other needs.
+template <bool GATHER, bool DRAWN>
 __global__ __launch_bounds__(kWdThreads, 1) void affine_wide_draw_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wd_smem[];
   float *wl = reinterpret_cast<float *>(wd_smem);
@@ -134,13 +145,23 @@ __global__ __launch_bounds__(kWdThreads, 1) void affine_wide_draw_kernel(WideArg
   const int64_t tiles = a.N / kWdTile;
   const uint32_t K = a.K;
   uint32_t bad = 0;
+  PhiloxStream ps = a.ps;
+  if constexpr (DRAWN) ps = philox_resolve(a.ps);
+  const uint32_t h = n >> 3, Q = a.Q, per_trip = Q / 8;
   for (int64_t tile = (int64_t)blockIdx.x * (kWdThreads / 64) + wave; tile < tiles; tile += (int64_t)gridDim.x * (kWdThreads / 64)) {
-    const int64_t n0 = tile * kWdTile;
-    const uint32_t b = (uint32_t)(n0 / K);      // (K a multiple of 32: a tile lies inside one batch row)
+    // the particle of column n of matrix tile nt; a tile lies inside one batch row (the host: K a multiple of 32, and
+    // of 4 Q when the launch draws)
+    const uint32_t trip = DRAWN ? (uint32_t)(tile / per_trip) : 0u;
+    const uint32_t pb = DRAWN ? ((uint32_t)(tile - (int64_t)trip * per_trip)) * 8u + (n & 7u) : 0u;
+    int64_t part[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      part[nt] = DRAWN ? (int64_t)4 * Q * trip + pb + (int64_t)Q * (2 * nt + h) : tile * kWdTile + 16 * nt + n;
+    const uint32_t b = (uint32_t)((DRAWN ? (int64_t)4 * Q * trip : tile * kWdTile) / K);
     float bx[2][32];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const int64_t p = n0 + 16 * nt + n;
+      const int64_t p = part[nt];
       int64_t row = p;
       if constexpr (GATHER) {
         int64_t anc = a.anc[p];
@@ -157,34 +178,56 @@ __global__ __launch_bounds__(kWdThreads, 1) void affine_wide_draw_kernel(WideArg
     wd_f4 acc[2][8][2];
     wide_offsets<2>(a, b, g, acc);
     wide_products<2>(wl, lane, bx, acc);
-    // ---- the draw and the two squared distances, outputs 16 mt + 4 g + r of particle n ----------------------
+    // ---- the draw and the two squared distances, outputs 16 mt + 4 g + r of the lane's two particles ------------
+    float q_sum[2] = {0.0f, 0.0f}, p_sum[2] = {0.0f, 0.0f};
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int64_t p = n0 + 16 * nt + n;
-      float q_sum = 0.0f, p_sum = 0.0f;
-      wd_f4 e[8];
+    for (int mt = 0; mt < 8; ++mt) {
+      wd_f4 e[2];
+      if constexpr (DRAWN) {
+        // outputs r = 2 h, 2 h + 1 are this lane's calls, the other two its partner's (lane ^ 8); of a call's four
+        // normals quarter h goes to this lane's particle of matrix tile 0, quarter 2 + h to tile 1, the rest across
+        const uint32_t t0 = pb * kWd + 16u * mt + 4u * g + 2u * h;
+        const float4 c0 = philox_normal4(ps, t0, trip), c1 = philox_normal4(ps, t0 + 1u, trip);
+        const float keep[2][2] = {{h ? c0.y : c0.x, h ? c0.w : c0.z}, {h ? c1.y : c1.x, h ? c1.w : c1.z}};      // [call][nt]
+        const float send[2][2] = {{h ? c0.x : c0.y, h ? c0.z : c0.w}, {h ? c1.x : c1.y, h ? c1.z : c1.w}};
+        float got[2][2];
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) e[mt] = *reinterpret_cast<const wd_f4 *>(a.eps + p * kWd + 16 * mt + 4 * g);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
+          for (int nt = 0; nt < 2; ++nt) got[u][nt] = __shfl_xor(send[u][nt], 8, kWave);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          e[nt][0] = h ? got[0][nt] : keep[0][nt];
+          e[nt][1] = h ? got[1][nt] : keep[1][nt];
+          e[nt][2] = h ? keep[0][nt] : got[0][nt];
+          e[nt][3] = h ? keep[1][nt] : got[1][nt];
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) e[nt] = *reinterpret_cast<const wd_f4 *>(a.eps + part[nt] * kWd + 16 * mt + 4 * g);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
         wd_f4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float noise = e[mt][r] * s_q;
+          const float noise = e[nt][r] * s_q;
           x[r] = acc[0][mt][nt][r] + noise;
           const float dq = x[r] - acc[0][mt][nt][r], dp = x[r] - acc[1][mt][nt][r];
-          q_sum = fma_t(dq, dq, q_sum);
-          p_sum = fma_t(dp, dp, p_sum);
+          q_sum[nt] = fma_t(dq, dq, q_sum[nt]);
+          p_sum[nt] = fma_t(dp, dp, p_sum[nt]);
         }
-        *reinterpret_cast<wd_f4 *>(a.out_x + p * kWd + 16 * mt + 4 * g) = x;
+        *reinterpret_cast<wd_f4 *>(a.out_x + part[nt] * kWd + 16 * mt + 4 * g) = x;
       }
-      q_sum = wide_particle_sum(q_sum, lane);
-      p_sum = wide_particle_sum(p_sum, lane);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float qs = wide_particle_sum(q_sum[nt], lane), ps_ = wide_particle_sum(p_sum[nt], lane);
       if (g == 0) {
         float2 out;
-        out.x = (-p_sum) / two_var_p - const_p;
-        out.y = (-q_sum) / two_var_q - const_q;
-        *reinterpret_cast<float2 *>(a.sums + 2 * p) = out;
+        out.x = (-ps_) / two_var_p - const_p;
+        out.y = (-qs) / two_var_q - const_q;
+        *reinterpret_cast<float2 *>(a.sums + 2 * part[nt]) = out;
       }
     }
   }
@@ -257,15 +300,19 @@ extern "C" int aesmc_affine_normal_propagate_wide(
     const void *x_src, const int64_t *ancestors, const void *eps, const void *y, int64_t y_stride_b,
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, void *ws, size_t ws_bytes,
-    int32_t *flags, int64_t B, int64_t K, void *stream) {
-  if (x_src == nullptr || eps == nullptr || y == nullptr || transition == nullptr || emission == nullptr ||
+    int32_t *flags, int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *rng_state,
+    void *stream) {
+  if (x_src == nullptr || y == nullptr || transition == nullptr || emission == nullptr ||
       proposal == nullptr || scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || out_x == nullptr ||
       out_lw == nullptr || ws == nullptr || B < 0 || K < 0)
     return AESMC_ERR_INVALID_ARGUMENT;
   const void *aligned[] = {x_src, eps, out_x, ws};
   for (const void *ptr : aligned)
-    if (!aligned16(ptr)) return AESMC_ERR_INVALID_ARGUMENT;
-  if (out_x == x_src || out_x == eps || (((uintptr_t)ancestors) & 7u) != 0 || (((uintptr_t)y) & 15u) != 0 ||
+    if (ptr != nullptr && !aligned16(ptr)) return AESMC_ERR_INVALID_ARGUMENT;
+  if (eps == nullptr && (threads <= 0 || (threads % 256) != 0 || threads > 0x7fffffffLL || (offset & 3u) != 0 ||
+                         (((uintptr_t)rng_state) & 7u) != 0))
+    return AESMC_ERR_INVALID_ARGUMENT;
+  if (out_x == x_src || (eps != nullptr && out_x == eps) || (((uintptr_t)ancestors) & 7u) != 0 || (((uintptr_t)y) & 15u) != 0 ||
       (y_stride_b % 4) != 0)
     return AESMC_ERR_INVALID_ARGUMENT;
   const aesmc_affine_map *maps[3] = {transition, emission, proposal};
@@ -278,6 +325,9 @@ extern "C" int aesmc_affine_normal_propagate_wide(
   }
   const int64_t N = B * K;
   if (K % kWdTile != 0 || N >= (1ll << 31) / 2) return AESMC_ERR_UNSUPPORTED;
+  // the noise formed in the launch: a trip's four quarters (Q = G / 128 particles each) inside one batch row
+  const int64_t Q = eps == nullptr ? threads / kWd : 0;
+  if (eps == nullptr && (Q % 8 != 0 || K % (4 * Q) != 0)) return AESMC_ERR_UNSUPPORTED;
   if (ws_bytes < aesmc_affine_wide_workspace_bytes(B, K)) return AESMC_ERR_WORKSPACE;
   if (N == 0) return AESMC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -291,23 +341,28 @@ extern "C" int aesmc_affine_normal_propagate_wide(
   a.s_q = static_cast<const float *>(scale_q);
   a.out_x = static_cast<float *>(out_x); a.sums = static_cast<float *>(ws); a.out_lw = static_cast<float *>(out_lw);
   a.flags = flags; a.N = N; a.K = (uint32_t)K;
+  a.ps = philox_stream(seed, offset, eps == nullptr ? threads : 256, rng_state); a.Q = (uint32_t)Q;
   const int64_t tiles = N / kWdTile;
   const unsigned grid = (unsigned)std::min<int64_t>(lg_cu_count(), (tiles + kWdThreads / 64 - 1) / (kWdThreads / 64));
   const size_t lds2 = sizeof(float) * 2 * (size_t)kWd * kWdRow, lds1 = sizeof(float) * (size_t)kWd * kWdRow;
-  static bool raised[3][64] = {};
-  if (ancestors != nullptr) {
-    if (!lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_wide_draw_kernel<true>), raised[0])) return AESMC_ERR_LAUNCH;
-    hipLaunchKernelGGL(affine_wide_draw_kernel<true>, dim3(grid), dim3(kWdThreads), lds2, s, a);
-  } else {
-    if (!lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_wide_draw_kernel<false>), raised[1])) return AESMC_ERR_LAUNCH;
-    hipLaunchKernelGGL(affine_wide_draw_kernel<false>, dim3(grid), dim3(kWdThreads), lds2, s, a);
-  }
+  static bool raised[5][64] = {};
+#define WIDE_DRAW(G, D, slot)                                                                                          \
+  do {                                                                                                                 \
+    if (!lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_wide_draw_kernel<G, D>), raised[slot]))           \
+      return AESMC_ERR_LAUNCH;                                                                                         \
+    hipLaunchKernelGGL((affine_wide_draw_kernel<G, D>), dim3(grid), dim3(kWdThreads), lds2, s, a);                     \
+  } while (0)
+  if (ancestors != nullptr && eps == nullptr) WIDE_DRAW(true, true, 0);
+  else if (ancestors != nullptr) WIDE_DRAW(true, false, 1);
+  else if (eps == nullptr) WIDE_DRAW(false, true, 2);
+  else WIDE_DRAW(false, false, 3);
+#undef WIDE_DRAW
   if (hipGetLastError() != hipSuccess) return AESMC_ERR_LAUNCH;
   WideArgs e = a;
   e.x_in = static_cast<const float *>(out_x); e.anc = nullptr;
   e.w[0] = static_cast<const float *>(emission->weight); e.off[0] = static_cast<const float *>(emission->offset);
   e.off_sb[0] = emission->offset_stride_b;
-  if (!lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_wide_emission_kernel), raised[2])) return AESMC_ERR_LAUNCH;
+  if (!lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_wide_emission_kernel), raised[4])) return AESMC_ERR_LAUNCH;
   hipLaunchKernelGGL(affine_wide_emission_kernel, dim3(grid), dim3(kWdThreads), lds1, s, e);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }

@@ -386,7 +386,7 @@ def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation):
     x_prev = prior.source
     if not (_same_tensor(proposal.source, x_prev) and _same_tensor(emission.source, latent)):
         return None
-    if type(x_prev) in (LazyDraw, LazyAffine) or not torch.is_tensor(latent.noise):
+    if type(x_prev) in (LazyDraw, LazyAffine):
         return None
     provider = _kernels.get()
     scales = (prior.scale_param, emission.scale_param, proposal.scale_param)
@@ -402,10 +402,14 @@ def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation):
             x_prev = x_prev.materialise()
     y_rows = observation[:, 0]
     x_t = torch.empty(latent.shape, dtype=torch.float32, device=y_rows.device)
-    log_weight = provider.affine_propagate_wide(x_prev.detach(), latent.noise, y_rows, (prior.weight.detach(), prior.offset),
-                                                (emission.weight.detach(), emission.offset),
-                                                (proposal.weight.detach(), proposal.offset), scales, x_t,
-                                                ancestors=ancestors)
+    maps = ((prior.weight.detach(), prior.offset), (emission.weight.detach(), emission.offset),
+            (proposal.weight.detach(), proposal.offset))
+    log_weight = provider.affine_propagate_wide(x_prev.detach(), latent.noise, y_rows, *maps, scales, x_t, ancestors=ancestors)
+    if log_weight is None and not torch.is_tensor(latent.noise):
+        # the launch cannot form this shape's noise itself: the same values as a tensor (the fill kernel), once
+        latent.noise = _noise_tensor(latent.noise, latent)
+        log_weight = provider.affine_propagate_wide(x_prev.detach(), latent.noise, y_rows, *maps, scales, x_t,
+                                                    ancestors=ancestors)
     if log_weight is None:
         return None
     latent.resolve(x_t)
@@ -463,7 +467,11 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
             # rows of 128 values (BASELINE.json configs[4]), forward only: the draw is left to the launch that weighs
             # the step (K17: both maps of x_{t-1} on the matrix cores, the draw, two of the three densities); its noise
             # is drawn here, by the very call `rsample` makes
-            eps = _standard_normal(base.batch_shape, dtype=terms.source.dtype, device=terms.source.device)
+            source = terms.source
+            if _kernel_noise_applies(source):      # (reserved in PyTorch's generator; K17 forms it, or the fill kernel does)
+                eps = _philox.reserve(source.numel() // source.size(-1) * terms.weight.size(0), source.device)
+            else:
+                eps = _standard_normal(base.batch_shape, dtype=source.dtype, device=source.device)
             draw = LazyDraw(terms, eps)
             draw.wide = True
             return draw

@@ -408,7 +408,10 @@ int aesmc_affine_normal_propagate_drawn(
  * (state.py:114-155) — three library GEMMs, their offsets' broadcast adds, the draw and the log-weight kernel before.
  * Weights [128,128] row-major contiguous (what an nn.Linear holds), offsets NULL / [128] / [B,128], scales one value
  * each, K a multiple of 32; `ws`: aesmc_affine_wide_workspace_bytes(B, K) bytes (two sums per particle between the two
- * launches).  The squared distances are summed per lane and then over a particle's four lanes: equal to the C oracle's
+ * launches).  `eps` NULL: the noise is formed in the launch — element e of `torch.empty([B,K,128]).normal_()` for the
+ * generator at (seed, offset) with ATen's `threads` (rng_state: as for aesmc_affine_normal_propagate_drawn); covered
+ * when K is a multiple of 4 * threads / 128 (configs[4]: threads = 524288, K = 16384), else AESMC_ERR_UNSUPPORTED: the
+ * caller fills the noise (aesmc_philox_normal_fill) and passes it.  The squared distances are summed per lane and then over a particle's four lanes: equal to the C oracle's
  * single chain to rounding (2e-6 relative in the tests), not bit for bit.  AESMC_ERR_UNSUPPORTED for every other shape
  * (the caller keeps the route through aesmc_normal_rsample / aesmc_normal_logweight). */
 int64_t aesmc_affine_wide_dim(void);      /* 128 */
@@ -417,7 +420,8 @@ int aesmc_affine_normal_propagate_wide(
     const void *x_src, const int64_t *ancestors, const void *eps, const void *y, int64_t y_stride_b,
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, void *ws, size_t ws_bytes,
-    int32_t *flags, int64_t B, int64_t K, void *stream);
+    int32_t *flags, int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *rng_state,
+    void *stream);
 
 /* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
  *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])

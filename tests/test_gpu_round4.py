@@ -375,3 +375,41 @@ def test_a_wide_model_runs_through_the_matrix_core_step_and_gives_the_other_rout
     out = inference.infer("smc", small, model.initial, model.transition, model.emission, model.proposal, 64,
                           return_log_marginal_likelihood=True)
     assert calls["wide"] == T - 1 and out["log_marginal_likelihood"].requires_grad
+
+
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("shape", [(1, 16384), (3, 16384), (2, 32768)])
+def test_the_wide_step_forms_torchs_noise_itself(kernels, hip_device, shape, gather):
+    """K17 handed a reservation instead of a noise tensor: x_t and the log-weights equal, bit for bit, the launch handed
+    `torch.empty([B,K,128]).normal_()` drawn at the same generator state — the launch's 32-particle tiles take eight
+    particles from each quarter of a Philox trip, two lanes share every call — and the generator ends where `normal_`
+    leaves it.  Shapes the quarters do not fit (K not a multiple of 4 G / 128) are declined."""
+    from aesmc_amd import _philox
+    B, K = shape
+    d = 128
+    gen = torch.Generator(device=hip_device).manual_seed(B + K)
+    make = lambda *s: torch.randn(*s, device=hip_device, generator=gen)
+    x_prev, y, off_q = make(B, K, d), make(B, d), make(B, d)
+    eye = torch.eye(d, device=hip_device)
+    A, C, Q = 0.9 * eye + 0.05 * make(d, d), 0.1 * make(d, d), 0.45 * eye + 0.05 * make(d, d)
+    scales = tuple(torch.tensor(v, device=hip_device) for v in (1.0, 0.5, 0.7))
+    terms = ((A, None), (C, None), (Q, off_q))
+    anc = _ancestors(B, K, hip_device, seed=B, spread=1.0) if gather else None
+    torch.manual_seed(77)
+    state = torch.cuda.get_rng_state(hip_device)
+    eps = torch.empty(B, K, d, device=hip_device).normal_()
+    after = torch.cuda.get_rng_state(hip_device)
+    want_x = torch.empty_like(x_prev)
+    want_lw = kernels.affine_propagate_wide(x_prev, eps, y, *terms, scales, want_x, ancestors=anc)
+    torch.cuda.set_rng_state(state, hip_device)
+    noise = _philox.reserve(B * K * d, hip_device)
+    assert torch.equal(torch.cuda.get_rng_state(hip_device), after)
+    got_x = torch.empty_like(x_prev)
+    got_lw = kernels.affine_propagate_wide(x_prev, noise, y, *terms, scales, got_x, ancestors=anc)
+    assert got_lw is not None and want_lw is not None
+    assert torch.equal(got_x, want_x)
+    assert got_lw.cpu().numpy().tobytes() == want_lw.cpu().numpy().tobytes()
+    # a row shorter than a trip's four quarters: declined
+    short = _philox.reserve(2 * 4096 * d, hip_device)
+    assert kernels.affine_propagate_wide(x_prev[:2, :4096].contiguous(), short, y[:2], (A, None), (C, None), (Q, off_q[:2]),
+                                         scales, torch.empty(2, 4096, d, device=hip_device)) is None if B >= 2 else True
