@@ -225,7 +225,7 @@ def _step_backward_both_forms(kernels, call, grid=0):
 
 
 @pytest.mark.parametrize("arrives", ["nothing", "grad_x", "children", "children_collapsed", "children_and_grad_x"])
-@pytest.mark.parametrize("shape", [(1024, 4096), (3, 256), (5, 1024), (130, 512)])
+@pytest.mark.parametrize("shape", [(1024, 4096), (3, 256), (5, 1024), (130, 512), (1, 256), (2, 8192)])
 def test_both_forms_of_the_step_backward_give_the_same_bits(kernels, hip_device, shape, arrives):
     """aesmc_affine_step_backward_resampled for rows of ten float32 values: the form that keeps a wavefront's rows in
     registers and reads the weights as scalar operands (linear_gaussian_step_backward.hip) equals the form that stages
@@ -273,7 +273,7 @@ def test_both_forms_of_the_step_backward_give_the_same_bits(kernels, hip_device,
 
 # ---- configs[4]'s extent (rows of 128 values) on the fp32 matrix cores: K17 + K18 -----------------
 @pytest.mark.parametrize("gather", [False, True])
-@pytest.mark.parametrize("shape", [(2, 64), (3, 320), (5, 1024), (2, 16384)])
+@pytest.mark.parametrize("shape", [(1, 32), (2, 64), (3, 320), (5, 1024), (2, 16384)])
 def test_the_wide_step_equals_the_c_oracle(kernels, hip_device, shape, gather):
     """aesmc_affine_normal_propagate_wide against oracle/smc_core.c at d = 128: x_t bit for bit (the gather of the
     ancestor rows, one fma chain per element started from the offset — 32 matrix-core k-steps —, eps * s rounded
