@@ -28,7 +28,8 @@ def kernels(hip_device):
     return provider
 
 
-ORACLE_SHAPES = [(1024, 4096, 10, 10), (300, 4099, 10, 7), (37, 29000, 6, 9)]
+ORACLE_SHAPES = [(1024, 4096, 10, 10), (300, 4099, 10, 7), (37, 29000, 6, 9), (1, 128, 2, 2), (2, 4096, 12, 12),
+                 (5, 777, 3, 11), (64, 1024, 8, 4), (3, 200000, 10, 10)]
 
 
 @pytest.mark.parametrize("spread", [1.0, 5.0])
