@@ -7,7 +7,12 @@
     other product kernels which equal the oracle);
   * BASELINE.json configs[3] (nonlinear SSM + MLP proposal) at its own per-GPU size B=128, K=4096, T=100:
     size-independent properties (finite log Z, sorted in-range ancestors, finite loss and gradients) and a sample
-    of batch rows against the CPU port of the reference run on those rows alone.
+    of batch rows against the CPU port of the reference run on those rows alone;
+  * the two forms of the fused propagation launch (scalar-register weights / matrix cores) and of the step's backward
+    (rows in registers / tiles through LDS) against each other, bit for bit;
+  * configs[4]'s extent (rows of 128 values): the step on the fp32 matrix cores (K17 + K18) against the C oracle —
+    x_t bit for bit at (2, 16384, 128) —, its in-kernel noise against `torch.empty(...).normal_()`, and `infer` end to
+    end against the GEMM route.
 """
 import numpy as np
 import pytest
