@@ -74,7 +74,10 @@ WORKLOADS["tiny"] = ("LGSSM d=3 B=8 K=64 T=5 (test-sized: exercises every leg of
                      "lgssm", 3, 8, 64, 5, {})
 ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
 NO_GRAD = {"c5", "c5h"}             # autograd retention of T x [B,K,128] temporaries exceeds HBM: forward under no_grad
-GRAPH_PARTICLES = 1 << 21           # B*K at or below this: the eager loop is host-bound, replay one hipGraph
+# B*K at or below this: the ELBO is captured once and replayed as one hipGraph (aesmc_amd.graphs.GraphedLoss).  Small
+# shapes are host-bound in the eager loop; at the north-star shape (2^22 particles) the replay still runs 3-5 % ahead of
+# the eager loop (13.7-14.0 against 14.2-14.6 ms in five sessions of round 4) — the eager figure is printed beside it
+GRAPH_PARTICLES = 1 << 22
                                     # (above it a captured graph does not pay and is erratic: B=512 K=4096 12.1, 16.8
                                     #  and 27.6 ms as a graph in three runs of round 3 against 13.7 ms eager, B=1024 29.0
                                     #  against 21 ms — the loop is device-bound there and the eager allocator's
