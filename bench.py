@@ -6,6 +6,9 @@
 One "step" = one SMC ELBO evaluation (aesmc_amd.losses.get_loss(..., 'aesmc') forward, autograd
 graph recorded as in training) over one synthetic batch already resident in HBM.  The default
 workload is the north-star shape of BASELINE.json: LGSSM d=10, B=1024, K=4096, T=100 ("c4").
+Up to 2^22 particles per timestep (c4 included) the ELBO is captured once and replayed as one hipGraph
+(aesmc_amd.graphs.GraphedLoss: fresh uniforms and noise per replay, verified against eager evaluations); `mode` says
+so and `eager_particle_steps_per_sec` gives the plain Python loop's figure beside it (`--mode eager` times that).
 
 N > 1: `python bench.py --gpus N` starts N fresh children itself (python -m
 torch.distributed.run, one rank per GPU, RCCL) before anything touches the GPU; it also runs as a
@@ -16,10 +19,11 @@ ranks; the only collective on the data path is the all-reduce of sum_b log Z_b. 
 `extras`, the all-reduce's own time in `allreduce_us_per_elbo`.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the resampling kernel (fused step K2+K3; K3 alone where the step does not cover the
-                 payload; K1 for the IWAE workload), timed per launch with HIP events on its stream
-                 on operands sampled from the timed steps; achieved = algorithmic bytes / time,
-                 next to the bytes that had to move given how many ancestors survived;
+  roofline     : the dominant kernel of the timed region (K16 — the launch that holds the resampling gather — on the
+                 linear-Gaussian route; the fused step K2+K3 or K3 elsewhere; K1 for the IWAE workload), timed per
+                 launch with HIP events on its stream on operands sampled from the timed steps; achieved =
+                 algorithmic bytes / time, next to the PMC traffic and the bytes that had to move given how many
+                 ancestors survived;
   cpu_baseline : oracle/reference_port.py (the op-for-op CPU port of the reference, kind "port")
                  timed on this box's host cores on a bounded sample of the same workload;
   kernels      : the same per-launch figures for every kernel of the path;
