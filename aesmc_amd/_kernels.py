@@ -1019,7 +1019,12 @@ class HipKernels:
         wide = self._wide_dim
         if wide is None:
             wide = self._wide_dim = int(self._lib.aesmc_affine_wide_dim())
-        if dx != wide or y_rows.dim() != 2 or y_rows.size(1) != wide or K % 32 != 0 or B * K == 0:
+        if dx != wide or K % 32 != 0 or B * K == 0 or not x_src.is_cuda:
+            return None
+        # the observation as K18 reads it: float32 [B, 128] on the latents' device (a float64 observation — torch.from_numpy
+        # data against a float32 model — would be read as float32 bytes: declined, PyTorch's promotion applies instead)
+        if not (torch.is_tensor(y_rows) and y_rows.dim() == 2 and tuple(y_rows.shape) == (B, wide) and
+                y_rows.dtype == torch.float32 and y_rows.device == x_src.device):
             return None
         drawn = not torch.is_tensor(eps)      # an `_philox.NoiseStream`: the launch forms the noise itself
         if drawn:
@@ -1029,15 +1034,19 @@ class HipKernels:
                 return None
         elif eps.shape != x_src.shape or eps.dtype != x_src.dtype or eps.device != x_src.device:
             raise ValueError("aesmc_amd: affine_propagate_wide noise must match x_src")
-        for weight, offset in (transition, emission, proposal):
-            if tuple(weight.shape) != (wide, wide) or not weight.is_contiguous() or weight.data_ptr() % 16 or \
-                    weight.dtype != torch.float32:
+        for (weight, offset), scale in zip((transition, emission, proposal), scales):
+            # (what affine_wide_covers tests, for callers that did not ask it)
+            if not (torch.is_tensor(weight) and tuple(weight.shape) == (wide, wide) and weight.is_contiguous() and
+                    weight.data_ptr() % 16 == 0 and weight.dtype == torch.float32 and weight.device == x_src.device):
                 return None
-            if offset is not None and (offset.dtype != torch.float32 or offset.stride(-1) != 1 or offset.data_ptr() % 16 or
-                                       (offset.dim() == 2 and offset.stride(0) % 4)):
+            if offset is not None and not (torch.is_tensor(offset) and offset.dtype == torch.float32 and
+                                           offset.device == x_src.device and
+                                           tuple(offset.shape) in ((wide,), (B, wide)) and offset.stride(-1) == 1 and
+                                           offset.data_ptr() % 16 == 0 and not (offset.dim() == 2 and offset.stride(0) % 4)):
                 return None
-        if any(scale.numel() != 1 for scale in scales):
-            return None
+            if not (torch.is_tensor(scale) and scale.numel() == 1 and scale.dtype == torch.float32 and
+                    scale.device == x_src.device):
+                return None
         self._check_out(out_x, (B, K, dx), x_src, "affine_propagate_wide")
         x_src = self._dense16(x_src)
         if not drawn:

@@ -43,7 +43,9 @@ class LazyParticles(torch.Tensor):
 
     @property
     def requires_grad(self):
-        return self._lazy_real.requires_grad if self._lazy_real is not None else self._lazy_requires_grad()
+        if self._lazy_real is not None:
+            return self._lazy_real.requires_grad
+        return self._lazy_grad_mode and self._lazy_requires_grad()      # made under no_grad: no history, as eager
 
     def size(self, dim=None):
         return self._lazy_shape if dim is None else self._lazy_shape[dim]
@@ -77,7 +79,9 @@ class LazyParticles(torch.Tensor):
             # The values are kept for every later reader.  A first reader under torch.no_grad() (a logging or
             # diagnostic look at latents[-1] inside a callable) must not leave them without their history: the
             # reference's eager tensors carry it whoever looks first.
-            if not torch.is_grad_enabled() and self._lazy_requires_grad():
+            # (... only if it was MADE with autograd on: one made under torch.no_grad() — a pure evaluation — stands
+            #  for a tensor that never had a history, and must not start retaining one for every later step)
+            if not torch.is_grad_enabled() and self._lazy_grad_mode and self._lazy_requires_grad():
                 with torch.enable_grad():
                     self._lazy_real = self._lazy_compute()
             else:
@@ -112,6 +116,7 @@ class LazyResampled(LazyParticles):
         return LazyParticles._make(cls, source.shape, source)
 
     def __init__(self, source, index):
+        self._lazy_grad_mode = torch.is_grad_enabled()
         self._lazy_like = source
         self._lazy_source = source
         self._lazy_index = index
@@ -140,6 +145,7 @@ class LazyAffine(LazyParticles):
         return LazyParticles._make(cls, torch.Size(tuple(source.shape[:-1]) + (weight.size(0),)), weight)
 
     def __init__(self, source, weight, offset=None):
+        self._lazy_grad_mode = torch.is_grad_enabled()
         self._lazy_like = weight
         self.source, self.weight, self.offset = source, weight, offset
         self._lazy_real = None
@@ -164,6 +170,7 @@ class LazyDraw(LazyParticles):
         return LazyParticles._make(cls, torch.Size(tuple(source.shape[:-1]) + (weight.size(0),)), weight)
 
     def __init__(self, terms, noise):
+        self._lazy_grad_mode = torch.is_grad_enabled()
         self._lazy_like = terms.weight
         self.terms = terms              # the proposal's (source, weight, offset, scale_param)
         self.noise = noise

@@ -401,7 +401,10 @@ def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation):
         else:
             x_prev = x_prev.materialise()
     y_rows = observation[:, 0]
-    x_t = torch.empty(latent.shape, dtype=torch.float32, device=y_rows.device)
+    if y_rows.dtype != torch.float32 or y_rows.device != latent.device or y_rows.dim() != 2 or \
+            tuple(y_rows.shape) != (latent.shape[0], emission.weight.size(0)):
+        return None      # (e.g. a float64 observation against a float32 model: PyTorch's promotion, not K18's bytes)
+    x_t = torch.empty(latent.shape, dtype=torch.float32, device=latent.device)
     maps = ((prior.weight.detach(), prior.offset), (emission.weight.detach(), emission.offset),
             (proposal.weight.detach(), proposal.offset))
     log_weight = provider.affine_propagate_wide(x_prev.detach(), latent.noise, y_rows, *maps, scales, x_t, ancestors=ancestors)

@@ -82,10 +82,6 @@ NO_GRAD = {"c5", "c5h"}             # autograd retention of T x [B,K,128] tempor
 # shapes are host-bound in the eager loop; at the north-star shape (2^22 particles) the replay still runs 3-5 % ahead of
 # the eager loop (13.7-14.0 against 14.2-14.6 ms in five sessions of round 4) — the eager figure is printed beside it
 GRAPH_PARTICLES = 1 << 22
-                                    # (above it a captured graph does not pay and is erratic: B=512 K=4096 12.1, 16.8
-                                    #  and 27.6 ms as a graph in three runs of round 3 against 13.7 ms eager, B=1024 29.0
-                                    #  against 21 ms — the loop is device-bound there and the eager allocator's
-                                    #  recycling of the per-step tensors beats a graph that gives every one its own address)
 
 
 def parse(argv=None):
@@ -184,10 +180,13 @@ def self_launch(args, argv):
 
 @contextlib.contextmanager
 def tunable_gemms(enable):
-    """PyTorch's TunableOp for the duration of one leg (each new GEMM shape is timed once, the best kernel kept)."""
+    """PyTorch's TunableOp for the duration of one leg (each new GEMM shape is timed once, the best kernel kept).
+    Yields a dict whose "state" says what was actually switched on."""
     import torch
+    report = {"state": "off"}
     if not enable:
-        yield
+        report["state"] = "already on for the whole run (--tunableop on)"
+        yield report
         return
     try:
         was = (torch.cuda.tunable.is_enabled(), torch.cuda.tunable.tuning_is_enabled())
@@ -198,10 +197,12 @@ def tunable_gemms(enable):
         torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "aesmc_tunableop_%d.csv" % os.getpid()))
     except Exception as error:      # an optional PyTorch knob
         print("TunableOp unavailable ({})".format(error), file=sys.stderr)
-        yield
+        report["state"] = "unavailable ({}): PyTorch's default GEMM picks".format(type(error).__name__)
+        yield report
         return
+    report["state"] = "on (this leg only: the MLP proposal's GEMMs are the user's PyTorch code)"
     try:
-        yield
+        yield report
     finally:
         torch.cuda.tunable.tuning_enable(was[1])
         torch.cuda.tunable.enable(was[0])
@@ -225,17 +226,18 @@ def build_model(kind, dim, device, state, proposal="stock", callables="matmul", 
     return model
 
 
-def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_kwargs=None, budget_s=20.0):
-    """The CPU port of the reference (oracle/reference_port.py) on a BOUNDED sample of the same
-    workload: same model, K and d; batch rows (and, if still too slow, timesteps) are cut until a
-    calibrated estimate fits `budget_s` seconds.  Threads: min(cores, 16) — PyTorch's default of
-    one thread per core is far slower on big hosts for these small ops."""
+def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_kwargs=None, budget_s=50.0):
+    """The CPU port of the reference (oracle/reference_port.py) on a BOUNDED sample of the same workload: same model,
+    K and d; batch rows (and, if still too slow, timesteps) are cut until one evaluation fits its share of `budget_s`.
+    SURVEY.md 8(d): the thread count is swept ({8, 16, 32, 64, all} of the host's cores on a calibration-sized piece —
+    PyTorch's default of one thread per core is far slower on big hosts for these small ops), then 1 warm-up and the
+    MEDIAN of 3 evaluations at the best count; the spread and the sweep are printed with it."""
     import numpy as np
     import torch
     from oracle import reference_port
+    started = time.perf_counter()
     cores = os.cpu_count() or 1
-    threads = min(cores, 16)
-    torch.set_num_threads(threads)
+    candidates = sorted({t for t in (8, 16, 32, 64, cores) if t <= cores}) or [cores]
     model = build_model(kind, dim, torch.device("cpu"), reference_port, proposal, **(model_kwargs or {}))
     parts = (model.initial, model.transition, model.emission, model.proposal)
 
@@ -250,24 +252,46 @@ def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_
     def cost(b, t):  # per-step work + O(T^2) history re-gather
         return b * K * dim * (t + 0.35 * t * t)
 
-    cal_b, cal_t = max(1, min(B, 32)), min(T, 6)
-    run(cal_b, cal_t)                       # warm-up (thread pool, allocator)
-    cal_s, _ = run(cal_b, cal_t)
-    rate = cost(cal_b, cal_t) / max(cal_s, 1e-6)
+    # calibration piece: at most ~8M latent values per timestep (c4: 32 rows; configs[4]'s d=128 K=16384: 4 rows)
+    cal_b, cal_t = max(1, min(B, 32, (1 << 23) // max(1, K * dim))), min(T, 6)
+    sweep, cal_seconds = {}, {}
+    for threads in candidates:
+        torch.set_num_threads(threads)
+        run(cal_b, cal_t)                   # warm-up (thread pool, allocator)
+        cal_seconds[threads], _ = run(cal_b, cal_t)
+        sweep[threads] = cal_b * K * cal_t / max(cal_seconds[threads], 1e-6)
+        if time.perf_counter() - started > 0.3 * budget_s:      # a slow host: what has been tried is what is compared
+            break
+    threads = max(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    rate = cost(cal_b, cal_t) / max(cal_seconds[threads], 1e-6)
+    per_run = max(1.0, (budget_s - (time.perf_counter() - started)) / 6.0)      # 2 warm-ups + 3 timed, some slack
     b, t = B, T
-    while cost(b, t) / rate > budget_s and b > 8:
+    while cost(b, t) / rate > per_run and b > 8:
         b //= 2
-    while cost(b, t) / rate > budget_s and t > 10:
+    while cost(b, t) / rate > per_run and t > 10:
         t -= 5
-    dt, loss = run(b, t)
-    while 2.5 * dt <= budget_s and 2 * b <= B:      # the estimate was pessimistic: a sample of about budget_s / 2 ... budget_s
-        b *= 2
-        dt, loss = run(b, t)
+    run(b, t)                               # warm-up at the sample's own size (the first pass grows the allocator)
+    dt, _ = run(b, t)
+    # the estimate is pessimistic (the history re-gather is cheaper per value than the per-step work): grow the sample
+    # — first back to the workload's T, then in rows — to what the measured time says fits an evaluation's share
+    grown = False
+    if t < T and dt * cost(b, T) / cost(b, t) * 1.3 <= per_run:
+        dt, t, grown = dt * cost(b, T) / cost(b, t), T, True
+    while 2.6 * dt <= per_run and 2 * b <= B:
+        dt, b, grown = 2 * dt, 2 * b, True
+    if grown:
+        run(b, t)
+    timed = sorted(run(b, t) for _ in range(3))
+    dt, loss = timed[1]
     return {"value": b * K * t / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
-            "sample": "1 forward ELBO, B={} K={} T={} d={} ({} proposal) in {:.1f} s on {} of {} host cores; "
-                      "oracle/reference_port.py (PyTorch-CPU + NumPy, keeps the reference's O(T^2) "
+            "sample": "median of 3 forward ELBOs (after 1 warm-up), B={} K={} T={} d={} ({} proposal), {:.1f} s each on {} "
+                      "of {} host cores; oracle/reference_port.py (PyTorch-CPU + NumPy, keeps the reference's O(T^2) "
                       "history re-gather and per-row np.digitize loop)".format(b, K, t, dim, proposal, dt, threads, cores),
-            "loss": loss}
+            "spread": [b * K * t / timed[2][0], b * K * t / timed[0][0]],
+            "thread_sweep": {"particle_steps_per_sec_by_threads": {str(k): round(v, 1) for k, v in sweep.items()},
+                             "piece": "B={} T={}".format(cal_b, cal_t)},
+            "host_cores": cores, "seconds": round(time.perf_counter() - started, 1), "loss": loss}
 
 
 @contextlib.contextmanager
@@ -474,7 +498,11 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         # the roofline kernel: the resample gather (K3, or the fused step that contains it); a workload
         # that never resamples (c3, IWAE) is what BASELINE.json uses to isolate the fused log-weight
         # + log-sum-exp kernel (K1)
-        if "affine_normal_propagate_drawn" in kernels:
+        wide = kernels.get("affine_normal_propagate_wide")
+        if wide is not None and wide["avg_us"] * wide["launches"] >= 0.5 * sum(
+                v["avg_us"] * v["launches"] for v in kernels.values()):
+            key, label = "affine_normal_propagate_wide", None      # K17 + K18: priced against the matrix cores below
+        elif "affine_normal_propagate_drawn" in kernels:
             key, label = "affine_normal_propagate_drawn", \
                 "affine_propagate_fused_kernel (K16: the resample gather, the proposal's noise and draw, the log-weight)"
         elif "affine_normal_propagate_resampled" in kernels:
@@ -486,7 +514,10 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
             key, label = "resample_gather", "resample_gather_kernel (K3)"
         else:
             key, label = "logweight_lse", "logweight_lse_kernel (K1)"
-        out["roofline"] = roofline_of(kernels.get(key), label, name, proposal, key)
+        if key == "affine_normal_propagate_wide":
+            out["roofline"] = wide_roofline_of(kernels[key], local_B, K, dim)
+        else:
+            out["roofline"] = roofline_of(kernels.get(key), label, name, proposal, key)
         if out["roofline"] is not None and use_smc_path(algorithm):
             # the WHOLE hot path against SURVEY.md 8(d)'s algorithmic figure (36 + 8 d B per particle-step: K1 16 +
             # K2 12 + K3 8 d + 8) over the timed ELBOs — what the fused launches are for (round 2: 0.24 of the peak)
@@ -515,6 +546,21 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
 
 def use_smc_path(algorithm):
     return algorithm == "aesmc"
+
+
+def wide_roofline_of(stats, B, K, d):
+    """The contract's `roofline` for a step on rows of 128 values (configs[4]): K17 + K18 — one C-ABI call, two launches —
+    are three d x d maps per particle on the fp32 matrix cores, so the bound is "mfma": 3 * 2 B K d^2 FLOPs over the
+    call's time against the dense fp32 matrix peak; the HBM figure of the same call rides beside it."""
+    flops = 3 * 2.0 * B * K * d * d
+    us = stats["avg_us"]
+    return {"kernel": "affine_wide_draw_kernel + affine_wide_emission_kernel (K17 + K18: gather, both maps of x_{t-1}, "
+                      "draw; emission map and log-weight — fp32 matrix cores)",
+            "bound": "mfma", "achieved": round(flops / us / 1e6, 1), "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(min(flops / us / 1e6 / MFMA_FP32_PEAK_TFLOPS, 1.0), 4), "pricing": "algorithmic",
+            "avg_launch_us": round(us, 2), "flops_per_launch": flops, "launches": stats["launches"],
+            "algorithmic_bytes_per_launch": stats["bytes_per_launch"], "hbm_GBps": round(stats["GBps"], 1),
+            "frac_hbm": round(stats["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None}
 
 
 def roofline_of(stats, label, workload, proposal, key):
@@ -858,11 +904,20 @@ def main(argv=None):
         "loss": head["loss"], "mode": head["mode"], "graph_error": head["graph_error"],
         "tunableop": args.tunableop, "peak_memory_GB": head["peak_memory_GB"],
         "eager_particle_steps_per_sec": head.get("eager_particle_steps_per_sec"),
+        # the same model written as the reference writes it — Normal(x @ W.t() + c, s), no library class — replayed and in
+        # the plain eager loop (filled in below from the `matmul_callables` leg when the extras run)
+        "reference_style_particle_steps_per_sec": None,
+        "reference_style_eager_particle_steps_per_sec": None,
         "fwd_bwd_particle_steps_per_sec": head.get("fwd_bwd_particle_steps_per_sec"),
         "fwd_bwd_error": head.get("fwd_bwd_error"),
         "roofline": head.get("roofline"),
         "kernels": head.get("kernels"),
     }
+
+    if head["callables"] == "matmul":
+        out["reference_style_particle_steps_per_sec"] = head["value"]
+        out["reference_style_eager_particle_steps_per_sec"] = head.get("eager_particle_steps_per_sec") \
+            if head["mode"] == "hipgraph" else head["value"]
 
     extras = {}
     if world > 1 and (args.extras or "on") == "on":
@@ -891,6 +946,10 @@ def main(argv=None):
                 ctx, args.workload, args.proposal, 3, 1,
                 want_backward=not args.no_backward, want_kernels=False, mode=args.mode, grad=args.grad,
                 callables="matmul"))
+            leg = extras["matmul_callables"]
+            out["reference_style_particle_steps_per_sec"] = leg["value"]
+            out["reference_style_eager_particle_steps_per_sec"] = leg.get("eager_particle_steps_per_sec") \
+                if leg["mode"] == "hipgraph" else leg["value"]
             lap("matmul callables")
         if args.workload != "c2":
             extras["c2_hipgraph"] = brief(run_workload(ctx, "c2", args.proposal, 20, 5,
@@ -904,10 +963,10 @@ def main(argv=None):
             # workgroups) take 898 + 822 us of the 2.1 ms per timestep (profiles/r04_rocprof_c4nl_fwd_bwd.csv) — so
             # this leg runs with PyTorch's TunableOp picking those GEMMs (a stock PyTorch switch; ~50 s of tuning,
             # here only), and says so.
-            with tunable_gemms(args.tunableop != "on"):
+            with tunable_gemms(args.tunableop != "on") as tuned:
                 extras["c4nl"] = brief(run_workload(ctx, "c4nl", "stock", 3, 2, want_backward=not args.no_backward,
                                                     want_kernels=False, callables="affine"))
-            extras["c4nl"]["tunableop"] = "on (this leg only: the MLP proposal's GEMMs are the user's PyTorch code)"
+            extras["c4nl"]["tunableop"] = tuned["state"]
             # What one GPU's shard of the north-star batch costs on THIS device (global B = 1024 split over N GPUs:
             # B / N rows here): the strong-scaling curve, the one all-reduce of sum log Z per ELBO aside.
             # projected_efficiency = t(B = 1024) / (N * t(B / N)).

@@ -663,13 +663,13 @@ def test_affine_route_reproduces_the_reference_s_own_fixtures(hip_device, name):
         for got, want in zip(result["latents"], case.series("out_latents")):
             np.testing.assert_allclose(got.detach().cpu().numpy(), want, **tol)
     lml, want = result["log_marginal_likelihood"].detach().cpu().numpy(), case["out_lml"]
-    bound = ((1e-10 if f64 else 1e-4) if exact else 0.05) * (1 + np.abs(want))
+    bound = ((1e-10 if f64 else 1e-4) if exact else 1e-2) * (1 + np.abs(want))
     assert (np.abs(lml - want) <= bound).all()
     with replay.replay(case.tape()):
         loss = losses.get_loss(observations, case.meta["num_particles"], "aesmc", parts["initial"],
                                parts["transition"], parts["emission"], parts["proposal"])
     loss.backward()
-    assert abs(loss.item() - float(case["out_loss"])) <= ((1e-10 if f64 else 1e-4) if exact else 0.05) * \
+    assert abs(loss.item() - float(case["out_loss"])) <= ((1e-10 if f64 else 1e-4) if exact else 1e-2) * \
         (1 + abs(float(case["out_loss"])))
     if exact:
         for pname, parameter in named.items():

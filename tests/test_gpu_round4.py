@@ -324,6 +324,17 @@ def test_the_wide_step_declines_what_it_does_not_cover_and_survives_bad_ancestor
     terms = ((W, None), (W, None), (W, None))
     assert kernels.affine_propagate_wide(x[:, :40], x[:, :40], y, *terms, (one, one, one), out[:, :40].contiguous()) is None
     assert kernels.affine_propagate_wide(x, x, y, (W.t(), None), (W, None), (W, None), (one, one, one), out) is None
+    # an observation K18 would misread: float64 bytes (torch.from_numpy data against a float32 model), another batch
+    # extent, another device; offsets and scales of the wrong shape / dtype / device — declined, nothing launched
+    before = out.zero_().clone()
+    assert kernels.affine_propagate_wide(x, x, y.double(), *terms, (one, one, one), out) is None
+    assert kernels.affine_propagate_wide(x, x, y[:1], *terms, (one, one, one), out) is None
+    assert kernels.affine_propagate_wide(x, x, y.cpu(), *terms, (one, one, one), out) is None
+    assert kernels.affine_propagate_wide(x, x, y, (W, y[0, :64]), (W, None), (W, None), (one, one, one), out) is None
+    assert kernels.affine_propagate_wide(x, x, y, (W, y.double()), (W, None), (W, None), (one, one, one), out) is None
+    assert kernels.affine_propagate_wide(x, x, y, *terms, (one, one.double(), one), out) is None
+    assert kernels.affine_propagate_wide(x, x, y, *terms, (one, one, one.cpu()), out) is None
+    assert torch.equal(out, before)
     anc = torch.zeros(2, 64, dtype=torch.int64, device=hip_device)
     anc[0, 3], anc[1, 5] = 64, -1
     kernels.read_flags(hip_device)

@@ -854,6 +854,18 @@ def test_a_reference_style_model_reaches_the_fused_route_unedited(oracle_backend
     (z.materialise() * 2.0).sum().backward()
     want = torch.zeros_like(source).scatter_add_(1, index.unsqueeze(-1).expand_as(source), torch.full_like(source, 2.0))
     torch.testing.assert_close(leaf.grad, want, rtol=0, atol=0)
+    # ... but a lazy MADE and read under no_grad (a pure evaluation) carries no history, as the reference's eager tensors
+    # do not: nothing is retained and nothing cascades into the later steps
+    parameter = torch.nn.Parameter(weight.clone())
+    with torch.no_grad():
+        made = _lazy.LazyResampled(leaf, index)
+        located = made @ parameter.t()
+        assert type(located) is _lazy.LazyAffine and not made.requires_grad and not located.requires_grad
+        values = located.materialise()
+        gathered = made.materialise()
+    assert not values.requires_grad and values.grad_fn is None
+    assert not gathered.requires_grad and gathered.grad_fn is None
+    torch.testing.assert_close(values, moved @ weight.t(), rtol=1e-13, atol=1e-13)
 
 
 def test_linked_step_nodes_give_the_gradients_of_unlinked_ones(oracle_backend):
