@@ -27,35 +27,9 @@
 //     five 8-byte pieces per lane at a 40-byte stride.
 // No lane-dependent branch surrounds a load: idle rows duplicate the window's last particle (same loads, same
 // arithmetic, nothing stored), an empty window computes on particle 0 and stores nothing.
-#include "linear_gaussian.hpp"
-#include "philox_normal.hpp"
+#include "linear_gaussian_fused.hpp"
 
 namespace aesmc {
-
-typedef float fz4 __attribute__((ext_vector_type(4)));
-typedef fz4 fz4_a4 __attribute__((aligned(4)));      // a 16-byte global access at 4-byte alignment (hardware: unaligned mode)
-
-constexpr uint32_t kRunP = 128;                       // rows per window: two chunks of 64
-constexpr uint32_t kTabF = 4 * 2 * 4 * 16;            // floats per table slot: [window][row 0/1][p, q, g, y][16]
-
-struct FusedPlan {
-  uint32_t numel;       // B K dx < 2^29
-  uint32_t G;           // thread ids of ATen's launch
-  uint32_t L, S;        // thread ids per block, Philox calls per lane and item
-  uint32_t blocks, items;
-  uint32_t blocks_mul, dx_mul, K_mul;      // floor(2^32 / divisor)
-  uint32_t tile_f;      // floats per noise tile
-  uint64_t *stamps;     // probe builds: [workgroup][2 roles][16] cycle sums per phase (AESMC_K16_STAMPS = device address), or null
-  uint32_t probe;       // 0 in a product build; with -DAESMC_K16_PROBES and AESMC_K16_PROBE in the environment, bits that SKIP
-                        // parts of the launch (timing only: the output is wrong): 1 the draws, 2 the particle role's arithmetic,
-                        // 4 x_t's stores, 8 the row loads, 16 the ancestor loads, 32 the emission part
-};
-
-// v / d for d >= 2 with mul = floor(2^32 / d): the estimate is the quotient or one less
-__device__ __forceinline__ uint32_t fused_div(uint32_t v, uint32_t d, uint32_t mul) {
-  const uint32_t q = __umulhi(v, mul);
-  return (v - q * d) >= d ? q + 1 : q;
-}
 
 #ifdef AESMC_K16_PROBES
 // cycle stamps of a diagnostic build (never in the product): where an item's time goes, by phase
@@ -79,32 +53,6 @@ __device__ __forceinline__ uint64_t fused_realtime() {
 #define FUSED_STAMP_INIT do { } while (0)
 #define FUSED_STAMP_FLUSH(role) do { } while (0)
 #endif
-
-// acc += w * x with the weight in a SCALAR register (one per wavefront: the launch's maps are the same for every
-// particle).  Written as an instruction because the compiler, left to itself, pairs two outputs per v_pk_fma_f32 and
-// spends two s_mov per multiply-add on putting their weights side by side.
-typedef const float __attribute__((address_space(4))) fused_cfloat;
-__device__ __forceinline__ float fused_fmac_s(float acc, float w, float x) {
-  asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(x));
-  return acc;
-}
-// five inputs of two chains in one statement (the compiler pads every asm statement's end with an s_nop: one per
-// ten multiply-adds instead of one each)
-__device__ __forceinline__ void fused_fmac_s5x2(float &a0, float &a1, const float *w0, const float *w1, const float *x) {
-  asm("v_fmac_f32 %0, %2, %12\n\tv_fmac_f32 %1, %7, %12\n\t"
-      "v_fmac_f32 %0, %3, %13\n\tv_fmac_f32 %1, %8, %13\n\t"
-      "v_fmac_f32 %0, %4, %14\n\tv_fmac_f32 %1, %9, %14\n\t"
-      "v_fmac_f32 %0, %5, %15\n\tv_fmac_f32 %1, %10, %15\n\t"
-      "v_fmac_f32 %0, %6, %16\n\tv_fmac_f32 %1, %11, %16"
-      : "+v"(a0), "+v"(a1)
-      : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w0[3]), "s"(w0[4]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "s"(w1[3]),
-        "s"(w1[4]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]));
-}
-
-struct FusedWin {
-  uint32_t nf, count, head, b0, k0;      // first particle, particles, elements in front of the first, its batch row, its k
-  uint32_t c, t0, tl;                    // the item's trip, first thread id and thread-id count
-};
 
 // Workgroup: four particle wavefronts and four noise wavefronts, two workgroups per CU (four wavefronts per SIMD).
 // (Measured and not kept: SIX noise wavefronts for the scalar-weight form, which fits 96 registers — ten wavefronts
@@ -770,50 +718,57 @@ static int fused_launch_g(dim3 grid, size_t lds, hipStream_t stream, const float
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
+int launch_affine_propagate_item(const void *xsrc, const int64_t *anc_idx, const void *y, int64_t y_sb,
+                                 const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
+                                 const void *sp, const void *sg, const void *sq, void *out_x, void *out_lw, int32_t *flags,
+                                 int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads,
+                                 const uint64_t *rng_state, hipStream_t stream);
+
+int g_fused_form = [] {
+  const char *v = getenv("AESMC_K16_FORM");      // ("roles": the first form whatever the shape — linear_gaussian_noise.hip)
+  return v == nullptr ? 0 : (v[0] == 'p' ? 1 : (v[0] == 'i' ? 2 : 0));
+}();
+int g_fused_last_form = 0;
+// One item per workgroup wherever that form applies: measured ahead of the persistent form at every size and extent tried
+// (profiles/r05_k16_forms.txt: B = 128 / 256 / 512 / 1024 at K = 4096, d = 10: 19.3 / 31.3 / 58.5 / 110.7 against 25.2 / 38.8 /
+// 63.7 / 113.8 us; d = 4 / 8 / 12 at B = 1024: 48.8 / 86.9 / 132.5 against 79.6 / 133.2 / 165.8 us).  The persistent form stays
+// for weights whose rows are not contiguous (its matrix-core branch) and as the comparison the tests pin the bits to.
+constexpr uint32_t kItemFormMaxItems = 0xffffffffu;
+
 // AESMC_ERR_UNSUPPORTED: the caller takes the first form (linear_gaussian_noise.hip)
 int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, const void *y, int64_t y_sb,
                                   const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                   const void *sp, const void *sg, const void *sq, void *out_x, void *out_lw,
                                   int32_t *flags, int64_t B, int64_t K, uint64_t seed, uint64_t offset,
                                   int64_t threads, const uint64_t *rng_state, hipStream_t stream) {
-  const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
-  if (dx < 2 || dx > 16 || dy < 1 || dy > 16 || K < (int64_t)kRunP || K >= (1ll << 24) || B >= (1ll << 31))
-    return AESMC_ERR_UNSUPPORTED;
-  const uint64_t numel = (uint64_t)N * (uint64_t)dx;
-  // 32-bit element arithmetic throughout (window bounds run up to numel + 4 G + L; byte offsets up to 8 N)
-  if (numel >= (1ull << 29) || (uint64_t)threads >= (1ull << 24)) return AESMC_ERR_UNSUPPORTED;
+  if (dx < 2 || dx > 16 || dy < 1 || dy > 16) return AESMC_ERR_UNSUPPORTED;
+  FusedPlan plan;
+  const int planned = fused_make_plan(plan, B, K, dx, threads);
+  if (planned != AESMC_OK) return planned;
+  // One item per workgroup (linear_gaussian_item.hip); the same bits either way.
+  if (g_fused_form == 2 || (g_fused_form == 0 && plan.items < kItemFormMaxItems)) {
+    const int status = launch_affine_propagate_item(xsrc, anc_idx, y, y_sb, mp, mg, mq, sp, sg, sq, out_x, out_lw, flags, B,
+                                                    K, seed, offset, threads, rng_state, stream);
+    if (status != AESMC_ERR_UNSUPPORTED) {
+      g_fused_last_form = 2;
+      return status;
+    }
+  }
+  g_fused_last_form = 1;      // (or, where this form declines below, the first form: the caller's)
   const int ks = (int)((std::max(dx, dy) + 3) / 4);
   // extents above 12: the first form is faster (rows of 16 values put a wavefront's noise reads on two LDS banks
   // here: 371 against 337 us at B=1024 K=4096 d=16, profiles/r04_k16bench_sweep.txt)
   if (ks > 3) return AESMC_ERR_UNSUPPORTED;
-  FusedPlan plan;
-  plan.numel = (uint32_t)numel;
-  plan.G = (uint32_t)threads;
-  plan.S = (uint32_t)(((uint64_t)(kRunP + 1) * dx - 1) / 256);      // 256 S <= (128 + 1) dx - 1: at most 128 particles per window
-  if (plan.S < 1) return AESMC_ERR_UNSUPPORTED;
-  plan.L = plan.S * 256u - ((uint32_t)dx - 1);
-  plan.blocks = (uint32_t)(((uint64_t)threads + plan.L - 1) / plan.L);
-  const uint64_t trips = (numel + 4ull * (uint64_t)threads - 1) / (4ull * (uint64_t)threads);
-  const uint64_t items = trips * plan.blocks;
-  if (items > 0x3fffffffull || plan.blocks < 2) return AESMC_ERR_UNSUPPORTED;
-  plan.items = (uint32_t)items;
-  plan.blocks_mul = (uint32_t)((1ull << 32) / plan.blocks);
-  plan.dx_mul = (uint32_t)((1ull << 32) / (uint64_t)dx);
-  plan.K_mul = (uint32_t)((1ull << 32) / (uint64_t)K);
-  plan.tile_f = (uint32_t)((4 * kRunP * dx + 4 + 3) & ~3ull);      // + the spare word unplaced normals go to
 #ifdef AESMC_K16_PROBES      /* timing experiments only (AESMC_HIPCC_FLAGS=-DAESMC_K16_PROBES): a probed launch's OUTPUT IS WRONG */
   { const char *v = getenv("AESMC_K16_PROBE"); plan.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
   { const char *v = getenv("AESMC_K16_STAMPS"); plan.stamps = v != nullptr ? reinterpret_cast<uint64_t *>(strtoull(v, nullptr, 10)) : nullptr; }
-#else
-  plan.probe = 0;
-  plan.stamps = nullptr;
 #endif
   const uint32_t rs = ks == 1 ? 4 : (ks <= 3 ? 12 : 20);
   const size_t lds = sizeof(float) * (2 * (size_t)kTabF + 2 * (size_t)plan.tile_f + 4 * 2 * 64 * (size_t)rs + 4 * 16);
   if (lds > kLgLdsLimit) return AESMC_ERR_UNSUPPORTED;
   const PhiloxStream ps = philox_stream(seed, offset, threads, rng_state);
-  const dim3 grid(lg_persistent_grid((int64_t)items, lds, 2));
+  const dim3 grid(lg_persistent_grid((int64_t)plan.items, lds, 2));
   const LgMap p = lg_map(mp), gm = lg_map(mg), q = lg_map(mq);
 #define FUSED_ARGS                                                                                                   \
   grid, lds, stream, static_cast<const float *>(xsrc), static_cast<const float *>(y), y_sb, p, gm, q,                  \
@@ -843,3 +798,14 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
 }
 
 }  // namespace aesmc
+
+// Test hooks (not part of the C ABI of include/aesmc_hip.h): 0 = the form is chosen by shape, 1 = the persistent form,
+// 2 = one item per workgroup wherever that form applies; and which of the two the last launch through
+// launch_affine_propagate_fused asked for (1 also stands for "this file declined": the first form ran).
+extern "C" int aesmc_test_last_k16_form(void) { return aesmc::g_fused_last_form; }
+
+extern "C" int aesmc_test_set_k16_form(int form) {
+  if (form < 0 || form > 2) return AESMC_ERR_INVALID_ARGUMENT;
+  aesmc::g_fused_form = form;
+  return AESMC_OK;
+}

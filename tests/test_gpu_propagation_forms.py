@@ -1,0 +1,149 @@
+"""The forms of the fused propagation launch (aesmc_affine_normal_propagate_drawn: resampling gather, the proposal's
+noise and draw, the step's log-weight — aesmc/inference.py:102-126, state.py:98, :179 for a linear-Gaussian model)
+against each other and against `oracle/`:
+
+  * the item form (linear_gaussian_item.hip: one work item per workgroup, what one GPU's shard of a batch takes) equals
+    the persistent form (linear_gaussian_fused.hip) BIT FOR BIT — x_t and the log-weights — at the strong-scaling shard
+    shapes of the north-star batch, at every even latent extent 2 .. 12 with equal and unequal observation extents,
+    ragged K, windows that straddle batch rows, with and without the gather, healthy and collapsed ancestries;
+  * x_t of the item form equals oracle/smc_core.c bit for bit, its log-weights to the tolerance the stand-alone
+    log-weight kernel is held to;
+  * bad ancestor indices are flagged, never followed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from tests.test_gpu_linear_gaussian import operands
+from tests.test_gpu_round3 import _ancestors
+
+pytestmark = pytest.mark.gpu
+
+PERSISTENT, ITEM = 1, 2
+
+
+@pytest.fixture(scope="module")
+def kernels(hip_device):
+    from aesmc_amd import _kernels
+    provider = _kernels.get()
+    assert provider.name == "hip"
+    return provider
+
+
+@pytest.fixture()
+def forms(kernels, monkeypatch):
+    """Pins the launch's form for the duration of a test: forms(PERSISTENT) / forms(ITEM); back to the policy afterwards."""
+    lib = kernels._lib
+    monkeypatch.setattr(type(kernels), "DRAWN_MIN_PARTICLES", 0)
+    yield lambda form: lib.aesmc_test_set_k16_form(form)
+    lib.aesmc_test_set_k16_form(0)
+
+
+# (B, K, dx, dy): one GPU's shards of the north-star batch (B = 128, 256), configs[1]'s shape, every even extent with
+# equal (compile-time) and unequal (run-time) observation extents, K ragged / prime / barely a window, one batch row
+FORM_SHAPES = [(128, 4096, 10, 10), (256, 1024, 10, 10), (300, 4099, 10, 7), (37, 29000, 6, 9), (1, 128, 2, 2),
+               (2, 4096, 12, 12), (64, 1024, 8, 4), (9, 513, 4, 1), (3, 200000, 10, 10), (7, 2222, 12, 5), (5, 131, 2, 12),
+               (33, 640, 6, 6), (12, 4096, 8, 8), (4, 8192, 4, 4), (2, 130, 10, 10)]
+
+
+def _run(kernels, o, x_prev, y, off_p, off_q, idx, seed):
+    from aesmc_amd import _philox
+    dev = x_prev.device
+    B, K, dx = x_prev.shape
+    torch.manual_seed(seed)
+    reservation = _philox.reserve(B * K * dx, dev)
+    out_x = torch.full_like(x_prev, float("nan"))
+    lw = kernels.affine_propagate_drawn(x_prev, reservation, y, (o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], off_q),
+                                        (o["s_p"], o["s_g"], o["s_q"]), out_x=out_x, ancestors=idx)
+    assert lw is not None
+    return out_x, lw, kernels._lib.aesmc_test_last_k16_form()
+
+
+@pytest.mark.parametrize("gather", [True, False])
+@pytest.mark.parametrize("shape", FORM_SHAPES)
+def test_the_item_form_equals_the_persistent_form_bit_for_bit(kernels, hip_device, forms, shape, gather):
+    B, K, dx, dy = shape
+    _, o = operands(4, 32, dx, dy, np.float32, hip_device, seed=B + K)
+    gen = torch.Generator(device=hip_device).manual_seed(K + dx)
+    x_prev = torch.randn(B, K, dx, device=hip_device, generator=gen)
+    y = torch.randn(B, dy, device=hip_device, generator=gen)
+    off_q = torch.randn(B, dx, device=hip_device, generator=gen)
+    off_p = torch.randn(dx, device=hip_device, generator=gen)
+    for spread in ((1.0, 5.0) if gather else (None,)):
+        idx = _ancestors(B, K, hip_device, seed=B + K, spread=spread) if gather else None
+        kernels.read_flags(hip_device)
+        forms(PERSISTENT)
+        want_x, want_lw, ran = _run(kernels, o, x_prev, y, off_p, off_q, idx, seed=5 + K)
+        assert ran == PERSISTENT
+        forms(ITEM)
+        got_x, got_lw, ran = _run(kernels, o, x_prev, y, off_p, off_q, idx, seed=5 + K)
+        assert ran == ITEM, "the item form declined a shape it is built for"
+        assert kernels.read_flags(hip_device) == 0
+        assert torch.equal(got_x, want_x), float((got_x - want_x).abs().max())
+        assert got_lw.cpu().numpy().tobytes() == want_lw.cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("shape", [(128, 4096, 10, 10), (37, 29000, 6, 9), (1, 128, 2, 2), (7, 2222, 12, 5), (9, 513, 4, 1),
+                                   (64, 1024, 8, 4)])
+def test_the_item_form_equals_the_c_oracle(kernels, hip_device, forms, shape):
+    """x_t bit for bit (gather of the ancestor rows, one fma chain per element started from the offset, eps * s rounded
+    before the sum, eps = what `torch.empty(shape).normal_()` holds for the same generator state), the log-weight to
+    5e-7 relative (the device's log(sigma) against glibc's, times d)."""
+    from aesmc_amd import _philox
+    B, K, dx, dy = shape
+    n, o = operands(4, 32, dx, dy, np.float32, hip_device, seed=B + K)
+    gen = torch.Generator(device=hip_device).manual_seed(K + dx)
+    x_prev = torch.randn(B, K, dx, device=hip_device, generator=gen)
+    y = torch.randn(B, dy, device=hip_device, generator=gen)
+    off_q = torch.randn(B, dx, device=hip_device, generator=gen)
+    off_p = torch.randn(dx, device=hip_device, generator=gen)
+    idx = _ancestors(B, K, hip_device, seed=B + K, spread=1.0)
+    torch.manual_seed(77 + K)
+    torch.randn(5, device=hip_device)
+    state = torch.cuda.get_rng_state(hip_device)
+    eps = torch.empty(B, K, dx, device=hip_device).normal_()      # what the reference's rsample would draw (state.py:98)
+    torch.cuda.set_rng_state(state, hip_device)
+    reservation = _philox.reserve(B * K * dx, hip_device)
+    forms(ITEM)
+    got_x = torch.full_like(x_prev, float("nan"))
+    got_lw = kernels.affine_propagate_drawn(x_prev, reservation, y, (o["A"], off_p), (o["C"], o["off_g"]), (o["Q"], off_q),
+                                            (o["s_p"], o["s_g"], o["s_q"]), out_x=got_x, ancestors=idx)
+    assert got_lw is not None and kernels._lib.aesmc_test_last_k16_form() == ITEM
+    assert kernels.read_flags(hip_device) == 0
+    moved, flags = c_oracle.gather(x_prev.cpu().numpy(), idx.cpu().numpy())
+    assert flags == 0
+    s_p, s_g, s_q = (float(o[k].cpu()) for k in ("s_p", "s_g", "s_q"))
+    want_x = c_oracle.affine_rsample(moved, n["Q"], off_q.cpu().numpy(), eps.cpu().numpy(), s_q)
+    np.testing.assert_array_equal(got_x.cpu().numpy(), want_x)
+    want_lw = c_oracle.affine_logweight(moved, want_x, y.cpu().numpy(), (n["A"], off_p.cpu().numpy()),
+                                        (n["C"], n["off_g"]), (n["Q"], off_q.cpu().numpy()), s_p, s_g, s_q)
+    np.testing.assert_allclose(got_lw.cpu().numpy(), want_lw, rtol=5e-7,
+                               atol=5e-7 * max(1.0, float(np.abs(want_lw).max())))
+
+
+def test_the_item_form_flags_bad_ancestors_and_declines_what_it_does_not_cover(kernels, hip_device, forms):
+    B, K, dx, dy = 3, 1000, 10, 10
+    _, o = operands(4, 32, dx, dy, np.float32, hip_device, seed=1)
+    gen = torch.Generator(device=hip_device).manual_seed(3)
+    x_prev = torch.randn(B, K, dx, device=hip_device, generator=gen)
+    y = torch.randn(B, dy, device=hip_device, generator=gen)
+    off_q = torch.randn(B, dx, device=hip_device, generator=gen)
+    idx = _ancestors(B, K, hip_device, seed=2, spread=1.0).clone()
+    idx[0, 5], idx[2, 999], idx[1, 0] = K, -1, K + 7      # K is what K2 writes for a degenerate row; the others are nobody's
+    forms(ITEM)
+    kernels.read_flags(hip_device)
+    out_x, lw, ran = _run(kernels, o, x_prev, y, None, off_q, idx, seed=9)
+    assert ran == ITEM
+    assert torch.isfinite(out_x).all() and torch.isfinite(lw).all()
+    from aesmc_amd import _lib
+    assert kernels.read_flags(hip_device) & _lib.FLAG_INDEX_OUT_OF_RANGE
+    # odd extents, extents above 12 and strided weights are another form's: same call, same answer, other kernel
+    for dx2, dy2, transpose in ((5, 5, False), (14, 14, False), (10, 10, True)):
+        _, o2 = operands(4, 32, dx2, dy2, np.float32, hip_device, seed=4)
+        if transpose:
+            o2 = dict(o2, A=o2["A"].t().contiguous().t())
+        x2 = torch.randn(2, 300, dx2, device=hip_device, generator=gen)
+        y2 = torch.randn(2, dy2, device=hip_device, generator=gen)
+        _, lw2, ran = _run(kernels, o2, x2, y2, None, None, None, seed=11)
+        assert ran != ITEM and torch.isfinite(lw2).all()
