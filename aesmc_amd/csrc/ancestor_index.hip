@@ -581,6 +581,325 @@ __global__ __launch_bounds__(kMaxThreads, (PAYLOAD || C > 8) ? 1 : 8) void ances
     gather_row_from_lds<4, (C <= 4 ? 5 : 4)>(marker, srow, drow, K, payload.ppp, payload.stride_k, tid, nt, part, parts);
 }
 
+// ---- the lean form of the primary kernel: whole rows, no payload ------------------------------------------------------
+//
+// What a step whose propagation launch fetches the rows itself runs (aesmc_resample_step[_ranges] without a payload) when
+// a row is exactly blockDim.x * C particles (K a multiple of 64 C: every BASELINE shape).  The same algorithm as
+// ancestor_index_inv_kernel — float64 weights, blocked scan, CDF inversion, int32 max-scan — written for the instruction
+// count: that kernel issues ~290 vector instructions per particle (2 336 per lane at C = 8; 490 of them float64
+// arithmetic), which at four workgroups per CU makes the launch issue-bound (20 us of its 25 at B = 1024, K = 4096).  Here:
+//   * wavefront scans and reductions run on the DPP crossbar (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: two moves and an
+//     add per step for a float64) instead of ds_bpermute + compare + select per step;
+//   * every "j < K" predicate is gone (whole rows), the row maximum and the prefixes of the earlier wavefronts are
+//     wavefront-uniform scalars (v_readlane of a 16-lane DPP scan over the wavefronts' totals: no loops over LDS);
+//   * the rare comparison that sits within rounding of flipping is settled out of line (one uniform branch per wavefront
+//     instead of two data-dependent loops per particle);
+//   * markers are stored without exchanging neighbours: a lane knows where its own next particle starts; the one marker
+//     per wavefront that depends on the NEXT wavefront's first particle is an LDS atomic max (a slot's final value is the
+//     largest particle that starts there whichever order the stores land in) — one barrier fewer, four in all.
+// The scan associates differently from ancestor_index_inv_kernel's (a tree over rows of 16 lanes instead of
+// Hillis-Steele over 64), so CDF entries may differ in the last place of a float64: indices agree except where a
+// comparison sits within ~1e-16 of flipping (tests/test_gpu_kernels.py holds both to the same oracle and fixtures).
+template <int CTRL, int ROW = 0xf> __device__ __forceinline__ int dpp_i32(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW, 0xf, false);
+}
+template <int CTRL, int ROW = 0xf> __device__ __forceinline__ float dpp_f32(float old, float src) {
+  return __builtin_bit_cast(float, dpp_i32<CTRL, ROW>(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src)));
+}
+template <int CTRL, int ROW = 0xf> __device__ __forceinline__ double dpp_f64(double old, double src) {
+  const long long o = __builtin_bit_cast(long long, old), v = __builtin_bit_cast(long long, src);
+  const int lo = dpp_i32<CTRL, ROW>((int)o, (int)v), hi = dpp_i32<CTRL, ROW>((int)(o >> 32), (int)(v >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118, kDppBcast15 = 0x142,
+              kDppBcast31 = 0x143, kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;
+
+// inclusive sum over the lanes of a row of 16 (what the first four steps of a wavefront scan leave)
+__device__ __forceinline__ double row16_scan_add(double x) {
+  x += dpp_f64<kDppShr1>(0.0, x);
+  x += dpp_f64<kDppShr2>(0.0, x);
+  x += dpp_f64<kDppShr4>(0.0, x);
+  x += dpp_f64<kDppShr8>(0.0, x);
+  return x;
+}
+__device__ __forceinline__ double wave_scan_add(double x) {
+  x = row16_scan_add(x);
+  x += dpp_f64<kDppBcast15, 0xa>(0.0, x);
+  x += dpp_f64<kDppBcast31, 0xc>(0.0, x);
+  return x;
+}
+__device__ __forceinline__ int row16_scan_max(int x) {      // values >= 0
+  x = max(x, dpp_i32<kDppShr1>(0, x));
+  x = max(x, dpp_i32<kDppShr2>(0, x));
+  x = max(x, dpp_i32<kDppShr4>(0, x));
+  x = max(x, dpp_i32<kDppShr8>(0, x));
+  return x;
+}
+__device__ __forceinline__ int wave_scan_max(int x) {
+  x = row16_scan_max(x);
+  x = max(x, dpp_i32<kDppBcast15, 0xa>(0, x));
+  x = max(x, dpp_i32<kDppBcast31, 0xc>(0, x));
+  return x;
+}
+__device__ __forceinline__ float lanes_max(float x, bool whole_wave) {      // lane 15 (row of 16) / lane 63 holds the maximum
+  const float ninf = -__builtin_huge_valf();
+  x = fmaxf(x, dpp_f32<kDppShr1>(ninf, x));
+  x = fmaxf(x, dpp_f32<kDppShr2>(ninf, x));
+  x = fmaxf(x, dpp_f32<kDppShr4>(ninf, x));
+  x = fmaxf(x, dpp_f32<kDppShr8>(ninf, x));
+  if (whole_wave) {
+    x = fmaxf(x, dpp_f32<kDppBcast15, 0xa>(ninf, x));
+    x = fmaxf(x, dpp_f32<kDppBcast31, 0xc>(ninf, x));
+  }
+  return x;
+}
+__device__ __forceinline__ double lanes_max(double x, bool whole_wave) {
+  const double ninf = -__builtin_huge_val();
+  x = fmax(x, dpp_f64<kDppShr1>(ninf, x));
+  x = fmax(x, dpp_f64<kDppShr2>(ninf, x));
+  x = fmax(x, dpp_f64<kDppShr4>(ninf, x));
+  x = fmax(x, dpp_f64<kDppShr8>(ninf, x));
+  if (whole_wave) {
+    x = fmax(x, dpp_f64<kDppBcast15, 0xa>(ninf, x));
+    x = fmax(x, dpp_f64<kDppBcast31, 0xc>(ninf, x));
+  }
+  return x;
+}
+__device__ __forceinline__ float read_lane(float x, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+__device__ __forceinline__ double read_lane(double x, int lane) {
+  const long long v = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_readlane((int)v, lane), hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
+// exp_nonpositive's constants held in SCALAR registers for the whole kernel: a float64 literal cannot be an operand, and
+// left to itself the compiler rebuilds each one in a vector register pair in front of the multiply-add that uses it (two
+// v_mov per Horner step: 26 per particle).  v_fma_f64 takes one scalar pair as an operand.
+struct ExpScalars {
+  double log2e, ln2_hi, ln2_lo, c[13];
+  __device__ __forceinline__ void init() {
+    const double values[16] = {1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+                               1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08,
+                               2.755731922398589e-07, 2.7557319223985893e-06, 2.48015873015873e-05,
+                               1.984126984126984e-04, 1.3888888888888889e-03, 8.333333333333333e-03,
+                               4.1666666666666664e-02, 1.6666666666666666e-01, 0.5, 1.0};
+    log2e = values[0]; ln2_hi = values[1]; ln2_lo = values[2];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) c[i] = values[3 + i];
+    asm volatile("" : "+s"(log2e), "+s"(ln2_hi), "+s"(ln2_lo));
+#pragma unroll
+    for (int i = 0; i < 13; ++i) asm volatile("" : "+s"(c[i]));
+  }
+};
+// exp(x) for x <= 0, not NaN: exp_nonpositive's arithmetic, operation for operation, on x clamped at -745.2 instead of
+// answering 0.0 below it — the clamp's value is a denormal (<= 2^-1074) where that function says zero, which no sum that
+// holds the row maximum's exp(0) = 1 can tell apart: the same indices, children ranges and log-sum-exp, without the
+// compare, the two selects and the branch around the polynomial.
+__device__ __forceinline__ double exp_nonpositive_s(double x, const ExpScalars &k) {
+  x = fmax(x, -745.2);
+  const double n = __builtin_rint(x * k.log2e);
+  double r = __builtin_fma(-n, k.ln2_hi, x);
+  r = __builtin_fma(-n, k.ln2_lo, r);
+  double p = k.c[0];
+#pragma unroll
+  for (int i = 1; i < 13; ++i) p = __builtin_fma(p, r, k.c[i]);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)n);
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_rows_kernel(
+    const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx, int32_t *flags, int K,
+    T *__restrict__ out_lse, int32_t *__restrict__ out_child_end) {
+  static_assert(C % 4 == 0, "a lane's particles are moved in 16-byte pieces");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *scratch = smem;                                          // [0,16) wavefront maxima, [16,32) wavefront totals, [32], [33]
+  int *scratch_i = reinterpret_cast<int *>(smem + 40);             // [0,16) NaN seen, [16,32) wavefront marker maxima
+  int *marker = reinterpret_cast<int *>(smem + kScratchDoubles);   // [K] + a spare slot for markers nobody needs
+  const int tid = threadIdx.x;
+  const int nt = blockDim.x;                                       // nt * C == K
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = nt >> 6;
+  const int64_t row = blockIdx.x;
+  const T *lw = log_w + row * (int64_t)K;
+  int64_t *idx = out_idx + row * (int64_t)K;
+  const int j0 = tid * C;
+  const double ub = u[row];      // (needed after the scan; sent for now)
+
+  // ---- load once; the markers' zero fill rides in front of the first barrier ---------------------------------------
+  T v[C];
+  constexpr int NV = Vec16<T>::N;
+  {
+    using V = typename Vec16<T>::type;
+#pragma unroll
+    for (int q = 0; q < C / NV; ++q) {
+      const V packed = reinterpret_cast<const V *>(lw + j0)[q];
+#pragma unroll
+      for (int r = 0; r < NV; ++r) v[q * NV + r] = Vec16<T>::get(packed, r);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < C / 4; ++q) reinterpret_cast<int4 *>(marker + j0)[q] = make_int4(0, 0, 0, 0);
+  T m = v[0];
+  bool nan_here = v[0] != v[0];
+#pragma unroll
+  for (int i = 1; i < C; ++i) {
+    nan_here |= v[i] != v[i];
+    m = Num<T>::max(m, v[i]);
+  }
+  {
+    const T wave_m = read_lane(lanes_max(m, true), kWave - 1);
+    const int wave_nan = __any(nan_here) ? 1 : 0;
+    if (lane == 0) {
+      scratch[wave] = (double)wave_m;
+      scratch_i[wave] = wave_nan;
+    }
+  }
+  __syncthreads();
+  const int slot = lane < nwaves ? lane : 0;
+  const double dm = read_lane(lanes_max(scratch[slot], false), 15);      // (nwaves <= 16: one row of lanes)
+  const bool has_nan = __any(scratch_i[slot] != 0);
+  const bool degenerate = has_nan || !(dm > -__builtin_huge_val() && dm < __builtin_huge_val());
+  if (degenerate) {  // same conventions as the reference: see include/aesmc_hip.h, K2
+    if (tid == 0) {
+      raise_flag(flags, has_nan ? AESMC_FLAG_NAN_LOG_WEIGHT : AESMC_FLAG_DEGENERATE_ROW);
+      if (out_lse != nullptr) out_lse[row] = has_nan ? Num<T>::nan() : (T)dm;      // torch.logsumexp's values for such rows
+    }
+    for (int i = 0; i < C; ++i) {
+      idx[j0 + i] = (int64_t)K;
+      if (out_child_end != nullptr) out_child_end[row * (int64_t)K + j0 + i] = 0;     // nobody has children
+    }
+    return;
+  }
+
+  // ---- float64 weights, blocked inclusive scan -----------------------------------------------------------------------
+  double s[C];
+  double run = 0.0;
+  ExpScalars ek;
+  ek.init();
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    run += exp_nonpositive_s((double)v[i] - dm, ek);
+    s[i] = run;
+  }
+  const double incl = wave_scan_add(run);
+  const double excl = dpp_f64<kDppWaveShr1>(0.0, incl);           // the lanes before this one, inside the wavefront
+  if (lane == kWave - 1) scratch[16 + wave] = incl;
+  // The CDF's last entry is the normaliser, so that c[K-1] == 1.0 exactly (reference: c / max(c)): its owner — the last
+  // lane — publishes the two terms only it has, and every lane forms  (excl + earlier wavefronts) + s  the way it does.
+  if (tid == nt - 1) {
+    scratch[32] = excl;
+    scratch[33] = run;
+  }
+  __syncthreads();
+  double before_waves, before_last;
+  {
+    const double totals = row16_scan_add(lane < nwaves ? scratch[16 + lane] : 0.0);      // inclusive, wavefronts 0 .. lane
+    before_waves = read_lane(totals, wave > 0 ? wave - 1 : 0);
+    before_last = read_lane(totals, nwaves > 1 ? nwaves - 2 : 0);
+    if (wave == 0) before_waves = 0.0;
+    if (nwaves == 1) before_last = 0.0;
+  }
+  const double base = excl + before_waves;
+  const double total = (scratch[32] + before_last) + scratch[33];
+  const double inv_total = 1.0 / total;
+  // by-product: logsumexp of the row (the step's contribution to log Z), float64 inside
+  if (out_lse != nullptr && tid == 0) out_lse[row] = (T)(dm + ::log(total));
+
+  // ---- first[j] = min{ k : (u + k) / K >= c[j] } ---------------------------------------------------------------------
+  const double dK = (double)K;
+  int first[C];
+  bool edge = false;
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    const double c = divide_with_reciprocal(base + s[i], total, inv_total);
+    // c <= (u + k) / K  <=>  k >= c K - u, up to the rounding of the position and of this product: both are below
+    // K * 2^-52, so unless c K - u sits within K * 1e-15 of an integer its ceiling IS the answer
+    const double x = __builtin_fma(c, dK, -ub);
+    const double t = __builtin_ceil(x);
+    first[i] = t < 0.0 ? 0 : (t > dK ? K : (int)t);
+    edge |= __builtin_fabs(x - __builtin_rint(x)) <= dK * 1e-15;
+  }
+  if (__any(edge)) {      // rare: settled against the exactly rounded positions, out of line
+    const double inv_K = 1.0 / dK;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      const double c = divide_with_reciprocal(base + s[i], total, inv_total);
+      const double x = __builtin_fma(c, dK, -ub);
+      if (__builtin_fabs(x - __builtin_rint(x)) <= dK * 1e-15) {
+        int k0 = first[i];
+        while (k0 > 0 && divide_with_reciprocal(ub + (double)(k0 - 1), dK, inv_K) >= c) --k0;
+        while (k0 < K && divide_with_reciprocal(ub + (double)k0, dK, inv_K) < c) ++k0;
+        first[i] = k0;
+      }
+    }
+  }
+  // By-product for the gather's backward: first[j] = where the children of particles 0..j end (see the kernel above)
+  if (out_child_end != nullptr) {
+    int32_t *ends = out_child_end + row * (int64_t)K + j0;
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q)
+      reinterpret_cast<int4 *>(ends)[q] = make_int4(first[4 * q], first[4 * q + 1], first[4 * q + 2], first[4 * q + 3]);
+  }
+  // ---- markers: slot first[j] holds j + 1 for the LAST particle that starts there ---------------------------------------
+  {
+    const int next_lane_first = dpp_i32<kDppWaveShl1>(K, first[0]);      // the next lane's first particle (lane 63: unknown)
+#pragma unroll
+    for (int i = 0; i < C - 1; ++i) marker[first[i] < first[i + 1] ? first[i] : K] = j0 + i + 1;      // (slot K: the spare)
+    const int last = first[C - 1];
+    if (lane != kWave - 1) {
+      marker[last < next_lane_first ? last : K] = j0 + C;
+    } else {
+      // the next wavefront's first particle is not known here: the largest particle that starts at a slot wins
+      // whichever order the stores land in (every other store to it is a plain store of a larger value, or another max)
+      atomicMax(marker + (last < K ? last : K), j0 + C);
+    }
+  }
+  __syncthreads();
+
+  // ---- idx[k] = running maximum of the markers ----------------------------------------------------------------------
+  int best[C];
+#pragma unroll
+  for (int q = 0; q < C / 4; ++q) {
+    const int4 packed = reinterpret_cast<const int4 *>(marker + j0)[q];
+    best[4 * q] = packed.x;
+    best[4 * q + 1] = packed.y;
+    best[4 * q + 2] = packed.z;
+    best[4 * q + 3] = packed.w;
+  }
+#pragma unroll
+  for (int i = 1; i < C; ++i) best[i] = max(best[i], best[i - 1]);
+  const int incl_max = wave_scan_max(best[C - 1]);
+  const int before_lanes = dpp_i32<kDppWaveShr1>(0, incl_max);
+  if (lane == kWave - 1) scratch_i[16 + wave] = incl_max;
+  __syncthreads();
+  int before;
+  {
+    const int maxima = row16_scan_max(lane < nwaves ? scratch_i[16 + lane] : 0);
+    before = __builtin_amdgcn_readlane(maxima, wave > 0 ? wave - 1 : 0);
+    if (wave == 0) before = 0;
+  }
+  before = max(before, before_lanes);
+#pragma unroll
+  for (int i = 0; i < C; i += 2) {
+    longlong2 pair;
+    pair.x = (int64_t)max(before, best[i]);
+    pair.y = (int64_t)max(before, best[i + 1]);
+    *reinterpret_cast<longlong2 *>(idx + j0 + i) = pair;
+  }
+}
+
+// which kernel a payload-free step launches: 0 by shape, 1 ancestor_index_inv_kernel always, 2 the lean form wherever it
+// applies (AESMC_K2_FORM=general / rows in the environment, or the test hook aesmc_test_set_k2_form)
+static int g_k2_form = [] {
+  const char *v = getenv("AESMC_K2_FORM");
+  return v == nullptr ? 0 : (v[0] == 'g' ? 1 : (v[0] == 'r' ? 2 : 0));
+}();
+static int g_k2_last_form = 0;
+
 static int pick_threads(int64_t K, int chunk) {
   int64_t nt = (K + chunk - 1) / chunk;  // one round when it fits
   nt = (nt + kWave - 1) / kWave * kWave;
@@ -615,6 +934,29 @@ static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t 
                       int64_t K, hipStream_t s, void *out_lse = nullptr,
                       const StepPayload &payload = StepPayload{nullptr, nullptr, 0, 0, 0, 0},
                       int32_t *child_end = nullptr) {
+  if constexpr (C % 4 == 0) {
+    // whole rows and no payload: the lean form (ancestor_index_rows_kernel)
+    const int64_t lanes = K / C;
+    const auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (g_k2_form != 1 && payload.src == nullptr && lanes * C == K && lanes % kWave == 0 && lanes <= kMaxThreads &&
+        aligned(log_w) && aligned(idx) && aligned(child_end)) {
+      const size_t lds_rows = (size_t)kScratchDoubles * sizeof(double) + (size_t)(K + 4) * sizeof(int);
+      static bool rows_attr_set[64] = {};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return AESMC_ERR_LAUNCH;
+      if (!rows_attr_set[dev]) {
+        if (hipFuncSetAttribute((const void *)ancestor_index_rows_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+          return AESMC_ERR_LAUNCH;
+        rows_attr_set[dev] = true;
+      }
+      g_k2_last_form = 2;
+      hipLaunchKernelGGL((ancestor_index_rows_kernel<T, C>), dim3((unsigned)B), dim3((unsigned)lanes), lds_rows, s,
+                         (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, child_end);
+      return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+    }
+  }
+  g_k2_last_form = 1;
   const int nt = pick_threads(K, C);
   const size_t lds = (size_t)kScratchDoubles * sizeof(double) + (size_t)(nt * C + nt + 8) * sizeof(int);
   // raise the dynamic-LDS cap once per device and instantiation (a process may drive several GPUs)
@@ -671,6 +1013,15 @@ static int launch(const void *log_w, const double *u, int64_t *idx, int32_t *fla
 }  // namespace aesmc
 
 extern "C" int64_t aesmc_ancestor_index_lds_max_particles(void) { return aesmc::kInvMaxParticles; }
+
+// Test hooks (not part of the C ABI of include/aesmc_hip.h): which kernel a payload-free resampling step launches
+// (0 by shape, 1 ancestor_index_inv_kernel, 2 ancestor_index_rows_kernel wherever it applies), and which one the last did.
+extern "C" int aesmc_test_set_k2_form(int form) {
+  if (form < 0 || form > 2) return AESMC_ERR_INVALID_ARGUMENT;
+  aesmc::g_k2_form = form;
+  return AESMC_OK;
+}
+extern "C" int aesmc_test_last_k2_form(void) { return aesmc::g_k2_last_form; }
 
 extern "C" int aesmc_test_set_step_parts(int parts) {
   if (parts < 0 || (parts & (parts - 1)) != 0) return AESMC_ERR_INVALID_ARGUMENT;

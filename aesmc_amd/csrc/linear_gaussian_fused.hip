@@ -742,6 +742,7 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
                                   int32_t *flags, int64_t B, int64_t K, uint64_t seed, uint64_t offset,
                                   int64_t threads, const uint64_t *rng_state, hipStream_t stream) {
   const int64_t dx = mp->dout, dy = mg->dout;
+  g_fused_last_form = 1;      // (or, where this file declines, the first form: the caller's)
   if (dx < 2 || dx > 16 || dy < 1 || dy > 16) return AESMC_ERR_UNSUPPORTED;
   FusedPlan plan;
   const int planned = fused_make_plan(plan, B, K, dx, threads);
@@ -755,7 +756,6 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
       return status;
     }
   }
-  g_fused_last_form = 1;      // (or, where this form declines below, the first form: the caller's)
   const int ks = (int)((std::max(dx, dy) + 3) / 4);
   // extents above 12: the first form is faster (rows of 16 values put a wavefront's noise reads on two LDS banks
   // here: 371 against 337 us at B=1024 K=4096 d=16, profiles/r04_k16bench_sweep.txt)

@@ -3,9 +3,10 @@ noise and draw, the step's log-weight — aesmc/inference.py:102-126, state.py:9
 against each other and against `oracle/`:
 
   * the item form (linear_gaussian_item.hip: one work item per workgroup, what one GPU's shard of a batch takes) equals
-    the persistent form (linear_gaussian_fused.hip) BIT FOR BIT — x_t and the log-weights — at the strong-scaling shard
-    shapes of the north-star batch, at every even latent extent 2 .. 12 with equal and unequal observation extents,
-    ragged K, windows that straddle batch rows, with and without the gather, healthy and collapsed ancestries;
+    the persistent form (linear_gaussian_fused.hip; above 12 values per row: the first form, linear_gaussian_noise.hip) BIT
+    FOR BIT — x_t and the log-weights — at the strong-scaling shard shapes of the north-star batch, at every latent extent
+    2 .. 16 with equal and unequal observation extents, ragged K, windows that straddle batch rows, with and without the
+    gather, healthy and collapsed ancestries;
   * x_t of the item form equals oracle/smc_core.c bit for bit, its log-weights to the tolerance the stand-alone
     log-weight kernel is held to;
   * bad ancestor indices are flagged, never followed.
@@ -44,7 +45,10 @@ def forms(kernels, monkeypatch):
 # equal (compile-time) and unequal (run-time) observation extents, K ragged / prime / barely a window, one batch row
 FORM_SHAPES = [(128, 4096, 10, 10), (256, 1024, 10, 10), (300, 4099, 10, 7), (37, 29000, 6, 9), (1, 128, 2, 2),
                (2, 4096, 12, 12), (64, 1024, 8, 4), (9, 513, 4, 1), (3, 200000, 10, 10), (7, 2222, 12, 5), (5, 131, 2, 12),
-               (33, 640, 6, 6), (12, 4096, 8, 8), (4, 8192, 4, 4), (2, 130, 10, 10)]
+               (33, 640, 6, 6), (12, 4096, 8, 8), (4, 8192, 4, 4), (2, 130, 10, 10),
+               # odd extents (rows of dwords) and rows of 13 .. 16 values
+               (5, 777, 3, 11), (3, 300, 5, 5), (2, 1000, 7, 3), (4, 640, 9, 9), (3, 512, 11, 11), (2, 700, 13, 2),
+               (2, 2048, 14, 14), (3, 1000, 15, 16), (6, 1024, 16, 16), (2, 4096, 16, 5), (130, 4096, 16, 16)]
 
 
 def _run(kernels, o, x_prev, y, off_p, off_q, idx, seed):
@@ -85,7 +89,7 @@ def test_the_item_form_equals_the_persistent_form_bit_for_bit(kernels, hip_devic
 
 
 @pytest.mark.parametrize("shape", [(128, 4096, 10, 10), (37, 29000, 6, 9), (1, 128, 2, 2), (7, 2222, 12, 5), (9, 513, 4, 1),
-                                   (64, 1024, 8, 4)])
+                                   (64, 1024, 8, 4), (5, 777, 3, 11), (3, 512, 11, 11), (3, 1000, 15, 16), (6, 1024, 16, 16)])
 def test_the_item_form_equals_the_c_oracle(kernels, hip_device, forms, shape):
     """x_t bit for bit (gather of the ancestor rows, one fma chain per element started from the offset, eps * s rounded
     before the sum, eps = what `torch.empty(shape).normal_()` holds for the same generator state), the log-weight to
@@ -138,8 +142,8 @@ def test_the_item_form_flags_bad_ancestors_and_declines_what_it_does_not_cover(k
     assert torch.isfinite(out_x).all() and torch.isfinite(lw).all()
     from aesmc_amd import _lib
     assert kernels.read_flags(hip_device) & _lib.FLAG_INDEX_OUT_OF_RANGE
-    # odd extents, extents above 12 and strided weights are another form's: same call, same answer, other kernel
-    for dx2, dy2, transpose in ((5, 5, False), (14, 14, False), (10, 10, True)):
+    # strided weights (a transposed view) are another form's: same call, same answer, other kernel
+    for dx2, dy2, transpose in ((10, 10, True), (6, 3, True)):
         _, o2 = operands(4, 32, dx2, dy2, np.float32, hip_device, seed=4)
         if transpose:
             o2 = dict(o2, A=o2["A"].t().contiguous().t())
