@@ -693,12 +693,14 @@ struct ExpScalars {
     for (int i = 0; i < 13; ++i) asm volatile("" : "+s"(c[i]));
   }
 };
-// exp(x) for x <= 0, not NaN: exp_nonpositive's arithmetic, operation for operation, on x clamped at -745.2 instead of
-// answering 0.0 below it — the clamp's value is a denormal (<= 2^-1074) where that function says zero, which no sum that
-// holds the row maximum's exp(0) = 1 can tell apart: the same indices, children ranges and log-sum-exp, without the
-// compare, the two selects and the branch around the polynomial.
+// exp(x) for x <= 0, not NaN: exp_nonpositive's arithmetic, operation for operation, on x clamped at -746 instead of a
+// test for x <= -745.2 — the same values, bit for bit: above -745.2 nothing changes, and from there down to the clamp the
+// polynomial's p <= exp(-0.0668) = 0.9354 is scaled by 2^-1075 or 2^-1076, below half the smallest denormal, which
+// v_ldexp_f64 rounds to the 0.0 that function answers (a zero weight must stay an exact zero: with u = 0 a CDF entry
+// of 0 is reached by the first position, a denormal one is not) — without the compare, the two selects and the branch
+// around the polynomial.
 __device__ __forceinline__ double exp_nonpositive_s(double x, const ExpScalars &k) {
-  x = fmax(x, -745.2);
+  x = fmax(x, -746.0);
   const double n = __builtin_rint(x * k.log2e);
   double r = __builtin_fma(-n, k.ln2_hi, x);
   r = __builtin_fma(-n, k.ln2_lo, r);
@@ -815,7 +817,10 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
   bool edge = false;
 #pragma unroll
   for (int i = 0; i < C; ++i) {
-    const double c = divide_with_reciprocal(base + s[i], total, inv_total);
+    // (a tree-ordered scan may leave an entry one ulp ABOVE the last one where the weights behind it are negligible; the
+    //  reference's sequential cumsum is monotone, its c / max(c) never exceeds 1: clamped, so first[] never exceeds
+    //  first[K-1] and stays non-decreasing where it matters)
+    const double c = fmin(divide_with_reciprocal(base + s[i], total, inv_total), 1.0);
     // c <= (u + k) / K  <=>  k >= c K - u, up to the rounding of the position and of this product: both are below
     // K * 2^-52, so unless c K - u sits within K * 1e-15 of an integer its ceiling IS the answer
     const double x = __builtin_fma(c, dK, -ub);
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
     const double inv_K = 1.0 / dK;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-      const double c = divide_with_reciprocal(base + s[i], total, inv_total);
+      const double c = fmin(divide_with_reciprocal(base + s[i], total, inv_total), 1.0);
       const double x = __builtin_fma(c, dK, -ub);
       if (__builtin_fabs(x - __builtin_rint(x)) <= dK * 1e-15) {
         int k0 = first[i];

@@ -504,7 +504,8 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
             key, label = "affine_normal_propagate_wide", None      # K17 + K18: priced against the matrix cores below
         elif "affine_normal_propagate_drawn" in kernels:
             key, label = "affine_normal_propagate_drawn", \
-                "affine_propagate_fused_kernel (K16: the resample gather, the proposal's noise and draw, the log-weight)"
+                "affine_propagate_item_kernel (K16: the resample gather, the proposal's noise and draw, the log-weight; " \
+                "one work item per workgroup — affine_propagate_fused_kernel where weights' rows are strided)"
         elif "affine_normal_propagate_resampled" in kernels:
             key, label = "affine_normal_propagate_resampled", \
                 "affine_logweight_kernel, DRAW + GATHER (the resample gather inside the propagation launch: K3 + K15)"
