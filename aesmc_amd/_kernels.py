@@ -956,12 +956,13 @@ class HipKernels:
                 self.timer.note(name, (entry, args), nbytes, (x_prev, ancestors, eps, y_rows, out, out_x, maps, scales))
         return out
 
-    # Below ~0.5M particles a launch has too few work items to hide a workgroup's start-up behind (measured, one launch
-    # each, hipGraph-timed, d=10, profiles/r04_k16bench_sweep.txt: B=128 K=4096 29.8 us for K16 against 9.7 + 25.8 for
-    # the noise as its own launch followed by K15 through the ancestors; B=256 K=1024 24.6 against 6.7 + 14.2): the
-    # noise is then materialised by aesmc_philox_normal_fill — the same values — and the step takes the launches that
-    # read it.  (Round 3's form of K16 needed 1M particles to win.)
-    DRAWN_MIN_PARTICLES = int(__import__("os").environ.get("AESMC_K16_MIN_PARTICLES", str(1 << 19)))
+    # Particles below which the noise is materialised (aesmc_philox_normal_fill, the same values) and the step takes the
+    # launches that read it instead of forming it in the propagation launch.  0 since round 5: with one work item per
+    # workgroup (linear_gaussian_item.hip) the fused launch is ahead at every size measured, down to B=8 K=128 (5.6 us
+    # against 3.0 + 7.3 for the fill followed by K15; B=256 K=1024: 14.6 against 6.2 + 13.8; profiles/r05_k16_small_shapes.txt).
+    # Rounds 3 / 4 needed 1M / 0.5M particles for the persistent form to win.  Shapes the launch's item geometry does not
+    # cover (fewer than 128 particles per row) are declined by the library and take the fill route as before.
+    DRAWN_MIN_PARTICLES = int(__import__("os").environ.get("AESMC_K16_MIN_PARTICLES", "0"))
 
     def philox_normal(self, stream_desc, shape, device):
         """The float32 tensor `torch.empty(shape).normal_()` would have held for the generator state

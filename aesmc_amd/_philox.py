@@ -57,13 +57,16 @@ def verified(device):
     trips) are drawn by PyTorch under a forked generator and formed again by aesmc_philox_normal_fill from the
     reservation `reserve` would have made; the values must be equal bit for bit and the generator must have advanced
     by `consumed`.  If not, noise is left to PyTorch for the rest of the process (`state.set_kernel_noise(False)`):
-    slower, never wrong.  Inside a hipGraph capture nothing can be checked; the warm-up evaluations in front of a
-    capture have run it."""
+    slower, never wrong.  Inside a hipGraph capture nothing can be checked: `graphs.GraphedLoss` runs the check before it
+    captures; a capture that reaches this unchecked gets False (PyTorch draws)."""
     index = device.index if device.index is not None else torch.cuda.current_device()
     ok = _VERIFIED.get(index)
     if ok is None:
         if torch.cuda.is_current_stream_capturing():
-            return True
+            # nothing can be checked inside a capture, and an unchecked restatement must not be baked into a graph: the
+            # noise is left to PyTorch for this capture (graphs.GraphedLoss runs the check itself before it captures, so
+            # this is only reached by a caller's own torch.cuda.graph without a warm-up)
+            return False
         _VERIFIED[index] = True          # (the check itself draws through this module's callers)
         ok = _self_check(torch.device("cuda", index))
         _VERIFIED[index] = ok

@@ -711,10 +711,15 @@ __device__ __forceinline__ double exp_nonpositive_s(double x, const ExpScalars &
   return __builtin_ldexp(p, (int)n);
 }
 
+// (Held to 64 registers like the kernel above: every row of the north-star batch resident at once.  Measured against a
+//  96-register build without the slow path's spills, which runs the batch in two rounds of workgroups: 20.2 against 19.9 us
+//  at B = 1024, K = 4096 and 4.0 against 5.7 us at B = 256, K = 1024 — profiles/r05_k2_forms.txt.  Also measured and not
+//  kept: a workgroup walking two or four rows so that one row's index stores drain under the next row's scan — the loop's
+//  live state spilt 72 registers and the launch took 31 - 33 us.)
 template <typename T, int C>
 __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_rows_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx, int32_t *flags, int K,
-    T *__restrict__ out_lse, int32_t *__restrict__ out_child_end, int B) {
+    T *__restrict__ out_lse, int32_t *__restrict__ out_child_end) {
   static_assert(C % 4 == 0, "a lane's particles are moved in 16-byte pieces");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *scratch = smem;                                          // [0,16) wavefront maxima, [16,32) wavefront totals, [32], [33]
@@ -725,15 +730,10 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = nt >> 6;
-  const int j0 = tid * C;
-  ExpScalars ek;
-  ek.init();
-  // A workgroup walks rows blockIdx.x, blockIdx.x + gridDim.x, ...: with more rows than resident workgroups' worth of
-  // grid (the host's choice) one row's index stores drain while the next row is loaded and scanned, instead of every
-  // resident row storing at once at the launch's end.
-  for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+  const int64_t row = blockIdx.x;
   const T *lw = log_w + row * (int64_t)K;
   int64_t *idx = out_idx + row * (int64_t)K;
+  const int j0 = tid * C;
   const double ub = u[row];      // (needed after the scan; sent for now)
 
   // ---- load once; the markers' zero fill rides in front of the first barrier ---------------------------------------
@@ -779,13 +779,14 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
       idx[j0 + i] = (int64_t)K;
       if (out_child_end != nullptr) out_child_end[row * (int64_t)K + j0 + i] = 0;     // nobody has children
     }
-    __syncthreads();      // (every lane of the workgroup takes this branch: the scratch slots are free for the next row)
-    continue;
+    return;
   }
 
   // ---- float64 weights, blocked inclusive scan -----------------------------------------------------------------------
   double s[C];
   double run = 0.0;
+  ExpScalars ek;
+  ek.init();
 #pragma unroll
   for (int i = 0; i < C; ++i) {
     run += exp_nonpositive_s((double)v[i] - dm, ek);
@@ -899,8 +900,6 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
     pair.y = (int64_t)max(before, best[i + 1]);
     *reinterpret_cast<longlong2 *>(idx + j0 + i) = pair;
   }
-  __syncthreads();      // the next row's zero fill and maxima reuse the markers and the scratch slots
-  }
 }
 
 // which kernel a payload-free step launches: 0 by shape, 1 ancestor_index_inv_kernel always, 2 the lean form wherever it
@@ -910,11 +909,6 @@ static int g_k2_form = [] {
   return v == nullptr ? 0 : (v[0] == 'g' ? 1 : (v[0] == 'r' ? 2 : 0));
 }();
 static int g_k2_last_form = 0;
-// rows a workgroup of the lean form walks (AESMC_K2_ROWS_PER_GROUP; a measurement knob)
-static int g_k2_rows_per_group = [] {
-  const char *v = getenv("AESMC_K2_ROWS_PER_GROUP");
-  return v != nullptr ? atoi(v) : 0;
-}();
 
 static int pick_threads(int64_t K, int chunk) {
   int64_t nt = (K + chunk - 1) / chunk;  // one round when it fits
@@ -967,10 +961,8 @@ static int launch_inv(const void *log_w, const double *u, int64_t *idx, int32_t 
         rows_attr_set[dev] = true;
       }
       g_k2_last_form = 2;
-      const int64_t per = g_k2_rows_per_group > 0 ? g_k2_rows_per_group : 1;
-      const int64_t groups = (B + per - 1) / per;
-      hipLaunchKernelGGL((ancestor_index_rows_kernel<T, C>), dim3((unsigned)groups), dim3((unsigned)lanes), lds_rows, s,
-                         (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, child_end, (int)B);
+      hipLaunchKernelGGL((ancestor_index_rows_kernel<T, C>), dim3((unsigned)B), dim3((unsigned)lanes), lds_rows, s,
+                         (const T *)log_w, u, idx, flags, (int)K, (T *)out_lse, child_end);
       return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
     }
   }

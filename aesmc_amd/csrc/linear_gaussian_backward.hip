@@ -1110,7 +1110,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   const int forced_grid = step ? affine_step_backward_forced_grid() : 0;      // test hook (aesmc_test_set_step_backward)
   int grid = (int)std::min<int64_t>(lg_persistent_grid(tiles, lds, (ppl == 2 || sizeof(T) == 8) ? 2 : (step ? LG_STEP_WAVES : 3)), kLgMaxGrid);   // what the registers allow
-  if (rows_form) grid = (int)affine_step_backward_rows_grid(B, K);
+  if (rows_form) grid = (int)affine_step_backward_rows_grid(B, K, mp->dout);
   if (forced_grid > 0) grid = (int)std::min<int64_t>(std::min<int64_t>(forced_grid, tiles), kLgMaxGrid);
   const int row_terms = (o->grad_offset_p != nullptr ? 1 : 0) | (o->grad_offset_g != nullptr ? 2 : 0) |
                         (o->grad_offset_q != nullptr ? 4 : 0);

@@ -105,10 +105,10 @@ constexpr int kLgChildLimit = 32;   // children a lane sums by itself; longer ru
                                     // (8: the bench shape's healthy ancestry 338 -> 348 us, a collapsed one 456 -> 437)
 constexpr int kLgChildTrip = 1;     // of them per trip out of the staged block (2: the same time, ten more registers; 4: slower)
 
-// linear_gaussian_step_backward.hip: the step's backward for rows of ten float32 values (the second form of K14)
+// linear_gaussian_step_backward.hip: the step's backward for rows of an even number (2 .. 14) of float32 values (the second form of K14)
 bool affine_step_backward_rows_covers(const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                       int64_t B, int64_t K);
-unsigned affine_step_backward_rows_grid(int64_t B, int64_t K);
+unsigned affine_step_backward_rows_grid(int64_t B, int64_t K, int64_t d);
 int affine_step_backward_forced_grid();      // test hook: > 0 pins the grid of both forms
 int launch_affine_step_backward_rows(const float *xprev, const float *x, const float *y, int64_t y_sb, const LgMap &mp,
                                      const LgMap &mg, const LgMap &mq, const float *sp, const float *sg, const float *sq,

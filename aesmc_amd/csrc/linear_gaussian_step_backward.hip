@@ -1,4 +1,4 @@
-// K14 for rows of ten float32 values (the BASELINE shapes): the whole backward of a linear-Gaussian SMC step whose x_t
+// K14 for rows of D float32 values, D even, 2 .. 14 (ten: the BASELINE shapes): the whole backward of a linear-Gaussian SMC step whose x_t
 // is the proposal's reparameterised draw — affine_step_backward_kernel's arithmetic (linear_gaussian_backward.hip: the
 // same fma chains, the same matrix-core accumulation order, the same records: every output equal bit for bit when the
 // two run on the same grid), rearranged the way the forward step was (linear_gaussian_fused.hip):
@@ -13,6 +13,7 @@
 //     ahead by loads that write LDS directly; a lane sums its run out of it in k order.
 // Reference: autograd of aesmc/state.py:114-155,179 and aesmc/inference.py:108-130 for one timestep.
 #include "linear_gaussian_backward.hpp"
+#include "linear_gaussian_fused.hpp"
 
 #include <atomic>
 
@@ -24,15 +25,17 @@ typedef float sb_f4 __attribute__((ext_vector_type(4)));
 typedef sb_f4 sb_f4_a4 __attribute__((aligned(4)));      // a 16-byte global access at 4-byte alignment (hardware: unaligned mode)
 typedef sb_f2 sb_f2_a4 __attribute__((aligned(4)));
 
-constexpr int kSbD = 10;                 // the rows' extent
 constexpr int kSbChildRows = 96;         // rows of a wavefront's staged block of children (mean 64; what does not fit: from HBM)
-constexpr int kSbTile = 64 * kSbD + 16;  // a wavefront's u / x area (+16: the matrix-core operand reads run past a row's end)
-constexpr int kSbWave = 2 * kSbTile + kSbChildRows * kSbD;      // floats per wavefront
 constexpr int kSbSlots = 2 * 192;        // the tile's column sums (three terms x four wavefronts x 16), two tiles' worth
-constexpr int kSbOnes = 15 * 4 * kSbD + 8;      // 1.0 wherever a lane of column 15 reads its "x" operand (sb_outer)
-constexpr size_t kSbLds = sizeof(float) * (kSbSlots + kSbOnes + 4 * (size_t)kSbWave);
-constexpr int kSbPerCu = 3;              // workgroups per CU (= wavefronts per SIMD) the registers allow
-static_assert(kSbLds * kSbPerCu <= 160 * 1024, "LDS of the resident workgroups");
+template <int D> struct Sb {             // D: the rows' extent (both the latent's and the observation's)
+  static_assert(D >= 2 && D <= 14 && D % 2 == 0, "even extents below 16: rows in 8-byte pieces, column 15 of a matrix tile free");
+  static constexpr int kTile = 64 * D + 16;  // a wavefront's u / x area (+16: the matrix-core operand reads run past a row's end)
+  static constexpr int kWave = 2 * kTile + kSbChildRows * D;      // floats per wavefront
+  static constexpr int kOnes = 15 * 4 * D + 8;      // 1.0 wherever a lane of column 15 reads its "x" operand (sb_outer)
+  static constexpr size_t kLds = sizeof(float) * (kSbSlots + kOnes + 4 * (size_t)kWave);
+  static constexpr int kPerCu = D <= 10 ? 3 : 2;      // workgroups per CU (= wavefronts per SIMD) the registers allow
+  static_assert(kLds * kPerCu <= 160 * 1024, "LDS of the resident workgroups");
+};
 
 // tile / tpr with mul = floor(2^32 / tpr): the high product is the quotient or one less (tile < 2^23)
 __device__ __forceinline__ uint32_t sb_row_of(uint32_t tile, uint32_t tpr, uint32_t mul) {
@@ -41,84 +44,115 @@ __device__ __forceinline__ uint32_t sb_row_of(uint32_t tile, uint32_t tpr, uint3
   return q;
 }
 
-// acc_j += W[j][i] x_i, two outputs' chains side by side, five inputs per statement (see linear_gaussian_fused.hip)
-__device__ __forceinline__ void sb_fmac_s5x2(float &a0, float &a1, const float *w0, const float *w1, const float *x) {
-  asm("v_fmac_f32 %0, %2, %12\n\tv_fmac_f32 %1, %7, %12\n\t"
-      "v_fmac_f32 %0, %3, %13\n\tv_fmac_f32 %1, %8, %13\n\t"
-      "v_fmac_f32 %0, %4, %14\n\tv_fmac_f32 %1, %9, %14\n\t"
-      "v_fmac_f32 %0, %5, %15\n\tv_fmac_f32 %1, %10, %15\n\t"
-      "v_fmac_f32 %0, %6, %16\n\tv_fmac_f32 %1, %11, %16"
-      : "+v"(a0), "+v"(a1)
-      : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w0[3]), "s"(w0[4]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "s"(w1[3]),
-        "s"(w1[4]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]));
+// the adjoint's step: acc_i += W[j][i] u_j then acc_i += W[j+1][i] u_{j+1} for N consecutive i — rows j, j + 1 of W as they
+// lie (the forward chains' counterpart, fused_fmac_sx2, is linear_gaussian_fused.hpp's)
+template <int N>
+__device__ __forceinline__ void sb_fmac_tx2(float *acc, const float *w0, const float *w1, float u0, float u1) {
+  static_assert(N >= 1 && N <= 5, "one to five inputs per statement");
+  if constexpr (N == 5) {
+    asm("v_fmac_f32 %0, %5, %15\n\tv_fmac_f32 %1, %6, %15\n\tv_fmac_f32 %2, %7, %15\n\tv_fmac_f32 %3, %8, %15\n\t"
+        "v_fmac_f32 %4, %9, %15\n\t"
+        "v_fmac_f32 %0, %10, %16\n\tv_fmac_f32 %1, %11, %16\n\tv_fmac_f32 %2, %12, %16\n\tv_fmac_f32 %3, %13, %16\n\t"
+        "v_fmac_f32 %4, %14, %16"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4])
+        : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w0[3]), "s"(w0[4]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "s"(w1[3]),
+          "s"(w1[4]), "v"(u0), "v"(u1));
+  } else if constexpr (N == 4) {
+    asm("v_fmac_f32 %0, %4, %12\n\tv_fmac_f32 %1, %5, %12\n\tv_fmac_f32 %2, %6, %12\n\tv_fmac_f32 %3, %7, %12\n\t"
+        "v_fmac_f32 %0, %8, %13\n\tv_fmac_f32 %1, %9, %13\n\tv_fmac_f32 %2, %10, %13\n\tv_fmac_f32 %3, %11, %13"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+        : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w0[3]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "s"(w1[3]), "v"(u0), "v"(u1));
+  } else if constexpr (N == 3) {
+    asm("v_fmac_f32 %0, %3, %9\n\tv_fmac_f32 %1, %4, %9\n\tv_fmac_f32 %2, %5, %9\n\t"
+        "v_fmac_f32 %0, %6, %10\n\tv_fmac_f32 %1, %7, %10\n\tv_fmac_f32 %2, %8, %10"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])
+        : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "v"(u0), "v"(u1));
+  } else if constexpr (N == 2) {
+    asm("v_fmac_f32 %0, %2, %6\n\tv_fmac_f32 %1, %3, %6\n\t"
+        "v_fmac_f32 %0, %4, %7\n\tv_fmac_f32 %1, %5, %7"
+        : "+v"(acc[0]), "+v"(acc[1])
+        : "s"(w0[0]), "s"(w0[1]), "s"(w1[0]), "s"(w1[1]), "v"(u0), "v"(u1));
+  } else {
+    asm("v_fmac_f32 %0, %1, %3\n\tv_fmac_f32 %0, %2, %4" : "+v"(acc[0]) : "s"(w0[0]), "s"(w1[0]), "v"(u0), "v"(u1));
+  }
 }
-// the adjoint's step: acc_i += W[j][i] u_j then acc_i += W[j+1][i] u_{j+1} for five i — rows j, j + 1 of W as they lie
-__device__ __forceinline__ void sb_fmac_t5x2(float *acc, const float *w0, const float *w1, float u0, float u1) {
-  asm("v_fmac_f32 %0, %5, %15\n\tv_fmac_f32 %1, %6, %15\n\tv_fmac_f32 %2, %7, %15\n\tv_fmac_f32 %3, %8, %15\n\t"
-      "v_fmac_f32 %4, %9, %15\n\t"
-      "v_fmac_f32 %0, %10, %16\n\tv_fmac_f32 %1, %11, %16\n\tv_fmac_f32 %2, %12, %16\n\tv_fmac_f32 %3, %13, %16\n\t"
-      "v_fmac_f32 %4, %14, %16"
-      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4])
-      : "s"(w0[0]), "s"(w0[1]), "s"(w0[2]), "s"(w0[3]), "s"(w0[4]), "s"(w1[0]), "s"(w1[1]), "s"(w1[2]), "s"(w1[3]),
-        "s"(w1[4]), "v"(u0), "v"(u1));
+template <int D, int I0 = 0>
+__device__ __forceinline__ void sb_adjoint_pair(float *acc, const float *w0, const float *w1, float u0, float u1) {
+  if constexpr (I0 < D) {
+    constexpr int N = fused_group(D - I0);
+    sb_fmac_tx2<N>(acc + I0, w0 + I0, w1 + I0, u0, u1);
+    sb_adjoint_pair<D, I0 + N>(acc, w0, w1, u0, u1);
+  }
 }
 
 __device__ __forceinline__ float sb_uniform(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
-// a row of ten values at 8-byte alignment
-__device__ __forceinline__ void sb_load_row(const float *__restrict__ src, float (&v)[kSbD]) {
-  const sb_f4 a = *reinterpret_cast<const sb_f4_a4 *>(src);
-  const sb_f4 b = *reinterpret_cast<const sb_f4_a4 *>(src + 4);
-  const sb_f2 c = *reinterpret_cast<const sb_f2_a4 *>(src + 8);
-  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-  v[8] = c[0]; v[9] = c[1];
-}
-__device__ __forceinline__ void sb_store_row(float *__restrict__ dst, const float (&v)[kSbD]) {
-  sb_f4 a, b;
-  sb_f2 c;
-  a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
-  b[0] = v[4]; b[1] = v[5]; b[2] = v[6]; b[3] = v[7];
-  c[0] = v[8]; c[1] = v[9];
-  *reinterpret_cast<sb_f4_a4 *>(dst) = a;
-  *reinterpret_cast<sb_f4_a4 *>(dst + 4) = b;
-  *reinterpret_cast<sb_f2_a4 *>(dst + 8) = c;
-}
-// the same row in LDS: 8-byte pieces (rows of 40 bytes)
-__device__ __forceinline__ void sb_lds_row(const float *row, float (&v)[kSbD]) {
+// a row of D values at 8-byte alignment: 16-byte pieces, then an 8-byte one where D is not a multiple of four
+template <int D> __device__ __forceinline__ void sb_load_row(const float *__restrict__ src, float (&v)[D]) {
 #pragma unroll
-  for (int j = 0; j < kSbD / 2; ++j) {
+  for (int e = 0; e + 4 <= D; e += 4) {
+    const sb_f4 a = *reinterpret_cast<const sb_f4_a4 *>(src + e);
+    v[e] = a[0]; v[e + 1] = a[1]; v[e + 2] = a[2]; v[e + 3] = a[3];
+  }
+  if constexpr (D % 4 != 0) {
+    const sb_f2 c = *reinterpret_cast<const sb_f2_a4 *>(src + (D & ~3));
+    v[D - 2] = c[0]; v[D - 1] = c[1];
+  }
+}
+template <int D> __device__ __forceinline__ void sb_store_row(float *__restrict__ dst, const float (&v)[D]) {
+#pragma unroll
+  for (int e = 0; e + 4 <= D; e += 4) {
+    sb_f4 a;
+    a[0] = v[e]; a[1] = v[e + 1]; a[2] = v[e + 2]; a[3] = v[e + 3];
+    *reinterpret_cast<sb_f4_a4 *>(dst + e) = a;
+  }
+  if constexpr (D % 4 != 0) {
+    sb_f2 c;
+    c[0] = v[D - 2]; c[1] = v[D - 1];
+    *reinterpret_cast<sb_f2_a4 *>(dst + (D & ~3)) = c;
+  }
+}
+// the same row in LDS: 8-byte pieces (rows of 4 D bytes)
+template <int D> __device__ __forceinline__ void sb_lds_row(const float *row, float (&v)[D]) {
+#pragma unroll
+  for (int j = 0; j < D / 2; ++j) {
     const sb_f2 q = reinterpret_cast<const sb_f2 *>(row)[j];
     v[2 * j] = q[0];
     v[2 * j + 1] = q[1];
   }
 }
-__device__ __forceinline__ void sb_lds_put(float *row, const float (&v)[kSbD]) {
+template <int D> __device__ __forceinline__ void sb_lds_put(float *row, const float (&v)[D]) {
 #pragma unroll
-  for (int j = 0; j < kSbD / 2; ++j) {
+  for (int j = 0; j < D / 2; ++j) {
     sb_f2 q;
     q[0] = v[2 * j];
     q[1] = v[2 * j + 1];
     reinterpret_cast<sb_f2 *>(row)[j] = q;
   }
 }
+// values a compiler barrier pins where they are (one empty statement per register: any extent)
+template <int N> __device__ __forceinline__ void sb_pin(float (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(v[j]));
+}
 
 // acc[j][i] += sum over the wavefront's 64 particles of tg[p][j] tx[p][i]: lg_outer_accumulate_own's whole-tile branch
 // with ONES (the lanes of column 15 feed 1: acc[j][15] gathers the column sums of tg), on the wavefront's own area
 // (`ones`: an area holding 1.0 at every offset the sixteen reads use — the lanes of column 15 read it instead of tx)
+template <int D>
 __device__ __forceinline__ void sb_outer(const float *tg, const float *tx, const float *ones, uint32_t lane,
                                          Mfma<float>::Acc &acc) {
-  const uint32_t col = lane & 15u, e = (lane >> 4) * kSbD + col;
+  const uint32_t col = lane & 15u, e = (lane >> 4) * D + col;
   const float *ta = tg + e, *tb = col == 15u ? ones : tx + e;
 #pragma unroll
   for (int group = 0; group < 4; ++group) {
     float a[4], b[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      a[t] = ta[(4 * group + t) * 4 * kSbD];
-      b[t] = tb[(4 * group + t) * 4 * kSbD];
+      a[t] = ta[(4 * group + t) * 4 * D];
+      b[t] = tb[(4 * group + t) * 4 * D];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = Mfma<float>::fma(a[t], b[t], acc);
@@ -155,11 +189,11 @@ struct SbArgs {
 #endif
 typedef const SbArgs __attribute__((address_space(4))) sb_cargs;
 
-template <bool GATHER, bool FOLDS>
-__global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_kernel(SbArgs unused_by_name) {
+template <int D, bool GATHER, bool FOLDS>
+__global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_rows_kernel(SbArgs unused_by_name) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
-  constexpr int D = kSbD;
+  constexpr int kSbTile = Sb<D>::kTile, kSbWave = Sb<D>::kWave, kSbOnes = Sb<D>::kOnes;
   // the argument block, re-derived (opaquely) wherever it is read: a field is loaded where it is used, never hoisted
   unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
 #define SB_A() ([&]() -> sb_cargs * { asm volatile("" : "+s"(ka)); return (sb_cargs *)ka; }())
@@ -279,13 +313,19 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
     // everything sent for during the last tile has landed (the block of children writes LDS from the vector-memory side)
     // (the prefetched registers are operands of the wait: the compiler then asks for them in front of it and never
     //  again behind it, where its own wait would also cover the stores that follow)
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(xp_n[0]), "+v"(xp_n[1]), "+v"(xp_n[2]), "+v"(xp_n[3]), "+v"(xp_n[4]), "+v"(xp_n[5]), "+v"(xp_n[6]),
-                   "+v"(xp_n[7]), "+v"(xp_n[8]), "+v"(xp_n[9]), "+v"(xt_n[0]), "+v"(xt_n[1]), "+v"(xt_n[2]), "+v"(xt_n[3]),
-                   "+v"(xt_n[4]), "+v"(xt_n[5]), "+v"(xt_n[6]), "+v"(xt_n[7]), "+v"(xt_n[8]), "+v"(xt_n[9]), "+v"(lw_n),
-                   "+v"(glw_n), "+v"(rb_n), "+v"(re_n), "+v"(anc_n)
-                 :
-                 : "memory");
+    if constexpr (D == 10) {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(xp_n[0]), "+v"(xp_n[1]), "+v"(xp_n[2]), "+v"(xp_n[3]), "+v"(xp_n[4]), "+v"(xp_n[5]), "+v"(xp_n[6]),
+                     "+v"(xp_n[7]), "+v"(xp_n[8]), "+v"(xp_n[9]), "+v"(xt_n[0]), "+v"(xt_n[1]), "+v"(xt_n[2]), "+v"(xt_n[3]),
+                     "+v"(xt_n[4]), "+v"(xt_n[5]), "+v"(xt_n[6]), "+v"(xt_n[7]), "+v"(xt_n[8]), "+v"(xt_n[9]), "+v"(lw_n),
+                     "+v"(glw_n), "+v"(rb_n), "+v"(re_n), "+v"(anc_n)
+                   :
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(lw_n), "+v"(glw_n), "+v"(rb_n), "+v"(re_n), "+v"(anc_n) : : "memory");
+      sb_pin(xp_n);
+      sb_pin(xt_n);
+    }
     uint32_t b;
     float g;
     float xp[D], xt[D], w[D];
@@ -365,10 +405,15 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       const uint32_t next = tile + step, after = next + step;
       // (w is complete here: nothing that waits for a load of THIS tile may sink behind the loads sent for the next one,
       //  where its wait would be a wait for all of them)
-      asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]),
-                        "+v"(w[9]), "+v"(g)
-                   :
-                   : "memory");
+      if constexpr (D == 10) {
+        asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]),
+                          "+v"(w[9]), "+v"(g)
+                     :
+                     : "memory");
+      } else {
+        asm volatile("" : "+v"(g) : : "memory");
+        sb_pin(w);
+      }
       if (next < tiles) {
         if constexpr (FOLDS) {
           // (this wavefront has taken its sums out of its block: the area is free; a wavefront's LDS accesses keep their order)
@@ -411,8 +456,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
 #pragma unroll
           for (int e = 0; e < 2 * D; ++e) nxt[e] = W[(jb + 2) * D + e];
         }
-#pragma unroll
-        for (int i0 = 0; i0 < D; i0 += 5) sb_fmac_s5x2(acc[jb], acc[jb + 1], cur + i0, cur + D + i0, in + i0);
+        fused_pair<D>(acc[jb], acc[jb + 1], cur, cur + D, in);
       }
     };
     // acc_i += sum_j W[j][i] u_j (ascending j): an adjoint
@@ -429,8 +473,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
 #pragma unroll
           for (int e = 0; e < 2 * D; ++e) nxt[e] = W[(jb + 2) * D + e];
         }
-#pragma unroll
-        for (int i0 = 0; i0 < D; i0 += 5) sb_fmac_t5x2(acc + i0, cur + i0, cur + D + i0, u[jb], u[jb + 1]);
+        sb_adjoint_pair<D>(acc, cur, cur + D, u[jb], u[jb + 1]);
       }
     };
     float *slot = slots + (trip & 1u) * 192;
@@ -460,7 +503,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       lg_wave_fence();
       if (!SB_PROBE(4u)) adjoint(A->wg, u, w);
       else for (int j = 0; j < D; ++j) w[j] += u[j];
-      if (!SB_PROBE(8u)) sb_outer(tu, tx, ones, lane, acc_c);
+      if (!SB_PROBE(8u)) sb_outer<D>(tu, tx, ones, lane, acc_c);
       lg_flush_column_sums<float>(acc_c, slot + 64, (A->row_terms & 2) != 0);
       lg_wave_fence();
     }
@@ -486,7 +529,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       lg_wave_fence();
       if (A->gxprev != nullptr && !SB_PROBE(4u)) adjoint(A->wp, u, gprev);
       else for (int j = 0; j < D; ++j) gprev[j] += u[j];
-      if (!SB_PROBE(8u)) sb_outer(tu, tx, ones, lane, acc_a);
+      if (!SB_PROBE(8u)) sb_outer<D>(tu, tx, ones, lane, acc_a);
       lg_flush_column_sums<float>(acc_a, slot, (A->row_terms & 1) != 0);
       lg_wave_fence();
     }
@@ -508,7 +551,7 @@ __global__ __launch_bounds__(kLgBlock, kSbPerCu) void affine_step_backward_rows_
       lg_wave_fence();
       if (A->gxprev != nullptr && !SB_PROBE(4u)) adjoint(A->wq, w, gprev);
       else for (int j = 0; j < D; ++j) gprev[j] += w[j];
-      if (!SB_PROBE(8u)) sb_outer(tu, tx, ones, lane, acc_q);
+      if (!SB_PROBE(8u)) sb_outer<D>(tu, tx, ones, lane, acc_q);
       const int row_terms = A->rows != nullptr ? A->row_terms : 0;
       lg_flush_column_sums<float>(acc_q, slot + 128, (row_terms & 4) != 0);
       lg_wave_fence();
@@ -571,23 +614,67 @@ static std::atomic<int> g_sb_form{[] { const char *v = getenv("AESMC_K14_FORM");
 static std::atomic<int> g_sb_grid{0};      // > 0: workgroups of either form's launch (the records' association follows the grid)
 int affine_step_backward_forced_grid() { return g_sb_grid.load(std::memory_order_relaxed); }
 
-// Does this form cover the call?  Rows of ten float32 values on both sides, every tile of 256 particles inside one
-// batch row, weights whose rows are contiguous (what an nn.Linear holds), 32-bit row numbers.
+// Does this form cover the call?  Rows of the same even number of float32 values (2 .. 14) on both sides, every tile of
+// 256 particles inside one batch row, weights whose rows are contiguous (what an nn.Linear holds), 32-bit row numbers.
+static std::atomic<int> g_sb_last{0};      // which form the last step's backward took: 1 tiles, 2 rows (test hook below)
+static bool sb_covers(const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq, int64_t B, int64_t K);
 bool affine_step_backward_rows_covers(const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                       int64_t B, int64_t K) {
+  const bool covers = sb_covers(mp, mg, mq, B, K);
+  g_sb_last.store(covers ? 2 : 1, std::memory_order_relaxed);
+  return covers;
+}
+static bool sb_covers(const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq, int64_t B, int64_t K) {
   if (g_sb_form.load(std::memory_order_relaxed) == 1) return false;
   const auto rows_contiguous = [](const aesmc_affine_map *m) {
     return m->stride_in == 1 && m->stride_out == m->din && (reinterpret_cast<uintptr_t>(m->weight) & 3u) == 0 &&
            (m->offset == nullptr || (reinterpret_cast<uintptr_t>(m->offset) & 3u) == 0);
   };
-  return mp->dout == kSbD && mp->din == kSbD && mg->dout == kSbD && mg->din == kSbD && mq->dout == kSbD &&
-         mq->din == kSbD && K % kLgBlock == 0 && B * K > 0 && B * K < (1ll << 31) && rows_contiguous(mp) &&
+  const int64_t d = mp->dout;
+#ifdef AESMC_LG_FAST_BUILD
+  if (d != 10) return false;
+#endif
+  return d >= 2 && d <= 14 && d % 2 == 0 && mp->din == d && mg->dout == d && mg->din == d && mq->dout == d &&
+         mq->din == d && K % kLgBlock == 0 && B * K > 0 && B * K < (1ll << 31) && rows_contiguous(mp) &&
          rows_contiguous(mg) && rows_contiguous(mq);
 }
 
-unsigned affine_step_backward_rows_grid(int64_t B, int64_t K) {
+template <int D> static unsigned sb_grid(int64_t tiles) {
+  return (unsigned)std::min<int64_t>(lg_persistent_grid(tiles, Sb<D>::kLds, Sb<D>::kPerCu), kLgMaxGrid);
+}
+unsigned affine_step_backward_rows_grid(int64_t B, int64_t K, int64_t d) {
   const int64_t tiles = B * K / kLgBlock;
-  return (unsigned)std::min<int64_t>(lg_persistent_grid(tiles, kSbLds, kSbPerCu), kLgMaxGrid);
+  switch (d) {
+#ifndef AESMC_LG_FAST_BUILD
+    case 2: return sb_grid<2>(tiles);
+    case 4: return sb_grid<4>(tiles);
+    case 6: return sb_grid<6>(tiles);
+    case 8: return sb_grid<8>(tiles);
+    case 12: return sb_grid<12>(tiles);
+    case 14: return sb_grid<14>(tiles);
+#endif
+    default: return sb_grid<10>(tiles);
+  }
+}
+
+template <int D>
+static void sb_launch(bool gathers, bool folds, unsigned grid, hipStream_t stream, const SbArgs &a, bool &ok) {
+  constexpr size_t lds = Sb<D>::kLds;
+  static bool raised[4][64] = {};
+  ok = true;
+  if (gathers && folds) {
+    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, true, true>), raised[0]);
+    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, true, true>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
+  } else if (gathers) {
+    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, true, false>), raised[1]);
+    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, true, false>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
+  } else if (folds) {
+    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, false, true>), raised[2]);
+    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, false, true>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
+  } else {
+    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, false, false>), raised[3]);
+    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, false, false>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
+  }
 }
 
 int launch_affine_step_backward_rows(const float *xprev, const float *x, const float *y, int64_t y_sb, const LgMap &mp,
@@ -617,14 +704,25 @@ int launch_affine_step_backward_rows(const float *xprev, const float *x, const f
 #ifdef AESMC_K14_PROBES
   { const char *v = getenv("AESMC_K14_PROBE"); a.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
 #endif
-  if (gathers && folds) hipLaunchKernelGGL((affine_step_backward_rows_kernel<true, true>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
-  else if (gathers) hipLaunchKernelGGL((affine_step_backward_rows_kernel<true, false>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
-  else if (folds) hipLaunchKernelGGL((affine_step_backward_rows_kernel<false, true>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
-  else hipLaunchKernelGGL((affine_step_backward_rows_kernel<false, false>), dim3(grid), dim3(kLgBlock), kSbLds, stream, a);
+  bool ok = true;
+  switch (mp.dout) {
+#ifndef AESMC_LG_FAST_BUILD
+    case 2: sb_launch<2>(gathers, folds, grid, stream, a, ok); break;
+    case 4: sb_launch<4>(gathers, folds, grid, stream, a, ok); break;
+    case 6: sb_launch<6>(gathers, folds, grid, stream, a, ok); break;
+    case 8: sb_launch<8>(gathers, folds, grid, stream, a, ok); break;
+    case 12: sb_launch<12>(gathers, folds, grid, stream, a, ok); break;
+    case 14: sb_launch<14>(gathers, folds, grid, stream, a, ok); break;
+#endif
+    case 10: sb_launch<10>(gathers, folds, grid, stream, a, ok); break;
+    default: return AESMC_ERR_UNSUPPORTED;
+  }
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
 }  // namespace aesmc
+
+extern "C" int aesmc_test_last_step_backward_form(void) { return aesmc::g_sb_last.load(std::memory_order_relaxed); }
 
 extern "C" int aesmc_test_set_step_backward(int form, int grid) {
   if ((form != 0 && form != 1) || grid < 0 || grid > aesmc::kLgMaxGrid) return AESMC_ERR_INVALID_ARGUMENT;

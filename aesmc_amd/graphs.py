@@ -111,11 +111,15 @@ class GraphedLoss:
 
     def __init__(self, observations, num_particles, algorithm, initial, transition, emission,
                  proposal, backward=False, warmup=2, check_flags=True, shard=None, group=None,
-                 verify_replays=4, guard_gradients=False):
+                 verify_replays=4, guard_gradients=False, preserve_random_state=False):
         """`shard=(global_batch_size, rank, world_size)`: `observations` are this rank's rows of a
         batch sharded over the process group; the graph then holds the LOCAL share
         -sum_local(log Z_b) / global_batch_size (and its backward) and every call finishes with
         the one all-reduce of the loss (gradients: `distributed.all_reduce_gradients`).
+        `preserve_random_state`: numpy's global RandomState and this device's torch generator are put back where they
+        were when the constructor was entered, so the warm-up, the capture and the verification consume nothing: the
+        first replay draws what the next eager evaluation would have drawn, and — a replay consuming both streams
+        exactly as an eager evaluation does — a seeded run that switches to replays follows the eager loop's trajectory.
         `verify_replays` (backward only): replays compared with eager evaluations right after the
         capture (0 switches the check off).  Each costs one replay plus one full eager forward + backward and,
         while it runs, the eager autograd graph's memory beside the capture's private pool (at B=1024, K=4096,
@@ -144,6 +148,7 @@ class GraphedLoss:
         if self.device.type != "cuda":
             raise RuntimeError("aesmc_amd: GraphedLoss captures a hipGraph and needs a HIP device, "
                                "got {}".format(self.device))
+        entry_state = (torch.cuda.get_rng_state(self.device), np.random.get_state()) if preserve_random_state else None
         self.static_observations = [obs.clone() for obs in observations]
         self.check_flags = check_flags
         self.backward = backward
@@ -162,6 +167,7 @@ class GraphedLoss:
 
         kernels = _kernels.get()
         kernels.flags(self.device)                       # allocate the status word before capture
+        _philox.verified(self.device)                    # (eagerly, with warmup=0 too: inside the capture nothing can be checked)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         self.noise = None
@@ -210,6 +216,16 @@ class GraphedLoss:
         self.replays = 0
         if backward and verify_replays > 0:
             self._verify(verify_replays)
+        if entry_state is not None:
+            torch.cuda.set_rng_state(entry_state[0], self.device)
+            np.random.set_state(entry_state[1])
+
+    def accepts(self, observations):
+        """Can `observations` be copied into the captured inputs (same count, shapes, dtypes, device)?"""
+        if len(observations) != len(self.static_observations):
+            return False
+        return all(torch.is_tensor(fresh) and fresh.shape == static.shape and fresh.dtype == static.dtype and
+                   fresh.device == static.device for static, fresh in zip(self.static_observations, observations))
 
     def _verify(self, replays):
         """Replays the fresh graph `replays` times; before each, the random streams are noted and the

@@ -43,10 +43,25 @@ def _minibatches(dataloader, num_epochs, limit):
             yield epoch, iteration, observations
 
 
+_AUTO_CAPTURE_AFTER = 8     # eager minibatches in front of the automatic capture: short runs never pay for one
+
+
+def _capturable(observations, algorithm):
+    """Host-side preconditions of a capture that can be told without trying: a sequence of HIP tensors of one device, an
+    algorithm `GraphedLoss` knows, and PyTorch's own noise source in place (a test harness that replays recorded draws
+    through `torch.distributions.normal._standard_normal` would have its first minibatch's draws baked into the graph)."""
+    from . import state
+    if algorithm not in ("iwae", "aesmc") or isinstance(observations, dict) or len(observations) == 0:
+        return False
+    if not all(torch.is_tensor(o) and o.is_cuda and o.device == observations[0].device for o in observations):
+        return False
+    return torch.distributions.normal._standard_normal is state._TORCH_STANDARD_NORMAL
+
+
 def train(dataloader, num_particles, algorithm, initial, transition, emission,
           proposal, num_epochs, num_iterations_per_epoch=None,
           optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
-          callback=None, hip_graph=False, verify_replays=4):
+          callback=None, hip_graph=None, verify_replays=4):
     """Fits the model parts by stochastic gradient descent on `losses.get_loss`.
 
     A single optimiser (`optimizer_algorithm(params, **optimizer_kwargs)`) owns the parameters of
@@ -55,49 +70,83 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
     `callback(epoch_idx, epoch_iteration_idx, loss, initial, transition, emission, proposal)`.
     Returns nothing, like the reference.
 
-    `hip_graph=True` (not in the reference; off by default) captures loss + backward of the first
-    minibatch into one hipGraph (`graphs.GraphedLoss`) and replays it for every later one — the
-    loop is then no longer bound by the host issuing each small kernel.  It needs what any capture
-    needs (fixed minibatch shapes, tensor observations, callables that never synchronise with the
-    host; see `aesmc_amd/graphs.py`) and its warm-up evaluations consume random numbers, so a
-    seeded run follows a different — equally distributed — trajectory than the eager loop.
-    The fresh graph is checked against eager evaluations before it is used (`verify_replays` of them, each a full
-    eager forward + backward with its memory peak; 0 switches the check off — see `graphs.GraphedLoss`).
-    The device status word (NaN log-weights, a degenerate row, ...) is then read every
-    `_FLAG_CHECK_INTERVAL` replays instead of every step; in between, the captured backward zeroes the
-    gradients of a flagged step on the device (`GraphedLoss(guard_gradients=True)`), so the optimiser
-    steps taken before the FloatingPointError / RuntimeError surfaces do not poison the parameters
-    (with a stateful optimiser they still decay its moments: restore a checkpoint if that matters)."""
+    `hip_graph` (not in the reference).  The reference's loop issues every small kernel of every timestep from Python; on
+    this device that loop is host-bound below about a million particles per timestep (configs[1]: 5x).  So by default
+    (None) the loop runs eagerly for `_AUTO_CAPTURE_AFTER` minibatches and then — when the minibatches are HIP tensors of
+    a fixed shape — captures loss + backward of the next one into one hipGraph (`graphs.GraphedLoss`) and replays it for
+    every later minibatch of that shape.  A capture needs callables that never synchronise with the host (see
+    `aesmc_amd/graphs.py`); one that cannot be made, or whose verification replays do not reproduce the eager evaluation,
+    is abandoned with ONE RuntimeWarning and the loop stays eager — as it does for the whole run with `hip_graph=False`
+    (opt-out).  `hip_graph=True` captures the first minibatch and lets a failure raise.
+    The capture leaves numpy's and torch's random streams where it found them and a replay consumes both exactly as an
+    eager evaluation does, so a seeded run follows the eager loop's trajectory (to the rounding of identical kernels
+    launched from a graph: the same bits in practice).  The fresh graph is checked against eager evaluations before it is
+    used (`verify_replays` of them; 0 switches the check off).  While replaying, the device status word (NaN
+    log-weights, a degenerate row, ...) is read every `_FLAG_CHECK_INTERVAL` replays instead of every step; in between, the
+    captured backward zeroes the gradients of a flagged step on the device (`GraphedLoss(guard_gradients=True)`), so the
+    optimiser steps taken before the FloatingPointError / RuntimeError surfaces do not poison the parameters (with a
+    stateful optimiser they still decay its moments: restore a checkpoint if that matters)."""
     model_parts = (initial, transition, emission, proposal)
     optimizer = optimizer_algorithm(get_chained_params(*model_parts), **optimizer_kwargs)
-    if hip_graph:
-        from . import graphs
-        graphed = None
-        for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
-            if graphed is None:
-                optimizer.zero_grad(set_to_none=True)   # the capture allocates the static .grad tensors
-                # check_flags=False: the device status word (NaN weights, ...) is read every
-                # _FLAG_CHECK_INTERVAL replays and once at the end instead of after each replay, so
-                # the host can prepare the next minibatch while the GPU still works on this one
-                graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
-                                             backward=True, check_flags=False, guard_gradients=True,
-                                             verify_replays=verify_replays)
+    graphed = None
+    may_capture = hip_graph is not False
+    capture_at = 0 if hip_graph is True else _AUTO_CAPTURE_AFTER
+    seen, shapes = 0, None
+    for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
+        if may_capture and graphed is None:
+            signature = None
+            if _capturable(observations, algorithm):
+                signature = tuple((tuple(o.shape), o.dtype, o.device) for o in observations)
+            if signature is None or (shapes is not None and signature != shapes):
+                if hip_graph is True:
+                    raise RuntimeError("aesmc_amd: train(hip_graph=True) needs minibatches that are sequences of HIP "
+                                       "tensors of one fixed shape")
+                may_capture = False          # (auto: minibatches a capture cannot hold — the loop stays eager)
+            shapes = signature
+            if may_capture and seen >= capture_at:
+                from . import graphs
+                import numpy as np
+                streams = (torch.cuda.get_rng_state(observations[0].device), np.random.get_state())
+                try:
+                    optimizer.zero_grad(set_to_none=True)   # the capture allocates the static .grad tensors
+                    # check_flags=False: the device status word (NaN weights, ...) is read every
+                    # _FLAG_CHECK_INTERVAL replays and once at the end instead of after each replay, so
+                    # the host can prepare the next minibatch while the GPU still works on this one
+                    graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
+                                                 backward=True, check_flags=False, guard_gradients=True,
+                                                 verify_replays=verify_replays, preserve_random_state=True)
+                except Exception as error:
+                    if hip_graph is True:
+                        raise
+                    import warnings
+                    warnings.warn("aesmc_amd.train: the loss could not be captured into a hipGraph ({}: {}); the loop "
+                                  "stays eager (train(..., hip_graph=False) skips the attempt)".format(
+                                      type(error).__name__, str(error)[:300]), RuntimeWarning)
+                    graphed, may_capture = None, False
+                    torch.cuda.synchronize()
+                    # (an abandoned capture's warm-up evaluations drew random numbers: put both streams back)
+                    torch.cuda.set_rng_state(streams[0], observations[0].device)
+                    np.random.set_state(streams[1])
+                    optimizer.zero_grad(set_to_none=True)
+        seen += 1
+        if graphed is not None and graphed.accepts(observations):
             loss = graphed(observations)     # refreshes every captured parameter's .grad in place
             optimizer.step()
             if graphed.replays % _FLAG_CHECK_INTERVAL == 0:
                 graphed.check()
             if callback is not None:         # the graph's loss tensor is reused by the next replay
                 callback(epoch, iteration, loss.clone(), *model_parts)
-        if graphed is not None:
-            graphed.check()
-        return
-    for epoch, iteration, observations in _minibatches(dataloader, num_epochs, num_iterations_per_epoch):
-        optimizer.zero_grad()
+            continue
+        # the reference's step (aesmc/train.py:33-37); beside a live graph the static .grad tensors are kept (zeroed in place)
+        optimizer.zero_grad(set_to_none=graphed is None)
         loss = losses.get_loss(observations, num_particles, algorithm, *model_parts)
         loss.backward()
         optimizer.step()
         if callback is not None:
             callback(epoch, iteration, loss, *model_parts)
+        del loss      # (no eager autograd graph may be alive when a capture starts)
+    if graphed is not None:
+        graphed.check()
 
 
 class SyntheticDataset(Dataset):

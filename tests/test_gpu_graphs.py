@@ -126,6 +126,55 @@ def test_train_with_hip_graph_learns(hip_device):
     assert all(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
 
 
+def test_train_captures_by_default_and_follows_the_eager_trajectory(hip_device):
+    """train() as a user of the reference calls it — no hip_graph argument: eager for the first minibatches, then the
+    captured loss + backward.  The capture consumes no random numbers and a replay consumes them as an eager step does,
+    so the seeded run's losses are the eager loop's (`hip_graph=False`), minibatch for minibatch; a model whose
+    callables cannot be captured (validate_args=True: a host sync) falls back to the eager loop with one warning."""
+    import warnings
+    import numpy as np
+    from aesmc_amd import train
+
+    def run(hip_graph, validate_args=False):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        model = models.LgssmNd(3, seed=0, validate_args=validate_args).to(hip_device)
+        truth = models.LgssmNd(3, seed=1, validate_args=False).to(hip_device)
+        loader = train.get_synthetic_dataloader(truth.initial, truth.transition, truth.emission, 6, 16)
+        history = []
+        train.train(loader, 128, "aesmc", model.initial, model.transition, model.emission, model.proposal,
+                    num_epochs=1, num_iterations_per_epoch=train._AUTO_CAPTURE_AFTER + 12,
+                    optimizer_algorithm=torch.optim.SGD, optimizer_kwargs={"lr": 1e-3}, hip_graph=hip_graph,
+                    callback=lambda e, i, loss, *parts: history.append(loss.item()))
+        return np.asarray(history), [p.detach().clone() for p in model.parameters()]
+    eager, eager_params = run(False)
+    calls = {"replays": 0}
+    from aesmc_amd import graphs
+    real = graphs.GraphedLoss.__call__
+
+    def counting(self, *args, **kwargs):
+        calls["replays"] += 1
+        return real(self, *args, **kwargs)
+    graphs.GraphedLoss.__call__ = counting
+    try:
+        auto, auto_params = run(None)
+    finally:
+        graphs.GraphedLoss.__call__ = real
+    assert calls["replays"] == 12, calls            # the minibatches behind the eager ones were replays
+    assert len(auto) == len(eager) == train._AUTO_CAPTURE_AFTER + 12
+    np.testing.assert_array_equal(auto[:train._AUTO_CAPTURE_AFTER], eager[:train._AUTO_CAPTURE_AFTER])
+    np.testing.assert_allclose(auto, eager, rtol=2e-5)
+    for a, b in zip(auto_params, eager_params):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+    # not capturable: one warning, the eager loop's numbers
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        fallback, _ = run(None, validate_args=True)
+    want, _ = run(False, validate_args=True)
+    assert sum("could not be captured" in str(w.message) for w in caught) == 1
+    np.testing.assert_allclose(fallback, want, rtol=2e-5)
+
+
 def test_graphs_captured_into_recycled_memory_give_eager_gradients(hip_device):
     """Regression: a graph captured after an earlier one was destroyed gets the earlier graph's
     memory back, dirty.  Every gradient of a replay must still equal the eager one bit for bit —

@@ -19,8 +19,13 @@ from tools.lgbench import SHAPES, graph_time, operands  # noqa: E402
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--shape", default="c4")
+    parser.add_argument("--dims", default=None, help="B,K,d: another shape (rows of d values on both sides)")
+    parser.add_argument("--only", default=None, help="run only the case whose label contains this")
     args = parser.parse_args()
     B, K, dx, dy = SHAPES[args.shape]
+    if args.dims:
+        B, K, dx = [int(v) for v in args.dims.split(",")]
+        dy = dx
     k = _kernels.get()
     device = torch.device("cuda:0")
     sets = [operands(B, K, dx, dy, torch.float32, device, seed=s) for s in range(4)]
@@ -62,13 +67,17 @@ def main():
     ]
     print("B={} K={} d={}  child staging {}".format(B, K, dx, os.environ.get("AESMC_LG_CHILD_STAGE", "1")))
     for label, kwargs, words in cases:
+        if args.only and args.only not in label:
+            continue
         us = graph_time(launch(**kwargs))
+        label = "{} [form {}]".format(label, k._lib.aesmc_test_last_step_backward_form())
         nbytes = esz * N * words
-        print("{:48s} {:8.1f} us  {:7.1f} MB  {:5.2f} TB/s".format(label, us, nbytes / 1e6, nbytes / us / 1e6), flush=True)
+        print("{:58s} {:8.1f} us  {:7.1f} MB  {:5.2f} TB/s".format(label, us, nbytes / 1e6, nbytes / us / 1e6), flush=True)
     # the launch the folding replaces
     gs = [torch.randn(B, K, dx, device=device) for _ in range(2)]
-    us = graph_time(lambda: k.gather_backward(gs[0], sets[0]["idx_healthy"], sorted_index=True))
-    print("{:48s} {:8.1f} us".format("segmented sum (gather's backward), healthy", us))
+    us = 0.0 if args.only else graph_time(lambda: k.gather_backward(gs[0], sets[0]["idx_healthy"], sorted_index=True))
+    if not args.only:
+        print("{:48s} {:8.1f} us".format("segmented sum (gather's backward), healthy", us))
 
 
 if __name__ == "__main__":
