@@ -55,4 +55,4 @@ from . import state  # noqa: F401
 from . import statistics  # noqa: F401
 from . import train  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

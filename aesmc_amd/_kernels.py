@@ -176,6 +176,9 @@ class HipKernels:
         self._map_cache = {}        # id(weight) -> (weight, its aesmc_affine_map, (shape, strides))
         self._covers_last = None    # the operands of the last step `affine_logweight_covers` accepted
         self._wide_dim = None       # aesmc_affine_wide_dim(): the extent K17 / K18 are built for
+        self._pairs = None          # (key, tensor): the interleaved weight pairs of the maps the fused launch met last
+        self.evaluation = 0         # bumped by `begin_evaluation`: what a cached weight-pair block belongs to
+        self.WEIGHT_PAIRS = __import__("os").environ.get("AESMC_K16_PAIRS", "1") != "0"      # measurement knob
 
     # ---- deferred status word ---------------------------------------------------------------
     def flags(self, device):
@@ -1081,6 +1084,25 @@ class HipKernels:
                                 nbytes, (x_src, ancestors, eps, y_rows, out, out_x, ws, maps, scales))
         return out
 
+    def begin_evaluation(self):
+        """Called once per `infer`: weight pairs built for an earlier evaluation are not reused (the weights may have been
+        stepped in between; inside a hipGraph capture the rebuild must be part of the captured work)."""
+        self.evaluation += 1
+
+    def _weight_pairs(self, maps, weights, device):
+        """The three maps' weights as interleaved pairs (aesmc_affine_weight_pairs) for the fused propagation launch: built
+        by one small launch the first time an evaluation meets these weights, then reused by its other timesteps."""
+        key = (self.evaluation,) + tuple((w.data_ptr(), w._version, tuple(w.shape), w.stride()) for w in weights)
+        held = self._pairs
+        if held is not None and held[0] == key:
+            return held[1]
+        pairs = torch.empty(int(self._lib.aesmc_affine_weight_pairs_floats()), dtype=torch.float32, device=device)
+        _lib.check(self._lib.aesmc_affine_weight_pairs(ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]),
+                                                       ctypes.byref(maps[2][0]), _ptr(pairs), self._stream(pairs)),
+                   "aesmc_affine_weight_pairs")
+        self._pairs = (key, pairs)
+        return pairs
+
     def affine_propagate_drawn(self, x_src, noise, y_rows, transition, emission, proposal, scales, out_x,
                                ancestors=None):
         """K16: K15 with the resampling gather (`ancestors`, or None) AND the noise inside the launch — `noise`
@@ -1108,18 +1130,22 @@ class HipKernels:
         out = torch.empty((B, K), dtype=x_src.dtype, device=x_src.device)
         maps = [self._affine_map(*term, slot=slot) for slot, term in enumerate((transition, emission, proposal))]
         with _on_device(x_src.device):
+            pairs = None
+            if self.WEIGHT_PAIRS and 2 <= dx <= 16:
+                pairs = self._weight_pairs(maps, (transition[0], emission[0], proposal[0]), x_src.device)
             args = (_ptr(x_src), _ptr(ancestors), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
                     ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
                     _ptr(scales[2]), _ptr(out_x), _ptr(out), _ptr(self.flags(x_src.device)), B, K, noise.seed,
-                    noise.offset, noise.threads, _ptr(noise.state), self._stream(x_src))
-            status = self._lib.aesmc_affine_normal_propagate_drawn(*args)
+                    noise.offset, noise.threads, _ptr(noise.state), _ptr(pairs), self._stream(x_src))
+            status = self._lib.aesmc_affine_normal_propagate_drawn_paired(*args)
             if status == 2:
                 return None
             _lib.check(status, "aesmc_affine_normal_propagate_drawn")
             if self.timer is not None:
                 nbytes = 4 * (B * K * (2 * dx + 1) + y_rows.numel()) + (8 * B * K if ancestors is not None else 0)
-                self.timer.note("affine_normal_propagate_drawn", (self._lib.aesmc_affine_normal_propagate_drawn, args),
-                                nbytes, (x_src, ancestors, None, y_rows, out, out_x, maps, scales))
+                self.timer.note("affine_normal_propagate_drawn",
+                                (self._lib.aesmc_affine_normal_propagate_drawn_paired, args), nbytes,
+                                (x_src, ancestors, None, y_rows, out, out_x, maps, scales, pairs))
         return out
 
     def affine_logweight_covers(self, x_prev, x, y_rows, transition, emission, proposal, scales):

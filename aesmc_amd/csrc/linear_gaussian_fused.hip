@@ -722,7 +722,7 @@ int launch_affine_propagate_item(const void *xsrc, const int64_t *anc_idx, const
                                  const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                  const void *sp, const void *sg, const void *sq, void *out_x, void *out_lw, int32_t *flags,
                                  int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads,
-                                 const uint64_t *rng_state, hipStream_t stream);
+                                 const uint64_t *rng_state, const float *weight_pairs, hipStream_t stream);
 
 int g_fused_form = [] {
   const char *v = getenv("AESMC_K16_FORM");      // ("roles": the first form whatever the shape — linear_gaussian_noise.hip)
@@ -740,7 +740,7 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
                                   const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                   const void *sp, const void *sg, const void *sq, void *out_x, void *out_lw,
                                   int32_t *flags, int64_t B, int64_t K, uint64_t seed, uint64_t offset,
-                                  int64_t threads, const uint64_t *rng_state, hipStream_t stream) {
+                                  int64_t threads, const uint64_t *rng_state, const float *weight_pairs, hipStream_t stream) {
   const int64_t dx = mp->dout, dy = mg->dout;
   g_fused_last_form = 1;      // (or, where this file declines, the first form: the caller's)
   if (dx < 2 || dx > 16 || dy < 1 || dy > 16) return AESMC_ERR_UNSUPPORTED;
@@ -750,7 +750,7 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
   // One item per workgroup (linear_gaussian_item.hip); the same bits either way.
   if (g_fused_form == 2 || (g_fused_form == 0 && plan.items < kItemFormMaxItems)) {
     const int status = launch_affine_propagate_item(xsrc, anc_idx, y, y_sb, mp, mg, mq, sp, sg, sq, out_x, out_lw, flags, B,
-                                                    K, seed, offset, threads, rng_state, stream);
+                                                    K, seed, offset, threads, rng_state, weight_pairs, stream);
     if (status != AESMC_ERR_UNSUPPORTED) {
       g_fused_last_form = 2;
       return status;

@@ -141,6 +141,74 @@ __device__ __forceinline__ void fused_chain(unsigned long long base, const float
   }
 }
 
+// ---- two chains per instruction: v_pk_fma_f32 with the weights of outputs j, j + 1 side by side in a scalar pair -------------
+// acc = (chain of output j, chain of output j + 1); one instruction advances both by input i: (w[j][i], w[j+1][i]) * x_i.
+// The weights come from an interleaved copy of the map — pairs[jp][i] = (W[2 jp][i], W[2 jp + 1][i]), zero where the
+// second row does not exist (aesmc_affine_weight_pairs) — so a pair is two consecutive scalar registers; x_i is the low or
+// the high half of a vector register pair, picked by the instruction's op_sel bits.  Each half is the IEEE fused
+// multiply-add v_fmac_f32 computes, in the same order (inputs ascending, started from the offset): the same bits.
+// N inputs (1 .. 4) of one output pair per statement; `w` = the pair's scalar registers from input I0 on, `x` = the inputs
+// as register pairs (x[i / 2], half i & 1).
+template <int N>
+__device__ __forceinline__ void fused_pk_group(lg_f2 &acc, const float *w, const lg_f2 *x) {
+  static_assert(N >= 1 && N <= 4, "one to four inputs per statement");
+#define FUSED_W(i) "s"(lg_f2{w[2 * (i)], w[2 * (i) + 1]})
+  if constexpr (N == 4) {
+    asm("v_pk_fma_f32 %0, %1, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc) : FUSED_W(0), FUSED_W(1), FUSED_W(2), FUSED_W(3), "v"(x[0]), "v"(x[1]));
+  } else if constexpr (N == 3) {
+    asm("v_pk_fma_f32 %0, %1, %4, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %0, %3, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+        : "+v"(acc) : FUSED_W(0), FUSED_W(1), FUSED_W(2), "v"(x[0]), "v"(x[1]));
+  } else if constexpr (N == 2) {
+    asm("v_pk_fma_f32 %0, %1, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc) : FUSED_W(0), FUSED_W(1), "v"(x[0]));
+  } else {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : FUSED_W(0), "v"(x[0]));
+  }
+#undef FUSED_W
+}
+template <int DIN, int I0 = 0>
+__device__ __forceinline__ void fused_pk_pair(lg_f2 &acc, const float *w, const lg_f2 *x) {
+  if constexpr (I0 < DIN) {
+    constexpr int N = DIN - I0 >= 4 ? 4 : DIN - I0;      // (I0 stays even: groups of four start on a register pair)
+    fused_pk_group<N>(acc, w + 2 * I0, x + I0 / 2);
+    fused_pk_pair<DIN, I0 + N>(acc, w, x);
+  }
+}
+// fused_chain with both chains of an output pair in one instruction stream: acc[jp] = (output 2 jp, output 2 jp + 1).
+// `base`: the map's interleaved copy; the NEXT pair's weights are sent for before this pair's multiply-adds.
+template <int DIN, int DP>
+__device__ __forceinline__ void fused_chain_pk(unsigned long long base, const float *offsets, uint32_t dout, const lg_f2 *in,
+                                               lg_f2 (&acc)[DP / 2]) {
+  fused_cfloat *W = (fused_cfloat *)base;
+#pragma unroll
+  for (int v = 0; v < DP / 4; ++v) {
+    const fz4 o4 = *reinterpret_cast<const fz4 *>(offsets + 4 * v);
+    acc[2 * v] = lg_f2{o4[0], o4[1]};
+    acc[2 * v + 1] = lg_f2{o4[2], o4[3]};
+  }
+  float wa[2 * DIN], wb[2 * DIN];
+#pragma unroll
+  for (int e = 0; e < 2 * DIN; ++e) wa[e] = W[e];
+#pragma unroll
+  for (int jp = 0; jp < DP / 2; ++jp) {
+    if ((uint32_t)(2 * jp) >= dout) break;
+    float (&cur_w)[2 * DIN] = (jp & 1) ? wb : wa;
+    float (&next_w)[2 * DIN] = (jp & 1) ? wa : wb;
+    if ((uint32_t)(2 * jp + 2) < dout) {
+#pragma unroll
+      for (int e = 0; e < 2 * DIN; ++e) next_w[e] = W[(jp + 1) * 2 * DIN + e];
+    }
+    fused_pk_pair<DIN>(acc[jp], cur_w, in);
+  }
+}
+
 // window `i` of work item `item`: first particle, particle count, elements in front of the first particle
 __device__ __forceinline__ FusedWin fused_window(const FusedPlan &plan, uint32_t item, uint32_t i, uint32_t dx, uint32_t K) {
   FusedWin v;

@@ -22,8 +22,10 @@
 
 namespace aesmc {
 
-// DXC: the latent's extent (compile time).  DYC: the observation's, or 0 = run time (<= 16).
-template <int DXC, int DYC, bool GATHER>
+// DXC: the latent's extent (compile time).  DYC: the observation's, or 0 = run time (<= 16).  PAIRED: the maps' `w` point
+// at their interleaved copies (aesmc_affine_weight_pairs) and the chains of two outputs advance together, one
+// v_pk_fma_f32 per input (linear_gaussian_fused.hpp: the same bits as the v_fmac_f32 chains).
+template <int DXC, int DYC, bool GATHER, bool PAIRED>
 __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
     const float *__restrict__ xsrc, const float *__restrict__ y, int64_t y_sb, LgMap mp, LgMap mg, LgMap mq,
     const float *__restrict__ sp_ptr, const float *__restrict__ sg_ptr, const float *__restrict__ sq_ptr,
@@ -191,8 +193,21 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
   const unsigned long long wq_a = (unsigned long long)mq.w, wp_a = (unsigned long long)mp.w, wg_a = (unsigned long long)mg.w;
 
   float locq[DPX], locp[DPX];
-  fused_chain<DXC, DPX>(wq_a, trow + 16, dx, xin, locq);
-  fused_chain<DXC, DPX>(wp_a, trow, dx, xin, locp);
+  if constexpr (PAIRED) {
+    lg_f2 xin2[(DXC + 1) / 2], q2[DPX / 2], p2[DPX / 2];
+#pragma unroll
+    for (int i = 0; i < (DXC + 1) / 2; ++i) xin2[i] = lg_f2{xin[2 * i], 2 * i + 1 < DXC ? xin[(2 * i + 1) % DXC] : 0.0f};
+    fused_chain_pk<DXC, DPX>(wq_a, trow + 16, dx, xin2, q2);
+    fused_chain_pk<DXC, DPX>(wp_a, trow, dx, xin2, p2);
+#pragma unroll
+    for (int j = 0; j < DPX; ++j) {
+      locq[j] = q2[j / 2][j % 2];
+      locp[j] = p2[j / 2][j % 2];
+    }
+  } else {
+    fused_chain<DXC, DPX>(wq_a, trow + 16, dx, xin, locq);
+    fused_chain<DXC, DPX>(wp_a, trow, dx, xin, locp);
+  }
   // the lane's noise (its row of the chunk: lanes past the window's end read the last row's, or — a chunk past the
   // window's end — the other chunk's region, which its owner may already be overwriting: values nobody keeps)
   float nz[DXC];
@@ -225,7 +240,16 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
     qq = fma_t(eq, eq, qq);
   }
   float locg[DPY];
-  fused_chain<DXC, DPY>(wg_a, trow + 32, dy, xx, locg);
+  if constexpr (PAIRED) {
+    lg_f2 xx2[(DXC + 1) / 2], g2[DPY / 2];
+#pragma unroll
+    for (int i = 0; i < (DXC + 1) / 2; ++i) xx2[i] = lg_f2{xx[2 * i], 2 * i + 1 < DXC ? xx[(2 * i + 1) % DXC] : 0.0f};
+    fused_chain_pk<DXC, DPY>(wg_a, trow + 32, dy, xx2, g2);
+#pragma unroll
+    for (int j = 0; j < DPY; ++j) locg[j] = g2[j / 2][j % 2];
+  } else {
+    fused_chain<DXC, DPY>(wg_a, trow + 32, dy, xx, locg);
+  }
 #pragma unroll
   for (int v = 0; v < DPY / 4; ++v) {
     const fz4 y4 = *reinterpret_cast<const fz4 *>(trow + 48 + 4 * v);
@@ -275,7 +299,7 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
 #endif
 }
 
-template <int DXC, int DYC>
+template <int DXC, int DYC, bool PAIRED>
 static int item_launch(dim3 grid, size_t lds, hipStream_t stream, const float *xsrc, const float *y, int64_t y_sb,
                        const LgMap &mp, const LgMap &mg, const LgMap &mq, const float *sp, const float *sg, const float *sq,
                        float *out_lw, uint32_t K, uint32_t Bn, float *out_x, const int64_t *anc, int32_t *flags,
@@ -283,33 +307,48 @@ static int item_launch(dim3 grid, size_t lds, hipStream_t stream, const float *x
   static bool raised[2][64] = {};
   if (anc != nullptr) {
     if (lds > 64 * 1024 &&
-        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_item_kernel<DXC, DYC, true>), raised[0]))
+        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_item_kernel<DXC, DYC, true, PAIRED>), raised[0]))
       return AESMC_ERR_LAUNCH;
-    hipLaunchKernelGGL((affine_propagate_item_kernel<DXC, DYC, true>), grid, dim3(512), lds, stream, xsrc, y, y_sb, mp, mg, mq,
-                       sp, sg, sq, out_lw, K, Bn, out_x, anc, flags, ps, plan);
+    hipLaunchKernelGGL((affine_propagate_item_kernel<DXC, DYC, true, PAIRED>), grid, dim3(512), lds, stream, xsrc, y, y_sb, mp,
+                       mg, mq, sp, sg, sq, out_lw, K, Bn, out_x, anc, flags, ps, plan);
   } else {
     if (lds > 64 * 1024 &&
-        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_item_kernel<DXC, DYC, false>), raised[1]))
+        !lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_propagate_item_kernel<DXC, DYC, false, PAIRED>), raised[1]))
       return AESMC_ERR_LAUNCH;
-    hipLaunchKernelGGL((affine_propagate_item_kernel<DXC, DYC, false>), grid, dim3(512), lds, stream, xsrc, y, y_sb, mp, mg,
-                       mq, sp, sg, sq, out_lw, K, Bn, out_x, anc, flags, ps, plan);
+    hipLaunchKernelGGL((affine_propagate_item_kernel<DXC, DYC, false, PAIRED>), grid, dim3(512), lds, stream, xsrc, y, y_sb, mp,
+                       mg, mq, sp, sg, sq, out_lw, K, Bn, out_x, anc, flags, ps, plan);
   }
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
-// AESMC_ERR_UNSUPPORTED: the caller takes another form.  Covers latent extents 2 .. 16 with observation extents 1 .. 16
-// and weights whose rows are contiguous ([dout, din] row-major, what an nn.Linear holds).
+// The maps' interleaved copies: pairs[jp][i] = (W[2 jp][i], W[2 jp + 1][i]) (zero where the second row does not exist), one
+// region of kPairFloats floats per map in the order transition, emission, proposal.  Any strides: a transposed view too.
+constexpr int kPairFloats = (kLgMaxDim / 2) * kLgMaxDim * 2;
+__global__ __launch_bounds__(256) void affine_weight_pairs_kernel(LgMap mp, LgMap mg, LgMap mq, float *__restrict__ out) {
+  const LgMap &m = blockIdx.x == 0 ? mp : (blockIdx.x == 1 ? mg : mq);
+  const float *w = reinterpret_cast<const float *>(m.w);
+  float *dst = out + blockIdx.x * kPairFloats;
+  const int din = m.din, dout = m.dout;
+  for (int e = threadIdx.x; e < kPairFloats; e += 256) {
+    const int jp = e / (2 * din), rem = e - jp * 2 * din, i = rem >> 1, j = 2 * jp + (rem & 1);
+    dst[e] = (j < dout && i < din) ? w[(int64_t)j * m.sj + (int64_t)i * m.si] : 0.0f;
+  }
+}
+
+// AESMC_ERR_UNSUPPORTED: the caller takes another form.  Covers latent extents 2 .. 16 with observation extents 1 .. 16;
+// without `weight_pairs` the weights' rows must be contiguous ([dout, din] row-major, what an nn.Linear holds).
 int launch_affine_propagate_item(const void *xsrc, const int64_t *anc_idx, const void *y, int64_t y_sb,
                                  const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                  const void *sp, const void *sg, const void *sq, void *out_x, void *out_lw, int32_t *flags,
                                  int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads,
-                                 const uint64_t *rng_state, hipStream_t stream) {
+                                 const uint64_t *rng_state, const float *weight_pairs, hipStream_t stream) {
   const int64_t dx = mp->dout, dy = mg->dout;
   if (dx < 2 || dx > 16 || dy < 1 || dy > 16) return AESMC_ERR_UNSUPPORTED;
   const auto rows_contiguous = [](const aesmc_affine_map *m) {
     return m->stride_in == 1 && m->stride_out == m->din && (reinterpret_cast<uintptr_t>(m->weight) & 3u) == 0;
   };
-  if (!(rows_contiguous(mp) && rows_contiguous(mg) && rows_contiguous(mq))) return AESMC_ERR_UNSUPPORTED;
+  const bool paired = weight_pairs != nullptr;
+  if (!paired && !(rows_contiguous(mp) && rows_contiguous(mg) && rows_contiguous(mq))) return AESMC_ERR_UNSUPPORTED;
   FusedPlan plan;
   const int planned = fused_make_plan(plan, B, K, dx, threads);
   if (planned != AESMC_OK) return planned;
@@ -317,13 +356,20 @@ int launch_affine_propagate_item(const void *xsrc, const int64_t *anc_idx, const
   if (lds > kLgLdsLimit) return AESMC_ERR_UNSUPPORTED;
   const PhiloxStream ps = philox_stream(seed, offset, threads, rng_state);
   const dim3 grid(plan.items);
-  const LgMap p = lg_map(mp), gm = lg_map(mg), q = lg_map(mq);
+  LgMap p = lg_map(mp), gm = lg_map(mg), q = lg_map(mq);
+  if (paired) {
+    p.w = weight_pairs;
+    gm.w = weight_pairs + kPairFloats;
+    q.w = weight_pairs + 2 * kPairFloats;
+  }
 #define ITEM_ARGS                                                                                                    \
   grid, lds, stream, static_cast<const float *>(xsrc), static_cast<const float *>(y), y_sb, p, gm, q,                  \
       static_cast<const float *>(sp), static_cast<const float *>(sg), static_cast<const float *>(sq),                  \
       static_cast<float *>(out_lw), (uint32_t)K, (uint32_t)B, static_cast<float *>(out_x), anc_idx, flags, ps, plan
 #define ITEM_CASE(D)                                                                                                 \
-  case D: return dy == D ? item_launch<D, D>(ITEM_ARGS) : item_launch<D, 0>(ITEM_ARGS);
+  case D:                                                                                                            \
+    if (paired) return dy == D ? item_launch<D, D, true>(ITEM_ARGS) : item_launch<D, 0, true>(ITEM_ARGS);              \
+    return dy == D ? item_launch<D, D, false>(ITEM_ARGS) : item_launch<D, 0, false>(ITEM_ARGS);
   switch (dx) {
 #ifdef AESMC_LG_FAST_BUILD
     ITEM_CASE(10)
@@ -338,3 +384,16 @@ int launch_affine_propagate_item(const void *xsrc, const int64_t *anc_idx, const
 }
 
 }  // namespace aesmc
+
+using namespace aesmc;
+
+extern "C" int64_t aesmc_affine_weight_pairs_floats(void) { return 3 * (int64_t)kPairFloats; }
+
+extern "C" int aesmc_affine_weight_pairs(const aesmc_affine_map *transition, const aesmc_affine_map *emission,
+                                         const aesmc_affine_map *proposal, void *out_pairs, void *stream) {
+  if (out_pairs == nullptr || (reinterpret_cast<uintptr_t>(out_pairs) & 15u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(affine_weight_pairs_kernel, dim3(3), dim3(256), 0, static_cast<hipStream_t>(stream), lg_map(transition),
+                     lg_map(emission), lg_map(proposal), static_cast<float *>(out_pairs));
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+}

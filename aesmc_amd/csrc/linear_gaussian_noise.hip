@@ -563,7 +563,7 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
                                   const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                   const void *sp, const void *sg, const void *sq, void *out_x, void *out_lw,
                                   int32_t *flags, int64_t B, int64_t K, uint64_t seed, uint64_t offset,
-                                  int64_t threads, const uint64_t *rng_state, hipStream_t stream);
+                                  int64_t threads, const uint64_t *rng_state, const float *weight_pairs, hipStream_t stream);
 
 }  // namespace aesmc
 
@@ -574,6 +574,17 @@ extern "C" int aesmc_affine_normal_propagate_drawn(
     const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
     const void *scale_q, void *out_x, void *out_lw, int32_t *flags, int64_t B, int64_t K, uint64_t seed,
     uint64_t offset, int64_t threads, const uint64_t *rng_state, void *stream) {
+  return aesmc_affine_normal_propagate_drawn_paired(x_src, ancestors, y, y_stride_b, transition, emission, proposal, scale_p,
+                                                    scale_g, scale_q, out_x, out_lw, flags, B, K, seed, offset, threads,
+                                                    rng_state, nullptr, stream);
+}
+
+extern "C" int aesmc_affine_normal_propagate_drawn_paired(
+    const void *x_src, const int64_t *ancestors, const void *y, int64_t y_stride_b, const aesmc_affine_map *transition,
+    const aesmc_affine_map *emission, const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+    const void *scale_q, void *out_x, void *out_lw, int32_t *flags, int64_t B, int64_t K, uint64_t seed,
+    uint64_t offset, int64_t threads, const uint64_t *rng_state, const void *weight_pairs, void *stream) {
+  if ((reinterpret_cast<uintptr_t>(weight_pairs) & 15u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
   if (x_src == nullptr || y == nullptr || transition == nullptr || emission == nullptr || proposal == nullptr ||
       scale_p == nullptr || scale_g == nullptr || scale_q == nullptr || out_lw == nullptr || out_x == nullptr || B < 0 ||
       K < 0 || threads <= 0 || (threads % 256) != 0 || threads > 0x7fffffffLL || (offset & 3u) != 0)
@@ -591,7 +602,8 @@ extern "C" int aesmc_affine_normal_propagate_drawn(
   if (!first_form) {
     const int status = launch_affine_propagate_fused(x_src, ancestors, y, y_stride_b, transition, emission, proposal,
                                                      scale_p, scale_g, scale_q, out_x, out_lw, flags, B, K, seed, offset,
-                                                     threads, rng_state, static_cast<hipStream_t>(stream));
+                                                     threads, rng_state, static_cast<const float *>(weight_pairs),
+                                                     static_cast<hipStream_t>(stream));
     if (status != AESMC_ERR_UNSUPPORTED) return status;
   }
   return launch_affine_propagate_noise(x_src, ancestors, y, y_stride_b, transition, emission, proposal, scale_p,

@@ -151,7 +151,8 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
     stay identical.  Seed numpy identically on all ranks (the resampler draws the global uniform
     block and keeps its rows) and torch differently per rank (independent proposal noise).
     `callback` sees the global loss.  `hip_graph=True` replays each rank's share of loss + backward
-    as one captured hipGraph (`graphs.GraphedLoss(shard=...)`); the two collectives stay outside it."""
+    as one captured hipGraph (`graphs.GraphedLoss(shard=...)`, its capture consuming no random numbers: the eager loop's
+    trajectory); the two collectives stay outside it."""
     from . import train as _train
     rank = dist.get_rank(group) if _group_is_live() else 0
     world_size = dist.get_world_size(group) if _group_is_live() else 1
@@ -168,7 +169,8 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
                 shard = (observations[0].size(0) * world_size, rank, world_size)
                 graphed = graphs.GraphedLoss(observations, num_particles, algorithm, *model_parts,
                                              backward=True, shard=shard, group=group, check_flags=False,
-                                             guard_gradients=True, verify_replays=verify_replays)
+                                             guard_gradients=True, verify_replays=verify_replays,
+                                             preserve_random_state=True)
             loss = graphed(observations)            # local replay + the all-reduce of the loss
             all_reduce_gradients(parameters, group=group)
             optimizer.step()

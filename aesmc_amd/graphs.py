@@ -334,7 +334,7 @@ class GraphedLoss:
                 loss.backward()
                 if self.guard_gradients:
                     # on the device, no host sync: a step flagged by the kernels contributes nothing
-                    healthy = _kernels.get().flags(self.device) == 0
+                    healthy = (_kernels.get().flags(self.device) == 0).reshape(())      # (0-dim: broadcasts into scalar parameters too)
                     for p in self.parameters:
                         if p.grad is not None:
                             p.grad.copy_(torch.where(healthy, p.grad, torch.zeros_like(p.grad)))

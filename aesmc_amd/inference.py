@@ -311,6 +311,9 @@ def infer(inference_algorithm, observations, initial, transition, emission,
     clean.
     """
     try:
+        begin = getattr(_kernels.get(), "begin_evaluation", None)
+        if begin is not None:
+            begin()
         with state.deferring_draws():
             return _infer(inference_algorithm, observations, initial, transition, emission, proposal,
                           num_particles, return_log_marginal_likelihood, return_latents,

@@ -49,7 +49,9 @@ extern "C" {
  *                aesmc_set_step_parts / aesmc_set_sorted_backward_kernel became test hooks outside this header
  *                (aesmc_test_*); aesmc_affine_normal_propagate_drawn keeps its signature and now runs the fused launch
  *                (gather + noise + draw + log-weight terms in one kernel); added aesmc_affine_normal_propagate_wide
- *                (+ aesmc_affine_wide_dim, aesmc_affine_wide_workspace_bytes). */
+ *                (+ aesmc_affine_wide_dim, aesmc_affine_wide_workspace_bytes).
+ *   300 (0.3.0)  added aesmc_affine_normal_propagate_drawn_paired, aesmc_affine_weight_pairs,
+ *                aesmc_affine_weight_pairs_floats (round 5: packed multiply-adds in the fused propagation launch). */
 int aesmc_version(void);
 const char *aesmc_target_arch(void); /* "gfx950" */
 
@@ -396,6 +398,26 @@ int aesmc_affine_normal_propagate_drawn(
     const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
     const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, int32_t *flags,
     int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *rng_state, void *stream);
+
+/* The same launch with the three maps' weights also at hand as interleaved pairs — `weight_pairs`:
+ * aesmc_affine_weight_pairs_floats() float32 values written by aesmc_affine_weight_pairs for the SAME three maps
+ * (their values at the time this launch runs: rebuild after the weights change — once per ELBO evaluation, and inside
+ * every hipGraph capture) — so that the location chains of two outputs advance together, one v_pk_fma_f32 per input
+ * (each half the fused multiply-add of the scalar chain, same order: the same bits, half the multiply-add
+ * instructions), and so that weights of any strides (a transposed view) take this form.  NULL: as
+ * aesmc_affine_normal_propagate_drawn.  Reference: aesmc/inference.py:102-126 as above. */
+int aesmc_affine_normal_propagate_drawn_paired(
+    const void *x_src, const int64_t *ancestors, const void *y, int64_t y_stride_b,
+    const aesmc_affine_map *transition, const aesmc_affine_map *emission, const aesmc_affine_map *proposal,
+    const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, int32_t *flags,
+    int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *rng_state,
+    const void *weight_pairs, void *stream);
+/* pairs[map][jp][i] = (W[2 jp][i], W[2 jp + 1][i]), zero where a row or column does not exist, for the transition,
+ * emission and proposal maps (float32, extents <= 16, any strides), into `out_pairs` (16-byte aligned device memory of
+ * aesmc_affine_weight_pairs_floats() floats).  One small launch. */
+int64_t aesmc_affine_weight_pairs_floats(void);
+int aesmc_affine_weight_pairs(const aesmc_affine_map *transition, const aesmc_affine_map *emission,
+                              const aesmc_affine_map *proposal, void *out_pairs, void *stream);
 
 /* K17 + K18 — one SMC step of a linear-Gaussian model whose latent and observation rows hold 128 float32 values
  * (BASELINE.json configs[4]), the three 128 x 128 maps on the fp32 matrix cores:

@@ -126,7 +126,7 @@ def test_the_item_form_equals_the_c_oracle(kernels, hip_device, forms, shape):
                                atol=5e-7 * max(1.0, float(np.abs(want_lw).max())))
 
 
-def test_the_item_form_flags_bad_ancestors_and_declines_what_it_does_not_cover(kernels, hip_device, forms):
+def test_the_item_form_flags_bad_ancestors_and_declines_what_it_does_not_cover(kernels, hip_device, forms, monkeypatch):
     B, K, dx, dy = 3, 1000, 10, 10
     _, o = operands(4, 32, dx, dy, np.float32, hip_device, seed=1)
     gen = torch.Generator(device=hip_device).manual_seed(3)
@@ -142,12 +142,52 @@ def test_the_item_form_flags_bad_ancestors_and_declines_what_it_does_not_cover(k
     assert torch.isfinite(out_x).all() and torch.isfinite(lw).all()
     from aesmc_amd import _lib
     assert kernels.read_flags(hip_device) & _lib.FLAG_INDEX_OUT_OF_RANGE
-    # strided weights (a transposed view) are another form's: same call, same answer, other kernel
-    for dx2, dy2, transpose in ((10, 10, True), (6, 3, True)):
+    # strided weights (a transposed view): the item form takes them through the interleaved weight pairs (built from any
+    # strides); without the pairs they are another form's — same call, same bits, other kernel
+    for dx2, dy2 in ((10, 10), (6, 3)):
         _, o2 = operands(4, 32, dx2, dy2, np.float32, hip_device, seed=4)
-        if transpose:
-            o2 = dict(o2, A=o2["A"].t().contiguous().t())
+        o2 = dict(o2, A=o2["A"].t().contiguous().t())
         x2 = torch.randn(2, 300, dx2, device=hip_device, generator=gen)
         y2 = torch.randn(2, dy2, device=hip_device, generator=gen)
-        _, lw2, ran = _run(kernels, o2, x2, y2, None, None, None, seed=11)
-        assert ran != ITEM and torch.isfinite(lw2).all()
+        monkeypatch.setattr(kernels, "WEIGHT_PAIRS", False)
+        want_x, want_lw, ran = _run(kernels, o2, x2, y2, None, None, None, seed=11)
+        assert ran != ITEM and torch.isfinite(want_lw).all()
+        monkeypatch.setattr(kernels, "WEIGHT_PAIRS", True)
+        got_x, got_lw, ran = _run(kernels, o2, x2, y2, None, None, None, seed=11)
+        assert ran == ITEM
+        assert torch.equal(got_x, want_x) and got_lw.cpu().numpy().tobytes() == want_lw.cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("shape", [(128, 4096, 10, 10), (37, 29000, 6, 9), (5, 777, 3, 11), (9, 513, 4, 1), (3, 1000, 15, 16),
+                                   (6, 1024, 16, 16), (2, 700, 13, 2), (1, 128, 2, 2), (64, 1024, 8, 4)])
+def test_packed_multiply_adds_give_the_scalar_chains_bits(kernels, hip_device, forms, shape, monkeypatch):
+    """The item form with its weights as interleaved pairs (one v_pk_fma_f32 advances the chains of two outputs) against
+    the same form with one v_fmac_f32 per output and input: x_t and the log-weights bit for bit — odd and even extents,
+    run-time and compile-time observation extents, an odd number of outputs (a pair's second row absent) — and the pairs
+    follow the weights: changed in place, the next evaluation's launch sees the new values."""
+    B, K, dx, dy = shape
+    _, o = operands(4, 32, dx, dy, np.float32, hip_device, seed=B + K)
+    gen = torch.Generator(device=hip_device).manual_seed(K + dx)
+    x_prev = torch.randn(B, K, dx, device=hip_device, generator=gen)
+    y = torch.randn(B, dy, device=hip_device, generator=gen)
+    off_q = torch.randn(B, dx, device=hip_device, generator=gen)
+    idx = _ancestors(B, K, hip_device, seed=B + K, spread=1.0)
+    forms(ITEM)
+    out = {}
+    for paired in (False, True):
+        monkeypatch.setattr(kernels, "WEIGHT_PAIRS", paired)
+        x, lw, ran = _run(kernels, o, x_prev, y, None, off_q, idx, seed=5 + K)
+        assert ran == ITEM
+        out[paired] = (x, lw)
+    assert torch.equal(out[True][0], out[False][0])
+    assert out[True][1].cpu().numpy().tobytes() == out[False][1].cpu().numpy().tobytes()
+    # the weights change in place (an optimiser step): same tensors, new values — the pairs are rebuilt
+    with torch.no_grad():
+        o["Q"].mul_(0.5)
+        o["C"].add_(0.25)
+    fresh = {}
+    for paired in (False, True):
+        monkeypatch.setattr(kernels, "WEIGHT_PAIRS", paired)
+        fresh[paired] = _run(kernels, o, x_prev, y, None, off_q, idx, seed=5 + K)[:2]
+    assert torch.equal(fresh[True][0], fresh[False][0]) and not torch.equal(fresh[True][0], out[True][0])
+    assert fresh[True][1].cpu().numpy().tobytes() == fresh[False][1].cpu().numpy().tobytes()

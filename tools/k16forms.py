@@ -63,9 +63,12 @@ def shape(B, K, d):
             ("noise fill", lambda i: k.philox_normal(res, (B, K, d), dev), N * 4 * d, 0),
             ("K15 through ancestors", lambda i: k.affine_propagate(x_prev[i], eps[i], y, *terms, scales, out_x=out_x[i],
                                                                    ancestors=idx[i]), N * (12 * d + 12), 0),
-            ("K16 persistent form", drawn, N * (8 * d + 12), 1), ("K16 item form", drawn, N * (8 * d + 12), 2)]
+            ("K16 persistent form", drawn, N * (8 * d + 12), 1), ("K16 item form, v_fmac chains", drawn, N * (8 * d + 12), 2),
+            ("K16 item form, v_pk_fma pairs", drawn, N * (8 * d + 12), 3)]
     print("B={} K={} d={}".format(B, K, d), flush=True)
     for name, fn, nbytes, form in rows:
+        k.WEIGHT_PAIRS = form == 3
+        form = min(form, 2)
         lib.aesmc_test_set_k16_form(form)
         if form and fn(0) is None:
             print("{:32s} declined".format(name))
@@ -76,6 +79,7 @@ def shape(B, K, d):
             name, us, nbytes / 1e6, nbytes / us / 1e6, nbytes / us / 1e6 / 8,
             "" if not form or ran == form else "   (ran as form {})".format(ran)), flush=True)
     lib.aesmc_test_set_k16_form(0)
+    k.WEIGHT_PAIRS = True
 
 
 for spec in sys.argv[1:] or ["128,4096,10", "256,4096,10", "512,4096,10", "1024,4096,10"]:
