@@ -1132,6 +1132,11 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   }
   out.carry = chain != nullptr ? chain->carry : nullptr;
   out.carry_records = chain != nullptr && chain->carry != nullptr ? chain->carry_records : 0;
+  {
+    const size_t used = (need * sizeof(T) + 15) & ~(size_t)15;
+    out.pairs = ws_bytes >= used + 3 * kLgPairFloats * sizeof(float) ? reinterpret_cast<float *>(static_cast<char *>(ws) + used)
+                                                                     : nullptr;
+  }
   if (chain != nullptr && !step) return AESMC_ERR_UNSUPPORTED;
   if ((child_grad != nullptr) != (child_end != nullptr) || (child_grad != nullptr && !step)) return AESMC_ERR_UNSUPPORTED;
   if (anc_idx != nullptr && (!step || N > 0x7fffffffLL)) return AESMC_ERR_UNSUPPORTED;
@@ -1350,7 +1355,8 @@ extern "C" int aesmc_affine_backward_collect(int dtype, const void *ws, int32_t 
 
 extern "C" size_t aesmc_affine_backward_workspace_bytes(int dtype, int64_t B, int64_t K) {
   const int64_t N = (B > 0 && K > 0) ? B * K : 0;
-  return (lg_record_elems() + lg_row_elems(N, 3)) * (dtype == AESMC_F64 ? 8 : 4);
+  // (+ the rows form's interleaved weight pairs behind them: 3 maps x 256 floats, 16-byte aligned)
+  return (lg_record_elems() + lg_row_elems(N, 3)) * (dtype == AESMC_F64 ? 8 : 4) + 16 + 3 * kLgPairFloats * sizeof(float);
 }
 
 extern "C" int aesmc_particle_affine_backward(int dtype, const void *grad, const void *x, const aesmc_affine_map *map,

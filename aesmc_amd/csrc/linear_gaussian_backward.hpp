@@ -99,7 +99,11 @@ struct LgBackwardOut {
   // workgroup w adds records w, w + grid, ... to its own, so the weights' gradients of a run of steps are finished once
   const void *carry;
   int carry_records;
+  // step kernel, rows form: room behind the records and row sums for the three maps' interleaved weight pairs (3 x
+  // kLgPairFloats floats; nullptr: a workspace of the older size — the location chains then run one output at a time)
+  float *pairs;
 };
+constexpr int kLgPairFloats = (kLgMaxDim / 2) * kLgMaxDim * 2;      // (== kPairFloats of linear_gaussian_fused.hpp)
 
 constexpr int kLgChildLimit = 32;   // children a lane sums by itself; longer runs (a collapsed system) take the wavefront
                                     // (8: the bench shape's healthy ancestry 338 -> 348 us, a collapsed one 456 -> 437)

@@ -257,6 +257,11 @@ static inline int fused_make_plan(FusedPlan &plan, int64_t B, int64_t K, int64_t
   return AESMC_OK;
 }
 
+// The maps' interleaved copies (aesmc_affine_weight_pairs; linear_gaussian_item.hip): one region of kPairFloats floats per
+// map in the order transition, emission, proposal.
+constexpr int kPairFloats = (kLgMaxDim / 2) * kLgMaxDim * 2;
+int launch_affine_weight_pairs(const LgMap &mp, const LgMap &mg, const LgMap &mq, float *out, hipStream_t stream);
+
 // which form `aesmc_affine_normal_propagate_drawn` launches: 0 by shape, 1 the persistent form, 2 one item per workgroup
 // (AESMC_K16_FORM=persistent / item in the environment, or the test hook aesmc_test_set_k16_form)
 extern int g_fused_form;

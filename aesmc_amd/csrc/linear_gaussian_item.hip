@@ -323,7 +323,6 @@ static int item_launch(dim3 grid, size_t lds, hipStream_t stream, const float *x
 
 // The maps' interleaved copies: pairs[jp][i] = (W[2 jp][i], W[2 jp + 1][i]) (zero where the second row does not exist), one
 // region of kPairFloats floats per map in the order transition, emission, proposal.  Any strides: a transposed view too.
-constexpr int kPairFloats = (kLgMaxDim / 2) * kLgMaxDim * 2;
 __global__ __launch_bounds__(256) void affine_weight_pairs_kernel(LgMap mp, LgMap mg, LgMap mq, float *__restrict__ out) {
   const LgMap &m = blockIdx.x == 0 ? mp : (blockIdx.x == 1 ? mg : mq);
   const float *w = reinterpret_cast<const float *>(m.w);
@@ -333,6 +332,11 @@ __global__ __launch_bounds__(256) void affine_weight_pairs_kernel(LgMap mp, LgMa
     const int jp = e / (2 * din), rem = e - jp * 2 * din, i = rem >> 1, j = 2 * jp + (rem & 1);
     dst[e] = (j < dout && i < din) ? w[(int64_t)j * m.sj + (int64_t)i * m.si] : 0.0f;
   }
+}
+
+int launch_affine_weight_pairs(const LgMap &mp, const LgMap &mg, const LgMap &mq, float *out, hipStream_t stream) {
+  hipLaunchKernelGGL(affine_weight_pairs_kernel, dim3(3), dim3(256), 0, stream, mp, mg, mq, out);
+  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
 // AESMC_ERR_UNSUPPORTED: the caller takes another form.  Covers latent extents 2 .. 16 with observation extents 1 .. 16;
@@ -393,7 +397,6 @@ extern "C" int aesmc_affine_weight_pairs(const aesmc_affine_map *transition, con
                                          const aesmc_affine_map *proposal, void *out_pairs, void *stream) {
   if (out_pairs == nullptr || (reinterpret_cast<uintptr_t>(out_pairs) & 15u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
   if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(affine_weight_pairs_kernel, dim3(3), dim3(256), 0, static_cast<hipStream_t>(stream), lg_map(transition),
-                     lg_map(emission), lg_map(proposal), static_cast<float *>(out_pairs));
-  return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  return launch_affine_weight_pairs(lg_map(transition), lg_map(emission), lg_map(proposal), static_cast<float *>(out_pairs),
+                                    static_cast<hipStream_t>(stream));
 }

@@ -25,6 +25,11 @@ typedef float sb_f4 __attribute__((ext_vector_type(4)));
 typedef sb_f4 sb_f4_a4 __attribute__((aligned(4)));      // a 16-byte global access at 4-byte alignment (hardware: unaligned mode)
 typedef sb_f2 sb_f2_a4 __attribute__((aligned(4)));
 
+#ifdef AESMC_K14_NO_PACKED      /* measurement build: the adjoints as v_fmac_f32 chains (round 4's form) */
+constexpr bool kSbPacked = false;
+#else
+constexpr bool kSbPacked = true;  // the three adjoints advance two outputs per instruction (v_pk_fma_f32: sb_pk_tx2)
+#endif
 constexpr int kSbChildRows = 96;         // rows of a wavefront's staged block of children (mean 64; what does not fit: from HBM)
 constexpr int kSbSlots = 2 * 192;        // the tile's column sums (three terms x four wavefronts x 16), two tiles' worth
 template <int D> struct Sb {             // D: the rows' extent (both the latent's and the observation's)
@@ -76,6 +81,46 @@ __device__ __forceinline__ void sb_fmac_tx2(float *acc, const float *w0, const f
     asm("v_fmac_f32 %0, %1, %3\n\tv_fmac_f32 %0, %2, %4" : "+v"(acc[0]) : "s"(w0[0]), "s"(w1[0]), "v"(u0), "v"(u1));
   }
 }
+// The same step on the packed pipe: (acc_i, acc_{i+1}) += (W[j][i], W[j][i+1]) u_j, then the same with row j + 1 — the two
+// weights of a pair are neighbours in a row of W as it lies, u_j / u_{j+1} the low / high half of one register pair.  Each
+// half is v_fmac_f32's fused multiply-add, rows ascending: the same bits, half the instructions.  NP pairs of outputs
+// (1 .. 3) per statement.
+template <int NP>
+__device__ __forceinline__ void sb_pk_tx2(lg_f2 *acc, const float *w0, const float *w1, lg_f2 u) {
+  static_assert(NP >= 1 && NP <= 3, "one to three output pairs per statement");
+#define SB_W(row, i) "s"(lg_f2{row[2 * (i)], row[2 * (i) + 1]})
+  if constexpr (NP == 3) {
+    asm("v_pk_fma_f32 %0, %3, %9, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %4, %9, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %5, %9, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %6, %9, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %1, %7, %9, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %2, %8, %9, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])
+        : SB_W(w0, 0), SB_W(w0, 1), SB_W(w0, 2), SB_W(w1, 0), SB_W(w1, 1), SB_W(w1, 2), "v"(u));
+  } else if constexpr (NP == 2) {
+    asm("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %3, %6, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %6, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc[0]), "+v"(acc[1])
+        : SB_W(w0, 0), SB_W(w0, 1), SB_W(w1, 0), SB_W(w1, 1), "v"(u));
+  } else {
+    asm("v_pk_fma_f32 %0, %1, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc[0]) : SB_W(w0, 0), SB_W(w1, 0), "v"(u));
+  }
+#undef SB_W
+}
+template <int D, int P0 = 0>
+__device__ __forceinline__ void sb_adjoint_pk(lg_f2 *acc, const float *w0, const float *w1, lg_f2 u) {
+  if constexpr (2 * P0 < D) {
+    constexpr int REM = D / 2 - P0, NP = REM >= 3 && REM != 4 ? 3 : (REM >= 2 ? 2 : 1);      // (4 = 2 + 2, never 3 + 1)
+    sb_pk_tx2<NP>(acc + P0, w0 + 2 * P0, w1 + 2 * P0, u);
+    sb_adjoint_pk<D, P0 + NP>(acc, w0, w1, u);
+  }
+}
+
 template <int D, int I0 = 0>
 __device__ __forceinline__ void sb_adjoint_pair(float *acc, const float *w0, const float *w1, float u0, float u1) {
   if constexpr (I0 < D) {
@@ -175,6 +220,7 @@ struct SbArgs {
   const float *carry;
   const float *child_rows;
   const int32_t *child_end;
+  const float *pairs;      // PAIRED: the maps' interleaved weight pairs (transition, emission, proposal), else unused
   const int64_t *anc;
   int32_t *flags;
   int64_t N, tiles;
@@ -189,7 +235,9 @@ struct SbArgs {
 #endif
 typedef const SbArgs __attribute__((address_space(4))) sb_cargs;
 
-template <int D, bool GATHER, bool FOLDS>
+// PAIRED: the location chains advance two outputs per instruction too (weights from the interleaved pairs the host's
+// launch wrote into the workspace just before this one: fused_pk_pair, linear_gaussian_fused.hpp) — the same bits.
+template <int D, bool GATHER, bool FOLDS, bool PAIRED>
 __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_rows_kernel(SbArgs unused_by_name) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
@@ -435,8 +483,8 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
     }
     // acc_j = offset_j + sum_i W[j][i] in_i (ascending i): a location.  The weights are scalar operands, two rows of
     // ten at a time, the next two sent for before this pair's multiply-adds.
-    auto chain = [&](const float *wptr, const float *off_ptr, int64_t off_sb, const float (&in)[D], float (&acc)[D]) {
-      sb_cfloat *W = (sb_cfloat *)wptr;
+    auto chain = [&](const float *wptr, int which, const float *off_ptr, int64_t off_sb, const float (&in)[D], float (&acc)[D]) {
+      sb_cfloat *W = PAIRED ? (sb_cfloat *)SB_A()->pairs + which * kPairFloats : (sb_cfloat *)wptr;
       if (off_ptr != nullptr) {
         sb_cfloat *off = (sb_cfloat *)off_ptr + (int64_t)b * off_sb;
 #pragma unroll
@@ -448,15 +496,31 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
       float wa[2 * D], wb[2 * D];
 #pragma unroll
       for (int e = 0; e < 2 * D; ++e) wa[e] = W[e];
+      lg_f2 in2[D / 2], acc2[D / 2];
+      if constexpr (PAIRED) {
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) {
+          in2[i] = lg_f2{in[2 * i], in[2 * i + 1]};
+          acc2[i] = lg_f2{acc[2 * i], acc[2 * i + 1]};
+        }
+      }
 #pragma unroll
       for (int jb = 0; jb < D; jb += 2) {
         float (&cur)[2 * D] = (jb & 2) ? wb : wa;
         float (&nxt)[2 * D] = (jb & 2) ? wa : wb;
         if (jb + 2 < D) {
 #pragma unroll
-          for (int e = 0; e < 2 * D; ++e) nxt[e] = W[(jb + 2) * D + e];
+          for (int e = 0; e < 2 * D; ++e) nxt[e] = W[(jb + 2) * D + e];      // (pairs: the next output pair's 2 D floats)
         }
-        fused_pair<D>(acc[jb], acc[jb + 1], cur, cur + D, in);
+        if constexpr (PAIRED) fused_pk_pair<D>(acc2[jb / 2], cur, in2);
+        else fused_pair<D>(acc[jb], acc[jb + 1], cur, cur + D, in);
+      }
+      if constexpr (PAIRED) {
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) {
+          acc[2 * i] = acc2[i][0];
+          acc[2 * i + 1] = acc2[i][1];
+        }
       }
     };
     // acc_i += sum_j W[j][i] u_j (ascending j): an adjoint
@@ -465,6 +529,11 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
       float wa[2 * D], wb[2 * D];
 #pragma unroll
       for (int e = 0; e < 2 * D; ++e) wa[e] = W[e];
+      lg_f2 acc2[D / 2];
+      if constexpr (kSbPacked) {
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) acc2[i] = lg_f2{acc[2 * i], acc[2 * i + 1]};
+      }
 #pragma unroll
       for (int jb = 0; jb < D; jb += 2) {
         float (&cur)[2 * D] = (jb & 2) ? wb : wa;
@@ -473,7 +542,15 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
 #pragma unroll
           for (int e = 0; e < 2 * D; ++e) nxt[e] = W[(jb + 2) * D + e];
         }
-        sb_adjoint_pair<D>(acc, cur, cur + D, u[jb], u[jb + 1]);
+        if constexpr (kSbPacked) sb_adjoint_pk<D>(acc2, cur, cur + D, lg_f2{u[jb], u[jb + 1]});
+        else sb_adjoint_pair<D>(acc, cur, cur + D, u[jb], u[jb + 1]);
+      }
+      if constexpr (kSbPacked) {
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) {
+          acc[2 * i] = acc2[i][0];
+          acc[2 * i + 1] = acc2[i][1];
+        }
       }
     };
     float *slot = slots + (trip & 1u) * 192;
@@ -484,7 +561,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
     // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u ----------------------------------------------------------
     {
       sb_cargs *A = SB_A();
-      if (!SB_PROBE(2u)) chain(A->wg, A->offg, A->offg_sb, xt, u);
+      if (!SB_PROBE(2u)) chain(A->wg, 1, A->offg, A->offg_sb, xt, u);
       else for (int j = 0; j < D; ++j) u[j] = xt[j];
       sb_cfloat *yrow = (sb_cfloat *)A->y + (int64_t)b * A->y_sb;
       float q = 0.0f;
@@ -510,7 +587,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
     // ---- transition term: u = g (x - loc_p) / s_p^2;  w -= u ------------------------------------------------------------
     {
       sb_cargs *A = SB_A();
-      if (!SB_PROBE(2u)) chain(A->wp, A->offp, A->offp_sb, xp, u);
+      if (!SB_PROBE(2u)) chain(A->wp, 0, A->offp, A->offp_sb, xp, u);
       else for (int j = 0; j < D; ++j) u[j] = xp[j];
       float q = 0.0f;
       const float scaled = g * inv_var_p;
@@ -537,7 +614,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
     {
       sb_cargs *A = SB_A();
       if (A->want_sq) {
-        if (!SB_PROBE(2u)) chain(A->wq, A->offq, A->offq_sb, xp, u);
+        if (!SB_PROBE(2u)) chain(A->wq, 2, A->offq, A->offq_sb, xp, u);
         else for (int j = 0; j < D; ++j) u[j] = xp[j];
         float dot = 0.0f;
 #pragma unroll
@@ -657,24 +734,29 @@ unsigned affine_step_backward_rows_grid(int64_t B, int64_t K, int64_t d) {
   }
 }
 
-template <int D>
+template <int D, bool PAIRED>
 static void sb_launch(bool gathers, bool folds, unsigned grid, hipStream_t stream, const SbArgs &a, bool &ok) {
   constexpr size_t lds = Sb<D>::kLds;
   static bool raised[4][64] = {};
   ok = true;
   if (gathers && folds) {
-    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, true, true>), raised[0]);
-    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, true, true>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
+    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, true, true, PAIRED>), raised[0]);
+    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, true, true, PAIRED>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
   } else if (gathers) {
-    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, true, false>), raised[1]);
-    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, true, false>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
+    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, true, false, PAIRED>), raised[1]);
+    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, true, false, PAIRED>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
   } else if (folds) {
-    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, false, true>), raised[2]);
-    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, false, true>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
+    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, false, true, PAIRED>), raised[2]);
+    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, false, true, PAIRED>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
   } else {
-    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, false, false>), raised[3]);
-    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, false, false>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
+    if (lds > 64 * 1024) ok = lg_raise_lds_limit(reinterpret_cast<const void *>(&affine_step_backward_rows_kernel<D, false, false, PAIRED>), raised[3]);
+    hipLaunchKernelGGL((affine_step_backward_rows_kernel<D, false, false, PAIRED>), ok ? dim3(grid) : dim3(0), dim3(kLgBlock), lds, stream, a);
   }
+}
+template <int D>
+static void sb_launch_either(bool paired, bool gathers, bool folds, unsigned grid, hipStream_t stream, const SbArgs &a, bool &ok) {
+  if (paired) sb_launch<D, true>(gathers, folds, grid, stream, a, ok);
+  else sb_launch<D, false>(gathers, folds, grid, stream, a, ok);
 }
 
 int launch_affine_step_backward_rows(const float *xprev, const float *x, const float *y, int64_t y_sb, const LgMap &mp,
@@ -704,17 +786,26 @@ int launch_affine_step_backward_rows(const float *xprev, const float *x, const f
 #ifdef AESMC_K14_PROBES
   { const char *v = getenv("AESMC_K14_PROBE"); a.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
 #endif
+  // the chains' weights as interleaved pairs, written into the workspace's tail by a small launch in front of this one (the
+  // weights may have been stepped since the last call; inside a hipGraph capture the rebuild is captured with it)
+  static const bool no_pairs = [] { const char *v = getenv("AESMC_K14_PAIRS"); return v != nullptr && v[0] == '0'; }();
+  const bool paired = kSbPacked && !no_pairs && out.pairs != nullptr;
+  if (paired) {
+    const int status = launch_affine_weight_pairs(mp, mg, mq, out.pairs, stream);
+    if (status != AESMC_OK) return status;
+    a.pairs = out.pairs;
+  }
   bool ok = true;
   switch (mp.dout) {
 #ifndef AESMC_LG_FAST_BUILD
-    case 2: sb_launch<2>(gathers, folds, grid, stream, a, ok); break;
-    case 4: sb_launch<4>(gathers, folds, grid, stream, a, ok); break;
-    case 6: sb_launch<6>(gathers, folds, grid, stream, a, ok); break;
-    case 8: sb_launch<8>(gathers, folds, grid, stream, a, ok); break;
-    case 12: sb_launch<12>(gathers, folds, grid, stream, a, ok); break;
-    case 14: sb_launch<14>(gathers, folds, grid, stream, a, ok); break;
+    case 2: sb_launch_either<2>(paired, gathers, folds, grid, stream, a, ok); break;
+    case 4: sb_launch_either<4>(paired, gathers, folds, grid, stream, a, ok); break;
+    case 6: sb_launch_either<6>(paired, gathers, folds, grid, stream, a, ok); break;
+    case 8: sb_launch_either<8>(paired, gathers, folds, grid, stream, a, ok); break;
+    case 12: sb_launch_either<12>(paired, gathers, folds, grid, stream, a, ok); break;
+    case 14: sb_launch_either<14>(paired, gathers, folds, grid, stream, a, ok); break;
 #endif
-    case 10: sb_launch<10>(gathers, folds, grid, stream, a, ok); break;
+    case 10: sb_launch_either<10>(paired, gathers, folds, grid, stream, a, ok); break;
     default: return AESMC_ERR_UNSUPPORTED;
   }
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
