@@ -51,6 +51,7 @@ else:
 from . import inference  # noqa: F401
 from . import losses  # noqa: F401
 from . import math  # noqa: F401
+from . import settings  # noqa: F401
 from . import state  # noqa: F401
 from . import statistics  # noqa: F401
 from . import train  # noqa: F401

@@ -1092,15 +1092,22 @@ class HipKernels:
     def _weight_pairs(self, maps, weights, device):
         """The three maps' weights as interleaved pairs (aesmc_affine_weight_pairs) for the fused propagation launch: built
         by one small launch the first time an evaluation meets these weights, then reused by its other timesteps."""
-        key = (self.evaluation,) + tuple((w.data_ptr(), w._version, tuple(w.shape), w.stride()) for w in weights)
         held = self._pairs
-        if held is not None and held[0] == key:
-            return held[1]
+        w0, w1, w2 = weights
+        if held is not None and held[2] is w0 and held[3] is w1 and held[4] is w2 and held[0] == (
+                self.evaluation, w0._version, w1._version, w2._version):
+            return held[1]      # (the very tensors of this evaluation's last step, unchanged since: a model's next timestep)
+        key = (self.evaluation, w0._version, w1._version, w2._version)
+        layout = tuple((w.data_ptr(), w.shape, w.stride()) for w in weights)
+        if held is not None and held[0] == key and held[5] == layout:
+            return held[1]      # (new view objects of the same storage: `x @ W.t()` makes one per call)
         pairs = torch.empty(int(self._lib.aesmc_affine_weight_pairs_floats()), dtype=torch.float32, device=device)
         _lib.check(self._lib.aesmc_affine_weight_pairs(ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]),
                                                        ctypes.byref(maps[2][0]), _ptr(pairs), self._stream(pairs)),
                    "aesmc_affine_weight_pairs")
-        self._pairs = (key, pairs)
+        # (a view with an autograd history is not kept: a cache that outlives the step would keep the step's graph alive)
+        keep = [None if w.grad_fn is not None else w for w in weights]
+        self._pairs = (key, pairs, keep[0], keep[1], keep[2], layout)
         return pairs
 
     def affine_propagate_drawn(self, x_src, noise, y_rows, transition, emission, proposal, scales, out_x,

@@ -309,18 +309,15 @@ class GraphedLoss:
             self._refill()
         if self.feed is not None:
             self.feed.begin()
-        from . import state
-        noise_scope = contextlib.nullcontext()
-        noise_was = state._KERNEL_NOISE
+        from . import settings
+        noise_scope = switches = contextlib.nullcontext()
         if capturing:
             if self.noise is not None:
                 noise_scope = _philox.graph_noise_scope(self.noise)
             else:
-                state.set_kernel_noise(False)       # every draw through PyTorch's own captured generator state
-        try:
+                switches = settings.override(kernel_noise=False)      # every draw through PyTorch's own captured generator state
+        with switches:
             return self._evaluate_body(noise_scope, num_particles, algorithm, initial, transition, emission, proposal)
-        finally:
-            state.set_kernel_noise(noise_was)
 
     def _evaluate_body(self, noise_scope, num_particles, algorithm, initial, transition, emission, proposal):
         with noise_scope, inference.uniform_feed(self.feed):

@@ -14,6 +14,7 @@ Differences from the reference that a caller can observe (all documented in DESI
 import collections.abc
 import contextlib
 import contextvars
+import os as _os
 
 import numpy as np
 import torch
@@ -21,59 +22,37 @@ import torch
 from . import _kernels
 from . import _lazy
 from . import _ops
+from . import settings
 from . import state
-
-_HISTORY_MODE = "lazy"
 
 
 def set_history_mode(mode):
     """'lazy' (default): resample history entries on access; 'eager': build the full list of
-    re-indexed latents every step exactly as aesmc/inference.py:102-104 does."""
-    global _HISTORY_MODE
-    if mode not in ("lazy", "eager"):
-        raise ValueError("history mode must be 'lazy' or 'eager', got {}".format(mode))
-    _HISTORY_MODE = mode
-
-
-import os as _os
-_LAZY_GATHER = _os.environ.get("AESMC_LAZY_GATHER", "1") != "0"      # measurement knob; see set_lazy_gather
+    re-indexed latents every step exactly as aesmc/inference.py:102-104 does.
+    (The process-wide default of `settings.Settings.history_mode`; `settings.override` scopes it.)"""
+    settings.set_default(history_mode=mode)
 
 
 def set_lazy_gather(enabled):
     """On (default): the newest latent is handed to the callables un-gathered (`_lazy.LazyResampled`) and a
     linear-Gaussian step fetches its rows through the ancestor indices inside the launch that weighs it.
     Off: the resampling launch always re-indexes the newest latent (rounds 1-2)."""
-    global _LAZY_GATHER
-    _LAZY_GATHER = bool(enabled)
+    settings.set_default(lazy_gather=bool(enabled))
 
 
-@contextlib.contextmanager
 def lazy_gather(enabled):
-    """`set_lazy_gather(enabled)` for the duration of a `with` block.  With it off the callables are handed plain
-    tensors, so a model written with PyTorch arithmetic (`x @ W.t() + c`) is evaluated by PyTorch itself — what the
-    tests use as the independent statement of such a model."""
-    global _LAZY_GATHER
-    previous, _LAZY_GATHER = _LAZY_GATHER, bool(enabled)
-    try:
-        yield
-    finally:
-        _LAZY_GATHER = previous
+    """`set_lazy_gather(enabled)` for the duration of a `with` block, in this context only.  With it off the callables
+    are handed plain tensors, so a model written with PyTorch arithmetic (`x @ W.t() + c`) is evaluated by PyTorch itself
+    — what the tests use as the independent statement of such a model."""
+    return settings.override(lazy_gather=bool(enabled))
 
 
-_FOLD_GATHER_BACKWARD = _os.environ.get("AESMC_FOLD_GATHER_BACKWARD", "1") != "0"      # measurement knob
-
-
-@contextlib.contextmanager
 def fold_gather_backward(enabled):
     """On (default): consecutive linear-Gaussian steps hand torch.gather's backward from autograd node to autograd
     node (`_ops.StepLink`; only when `infer` returns the latents to nobody).  Off: each step's backward sums the
-    children's gradients into their ancestors in a launch of its own (rounds 2-3a) — the tests' comparison run."""
-    global _FOLD_GATHER_BACKWARD
-    previous, _FOLD_GATHER_BACKWARD = _FOLD_GATHER_BACKWARD, bool(enabled)
-    try:
-        yield
-    finally:
-        _FOLD_GATHER_BACKWARD = previous
+    children's gradients into their ancestors in a launch of its own (rounds 2-3a) — the tests' comparison run.
+    A `with` block, scoped to this context."""
+    return settings.override(fold_gather_backward=bool(enabled))
 
 
 class ResampledHistory(collections.abc.Sequence):
@@ -136,8 +115,18 @@ def _mapped_view(pinned, device):
             return None
         view._aesmc_pinned = pinned      # the device view must not outlive the host block
         return view
-    except Exception:
+    except Exception as error:      # (an optional fast path: a PyTorch that cannot wrap the address takes the copy route)
+        global _MAPPED_VIEW_WARNED
+        if not _MAPPED_VIEW_WARNED:
+            _MAPPED_VIEW_WARNED = True
+            import warnings
+            warnings.warn("aesmc_amd: the pinned uniform block could not be addressed from the device ({}: {}); every "
+                          "resampling step copies its uniforms instead (slower by one small launch per timestep; said "
+                          "once)".format(type(error).__name__, error), RuntimeWarning)
         return None
+
+
+_MAPPED_VIEW_WARNED = False
 
 
 class _UniformFeed:
@@ -374,8 +363,10 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
     running_lse = None
     feed = None
     device = None
-    lazy_gather = _LAZY_GATHER
-    fold_children = _FOLD_GATHER_BACKWARD and use_smc and not keep_originals
+    cfg = settings.current()
+    lazy_history = cfg.history_mode == "lazy"
+    lazy_gather = cfg.lazy_gather
+    fold_children = cfg.fold_gather_backward and use_smc and not keep_originals
     bound_rows = []       # (timestep, PendingStep): rows of the log-sum-exp stack that are values owned by step nodes
 
     for time in range(num_timesteps):
@@ -396,7 +387,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                 # distributions in terms of it: the launch that weighs the step fetches the rows itself.  The
                 # first time a step reads the values after all, the remaining steps go back to gathering inside
                 # the resampling launch (one launch and one read of the indices cheaper than K2, then K3).
-                lazy_step = lazy_gather and newest is not None and _HISTORY_MODE == "lazy" and \
+                lazy_step = lazy_gather and newest is not None and lazy_history and \
                     newest.dim() == 3 and newest.is_floating_point()
                 # (with the latents handed to nobody, consecutive linear-Gaussian steps pass the gather's backward from
                 #  node to node — `_ops.StepLink` — and the resampling launch writes the children ranges it needs)
@@ -415,7 +406,7 @@ def _infer(inference_algorithm, observations, initial, transition, emission,
                         step_lse[-1] = lse_previous if (time - 1) not in deferred else \
                             _ops.attach_lse(lse_previous, previous, deferred.pop(time - 1))
                 indices.append(index)
-                if _HISTORY_MODE == "lazy":
+                if lazy_history:
                     ancestors = ResampledHistory(history, index, newest=moved, lazy_newest=lazy_step)
                 else:
                     ancestors = [state.resample(x, index) for x in history[:-1]]

@@ -1,0 +1,82 @@
+"""The package's behaviour switches in ONE place, scoped by context.
+
+Rounds 1-4 kept these as module globals of `state` and `inference` (six of them, plus the setters that wrote them): two
+models in one process — or two threads — shared every switch, and a `with` block that flipped one flipped it for
+everybody.  Here a `Settings` object holds them all; `current()` is what the code reads:
+
+  * the process-wide defaults (`set_default`, and the module-level setters `state.set_fused_normal`,
+    `state.set_validation_mode`, `state.set_kernel_noise`, `inference.set_history_mode`, `inference.set_lazy_gather`,
+    which keep their names and meaning);
+  * `with override(fused_normal=False, ...)`: a copy with those fields changed, active for the duration of the block in
+    THIS context only (contextvars: per thread, per asyncio task) — what `inference.lazy_gather(...)`,
+    `inference.fold_gather_backward(...)` and the hipGraph capture use.
+
+The reference has no switches (aesmc/ is one code path); every combination here gives the same numbers — they select
+which of this package's equivalent routes runs (see each field) — except `validation_mode`, which chooses WHEN a
+violation surfaces.  Environment variables give the defaults' initial values (measurement knobs, read once at import).
+"""
+import contextlib
+import contextvars
+import dataclasses
+import os
+
+
+def _env_flag(name, default=True):
+    value = os.environ.get(name)
+    return default if value is None else value != "0"
+
+
+@dataclasses.dataclass
+class Settings:
+    # 'lazy': `previous_latents` gathers an entry on first access; 'eager': the full re-indexed list every step, exactly
+    # as aesmc/inference.py:102-104 builds it
+    history_mode: str = "lazy"
+    # the newest latent is handed to the callables un-gathered and a linear-Gaussian step fetches its rows through the
+    # ancestor indices inside its own launch (off: the resampling launch always re-indexes it)  [AESMC_LAZY_GATHER]
+    lazy_gather: bool = True
+    # consecutive linear-Gaussian steps hand torch.gather's backward from autograd node to autograd node (off: a launch of
+    # its own per step)  [AESMC_FOLD_GATHER_BACKWARD]
+    fold_gather_backward: bool = True
+    # how `state.log_prob` performs the reference's `_validate_sample` (aesmc/state.py:142) on the device: 'deferred'
+    # (support checks set a device flag raised at the end of `infer`) or 'eager' (one host sync per call, as the reference)
+    validation_mode: str = "deferred"
+    # plain `Normal`s go through the fused kernels K4 / K5 / K6 (off: `distribution.log_prob` / `rsample` in eager PyTorch)
+    fused_normal: bool = True
+    # a deferred draw's float32 noise is formed inside the launch that uses it, from PyTorch's own Philox stream (off:
+    # `_standard_normal` materialises it first)  [AESMC_KERNEL_NOISE]
+    kernel_noise: bool = True
+
+    def validate(self):
+        if self.history_mode not in ("lazy", "eager"):
+            raise ValueError("history mode must be 'lazy' or 'eager', got {}".format(self.history_mode))
+        if self.validation_mode not in ("deferred", "eager"):
+            raise ValueError("validation mode must be 'deferred' or 'eager', got {}".format(self.validation_mode))
+        return self
+
+
+_DEFAULT = Settings(lazy_gather=_env_flag("AESMC_LAZY_GATHER"), fold_gather_backward=_env_flag("AESMC_FOLD_GATHER_BACKWARD"),
+                    kernel_noise=_env_flag("AESMC_KERNEL_NOISE"))
+_SCOPED = contextvars.ContextVar("aesmc_amd_settings", default=None)
+
+
+def current():
+    """The settings in force here: the innermost `override` of this context, else the process-wide defaults."""
+    scoped = _SCOPED.get()
+    return _DEFAULT if scoped is None else scoped
+
+
+def set_default(**changes):
+    """Changes the process-wide defaults (what every context sees outside an `override`)."""
+    candidate = dataclasses.replace(_DEFAULT, **changes).validate()
+    for name in changes:
+        setattr(_DEFAULT, name, getattr(candidate, name))
+
+
+@contextlib.contextmanager
+def override(**changes):
+    """`current()` with `changes` applied, for the duration of the block, in this context only."""
+    token = _SCOPED.set(dataclasses.replace(current(), **changes).validate())
+    try:
+        yield
+    finally:
+        _SCOPED.reset(token)

@@ -15,12 +15,10 @@ import torch
 from . import _kernels
 from . import _ops
 from . import _philox
+from . import settings
 from ._lazy import LazyAffine, LazyDraw, LazyParticles, LazyResampled
 from ._lazy import real as _lazy_real
 from .linear_gaussian import AffineNormal, affine_terms
-
-_VALIDATION_MODE = "deferred"
-
 
 def set_validation_mode(mode):
     """How `log_prob` performs the reference's explicit `distribution._validate_sample(value)`
@@ -29,11 +27,9 @@ def set_validation_mode(mode):
           the device without synchronising and a violation raises ValueError at the end of
           `inference.infer` (values outside a real-valued support are NaN and surface through the
           resampler's NaN flag as FloatingPointError);
-      'eager' — call `_validate_sample` as the reference does (one host sync per call)."""
-    global _VALIDATION_MODE
-    if mode not in ("deferred", "eager"):
-        raise ValueError("validation mode must be 'deferred' or 'eager', got {}".format(mode))
-    _VALIDATION_MODE = mode
+      'eager' — call `_validate_sample` as the reference does (one host sync per call).
+    (The process-wide default of `settings.Settings.validation_mode`; `settings.override` scopes it.)"""
+    settings.set_default(validation_mode=mode)
 
 
 def _is_real_support(support):
@@ -44,7 +40,7 @@ def _is_real_support(support):
 
 
 def _validate_sample(distribution, value):
-    if _VALIDATION_MODE == "eager" or not value.is_cuda:
+    if settings.current().validation_mode == "eager" or not value.is_cuda:
         distribution._validate_sample(value)
         return
     # Host half of torch.distributions.Distribution._validate_sample: shapes only, no sync.
@@ -136,7 +132,7 @@ def sample(distribution, batch_size, num_particles):
         raise ValueError("distribution not reparameterizable")
     sample_shape = _SAMPLE_SHAPE[mode](batch_size, num_particles)
     batch_expanded = mode == BatchShapeMode.BATCH_EXPANDED
-    draw = _fused_normal_rsample(distribution, sample_shape, batch_expanded) if _FUSED_NORMAL else None
+    draw = _fused_normal_rsample(distribution, sample_shape, batch_expanded) if settings.current().fused_normal else None
     if draw is None:
         draw = distribution.rsample(sample_shape=sample_shape)
         if batch_expanded:
@@ -169,7 +165,7 @@ def log_prob(distribution, value):
             distribution.batch_shape, value.shape))
     if missing != 1:
         _validate_sample(distribution, value)
-    fused = _fused_normal_views(distribution, value, missing) if _FUSED_NORMAL else None
+    fused = _fused_normal_views(distribution, value, missing) if settings.current().fused_normal else None
     if fused is not None:
         if missing == 1 and distribution._validate_args:  # what Normal.log_prob itself would check
             _validate_sample(distribution, value.transpose(0, 1))
@@ -189,7 +185,7 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     already expanded over particles.  Validation is what the three `log_prob` calls would do.
     `defer_grad`: return (log-weights without an autograd node, K5's operands) for a caller that
     differentiates only through the row log-sum-exp (`_ops.attach_lse`)."""
-    if not _FUSED_NORMAL:
+    if not settings.current().fused_normal:
         return None
     if type(latent) is LazyDraw and latent.is_pending and getattr(latent, "wide", False):
         log_weight = _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation)
@@ -262,22 +258,18 @@ def deferring_draws():
 
 
 _TORCH_STANDARD_NORMAL = torch.distributions.normal._standard_normal
-_KERNEL_NOISE = __import__("os").environ.get("AESMC_KERNEL_NOISE", "1") != "0"      # measurement knob
-
-
 def set_kernel_noise(enabled):
     """On (default): a deferred draw's float32 noise is formed inside the propagation launch from PyTorch's own
     Philox stream (same values, same generator state afterwards as `_standard_normal`); off: `_standard_normal`
-    materialises it first (rounds 1-2)."""
-    global _KERNEL_NOISE
-    _KERNEL_NOISE = bool(enabled)
+    materialises it first (rounds 1-2).  (The process-wide default of `settings.Settings.kernel_noise`.)"""
+    settings.set_default(kernel_noise=bool(enabled))
 
 
 def _kernel_noise_applies(source):
     """Float32 on the HIP device, PyTorch's `_standard_normal` in place (tests replay recorded noise through
     it), and — inside a hipGraph capture — a `_philox.GraphNoise` scope to hold the generator state on the device
     (graphs.GraphedLoss opens one when every draw of the ELBO is one this package can place itself)."""
-    return (_KERNEL_NOISE and source.is_cuda and source.dtype == torch.float32 and _kernels.get().name == "hip" and
+    return (settings.current().kernel_noise and source.is_cuda and source.dtype == torch.float32 and _kernels.get().name == "hip" and
             torch.distributions.normal._standard_normal is _TORCH_STANDARD_NORMAL and
             (_philox.graph_noise() is not None or not torch.cuda.is_current_stream_capturing()) and
             _philox.verified(source.device))
@@ -289,7 +281,8 @@ def _standard_normal(shape, dtype, device):
     come from aesmc_philox_normal_fill, so that every draw of the captured region sits at the offset the eager
     evaluation gives it.  Outside a capture the call is only counted (see `_philox.COUNTERS`)."""
     draw = torch.distributions.normal._standard_normal
-    if draw is _TORCH_STANDARD_NORMAL and dtype == torch.float32 and device.type == "cuda" and _KERNEL_NOISE and \
+    if draw is _TORCH_STANDARD_NORMAL and dtype == torch.float32 and device.type == "cuda" and \
+            settings.current().kernel_noise and \
             _kernels.get().name == "hip" and _philox.verified(device):
         numel = 1
         for size in shape:
@@ -419,15 +412,11 @@ def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation):
     return log_weight
 
 
-_FUSED_NORMAL = True
-
-
 def set_fused_normal(enabled):
     """Switches the fused Normal kernels (log-density K4 / K5 inside `log_prob`, draw K6 inside
     `sample`) on (default) or off; off evaluates `distribution.log_prob` / `rsample` in eager
-    PyTorch exactly as the reference does."""
-    global _FUSED_NORMAL
-    _FUSED_NORMAL = bool(enabled)
+    PyTorch exactly as the reference does.  (The process-wide default of `settings.Settings.fused_normal`.)"""
+    settings.set_default(fused_normal=bool(enabled))
 
 
 def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):

@@ -1065,3 +1065,39 @@ def test_the_deprecated_particle_mlp_is_the_pytorch_expression():
         got = linear_gaussian.particle_mlp(x, w1, o1, w2, b2)
     assert any(issubclass(w.category, DeprecationWarning) for w in seen)
     torch.testing.assert_close(got, torch.tanh(x @ w1.t() + o1.unsqueeze(1)) @ w2.t() + b2)
+
+
+def test_settings_are_scoped_by_context_and_keep_the_setters_meaning():
+    """`settings`: the module-level setters change the process-wide defaults; `override` (what `inference.lazy_gather`,
+    `inference.fold_gather_backward` and the hipGraph capture use) changes a copy for the duration of a block in THIS
+    context only — another thread keeps seeing the defaults; invalid values are refused before anything changes."""
+    import threading
+    import pytest
+    from aesmc_amd import inference, settings, state
+    assert settings.current().history_mode == "lazy" and settings.current().fused_normal
+    seen = {}
+    with settings.override(fused_normal=False, history_mode="eager"):
+        assert not settings.current().fused_normal and settings.current().history_mode == "eager"
+        with inference.lazy_gather(False):
+            assert not settings.current().lazy_gather and not settings.current().fused_normal
+            worker = threading.Thread(target=lambda: seen.update(other=settings.current()))
+            worker.start()
+            worker.join()
+        assert settings.current().lazy_gather
+    assert seen["other"].fused_normal and seen["other"].lazy_gather and seen["other"].history_mode == "lazy"
+    assert settings.current().fused_normal and settings.current().history_mode == "lazy"
+    state.set_fused_normal(False)
+    try:
+        assert not settings.current().fused_normal
+        with settings.override(kernel_noise=False):
+            assert not settings.current().fused_normal and not settings.current().kernel_noise
+    finally:
+        state.set_fused_normal(True)
+    with pytest.raises(ValueError):
+        inference.set_history_mode("sometimes")
+    with pytest.raises(ValueError):
+        state.set_validation_mode("later")
+    with pytest.raises(ValueError):
+        with settings.override(validation_mode="never"):
+            pass
+    assert settings.current().history_mode == "lazy" and settings.current().validation_mode == "deferred"

@@ -69,8 +69,9 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.aesmc_affine_normal_rsample(0, 16, ctypes.byref(amap), 32, 48, 32, 1, 1, None) == 1      # out aliases eps
     assert lib.aesmc_affine_normal_logweight(0, None, None, None, 0, None, None, None, None, None, None, None, 1, 1,
                                              None) == 1
-    assert lib.aesmc_affine_backward_workspace_bytes(0, 0, 0) == 1024 * 4 * 256 * 4
-    assert lib.aesmc_affine_backward_workspace_bytes(1, 2, 300) == (1024 * 4 * 256 + 3 * 3 * 8 * 16) * 8
+    pairs = 16 + 3 * 256 * 4      # (round 5: behind the records and row sums, the three maps' interleaved weight pairs)
+    assert lib.aesmc_affine_backward_workspace_bytes(0, 0, 0) == 1024 * 4 * 256 * 4 + pairs
+    assert lib.aesmc_affine_backward_workspace_bytes(1, 2, 300) == (1024 * 4 * 256 + 3 * 3 * 8 * 16) * 8 + pairs
     assert lib.aesmc_particle_affine_backward(0, 16, 32, ctypes.byref(amap), None, 48, None, None, 0, 1, 1, None) == 1
 
 
