@@ -1412,6 +1412,11 @@ class HipKernels:
             chain["left"] = None
             if ancestors is None:
                 raise ValueError("aesmc_amd: affine_step_backward chains the weights' gradients only through ancestors")
+        if x.dim() == 3 and x.size(2) > self.affine_max_dim():
+            if chain is not None or child_grad is not None:
+                raise ValueError("aesmc_amd: a wide step's backward takes the summed gradient (no children ranges, no chain)")
+            return self.affine_step_backward_wide(x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
+                                                  grad_lse=grad_lse, grad_x=grad_x, grad_lw=grad_lw, ancestors=ancestors)
         if not self.affine_logweight_covers(x_prev, x, y_rows, transition, emission, proposal, scales):
             raise ValueError("aesmc_amd: affine_step_backward operands outside what kernel K14 covers")
         if need[1]:
@@ -1531,6 +1536,86 @@ class HipKernels:
         for slot, s in ((9, scales[0]), (10, scales[1]), (11, scales[2])):
             if need[slot] and gscales is not None:
                 grads[slot] = gscales[slot - 9].reshape(s.shape)
+        return grads
+
+    def affine_step_backward_wide(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
+                                  grad_lse=None, grad_x=None, grad_lw=None, ancestors=None):
+        """`affine_step_backward` for rows wider than the fused kernels take (BASELINE.json configs[4]: 128 values): the
+        same twelve gradients, RECOMPUTED from what the forward launches (K17 / K18) left — x_{t-1}, the ancestors, x_t,
+        the log-weights — instead of retained: the step keeps no location, no noise and no resampled latent for its
+        backward (three [B,K,128] tensors per timestep in the GEMM route: what made training at this extent outgrow HBM).
+        The adjoint's contractions — three locations, three transposed maps, three sums of outer products over the
+        particles — are [B K, 128] x [128, 128] products on the matrix cores through the GEMM library; the element-wise
+        parts between them are PyTorch's.  Reference: autograd of aesmc/state.py:114-155, :179 and
+        aesmc/inference.py:108-130 for one timestep."""
+        (A, off_p), (C, off_g), (Q, off_q) = transition, emission, proposal
+        s_p, s_g, s_q = scales
+        B, K, dx = x.shape
+        dy = y_rows.size(1)
+        with torch.no_grad():
+            moved = x_prev if ancestors is None else self.gather(x_prev, ancestors)      # x_{t-1}[b, ancestors[b, k]]
+            weight = None
+            if grad_lse is not None:
+                weight = grad_lse.unsqueeze(1) * torch.exp(lw - lse.unsqueeze(1))           # d L / d lw through the row lse
+            if grad_lw is not None:
+                weight = grad_lw if weight is None else weight + grad_lw
+            flat = lambda t: t.reshape(B * K, t.size(2))
+            row = lambda off: 0 if off is None else (off.unsqueeze(1) if off.dim() == 2 else off)
+            incoming = grad_x      # what arrives at x_t from later steps
+            grads = [None] * 12
+            if weight is not None:
+                g = weight.unsqueeze(2)
+                # emission: u_g = g (y - loc_g) / s_g^2 — its gradient reaches C, its offset, y, s_g and x_t (C^T u_g)
+                diff_g = y_rows.unsqueeze(1) - (torch.matmul(x, C.t()) + row(off_g))
+                if need[10]:
+                    grads[10] = (weight * (diff_g.square().sum(2) / s_g ** 3 - dy / s_g)).sum().reshape(s_g.shape)
+                u_g = diff_g.mul_(g / (s_g * s_g))
+                at_x = torch.matmul(u_g, C)
+                if need[5]:
+                    grads[5] = torch.matmul(flat(u_g).t(), flat(x))
+                if (need[6] and off_g is not None) or need[2]:
+                    rows_g = u_g.sum(1)
+                    if need[6] and off_g is not None:
+                        grads[6] = rows_g if off_g.dim() == 2 else rows_g.sum(0)
+                    if need[2]:
+                        grads[2] = -rows_g
+                del u_g, diff_g
+                # transition: u_p = g (x_t - loc_p) / s_p^2 — reaches A, its offset, s_p, x_{t-1} (A^T u_p) and x_t (- u_p)
+                diff_p = x - (torch.matmul(moved, A.t()) + row(off_p))
+                if need[9]:
+                    grads[9] = (weight * (diff_p.square().sum(2) / s_p ** 3 - dx / s_p)).sum().reshape(s_p.shape)
+                u_p = diff_p.mul_(g / (s_p * s_p))
+                at_x.sub_(u_p)
+                if need[3]:
+                    grads[3] = torch.matmul(flat(u_p).t(), flat(moved))
+                if need[4] and off_p is not None:
+                    rows_p = u_p.sum(1)
+                    grads[4] = rows_p if off_p.dim() == 2 else rows_p.sum(0)
+                at_prev = torch.matmul(u_p, A) if need[0] else None
+                del u_p, diff_p
+                incoming = at_x if incoming is None else at_x.add_(incoming)
+            else:
+                at_prev = None
+            # the draw x_t = loc_q(x_{t-1}) + s_q eps carries everything that arrived at x_t to Q, its offset, s_q, x_{t-1}
+            if incoming is not None:
+                if need[7]:
+                    grads[7] = torch.matmul(flat(incoming).t(), flat(moved))
+                if need[8] and off_q is not None:
+                    rows_q = incoming.sum(1)
+                    grads[8] = rows_q if off_q.dim() == 2 else rows_q.sum(0)
+                if need[11]:
+                    noise_times_scale = x - (torch.matmul(moved, Q.t()) + row(off_q))       # s_q eps
+                    value = (incoming * noise_times_scale).sum() / s_q
+                    if weight is not None:
+                        value = value + weight.sum() * (dx / s_q)      # - d log q / d s_q = + d / s_q per particle
+                    grads[11] = value.reshape(s_q.shape)
+                if need[0]:
+                    through = torch.matmul(incoming, Q)
+                    at_prev = through if at_prev is None else at_prev.add_(through)
+            elif need[11] and weight is not None:
+                grads[11] = (weight.sum() * (dx / s_q)).reshape(s_q.shape)
+            if need[0]:
+                grads[0] = at_prev if at_prev is not None else torch.zeros_like(x)
         return grads
 
     def affine_backward_collect(self, left, dtype, device, dx, dy, need, scales):

@@ -443,6 +443,7 @@ class AffineOperands(tuple):
     launch fetches its rows through the indices (aesmc_affine_normal_propagate_resampled)."""
     pending_gather = None
     is_draw = False
+    wide = False      # rows wider than the fused kernels take (K17 / K18's extent): the backward recomputes, nothing is folded
 
     def requires_grad(self):
         return any(t is not None and t.requires_grad for t in self)
@@ -459,7 +460,7 @@ class AffineOperands(tuple):
         """The same operands with the latent being weighed (slot 1) replaced — a lazy draw by the tensor that
         receives / holds its values."""
         out = AffineOperands((self[0], x_t) + tuple(self[2:]))
-        out.is_draw, out.pending_gather = self.is_draw, self.pending_gather
+        out.is_draw, out.pending_gather, out.wide = self.is_draw, self.pending_gather, self.wide
         return out
 
 
@@ -698,7 +699,7 @@ def affine_step(lw, operands, fold_gather_backward=False):
         inputs[0] = inputs[0].materialise()
     own_link = parent_link = None
     defer_shared = False
-    if fold_gather_backward:
+    if fold_gather_backward and not operands.wide:
         shared = tuple(inputs[slot] for slot in _SHARED_SLOTS)
         own_link = StepLink(shared)
         if ancestors is not None:

@@ -7,7 +7,7 @@ does the bookkeeping half of such a call WITHOUT launching it: it reads (seed, o
 by what `normal_` would have consumed, and returns the stream descriptor a kernel needs to form the same
 values where it consumes them.  Everything drawn afterwards — by PyTorch or by this package — is unchanged.
 `verified(device)` checks these assumptions against the installed PyTorch once per device (tests:
-tests/test_gpu_round3.py, the Philox tests).
+tests/test_gpu_noise_and_lazy_latents.py, the Philox tests).
 """
 import collections
 import contextlib

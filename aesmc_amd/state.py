@@ -188,7 +188,7 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     if not settings.current().fused_normal:
         return None
     if type(latent) is LazyDraw and latent.is_pending and getattr(latent, "wide", False):
-        log_weight = _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation)
+        log_weight = _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation, defer_grad)
         if log_weight is not None:
             return log_weight
     affine = _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, observation)
@@ -366,13 +366,22 @@ def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, obse
     return operands
 
 
-def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation):
-    """A linear-Gaussian step on rows of 128 values whose latent is this proposal's deferred draw, forward only: K17 +
-    K18 form the draw (through the ancestors when nothing has gathered x_{t-1} yet) and the log-weights; the draw
-    resolves to the tensor they wrote.  None when the step is not of that kind (the caller's other routes apply)."""
-    if torch.is_grad_enabled() or not (torch.is_tensor(observation) and observation.dim() == 3 and
-                                       observation.stride(1) == 0):
+def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation, defer_grad=False):
+    """A linear-Gaussian step on rows of 128 values whose latent is this proposal's deferred draw: K17 + K18 form the draw
+    (through the ancestors when nothing has gathered x_{t-1} yet) and the log-weights; the draw resolves to the tensor
+    they wrote.  Under autograd only for a caller that differentiates the log-weights through their row log-sum-exp
+    (`defer_grad`: what `get_loss` asks of `infer`): the launches run without autograd nodes and the step's operands come
+    back beside the log-weights — `_ops.affine_step` ties x_t and the log-sum-exp to them, and the backward RECOMPUTES the
+    locations from x_{t-1}, the ancestors and x_t (`_kernels.affine_step_backward_wide`): nothing but x_t, the
+    log-weights and the indices is kept per timestep.  None when the step is not of that kind (the other routes apply)."""
+    if not (torch.is_tensor(observation) and observation.dim() == 3 and observation.stride(1) == 0):
         return None
+    if torch.is_grad_enabled() and not defer_grad:
+        prior, proposal, emission = affine_terms(prior_dist), affine_terms(proposal_dist), affine_terms(emission_dist)
+        if any(t is not None and any(v is not None and torch.is_tensor(v) and v.requires_grad
+                                     for v in (t.source, t.weight, t.offset, t.scale_param))
+               for t in (prior, proposal, emission)):
+            return None      # differentiable log-weights themselves: the GEMM route's autograd
     prior, proposal, emission = affine_terms(prior_dist), affine_terms(proposal_dist), affine_terms(emission_dist)
     if prior is None or proposal is None or emission is None or not latent.terms.same_terms(proposal):
         return None
@@ -409,7 +418,16 @@ def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation):
     if log_weight is None:
         return None
     latent.resolve(x_t)
-    return log_weight
+    if not defer_grad:
+        return log_weight
+    # slot 0: x_{t-1} as the step read it — the pending LazyResampled itself while its rows were fetched through the
+    # ancestors (`_ops.affine_step` takes (source, ancestors) out of `pending_gather`), else the tensor
+    first = prior.source if ancestors is not None else x_prev
+    operands = _ops.AffineOperands((first, x_t, y_rows, prior.weight, prior.offset, emission.weight, emission.offset,
+                                    proposal.weight, proposal.offset) + scales)
+    operands.is_draw, operands.wide = True, True
+    operands.pending_gather = (x_prev, ancestors) if ancestors is not None else None
+    return log_weight, operands
 
 
 def set_fused_normal(enabled):
@@ -453,12 +471,13 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
             draw = _ops.affine_rsample(source, terms.weight, terms.offset, scale, eps)
             draw._aesmc_draw_of = terms      # lets `infer` differentiate the whole step in one node (K14)
             return draw
-        if _DEFER_DRAWS.get() and not torch.is_grad_enabled() and getattr(terms, "defer_draw", None) is not False and \
+        if _DEFER_DRAWS.get() and getattr(terms, "defer_draw", None) is not False and \
                 _kernels.get().name == "hip" and _kernels.get().affine_wide_covers(terms.source, terms.weight, terms.offset,
                                                                                  scale):
-            # rows of 128 values (BASELINE.json configs[4]), forward only: the draw is left to the launch that weighs
-            # the step (K17: both maps of x_{t-1} on the matrix cores, the draw, two of the three densities); its noise
-            # is drawn here, by the very call `rsample` makes
+            # rows of 128 values (BASELINE.json configs[4]): the draw is left to the launch that weighs the step (K17:
+            # both maps of x_{t-1} on the matrix cores, the draw, two of the three densities); its noise is drawn here,
+            # by the very call `rsample` makes.  (Under autograd too: `_wide_step` takes the step when the caller
+            # differentiates through the row log-sum-exp only; else the draw is formed, differentiably, when it is read.)
             source = terms.source
             if _kernel_noise_applies(source):      # (reserved in PyTorch's generator; K17 forms it, or the fill kernel does)
                 eps = _philox.reserve(source.numel() // source.size(-1) * terms.weight.size(0), source.device)

@@ -12,7 +12,7 @@ valid — particle systems, so "compare everything at the end" says little.  Hen
     and EVERY step's log-weights can be held against the reference's to float32 rounding — a flip no longer
     switches the comparison off — while the flips themselves are counted per step.
 
-Used by tests/test_gpu_round3.py (bounds) and bench.py (`extras.fp32_fixture_parity`: the achieved numbers).
+Used by tests/test_gpu_noise_and_lazy_latents.py (bounds) and bench.py (`extras.fp32_fixture_parity`: the achieved numbers).
 No oracle import: the fixture arrays are handed in.
 """
 import numpy as np

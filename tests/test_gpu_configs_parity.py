@@ -1,4 +1,4 @@
-"""GPU parity tests added in round 2 ("close the parity gaps"):
+"""BASELINE.json's configs at their own sizes and the reference's recorded runs, on the device (added in round 2):
 
   * configs[4]'s shape end to end (d=128, K=16384) against the CPU port: float64 exact, float32 flip
     rate bounded;
@@ -117,7 +117,7 @@ def test_config2_like_float32_fixture_flip_rate(hip_device, name):
     assert wrong <= float32_flip_bound(meta["num_particles"]) * total
 
     # (the end-to-end agreement of this fixture — free-running and teacher-forced, both model statements — is
-    # measured and bounded in tests/test_gpu_round3.py::test_float32_runs_of_the_reference_*)
+    # measured and bounded in tests/test_gpu_noise_and_lazy_latents.py::test_float32_runs_of_the_reference_*)
 
 
 def _train_case_parts(meta, device):

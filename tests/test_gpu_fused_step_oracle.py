@@ -1,4 +1,5 @@
-"""GPU parity tests added in round 4 ("Next round" item 2):
+"""The fused propagation step against `oracle/` first hand, configs[3] at its own size, the forms of the step's backward,
+the wide (d = 128) step forward and backward (added in rounds 4 and 5):
 
   * the propagation launch that draws its own noise AND fetches x_{t-1} through the ancestors — the kernel that
     takes most of the forward pass — against `oracle/` FIRST HAND: the C restatement's gather, fma-chain draw and
@@ -20,7 +21,7 @@ import torch
 
 from oracle import c_oracle
 from tests.test_gpu_linear_gaussian import operands
-from tests.test_gpu_round3 import _ancestors
+from tests.test_gpu_noise_and_lazy_latents import _ancestors
 
 pytestmark = pytest.mark.gpu
 
@@ -246,7 +247,7 @@ def test_both_forms_of_the_step_backward_give_the_same_bits(kernels, hip_device,
     tiles through LDS in every output bit — particle gradients, the three weight gradients, the offsets' row sums, the
     scales — on the same grid (the records' association follows the grid), with and without the gather's backward
     folded in, for a healthy and a collapsed next-step ancestry (runs longer than a lane sums by itself)."""
-    from tests.test_gpu_round3 import _next_resampling
+    from tests.test_gpu_noise_and_lazy_latents import _next_resampling
     B, K, d = shape
     _, o = operands(B, K, d, d, np.float32, hip_device, seed=B + K)
     off_p = torch.from_numpy(np.random.RandomState(4).randn(d).astype(np.float32)).to(hip_device)
@@ -447,3 +448,94 @@ def test_the_wide_step_forms_torchs_noise_itself(kernels, hip_device, shape, gat
     short = _philox.reserve(2 * 4096 * d, hip_device)
     assert kernels.affine_propagate_wide(x_prev[:2, :4096].contiguous(), short, y[:2], (A, None), (C, None), (Q, off_q[:2]),
                                          scales, torch.empty(2, 4096, d, device=hip_device)) is None if B >= 2 else True
+
+
+# ---- the wide step under autograd: recomputation instead of retention ------------------------------------
+@pytest.mark.parametrize("shape", [(2, 16384, 1), (3, 1024, 1)])
+def test_the_wide_steps_backward_equals_float64_autograd(kernels, hip_device, shape):
+    """`affine_step_backward` on rows of 128 values (the backward of a K17 / K18 step, recomputed from x_{t-1}, the
+    ancestors, x_t and the log-weights) against float64 autograd of the same step written with PyTorch operations —
+    aesmc/state.py:114-155, :179 and aesmc/inference.py:108-130 for one timestep: every gradient (resampled rows, the
+    three maps, their offsets — per batch row, shared, absent —, the observation, the three scales) to float32 rounding
+    of sums over B K particles."""
+    B, K, _ = shape
+    d = 128
+    gen = torch.Generator(device=hip_device).manual_seed(B + K)
+    make = lambda *s: torch.randn(*s, device=hip_device, generator=gen)
+    x_prev, eps, y, off_q, off_g = make(B, K, d), make(B, K, d), make(B, d), make(B, d), make(d)
+    eye = torch.eye(d, device=hip_device)
+    A, C, Q = 0.9 * eye + 0.05 * make(d, d), 0.1 * make(d, d), 0.45 * eye + 0.05 * make(d, d)
+    scales = tuple(torch.tensor(v, device=hip_device) for v in (1.0, 0.5, 0.7))
+    anc = _ancestors(B, K, hip_device, seed=B, spread=1.0)
+    terms = ((A, None), (C, off_g), (Q, off_q))
+    x = torch.empty_like(x_prev)
+    lw = kernels.affine_propagate_wide(x_prev, eps, y, *terms, scales, x, ancestors=anc)
+    assert lw is not None
+    lse = torch.logsumexp(lw, dim=1)
+    glse = make(B)
+    grad_x = make(B, K, d) * 1e-3
+    need = [True, False, True, True, False, True, True, True, True, True, True, True]
+    got = kernels.affine_step_backward(x_prev, x, y, *terms, scales, need, lw, lse, grad_lse=glse, grad_x=grad_x, ancestors=anc)
+    # float64 autograd of the same step
+    f = lambda t: t.double().detach().clone().requires_grad_(True)
+    moved = f(torch.gather(x_prev, 1, anc.unsqueeze(-1).expand_as(x_prev)))
+    A_, C_, Q_, y_, og_, oq_ = f(A), f(C), f(Q), f(y), f(off_g), f(off_q)
+    sp_, sg_, sq_ = (f(s_) for s_ in scales)
+    loc_q = moved @ Q_.t() + oq_.unsqueeze(1)
+    noise = ((x.double() - loc_q) / sq_).detach()      # the eps the launch used, as float64
+    x_t = loc_q + sq_ * noise
+    logn = lambda v, loc, sc: torch.distributions.Normal(loc, sc).log_prob(v).sum(2)
+    lw64 = logn(x_t, moved @ A_.t(), sp_) + logn(y_.unsqueeze(1), x_t @ C_.t() + og_, sg_) - logn(x_t, loc_q, sq_)
+    loss = (glse.double() * torch.logsumexp(lw64, dim=1)).sum() + (grad_x.double() * x_t).sum()
+    loss.backward()
+    want = {0: moved.grad, 2: y_.grad, 3: A_.grad, 5: C_.grad, 6: og_.grad, 7: Q_.grad, 8: oq_.grad, 9: sp_.grad, 10: sg_.grad,
+            11: sq_.grad}
+    for slot, reference in want.items():
+        assert got[slot] is not None, slot
+        scale = float(reference.abs().max()) + 1e-30
+        error = float((got[slot].double().reshape(reference.shape) - reference).abs().max())
+        assert error <= 5e-4 * scale, (slot, error, scale)
+    assert got[1] is None and got[4] is None
+
+
+def test_a_wide_model_trains_through_the_matrix_core_step(hip_device, monkeypatch):
+    """configs[4]'s model (d = 128) through `get_loss` WITH gradients: every resampled step's forward is K17 + K18
+    (counted), its backward the recomputing adjoint; loss and parameter gradients agree with the GEMM route's autograd on
+    the same seeds (float32 rounding of a different association: 2e-3 of each gradient's largest entry)."""
+    from aesmc_amd import _kernels, losses
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    B, K, T = 8, 4096, 6
+
+    def run(wide):
+        model = LgssmNd(128, dtype=torch.float32, affine=True, validate_args=False, emission_scale=0.05).tune_proposal().to(hip_device)
+        observations = model.simulate(T, B, seed=2)
+        calls = {"wide": 0, "backward": 0}
+        real, real_bwd = provider.affine_propagate_wide, provider.affine_step_backward_wide
+        if wide:
+            def counting(*args, **kwargs):
+                out = real(*args, **kwargs)
+                calls["wide"] += out is not None
+                return out
+
+            def counting_bwd(*args, **kwargs):
+                calls["backward"] += 1
+                return real_bwd(*args, **kwargs)
+            monkeypatch.setattr(provider, "affine_propagate_wide", counting)
+            monkeypatch.setattr(provider, "affine_step_backward_wide", counting_bwd)
+        else:
+            monkeypatch.setattr(provider, "affine_wide_covers", lambda *a, **k: False)
+        np.random.seed(4)
+        torch.manual_seed(4)
+        loss = losses.get_loss(observations, K, "aesmc", model.initial, model.transition, model.emission, model.proposal)
+        loss.backward()
+        monkeypatch.undo()
+        return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, calls
+    wide_loss, wide_grads, calls = run(True)
+    assert calls == {"wide": T - 1, "backward": T - 1}, calls
+    plain_loss, plain_grads, _ = run(False)
+    assert abs(wide_loss - plain_loss) <= 2e-3 * abs(plain_loss)
+    assert set(wide_grads) == set(plain_grads) and len(wide_grads) >= 4
+    for name, g in plain_grads.items():
+        scale = float(g.abs().max()) + 1e-30
+        assert float((wide_grads[name] - g).abs().max()) <= 2e-2 * scale, name

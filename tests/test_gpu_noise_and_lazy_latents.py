@@ -1,4 +1,4 @@
-"""GPU parity tests added in round 3:
+"""Noise formed inside kernels, propagation through the ancestor indices, lazily resampled latents (added in round 3):
 
   * the noise a kernel draws for itself IS `torch.empty(n).normal_()` — bit for bit, whatever the seed, the
     offset and the size, and the generator ends where PyTorch's own call would leave it;

@@ -17,7 +17,7 @@ import torch
 
 from oracle import c_oracle
 from tests.test_gpu_linear_gaussian import operands
-from tests.test_gpu_round3 import _ancestors
+from tests.test_gpu_noise_and_lazy_latents import _ancestors
 
 pytestmark = pytest.mark.gpu
 

@@ -8,7 +8,7 @@ for MW in 8; do
   AESMC_K2_MIN_WAVES=$MW timeout -k 10 200 python tools/k2forms.py 1024,4096 512,4096 128,4096 256,1024 > $OUT/r05e_k2_minw$MW.txt 2>&1; rc=$?; stop_if_killed $rc
   echo "min waves $MW"; grep -E "^B=|rows " $OUT/r05e_k2_minw$MW.txt | cut -c1-120
 done
-timeout -k 10 900 python -m pytest tests/test_gpu_round4.py tests/test_gpu_resampler_forms.py -m gpu --maxfail=5 -q -x -k "step_backward or lean" > $OUT/r05e_pytest.txt 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests/test_gpu_fused_step_oracle.py tests/test_gpu_resampler_forms.py -m gpu --maxfail=5 -q -x -k "step_backward or lean" > $OUT/r05e_pytest.txt 2>&1; rc=$?
 tail -5 $OUT/r05e_pytest.txt | cut -c1-300
 if [ $rc -ne 0 ]; then grep -n "Error\|assert\|FAILED" $OUT/r05e_pytest.txt | head -30 | cut -c1-300; exit $rc; fi
 for D in 4 8 12 14 10; do

@@ -4,7 +4,7 @@
 set -u
 OUT=gpurun_out; mkdir -p $OUT
 stop_if_killed() { if [ $1 -eq 124 ] || [ $1 -eq 137 ]; then echo "step killed at its limit: stopping"; exit $1; fi; }
-timeout -k 10 900 python -m pytest tests/test_gpu_round4.py tests/test_gpu_linear_gaussian.py tests/test_gpu_round3.py -m gpu --maxfail=5 -q -x > $OUT/r05g_pytest.txt 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests/test_gpu_fused_step_oracle.py tests/test_gpu_linear_gaussian.py tests/test_gpu_noise_and_lazy_latents.py -m gpu --maxfail=5 -q -x > $OUT/r05g_pytest.txt 2>&1; rc=$?
 tail -5 $OUT/r05g_pytest.txt | cut -c1-300
 if [ $rc -ne 0 ]; then grep -n "Error\|assert\|FAILED" $OUT/r05g_pytest.txt | head -30 | cut -c1-300; exit $rc; fi
 for P in 1 0; do
