@@ -1412,7 +1412,7 @@ class HipKernels:
             chain["left"] = None
             if ancestors is None:
                 raise ValueError("aesmc_amd: affine_step_backward chains the weights' gradients only through ancestors")
-        if x.dim() == 3 and x.size(2) > self.affine_max_dim():
+        if x.dim() == 3 and x.size(2) > self.affine_max_dim:
             if chain is not None or child_grad is not None:
                 raise ValueError("aesmc_amd: a wide step's backward takes the summed gradient (no children ranges, no chain)")
             return self.affine_step_backward_wide(x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,

@@ -500,18 +500,22 @@ def test_the_wide_steps_backward_equals_float64_autograd(kernels, hip_device, sh
 
 def test_a_wide_model_trains_through_the_matrix_core_step(hip_device, monkeypatch):
     """configs[4]'s model (d = 128) through `get_loss` WITH gradients: every resampled step's forward is K17 + K18
-    (counted), its backward the recomputing adjoint; loss and parameter gradients agree with the GEMM route's autograd on
-    the same seeds (float32 rounding of a different association: 2e-3 of each gradient's largest entry)."""
+    (counted), its backward the recomputing adjoint.  Loss and every parameter gradient agree with the GEMM route's
+    autograd — run on the same seeds and handed the wide run's ancestors at every resampling (teacher forcing: at this
+    extent the log-weights are of order 1e4, float32 rounding differs between two routes by ~1e-2 absolute, and two
+    free-running evaluations resample a few per cent of their particles differently: both valid, not comparable
+    gradient by gradient) — to float32 rounding of a different association; free-running, the estimates agree."""
     from aesmc_amd import _kernels, losses
     from aesmc_amd.testing.models import LgssmNd
     provider = _kernels.get()
-    B, K, T = 8, 4096, 6
+    B, K = 8, 4096
 
-    def run(wide):
+    def run(wide, T, forced=None):
         model = LgssmNd(128, dtype=torch.float32, affine=True, validate_args=False, emission_scale=0.05).tune_proposal().to(hip_device)
         observations = model.simulate(T, B, seed=2)
         calls = {"wide": 0, "backward": 0}
-        real, real_bwd = provider.affine_propagate_wide, provider.affine_step_backward_wide
+        recorded = []
+        real, real_bwd, real_step = provider.affine_propagate_wide, provider.affine_step_backward_wide, provider.resample_step
         if wide:
             def counting(*args, **kwargs):
                 out = real(*args, **kwargs)
@@ -525,17 +529,30 @@ def test_a_wide_model_trains_through_the_matrix_core_step(hip_device, monkeypatc
             monkeypatch.setattr(provider, "affine_step_backward_wide", counting_bwd)
         else:
             monkeypatch.setattr(provider, "affine_wide_covers", lambda *a, **k: False)
+
+        def resampling(*args, **kwargs):
+            out = real_step(*args, **kwargs)
+            if forced is not None:
+                out[0].copy_(forced[len(recorded)])      # the other run's ancestors (this run's own log-sum-exp)
+            recorded.append(out[0].clone())
+            return out
+        monkeypatch.setattr(provider, "resample_step", resampling)
         np.random.seed(4)
         torch.manual_seed(4)
         loss = losses.get_loss(observations, K, "aesmc", model.initial, model.transition, model.emission, model.proposal)
         loss.backward()
         monkeypatch.undo()
-        return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, calls
-    wide_loss, wide_grads, calls = run(True)
+        return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, calls, recorded
+    T = 5
+    wide_loss, wide_grads, calls, ancestors = run(True, T)
     assert calls == {"wide": T - 1, "backward": T - 1}, calls
-    plain_loss, plain_grads, _ = run(False)
-    assert abs(wide_loss - plain_loss) <= 2e-3 * abs(plain_loss)
-    assert set(wide_grads) == set(plain_grads) and len(wide_grads) >= 4
-    for name, g in plain_grads.items():
+    assert len(ancestors) == T - 1
+    forced_loss, forced_grads, _, _ = run(False, T, forced=ancestors)
+    assert abs(wide_loss - forced_loss) <= 1e-5 * abs(forced_loss)
+    assert set(wide_grads) == set(forced_grads) and len(wide_grads) >= 4
+    for name, g in forced_grads.items():
         scale = float(g.abs().max()) + 1e-30
-        assert float((wide_grads[name] - g).abs().max()) <= 2e-2 * scale, name
+        assert float((wide_grads[name] - g).abs().max()) <= 2e-3 * scale, (name, float((wide_grads[name] - g).abs().max()), scale)
+    free_loss, free_grads, _, _ = run(False, T)
+    assert abs(wide_loss - free_loss) <= 2e-3 * abs(free_loss)
+    assert all(bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0 for g in wide_grads.values())
