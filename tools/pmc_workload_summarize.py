@@ -16,11 +16,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
-KERNELS = {"resample_step": "ancestor_index_inv_kernel", "resample_gather": "resample_gather_kernel",
+KERNELS = {"resample_step": "ancestor_index_",      # (K2: the lean form ancestor_index_rows_kernel or ancestor_index_inv_kernel)
+            "resample_gather": "resample_gather_kernel",
            "normal_logweight": "normal_logweight", "normal_rsample": "normal_rsample",
            "affine_normal_rsample": "affine_rsample_kernel", "affine_normal_logweight": "affine_logweight_kernel",
            "affine_normal_propagate": "affine_logweight_kernel",      # K15 = K10's kernel in DRAW mode: it also writes x_t
-           "affine_normal_propagate_drawn": "affine_propagate_fused_kernel",      # K16 (round 4's form)
+           "affine_normal_propagate_drawn": "affine_propagate_item_kernel",      # K16 (round 5's form: one item per workgroup)
            "affine_normal_propagate_resampled": "affine_logweight_kernel",      # K15 fetching x_{t-1} through the ancestors
            "philox_normal_fill": "philox_normal_fill_kernel",
            "affine_step_backward_resampled": "affine_step_backward_rows_kernel"}      # K14 (pmc_workload.py with a backward)
