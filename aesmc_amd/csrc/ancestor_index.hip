@@ -714,8 +714,10 @@ __device__ __forceinline__ double exp_nonpositive_s(double x, const ExpScalars &
 // (Held to 64 registers like the kernel above: every row of the north-star batch resident at once.  Measured against a
 //  96-register build without the slow path's spills, which runs the batch in two rounds of workgroups: 20.2 against 19.9 us
 //  at B = 1024, K = 4096 and 4.0 against 5.7 us at B = 256, K = 1024 — profiles/r05_k2_forms.txt.  Also measured and not
-//  kept: a workgroup walking two or four rows so that one row's index stores drain under the next row's scan — the loop's
-//  live state spilt 72 registers and the launch took 31 - 33 us.)
+//  kept: a workgroup walking two to four rows so that one row's index stores drain under the next row's scan — at 64
+//  registers the loop's live state spilt 72 of them (31 - 33 us); as a kernel of its own at 107 registers, two workgroups
+//  per CU: 21.9 / 26.4 / 25.5 us for 2 / 3 / 4 rows per workgroup against 20.2 at B = 1024, 39.8 against 36.7 at B = 2048 —
+//  where two rounds of the plain kernel already overlap by themselves (0.46 of HBM): profiles/r05_k2_row_walk.txt.)
 template <typename T, int C>
 __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_rows_kernel(
     const T *__restrict__ log_w, const double *__restrict__ u, int64_t *__restrict__ out_idx, int32_t *flags, int K,

@@ -286,6 +286,13 @@ def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_
         run(b, t)
     timed = sorted(run(b, t) for _ in range(3))
     dt, loss = timed[1]
+    # (the sizing passes run cold — allocator growth, page faults — and can overstate an evaluation several times over:
+    #  while the median says the sample is well under its share and time remains, double the rows and time again)
+    while 2.6 * dt <= per_run and 2 * b <= B and time.perf_counter() - started + 8.5 * dt < budget_s:
+        b *= 2
+        run(b, t)
+        timed = sorted(run(b, t) for _ in range(3))
+        dt, loss = timed[1]
     return {"value": b * K * t / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
             "sample": "median of 3 forward ELBOs (after 1 warm-up), B={} K={} T={} d={} ({} proposal), {:.1f} s each on {} "
                       "of {} host cores; oracle/reference_port.py (PyTorch-CPU + NumPy, keeps the reference's O(T^2) "
