@@ -1559,59 +1559,72 @@ class HipKernels:
                 weight = grad_lse.unsqueeze(1) * torch.exp(lw - lse.unsqueeze(1))           # d L / d lw through the row lse
             if grad_lw is not None:
                 weight = grad_lw if weight is None else weight + grad_lw
-            flat = lambda t: t.reshape(B * K, t.size(2))
-            row = lambda off: 0 if off is None else (off.unsqueeze(1) if off.dim() == 2 else off)
+            # residual = base - source @ W.T with the map's offset folded into `base` ([B,1,d'] broadcast over the
+            # particles, or the full [B,K,d'] tensor): ONE pass — the GEMM's epilogue — instead of a product, an offset add
+            # and a subtraction
+            def residual(base, source, W, offset):
+                if offset is not None:
+                    base = base - (offset.unsqueeze(1) if offset.dim() == 2 else offset)
+                return torch.baddbmm(base, source, W.t().unsqueeze(0).expand(B, -1, -1), beta=1, alpha=-1)
+            # sum over the particles of u ⊗ v: [d', N] x [N, d] with N = B K in the millions is a shape the GEMM library
+            # picks poor tiles for (0.8 - 0.9 ms at N = 2^20); as a batch of N / 4096 products of depth 4096, summed: ~0.4 ms
+            def outer_sum(u, v):
+                n = B * K
+                depth = 4096 if n % 4096 == 0 and n > 4096 else n
+                parts = torch.bmm(u.reshape(n // depth, depth, u.size(2)).transpose(1, 2), v.reshape(n // depth, depth, v.size(2)))
+                return parts.sum(0) if parts.size(0) > 1 else parts[0]
+            rows = lambda u, off: u.sum(1) if off.dim() == 2 else u.sum((0, 1))
             incoming = grad_x      # what arrives at x_t from later steps
             grads = [None] * 12
+            at_prev = None
             if weight is not None:
                 g = weight.unsqueeze(2)
                 # emission: u_g = g (y - loc_g) / s_g^2 — its gradient reaches C, its offset, y, s_g and x_t (C^T u_g)
-                diff_g = y_rows.unsqueeze(1) - (torch.matmul(x, C.t()) + row(off_g))
+                u_g = residual(y_rows.unsqueeze(1), x, C, off_g)
                 if need[10]:
-                    grads[10] = (weight * (diff_g.square().sum(2) / s_g ** 3 - dy / s_g)).sum().reshape(s_g.shape)
-                u_g = diff_g.mul_(g / (s_g * s_g))
-                at_x = torch.matmul(u_g, C)
+                    grads[10] = (weight * (u_g.square().sum(2) / s_g ** 3 - dy / s_g)).sum().reshape(s_g.shape)
+                u_g.mul_(g / (s_g * s_g))
                 if need[5]:
-                    grads[5] = torch.matmul(flat(u_g).t(), flat(x))
+                    grads[5] = outer_sum(u_g, x)
                 if (need[6] and off_g is not None) or need[2]:
                     rows_g = u_g.sum(1)
                     if need[6] and off_g is not None:
                         grads[6] = rows_g if off_g.dim() == 2 else rows_g.sum(0)
                     if need[2]:
                         grads[2] = -rows_g
-                del u_g, diff_g
+                # what arrives at x_t: later steps' gradient + C^T u_g - u_p, accumulated in the products' epilogues
+                at_x = torch.matmul(u_g, C) if incoming is None else \
+                    torch.baddbmm(incoming, u_g, C.unsqueeze(0).expand(B, -1, -1))
+                del u_g
                 # transition: u_p = g (x_t - loc_p) / s_p^2 — reaches A, its offset, s_p, x_{t-1} (A^T u_p) and x_t (- u_p)
-                diff_p = x - (torch.matmul(moved, A.t()) + row(off_p))
+                u_p = residual(x, moved, A, off_p)
                 if need[9]:
-                    grads[9] = (weight * (diff_p.square().sum(2) / s_p ** 3 - dx / s_p)).sum().reshape(s_p.shape)
-                u_p = diff_p.mul_(g / (s_p * s_p))
+                    grads[9] = (weight * (u_p.square().sum(2) / s_p ** 3 - dx / s_p)).sum().reshape(s_p.shape)
+                u_p.mul_(g / (s_p * s_p))
                 at_x.sub_(u_p)
                 if need[3]:
-                    grads[3] = torch.matmul(flat(u_p).t(), flat(moved))
+                    grads[3] = outer_sum(u_p, moved)
                 if need[4] and off_p is not None:
-                    rows_p = u_p.sum(1)
-                    grads[4] = rows_p if off_p.dim() == 2 else rows_p.sum(0)
-                at_prev = torch.matmul(u_p, A) if need[0] else None
-                del u_p, diff_p
-                incoming = at_x if incoming is None else at_x.add_(incoming)
-            else:
-                at_prev = None
+                    grads[4] = rows(u_p, off_p)
+                if need[0]:
+                    at_prev = torch.matmul(u_p, A)
+                del u_p
+                incoming = at_x
             # the draw x_t = loc_q(x_{t-1}) + s_q eps carries everything that arrived at x_t to Q, its offset, s_q, x_{t-1}
             if incoming is not None:
                 if need[7]:
-                    grads[7] = torch.matmul(flat(incoming).t(), flat(moved))
+                    grads[7] = outer_sum(incoming, moved)
                 if need[8] and off_q is not None:
-                    rows_q = incoming.sum(1)
-                    grads[8] = rows_q if off_q.dim() == 2 else rows_q.sum(0)
+                    grads[8] = rows(incoming, off_q)
                 if need[11]:
-                    noise_times_scale = x - (torch.matmul(moved, Q.t()) + row(off_q))       # s_q eps
+                    noise_times_scale = residual(x, moved, Q, off_q)       # s_q eps
                     value = (incoming * noise_times_scale).sum() / s_q
                     if weight is not None:
                         value = value + weight.sum() * (dx / s_q)      # - d log q / d s_q = + d / s_q per particle
                     grads[11] = value.reshape(s_q.shape)
                 if need[0]:
-                    through = torch.matmul(incoming, Q)
-                    at_prev = through if at_prev is None else at_prev.add_(through)
+                    at_prev = torch.matmul(incoming, Q) if at_prev is None else \
+                        torch.baddbmm(at_prev, incoming, Q.unsqueeze(0).expand(B, -1, -1))
             elif need[11] and weight is not None:
                 grads[11] = (weight.sum() * (dx / s_q)).reshape(s_q.shape)
             if need[0]:

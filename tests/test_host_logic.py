@@ -1101,3 +1101,45 @@ def test_settings_are_scoped_by_context_and_keep_the_setters_meaning():
         with settings.override(validation_mode="never"):
             pass
     assert settings.current().history_mode == "lazy" and settings.current().validation_mode == "deferred"
+
+
+def test_the_wide_steps_recomputing_backward_is_float64_autograds():
+    """`_kernels.affine_step_backward_wide` (the backward of a step on rows wider than the fused kernels take: recomputed
+    from x_{t-1}, the ancestors, x_t and the log-weights) is plain tensor algebra around the gather: on CPU float64
+    tensors, with `torch.gather` standing in for K3, every one of its eleven gradients equals autograd of the step
+    written with `torch.distributions` (aesmc/state.py:114-155, :179, aesmc/inference.py:108-130) to 1e-12 — offsets per
+    batch row, shared and absent, the observation, the three scales, with and without a gradient arriving at x_t."""
+    from aesmc_amd import _kernels
+    provider = _kernels.HipKernels.__new__(_kernels.HipKernels)      # (no library needed: the method launches nothing itself)
+    provider.gather = lambda src, idx: torch.gather(src, 1, idx.unsqueeze(-1).expand_as(src))
+    torch.manual_seed(0)
+    B, K, d = 3, 8192, 6
+    make = lambda *shape: torch.randn(*shape, dtype=torch.float64)
+    x_prev, eps, y, glse = make(B, K, d), make(B, K, d), make(B, d), make(B)
+    ancestors = torch.sort(torch.randint(0, K, (B, K)), 1)[0]
+    A, C, Q = (0.3 * make(d, d) for _ in range(3))
+    scales = [torch.tensor(v, dtype=torch.float64) for v in (1.0, 0.5, 0.7)]
+    leaf = lambda t: None if t is None else t.clone().requires_grad_(True)
+    for off_p, off_g, off_q, gx in ((make(d), make(B, d), make(B, d), 1e-2 * make(B, K, d)), (None, None, make(d), None)):
+        moved = leaf(provider.gather(x_prev, ancestors))
+        A_, C_, Q_, y_, op_, og_, oq_ = (leaf(t) for t in (A, C, Q, y, off_p, off_g, off_q))
+        s_ = [leaf(v) for v in scales]
+        row = lambda off: 0 if off is None else (off.unsqueeze(1) if off.dim() == 2 else off)
+        loc_q = moved @ Q_.t() + row(oq_)
+        x_t = loc_q + s_[2] * eps
+        logn = lambda v, loc, scale: torch.distributions.Normal(loc, scale).log_prob(v).sum(2)
+        lw = logn(x_t, moved @ A_.t() + row(op_), s_[0]) + logn(y_.unsqueeze(1), x_t @ C_.t() + row(og_), s_[1]) - \
+            logn(x_t, loc_q, s_[2])
+        lse = torch.logsumexp(lw, 1)
+        ((glse * lse).sum() + (0 if gx is None else (gx * x_t).sum())).backward()
+        need = [True, False, True, True, off_p is not None, True, off_g is not None, True, True, True, True, True]
+        got = provider.affine_step_backward_wide(x_prev, x_t.detach(), y, (A, off_p), (C, off_g), (Q, off_q), scales, need,
+                                                 lw.detach(), lse.detach(), grad_lse=glse, grad_x=gx, ancestors=ancestors)
+        want = {0: moved.grad, 2: y_.grad, 3: A_.grad, 5: C_.grad, 7: Q_.grad, 8: oq_.grad, 9: s_[0].grad, 10: s_[1].grad,
+                11: s_[2].grad}
+        if off_p is not None:
+            want[4], want[6] = op_.grad, og_.grad
+        for slot, reference in want.items():
+            error = float((got[slot].reshape(reference.shape) - reference).abs().max())
+            assert error <= 1e-12 * (1 + float(reference.abs().max())), (slot, error)
+        assert got[1] is None and (off_p is not None or (got[4] is None and got[6] is None))
