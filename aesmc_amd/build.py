@@ -28,6 +28,21 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _depends_on(path, seen=None):
+    """`path` and every file it includes with quotes, transitively (what a translation unit is rebuilt for)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as handle:
+        for line in handle:
+            line = line.strip()
+            if line.startswith("#include \""):
+                _depends_on(os.path.join(os.path.dirname(path), line.split('"')[1]), seen)
+    return seen
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
@@ -53,11 +68,10 @@ def build(force=False, verbose=True):
     flags += extra
     objdir = os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
-    newest_header = max(os.path.getmtime(h) for h in HEADERS)
     jobs = []
     for source in SOURCES:      # one hipcc per translation unit, side by side; unchanged ones are kept
         src, obj = os.path.join(CSRC, source), os.path.join(objdir, source[:-4] + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in _depends_on(src)):
             continue
         cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
         if verbose:
