@@ -69,10 +69,14 @@ __device__ __forceinline__ void wide_stage_weights(const WideArgs &a, float *wl)
   }
 }
 
-// acc[map][mt][nt] += W_map x over all 32 k-steps; bx[nt][s] = x[particle n of tile nt][4 s + g]
+// acc[map][mt][nt] += W_map x over all 32 k-steps; bx[nt][s] = x[particle n of tile nt][4 s + g].
+// ROLLING PREFETCH: the four inputs a k-group consumed are dead once its last product has issued, so the NEXT tile's
+// values for them (next[nt]: that tile's row of particle n, at input g) are sent for right there — eight dword loads per
+// k-group — and have the rest of this tile's products and its element-wise part to arrive (rocprofv3 before: the matrix
+// pipe busy 63 % of the launch, every wavefront waiting 18 600 cycles per tile for its rows in front of the first product).
 template <int NMAPS>
-__device__ __forceinline__ void wide_products(const float *wl, uint32_t lane, const float (&bx)[2][32],
-                                              wd_f4 (&acc)[NMAPS][8][2]) {
+__device__ __forceinline__ void wide_products(const float *wl, uint32_t lane, float (&bx)[2][32], wd_f4 (&acc)[NMAPS][8][2],
+                                              const float *next0, const float *next1) {
   const uint32_t m = lane & 15u, g = lane >> 4;
   const float *wa = wl + m * kWdRow + g * 32;
   // One 16-byte read feeds eight multiply-accumulates (four k-steps x two particle tiles); the NEXT read is sent for
@@ -94,6 +98,13 @@ __device__ __forceinline__ void wide_products(const float *wl, uint32_t lane, co
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
         acc[map][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t], bx[nt][4 * sg + t], acc[map][mt][nt], 0, 0, 0);
+    }
+    if ((idx + 1) % (NMAPS * 8) == 0) {      // this k-group's inputs are spent: the next tile's take their registers
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bx[0][4 * sg + t] = next0[4 * (4 * sg + t)];
+        bx[1][4 * sg + t] = next1[4 * (4 * sg + t)];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
@@ -148,36 +159,72 @@ __global__ __launch_bounds__(kWdThreads, 1) void affine_wide_draw_kernel(WideArg
   PhiloxStream ps = a.ps;
   if constexpr (DRAWN) ps = philox_resolve(a.ps);
   const uint32_t h = n >> 3, Q = a.Q, per_trip = Q / 8;
-  for (int64_t tile = (int64_t)blockIdx.x * (kWdThreads / 64) + wave; tile < tiles; tile += (int64_t)gridDim.x * (kWdThreads / 64)) {
-    // the particle of column n of matrix tile nt; a tile lies inside one batch row (the host: K a multiple of 32, and
-    // of 4 Q when the launch draws)
-    const uint32_t trip = DRAWN ? (uint32_t)(tile / per_trip) : 0u;
-    const uint32_t pb = DRAWN ? ((uint32_t)(tile - (int64_t)trip * per_trip)) * 8u + (n & 7u) : 0u;
-    int64_t part[2];
+  // A tile's rows of x_{t-1} are sent for a tile AHEAD — its ancestor indices before the tile in hand multiplies, its rows
+  // k-group by k-group inside the multiplications as the operand registers fall free (wide_products) — so both memory
+  // round trips pass under this wavefront's own work instead of in front of the next tile's first product.
+  const int64_t tile_stride = (int64_t)gridDim.x * (kWdThreads / 64);
+  auto particles_of = [&](int64_t tile, int64_t (&part)[2], uint32_t &trip, uint32_t &pb) {
+    trip = DRAWN ? (uint32_t)(tile / per_trip) : 0u;
+    pb = DRAWN ? ((uint32_t)(tile - (int64_t)trip * per_trip)) * 8u + (n & 7u) : 0u;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
       part[nt] = DRAWN ? (int64_t)4 * Q * trip + pb + (int64_t)Q * (2 * nt + h) : tile * kWdTile + 16 * nt + n;
-    const uint32_t b = (uint32_t)((DRAWN ? (int64_t)4 * Q * trip : tile * kWdTile) / K);
-    float bx[2][32];
+  };
+  auto batch_row_of = [&](int64_t tile, uint32_t trip) { return (uint32_t)((DRAWN ? (int64_t)4 * Q * trip : tile * kWdTile) / K); };
+  auto rows_of = [&](const int64_t (&part)[2], const int64_t (&anc_in)[2], uint32_t b, const float *(&src)[2]) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const int64_t p = part[nt];
-      int64_t row = p;
+      int64_t row = part[nt];
       if constexpr (GATHER) {
-        int64_t anc = a.anc[p];
+        int64_t anc = anc_in[nt];
         if (anc < 0 || anc >= (int64_t)K) {      // K2 writes K for a degenerate row (flagged there); never fault on it
           bad = 1;
           anc = anc < 0 ? 0 : (int64_t)K - 1;
         }
         row = (int64_t)b * K + anc;
       }
-      const float *src = a.x_in + row * kWd + g;
-#pragma unroll
-      for (int s = 0; s < 32; ++s) bx[nt][s] = src[4 * s];
+      src[nt] = a.x_in + row * kWd + g;
     }
+  };
+  float bx[2][32];
+  int64_t tile = (int64_t)blockIdx.x * (kWdThreads / 64) + wave;
+  if (tile < tiles) {
+    int64_t part0[2], anc0[2] = {0, 0};
+    uint32_t trip0, pb0;
+    particles_of(tile, part0, trip0, pb0);
+    if constexpr (GATHER) {
+      anc0[0] = a.anc[part0[0]];
+      anc0[1] = a.anc[part0[1]];
+    }
+    const float *src0[2];
+    rows_of(part0, anc0, batch_row_of(tile, trip0), src0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int s = 0; s < 32; ++s) bx[nt][s] = src0[nt][4 * s];
+  }
+  for (; tile < tiles; tile += tile_stride) {
+    // the particle of column n of matrix tile nt; a tile lies inside one batch row (the host: K a multiple of 32, and
+    // of 4 Q when the launch draws)
+    uint32_t trip, pb;
+    int64_t part[2];
+    particles_of(tile, part, trip, pb);
+    const uint32_t b = batch_row_of(tile, trip);
+    // the next tile's particles and their ancestors (no branch around loads — the compiler would wait for every load in
+    // flight where the branch ends —: behind the last tile the last tile's are fetched again and dropped)
+    const int64_t tile_next = tile + tile_stride < tiles ? tile + tile_stride : tile;
+    uint32_t trip_next, pb_next;
+    int64_t part_next[2], anc_next[2] = {0, 0};
+    particles_of(tile_next, part_next, trip_next, pb_next);
+    if constexpr (GATHER) {
+      anc_next[0] = a.anc[part_next[0]];
+      anc_next[1] = a.anc[part_next[1]];
+    }
+    const float *src_next[2];
+    rows_of(part_next, anc_next, batch_row_of(tile_next, trip_next), src_next);
     wd_f4 acc[2][8][2];
     wide_offsets<2>(a, b, g, acc);
-    wide_products<2>(wl, lane, bx, acc);
+    wide_products<2>(wl, lane, bx, acc, src_next[0], src_next[1]);
     // ---- the draw and the two squared distances, outputs 16 mt + 4 g + r of the lane's two particles ------------
     float q_sum[2] = {0.0f, 0.0f}, p_sum[2] = {0.0f, 0.0f};
 #pragma unroll
@@ -247,19 +294,27 @@ __global__ __launch_bounds__(kWdThreads, 1) void affine_wide_emission_kernel(Wid
   const float const_g = (float)kWd * (Num<float>::log(s_g) + LgConst<float>::half_log_2pi());
   const int64_t tiles = a.N / kWdTile;
   const uint32_t K = a.K;
-  for (int64_t tile = (int64_t)blockIdx.x * (kWdThreads / 64) + wave; tile < tiles; tile += (int64_t)gridDim.x * (kWdThreads / 64)) {
-    const int64_t n0 = tile * kWdTile;
-    const uint32_t b = (uint32_t)(n0 / K);
-    float bx[2][32];
+  // (the next tile's rows of x_t are sent for k-group by k-group inside this tile's multiplications, as in K17)
+  const int64_t tile_stride = (int64_t)gridDim.x * (kWdThreads / 64);
+  auto rows_load = [&](int64_t tile, float (&bx)[2][32]) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const float *src = a.x_in + (n0 + 16 * nt + n) * kWd + g;
+      const float *src = a.x_in + (tile * kWdTile + 16 * nt + n) * kWd + g;
 #pragma unroll
       for (int s = 0; s < 32; ++s) bx[nt][s] = src[4 * s];
     }
+  };
+  float bx[2][32];
+  int64_t tile = (int64_t)blockIdx.x * (kWdThreads / 64) + wave;
+  if (tile < tiles) rows_load(tile, bx);
+  for (; tile < tiles; tile += tile_stride) {
+    const int64_t n0 = tile * kWdTile;
+    const uint32_t b = (uint32_t)(n0 / K);
+    const int64_t tile_next = tile + tile_stride < tiles ? tile + tile_stride : tile;      // (behind the last tile: fetched again, dropped)
+    const float *next0 = a.x_in + (tile_next * kWdTile + n) * kWd + g, *next1 = next0 + 16 * kWd;
     wd_f4 acc[1][8][2];
     wide_offsets<1>(a, b, g, acc);
-    wide_products<1>(wl, lane, bx, acc);
+    wide_products<1>(wl, lane, bx, acc, next0, next1);
     wd_f4 yv[8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) yv[mt] = *reinterpret_cast<const wd_f4 *>(a.y + (int64_t)b * a.y_sb + 16 * mt + 4 * g);

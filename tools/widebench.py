@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aesmc_amd  # noqa: E402,F401
-from aesmc_amd import _kernels  # noqa: E402
+from aesmc_amd import _kernels, _philox  # noqa: E402
 from tools.lgbench import graph_time  # noqa: E402
 
 
@@ -35,6 +35,10 @@ def main(B, K):
     terms = ((A, None), (C, off_g), (Q, off_q))
     t_wide = graph_time(lambda: k.affine_propagate_wide(x, eps, y, *terms, scales, out_x, ancestors=anc))
     assert k.affine_propagate_wide(x, eps, y, *terms, scales, out_x, ancestors=anc) is not None
+    res = _philox.reserve(B * K * d, dev)
+    t_drawn = None
+    if k.affine_propagate_wide(x, res, y, *terms, scales, out_x, ancestors=anc) is not None:
+        t_drawn = graph_time(lambda: k.affine_propagate_wide(x, res, y, *terms, scales, out_x, ancestors=anc))
 
     def pieces():
         moved = k.gather(x, anc)
@@ -49,6 +53,8 @@ def main(B, K):
     print("B={} K={} d={}: K17 + K18 {:.1f} us = {:.1f} TFLOP/s fp32 on the matrix cores, {:.2f} TB/s of {:.0f} MB; gather + three "
           "GEMMs + adds + draw (no log-weight kernel) {:.1f} us".format(B, K, d, t_wide, flops / t_wide / 1e6,
                                                                        nbytes / t_wide / 1e6, nbytes / 1e6, t_pieces), flush=True)
+    if t_drawn is not None:
+        print("   with the noise formed in the launch: {:.1f} us = {:.1f} TFLOP/s".format(t_drawn, flops / t_drawn / 1e6), flush=True)
 
 
 if __name__ == "__main__":
