@@ -142,7 +142,7 @@ __device__ __forceinline__ float wide_particle_sum(float v, uint32_t lane) {
 // call's four normals all land in this wavefront: the two lanes n and n ^ 8 that hold the same outputs of the same
 // eight particles share the calls (two of a group's four outputs each) and swap what the other needs.
 template <bool GATHER, bool DRAWN>
-__global__ __launch_bounds__(kWdThreads, 1) void affine_wide_draw_kernel(WideArgs a) {
+__global__ __launch_bounds__(kWdThreads, 2) void affine_wide_draw_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wd_smem[];
   float *wl = reinterpret_cast<float *>(wd_smem);
   wide_stage_weights<2>(a, wl);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kWdThreads, 1) void affine_wide_draw_kernel(WideArg
 }
 
 // K18
-__global__ __launch_bounds__(kWdThreads, 1) void affine_wide_emission_kernel(WideArgs a) {
+__global__ __launch_bounds__(kWdThreads, 2) void affine_wide_emission_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wd_smem[];
   float *wl = reinterpret_cast<float *>(wd_smem);
   wide_stage_weights<1>(a, wl);
