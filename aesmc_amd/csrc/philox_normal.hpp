@@ -67,9 +67,16 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    // (a ^ b ^ c in one instruction: v_bitop3_b32 with the truth table of a three-way exclusive or — gfx950; the compiler
+    //  writes two v_xor_b32)
+#if defined(__HIP_DEVICE_COMPILE__)
+    c0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
+    c2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+#else
     c0 = hi1 ^ c1 ^ k0;
-    c1 = lo1;
     c2 = hi0 ^ c3 ^ k1;
+#endif
+    c1 = lo1;
     c3 = lo0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
