@@ -395,8 +395,8 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
     observations = model.simulate(T, global_B, seed=1)          # same data on every rank ...
     observations = distributed.shard_observations(observations, rank, world)  # ... own rows only
     parts = (model.initial, model.transition, model.emission, model.proposal)
-    np.random.seed(0)
-    torch.manual_seed(0)
+    np.random.seed(0)             # the same on every rank: the resampler draws the global uniform block and keeps its rows
+    torch.manual_seed(rank)       # different per rank: independent proposal noise (rank 0: the single-GPU run's stream)
 
     if mode is None:      # small per-step sizes are host-bound in the eager loop
         mode = "graph" if (local_B * K <= GRAPH_PARTICLES and name not in NO_GRAD) else "eager"
