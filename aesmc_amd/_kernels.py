@@ -1403,7 +1403,7 @@ class HipKernels:
         (x_prev, x, y_rows, A, off_p, C, off_g, Q, off_q, s_p, s_g, s_q) — x's own slot is always None: the
         gradient `grad_x` that arrives at x from later steps and the step's own gradient at x travel on
         through the draw inside the kernel (K12 + K11 + the accumulations between them, one pass).
-        `chain` (a dict, only through ancestors): {"carry": (workspace, records) of the step run before this one with the
+        `chain` (a dict, only through ancestors): {"carry": (workspace, records[, pairs address, pairs' holder]) of the step run before this one with the
         SAME A, C, Q and scales, or None; "defer": leave this step's sums for those parameters as records}.  A
         deferring call returns None in their slots and sets chain["left"] = (workspace, records) for the next call
         to carry; a carrying call's gradients for them include everything carried.  Where the kernel declines the
@@ -1483,8 +1483,11 @@ class HipKernels:
             tail = (ctypes.byref(outs), _ptr(ws), ws_bytes)
             link = None
             if chain is not None:
+                # (carry[2], carry[3]: where the run's interleaved weight pairs lie and the workspace that holds them — built by
+                #  the run's first call, handed on from step to step instead of one small launch per step)
+                pairs_in = carry[2] if carry is not None and len(carry) > 2 and carry[2] else 0
                 link = _lib.AffineChain(_ptr(carry[0]) if carry is not None else 0, carry[1] if carry is not None else 0,
-                                        (2 if (need[9] or need[10] or need[11]) else 1) if defer else 0, 0)
+                                        (2 if (need[9] or need[10] or need[11]) else 1) if defer else 0, 0, pairs_in, 0)
             if ancestors is not None:
                 entry = self._lib.aesmc_affine_step_backward_resampled
                 args = (tag, _ptr(x_prev), _ptr(ancestors)) + middle + (_ptr(child_grad), _ptr(child_end)) + tail + \
@@ -1511,7 +1514,8 @@ class HipKernels:
                 return grads
             _lib.check(status, "aesmc_affine_step_backward")
             if defer:
-                chain["left"] = (ws, int(link.records))
+                handed_on = carry is not None and len(carry) > 2 and carry[2] and link.pairs_out == carry[2]
+                chain["left"] = (ws, int(link.records), link.pairs_out or 0, carry[3] if handed_on else ws)
             if self.timer is not None:
                 nbytes = x.element_size() * B * K * (2 * dx + 1 + (dx if grad_x is not None else 0) +
                                                      (dx if gx_prev is not None else 0))
@@ -1634,7 +1638,7 @@ class HipKernels:
     def affine_backward_collect(self, left, dtype, device, dx, dy, need, scales):
         """The weights' and scales' gradients (a 12-slot list like affine_step_backward's, None elsewhere) out of the
         records a deferring K14 call left — `left` = its chain["left"] — when no later call carried them on."""
-        ws, records = left
+        ws, records = left[0], left[1]      # (+ where the run's weight pairs lie and their holder: not needed here)
         make = lambda shape, wanted: torch.empty(shape, dtype=dtype, device=device) if wanted else None
         gA, gC, gQ = make((dx, dx), need[3]), make((dy, dx), need[5]), make((dx, dx), need[7])
         gscales = make((3,), need[9] or need[10] or need[11])

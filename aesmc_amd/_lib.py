@@ -50,7 +50,7 @@ class AffineLogweightGrads(ctypes.Structure):
 class AffineChain(ctypes.Structure):
     """`aesmc_affine_chain` of include/aesmc_hip.h: how K14's weight gradients join those of the steps around it."""
     _fields_ = [("carry", ctypes.c_void_p), ("carry_records", ctypes.c_int32), ("defer", ctypes.c_int32),
-                ("records", ctypes.c_int32)]
+                ("records", ctypes.c_int32), ("pairs_in", ctypes.c_void_p), ("pairs_out", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/aesmc_hip.h one to one.

@@ -1136,6 +1136,12 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
     const size_t used = (need * sizeof(T) + 15) & ~(size_t)15;
     out.pairs = ws_bytes >= used + 3 * kLgPairFloats * sizeof(float) ? reinterpret_cast<float *>(static_cast<char *>(ws) + used)
                                                                      : nullptr;
+    out.pairs_ready = 0;
+    if (chain != nullptr && chain->pairs_in != nullptr) {      // an earlier call of this run of steps built them
+      out.pairs = static_cast<float *>(const_cast<void *>(chain->pairs_in));
+      out.pairs_ready = 1;
+    }
+    if (chain != nullptr) chain->pairs_out = nullptr;
   }
   if (chain != nullptr && !step) return AESMC_ERR_UNSUPPORTED;
   if ((child_grad != nullptr) != (child_end != nullptr) || (child_grad != nullptr && !step)) return AESMC_ERR_UNSUPPORTED;
@@ -1154,6 +1160,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
           static_cast<const float *>(grad_lse), static_cast<const float *>(grad_lw), out, N, (uint32_t)K, (unsigned)grid,
           stream);
       if (status != AESMC_OK) return status;
+      if (chain != nullptr && affine_step_backward_rows_pairs()) chain->pairs_out = out.pairs;
     }
   } else if (step && dx == dp && dy == dp) {
     LG_DISPATCH(affine_step_backward_exact, T, dp, ppl, dim3((unsigned)grid), lds, stream, LG_BACKWARD_ARGS);

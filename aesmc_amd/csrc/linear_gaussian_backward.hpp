@@ -102,6 +102,7 @@ struct LgBackwardOut {
   // step kernel, rows form: room behind the records and row sums for the three maps' interleaved weight pairs (3 x
   // kLgPairFloats floats; nullptr: a workspace of the older size — the location chains then run one output at a time)
   float *pairs;
+  int pairs_ready;      // the pairs at `pairs` are an earlier call's of the same run (aesmc_affine_chain::pairs_in): not rebuilt
 };
 constexpr int kLgPairFloats = (kLgMaxDim / 2) * kLgMaxDim * 2;      // (== kPairFloats of linear_gaussian_fused.hpp)
 
@@ -113,6 +114,7 @@ constexpr int kLgChildTrip = 1;     // of them per trip out of the staged block 
 bool affine_step_backward_rows_covers(const aesmc_affine_map *mp, const aesmc_affine_map *mg, const aesmc_affine_map *mq,
                                       int64_t B, int64_t K);
 unsigned affine_step_backward_rows_grid(int64_t B, int64_t K, int64_t d);
+bool affine_step_backward_rows_pairs();      // does the rows form take the interleaved weight pairs?
 int affine_step_backward_forced_grid();      // test hook: > 0 pins the grid of both forms
 int launch_affine_step_backward_rows(const float *xprev, const float *x, const float *y, int64_t y_sb, const LgMap &mp,
                                      const LgMap &mg, const LgMap &mq, const float *sp, const float *sg, const float *sq,

@@ -759,6 +759,12 @@ static void sb_launch_either(bool paired, bool gathers, bool folds, unsigned gri
   else sb_launch<D, false>(gathers, folds, grid, stream, a, ok);
 }
 
+// does the rows form take the maps' interleaved weight pairs (AESMC_K14_PAIRS=0 in the environment: a measurement knob)?
+bool affine_step_backward_rows_pairs() {
+  static const bool no_pairs = [] { const char *v = getenv("AESMC_K14_PAIRS"); return v != nullptr && v[0] == '0'; }();
+  return kSbPacked && !no_pairs;
+}
+
 int launch_affine_step_backward_rows(const float *xprev, const float *x, const float *y, int64_t y_sb, const LgMap &mp,
                                      const LgMap &mg, const LgMap &mq, const float *sp, const float *sg, const float *sq,
                                      const float *lw, const float *lse, const float *grad_lse, const float *grad_lw,
@@ -788,11 +794,12 @@ int launch_affine_step_backward_rows(const float *xprev, const float *x, const f
 #endif
   // the chains' weights as interleaved pairs, written into the workspace's tail by a small launch in front of this one (the
   // weights may have been stepped since the last call; inside a hipGraph capture the rebuild is captured with it)
-  static const bool no_pairs = [] { const char *v = getenv("AESMC_K14_PAIRS"); return v != nullptr && v[0] == '0'; }();
-  const bool paired = kSbPacked && !no_pairs && out.pairs != nullptr;
+  const bool paired = affine_step_backward_rows_pairs() && out.pairs != nullptr;
   if (paired) {
-    const int status = launch_affine_weight_pairs(mp, mg, mq, out.pairs, stream);
-    if (status != AESMC_OK) return status;
+    if (!out.pairs_ready) {      // (a run of steps shares its weights: its first call builds them, the others are handed them)
+      const int status = launch_affine_weight_pairs(mp, mg, mq, out.pairs, stream);
+      if (status != AESMC_OK) return status;
+    }
     a.pairs = out.pairs;
   }
   bool ok = true;

@@ -50,6 +50,7 @@ extern "C" {
  *                (aesmc_test_*); aesmc_affine_normal_propagate_drawn keeps its signature and now runs the fused launch
  *                (gather + noise + draw + log-weight terms in one kernel); added aesmc_affine_normal_propagate_wide
  *                (+ aesmc_affine_wide_dim, aesmc_affine_wide_workspace_bytes).
+ *   400 (0.4.0)  aesmc_affine_chain grew `pairs_in` / `pairs_out` (a run of backward steps builds the weight pairs once)
  *   300 (0.3.0)  added aesmc_affine_normal_propagate_drawn_paired, aesmc_affine_weight_pairs,
  *                aesmc_affine_weight_pairs_floats (round 5: packed multiply-adds in the fused propagation launch). */
 int aesmc_version(void);
@@ -545,6 +546,11 @@ typedef struct {
   int32_t carry_records;  /* in: how many records it holds (what that call left in `records`) */
   int32_t defer;          /* in: non-zero = leave this call's sums as records in `ws` (2: the scales' among them) */
   int32_t records;        /* out: records this call left in `ws` */
+  const void *pairs_in;   /* in: the three maps' interleaved weight pairs as an EARLIER call of this run left them in
+                           *     `pairs_out` (the same weights: a run shares them), or NULL: this call writes its own into
+                           *     its workspace's tail (one small launch in front) */
+  void *pairs_out;        /* out: where the pairs this call used lie (its own, or `pairs_in` handed on), NULL if it used
+                           *      none; valid while the workspace that holds them is */
 } aesmc_affine_chain;
 int aesmc_affine_step_backward_resampled(
     int dtype, const void *x_src, const int64_t *ancestors, const void *x, const void *y, int64_t y_stride_b,

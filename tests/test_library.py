@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in names:
         getattr(raw, name)
-    assert lib.aesmc_version() == 300
+    assert lib.aesmc_version() == 400
     assert lib.aesmc_target_arch() == b"gfx950"
     assert lib.aesmc_ancestor_index_lds_max_particles() >= 16384
     assert lib.aesmc_workspace_bytes(4, 1024) == 0
