@@ -924,6 +924,9 @@ def test_steps_that_share_their_parameters_finish_their_gradients_once(kernels, 
     chain = {"carry": left, "defer": True}
     middle = earlier["call"](chain)
     assert all(middle[names.index(name)] is None for name in shared)
+    # the run's interleaved weight pairs are built by its first call and handed on with the records (rows form only)
+    if len(left) > 2 and left[2]:
+        assert chain["left"][2] == left[2] and chain["left"][3] is left[3], "the pairs were rebuilt instead of handed on"
     both = kernels.affine_backward_collect(chain["left"], deferred[0].dtype, hip_device, dx, dy, need,
                                            (earlier["o"]["s_p"], earlier["o"]["s_g"], earlier["o"]["s_q"]))
     for name, got, want in zip(names, both, results[0]):
