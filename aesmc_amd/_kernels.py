@@ -1542,6 +1542,64 @@ class HipKernels:
                 grads[slot] = gscales[slot - 9].reshape(s.shape)
         return grads
 
+    @property
+    def wide_dim(self):
+        if self._wide_dim is None:
+            self._wide_dim = int(self._lib.aesmc_affine_wide_dim())
+        return self._wide_dim
+
+    @property
+    def wide_adjoint_tile(self):
+        tile = getattr(self, "_wide_adjoint_tile", None)
+        if tile is None:
+            tile = self._wide_adjoint_tile = int(self._lib.aesmc_wide_adjoint_tile())
+        return tile
+
+    def _wide_adjoint_covers(self, u, weight, scale):
+        """Do aesmc_wide_adjoint_scale / _merge take these operands (rows of 128 float32 values, dense, whole tiles)?"""
+        return (u.dtype == torch.float32 and u.dim() == 3 and u.size(2) == self.wide_dim and u.is_contiguous() and
+                u.size(1) % self.wide_adjoint_tile == 0 and u.numel() > 0 and weight.dtype == torch.float32 and
+                weight.shape == u.shape[:2] and weight.is_contiguous() and scale.dtype == torch.float32 and
+                scale.numel() == 1 and u.data_ptr() % 16 == 0)
+
+    def wide_adjoint_scale(self, u, weight, scale, want_sq, want_rows, base=None):
+        """`u` [B,K,128] (a residual d — or, `base` [B,128] given, the location, d = base[b] - u — overwritten by the
+        location's adjoint weight d / scale^2) -> (sum_j d_j^2 [B,K] or None, the adjoint summed over each batch row's
+        particles [B,128] or None): aesmc_wide_adjoint_scale."""
+        B, K, d = u.shape
+        sq = torch.empty((B, K), dtype=torch.float32, device=u.device) if want_sq else None
+        tiles = K // self.wide_adjoint_tile
+        rows = torch.empty((B, tiles, d), dtype=torch.float32, device=u.device) if want_rows else None
+        with _on_device(u.device):
+            args = (_ptr(u), _ptr(weight), _ptr(scale), _ptr(base), base.stride(0) if base is not None else 0, _ptr(sq),
+                    _ptr(rows), B, K, self._stream(u))
+            _lib.check(self._lib.aesmc_wide_adjoint_scale(*args), "aesmc_wide_adjoint_scale")
+            if self.timer is not None:
+                self.timer.note("wide_adjoint_scale", (self._lib.aesmc_wide_adjoint_scale, args), 8 * u.numel(),
+                                (u, weight, scale, sq, rows, base))
+        return sq, (rows.sum(1) if rows is not None else None)
+
+    def wide_adjoint_merge(self, u_p, at_x, weight, scale, want_sq, want_rows_p, want_rows_x, value=None, base=None,
+                           add=None):
+        """The transition's residual d in `u_p` (or, `value` [B,K,128] given, its location: d = (value - base[b]) - u_p, base
+        [B,128] or None) and the gradient arriving at x_t in `at_x` (plus `add`, if given), both [B,K,128] and overwritten:
+        u_p <- weight d / scale^2, at_x <- (add + at_x) - u_p; returns (sum_j d_j^2 [B,K], u_p's and at_x's sums over each batch row's particles
+        [B,128]), None where not wanted: aesmc_wide_adjoint_merge."""
+        B, K, d = u_p.shape
+        tiles = K // self.wide_adjoint_tile
+        sq = torch.empty((B, K), dtype=torch.float32, device=u_p.device) if want_sq else None
+        rows_p = torch.empty((B, tiles, d), dtype=torch.float32, device=u_p.device) if want_rows_p else None
+        rows_x = torch.empty((B, tiles, d), dtype=torch.float32, device=u_p.device) if want_rows_x else None
+        with _on_device(u_p.device):
+            args = (_ptr(u_p), _ptr(at_x), _ptr(weight), _ptr(scale), _ptr(value), _ptr(base),
+                    base.stride(0) if base is not None else 0, _ptr(add), _ptr(sq), _ptr(rows_p), _ptr(rows_x), B, K,
+                    self._stream(u_p))
+            _lib.check(self._lib.aesmc_wide_adjoint_merge(*args), "aesmc_wide_adjoint_merge")
+            if self.timer is not None:
+                self.timer.note("wide_adjoint_merge", (self._lib.aesmc_wide_adjoint_merge, args), 16 * u_p.numel(),
+                                (u_p, at_x, weight, scale, sq, rows_p, rows_x, value, base, add))
+        return sq, (rows_p.sum(1) if rows_p is not None else None), (rows_x.sum(1) if rows_x is not None else None)
+
     def affine_step_backward_wide(self, x_prev, x, y_rows, transition, emission, proposal, scales, need, lw, lse,
                                   grad_lse=None, grad_x=None, grad_lw=None, ancestors=None):
         """`affine_step_backward` for rows wider than the fused kernels take (BASELINE.json configs[4]: 128 values): the
@@ -1581,35 +1639,75 @@ class HipKernels:
             incoming = grad_x      # what arrives at x_t from later steps
             grads = [None] * 12
             at_prev = None
+            rows_x = None
             if weight is not None:
                 g = weight.unsqueeze(2)
                 # emission: u_g = g (y - loc_g) / s_g^2 — its gradient reaches C, its offset, y, s_g and x_t (C^T u_g)
-                u_g = residual(y_rows.unsqueeze(1), x, C, off_g)
-                if need[10]:
-                    grads[10] = (weight * (u_g.square().sum(2) / s_g ** 3 - dy / s_g)).sum().reshape(s_g.shape)
-                u_g.mul_(g / (s_g * s_g))
+                weight = weight.contiguous()
+                want_rows_g = (need[6] and off_g is not None) or need[2]
+                fused = dx == dy and x.is_contiguous() and moved.is_contiguous() and \
+                    self._wide_adjoint_covers(x, weight, s_g) and self._wide_adjoint_covers(x, weight, s_p)
+                rows_g = None
+                if fused:
+                    # the location by a plain product, then ONE pass (K19): d = (y - offset)[b] - location formed there (no
+                    # [B,K,128] copy of the broadcast row for an epilogue to start from), the adjoint in place, sum_j d_j^2
+                    # per particle, the rows' sums
+                    base_g = y_rows if off_g is None else y_rows - off_g
+                    base_g = base_g.contiguous()
+                    u_g = torch.matmul(x, C.t())
+                    sq_g, rows_g = self.wide_adjoint_scale(u_g, weight, s_g, need[10], want_rows_g, base=base_g)
+                    if need[10]:
+                        grads[10] = (weight * (sq_g / s_g ** 3 - dy / s_g)).sum().reshape(s_g.shape)
+                else:
+                    u_g = residual(y_rows.unsqueeze(1), x, C, off_g)
+                    if need[10]:
+                        grads[10] = (weight * (u_g.square().sum(2) / s_g ** 3 - dy / s_g)).sum().reshape(s_g.shape)
+                    u_g.mul_(g / (s_g * s_g))
                 if need[5]:
                     grads[5] = outer_sum(u_g, x)
-                if (need[6] and off_g is not None) or need[2]:
-                    rows_g = u_g.sum(1)
+                if want_rows_g:
+                    if rows_g is None:
+                        rows_g = u_g.sum(1)
                     if need[6] and off_g is not None:
                         grads[6] = rows_g if off_g.dim() == 2 else rows_g.sum(0)
                     if need[2]:
                         grads[2] = -rows_g
-                # what arrives at x_t: later steps' gradient + C^T u_g - u_p, accumulated in the products' epilogues
-                at_x = torch.matmul(u_g, C) if incoming is None else \
-                    torch.baddbmm(incoming, u_g, C.unsqueeze(0).expand(B, -1, -1))
+                # what arrives at x_t: later steps' gradient + C^T u_g - u_p — in K19's one pass where it runs, else
+                # accumulated in the products' epilogues
+                later = None
+                if fused and incoming is not None and incoming.is_contiguous() and incoming.dtype == torch.float32 and \
+                        incoming.data_ptr() % 16 == 0:
+                    later, at_x = incoming, torch.matmul(u_g, C)
+                else:
+                    at_x = torch.matmul(u_g, C) if incoming is None else \
+                        torch.baddbmm(incoming, u_g, C.unsqueeze(0).expand(B, -1, -1))
                 del u_g
                 # transition: u_p = g (x_t - loc_p) / s_p^2 — reaches A, its offset, s_p, x_{t-1} (A^T u_p) and x_t (- u_p)
-                u_p = residual(x, moved, A, off_p)
-                if need[9]:
-                    grads[9] = (weight * (u_p.square().sum(2) / s_p ** 3 - dx / s_p)).sum().reshape(s_p.shape)
-                u_p.mul_(g / (s_p * s_p))
-                at_x.sub_(u_p)
+                rows_x = None
+                if fused and at_x.is_contiguous():
+                    # the location by a plain product, then one pass over it, x_t and at_x (K19): d = (x_t - offset) -
+                    # location, u_p and at_x in place, sum_j d_j^2, both tensors' row sums
+                    u_p = torch.matmul(moved, A.t())
+                    sq_p, rows_p, rows_x = self.wide_adjoint_merge(
+                        u_p, at_x, weight, s_p, need[9], need[4] and off_p is not None, need[8] and off_q is not None,
+                        value=x, base=None if off_p is None else (off_p if off_p.dim() == 2 else off_p.unsqueeze(0).expand(B, -1)).contiguous(),
+                        add=later)
+                    if need[9]:
+                        grads[9] = (weight * (sq_p / s_p ** 3 - dx / s_p)).sum().reshape(s_p.shape)
+                    if need[4] and off_p is not None:
+                        grads[4] = rows_p if off_p.dim() == 2 else rows_p.sum(0)
+                else:
+                    if later is not None:
+                        at_x.add_(later)
+                    u_p = residual(x, moved, A, off_p)
+                    if need[9]:
+                        grads[9] = (weight * (u_p.square().sum(2) / s_p ** 3 - dx / s_p)).sum().reshape(s_p.shape)
+                    u_p.mul_(g / (s_p * s_p))
+                    at_x.sub_(u_p)
+                    if need[4] and off_p is not None:
+                        grads[4] = rows(u_p, off_p)
                 if need[3]:
                     grads[3] = outer_sum(u_p, moved)
-                if need[4] and off_p is not None:
-                    grads[4] = rows(u_p, off_p)
                 if need[0]:
                     at_prev = torch.matmul(u_p, A)
                 del u_p
@@ -1619,7 +1717,10 @@ class HipKernels:
                 if need[7]:
                     grads[7] = outer_sum(incoming, moved)
                 if need[8] and off_q is not None:
-                    grads[8] = rows(incoming, off_q)
+                    if weight is not None and rows_x is not None:
+                        grads[8] = rows_x if off_q.dim() == 2 else rows_x.sum(0)
+                    else:
+                        grads[8] = rows(incoming, off_q)
                 if need[11]:
                     noise_times_scale = residual(x, moved, Q, off_q)       # s_q eps
                     value = (incoming * noise_times_scale).sum() / s_q
@@ -1627,8 +1728,9 @@ class HipKernels:
                         value = value + weight.sum() * (dx / s_q)      # - d log q / d s_q = + d / s_q per particle
                     grads[11] = value.reshape(s_q.shape)
                 if need[0]:
+                    # (at_prev is this function's own product: accumulated in place — an out-of-place baddbmm copies it first)
                     at_prev = torch.matmul(incoming, Q) if at_prev is None else \
-                        torch.baddbmm(at_prev, incoming, Q.unsqueeze(0).expand(B, -1, -1))
+                        at_prev.baddbmm_(incoming, Q.unsqueeze(0).expand(B, -1, -1))
             elif need[11] and weight is not None:
                 grads[11] = (weight.sum() * (dx / s_q)).reshape(s_q.shape)
             if need[0]:

@@ -103,6 +103,9 @@ SIGNATURES = {
     "aesmc_affine_weight_pairs_floats": (_i64, []),
     "aesmc_affine_weight_pairs": (_i32, [_map_p, _map_p, _map_p, _vp, _vp]),
     "aesmc_affine_wide_dim": (_i64, []),
+    "aesmc_wide_adjoint_tile": (_i64, []),
+    "aesmc_wide_adjoint_scale": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
+    "aesmc_wide_adjoint_merge": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_wide_workspace_bytes": (_sz, [_i64, _i64]),
     "aesmc_affine_normal_propagate_wide": (_i32, [_vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp, _vp,
                                                   _vp, _sz, _vp, _i64, _i64, _u64, _u64, _i64, _vp, _vp]),

@@ -50,7 +50,8 @@ extern "C" {
  *                (aesmc_test_*); aesmc_affine_normal_propagate_drawn keeps its signature and now runs the fused launch
  *                (gather + noise + draw + log-weight terms in one kernel); added aesmc_affine_normal_propagate_wide
  *                (+ aesmc_affine_wide_dim, aesmc_affine_wide_workspace_bytes).
- *   400 (0.4.0)  aesmc_affine_chain grew `pairs_in` / `pairs_out` (a run of backward steps builds the weight pairs once)
+ *   400 (0.4.0)  aesmc_affine_chain grew `pairs_in` / `pairs_out` (a run of backward steps builds the weight pairs once);
+ *                added aesmc_wide_adjoint_tile, aesmc_wide_adjoint_scale, aesmc_wide_adjoint_merge
  *   300 (0.3.0)  added aesmc_affine_normal_propagate_drawn_paired, aesmc_affine_weight_pairs,
  *                aesmc_affine_weight_pairs_floats (round 5: packed multiply-adds in the fused propagation launch). */
 int aesmc_version(void);
@@ -445,6 +446,31 @@ int aesmc_affine_normal_propagate_wide(
     const void *scale_p, const void *scale_g, const void *scale_q, void *out_x, void *out_lw, void *ws, size_t ws_bytes,
     int32_t *flags, int64_t B, int64_t K, uint64_t seed, uint64_t offset, int64_t threads, const uint64_t *rng_state,
     void *stream);
+
+/* The element-wise parts of the WIDE step's backward (rows of aesmc_affine_wide_dim() = 128 float32 values), between the
+ * [B K,128] x [128,128] products a binder runs through its GEMM library — autograd of aesmc/state.py:114-155 (`log_prob` of
+ * the emission and the transition) and :98 (the reparameterised draw) for one timestep, recomputed from x_{t-1}, the
+ * ancestors, x_t and the log-weights:
+ *   aesmc_wide_adjoint_scale: `u` [B,K,128] holds a residual d = value - location (a product's epilogue) — or, with
+ *     `base` [B,128] (row stride base_stride_b, a multiple of 4) given, the LOCATION itself, and d = base[b] - u (base = the
+ *     value's row minus the map's offset: no [B,K,128] copy of a broadcast row for a product's epilogue to start from); in place
+ *     u <- weight[b,k] d / scale^2  (the location's adjoint; weight = the gradient arriving at the particle's log-weight),
+ *     out_sq[b,k] = sum_j d_j^2  (the scale's gradient is weight (out_sq / scale^3 - 128 / scale) summed),
+ *     out_rows[b, tile, :] = the new u summed over a tile of aesmc_wide_adjoint_tile() = 256 particles (the offset's
+ *     gradient is their sum over a row's K / 256 tiles).  out_sq / out_rows may be NULL.
+ *   aesmc_wide_adjoint_merge: the same for the transition's residual in `u_p` (or, `value` [B,K,128] given, its LOCATION:
+ *     d = (value - base[b]) - u_p, base NULL or as above), and the gradient arriving at x_t in `at_x` takes the term the
+ *     transition's density contributes: at_x <- (add + at_x) - u_p (`add` [B,K,128]: what later steps sent to x_t, or NULL);
+ *     out_rows_x holds the tiles' sums of the new at_x (the
+ *     proposal's offset: the draw carries what arrives at x_t to it).
+ * One read and one write per tensor where the PyTorch operations they replace made eight passes and three copies.  float32,
+ * dense, 16-byte aligned, K a multiple of 256 (else AESMC_ERR_UNSUPPORTED: the caller keeps its own operations). */
+int64_t aesmc_wide_adjoint_tile(void);      /* 256 */
+int aesmc_wide_adjoint_scale(void *u, const void *weight, const void *scale, const void *base, int64_t base_stride_b,
+                             void *out_sq, void *out_rows, int64_t B, int64_t K, void *stream);
+int aesmc_wide_adjoint_merge(void *u_p, void *at_x, const void *weight, const void *scale, const void *value,
+                             const void *base, int64_t base_stride_b, const void *add, void *out_sq, void *out_rows_p,
+                             void *out_rows_x, int64_t B, int64_t K, void *stream);
 
 /* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
  *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])
