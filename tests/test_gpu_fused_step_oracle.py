@@ -556,3 +556,47 @@ def test_a_wide_model_trains_through_the_matrix_core_step(hip_device, monkeypatc
     free_loss, free_grads, _, _ = run(False, T)
     assert abs(wide_loss - free_loss) <= 2e-3 * abs(free_loss)
     assert all(bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0 for g in wide_grads.values())
+
+
+# ---- K19: the wide backward's element-wise parts (linear_gaussian_wide_backward.hip) against the PyTorch operations they replace ----
+@pytest.mark.parametrize("shape", [(2, 512), (3, 4096), (1, 256)])
+@pytest.mark.parametrize("with_base", [False, True])
+def test_the_wide_adjoints_elementwise_launches_equal_the_pytorch_operations(kernels, hip_device, shape, with_base):
+    """aesmc_wide_adjoint_scale / _merge — residual, adjoint in place, sum_j d_j^2, the rows' sums, the arriving gradient
+    merged — against the same steps written with PyTorch operations (autograd of aesmc/state.py:114-155 between the
+    products): the element-wise results bit for bit (the same float32 operations in the same order), the sums to
+    float32 rounding of another association."""
+    B, K = shape
+    d = 128
+    gen = torch.Generator(device=hip_device).manual_seed(B * 1000 + K)
+    make = lambda *s: torch.randn(*s, device=hip_device, generator=gen)
+    weight, scale = make(B, K).abs() * 1e-3, torch.tensor(0.7, device=hip_device)
+    loc, base = make(B, K, d), make(B, d)
+    u = loc.clone()
+    sq, rows = kernels.wide_adjoint_scale(u, weight, scale, True, True, base=base if with_base else None)
+    resid = (base.unsqueeze(1) - loc) if with_base else loc
+    want_u = resid * (weight / (scale * scale)).unsqueeze(2)
+    assert torch.equal(u, want_u)
+    assert torch.allclose(sq, resid.square().sum(2), rtol=2e-6, atol=0)
+    assert torch.allclose(rows, want_u.sum(1), rtol=1e-5, atol=1e-6 * float(want_u.abs().max()) * (K ** 0.5))
+    # the merge: location, value, offsets' rows, what later steps sent
+    loc_p, value, arriving, later = make(B, K, d), make(B, K, d), make(B, K, d), make(B, K, d)
+    u_p, at_x = loc_p.clone(), arriving.clone()
+    sq_p, rows_p, rows_x = kernels.wide_adjoint_merge(u_p, at_x, weight, scale, True, True, True, value=value,
+                                                      base=base if with_base else None, add=later if with_base else None)
+    resid = (value - base.unsqueeze(1)) - loc_p if with_base else value - loc_p
+    want_p = resid * (weight / (scale * scale)).unsqueeze(2)
+    want_x = ((later + arriving) if with_base else arriving) - want_p
+    assert torch.equal(u_p, want_p)
+    assert torch.equal(at_x, want_x)
+    assert torch.allclose(sq_p, resid.square().sum(2), rtol=2e-6, atol=0)
+    bound = lambda t: 1e-6 * float(t.abs().max()) * (K ** 0.5)
+    assert torch.allclose(rows_p, want_p.sum(1), rtol=1e-5, atol=bound(want_p))
+    assert torch.allclose(rows_x, want_x.sum(1), rtol=1e-5, atol=bound(want_x))
+    # a residual already formed (no value): the kernel takes u_p as it comes
+    u_q, at_q = loc_p.clone(), arriving.clone()
+    kernels.wide_adjoint_merge(u_q, at_q, weight, scale, False, False, False)
+    assert torch.equal(u_q, loc_p * (weight / (scale * scale)).unsqueeze(2))
+    assert torch.equal(at_q, arriving - u_q)
+    # rows that are not whole tiles: declined by the wrapper's test, the caller keeps its PyTorch operations
+    assert not kernels._wide_adjoint_covers(make(2, 384, d), make(2, 384), scale)
