@@ -33,12 +33,13 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
     const int64_t *__restrict__ anc_idx, int32_t *flags, PhiloxStream ps_in, FusedPlan plan) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr uint32_t dx = DXC;
+  constexpr uint32_t kRunStride = kRunP * (uint32_t)DXC + 4u;      // floats between two windows' areas of the noise tile
   constexpr int DPX = 4 * ((DXC + 3) / 4);
   constexpr int DPY = DYC != 0 ? 4 * ((DYC + 3) / 4) : 16;
   const uint32_t dy = DYC != 0 ? (uint32_t)DYC : (uint32_t)mg.dout;
   extern __shared__ __attribute__((aligned(16))) unsigned char item_smem[];
   float *tab = reinterpret_cast<float *>(item_smem);            // [kTabF]: [window][batch row 0 / 1][p, q, g, y][16]
-  float *noise = tab + kTabF;                                   // [plan.tile_f]: window i's run at i * kRunP * dx, rows end to end
+  float *noise = tab + kTabF;                                   // [4][kRunP * dx + 4]: window i's run at i * kRunStride, rows end to end
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -102,13 +103,14 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
     if (wraps) {
       n4[0] = first.y; n4[1] = first.z; n4[2] = first.w; n4[3] = second.x;
     }
-    // rows of the tile lie end to end: element v of a window's run is at v — one unsigned comparison places a normal
-    // (j < head wraps around to a huge v; thread ids past the block's span fall behind every limit), and a normal that
-    // belongs to nobody goes to a spare word behind the tile: no branch around the store
+    // rows of a window lie end to end: element v of its run is at v — one unsigned minimum places a normal (j < head wraps
+    // around to a huge v; thread ids past the block's span fall behind every limit): a normal that belongs to nobody goes
+    // to the word behind the window's run, which nobody reads (a full window's is the four spare words between the
+    // windows' areas) — no branch around the store, no comparison and select in front of it
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t v = j - head[i];
-      noise[v < limit[i] ? (uint32_t)i * kRunP * dx + v : 4u * kRunP * dx] = n4[i];
+      noise[(uint32_t)i * kRunStride + min(v, limit[i])] = n4[i];
     }
   };
 
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
   const float two_var_p = uniform(2.0f * (s_p * s_p)), const_p = uniform((float)dx * (Num<float>::log(s_p) + half_log_2pi));
   const float two_var_g = uniform(2.0f * (s_g * s_g)), const_g = uniform((float)dy * (Num<float>::log(s_g) + half_log_2pi));
   const float two_var_q = uniform(2.0f * (s_q * s_q)), const_q = uniform((float)dx * (Num<float>::log(s_q) + half_log_2pi));
-  float *mine = noise + (wi * kRunP + 64u * c) * dx;                            // this chunk's 64 rows of noise; later of x_t
+  float *mine = noise + wi * kRunStride + 64u * c * dx;                         // this chunk's 64 rows of noise; later of x_t
   const float *trow = tab + wi * (2u * 4u * 16u) + ((cur.k0 + rr) >= K ? 64u : 0u);      // the lane's batch row's vectors
   const unsigned long long wq_a = (unsigned long long)mq.w, wp_a = (unsigned long long)mp.w, wg_a = (unsigned long long)mg.w;
 
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
   {
     // (whole 16- / 8-byte pieces where rows are: a wavefront's reads then fall on distinct LDS banks for every even
     //  extent but 8 and 16 — two- and four-way there —; odd extents read dwords, conflict-free)
-    const float *nrow = noise + (wi * kRunP + rr) * dx;
+    const float *nrow = noise + wi * kRunStride + rr * dx;
     constexpr int PW = DXC % 4 == 0 ? 4 : (DXC % 2 == 0 ? 2 : 1);
 #pragma unroll
     for (int e0 = 0; e0 < DXC; e0 += PW) {
@@ -356,7 +358,7 @@ int launch_affine_propagate_item(const void *xsrc, const int64_t *anc_idx, const
   FusedPlan plan;
   const int planned = fused_make_plan(plan, B, K, dx, threads);
   if (planned != AESMC_OK) return planned;
-  const size_t lds = sizeof(float) * ((size_t)kTabF + (size_t)plan.tile_f);
+  const size_t lds = sizeof(float) * ((size_t)kTabF + 4 * ((size_t)kRunP * (size_t)dx + 4));      // (four windows' areas)
   if (lds > kLgLdsLimit) return AESMC_ERR_UNSUPPORTED;
   const PhiloxStream ps = philox_stream(seed, offset, threads, rng_state);
   const dim3 grid(plan.items);

@@ -113,7 +113,10 @@ __device__ __forceinline__ float box_muller_sqrt(float a) {
   const float err_below = __builtin_fmaf(-below, r, a), err_above = __builtin_fmaf(-above, r, a);
   float s = (0.0f >= err_below) ? below : r;
   s = (0.0f < err_above) ? above : s;
-  return a == 0.0f ? a : s;                                             // (+-0 stay themselves)
+  // (a = -0.0 — u = 1 — needs no case of its own: v_sqrt_f32 gives -0.0, `below` is then a NaN and `above` a denormal
+  //  whose error term is -0.0: neither comparison holds and s = r = a, the value the device library's own `a == 0 ? a : s`
+  //  returns; +0.0 does not occur, and every other a is at least 1.1e-7)
+  return s;
 }
 
 // FUSED = false (separate multiply and add) exists for the probe that established which one PyTorch's build
