@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--grad", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--affine", type=int, default=1)
+    ap.add_argument("--particles", type=int, default=64, help="K (>= 128: the steps take K16 as at the BASELINE shapes)")
+    ap.add_argument("--profile", type=int, default=1)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     T = 100
@@ -35,7 +37,7 @@ def main():
 
     def step():
         with torch.set_grad_enabled(bool(args.grad)):
-            return losses.get_loss(observations, 64, "aesmc", model.initial, model.transition, model.emission,
+            return losses.get_loss(observations, args.particles, "aesmc", model.initial, model.transition, model.emission,
                                    model.proposal)
     for _ in range(3):
         step()
@@ -46,6 +48,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("host us per timestep: %.1f" % (1e6 * dt / (args.steps * T)))
+    if not args.profile:
+        return
     prof = cProfile.Profile()
     prof.enable()
     for _ in range(5):
