@@ -191,16 +191,27 @@ __device__ __forceinline__ void sb_outer(const float *tg, const float *tx, const
                                          Mfma<float>::Acc &acc) {
   const uint32_t col = lane & 15u, e = (lane >> 4) * D + col;
   const float *ta = tg + e, *tb = col == 15u ? ones : tx + e;
+  // the NEXT group's eight operands are sent for before this group's four products: an LDS round trip per group passes
+  // under matrix work instead of in front of it (counters: 55 % of this kernel's wave cycles are waits, three wavefronts
+  // per SIMD do not cover one another's)
+  float a[2][4], b[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    a[0][t] = ta[t * 4 * D];
+    b[0][t] = tb[t * 4 * D];
+  }
 #pragma unroll
   for (int group = 0; group < 4; ++group) {
-    float a[4], b[4];
+    if (group + 1 < 4) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      a[t] = ta[(4 * group + t) * 4 * D];
-      b[t] = tb[(4 * group + t) * 4 * D];
+      for (int t = 0; t < 4; ++t) {
+        a[(group + 1) & 1][t] = ta[(4 * (group + 1) + t) * 4 * D];
+        b[(group + 1) & 1][t] = tb[(4 * (group + 1) + t) * 4 * D];
+      }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc = Mfma<float>::fma(a[t], b[t], acc);
+    for (int t = 0; t < 4; ++t) acc = Mfma<float>::fma(a[group & 1][t], b[group & 1][t], acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
