@@ -999,6 +999,11 @@ static int launch_step(const void *log_w, const double *u, int64_t *idx, void *o
                        int64_t B, int64_t K, const StepPayload &payload, hipStream_t s, int32_t *child_end = nullptr) {
   if (K <= 512) return launch_inv<T, 2>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
   if (K <= 2048) return launch_inv<T, 4>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
+  // (rows of up to 4096 particles without a payload: four per lane on up to 1024 lanes rather than eight on 512 — half the
+  //  serial work per lane in a kernel bound by its phases' latency: 18.5 against 20.1 us at B = 1024, 6.2 / 8.1 / 11.7 against
+  //  6.6 / 8.8 / 13.0 at B = 128 / 256 / 512, profiles/r05_k2_forms_final.txt)
+  if (K <= 4096 && K % 256 == 0 && payload.src == nullptr && g_k2_form != 1)      // (whole wavefronts of four: the lean form's shapes)
+    return launch_inv<T, 4>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
   if (K <= 8192) return launch_inv<T, 8>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
   if (K <= 16384) return launch_inv<T, 16>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
   if (K <= kInvMaxParticles) return launch_inv<T, 32>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
