@@ -586,6 +586,10 @@ class _BindRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
+        # (a reduction like `-lml.sum() / n` sends back an EXPANDED gradient — every stride zero —, and each step's node
+        #  would make its own dense copy of its row for K14 to read: one launch per timestep; made dense once here)
+        if ctx.positions and not grad.is_contiguous():
+            grad = grad.contiguous()
         return (grad, None) + tuple(grad[position] for position in ctx.positions)
 
 
