@@ -453,7 +453,10 @@ __global__ __launch_bounds__(kMaxThreads, (PAYLOAD || C > 8) ? 1 : 8) void ances
 #pragma unroll
   for (int i = 0; i < C; ++i) {
     if (j0 + i < K) {
-      const double c = divide_with_reciprocal(base + s[i], total, inv_total);
+      // (an entry behind which only negligible weights lie may come out one ulp ABOVE the last one, 1.0, under a
+      //  tree-ordered scan; the reference's sequential cumsum is monotone and its c / max(c) never exceeds 1: clamped, as in
+      //  the lean form, so that first[] — the children ranges — stays non-decreasing on knife-edge rows too)
+      const double c = fmin(divide_with_reciprocal(base + s[i], total, inv_total), 1.0);
       // c <= (u + k) / K  <=>  k >= c K - u, up to the rounding of the position and of this
       // product: both are below K * 2^-52, so unless c K - u sits within K * 1e-15 of an integer
       // its ceiling IS the answer; only that rare case is settled against the exact positions.
@@ -1002,7 +1005,7 @@ static int launch_step(const void *log_w, const double *u, int64_t *idx, void *o
   // (rows of up to 4096 particles without a payload: four per lane on up to 1024 lanes rather than eight on 512 — half the
   //  serial work per lane in a kernel bound by its phases' latency: 18.5 against 20.1 us at B = 1024, 6.2 / 8.1 / 11.7 against
   //  6.6 / 8.8 / 13.0 at B = 128 / 256 / 512, profiles/r05_k2_forms_final.txt)
-  if (K <= 4096 && K % 256 == 0 && payload.src == nullptr && g_k2_form != 1)      // (whole wavefronts of four: the lean form's shapes)
+  if (K <= 4096 && K % 256 == 0 && payload.src == nullptr)      // (whole wavefronts of four: the lean form's shapes)
     return launch_inv<T, 4>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
   if (K <= 8192) return launch_inv<T, 8>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
   if (K <= 16384) return launch_inv<T, 16>(log_w, u, idx, flags, B, K, s, out_lse, payload, child_end);
