@@ -216,6 +216,12 @@ class HipKernels:
         bad = torch.logical_not(valid).any().to(torch.int32) * _lib.FLAG_VALUE_OUTSIDE_SUPPORT
         self.flags(valid.device).bitwise_or_(bad)
 
+    def defer_parameter_check(self, valid):
+        """ORs FLAG_INVALID_PARAMETER into the status word if any element of the boolean tensor `valid` (a
+        distribution parameter against its constraint) is False — device-side, no synchronisation."""
+        bad = torch.logical_not(valid).any().to(torch.int32) * _lib.FLAG_INVALID_PARAMETER
+        self.flags(valid.device).bitwise_or_(bad)
+
     @staticmethod
     def _stream(t):
         # the raw handle of torch's current stream on t's device (torch.cuda.current_stream builds a Stream

@@ -19,6 +19,7 @@ FLAG_DEGENERATE_ROW = 2
 FLAG_INDEX_OUT_OF_RANGE = 4
 FLAG_VALUE_OUTSIDE_SUPPORT = 8  # host-side deferred validation (state.log_prob), not a kernel
 FLAG_UNSORTED_INDEX = 16
+FLAG_INVALID_PARAMETER = 32  # host-side deferred argument validation (_syncfree: Distribution.__init__), not a kernel
 F32, F64 = 0, 1
 
 _vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t

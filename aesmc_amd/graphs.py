@@ -227,48 +227,72 @@ class GraphedLoss:
         return all(torch.is_tensor(fresh) and fresh.shape == static.shape and fresh.dtype == static.dtype and
                    fresh.device == static.device for static, fresh in zip(self.static_observations, observations))
 
+    def _replay_against_eager(self, observations=None):
+        """One replay and the same evaluation made eagerly from the random state the replay started with (same inputs,
+        same draws).  Returns (problems, loss): `problems` lists what differs — loss to rtol 1e-5, every gradient to
+        1e-4 of its norm (a user model may contain float atomics whose order differs from run to run; the faults this
+        guards against are off by orders of magnitude); `loss` is the replay's.  Afterwards both random streams have
+        moved by ONE evaluation; the parameters' `.grad` are the static tensors with the replay's values when nothing
+        differs, and the EAGER evaluation's fresh tensors when something does (the caller drops the graph)."""
+        params = self.parameters
+        static = [p.grad for p in params]
+        cuda_state, numpy_state = torch.cuda.get_rng_state(self.device), np.random.get_state()
+        if observations is not None:
+            for held, fresh in zip(self.static_observations, observations):
+                held.copy_(fresh, non_blocking=True)
+        self._replay()
+        graph_loss = self.static_loss.clone()
+        graph_grads = [None if g is None else g.clone() for g in static]
+        after_replay = (torch.cuda.get_rng_state(self.device), np.random.get_state())
+        for p in params:
+            p.grad = None
+        torch.cuda.set_rng_state(cuda_state, self.device)
+        np.random.set_state(numpy_state)
+        try:
+            eager_loss = self._evaluate(refill=True)
+        except torch.cuda.OutOfMemoryError:
+            # the eager autograd graph does not fit beside the capture's private pool: the replay's results stand
+            for p, grad in zip(params, static):
+                p.grad = grad
+            torch.cuda.empty_cache()
+            torch.cuda.set_rng_state(after_replay[0], self.device)
+            np.random.set_state(after_replay[1])
+            warnings.warn("aesmc_amd: no memory for the eager evaluation a replay is compared with; the comparison "
+                          "is skipped", RuntimeWarning)
+            return [], graph_loss
+        problems = []
+        if not torch.allclose(graph_loss, eager_loss, rtol=1e-5, atol=1e-6, equal_nan=True):
+            problems.append("loss {} vs {}".format(float(graph_loss), float(eager_loss)))
+        for position, (p, got) in enumerate(zip(params, graph_grads)):
+            want = p.grad
+            if (got is None) != (want is None):
+                problems.append("parameter {}: gradient present in only one of the two".format(position))
+            elif got is not None:
+                scale = float(torch.linalg.vector_norm(want.double()))
+                worst = float(torch.linalg.vector_norm((got - want).double()))
+                if not worst <= 1e-4 * scale + 1e-12:
+                    problems.append("parameter {} {}: |difference| {:.3g} against a gradient of norm {:.3g}".format(
+                        position, tuple(p.shape), worst, scale))
+        if self.shard and dist.is_available() and dist.is_initialized():
+            # every rank reaches the same verdict: a rank that went on alone would wait in the next all-reduce for good
+            failed = torch.tensor([1.0 if problems else 0.0], device=self.device)
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=self.group)
+            if float(failed) > 0 and not problems:
+                problems.append("another rank's replay did not reproduce its eager evaluation")
+        if not problems:
+            for p, grad in zip(params, static):
+                p.grad = grad
+        return problems, (graph_loss if not problems else eager_loss)
+
     def _verify(self, replays):
-        """Replays the fresh graph `replays` times; before each, the random streams are noted and the
-        same evaluation is then repeated eagerly from that state.  Loss and every gradient must agree
-        (to 1e-4 of the largest entry: a user model may contain atomics; the hipGraph memset fault
-        this guards against is off by orders of magnitude).  Leaves both streams where they were."""
+        """Replays the fresh graph `replays` times, each against an eager evaluation on the same inputs and random
+        draws (`_replay_against_eager`); a mismatch raises.  Leaves both random streams where they were."""
         params = self.parameters
         start_cuda, start_numpy = torch.cuda.get_rng_state(self.device), np.random.get_state()
         static = [p.grad for p in params]
         try:
             for replay in range(replays):
-                cuda_state, numpy_state = torch.cuda.get_rng_state(self.device), np.random.get_state()
-                self._replay()
-                graph_loss = self.static_loss.clone()
-                graph_grads = [None if g is None else g.clone() for g in static]
-                for p in params:
-                    p.grad = None
-                torch.cuda.set_rng_state(cuda_state, self.device)
-                np.random.set_state(numpy_state)
-                eager_loss = self._evaluate(refill=True)
-                problems = []
-                if not torch.allclose(graph_loss, eager_loss, rtol=1e-5, atol=1e-6, equal_nan=True):
-                    problems.append("loss {} vs {}".format(float(graph_loss), float(eager_loss)))
-                for position, (p, got) in enumerate(zip(params, graph_grads)):
-                    want = p.grad
-                    if (got is None) != (want is None):
-                        problems.append("parameter {}: gradient present in only one of the two".format(position))
-                    elif got is not None:
-                        # relative to the gradient's norm: a user model may contain float atomics (scatter, index_add)
-                        # whose order differs from run to run; the fault this guards against is off by orders of magnitude
-                        scale = float(torch.linalg.vector_norm(want.double()))
-                        worst = float(torch.linalg.vector_norm((got - want).double()))
-                        if not worst <= 1e-4 * scale + 1e-12:
-                            problems.append("parameter {} {}: |difference| {:.3g} against a gradient of norm {:.3g}".format(
-                                position, tuple(p.shape), worst, scale))
-                for p, grad in zip(params, static):
-                    p.grad = grad
-                if self.shard and dist.is_available() and dist.is_initialized():
-                    # every rank raises together: a rank that went on alone would wait in the next all-reduce for good
-                    failed = torch.tensor([1.0 if problems else 0.0], device=self.device)
-                    dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=self.group)
-                    if float(failed) > 0 and not problems:
-                        problems.append("another rank's replay did not reproduce its eager evaluation")
+                problems, _ = self._replay_against_eager()
                 if problems:
                     import aesmc_amd
                     raise RuntimeError(
@@ -284,6 +308,21 @@ class GraphedLoss:
             torch.cuda.set_rng_state(start_cuda, self.device)
             np.random.set_state(start_numpy)
         inference._raise_for_flags(_kernels.get().read_flags(self.device))
+
+    def reverify(self, observations):
+        """A training step taken as a replay AND checked against the eager evaluation of the same minibatch with the same
+        draws (backward graphs only): what detects that the callables' HOST-side state has moved since the capture — a
+        Python-number coefficient annealed from a callback, `module.eval()`, a counter — which a replay cannot see.
+        Returns (problems, loss); with problems the parameters' `.grad` hold the eager evaluation's gradients and the
+        graph must be dropped.  Consumes both random streams exactly as one evaluation does."""
+        if not self.backward:
+            raise RuntimeError("aesmc_amd: GraphedLoss.reverify needs a graph captured with backward=True")
+        problems, loss = self._replay_against_eager(observations)
+        self.replays += 1
+        if self.shard and dist.is_available() and dist.is_initialized():
+            loss = loss.clone()
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+        return problems, loss
 
     def _shard_scope(self):
         return distributed.shard_scope(*self.shard) if self.shard else contextlib.nullcontext()

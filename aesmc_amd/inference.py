@@ -22,6 +22,7 @@ import torch
 from . import _kernels
 from . import _lazy
 from . import _ops
+from . import _syncfree
 from . import settings
 from . import state
 
@@ -216,6 +217,11 @@ def _raise_for_flags(flags):
     from . import _lib
     if flags & _lib.FLAG_NAN_LOG_WEIGHT:
         raise FloatingPointError("log_weight contains nan element(s)")
+    if flags & _lib.FLAG_INVALID_PARAMETER:
+        from . import _syncfree
+        raise ValueError("Expected the parameters of a distribution to satisfy their constraints, but found invalid "
+                         "values (detected on the device; checks deferred lately: {})".format(
+                             "; ".join(_syncfree.checked_parameters()) or "none recorded"))
     if flags & _lib.FLAG_VALUE_OUTSIDE_SUPPORT:
         raise ValueError("The value argument must be within the support of the distribution "
                          "(detected on the device during log_prob)")
@@ -303,7 +309,9 @@ def infer(inference_algorithm, observations, initial, transition, emission,
         begin = getattr(_kernels.get(), "begin_evaluation", None)
         if begin is not None:
             begin()
-        with state.deferring_draws():
+        # (`_syncfree.scope`: distributions the callables build with Python-number parameters / default validate_args
+        #  neither copy from the host nor synchronise with it — the reference's own model style, test/models/lgssm.py)
+        with state.deferring_draws(), _syncfree.scope():
             return _infer(inference_algorithm, observations, initial, transition, emission, proposal,
                           num_particles, return_log_marginal_likelihood, return_latents,
                           return_original_latents, return_log_weight, return_log_weights,

@@ -15,6 +15,7 @@ import torch
 from . import _kernels
 from . import _ops
 from . import _philox
+from . import _syncfree
 from . import settings
 from ._lazy import LazyAffine, LazyDraw, LazyParticles, LazyResampled
 from ._lazy import real as _lazy_real
@@ -43,28 +44,7 @@ def _validate_sample(distribution, value):
     if settings.current().validation_mode == "eager" or not value.is_cuda:
         distribution._validate_sample(value)
         return
-    # Host half of torch.distributions.Distribution._validate_sample: shapes only, no sync.
-    if not isinstance(value, torch.Tensor):
-        raise ValueError("The value argument to log_prob must be a Tensor")
-    event_start = value.dim() - len(distribution.event_shape)
-    if value.size()[event_start:] != distribution.event_shape:
-        raise ValueError("The right-most size of value must match event_shape: {} vs {}.".format(
-            value.size(), distribution.event_shape))
-    expected = distribution.batch_shape + distribution.event_shape
-    for got, want in zip(reversed(value.size()), reversed(expected)):
-        if got != 1 and want != 1 and got != want:
-            raise ValueError("Value is not broadcastable with batch_shape+event_shape: {} vs {}."
-                             .format(value.size(), expected))
-    try:
-        support = distribution.support
-    except NotImplementedError:
-        warnings.warn("{} does not define `support` to enable sample validation. Please "
-                      "initialize the distribution with `validate_args=False` to turn off "
-                      "validation.".format(distribution.__class__))
-        return
-    if _is_real_support(support):
-        return  # only NaN violates it; NaN reaches the log-weights and raises there
-    _kernels.get().defer_support_check(support.check(value))
+    _syncfree.validate_sample(distribution, value)      # shapes on the host at once, the support on the device
 
 
 class BatchShapeMode(enum.Enum):
@@ -537,7 +517,12 @@ def _fused_normal_views(distribution, value, missing):
         if param.device != value.device:
             if param.numel() != 1:
                 return None
-            param = param.to(value.device)  # Normal(0.0, 1.0): Python-number parameters live on the host
+            # Normal(0.0, 1.0): Python-number parameters live on the host.  Their value as a cached device constant
+            # (read on the host — free for a host tensor — no copy per call; a capture can hold it)
+            if param.requires_grad:
+                param = param.to(value.device)
+            else:
+                param = _syncfree.constant(param.item(), param.dtype, value.device)
         if missing == 1:
             if param.dim() == 0:
                 return None

@@ -8,6 +8,11 @@ inside oracle/capture_golden.py only — under the imported reference when fixtu
                 including its quirk that the proposal uses scale_0 at every time step
                 (test/models/lgssm.py:71).
   * Gaussian* : counterpart of the reference's test/models/gaussian.py (one-step IWAE model).
+                Both families are stated in the reference's own style ON PURPOSE — Python-number scales,
+                PyTorch's default `validate_args`, the `cat` / `view` proposal, a host-resident `std` —
+                because that is what a user who switches packages brings along: `inference.infer` makes
+                such callables sync-free (`_syncfree`), so they run in the eager loop without a copy or a
+                host read per distribution and can be captured into a hipGraph (`train(hip_graph=...)`).
   * LgssmNd   : d-dimensional linear-Gaussian SSM of SURVEY.md section 8(d) (bench workloads).
   * NonlinearSsm : tanh transition + 2-layer MLP proposal (config 4 of BASELINE.json).
 """
@@ -84,7 +89,9 @@ class GaussianPrior(nn.Module):
     def __init__(self, init_mean, std):
         super().__init__()
         self.mean = nn.Parameter(torch.tensor(init_mean, dtype=torch.float))
-        self.register_buffer("std", torch.tensor(std, dtype=torch.float))
+        # a plain attribute, as the reference has it (test/models/gaussian.py:10): NOT a buffer, so `.to(device)`
+        # leaves it on the host and `Normal(loc=<device>, scale=<host 0-dim>)` is what the library is handed
+        self.std = torch.tensor(std, dtype=torch.float)
 
     def forward(self):
         return torch.distributions.Normal(loc=self.mean, scale=self.std)

@@ -44,6 +44,19 @@ def _minibatches(dataloader, num_epochs, limit):
 
 
 _AUTO_CAPTURE_AFTER = 8     # eager minibatches in front of the automatic capture: short runs never pay for one
+_REVERIFY_EVERY = 256       # replays between checks of a replay against an eager evaluation of the same minibatch
+
+
+def _default_hip_graph():
+    """What `train(hip_graph=None)` means: AESMC_TRAIN_HIP_GRAPH = 'auto' (default), '0' / 'off' (the reference's eager
+    loop, never a capture) or '1' / 'on' (capture the first minibatch, failures raise)."""
+    import os
+    choice = os.environ.get("AESMC_TRAIN_HIP_GRAPH", "auto").strip().lower()
+    if choice in ("0", "off", "false", "no"):
+        return False
+    if choice in ("1", "on", "true", "yes"):
+        return True
+    return "auto"
 
 
 def _capturable(observations, algorithm):
@@ -61,7 +74,7 @@ def _capturable(observations, algorithm):
 def train(dataloader, num_particles, algorithm, initial, transition, emission,
           proposal, num_epochs, num_iterations_per_epoch=None,
           optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
-          callback=None, hip_graph=None, verify_replays=4):
+          callback=None, hip_graph=None, verify_replays=4, reverify_every=_REVERIFY_EVERY):
     """Fits the model parts by stochastic gradient descent on `losses.get_loss`.
 
     A single optimiser (`optimizer_algorithm(params, **optimizer_kwargs)`) owns the parameters of
@@ -71,13 +84,26 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
     Returns nothing, like the reference.
 
     `hip_graph` (not in the reference).  The reference's loop issues every small kernel of every timestep from Python; on
-    this device that loop is host-bound below about a million particles per timestep (configs[1]: 5x).  So by default
-    (None) the loop runs eagerly for `_AUTO_CAPTURE_AFTER` minibatches and then — when the minibatches are HIP tensors of
-    a fixed shape — captures loss + backward of the next one into one hipGraph (`graphs.GraphedLoss`) and replays it for
-    every later minibatch of that shape.  A capture needs callables that never synchronise with the host (see
-    `aesmc_amd/graphs.py`); one that cannot be made, or whose verification replays do not reproduce the eager evaluation,
-    is abandoned with ONE RuntimeWarning and the loop stays eager — as it does for the whole run with `hip_graph=False`
-    (opt-out).  `hip_graph=True` captures the first minibatch and lets a failure raise.
+    this device that loop is host-bound below about a million particles per timestep (configs[1]: 5x).  So with 'auto'
+    (what None means unless AESMC_TRAIN_HIP_GRAPH says otherwise) the loop runs eagerly for `_AUTO_CAPTURE_AFTER`
+    minibatches and then — when the minibatches are HIP tensors of a fixed shape — captures loss + backward of the next
+    one into one hipGraph (`graphs.GraphedLoss`) and replays it for every later minibatch of that shape.  A capture
+    that cannot be made, or whose verification replays do not reproduce the eager evaluation, is abandoned with ONE
+    RuntimeWarning and the loop stays eager — as it does for the whole run with `hip_graph=False` (opt-out: the
+    reference's loop, step for step).  `hip_graph=True` captures the first minibatch and lets a failure raise.
+    Callables in the reference's own style — `Normal(mult * x, 0.5)`, default `validate_args` — can be captured: inside
+    `infer` such distributions neither copy from nor synchronise with the host (`aesmc_amd/_syncfree.py`).
+
+    THE FROZEN-CALLABLES CONTRACT.  A replay re-issues the device work recorded at the capture; the four callables'
+    Python code does not run again.  Everything they read from DEVICE memory is live (parameters, buffers and
+    observations are updated in place), everything they computed on the HOST is frozen at its value during the capture:
+    a Python-number coefficient annealed from `callback`, `module.train()` / `.eval()` toggles, counters, logging,
+    branches on host state.  To keep that from going unnoticed, every `reverify_every`-th replay (default 256; 0 switches
+    it off) is ALSO evaluated eagerly on the same minibatch with the same random draws and compared (loss and every
+    gradient): on a mismatch the graph is dropped with a RuntimeWarning, that step and all later ones are the eager
+    loop's.  A model that changes host-side state on purpose passes `hip_graph=False`, or keeps the state in a device
+    tensor it updates in place.  A capture also holds a private memory pool beside the eager loop's.
+
     The capture leaves numpy's and torch's random streams where it found them and a replay consumes both exactly as an
     eager evaluation does, so a seeded run follows the eager loop's trajectory (to the rounding of identical kernels
     launched from a graph: the same bits in practice).  The fresh graph is checked against eager evaluations before it is
@@ -89,6 +115,10 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
     model_parts = (initial, transition, emission, proposal)
     optimizer = optimizer_algorithm(get_chained_params(*model_parts), **optimizer_kwargs)
     graphed = None
+    if hip_graph is None:
+        hip_graph = _default_hip_graph()
+    if hip_graph not in (True, False, "auto"):
+        raise ValueError("aesmc_amd.train: hip_graph must be None, 'auto', True or False, got {!r}".format(hip_graph))
     may_capture = hip_graph is not False
     capture_at = 0 if hip_graph is True else _AUTO_CAPTURE_AFTER
     seen, shapes = 0, None
@@ -130,7 +160,18 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
                     optimizer.zero_grad(set_to_none=True)
         seen += 1
         if graphed is not None and graphed.accepts(observations):
-            loss = graphed(observations)     # refreshes every captured parameter's .grad in place
+            if reverify_every and (graphed.replays + 1) % reverify_every == 0:
+                # this step as a replay AND eagerly, same minibatch, same draws: has the callables' host side moved?
+                problems, loss = _reverified_step(graphed, observations)
+                if problems:
+                    graphed.check()
+                    graphed, may_capture = None, False      # (.grad now holds the eager evaluation's gradients)
+                    optimizer.step()
+                    if callback is not None:
+                        callback(epoch, iteration, loss, *model_parts)
+                    continue
+            else:
+                loss = graphed(observations)     # refreshes every captured parameter's .grad in place
             optimizer.step()
             if graphed.replays % _FLAG_CHECK_INTERVAL == 0:
                 graphed.check()
@@ -147,6 +188,21 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
         del loss      # (no eager autograd graph may be alive when a capture starts)
     if graphed is not None:
         graphed.check()
+
+
+def _reverified_step(graphed, observations):
+    """`graphed.reverify` with a mismatch turned into the one RuntimeWarning the caller's return to the eager loop
+    deserves (an eager evaluation that does not fit beside the graph's memory pool skips the check with a warning of
+    its own, `graphs.GraphedLoss._replay_against_eager`)."""
+    problems, loss = graphed.reverify(observations)
+    if problems:
+        import warnings
+        warnings.warn("aesmc_amd.train: replay {} of the captured loss no longer reproduces an eager evaluation of the "
+                      "same minibatch with the same draws ({}). The callables' host-side state has changed since the "
+                      "capture (a replay cannot see that); the loop goes back to eager evaluations. Pass "
+                      "hip_graph=False for a model that changes such state on purpose.".format(
+                          graphed.replays, "; ".join(problems)[:300]), RuntimeWarning)
+    return problems, loss
 
 
 class SyntheticDataset(Dataset):

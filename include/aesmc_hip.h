@@ -37,6 +37,7 @@ extern "C" {
 #define AESMC_FLAG_INDEX_OUT_OF_RANGE 4 /* gather saw idx < 0 or idx >= K (torch.gather would raise)     */
 #define AESMC_FLAG_VALUE_OUTSIDE_SUPPORT 8 /* reserved for the host's deferred sample validation         */
 #define AESMC_FLAG_UNSORTED_INDEX 16 /* gather backward was promised sorted indices and met a descent   */
+#define AESMC_FLAG_INVALID_PARAMETER 32 /* reserved for the host's deferred distribution-argument validation */
 
 /* ---- dtype tags ----------------------------------------------------------------------------- */
 #define AESMC_F32 0
