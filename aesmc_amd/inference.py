@@ -215,13 +215,13 @@ def check_device_status(device=None):
 
 def _raise_for_flags(flags):
     from . import _lib
-    if flags & _lib.FLAG_NAN_LOG_WEIGHT:
-        raise FloatingPointError("log_weight contains nan element(s)")
-    if flags & _lib.FLAG_INVALID_PARAMETER:
+    if flags & _lib.FLAG_INVALID_PARAMETER:      # the cause first: an invalid scale also makes the log-weights NaN
         from . import _syncfree
         raise ValueError("Expected the parameters of a distribution to satisfy their constraints, but found invalid "
                          "values (detected on the device; checks deferred lately: {})".format(
                              "; ".join(_syncfree.checked_parameters()) or "none recorded"))
+    if flags & _lib.FLAG_NAN_LOG_WEIGHT:
+        raise FloatingPointError("log_weight contains nan element(s)")
     if flags & _lib.FLAG_VALUE_OUTSIDE_SUPPORT:
         raise ValueError("The value argument must be within the support of the distribution "
                          "(detected on the device during log_prob)")

@@ -82,6 +82,49 @@ class Lgssm1dProposal(nn.Module):
             torch.distributions.Normal(loc=loc, scale=self.scale_0), modes.FULLY_EXPANDED)
 
 
+class ReferenceLgssm1d(nn.Module):
+    """The four reference-style 1-D classes above as one module with the bench's model interface (`initial`,
+    `transition`, `emission`, `proposal`, `simulate`): x_0 ~ N(0, 1), x_t ~ N(a x_{t-1}, sx^2), y_t ~ N(c x_t, sy^2).
+    Nothing is adapted for the device: Python-number scales, default `validate_args`, `cat` / `view` proposal.  The
+    proposal's two Linear layers are set to the model's locally optimal proposal (what training converges towards), its
+    one scale — the reference reads `scale_0` at every step, test/models/lgssm.py:71 — to that proposal's."""
+
+    def __init__(self, transition_mult=0.9, emission_mult=1.0, transition_scale=1.0, emission_scale=0.5,
+                 state=_default_state, **_):
+        super().__init__()
+        a, c, sx2, sy2 = transition_mult, emission_mult, transition_scale ** 2, emission_scale ** 2
+        spread = 1.0 / (1.0 / sx2 + c * c / sy2)
+        self.initial = Lgssm1dInitial(0.0, 1.0)
+        self.transition = Lgssm1dTransition(a, transition_scale, state=state)
+        self.emission = Lgssm1dEmission(c, emission_scale, state=state)
+        self.proposal = Lgssm1dProposal(float(np.sqrt(spread)), float(np.sqrt(spread)), state=state)
+        with torch.no_grad():
+            spread0 = 1.0 / (1.0 + c * c / sy2)
+            self.proposal.lin_0.weight.fill_(spread0 * c / sy2)
+            self.proposal.lin_0.bias.zero_()
+            self.proposal.lin_t.weight.copy_(torch.tensor([[spread * a / sx2, spread * c / sy2]]))
+            self.proposal.lin_t.bias.zero_()
+        self._numbers = (a, c, transition_scale, emission_scale)
+
+    @torch.no_grad()
+    def simulate(self, num_timesteps, batch_size, seed=0):
+        """Observations [T] x [B] drawn from the model (float64 host noise, cast), on the parameters' device."""
+        a, c, sx, sy = self._numbers
+        device = self.transition.mult.device
+        gen = torch.Generator().manual_seed(seed)
+
+        def noise():
+            return torch.randn(batch_size, generator=gen, dtype=torch.float64)
+
+        x = noise()
+        observations = []
+        for time in range(num_timesteps):
+            if time > 0:
+                x = a * x + sx * noise()
+            observations.append((c * x + sy * noise()).to(device=device, dtype=torch.float32))
+        return observations
+
+
 # ------------------------------------------------------------------------------------------------
 # One-step Gaussian model (reference test/models/gaussian.py)
 # ------------------------------------------------------------------------------------------------

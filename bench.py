@@ -74,6 +74,10 @@ WORKLOADS = {
 for _rows in (320, 384, 448, 640, 768):      # intermediate shards of the north-star shape (graph-replay / host-bound studies)
     WORKLOADS["c4b%d" % _rows] = ("LGSSM d=10 B=%d K=4096 T=100, SMC ELBO (a part of c4's batch)" % _rows, "lgssm", 10,
                                   _rows, 4096, 100, {})
+# the reference's own model classes, untouched (test/models/lgssm.py: Python-number scales, default validate_args, the
+# cat / view proposal), at configs[1]'s B, K, T: what a user who switches packages runs on day one
+WORKLOADS["c2ref"] = ("1-D LGSSM written as the reference writes it (test/models/lgssm.py classes) B=256 K=1024 T=50, SMC ELBO",
+                      "lgssm1d_reference", 1, 256, 1024, 50, {})
 WORKLOADS["tiny"] = ("LGSSM d=3 B=8 K=64 T=5 (test-sized: exercises every leg of this file in seconds)",
                      "lgssm", 3, 8, 64, 5, {})
 ALGORITHM = {"c3": "iwae"}          # every other workload is the SMC ELBO ('aesmc')
@@ -212,7 +216,9 @@ def tunable_gemms(enable):
 def build_model(kind, dim, device, state, proposal="stock", callables="matmul", **model_kwargs):
     from aesmc_amd.testing import models
     cls = {"lgssm": models.LgssmNd, "nonlinear": models.NonlinearSsm, "gaussian": models.GaussianIwae,
-           "learned_scale": models.LearnedScaleSsm}[kind]
+           "learned_scale": models.LearnedScaleSsm, "lgssm1d_reference": models.ReferenceLgssm1d}[kind]
+    if kind == "lgssm1d_reference":      # nothing passed down: the classes' own defaults (validate_args included)
+        return cls(state=state).to(device)
     if kind == "gaussian":
         return cls(state=state, validate_args=False).to(device)
     if kind == "lgssm":
@@ -352,8 +358,12 @@ class Context:
             loss = fn()
         self.barrier()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.device)
+        self.last_per_rank_seconds = [float(dt.item())]
         if self.use_dist:
             import torch.distributed as dist
+            every = [torch.zeros_like(dt) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, dt)          # each rank's own clock: a slow rank shows up by name in the JSON line
+            self.last_per_rank_seconds = [float(t.item()) for t in every]
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return float(dt.item()), float(loss.detach())
 
@@ -446,6 +456,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
     for _ in range(warmup):
         forward()
     seconds, loss = ctx.timed(forward, steps)
+    per_rank_ms = [round(1e3 * t / steps, 4) for t in ctx.last_per_rank_seconds]
     if graphed is not None:
         graphed.check()
     out = {
@@ -454,7 +465,7 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         "value": global_B * K * T * steps / seconds, "ms_per_step": 1e3 * seconds / steps, "loss": loss,
         "mode": ran_as, "graph_error": graph_error, "grad": grad, "scaling": scaling,
         "batch_per_gpu": local_B, "global_batch": global_B, "num_particles": K, "num_timesteps": T,
-        "state_dim": dim, "algorithm": algorithm,
+        "state_dim": dim, "algorithm": algorithm, "per_rank_ms_per_step": per_rank_ms,
         "peak_memory_GB": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
     }
 
@@ -511,6 +522,18 @@ def run_workload(ctx, name, proposal, steps, warmup, scaling="weak", want_backwa
         finally:
             provider.timer = None
         out["kernels"] = {k: _round(v) for k, v in kernels.items()}
+        if want_backward and "fwd_bwd_error" not in out:
+            # the backward's launches, timed the same way (one eager forward + backward with every launch noted): K14 —
+            # a linear-Gaussian timestep's whole backward — is 43 % of a training step's device time at c4
+            provider.timer = _kernels.KernelTimer(keep=12)
+            try:
+                step(backward=True)
+                backward = {k: v for k, v in provider.timer.summary().items() if k not in kernels}
+            finally:
+                provider.timer = None
+            model.zero_grad(set_to_none=True)
+            out["backward_kernels"] = {k: dict(_round(v), frac=round(v["GBps"] / HBM_PEAK_GBPS, 4))
+                                       for k, v in backward.items()}
         # the roofline kernel: the resample gather (K3, or the fused step that contains it); a workload
         # that never resamples (c3, IWAE) is what BASELINE.json uses to isolate the fused log-weight
         # + log-sum-exp kernel (K1)
@@ -815,6 +838,66 @@ def fixture_parity_block(ctx):
     return out
 
 
+def summary_of(out, head, extras):
+    """Every claimed number of the run in well under 1.5 KB, as the last key of the JSON line: [particle-steps/s, ms per
+    ELBO] per workload (replayed; `eager` beside it), forward + backward rates, per-kernel roofline fractions, the
+    strong- and weak-scaling projections from one GPU, the float32 index flip rates against the reference's fixtures."""
+    def rate(x):
+        return None if x is None else float("%.4g" % x)
+
+    def pair(leg):
+        return None if not leg or leg.get("value") is None else [rate(leg["value"]), round(leg["ms_per_step"], 3)]
+
+    summary = {"head": pair(head), "head_eager": rate(head.get("eager_particle_steps_per_sec")),
+               "head_fwd_bwd": rate(head.get("fwd_bwd_particle_steps_per_sec"))}
+    fracs = {}
+    roof = head.get("roofline") or {}
+    if roof:
+        fracs["head_kernel"] = roof.get("frac")
+        if roof.get("whole_path"):
+            fracs["whole_path"] = roof["whole_path"]["frac"]
+        for other in roof.get("path_kernels", []):
+            if other["kernel"].startswith("ancestor_index"):
+                fracs["K2"] = other["frac"]
+                summary["K2_us"] = other["avg_launch_us"]
+    for name, stats in (head.get("backward_kernels") or {}).items():
+        if name.startswith("affine_step_backward"):
+            fracs["K14"] = stats["frac"]
+            summary["K14_us"] = round(stats["avg_us"], 1)
+    legs = extras.get("kernel_legs") or {}
+    for label, key in (("K1_c3", "K1_c3_combine_lse"), ("K3_c4", "K3_c4_s1"), ("K3_c5", "K3_c5_s1"),
+                       ("K17_K18_mfma", "K17_K18_c5_wide_step")):
+        if key in legs:
+            fracs[label] = legs[key]["frac"]
+    summary["frac"] = fracs
+    for label, key in (("c2", "c2_hipgraph"), ("c2ref", "reference_models"), ("c4_matmul", "matmul_callables"),
+                       ("c4nl", "c4nl"), ("c5", "c5")):
+        leg = extras.get(key)
+        if leg:
+            summary[label] = pair(leg) + [rate(leg.get("eager_particle_steps_per_sec")),
+                                          rate(leg.get("fwd_bwd_particle_steps_per_sec"))]
+    if summary.get("c2") or summary.get("c5"):
+        summary["legend"] = "per workload: [replayed particle-steps/s, ms per ELBO, eager loop, fwd+bwd]"
+    if (extras.get("c5") or {}).get("roofline"):
+        fracs["c5_mfma"] = extras["c5"]["roofline"].get("frac")
+    projection = extras.get("strong_scaling_projection")
+    if projection:
+        # strong: B = 1024 split over N GPUs (efficiency = t(1024) / (N t(1024 / N)), one GPU running one shard);
+        # weak: every GPU keeps B = 1024 — the batch shard has no data-path collective but one 4-byte all-reduce per ELBO,
+        # so its projection is t / (t + all-reduce)
+        summary["strong_eff"] = {n: e["projected_efficiency"] for n, e in projection.items()}
+        allreduce_ms = 1e-3 * (out.get("allreduce_us_per_elbo") or 25.0)
+        summary["weak_eff"] = round(head["ms_per_step"] / (head["ms_per_step"] + allreduce_ms), 4)
+    flips = extras.get("index_parity_vs_reference_fixtures") or {}
+    if flips:
+        summary["fp32_flip_rate"] = {name.replace("resampler_", ""): float("%.3g" % entry["flip_rate"])
+                                     for name, entry in flips.items() if entry["dtype"] == "float32"}
+        summary["fp64_flips"] = sum(entry["mismatches"] for entry in flips.values() if entry["dtype"] == "float64")
+    if out.get("cpu_baseline"):
+        summary["cpu"] = rate(out["cpu_baseline"]["value"])
+    return summary
+
+
 # ---- main ----------------------------------------------------------------------------------------------
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
@@ -918,6 +1001,7 @@ def main(argv=None):
                            (", all T timesteps replayed as one hipGraph" if head["mode"] == "hipgraph"
                             else ", eager Python loop")},
         "rccl_world_size": rccl_world, "allreduce_us_per_elbo": allreduce_us,
+        "per_rank_ms_per_step": head["per_rank_ms_per_step"],      # each rank's own clock over the timed region (value uses the max)
         "loss": head["loss"], "mode": head["mode"], "graph_error": head["graph_error"],
         "tunableop": args.tunableop, "peak_memory_GB": head["peak_memory_GB"],
         "eager_particle_steps_per_sec": head.get("eager_particle_steps_per_sec"),
@@ -972,6 +1056,17 @@ def main(argv=None):
             extras["c2_hipgraph"] = brief(run_workload(ctx, "c2", args.proposal, 20, 5,
                                                        want_backward=not args.no_backward))
             lap("c2")
+        if args.workload != "c2ref":
+            # the reference's own model classes, unedited (Python-number scales, default validate_args): replayed as a
+            # hipGraph and in the eager loop (`eager_particle_steps_per_sec`) — the day-one experience of a user who switches
+            extras["reference_models"] = brief(run_workload(ctx, "c2ref", "stock", 20, 5, want_kernels=False,
+                                                            want_backward=not args.no_backward))
+            lap("reference-style models")
+        if args.workload == "c4":
+            # BASELINE.json configs[4]: rows of 128 values, forward only (autograd retention exceeds HBM); its
+            # roofline is the matrix-core step K17 + K18
+            extras["c5"] = brief(run_workload(ctx, "c5", args.proposal, 2, 1, want_backward=False))
+            lap("c5")
         if args.workload == "c4":
             # BASELINE.json configs[3]'s model (nonlinear SSM, learned proposal net) on one GPU's shard of it, forward
             # AND backward: the d x d maps through K8 / K11; the proposal net is the user's PyTorch module
@@ -1013,6 +1108,7 @@ def main(argv=None):
     if extras:
         extras["bench_seconds"] = seconds
         out["extras"] = extras
+    out["summary"] = summary_of(out, head, extras)      # LAST key: what survives a reader that keeps the line's tail
     if use_dist:
         dist.barrier()
     if rank == 0:

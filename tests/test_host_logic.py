@@ -1143,3 +1143,70 @@ def test_the_wide_steps_recomputing_backward_is_float64_autograds():
             error = float((got[slot].reshape(reference.shape) - reference).abs().max())
             assert error <= 1e-12 * (1 + float(reference.abs().max())), (slot, error)
         assert got[1] is None and (off_p is not None or (got[4] is None and got[6] is None))
+
+
+# ---- torch.distributions made sync-free inside `infer` (aesmc_amd/_syncfree.py) -----------------------------------
+def test_syncfree_wrappers_are_stock_outside_a_scope_and_for_host_tensors():
+    """The wrappers installed by the first scope delegate to PyTorch's own functions outside a scope, and inside one for
+    anything that does not live on a HIP device: same objects, same values, same errors at the same place."""
+    from aesmc_amd import _syncfree
+    loc = torch.zeros(3)
+    with _syncfree.scope():
+        inside = torch.distributions.Normal(loc, 0.7)
+        assert _syncfree.active()
+        assert inside._validate_args is True
+        with pytest.raises(ValueError, match="Expected parameter scale"):
+            torch.distributions.Normal(loc, -1.0)          # a host tensor is checked on the host, at once
+        with pytest.raises(ValueError, match="within the support"):
+            torch.distributions.Exponential(torch.ones(3)).log_prob(-torch.ones(3))
+        assert torch.distributions.Normal(loc, -1.0, validate_args=False).scale[0] == -1.0
+    assert not _syncfree.active()
+    outside = torch.distributions.Normal(loc, 0.7)
+    torch.testing.assert_close(inside.scale, outside.scale, rtol=0, atol=0)
+    torch.testing.assert_close(inside.log_prob(loc + 0.3), outside.log_prob(loc + 0.3), rtol=0, atol=0)
+    with pytest.raises(ValueError, match="Expected parameter scale"):
+        torch.distributions.Normal(loc, -1.0)
+    # eager validation mode: PyTorch's own __init__ / _validate_sample even inside a scope
+    from aesmc_amd import settings
+    with _syncfree.scope(), settings.override(validation_mode="eager"):
+        with pytest.raises(ValueError, match="Expected parameter scale"):
+            torch.distributions.Normal(loc, -1.0)
+
+
+def test_syncfree_constant_cache_keys_on_type_value_dtype_and_sign():
+    from aesmc_amd import _syncfree
+    cpu = torch.device("cpu")
+    a = _syncfree.constant(0.7, torch.float32, cpu)
+    assert a is _syncfree.constant(0.7, torch.float32, cpu)
+    assert a is not _syncfree.constant(0.7, torch.float64, cpu)
+    assert float(a) == float(torch.tensor(0.7, dtype=torch.float32))
+    assert _syncfree.constant(1, torch.float32, cpu) is not _syncfree.constant(1.0, torch.float32, cpu)
+    assert _syncfree.constant(True, torch.float32, cpu) is not _syncfree.constant(1, torch.float32, cpu)
+    assert np.signbit(float(_syncfree.constant(-0.0, torch.float32, cpu)))
+    assert not np.signbit(float(_syncfree.constant(0.0, torch.float32, cpu)))
+
+
+def test_reference_style_1d_model_under_the_oracle_provider_matches_the_port(oracle_backend):
+    """The literal reference classes (Python-number scales, default validate_args) through `infer` with the scope
+    active: the CPU port of the reference on the same draws gives the same numbers."""
+    from aesmc_amd.testing import replay
+    from oracle import reference_port
+
+    def parts(which):
+        return (models.Lgssm1dInitial(0.0, 1.0), models.Lgssm1dTransition(0.7, 0.5, state=which),
+                models.Lgssm1dEmission(0.9, 0.4, state=which), models.Lgssm1dProposal(0.8, 0.8, state=which))
+    torch.manual_seed(3)
+    observations = [torch.randn(4) for _ in range(5)]
+    flags = dict(return_log_marginal_likelihood=True, return_log_weights=True, return_ancestral_indices=True)
+    torch.manual_seed(0)
+    theirs = parts(reference_port)
+    np.random.seed(1)
+    with replay.record() as tape:
+        want = reference_port.infer("smc", observations, *theirs, 16, **flags)
+    torch.manual_seed(0)
+    ours = parts(state)
+    with replay.replay(tape):
+        got = inference.infer("smc", observations, *ours, 16, **flags)
+    for a, b in zip(got["ancestral_indices"], want["ancestral_indices"]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(got["log_marginal_likelihood"], want["log_marginal_likelihood"], rtol=1e-5, atol=1e-5)
