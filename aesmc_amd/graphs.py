@@ -15,9 +15,12 @@ What stays faithful to the eager path
     raises the same exceptions as `inference.infer`.
 
 Requirements on the model (they hold for any capture): callables must not synchronise with the
-host (construct distributions with validate_args=False and tensor — not Python-number —
-parameters, no .item()/.cpu() inside), shapes are fixed, parameters and observations stay at the
-same addresses (update them in place).  With backward=True no autograd graph built EAGERLY from the
+host (no .item() / .cpu() / float() of device tensors inside, no tensors made from host data per
+call), shapes are fixed, parameters and observations stay at the same addresses (update them in
+place).  Distributions in the reference's own style — `Normal(mult * x, 0.5)` with a Python-number
+scale and PyTorch's default validate_args — are fine: inside `infer` the number is a cached device
+constant and the checks run on the device (aesmc_amd/_syncfree.py).  Host-side state the callables
+read is FROZEN at its value during the capture (see `train.train`'s frozen-callables contract).  With backward=True no autograd graph built EAGERLY from the
 same parameters may still be alive when the capture starts (drop earlier `loss` tensors): PyTorch
 would reuse that graph's gradient accumulators, which are bound to the eager stream, and the
 capture could not be closed.
@@ -207,12 +210,12 @@ class GraphedLoss:
                 raise
             raise RuntimeError(
                 "aesmc_amd: the ELBO could not be captured into a hipGraph — something in the four "
-                "callables talks to the host while the stream is capturing. Usual causes: a "
-                "distribution built with validate_args=True (its checks call .all() on the device: "
-                "pass validate_args=False), a Python-number distribution parameter such as "
-                "Normal(loc, 0.7) (uploaded on every call: keep it in a buffer on the device), "
-                ".item() / .cpu() / print of a device tensor, or host-side control flow on tensor "
-                "values. Original error: {}".format(error)) from error
+                "callables talks to the host while the stream is capturing. Usual causes: "
+                ".item() / float() / .cpu() / print of a device tensor, host-side control flow on tensor "
+                "values, a tensor made from host data on every call (torch.tensor(..., device=...): keep it "
+                "in a buffer on the device), or validation_mode 'eager' (PyTorch's own argument checks read "
+                ".all() on the host; in the default 'deferred' mode Python-number parameters and default "
+                "validate_args are fine). Original error: {}".format(error)) from error
         self.replays = 0
         if backward and verify_replays > 0:
             self._verify(verify_replays)

@@ -129,16 +129,23 @@ def test_train_with_hip_graph_learns(hip_device):
 def test_train_captures_by_default_and_follows_the_eager_trajectory(hip_device):
     """train() as a user of the reference calls it — no hip_graph argument: eager for the first minibatches, then the
     captured loss + backward.  The capture consumes no random numbers and a replay consumes them as an eager step does,
-    so the seeded run's losses are the eager loop's (`hip_graph=False`), minibatch for minibatch; a model whose
-    callables cannot be captured (validate_args=True: a host sync) falls back to the eager loop with one warning."""
+    so the seeded run's losses are the eager loop's (`hip_graph=False`), minibatch for minibatch.  PyTorch's default
+    `validate_args=True` is no obstacle (inside `infer` the checks stay on the device: aesmc_amd/_syncfree.py); a model
+    whose callables really talk to the host (a `float(...)` of a device tensor) falls back to the eager loop with one
+    warning."""
     import warnings
     import numpy as np
     from aesmc_amd import train
 
-    def run(hip_graph, validate_args=False):
+    class Chatty(models.LgssmNd):
+        def emission(self, latents=None, time=None, previous_observations=None):
+            float(self.C.sum())      # a host read of a device tensor: no capture can hold it
+            return super().emission(latents=latents, time=time, previous_observations=previous_observations)
+
+    def run(hip_graph, validate_args=False, cls=models.LgssmNd):
         torch.manual_seed(3)
         np.random.seed(3)
-        model = models.LgssmNd(3, seed=0, validate_args=validate_args).to(hip_device)
+        model = cls(3, seed=0, validate_args=validate_args).to(hip_device)
         truth = models.LgssmNd(3, seed=1, validate_args=False).to(hip_device)
         loader = train.get_synthetic_dataloader(truth.initial, truth.transition, truth.emission, 6, 16)
         history = []
@@ -166,11 +173,23 @@ def test_train_captures_by_default_and_follows_the_eager_trajectory(hip_device):
     np.testing.assert_allclose(auto, eager, rtol=2e-5)
     for a, b in zip(auto_params, eager_params):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+    # PyTorch's default validate_args: captured all the same, no warning, the eager loop's numbers
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        calls["replays"] = 0
+        graphs.GraphedLoss.__call__ = counting
+        try:
+            validated, _ = run(None, validate_args=None)
+        finally:
+            graphs.GraphedLoss.__call__ = real
+    assert calls["replays"] == 12 and not [w for w in caught if "captured" in str(w.message)], [str(w.message) for w in caught]
+    want, _ = run(False, validate_args=None)
+    np.testing.assert_allclose(validated, want, rtol=2e-5)
     # not capturable: one warning, the eager loop's numbers
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
-        fallback, _ = run(None, validate_args=True)
-    want, _ = run(False, validate_args=True)
+        fallback, _ = run(None, cls=Chatty)
+    want, _ = run(False, cls=Chatty)
     assert sum("could not be captured" in str(w.message) for w in caught) == 1
     np.testing.assert_allclose(fallback, want, rtol=2e-5)
 
@@ -253,14 +272,16 @@ def test_replayed_gradients_stay_equal_to_eager_over_a_training_run(hip_device):
 
 
 def test_capture_failure_explains_itself(hip_device):
-    """A callable that synchronises with the host (Python-number scale: uploaded on every call)
-    cannot be captured; the error must say what to change."""
+    """A callable that talks to the host (a scale uploaded with `torch.tensor(..., device=)` on every call — a
+    pageable host-to-device copy) cannot be captured; the error must say what to change.  (A Python-number parameter
+    as such is fine: inside `infer` it is a cached device constant, tests/test_gpu_reference_models.py.)"""
     from aesmc_amd import state
     model, observations, parts = make(hip_device)
 
     def emission(latents=None, time=None, previous_observations=None):
         dist = model.emission(latents=latents, time=time)
-        return state.set_batch_shape_mode(torch.distributions.Normal(dist.loc, 0.5, validate_args=False),
+        scale = torch.tensor(0.5, device=hip_device)
+        return state.set_batch_shape_mode(torch.distributions.Normal(dist.loc, scale, validate_args=False),
                                           state.BatchShapeMode.FULLY_EXPANDED)
 
     with pytest.raises(RuntimeError, match="could not be captured"):
