@@ -171,6 +171,7 @@ class HipKernels:
         self._flags = {}
         self._lock = threading.Lock()
         self.timer = None  # set to a KernelTimer to time every launch (bench only)
+        self._flag_constants = {}
         self.lds_max_particles = int(self._lib.aesmc_ancestor_index_lds_max_particles())
         self._affine_max_dim = None
         self._map_cache = {}        # id(weight) -> (weight, its aesmc_affine_map, (shape, strides))
@@ -210,17 +211,23 @@ class HipKernels:
                 if not torch.cuda.is_current_stream_capturing():
                     word.zero_()
 
+    def _flag_unless_all(self, valid, bit):
+        """ORs `bit` into the status word unless every element of the boolean tensor `valid` is True — device-side, no
+        synchronisation, three small launches (all, select, or)."""
+        device = valid.device
+        constants = self._flag_constants.get((device, bit))
+        if constants is None:
+            constants = self._flag_constants[(device, bit)] = (
+                torch.zeros((), dtype=torch.int32, device=device), torch.full((), bit, dtype=torch.int32, device=device))
+        self.flags(device).bitwise_or_(torch.where(valid.all(), constants[0], constants[1]))
+
     def defer_support_check(self, valid):
-        """ORs FLAG_VALUE_OUTSIDE_SUPPORT into the status word if any element of the boolean
-        tensor `valid` is False — device-side, no synchronisation."""
-        bad = torch.logical_not(valid).any().to(torch.int32) * _lib.FLAG_VALUE_OUTSIDE_SUPPORT
-        self.flags(valid.device).bitwise_or_(bad)
+        """FLAG_VALUE_OUTSIDE_SUPPORT unless all of `valid` (a value against a distribution's support) holds."""
+        self._flag_unless_all(valid, _lib.FLAG_VALUE_OUTSIDE_SUPPORT)
 
     def defer_parameter_check(self, valid):
-        """ORs FLAG_INVALID_PARAMETER into the status word if any element of the boolean tensor `valid` (a
-        distribution parameter against its constraint) is False — device-side, no synchronisation."""
-        bad = torch.logical_not(valid).any().to(torch.int32) * _lib.FLAG_INVALID_PARAMETER
-        self.flags(valid.device).bitwise_or_(bad)
+        """FLAG_INVALID_PARAMETER unless all of `valid` (a distribution parameter against its constraint) holds."""
+        self._flag_unless_all(valid, _lib.FLAG_INVALID_PARAMETER)
 
     @staticmethod
     def _stream(t):

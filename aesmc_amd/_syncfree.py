@@ -59,6 +59,7 @@ def constant(value, dtype, device):
     held = _CONSTANTS.get(key)
     if held is None:
         held = torch.full((), value, dtype=dtype, device=device)
+        held._aesmc_number = value      # (its value without a device read: parameter checks of a number run on the host)
         if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             _CONSTANTS[key] = held
     return held
@@ -141,7 +142,14 @@ def _init(self, batch_shape=torch.Size(), event_shape=torch.Size(), validate_arg
         if torch.is_tensor(value) and value.is_cuda and _is_real(constraint):
             continue      # only NaN violates it; NaN reaches the log-weights and raises there (FloatingPointError)
         if type(value) in (torch.Tensor, torch.nn.Parameter) and getattr(constraint, "event_dim", 0) == 0:
-            value = _one_value(value)      # (plain tensors only: a lazy particle tensor answers `check` without values)
+            base = value if value._base is None else value._base
+            number = getattr(base, "_aesmc_number", None)
+            if number is not None and base.numel() == 1:
+                # a Python number `broadcast_all` turned into a cached device constant: checked on the host, as a
+                # host tensor of the same dtype (so the verdict is the one the device values would get)
+                value = torch.tensor(number, dtype=value.dtype)
+            else:
+                value = _one_value(value)      # (plain tensors only: a lazy particle tensor answers `check` without values)
         what = "{} of {} ({})".format(name, type(self).__name__, constraint)
         if not _defer(constraint.check(value), _lib.FLAG_INVALID_PARAMETER, what):
             raise ValueError("Expected parameter {} ({} of shape {}) of distribution {} to satisfy the constraint {}, "
