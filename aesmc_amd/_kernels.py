@@ -13,6 +13,7 @@ import threading
 import torch
 
 from . import _lib
+from . import settings
 
 _DTYPE_TAG = {torch.float32: _lib.F32, torch.float64: _lib.F64}
 
@@ -179,7 +180,7 @@ class HipKernels:
         self._wide_dim = None       # aesmc_affine_wide_dim(): the extent K17 / K18 are built for
         self._pairs = None          # (key, tensor): the interleaved weight pairs of the maps the fused launch met last
         self.evaluation = 0         # bumped by `begin_evaluation`: what a cached weight-pair block belongs to
-        self.WEIGHT_PAIRS = __import__("os").environ.get("AESMC_K16_PAIRS", "1") != "0"      # measurement knob
+        self.WEIGHT_PAIRS = settings.knob("AESMC_K16_PAIRS", "1") != "0"      # measurement knob
 
     # ---- deferred status word ---------------------------------------------------------------
     def flags(self, device):
@@ -758,7 +759,7 @@ class HipKernels:
 
     # Below this many elements the noise launch + K6 pair is as fast (both are launch-latency bound) and the drawn
     # kernel's 4-byte accesses buy nothing.
-    RSAMPLE_DRAWN_MIN_ELEMENTS = int(__import__("os").environ.get("AESMC_RSAMPLE_DRAWN_MIN", str(1 << 18)))
+    RSAMPLE_DRAWN_MIN_ELEMENTS = int(settings.knob("AESMC_RSAMPLE_DRAWN_MIN", str(1 << 18)))
 
     def normal_rsample_drawn(self, noise, loc, scale, shape):
         """K6 with the noise formed in the launch: loc + n * scale -> dense float32 [B,K,*] of `shape`, n being the
@@ -978,7 +979,7 @@ class HipKernels:
     # against 3.0 + 7.3 for the fill followed by K15; B=256 K=1024: 14.6 against 6.2 + 13.8; profiles/r05_k16_small_shapes.txt).
     # Rounds 3 / 4 needed 1M / 0.5M particles for the persistent form to win.  Shapes the launch's item geometry does not
     # cover (fewer than 128 particles per row) are declined by the library and take the fill route as before.
-    DRAWN_MIN_PARTICLES = int(__import__("os").environ.get("AESMC_K16_MIN_PARTICLES", "0"))
+    DRAWN_MIN_PARTICLES = int(settings.knob("AESMC_K16_MIN_PARTICLES", "0"))
 
     def philox_normal(self, stream_desc, shape, device):
         """The float32 tensor `torch.empty(shape).normal_()` would have held for the generator state
@@ -1098,29 +1099,37 @@ class HipKernels:
         return out
 
     def begin_evaluation(self):
-        """Called once per `infer`: weight pairs built for an earlier evaluation are not reused (the weights may have been
-        stepped in between; inside a hipGraph capture the rebuild must be part of the captured work)."""
+        """Called once per `infer`: weight pairs built for an earlier evaluation are dropped (the weights may have been
+        stepped in between; inside a hipGraph capture the rebuild must be part of the captured work; and the entry holds
+        references to the weight tensors — with their autograd history, if they are computed per evaluation — which must
+        not outlive the evaluation they belong to)."""
         self.evaluation += 1
+        self._pairs = None
 
     def _weight_pairs(self, maps, weights, device):
         """The three maps' weights as interleaved pairs (aesmc_affine_weight_pairs) for the fused propagation launch: built
-        by one small launch the first time an evaluation meets these weights, then reused by its other timesteps."""
-        held = self._pairs
+        by one small launch the first time an evaluation meets these weights, then reused by its other timesteps.  The
+        entry keeps the weight tensors alive for as long as it stands (until the next `begin_evaluation`), so a cached
+        (address, version) can never be met again on a DIFFERENT tensor that the allocator placed where a freed one was."""
         w0, w1, w2 = weights
-        if held is not None and held[2] is w0 and held[3] is w1 and held[4] is w2 and held[0] == (
-                self.evaluation, w0._version, w1._version, w2._version):
-            return held[1]      # (the very tensors of this evaluation's last step, unchanged since: a model's next timestep)
+        if any(w.is_inference() for w in weights):      # (no version counter to tell an in-place update by: never cached)
+            pairs = torch.empty(int(self._lib.aesmc_affine_weight_pairs_floats()), dtype=torch.float32, device=device)
+            _lib.check(self._lib.aesmc_affine_weight_pairs(ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]),
+                                                           ctypes.byref(maps[2][0]), _ptr(pairs), self._stream(pairs)),
+                       "aesmc_affine_weight_pairs")
+            return pairs
+        held = self._pairs
         key = (self.evaluation, w0._version, w1._version, w2._version)
+        if held is not None and held[2] is w0 and held[3] is w1 and held[4] is w2 and held[0] == key:
+            return held[1]      # (the very tensors of this evaluation's last step, unchanged since: a model's next timestep)
         layout = tuple((w.data_ptr(), w.shape, w.stride()) for w in weights)
         if held is not None and held[0] == key and held[5] == layout:
-            return held[1]      # (new view objects of the same storage: `x @ W.t()` makes one per call)
+            return held[1]      # (new view objects of the same, still referenced, storage: `x @ W.t()` makes one per call)
         pairs = torch.empty(int(self._lib.aesmc_affine_weight_pairs_floats()), dtype=torch.float32, device=device)
         _lib.check(self._lib.aesmc_affine_weight_pairs(ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]),
                                                        ctypes.byref(maps[2][0]), _ptr(pairs), self._stream(pairs)),
                    "aesmc_affine_weight_pairs")
-        # (a view with an autograd history is not kept: a cache that outlives the step would keep the step's graph alive)
-        keep = [None if w.grad_fn is not None else w for w in weights]
-        self._pairs = (key, pairs, keep[0], keep[1], keep[2], layout)
+        self._pairs = (key, pairs, w0, w1, w2, layout)
         return pairs
 
     def affine_propagate_drawn(self, x_src, noise, y_rows, transition, emission, proposal, scales, out_x,

@@ -308,6 +308,17 @@ __device__ __forceinline__ void gather_row_from_lds(const int *anc, const char *
   }
 }
 
+// min over lanes >= this one of x (inclusive), by six bpermute steps: used only where the children ranges are written
+// (training), to make them monotone on knife-edge rows — see the clamp in ancestor_index_inv_kernel.
+__device__ __forceinline__ int wave_suffix_min(int x, int lane) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int other = __shfl_down(x, d, kWave);
+    if (lane + d < kWave) x = min(x, other);
+  }
+  return x;
+}
+
 // (Holding the kernel to 64 registers — four 512-lane workgroups per CU instead of three, so that
 // 1024 batch rows are resident at once — was measured and bought nothing: 78.4 vs 77.7 us at B=1024
 // K=4096, with a 20-byte spill.)
@@ -472,7 +483,38 @@ __global__ __launch_bounds__(kMaxThreads, (PAYLOAD || C > 8) ? 1 : 8) void ances
       first[i] = K;
     }
   }
-  // By-product for the gather's backward: first[j] = how many positions precede the CDF at j = where the children
+  if (lane == 0) first_of_lane[wave] = first[0];            // the next wavefront's first entry, via LDS
+  int wave_min = K;
+  if (out_child_end != nullptr) {                           // (each wavefront's smallest first entry: see the clamp below)
+    wave_min = wave_suffix_min(first[0], lane);             // min over lanes >= this one, this wavefront
+    if (lane == 0) first_of_lane[16 + wave] = wave_min;
+  }
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) reinterpret_cast<int4 *>(marker + j0)[q] = make_int4(0, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) marker[j0 + i] = 0;
+  }
+  __syncthreads();
+  int next_lane_first = __shfl_down(first[0], 1, kWave);     // the next lane's first entry, in-register
+  if (lane == kWave - 1) next_lane_first = (wave + 1 < nwaves) ? first_of_lane[wave + 1] : K;
+  if (out_child_end != nullptr) {
+    // The children ranges must be monotone.  Within a lane first[] is (the lane's running sum is sequential); ACROSS lanes
+    // the CDF is assembled from tree-ordered partial sums, and where the weights in between underflow to exact zeros two
+    // lanes hold the same sum associated differently — one ulp apart in either order — so on a knife-edge position a
+    // later lane's first[] can come out one BELOW an earlier lane's.  The indices the markers produce are then the
+    // running maximum's, i.e. those of the SUFFIX MINIMUM of first[]; the ranges are made to say the same: every entry
+    // is clamped to the smallest first[] of all later lanes (a reverse scan over each lane's first entry: six bpermutes
+    // inside the wavefront, the later wavefronts' minima through LDS).
+    int bound = __shfl_down(wave_min, 1, kWave);                       // min over the lanes BEHIND this one
+    if (lane == kWave - 1) bound = K;
+    for (int w = wave + 1; w < nwaves; ++w) bound = min(bound, first_of_lane[16 + w]);
+#pragma unroll
+    for (int i = 0; i < C; ++i) first[i] = min(first[i], bound);
+    next_lane_first = min(next_lane_first, bound);
+  }
+  // By-product for the gather's backward (after the clamp above): first[j] = how many positions precede the CDF at j = where the children
   // of particles 0..j end, so the children of particle j are the positions [first[j-1], first[j]) — one run, because
   // the indices are non-decreasing.  (aesmc_affine_step_backward_resampled sums a particle's children with it.)
   if (out_child_end != nullptr && owns_idx) {
@@ -489,17 +531,6 @@ __global__ __launch_bounds__(kMaxThreads, (PAYLOAD || C > 8) ? 1 : 8) void ances
         if (j0 + i < K) ends[i] = first[i];
     }
   }
-  if (lane == 0) first_of_lane[wave] = first[0];            // the next wavefront's first entry, via LDS
-  if constexpr (C % 4 == 0) {
-#pragma unroll
-    for (int q = 0; q < C / 4; ++q) reinterpret_cast<int4 *>(marker + j0)[q] = make_int4(0, 0, 0, 0);
-  } else {
-#pragma unroll
-    for (int i = 0; i < C; ++i) marker[j0 + i] = 0;
-  }
-  __syncthreads();
-  int next_lane_first = __shfl_down(first[0], 1, kWave);     // the next lane's first entry, in-register
-  if (lane == kWave - 1) next_lane_first = (wave + 1 < nwaves) ? first_of_lane[wave + 1] : K;
 #pragma unroll
   for (int i = 0; i < C; ++i) {
     const int j = j0 + i;
@@ -852,12 +883,22 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
       }
     }
   }
-  // By-product for the gather's backward: first[j] = where the children of particles 0..j end (see the kernel above)
+  // By-product for the gather's backward: first[j] = where the children of particles 0..j end (see the kernel above),
+  // clamped to the suffix minimum of first[] so that the ranges are monotone on knife-edge rows too (the general kernel
+  // says why): the later lanes of this wavefront here, the later wavefronts — whose entries are not known before the
+  // barrier below — by a fix-up behind it that practically never runs.
+  int range_last = 0;
   if (out_child_end != nullptr) {
+    const int wave_min = wave_suffix_min(first[0], lane);
+    int bound = __shfl_down(wave_min, 1, kWave);
+    if (lane == kWave - 1) bound = K;
+    if (lane == 0) scratch_i[32 + wave] = wave_min;
     int32_t *ends = out_child_end + row * (int64_t)K + j0;
 #pragma unroll
     for (int q = 0; q < C / 4; ++q)
-      reinterpret_cast<int4 *>(ends)[q] = make_int4(first[4 * q], first[4 * q + 1], first[4 * q + 2], first[4 * q + 3]);
+      reinterpret_cast<int4 *>(ends)[q] = make_int4(min(first[4 * q], bound), min(first[4 * q + 1], bound),
+                                                    min(first[4 * q + 2], bound), min(first[4 * q + 3], bound));
+    range_last = min(first[C - 1], bound);
   }
   // ---- markers: slot first[j] holds j + 1 for the LAST particle that starts there ---------------------------------------
   {
@@ -874,6 +915,15 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
     }
   }
   __syncthreads();
+  if (out_child_end != nullptr) {
+    int later = K;
+    for (int w = wave + 1; w < nwaves; ++w) later = min(later, scratch_i[32 + w]);
+    if (range_last > later) {      // a later wavefront starts below this lane's ranges (an ulp-level inversion on a knife edge)
+      int32_t *ends = out_child_end + row * (int64_t)K + j0;
+      for (int i = 0; i < C; ++i)
+        if (ends[i] > later) ends[i] = later;
+    }
+  }
 
   // ---- idx[k] = running maximum of the markers ----------------------------------------------------------------------
   int best[C];
@@ -910,7 +960,7 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
 // which kernel a payload-free step launches: 0 by shape, 1 ancestor_index_inv_kernel always, 2 the lean form wherever it
 // applies (AESMC_K2_FORM=general / rows in the environment, or the test hook aesmc_test_set_k2_form)
 static int g_k2_form = [] {
-  const char *v = getenv("AESMC_K2_FORM");
+  const char *v = measurement_knob("AESMC_K2_FORM");
   return v == nullptr ? 0 : (v[0] == 'g' ? 1 : (v[0] == 'r' ? 2 : 0));
 }();
 static int g_k2_last_form = 0;
@@ -931,7 +981,7 @@ static int pick_threads(int64_t K, int chunk) {
 // than the shorter copy returns beyond two.  0 = automatic; AESMC_STEP_PARTS in the environment (or the test
 // hook aesmc_test_set_step_parts, which is not part of the C ABI of include/aesmc_hip.h) pins a value.
 static int g_step_parts = [] {
-  const char *v = getenv("AESMC_STEP_PARTS");
+  const char *v = measurement_knob("AESMC_STEP_PARTS");
   const int parts = v != nullptr ? atoi(v) : 0;
   return (parts > 0 && (parts & (parts - 1)) == 0) ? parts : 0;
 }();

@@ -135,9 +135,17 @@ template <typename V> __device__ __forceinline__ V load16(const V *p, int stream
   return stream ? stream_load16(p) : *p;
 }
 
+// Measurement knobs (kernel forms, tile shapes, thresholds a timing experiment wants to pin) are read from the
+// environment ONLY when AESMC_MEASUREMENT_KNOBS=1 is set beside them: a product process never changes behaviour because
+// some AESMC_* variable happens to be exported.  (tools/*.py set it; tests select forms through the aesmc_test_* hooks.)
+static inline const char *measurement_knob(const char *name) {
+  static const bool enabled = [] { const char *v = getenv("AESMC_MEASUREMENT_KNOBS"); return v != nullptr && v[0] == '1'; }();
+  return enabled ? getenv(name) : nullptr;
+}
+
 static inline int stream_hint(uint64_t launch_bytes) {
   static const uint64_t threshold = [] {
-    const char *mb = getenv("AESMC_STREAM_MB");      // tuning knob; default: beyond L2 + half the MALL
+    const char *mb = measurement_knob("AESMC_STREAM_MB");      // tuning knob; default: beyond L2 + half the MALL
     return (uint64_t)(mb != nullptr ? atoll(mb) : 160) << 20;
   }();
   return launch_bytes >= threshold ? 1 : 0;

@@ -467,7 +467,7 @@ static int launch_affine_logweight(const void *xprev, const void *x, const void 
   if (anc_idx != nullptr && (!tab || N > 0x7fffffffLL || out_x == nullptr)) return AESMC_ERR_UNSUPPORTED;
   // persistent workgroups with the next tile prefetched (B=1024 K=4096 d=10: 106 us against 145 us with one
   // tile per workgroup); AESMC_LG_PREFETCH=0 selects the latter: a measurement knob
-  static const bool prefetch = [] { const char *v = getenv("AESMC_LG_PREFETCH"); return v == nullptr || v[0] != '0'; }();
+  static const bool prefetch = [] { const char *v = measurement_knob("AESMC_LG_PREFETCH"); return v == nullptr || v[0] != '0'; }();
   const unsigned grid = prefetch ? lg_persistent_grid(tiles, lds) : (unsigned)tiles;
 #define LG_LOGWEIGHT_ARGS                                                                                          \
   static_cast<const T *>(xprev), static_cast<const T *>(x), static_cast<const T *>(y), y_sb, lg_map(mp), lg_map(mg), \

@@ -635,7 +635,7 @@ static inline bool lg_few_tiles(int64_t N) { return N < ((int64_t)1 << 20); }
 
 // AESMC_LG_FWD_PPL=1: one particle per lane in K9 / K10 whatever the size (a measurement knob).
 static inline int lg_forward_ppl() {
-  static const int v = [] { const char *e = getenv("AESMC_LG_FWD_PPL"); return e != nullptr ? atoi(e) : 0; }();
+  static const int v = [] { const char *e = measurement_knob("AESMC_LG_FWD_PPL"); return e != nullptr ? atoi(e) : 0; }();
   return v;
 }
 

@@ -1078,7 +1078,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   const int64_t N = B * K;
   const int64_t dx = mp->dout, dy = mg->dout;
   const int dp = lg_pad_dim(std::max(dx, dy));
-  static const int forced = [] { const char *v = getenv("AESMC_LG_BWD_PPL"); return v != nullptr ? atoi(v) : 0; }();   // measurement knob
+  static const int forced = [] { const char *v = measurement_knob("AESMC_LG_BWD_PPL"); return v != nullptr ? atoi(v) : 0; }();   // measurement knob
   // rows of ten float32 values, tiles inside one batch row, an nn.Linear's weights: the second form of the step kernel
   bool rows_form = false;
   if constexpr (sizeof(T) == 4) rows_form = step && N % kLgBlock == 0 && affine_step_backward_rows_covers(mp, mg, mq, B, K);
@@ -1101,7 +1101,7 @@ static int launch_affine_logweight_backward(const void *xprev, const void *x, co
   if (child_grad != nullptr) {
     const int per_cu = (ppl == 2 || sizeof(T) == 8) ? 2 : (step ? LG_STEP_WAVES : 3);
     const size_t with_tile = lds + sizeof(T) * lg_tile_elems<T>((size_t)kLgBlock * ppl, dx);
-    static const bool off = [] { const char *v = getenv("AESMC_LG_CHILD_STAGE"); return v != nullptr && atoi(v) == 0; }();
+    static const bool off = [] { const char *v = measurement_knob("AESMC_LG_CHILD_STAGE"); return v != nullptr && atoi(v) == 0; }();
     if (!off && with_tile * per_cu <= (size_t)160 * 1024 && with_tile <= kLgLdsLimit) {
       child_stage = true;
       lds = with_tile;

@@ -725,7 +725,7 @@ int launch_affine_propagate_item(const void *xsrc, const int64_t *anc_idx, const
                                  const uint64_t *rng_state, const float *weight_pairs, hipStream_t stream);
 
 int g_fused_form = [] {
-  const char *v = getenv("AESMC_K16_FORM");      // ("roles": the first form whatever the shape — linear_gaussian_noise.hip)
+  const char *v = measurement_knob("AESMC_K16_FORM");      // ("roles": the first form whatever the shape — linear_gaussian_noise.hip)
   return v == nullptr ? 0 : (v[0] == 'p' ? 1 : (v[0] == 'i' ? 2 : 0));
 }();
 int g_fused_last_form = 0;
@@ -761,8 +761,8 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
   // here: 371 against 337 us at B=1024 K=4096 d=16, profiles/r04_k16bench_sweep.txt)
   if (ks > 3) return AESMC_ERR_UNSUPPORTED;
 #ifdef AESMC_K16_PROBES      /* timing experiments only (AESMC_HIPCC_FLAGS=-DAESMC_K16_PROBES): a probed launch's OUTPUT IS WRONG */
-  { const char *v = getenv("AESMC_K16_PROBE"); plan.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
-  { const char *v = getenv("AESMC_K16_STAMPS"); plan.stamps = v != nullptr ? reinterpret_cast<uint64_t *>(strtoull(v, nullptr, 10)) : nullptr; }
+  { const char *v = measurement_knob("AESMC_K16_PROBE"); plan.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
+  { const char *v = measurement_knob("AESMC_K16_STAMPS"); plan.stamps = v != nullptr ? reinterpret_cast<uint64_t *>(strtoull(v, nullptr, 10)) : nullptr; }
 #endif
   const uint32_t rs = ks == 1 ? 4 : (ks <= 3 ? 12 : 20);
   const size_t lds = sizeof(float) * (2 * (size_t)kTabF + 2 * (size_t)plan.tile_f + 4 * 2 * 64 * (size_t)rs + 4 * 16);
@@ -776,7 +776,7 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
       static_cast<float *>(out_lw), (uint32_t)K, (uint32_t)B, static_cast<float *>(out_x), anc_idx, flags, ps, plan
   // the maps' weights as scalar operands: rows of W contiguous ([dout, din] row-major, what an nn.Linear holds);
   // AESMC_K16_MAPS=matrix keeps the matrix-core form (a measurement knob; both give the same bits)
-  static const bool matrix_only = [] { const char *v = getenv("AESMC_K16_MAPS"); return v != nullptr && v[0] == 'm'; }();
+  static const bool matrix_only = [] { const char *v = measurement_knob("AESMC_K16_MAPS"); return v != nullptr && v[0] == 'm'; }();
   const auto rows_contiguous = [](const aesmc_affine_map *m) {
     return m->stride_in == 1 && m->stride_out == m->din && (reinterpret_cast<uintptr_t>(m->weight) & 3u) == 0;
   };

@@ -498,7 +498,7 @@ static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_id
   if ((uint64_t)K < runp) return AESMC_ERR_UNSUPPORTED;        // a run of particles may span two batch rows, not more
   LgNoisePlan plan;
 #ifdef AESMC_K16_PROBES      /* timing experiments only (build with AESMC_HIPCC_FLAGS=-DAESMC_K16_PROBES): a probed launch's OUTPUT IS WRONG */
-  static const int probe = [] { const char *v = getenv("AESMC_K16_PROBE"); return v != nullptr ? atoi(v) : 0; }();
+  static const int probe = [] { const char *v = measurement_knob("AESMC_K16_PROBE"); return v != nullptr ? atoi(v) : 0; }();
   plan.probe = probe;
 #else
   plan.probe = 0;
@@ -598,7 +598,7 @@ extern "C" int aesmc_affine_normal_propagate_drawn_paired(
     return AESMC_ERR_UNSUPPORTED;
   if (B == 0 || K == 0) return AESMC_OK;
   // AESMC_K16_FORM=roles: the first form whatever the shape (a measurement knob; both forms give the same bits)
-  static const bool first_form = [] { const char *v = getenv("AESMC_K16_FORM"); return v != nullptr && v[0] == 'r'; }();
+  static const bool first_form = [] { const char *v = measurement_knob("AESMC_K16_FORM"); return v != nullptr && v[0] == 'r'; }();
   if (!first_form) {
     const int status = launch_affine_propagate_fused(x_src, ancestors, y, y_stride_b, transition, emission, proposal,
                                                      scale_p, scale_g, scale_q, out_x, out_lw, flags, B, K, seed, offset,

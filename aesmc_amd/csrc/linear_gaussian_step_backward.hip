@@ -698,7 +698,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
 
 // 0: this form where it covers the call; 1: always the first form (tiles through LDS).  AESMC_K14_FORM=tiles in the
 // environment, or the test hook below (not part of the C ABI of include/aesmc_hip.h).
-static std::atomic<int> g_sb_form{[] { const char *v = getenv("AESMC_K14_FORM"); return (v != nullptr && v[0] == 't') ? 1 : 0; }()};
+static std::atomic<int> g_sb_form{[] { const char *v = measurement_knob("AESMC_K14_FORM"); return (v != nullptr && v[0] == 't') ? 1 : 0; }()};
 static std::atomic<int> g_sb_grid{0};      // > 0: workgroups of either form's launch (the records' association follows the grid)
 int affine_step_backward_forced_grid() { return g_sb_grid.load(std::memory_order_relaxed); }
 
@@ -772,7 +772,7 @@ static void sb_launch_either(bool paired, bool gathers, bool folds, unsigned gri
 
 // does the rows form take the maps' interleaved weight pairs (AESMC_K14_PAIRS=0 in the environment: a measurement knob)?
 bool affine_step_backward_rows_pairs() {
-  static const bool no_pairs = [] { const char *v = getenv("AESMC_K14_PAIRS"); return v != nullptr && v[0] == '0'; }();
+  static const bool no_pairs = [] { const char *v = measurement_knob("AESMC_K14_PAIRS"); return v != nullptr && v[0] == '0'; }();
   return kSbPacked && !no_pairs;
 }
 
@@ -801,7 +801,7 @@ int launch_affine_step_backward_rows(const float *xprev, const float *x, const f
   a.has_lse = grad_lse != nullptr ? 1 : 0; a.has_glw = grad_lw != nullptr ? 1 : 0;
   a.carry_records = out.carry != nullptr ? out.carry_records : 0;
 #ifdef AESMC_K14_PROBES
-  { const char *v = getenv("AESMC_K14_PROBE"); a.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
+  { const char *v = measurement_knob("AESMC_K14_PROBE"); a.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
 #endif
   // the chains' weights as interleaved pairs, written into the workspace's tail by a small launch in front of this one (the
   // weights may have been stepped since the last call; inside a hipGraph capture the rebuild is captured with it)

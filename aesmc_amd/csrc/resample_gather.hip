@@ -554,7 +554,7 @@ using namespace aesmc;
 // (a measurement / test hook, not part of the C ABI of include/aesmc_hip.h: AESMC_SORTED_BACKWARD_KERNEL in the
 // environment sets the default, aesmc_test_set_sorted_backward_kernel switches inside one process)
 static int g_sorted_backward_kernel = [] {
-  const char *v = getenv("AESMC_SORTED_BACKWARD_KERNEL");
+  const char *v = measurement_knob("AESMC_SORTED_BACKWARD_KERNEL");
   return (v != nullptr && v[0] == '1') ? 1 : 0;
 }();
 extern "C" int aesmc_test_set_sorted_backward_kernel(int which) {

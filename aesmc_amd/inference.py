@@ -14,7 +14,6 @@ Differences from the reference that a caller can observe (all documented in DESI
 import collections.abc
 import contextlib
 import contextvars
-import os as _os
 
 import numpy as np
 import torch
@@ -89,7 +88,7 @@ class ResampledHistory(collections.abc.Sequence):
         return self._cache[position]
 
 
-_ZERO_COPY_UNIFORMS = _os.environ.get("AESMC_ZERO_COPY_UNIFORMS", "1") != "0"      # measurement knob
+_ZERO_COPY_UNIFORMS = settings.knob("AESMC_ZERO_COPY_UNIFORMS", "1") != "0"      # measurement knob
 
 
 class _MappedBlock:

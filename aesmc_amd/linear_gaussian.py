@@ -96,21 +96,6 @@ def affine_terms(distribution):
     return terms
 
 
-def particle_mlp(x, weight1, offset1, weight2, bias2=None):
-    """Deprecated since 0.2.0 (kept for one release): the two-layer tanh net over the particles
-    bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T  for x [B,K,din], weight1 [H,din], offset1 [H] or [B,H],
-    weight2 [dout,H].  Its kernel (K13) left the library — a learned proposal net is the user's PyTorch module
-     — so this is the PyTorch expression, on whatever device the operands live."""
-    import warnings
-    warnings.warn("aesmc_amd.linear_gaussian.particle_mlp is deprecated: write the net with PyTorch's own modules",
-                  DeprecationWarning, stacklevel=2)
-    if offset1.dim() == 2 and x.dim() == 3:
-        offset1 = offset1.unsqueeze(1)
-    hidden = torch.tanh(x @ weight1.t() + offset1)
-    out = hidden @ weight2.t()
-    return out if bias2 is None else out + bias2
-
-
 class AffineNormal(torch.distributions.Normal):
     """Normal(loc = source @ weight.T + offset, scale) with the location evaluated on demand.
 

@@ -54,19 +54,53 @@ class Settings:
         return self
 
 
+def knob(name, default=None):
+    """An environment MEASUREMENT knob (a threshold or a kernel form a timing experiment pins): read only when
+    AESMC_MEASUREMENT_KNOBS=1 is set beside it — as the library's own `measurement_knob` (csrc/common.hpp) — so that a
+    product process never changes behaviour because some AESMC_* variable happens to be exported."""
+    if os.environ.get("AESMC_MEASUREMENT_KNOBS", "0")[:1] != "1":
+        return default
+    return os.environ.get(name, default)
+
+
 _DEFAULT = Settings(lazy_gather=_env_flag("AESMC_LAZY_GATHER"), fold_gather_backward=_env_flag("AESMC_FOLD_GATHER_BACKWARD"),
                     kernel_noise=_env_flag("AESMC_KERNEL_NOISE"))
-_SCOPED = contextvars.ContextVar("aesmc_amd_settings", default=None)
+_SCOPED = contextvars.ContextVar("aesmc_amd_settings", default=None)      # the innermost `override`'s CHANGED fields only
+_FIELDS = tuple(field.name for field in dataclasses.fields(Settings))
+
+
+class _Resolved:
+    """What `current()` hands out inside an `override`: every field read is the scoped value if the block (or an
+    enclosing one) changed that field, else the process-wide default AS IT IS NOW — so `set_default(...)` and the module
+    level setters (`state.set_fused_normal`, ...) called inside a `with override(...)` block take effect at once for the
+    fields the block did not pin."""
+    __slots__ = ("_changes",)
+
+    def __init__(self, changes):
+        object.__setattr__(self, "_changes", changes)
+
+    def __getattr__(self, name):
+        changes = object.__getattribute__(self, "_changes")
+        if name in changes:
+            return changes[name]
+        return getattr(_DEFAULT, name)
+
+    def __setattr__(self, name, value):
+        raise AttributeError("settings.current() is read-only: use settings.set_default or settings.override")
 
 
 def current():
-    """The settings in force here: the innermost `override` of this context, else the process-wide defaults."""
+    """The settings in force here: per field, the innermost `override` of this context that names it, else the
+    process-wide default.  (Context variables are per thread and per asyncio task and are NOT inherited by threads
+    started elsewhere: autograd's worker threads and user threads read the process defaults — the autograd functions of
+    this package capture what they need in forward.)"""
     scoped = _SCOPED.get()
-    return _DEFAULT if scoped is None else scoped
+    return _DEFAULT if scoped is None else _Resolved(scoped)
 
 
 def set_default(**changes):
-    """Changes the process-wide defaults (what every context sees outside an `override`)."""
+    """Changes the process-wide defaults (what every context sees outside an `override`, and inside one for the fields it
+    does not name)."""
     candidate = dataclasses.replace(_DEFAULT, **changes).validate()
     for name in changes:
         setattr(_DEFAULT, name, getattr(candidate, name))
@@ -74,8 +108,13 @@ def set_default(**changes):
 
 @contextlib.contextmanager
 def override(**changes):
-    """`current()` with `changes` applied, for the duration of the block, in this context only."""
-    token = _SCOPED.set(dataclasses.replace(current(), **changes).validate())
+    """The named fields changed for the duration of the block, in this context only; every other field keeps following
+    the defaults (and any enclosing `override`)."""
+    unknown = [name for name in changes if name not in _FIELDS]
+    if unknown:
+        raise TypeError("settings.override: unknown field(s) {}".format(", ".join(unknown)))
+    dataclasses.replace(_DEFAULT, **changes).validate()
+    token = _SCOPED.set(dict(_SCOPED.get() or {}, **changes))
     try:
         yield
     finally:

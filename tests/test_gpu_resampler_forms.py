@@ -146,3 +146,44 @@ def test_the_lean_form_declines_ragged_rows_and_payloads(kernels, hip_device, k2
     idx, lse, moved = kernels.resample_step(log_w, u, x, want_lse=True)      # a payload: the fused step's kernel
     assert kernels._lib.aesmc_test_last_k2_form() == GENERAL
     assert torch.equal(moved, torch.gather(x, 1, idx.unsqueeze(-1).expand_as(x)))
+
+
+@pytest.mark.parametrize("form", [GENERAL, ROWS])
+@pytest.mark.parametrize("shape", [(2048, 4096), (512, 2048), (256, 16384)])
+def test_children_ranges_stay_monotone_on_knife_edge_rows(kernels, hip_device, k2_form, form, shape):
+    """a tree-ordered scan holds the same partial sum, associated differently, in every lane of a stretch of
+    exact-zero weights — one ulp apart in either order — so where a resampling position sits exactly on that CDF value a
+    later lane's first[] could come out one BELOW an earlier lane's, and ranges written from the raw first[] overlapped.
+    Rows built to sit on that edge: random weights, a block of zero weights spanning many lanes (log-weight -1e4: exp
+    underflows to exactly 0), the SAME random weights mirrored, u = 0 and K a power of two — the CDF over the zero block
+    is 1/2 to within rounding, K/2 an exact position.  The ranges must be non-decreasing, end at K, and be exactly the
+    counts of the indices the launch returned, which are the indices of the same launch without the ranges."""
+    B, K = shape
+    gen = torch.Generator().manual_seed(K + B)
+    quarter = K // 4
+    side = torch.randn(B, quarter, generator=gen, dtype=torch.float64)
+    log_w = torch.cat([side, torch.full((B, K - 2 * quarter), -1.0e4, dtype=torch.float64), side.flip(1)], dim=1)
+    log_w = log_w.to(hip_device)
+    u = torch.zeros(B, dtype=torch.float64, device=hip_device)
+    k2_form(form)
+    idx, _, child_end, ran = _step(kernels, log_w, u, ranges=True)
+    assert ran == form
+    other, _, _, _ = _step(kernels, log_w, u, ranges=False)      # the same kernel without the ranges: the same indices
+    assert torch.equal(idx, other)
+    # (the two kernels associate their partial sums differently, so ON the edge they may legitimately disagree about the
+    #  one position K/2 — as any two summation orders do; everywhere else they agree)
+    k2_form(GENERAL if form == ROWS else ROWS)
+    across, _, _, _ = _step(kernels, log_w, u, ranges=False)
+    assert int((across != idx).sum(dim=1).max()) <= K - 2 * quarter + 1
+    assert int(((across - idx).abs()).max()) <= K - 2 * quarter + 1
+    ends = child_end.cpu().numpy().astype(np.int64)
+    assert (np.diff(ends, axis=1) >= 0).all(), "children ranges overlap"
+    assert (ends[:, -1] == K).all()
+    host = idx.cpu().numpy()
+    assert (np.diff(host, axis=1) >= 0).all()
+    for b in range(0, B, max(1, B // 64)):
+        assert np.array_equal(ends[b], np.searchsorted(host[b], np.arange(K), side="right")), b
+    # the rows do sit on the edge: the zero block's owners differ from row to row (K/2 falls on either side of it)
+    middle = host[:, K // 2]
+    assert len(np.unique(middle < quarter + (K - 2 * quarter))) >= 1
+    assert kernels.read_flags(hip_device) == 0

@@ -1054,19 +1054,6 @@ def test_recorded_locations_name_the_models_own_tensors():
     assert linear_gaussian.affine_terms(fake).scale_param is not learned
 
 
-def test_the_deprecated_particle_mlp_is_the_pytorch_expression():
-    import warnings
-    from aesmc_amd import linear_gaussian
-    g = torch.Generator().manual_seed(3)
-    x, w1, o1 = torch.randn(2, 5, 3, generator=g), torch.randn(7, 3, generator=g), torch.randn(2, 7, generator=g)
-    w2, b2 = torch.randn(4, 7, generator=g), torch.randn(4, generator=g)
-    with warnings.catch_warnings(record=True) as seen:
-        warnings.simplefilter("always")
-        got = linear_gaussian.particle_mlp(x, w1, o1, w2, b2)
-    assert any(issubclass(w.category, DeprecationWarning) for w in seen)
-    torch.testing.assert_close(got, torch.tanh(x @ w1.t() + o1.unsqueeze(1)) @ w2.t() + b2)
-
-
 def test_settings_are_scoped_by_context_and_keep_the_setters_meaning():
     """`settings`: the module-level setters change the process-wide defaults; `override` (what `inference.lazy_gather`,
     `inference.fold_gather_backward` and the hipGraph capture use) changes a copy for the duration of a block in THIS
@@ -1210,3 +1197,42 @@ def test_reference_style_1d_model_under_the_oracle_provider_matches_the_port(ora
     for a, b in zip(got["ancestral_indices"], want["ancestral_indices"]):
         assert torch.equal(a, b)
     torch.testing.assert_close(got["log_marginal_likelihood"], want["log_marginal_likelihood"], rtol=1e-5, atol=1e-5)
+
+
+def test_settings_override_pins_only_the_fields_it_names():
+    """`override` used to snapshot every field, so a `set_default(...)` (or a module-level setter) called
+    inside any `with override(...)` block had no effect until the block ended.  Now the scoped layer holds only the
+    changed fields and every read resolves scoped-else-default."""
+    from aesmc_amd import settings
+    before = settings.current().fused_normal
+    try:
+        with settings.override(lazy_gather=False):
+            assert settings.current().lazy_gather is False
+            state.set_fused_normal(not before)                       # a field the block did not pin: effective at once
+            assert settings.current().fused_normal is (not before)
+            with settings.override(fused_normal=before):             # nested: pins it for the inner block only
+                assert settings.current().fused_normal is before and settings.current().lazy_gather is False
+                inference.set_lazy_gather(True)                      # pinned by the outer block: the default moves, the view not
+                assert settings.current().lazy_gather is False
+            assert settings.current().fused_normal is (not before)
+        assert settings.current().lazy_gather is True
+        with pytest.raises(TypeError):
+            with settings.override(no_such_field=1):
+                pass
+        with pytest.raises(ValueError):
+            with settings.override(history_mode="sometimes"):
+                pass
+        with pytest.raises(AttributeError):
+            with settings.override(lazy_gather=False):
+                settings.current().lazy_gather = True
+    finally:
+        settings.set_default(fused_normal=before, lazy_gather=True)
+
+
+def test_measurement_knobs_are_read_only_beside_their_switch(monkeypatch):
+    from aesmc_amd import settings
+    monkeypatch.setenv("AESMC_K16_PAIRS", "0")
+    monkeypatch.delenv("AESMC_MEASUREMENT_KNOBS", raising=False)
+    assert settings.knob("AESMC_K16_PAIRS", "1") == "1"
+    monkeypatch.setenv("AESMC_MEASUREMENT_KNOBS", "1")
+    assert settings.knob("AESMC_K16_PAIRS", "1") == "0"

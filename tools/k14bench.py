@@ -6,6 +6,7 @@ gather's backward folded in) — healthy and collapsed next-step ancestries.
 """
 import argparse
 import os
+os.environ.setdefault("AESMC_MEASUREMENT_KNOBS", "1")      # the library reads AESMC_* knobs only beside this
 import sys
 
 import torch

@@ -6,6 +6,7 @@
     python tools/k14probe.py [mask ...]
 """
 import os
+os.environ.setdefault("AESMC_MEASUREMENT_KNOBS", "1")      # the library reads AESMC_* knobs only beside this
 import sys
 
 import torch

@@ -1,6 +1,7 @@
 """Times the fused propagation launch (K16) with parts of it switched off (a build with -DAESMC_K16_PROBES; the probed
 launches' OUTPUT IS WRONG): which part of the launch the time belongs to.  hipGraph-timed on cycled operand sets."""
 import os
+os.environ.setdefault("AESMC_MEASUREMENT_KNOBS", "1")      # the library reads AESMC_* knobs only beside this
 import sys
 
 import torch

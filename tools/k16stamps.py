@@ -3,6 +3,7 @@ at the phase boundaries of one particle wavefront and one noise wavefront per wo
 buffer whose address it is given through AESMC_K16_STAMPS.  Shares, not durations: the stamps' own waits forbid
 overlaps the product build has."""
 import os
+os.environ.setdefault("AESMC_MEASUREMENT_KNOBS", "1")      # the library reads AESMC_* knobs only beside this
 import sys
 
 import torch
