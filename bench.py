@@ -232,12 +232,13 @@ def build_model(kind, dim, device, state, proposal="stock", callables="matmul", 
     return model
 
 
-def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_kwargs=None, budget_s=50.0):
+def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_kwargs=None, budget_s=60.0):
     """The CPU port of the reference (oracle/reference_port.py) on a BOUNDED sample of the same workload: same model,
-    K and d; batch rows (and, if still too slow, timesteps) are cut until one evaluation fits its share of `budget_s`.
-    SURVEY.md 8(d): the thread count is swept ({8, 16, 32, 64, all} of the host's cores on a calibration-sized piece —
-    PyTorch's default of one thread per core is far slower on big hosts for these small ops), then 1 warm-up and the
-    MEDIAN of 3 evaluations at the best count; the spread and the sweep are printed with it."""
+    K, T and d; batch rows (and, only if one row is still too slow, timesteps) are cut until one evaluation takes about a
+    twelfth of `budget_s`.  SURVEY.md 8(d) / BASELINE.md section 3: the thread count is swept AT THE TIMED SIZE ({8, 16, 32,
+    64, all} of the host's cores, ascending, one evaluation each, stopped once a count is clearly slower — PyTorch's
+    default of one thread per core is far slower on big hosts for these small ops), then the MEDIAN of 5 evaluations at
+    the best count; the spread and the sweep are printed with it."""
     import numpy as np
     import torch
     from oracle import reference_port
@@ -258,61 +259,53 @@ def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_
     def cost(b, t):  # per-step work + O(T^2) history re-gather
         return b * K * dim * (t + 0.35 * t * t)
 
-    # calibration piece: the workload's OWN number of timesteps where that fits about a second per candidate (the history
-    # re-gather — O(T^2), memory-bound — decides which thread count is best: a 6-step piece preferred 32 threads at c4 where
-    # the 100-step evaluation runs four times faster on 8), a few rows of it; fewer timesteps only where one row is too much
-    target = 1.5e9
+    # ---- size the sample: a small piece at the workload's own T (the O(T^2) history re-gather decides the rate), timed
+    # on the first candidate's threads, scaled to the evaluation's share of the budget
+    per_run = budget_s / 12.0
+    torch.set_num_threads(candidates[0])
     cal_t = T
-    while cost(1, cal_t) > 3 * target and cal_t > 6:
+    while cost(1, cal_t) > 3e9 and cal_t > 6:
         cal_t = max(6, cal_t // 2)
-    cal_b = int(max(1, min(B, 32, target // max(1.0, cost(1, cal_t)))))
-    sweep, cal_seconds = {}, {}
-    for threads in candidates:
-        torch.set_num_threads(threads)
-        run(cal_b, cal_t)                   # warm-up (thread pool, allocator)
-        cal_seconds[threads], _ = run(cal_b, cal_t)
-        sweep[threads] = cal_b * K * cal_t / max(cal_seconds[threads], 1e-6)
-        # a slow host: what has been tried is what is compared; and past the best count more threads only lose (at 256
-        # threads these small ops run 500 times slower than at 16: that one candidate took 40 s of a 50 s budget)
-        if time.perf_counter() - started > 0.3 * budget_s or sweep[threads] < 0.6 * max(sweep.values()):
-            break
-    # the FEWEST threads within 5 % of the best rate (near-ties go to the count that depends least on the host's mood)
-    threads = min(t for t in sweep if sweep[t] >= 0.95 * max(sweep.values()))
-    torch.set_num_threads(threads)
-    rate = cost(cal_b, cal_t) / max(cal_seconds[threads], 1e-6)
-    per_run = max(1.0, (budget_s - (time.perf_counter() - started)) / 6.0)      # 2 warm-ups + 3 timed, some slack
+    cal_b = int(max(1, min(B, 4)))
+    run(cal_b, cal_t)                       # warm-up (thread pool, allocator)
+    cal_dt, _ = run(cal_b, cal_t)
+    rate = cost(cal_b, cal_t) / max(cal_dt, 1e-6)
     b, t = B, T
-    while cost(b, t) / rate > per_run and b > 8:
-        b //= 2
+    while cost(b, t) / rate > per_run and b > 1:
+        b = max(1, b // 2)
     while cost(b, t) / rate > per_run and t > 10:
         t -= 5
     run(b, t)                               # warm-up at the sample's own size (the first pass grows the allocator)
-    dt, _ = run(b, t)
-    # the estimate is pessimistic (the history re-gather is cheaper per value than the per-step work): grow the sample
-    # — first back to the workload's T, then in rows — to what the measured time says fits an evaluation's share
-    grown = False
-    if t < T and dt * cost(b, T) / cost(b, t) * 1.3 <= per_run:
-        dt, t, grown = dt * cost(b, T) / cost(b, t), T, True
-    while 2.6 * dt <= per_run and 2 * b <= B:
-        dt, b, grown = 2 * dt, 2 * b, True
-    if grown:
-        run(b, t)
-    timed = sorted(run(b, t) for _ in range(3))
-    dt, loss = timed[1]
-    # (the sizing passes run cold — allocator growth, page faults — and can overstate an evaluation several times over:
-    #  while the median says the sample is well under its share and time remains, double the rows and time again)
-    while 2.6 * dt <= per_run and 2 * b <= B and time.perf_counter() - started + 8.5 * dt < budget_s:
-        b *= 2
-        run(b, t)
-        timed = sorted(run(b, t) for _ in range(3))
-        dt, loss = timed[1]
+    # ---- the thread sweep at the timed size
+    sweep_seconds = {}
+    for threads in candidates:
+        torch.set_num_threads(threads)
+        if threads != candidates[0]:
+            run(min(b, 2), min(t, 10))      # (a new pool's first pass)
+        sweep_seconds[threads], _ = run(b, t)
+        best = min(sweep_seconds.values())
+        # past the best count more threads only lose (at 256 threads these small ops ran 500 times slower than at 16)
+        if sweep_seconds[threads] > best / 0.6 or time.perf_counter() - started > 0.5 * budget_s:
+            break
+    sweep = {k: b * K * t / max(v, 1e-6) for k, v in sweep_seconds.items()}
+    # the FEWEST threads within 5 % of the best rate (near-ties go to the count that depends least on the host's mood)
+    threads = min(k for k in sweep if sweep[k] >= 0.95 * max(sweep.values()))
+    torch.set_num_threads(threads)
+    run(min(b, 2), min(t, 10))
+    runs = 5
+    remaining = 1.3 * budget_s - (time.perf_counter() - started)
+    if sweep_seconds[threads] * runs > remaining:      # a slow host: what fits, at least 3
+        runs = max(3, int(remaining / max(sweep_seconds[threads], 1e-6)))
+    timed = sorted(run(b, t) for _ in range(runs))
+    dt, loss = timed[len(timed) // 2]
     return {"value": b * K * t / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
-            "sample": "median of 3 forward ELBOs (after 1 warm-up), B={} K={} T={} d={} ({} proposal), {:.1f} s each on {} "
+            "sample": "median of {} forward ELBOs (after warm-up), B={} K={} T={} d={} ({} proposal), {:.1f} s each on {} "
                       "of {} host cores; oracle/reference_port.py (PyTorch-CPU + NumPy, keeps the reference's O(T^2) "
-                      "history re-gather and per-row np.digitize loop)".format(b, K, t, dim, proposal, dt, threads, cores),
-            "spread": [b * K * t / timed[2][0], b * K * t / timed[0][0]],
+                      "history re-gather and per-row np.digitize loop)".format(runs, b, K, t, dim, proposal, dt, threads,
+                                                                               cores),
+            "spread": [b * K * t / timed[-1][0], b * K * t / timed[0][0]],
             "thread_sweep": {"particle_steps_per_sec_by_threads": {str(k): round(v, 1) for k, v in sweep.items()},
-                             "piece": "B={} T={}".format(cal_b, cal_t)},
+                             "piece": "B={} T={} (the timed sample itself)".format(b, t)},
             "host_cores": cores, "seconds": round(time.perf_counter() - started, 1), "loss": loss}
 
 
