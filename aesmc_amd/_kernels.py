@@ -177,7 +177,7 @@ class HipKernels:
         self._affine_max_dim = None
         self._map_cache = {}        # id(weight) -> (weight, its aesmc_affine_map, (shape, strides))
         self._covers_last = None    # the operands of the last step `affine_logweight_covers` accepted
-        self._wide_dim = None       # aesmc_affine_wide_dim(): the extent K17 / K18 are built for
+        self._wide_dim = None       # (aesmc_affine_wide_dim(), _min_dim(), _max_dim()): see `_wide_limits`
         self._pairs = None          # (key, tensor): the interleaved weight pairs of the maps the fused launch met last
         self.evaluation = 0         # bumped by `begin_evaluation`: what a cached weight-pair block belongs to
         self.WEIGHT_PAIRS = settings.knob("AESMC_K16_PAIRS", "1") != "0"      # measurement knob
@@ -998,24 +998,35 @@ class HipKernels:
                 self.timer.note("philox_normal_fill", (self._lib.aesmc_philox_normal_fill, args), 4 * out.numel(), (out,))
         return out
 
+    def _wide_limits(self):
+        """(the extent with the noise in the launch and the backward pieces, smallest latent width, largest width) of the
+        matrix-core step, from the library."""
+        limits = self._wide_dim
+        if limits is None:
+            limits = self._wide_dim = (int(self._lib.aesmc_affine_wide_dim()), int(self._lib.aesmc_affine_wide_min_dim()),
+                                       int(self._lib.aesmc_affine_wide_max_dim()))
+        return limits
+
     def affine_wide_covers(self, source, weight, offset=None, scale=None):
-        """Host-only test of what K17 / K18 assume about one location `offset + source @ weight.T`: source [B,K,128]
-        float32 on the HIP device with K a multiple of 32, weight [128,128] as an nn.Linear holds it, offset None,
-        [128] or [B,128], scale (if given) one value."""
+        """Host-only test of what K17 / K18 (rows of 128 values) and K17g / K18g (every other width) assume about one
+        location `offset + source @ weight.T`: source [B,K,din] float32 on the HIP device with din a multiple of 4 between
+        20 and 256, weight [dout,din] as an nn.Linear holds it with dout a multiple of 4 up to 256, offset None, [dout] or
+        [B,dout], scale (if given) one value.  (Maps of at most 16 x 16 are the item kernels': `affine_covers`.)"""
         if not (torch.is_tensor(weight) and weight.dim() == 2 and weight.dtype == torch.float32 and weight.is_cuda):
             return False
-        wide = self._wide_dim
-        if wide is None:
-            wide = self._wide_dim = int(self._lib.aesmc_affine_wide_dim())
+        _, smallest, largest = self._wide_limits()
         shape = tuple(source.shape)
-        if len(shape) != 3 or shape[2] != wide or tuple(weight.shape) != (wide, wide) or source.dtype != torch.float32 or \
-                source.device != weight.device or shape[1] % 32 != 0 or shape[0] * shape[1] == 0:
+        dout, din = weight.shape
+        if len(shape) != 3 or shape[2] != din or source.dtype != torch.float32 or source.device != weight.device or \
+                shape[0] * shape[1] == 0:
+            return False
+        if din % 4 or dout % 4 or not (smallest <= din <= largest) or not (4 <= dout <= largest):
             return False
         if not weight.is_contiguous() or weight.data_ptr() % 16:
             return False
         if offset is not None:
             if not torch.is_tensor(offset) or offset.dtype != torch.float32 or offset.device != weight.device or \
-                    tuple(offset.shape) not in ((wide,), (shape[0], wide)) or offset.stride(-1) != 1 or \
+                    tuple(offset.shape) not in ((dout,), (shape[0], dout)) or offset.stride(-1) != 1 or \
                     offset.data_ptr() % 16 or (offset.dim() == 2 and offset.stride(0) % 4):
                 return False
         if scale is not None and not (torch.is_tensor(scale) and scale.numel() == 1 and scale.dtype == torch.float32 and
@@ -1024,42 +1035,44 @@ class HipKernels:
         return True
 
     def affine_propagate_wide(self, x_src, eps, y_rows, transition, emission, proposal, scales, out_x, ancestors=None):
-        """K17 + K18: a linear-Gaussian step whose rows hold 128 float32 values (BASELINE.json configs[4]) on the fp32
-        matrix cores — the draw `loc_q(x_prev) + eps * s_q` into `out_x` (the C oracle's bits) and the step's
-        log-weights [B,K] (its values to rounding), x_prev = x_src[b, ancestors[b,k]] when `ancestors` is given.
-        `eps`: the noise [B,K,128], or an `_philox.NoiseStream` — the reservation of the `normal_` call that did not
-        happen: the launch then forms the noise itself (None when the shape does not allow it: the caller materialises
-        it with `philox_normal`).
-        None when the launch does not cover the operands (other extents, strided weights, K not a multiple of 32)."""
+        """K17 + K18 (rows of 128 values) / K17g + K18g (any width that is a multiple of 4 from 20 to 256, dx != dy allowed,
+        any K): a linear-Gaussian step on the fp32 matrix cores — the draw `loc_q(x_prev) + eps * s_q` into `out_x` (the C
+        oracle's bits) and the step's log-weights [B,K] (its values to rounding), x_prev = x_src[b, ancestors[b,k]] when
+        `ancestors` is given.
+        `eps`: the noise [B,K,dx], or an `_philox.NoiseStream` — the reservation of the `normal_` call that did not
+        happen: the launch then forms the noise itself (None when the shape does not allow it — anything but rows of 128
+        values with K a multiple of 4 * threads / 128: the caller materialises it with `philox_normal`).
+        None when the launch does not cover the operands (other extents, strided weights)."""
         if x_src.dtype != torch.float32 or x_src.dim() != 3:
             return None
         B, K, dx = x_src.shape
-        wide = self._wide_dim
-        if wide is None:
-            wide = self._wide_dim = int(self._lib.aesmc_affine_wide_dim())
-        if dx != wide or K % 32 != 0 or B * K == 0 or not x_src.is_cuda:
+        wide, smallest, largest = self._wide_limits()
+        if dx % 4 or not (smallest <= dx <= largest) or B * K == 0 or not x_src.is_cuda:
             return None
-        # the observation as K18 reads it: float32 [B, 128] on the latents' device (a float64 observation — torch.from_numpy
+        # the observation as K18 reads it: float32 [B, dy] on the latents' device (a float64 observation — torch.from_numpy
         # data against a float32 model — would be read as float32 bytes: declined, PyTorch's promotion applies instead)
-        if not (torch.is_tensor(y_rows) and y_rows.dim() == 2 and tuple(y_rows.shape) == (B, wide) and
+        if not (torch.is_tensor(y_rows) and y_rows.dim() == 2 and y_rows.size(0) == B and
                 y_rows.dtype == torch.float32 and y_rows.device == x_src.device):
+            return None
+        dy = y_rows.size(1)
+        if dy % 4 or not (4 <= dy <= largest):
             return None
         drawn = not torch.is_tensor(eps)      # an `_philox.NoiseStream`: the launch forms the noise itself
         if drawn:
             if eps.numel != x_src.numel():
                 raise ValueError("aesmc_amd: affine_propagate_wide: the reservation does not match x_src")
-            if eps.threads % wide or K % (4 * (eps.threads // wide)):
+            if dx != wide or dy != wide or K % 32 or eps.threads % wide or K % (4 * (eps.threads // wide)):
                 return None
         elif eps.shape != x_src.shape or eps.dtype != x_src.dtype or eps.device != x_src.device:
             raise ValueError("aesmc_amd: affine_propagate_wide noise must match x_src")
-        for (weight, offset), scale in zip((transition, emission, proposal), scales):
+        for (weight, offset), scale, shape in zip((transition, emission, proposal), scales, ((dx, dx), (dy, dx), (dx, dx))):
             # (what affine_wide_covers tests, for callers that did not ask it)
-            if not (torch.is_tensor(weight) and tuple(weight.shape) == (wide, wide) and weight.is_contiguous() and
+            if not (torch.is_tensor(weight) and tuple(weight.shape) == shape and weight.is_contiguous() and
                     weight.data_ptr() % 16 == 0 and weight.dtype == torch.float32 and weight.device == x_src.device):
                 return None
             if offset is not None and not (torch.is_tensor(offset) and offset.dtype == torch.float32 and
                                            offset.device == x_src.device and
-                                           tuple(offset.shape) in ((wide,), (B, wide)) and offset.stride(-1) == 1 and
+                                           tuple(offset.shape) in ((shape[0],), (B, shape[0])) and offset.stride(-1) == 1 and
                                            offset.data_ptr() % 16 == 0 and not (offset.dim() == 2 and offset.stride(0) % 4)):
                 return None
             if not (torch.is_tensor(scale) and scale.numel() == 1 and scale.dtype == torch.float32 and
@@ -1079,7 +1092,7 @@ class HipKernels:
         if y_rows.stride(1) != 1 or y_rows.stride(0) % 4 or y_rows.data_ptr() % 16:
             y_rows = y_rows.contiguous()
         out = torch.empty((B, K), dtype=torch.float32, device=x_src.device)
-        ws_bytes = int(self._lib.aesmc_affine_wide_workspace_bytes(B, K))
+        ws_bytes = int(self._lib.aesmc_affine_wide_workspace_bytes_for(B, K, dx, dy))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_src.device)
         maps = [self._affine_map(*term, slot=slot) for slot, term in enumerate((transition, emission, proposal))]
         with _on_device(x_src.device):
@@ -1566,9 +1579,7 @@ class HipKernels:
 
     @property
     def wide_dim(self):
-        if self._wide_dim is None:
-            self._wide_dim = int(self._lib.aesmc_affine_wide_dim())
-        return self._wide_dim
+        return self._wide_limits()[0]
 
     @property
     def wide_adjoint_tile(self):

@@ -108,6 +108,9 @@ SIGNATURES = {
     "aesmc_wide_adjoint_scale": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_wide_adjoint_merge": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_wide_workspace_bytes": (_sz, [_i64, _i64]),
+    "aesmc_affine_wide_min_dim": (_i64, []),
+    "aesmc_affine_wide_max_dim": (_i64, []),
+    "aesmc_affine_wide_workspace_bytes_for": (_sz, [_i64, _i64, _i64, _i64]),
     "aesmc_affine_normal_propagate_wide": (_i32, [_vp, _vp, _vp, _vp, _i64, _map_p, _map_p, _map_p, _vp, _vp, _vp, _vp, _vp,
                                                   _vp, _sz, _vp, _i64, _i64, _u64, _u64, _i64, _vp, _vp]),
     "aesmc_philox_normal_fill": (_i32, [_vp, _i64, _u64, _u64, _i64, _i32, _vp, _vp]),

@@ -13,10 +13,11 @@ LIB_PATH = os.path.join(HERE, "libaesmc_hip.so")
 SOURCES = ["abi.hip", "logweight_lse.hip", "ancestor_index.hip", "resample_gather.hip",
            "normal_logprob.hip", "normal_rsample.hip", "particle_summary.hip", "linear_gaussian.hip",
            "linear_gaussian_backward.hip", "philox_normal.hip", "linear_gaussian_noise.hip",
-           "linear_gaussian_fused.hip", "linear_gaussian_item.hip", "linear_gaussian_step_backward.hip", "linear_gaussian_wide.hip", "linear_gaussian_wide_backward.hip"]
+           "linear_gaussian_fused.hip", "linear_gaussian_item.hip", "linear_gaussian_step_backward.hip", "linear_gaussian_wide.hip", "linear_gaussian_wide_backward.hip",
+           "linear_gaussian_wide_generic_draw.hip", "linear_gaussian_wide_generic_emit.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "linear_gaussian.hpp"),
            os.path.join(CSRC, "philox_normal.hpp"), os.path.join(CSRC, "linear_gaussian_fused.hpp"),
-           os.path.join(CSRC, "linear_gaussian_backward.hpp"),
+           os.path.join(CSRC, "linear_gaussian_backward.hpp"), os.path.join(CSRC, "linear_gaussian_wide_generic.hpp"),
            os.path.join(os.path.dirname(HERE), "include", "aesmc_hip.h")]
 ARCH = "gfx950"
 

@@ -22,6 +22,7 @@
 // lane (g, n) with outputs 16 mt + 4 g + r of particle n: the element-wise part (draw, residuals) runs in that layout
 // on 16-byte pieces, a particle's four lanes add their sums through two cross-lane steps.
 #include "linear_gaussian.hpp"
+#include "linear_gaussian_wide_generic.hpp"
 #include "philox_normal.hpp"
 
 namespace aesmc {
@@ -350,6 +351,67 @@ extern "C" size_t aesmc_affine_wide_workspace_bytes(int64_t B, int64_t K) {
   return (B > 0 && K > 0) ? (size_t)B * (size_t)K * 2 * sizeof(float) : 0;
 }
 
+extern "C" int64_t aesmc_affine_wide_min_dim(void) { return kWgMinDim; }
+extern "C" int64_t aesmc_affine_wide_max_dim(void) { return kWgMaxDim; }
+
+// floats per particle between the launches: two raw sums per chunk of the draw's output rows, one per chunk of the emission's
+static inline uint32_t wideg_record_floats(int64_t dx, int64_t dy) {
+  const int dxp = wideg_padded(dx);
+  return 2u * wideg_chunks(dx, wideg_draw_chunk(dxp)) + wideg_chunks(dy, wideg_emit_chunk(dy));
+}
+
+extern "C" size_t aesmc_affine_wide_workspace_bytes_for(int64_t B, int64_t K, int64_t dx, int64_t dy) {
+  if (B <= 0 || K <= 0 || dx <= 0 || dy <= 0 || wideg_padded(dx) == 0 || wideg_padded(dy) == 0) return 0;
+  const size_t floats = std::max<size_t>(2, wideg_record_floats(dx, dy));
+  return (size_t)B * (size_t)K * floats * sizeof(float);
+}
+
+// K17g + K18g (linear_gaussian_wide_generic.hpp): every shape the 128-wide kernels above do not take
+static int wideg_propagate(const void *x_src, const int64_t *ancestors, const void *eps, const void *y, int64_t y_stride_b,
+                           const aesmc_affine_map *transition, const aesmc_affine_map *emission,
+                           const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g, const void *scale_q,
+                           void *out_x, void *out_lw, void *ws, size_t ws_bytes, int32_t *flags, int64_t B, int64_t K,
+                           hipStream_t s) {
+  const int64_t dx = proposal->dout, dy = emission->dout;
+  if (proposal->din != dx || transition->dout != dx || transition->din != dx || emission->din != dx) return AESMC_ERR_UNSUPPORTED;
+  if (dx < kWgMinDim || dx > kWgMaxDim || dy < 4 || dy > kWgMaxDim || (dx % 4) != 0 || (dy % 4) != 0) return AESMC_ERR_UNSUPPORTED;
+  if (eps == nullptr) return AESMC_ERR_UNSUPPORTED;      // the noise in the launch: the 128-wide kernels only (the caller fills it)
+  const aesmc_affine_map *maps[3] = {transition, emission, proposal};
+  for (const aesmc_affine_map *m : maps) {
+    if (m->stride_in != 1 || m->stride_out != m->din || !aligned16(m->weight) ||
+        (m->offset != nullptr && (!aligned16(m->offset) || (m->offset_stride_b % 4) != 0)))
+      return AESMC_ERR_UNSUPPORTED;
+  }
+  const int64_t N = B * K;
+  if (B >= (1ll << 31) || K >= (1ll << 31) || N >= (1ll << 31) / 2) return AESMC_ERR_UNSUPPORTED;
+  if (ws_bytes < aesmc_affine_wide_workspace_bytes_for(B, K, dx, dy)) return AESMC_ERR_WORKSPACE;
+  if (N == 0) return AESMC_OK;
+  const int dxp = wideg_padded(dx);
+  WideGArgs a = {};
+  a.x_in = static_cast<const float *>(x_src); a.anc = ancestors; a.eps = static_cast<const float *>(eps);
+  a.y = static_cast<const float *>(y); a.y_sb = y_stride_b;
+  a.w[0] = static_cast<const float *>(proposal->weight); a.w[1] = static_cast<const float *>(transition->weight);
+  a.off[0] = static_cast<const float *>(proposal->offset); a.off[1] = static_cast<const float *>(transition->offset);
+  a.off_sb[0] = proposal->offset_stride_b; a.off_sb[1] = transition->offset_stride_b;
+  a.s_p = static_cast<const float *>(scale_p); a.s_g = static_cast<const float *>(scale_g);
+  a.s_q = static_cast<const float *>(scale_q);
+  a.out_x = static_cast<float *>(out_x); a.sums = static_cast<float *>(ws); a.out_lw = static_cast<float *>(out_lw);
+  a.flags = flags; a.B = (uint32_t)B; a.K = (uint32_t)K; a.tiles_per_row = (uint32_t)((K + kWgTile - 1) / kWgTile);
+  a.din = (uint32_t)dx; a.dout = (uint32_t)dx; a.dx = (uint32_t)dx;
+  a.chunks_draw = wideg_chunks(dx, wideg_draw_chunk(dxp));
+  a.chunks_emit = wideg_chunks(dy, wideg_emit_chunk(dy));
+  a.sums_stride = std::max<uint32_t>(2u, wideg_record_floats(dx, dy));
+  int status = wideg_launch_draw(a, dxp, ancestors != nullptr, s);
+  if (status != AESMC_OK) return status;
+  WideGArgs e = a;
+  e.x_in = static_cast<const float *>(out_x); e.anc = nullptr; e.eps = nullptr;
+  e.w[0] = static_cast<const float *>(emission->weight); e.w[1] = nullptr;
+  e.off[0] = static_cast<const float *>(emission->offset); e.off[1] = nullptr;
+  e.off_sb[0] = emission->offset_stride_b; e.off_sb[1] = 0;
+  e.dout = (uint32_t)dy;
+  return wideg_launch_emission(e, dxp, s);
+}
+
 // K17 + K18: see include/aesmc_hip.h
 extern "C" int aesmc_affine_normal_propagate_wide(
     const void *x_src, const int64_t *ancestors, const void *eps, const void *y, int64_t y_stride_b,
@@ -371,15 +433,22 @@ extern "C" int aesmc_affine_normal_propagate_wide(
       (y_stride_b % 4) != 0)
     return AESMC_ERR_INVALID_ARGUMENT;
   const aesmc_affine_map *maps[3] = {transition, emission, proposal};
+  bool exact = true;      // rows of exactly 128 values on both sides and whole tiles: the kernels of this file
   for (const aesmc_affine_map *m : maps) {
     if (m->weight == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
-    // rows of 128 values on both sides, weights as an nn.Linear holds them, 16-byte aligned operands
-    if (m->dout != kWd || m->din != kWd || m->stride_in != 1 || m->stride_out != kWd || !aligned16(m->weight) ||
+    exact = exact && m->dout == kWd && m->din == kWd;
+  }
+  if (!exact || K % kWdTile != 0)      // any other width (20 .. 256, a multiple of 4, dx != dy allowed), any K
+    return wideg_propagate(x_src, ancestors, eps, y, y_stride_b, transition, emission, proposal, scale_p, scale_g, scale_q,
+                           out_x, out_lw, ws, ws_bytes, flags, B, K, static_cast<hipStream_t>(stream));
+  for (const aesmc_affine_map *m : maps) {
+    // weights as an nn.Linear holds them, 16-byte aligned operands
+    if (m->stride_in != 1 || m->stride_out != kWd || !aligned16(m->weight) ||
         (m->offset != nullptr && (!aligned16(m->offset) || (m->offset_stride_b % 4) != 0)))
       return AESMC_ERR_UNSUPPORTED;
   }
   const int64_t N = B * K;
-  if (K % kWdTile != 0 || N >= (1ll << 31) / 2) return AESMC_ERR_UNSUPPORTED;
+  if (N >= (1ll << 31) / 2) return AESMC_ERR_UNSUPPORTED;
   // the noise formed in the launch: a trip's four quarters (Q = G / 128 particles each) inside one batch row
   const int64_t Q = eps == nullptr ? threads / kWd : 0;
   if (eps == nullptr && (Q % 8 != 0 || K % (4 * Q) != 0)) return AESMC_ERR_UNSUPPORTED;

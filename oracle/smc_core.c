@@ -158,7 +158,7 @@ void smc_oracle_logweight_lse(const double *a, const double *b, const double *c,
                                            int64_t d1, const T *x2, const T *w2, int64_t w2_sj,         \
                                            int64_t w2_si, int64_t d2, const T *off, int64_t off_sb,     \
                                            const T *base, T *out, int64_t B, int64_t K, int64_t dout) { \
-    T acc[128];                                                                                          \
+    T acc[256];                                                                                          \
     for (int64_t b = 0; b < B; ++b)                                                                     \
       for (int64_t k = 0; k < K; ++k) {                                                                 \
         const int64_t n = b * K + k;                                                                    \
@@ -172,7 +172,7 @@ void smc_oracle_logweight_lse(const double *a, const double *b, const double *c,
   void smc_oracle_affine_rsample_##SUFFIX(const T *src, const T *w, int64_t sj, int64_t si,             \
                                           const T *off, int64_t off_sb, const T *eps, T scale, T *out,  \
                                           int64_t B, int64_t K, int64_t dout, int64_t din) {            \
-    T acc[128];                                                                                          \
+    T acc[256];                                                                                          \
     for (int64_t b = 0; b < B; ++b)                                                                     \
       for (int64_t k = 0; k < K; ++k) {                                                                 \
         const int64_t n = b * K + k;                                                                    \
@@ -202,7 +202,7 @@ void smc_oracle_logweight_lse(const double *a, const double *b, const double *c,
       const T *xprev, const T *x, const T *y, int64_t y_sb, const T *wp, const T *offp, int64_t offp_sb, \
       const T *wg, const T *offg, int64_t offg_sb, const T *wq, const T *offq, int64_t offq_sb, T sp,   \
       T sg, T sq, T *lw, int64_t B, int64_t K, int64_t dx, int64_t dy) {                                \
-    T loc[128];                                                                                          \
+    T loc[256];                                                                                          \
     for (int64_t b = 0; b < B; ++b)                                                                     \
       for (int64_t k = 0; k < K; ++k) {                                                                 \
         const int64_t n = b * K + k;                                                                    \

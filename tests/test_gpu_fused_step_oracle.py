@@ -331,6 +331,65 @@ def test_the_wide_step_equals_the_c_oracle(kernels, hip_device, shape, gather):
     assert kernels.read_flags(hip_device) == 0
 
 
+# ---- every other width: K17g + K18g (aesmc/state.py:61-183 is dimension-agnostic) ----------------------
+WIDTHS = [(24, 24), (32, 32), (64, 64), (96, 96), (256, 256), (32, 48), (192, 80), (48, 20), (128, 128), (20, 4), (100, 136),
+          (160, 256)]
+
+
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("shape", [(3, 40), (2, 320), (1, 1000)])
+@pytest.mark.parametrize("widths", WIDTHS)
+def test_the_matrix_core_step_at_every_width_equals_the_c_oracle(kernels, hip_device, widths, shape, gather):
+    """aesmc_affine_normal_propagate_wide at latent width dx and observation width dy — multiples of 4 from 20 to 256,
+    dx != dy included, padded inside the launch to 32 / 48 / 64 / 96 / 128 / 192 / 256, rows wider than 128 cut into chunks
+    of output rows — and K not a multiple of 32 (a masked last tile) against oracle/smc_core.c: x_t bit for bit (one fma
+    chain per element started from the offset; zero padding leaves a chain as it is), the log-weight to rounding (the
+    squared distances are summed per lane, per particle and per chunk instead of in one chain).  (128, 128) at these K is
+    the generic kernel too: K = 40 / 1000 are not whole tiles."""
+    dx, dy = widths
+    B, K = shape
+    rng = np.random.RandomState(B * K + dx + 7 * dy)
+    r = lambda *s: rng.randn(*s).astype(np.float32)
+    host = {"x_prev": r(B, K, dx), "eps": r(B, K, dx), "y": r(B, dy),
+            "A": (0.9 * np.eye(dx) + 0.3 / np.sqrt(dx) * rng.randn(dx, dx)).astype(np.float32),
+            "Q": (0.45 * np.eye(dx) + 0.3 / np.sqrt(dx) * rng.randn(dx, dx)).astype(np.float32),
+            "C": (1.0 / np.sqrt(dx) * rng.randn(dy, dx)).astype(np.float32), "off_q": r(B, dx), "off_g": r(dy)}
+    o = {key: torch.from_numpy(value).to(hip_device) for key, value in host.items()}
+    s_p, s_g, s_q = (torch.tensor(v, dtype=torch.float32, device=hip_device) for v in (1.0, 0.5, 0.7))
+    terms = ((o["A"], None), (o["C"], o["off_g"]), (o["Q"], o["off_q"]))
+    for (weight, offset) in terms:
+        source = o["x_prev"]
+        assert kernels.affine_wide_covers(source, weight, offset, s_p)
+    anc = _ancestors(B, K, hip_device, seed=B + K, spread=2.0) if gather else None
+    out_x = torch.full((B, K, dx), float("nan"), device=hip_device)
+    kernels.read_flags(hip_device)
+    lw = kernels.affine_propagate_wide(o["x_prev"], o["eps"], o["y"], *terms, (s_p, s_g, s_q), out_x, ancestors=anc)
+    assert lw is not None, "the matrix-core step declined a width it is built for"
+    moved = host["x_prev"] if anc is None else c_oracle.gather(host["x_prev"], anc.cpu().numpy())[0]
+    want_x = c_oracle.affine_rsample(moved, host["Q"], host["off_q"], host["eps"], 0.7)
+    np.testing.assert_array_equal(out_x.cpu().numpy(), want_x)
+    want_lw = c_oracle.affine_logweight(moved, want_x, host["y"], (host["A"], None), (host["C"], host["off_g"]),
+                                        (host["Q"], host["off_q"]), 1.0, 0.5, 0.7)
+    got = lw.cpu().numpy()
+    assert got.shape == (B, K) and np.isfinite(got).all()
+    scale = np.maximum(np.abs(want_lw), 1.0)
+    assert float((np.abs(got - want_lw) / scale).max()) <= 2e-6 * 4
+    assert kernels.read_flags(hip_device) == 0
+
+
+def test_widths_the_matrix_core_step_leaves_to_the_other_routes(kernels, hip_device):
+    """Not a multiple of 4, below 20 (the item kernels' side), above 256: declined — the GEMM route applies."""
+    g = torch.Generator(device=hip_device).manual_seed(0)
+    one = torch.tensor(1.0, device=hip_device)
+    for dx, dy in ((18, 18), (22, 24), (24, 22), (16, 16), (260, 260), (24, 260)):
+        x = torch.randn(2, 64, dx, device=hip_device, generator=g)
+        y = torch.randn(2, dy, device=hip_device, generator=g)
+        A = torch.randn(dx, dx, device=hip_device, generator=g) * 0.05
+        C = torch.randn(dy, dx, device=hip_device, generator=g) * 0.05
+        assert kernels.affine_propagate_wide(x, x.clone(), y, (A, None), (C, None), (A, None), (one, one, one),
+                                             torch.empty_like(x)) is None, (dx, dy)
+
+
 def test_the_wide_step_declines_what_it_does_not_cover_and_survives_bad_ancestors(kernels, hip_device):
     d = 128
     g = torch.Generator(device=hip_device).manual_seed(0)
@@ -340,7 +399,7 @@ def test_the_wide_step_declines_what_it_does_not_cover_and_survives_bad_ancestor
     one = torch.tensor(1.0, device=hip_device)
     out = torch.empty_like(x)
     terms = ((W, None), (W, None), (W, None))
-    assert kernels.affine_propagate_wide(x[:, :40], x[:, :40], y, *terms, (one, one, one), out[:, :40].contiguous()) is None
+    # (K = 40, not a multiple of 32, is covered since 0.5.0 — a masked last tile: tested with the other widths below)
     assert kernels.affine_propagate_wide(x, x, y, (W.t(), None), (W, None), (W, None), (one, one, one), out) is None
     # an observation K18 would misread: float64 bytes (torch.from_numpy data against a float32 model), another batch
     # extent, another device; offsets and scales of the wrong shape / dtype / device — declined, nothing launched
