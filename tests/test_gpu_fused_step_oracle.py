@@ -510,20 +510,20 @@ def test_the_wide_step_forms_torchs_noise_itself(kernels, hip_device, shape, gat
 
 
 # ---- the wide step under autograd: recomputation instead of retention ------------------------------------
-@pytest.mark.parametrize("shape", [(2, 16384, 1), (3, 1024, 1)])
+@pytest.mark.parametrize("shape", [(2, 16384, 128, 128), (3, 1024, 128, 128), (2, 1000, 24, 24), (2, 512, 64, 48),
+                                   (1, 320, 192, 80), (2, 96, 256, 256)])
 def test_the_wide_steps_backward_equals_float64_autograd(kernels, hip_device, shape):
     """`affine_step_backward` on rows of 128 values (the backward of a K17 / K18 step, recomputed from x_{t-1}, the
     ancestors, x_t and the log-weights) against float64 autograd of the same step written with PyTorch operations —
     aesmc/state.py:114-155, :179 and aesmc/inference.py:108-130 for one timestep: every gradient (resampled rows, the
     three maps, their offsets — per batch row, shared, absent —, the observation, the three scales) to float32 rounding
     of sums over B K particles."""
-    B, K, _ = shape
-    d = 128
+    B, K, d, dy = shape      # (other widths than 128: K17g / K18g forward, the same recomputing backward)
     gen = torch.Generator(device=hip_device).manual_seed(B + K)
     make = lambda *s: torch.randn(*s, device=hip_device, generator=gen)
-    x_prev, eps, y, off_q, off_g = make(B, K, d), make(B, K, d), make(B, d), make(B, d), make(d)
+    x_prev, eps, y, off_q, off_g = make(B, K, d), make(B, K, d), make(B, dy), make(B, d), make(dy)
     eye = torch.eye(d, device=hip_device)
-    A, C, Q = 0.9 * eye + 0.05 * make(d, d), 0.1 * make(d, d), 0.45 * eye + 0.05 * make(d, d)
+    A, C, Q = 0.9 * eye + 0.05 * make(d, d), 0.1 * make(dy, d), 0.45 * eye + 0.05 * make(d, d)
     scales = tuple(torch.tensor(v, device=hip_device) for v in (1.0, 0.5, 0.7))
     anc = _ancestors(B, K, hip_device, seed=B, spread=1.0)
     terms = ((A, None), (C, off_g), (Q, off_q))
@@ -659,3 +659,61 @@ def test_the_wide_adjoints_elementwise_launches_equal_the_pytorch_operations(ker
     assert torch.equal(at_q, arriving - u_q)
     # rows that are not whole tiles: declined by the wrapper's test, the caller keeps its PyTorch operations
     assert not kernels._wide_adjoint_covers(make(2, 384, d), make(2, 384), scale)
+
+
+@pytest.mark.parametrize("dim,K", [(24, 1000), (64, 512), (192, 320)])
+def test_models_of_other_widths_run_and_train_through_the_matrix_core_step(hip_device, monkeypatch, dim, K):
+    """An LGSSM with rows of 24 / 64 / 192 values (AffineNormal callables), forward and under autograd: every resampled
+    timestep is K17g + K18g, its backward the recomputing `affine_step_backward_wide` (library products, PyTorch
+    element-wise parts at these widths); the loss and every parameter gradient equal the GEMM route's — the same model
+    with the matrix-core step switched off, handed this run's ancestors (teacher forcing) — to what float32 log-weights of
+    order 1e2 .. 1e3 allow two different summation orders to agree on after the softmax (2 % of a gradient's largest entry;
+    the backward itself is held to float64 autograd at 5e-4 in test_the_wide_steps_backward_equals_float64_autograd).
+    K = 1000 is not a multiple of 32 (masked tail)."""
+    from aesmc_amd import _kernels, losses
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    B, T = 4, 4
+
+    def run(wide, forced=None):
+        model = LgssmNd(dim, dtype=torch.float32, affine=True, validate_args=False, emission_scale=0.5).tune_proposal().to(hip_device)
+        observations = model.simulate(T, B, seed=2)
+        calls = {"wide": 0, "backward": 0}
+        recorded = []
+        real, real_bwd, real_step = provider.affine_propagate_wide, provider.affine_step_backward_wide, provider.resample_step
+        if wide:
+            def counting(*args, **kwargs):
+                out = real(*args, **kwargs)
+                calls["wide"] += out is not None
+                return out
+
+            def counting_bwd(*args, **kwargs):
+                calls["backward"] += 1
+                return real_bwd(*args, **kwargs)
+            monkeypatch.setattr(provider, "affine_propagate_wide", counting)
+            monkeypatch.setattr(provider, "affine_step_backward_wide", counting_bwd)
+        else:
+            monkeypatch.setattr(provider, "affine_wide_covers", lambda *a, **k: False)
+
+        def resampling(*args, **kwargs):
+            out = real_step(*args, **kwargs)
+            if forced is not None:
+                out[0].copy_(forced[len(recorded)])
+            recorded.append(out[0].clone())
+            return out
+        monkeypatch.setattr(provider, "resample_step", resampling)
+        np.random.seed(4)
+        torch.manual_seed(4)
+        loss = losses.get_loss(observations, K, "aesmc", model.initial, model.transition, model.emission, model.proposal)
+        loss.backward()
+        monkeypatch.undo()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, calls, recorded
+
+    wide_loss, wide_grads, calls, ancestors = run(True)
+    assert calls == {"wide": T - 1, "backward": T - 1}, calls
+    forced_loss, forced_grads, _, _ = run(False, forced=ancestors)
+    assert abs(wide_loss - forced_loss) <= 2e-5 * abs(forced_loss), (wide_loss, forced_loss)
+    assert set(wide_grads) == set(forced_grads) and len(wide_grads) >= 4
+    for name, g in forced_grads.items():
+        scale = float(g.abs().max()) + 1e-30
+        assert float((wide_grads[name] - g).abs().max()) <= 2e-2 * scale, (name, float((wide_grads[name] - g).abs().max()), scale)
