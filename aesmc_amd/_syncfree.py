@@ -20,6 +20,14 @@ forms that never leave the device:
     `infer` — the library's existing deferred-validation mode (`state.set_validation_mode`); 'eager' restores
     PyTorch's own checks, syncs included.
 
+A fourth wrapper rides along: `torch.nn.functional.linear` (what `nn.Linear.forward` calls).  The reference's own
+proposal is `Linear(2, 1)` over all B K particles (test/models/lgssm.py:61-72): a [B K, 2] x [2, 1] product, for which
+the GEMM library picks tiles made for square problems (forward 18 us, the weight gradient — a 262 144-long contraction
+onto one workgroup — 747 us at configs[1]'s B K).  Inside a scope such a map (at most 16 x 16, at least 2^14 rows, on a HIP
+device) is kernel K8 (`_ops.particle_affine`: one fma chain per output, inputs ascending, started from the bias) with K11
+as its backward (`settings.particle_linear`; the numbers differ from the library's by float rounding of another summation
+order, as any two GEMM kernels' do).
+
 The wrappers are installed once (first scope) and delegate to PyTorch's originals whenever no scope is active in the
 calling context, so code outside `infer` sees stock `torch.distributions`.
 """
@@ -42,6 +50,8 @@ _INSTALLED = False
 _TORCH_BROADCAST_ALL = torch.distributions.utils.broadcast_all
 _TORCH_INIT = Distribution.__init__
 _TORCH_VALIDATE_SAMPLE = Distribution._validate_sample
+_TORCH_LINEAR = torch.nn.functional.linear
+_PARTICLE_LINEAR_MIN_ROWS = 1 << 14
 
 _CONSTANTS = {}
 _NUMBER = (int, float, bool)
@@ -195,6 +205,22 @@ def _validate_sample(self, value):
     return validate_sample(self, value)
 
 
+def _linear(input, weight, bias=None):
+    """`torch.nn.functional.linear` whose small maps over many rows run as K8 / K11 inside a scope."""
+    if _ACTIVE.get() and type(input) is torch.Tensor and input.is_cuda and weight.dim() == 2 and input.dim() in (2, 3) and \
+            weight.size(0) <= 16 and weight.size(1) <= 16 and input.size(-1) == weight.size(1) and \
+            input.numel() >= _PARTICLE_LINEAR_MIN_ROWS * weight.size(1) and input.dtype == weight.dtype and \
+            type(weight) in (torch.Tensor, torch.nn.Parameter) and settings.current().particle_linear and \
+            (bias is None or (type(bias) in (torch.Tensor, torch.nn.Parameter) and tuple(bias.shape) == (weight.size(0),))):
+        from . import _kernels, _ops
+        rows = input if input.dim() == 3 else input.unsqueeze(0)      # [1, N, din]: one "batch row" of N particles
+        provider = _kernels.get()
+        if provider.name == "hip" and provider.affine_covers(rows, weight, bias):
+            out = _ops.particle_affine(rows.contiguous(), weight, bias)
+            return out if input.dim() == 3 else out.squeeze(0)
+    return _TORCH_LINEAR(input, weight, bias)
+
+
 def _install():
     global _INSTALLED
     with _INSTALL_LOCK:
@@ -207,6 +233,8 @@ def _install():
                 module.broadcast_all = _broadcast_all
         Distribution.__init__ = _init
         Distribution._validate_sample = _validate_sample
+        if torch.nn.functional.linear is _TORCH_LINEAR:
+            torch.nn.functional.linear = _linear
         _INSTALLED = True
 
 

@@ -46,6 +46,13 @@ class Settings:
     # `_standard_normal` materialises it first)  [AESMC_KERNEL_NOISE]
     kernel_noise: bool = True
 
+    # inside `infer`, an `nn.Linear` / `F.linear` of at most 16 x 16 applied to a particle tensor (at least 2^14 rows on the
+    # HIP device) runs as kernel K8 — its backward as K11, the weight gradient a matrix-core contraction over the
+    # particles — instead of a library GEMM whose picks for such skinny shapes are poor (the reference's own model:
+    # Linear(2, 1) over B K rows, test/models/lgssm.py:61-72 — hipBLASLt's weight-gradient GEMM ran 747 us at 262 144
+    # rows); off: the library GEMM  [AESMC_PARTICLE_LINEAR]
+    particle_linear: bool = True
+
     def validate(self):
         if self.history_mode not in ("lazy", "eager"):
             raise ValueError("history mode must be 'lazy' or 'eager', got {}".format(self.history_mode))
@@ -64,7 +71,7 @@ def knob(name, default=None):
 
 
 _DEFAULT = Settings(lazy_gather=_env_flag("AESMC_LAZY_GATHER"), fold_gather_backward=_env_flag("AESMC_FOLD_GATHER_BACKWARD"),
-                    kernel_noise=_env_flag("AESMC_KERNEL_NOISE"))
+                    kernel_noise=_env_flag("AESMC_KERNEL_NOISE"), particle_linear=_env_flag("AESMC_PARTICLE_LINEAR"))
 _SCOPED = contextvars.ContextVar("aesmc_amd_settings", default=None)      # the innermost `override`'s CHANGED fields only
 _FIELDS = tuple(field.name for field in dataclasses.fields(Settings))
 

@@ -319,3 +319,47 @@ def test_reference_training_run_replayed_through_the_captured_loop(hip_device, n
     np.testing.assert_allclose(seen, case["losses"], rtol=1e-4)
     for pname, p in named.items():
         np.testing.assert_allclose(p.detach().cpu().numpy(), case["final_" + pname], rtol=1e-3, atol=1e-5)
+
+
+def test_small_linear_layers_over_the_particles_run_as_k8_inside_infer(hip_device):
+    """`nn.Linear(2, 1)` over B K rows — the reference's proposal net, test/models/lgssm.py:61-72 — is kernel K8 inside a
+    sync-free scope (its backward K11), the library GEMM outside one and with `particle_linear` off: the same values and
+    gradients to float32 rounding of another summation order."""
+    from aesmc_amd import _kernels, settings
+    provider = _kernels.get()
+    torch.manual_seed(0)
+    layer = torch.nn.Linear(2, 1).to(hip_device)
+    rows = torch.randn(1 << 16, 2, device=hip_device, requires_grad=True)
+    upstream = torch.randn(1 << 16, 1, device=hip_device)
+    calls = {"k8": 0}
+    real = provider.particle_affine
+
+    def counting(*args, **kwargs):
+        calls["k8"] += 1
+        return real(*args, **kwargs)
+    provider.particle_affine = counting
+    try:
+        def evaluate():
+            for p in list(layer.parameters()) + [rows]:
+                p.grad = None
+            out = layer(rows)
+            (out * upstream).sum().backward()
+            return out.detach().clone(), rows.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone()
+        plain = evaluate()
+        assert calls["k8"] == 0                      # outside `infer`: stock PyTorch
+        with _syncfree.scope():
+            fused = evaluate()
+            assert calls["k8"] == 1
+            with settings.override(particle_linear=False):
+                off = evaluate()
+            assert calls["k8"] == 1
+            small = layer(rows[:64])                 # a handful of rows: not worth a launch of its own kind
+            assert calls["k8"] == 1 and small.shape == (64, 1)
+            three = layer(rows.view(4, -1, 2))       # [B, K, din] as the callables see particles
+            assert calls["k8"] == 2 and three.shape == (4, (1 << 16) // 4, 1)
+            torch.testing.assert_close(three.reshape(-1, 1), fused[0], rtol=0, atol=0)
+    finally:
+        provider.particle_affine = real
+    for got, want, other in zip(fused, plain, off):
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+        torch.testing.assert_close(other, want, rtol=0, atol=0)
