@@ -213,11 +213,18 @@ def _linear(input, weight, bias=None):
             type(weight) in (torch.Tensor, torch.nn.Parameter) and settings.current().particle_linear and \
             (bias is None or (type(bias) in (torch.Tensor, torch.nn.Parameter) and tuple(bias.shape) == (weight.size(0),))):
         from . import _kernels, _ops
-        rows = input if input.dim() == 3 else input.unsqueeze(0)      # [1, N, din]: one "batch row" of N particles
+        rows = input
+        if input.dim() == 2:
+            # [N, din] as "batch rows" of a few thousand particles each: K11 leaves one record per tile of 256 particles
+            # and the bias' gradient is summed per batch row, a lane walking the row's tiles — 76 us for ONE row of 2^18
+            count = input.size(0)
+            per_row = next((k for k in (4096, 2048, 1024, 512, 256) if count % k == 0), count)
+            rows = input.view(count // per_row, per_row, input.size(1)) if input.is_contiguous() else \
+                input.reshape(count // per_row, per_row, input.size(1))
         provider = _kernels.get()
         if provider.name == "hip" and provider.affine_covers(rows, weight, bias):
             out = _ops.particle_affine(rows.contiguous(), weight, bias)
-            return out if input.dim() == 3 else out.squeeze(0)
+            return out if input.dim() == 3 else out.reshape(input.size(0), weight.size(0))
     return _TORCH_LINEAR(input, weight, bias)
 
 
