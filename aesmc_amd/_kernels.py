@@ -998,6 +998,90 @@ class HipKernels:
                 self.timer.note("philox_normal_fill", (self._lib.aesmc_philox_normal_fill, args), 4 * out.numel(), (out,))
         return out
 
+    # ---- K13: two-layer tanh net over the particles ---------------------------------------------
+    def particle_mlp_covers(self, x, weight1, offset1, weight2, bias2=None):
+        """Host-only test of K13's preconditions: x [B,K,din] (din <= 16), weight1 [H,din] (H <= 64),
+        offset1 [H] or [B,H], weight2 [dout,H] (dout <= 16), bias2 [dout] or None; at least ~43
+        particles per batch row (the kernel stages the rows' offsets per 256-particle tile)."""
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype in _DTYPE_TAG and x.dim() == 3 and x.numel() > 0):
+            return False
+        tensors = [weight1, offset1, weight2] + ([bias2] if bias2 is not None else [])
+        if not all(torch.is_tensor(t) and t.dtype == x.dtype and t.device == x.device for t in tensors):
+            return False
+        if weight1.dim() != 2 or weight2.dim() != 2:
+            return False
+        H, din = weight1.shape
+        dout = weight2.size(0)
+        if din != x.size(2) or weight2.size(1) != H or not (1 <= din <= 16 and 1 <= dout <= 16 and 1 <= H <= 64):
+            return False
+        if tuple(offset1.shape) not in ((H,), (x.size(0), H)):
+            return False
+        if bias2 is not None and tuple(bias2.shape) != (dout,):
+            return False
+        return (256 - 1) // x.size(1) + 2 <= 8
+
+    def particle_mlp(self, x, weight1, offset1, weight2, bias2=None):
+        """K13: bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T -> dense [B,K,dout]; None when the kernel
+        declines the shape (the caller keeps the PyTorch expression)."""
+        if not self.particle_mlp_covers(x, weight1, offset1, weight2, bias2):
+            return None
+        tag = _DTYPE_TAG[x.dtype]
+        B, K = x.shape[:2]
+        x = self._dense16(x)
+        out = torch.empty((B, K, weight2.size(0)), dtype=x.dtype, device=x.device)
+        m1, keep1 = self._affine_map(weight1, offset1)
+        m2, keep2 = self._affine_map(weight2, bias2)
+        with _on_device(x.device):
+            args = (tag, _ptr(x), ctypes.byref(m1), ctypes.byref(m2), _ptr(out), B, K, self._stream(x))
+            status = self._lib.aesmc_particle_mlp(*args)
+            if status == 2:
+                return None
+            _lib.check(status, "aesmc_particle_mlp")
+            if self.timer is not None:
+                nbytes = x.element_size() * B * K * (x.size(2) + out.size(2))
+                self.timer.note("particle_mlp", (self._lib.aesmc_particle_mlp, args), nbytes,
+                                (x, out, m1, m2, keep1, keep2))
+        return out
+
+    def particle_mlp_backward(self, grad_out, x, weight1, offset1, weight2, need_x=True):
+        """K13b: for grad_out [B,K,dout] -> (grad_x [B,K,din] or None, grad_weight1 [H,din], grad_offset1 summed per batch
+        row [B,H], grad_weight2 [dout,H]) with the hidden layer RECOMPUTED from x and offset1; None when the kernel
+        declines the shape (K not a multiple of 256, din = 16: the caller differentiates the PyTorch expression)."""
+        if not self.particle_mlp_covers(x, weight1, offset1, weight2) or grad_out.dtype != x.dtype or \
+                grad_out.device != x.device or tuple(grad_out.shape) != (x.size(0), x.size(1), weight2.size(0)):
+            return None
+        B, K, din = x.shape
+        H, dout = weight1.size(0), weight2.size(0)
+        records = int(self._lib.aesmc_particle_mlp_backward_records(B, K))
+        if records <= 0 or din > 15:
+            return None
+        tag = _DTYPE_TAG[x.dtype]
+        x, grad_out = self._dense16(x), self._dense16(grad_out)
+        chunks = (H + 15) // 16
+        grad_x = torch.empty_like(x) if need_x else None
+        rec_w1 = torch.empty((records, chunks, 16, 16), dtype=x.dtype, device=x.device)
+        rec_w2 = torch.empty((records, chunks, 16, 16), dtype=x.dtype, device=x.device)
+        rows = torch.empty((B, K // 64, 16 * chunks), dtype=x.dtype, device=x.device)
+        m1, keep1 = self._affine_map(weight1, offset1)
+        m2, keep2 = self._affine_map(weight2, None)
+        with _on_device(x.device):
+            args = (tag, _ptr(x), _ptr(grad_out), ctypes.byref(m1), ctypes.byref(m2), _ptr(grad_x), _ptr(rec_w1),
+                    _ptr(rec_w2), _ptr(rows), B, K, self._stream(x))
+            status = self._lib.aesmc_particle_mlp_backward(*args)
+            if status == 2:
+                return None
+            _lib.check(status, "aesmc_particle_mlp_backward")
+            if self.timer is not None:
+                nbytes = x.element_size() * B * K * (2 * din + dout)
+                self.timer.note("particle_mlp_backward", (self._lib.aesmc_particle_mlp_backward, args), nbytes,
+                                (x, grad_out, grad_x, rec_w1, rec_w2, rows, m1, m2, keep1, keep2))
+        # the wavefronts' partials, added in record order; grad_W1's chunk c holds rows 16 c .. 16 c + 15 (hidden units) x
+        # inputs, grad_W2's chunk c holds outputs x hidden units 16 c .. 16 c + 15
+        grad_w1 = rec_w1.sum(0).reshape(16 * chunks, 16)[:H, :din]
+        grad_w2 = rec_w2.sum(0).permute(1, 0, 2).reshape(16, 16 * chunks)[:dout, :H]
+        grad_rows = rows.sum(1)[:, :H]
+        return grad_x, grad_w1, grad_rows, grad_w2
+
     def _wide_limits(self):
         """(the extent with the noise in the launch and the backward pieces, smallest latent width, largest width) of the
         matrix-core step, from the library."""

@@ -399,6 +399,70 @@ def particle_affine(x, weight, offset=None):
     return _kernels.get().particle_affine(x.detach(), weight.detach(), None if offset is None else offset.detach())
 
 
+# ---- K13: a two-layer tanh net over the particles --------------------------------------------------------
+def _mlp_reference(x, weight1, offset1, weight2, bias2):
+    hidden = torch.matmul(x, weight1.t()) + (offset1.unsqueeze(1) if offset1.dim() == 2 else offset1)
+    out = torch.matmul(torch.tanh(hidden), weight2.t())
+    return out if bias2 is None else out + bias2
+
+
+class _MlpDeclined(Exception):
+    pass
+
+
+class _ParticleMlp(torch.autograd.Function):
+    """Forward: kernel K13 (the hidden layer never leaves registers).  Backward: kernel K13b — the hidden layer recomputed
+    from the saved inputs, the two weight gradients contracted over the particles on the matrix cores; where it declines
+    the shape (K not a multiple of 256), PyTorch's autograd over the same expression."""
+
+    @staticmethod
+    def forward(ctx, x, weight1, offset1, weight2, bias2):
+        out = _kernels.get().particle_mlp(x, weight1, offset1, weight2, bias2)
+        if out is None:
+            raise _MlpDeclined()
+        ctx.save_for_backward(x, weight1, offset1, weight2, bias2)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight1, offset1, weight2, bias2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        fused = _kernels.get().particle_mlp_backward(grad, x, weight1, offset1, weight2, need_x=need[0])
+        if fused is not None:
+            grad_x, grad_w1, grad_rows, grad_w2 = fused
+            grad_offset = None
+            if need[2]:
+                grad_offset = grad_rows if offset1.dim() == 2 else grad_rows.sum(0)
+            grad_bias = grad.sum((0, 1)) if (bias2 is not None and need[4]) else None
+            return (grad_x if need[0] else None, grad_w1 if need[1] else None, grad_offset,
+                    grad_w2 if need[3] else None, grad_bias)
+        saved = (x, weight1, offset1, weight2, bias2)
+        with torch.enable_grad():
+            leaves = [None if t is None else t.detach().requires_grad_(flag) for t, flag in zip(saved, need)]
+            out = _mlp_reference(*leaves)
+            wanted = [t for t, flag in zip(leaves, need) if t is not None and flag]
+            grads = iter(torch.autograd.grad(out, wanted, grad))
+        return tuple(next(grads) if (t is not None and flag) else None for t, flag in zip(leaves, need))
+
+
+def particle_mlp(x, weight1, offset1, weight2, bias2=None):
+    """bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T over particles x [B,K,din]; kernels K13 / K13b when they
+    cover the shape, the PyTorch expression otherwise (same numbers to rounding)."""
+    if isinstance(x, LazyParticles):
+        x = x.materialise()
+    k = _kernels.get()
+    if not k.particle_mlp_covers(x, weight1, offset1, weight2, bias2):
+        return _mlp_reference(x, weight1, offset1, weight2, bias2)
+    tensors = (x, weight1, offset1, weight2, bias2)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        try:
+            return _ParticleMlp.apply(*tensors)
+        except _MlpDeclined:
+            return _mlp_reference(*tensors)
+    out = k.particle_mlp(*[None if t is None else t.detach() for t in tensors])
+    return out if out is not None else _mlp_reference(*tensors)
+
+
 class _AffineRsample(torch.autograd.Function):
     """draw = (offset + source @ weight.T) + eps * scale in one launch (kernel K9)."""
 

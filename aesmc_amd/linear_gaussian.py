@@ -96,6 +96,18 @@ def affine_terms(distribution):
     return terms
 
 
+def particle_mlp(x, weight1, offset1, weight2, bias2=None):
+    """A learned proposal net over the particles: the two-layer tanh MLP
+    bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T  for x [B,K,din] (din <= 16), weight1 [H,din] (H <= 64),
+    offset1 [H] or [B,H] (the per-row part of the first layer: its bias plus the observation's columns of the weight
+    applied to y_t), weight2 [dout,H] (dout <= 16).  Kernel K13 forward — the hidden layer never leaves registers — and
+    K13b backward (recomputed hidden layer, weight gradients on the matrix cores); the PyTorch expression wherever the
+    kernels do not cover the operands (other extents, fewer than ~43 particles per batch row; backward: K not a multiple
+    of 256).  What BASELINE.json's configs[3] (nonlinear SSM with a learned proposal net) evaluates per timestep;
+    `torch.cat + nn.Linear + nn.Tanh + nn.Linear` of the same weights gives the same numbers to float rounding."""
+    return _ops.particle_mlp(x, weight1, offset1, weight2, bias2)
+
+
 class AffineNormal(torch.distributions.Normal):
     """Normal(loc = source @ weight.T + offset, scale) with the location evaluated on demand.
 

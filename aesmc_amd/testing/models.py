@@ -313,8 +313,8 @@ class NonlinearSsm(nn.Module):
                  seed=0, dtype=torch.float32, state=_default_state, validate_args=None, fused=False):
         super().__init__()
         self.validate_args = validate_args
-        # fused=True: the d x d maps through aesmc_amd.linear_gaussian (particle_affine / AffineNormal: kernel K8)
-        # instead of PyTorch matmuls; the proposal net stays PyTorch's (the callables are the user's)
+        # fused=True: the d x d maps through aesmc_amd.linear_gaussian (particle_affine / AffineNormal: kernel K8) and the
+        # proposal net through particle_mlp (kernels K13 / K13b) instead of PyTorch matmuls
         self.fused = bool(fused)
         gen = torch.Generator().manual_seed(seed)
         eye = torch.eye(dim, dtype=torch.float64)
@@ -363,7 +363,13 @@ class NonlinearSsm(nn.Module):
                          "FULLY_EXPANDED")
 
     def _proposal_loc(self, x_prev, y_now):
-        """The net of [x_{t-1}, y_t]."""
+        """The net of [x_{t-1}, y_t]: fused, its first layer splits into the particles' columns (inside kernel K13) and
+        the observation's columns + bias (one [B,H] row offset, a small product)."""
+        first, second = self.net[0], self.net[2]
+        if self.fused:
+            from ..linear_gaussian import particle_mlp
+            from_observation = y_now @ first.weight[:, self.dim:].t() + first.bias
+            return particle_mlp(x_prev, first.weight[:, :self.dim], from_observation, second.weight, second.bias)
         expanded = y_now.unsqueeze(1).expand(-1, x_prev.size(1), -1)
         return self.net(torch.cat([x_prev, expanded], dim=2))
 

@@ -53,7 +53,9 @@ extern "C" {
  *                (+ aesmc_affine_wide_dim, aesmc_affine_wide_workspace_bytes).
  *   500 (0.5.0)  aesmc_affine_normal_propagate_wide takes every width 20 .. 256 that is a multiple of 4, dx != dy, any K
  *                (added aesmc_affine_wide_min_dim, aesmc_affine_wide_max_dim, aesmc_affine_wide_workspace_bytes_for);
- *                AESMC_FLAG_INVALID_PARAMETER reserved for the host's deferred distribution-argument validation.
+ *                AESMC_FLAG_INVALID_PARAMETER reserved for the host's deferred distribution-argument validation;
+ *                aesmc_particle_mlp is back (0.1.0 had it, 0.2.0 dropped it) WITH its backward: aesmc_particle_mlp_backward,
+ *                aesmc_particle_mlp_backward_records (+ aesmc_particle_mlp_max_hidden).
  *   400 (0.4.0)  aesmc_affine_chain grew `pairs_in` / `pairs_out` (a run of backward steps builds the weight pairs once);
  *                added aesmc_wide_adjoint_tile, aesmc_wide_adjoint_scale, aesmc_wide_adjoint_merge
  *   300 (0.3.0)  added aesmc_affine_normal_propagate_drawn_paired, aesmc_affine_weight_pairs,
@@ -487,6 +489,34 @@ int aesmc_wide_adjoint_scale(void *u, const void *weight, const void *scale, con
 int aesmc_wide_adjoint_merge(void *u_p, void *at_x, const void *weight, const void *scale, const void *value,
                              const void *base, int64_t base_stride_b, const void *add, void *out_sq, void *out_rows_p,
                              void *out_rows_x, int64_t B, int64_t K, void *stream);
+
+/* K13 — a learned proposal net over the particles: the two-layer tanh MLP
+ *   out[b,k,:] = layer2->offset + W2 tanh( layer1->offset[b,:] + W1 x[b,k,:] )
+ * with W1 [H, din] (din <= 16, H <= aesmc_particle_mlp_max_hidden() = 64), W2 [dout, H] (dout <= 16);
+ * layer1->offset is [H] or [B, H] (the per-row part of the first layer: its bias and the observation's
+ * columns of the weight applied to y_t), layer2->offset [dout] or NULL.  x, out dense and 16-byte
+ * aligned.  Replaces, in a model whose proposal is such a net of [x_{t-1}, y_t] (BASELINE.json configs[3]'s
+ * nonlinear state-space model; the reference's own proposal at test/models/lgssm.py:66-77 is its
+ * one-layer case), torch.cat + Linear + tanh + Linear: two GEMMs with [B,K,H] round trips through HBM.
+ * Returns AESMC_ERR_UNSUPPORTED (caller keeps the PyTorch expression) beyond those extents or with
+ * fewer than ~43 particles per batch row.
+ * K13b — its backward, recomputing the hidden layer (nothing of [B,K,H] is stored): for grad_out [B,K,dout]
+ *   grad_x[b,k,:] = W1^T dh,  dh = (W2^T grad_out) (1 - h^2)                     (dense [B,K,din]; may be NULL)
+ *   rec_w1 / rec_w2: [aesmc_particle_mlp_backward_records(B, K)][ceil(H / 16)][256] — per wavefront of the launch the
+ *     16 x 16 partials of grad_W1 (rows: 16 hidden units of the chunk, columns: inputs) and grad_W2 (rows: outputs,
+ *     columns: the chunk's hidden units), contracted over the particles on the matrix cores; the binder adds the records
+ *     (a fixed order: reproducible) and cuts them to [H, din] / [dout, H];
+ *   rows: [B K / 256][4][16 ceil(H / 16)] — sum of dh over each wavefront's 64 particles (the gradient of a per-row
+ *     layer1->offset is their sum over a row's K / 64 groups); may be NULL.
+ *   The output bias' gradient is grad_out summed over the particles (the binder's reduction).
+ * K a multiple of 256 (a tile of 256 particles inside one batch row) and din <= 15, else AESMC_ERR_UNSUPPORTED. */
+int64_t aesmc_particle_mlp_max_hidden(void);
+int aesmc_particle_mlp(int dtype, const void *x, const aesmc_affine_map *layer1, const aesmc_affine_map *layer2,
+                       void *out, int64_t B, int64_t K, void *stream);
+int64_t aesmc_particle_mlp_backward_records(int64_t B, int64_t K);
+int aesmc_particle_mlp_backward(int dtype, const void *x, const void *grad_out, const aesmc_affine_map *layer1,
+                                const aesmc_affine_map *layer2, void *grad_x, void *rec_w1, void *rec_w2, void *rows,
+                                int64_t B, int64_t K, void *stream);
 
 /* K11 — the adjoint of an affine location  loc = offset + W x  for an incoming gradient grad [B,K,dout]:
  *   out_grad_x[b,k,i]      = sum_j grad[b,k,j] W[j,i]                       (dense [B,K,din])

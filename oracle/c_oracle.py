@@ -42,6 +42,9 @@ def load():
             fn.restype = None
             fn.argtypes = [rp, rp, rp, _i64, rp, rp, _i64, rp, rp, _i64, rp, rp, _i64, real, real, real, rp,
                            _i64, _i64, _i64, _i64]
+            fn = getattr(lib, "smc_oracle_particle_mlp_" + suffix)
+            fn.restype = None
+            fn.argtypes = [rp, rp, rp, _i64, rp, rp, rp, _i64, _i64, _i64, _i64, _i64]
         _lib = lib
     return _lib
 
@@ -182,3 +185,18 @@ def affine_logweight(x_prev, x, y, transition, emission, proposal, scale_p, scal
         _ptr(args[6], rp), _ptr(args[7], rp), args[8], float(scale_p), float(scale_g), float(scale_q),
         _ptr(lw, rp), B, K, dx, dy)
     return lw
+
+
+def particle_mlp(x, weight1, offset1, weight2, bias2=None):
+    """K13: bias2 + tanh(offset1 + x @ weight1.T) @ weight2.T; offset1 [H] or [B, H]."""
+    dtype = x.dtype
+    suffix, rp = _kind(dtype)
+    x, weight1, weight2, bias2 = _real(x, dtype), _real(weight1, dtype), _real(weight2, dtype), _real(bias2, dtype)
+    B, K, din = x.shape
+    hid, dout = weight1.shape[0], weight2.shape[0]
+    off, off_sb = _offset(offset1, B, hid, dtype)
+    out = np.empty((B, K, dout), dtype=dtype)
+    getattr(load(), "smc_oracle_particle_mlp_" + suffix)(
+        _ptr(x, rp), _ptr(weight1, rp), _ptr(off, rp), off_sb, _ptr(weight2, rp), _ptr(bias2, rp), _ptr(out, rp),
+        B, K, din, hid, dout)
+    return out

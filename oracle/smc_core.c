@@ -222,3 +222,30 @@ void smc_oracle_logweight_lse(const double *a, const double *b, const double *c,
 DEFINE_AFFINE(f32, float, fmaf, logf)
 DEFINE_AFFINE(f64, double, fma, log)
 
+
+/* K13: the two-layer tanh net over particles  out = b2 + W2 tanh(c1[b] + W1 x[b,k])  that BASELINE.json's
+ * nonlinear state-space model uses as its proposal (torch.cat + Linear + Tanh + Linear through the
+ * reference's callable contract; its one-layer case is the reference's own test/models/lgssm.py:66-77).
+ * Chains as above (fma, inputs ascending, started from the offset / bias); tanh is libm's. */
+#define DEFINE_MLP(SUFFIX, T, FMA, TANH)                                                                \
+  void smc_oracle_particle_mlp_##SUFFIX(const T *x, const T *w1, const T *off1, int64_t off1_sb,        \
+                                        const T *w2, const T *b2, T *out, int64_t B, int64_t K,         \
+                                        int64_t din, int64_t hid, int64_t dout) {                       \
+    T hidden[256];                                                                                      \
+    for (int64_t b = 0; b < B; ++b)                                                                     \
+      for (int64_t k = 0; k < K; ++k) {                                                                 \
+        const int64_t n = b * K + k;                                                                    \
+        for (int64_t h = 0; h < hid; ++h) {                                                             \
+          T acc = off1 ? off1[b * off1_sb + h] : (T)0;                                                  \
+          for (int64_t i = 0; i < din; ++i) acc = FMA(w1[h * din + i], x[n * din + i], acc);            \
+          hidden[h] = TANH(acc);                                                                        \
+        }                                                                                               \
+        for (int64_t o = 0; o < dout; ++o) {                                                            \
+          T acc = b2 ? b2[o] : (T)0;                                                                    \
+          for (int64_t h = 0; h < hid; ++h) acc = FMA(w2[o * hid + h], hidden[h], acc);                 \
+          out[n * dout + o] = acc;                                                                      \
+        }                                                                                               \
+      }                                                                                                 \
+  }
+DEFINE_MLP(f32, float, fmaf, tanhf)
+DEFINE_MLP(f64, double, fma, tanh)

@@ -139,6 +139,26 @@ class OracleKernels:
             self._n(x_prev), self._n(x), self._n(y_rows), pair(transition), pair(emission), pair(proposal),
             float(scales[0]), float(scales[1]), float(scales[2])))
 
+    # ---- K13 / K13b on the C oracle (forward) and float64 autograd (backward) ----------------------------------
+    def particle_mlp_covers(self, x, weight1, offset1, weight2, bias2=None):
+        return torch.is_tensor(x) and x.dim() == 3 and x.dtype in (torch.float32, torch.float64) and \
+            weight1.dim() == 2 and weight1.size(1) == x.size(2) <= 16 and weight1.size(0) <= 64 and \
+            weight2.dim() == 2 and weight2.size(1) == weight1.size(0) and weight2.size(0) <= 16
+
+    def particle_mlp(self, x, weight1, offset1, weight2, bias2=None):
+        from oracle import c_oracle
+        return torch.from_numpy(c_oracle.particle_mlp(self._n(x), self._n(weight1), self._n(offset1), self._n(weight2),
+                                                      None if bias2 is None else self._n(bias2)))
+
+    def particle_mlp_backward(self, grad_out, x, weight1, offset1, weight2, need_x=True):
+        with torch.enable_grad():
+            leaves = [t.detach().double().requires_grad_(True) for t in (x, weight1, offset1, weight2)]
+            hidden = torch.tanh(leaves[0] @ leaves[1].t() + (leaves[2].unsqueeze(1) if leaves[2].dim() == 2 else leaves[2]))
+            out = hidden @ leaves[3].t()
+            gx, gw1, goff, gw2 = torch.autograd.grad(out, leaves, grad_out.double())
+        rows = goff if goff.dim() == 2 else goff.unsqueeze(0).expand(x.size(0), -1) / x.size(0)
+        return (gx.to(x.dtype) if need_x else None, gw1.to(x.dtype), rows.to(x.dtype), gw2.to(x.dtype))
+
     def particle_affine_backward(self, grad, x, weight, need_x=True, need_weight=True, need_offset=False):
         g2, x2 = grad.reshape(-1, grad.size(-1)).double(), x.reshape(-1, x.size(-1)).double()
         gx = (grad.double() @ weight.double()).to(grad.dtype) if need_x else None

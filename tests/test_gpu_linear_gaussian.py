@@ -733,3 +733,134 @@ def test_full_size_step_is_the_same_by_every_route(hip_device):
     for name in ga:
         scale = max(float(gc[name].abs().max()), 1e-30)
         assert float((ga[name] - gc[name]).abs().max()) <= 5e-2 * scale, name
+
+
+# ---- K13 / K13b: the proposal net and its backward --------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(3, 700, 10, 64, 10), (2, 513, 5, 16, 3), (5, 64, 16, 33, 16), (1, 1000, 3, 7, 7),
+                                   (4, 300, 1, 1, 1), (128, 4096, 10, 64, 10)])
+def test_particle_mlp_matches_the_c_oracle_and_the_pytorch_expression(kernels, hip_device, dtype, shape):
+    """K13 against oracle/smc_core.c (same fma chains; the device's tanh against libm's: a few ulp) and
+    against the PyTorch expression it replaces (cat + Linear + tanh + Linear)."""
+    B, K, din, hid, dout = shape
+    rng = np.random.RandomState(B + K + hid)
+    r = lambda *s_: rng.randn(*s_).astype(dtype)
+    x, w1, off1, w2, b2 = r(B, K, din), (r(hid, din) / np.sqrt(din)).astype(dtype), r(B, hid), \
+        (r(dout, hid) / np.sqrt(hid)).astype(dtype), r(dout)
+    dev = lambda a: torch.from_numpy(a).to(hip_device)
+    out = kernels.particle_mlp(dev(x), dev(w1), dev(off1), dev(w2), dev(b2))
+    assert out is not None and out.shape == (B, K, dout)
+    tolerance = 3e-6 if dtype == np.float32 else 1e-14
+    if B * K <= 4096:
+        want = c_oracle.particle_mlp(x, w1, off1, w2, b2)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=tolerance, atol=tolerance * 4)
+    ref = torch.tanh(dev(x).double() @ dev(w1).double().t() + dev(off1).double().unsqueeze(1)) @ dev(w2).double().t() \
+        + dev(b2).double()
+    assert float((out.double() - ref).abs().max()) <= 4 * tolerance * max(1.0, float(ref.abs().max()))
+    shared = kernels.particle_mlp(dev(x), dev(w1), dev(off1[0]), dev(w2), None)     # [H] offset, no output bias
+    ref = torch.tanh(dev(x).double() @ dev(w1).double().t() + dev(off1[0]).double()) @ dev(w2).double().t()
+    assert float((shared.double() - ref).abs().max()) <= 4 * tolerance * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", [(3, 768, 10, 64, 10), (2, 512, 5, 16, 3), (5, 256, 15, 33, 16), (1, 1024, 3, 7, 7),
+                                   (4, 256, 1, 1, 1), (128, 4096, 10, 64, 10)])
+def test_particle_mlp_backward_equals_float64_autograd(kernels, hip_device, dtype, shape):
+    """K13b — grad_x per particle, grad_W1 / grad_W2 contracted over the particles on the matrix cores (one record per
+    wavefront, added by the binder), the per-row sums of dh riding in the column of ones — against float64 autograd of
+    tanh(x W1^T + c1) W2^T: float64 to 1e-11 of a gradient's largest entry, float32 to rounding of sums over B K
+    particles.  The last shape is configs[3]'s per-GPU shard (B = 128, K = 4096, d = 10, 64 hidden units)."""
+    B, K, din, hid, dout = shape
+    gen = torch.Generator(device=hip_device).manual_seed(B + K + hid)
+    make = lambda *s_: torch.randn(*s_, device=hip_device, dtype=dtype, generator=gen)
+    x, w1, off1, w2 = make(B, K, din), make(hid, din) / din ** 0.5, make(B, hid), make(dout, hid) / hid ** 0.5
+    upstream = make(B, K, dout)
+    got = kernels.particle_mlp_backward(upstream, x, w1, off1, w2)
+    assert got is not None, "K13b declined a shape it is built for"
+    leaves = [t.double().requires_grad_(True) for t in (x, w1, off1, w2)]
+    out = torch.tanh(leaves[0] @ leaves[1].t() + leaves[2].unsqueeze(1)) @ leaves[3].t()
+    want = torch.autograd.grad(out, leaves, upstream.double())
+    # (float32: a sum over B K products of order one that cancels to a tenth of that — the 1 x 1 net — keeps ~5e-5)
+    tolerance = 1e-11 if dtype == torch.float64 else 6e-5
+    for name, a, b in zip(("grad_x", "grad_w1", "grad_offset1", "grad_w2"), got, want):
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        scale = max(float(b.abs().max()), 1e-30)
+        assert float((a.double() - b).abs().max()) <= tolerance * scale, (name, float((a.double() - b).abs().max()), scale)
+    # what it leaves to the caller's own operations: K not a multiple of 256, sixteen inputs (no column left for the ones)
+    assert kernels.particle_mlp_backward(make(2, 300, dout), make(2, 300, din), w1, make(2, hid), w2) is None
+    if din < 16:
+        wide_in = make(2, 256, 16)
+        assert kernels.particle_mlp_backward(make(2, 256, dout), wide_in, make(hid, 16), make(2, hid), w2) is None
+
+
+def test_particle_mlp_operator_gradients_and_fallbacks(hip_device):
+    from aesmc_amd.linear_gaussian import particle_mlp
+    gen = torch.Generator(device=hip_device).manual_seed(4)
+    make = lambda *shape: torch.randn(*shape, device=hip_device, dtype=torch.float64, generator=gen).requires_grad_(True)
+    for K in (512, 300):      # a multiple of 256: K13b; else K13 forward and PyTorch's autograd of the expression
+        x, w1, off1, w2, b2 = make(3, K, 6), make(20, 6), make(3, 20), make(4, 20), make(4)
+        out = particle_mlp(x, w1, off1, w2, b2)
+        upstream = torch.randn(out.shape, device=hip_device, dtype=torch.float64, generator=gen)
+        got = torch.autograd.grad(out, (x, w1, off1, w2, b2), upstream)
+        ref_out = torch.tanh(x @ w1.t() + off1.unsqueeze(1)) @ w2.t() + b2
+        ref = torch.autograd.grad(ref_out, (x, w1, off1, w2, b2), upstream)
+        torch.testing.assert_close(out, ref_out, rtol=1e-12, atol=1e-12)
+        for a, b in zip(got, ref):
+            torch.testing.assert_close(a, b, rtol=1e-10, atol=1e-10)
+    shared = make(20)      # one offset for every row: its gradient is the sum over the rows
+    out = particle_mlp(x.detach(), w1.detach(), shared, w2.detach(), None)
+    (grad_shared,) = torch.autograd.grad(out, (shared,), torch.ones_like(out))
+    ref = torch.autograd.grad(torch.tanh(x.detach() @ w1.detach().t() + shared) @ w2.detach().t(), (shared,),
+                              torch.ones_like(out))[0]
+    torch.testing.assert_close(grad_shared, ref, rtol=1e-10, atol=1e-10)
+    wide = particle_mlp(make(2, 64, 6), make(100, 6), make(100), make(4, 100))     # beyond 64 hidden units: PyTorch
+    assert wide.shape == (2, 64, 4)
+    few = particle_mlp(make(50, 8, 6), w1, make(50, 20), w2, b2)                     # 8 particles per row: PyTorch
+    assert few.shape == (50, 8, 4)
+
+
+@pytest.mark.parametrize("algorithm,B,K,T,d", [("aesmc", 3, 256, 4, 5), ("aesmc", 2, 512, 3, 10)])
+def test_fused_nonlinear_model_matches_the_cpu_port_with_gradients(hip_device, algorithm, B, K, T, d):
+    """BASELINE.json's nonlinear state-space model with its maps through K8 and its proposal net through
+    K13 / K13b (`fused=True`) against the CPU port running the plain PyTorch callables, draws replayed:
+    float64 loss to 1e-10, every parameter gradient to 1e-8 of its largest entry."""
+    from aesmc_amd import _kernels, losses
+    from aesmc_amd.testing import models, replay
+    from oracle import reference_port
+    dtype = torch.float64
+    cpu_model = models.NonlinearSsm(d, hidden=24, seed=0, dtype=dtype, state=reference_port)
+    observations = cpu_model.simulate(T, B, seed=1)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    with replay.record() as tape:
+        want = reference_port.get_loss(observations, K, algorithm, *_parts(cpu_model))
+    want.backward()
+    model = models.NonlinearSsm(d, hidden=24, seed=0, dtype=dtype, fused=True).to(hip_device)
+    provider = _kernels.get()
+    calls = {"forward": 0, "backward": 0}
+    forward, backward = provider.particle_mlp, provider.particle_mlp_backward
+
+    def spy_forward(*args, **kwargs):
+        calls["forward"] += 1
+        return forward(*args, **kwargs)
+
+    def spy_backward(*args, **kwargs):
+        out = backward(*args, **kwargs)
+        calls["backward"] += out is not None
+        return out
+    provider.particle_mlp, provider.particle_mlp_backward = spy_forward, spy_backward
+    try:
+        with replay.replay(tape):
+            got = losses.get_loss([o.to(hip_device) for o in observations], K, algorithm, *_parts(model))
+        got.backward()
+    finally:
+        del provider.particle_mlp, provider.particle_mlp_backward
+    assert calls == {"forward": T - 1, "backward": T - 1}, calls
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-10, atol=1e-10)
+    expected = dict(cpu_model.named_parameters())
+    for name, parameter in model.named_parameters():
+        reference = expected[name].grad
+        if reference is None:
+            continue
+        scale = max(float(reference.abs().max()), 1e-30)
+        assert float((parameter.grad.cpu() - reference).abs().max()) <= 1e-8 * scale, name
