@@ -30,6 +30,16 @@ template <typename T> __device__ __forceinline__ T mlp_tanh(T x);
 template <> __device__ __forceinline__ float mlp_tanh<float>(float x) { return ::tanhf(x); }
 template <> __device__ __forceinline__ double mlp_tanh<double>(double x) { return ::tanh(x); }
 
+// The backward RECOMPUTES the hidden layer only to form 1 - h^2 and the outer products: float32 there takes
+// tanh(v) = 1 - 2 / (1 + e^{2 v}) on the hardware's exp2 / reciprocal (absolute error ~1e-7, saturating correctly at both
+// ends) instead of the device library's 40-instruction tanhf — two thirds of the kernel's vector instructions were that
+// call (142 us -> see profiles/README.md).  The FORWARD keeps the library's tanhf: its values are the ones torch.tanh gives.
+template <typename T> __device__ __forceinline__ T mlp_tanh_backward(T x) { return mlp_tanh<T>(x); }
+template <> __device__ __forceinline__ float mlp_tanh_backward<float>(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // e^{2 x}
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 constexpr int kMlpMaxHidden = 64;
 
 template <typename T, int DP>
@@ -164,6 +174,16 @@ struct MlpBackwardArgs {
   uint32_t K, HP;
 };
 
+// The transposing areas belong to ONE wavefront: what it wrote must have landed before its lanes read each other's rows
+// (LDS serves a wavefront's accesses in order; the wait makes that explicit and keeps the compiler from moving accesses
+// across it) — no workgroup barrier, the four wavefronts of a workgroup never wait for each other inside a tile.
+__device__ __forceinline__ void mlp_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename T, int DP>
 __global__ __launch_bounds__(kLgBlock, sizeof(T) == 4 ? 2 : 1) void particle_mlp_backward_kernel(MlpBackwardArgs a) {      // (float32: two workgroups per CU — 256 registers a wavefront)
   extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(kLgBlock, sizeof(T) == 4 ? 2 : 1) void particle_mlp
       buf_x[lane * kMlpStride + i] = i == 15 ? T(1) : (i < DP ? xv[i < DP ? i : 0] : T(0));
     }
     if (lane < HP) tab[lane] = (off1 != nullptr && lane < hid) ? off1[(int64_t)b * a.m1.off_sb + lane] : T(0);
-    __syncthreads();
+    mlp_wave_sync();
 #pragma unroll
     for (int c = 0; c < kMlpMaxHidden / 16; ++c) {
       if ((uint32_t)c < chunks) {      // (uniform)
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(kLgBlock, sizeof(T) == 4 ? 2 : 1) void particle_mlp
         }
 #pragma unroll
         for (int h = 0; h < 16; ++h) {
-          hv[h] = mlp_tanh<T>(hv[h]);
+          hv[h] = mlp_tanh_backward<T>(hv[h]);
           const T *w = w2 + (16 * c + h) * DP;
           T t = T(0);
 #pragma unroll
@@ -249,23 +269,23 @@ __global__ __launch_bounds__(kLgBlock, sizeof(T) == 4 ? 2 : 1) void particle_mlp
         // grad_W2's chunk: D[o][h] += sum over the 64 particles of g[p][o] h[p][h]
 #pragma unroll
         for (int h = 0; h < 16; ++h) buf_t[lane * kMlpStride + h] = hv[h];
-        __syncthreads();
+        mlp_wave_sync();
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
           const uint32_t p = 4 * s + kq;
           acc2[c] = Mfma<T>::fma(buf_g[p * kMlpStride + m], buf_t[p * kMlpStride + m], acc2[c]);
         }
-        __syncthreads();
+        mlp_wave_sync();
         // grad_W1's chunk: D[h][i] += sum over the particles of dh[p][h] x[p][i]   (i = 15: the ones)
 #pragma unroll
         for (int h = 0; h < 16; ++h) buf_t[lane * kMlpStride + h] = dh[h];
-        __syncthreads();
+        mlp_wave_sync();
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
           const uint32_t p = 4 * s + kq;
           acc1[c] = Mfma<T>::fma(buf_t[p * kMlpStride + m], buf_x[p * kMlpStride + m], acc1[c]);
         }
-        __syncthreads();
+        mlp_wave_sync();
         __builtin_amdgcn_sched_barrier(0);      // (a chunk's weights and hidden values are not sent for during the chunk before)
       }
     }

@@ -182,36 +182,6 @@ def self_launch(args, argv):
     return subprocess.run(command, env=child_environment()).returncode
 
 
-@contextlib.contextmanager
-def tunable_gemms(enable):
-    """PyTorch's TunableOp for the duration of one leg (each new GEMM shape is timed once, the best kernel kept).
-    Yields a dict whose "state" says what was actually switched on."""
-    import torch
-    report = {"state": "off"}
-    if not enable:
-        report["state"] = "already on for the whole run (--tunableop on)"
-        yield report
-        return
-    try:
-        was = (torch.cuda.tunable.is_enabled(), torch.cuda.tunable.tuning_is_enabled())
-        torch.cuda.tunable.enable(True)
-        torch.cuda.tunable.tuning_enable(True)
-        torch.cuda.tunable.set_max_tuning_duration(30)
-        torch.cuda.tunable.set_max_tuning_iterations(20)
-        torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "aesmc_tunableop_%d.csv" % os.getpid()))
-    except Exception as error:      # an optional PyTorch knob
-        print("TunableOp unavailable ({})".format(error), file=sys.stderr)
-        report["state"] = "unavailable ({}): PyTorch's default GEMM picks".format(type(error).__name__)
-        yield report
-        return
-    report["state"] = "on (this leg only: the MLP proposal's GEMMs are the user's PyTorch code)"
-    try:
-        yield report
-    finally:
-        torch.cuda.tunable.tuning_enable(was[1])
-        torch.cuda.tunable.enable(was[0])
-
-
 # ---- models / CPU baseline -------------------------------------------------------------------------
 def build_model(kind, dim, device, state, proposal="stock", callables="matmul", **model_kwargs):
     from aesmc_amd.testing import models
@@ -1006,6 +976,7 @@ def main(argv=None):
         "fwd_bwd_error": head.get("fwd_bwd_error"),
         "roofline": head.get("roofline"),
         "kernels": head.get("kernels"),
+        "backward_kernels": head.get("backward_kernels"),
     }
 
     if head["callables"] == "matmul":
@@ -1062,16 +1033,13 @@ def main(argv=None):
             lap("c5")
         if args.workload == "c4":
             # BASELINE.json configs[3]'s model (nonlinear SSM, learned proposal net) on one GPU's shard of it, forward
-            # AND backward: the d x d maps through K8 / K11; the proposal net is the user's PyTorch module
-            # The backward's time is the user's module: hipBLASLt's default picks for the MLP's two weight-gradient GEMMs
-            # ([hidden, B K] x [B K, 2 d] and [d, B K] x [B K, hidden]: a 524288-long contraction onto a few
-            # workgroups) take 898 + 822 us of the 2.1 ms per timestep (profiles/r04_rocprof_c4nl_fwd_bwd.csv) — so
-            # this leg runs with PyTorch's TunableOp picking those GEMMs (a stock PyTorch switch; ~50 s of tuning,
-            # here only), and says so.
-            with tunable_gemms(args.tunableop != "on") as tuned:
-                extras["c4nl"] = brief(run_workload(ctx, "c4nl", "stock", 3, 2, want_backward=not args.no_backward,
-                                                    want_kernels=False, callables="affine"))
-            extras["c4nl"]["tunableop"] = tuned["state"]
+            # AND backward: the d x d maps through K8 / K11, the proposal net through K13 / K13b (round 6: until then the
+            # net was PyTorch's cat + Linear + tanh + Linear — 173 us of a 260 us timestep — and its two weight-gradient
+            # GEMMs, a 524 288-long contraction onto a few workgroups, 898 + 822 us of the backward's 2.1 ms per timestep
+            # under hipBLASLt's default picks: this leg then ran under TunableOp, ~50 s of tuning; no longer needed)
+            extras["c4nl"] = brief(run_workload(ctx, "c4nl", "stock", 3, 2, want_backward=not args.no_backward,
+                                                want_kernels=False, callables="affine"))
+            extras["c4nl"]["tunableop"] = "off (the proposal net runs in the library's own kernels K13 / K13b)"
             # What one GPU's shard of the north-star batch costs on THIS device (global B = 1024 split over N GPUs:
             # B / N rows here): the strong-scaling curve, the one all-reduce of sum log Z per ELBO aside.
             # projected_efficiency = t(B = 1024) / (N * t(B / N)).
