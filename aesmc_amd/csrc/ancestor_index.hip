@@ -800,6 +800,7 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
       scratch[wave] = (double)wave_m;
       scratch_i[wave] = wave_nan;
     }
+    if (tid == 0) *reinterpret_cast<int *>(scratch + 34) = 0;      // (the row's "ranges descend somewhere" flag, see below)
   }
   __syncthreads();
   const int slot = lane < nwaves ? lane : 0;
@@ -883,26 +884,26 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
       }
     }
   }
-  // By-product for the gather's backward: first[j] = where the children of particles 0..j end (see the kernel above),
-  // clamped to the suffix minimum of first[] so that the ranges are monotone on knife-edge rows too (the general kernel
-  // says why): the later lanes of this wavefront here, the later wavefronts — whose entries are not known before the
-  // barrier below — by a fix-up behind it that practically never runs.
+  // By-product for the gather's backward: first[j] = where the children of particles 0..j end (see the kernel above).
+  // The ranges must be monotone; first[] is, except where two lanes hold the same partial sum associated differently (the
+  // general kernel says how: exact-zero weights in between, a knife-edge position) — then the consistent ranges are those
+  // of first[]'s SUFFIX MINIMUM.  Here: written as they are; whether any NEIGHBOURING pair of lanes (or of wavefronts)
+  // descends is one comparison and a vote — a row-wide flag in LDS — and only a flagged row (about one in 1e9 with random
+  // uniforms) repairs its ranges, out of line, behind the last barrier.
+  int *inverted = reinterpret_cast<int *>(scratch + 34);      // (a free slot of the scratch area; cleared in front of the first barrier)
   int range_last = 0;
+  const int next_lane_first = dpp_i32<kDppWaveShl1>(K, first[0]);      // the next lane's first particle (lane 63: unknown)
   if (out_child_end != nullptr) {
-    const int wave_min = wave_suffix_min(first[0], lane);
-    int bound = __shfl_down(wave_min, 1, kWave);
-    if (lane == kWave - 1) bound = K;
-    if (lane == 0) scratch_i[32 + wave] = wave_min;
+    if (lane == 0) scratch_i[32 + wave] = first[0];
+    range_last = first[C - 1];
+    if (__any(lane != kWave - 1 && range_last > next_lane_first) && lane == 0) *inverted = 1;
     int32_t *ends = out_child_end + row * (int64_t)K + j0;
 #pragma unroll
     for (int q = 0; q < C / 4; ++q)
-      reinterpret_cast<int4 *>(ends)[q] = make_int4(min(first[4 * q], bound), min(first[4 * q + 1], bound),
-                                                    min(first[4 * q + 2], bound), min(first[4 * q + 3], bound));
-    range_last = min(first[C - 1], bound);
+      reinterpret_cast<int4 *>(ends)[q] = make_int4(first[4 * q], first[4 * q + 1], first[4 * q + 2], first[4 * q + 3]);
   }
   // ---- markers: slot first[j] holds j + 1 for the LAST particle that starts there ---------------------------------------
   {
-    const int next_lane_first = dpp_i32<kDppWaveShl1>(K, first[0]);      // the next lane's first particle (lane 63: unknown)
 #pragma unroll
     for (int i = 0; i < C - 1; ++i) marker[first[i] < first[i + 1] ? first[i] : K] = j0 + i + 1;      // (slot K: the spare)
     const int last = first[C - 1];
@@ -915,15 +916,8 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
     }
   }
   __syncthreads();
-  if (out_child_end != nullptr) {
-    int later = K;
-    for (int w = wave + 1; w < nwaves; ++w) later = min(later, scratch_i[32 + w]);
-    if (range_last > later) {      // a later wavefront starts below this lane's ranges (an ulp-level inversion on a knife edge)
-      int32_t *ends = out_child_end + row * (int64_t)K + j0;
-      for (int i = 0; i < C; ++i)
-        if (ends[i] > later) ends[i] = later;
-    }
-  }
+  if (out_child_end != nullptr && lane == kWave - 1 && wave + 1 < nwaves && range_last > scratch_i[32 + wave + 1])
+    *inverted = 1;      // (a wavefront's last particle against the next wavefront's first; seen by all behind the next barrier)
 
   // ---- idx[k] = running maximum of the markers ----------------------------------------------------------------------
   int best[C];
@@ -946,6 +940,21 @@ __global__ __launch_bounds__(kMaxThreads, C > 8 ? 1 : 8) void ancestor_index_row
     const int maxima = row16_scan_max(lane < nwaves ? scratch_i[16 + lane] : 0);
     before = __builtin_amdgcn_readlane(maxima, wave > 0 ? wave - 1 : 0);
     if (wave == 0) before = 0;
+  }
+  if (out_child_end != nullptr && *inverted != 0) {      // (uniform: read behind the barrier above)
+    // the rare row: every entry clamped to the smallest first[] behind it — the later lanes of the wavefront by a reverse
+    // scan over each lane's first entry, the later wavefronts' minima through LDS; the entries are read back from where
+    // this lane stored them
+    int32_t *ends = out_child_end + row * (int64_t)K + j0;
+    const int wave_min = wave_suffix_min(ends[0], lane);
+    int bound = __shfl_down(wave_min, 1, kWave);
+    if (lane == kWave - 1) bound = K;
+    __syncthreads();      // (scratch_i[32 ..) was last read in front of the barrier above)
+    if (lane == 0) scratch_i[32 + wave] = wave_min;
+    __syncthreads();
+    for (int w = wave + 1; w < nwaves; ++w) bound = min(bound, scratch_i[32 + w]);
+    for (int i = 0; i < C; ++i)
+      if (ends[i] > bound) ends[i] = bound;
   }
   before = max(before, before_lanes);
 #pragma unroll
