@@ -60,12 +60,7 @@ def build(force=False, verbose=True):
              "-ffp-contract=off",  # keep float64 CDF arithmetic as written (no fused a*b+c)
              "-munsafe-fp-atomics",  # hardware float atomics for the gather backward
              "-Wall", "-Wno-unused-function"]
-    extra = os.environ.get("AESMC_HIPCC_FLAGS", "").split()      # experiments (e.g. -DAESMC_K16_PROBES); empty in a product build
-    if any("_PROBES" in flag for flag in extra) and os.environ.get("AESMC_PROBE_BUILD") != "1":
-        # the probe paths SKIP parts of a kernel on purpose (their output is wrong): never by accident in the library
-        # the package loads — a timing experiment says so explicitly and rebuilds without the flag afterwards
-        raise RuntimeError("aesmc_amd.build: AESMC_HIPCC_FLAGS defines a *_PROBES macro (kernels with parts left out); "
-                           "set AESMC_PROBE_BUILD=1 to build such a measurement library on purpose")
+    extra = os.environ.get("AESMC_HIPCC_FLAGS", "").split()      # experiments (another -O level, -save-temps, ...); empty in a product build
     flags += extra
     objdir = os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)

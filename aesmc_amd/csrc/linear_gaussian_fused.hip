@@ -31,28 +31,6 @@
 
 namespace aesmc {
 
-#ifdef AESMC_K16_PROBES
-// cycle stamps of a diagnostic build (never in the product): where an item's time goes, by phase
-__device__ __forceinline__ uint64_t fused_stamp() {
-  uint64_t t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define FUSED_STAMP(k) do { if (plan.stamps != nullptr) { const uint64_t now_ = fused_stamp(); acc_[k] += now_ - last_; last_ = now_; } } while (0)
-__device__ __forceinline__ uint64_t fused_realtime() {
-  uint64_t t;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define FUSED_STAMP_INIT uint64_t acc_[16] = {}; uint64_t last_ = plan.stamps != nullptr ? fused_stamp() : 0; const uint64_t real0_ = fused_realtime(), cyc0_ = last_
-#define FUSED_STAMP_FLUSH(role) do { if (plan.stamps != nullptr && (threadIdx.x & 255u) == 0) { acc_[14] = fused_stamp() - cyc0_; acc_[15] = fused_realtime() - real0_; for (int k_ = 0; k_ < 16; ++k_) plan.stamps[((size_t)blockIdx.x * 2 + (role)) * 16 + k_] = acc_[k_]; } } while (0)
-#else
-#define FUSED_STAMP(k) do { } while (0)
-#define FUSED_STAMP_INIT do { } while (0)
-#define FUSED_STAMP_FLUSH(role) do { } while (0)
-#endif
 
 // Workgroup: four particle wavefronts and four noise wavefronts, two workgroups per CU (four wavefronts per SIMD).
 // (Measured and not kept: SIX noise wavefronts for the scalar-weight form, which fits 96 registers — ten wavefronts
@@ -76,11 +54,6 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
   float *scratch = noise + 2 * plan.tile_f;                     // [4 wavefronts][2][64 * RS]
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#ifdef AESMC_K16_PROBES
-  const uint32_t probe = plan.probe;
-#else
-  constexpr uint32_t probe = 0;
-#endif
   const uint32_t G = plan.G;
   const uint32_t last_item = plan.items - 1;
 
@@ -213,7 +186,7 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         const uint32_t tt = wraps ? t - G : t;
         first = make_float4(0.5f, 0.25f, 0.125f, 1.0f);
         second = first;
-        if (!(probe & 1u)) {
+        {
           first = philox_normal4(ps, tt, r.c);
           if (__any(wraps)) second = philox_normal4(ps, tt, r.c + 1);      // (uniform branch, rarely taken)
         }
@@ -223,7 +196,7 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
       // vector ALU to interleave (one call at a time a noise wavefront issued an instruction every ~7 cycles even with
       // the SIMD to itself).  No lane-dependent branch: a lane past the span draws a value that lands on the spare word.
       constexpr uint32_t SC = DXC != 0 ? ((kRunP + 1u) * (uint32_t)DXC - 1u) / 256u : 0u;      // == plan.S
-      if (SC != 0 && NL == 256u && r.t0 + r.span <= G && !(probe & 1u)) {      // (uniform; no thread id wraps: all but a trip's last block)
+      if (SC != 0 && NL == 256u && r.t0 + r.span <= G) {      // (uniform; no thread id wraps: all but a trip's last block)
         float4 drawn[SC != 0 ? SC : 1];
 #pragma unroll
         for (uint32_t s = 0; s < SC; ++s) drawn[s] = philox_normal4(ps, r.t0 + tid + s * NL, r.c);
@@ -248,7 +221,6 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         if (nw + NW * trip < 8u) tab[64u * (nw + NW * trip) + lane] = held[trip];
     };
     float held[2], held_next[2];
-    FUSED_STAMP_INIT;
     {
       const Record first = locate(min(blockIdx.x, last_item)), second = locate(min(blockIdx.x + gridDim.x, last_item));
       const uint32_t rows0[2] = {first.row[nw >> 1], first.row[((nw + NW) >> 1) & 3u]};
@@ -263,21 +235,16 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
       const uint32_t next = item + gridDim.x;
       held[0] = held_next[0];
       held[1] = held_next[1];
-      FUSED_STAMP(0);
       {
         const uint32_t *rec = ring + ((it + 2u) & 3u) * 16u;      // the record of item + 2 strides
         const uint32_t rows[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)rec[12 + (nw >> 1)]),
                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[12 + (((nw + NW) >> 1) & 3u)])};
         table_load(rows, held_next);
       }
-      FUSED_STAMP(1);
       if (next < plan.items) draw_item(read_record(it + 1u), slot ^ 1u, held);
-      FUSED_STAMP(2);
       lg_lds_barrier();
-      FUSED_STAMP(3);
       slot ^= 1u;
     }
-    FUSED_STAMP_FLUSH(1);
     return;
   }
 
@@ -390,9 +357,7 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
   for (int c = 0; c < 2; ++c) araw[c] = anc_load(nxt, c);
   publish(1, nxt, w);
   publish(2, ahd, w);
-  FUSED_STAMP_INIT;
   lg_lds_barrier();       // the first item's noise and table are there
-  FUSED_STAMP(0);
   uint32_t slot = 0, it = 0;
   for (uint32_t item = blockIdx.x; item < plan.items; item += stride, ++it) {
     const float *tx = noise + slot * plan.tile_f + w * kRunP * dx;
@@ -411,7 +376,6 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         // (the chunk's rows are read where the prefetch left them; the next item's are sent for once the two chains that
         //  read them are done)
         float (&xin)[XN] = xr[c];
-        FUSED_STAMP(1);
         const uint32_t rl = 64u * c + ln;
         const uint32_t rr = lane_row(cur, c);
         const bool live = rl < cur.count;
@@ -460,12 +424,11 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         };
         float locq[DP], locp[DP];
         float xx[DP], qp = 0.0f, qq = 0.0f, qg = 0.0f;
-        if (!(probe & 2u)) {
+        {
           chain(wq_a, trow + 16, dx, xin, locq);
           chain(wp_a, trow, dx, xin, locp);
-          if (!(probe & 8u)) rows_load(nxt, c, araw[c], xr[c]);
-          if (!(probe & 16u)) araw[c] = anc_load(ahd, c);
-          FUSED_STAMP(2);
+          rows_load(nxt, c, araw[c], xr[c]);
+          araw[c] = anc_load(ahd, c);
 #pragma unroll
           for (int j = 0; j < DP; ++j) {
             if ((uint32_t)j < dx) {
@@ -477,10 +440,8 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
               xx[j] = 0.0f;
             }
           }
-          FUSED_STAMP(3);
           float locg[DP];
           chain(wg_a, trow + 32, dy, xx, locg);
-          FUSED_STAMP(4);
 #pragma unroll
           for (int v = 0; v < KS; ++v) {
             const fz4 y4 = *reinterpret_cast<const fz4 *>(trow + 48 + 4 * v);
@@ -495,11 +456,6 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
 #pragma unroll
           for (int j = 0; j < DP; ++j)
             if ((uint32_t)j < dx) scr_q[ln * dx + j] = xx[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < XN; ++j) qp += xin[j];
-          if (!(probe & 8u)) rows_load(nxt, c, araw[c], xr[c]);
-          if (!(probe & 16u)) araw[c] = anc_load(ahd, c);
         }
         if (live) {
           const float lp = (-qp) / two_var_p - const_p;
@@ -507,8 +463,7 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
           const float lq = (-qq) / two_var_q - const_q;
           out_lw[cur.nf + rl] = (lp + lg) - lq;
         }
-        FUSED_STAMP(5);
-        if (!(probe & 4u)) {
+        {
           const uint32_t rows = cur.count > 64u * c ? min(cur.count - 64u * c, 64u) : 0u;
           const uint32_t words = rows * dx;
           float *run = out_x + (size_t)(cur.nf + 64u * c) * dx;
@@ -530,12 +485,8 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
       //      dependent products of each map would wait out the accumulator latency) ---------------------------------
       // the chunk's rows (lane = particle) -> scr_p, end to end; back as the matrix operand B[k = 4 s + g][particle n]
       // of its four tiles (a wavefront's LDS accesses execute in order)
-      float probe_keep = 0.0f;
       float bx[4][KS];
-      if (probe & 2u) {
-#pragma unroll
-        for (int j = 0; j < XN; ++j) probe_keep += xr[c][j];
-      } else {
+      {
 #pragma unroll
         for (int j = 0; j < XN; ++j)
           if ((uint32_t)j < dx) scr_p[ln * dx + j] = xr[c][j];
@@ -549,12 +500,10 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
           }
       }
       // ---- the next item's rows into the registers just emptied; then the item after's ancestors ----------------
-      if (!(probe & 8u)) rows_load(nxt, c, araw[c], xr[c]);
-      if (!(probe & 16u)) araw[c] = anc_load(ahd, c);
-      FUSED_STAMP(1);
+      rows_load(nxt, c, araw[c], xr[c]);
+      araw[c] = anc_load(ahd, c);
 #pragma unroll
       for (int pair = 0; pair < 2; ++pair) {
-        if (probe & 2u) break;
         fz4 dq4[2], dp4[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -581,7 +530,6 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
           }
         }
       }
-      FUSED_STAMP(2);
       // ---- lane = particle: draw, residuals, quadratic chains (ascending j); x_t's rows, end to end, go into the
       //      scratch the proposal's locations came from (a wavefront's LDS accesses execute in order: every lane
       //      has read its locations before any row is overwritten) ------------------------------------------------
@@ -589,8 +537,8 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
       const uint32_t rr = lane_row(cur, c);
       const bool live = rl < cur.count;
       const uint32_t relL = (cur.k0 + rr) >= K ? 1u : 0u;
-      float xx[DP], qp = probe_keep, qq = 0.0f;
-      if (!(probe & 2u)) {
+      float xx[DP], qp = 0.0f, qq = 0.0f;
+      {
         fz4 q4[KS], p4[KS];
 #pragma unroll
         for (int v = 0; v < KS; ++v) {
@@ -613,9 +561,8 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         for (int j = 0; j < DP; ++j)
           if ((uint32_t)j < dx) scr_q[ln * dx + j] = xx[j];
       }
-      FUSED_STAMP(3);
       // ---- emission locations: operand B from those rows; the four tiles' chains interleaved ----------------------
-      if (!(probe & (2u | 32u))) {
+      {
         fz4 dg4[4];
         float bg[4][KS];
 #pragma unroll
@@ -638,9 +585,8 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
           for (int t = 0; t < 4; ++t) *reinterpret_cast<fz4 *>(scr_p + (16u * t + n) * RS + 4u * g) = dg4[t];
         }
       }
-      FUSED_STAMP(4);
       float qg = 0.0f;
-      if (!(probe & (2u | 32u))) {
+      {
 #pragma unroll
         for (int v = 0; v < KS; ++v) {
           const fz4 g4 = *reinterpret_cast<const fz4 *>(scr_p + ln * RS + 4 * v);
@@ -660,9 +606,8 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
         const float lq = (-qq) / two_var_q - const_q;
         out_lw[cur.nf + rl] = (lp + lg) - lq;
       }
-      FUSED_STAMP(5);
       // ---- the chunk's rows of x_t leave as one contiguous run ----------------------------------------------------
-      if (!(probe & 4u)) {
+      {
         const uint32_t rows = cur.count > 64u * c ? min(cur.count - 64u * c, 64u) : 0u;
         const uint32_t words = rows * dx;
         float *run = out_x + (size_t)(cur.nf + 64u * c) * dx;
@@ -682,16 +627,12 @@ __global__ __launch_bounds__(fused_threads<SCALARW>(), 4) void affine_propagate_
     }
     const FusedWin far = window(min(item + 3 * stride, last_item), w);
     publish(it + 3u, far, w);
-    FUSED_STAMP(6);
     lg_lds_barrier();     // hand-over: the other half of the buffers now holds the next item's noise and table
-    FUSED_STAMP(7);
     slot ^= 1u;
     cur = nxt;
     nxt = ahd;
     ahd = far;
-    FUSED_STAMP(8);
   }
-  FUSED_STAMP_FLUSH(0);
   if (bad != 0u) raise_flag(flags, AESMC_FLAG_INDEX_OUT_OF_RANGE);
 #endif
 }
@@ -760,10 +701,6 @@ int launch_affine_propagate_fused(const void *xsrc, const int64_t *anc_idx, cons
   // extents above 12: the first form is faster (rows of 16 values put a wavefront's noise reads on two LDS banks
   // here: 371 against 337 us at B=1024 K=4096 d=16, profiles/r04_k16bench_sweep.txt)
   if (ks > 3) return AESMC_ERR_UNSUPPORTED;
-#ifdef AESMC_K16_PROBES      /* timing experiments only (AESMC_HIPCC_FLAGS=-DAESMC_K16_PROBES): a probed launch's OUTPUT IS WRONG */
-  { const char *v = measurement_knob("AESMC_K16_PROBE"); plan.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
-  { const char *v = measurement_knob("AESMC_K16_STAMPS"); plan.stamps = v != nullptr ? reinterpret_cast<uint64_t *>(strtoull(v, nullptr, 10)) : nullptr; }
-#endif
   const uint32_t rs = ks == 1 ? 4 : (ks <= 3 ? 12 : 20);
   const size_t lds = sizeof(float) * (2 * (size_t)kTabF + 2 * (size_t)plan.tile_f + 4 * 2 * 64 * (size_t)rs + 4 * 16);
   if (lds > kLgLdsLimit) return AESMC_ERR_UNSUPPORTED;

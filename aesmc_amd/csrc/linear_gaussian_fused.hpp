@@ -20,10 +20,6 @@ struct FusedPlan {
   uint32_t blocks, items;
   uint32_t blocks_mul, dx_mul, K_mul;      // floor(2^32 / divisor)
   uint32_t tile_f;      // floats per noise tile
-  uint64_t *stamps;     // probe builds: [workgroup][2 roles][16] cycle sums per phase (AESMC_K16_STAMPS = device address), or null
-  uint32_t probe;       // 0 in a product build; with -DAESMC_K16_PROBES and AESMC_K16_PROBE in the environment, bits that SKIP
-                        // parts of the launch (timing only: the output is wrong): 1 the draws, 2 the particle role's arithmetic,
-                        // 4 x_t's stores, 8 the row loads, 16 the ancestor loads, 32 the emission part
 };
 
 // v / d for d >= 2 with mul = floor(2^32 / d): the estimate is the quotient or one less
@@ -252,8 +248,6 @@ static inline int fused_make_plan(FusedPlan &plan, int64_t B, int64_t K, int64_t
   plan.dx_mul = (uint32_t)((1ull << 32) / (uint64_t)dx);
   plan.K_mul = (uint32_t)((1ull << 32) / (uint64_t)K);
   plan.tile_f = (uint32_t)((4 * kRunP * dx + 4 + 3) & ~3ull);      // + the spare word unplaced normals go to
-  plan.probe = 0;
-  plan.stamps = nullptr;
   return AESMC_OK;
 }
 

@@ -23,8 +23,6 @@
 namespace aesmc {
 
 struct LgNoisePlan {
-  int32_t probe;        // 0 in a product build; with -DAESMC_K16_PROBES and AESMC_K16_PROBE in the environment: 1 = the noise role
-                        // draws nothing, 2 = the particle role skips its arithmetic, 3 = both (timing only: the output is wrong)
   uint64_t numel;       // B K d
   uint64_t magic;       // ceil(2^40 / d): (v * magic) >> 40 == v / d for v < 2^32
   uint32_t L;           // thread ids per block (elements per window): 256 S - (d - 1)
@@ -148,9 +146,7 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       if (j >= it.tl + dx - 1) break;
       const uint64_t t = (uint64_t)it.t0 + j;
       float n4[4];
-      if (plan.probe & 1) {
-        n4[0] = n4[1] = n4[2] = n4[3] = 0.5f;
-      } else if (t < G) {
+      if (t < G) {
         const float4 n = philox_normal4(ps, (uint32_t)t, it.c);
         n4[0] = n.x; n4[1] = n.y; n4[2] = n.z; n4[3] = n.w;
       } else {      // past the last thread id: the elements belong to the next window's first thread ids
@@ -321,15 +317,6 @@ __global__ __launch_bounds__(kNoiseThreads, 4) void affine_propagate_noise_kerne
       const uint32_t k0 = first - (first / K) * K;
       trow[r] = ((seg[r] * kLgSegRows + ((k0 + rr) >= K ? 1u : 0u)) * 4) * DP;
     }
-    if (plan.probe & 2) {
-#pragma unroll
-      for (int r = 0; r < PPL; ++r)
-        if (live[r]) out_lw[n_of[r]] = tprev[at[r]] + tx[an[r]];
-      lg_lds_barrier();
-      slot ^= 1u;
-      cur = nxt;
-      continue;
-    }
     T locp[DP][PPL], locq[DP][PPL], locg[DP][PPL];
 #pragma unroll
     for (int r = 0; r < PPL; ++r)
@@ -497,12 +484,6 @@ static int launch_affine_propagate_noise(const void *xsrc, const int64_t *anc_id
   const uint32_t runp = (uint32_t)(kLgBlock * ppl / 4);
   if ((uint64_t)K < runp) return AESMC_ERR_UNSUPPORTED;        // a run of particles may span two batch rows, not more
   LgNoisePlan plan;
-#ifdef AESMC_K16_PROBES      /* timing experiments only (build with AESMC_HIPCC_FLAGS=-DAESMC_K16_PROBES): a probed launch's OUTPUT IS WRONG */
-  static const int probe = [] { const char *v = measurement_knob("AESMC_K16_PROBE"); return v != nullptr ? atoi(v) : 0; }();
-  plan.probe = probe;
-#else
-  plan.probe = 0;
-#endif
   plan.numel = numel;
   plan.magic = ((1ull << 40) + (uint64_t)dx - 1) / (uint64_t)dx;
   plan.small_magic = (uint32_t)(((1u << 20) + (uint32_t)dx - 1) / (uint32_t)dx);

@@ -237,13 +237,7 @@ struct SbArgs {
   int64_t N, tiles;
   uint32_t K, tpr, tpr_mul;      // tiles per batch row (K / 256) and floor(2^32 / tpr)
   int32_t row_terms, want_sq, has_lse, has_glw, carry_records;
-  uint32_t probe;      // timing experiments only (-DAESMC_K14_PROBES + AESMC_K14_PROBE): a probed launch's OUTPUT IS WRONG
 };
-#ifdef AESMC_K14_PROBES
-#define SB_PROBE(bit) ((probe & (bit)) != 0u)
-#else
-#define SB_PROBE(bit) false
-#endif
 typedef const SbArgs __attribute__((address_space(4))) sb_cargs;
 
 // PAIRED: the location chains advance two outputs per instruction too (weights from the interleaved pairs the host's
@@ -279,8 +273,6 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
   float scale_acc[3] = {0.0f, 0.0f, 0.0f};
   const uint32_t step = gridDim.x;
   int bad = 0;
-  const uint32_t probe = SB_A()->probe;
-  (void)probe;
 
   // ---- what waits in registers for the NEXT tile ----------------------------------------------------------------
   float xp_n[D], xt_n[D], lw_n = 0.0f, glw_n = 0.0f;
@@ -391,7 +383,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
     {
       sb_cargs *A = SB_A();
       float *gxprev = A->gxprev;
-      if (old_tile != 0xffffffffu && gxprev != nullptr && !SB_PROBE(32u)) sb_store_row(gxprev + ((uint64_t)old_tile * kLgBlock + tid) * D, g_old);
+      if (old_tile != 0xffffffffu && gxprev != nullptr) sb_store_row(gxprev + ((uint64_t)old_tile * kLgBlock + tid) * D, g_old);
       b = sb_row_of(tile, A->tpr, A->tpr_mul);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
@@ -412,7 +404,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
         for (int j = 0; j < D; ++j) w[j] = 0.0f;
       }
     }
-    if (FOLDS && !SB_PROBE(1u)) {
+    if (FOLDS) {
       const float *child_rows = SB_A()->child_rows;
       uint32_t lo, hi;
       child_range(tile, rb_c, re_c, lo, hi);
@@ -485,7 +477,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
           re_c = re_n;
           if (after < tiles) raw_load(after, rb_n, re_n);
         }
-        if (!SB_PROBE(64u)) rows_prefetch(next, anc_n);
+        rows_prefetch(next, anc_n);
         if constexpr (GATHER) {
           if (after < tiles) anc_n = anc_load(after);
         }
@@ -572,8 +564,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
     // ---- emission term: u = g (y - loc_g) / s_g^2;  w += C^T u ----------------------------------------------------------
     {
       sb_cargs *A = SB_A();
-      if (!SB_PROBE(2u)) chain(A->wg, 1, A->offg, A->offg_sb, xt, u);
-      else for (int j = 0; j < D; ++j) u[j] = xt[j];
+      chain(A->wg, 1, A->offg, A->offg_sb, xt, u);
       sb_cfloat *yrow = (sb_cfloat *)A->y + (int64_t)b * A->y_sb;
       float q = 0.0f;
       const float scaled = g * inv_var_g;
@@ -584,22 +575,20 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
         u[j] = scaled * diff;
       }
       scale_acc[1] += g * (q * inv_var_g * inv_s_g - (float)D * inv_s_g);
-      if (!SB_PROBE(16u)) {
+      {
         sb_lds_put(tu + lane * D, u);
         sb_lds_put(tx + lane * D, xt);
       }
       lg_wave_fence();
-      if (!SB_PROBE(4u)) adjoint(A->wg, u, w);
-      else for (int j = 0; j < D; ++j) w[j] += u[j];
-      if (!SB_PROBE(8u)) sb_outer<D>(tu, tx, ones, lane, acc_c);
+      adjoint(A->wg, u, w);
+      sb_outer<D>(tu, tx, ones, lane, acc_c);
       lg_flush_column_sums<float>(acc_c, slot + 64, (A->row_terms & 2) != 0);
       lg_wave_fence();
     }
     // ---- transition term: u = g (x - loc_p) / s_p^2;  w -= u ------------------------------------------------------------
     {
       sb_cargs *A = SB_A();
-      if (!SB_PROBE(2u)) chain(A->wp, 0, A->offp, A->offp_sb, xp, u);
-      else for (int j = 0; j < D; ++j) u[j] = xp[j];
+      chain(A->wp, 0, A->offp, A->offp_sb, xp, u);
       float q = 0.0f;
       const float scaled = g * inv_var_p;
 #pragma unroll
@@ -610,14 +599,14 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
         w[j] = w[j] - u[j];
       }
       scale_acc[0] += g * (q * inv_var_p * inv_s_p - (float)D * inv_s_p);
-      if (!SB_PROBE(16u)) {
+      {
         sb_lds_put(tu + lane * D, u);
         sb_lds_put(tx + lane * D, xp);
       }
       lg_wave_fence();
-      if (A->gxprev != nullptr && !SB_PROBE(4u)) adjoint(A->wp, u, gprev);
+      if (A->gxprev != nullptr) adjoint(A->wp, u, gprev);
       else for (int j = 0; j < D; ++j) gprev[j] += u[j];
-      if (!SB_PROBE(8u)) sb_outer<D>(tu, tx, ones, lane, acc_a);
+      sb_outer<D>(tu, tx, ones, lane, acc_a);
       lg_flush_column_sums<float>(acc_a, slot, (A->row_terms & 1) != 0);
       lg_wave_fence();
     }
@@ -625,8 +614,7 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
     {
       sb_cargs *A = SB_A();
       if (A->want_sq) {
-        if (!SB_PROBE(2u)) chain(A->wq, 2, A->offq, A->offq_sb, xp, u);
-        else for (int j = 0; j < D; ++j) u[j] = xp[j];
+        chain(A->wq, 2, A->offq, A->offq_sb, xp, u);
         float dot = 0.0f;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -635,11 +623,11 @@ __global__ __launch_bounds__(kLgBlock, Sb<D>::kPerCu) void affine_step_backward_
         }
         scale_acc[2] += g * ((float)D * inv_s_q) + dot * inv_s_q;
       }
-      if (!SB_PROBE(16u)) sb_lds_put(tu + lane * D, w);
+      sb_lds_put(tu + lane * D, w);
       lg_wave_fence();
-      if (A->gxprev != nullptr && !SB_PROBE(4u)) adjoint(A->wq, w, gprev);
+      if (A->gxprev != nullptr) adjoint(A->wq, w, gprev);
       else for (int j = 0; j < D; ++j) gprev[j] += w[j];
-      if (!SB_PROBE(8u)) sb_outer<D>(tu, tx, ones, lane, acc_q);
+      sb_outer<D>(tu, tx, ones, lane, acc_q);
       const int row_terms = A->rows != nullptr ? A->row_terms : 0;
       lg_flush_column_sums<float>(acc_q, slot + 128, (row_terms & 4) != 0);
       lg_wave_fence();
@@ -800,9 +788,6 @@ int launch_affine_step_backward_rows(const float *xprev, const float *x, const f
   a.row_terms = out.rows != nullptr ? out.row_terms : 0; a.want_sq = out.want_scale_q;
   a.has_lse = grad_lse != nullptr ? 1 : 0; a.has_glw = grad_lw != nullptr ? 1 : 0;
   a.carry_records = out.carry != nullptr ? out.carry_records : 0;
-#ifdef AESMC_K14_PROBES
-  { const char *v = measurement_knob("AESMC_K14_PROBE"); a.probe = v != nullptr ? (uint32_t)atoi(v) : 0u; }
-#endif
   // the chains' weights as interleaved pairs, written into the workspace's tail by a small launch in front of this one (the
   // weights may have been stepped since the last call; inside a hipGraph capture the rebuild is captured with it)
   const bool paired = affine_step_backward_rows_pairs() && out.pairs != nullptr;

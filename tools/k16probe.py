@@ -1,5 +1,11 @@
 """Times the fused propagation launch (K16) with parts of it switched off (a build with -DAESMC_K16_PROBES; the probed
-launches' OUTPUT IS WRONG): which part of the launch the time belongs to.  hipGraph-timed on cycled operand sets."""
+launches' OUTPUT IS WRONG): which part of the launch the time belongs to.  hipGraph-timed on cycled operand sets.
+NOTE (round 6): the probe / stamp code this script drives was removed from the product translation units (VERDICT r05,
+hygiene).  The instrumented kernels are the tree at commit 549e68a: to repeat the experiment, check that commit's
+aesmc_amd/csrc/ out into tools/exp/ (git-ignored), build it with AESMC_HIPCC_FLAGS=-DAESMC_K16_PROBES (or -DAESMC_K14_PROBES)
+and AESMC_PROBE_BUILD=1, and point the loader at that library.  The results it produced are under profiles/ (r04_k16_stamps.txt,
+r04_k14_probes.txt, r05_pmc_k14_c4.txt, ...).
+"""
 import os
 os.environ.setdefault("AESMC_MEASUREMENT_KNOBS", "1")      # the library reads AESMC_* knobs only beside this
 import sys
