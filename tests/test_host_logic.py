@@ -1236,3 +1236,45 @@ def test_measurement_knobs_are_read_only_beside_their_switch(monkeypatch):
     assert settings.knob("AESMC_K16_PAIRS", "1") == "1"
     monkeypatch.setenv("AESMC_MEASUREMENT_KNOBS", "1")
     assert settings.knob("AESMC_K16_PAIRS", "1") == "0"
+
+
+def test_the_proposal_net_operator_and_its_backward_on_the_oracle_backend(oracle_backend):
+    """BASELINE.json's nonlinear model with `fused=True` — the proposal net through `linear_gaussian.particle_mlp`
+    (`_ops._ParticleMlp`: K13 forward, K13b backward; here the C oracle and float64 autograd behind the same provider
+    interface) — against the same model with PyTorch modules: float64 loss and every gradient.  Holds the autograd wiring
+    (which gradient goes to which of x, W1, the per-row offset, W2, b2; the shared-offset sum) without a GPU."""
+    from aesmc_amd.testing.models import NonlinearSsm
+    from aesmc_amd import _kernels
+    provider = _kernels.get()
+    calls = {"forward": 0, "backward": 0}
+    forward, backward = provider.particle_mlp, provider.particle_mlp_backward
+
+    def spy_forward(*args, **kwargs):
+        calls["forward"] += 1
+        return forward(*args, **kwargs)
+
+    def spy_backward(*args, **kwargs):
+        calls["backward"] += 1
+        return backward(*args, **kwargs)
+    results = []
+    for fused in (False, True):
+        model = NonlinearSsm(3, hidden=12, dtype=torch.float64, fused=fused)
+        observations = model.simulate(4, 3, seed=2)
+        torch.manual_seed(9)
+        np.random.seed(9)
+        provider.particle_mlp, provider.particle_mlp_backward = spy_forward, spy_backward
+        try:
+            loss = losses.get_loss(observations, 24, "aesmc", model.initial, model.transition, model.emission,
+                                   model.proposal)
+            loss.backward()
+        finally:
+            del provider.particle_mlp, provider.particle_mlp_backward
+        results.append((loss.detach(), {name: p.grad.clone() for name, p in model.named_parameters()
+                                        if p.grad is not None}))
+    assert calls == {"forward": 3, "backward": 3}, calls
+    (loss_a, grads_a), (loss_b, grads_b) = results
+    assert abs(float(loss_a - loss_b)) <= 1e-12 * max(1.0, abs(float(loss_a)))
+    assert sorted(grads_a) == sorted(grads_b)
+    for name in grads_a:
+        scale = max(float(grads_a[name].abs().max()), 1e-30)
+        assert float((grads_a[name] - grads_b[name]).abs().max()) <= 1e-9 * scale, name
