@@ -474,3 +474,37 @@ def test_back_to_back_replays_each_read_their_own_generator_offset(hip_device, a
     torch.cuda.synchronize()
     assert [int(s[1]) for s in seen] == before
     assert len(set(before)) == len(before)          # and every replay advanced the generator
+
+
+@pytest.mark.parametrize("kind", ["wide24", "wide192", "nonlinear_fused"])
+def test_round6_kernels_inside_a_captured_loss_and_backward(hip_device, kind):
+    """The kernels added in round 6 inside `GraphedLoss(backward=True)`: K17g / K18g (rows of 24 and of 192 values — the
+    chunked form — with their recomputing backward and its workspace allocations) and K13 / K13b (the proposal net of the
+    nonlinear model, its records and the binder's sums).  The capture verifies itself (4 replays against eager
+    evaluations on the same draws); a seeded replay afterwards equals the seeded eager evaluation."""
+    if kind == "nonlinear_fused":
+        model = models.NonlinearSsm(6, hidden=32, seed=0, dtype=torch.float32, validate_args=False, fused=True).to(hip_device)
+        B, K, T = 4, 256, 4
+    else:
+        dim = 24 if kind == "wide24" else 192
+        model = models.LgssmNd(dim, seed=0, dtype=torch.float32, validate_args=False, affine=True,
+                               emission_scale=0.5).tune_proposal().to(hip_device)
+        B, K, T = 3, 96, 4
+    observations = model.simulate(T, B, seed=1)
+    parts = (model.initial, model.transition, model.emission, model.proposal)
+    seed(13)
+    eager_loss = losses.get_loss(observations, K, "aesmc", *parts)
+    eager_loss.backward()
+    eager = eager_loss.detach().clone()
+    del eager_loss
+    eager_grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    graphed = graphs.GraphedLoss(observations, K, "aesmc", *parts, backward=True, verify_replays=4)
+    seed(13)
+    loss = graphed()
+    torch.testing.assert_close(loss, eager, rtol=2e-6, atol=2e-6)
+    for name, p in model.named_parameters():
+        if name in eager_grads:
+            want = eager_grads[name]
+            scale = float(want.abs().max()) + 1e-30
+            assert float((p.grad - want).abs().max()) <= 1e-4 * scale, name
