@@ -451,8 +451,11 @@ def particle_mlp(x, weight1, offset1, weight2, bias2=None):
     if isinstance(x, LazyParticles):
         x = x.materialise()
     k = _kernels.get()
+    if k.name == "hip" and not (torch.is_tensor(x) and x.is_cuda):
+        raise RuntimeError("aesmc_amd: particle_mlp operand lives on '{}'; this package computes only on a "
+                           "HIP device (MI355X) and has no CPU fallback.".format(getattr(x, "device", None)))
     if not k.particle_mlp_covers(x, weight1, offset1, weight2, bias2):
-        return _mlp_reference(x, weight1, offset1, weight2, bias2)
+        return _mlp_reference(x, weight1, offset1, weight2, bias2)      # (other extents: PyTorch's operators, on the device)
     tensors = (x, weight1, offset1, weight2, bias2)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         try:

@@ -75,6 +75,28 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.aesmc_affine_backward_workspace_bytes(0, 0, 0) == 1024 * 4 * 256 * 4 + pairs
     assert lib.aesmc_affine_backward_workspace_bytes(1, 2, 300) == (1024 * 4 * 256 + 3 * 3 * 8 * 16) * 8 + pairs
     assert lib.aesmc_particle_affine_backward(0, 16, 32, ctypes.byref(amap), None, 48, None, None, 0, 1, 1, None) == 1
+    # the matrix-core step's extents (0.5.0) and its workspace by width
+    assert (lib.aesmc_affine_wide_dim(), lib.aesmc_affine_wide_min_dim(), lib.aesmc_affine_wide_max_dim()) == (128, 20, 256)
+    assert lib.aesmc_affine_wide_workspace_bytes_for(2, 64, 128, 128) == 2 * 64 * 3 * 4        # two draw sums + one emission sum
+    assert lib.aesmc_affine_wide_workspace_bytes_for(2, 64, 256, 256) == 2 * 64 * (2 * 4 + 2) * 4      # four + two chunks
+    assert lib.aesmc_affine_wide_workspace_bytes_for(2, 64, 300, 16) == 0                       # beyond the widest row
+    # the proposal net (K13 / K13b): NULL operands, a hidden layer wider than 64, sixteen inputs in the backward
+    assert lib.aesmc_particle_mlp_max_hidden() == 64
+    hidden = _lib.AffineMap(16, 4, 1, 0, 0, 32, 4)        # [32, 4]
+    output = _lib.AffineMap(16, 32, 1, 0, 0, 4, 32)       # [4, 32]
+    assert lib.aesmc_particle_mlp(0, None, ctypes.byref(hidden), ctypes.byref(output), 32, 1, 256, None) == 1
+    assert lib.aesmc_particle_mlp(0, 16, ctypes.byref(hidden), ctypes.byref(output), 16, 1, 256, None) == 1      # out aliases x
+    too_wide = _lib.AffineMap(16, 4, 1, 0, 0, 65, 4)
+    assert lib.aesmc_particle_mlp(0, 16, ctypes.byref(too_wide), ctypes.byref(output), 32, 1, 256, None) == 2
+    assert lib.aesmc_particle_mlp(0, 16, ctypes.byref(hidden), ctypes.byref(output), 32, 0, 256, None) == 0      # B == 0: no-op
+    assert lib.aesmc_particle_mlp_backward_records(4, 300) == 0 and lib.aesmc_particle_mlp_backward_records(4, 512) > 0
+    assert lib.aesmc_particle_mlp_backward(0, 16, None, ctypes.byref(hidden), ctypes.byref(output), None, None, None, None,
+                                           1, 256, None) == 1
+    assert lib.aesmc_particle_mlp_backward(0, 16, 32, ctypes.byref(hidden), ctypes.byref(output), None, None, None, None,
+                                           1, 300, None) == 2                                    # K not a multiple of 256
+    sixteen = _lib.AffineMap(16, 16, 1, 0, 0, 32, 16)
+    assert lib.aesmc_particle_mlp_backward(0, 16, 32, ctypes.byref(sixteen), ctypes.byref(output), None, None, None, None,
+                                           1, 256, None) == 2                                    # no column left for the ones
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
@@ -92,9 +114,11 @@ def test_product_refuses_cpu_tensors_loudly():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         inference.infer("smc", model.simulate(3, 2), model.initial, model.transition, model.emission,
                         model.proposal, 4)
-    from aesmc_amd.linear_gaussian import AffineNormal, particle_affine
+    from aesmc_amd.linear_gaussian import AffineNormal, particle_affine, particle_mlp
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         particle_affine(torch.zeros(2, 3, 4), torch.zeros(4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        particle_mlp(torch.zeros(2, 256, 4), torch.zeros(8, 4), torch.zeros(8), torch.zeros(3, 8))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         AffineNormal(torch.zeros(2, 3, 4), torch.zeros(4, 4), torch.tensor(1.0)).loc
 
