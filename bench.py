@@ -246,6 +246,13 @@ def cpu_baseline(kind, dim, B, K, T, algorithm="aesmc", proposal="stock", model_
     while cost(b, t) / rate > per_run and t > 10:
         t -= 5
     run(b, t)                               # warm-up at the sample's own size (the first pass grows the allocator)
+    # the calibration piece is pessimistic (a handful of rows run less efficiently than dozens): grow the sample, in rows,
+    # to what a WARM evaluation's measured time says fits its share
+    dt, _ = run(b, t)
+    while 2.3 * dt <= per_run and 2 * b <= B:
+        b *= 2
+        run(b, t)
+        dt, _ = run(b, t)
     # ---- the thread sweep at the timed size
     sweep_seconds = {}
     for threads in candidates:
