@@ -152,7 +152,10 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
     block and keeps its rows) and torch differently per rank (independent proposal noise).
     `callback` sees the global loss.  `hip_graph=True` replays each rank's share of loss + backward
     as one captured hipGraph (`graphs.GraphedLoss(shard=...)`, its capture consuming no random numbers: the eager loop's
-    trajectory); the two collectives stay outside it."""
+    trajectory); the two collectives stay outside it.  A replay freezes whatever the callables computed on the
+    HOST at its value during the capture (`train.train`'s docstring: the frozen-callables contract); this loop does not
+    re-verify replays — every rank would have to reach the same verdict at the same step — so a model that changes
+    host-side state during training keeps `hip_graph=False` here."""
     from . import train as _train
     rank = dist.get_rank(group) if _group_is_live() else 0
     world_size = dist.get_world_size(group) if _group_is_live() else 1
