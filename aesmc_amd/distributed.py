@@ -143,7 +143,7 @@ def all_reduce_gradients(parameters, group=None):
 
 def train(dataloader, num_particles, algorithm, initial, transition, emission, proposal, num_epochs,
           num_iterations_per_epoch=None, optimizer_algorithm=torch.optim.Adam, optimizer_kwargs={},
-          callback=None, group=None, hip_graph=False, verify_replays=4):
+          callback=None, group=None, hip_graph=False, verify_replays=4, reverify_every=256):
     """`train.train` (aesmc/train.py:22-41) with one process per GPU: every rank's `dataloader`
     yields ITS OWN rows of each minibatch (equal counts on all ranks), the loss is the mean over
     the global batch (one all-reduce of sum log Z, `sharded_get_loss`) and the parameter gradients
@@ -152,21 +152,22 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
     block and keeps its rows) and torch differently per rank (independent proposal noise).
     `callback` sees the global loss.  `hip_graph=True` replays each rank's share of loss + backward
     as one captured hipGraph (`graphs.GraphedLoss(shard=...)`, its capture consuming no random numbers: the eager loop's
-    trajectory); the two collectives stay outside it.  A replay freezes whatever the callables computed on the
-    HOST at its value during the capture (`train.train`'s docstring: the frozen-callables contract); this loop does not
-    re-verify replays — every rank would have to reach the same verdict at the same step — so a model that changes
-    host-side state during training keeps `hip_graph=False` here."""
+    trajectory); the two collectives stay outside it.  A replay freezes whatever the callables computed on the HOST at its
+    value during the capture (`train.train`'s docstring: the frozen-callables contract): every `reverify_every`-th replay
+    is also evaluated eagerly on the same rows with the same draws and compared — the ranks agree on the verdict (one
+    all-reduce) — and on a mismatch every rank drops its graph with a RuntimeWarning and the loop is the eager sharded
+    loop from that step on."""
     from . import train as _train
     rank = dist.get_rank(group) if _group_is_live() else 0
     world_size = dist.get_world_size(group) if _group_is_live() else 1
     model_parts = (initial, transition, emission, proposal)
     parameters = list(_train.get_chained_params(*model_parts))
     optimizer = optimizer_algorithm(parameters, **optimizer_kwargs)
-    if hip_graph:
-        from . import graphs
-        graphed = None
-        for epoch, iteration, observations in _train._minibatches(dataloader, num_epochs,
-                                                                  num_iterations_per_epoch):
+    graphed = None
+    for epoch, iteration, observations in _train._minibatches(dataloader, num_epochs,
+                                                              num_iterations_per_epoch):
+        if hip_graph:
+            from . import graphs
             if graphed is None:
                 optimizer.zero_grad(set_to_none=True)
                 shard = (observations[0].size(0) * world_size, rank, world_size)
@@ -174,18 +175,22 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
                                              backward=True, shard=shard, group=group, check_flags=False,
                                              guard_gradients=True, verify_replays=verify_replays,
                                              preserve_random_state=True)
-            loss = graphed(observations)            # local replay + the all-reduce of the loss
+            problems = []
+            if reverify_every and (graphed.replays + 1) % reverify_every == 0:
+                problems, loss = _train._reverified_step(graphed, observations)      # (the same verdict on every rank)
+            else:
+                loss = graphed(observations)        # local replay + the all-reduce of the loss
             all_reduce_gradients(parameters, group=group)
             optimizer.step()
-            if graphed.replays % _train._FLAG_CHECK_INTERVAL == 0:
+            if problems:
+                graphed.check()
+                graphed, hip_graph = None, False    # (.grad held the eager evaluation's gradients for this step)
+                optimizer.zero_grad(set_to_none=True)
+            elif graphed.replays % _train._FLAG_CHECK_INTERVAL == 0:
                 graphed.check()
             if callback is not None:
                 callback(epoch, iteration, loss.clone(), *model_parts)
-        if graphed is not None:
-            graphed.check()
-        return
-    for epoch, iteration, observations in _train._minibatches(dataloader, num_epochs,
-                                                              num_iterations_per_epoch):
+            continue
         first = observations[0]
         first = next(iter(first.values())) if isinstance(first, dict) else first
         global_batch_size = first.size(0) * world_size
@@ -198,3 +203,5 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission, p
         optimizer.step()
         if callback is not None:
             callback(epoch, iteration, loss, *model_parts)
+    if graphed is not None:
+        graphed.check()

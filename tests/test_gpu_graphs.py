@@ -294,7 +294,9 @@ def test_capture_failure_explains_itself(hip_device):
 def test_distributed_train_on_a_one_rank_rccl_group_equals_single_process_training(hip_device):
     """distributed.train (eager and hip_graph) with a one-rank RCCL group takes the sharded code
     path — shard scope, all-reduce of the loss and of the flat gradient bucket — and must land on
-    exactly the parameters train.train reaches from the same seeds."""
+    exactly the parameters train.train reaches from the same seeds.  Every second replay is re-verified against an eager
+    evaluation (`reverify_every=2`: the ranks' agreed verdict, the random streams moved by exactly one evaluation): the
+    trajectory must not notice."""
     import torch.distributed as dist
     from aesmc_amd import distributed, train
     created = False
@@ -309,8 +311,8 @@ def test_distributed_train_on_a_one_rank_rccl_group_equals_single_process_traini
     try:
         results = {}
         for label, fn, kwargs in (("single", train.train, {}), ("sharded", distributed.train, {}),
-                                  ("single_graph", train.train, {"hip_graph": True}),
-                                  ("sharded_graph", distributed.train, {"hip_graph": True})):
+                                  ("single_graph", train.train, {"hip_graph": True, "reverify_every": 2}),
+                                  ("sharded_graph", distributed.train, {"hip_graph": True, "reverify_every": 2})):
             seed(0)
             truth = models.LgssmNd(2, seed=1, validate_args=False).to(hip_device)
             model = models.LgssmNd(2, seed=0, validate_args=False).to(hip_device)
