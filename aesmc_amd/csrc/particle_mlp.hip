@@ -7,7 +7,7 @@
 //
 // (the y_t columns of the first layer and its bias arrive as the per-row offset c1).  Through PyTorch this is a
 // concatenation, two GEMMs and a tanh with [B,K,H] round trips through HBM between them — 173 us of a 260 us timestep at
-// B = 128, K = 4096, d = 10, H = 64 (profiles/r06b_rocprof_c4nl.csv) — and, backward, two weight-gradient GEMMs that
+// B = 128, K = 4096, d = 10, H = 64 (profiles/r06b_rocprof_c4nl_before_k13.csv) — and, backward, two weight-gradient GEMMs that
 // contract over B K = 524 288 particles onto a handful of workgroups (hipBLASLt's default picks: 898 + 822 us).
 //
 //   K13   forward: the hidden layer lives in registers (one particle per lane, 16 hidden units at a time), both weight
