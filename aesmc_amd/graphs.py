@@ -379,6 +379,32 @@ class GraphedLoss:
                             p.grad.copy_(torch.where(healthy, p.grad, torch.zeros_like(p.grad)))
         return loss.detach()
 
+    def poll(self):
+        """The device status word WITHOUT a synchronisation: after each replay a 4-byte copy of the word into pinned host
+        memory is enqueued behind it (two slots, an event each); this call looks at the copies that have landed and, if one
+        of them is non-zero, does the synchronising `check()` — which raises what `inference.infer` would have raised.  A
+        flagged replay therefore surfaces one or two replays later instead of at the next `check()` (`train()` checks every
+        `_FLAG_CHECK_INTERVAL` replays), at the cost of one tiny copy per replay and no stall."""
+        probes = getattr(self, "_flag_probes", None)
+        if probes is None:
+            host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            probes = self._flag_probes = {"host": host, "events": [None, None], "turn": 0}
+        word = _kernels.get().flags(self.device)
+        for slot in (0, 1):
+            event = probes["events"][slot]
+            if event is not None and event.query():
+                probes["events"][slot] = None
+                if int(probes["host"][slot]) != 0:
+                    probes["events"] = [None, None]
+                    self.check()
+        slot = probes["turn"]
+        if probes["events"][slot] is None:      # (a copy still in flight keeps its slot: skip this replay's probe)
+            probes["host"][slot:slot + 1].copy_(word, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(self.device))
+            probes["events"][slot] = event
+            probes["turn"] = slot ^ 1
+
     def check(self):
         """Synchronising read of the device status word; raises what `inference.infer` would have
         raised for any replay since the last check (with check_flags=False call it yourself, e.g.

@@ -108,7 +108,9 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
     eager evaluation does, so a seeded run follows the eager loop's trajectory (to the rounding of identical kernels
     launched from a graph: the same bits in practice).  The fresh graph is checked against eager evaluations before it is
     used (`verify_replays` of them; 0 switches the check off).  While replaying, the device status word (NaN
-    log-weights, a degenerate row, ...) is read every `_FLAG_CHECK_INTERVAL` replays instead of every step; in between, the
+    log-weights, a degenerate row, ...) is read with a synchronisation every `_FLAG_CHECK_INTERVAL` replays only; in
+    between, a 4-byte asynchronous copy of the word follows every replay and is looked at when it has landed
+    (`GraphedLoss.poll`: a flagged replay raises one or two replays later, without a stall), and the
     captured backward zeroes the gradients of a flagged step on the device (`GraphedLoss(guard_gradients=True)`), so the
     optimiser steps taken before the FloatingPointError / RuntimeError surfaces do not poison the parameters (with a
     stateful optimiser they still decay its moments: restore a checkpoint if that matters)."""
@@ -175,6 +177,8 @@ def train(dataloader, num_particles, algorithm, initial, transition, emission,
             optimizer.step()
             if graphed.replays % _FLAG_CHECK_INTERVAL == 0:
                 graphed.check()
+            else:
+                graphed.poll()       # (no synchronisation: a flagged replay surfaces a replay or two later, not up to 31)
             if callback is not None:         # the graph's loss tensor is reused by the next replay
                 callback(epoch, iteration, loss.clone(), *model_parts)
             continue

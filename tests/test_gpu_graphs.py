@@ -510,3 +510,29 @@ def test_round6_kernels_inside_a_captured_loss_and_backward(hip_device, kind):
             want = eager_grads[name]
             scale = float(want.abs().max()) + 1e-30
             assert float((p.grad - want).abs().max()) <= 1e-4 * scale, name
+
+
+def test_a_flagged_replay_surfaces_within_a_few_replays_without_a_stall(hip_device):
+    """the captured training loop reads the device status word with a synchronisation every 32
+    replays only — a NaN minibatch used to surface up to 31 optimiser steps late.  `GraphedLoss.poll` looks at an
+    asynchronous 4-byte copy of the word after every replay: the FloatingPointError is raised within three replays of the
+    one that was flagged (and the flagged steps' gradients were zeroed on the device meanwhile)."""
+    from aesmc_amd import train
+    seed(0)
+    truth = models.LgssmNd(2, seed=1, validate_args=False).to(hip_device)
+    model = models.LgssmNd(2, seed=0, validate_args=False).to(hip_device)
+    loader = [truth.simulate(4, 16, seed=20 + i) for i in range(40)]
+    seen = []
+
+    def callback(epoch, iteration, loss, *parts):
+        seen.append(iteration)
+        if iteration == 4:
+            with torch.no_grad():
+                model.A.fill_(float("nan"))      # every later replay's log-weights are NaN
+    with pytest.raises(FloatingPointError):
+        train.train(loader, 32, "aesmc", model.initial, model.transition, model.emission, model.proposal, num_epochs=1,
+                    optimizer_algorithm=torch.optim.SGD, optimizer_kwargs={"lr": 1e-3}, callback=callback, hip_graph=True,
+                    reverify_every=0)
+    assert 4 < seen[-1] <= 8, seen      # (iteration 5 is the first flagged replay)
+    from aesmc_amd import inference
+    inference.check_device_status(hip_device)      # the word was cleared when it was raised
