@@ -1093,9 +1093,9 @@ class HipKernels:
 
     def affine_wide_covers(self, source, weight, offset=None, scale=None):
         """Host-only test of what K17 / K18 (rows of 128 values) and K17g / K18g (every other width) assume about one
-        location `offset + source @ weight.T`: source [B,K,din] float32 on the HIP device with din a multiple of 4 between
-        20 and 256, weight [dout,din] as an nn.Linear holds it with dout a multiple of 4 up to 256, offset None, [dout] or
-        [B,dout], scale (if given) one value.  (Maps of at most 16 x 16 are the item kernels': `affine_covers`.)"""
+        location `offset + source @ weight.T`: source [B,K,din] float32 on the HIP device with 17 <= din <= 256, weight
+        [dout,din] as an nn.Linear holds it with dout <= 256, offset None, [dout] or [B,dout], scale (if given) one value.
+        (Maps of at most 16 x 16 are the item kernels': `affine_covers`.)"""
         if not (torch.is_tensor(weight) and weight.dim() == 2 and weight.dtype == torch.float32 and weight.is_cuda):
             return False
         _, smallest, largest = self._wide_limits()
@@ -1104,14 +1104,13 @@ class HipKernels:
         if len(shape) != 3 or shape[2] != din or source.dtype != torch.float32 or source.device != weight.device or \
                 shape[0] * shape[1] == 0:
             return False
-        if din % 4 or dout % 4 or not (smallest <= din <= largest) or not (4 <= dout <= largest):
+        if not (smallest <= din <= largest) or not (1 <= dout <= largest):
             return False
-        if not weight.is_contiguous() or weight.data_ptr() % 16:
+        if not weight.is_contiguous():
             return False
         if offset is not None:
             if not torch.is_tensor(offset) or offset.dtype != torch.float32 or offset.device != weight.device or \
-                    tuple(offset.shape) not in ((dout,), (shape[0], dout)) or offset.stride(-1) != 1 or \
-                    offset.data_ptr() % 16 or (offset.dim() == 2 and offset.stride(0) % 4):
+                    tuple(offset.shape) not in ((dout,), (shape[0], dout)) or offset.stride(-1) != 1:
                 return False
         if scale is not None and not (torch.is_tensor(scale) and scale.numel() == 1 and scale.dtype == torch.float32 and
                                       scale.device == weight.device):
@@ -1119,7 +1118,7 @@ class HipKernels:
         return True
 
     def affine_propagate_wide(self, x_src, eps, y_rows, transition, emission, proposal, scales, out_x, ancestors=None):
-        """K17 + K18 (rows of 128 values) / K17g + K18g (any width that is a multiple of 4 from 20 to 256, dx != dy allowed,
+        """K17 + K18 (rows of 128 values) / K17g + K18g (any latent width from 17 to 256, any observation width up to 256,
         any K): a linear-Gaussian step on the fp32 matrix cores — the draw `loc_q(x_prev) + eps * s_q` into `out_x` (the C
         oracle's bits) and the step's log-weights [B,K] (its values to rounding), x_prev = x_src[b, ancestors[b,k]] when
         `ancestors` is given.
@@ -1131,7 +1130,7 @@ class HipKernels:
             return None
         B, K, dx = x_src.shape
         wide, smallest, largest = self._wide_limits()
-        if dx % 4 or not (smallest <= dx <= largest) or B * K == 0 or not x_src.is_cuda:
+        if not (smallest <= dx <= largest) or B * K == 0 or not x_src.is_cuda:
             return None
         # the observation as K18 reads it: float32 [B, dy] on the latents' device (a float64 observation — torch.from_numpy
         # data against a float32 model — would be read as float32 bytes: declined, PyTorch's promotion applies instead)
@@ -1139,7 +1138,7 @@ class HipKernels:
                 y_rows.dtype == torch.float32 and y_rows.device == x_src.device):
             return None
         dy = y_rows.size(1)
-        if dy % 4 or not (4 <= dy <= largest):
+        if not (1 <= dy <= largest):
             return None
         drawn = not torch.is_tensor(eps)      # an `_philox.NoiseStream`: the launch forms the noise itself
         if drawn:
@@ -1152,13 +1151,12 @@ class HipKernels:
         for (weight, offset), scale, shape in zip((transition, emission, proposal), scales, ((dx, dx), (dy, dx), (dx, dx))):
             # (what affine_wide_covers tests, for callers that did not ask it)
             if not (torch.is_tensor(weight) and tuple(weight.shape) == shape and weight.is_contiguous() and
-                    weight.data_ptr() % 16 == 0 and weight.dtype == torch.float32 and weight.device == x_src.device):
+                    weight.dtype == torch.float32 and weight.device == x_src.device):
                 return None
             if offset is not None and not (torch.is_tensor(offset) and offset.dtype == torch.float32 and
                                            offset.device == x_src.device and
-                                           tuple(offset.shape) in ((shape[0],), (B, shape[0])) and offset.stride(-1) == 1 and
-                                           offset.data_ptr() % 16 == 0 and not (offset.dim() == 2 and offset.stride(0) % 4)):
-                return None
+                                           tuple(offset.shape) in ((shape[0],), (B, shape[0])) and offset.stride(-1) == 1):
+                return None      # (rows / bases that are not 16-byte pieces: the launch moves them element by element)
             if not (torch.is_tensor(scale) and scale.numel() == 1 and scale.dtype == torch.float32 and
                     scale.device == x_src.device):
                 return None

@@ -20,6 +20,12 @@ HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "linear_gaussian
            os.path.join(CSRC, "linear_gaussian_backward.hpp"), os.path.join(CSRC, "linear_gaussian_wide_generic.hpp"),
            os.path.join(os.path.dirname(HERE), "include", "aesmc_hip.h")]
 ARCH = "gfx950"
+# per translation unit: the generic matrix-core step's product loops are 96 - 128 operand groups of eight v_mfma each, written
+# as ONE loop that must be unrolled in full (the accumulator tiles are register arrays indexed by the loop counter); the
+# compiler's default budget for `#pragma unroll` is a few instructions short of the largest instantiations — it then keeps
+# the loop and puts the tiles in scratch (784 bytes, five times slower).  The other sources keep the default budget.
+SOURCE_FLAGS = {"linear_gaussian_wide_generic_draw.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
+                "linear_gaussian_wide_generic_emit.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
 def _hipcc():
@@ -69,7 +75,7 @@ def build(force=False, verbose=True):
         src, obj = os.path.join(CSRC, source), os.path.join(objdir, source[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in _depends_on(src)):
             continue
-        cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+        cmd = [_hipcc()] + flags + SOURCE_FLAGS.get(source, []) + ["-c", src, "-o", obj]
         if verbose:
             print("[aesmc_amd.build]", " ".join(cmd), flush=True)
         jobs.append((cmd, subprocess.Popen(cmd)))

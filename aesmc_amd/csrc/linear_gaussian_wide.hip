@@ -374,14 +374,23 @@ static int wideg_propagate(const void *x_src, const int64_t *ancestors, const vo
                            hipStream_t s) {
   const int64_t dx = proposal->dout, dy = emission->dout;
   if (proposal->din != dx || transition->dout != dx || transition->din != dx || emission->din != dx) return AESMC_ERR_UNSUPPORTED;
-  if (dx < kWgMinDim || dx > kWgMaxDim || dy < 4 || dy > kWgMaxDim || (dx % 4) != 0 || (dy % 4) != 0) return AESMC_ERR_UNSUPPORTED;
+  if (dx < kWgMinDim || dx > kWgMaxDim || dy < 1 || dy > kWgMaxDim) return AESMC_ERR_UNSUPPORTED;
   if (eps == nullptr) return AESMC_ERR_UNSUPPORTED;      // the noise in the launch: the 128-wide kernels only (the caller fills it)
   const aesmc_affine_map *maps[3] = {transition, emission, proposal};
-  for (const aesmc_affine_map *m : maps) {
-    if (m->stride_in != 1 || m->stride_out != m->din || !aligned16(m->weight) ||
-        (m->offset != nullptr && (!aligned16(m->offset) || (m->offset_stride_b % 4) != 0)))
+  for (const aesmc_affine_map *m : maps) {      // weights as an nn.Linear holds them (dense rows)
+    if (m->stride_in != 1 || m->stride_out != m->din || (((uintptr_t)m->weight) & 3u) != 0 ||
+        (((uintptr_t)m->offset) & 3u) != 0)
       return AESMC_ERR_UNSUPPORTED;
   }
+  // pieces of four move as 16-byte accesses where rows, strides and bases allow it; element by element elsewhere
+  auto offset_vec = [](const aesmc_affine_map *m) {
+    return m->offset == nullptr || (aligned16(m->offset) && (m->offset_stride_b % 4) == 0);
+  };
+  const bool vec_x = (dx % 4) == 0;
+  const uint32_t vec_in = (vec_x && aligned16(transition->weight) && aligned16(proposal->weight) &&
+                           aligned16(emission->weight)) ? 1u : 0u;
+  const uint32_t vec_draw = (vec_x && offset_vec(transition) && offset_vec(proposal)) ? 1u : 0u;
+  const uint32_t vec_emit = ((dy % 4) == 0 && offset_vec(emission) && aligned16(y) && (y_stride_b % 4) == 0) ? 1u : 0u;
   const int64_t N = B * K;
   if (B >= (1ll << 31) || K >= (1ll << 31) || N >= (1ll << 31) / 2) return AESMC_ERR_UNSUPPORTED;
   if (ws_bytes < aesmc_affine_wide_workspace_bytes_for(B, K, dx, dy)) return AESMC_ERR_WORKSPACE;
@@ -401,6 +410,7 @@ static int wideg_propagate(const void *x_src, const int64_t *ancestors, const vo
   a.chunks_draw = wideg_chunks(dx, wideg_draw_chunk(dxp));
   a.chunks_emit = wideg_chunks(dy, wideg_emit_chunk(dy));
   a.sums_stride = std::max<uint32_t>(2u, wideg_record_floats(dx, dy));
+  a.vec_in = vec_in; a.vec_out = vec_draw;
   int status = wideg_launch_draw(a, dxp, ancestors != nullptr, s);
   if (status != AESMC_OK) return status;
   WideGArgs e = a;
@@ -408,7 +418,7 @@ static int wideg_propagate(const void *x_src, const int64_t *ancestors, const vo
   e.w[0] = static_cast<const float *>(emission->weight); e.w[1] = nullptr;
   e.off[0] = static_cast<const float *>(emission->offset); e.off[1] = nullptr;
   e.off_sb[0] = emission->offset_stride_b; e.off_sb[1] = 0;
-  e.dout = (uint32_t)dy;
+  e.dout = (uint32_t)dy; e.vec_out = vec_emit;
   return wideg_launch_emission(e, dxp, s);
 }
 
@@ -429,8 +439,7 @@ extern "C" int aesmc_affine_normal_propagate_wide(
   if (eps == nullptr && (threads <= 0 || (threads % 256) != 0 || threads > 0x7fffffffLL || (offset & 3u) != 0 ||
                          (((uintptr_t)rng_state) & 7u) != 0))
     return AESMC_ERR_INVALID_ARGUMENT;
-  if (out_x == x_src || (eps != nullptr && out_x == eps) || (((uintptr_t)ancestors) & 7u) != 0 || (((uintptr_t)y) & 15u) != 0 ||
-      (y_stride_b % 4) != 0)
+  if (out_x == x_src || (eps != nullptr && out_x == eps) || (((uintptr_t)ancestors) & 7u) != 0 || (((uintptr_t)y) & 3u) != 0)
     return AESMC_ERR_INVALID_ARGUMENT;
   const aesmc_affine_map *maps[3] = {transition, emission, proposal};
   bool exact = true;      // rows of exactly 128 values on both sides and whole tiles: the kernels of this file
@@ -438,7 +447,8 @@ extern "C" int aesmc_affine_normal_propagate_wide(
     if (m->weight == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
     exact = exact && m->dout == kWd && m->din == kWd;
   }
-  if (!exact || K % kWdTile != 0)      // any other width (20 .. 256, a multiple of 4, dx != dy allowed), any K
+  exact = exact && (((uintptr_t)y) & 15u) == 0 && (y_stride_b % 4) == 0;
+  if (!exact || K % kWdTile != 0)      // any other width (17 .. 256, dx != dy allowed), any K, any row alignment
     return wideg_propagate(x_src, ancestors, eps, y, y_stride_b, transition, emission, proposal, scale_p, scale_g, scale_q,
                            out_x, out_lw, ws, ws_bytes, flags, B, K, static_cast<hipStream_t>(stream));
   for (const aesmc_affine_map *m : maps) {

@@ -1,5 +1,5 @@
 // K17g / K18g: the matrix-core linear-Gaussian step of linear_gaussian_wide.hip (rows of exactly 128 values) for ANY row
-// width that is a multiple of 4 between 20 and 256, latent and observation widths free of each other (dx != dy), any K.
+// width from 17 to 256 (observations: 1 to 256), latent and observation widths free of each other (dx != dy), any K.
 // aesmc/state.py:61-183 is dimension-agnostic: before this file every width between the item kernels' 16 and the wide
 // kernels' 128 — and everything above 128 — took three library GEMMs, their offsets' broadcast adds, the draw and a
 // three-Normal log-weight kernel per timestep (17 passes over [B,K,d] tensors).
@@ -22,7 +22,10 @@
 //     maps resident, walks the tiles as before and leaves the chunk's partial sums per particle; x_{t-1} is read once per
 //     chunk (L2 / MALL absorb most of it: the chunks of a tile run side by side);
 //   * K not a multiple of 32: a batch row's last tile is masked — its missing particles load the row's last particle
-//     again and store nothing.
+//     again and store nothing;
+//   * widths that are not multiples of 4: a row is then not a whole number of 16-byte pieces, so the pieces of four (the
+//     noise in, x_t out, offsets, the observation, the weights' staging) are moved element by element with an element's own
+//     bounds test (`vec_in` / `vec_out`: wavefront-uniform switches; the matrix operands were dword loads all along).
 #pragma once
 #include "linear_gaussian.hpp"
 
@@ -52,7 +55,32 @@ struct WideGArgs {
   uint32_t chunks_draw;     // K17g's chunks (their 2 sums each lead a particle's record)
   uint32_t chunks_emit;     // K18g's chunks
   uint32_t dx;              // latent width (the constant of the two latent densities)
+  uint32_t vec_in;          // 1: din is a multiple of 4 and the weights are 16-byte aligned (rows staged in 16-byte pieces)
+  uint32_t vec_out;         // 1: dout, the offsets' / the observation's row strides are multiples of 4: pieces of four as such
 };
+
+// four consecutive values of a row of `limit` values starting at column `col`: one 16-byte piece, or element by element
+// (columns beyond the row read as zero)
+__device__ __forceinline__ wg_f4 wideg_load4(const float *row, uint32_t col, uint32_t limit, bool vec) {
+  wg_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (vec) {
+    if (col < limit) v = *reinterpret_cast<const wg_f4 *>(row + col);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col + r < limit) v[r] = row[col + r];
+  }
+  return v;
+}
+__device__ __forceinline__ void wideg_store4(float *row, uint32_t col, uint32_t limit, bool vec, const wg_f4 &v) {
+  if (vec) {
+    if (col < limit) *reinterpret_cast<wg_f4 *>(row + col) = v;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col + r < limit) row[col + r] = v[r];
+  }
+}
 
 // chunk `chunk`'s MC rows of NMAPS maps into LDS, zero-padded to DXP inputs; a row's inputs permuted — input 4 s + g at
 // g * (DXP / 4) + s — so that the four k-steps of a group come in one 16-byte read (linear_gaussian_wide.hip)
@@ -64,7 +92,7 @@ __device__ __forceinline__ void wideg_stage_weights(const WideGArgs &a, float *w
     for (uint32_t v = threadIdx.x; v < (uint32_t)(MC * G4); v += kWgThreads) {
       const uint32_t j = v / G4, s = v % G4, jr = chunk * MC + j;
       wg_f4 q = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (jr < a.dout && 4u * s < a.din) q = *reinterpret_cast<const wg_f4 *>(w + (size_t)jr * a.din + 4 * s);
+      if (jr < a.dout) q = wideg_load4(w + (size_t)jr * a.din, 4u * s, a.din, a.vec_in != 0u);
       float *row = wl + (size_t)m * MC * Row + j * Row;
 #pragma unroll
       for (int g = 0; g < 4; ++g) row[g * G4 + s] = q[g];
@@ -79,7 +107,7 @@ __device__ __forceinline__ void wideg_stage_weights(const WideGArgs &a, float *w
 template <int DXP, int MC, int NMAPS>
 __device__ __forceinline__ void wideg_products(const float *wl, uint32_t lane, float (&bx)[2][DXP / 4],
                                                wg_f4 (&acc)[NMAPS][MC / 16][2], const float *next0, const float *next1,
-                                               uint32_t mtiles, uint32_t kgroups, uint32_t nin4) {
+                                               uint32_t mtiles, uint32_t kgroups, uint32_t din) {
   constexpr int Row = DXP + 4, G4 = DXP / 4, MT = MC / 16, KG = DXP / 16;
   const uint32_t m = lane & 15u, g = lane >> 4;
   const float *wa = wl + m * Row + g * G4;
@@ -106,7 +134,7 @@ __device__ __forceinline__ void wideg_products(const float *wl, uint32_t lane, f
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const uint32_t s = 4 * sg + t;
-        const bool real = s < nin4;
+        const bool real = 4u * s + g < din;      // (input 4 s + g of the row)
         bx[0][s] = real ? next0[4 * s] : 0.0f;
         bx[1][s] = real ? next1[4 * s] : 0.0f;
       }
@@ -126,7 +154,7 @@ __device__ __forceinline__ void wideg_offsets(const WideGArgs &a, uint32_t b, ui
     for (int mt = 0; mt < MC / 16; ++mt) {
       wg_f4 o = {0.0f, 0.0f, 0.0f, 0.0f};
       const uint32_t col = chunk * MC + 16 * mt + 4 * g;
-      if (off != nullptr && col < a.dout) o = *reinterpret_cast<const wg_f4 *>(off + (int64_t)b * a.off_sb[map] + col);
+      if (off != nullptr) o = wideg_load4(off + (int64_t)b * a.off_sb[map], col, a.dout, a.vec_out != 0u);
       acc[map][mt][0] = o;
       acc[map][mt][1] = o;
     }
@@ -177,7 +205,8 @@ __global__ __launch_bounds__(kWgThreads) void affine_wideg_draw_kernel(WideGArgs
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t n = lane & 15u, g = lane >> 4;
   const float s_q = a.s_q[0];
-  const uint32_t K = a.K, din = a.din, nin4 = a.din / 4;
+  const uint32_t K = a.K, din = a.din;
+  const bool vec = a.vec_out != 0u;
   const uint32_t kgroups = (din + 15u) / 16u;
   const uint32_t rows_here = a.dout > chunk * MC ? a.dout - chunk * MC : 0u;      // real outputs in this chunk
   const uint32_t mtiles = (rows_here + 15u) / 16u < (uint32_t)(MC / 16) ? (rows_here + 15u) / 16u : (uint32_t)(MC / 16);
@@ -212,7 +241,7 @@ __global__ __launch_bounds__(kWgThreads) void affine_wideg_draw_kernel(WideGArgs
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int s = 0; s < DXP / 4; ++s) bx[nt][s] = (uint32_t)s < nin4 ? src0[nt][4 * s] : 0.0f;
+      for (int s = 0; s < DXP / 4; ++s) bx[nt][s] = 4u * s + g < din ? src0[nt][4 * s] : 0.0f;
   }
   for (; tile < tiles; tile += tile_stride) {
     uint32_t b, k0;
@@ -222,7 +251,7 @@ __global__ __launch_bounds__(kWgThreads) void affine_wideg_draw_kernel(WideGArgs
     rows_of(tile_next, src_next);
     wg_f4 acc[2][MC / 16][2];
     wideg_offsets<MC, 2>(a, b, g, chunk, acc);
-    wideg_products<DXP, MC, 2>(wl, lane, bx, acc, src_next[0], src_next[1], mtiles, kgroups, nin4);
+    wideg_products<DXP, MC, 2>(wl, lane, bx, acc, src_next[0], src_next[1], mtiles, kgroups, din);
     // ---- the draw and the two squared distances, outputs chunk * MC + 16 mt + 4 g + r of the lane's two particles ------
     float q_sum[2] = {0.0f, 0.0f}, p_sum[2] = {0.0f, 0.0f};
     int64_t part[2];
@@ -239,17 +268,19 @@ __global__ __launch_bounds__(kWgThreads) void affine_wideg_draw_kernel(WideGArgs
       if (col < a.dout) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const wg_f4 e = *reinterpret_cast<const wg_f4 *>(a.eps + part[nt] * a.dout + col);
+          const wg_f4 e = wideg_load4(a.eps + part[nt] * a.dout, col, a.dout, vec);
           wg_f4 x;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float noise = e[r] * s_q;
             x[r] = acc[0][mt][nt][r] + noise;
-            const float dq = x[r] - acc[0][mt][nt][r], dp = x[r] - acc[1][mt][nt][r];
-            q_sum[nt] = fma_t(dq, dq, q_sum[nt]);
-            p_sum[nt] = fma_t(dp, dp, p_sum[nt]);
+            if (vec || col + r < a.dout) {      // (a row that is not whole pieces of four: its last piece holds padding)
+              const float dq = x[r] - acc[0][mt][nt][r], dp = x[r] - acc[1][mt][nt][r];
+              q_sum[nt] = fma_t(dq, dq, q_sum[nt]);
+              p_sum[nt] = fma_t(dp, dp, p_sum[nt]);
+            }
           }
-          if (live[nt]) *reinterpret_cast<wg_f4 *>(a.out_x + part[nt] * a.dout + col) = x;
+          if (live[nt]) wideg_store4(a.out_x + part[nt] * a.dout, col, a.dout, vec, x);
         }
       }
     }
@@ -277,7 +308,8 @@ __global__ __launch_bounds__(kWgThreads) void affine_wideg_emission_kernel(WideG
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t n = lane & 15u, g = lane >> 4;
-  const uint32_t K = a.K, din = a.din, nin4 = a.din / 4;
+  const uint32_t K = a.K, din = a.din;
+  const bool vec = a.vec_out != 0u;
   const uint32_t kgroups = (din + 15u) / 16u;
   const uint32_t rows_here = a.dout > chunk * MC ? a.dout - chunk * MC : 0u;
   const uint32_t mtiles = (rows_here + 15u) / 16u < (uint32_t)(MC / 16) ? (rows_here + 15u) / 16u : (uint32_t)(MC / 16);
@@ -302,7 +334,7 @@ __global__ __launch_bounds__(kWgThreads) void affine_wideg_emission_kernel(WideG
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int s = 0; s < DXP / 4; ++s) bx[nt][s] = (uint32_t)s < nin4 ? src0[nt][4 * s] : 0.0f;
+      for (int s = 0; s < DXP / 4; ++s) bx[nt][s] = 4u * s + g < din ? src0[nt][4 * s] : 0.0f;
   }
   for (; tile < tiles; tile += tile_stride) {
     uint32_t b, k0;
@@ -312,19 +344,21 @@ __global__ __launch_bounds__(kWgThreads) void affine_wideg_emission_kernel(WideG
     rows_of(tile_next, src_next);
     wg_f4 acc[1][MC / 16][2];
     wideg_offsets<MC, 1>(a, b, g, chunk, acc);
-    wideg_products<DXP, MC, 1>(wl, lane, bx, acc, src_next[0], src_next[1], mtiles, kgroups, nin4);
+    wideg_products<DXP, MC, 1>(wl, lane, bx, acc, src_next[0], src_next[1], mtiles, kgroups, din);
     float g_sum[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int mt = 0; mt < MC / 16; ++mt) {
       const uint32_t col = chunk * MC + 16 * mt + 4 * g;
       if (col < a.dout) {
-        const wg_f4 yv = *reinterpret_cast<const wg_f4 *>(a.y + (int64_t)b * a.y_sb + col);
+        const wg_f4 yv = wideg_load4(a.y + (int64_t)b * a.y_sb, col, a.dout, vec);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float d = yv[r] - acc[0][mt][nt][r];
-            g_sum[nt] = fma_t(d, d, g_sum[nt]);
+            if (vec || col + r < a.dout) {
+              const float d = yv[r] - acc[0][mt][nt][r];
+              g_sum[nt] = fma_t(d, d, g_sum[nt]);
+            }
           }
         }
       }
@@ -345,7 +379,7 @@ __global__ __launch_bounds__(kWgThreads) void affine_wideg_emission_kernel(WideG
 
 // ---- host side: which instantiation a width takes, and the launchers (one translation unit each: the unrolled kernels
 // are slow to compile) ----------------------------------------------------------------------------------------------------
-constexpr int kWgMinDim = 20, kWgMaxDim = 256;
+constexpr int kWgMinDim = 17, kWgMaxDim = 256;      // (rows of at most 16 values are the item kernels')
 
 // the smallest padded extent that holds a row of `d` values (0: not covered)
 static inline int wideg_padded(int64_t d) {

@@ -51,7 +51,7 @@ extern "C" {
  *                (aesmc_test_*); aesmc_affine_normal_propagate_drawn keeps its signature and now runs the fused launch
  *                (gather + noise + draw + log-weight terms in one kernel); added aesmc_affine_normal_propagate_wide
  *                (+ aesmc_affine_wide_dim, aesmc_affine_wide_workspace_bytes).
- *   500 (0.5.0)  aesmc_affine_normal_propagate_wide takes every width 20 .. 256 that is a multiple of 4, dx != dy, any K
+ *   500 (0.5.0)  aesmc_affine_normal_propagate_wide takes every width 17 .. 256 (observations 1 .. 256), dx != dy, any K
  *                (added aesmc_affine_wide_min_dim, aesmc_affine_wide_max_dim, aesmc_affine_wide_workspace_bytes_for);
  *                AESMC_FLAG_INVALID_PARAMETER reserved for the host's deferred distribution-argument validation;
  *                aesmc_particle_mlp is back (0.1.0 had it, 0.2.0 dropped it) WITH its backward: aesmc_particle_mlp_backward,
@@ -446,16 +446,18 @@ int aesmc_affine_weight_pairs(const aesmc_affine_map *transition, const aesmc_af
  * (the caller keeps the route through aesmc_normal_rsample / aesmc_normal_logweight). */
 int64_t aesmc_affine_wide_dim(void);      /* 128: the extent with the noise in the launch and the backward pieces below */
 size_t aesmc_affine_wide_workspace_bytes(int64_t B, int64_t K);      /* ... at that extent */
-/* 0.5.0: the same entry point takes ANY latent width dx and observation width dy that are multiples of 4 with
- * aesmc_affine_wide_min_dim() = 20 <= dx <= aesmc_affine_wide_max_dim() = 256, 4 <= dy <= 256 (dx != dy allowed:
- * transition and proposal [dx,dx], emission [dy,dx], y [B,dy], x / eps / out_x [B,K,dx]) and any K — aesmc/state.py:61-183
- * is dimension-agnostic.  Rows are padded to the next of 32 / 48 / 64 / 96 / 128 / 192 / 256 inside the launch (zero
- * inputs leave an fma chain as it is: out_x keeps the C oracle's bits), rows wider than 128 are cut into chunks of output
- * rows (the maps' weights stay LDS-resident per chunk; a particle's partial squared distances meet in `ws`, added in
- * ascending chunk order, for dy > 128 by a third small launch), a batch row's last tile is masked when K is not a
- * multiple of 32.  `eps` must be given at these shapes (NULL: AESMC_ERR_UNSUPPORTED — the caller fills the noise with
- * aesmc_philox_normal_fill); `ws`: aesmc_affine_wide_workspace_bytes_for(B, K, dx, dy) bytes. */
-int64_t aesmc_affine_wide_min_dim(void);  /* 20 */
+/* 0.5.0: the same entry point takes ANY latent width dx with aesmc_affine_wide_min_dim() = 17 <= dx <=
+ * aesmc_affine_wide_max_dim() = 256 and any observation width 1 <= dy <= 256 (dx != dy allowed: transition and proposal
+ * [dx,dx], emission [dy,dx], y [B,dy], x / eps / out_x [B,K,dx]) and any K — aesmc/state.py:61-183 is dimension-agnostic
+ * (rows of at most 16 values are the item kernels': aesmc_affine_normal_propagate_drawn).  Rows are padded to the next of
+ * 32 / 48 / 64 / 96 / 128 / 192 / 256 inside the launch (zero inputs leave an fma chain as it is: out_x keeps the C oracle's
+ * bits), rows wider than 128 are cut into chunks of output rows (the maps' weights stay LDS-resident per chunk; a
+ * particle's partial squared distances meet in `ws`, added in ascending chunk order, for dy > 128 by a third small
+ * launch), a batch row's last tile is masked when K is not a multiple of 32, and widths that are not multiples of 4 (rows
+ * that are not whole 16-byte pieces) move their pieces of four element by element.  `eps` must be given at these shapes
+ * (NULL: AESMC_ERR_UNSUPPORTED — the caller fills the noise with aesmc_philox_normal_fill); `ws`:
+ * aesmc_affine_wide_workspace_bytes_for(B, K, dx, dy) bytes. */
+int64_t aesmc_affine_wide_min_dim(void);  /* 17 */
 int64_t aesmc_affine_wide_max_dim(void);  /* 256 */
 size_t aesmc_affine_wide_workspace_bytes_for(int64_t B, int64_t K, int64_t dx, int64_t dy);
 int aesmc_affine_normal_propagate_wide(

@@ -333,16 +333,17 @@ def test_the_wide_step_equals_the_c_oracle(kernels, hip_device, shape, gather):
 
 # ---- every other width: K17g + K18g (aesmc/state.py:61-183 is dimension-agnostic) ----------------------
 WIDTHS = [(24, 24), (32, 32), (64, 64), (96, 96), (256, 256), (32, 48), (192, 80), (48, 20), (128, 128), (20, 4), (100, 136),
-          (160, 256)]
+          (160, 256), (17, 17), (18, 23), (19, 1), (33, 65), (127, 129), (255, 254), (130, 3)]
 
 
 @pytest.mark.parametrize("gather", [False, True])
 @pytest.mark.parametrize("shape", [(3, 40), (2, 320), (1, 1000)])
 @pytest.mark.parametrize("widths", WIDTHS)
 def test_the_matrix_core_step_at_every_width_equals_the_c_oracle(kernels, hip_device, widths, shape, gather):
-    """aesmc_affine_normal_propagate_wide at latent width dx and observation width dy — multiples of 4 from 20 to 256,
-    dx != dy included, padded inside the launch to 32 / 48 / 64 / 96 / 128 / 192 / 256, rows wider than 128 cut into chunks
-    of output rows — and K not a multiple of 32 (a masked last tile) against oracle/smc_core.c: x_t bit for bit (one fma
+    """aesmc_affine_normal_propagate_wide at latent width dx (17 .. 256) and observation width dy (1 .. 256) — dx != dy
+    included, padded inside the launch to 32 / 48 / 64 / 96 / 128 / 192 / 256, rows wider than 128 cut into chunks of
+    output rows, widths that are not multiples of 4 moved element by element — and K not a multiple of 32 (a masked last
+    tile) against oracle/smc_core.c: x_t bit for bit (one fma
     chain per element started from the offset; zero padding leaves a chain as it is), the log-weight to rounding (the
     squared distances are summed per lane, per particle and per chunk instead of in one chain).  (128, 128) at these K is
     the generic kernel too: K = 40 / 1000 are not whole tiles."""
@@ -378,10 +379,10 @@ def test_the_matrix_core_step_at_every_width_equals_the_c_oracle(kernels, hip_de
 
 
 def test_widths_the_matrix_core_step_leaves_to_the_other_routes(kernels, hip_device):
-    """Not a multiple of 4, below 20 (the item kernels' side), above 256: declined — the GEMM route applies."""
+    """At most 16 (the item kernels' side) or above 256: declined — the item kernels / the GEMM route apply."""
     g = torch.Generator(device=hip_device).manual_seed(0)
     one = torch.tensor(1.0, device=hip_device)
-    for dx, dy in ((18, 18), (22, 24), (24, 22), (16, 16), (260, 260), (24, 260)):
+    for dx, dy in ((16, 16), (12, 40), (260, 260), (24, 260)):
         x = torch.randn(2, 64, dx, device=hip_device, generator=g)
         y = torch.randn(2, dy, device=hip_device, generator=g)
         A = torch.randn(dx, dx, device=hip_device, generator=g) * 0.05

@@ -76,7 +76,7 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.aesmc_affine_backward_workspace_bytes(1, 2, 300) == (1024 * 4 * 256 + 3 * 3 * 8 * 16) * 8 + pairs
     assert lib.aesmc_particle_affine_backward(0, 16, 32, ctypes.byref(amap), None, 48, None, None, 0, 1, 1, None) == 1
     # the matrix-core step's extents (0.5.0) and its workspace by width
-    assert (lib.aesmc_affine_wide_dim(), lib.aesmc_affine_wide_min_dim(), lib.aesmc_affine_wide_max_dim()) == (128, 20, 256)
+    assert (lib.aesmc_affine_wide_dim(), lib.aesmc_affine_wide_min_dim(), lib.aesmc_affine_wide_max_dim()) == (128, 17, 256)
     assert lib.aesmc_affine_wide_workspace_bytes_for(2, 64, 128, 128) == 2 * 64 * 3 * 4        # two draw sums + one emission sum
     assert lib.aesmc_affine_wide_workspace_bytes_for(2, 64, 256, 256) == 2 * 64 * (2 * 4 + 2) * 4      # four + two chunks
     assert lib.aesmc_affine_wide_workspace_bytes_for(2, 64, 300, 16) == 0                       # beyond the widest row
