@@ -22,7 +22,8 @@ reaches the fused kernels (K16 / K15 / K14) without being edited, and one that n
 """
 import torch
 
-_MAX_DIM = 16      # the fused kernels' extent limit (aesmc_affine_max_dim)
+_MAX_DIM = 16      # the item kernels' extent limit (aesmc_affine_max_dim): `scalar * x` is recorded as a map up to here
+_MAX_MAP = 256     # the matrix-core step's (aesmc_affine_wide_max_dim): `x @ W.t()` / `F.linear` are recorded up to here
 
 
 class LazyParticles(torch.Tensor):
@@ -207,8 +208,11 @@ def _plain(value):
 
 
 def _small_map(weight, din):
+    """A map some fused launch may take: at most 16 x 16 (the item kernels), or rows of 17 .. 256 values (the matrix-core
+    step, since round 6) — anything a launch then declines is evaluated by `particle_affine` (K8, or the library's GEMM
+    above 16 x 16) the moment the location's values are read: the eager numbers either way."""
     return _plain(weight) and weight.dim() == 2 and weight.size(1) == din and \
-        1 <= weight.size(0) <= _MAX_DIM and 1 <= din <= _MAX_DIM
+        1 <= weight.size(0) <= _MAX_MAP and 1 <= din <= _MAX_MAP
 
 
 def _as_offset(affine, other):

@@ -718,3 +718,42 @@ def test_models_of_other_widths_run_and_train_through_the_matrix_core_step(hip_d
     for name, g in forced_grads.items():
         scale = float(g.abs().max()) + 1e-30
         assert float((wide_grads[name] - g).abs().max()) <= 2e-2 * scale, (name, float((wide_grads[name] - g).abs().max()), scale)
+
+
+@pytest.mark.parametrize("dim", [24, 50])
+def test_a_wide_model_written_with_matmuls_reaches_the_matrix_core_step_unedited(hip_device, monkeypatch, dim):
+    """The reference's own style at a width the item kernels do not take — `Normal(x @ W.t() + c, s)` callables, no
+    library class (test/models/lgssm.py:40's pattern, d = 24 / 50) — recorded on the lazy latents like the small maps and
+    weighed by K17g + K18g: every resampled timestep is the matrix-core launch, and the estimate equals the eager PyTorch
+    evaluation of the same model (lazy latents off) to float32 rounding of another summation order."""
+    from aesmc_amd import _kernels, inference
+    from aesmc_amd.testing.models import LgssmNd
+    provider = _kernels.get()
+    model = LgssmNd(dim, dtype=torch.float32, affine=False, validate_args=False, emission_scale=0.5).tune_proposal().to(hip_device)
+    B, K, T = 3, 200, 5
+    observations = model.simulate(T, B, seed=2)
+    calls = {"wide": 0}
+    real = provider.affine_propagate_wide
+
+    def counting(*args, **kwargs):
+        out = real(*args, **kwargs)
+        calls["wide"] += out is not None
+        return out
+    monkeypatch.setattr(provider, "affine_propagate_wide", counting)
+
+    def run():
+        np.random.seed(4)
+        torch.manual_seed(4)
+        with torch.no_grad():
+            return inference.infer("smc", observations, model.initial, model.transition, model.emission, model.proposal, K,
+                                   return_log_marginal_likelihood=True, return_latents=False, return_original_latents=True)
+    fused = run()
+    assert calls["wide"] == T - 1, calls
+    with inference.lazy_gather(False):
+        plain = run()
+    assert calls["wide"] == T - 1
+    for t in range(2):      # (identical weights at the first resampling; later steps only while no ancestor flips)
+        a, b = fused["original_latents"][t], plain["original_latents"][t]
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), t
+    lml_f, lml_p = fused["log_marginal_likelihood"], plain["log_marginal_likelihood"]
+    assert float(((lml_f - lml_p).abs() / lml_p.abs().clamp_min(1.0)).max()) <= 2e-3
