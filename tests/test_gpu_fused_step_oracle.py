@@ -757,3 +757,37 @@ def test_a_wide_model_written_with_matmuls_reaches_the_matrix_core_step_unedited
         assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), t
     lml_f, lml_p = fused["log_marginal_likelihood"], plain["log_marginal_likelihood"]
     assert float(((lml_f - lml_p).abs() / lml_p.abs().clamp_min(1.0)).max()) <= 2e-3
+
+
+@pytest.mark.parametrize("widths", [(64, 64), (200, 72), (256, 256)])
+def test_the_matrix_core_step_at_a_million_particles_against_float64(kernels, hip_device, widths):
+    """K17g + K18g at B K = 2^20 particles (B = 64, K = 16384: configs[4]'s particle count) — sizes the C oracle does not
+    finish in seconds — through properties that do not depend on the size: x_t - eps s_q is the proposal's location and the
+    log-weight is the three Normal log-densities, both evaluated in float64 by PyTorch on the gathered rows; every row of
+    x_t written exactly once (no NaN left of the poison fill)."""
+    dx, dy = widths
+    B, K = 64, 16384
+    gen = torch.Generator(device=hip_device).manual_seed(dx + dy)
+    make = lambda *s: torch.randn(*s, device=hip_device, generator=gen)
+    x_prev, eps, y, off_q, off_g = make(B, K, dx), make(B, K, dx), make(B, dy), make(B, dx), make(dy)
+    eye = torch.eye(dx, device=hip_device)
+    A = 0.9 * eye + 0.3 / dx ** 0.5 * make(dx, dx)
+    Q = 0.45 * eye + 0.3 / dx ** 0.5 * make(dx, dx)
+    C = make(dy, dx) / dx ** 0.5
+    scales = tuple(torch.tensor(v, device=hip_device) for v in (1.0, 0.5, 0.7))
+    anc = _ancestors(B, K, hip_device, seed=5, spread=1.0)
+    out_x = torch.full((B, K, dx), float("nan"), device=hip_device)
+    lw = kernels.affine_propagate_wide(x_prev, eps, y, (A, None), (C, off_g), (Q, off_q), scales, out_x, ancestors=anc)
+    assert lw is not None and bool(torch.isfinite(out_x).all()) and bool(torch.isfinite(lw).all())
+    rows = slice(0, B, 9)      # a sample of batch rows in float64 (the full tensors would be 3 x 2 GB)
+    moved = torch.gather(x_prev[rows], 1, anc[rows].unsqueeze(-1).expand(-1, -1, dx)).double()
+    loc_q = moved @ Q.double().t() + off_q[rows].double().unsqueeze(1)
+    want_x = loc_q + eps[rows].double() * 0.7
+    assert float((out_x[rows].double() - want_x).abs().max()) <= 2e-5 * float(want_x.abs().max())
+    x64 = out_x[rows].double()
+    logn = lambda v, loc, s: torch.distributions.Normal(loc, s).log_prob(v).sum(-1)
+    want_lw = logn(x64, moved @ A.double().t(), 1.0) + logn(y[rows].double().unsqueeze(1), x64 @ C.double().t() + off_g.double(), 0.5) \
+        - logn(x64, loc_q, 0.7)
+    scale = want_lw.abs().clamp_min(1.0)
+    assert float(((lw[rows].double() - want_lw).abs() / scale).max()) <= 2e-5
+    assert kernels.read_flags(hip_device) == 0
