@@ -54,6 +54,7 @@ _TORCH_LINEAR = torch.nn.functional.linear
 _PARTICLE_LINEAR_MIN_ROWS = 1 << 14
 
 _CONSTANTS = {}
+_CONSTANTS_LIMIT = 4096
 _NUMBER = (int, float, bool)
 # what a deferred parameter check was about, for the message of the ValueError raised later (newest last)
 _CHECKED = []
@@ -71,6 +72,8 @@ def constant(value, dtype, device):
         held = torch.full((), value, dtype=dtype, device=device)
         held._aesmc_number = value      # (its value without a device read: parameter checks of a number run on the host)
         if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            if len(_CONSTANTS) >= _CONSTANTS_LIMIT:      # (a model that anneals a number every step: the cache must not grow
+                _CONSTANTS.clear()                       #  without bound; constants still in use stay alive with their users)
             _CONSTANTS[key] = held
     return held
 
