@@ -856,9 +856,10 @@ class HipKernels:
             self._map_cache[(id(weight), slot)] = (weight, amap, (weight.shape, weight.stride()))
         return amap, (weight, offset)
 
-    def particle_affine(self, x1, w1, offset=None, x2=None, w2=None, base=None):
+    def particle_affine(self, x1, w1, offset=None, x2=None, w2=None, base=None, through_tanh=False):
         """K8: base + (offset + x1 @ w1.T + x2 @ w2.T) -> dense [B,K,dout]; x2 / w2, offset, base optional.
-        Every element is one fma chain (w1's terms, then w2's) started from the offset."""
+        Every element is one fma chain (w1's terms, then w2's) started from the offset.  `through_tanh`: the launch stores
+        tanh of that (aesmc_particle_affine_tanh: the bits `torch.tanh` of the plain result holds)."""
         if not self.affine_covers(x1, w1, offset) or (x2 is not None and not self.affine_covers(x2, w2)):
             raise ValueError("aesmc_amd: particle_affine operands outside what kernel K8 covers")
         tag = _DTYPE_TAG[x1.dtype]
@@ -878,12 +879,13 @@ class HipKernels:
         with _on_device(x1.device):
             args = (tag, _ptr(x1), ctypes.byref(m1), _ptr(x2), ctypes.byref(m2) if m2 is not None else None,
                     _ptr(base), _ptr(out), B, K, self._stream(x1))
-            _lib.check(self._lib.aesmc_particle_affine(*args), "aesmc_particle_affine")
+            entry = self._lib.aesmc_particle_affine_tanh if through_tanh else self._lib.aesmc_particle_affine
+            _lib.check(entry(*args), "aesmc_particle_affine")
             if self.timer is not None:
                 esz = x1.element_size()
                 nbytes = esz * B * K * (x1.size(2) + (x2.size(2) if x2 is not None else 0) +
                                         dout * (2 if base is not None else 1))
-                self.timer.note("particle_affine", (self._lib.aesmc_particle_affine, args), nbytes,
+                self.timer.note("particle_affine", (entry, args), nbytes,
                                 (x1, x2, base, out, m1, m2, keep1, keep2))
         return out
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "aesmc_normal_rsample": (_i32, [_i32] + [ctypes.POINTER(View3)] * 3 + [_vp, _i64, _i64, _i64, _vp]),
     "aesmc_affine_max_dim": (_i64, []),
     "aesmc_particle_affine": (_i32, [_i32, _vp, _map_p, _vp, _map_p, _vp, _vp, _i64, _i64, _vp]),
+    "aesmc_particle_affine_tanh": (_i32, [_i32, _vp, _map_p, _vp, _map_p, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_normal_rsample": (_i32, [_i32, _vp, _map_p, _vp, _vp, _vp, _i64, _i64, _vp]),
     "aesmc_affine_backward_workspace_bytes": (_sz, [_i32, _i64, _i64]),
     "aesmc_particle_affine_backward": (_i32, [_i32, _vp, _vp, _map_p, _vp, _vp, _vp, _vp, _sz, _i64, _i64, _vp]),

@@ -370,33 +370,39 @@ def ancestor_index(log_weight, uniforms):
 # ---- linear-Gaussian particle propagation (K8 / K9 / K10) --------------------------------------------
 
 class _ParticleAffine(torch.autograd.Function):
-    """x @ weight.T + offset through kernel K8; backward: the adjoint map through K8 on the transposed
-    weight view, the weight gradient through the outer-sum kernel."""
+    """x @ weight.T + offset through kernel K8 (or tanh of it: the same launch); backward: the adjoint map through K8 on
+    the transposed weight view, the weight gradient through the outer-sum kernel — behind tanh's own factor 1 - out^2
+    where the location left through it."""
 
     @staticmethod
-    def forward(ctx, x, weight, offset):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, offset, through_tanh=False):
+        out = _kernels.get().particle_affine(x, weight, offset, through_tanh=through_tanh)
+        ctx.save_for_backward(x, weight, out if through_tanh else None)
         ctx.offset_shape = None if offset is None else tuple(offset.shape)
-        return _kernels.get().particle_affine(x, weight, offset)
+        return out
 
     @staticmethod
     def backward(ctx, grad):
-        x, weight = ctx.saved_tensors
+        x, weight, out = ctx.saved_tensors
         k = _kernels.get()
-        need_x, need_w, need_off = ctx.needs_input_grad
+        need_x, need_w, need_off = ctx.needs_input_grad[:3]
         need_off = need_off and ctx.offset_shape is not None
+        if out is not None:
+            grad = grad * (1 - out * out)      # d tanh(v) / d v, from the stored output as torch.tanh's backward does
         gx, gw, rows = k.particle_affine_backward(grad.contiguous(), x, weight, need_x, need_w, need_off)
         goff = None if not need_off else (rows if len(ctx.offset_shape) == 2 else rows.sum(dim=0))
-        return gx, gw, goff
+        return gx, gw, goff, None
 
 
-def particle_affine(x, weight, offset=None):
-    """[B,K,dout] location  offset + x @ weight.T  (kernel K8), differentiable in x, weight and offset."""
+def particle_affine(x, weight, offset=None, through_tanh=False):
+    """[B,K,dout] location  offset + x @ weight.T  (kernel K8) — or tanh of it from the same launch —, differentiable in
+    x, weight and offset."""
     if isinstance(x, LazyParticles):
         x = x.materialise()
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, offset)):
-        return _ParticleAffine.apply(x, weight, offset)
-    return _kernels.get().particle_affine(x.detach(), weight.detach(), None if offset is None else offset.detach())
+        return _ParticleAffine.apply(x, weight, offset, through_tanh)
+    return _kernels.get().particle_affine(x.detach(), weight.detach(), None if offset is None else offset.detach(),
+                                          through_tanh=through_tanh)
 
 
 # ---- K13: a two-layer tanh net over the particles --------------------------------------------------------

@@ -30,13 +30,22 @@
 namespace aesmc {
 
 // ---- K8 ----------------------------------------------------------------------------------------
+// (`stream`: bit 0 the streaming-load hint; bit 1: the location leaves through tanh — `tanh(A x)` of a nonlinear
+//  transition, aesmc_particle_affine_tanh — the device library's function, the one torch.tanh calls, applied to the very
+//  bits the plain launch would store)
+template <typename T> __device__ __forceinline__ T lg_tanh(T x);
+template <> __device__ __forceinline__ float lg_tanh<float>(float x) { return ::tanhf(x); }
+template <> __device__ __forceinline__ double lg_tanh<double>(double x) { return ::tanh(x); }
+
 template <typename T, int DP, int PPL>
 __global__ __launch_bounds__(kLgBlock) void particle_affine_kernel(const T *__restrict__ x1, LgMap m1,
                                                                     const T *__restrict__ x2, LgMap m2,
                                                                     const T *__restrict__ base, T *__restrict__ out,
-                                                                    int64_t N, uint32_t K, int stream) {
+                                                                    int64_t N, uint32_t K, int stream_and_activation) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   constexpr uint32_t TP = kLgBlock * PPL;
+  const int stream = stream_and_activation & 1;
+  const bool through_tanh = (stream_and_activation & 2) != 0;
   const uint32_t d1 = m1.din, d2 = x2 != nullptr ? m2.din : 0, dout = m1.dout;
   T *w1 = reinterpret_cast<T *>(lg_smem);
   T *w2 = w1 + DP * DP;
@@ -74,7 +83,8 @@ __global__ __launch_bounds__(kLgBlock) void particle_affine_kernel(const T *__re
       for (int r = 0; r < PPL; ++r) {
         if (live[r]) {
           const uint32_t slot = p[r] * lo.rs + j;
-          to[slot] = base != nullptr ? to[slot] + acc[j][r] : acc[j][r];
+          const T location = base != nullptr ? to[slot] + acc[j][r] : acc[j][r];
+          to[slot] = through_tanh ? lg_tanh<T>(location) : location;
         }
       }
     }
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(kLgBlock, 3) void affine_logweight_kernel(
 template <typename T>
 static int launch_particle_affine(const void *x1, const aesmc_affine_map *m1, const void *x2,
                                   const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, bool through_tanh = false) {
   const int64_t N = B * K;
   const int64_t d1 = m1->din, d2 = x2 != nullptr ? m2->din : 0, dout = m1->dout;
   const int dp = lg_pad_dim(std::max(std::max(d1, d2), dout));
@@ -364,7 +374,7 @@ static int launch_particle_affine(const void *x1, const aesmc_affine_map *m1, co
   const int64_t tiles = (N + (int64_t)kLgBlock * ppl - 1) / ((int64_t)kLgBlock * ppl);
   if (tiles > 0x7fffffff) return AESMC_ERR_UNSUPPORTED;
   LgMap a = lg_map(m1), b = x2 != nullptr ? lg_map(m2) : a;
-  const int hint = stream_hint((uint64_t)N * (d1 + d2 + dout) * sizeof(T));
+  const int hint = stream_hint((uint64_t)N * (d1 + d2 + dout) * sizeof(T)) | (through_tanh ? 2 : 0);
   LG_DISPATCH(particle_affine_kernel, T, dp, ppl, dim3((unsigned)tiles), lds, stream, static_cast<const T *>(x1), a,
               static_cast<const T *>(x2), b, static_cast<const T *>(base), static_cast<T *>(out), N, (uint32_t)K,
               hint);
@@ -497,9 +507,9 @@ using namespace aesmc;
 
 extern "C" int64_t aesmc_affine_max_dim(void) { return kLgMaxDim; }
 
-extern "C" int aesmc_particle_affine(int dtype, const void *x1, const aesmc_affine_map *m1, const void *x2,
-                                     const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
-                                     void *stream) {
+static int particle_affine_entry(int dtype, const void *x1, const aesmc_affine_map *m1, const void *x2,
+                                 const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
+                                 void *stream, bool through_tanh) {
   if (x1 == nullptr || out == nullptr || m1 == nullptr || m1->weight == nullptr || B < 0 || K < 0 ||
       (x2 != nullptr && (m2 == nullptr || m2->weight == nullptr)))
     return AESMC_ERR_INVALID_ARGUMENT;
@@ -509,8 +519,22 @@ extern "C" int aesmc_particle_affine(int dtype, const void *x1, const aesmc_affi
   if (!lg_map_ok(m1) || (x2 != nullptr && (!lg_map_ok(m2) || m2->dout != m1->dout))) return AESMC_ERR_UNSUPPORTED;
   if (B == 0 || K == 0) return AESMC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == AESMC_F32 ? launch_particle_affine<float>(x1, m1, x2, m2, base, out, B, K, s)
-                            : launch_particle_affine<double>(x1, m1, x2, m2, base, out, B, K, s);
+  return dtype == AESMC_F32 ? launch_particle_affine<float>(x1, m1, x2, m2, base, out, B, K, s, through_tanh)
+                            : launch_particle_affine<double>(x1, m1, x2, m2, base, out, B, K, s, through_tanh);
+}
+
+extern "C" int aesmc_particle_affine(int dtype, const void *x1, const aesmc_affine_map *m1, const void *x2,
+                                     const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
+                                     void *stream) {
+  return particle_affine_entry(dtype, x1, m1, x2, m2, base, out, B, K, stream, false);
+}
+
+// tanh(location): the nonlinear transition of BASELINE.json configs[3] (`tanh(A x_{t-1})`) without the element-wise
+// launch behind K8 (a read and a write of [B,K,d] more)
+extern "C" int aesmc_particle_affine_tanh(int dtype, const void *x1, const aesmc_affine_map *m1, const void *x2,
+                                          const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
+                                          void *stream) {
+  return particle_affine_entry(dtype, x1, m1, x2, m2, base, out, B, K, stream, true);
 }
 
 extern "C" int aesmc_affine_normal_rsample(int dtype, const void *source, const aesmc_affine_map *map,

@@ -33,20 +33,24 @@ from . import _lazy
 from . import _ops
 
 
-def particle_affine(x, weight, offset=None):
+def particle_affine(x, weight, offset=None, activation=None):
     """x @ weight.T + offset (offset [dout], or [B, dout] broadcast over particles) for particles
     x [B,K,din]; differentiable in all three.  Kernel K8 when the map is at most 16 x 16, the
-    library's matmul otherwise."""
+    library's matmul otherwise.  `activation="tanh"`: tanh of that — from the same launch where K8 applies (the bits
+    `torch.tanh(particle_affine(x, weight, offset))` holds, without the element-wise pass behind it): the nonlinear
+    transition `tanh(A x_{t-1})` of BASELINE.json configs[3]."""
+    if activation not in (None, "tanh"):
+        raise ValueError("aesmc_amd: particle_affine activation must be None or 'tanh', got {!r}".format(activation))
     provider = _kernels.get()
     if provider.affine_covers(x, weight, offset):
-        return _ops.particle_affine(x, weight, offset)
+        return _ops.particle_affine(x, weight, offset, through_tanh=activation == "tanh")
     if provider.name == "hip" and not (torch.is_tensor(x) and x.is_cuda):
         raise RuntimeError("aesmc_amd: particle_affine operand lives on '{}'; this package computes only on a "
                            "HIP device (MI355X) and has no CPU fallback.".format(getattr(x, "device", None)))
     out = torch.matmul(x, weight.t())      # wider than 16 x 16 (or not [B,K,d]): the library's GEMM, on the device
     if offset is not None:
         out = out + (offset.unsqueeze(1) if offset.dim() == 2 else offset)
-    return out
+    return torch.tanh(out) if activation == "tanh" else out
 
 
 class _Terms:

@@ -344,14 +344,12 @@ class NonlinearSsm(nn.Module):
     def initial(self):
         return self._tag(self._normal(self.loc0, self.scale0), "NOT_EXPANDED")
 
-    def _linear(self, x, weight):
-        if self.fused:
-            from ..linear_gaussian import particle_affine
-            return particle_affine(x, weight)
-        return x @ weight.t()
-
     def transition(self, previous_latents=None, time=None, previous_observations=None):
-        loc = torch.tanh(self._linear(previous_latents[-1], self.A))
+        if self.fused:      # tanh(A x) from K8's own launch
+            from ..linear_gaussian import particle_affine
+            loc = particle_affine(previous_latents[-1], self.A, activation="tanh")
+        else:
+            loc = torch.tanh(previous_latents[-1] @ self.A.t())
         return self._tag(self._normal(loc, self.transition_scale), "FULLY_EXPANDED")
 
     def emission(self, latents=None, time=None, previous_observations=None):

@@ -55,7 +55,7 @@ extern "C" {
  *                (added aesmc_affine_wide_min_dim, aesmc_affine_wide_max_dim, aesmc_affine_wide_workspace_bytes_for);
  *                AESMC_FLAG_INVALID_PARAMETER reserved for the host's deferred distribution-argument validation;
  *                aesmc_particle_mlp is back (0.1.0 had it, 0.2.0 dropped it) WITH its backward: aesmc_particle_mlp_backward,
- *                aesmc_particle_mlp_backward_records (+ aesmc_particle_mlp_max_hidden).
+ *                aesmc_particle_mlp_backward_records (+ aesmc_particle_mlp_max_hidden); aesmc_particle_affine_tanh.
  *   400 (0.4.0)  aesmc_affine_chain grew `pairs_in` / `pairs_out` (a run of backward steps builds the weight pairs once);
  *                added aesmc_wide_adjoint_tile, aesmc_wide_adjoint_scale, aesmc_wide_adjoint_merge
  *   300 (0.3.0)  added aesmc_affine_normal_propagate_drawn_paired, aesmc_affine_weight_pairs,
@@ -327,6 +327,11 @@ int64_t aesmc_affine_max_dim(void); /* 16: larger maps are proper GEMMs and stay
  * model callables named above, and — with transposed weight views — the input-gradient matmuls of
  * their autograd.  out may alias base. */
 int aesmc_particle_affine(int dtype, const void *x1, const aesmc_affine_map *m1, const void *x2,
+                          const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
+                          void *stream);
+/* ... and tanh(location) from the same launch (0.5.0): the device library's tanh — the one torch.tanh calls — applied to the
+ * bits the plain launch would store; `tanh(A x_{t-1})` of a nonlinear transition without an element-wise launch behind K8. */
+int aesmc_particle_affine_tanh(int dtype, const void *x1, const aesmc_affine_map *m1, const void *x2,
                           const aesmc_affine_map *m2, const void *base, void *out, int64_t B, int64_t K,
                           void *stream);
 

@@ -104,10 +104,11 @@ class OracleKernels:
     def _n(t):
         return None if t is None else t.detach().contiguous().numpy()
 
-    def particle_affine(self, x1, w1, offset=None, x2=None, w2=None, base=None):
+    def particle_affine(self, x1, w1, offset=None, x2=None, w2=None, base=None, through_tanh=False):
         from oracle import c_oracle
-        return torch.from_numpy(c_oracle.particle_affine(self._n(x1), self._n(w1), self._n(x2), self._n(w2),
-                                                         self._n(offset), self._n(base)))
+        out = torch.from_numpy(c_oracle.particle_affine(self._n(x1), self._n(w1), self._n(x2), self._n(w2),
+                                                        self._n(offset), self._n(base)))
+        return torch.tanh(out) if through_tanh else out
 
     def affine_rsample(self, source, weight, offset, eps, scale, out=None):
         from oracle import c_oracle

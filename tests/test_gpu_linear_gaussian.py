@@ -864,3 +864,31 @@ def test_fused_nonlinear_model_matches_the_cpu_port_with_gradients(hip_device, a
             continue
         scale = max(float(reference.abs().max()), 1e-30)
         assert float((parameter.grad.cpu() - reference).abs().max()) <= 1e-8 * scale, name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_particle_affine_through_tanh_is_torch_tanh_of_the_plain_launch(kernels, hip_device, dtype):
+    """aesmc_particle_affine_tanh: the values are `torch.tanh` of what the plain launch stores — the
+    same bits (the device library's tanh on the same chain) — and the operator's gradients are autograd's of
+    `tanh(x @ W.t() + c)` in float64."""
+    from aesmc_amd.linear_gaussian import particle_affine
+    gen = torch.Generator(device=hip_device).manual_seed(3)
+    make = lambda *s_: torch.randn(*s_, device=hip_device, dtype=dtype, generator=gen)
+    x, W, c = make(5, 700, 10), make(10, 10) * 0.4, make(5, 10)
+    plain = kernels.particle_affine(x, W, c)
+    fused = kernels.particle_affine(x, W, c, through_tanh=True)
+    assert torch.equal(fused, torch.tanh(plain))
+    leaves = [t.clone().requires_grad_(True) for t in (x, W, c)]
+    out = particle_affine(*leaves, activation="tanh")
+    upstream = make(*out.shape)
+    got = torch.autograd.grad(out, leaves, upstream)
+    ref_leaves = [t.double().requires_grad_(True) for t in (x, W, c)]
+    ref = torch.tanh(ref_leaves[0] @ ref_leaves[1].t() + ref_leaves[2].unsqueeze(1))
+    want = torch.autograd.grad(ref, ref_leaves, upstream.double())
+    tolerance = 1e-11 if dtype == torch.float64 else 3e-5
+    for a, b in zip(got, want):
+        assert float((a.double() - b).abs().max()) <= tolerance * max(1.0, float(b.abs().max()))
+    wide = particle_affine(make(2, 64, 20), make(20, 20), activation="tanh")      # wider than K8 takes: PyTorch's operators
+    assert wide.shape == (2, 64, 20)
+    with pytest.raises(ValueError):
+        particle_affine(x, W, c, activation="relu")
