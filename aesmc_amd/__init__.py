@@ -56,4 +56,4 @@ from . import state  # noqa: F401
 from . import statistics  # noqa: F401
 from . import train  # noqa: F401
 
-__version__ = "0.5.0"      # = the C ABI's aesmc_version() / 100 (include/aesmc_hip.h holds the history)
+__version__ = "0.5.1"      # = the C ABI's aesmc_version() / 100 (include/aesmc_hip.h holds the history)

@@ -1203,30 +1203,65 @@ class HipKernels:
         self.evaluation += 1
         self._pairs = None
 
-    def _weight_pairs(self, maps, weights, device):
-        """The three maps' weights as interleaved pairs (aesmc_affine_weight_pairs) for the fused propagation launch: built
-        by one small launch the first time an evaluation meets these weights, then reused by its other timesteps.  The
-        entry keeps the weight tensors alive for as long as it stands (until the next `begin_evaluation`), so a cached
-        (address, version) can never be met again on a DIFFERENT tensor that the allocator placed where a freed one was."""
-        w0, w1, w2 = weights
-        if any(w.is_inference() for w in weights):      # (no version counter to tell an in-place update by: never cached)
-            pairs = torch.empty(int(self._lib.aesmc_affine_weight_pairs_floats()), dtype=torch.float32, device=device)
+    def _build_pairs(self, maps, scales, device):
+        """One launch: the interleaved pairs, with the three densities' constants behind them when `scales` is given
+        (aesmc_affine_weight_pairs_scaled) — else their tag cleared (the propagating launch forms them itself)."""
+        pairs = torch.empty(int(self._lib.aesmc_affine_weight_pairs_floats()), dtype=torch.float32, device=device)
+        if scales is not None:
+            _lib.check(self._lib.aesmc_affine_weight_pairs_scaled(
+                ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]),
+                _ptr(scales[1]), _ptr(scales[2]), _ptr(pairs), self._stream(pairs)), "aesmc_affine_weight_pairs_scaled")
+        else:
             _lib.check(self._lib.aesmc_affine_weight_pairs(ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]),
                                                            ctypes.byref(maps[2][0]), _ptr(pairs), self._stream(pairs)),
                        "aesmc_affine_weight_pairs")
-            return pairs
+        return pairs
+
+    # how often one evaluation may rebuild the pairs because the SCALES it was handed are other tensors than last time
+    # (a model that computes them per timestep): after that the pairs carry no constants and fit any scales
+    SCALED_PAIRS_REBUILDS = 2
+
+    def _weight_pairs(self, maps, weights, device, scales=None):
+        """The three maps' weights as interleaved pairs (aesmc_affine_weight_pairs[_scaled]) for the fused propagation
+        launch: built by one small launch the first time an evaluation meets these weights, then reused by its other
+        timesteps.  The entry keeps the weight (and scale) tensors alive for as long as it stands (until the next
+        `begin_evaluation`), so a cached (address, version) can never be met again on a DIFFERENT tensor that the
+        allocator placed where a freed one was.
+
+        `scales` (three one-value float32 tensors): the densities' constants ride behind the pairs while the evaluation
+        keeps handing in the SAME scale tensors, unchanged (`is` and `_version`: Python-number scales are cached device
+        constants, parameters live as long as the model); other tensors rebuild — twice per evaluation at most, then
+        the entry carries no constants."""
+        w0, w1, w2 = weights
+        if scales is not None and not all(torch.is_tensor(s) and s.dtype == torch.float32 and s.numel() == 1 and
+                                          not s.is_inference() for s in scales):
+            scales = None
+        if any(w.is_inference() for w in weights):      # (no version counter to tell an in-place update by: never cached)
+            return self._build_pairs(maps, scales, device)
         held = self._pairs
         key = (self.evaluation, w0._version, w1._version, w2._version)
-        if held is not None and held[2] is w0 and held[3] is w1 and held[4] is w2 and held[0] == key:
-            return held[1]      # (the very tensors of this evaluation's last step, unchanged since: a model's next timestep)
-        layout = tuple((w.data_ptr(), w.shape, w.stride()) for w in weights)
-        if held is not None and held[0] == key and held[5] == layout:
-            return held[1]      # (new view objects of the same, still referenced, storage: `x @ W.t()` makes one per call)
-        pairs = torch.empty(int(self._lib.aesmc_affine_weight_pairs_floats()), dtype=torch.float32, device=device)
-        _lib.check(self._lib.aesmc_affine_weight_pairs(ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]),
-                                                       ctypes.byref(maps[2][0]), _ptr(pairs), self._stream(pairs)),
-                   "aesmc_affine_weight_pairs")
-        self._pairs = (key, pairs, w0, w1, w2, layout)
+        layout = None
+        same = held is not None and held[0] == key and held[2] is w0 and held[3] is w1 and held[4] is w2
+        # (the very tensors of this evaluation's last step, unchanged since: a model's next timestep)
+        if not same and held is not None and held[0] == key:
+            layout = tuple((w.data_ptr(), w.shape, w.stride()) for w in weights)
+            same = held[5] == layout      # (new view objects of the same, still referenced, storage: `x @ W.t()` makes one per call)
+        rebuilds = 0
+        if same:
+            for_scales = held[6]
+            if for_scales is None:      # no constants behind these pairs: they fit any scales
+                return held[1]
+            if scales is not None and all(a is b for a, b in zip(for_scales[0], scales)) and \
+                    for_scales[1] == tuple(s._version for s in scales):
+                return held[1]
+            rebuilds = held[7] + 1
+            if rebuilds > self.SCALED_PAIRS_REBUILDS:
+                scales = None
+        if layout is None:
+            layout = tuple((w.data_ptr(), w.shape, w.stride()) for w in weights)
+        pairs = self._build_pairs(maps, scales, device)
+        for_scales = None if scales is None else (tuple(scales), tuple(s._version for s in scales))
+        self._pairs = (key, pairs, w0, w1, w2, layout, for_scales, rebuilds)
         return pairs
 
     def affine_propagate_drawn(self, x_src, noise, y_rows, transition, emission, proposal, scales, out_x,
@@ -1258,7 +1293,7 @@ class HipKernels:
         with _on_device(x_src.device):
             pairs = None
             if self.WEIGHT_PAIRS and 2 <= dx <= 16:
-                pairs = self._weight_pairs(maps, (transition[0], emission[0], proposal[0]), x_src.device)
+                pairs = self._weight_pairs(maps, (transition[0], emission[0], proposal[0]), x_src.device, scales)
             args = (_ptr(x_src), _ptr(ancestors), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
                     ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
                     _ptr(scales[2]), _ptr(out_x), _ptr(out), _ptr(self.flags(x_src.device)), B, K, noise.seed,

@@ -1,7 +1,7 @@
 // Library identification entry points of the C ABI (include/aesmc_hip.h).
 #include "common.hpp"
 
-extern "C" int aesmc_version(void) { return 500; /* 0.5.0: see the history beside the declaration */ }
+extern "C" int aesmc_version(void) { return 501; /* 0.5.1: see the history beside the declaration */ }
 extern "C" const char *aesmc_target_arch(void) { return "gfx950"; }
 
 // The address a kernel can use for `host_ptr`, a pointer into PINNED host memory (hipHostMalloc; PyTorch's

@@ -254,7 +254,18 @@ static inline int fused_make_plan(FusedPlan &plan, int64_t B, int64_t K, int64_t
 // The maps' interleaved copies (aesmc_affine_weight_pairs; linear_gaussian_item.hip): one region of kPairFloats floats per
 // map in the order transition, emission, proposal.
 constexpr int kPairFloats = (kLgMaxDim / 2) * kLgMaxDim * 2;
-int launch_affine_weight_pairs(const LgMap &mp, const LgMap &mg, const LgMap &mq, float *out, hipStream_t stream);
+// Behind the three regions of a buffer of aesmc_affine_weight_pairs_floats() values: the launch's constants of the three
+// densities — (2 s^2, d (log s + log(2 pi) / 2)) for transition, emission, proposal, the very expressions the propagating
+// kernels evaluate — then a tag: fused_consts_tag(dx, dy) when aesmc_affine_weight_pairs_scaled wrote them for these
+// extents, 0 when nobody did (aesmc_affine_weight_pairs).  The item form reads them instead of taking three logarithms
+// per wavefront (36 of its 660 vector instructions, the pipe it saturates).
+constexpr int kPairConsts = 8;
+__host__ __device__ constexpr uint32_t fused_consts_tag(uint32_t dx, uint32_t dy) { return 0x5c000000u | (dy << 8) | dx; }
+// `sp` .. `sq`: the three scales (device, one float32 each), or all nullptr; `tail`: `out` has the kPairConsts values'
+// room behind the regions (they are written — the tag 0 without scales); without it nothing behind the regions is touched
+int launch_affine_weight_pairs(const LgMap &mp, const LgMap &mg, const LgMap &mq, float *out, hipStream_t stream,
+                               const float *sp = nullptr, const float *sg = nullptr, const float *sq = nullptr,
+                               bool tail = false);
 
 // which form `aesmc_affine_normal_propagate_drawn` launches: 0 by shape, 1 the persistent form, 2 one item per workgroup
 // (AESMC_K16_FORM=persistent / item in the environment, or the test hook aesmc_test_set_k16_form)

@@ -95,6 +95,12 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
     held = present ? value : 0.0f;
   }
 
+  // (PAIRED: the densities' constants behind the pairs — eight scalar registers sent for here, read behind the barrier)
+  typedef float item_f8 __attribute__((ext_vector_type(8)));
+  item_f8 consts = {};
+  if constexpr (PAIRED)
+    consts = *reinterpret_cast<const item_f8 __attribute__((address_space(4))) *>((fused_cfloat *)(unsigned long long)mp.w + 3 * kPairFloats);
+
   // ---- the item's normals: element G (4 trip + i) + t0 + j is output i of thread t0 + j ------------------------------
   const PhiloxStream ps = philox_resolve(ps_in);
   const uint32_t t0 = cur.t0, trip = cur.c, span = cur.tl + dx - 1;
@@ -185,14 +191,29 @@ __global__ __launch_bounds__(512, 4) void affine_propagate_item_kernel(
 
   // ---- propagate: lane = particle; the maps' weights in scalar registers --------------------------------------------
   auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-  const float s_p = sp_ptr[0], s_g = sg_ptr[0], s_q = sq_ptr[0];
-  const float half_log_2pi = LgConst<float>::half_log_2pi();
-  const float two_var_p = uniform(2.0f * (s_p * s_p)), const_p = uniform((float)dx * (Num<float>::log(s_p) + half_log_2pi));
-  const float two_var_g = uniform(2.0f * (s_g * s_g)), const_g = uniform((float)dy * (Num<float>::log(s_g) + half_log_2pi));
-  const float two_var_q = uniform(2.0f * (s_q * s_q)), const_q = uniform((float)dx * (Num<float>::log(s_q) + half_log_2pi));
+  const float s_q = sq_ptr[0];
   float *mine = noise + wi * kRunStride + 64u * c * dx;                         // this chunk's 64 rows of noise; later of x_t
   const float *trow = tab + wi * (2u * 4u * 16u) + ((cur.k0 + rr) >= K ? 64u : 0u);      // the lane's batch row's vectors
   const unsigned long long wq_a = (unsigned long long)mq.w, wp_a = (unsigned long long)mp.w, wg_a = (unsigned long long)mg.w;
+  // the densities' constants: behind the pairs when the launch that interleaved them had the scales (scalar loads; the tag
+  // names the extents they were formed for), else from the scales here — the same expressions, the same bits
+  float two_var_p, const_p, two_var_g, const_g, two_var_q, const_q;
+  bool at_hand = false;
+  if constexpr (PAIRED) {
+    at_hand = __float_as_uint(consts[6]) == fused_consts_tag(dx, dy);
+    if (at_hand) {
+      two_var_p = consts[0]; const_p = consts[1];
+      two_var_g = consts[2]; const_g = consts[3];
+      two_var_q = consts[4]; const_q = consts[5];
+    }
+  }
+  if (!at_hand) {
+    const float s_p = sp_ptr[0], s_g = sg_ptr[0];
+    const float half_log_2pi = LgConst<float>::half_log_2pi();
+    two_var_p = uniform(2.0f * (s_p * s_p)); const_p = uniform((float)dx * (Num<float>::log(s_p) + half_log_2pi));
+    two_var_g = uniform(2.0f * (s_g * s_g)); const_g = uniform((float)dy * (Num<float>::log(s_g) + half_log_2pi));
+    two_var_q = uniform(2.0f * (s_q * s_q)); const_q = uniform((float)dx * (Num<float>::log(s_q) + half_log_2pi));
+  }
 
   float locq[DPX], locp[DPX];
   if constexpr (PAIRED) {
@@ -325,7 +346,11 @@ static int item_launch(dim3 grid, size_t lds, hipStream_t stream, const float *x
 
 // The maps' interleaved copies: pairs[jp][i] = (W[2 jp][i], W[2 jp + 1][i]) (zero where the second row does not exist), one
 // region of kPairFloats floats per map in the order transition, emission, proposal.  Any strides: a transposed view too.
-__global__ __launch_bounds__(256) void affine_weight_pairs_kernel(LgMap mp, LgMap mg, LgMap mq, float *__restrict__ out) {
+// `tail`: 0 nothing behind the regions is written; 1 the constants' tag is cleared; 2 the constants of the three
+// densities and their tag (linear_gaussian_fused.hpp: kPairConsts) from the scales `sp`, `sg`, `sq`.
+__global__ __launch_bounds__(256) void affine_weight_pairs_kernel(LgMap mp, LgMap mg, LgMap mq, float *__restrict__ out,
+                                                                  const float *__restrict__ sp, const float *__restrict__ sg,
+                                                                  const float *__restrict__ sq, int tail) {
   const LgMap &m = blockIdx.x == 0 ? mp : (blockIdx.x == 1 ? mg : mq);
   const float *w = reinterpret_cast<const float *>(m.w);
   float *dst = out + blockIdx.x * kPairFloats;
@@ -334,10 +359,27 @@ __global__ __launch_bounds__(256) void affine_weight_pairs_kernel(LgMap mp, LgMa
     const int jp = e / (2 * din), rem = e - jp * 2 * din, i = rem >> 1, j = 2 * jp + (rem & 1);
     dst[e] = (j < dout && i < din) ? w[(int64_t)j * m.sj + (int64_t)i * m.si] : 0.0f;
   }
+  if (tail != 0 && blockIdx.x == 0 && threadIdx.x < (unsigned)kPairConsts) {
+    const int t = threadIdx.x, which = t >> 1;
+    const uint32_t dx = (uint32_t)mp.dout, dy = (uint32_t)mg.dout;
+    float value = 0.0f;
+    if (tail == 2 && t < 6) {
+      // (the expressions of affine_propagate_item_kernel, in this translation unit: the same instructions)
+      const float s = which == 0 ? sp[0] : (which == 1 ? sg[0] : sq[0]);
+      const float extent = (float)(which == 1 ? dy : dx);
+      value = (t & 1) == 0 ? 2.0f * (s * s) : extent * (Num<float>::log(s) + LgConst<float>::half_log_2pi());
+    } else if (tail == 2 && t == 6) {
+      value = __uint_as_float(fused_consts_tag(dx, dy));
+    }
+    out[3 * kPairFloats + t] = value;
+  }
 }
 
-int launch_affine_weight_pairs(const LgMap &mp, const LgMap &mg, const LgMap &mq, float *out, hipStream_t stream) {
-  hipLaunchKernelGGL(affine_weight_pairs_kernel, dim3(3), dim3(256), 0, stream, mp, mg, mq, out);
+int launch_affine_weight_pairs(const LgMap &mp, const LgMap &mg, const LgMap &mq, float *out, hipStream_t stream,
+                               const float *sp, const float *sg, const float *sq, bool tail) {
+  const bool scaled = sp != nullptr && sg != nullptr && sq != nullptr;
+  hipLaunchKernelGGL(affine_weight_pairs_kernel, dim3(3), dim3(256), 0, stream, mp, mg, mq, out, sp, sg, sq,
+                     tail ? (scaled ? 2 : 1) : 0);
   return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
 }
 
@@ -393,12 +435,23 @@ int launch_affine_propagate_item(const void *xsrc, const int64_t *anc_idx, const
 
 using namespace aesmc;
 
-extern "C" int64_t aesmc_affine_weight_pairs_floats(void) { return 3 * (int64_t)kPairFloats; }
+extern "C" int64_t aesmc_affine_weight_pairs_floats(void) { return 3 * (int64_t)kPairFloats + kPairConsts; }
 
 extern "C" int aesmc_affine_weight_pairs(const aesmc_affine_map *transition, const aesmc_affine_map *emission,
                                          const aesmc_affine_map *proposal, void *out_pairs, void *stream) {
   if (out_pairs == nullptr || (reinterpret_cast<uintptr_t>(out_pairs) & 15u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
   if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
   return launch_affine_weight_pairs(lg_map(transition), lg_map(emission), lg_map(proposal), static_cast<float *>(out_pairs),
-                                    static_cast<hipStream_t>(stream));
+                                    static_cast<hipStream_t>(stream), nullptr, nullptr, nullptr, true);
+}
+
+extern "C" int aesmc_affine_weight_pairs_scaled(const aesmc_affine_map *transition, const aesmc_affine_map *emission,
+                                                const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+                                                const void *scale_q, void *out_pairs, void *stream) {
+  if (out_pairs == nullptr || (reinterpret_cast<uintptr_t>(out_pairs) & 15u) != 0) return AESMC_ERR_INVALID_ARGUMENT;
+  if (scale_p == nullptr || scale_g == nullptr || scale_q == nullptr) return AESMC_ERR_INVALID_ARGUMENT;
+  if (!lg_map_ok(transition) || !lg_map_ok(emission) || !lg_map_ok(proposal)) return AESMC_ERR_UNSUPPORTED;
+  return launch_affine_weight_pairs(lg_map(transition), lg_map(emission), lg_map(proposal), static_cast<float *>(out_pairs),
+                                    static_cast<hipStream_t>(stream), static_cast<const float *>(scale_p),
+                                    static_cast<const float *>(scale_g), static_cast<const float *>(scale_q), true);
 }

@@ -56,6 +56,8 @@ extern "C" {
  *                AESMC_FLAG_INVALID_PARAMETER reserved for the host's deferred distribution-argument validation;
  *                aesmc_particle_mlp is back (0.1.0 had it, 0.2.0 dropped it) WITH its backward: aesmc_particle_mlp_backward,
  *                aesmc_particle_mlp_backward_records (+ aesmc_particle_mlp_max_hidden); aesmc_particle_affine_tanh.
+ *   501 (0.5.1)  added aesmc_affine_weight_pairs_scaled; aesmc_affine_weight_pairs_floats() grew by eight values (the
+ *                three densities' constants and their tag behind the pairs: aesmc_affine_weight_pairs clears the tag).
  *   400 (0.4.0)  aesmc_affine_chain grew `pairs_in` / `pairs_out` (a run of backward steps builds the weight pairs once);
  *                added aesmc_wide_adjoint_tile, aesmc_wide_adjoint_scale, aesmc_wide_adjoint_merge
  *   300 (0.3.0)  added aesmc_affine_normal_propagate_drawn_paired, aesmc_affine_weight_pairs,
@@ -431,6 +433,17 @@ int aesmc_affine_normal_propagate_drawn_paired(
 int64_t aesmc_affine_weight_pairs_floats(void);
 int aesmc_affine_weight_pairs(const aesmc_affine_map *transition, const aesmc_affine_map *emission,
                               const aesmc_affine_map *proposal, void *out_pairs, void *stream);
+/* (0.5.1) The same launch with the three scales at hand (device pointers, one float32 each, the values
+ * aesmc_affine_normal_propagate_drawn_paired will be handed): behind the pairs it also leaves the launch-wide constants
+ * of the three Normal densities of aesmc/state.py:98 — 2 s^2 and d (log s + log(2 pi) / 2) for transition, emission,
+ * proposal — and a tag naming the extents they were formed for.  The fused launch then reads them as scalars instead of
+ * taking three logarithms in every wavefront (5 % of the vector instructions of a kernel that saturates the vector
+ * pipe); the log-weights' bits do not change (the same expressions, evaluated once).  Rebuild whenever a weight OR a
+ * scale changes; a buffer written by aesmc_affine_weight_pairs carries a cleared tag and the launch forms the constants
+ * itself, as before. */
+int aesmc_affine_weight_pairs_scaled(const aesmc_affine_map *transition, const aesmc_affine_map *emission,
+                                     const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
+                                     const void *scale_q, void *out_pairs, void *stream);
 
 /* K17 + K18 — one SMC step of a linear-Gaussian model whose latent and observation rows hold 128 float32 values
  * (BASELINE.json configs[4]), the three 128 x 128 maps on the fp32 matrix cores:

@@ -191,3 +191,87 @@ def test_packed_multiply_adds_give_the_scalar_chains_bits(kernels, hip_device, f
         fresh[paired] = _run(kernels, o, x_prev, y, None, off_q, idx, seed=5 + K)[:2]
     assert torch.equal(fresh[True][0], fresh[False][0]) and not torch.equal(fresh[True][0], out[True][0])
     assert fresh[True][1].cpu().numpy().tobytes() == fresh[False][1].cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("shape", [(16, 4096, 10, 10), (5, 777, 3, 11), (6, 1024, 16, 16), (9, 513, 4, 1)])
+def test_the_densities_constants_behind_the_pairs_follow_the_scales(kernels, hip_device, forms, shape, monkeypatch):
+    """aesmc_affine_weight_pairs_scaled leaves 2 s^2 and d (log s + log(2 pi) / 2) of the three densities behind the pairs
+    and the item form reads them instead of taking three logarithms per wavefront: the log-weights' bits are those of
+    the launch that forms them itself (pairs without constants, and no pairs at all); a scale changed in place, or
+    other scale tensors, never meet stale constants; a model that hands in fresh scale tensors every timestep stops
+    rebuilding after two launches.  (aesmc/state.py:98's Normal log-density, the same expression evaluated once.)"""
+    from aesmc_amd import _philox
+    B, K, dx, dy = shape
+    _, o = operands(4, 32, dx, dy, np.float32, hip_device, seed=B + K)
+    gen = torch.Generator(device=hip_device).manual_seed(K + dx)
+    x_prev = torch.randn(B, K, dx, device=hip_device, generator=gen)
+    y = torch.randn(B, dy, device=hip_device, generator=gen)
+    off_q = torch.randn(B, dx, device=hip_device, generator=gen)
+    idx = _ancestors(B, K, hip_device, seed=B + K, spread=1.0)
+    forms(ITEM)
+    kernels.begin_evaluation()
+
+    def run(scales):
+        return _run(kernels, dict(o, s_p=scales[0], s_g=scales[1], s_q=scales[2]), x_prev, y, None, off_q, idx, seed=5 + K)
+
+    def tag():
+        return int(kernels._pairs[1][-2:-1].view(torch.int32).item())
+
+    scales = [o["s_p"], o["s_g"], o["s_q"]]
+    monkeypatch.setattr(kernels, "WEIGHT_PAIRS", False)
+    want_x, want_lw, ran = run(scales)
+    assert ran == ITEM
+    monkeypatch.setattr(kernels, "WEIGHT_PAIRS", True)
+    got_x, got_lw, ran = run(scales)
+    assert ran == ITEM and kernels._pairs[6] is not None and tag() == (0x5c000000 | (dy << 8) | dx)
+    assert torch.equal(got_x, want_x) and got_lw.cpu().numpy().tobytes() == want_lw.cpu().numpy().tobytes()
+    held = kernels._pairs[1]
+    assert run(scales)[1].cpu().numpy().tobytes() == want_lw.cpu().numpy().tobytes() and kernels._pairs[1] is held
+    # the constants are the kernel's own expressions of the scales
+    consts = held[-8:-2].cpu().numpy()
+    s = np.array([float(t.cpu()) for t in scales], dtype=np.float32)
+    np.testing.assert_array_equal(consts[0::2], np.float32(2.0) * (s * s))
+    extents = np.array([dx, dy, dx], dtype=np.float32)
+    np.testing.assert_allclose(consts[1::2], extents * (np.log(s.astype(np.float64)) + 0.5 * np.log(2 * np.pi)), rtol=2e-6)
+    # a scale changed in place: same tensor, new value, new constants
+    with torch.no_grad():
+        scales[1].mul_(1.75)
+    monkeypatch.setattr(kernels, "WEIGHT_PAIRS", False)
+    want_lw2 = run(scales)[1]
+    monkeypatch.setattr(kernels, "WEIGHT_PAIRS", True)
+    got_lw2 = run(scales)[1]
+    assert kernels._pairs[1] is not held and kernels._pairs[7] == 1
+    assert got_lw2.cpu().numpy().tobytes() == want_lw2.cpu().numpy().tobytes()
+    assert got_lw2.cpu().numpy().tobytes() != want_lw.cpu().numpy().tobytes()
+    # other scale tensors every call (a model that computes them per timestep): two rebuilds, then pairs without constants
+    for trip in range(4):
+        fresh = [t.clone() * (1.0 + 0.125 * trip) for t in scales]
+        monkeypatch.setattr(kernels, "WEIGHT_PAIRS", False)
+        want = run(fresh)[1]
+        monkeypatch.setattr(kernels, "WEIGHT_PAIRS", True)
+        got = run(fresh)[1]
+        assert got.cpu().numpy().tobytes() == want.cpu().numpy().tobytes(), trip
+    assert kernels._pairs[6] is None and tag() == 0
+    last = kernels._pairs[1]
+    assert run([t.clone() for t in scales])[1] is not None and kernels._pairs[1] is last
+    # the C ABI's two builders side by side: a cleared tag makes the launch form the constants itself
+    import ctypes
+    from aesmc_amd._kernels import _ptr
+    maps = [kernels._affine_map(*term, slot=slot) for slot, term in enumerate(((o["A"], None), (o["C"], o["off_g"]), (o["Q"], off_q)))]
+    outs = []
+    for scaled in (False, True):
+        pairs = kernels._build_pairs(maps, scales if scaled else None, hip_device)
+        torch.manual_seed(5 + K)
+        reservation = _philox.reserve(B * K * dx, hip_device)
+        out_x = torch.empty_like(x_prev)
+        lw = torch.empty(B, K, device=hip_device)
+        status = kernels._lib.aesmc_affine_normal_propagate_drawn_paired(
+            _ptr(x_prev), _ptr(idx), _ptr(y), y.stride(0), ctypes.byref(maps[0][0]), ctypes.byref(maps[1][0]),
+            ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]), _ptr(scales[2]), _ptr(out_x), _ptr(lw),
+            _ptr(kernels.flags(hip_device)), B, K, reservation.seed, reservation.offset, reservation.threads,
+            _ptr(reservation.state), _ptr(pairs), kernels._stream(x_prev))
+        assert status == 0
+        outs.append((out_x, lw))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1].cpu().numpy().tobytes() == outs[1][1].cpu().numpy().tobytes()
+    assert outs[1][1].cpu().numpy().tobytes() == want_lw2.cpu().numpy().tobytes()
+    assert kernels.read_flags(hip_device) == 0

@@ -436,7 +436,7 @@ def test_package_surface():
     """aesmc/__init__.py:1-7."""
     for name in ("inference", "losses", "math", "state", "statistics", "train"):
         assert hasattr(aesmc_amd, name)
-    assert aesmc_amd.__version__ == "0.5.0"      # = the C ABI (tests/test_library.py holds the two together)
+    assert aesmc_amd.__version__ == "0.5.1"      # = the C ABI (tests/test_library.py holds the two together)
 
 
 def test_public_surface_matches_the_reference_signature_table():

@@ -30,9 +30,9 @@ def test_library_builds_and_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in names:
         getattr(raw, name)
-    assert lib.aesmc_version() == 500
+    assert lib.aesmc_version() == 501
     import aesmc_amd
-    assert aesmc_amd.__version__ == "0.{}.{}".format(500 // 100, (500 // 10) % 10)      # the package says the ABI's version (500 = 0.5.0)
+    assert aesmc_amd.__version__ == "0.{}.{}".format(501 // 100, 501 % 100)      # the package says the ABI's version (501 = 0.5.1)
     assert lib.aesmc_target_arch() == b"gfx950"
     assert lib.aesmc_ancestor_index_lds_max_particles() >= 16384
     assert lib.aesmc_workspace_bytes(4, 1024) == 0
