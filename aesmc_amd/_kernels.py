@@ -181,6 +181,7 @@ class HipKernels:
         self._pairs = None          # (key, tensor): the interleaved weight pairs of the maps the fused launch met last
         self.evaluation = 0         # bumped by `begin_evaluation`: what a cached weight-pair block belongs to
         self.WEIGHT_PAIRS = settings.knob("AESMC_K16_PAIRS", "1") != "0"      # measurement knob
+        self.SCALED_PAIRS = settings.knob("AESMC_K16_SCALED", "1") != "0"     # measurement knob: the constants behind the pairs
 
     # ---- deferred status word ---------------------------------------------------------------
     def flags(self, device):
@@ -1293,7 +1294,8 @@ class HipKernels:
         with _on_device(x_src.device):
             pairs = None
             if self.WEIGHT_PAIRS and 2 <= dx <= 16:
-                pairs = self._weight_pairs(maps, (transition[0], emission[0], proposal[0]), x_src.device, scales)
+                pairs = self._weight_pairs(maps, (transition[0], emission[0], proposal[0]), x_src.device,
+                                           scales if self.SCALED_PAIRS else None)
             args = (_ptr(x_src), _ptr(ancestors), _ptr(y_rows), y_rows.stride(0), ctypes.byref(maps[0][0]),
                     ctypes.byref(maps[1][0]), ctypes.byref(maps[2][0]), _ptr(scales[0]), _ptr(scales[1]),
                     _ptr(scales[2]), _ptr(out_x), _ptr(out), _ptr(self.flags(x_src.device)), B, K, noise.seed,
