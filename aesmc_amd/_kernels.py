@@ -1196,6 +1196,45 @@ class HipKernels:
                                 nbytes, (x_src, ancestors, eps, y_rows, out, out_x, ws, maps, scales))
         return out
 
+    def affine_initial_step(self, eps, loc_q, scale_q, loc_p, scale_p, y, weight, offset, scale_g, out_x):
+        """K20: the first timestep of a run in one launch — `out_x[b,k,:] = loc_q + eps[k,b,:] * scale_q` (the reference's
+        transposed `rsample((K,))`), the emission's location `offset + out_x @ weight.T` and the three Normal
+        log-densities — with the bits of K6 + K8 + K5 (aesmc_affine_normal_initial_step).  `eps` [K,B,dx] contiguous;
+        `loc_q`, `scale_q`, `loc_p`, `scale_p` views of [B,K,dx] and `y`, `scale_g` of [B,K,dy] whose particle stride is 0;
+        `weight` [dy,dx] (any strides), `offset` None, [dy] or [B,dy].  Returns the log-weights [B,K], or None where the
+        launch does not apply (nothing has been launched then)."""
+        B, K, dx = out_x.shape
+        if not (torch.is_tensor(eps) and eps.dtype == torch.float32 and eps.is_cuda and tuple(eps.shape) == (K, B, dx) and
+                eps.is_contiguous() and out_x.dtype == torch.float32 and out_x.is_contiguous() and out_x.device == eps.device):
+            return None
+        if not (torch.is_tensor(weight) and weight.dim() == 2 and weight.size(1) == dx and weight.dtype == torch.float32 and
+                weight.device == eps.device and 1 <= dx <= 16 and 1 <= weight.size(0) <= 16):
+            return None
+        dy = weight.size(0)
+        if offset is not None and not (torch.is_tensor(offset) and offset.dtype == torch.float32 and
+                                       offset.device == eps.device and tuple(offset.shape) in ((dy,), (B, dy))):
+            return None
+        views = []
+        for view, extent in ((loc_q, dx), (scale_q, dx), (loc_p, dx), (scale_p, dx), (y, dy), (scale_g, dy)):
+            if not (torch.is_tensor(view) and view.dtype == torch.float32 and view.device == eps.device and
+                    tuple(view.shape) == (B, K, extent) and (K == 1 or view.stride(1) == 0)):
+                return None
+            views.append(_lib.View3(_ptr(view), view.stride(0), 0, view.stride(2)))
+        out = torch.empty((B, K), dtype=torch.float32, device=eps.device)
+        amap, held = self._affine_map(weight, offset)
+        with _on_device(eps.device):
+            args = (_ptr(eps),) + tuple(ctypes.byref(v) for v in views[:5]) + (ctypes.byref(amap), ctypes.byref(views[5]),
+                                                                                _ptr(out_x), _ptr(out), B, K, self._stream(eps))
+            status = self._lib.aesmc_affine_normal_initial_step(*args)
+            if status == 2:
+                return None
+            _lib.check(status, "aesmc_affine_normal_initial_step")
+            if self.timer is not None:
+                nbytes = 4 * (2 * B * K * dx + B * K)
+                self.timer.note("affine_normal_initial_step", (self._lib.aesmc_affine_normal_initial_step, args), nbytes,
+                                (eps, loc_q, scale_q, loc_p, scale_p, y, scale_g, out_x, out, views, amap, held))
+        return out
+
     def begin_evaluation(self):
         """Called once per `infer`: weight pairs built for an earlier evaluation are dropped (the weights may have been
         stepped in between; inside a hipGraph capture the rebuild must be part of the captured work; and the entry holds

@@ -10,6 +10,7 @@ dtype / device behave) that hold no values:
 
   LazyResampled(source, index)       previous_latents[-1]: x_{t-1} re-indexed by the newest ancestors
   LazyDraw(location terms, noise)    latents[-1]: the proposal's reparameterised draw  loc_q + s_q * eps
+  LazyInitialDraw(proposal, noise)   latents[-1] of the FIRST step: a BATCH_EXPANDED Normal's transposed draw
   LazyAffine(source, weight, offset) what `x @ W.t()`, `F.linear(x, W, b)`, `+ offset`, `scalar * x` of one of the
                                      above evaluate to: a location  offset + source @ weight.T
 
@@ -196,11 +197,39 @@ class LazyDraw(LazyParticles):
         return _ops.affine_rsample(real(terms.source), terms.weight, terms.offset, terms.scale_param, eps)
 
 
+class LazyInitialDraw(LazyParticles):
+    """The FIRST timestep's draw of a BATCH_EXPANDED Normal proposal, `rsample((K,))` transposed to [B,K,d]
+    (aesmc/state.py:98, :102-103):  loc[b] + eps[k,b] * scale[b]  with its noise `eps` [K,B,d] already drawn.  Formed by
+    the launch that weighs the step when that step is linear-Gaussian in it (K20, `state._initial_step`) or, the moment
+    anything reads it, by K6 — the transposed draw `state.sample` used to make right away."""
+
+    @staticmethod
+    def __new__(cls, distribution, loc, scale, noise):
+        return LazyParticles._make(cls, torch.Size((noise.size(1), noise.size(0)) + tuple(noise.shape[2:])), noise)
+
+    def __init__(self, distribution, loc, scale, noise):
+        self._lazy_grad_mode = torch.is_grad_enabled()
+        self._lazy_like = noise
+        self.distribution = distribution      # the proposal this is the draw of
+        self.loc, self.scale = loc, scale     # expanded to the noise's shape [K,B,d]
+        self.noise = noise
+        self._lazy_real = None
+        self._lazy_shape = torch.Size((noise.size(1), noise.size(0)) + tuple(noise.shape[2:]))
+
+    def _lazy_requires_grad(self):
+        return self.loc.requires_grad or self.scale.requires_grad
+
+    def _lazy_compute(self):
+        from . import _ops
+        return _ops.normal_rsample(self.noise.transpose(0, 1), self.loc.transpose(0, 1), self.scale.transpose(0, 1))
+
+
 # ---- what is recorded instead of computed ----------------------------------------------------------------------
 def _is_particles(value):
     """A pending lazy [B,K,d] particle tensor an affine map may be recorded on (not a location: maps of maps are
     evaluated)."""
-    return type(value) in (LazyResampled, LazyDraw) and value._lazy_real is None and len(value._lazy_shape) == 3
+    return type(value) in (LazyResampled, LazyDraw, LazyInitialDraw) and value._lazy_real is None and \
+        len(value._lazy_shape) == 3
 
 
 def _plain(value):

@@ -105,6 +105,8 @@ SIGNATURES = {
     "aesmc_affine_weight_pairs_floats": (_i64, []),
     "aesmc_affine_weight_pairs": (_i32, [_map_p, _map_p, _map_p, _vp, _vp]),
     "aesmc_affine_weight_pairs_scaled": (_i32, [_map_p, _map_p, _map_p, _vp, _vp, _vp, _vp, _vp]),
+    "aesmc_affine_normal_initial_step": (_i32, [_vp] + [ctypes.POINTER(View3)] * 5 + [_map_p, ctypes.POINTER(View3), _vp, _vp,
+                                                _i64, _i64, _vp]),
     "aesmc_particle_mlp_max_hidden": (_i64, []),
     "aesmc_particle_mlp": (_i32, [_i32, _vp, _map_p, _map_p, _vp, _i64, _i64, _vp]),
     "aesmc_particle_mlp_backward_records": (_i64, [_i64, _i64]),

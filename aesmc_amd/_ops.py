@@ -180,6 +180,66 @@ class _NormalLogWeightLSE(torch.autograd.Function):
         return (None, None) + tuple(fused)
 
 
+# ---- K20: the first timestep in one launch (state._initial_step) -------------------------------------------
+class _NormalRsampleGiven(torch.autograd.Function):
+    """draw = loc + eps * scale whose VALUES another launch has already formed (K20 wrote `value`): `_NormalRsample`'s
+    node without its launch — the same backward."""
+
+    @staticmethod
+    def forward(ctx, eps, loc, scale, value):
+        ctx.save_for_backward(eps if scale.requires_grad else None)
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (eps,) = ctx.saved_tensors
+        grad_loc = grad if ctx.needs_input_grad[1] else None
+        grad_scale = grad * eps if ctx.needs_input_grad[2] else None
+        return None, grad_loc, grad_scale, None
+
+
+def normal_rsample_given(eps, loc, scale, value):
+    """`value` = loc + eps * scale (formed elsewhere) as a differentiable function of loc and scale."""
+    if torch.is_grad_enabled() and (loc.requires_grad or scale.requires_grad):
+        return _NormalRsampleGiven.apply(eps, loc, scale, value)
+    return value
+
+
+class InitialOperands(tuple):
+    """The operands of a K20 launch as `attach_lse` wants them: (x_0, loc_p, scale_p, y, location port, weight, offset,
+    scale_g, loc_q, scale_q) — K5's eight with the emission's location, which was never written, replaced by its
+    autograd port (`particle_affine_port`) and the map that gives its values."""
+
+
+class _InitialLogWeightLSE(torch.autograd.Function):
+    """`_NormalLogWeightLSE` for a step K20 weighed: the emission's location C x_0 + g exists only inside that launch, so
+    the backward evaluates it first (K8: the values K20 used) and then runs K5's backward with K1's softmax term formed
+    in place; the location's gradient leaves through the port — `_ParticleAffine`'s node, created where the three-launch
+    route creates it — so every parameter's gradient is accumulated from the same contributions in the same order: the
+    same bits as that route."""
+
+    @staticmethod
+    def forward(ctx, lse, lw, x, loc_p, scale_p, y, port, weight, offset, scale_g, loc_q, scale_q):
+        ctx.save_for_backward(lse, lw, x, loc_p, scale_p, y, weight, offset, scale_g, loc_q, scale_q)
+        return lse.view_as(lse)
+
+    @staticmethod
+    def backward(ctx, grad_lse):
+        lse, lw, x, loc_p, scale_p, y, weight, offset, scale_g, loc_q, scale_q = ctx.saved_tensors
+        wanted = ctx.needs_input_grad
+        need8 = [wanted[2], wanted[3], wanted[4], wanted[5], wanted[6], wanted[9], wanted[10], wanted[11]]
+        k = _kernels.get()
+        loc_g = k.particle_affine(x, weight, offset)
+        grad_lse = grad_lse.contiguous()
+        fused = k.normal_logweight_backward(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, None, need8,
+                                            lw=lw, lse=lse, grad_lse=grad_lse)
+        if fused is None:   # not reached with today's kernels (the backward is elementwise); kept for safety
+            grad, _ = k.logweight_lse_backward(lw, lse, None, grad_lse, want_neg=False)
+            fused = k.normal_logweight_backward(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad, need8)
+        g_x, g_loc_p, g_scale_p, g_y, g_loc_g, g_scale_g, g_loc_q, g_scale_q = fused
+        return None, None, g_x, g_loc_p, g_scale_p, g_y, g_loc_g, None, None, g_scale_g, g_loc_q, g_scale_q
+
+
 def normal_log_weight_deferred(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q):
     """K5 forward WITHOUT an autograd node: (log-weights [B,K] carrying no gradient, the operands
     as given) — or None when K5 does not cover the operands.  For callers that differentiate the
@@ -200,6 +260,8 @@ def attach_lse(lse, lw, operands):
         return operands.bind(lse.detach())
     if isinstance(operands, AffineOperands):
         return _AffineLogWeightLSE.apply(lse.detach(), lw, *operands)
+    if isinstance(operands, InitialOperands):
+        return _InitialLogWeightLSE.apply(lse.detach(), lw, *operands)
     return _NormalLogWeightLSE.apply(lse.detach(), lw, *operands)
 
 
@@ -392,6 +454,23 @@ class _ParticleAffine(torch.autograd.Function):
         gx, gw, rows = k.particle_affine_backward(grad.contiguous(), x, weight, need_x, need_w, need_off)
         goff = None if not need_off else (rows if len(ctx.offset_shape) == 2 else rows.sum(dim=0))
         return gx, gw, goff, None
+
+
+class _ParticleAffinePort(_ParticleAffine):
+    """`_ParticleAffine`'s node for a location nobody writes (K20 forms it inside its launch): the output holds no values
+    — one element expanded to the location's shape — and exists to receive the location's gradient where the written
+    location would have; the backward is `_ParticleAffine`'s."""
+
+    @staticmethod
+    def forward(ctx, x, weight, offset, through_tanh=False):
+        ctx.save_for_backward(x, weight, None)
+        ctx.offset_shape = None if offset is None else tuple(offset.shape)
+        return x.new_zeros(()).expand(x.size(0), x.size(1), weight.size(0))
+
+
+def particle_affine_port(x, weight, offset=None):
+    """The autograd identity of `particle_affine(x, weight, offset)` without its values (see `_ParticleAffinePort`)."""
+    return _ParticleAffinePort.apply(x, weight, offset, False)
 
 
 def particle_affine(x, weight, offset=None, through_tanh=False):

@@ -14,7 +14,8 @@ SOURCES = ["abi.hip", "logweight_lse.hip", "ancestor_index.hip", "resample_gathe
            "normal_logprob.hip", "normal_rsample.hip", "particle_summary.hip", "linear_gaussian.hip",
            "linear_gaussian_backward.hip", "philox_normal.hip", "linear_gaussian_noise.hip",
            "linear_gaussian_fused.hip", "linear_gaussian_item.hip", "linear_gaussian_step_backward.hip", "linear_gaussian_wide.hip", "linear_gaussian_wide_backward.hip",
-           "linear_gaussian_wide_generic_draw.hip", "linear_gaussian_wide_generic_emit.hip", "particle_mlp.hip"]
+           "linear_gaussian_wide_generic_draw.hip", "linear_gaussian_wide_generic_emit.hip", "particle_mlp.hip",
+           "linear_gaussian_initial.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "linear_gaussian.hpp"),
            os.path.join(CSRC, "philox_normal.hpp"), os.path.join(CSRC, "linear_gaussian_fused.hpp"),
            os.path.join(CSRC, "linear_gaussian_backward.hpp"), os.path.join(CSRC, "linear_gaussian_wide_generic.hpp"),

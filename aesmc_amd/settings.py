@@ -53,6 +53,12 @@ class Settings:
     # rows); off: the library GEMM  [AESMC_PARTICLE_LINEAR]
     particle_linear: bool = True
 
+    # inside `infer`, the FIRST timestep of a model whose time-0 proposal is a BATCH_EXPANDED Normal and whose emission is
+    # linear-Gaussian in the latent (the reference's own models: test/models/lgssm.py) runs as ONE launch, K20 — the
+    # transposed draw, the emission's location and the three log-densities — with the bits of the three launches it
+    # stands for (K6, K8, K5); off: those three  [AESMC_INITIAL_STEP]
+    initial_step: bool = True
+
     def validate(self):
         if self.history_mode not in ("lazy", "eager"):
             raise ValueError("history mode must be 'lazy' or 'eager', got {}".format(self.history_mode))
@@ -71,7 +77,8 @@ def knob(name, default=None):
 
 
 _DEFAULT = Settings(lazy_gather=_env_flag("AESMC_LAZY_GATHER"), fold_gather_backward=_env_flag("AESMC_FOLD_GATHER_BACKWARD"),
-                    kernel_noise=_env_flag("AESMC_KERNEL_NOISE"), particle_linear=_env_flag("AESMC_PARTICLE_LINEAR"))
+                    kernel_noise=_env_flag("AESMC_KERNEL_NOISE"), particle_linear=_env_flag("AESMC_PARTICLE_LINEAR"),
+                    initial_step=_env_flag("AESMC_INITIAL_STEP"))
 _SCOPED = contextvars.ContextVar("aesmc_amd_settings", default=None)      # the innermost `override`'s CHANGED fields only
 _FIELDS = tuple(field.name for field in dataclasses.fields(Settings))
 

@@ -17,7 +17,7 @@ from . import _ops
 from . import _philox
 from . import _syncfree
 from . import settings
-from ._lazy import LazyAffine, LazyDraw, LazyParticles, LazyResampled
+from ._lazy import LazyAffine, LazyDraw, LazyInitialDraw, LazyParticles, LazyResampled
 from ._lazy import real as _lazy_real
 from .linear_gaussian import AffineNormal, affine_terms
 
@@ -167,6 +167,11 @@ def normal_log_weight(prior_dist, proposal_dist, latent, emission_dist, observat
     differentiates only through the row log-sum-exp (`_ops.attach_lse`)."""
     if not settings.current().fused_normal:
         return None
+    if type(latent) is LazyInitialDraw and latent.is_pending:
+        log_weight = _initial_step(prior_dist, proposal_dist, latent, emission_dist, observation, defer_grad)
+        if log_weight is not None:
+            return log_weight
+        latent = latent.materialise()      # K6, as `sample` would have drawn it; the three-launch route below
     if type(latent) is LazyDraw and latent.is_pending and getattr(latent, "wide", False):
         log_weight = _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation, defer_grad)
         if log_weight is not None:
@@ -346,6 +351,76 @@ def _affine_step_operands(prior_dist, proposal_dist, latent, emission_dist, obse
     return operands
 
 
+def _initial_step(prior_dist, proposal_dist, latent, emission_dist, observation, defer_grad=False):
+    """The FIRST timestep in one launch (K20, aesmc_affine_normal_initial_step) when `latent` is this proposal's pending
+    transposed draw (`LazyInitialDraw`: a BATCH_EXPANDED Normal), the prior a plain Normal whose parameters do not vary
+    along the particles, and the emission linear-Gaussian in the latent itself (an AffineNormal, or `Normal(x @ C.t() +
+    g, s)` recorded on the lazy draw) with one scale value: the draw, the emission's location and the three log-densities
+    — the bits of K6 + K8 + K5, the route taken otherwise (None).  Under autograd only for a caller that differentiates
+    the log-weights through their row log-sum-exp (`defer_grad`): the draw resolves to a tensor with `_NormalRsample`'s
+    history, and the operands come back for `_ops.attach_lse` (`_ops.InitialOperands`), whose backward forms the
+    emission's location again (K8) in front of K5's backward."""
+    provider = _kernels.get()
+    if provider.name != "hip" or not hasattr(provider, "affine_initial_step") or latent.distribution is not proposal_dist:
+        return None
+    if len(latent.shape) != 3 or latent.dtype != torch.float32:
+        return None
+    if not (torch.is_tensor(observation) and observation.dim() == 3 and observation.stride(1) == 0 and
+            observation.dtype == torch.float32 and observation.device == latent.device):
+        return None
+    emission = affine_terms(emission_dist)
+    if emission is None or emission.source is not latent:
+        return None
+    weight, offset, scale_g = emission.weight, emission.offset, emission.scale_param
+    B, K, dx = latent.shape
+    if not (torch.is_tensor(weight) and weight.dim() == 2 and weight.size(1) == dx and 1 <= dx <= 16 and
+            1 <= weight.size(0) <= 16 and weight.dtype == torch.float32 and weight.device == latent.device and
+            tuple(observation.shape) == (B, K, weight.size(0))):
+        return None
+    if not (torch.is_tensor(scale_g) and scale_g.numel() == 1 and scale_g.dtype == torch.float32 and
+            scale_g.device == latent.device):
+        return None
+    if offset is not None and not (torch.is_tensor(offset) and offset.dtype == torch.float32 and
+                                   offset.device == latent.device and tuple(offset.shape) in ((weight.size(0),),
+                                                                                              (B, weight.size(0)))):
+        return None
+    views = []
+    for distribution in (prior_dist, proposal_dist):
+        if not isinstance(distribution, torch.distributions.Distribution):
+            return None
+        missing = (3 - len(distribution.event_shape)) - len(distribution.batch_shape)
+        if missing not in (0, 1, 2) or (distribution is proposal_dist and missing != 1):
+            return None
+        pair = _fused_normal_views(distribution, latent, missing)
+        if pair is None or any(K > 1 and view.stride(1) != 0 for view in pair):
+            return None
+        views.append(pair)
+    (loc_p, scale_p), (loc_q, scale_q) = views
+    scale_g_view = scale_g.expand(B, K, weight.size(0))      # (as `AffineNormal.scale` expands it: the same reduction folds its gradient)
+    operands = (loc_p, scale_p, observation, weight, offset, scale_g_view, loc_q, scale_q)
+    wants_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in operands)
+    if wants_grad and not defer_grad:
+        return None      # differentiable log-weights themselves: the three launches' own autograd nodes
+    x_0 = torch.empty((B, K, dx), dtype=torch.float32, device=latent.device)
+    log_weight = provider.affine_initial_step(latent.noise, loc_q.detach(), scale_q.detach(), loc_p.detach(), scale_p.detach(),
+                                              observation.detach(), weight.detach(),
+                                              None if offset is None else offset.detach(), scale_g_view.detach(), x_0)
+    if log_weight is None:
+        return None
+    # (what `_validate_sample` would check is settled as in the fused step: the three are Normals — real support —
+    #  whose parameter shapes were matched against the very tensors the launch wrote and read)
+    if not wants_grad:
+        latent.resolve(x_0)
+        return (log_weight, ()) if defer_grad else log_weight
+    # (the draw's own views of the proposal's parameters — expanded to the noise's shape, then transposed — as K6's node
+    #  would have been handed: the reductions that fold their gradients are then the same launches, the same bits)
+    x_0 = _ops.normal_rsample_given(latent.noise.transpose(0, 1), latent.loc.transpose(0, 1), latent.scale.transpose(0, 1), x_0)
+    latent.resolve(x_0)
+    port = _ops.particle_affine_port(x_0, weight, offset)
+    return log_weight, _ops.InitialOperands((x_0, loc_p, scale_p, observation, port, weight.detach(),
+                                             None if offset is None else offset.detach(), scale_g_view, loc_q, scale_q))
+
+
 def _wide_step(prior_dist, proposal_dist, latent, emission_dist, observation, defer_grad=False):
     """A linear-Gaussian step on rows of 128 values whose latent is this proposal's deferred draw: K17 + K18 form the draw
     (through the ancestors when nothing has gathered x_{t-1} yet) and the log-weights; the draw resolves to the tensor
@@ -491,6 +566,11 @@ def _fused_normal_rsample(distribution, sample_shape, swap_leading_dims):
         eps = _kernels.get().philox_normal(noise, tuple(shape), loc.device)      # (declined: the values as a tensor)
     else:
         eps = _standard_normal(shape, dtype=loc.dtype, device=loc.device)
+    if swap_leading_dims and _DEFER_DRAWS.get() and len(shape) == 3 and loc.dtype == torch.float32 and \
+            settings.current().initial_step and _kernels.get().name == "hip":
+        # inside `infer`: the first timestep's draw is left to the launch that weighs the step (K20, `_initial_step`) —
+        # its noise is drawn here, by the very call `rsample` makes; whoever reads the values first gets K6's draw
+        return LazyInitialDraw(distribution, loc, scale, eps)
     if swap_leading_dims:
         eps, loc, scale = eps.transpose(0, 1), loc.transpose(0, 1), scale.transpose(0, 1)
     return _ops.normal_rsample(eps, loc, scale)

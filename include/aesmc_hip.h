@@ -57,7 +57,9 @@ extern "C" {
  *                aesmc_particle_mlp is back (0.1.0 had it, 0.2.0 dropped it) WITH its backward: aesmc_particle_mlp_backward,
  *                aesmc_particle_mlp_backward_records (+ aesmc_particle_mlp_max_hidden); aesmc_particle_affine_tanh.
  *   501 (0.5.1)  added aesmc_affine_weight_pairs_scaled; aesmc_affine_weight_pairs_floats() grew by eight values (the
- *                three densities' constants and their tag behind the pairs: aesmc_affine_weight_pairs clears the tag).
+ *                three densities' constants and their tag behind the pairs: aesmc_affine_weight_pairs clears the tag);
+ *                added aesmc_affine_normal_initial_step (K20: the first timestep's draw, emission location and
+ *                log-weight in one launch).
  *   400 (0.4.0)  aesmc_affine_chain grew `pairs_in` / `pairs_out` (a run of backward steps builds the weight pairs once);
  *                added aesmc_wide_adjoint_tile, aesmc_wide_adjoint_scale, aesmc_wide_adjoint_merge
  *   300 (0.3.0)  added aesmc_affine_normal_propagate_drawn_paired, aesmc_affine_weight_pairs,
@@ -444,6 +446,24 @@ int aesmc_affine_weight_pairs(const aesmc_affine_map *transition, const aesmc_af
 int aesmc_affine_weight_pairs_scaled(const aesmc_affine_map *transition, const aesmc_affine_map *emission,
                                      const aesmc_affine_map *proposal, const void *scale_p, const void *scale_g,
                                      const void *scale_q, void *out_pairs, void *stream);
+
+/* K20 (0.5.1) — the FIRST step of a run whose proposal and prior do not depend on a latent and whose emission is
+ * linear-Gaussian in the latent being drawn (aesmc/inference.py:79-98 with the reference's model style,
+ * test/models/lgssm.py: `initial()` a Normal, the time-0 proposal Normal(f(y_0), s) BATCH_EXPANDED, the emission
+ * Normal(C x_0 + g, s_g)), float32, latent and observation rows of 1 .. 16 values:
+ *   out_x[b,k,:] = loc_q[b,:] + eps[k,b,:] * scale_q[b,:]        (state.py:98, :102-103: `rsample((K,))`, transposed)
+ *   out_lw[b,k]  = (sum_j log N(out_x; loc_p, scale_p) + sum_j log N(y_b; C out_x + g, scale_g)) - sum_j log N(out_x; loc_q, scale_q)
+ * `eps`: the noise in the reference's order, [K, B, dx] contiguous.  The six views are [B, K, d] views whose stride_k is 0
+ * (anything constant along the particles: a scalar, a per-column vector, one row per batch element — any mix); the
+ * emission map is C [dy, dx] (any strides) with offset g NULL, [dy] or [B, dy].  One launch in place of
+ * aesmc_normal_rsample + aesmc_particle_affine + aesmc_normal_logweight, and the bits of those three: the draw's
+ * product is rounded before its sum, the location is one fma chain per output (inputs ascending, started from the
+ * offset), an element's log-density (-(d d)) / (2 s s) - log s - log(2 pi) / 2, summed over j ascending from zero.
+ * AESMC_ERR_UNSUPPORTED (a view that varies along the particles, rows wider than 16): the caller takes the three. */
+int aesmc_affine_normal_initial_step(const void *eps, const aesmc_view3 *loc_q, const aesmc_view3 *scale_q,
+                                     const aesmc_view3 *loc_p, const aesmc_view3 *scale_p, const aesmc_view3 *y,
+                                     const aesmc_affine_map *emission, const aesmc_view3 *scale_g, void *out_x,
+                                     void *out_lw, int64_t B, int64_t K, void *stream);
 
 /* K17 + K18 — one SMC step of a linear-Gaussian model whose latent and observation rows hold 128 float32 values
  * (BASELINE.json configs[4]), the three 128 x 128 maps on the fp32 matrix cores:
