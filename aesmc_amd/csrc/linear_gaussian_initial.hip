@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kInBlock) void affine_initial_step_kernel(const flo
     for (uint32_t t = tid; t < total; t += kInBlock) {
       const uint32_t kk = t / run, rest = t - kk * run;
       const uint32_t bb = rest / (uint32_t)DX, j = rest - bb * (uint32_t)DX;
-      const float noise = eps[((uint64_t)(k0 + kk) * B + b0) * (uint32_t)DX + rest];
+      const float noise = eps[((k0 + kk) * B + b0) * (uint32_t)DX + rest];      // (32-bit: the host admits B K d < 2^31)
       park[bb * pitch + kk * (uint32_t)DX + j] = tab[kInMuQ * kInBlock + bb * 16 + j] + noise * tab[kInSQ * kInBlock + bb * 16 + j];
     }
   };
@@ -140,17 +140,17 @@ __global__ __launch_bounds__(kInBlock) void affine_initial_step_kernel(const flo
       constexpr uint32_t full = kInK * (uint32_t)DX;
       for (uint32_t t = tid; t < total; t += kInBlock) {
         const uint32_t bb = t / full, rest = t - bb * full;
-        out_x[((uint64_t)(b0 + bb) * K + k0) * (uint32_t)DX + rest] = park[bb * pitch + rest];
+        out_x[((b0 + bb) * K + k0) * (uint32_t)DX + rest] = park[bb * pitch + rest];
       }
     } else {
       for (uint32_t t = tid; t < total; t += kInBlock) {
         const uint32_t bb = t / run, rest = t - bb * run;
-        out_x[((uint64_t)(b0 + bb) * K + k0) * (uint32_t)DX + rest] = park[bb * pitch + rest];
+        out_x[((b0 + bb) * K + k0) * (uint32_t)DX + rest] = park[bb * pitch + rest];
       }
     }
     for (uint32_t t = tid; t < nb * kInK; t += kInBlock) {
       const uint32_t bb = t / kInK, kk = t & (kInK - 1u);
-      if (kk < nk) out_lw[(uint64_t)(b0 + bb) * K + k0 + kk] = lwt[bb * (kInK + 1u) + kk];
+      if (kk < nk) out_lw[(b0 + bb) * K + k0 + kk] = lwt[bb * (kInK + 1u) + kk];
     }
   }
 }
@@ -188,6 +188,9 @@ extern "C" int aesmc_affine_normal_initial_step(const void *eps, const aesmc_vie
   if (B == 0 || K == 0) return AESMC_OK;
   const int64_t tiles_b = (B + kInB - 1) / kInB, tiles_k = (K + kInK - 1) / kInK;
   if (tiles_k > 65535 || tiles_b > 0x7fffffff || B >= (1ll << 31) || K >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
+  if (B * K * std::max<int64_t>(emission->din, emission->dout) >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;      // 32-bit element arithmetic
+  for (int i = 0; i < 6; ++i)      // ... and the per-row operands' rows within it
+    if (B * std::max<int64_t>(v[i].sb < 0 ? -v[i].sb : v[i].sb, 1) >= (1ll << 31)) return AESMC_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)tiles_b, (unsigned)tiles_k);
   const LgMap mg = lg_map(emission);
   hipStream_t s = static_cast<hipStream_t>(stream);
