@@ -94,6 +94,25 @@ def test_argument_validation_happens_before_any_launch():
                                            1, 256, None) == 1
     assert lib.aesmc_particle_mlp_backward(0, 16, 32, ctypes.byref(hidden), ctypes.byref(output), None, None, None, None,
                                            1, 300, None) == 2                                    # K not a multiple of 256
+    # the weight pairs with the densities' constants behind them (0.5.1), and the first timestep's launch (K20)
+    assert lib.aesmc_affine_weight_pairs_floats() == 3 * 256 + 8
+    assert lib.aesmc_affine_weight_pairs_scaled(ctypes.byref(amap), ctypes.byref(amap), ctypes.byref(amap), 16, 16, 16, None,
+                                                None) == 1                                       # no buffer
+    assert lib.aesmc_affine_weight_pairs_scaled(ctypes.byref(amap), ctypes.byref(amap), ctypes.byref(amap), None, 16, 16, 64,
+                                                None) == 1                                       # a scale missing
+    assert lib.aesmc_affine_weight_pairs_scaled(ctypes.byref(amap), ctypes.byref(wide), ctypes.byref(amap), 16, 16, 16, 64,
+                                                None) == 2                                       # a map wider than 16
+    row = _lib.View3(16, 4, 0, 1)          # one row per batch element, constant along the particles
+    along = _lib.View3(16, 64, 4, 1)       # varies along the particles
+    views = [ctypes.byref(row)] * 5
+    assert lib.aesmc_affine_normal_initial_step(None, *views, ctypes.byref(amap), ctypes.byref(row), 32, 48, 1, 16, None) == 1
+    assert lib.aesmc_affine_normal_initial_step(16, *views, ctypes.byref(amap), ctypes.byref(row), 32, 48, -1, 16, None) == 1
+    assert lib.aesmc_affine_normal_initial_step(16, ctypes.byref(along), *views[1:], ctypes.byref(amap), ctypes.byref(row), 32, 48,
+                                                1, 16, None) == 2                                # not constant along particles
+    assert lib.aesmc_affine_normal_initial_step(16, *views, ctypes.byref(wide), ctypes.byref(row), 32, 48, 1, 16, None) == 2
+    assert lib.aesmc_affine_normal_initial_step(16, *views, ctypes.byref(amap), ctypes.byref(row), 32, 48, 1 << 20, 1 << 12,
+                                                None) == 2                                       # beyond 32-bit element arithmetic
+    assert lib.aesmc_affine_normal_initial_step(16, *views, ctypes.byref(amap), ctypes.byref(row), 32, 48, 0, 16, None) == 0   # B == 0: no-op
     sixteen = _lib.AffineMap(16, 16, 1, 0, 0, 32, 16)
     assert lib.aesmc_particle_mlp_backward(0, 16, 32, ctypes.byref(sixteen), ctypes.byref(output), None, None, None, None,
                                            1, 256, None) == 2                                    # no column left for the ones
