@@ -715,6 +715,26 @@ def kernel_legs(ctx):
         legs["K11_{}_affine_adjoint".format(label)] = leg(
             timeit(lambda: k.particle_affine_backward(eps, x_prev, Q), reps=5), 4 * N * 3 * d, shape=shape)
         del x_prev, x, eps, lw
+    # the FIRST timestep in one launch (K20: the BATCH_EXPANDED proposal's transposed draw, the emission's location, the
+    # log-weight) beside the three launches it stands for (K6 + K8 + K5), the headline model's parameter shapes
+    for label, (B, K, d) in (("c4", (1024, 4096, 10)), ("c2", (256, 1024, 10))):
+        make = lambda *shape: torch.randn(*shape, device=dev, generator=gen)
+        full = lambda t: (t if t.dim() < 2 else t.unsqueeze(1)).expand(B, K, d)
+        eps, out_x, C = make(K, B, d), torch.empty(B, K, d, device=dev), torch.eye(d, device=dev) + 0.01 * make(d, d)
+        loc_q, scale_q = full(make(B, d)), full(torch.tensor(0.7, device=dev))
+        loc_p, scale_p = full(torch.zeros(d, device=dev)), full(torch.ones(d, device=dev))
+        obs, scale_g = full(make(B, d)), full(torch.tensor(0.5, device=dev))
+
+        def three():
+            x = k.normal_rsample(eps.transpose(0, 1), loc_q, scale_q)
+            return k.normal_logweight(x, loc_p, scale_p, obs, k.particle_affine(x, C, None), scale_g, loc_q, scale_q)
+
+        one = lambda: k.affine_initial_step(eps, loc_q, scale_q, loc_p, scale_p, obs, C, None, scale_g, out_x)
+        if one() is not None:
+            legs["K20_{}_first_step".format(label)] = leg(
+                timeit(one, reps=5), 4 * B * K * (2 * d + 1), shape="B={} K={} d={}".format(B, K, d),
+                three_launches_us=round(timeit(three, reps=5), 2))
+        del eps, out_x
     # configs[4]'s extent: the step on the fp32 matrix cores (K17 + K18), priced against their dense peak
     B, K, d = 64, 16384, 128
     make = lambda *shape: torch.randn(*shape, device=dev, generator=gen)
@@ -839,6 +859,8 @@ def summary_of(out, head, extras):
                        ("K17_K18_mfma", "K17_K18_c5_wide_step")):
         if key in legs:
             fracs[label] = legs[key]["frac"]
+    if "K20_c4_first_step" in legs:      # [the first timestep in one launch, the three launches it stands for] in us
+        summary["K20_us"] = [legs["K20_c4_first_step"]["avg_launch_us"], legs["K20_c4_first_step"]["three_launches_us"]]
     summary["frac"] = fracs
     for label, key in (("c2", "c2_hipgraph"), ("c2ref", "reference_models"), ("c4_matmul", "matmul_callables"),
                        ("c4nl", "c4nl"), ("c5", "c5")):
