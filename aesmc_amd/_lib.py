@@ -136,6 +136,7 @@ TEST_HOOKS = {
     "aesmc_test_last_step_backward_form": (_i32, []),
     "aesmc_test_set_k2_form": (_i32, [_i32]),
     "aesmc_test_last_k2_form": (_i32, []),
+    "aesmc_test_last_logweight_backward_form": (_i32, []),
 }
 
 _lib = None

@@ -1034,14 +1034,141 @@ static bool launch_logweight_bwd_dense(const View3 *v, const void *grad_lw, void
   return true;
 }
 
+// K5 backward, the layout of a FIRST timestep (aesmc/inference.py:79-98: `initial()` NOT_EXPANDED, the time-0 proposal
+// BATCH_EXPANDED): x dense [B,K,Dx], mu_g dense [B,K,Dy], and every other operand — the prior's and the proposal's
+// location and scale, the observation, the emission's scale — constant along the particles (particle stride 0: a scalar,
+// a per-column vector, one row per batch element).  The generic kernel addresses each element through strided views
+// with two 64-bit divisions: 523 us at B=1024 K=4096 d=10.  Here a workgroup lies inside ONE batch row and a lane walks
+// 16-byte vectors of that row's flat elements (coalesced loads of x / mu_g, 16-byte stores of every gradient) in 32-bit
+// arithmetic; the row-constant operands are 4-byte reads of a few cache lines.  Element arithmetic is the generic
+// kernel's, operation for operation: same bits.
+template <typename T>
+__global__ __launch_bounds__(kLpBlock) void normal_logweight_bwd_rows_kernel(
+    const T *__restrict__ x, const T *__restrict__ mu_g, View3 mu_p, View3 sc_p, View3 y, View3 sc_g, View3 mu_q, View3 sc_q,
+    const T *__restrict__ grad_lw, const T *__restrict__ lw, const T *__restrict__ lse, const T *__restrict__ grad_lse,
+    T *__restrict__ gx, T *__restrict__ gmu_p, T *__restrict__ gy, T *__restrict__ gmu_g, T *__restrict__ gmu_q,
+    T *__restrict__ gs_p, T *__restrict__ gs_g, T *__restrict__ gs_q, uint32_t K, uint32_t Dx, uint32_t Dy) {
+  constexpr int N = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const uint32_t b = blockIdx.y;
+  const uint32_t v = blockIdx.x * kLpBlock + threadIdx.x;      // this lane's vector of the row
+  auto incoming = [&](uint32_t p) -> T {   // as in normal_logweight_bwd_kernel
+    T g = grad_lse != nullptr ? grad_lse[b] * Num<T>::exp(lw[p] - lse[b]) : T(0);
+    if (grad_lw != nullptr) g = grad_lse != nullptr ? g + grad_lw[p] : grad_lw[p];
+    return g;
+  };
+  auto row = [&](const View3 &view, uint32_t j) {
+    return reinterpret_cast<const T *>(view.ptr)[(int64_t)b * view.st.b + (int64_t)j * view.st.d];
+  };
+  auto put = [](V &out, int r, T value) {
+    if (r == 0) out.x = value;
+    else if (r == 1) out.y = value;
+    if constexpr (N == 4) {
+      if (r == 2) out.z = value;
+      else if (r == 3) out.w = value;
+    }
+  };
+  if ((gx != nullptr || gmu_p != nullptr || gmu_q != nullptr || gs_p != nullptr || gs_q != nullptr) && v * N < K * Dx) {
+    const uint32_t at = (b * K * Dx) / N + v;      // (a row is whole vectors: the host admits K Dx % N == 0)
+    uint32_t k = (v * N) / Dx, j = v * N - k * Dx;
+    const V xv = reinterpret_cast<const V *>(x)[at];
+    V out_p, out_q, out_x, out_sp, out_sq;
+    T g = incoming(b * K + k);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const T value = Vec16<T>::get(xv, r);
+      const T s_p = row(sc_p, j), s_q = row(sc_q, j);
+      const T var_p = s_p * s_p, var_q = s_q * s_q;
+      const T dp = value - row(mu_p, j), dq = value - row(mu_q, j);
+      const T gq = -g;                                  // log q enters the weight with a minus sign
+      const T gz_p = g * (dp / var_p);
+      const T gz_q = gq * (dq / var_q);
+      put(out_p, r, gz_p);
+      put(out_q, r, gz_q);
+      put(out_x, r, (-gz_p) + (-gz_q));
+      if (gs_p) put(out_sp, r, g * ((dp * dp) / (var_p * s_p) - T(1) / s_p));
+      if (gs_q) put(out_sq, r, gq * ((dq * dq) / (var_q * s_q) - T(1) / s_q));
+      if (++j == Dx && r + 1 < N) {
+        j = 0;
+        ++k;
+        g = incoming(b * K + k);
+      }
+    }
+    if (gmu_p) reinterpret_cast<V *>(gmu_p)[at] = out_p;
+    if (gmu_q) reinterpret_cast<V *>(gmu_q)[at] = out_q;
+    if (gx) reinterpret_cast<V *>(gx)[at] = out_x;
+    if (gs_p) reinterpret_cast<V *>(gs_p)[at] = out_sp;
+    if (gs_q) reinterpret_cast<V *>(gs_q)[at] = out_sq;
+  }
+  if ((gy != nullptr || gmu_g != nullptr || gs_g != nullptr) && v * N < K * Dy) {
+    const uint32_t at = (b * K * Dy) / N + v;
+    uint32_t k = (v * N) / Dy, j = v * N - k * Dy;
+    const V gv = reinterpret_cast<const V *>(mu_g)[at];
+    V out_g, out_y, out_sg;
+    T g = incoming(b * K + k);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const T s_g = row(sc_g, j);
+      const T var_g = s_g * s_g;
+      const T dg = row(y, j) - Vec16<T>::get(gv, r);
+      const T gz_g = g * (dg / var_g);
+      put(out_g, r, gz_g);
+      put(out_y, r, -gz_g);
+      if (gs_g) put(out_sg, r, g * ((dg * dg) / (var_g * s_g) - T(1) / s_g));
+      if (++j == Dy && r + 1 < N) {
+        j = 0;
+        ++k;
+        g = incoming(b * K + k);
+      }
+    }
+    if (gmu_g) reinterpret_cast<V *>(gmu_g)[at] = out_g;
+    if (gy) reinterpret_cast<V *>(gy)[at] = out_y;
+    if (gs_g) reinterpret_cast<V *>(gs_g)[at] = out_sg;
+  }
+}
+
+template <typename T>
+static bool launch_logweight_bwd_rows(const View3 *v, const void *grad_lw, void *gx, void *gmu_p, void *gy,
+                                      void *gmu_g, void *gmu_q, void *gs_p, void *gs_g, void *gs_q, int64_t B,
+                                      int64_t K, int64_t Dx, int64_t Dy, hipStream_t s, const void *lw,
+                                      const void *lse, const void *grad_lse) {
+  constexpr int N = Vec16<T>::N;
+  if (B * K * std::max(Dx, Dy) >= (1ll << 31) || B > 65535 || K < 2) return false;
+  if ((K * Dx) % N != 0 || (K * Dy) % N != 0) return false;      // a batch row: whole 16-byte vectors
+  auto flat = [&](const View3 &view, int64_t D) {
+    return (D == 1 || view.st.d == 1) && view.st.k == D && view.st.b == K * D &&
+           (reinterpret_cast<uintptr_t>(view.ptr) & 15u) == 0;
+  };
+  if (!flat(v[0], Dx) || !flat(v[4], Dy)) return false;
+  for (int i : {1, 2, 3, 5, 6, 7})
+    if (v[i].st.k != 0) return false;
+  for (void *out : {gx, gmu_p, gy, gmu_g, gmu_q, gs_p, gs_g, gs_q})
+    if (out != nullptr && (reinterpret_cast<uintptr_t>(out) & 15u) != 0) return false;
+  const int64_t vectors = K * std::max(Dx, Dy) / N;
+  const dim3 grid((unsigned)((vectors + kLpBlock - 1) / kLpBlock), (unsigned)B);
+  hipLaunchKernelGGL((normal_logweight_bwd_rows_kernel<T>), grid, dim3(kLpBlock), 0, s, (const T *)v[0].ptr,
+                     (const T *)v[4].ptr, v[1], v[2], v[3], v[5], v[6], v[7], (const T *)grad_lw, (const T *)lw,
+                     (const T *)lse, (const T *)grad_lse, (T *)gx, (T *)gmu_p, (T *)gy, (T *)gmu_g, (T *)gmu_q, (T *)gs_p,
+                     (T *)gs_g, (T *)gs_q, (uint32_t)K, (uint32_t)Dx, (uint32_t)Dy);
+  return true;
+}
+
+static int g_lw_bwd_last = 0;      // which form K5's backward took last: 1 dense, 2 rows, 3 generic (test hook below)
+
 template <typename T>
 static int launch_logweight_bwd(const View3 *v, const void *grad_lw, void *gx, void *gmu_p, void *gy,
                                 void *gmu_g, void *gmu_q, void *gs_p, void *gs_g, void *gs_q, int64_t B,
                                 int64_t K, int64_t Dx, int64_t Dy, hipStream_t s, const void *lw = nullptr,
                                 const void *lse = nullptr, const void *grad_lse = nullptr) {
+  g_lw_bwd_last = 1;
   if (launch_logweight_bwd_dense<T>(v, grad_lw, gx, gmu_p, gy, gmu_g, gmu_q, gs_p, gs_g, gs_q, B, K, Dx, Dy, s, lw,
                                     lse, grad_lse))
     return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  g_lw_bwd_last = 2;
+  if (launch_logweight_bwd_rows<T>(v, grad_lw, gx, gmu_p, gy, gmu_g, gmu_q, gs_p, gs_g, gs_q, B, K, Dx, Dy, s, lw, lse,
+                                   grad_lse))
+    return hipGetLastError() == hipSuccess ? AESMC_OK : AESMC_ERR_LAUNCH;
+  g_lw_bwd_last = 3;
   const int64_t total_x = B * K * Dx, total_y = B * K * Dy;
   const int64_t most = total_x > total_y ? total_x : total_y;
   int64_t blocks = (most + kLpBlock - 1) / kLpBlock;
@@ -1055,6 +1182,8 @@ static int launch_logweight_bwd(const View3 *v, const void *grad_lw, void *gx, v
 }
 
 }  // namespace aesmc
+
+extern "C" int aesmc_test_last_logweight_backward_form(void) { return aesmc::g_lw_bwd_last; }
 
 extern "C" int aesmc_normal_logprob_sum(int dtype, const void *value, const void *loc,
                                         const void *scale, void *out, int64_t B, int64_t K,

@@ -226,3 +226,37 @@ def test_a_model_that_reads_the_first_draw_gets_its_values(hip_device, kernels):
     assert torch.equal(got_loss, want_loss)
     for name in want_grads:
         assert torch.equal(got_grads[name], want_grads[name]), name
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("through_lse", [True, False])
+def test_the_first_steps_backward_rows_form_gives_the_generic_kernels_bits(kernels, hip_device, case, through_lse):
+    """K5's backward for the first timestep's layout — x and the emission's location dense, every other operand constant
+    along the particles — against the generic strided kernel (forced by handing x in as a strided view of the same
+    values): every gradient it writes, bit for bit; with K1's softmax term formed in place and with a given grad_lw."""
+    B, K, dx, dy = case[:4]
+    if K < 2:
+        pytest.skip("one particle per row: the generic kernel")
+    o = _operands(B, K, dx, dy, hip_device, 11 + B + K, *case[4:])
+    loc_q, scale_q, loc_p, scale_p, y, scale_g = _views(o, B, K, dx, dy)
+    x, lw = _three_launches(kernels, o, B, K, dx, dy)
+    loc_g = kernels.particle_affine(x, o["C"], o["off"])
+    gen = torch.Generator(device=hip_device).manual_seed(5)
+    need = [True] * 8
+    if through_lse:
+        lse = torch.logsumexp(lw, dim=1)
+        extra = dict(lw=lw, lse=lse, grad_lse=torch.randn(B, device=hip_device, generator=gen))
+        grad_lw = None
+    else:
+        extra, grad_lw = {}, torch.randn(B, K, device=hip_device, generator=gen)
+    got = kernels.normal_logweight_backward(x, loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw, need, **extra)
+    rows_form = (K * dx) % 4 == 0 and (K * dy) % 4 == 0      # a batch row of whole 16-byte vectors
+    assert kernels._lib.aesmc_test_last_logweight_backward_form() == (2 if rows_form else 3)
+    wider = torch.zeros(B, K, dx + 1, device=hip_device)
+    wider[:, :, :dx] = x
+    want = kernels.normal_logweight_backward(wider[:, :, :dx], loc_p, scale_p, y, loc_g, scale_g, loc_q, scale_q, grad_lw,
+                                             need, **extra)
+    assert kernels._lib.aesmc_test_last_logweight_backward_form() == 3
+    assert len(got) == len(want) == 8
+    for a, b in zip(got, want):
+        assert a is not None and b is not None and torch.equal(a, b)
