@@ -14,7 +14,7 @@
 // (tests/test_gpu_initial_step.py holds the launch to the three, bit for bit).
 //
 // The noise comes in the reference's order — [K, B, d], what `Normal(loc [B,d], s).rsample((K,))` draws — and the draw
-// leaves as [B, K, d]: a workgroup owns 16 batch rows x 16 particles (one per lane; 32 particles per row: 190 against 178 us), reads its noise in runs along (b, j), parks the
+// leaves as [B, K, d]: a workgroup owns 16 batch rows x 16 particles (one per lane; 32 particles per row: 190 against 178 us), reads its noise in runs along (b, j) — 16-byte pieces at 4-byte alignment —, parks the
 // draws in LDS, weighs one particle per lane out of there, and writes x_0 and the log-weights in runs along (k, j).
 // What depends on the batch row only — the proposal's and the prior's location and scale, the observation, the
 // emission's offset, and per scale 2 s^2 and log s — is tabulated once per workgroup (16 rows x 16 columns = its 256
@@ -25,6 +25,9 @@ namespace aesmc {
 
 constexpr uint32_t kInB = 16, kInK = 16, kInBlock = 256;
 static_assert(kInB * 16 == kInBlock, "one lane per (batch row, column) of the tables");
+
+typedef float in_f4 __attribute__((ext_vector_type(4)));
+typedef in_f4 in_f4_a4 __attribute__((aligned(4)));      // a 16-byte global access at 4-byte alignment (hardware: unaligned mode)
 
 // an operand that is constant along the particles: value(b, j) = ptr[b * sb + j * sd] (0 strides: broadcast)
 struct InView {
@@ -98,8 +101,24 @@ __global__ __launch_bounds__(kInBlock) void affine_initial_step_kernel(const flo
       park[bb * pitch + kk * (uint32_t)DX + j] = tab[kInMuQ * kInBlock + bb * 16 + j] + noise * tab[kInSQ * kInBlock + bb * 16 + j];
     }
   };
-  if (nb == kInB) draw(kInB * (uint32_t)DX);
-  else draw(nb * (uint32_t)DX);
+  if (nb == kInB) {      // a whole tile: 16 DX values per run = 4 DX pieces of 16 bytes (at 4-byte alignment: any extent, any B)
+    constexpr uint32_t pieces = kInB * (uint32_t)DX / 4u;
+    for (uint32_t t = tid; t < nk * pieces; t += kInBlock) {
+      const uint32_t kk = t / pieces, rest = 4u * (t - kk * pieces);
+      const in_f4 noise = *reinterpret_cast<const in_f4_a4 *>(eps + (((k0 + kk) * B + b0) * (uint32_t)DX + rest));
+      uint32_t bb = rest / (uint32_t)DX, j = rest - bb * (uint32_t)DX;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        park[bb * pitch + kk * (uint32_t)DX + j] = tab[kInMuQ * kInBlock + bb * 16 + j] + noise[r] * tab[kInSQ * kInBlock + bb * 16 + j];
+        if (++j == (uint32_t)DX) {
+          j = 0;
+          ++bb;
+        }
+      }
+    }
+  } else {
+    draw(nb * (uint32_t)DX);
+  }
   __syncthreads();
 
   // ---- one particle per lane: the emission's location (K8's chain), the three sums (K5's terms, j ascending) ---------------
@@ -136,11 +155,12 @@ __global__ __launch_bounds__(kInBlock) void affine_initial_step_kernel(const flo
   // ---- out: a batch row's particles are one contiguous run of x_0 and one of the log-weights --------------------------------
   {
     const uint32_t run = nk * (uint32_t)DX, total = nb * run;
-    if (nk == kInK) {
-      constexpr uint32_t full = kInK * (uint32_t)DX;
-      for (uint32_t t = tid; t < total; t += kInBlock) {
-        const uint32_t bb = t / full, rest = t - bb * full;
-        out_x[((b0 + bb) * K + k0) * (uint32_t)DX + rest] = park[bb * pitch + rest];
+    if (nk == kInK) {      // whole runs: 16-byte stores (at 4-byte alignment)
+      constexpr uint32_t pieces = kInK * (uint32_t)DX / 4u;
+      for (uint32_t t = tid; t < nb * pieces; t += kInBlock) {
+        const uint32_t bb = t / pieces, rest = 4u * (t - bb * pieces);
+        const float *from = park + bb * pitch + rest;
+        *reinterpret_cast<in_f4_a4 *>(out_x + (((b0 + bb) * K + k0) * (uint32_t)DX + rest)) = in_f4{from[0], from[1], from[2], from[3]};
       }
     } else {
       for (uint32_t t = tid; t < total; t += kInBlock) {
